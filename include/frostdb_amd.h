@@ -1,0 +1,212 @@
+/* frostdb_amd.h — C ABI of the MI355X-native TableScan → PredicateFilter → HashAggregate path.
+ *
+ * This is the thin cgo surface a FrostDB maintainer binds (see INTEGRATION.md for the Go stub).
+ * The reference has no FFI today; the seam is the Go push-operator interface
+ *
+ *     type PhysicalPlan interface {                     // query/physicalplan/physicalplan.go:24-30
+ *         Callback(ctx, arrow.Record) error             //   → fdb_plan_push / fdb_plan_push_batch
+ *         Finish(ctx) error                             //   → fdb_plan_finish
+ *         SetNext(PhysicalPlan)                         //   (stays in Go: the shim forwards the finish record)
+ *         Draw() *Diagram                               //   → fdb_plan_draw
+ *         Close()                                       //   → fdb_plan_close
+ *     }
+ *
+ * One fdb_plan replaces one operator chain  PredicateFilter → HashAggregate(final=false)
+ * (physicalplan.go:417-474). Plain pointers and sizes only; record batches cross the boundary as
+ * Arrow C Data Interface structs (arrow-go: arrow/cdata; pyarrow: _export_to_c).
+ *
+ * Every function returns FDB_OK (0) or an fdb_status error code and never aborts the process;
+ * the text of the last error is available per handle (fdb_plan_last_error) or per thread
+ * (fdb_last_error) — the Go shim turns rc != 0 into `errors.New(text)`.
+ */
+#ifndef FROSTDB_AMD_H
+#define FROSTDB_AMD_H
+
+#include <stdint.h>
+#include "arrow_c_data.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum fdb_status {
+  FDB_OK = 0,
+  FDB_ERR_INVALID = 1,      /* malformed descriptor / arguments */
+  FDB_ERR_UNSUPPORTED = 2,  /* ≙ ErrUnsupportedBooleanExpression (filter.go:46), ErrUnsupportedBinaryOperation
+                               (binaryscalarexpr.go:82), ErrUnsupportedSumType/MinType/MaxType (aggregate.go:736,782,862) */
+  FDB_ERR_NOT_FOUND = 3,    /* ≙ "aggregate field(s) not found" (aggregate.go:367-380) */
+  FDB_ERR_DEVICE = 4,       /* HIP runtime error (text carries hipGetErrorString) */
+  FDB_ERR_OOM = 5,          /* host or device allocation failed */
+  FDB_ERR_STATE = 6         /* call order violated (push after finish, …) */
+} fdb_status;
+
+/* logicalplan.Op (query/logicalplan/expr.go:17-35) — same numeric values as the reference's iota
+ * and as storage.proto's Op enum, so a Go shim can pass `int32(expr.Op)` through unchanged. */
+typedef enum fdb_op {
+  FDB_OP_UNKNOWN = 0,
+  FDB_OP_EQ = 1,
+  FDB_OP_NOT_EQ = 2,
+  FDB_OP_LT = 3,
+  FDB_OP_LT_EQ = 4,
+  FDB_OP_GT = 5,
+  FDB_OP_GT_EQ = 6,
+  FDB_OP_REGEX_MATCH = 7,
+  FDB_OP_REGEX_NOT_MATCH = 8,
+  FDB_OP_AND = 9,
+  FDB_OP_OR = 10,
+  FDB_OP_ADD = 11,
+  FDB_OP_SUB = 12,
+  FDB_OP_MUL = 13,
+  FDB_OP_DIV = 14,
+  FDB_OP_CONTAINS = 15,
+  FDB_OP_NOT_CONTAINS = 16
+} fdb_op;
+
+/* logicalplan.AggFunc (query/logicalplan/expr.go:718-729), same numeric values. */
+typedef enum fdb_agg_func {
+  FDB_AGG_UNKNOWN = 0,
+  FDB_AGG_SUM = 1,
+  FDB_AGG_MIN = 2,
+  FDB_AGG_MAX = 3,
+  FDB_AGG_COUNT = 4,
+  FDB_AGG_AVG = 5,    /* never reaches the operator: lowered to SUM+COUNT+Projection (logicalplan/builder.go:205-238) */
+  FDB_AGG_UNIQUE = 6,
+  FDB_AGG_AND = 7
+} fdb_agg_func;
+
+/* scalar.Scalar of a LiteralExpr (the right-hand side of a filter leaf, filter.go:95-103). */
+typedef enum fdb_literal_type {
+  FDB_LIT_NULL = 0,   /* scalar.ScalarNull: `col = null` ≙ IS NULL, `col != null` ≙ IS NOT NULL */
+  FDB_LIT_INT64 = 1,
+  FDB_LIT_UINT64 = 2,
+  FDB_LIT_FLOAT64 = 3,
+  FDB_LIT_STRING = 4, /* scalar.String */
+  FDB_LIT_BINARY = 5, /* scalar.Binary */
+  FDB_LIT_BOOL = 6
+} fdb_literal_type;
+
+typedef struct fdb_literal {
+  int32_t type;      /* fdb_literal_type */
+  int32_t _pad;
+  int64_t i64;       /* INT64, BOOL (0/1) */
+  uint64_t u64;      /* UINT64 */
+  double f64;        /* FLOAT64 */
+  const char* data;  /* STRING / BINARY bytes (not NUL-terminated) */
+  int64_t len;
+} fdb_literal;
+
+/* One node of the filter expression tree, flattened into an array.
+ *   leaf:    op ∈ {EQ … GT_EQ, REGEX_*, CONTAINS, NOT_CONTAINS}, `column` ⟨op⟩ `literal`
+ *            (left must be a column, right a literal: filter.go:79-103)
+ *   branch:  op ∈ {AND, OR}, `left`/`right` are indices into the same array (filter.go:129-160) */
+typedef struct fdb_expr {
+  int32_t op;          /* fdb_op */
+  int32_t left;        /* child index for AND/OR, else -1 */
+  int32_t right;       /* child index for AND/OR, else -1 */
+  int32_t _pad;
+  const char* column;  /* NUL-terminated exact column name (ArrayRef.ColumnName, binaryscalarexpr.go:18-29) */
+  fdb_literal literal;
+} fdb_expr;
+
+/* One AggregationFunction (aggregate.go:104-110): `func(column)`; the output column is named
+ * "<func>(<column>)" exactly like AggregationFunction.Name() (logicalplan/expr.go:700-702). */
+typedef struct fdb_aggregation {
+  int32_t func;        /* fdb_agg_func */
+  int32_t _pad;
+  const char* column;
+} fdb_aggregation;
+
+/* One group-by matcher (aggregate.go:286-289): Column ≙ exact name (logicalplan/expr.go:353-355),
+ * DynamicColumn ≙ every column whose name starts with name+"." (expr.go:564-566). */
+typedef struct fdb_group_expr {
+  const char* name;
+  int32_t dynamic;
+  int32_t _pad;
+} fdb_group_expr;
+
+typedef struct fdb_plan_desc {
+  const fdb_expr* filter;      /* NULL / n_filter == 0 ⇒ no PredicateFilter in the chain */
+  int32_t n_filter;
+  int32_t filter_root;         /* index of the root node */
+  const fdb_aggregation* aggs; /* n_aggs == 0 ⇒ filter-only plan (only fdb_plan_filter is valid) */
+  int32_t n_aggs;
+  int32_t n_groups;
+  const fdb_group_expr* groups;
+  int32_t final_stage;         /* 1 ⇒ behave like HashAggregate(finalStage=true): aggregate columns are matched
+                                  by result name and COUNT merges by SUM (aggregate.go:340-348, :965-969) */
+  int32_t _pad;
+} fdb_plan_desc;
+
+typedef struct fdb_plan fdb_plan;   /* one operator chain; push is single-threaded per handle (table.go:783-860) */
+typedef struct fdb_batch fdb_batch; /* an Arrow record resident in HBM (a cached part / row group) */
+
+/* ---- library ---------------------------------------------------------------------------------- */
+const char* fdb_version(void);
+/* Text of the last error raised on the calling thread by a call that had no plan handle. */
+const char* fdb_last_error(void);
+int fdb_device_count(int* n_devices);
+
+/* ---- plan life cycle (≙ physicalplan.Build for one chain, physicalplan.go:417-474) -------------- */
+int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
+/* ≙ PhysicalPlan.Callback: borrows `batch` for the duration of the call only (the reference releases
+ * the record right after Callback returns, table.go:808,:827); the columns the plan references are
+ * staged to HBM, filtered and aggregated before returning control (kernels may still be in flight). */
+int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema);
+/* Same, for a record that is already resident in HBM. */
+int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch);
+/* ≙ PhysicalPlan.Finish: waits for the device, emits ONE record (group columns in first-seen field
+ * order with their input Arrow type, then one column per aggregation named "<func>(<column>)")
+ * (aggregate.go:543-633). The caller owns `out`/`out_schema` and must call their release().
+ * A plan that saw no selected rows emits a zero-row record and sets *n_rows = 0. */
+int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows);
+/* ≙ Synchronizer + HashAggregate(final=true) on one device (synchronize.go:31-53): folds the partial
+ * table of `src` into `dst` (SUM of sums and counts, MIN of mins, MAX of maxes). `src` stays valid. */
+int fdb_plan_merge(fdb_plan* dst, fdb_plan* src);
+/* ≙ filter() (filter.go:276-323): the compacted record of the rows that satisfy the plan's filter.
+ * *n_selected == 0 ⇒ `out`/`out_schema` are left untouched (the reference skips empty records, filter.go:264-266). */
+int fdb_plan_filter(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema,
+                    struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_selected);
+/* Selection vector only: ascending row indices of the rows that satisfy the filter, written to the
+ * caller's host buffer `indices` (capacity ≥ batch length). */
+int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema,
+                    uint32_t* indices, int64_t capacity, int64_t* n_selected);
+/* ≙ PhysicalPlan.Draw: "PredicateFilter (…) - HashAggregate (sum(value) by labels.path)". Owned by the plan. */
+const char* fdb_plan_draw(fdb_plan* plan);
+const char* fdb_plan_last_error(const fdb_plan* plan);
+/* ≙ PhysicalPlan.Close: frees every host and device buffer of the plan. NULL is a no-op. */
+void fdb_plan_close(fdb_plan* plan);
+
+/* ---- cross-process merge support (the RCCL reduce of per-GPU partial tables) ------- */
+/* Number of groups currently in the plan's partial table (waits for the device). */
+int fdb_plan_num_groups(fdb_plan* plan, int64_t* n_groups);
+/* The group-key columns only, one row per table slot, in slot order (same types as fdb_plan_finish). */
+int fdb_plan_partial_keys(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema);
+/* Copies the partial accumulator of aggregation `agg` (n_groups × 8 bytes, slot order; int64 or
+ * float64 per fdb_plan_agg_type) to `dst`, a host or device pointer (hipMemcpyDefault). */
+int fdb_plan_partial_state(fdb_plan* plan, int32_t agg, void* dst, int64_t capacity_bytes);
+/* 'l' (int64) or 'g' (float64): the Arrow format of aggregation `agg`'s output column; 0 until the first push. */
+int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out);
+
+/* ---- resident batches (a part kept in HBM between queries; 288 GB per GPU) ---------------------- */
+int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int device, fdb_batch** out);
+int64_t fdb_batch_num_rows(const fdb_batch* batch);
+/* Bytes this batch occupies in HBM (values/indices + validity bitmaps; dictionaries stay on the host). */
+int64_t fdb_batch_device_bytes(const fdb_batch* batch);
+void fdb_batch_release(fdb_batch* batch);
+
+/* ---- measurement hooks (bench.py / rocprof correlation; not needed by the Go shim) -------------- */
+/* Algorithmic bytes (values-or-indices + validity of every referenced column, once per
+ * row) and accumulated device time in ms (hipEvent pairs on the plan's stream around each scan
+ * kernel) since the plan was created; `n_launches` scan-kernel launches. */
+int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms, int64_t* n_launches,
+                   int64_t* rows_scanned);
+/* Enables/disables the per-launch hipEvent timing above (off by default; costs two events per launch). */
+int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled);
+/* The hipStream_t the plan launches on, as an opaque pointer. */
+int fdb_plan_stream(fdb_plan* plan, void** stream_out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FROSTDB_AMD_H */

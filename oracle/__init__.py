@@ -1,0 +1,214 @@
+"""ctypes wrapper of the CPU oracle (oracle/oracle.cpp).
+
+*** TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT. *** Only tests/, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this package; nothing under ``frostdb_amd/`` does.
+
+``OraclePlan`` mirrors one query: N operator chains ``PredicateFilter → HashAggregate(final=false)``
+fanned into a ``Synchronizer`` and a ``HashAggregate(final=true)`` (query/physicalplan/physicalplan.go:432-474).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+import pyarrow as pa
+
+from frostdb_amd.arrow_c import ExportedBatch
+from frostdb_amd.logicalplan import AggregationFunction, Column, Expr, to_desc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+T_I64, T_U64, T_F64, T_BOOL, T_STR, T_DICT = 1, 2, 3, 4, 5, 6
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, i32, i64, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+        L.oracle_last_error.restype = ctypes.c_char_p
+        L.oracle_metro_hash64.restype = u64
+        L.oracle_metro_hash64.argtypes = [ctypes.c_char_p, i64, u64]
+        L.oracle_hash_combine.restype = u64
+        L.oracle_hash_combine.argtypes = [u64, u64]
+        L.oracle_batch_import.argtypes = [vp, vp, ctypes.POINTER(vp)]
+        L.oracle_batch_release.argtypes = [vp]
+        L.oracle_batch_num_rows.restype = i64
+        L.oracle_batch_num_rows.argtypes = [vp]
+        L.oracle_batch_num_cols.restype = i32
+        L.oracle_batch_num_cols.argtypes = [vp]
+        L.oracle_batch_col_name.restype = ctypes.c_char_p
+        L.oracle_batch_col_name.argtypes = [vp, i32]
+        L.oracle_batch_col_type.restype = i32
+        L.oracle_batch_col_type.argtypes = [vp, i32]
+        L.oracle_batch_col_valid.argtypes = [vp, i32, vp]
+        L.oracle_batch_col_i64.argtypes = [vp, i32, vp]
+        L.oracle_batch_col_f64.argtypes = [vp, i32, vp]
+        L.oracle_batch_col_str.argtypes = [vp, i32, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64)]
+        L.oracle_plan_create.argtypes = [vp, i32, u64, ctypes.POINTER(vp)]
+        L.oracle_plan_close.argtypes = [vp]
+        L.oracle_plan_last_error.restype = ctypes.c_char_p
+        L.oracle_plan_last_error.argtypes = [vp]
+        L.oracle_plan_push.argtypes = [vp, i32, vp]
+        L.oracle_plan_filter.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(i32), vp, ctypes.POINTER(i64)]
+        L.oracle_plan_finish.argtypes = [vp, ctypes.POINTER(vp)]
+        L.oracle_plan_execute.argtypes = [vp, ctypes.POINTER(vp), i64, i32, ctypes.POINTER(vp)]
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"oracle error {code}: {msg}")
+        self.code = code
+
+
+def metro_hash64(data: bytes, seed: int = 0) -> int:
+    return lib().oracle_metro_hash64(data, len(data), seed)
+
+
+class OracleBatch:
+    def __init__(self, handle: int):
+        self.handle = handle
+
+    @classmethod
+    def from_arrow(cls, batch: pa.RecordBatch) -> "OracleBatch":
+        out = ctypes.c_void_p()
+        with ExportedBatch(batch) as ex:
+            rc = lib().oracle_batch_import(ctypes.addressof(ex.array), ctypes.addressof(ex.schema), ctypes.byref(out))
+        if rc != 0:
+            raise OracleError(rc, lib().oracle_last_error().decode())
+        return cls(out.value)
+
+    @property
+    def num_rows(self) -> int:
+        return lib().oracle_batch_num_rows(self.handle)
+
+    def to_pydict(self) -> Dict[str, List[Any]]:
+        """Column name → list of Python values (None for null; bytes for string-like columns)."""
+        L = lib()
+        n = self.num_rows
+        out: Dict[str, List[Any]] = {}
+        for c in range(L.oracle_batch_num_cols(self.handle)):
+            name = L.oracle_batch_col_name(self.handle, c).decode()
+            t = L.oracle_batch_col_type(self.handle, c)
+            valid = np.zeros(n, dtype=np.uint8)
+            if n:
+                L.oracle_batch_col_valid(self.handle, c, valid.ctypes.data)
+            if t in (T_I64, T_U64, T_BOOL):
+                v = np.zeros(n, dtype=np.int64)
+                if n:
+                    L.oracle_batch_col_i64(self.handle, c, v.ctypes.data)
+                if t == T_U64:
+                    v = v.view(np.uint64)
+                vals = [(bool(x) if t == T_BOOL else int(x)) if ok else None for x, ok in zip(v, valid)]
+            elif t == T_F64:
+                v = np.zeros(n, dtype=np.float64)
+                if n:
+                    L.oracle_batch_col_f64(self.handle, c, v.ctypes.data)
+                vals = [float(x) if ok else None for x, ok in zip(v, valid)]
+            else:
+                vals = []
+                p = ctypes.c_char_p()
+                ln = ctypes.c_int64()
+                for r in range(n):
+                    if not valid[r]:
+                        vals.append(None)
+                        continue
+                    L.oracle_batch_col_str(self.handle, c, r, ctypes.byref(p), ctypes.byref(ln))
+                    vals.append(ctypes.string_at(p, ln.value))
+            out[name] = vals
+        return out
+
+    def close(self) -> None:
+        if self.handle:
+            lib().oracle_batch_release(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OraclePlan:
+    def __init__(self, filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (),
+                 groups: Sequence[Column] = (), nchains: int = 1, seed: int = 0x5EED):
+        self._desc = to_desc(filter_expr, list(aggs), list(groups))
+        out = ctypes.c_void_p()
+        rc = lib().oracle_plan_create(ctypes.addressof(self._desc.desc), nchains, seed, ctypes.byref(out))
+        if rc != 0:
+            raise OracleError(rc, lib().oracle_last_error().decode())
+        self.handle = out.value
+        self.nchains = nchains
+        self._rr = 0
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise OracleError(rc, lib().oracle_plan_last_error(self.handle).decode())
+
+    def push(self, batch, chain: Optional[int] = None) -> None:
+        """≙ Callback on one chain (round-robin like query.FakeTableReader, query/testing.go:24-43)."""
+        own = None
+        if isinstance(batch, pa.RecordBatch):
+            own = batch = OracleBatch.from_arrow(batch)
+        if chain is None:
+            chain = self._rr % self.nchains
+            self._rr += 1
+        self._check(lib().oracle_plan_push(self.handle, chain, batch.handle))
+        if own is not None:
+            own.close()
+
+    def filter(self, batch):
+        """≙ filter(): (compacted OracleBatch or None, selected indices)."""
+        own = None
+        if isinstance(batch, pa.RecordBatch):
+            own = batch = OracleBatch.from_arrow(batch)
+        out = ctypes.c_void_p()
+        empty = ctypes.c_int32()
+        idx = np.zeros(max(batch.num_rows, 1), dtype=np.uint32)
+        n = ctypes.c_int64()
+        self._check(lib().oracle_plan_filter(self.handle, batch.handle, ctypes.byref(out), ctypes.byref(empty),
+                                             idx.ctypes.data, ctypes.byref(n)))
+        if own is not None:
+            own.close()
+        return (None if empty.value else OracleBatch(out.value)), idx[: n.value].copy()
+
+    def finish(self) -> OracleBatch:
+        out = ctypes.c_void_p()
+        self._check(lib().oracle_plan_finish(self.handle, ctypes.byref(out)))
+        return OracleBatch(out.value)
+
+    def execute(self, batches: Sequence[OracleBatch], nthreads: int) -> OracleBatch:
+        """The CPU baseline: `nthreads` chains pulling from one queue, then Synchronizer + final stage."""
+        arr = (ctypes.c_void_p * len(batches))(*[b.handle for b in batches])
+        out = ctypes.c_void_p()
+        self._check(lib().oracle_plan_execute(self.handle, arr, len(batches), nthreads, ctypes.byref(out)))
+        return OracleBatch(out.value)
+
+    def close(self) -> None:
+        if self.handle:
+            lib().oracle_plan_close(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

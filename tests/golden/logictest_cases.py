@@ -1,0 +1,245 @@
+"""Golden vectors transcribed from the reference's data-driven SQL logic tests.
+
+Source: /root/reference/logictest/testdata/exec/{filter,aggregate}/* (cockroachdb/datadriven format:
+``createtable`` / ``insert cols=(…)`` / ``exec`` + expected tab-separated rows; ``null`` is the NULL literal,
+logictest/runner.go:27). The SQL of each ``exec`` is transcribed by hand into the logicalplan builders the
+SQL front end (sqlparse/) would produce; the expected rows are copied verbatim. Each case cites file:line.
+
+Only queries the hot path serves are listed (filter leaves / AND / OR, SUM/MIN/MAX/COUNT by label columns).
+AVG is lowered by the reference to SUM + COUNT + a Projection (logicalplan/builder.go:205-238); its cases
+carry ``avg_of=(sum_col, count_col)`` and the harness performs the reference's division (integer division
+for int64, builder.go:224-226) on the operator output. ``limit`` cases are checked as "a prefix-sized subset".
+
+Schema "default" = dynparquet.SampleDefinitionWithFloat() (logictest/logic_test.go:41): labels.* and
+stacktrace are RLE-dictionary strings (→ Arrow dictionary<uint32, binary>, pqarrow/convert/convert.go:64-70),
+timestamp/value int64, floatvalue nullable float64. One ``insert`` = one Arrow record (an L0 part).
+"""
+from frostdb_amd.logicalplan import And, Col, Count, DynCol, Max, Min, Or, Sum
+
+AGG_FILE = "logictest/testdata/exec/aggregate/aggregate"
+NULLS_FILE = "logictest/testdata/exec/aggregate/aggregate_nulls"
+FILTER_FILE = "logictest/testdata/exec/filter/filter"
+FPROJ_FILE = "logictest/testdata/exec/filter/filter_projection"
+WINDOW_FILE = "logictest/testdata/exec/aggregate/window"
+
+# ---- tables -------------------------------------------------------------------------------------
+
+AGG_TABLE = dict(  # aggregate:4-14
+    cols=["labels.label1", "labels.label2", "labels.label3", "labels.label4", "stacktrace", "timestamp", "value", "floatvalue"],
+    inserts=[
+        """
+        value1  value2  null    null    stack1  1   1   1.1
+        value2  value2  value3  null    stack1  2   2   2.2
+        value3  value2  null    value4  stack1  3   3   3.3
+        """,
+        """
+        value4  value2  null    null    stack1  4   4   4.4
+        value5  value2  value3  null    stack1  5   5   5.5
+        value6  value2  null    value4  stack1  6   6   6.6
+        """,
+    ],
+)
+
+NULLS_TABLE = dict(  # aggregate_nulls:4-8
+    cols=["labels.label1", "labels.label2", "stacktrace", "timestamp", "value"],
+    inserts=[
+        """
+        value1  null    stack1  1   1
+        null    value2  stack1  2   2
+        null    value2  stack1  3   3
+        """,
+    ],
+)
+
+FILTER_TABLE = dict(  # filter:4-8 (and filter_projection:4-8)
+    cols=["labels.label1", "labels.label2", "labels.label3", "labels.label4", "stacktrace", "timestamp", "value"],
+    inserts=[
+        """
+        value1  value2  null    null    stack1  1   1
+        value2  value2  value3  null    stack1  2   2
+        value3  value2  null    value4  stack1  3   3
+        """,
+    ],
+)
+
+WINDOW_TABLE = dict(  # window:6-11
+    cols=["labels.label1", "stacktrace", "timestamp", "value"],
+    inserts=[
+        """
+        value1  stack1  120000  1
+        value2  stack1  121000  2
+        value3  stack1  122000  3
+        value4  stack1  123000  4
+        """,
+    ],
+)
+
+L2 = Col("labels.label2")
+
+# ---- aggregate cases: (id, cite, table, filter, aggs, groups, out_cols, expected_rows[, extra]) ---
+# out_cols name operator output columns ("sum(value)" …) or group columns, in the SELECT's order.
+
+AGG_CASES = [
+    dict(id="sum_by_label2", cite=f"{AGG_FILE}:16-19", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("value"))], groups=[L2], out=["sum(value)", "labels.label2"],
+         expected=[(21, b"value2")]),
+    dict(id="sumfloat_by_label2", cite=f"{AGG_FILE}:21-24", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("floatvalue"))], groups=[L2], out=["labels.label2", "sum(floatvalue)"],
+         expected=[(b"value2", "23.100000")]),
+    dict(id="max_by_label2", cite=f"{AGG_FILE}:26-29", table=AGG_TABLE, filter=None,
+         aggs=[Max(Col("value"))], groups=[L2], out=["labels.label2", "max(value)"],
+         expected=[(b"value2", 6)]),
+    dict(id="maxfloat_by_label2", cite=f"{AGG_FILE}:31-34", table=AGG_TABLE, filter=None,
+         aggs=[Max(Col("floatvalue"))], groups=[L2], out=["labels.label2", "max(floatvalue)"],
+         expected=[(b"value2", "6.600000")]),
+    dict(id="minfloat_by_label2", cite=f"{AGG_FILE}:36-39", table=AGG_TABLE, filter=None,
+         aggs=[Min(Col("floatvalue"))], groups=[L2], out=["labels.label2", "min(floatvalue)"],
+         expected=[(b"value2", "1.100000")]),
+    dict(id="count_by_label2", cite=f"{AGG_FILE}:41-44", table=AGG_TABLE, filter=None,
+         aggs=[Count(Col("value"))], groups=[L2], out=["labels.label2", "count(value)"],
+         expected=[(b"value2", 6)]),
+    dict(id="avg_by_label2", cite=f"{AGG_FILE}:46-54", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("value")), Count(Col("value"))], groups=[L2], out=["labels.label2", "avg"],
+         avg_of=("sum(value)", "count(value)"), expected=[(b"value2", 3)]),
+    dict(id="avgfloat_by_label2", cite=f"{AGG_FILE}:56-59", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("floatvalue")), Count(Col("floatvalue"))], groups=[L2], out=["labels.label2", "avg"],
+         avg_of=("sum(floatvalue)", "count(floatvalue)"), expected=[(b"value2", "3.850000")]),
+    dict(id="avg_by_label4_nullgroup", cite=f"{AGG_FILE}:61-65", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("value")), Count(Col("value"))], groups=[Col("labels.label4")], out=["labels.label4", "avg"],
+         avg_of=("sum(value)", "count(value)"), expected=[(None, 3), (b"value4", 4)]),
+    dict(id="sum_count_by_stacktrace", cite=f"{AGG_FILE}:67-70", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("value")), Count(Col("value"))], groups=[Col("stacktrace")],
+         out=["stacktrace", "sum(value)", "count(value)"], expected=[(b"stack1", 21, 6)]),
+    dict(id="sumfloat_count_by_stacktrace", cite=f"{AGG_FILE}:72-75", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("floatvalue")), Count(Col("floatvalue"))], groups=[Col("stacktrace")],
+         out=["stacktrace", "sum(floatvalue)", "count(floatvalue)"], expected=[(b"stack1", "23.100000", 6)]),
+    dict(id="sum_count_alias_by_stacktrace", cite=f"{AGG_FILE}:77-80", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("value")), Count(Col("value"))], groups=[Col("stacktrace")],
+         out=["stacktrace", "sum(value)", "count(value)"], expected=[(b"stack1", 21, 6)]),
+    dict(id="four_aggs_by_label2", cite=f"{AGG_FILE}:82-85", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("value")), Count(Col("value")), Min(Col("value")), Max(Col("value"))], groups=[L2],
+         out=["labels.label2", "sum(value)", "count(value)", "min(value)", "max(value)"],
+         expected=[(b"value2", 21, 6, 1, 6)]),
+    dict(id="four_float_aggs_by_label2", cite=f"{AGG_FILE}:87-90", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("floatvalue")), Count(Col("floatvalue")), Min(Col("floatvalue")), Max(Col("floatvalue"))],
+         groups=[L2], out=["labels.label2", "sum(floatvalue)", "count(floatvalue)", "min(floatvalue)", "max(floatvalue)"],
+         expected=[(b"value2", "23.100000", 6, "1.100000", "6.600000")]),
+    dict(id="sum_where_ts_by_label1", cite=f"{AGG_FILE}:92-100", table=AGG_TABLE, filter=Col("timestamp") >= 1,
+         aggs=[Sum(Col("value"))], groups=[Col("labels.label1")], out=["labels.label1", "sum(value)"],
+         expected=[(b"value1", 1), (b"value2", 2), (b"value3", 3), (b"value4", 4), (b"value5", 5), (b"value6", 6)]),
+    dict(id="sum_by_all_labels", cite=f"{AGG_FILE}:102-110", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("value"))], groups=[DynCol("labels")],
+         out=["labels.label1", "labels.label2", "labels.label3", "labels.label4", "sum(value)"],
+         expected=[(b"value1", b"value2", None, None, 1), (b"value2", b"value2", b"value3", None, 2),
+                   (b"value3", b"value2", None, b"value4", 3), (b"value4", b"value2", None, None, 4),
+                   (b"value5", b"value2", b"value3", None, 5), (b"value6", b"value2", None, b"value4", 6)]),
+    dict(id="sum_by_label3_limit3", cite=f"{AGG_FILE}:112-117", table=AGG_TABLE, filter=None,
+         aggs=[Sum(Col("value"))], groups=[Col("labels.label3")], out=["sum(value)", "labels.label3"],
+         expected=[(14, None), (7, b"value3")]),
+    # aggregate_nulls
+    dict(id="nulls_sum", cite=f"{NULLS_FILE}:12-16", table=NULLS_TABLE, filter=None,
+         aggs=[Sum(Col("value"))], groups=[L2], out=["labels.label2", "sum(value)"],
+         expected=[(b"value2", 5), (None, 1)]),
+    dict(id="nulls_max", cite=f"{NULLS_FILE}:18-22", table=NULLS_TABLE, filter=None,
+         aggs=[Max(Col("value"))], groups=[L2], out=["labels.label2", "max(value)"],
+         expected=[(b"value2", 3), (None, 1)]),
+    dict(id="nulls_count", cite=f"{NULLS_FILE}:24-28", table=NULLS_TABLE, filter=None,
+         aggs=[Count(Col("value"))], groups=[L2], out=["labels.label2", "count(value)"],
+         expected=[(b"value2", 2), (None, 1)]),
+    dict(id="nulls_sum_count", cite=f"{NULLS_FILE}:30-34", table=NULLS_TABLE, filter=None,
+         aggs=[Sum(Col("value")), Count(Col("value"))], groups=[L2], out=["labels.label2", "sum(value)", "count(value)"],
+         expected=[(b"value2", 5, 2), (None, 1, 1)]),
+]
+
+# window: `(timestamp/N)*N as timestamp_bucket` is a pre-aggregate Projection (a "next" row);
+# the harness materialises that int64 column the way the Projection operator would and feeds the aggregate,
+# which pins int64 group keys. cases: (N, aggs, out, expected)
+WINDOW_CASES = [
+    dict(id="window_1000", cite=f"{WINDOW_FILE}:13-19", bucket=1000, aggs=[Sum(Col("value"))],
+         groups=[Col("timestamp_bucket")], out=["sum(value)", "timestamp_bucket"],
+         expected=[(1, 120000), (2, 121000), (3, 122000), (4, 123000)]),
+    dict(id="window_2000", cite=f"{WINDOW_FILE}:21-25", bucket=2000, aggs=[Sum(Col("value"))],
+         groups=[Col("timestamp_bucket")], out=["sum(value)", "timestamp_bucket"],
+         expected=[(3, 120000), (7, 122000)]),
+    dict(id="window_3000", cite=f"{WINDOW_FILE}:27-31", bucket=3000, aggs=[Sum(Col("value"))],
+         groups=[Col("timestamp_bucket")], out=["sum(value)", "timestamp_bucket"],
+         expected=[(6, 120000), (4, 123000)]),
+    dict(id="window_3000_count", cite=f"{WINDOW_FILE}:33-37", bucket=3000, aggs=[Sum(Col("value")), Count(Col("value"))],
+         groups=[Col("timestamp_bucket")], out=["sum(value)", "count(value)", "timestamp_bucket"],
+         expected=[(6, 3, 120000), (4, 1, 123000)]),
+    dict(id="window_4000", cite=f"{WINDOW_FILE}:39-42", bucket=4000, aggs=[Sum(Col("value"))],
+         groups=[Col("timestamp_bucket")], out=["sum(value)", "timestamp_bucket"],
+         expected=[(10, 120000)]),
+    dict(id="window_5000_by_label", cite=f"{WINDOW_FILE}:44-51", bucket=5000, aggs=[Sum(Col("value"))],
+         groups=[Col("labels.label1"), Col("timestamp_bucket")], out=["labels.label1", "timestamp_bucket", "sum(value)"],
+         expected=[(b"value1", 120000, 1), (b"value2", 120000, 2), (b"value3", 120000, 3), (b"value4", 120000, 4)]),
+    dict(id="window_2000_count_ts", cite=f"{WINDOW_FILE}:53-57", bucket=2000, aggs=[Sum(Col("value")), Count(Col("timestamp"))],
+         groups=[Col("timestamp_bucket")], out=["timestamp_bucket", "sum(value)", "count(timestamp)"],
+         expected=[(120000, 3, 2), (122000, 7, 2)]),
+    dict(id="window_3000_count_ts", cite=f"{WINDOW_FILE}:59-63", bucket=3000, aggs=[Count(Col("timestamp"))],
+         groups=[Col("timestamp_bucket")], out=["timestamp_bucket", "count(timestamp)"],
+         expected=[(120000, 3), (123000, 1)]),
+]
+
+# ---- filter cases: (id, cite, filter, expected selected row numbers of FILTER_TABLE (0-based)) ------
+# Expected rows in the testdata are the full rows value1/value2/value3 (timestamps 1/2/3) → row 0/1/2.
+L = lambda k: Col(f"labels.label{k}")  # noqa: E731
+TS = Col("timestamp")
+
+FILTER_CASES = [
+    dict(id="ts_eq", cite=f"{FILTER_FILE}:10-13", filter=TS == 2, rows=[1]),
+    dict(id="ts_neq", cite=f"{FILTER_FILE}:15-19", filter=TS != 2, rows=[0, 2]),
+    dict(id="ts_lt", cite=f"{FILTER_FILE}:21-24", filter=TS < 2, rows=[0]),
+    dict(id="ts_le", cite=f"{FILTER_FILE}:26-30", filter=TS <= 2, rows=[0, 1]),
+    dict(id="ts_gt", cite=f"{FILTER_FILE}:37-40", filter=TS > 2, rows=[2]),
+    dict(id="ts_ge", cite=f"{FILTER_FILE}:42-46", filter=TS >= 2, rows=[1, 2]),
+    dict(id="label4_eq", cite=f"{FILTER_FILE}:48-51", filter=L(4) == "value4", rows=[2]),
+    dict(id="label1_or_label2", cite=f"{FILTER_FILE}:53-58", filter=Or(L(1) == "value1", L(2) == "value2"), rows=[0, 1, 2]),
+    dict(id="missing_neq", cite=f"{FILTER_FILE}:60-65", filter=L(5) != "value4", rows=[0, 1, 2]),
+    dict(id="missing_eq_empty", cite=f"{FILTER_FILE}:67-72", filter=L(5) == "", rows=[0, 1, 2]),
+    dict(id="regex_and_eq", cite=f"{FILTER_FILE}:74-79", filter=And(L(1).RegexMatch("value."), L(2) == "value2"), rows=[0, 1, 2]),
+    dict(id="missing_regex_empty", cite=f"{FILTER_FILE}:81-86", filter=L(5).RegexMatch(""), rows=[0, 1, 2]),
+    dict(id="missing_not_regex", cite=f"{FILTER_FILE}:88-93", filter=L(5).RegexNotMatch("foo"), rows=[0, 1, 2]),
+    dict(id="regex_missing_eq", cite=f"{FILTER_FILE}:95-98",
+         filter=And(L(3).RegexMatch("value."), L(5).RegexMatch(""), L(2) == "value2"), rows=[1]),
+    dict(id="regex_eq_neq", cite=f"{FILTER_FILE}:100-104",
+         filter=And(L(1).RegexMatch("value."), L(2) == "value2", L(1) != "value3"), rows=[0, 1]),
+    dict(id="regex_simple", cite=f"{FILTER_FILE}:106-112", filter=L(1).RegexMatch("value."), rows=[0, 1, 2]),
+    dict(id="regex_nomatch", cite=f"{FILTER_FILE}:114-117", filter=L(1).RegexMatch("values."), rows=[]),
+    dict(id="regex_and_missing_empty", cite=f"{FILTER_FILE}:119-124", filter=And(L(1).RegexMatch("value."), L(5) == ""), rows=[0, 1, 2]),
+    dict(id="regex_and_or", cite=f"{FILTER_FILE}:126-129",
+         filter=And(L(3).RegexMatch("value."), Or(L(1) == "value1", L(1) == "value2")), rows=[1]),
+    dict(id="or_and", cite=f"{FILTER_FILE}:131-135",
+         filter=Or(L(4) == "value4", And(L(2).RegexMatch("value."), L(1) == "value2")), rows=[1, 2]),
+    dict(id="eq_null", cite=f"{FILTER_FILE}:137-141", filter=L(4) == None, rows=[0, 1]),  # noqa: E711
+    dict(id="neq_null", cite=f"{FILTER_FILE}:143-146", filter=L(4) != None, rows=[2]),  # noqa: E711
+    dict(id="missing_gt", cite=f"{FILTER_FILE}:148-151", filter=Col("doesntexist") > 4, rows=[]),
+    dict(id="missing_lt", cite=f"{FILTER_FILE}:153-155", filter=Col("doesntexist") < 4, rows=[]),
+    dict(id="missing_ge", cite=f"{FILTER_FILE}:157-159", filter=Col("doesntexist") >= 4, rows=[]),
+    dict(id="missing_le", cite=f"{FILTER_FILE}:161-163", filter=Col("doesntexist") <= 4, rows=[]),
+    dict(id="like", cite=f"{FILTER_FILE}:165-170", filter=Col("stacktrace").Contains("ack"), rows=[0, 1, 2]),
+    dict(id="like_nomatch", cite=f"{FILTER_FILE}:172-174", filter=Col("stacktrace").Contains("ack2"), rows=[]),
+    dict(id="not_like", cite=f"{FILTER_FILE}:176-178", filter=Col("stacktrace").NotContains("ack"), rows=[]),
+    dict(id="not_like_all", cite=f"{FILTER_FILE}:180-185", filter=Col("stacktrace").NotContains("ack2"), rows=[0, 1, 2]),
+    dict(id="not_like_and_like", cite=f"{FILTER_FILE}:187-191",
+         filter=And(L(1).NotContains("ue2"), Col("stacktrace").Contains("ack")), rows=[0, 2]),
+    # filter_projection
+    dict(id="proj_ts_ge", cite=f"{FPROJ_FILE}:11-21", filter=TS >= 2, rows=[1, 2]),
+    dict(id="proj_null_and_notnull", cite=f"{FPROJ_FILE}:23-27", filter=And(L(5) == None, L(3) != None), rows=[1]),  # noqa: E711
+    dict(id="proj_inverse_null", cite=f"{FPROJ_FILE}:29-32", filter=And(L(5) != None, L(3) != None), rows=[]),  # noqa: E711
+    dict(id="proj_multi_null", cite=f"{FPROJ_FILE}:34-39",
+         filter=Or(And(L(3) == "value3", L(5) == None), And(L(3) == None, L(5) == "a")), rows=[1]),  # noqa: E711
+]
+
+# aggregate_test.go:23-148 TestAggregateInconsistentSchema: three single-row records with different label
+# sets; GROUP BY labels.label2 (a concrete column that the first record lacks). Expected values, sorted
+# descending like the test does (aggregate_test.go:141-145).
+INCONSISTENT_SCHEMA = dict(
+    records=[
+        dict(cols=["labels.label1", "stacktrace", "timestamp", "value"], rows="value1 s 1 1"),
+        dict(cols=["labels.label2", "stacktrace", "timestamp", "value"], rows="value2 s 2 2"),
+        dict(cols=["labels.label2", "stacktrace", "timestamp", "value"], rows="value2 s 3 3"),
+    ],
+    cite="aggregate_test.go:85-114",
+    expected={"sum": [5, 1], "min": [2, 1], "max": [3, 1], "count": [2, 1], "avg": [2, 1]},
+)

@@ -1,0 +1,121 @@
+"""Pins the CPU oracle (oracle/oracle.cpp) against the reference's own golden vectors.
+
+Runs on CPU (-m "not gpu"). The same vectors drive the HIP path in tests/test_gpu_parity.py.
+"""
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+import oracle
+from oracle import OraclePlan
+from tests.golden import logictest_cases as G
+from tests.util import batch_rows, fmt, parse_rows, record_from_rows, sort_key, table_records
+
+
+def test_metrohash64_published_vectors():
+    # MetroHash64 reference test vectors (metrohash testvector.h): key = 63 bytes "0123456789…012";
+    # go-metro's Hash64 is a port of this function (dynparquet/hashed.go:207 calls it with seed 0).
+    key = b"012345678901234567890123456789012345678901234567890123456789012"
+    assert len(key) == 63
+    assert oracle.metro_hash64(key, 0).to_bytes(8, "little") == bytes([0x6B, 0x75, 0x3D, 0xAE, 0x06, 0x70, 0x4B, 0xAD])
+    assert oracle.metro_hash64(key, 1).to_bytes(8, "little") == bytes([0x3B, 0x0D, 0x48, 0x1C, 0xF4, 0xB9, 0xB8, 0xDF])
+
+
+def test_hash_combine_matches_boost_formula():
+    L = oracle.lib()
+    lhs, rhs = 0x0123456789ABCDEF, 0xFEDCBA9876543210
+    want = lhs ^ ((rhs + 0x9E3779B9 + ((lhs << 6) & (2**64 - 1)) + (lhs >> 2)) & (2**64 - 1))
+    assert L.oracle_hash_combine(lhs, rhs) == want  # aggregate.go:245-247
+
+
+def run_aggregate(case, nchains):
+    plan = OraclePlan(case.get("filter"), case["aggs"], case["groups"], nchains=nchains)
+    for rec in table_records(case["table"]):
+        plan.push(rec)
+    res = plan.finish().to_pydict()
+    plan.close()
+    return res
+
+
+def check_aggregate(case, res):
+    d = dict(res)
+    if "avg_of" in case:  # the reference's AVG Projection (logicalplan/builder.go:205-238)
+        s, c = case["avg_of"]
+        d["avg"] = [(a // b if isinstance(a, int) else a / float(b)) for a, b in zip(d[s], d[c])]
+    got = sorted([tuple(fmt(v) for v in row) for row in batch_rows(d, case["out"])], key=sort_key)
+    want = sorted(case["expected"], key=sort_key)
+    assert got == want, f"{case['cite']}: got {got} want {want}"
+
+
+@pytest.mark.parametrize("nchains", [1, 2, 3])
+@pytest.mark.parametrize("case", G.AGG_CASES, ids=[c["id"] for c in G.AGG_CASES])
+def test_oracle_aggregate_golden(case, nchains):
+    check_aggregate(case, run_aggregate(case, nchains))
+
+
+def window_records(bucket):
+    rec = table_records(G.WINDOW_TABLE)[0]
+    ts = rec.column(rec.schema.get_field_index("timestamp"))
+    b = pc.multiply(pc.divide(ts, pa.scalar(bucket, pa.int64())), pa.scalar(bucket, pa.int64()))
+    return [rec.append_column("timestamp_bucket", b)]
+
+
+@pytest.mark.parametrize("case", G.WINDOW_CASES, ids=[c["id"] for c in G.WINDOW_CASES])
+def test_oracle_window_golden(case):
+    plan = OraclePlan(None, case["aggs"], case["groups"], nchains=1)
+    for rec in window_records(case["bucket"]):
+        plan.push(rec)
+    res = plan.finish().to_pydict()
+    plan.close()
+    got = sorted(batch_rows(res, case["out"]), key=sort_key)
+    assert got == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+@pytest.mark.parametrize("case", G.FILTER_CASES, ids=[c["id"] for c in G.FILTER_CASES])
+def test_oracle_filter_golden(case):
+    rec = table_records(G.FILTER_TABLE)[0]
+    plan = OraclePlan(case["filter"])
+    out, idx = plan.filter(rec)
+    assert list(idx) == case["rows"], case["cite"]
+    if case["rows"]:
+        d = out.to_pydict()
+        assert d["timestamp"] == [r + 1 for r in case["rows"]]
+        assert d["labels.label1"] == [b"value%d" % (r + 1) for r in case["rows"]]
+    else:
+        assert out is None  # filter.go:264-266: empty ⇒ nothing is pushed downstream
+    plan.close()
+
+
+@pytest.mark.parametrize("nchains", [1, 3])
+def test_oracle_inconsistent_schema(nchains):
+    from frostdb_amd.logicalplan import Col, Count, Max, Min, Sum
+    spec = G.INCONSISTENT_SCHEMA
+    recs = [record_from_rows(r["cols"], parse_rows(r["cols"], r["rows"])) for r in spec["records"]]
+    fns = {"sum": [Sum], "min": [Min], "max": [Max], "count": [Count], "avg": [Sum, Count]}
+    for name, want in spec["expected"].items():
+        plan = OraclePlan(None, [f(Col("value")) for f in fns[name]], [Col("labels.label2")], nchains=nchains)
+        for r in recs:
+            plan.push(r)
+        d = plan.finish().to_pydict()
+        plan.close()
+        if name == "avg":
+            vals = [a // b for a, b in zip(d["sum(value)"], d["count(value)"])]
+        else:
+            vals = d[f"{name}(value)"]
+        assert sorted(vals, reverse=True) == want, (spec["cite"], name)
+
+
+def test_oracle_filter_contains_on_plain_binary():
+    # logictest/testdata/exec/filter/filter_contains: schema "bytes" has a plain (non-dictionary) `value` column.
+    from frostdb_amd.logicalplan import Col, UInt64
+    from tests.util import dict_array
+    rec = pa.RecordBatch.from_arrays(
+        [dict_array([b"value1", b"value2", b"value3"]), pa.array([1, 2, 3], type=pa.uint64()),
+         pa.array([b"foo", b"bar", b"baz"], type=pa.binary())],
+        names=["labels.label1", "timestamp", "value"])
+    p = OraclePlan(Col("value").Contains("a"))
+    assert list(p.filter(rec)[1]) == [1, 2]  # filter_contains:15-19
+    p = OraclePlan(Col("value").NotContains("a"))
+    assert list(p.filter(rec)[1]) == [0]  # filter_contains:21-24
+    p = OraclePlan(Col("timestamp") == UInt64(2))
+    assert list(p.filter(rec)[1]) == [1]  # filter_contains:10-13
