@@ -1,0 +1,47 @@
+"""Builds libfrostdb_amd.so (HIP kernels + host C++ + C ABI) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs on the CPU-only build container too. The .so is git-ignored
+but travels to the GPU box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfrostdb_amd.so")
+SOURCES = ["fdb_kernels.hip", "fdb_arrow.cpp", "fdb_plan.cpp", "fdb_capi.cpp"]
+HEADERS = ["fdb_kernels.h", "fdb_arrow.h", "fdb_plan.h", "../../include/frostdb_amd.h", "../../include/arrow_c_data.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-result"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,239 @@
+// fdb_arrow.cpp — see fdb_arrow.h.
+#include "fdb_arrow.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace fdb {
+
+namespace {
+
+ColKind kind_of(const std::string& f, bool has_dict) {
+  if (has_dict) return ColKind::DICT;
+  if (f == "l") return ColKind::I64;
+  if (f == "L") return ColKind::U64;
+  if (f == "g") return ColKind::F64;
+  if (f == "b") return ColKind::BOOL;
+  if (f == "u" || f == "z" || f == "U" || f == "Z") return ColKind::STR;
+  return ColKind::OTHER;
+}
+
+int index_width_of(const std::string& f) {
+  if (f.empty()) return 0;
+  switch (f[0]) {
+    case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': return 4;
+    case 'l': case 'L': return 8;
+  }
+  return 0;
+}
+
+}  // namespace
+
+void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordView* out) {
+  if (array == nullptr || schema == nullptr) throw Error(FDB_ERR_INVALID, "null record");
+  if (schema->format == nullptr || std::strcmp(schema->format, "+s") != 0)
+    throw Error(FDB_ERR_INVALID, "record batch must be exported as a struct array (format \"+s\")");
+  if (array->n_children != schema->n_children) throw Error(FDB_ERR_INVALID, "schema/array children mismatch");
+  if (array->offset != 0) throw Error(FDB_ERR_INVALID, "sliced struct records are not supported; slice the columns instead");
+  out->rows = array->length;
+  out->cols.clear();
+  out->cols.reserve((size_t)array->n_children);
+  for (int64_t i = 0; i < array->n_children; i++) {
+    const ArrowSchema* cs = schema->children[i];
+    const ArrowArray* ca = array->children[i];
+    HostColView c;
+    c.name = cs->name ? cs->name : "";
+    c.format = cs->format ? cs->format : "";
+    c.kind = kind_of(c.format, cs->dictionary != nullptr);
+    c.length = ca->length;
+    c.offset = ca->offset;
+    c.array = ca;
+    c.schema = cs;
+    if (ca->length != array->length) throw Error(FDB_ERR_INVALID, "column length differs from record length: " + c.name);
+    c.validity = ca->n_buffers > 0 ? (const uint8_t*)ca->buffers[0] : nullptr;
+    c.null_count = ca->null_count;
+    if (c.validity == nullptr) c.null_count = 0;
+    else if (c.null_count < 0) c.null_count = count_nulls(c.validity, c.offset, c.length);
+    if (c.kind == ColKind::DICT) {
+      c.index_width = index_width_of(c.format);
+      if (c.index_width == 0) throw Error(FDB_ERR_INVALID, "unsupported dictionary index type " + c.format);
+      const std::string df = cs->dictionary->format ? cs->dictionary->format : "";
+      if (!(df == "u" || df == "z" || df == "U" || df == "Z")) c.kind = ColKind::OTHER;  // non-string dictionaries
+    }
+    if (c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::DICT ||
+        c.kind == ColKind::BOOL) {
+      if (ca->n_buffers < 2) throw Error(FDB_ERR_INVALID, "missing values buffer: " + c.name);
+      c.values = ca->buffers[1];
+    }
+    out->cols.push_back(std::move(c));
+  }
+}
+
+std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
+  auto d = std::make_shared<HostDict>();
+  const ArrowArray* da = col.array->dictionary;
+  const std::string df = col.schema->dictionary->format;
+  d->value_format = (df == "u" || df == "U") ? "u" : "z";
+  const int64_t n = da->length, off = da->offset;
+  d->values.resize((size_t)n);
+  const char* data = (const char*)da->buffers[2];
+  if (df == "u" || df == "z") {
+    const int32_t* offs = (const int32_t*)da->buffers[1];
+    for (int64_t i = 0; i < n; i++) d->values[(size_t)i].assign(data + offs[off + i], (size_t)(offs[off + i + 1] - offs[off + i]));
+  } else {
+    const int64_t* offs = (const int64_t*)da->buffers[1];
+    for (int64_t i = 0; i < n; i++) d->values[(size_t)i].assign(data + offs[off + i], (size_t)(offs[off + i + 1] - offs[off + i]));
+  }
+  return d;
+}
+
+int64_t count_nulls(const uint8_t* validity, int64_t offset, int64_t length) {
+  int64_t set = 0;
+  for (int64_t i = 0; i < length; i++) set += (validity[(offset + i) >> 3] >> ((offset + i) & 7)) & 1;
+  return length - set;
+}
+
+void copy_bits(const uint8_t* src, int64_t offset, int64_t length, uint8_t* dst) {
+  const int64_t nbytes = (length + 7) / 8;
+  if (nbytes == 0) return;
+  if ((offset & 7) == 0) {
+    std::memcpy(dst, src + (offset >> 3), (size_t)nbytes);
+  } else {
+    const int sh = (int)(offset & 7);
+    const uint8_t* s = src + (offset >> 3);
+    const int64_t src_bytes = (offset + length + 7) / 8 - (offset >> 3);
+    for (int64_t i = 0; i < nbytes; i++) {
+      uint32_t lo = s[i];
+      uint32_t hi = (i + 1 < src_bytes) ? s[i + 1] : 0;
+      dst[i] = (uint8_t)((lo >> sh) | (hi << (8 - sh)));
+    }
+  }
+  const int tail = (int)(length & 7);
+  if (tail) dst[nbytes - 1] &= (uint8_t)((1u << tail) - 1u);
+}
+
+// ---- export --------------------------------------------------------------------------------------------
+
+namespace {
+
+struct Holder {
+  std::vector<OutColumn> cols;
+  // C structs handed out
+  std::vector<ArrowArray> child_arrays;
+  std::vector<ArrowArray*> child_array_ptrs;
+  std::vector<ArrowArray> dict_arrays;
+  std::vector<std::vector<const void*>> buffers;  // per child + per dict + top
+  std::vector<ArrowSchema> child_schemas;
+  std::vector<ArrowSchema*> child_schema_ptrs;
+  std::vector<ArrowSchema> dict_schemas;
+  int refs = 2;  // array + schema
+};
+
+void noop_release_array(ArrowArray* a) { a->release = nullptr; }
+void noop_release_schema(ArrowSchema* s) { s->release = nullptr; }
+
+void drop(Holder* h) {
+  if (--h->refs == 0) delete h;
+}
+
+void release_top_array(ArrowArray* a) {
+  Holder* h = (Holder*)a->private_data;
+  for (auto& c : h->child_arrays) {
+    if (c.release) c.release(&c);
+  }
+  a->release = nullptr;
+  drop(h);
+}
+
+void release_top_schema(ArrowSchema* s) {
+  Holder* h = (Holder*)s->private_data;
+  for (auto& c : h->child_schemas) {
+    if (c.release) c.release(&c);
+  }
+  s->release = nullptr;
+  drop(h);
+}
+
+}  // namespace
+
+void export_record(std::vector<OutColumn>&& cols_in, int64_t rows, ArrowArray* out, ArrowSchema* out_schema) {
+  Holder* h = new Holder();
+  h->cols = std::move(cols_in);
+  const size_t n = h->cols.size();
+  h->child_arrays.resize(n);
+  h->child_array_ptrs.resize(n);
+  h->dict_arrays.resize(n);
+  h->child_schemas.resize(n);
+  h->child_schema_ptrs.resize(n);
+  h->dict_schemas.resize(n);
+  h->buffers.resize(2 * n + 1);
+  for (size_t i = 0; i < n; i++) {
+    OutColumn& c = h->cols[i];
+    ArrowArray& a = h->child_arrays[i];
+    std::memset(&a, 0, sizeof(a));
+    a.length = c.length;
+    a.null_count = c.null_count;
+    a.offset = 0;
+    a.n_buffers = 2;
+    std::vector<const void*>& b = h->buffers[i];
+    b.resize(2);
+    b[0] = (c.null_count > 0 && !c.validity.empty()) ? (const void*)c.validity.data() : nullptr;
+    static const uint64_t kEmpty = 0;
+    b[1] = c.values.empty() ? (const void*)&kEmpty : (const void*)c.values.data();
+    a.buffers = b.data();
+    a.release = noop_release_array;
+    ArrowSchema& s = h->child_schemas[i];
+    std::memset(&s, 0, sizeof(s));
+    s.format = c.format.c_str();
+    s.name = c.name.c_str();
+    s.flags = ARROW_FLAG_NULLABLE;
+    s.release = noop_release_schema;
+    if (c.is_dict) {
+      ArrowArray& d = h->dict_arrays[i];
+      std::memset(&d, 0, sizeof(d));
+      d.length = (int64_t)c.dict_offsets.size() - 1;
+      d.null_count = 0;
+      d.n_buffers = 3;
+      std::vector<const void*>& db = h->buffers[n + i];
+      db.resize(3);
+      db[0] = nullptr;
+      db[1] = c.dict_offsets.data();
+      static const char kNoData = 0;
+      db[2] = c.dict_data.empty() ? (const void*)&kNoData : (const void*)c.dict_data.data();
+      d.buffers = db.data();
+      d.release = noop_release_array;
+      a.dictionary = &d;
+      ArrowSchema& ds = h->dict_schemas[i];
+      std::memset(&ds, 0, sizeof(ds));
+      ds.format = c.dict_format.c_str();
+      ds.name = "";
+      ds.flags = ARROW_FLAG_NULLABLE;
+      ds.release = noop_release_schema;
+      s.dictionary = &ds;
+    }
+    h->child_array_ptrs[i] = &a;
+    h->child_schema_ptrs[i] = &s;
+  }
+  std::memset(out, 0, sizeof(*out));
+  out->length = rows;
+  out->null_count = 0;
+  out->n_buffers = 1;
+  std::vector<const void*>& tb = h->buffers[2 * n];
+  tb.assign(1, nullptr);
+  out->buffers = tb.data();
+  out->n_children = (int64_t)n;
+  out->children = h->child_array_ptrs.data();
+  out->release = release_top_array;
+  out->private_data = h;
+  std::memset(out_schema, 0, sizeof(*out_schema));
+  out_schema->format = "+s";
+  out_schema->name = "";
+  out_schema->n_children = (int64_t)n;
+  out_schema->children = h->child_schema_ptrs.data();
+  out_schema->release = release_top_schema;
+  out_schema->private_data = h;
+}
+
+}  // namespace fdb

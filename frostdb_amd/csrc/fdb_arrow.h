@@ -1,0 +1,73 @@
+// fdb_arrow.h — Arrow C Data Interface plumbing: host views of incoming records and construction of
+// outgoing ones. No Arrow library is linked; the ABI structs are all that crosses the boundary.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/frostdb_amd.h"
+
+namespace fdb {
+
+struct Error : public std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+enum class ColKind : int32_t { I64 = 1, U64 = 2, F64 = 3, BOOL = 4, STR = 5, DICT = 6, OTHER = 7 };
+
+// The dictionary of one dictionary-encoded column, kept on the host (strings never go to the device).
+struct HostDict {
+  std::vector<std::string> values;
+  std::string value_format;  // "z" (binary) or "u" (utf8); large variants are narrowed on import
+  bool utf8() const { return value_format == "u"; }
+};
+
+// A borrowed view of one column of an incoming record; valid only while the caller's ArrowArray is.
+struct HostColView {
+  std::string name;
+  std::string format;
+  ColKind kind = ColKind::OTHER;
+  int64_t length = 0, offset = 0, null_count = 0;
+  const uint8_t* validity = nullptr;  // may be nullptr when null_count == 0
+  const void* values = nullptr;       // fixed-width values / dictionary indices (element 0 of the buffer)
+  int index_width = 0;                // DICT: bytes per index
+  const ArrowArray* array = nullptr;
+  const ArrowSchema* schema = nullptr;
+};
+
+struct HostRecordView {
+  int64_t rows = 0;
+  std::vector<HostColView> cols;
+};
+
+// Throws fdb::Error(FDB_ERR_INVALID) on a malformed record.
+void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordView* out);
+std::shared_ptr<HostDict> read_dictionary(const HostColView& col);
+int64_t count_nulls(const uint8_t* validity, int64_t offset, int64_t length);
+// Copies `length` bits starting at bit `offset` of `src` to bit 0 of `dst` (dst has (length+7)/8 bytes, zero padded).
+void copy_bits(const uint8_t* src, int64_t offset, int64_t length, uint8_t* dst);
+
+// ---- building an outgoing record ----------------------------------------------------------------------
+struct OutColumn {
+  std::string name;
+  std::string format;                 // "l", "g", or the index format "I" for dictionary columns
+  int64_t length = 0;
+  int64_t null_count = 0;
+  std::vector<uint8_t> validity;      // empty ⇒ no validity buffer
+  std::vector<uint8_t> values;        // fixed-width values / uint32 indices
+  // dictionary columns:
+  bool is_dict = false;
+  std::string dict_format;            // "z" / "u"
+  std::vector<int32_t> dict_offsets;  // n_dict + 1
+  std::vector<char> dict_data;
+};
+
+// Moves `cols` into a heap holder and fills `out`/`out_schema` (struct-typed record, `rows` long) whose
+// release callbacks free that holder.
+void export_record(std::vector<OutColumn>&& cols, int64_t rows, ArrowArray* out, ArrowSchema* out_schema);
+
+}  // namespace fdb

@@ -1,0 +1,155 @@
+// fdb_capi.cpp — the extern "C" surface declared in include/frostdb_amd.h. Every entry point converts C++
+// exceptions into fdb_status codes (never aborts: the Go side wraps chains in recovery.Do, physicalplan.go:142).
+#include <new>
+#include <string>
+
+#include "fdb_plan.h"
+
+struct fdb_plan { fdb::Plan plan; fdb_plan(const fdb_plan_desc* d, int dev) : plan(d, dev) {} };
+struct fdb_batch { std::unique_ptr<fdb::DeviceBatch> b; };
+
+namespace {
+thread_local std::string g_last_error;
+
+template <typename F>
+int guard(fdb_plan* p, F&& f) {
+  try {
+    f();
+    return FDB_OK;
+  } catch (const fdb::Error& e) {
+    if (p) p->plan.error = e.what(); else g_last_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    if (p) p->plan.error = "out of host memory"; else g_last_error = "out of host memory";
+    return FDB_ERR_OOM;
+  } catch (const std::exception& e) {
+    if (p) p->plan.error = e.what(); else g_last_error = e.what();
+    return FDB_ERR_INVALID;
+  } catch (...) {
+    if (p) p->plan.error = "unknown error"; else g_last_error = "unknown error";
+    return FDB_ERR_INVALID;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* fdb_version(void) { return "frostdb_amd 0.1.0 (gfx950)"; }
+const char* fdb_last_error(void) { return g_last_error.c_str(); }
+
+int fdb_device_count(int* n_devices) {
+  return guard(nullptr, [&] {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    *n_devices = n;
+  });
+}
+
+int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out) {
+  return guard(nullptr, [&] {
+    if (out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null out pointer");
+    *out = new fdb_plan(desc, device);
+  });
+}
+
+int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.push(batch, schema); });
+}
+
+int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch) {
+  if (!plan || !batch) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.push_batch(*batch->b); });
+}
+
+int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.finish(out, out_schema, n_rows); });
+}
+
+int fdb_plan_merge(fdb_plan* dst, fdb_plan* src) {
+  if (!dst || !src) return FDB_ERR_INVALID;
+  return guard(dst, [&] { dst->plan.merge_from(src->plan); });
+}
+
+int fdb_plan_filter(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out,
+                    struct ArrowSchema* out_schema, int64_t* n_selected) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.filter(batch, schema, out, out_schema, n_selected); });
+}
+
+int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema, uint32_t* indices, int64_t capacity,
+                    int64_t* n_selected) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.select(batch, schema, indices, capacity, n_selected); });
+}
+
+const char* fdb_plan_draw(fdb_plan* plan) { return plan ? plan->plan.draw() : ""; }
+const char* fdb_plan_last_error(const fdb_plan* plan) { return plan ? plan->plan.error.c_str() : g_last_error.c_str(); }
+void fdb_plan_close(fdb_plan* plan) { delete plan; }
+
+int fdb_plan_num_groups(fdb_plan* plan, int64_t* n_groups) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { *n_groups = plan->plan.num_groups(); });
+}
+
+int fdb_plan_partial_keys(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.partial_keys(out, out_schema); });
+}
+
+int fdb_plan_partial_state(fdb_plan* plan, int32_t agg, void* dst, int64_t capacity_bytes) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.partial_state(agg, dst, capacity_bytes); });
+}
+
+int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { *format_out = plan->plan.agg_format(agg); });
+}
+
+int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int device, fdb_batch** out) {
+  return guard(nullptr, [&] {
+    fdb::HostRecordView view;
+    fdb::view_record(batch, schema, &view);
+    std::unique_ptr<fdb_batch> b(new fdb_batch());
+    b->b = fdb::import_batch(view, device, nullptr, nullptr);
+    *out = b.release();
+  });
+}
+
+int64_t fdb_batch_num_rows(const fdb_batch* batch) { return batch ? batch->b->rows : 0; }
+int64_t fdb_batch_device_bytes(const fdb_batch* batch) { return batch ? (int64_t)batch->b->arena_bytes : 0; }
+void fdb_batch_release(fdb_batch* batch) { delete batch; }
+
+int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms, int64_t* n_launches, int64_t* rows_scanned) {
+  if (!plan) return FDB_ERR_INVALID;
+  if (algorithmic_bytes) *algorithmic_bytes = plan->plan.stat_bytes;
+  if (kernel_ms) *kernel_ms = plan->plan.stat_ms;
+  if (n_launches) *n_launches = plan->plan.stat_launches;
+  if (rows_scanned) *rows_scanned = plan->plan.stat_rows;
+  return FDB_OK;
+}
+
+int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled) {
+  if (!plan) return FDB_ERR_INVALID;
+  plan->plan.timing = enabled != 0;
+  return FDB_OK;
+}
+
+int fdb_plan_stream(fdb_plan* plan, void** stream_out) {
+  if (!plan) return FDB_ERR_INVALID;
+  *stream_out = (void*)plan->plan.stream();
+  return FDB_OK;
+}
+
+// Tuning knobs used by bench.py's variant sweeps (not part of the Go binding).
+int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_blocks) {
+  if (!plan) return FDB_ERR_INVALID;
+  if (rows_per_thread == 4 || rows_per_thread == 8) plan->plan.rows_per_thread = rows_per_thread;
+  plan->plan.grid_override = grid_blocks;
+  return FDB_OK;
+}
+
+}  // extern "C"

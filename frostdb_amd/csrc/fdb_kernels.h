@@ -1,0 +1,115 @@
+// fdb_kernels.h — argument blocks and launch wrappers of the gfx950 scan kernels (host/device shared).
+//
+// The device sees no strings: every dictionary column is reduced on the host, once per batch and per
+// dictionary ENTRY, to small look-up tables (predicate LUT: entry → 0/1; group LUT: entry → per-column
+// key id, 0 = NULL). That replaces the reference's per-ROW bytes.Equal / metro.Hash64
+// (binaryscalarexpr.go:214-229, dynparquet/hashed.go:201-216).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#define FDB_MAX_LEAVES 12
+#define FDB_MAX_CODE 32
+#define FDB_MAX_DENSE_GCOLS 8
+#define FDB_MAX_HASH_GCOLS 64
+#define FDB_MAX_AGGS 8
+#define FDB_BLOCK 1024          // 16 waves share one LDS partial table
+#define FDB_LDS_BUDGET 65536    // bytes of LDS per workgroup (2 workgroups/CU of the 160 KiB)
+#define FDB_NO_LDS 0xFFFFFFFFu
+
+enum FdbLeafKind : int32_t {
+  FDB_LEAF_CONST = 0,      // op = 0/1: no row / every row (missing-column rules, binaryscalarexpr.go:47-73)
+  FDB_LEAF_DICT_LUT = 1,   // values = uint32 indices; lut[idx] ∈ {0,1}
+  FDB_LEAF_CMP_I64 = 2,    // values = int64;  lit = int64
+  FDB_LEAF_CMP_U64 = 3,    // values = uint64; lit = uint64
+  FDB_LEAF_CMP_F64 = 4,    // values = double; lit = double bits
+  FDB_LEAF_CMP_I64_F64 = 5,// values = int64 compared as double against a double literal
+  FDB_LEAF_VALIDITY = 6    // op = 0: IS NULL, 1: IS NOT NULL (binaryscalarexpr.go:165-172, :205-212)
+};
+
+enum FdbCode : uint8_t { FDB_CODE_AND = 0x80, FDB_CODE_OR = 0x81 };  // < 0x80: push leaf i
+
+struct FdbLeaf {
+  const void* values;
+  const uint8_t* validity;  // Arrow validity bitmap at bit offset 0, or nullptr (no nulls)
+  const uint8_t* lut;       // FDB_LEAF_DICT_LUT: global copy of the LUT
+  int64_t lit;
+  int32_t kind;
+  int32_t op;               // fdb_op for compares
+  uint32_t lut_len;
+  uint32_t lut_lds;         // byte offset of the LUT's LDS copy, or FDB_NO_LDS (too big: gather from L2)
+};
+
+struct FdbGroupCol {
+  const uint32_t* idx;
+  const uint8_t* validity;
+  const uint32_t* lut;      // dictionary entry → key id (≥ 1); NULL rows take id 0
+  uint32_t lut_len;
+  uint32_t lut_lds;
+  uint32_t stride;          // dense path: mixed-radix multiplier of this column
+  uint32_t _pad;
+};
+
+enum FdbAggType : int32_t { FDB_T_NONE = 0, FDB_T_I64 = 1, FDB_T_F64 = 2 };
+
+struct FdbAgg {
+  const void* values;       // nullptr for COUNT (row count only)
+  const uint8_t* validity;
+  unsigned long long* acc;  // global accumulator array [n_slots] (int64 bits / double bits / ordered-f64 keys)
+  int32_t func;             // fdb_agg_func (SUM/MIN/MAX/COUNT)
+  int32_t type;             // FdbAggType of the input column
+};
+
+struct FdbScanArgs {
+  int64_t n_rows;
+  unsigned long long* cnt;  // global selected-row count per slot (occupancy + COUNT)
+  uint32_t n_slots;
+  int32_t n_leaves;
+  int32_t n_code;
+  int32_t n_gcols;
+  int32_t n_aggs;
+  int32_t lds_acc;          // 1: stage partial aggregates in LDS, flush once per workgroup; 0: global atomics per row
+  uint32_t lds_lut_bytes;   // bytes of LUT copies at the start of dynamic LDS
+  int32_t need_count;       // 1: some aggregation is COUNT (exact per-slot row counts needed)
+  uint8_t code[FDB_MAX_CODE];
+  FdbLeaf leaves[FDB_MAX_LEAVES];
+  FdbGroupCol gcols[FDB_MAX_DENSE_GCOLS];
+  FdbAgg aggs[FDB_MAX_AGGS];
+};
+
+// Identity elements stored in accumulators. MIN/MAX over float64 run on order-preserving int64 keys
+// (fdb_f64_to_ordered) so one integer atomic serves both types.
+#define FDB_I64_MAX 0x7FFFFFFFFFFFFFFFLL
+#define FDB_I64_MIN (-0x7FFFFFFFFFFFFFFFLL - 1)
+
+static inline int64_t fdb_f64_to_ordered_host(double d) {
+  int64_t b;
+  __builtin_memcpy(&b, &d, 8);
+  return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
+}
+static inline double fdb_ordered_to_f64_host(int64_t k) {
+  int64_t b = k ^ ((k >> 63) & 0x7FFFFFFFFFFFFFFFLL);
+  double d;
+  __builtin_memcpy(&d, &b, 8);
+  return d;
+}
+
+// ---- launch wrappers (fdb_kernels.hip) ---------------------------------------------------------------
+// All launches are asynchronous on `stream`.
+hipError_t fdb_launch_scan_dense(const FdbScanArgs& args, int grid_blocks, size_t lds_bytes, int rows_per_thread,
+                                 hipStream_t stream);
+hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value, int64_t n, hipStream_t stream);
+// dst[map[i]] (op)= src[i] for i < n; op: fdb_agg_func (SUM/COUNT add, MIN/MAX signed 64-bit, f64 SUM when is_f64).
+hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long long* src, const uint32_t* map,
+                                int64_t n, int32_t func, int32_t is_f64, hipStream_t stream);
+// Selection: flags → ascending row indices (wave ballot + prefix sums). Two passes over per-tile counts.
+hipError_t fdb_launch_select(const FdbScanArgs& args, uint32_t* indices_out, unsigned long long* n_selected_out,
+                             uint32_t* tile_counts, hipStream_t stream);
+// Gather for the compacted record of fdb_plan_filter: dst[i] = src[indices[i]] for 4/8-byte values, and
+// validity bits packed from src bitmap.
+hipError_t fdb_launch_gather(const void* src, void* dst, const uint32_t* indices, int64_t n, int elem_bytes,
+                             hipStream_t stream);
+hipError_t fdb_launch_gather_bits(const uint8_t* src_bitmap, uint8_t* dst_bitmap, const uint32_t* indices, int64_t n,
+                                  hipStream_t stream);
+int fdb_scan_default_grid(int device);

@@ -1,0 +1,532 @@
+// fdb_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the fused  PredicateFilter → HashAggregate  scan.
+//
+// Replaces, per batch, the reference's three hot loops:
+//   filter():            roaring bitmap → index ranges → slice + concatenate    (filter.go:276-323)
+//   HashAggregate:       per-row hash + Go map probe + builder append           (aggregate.go:398-486)
+//   Finish reducers:     per-group array reduce                                 (aggregate.go:734-971)
+// with ONE pass over the referenced columns: coalesced 16-byte loads → predicate bit masks in registers →
+// group slot from per-dictionary-entry LUTs (LDS copies) → online SUM/COUNT/MIN/MAX into a per-workgroup
+// LDS table (ds_add_f64 / ds_add_u64 / ds_min_i64 / ds_max_i64) → one flush per workgroup into the global
+// table with global_atomic_*. The path is HBM-bound: no MFMA, no GEMM reshaping.
+//
+// Geometry: 1024-thread workgroups (16 waves share one LDS table, so flush traffic is per-CU-half, not
+// per-wave), persistent grid = 2 workgroups per CU, tiles of 1024 × R rows taken grid-stride so that
+// consecutive workgroups (which land on different XCDs, block b → XCD b % 8) stream disjoint 32-64 KiB
+// spans. Each lane owns R consecutive rows: a uint32 index column is one or two dwordx4 loads per lane,
+// an 8-byte value column R/2 of them, a validity bitmap one byte.
+#include <hip/hip_runtime.h>
+
+#include "fdb_kernels.h"
+
+namespace {
+
+// fdb_op values used on the device (include/frostdb_amd.h)
+constexpr int OP_EQ = 1, OP_NOT_EQ = 2, OP_LT = 3, OP_LT_EQ = 4, OP_GT = 5, OP_GT_EQ = 6;
+constexpr int AGG_SUM = 1, AGG_MIN = 2, AGG_MAX = 3, AGG_COUNT = 4;
+
+__device__ __forceinline__ long long f64_to_ordered(double d) {
+  long long b = __double_as_longlong(d);
+  return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+template <int R>
+__device__ __forceinline__ void load_u32(const uint32_t* __restrict__ p, uint32_t (&v)[R]) {
+#pragma unroll
+  for (int j = 0; j < R / 4; j++) {
+    const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + j);
+    v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void load_u64(const unsigned long long* __restrict__ p, unsigned long long (&v)[R]) {
+#pragma unroll
+  for (int j = 0; j < R / 2; j++) {
+    const u64x2 q = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(p) + j);
+    v[2 * j + 0] = q.x; v[2 * j + 1] = q.y;
+  }
+}
+
+// R validity bits of rows [row0, row0+R); row0 is a multiple of R (R ∈ {4, 8}).
+template <int R>
+__device__ __forceinline__ uint32_t load_valid(const uint8_t* __restrict__ bm, int64_t row0) {
+  const uint32_t b = bm[row0 >> 3];
+  if (R == 8) return b;
+  return (b >> (row0 & 4)) & 0xFu;
+}
+
+template <int R, typename T>
+__device__ __forceinline__ uint32_t cmp_mask(const T (&v)[R], T lit, int op) {
+  uint32_t m = 0;
+  switch (op) {
+    case OP_EQ:
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)(v[r] == lit) << r;
+      break;
+    case OP_NOT_EQ:
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)(v[r] != lit) << r;
+      break;
+    case OP_LT:
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)(v[r] < lit) << r;
+      break;
+    case OP_LT_EQ:
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)(v[r] <= lit) << r;
+      break;
+    case OP_GT:
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)(v[r] > lit) << r;
+      break;
+    case OP_GT_EQ:
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)(v[r] >= lit) << r;
+      break;
+    default: break;
+  }
+  return m;
+}
+
+// One predicate leaf over R rows → R-bit mask (bit r = row0 + r satisfies the leaf). NULL rows never match
+// a value compare (binaryscalarexpr.go:143-150, :175-177, :215-217).
+template <int R>
+__device__ __forceinline__ uint32_t eval_leaf(const FdbLeaf& L, int64_t row0, const unsigned char* smem) {
+  constexpr uint32_t FULL = (1u << R) - 1u;
+  if (L.kind == FDB_LEAF_CONST) return L.op ? FULL : 0u;
+  uint32_t valid = FULL;
+  if (L.validity != nullptr) valid = load_valid<R>(L.validity, row0);
+  if (L.kind == FDB_LEAF_VALIDITY) return L.op ? valid : (~valid & FULL);
+  uint32_t m = 0;
+  if (L.kind == FDB_LEAF_DICT_LUT) {
+    uint32_t idx[R];
+    load_u32<R>(reinterpret_cast<const uint32_t*>(L.values) + row0, idx);
+    if (L.lut_lds != FDB_NO_LDS) {
+      const unsigned char* lut = smem + L.lut_lds;
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)lut[((valid >> r) & 1u) ? idx[r] : 0u] << r;
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)L.lut[((valid >> r) & 1u) ? idx[r] : 0u] << r;
+    }
+  } else {
+    unsigned long long raw[R];
+    load_u64<R>(reinterpret_cast<const unsigned long long*>(L.values) + row0, raw);
+    if (L.kind == FDB_LEAF_CMP_I64) {
+      long long v[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) v[r] = (long long)raw[r];
+      m = cmp_mask<R, long long>(v, (long long)L.lit, L.op);
+    } else if (L.kind == FDB_LEAF_CMP_U64) {
+      m = cmp_mask<R, unsigned long long>(raw, (unsigned long long)L.lit, L.op);
+    } else if (L.kind == FDB_LEAF_CMP_F64) {
+      double v[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) v[r] = __longlong_as_double((long long)raw[r]);
+      m = cmp_mask<R, double>(v, __longlong_as_double(L.lit), L.op);
+    } else {  // FDB_LEAF_CMP_I64_F64
+      double v[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) v[r] = (double)(long long)raw[r];
+      m = cmp_mask<R, double>(v, __longlong_as_double(L.lit), L.op);
+    }
+  }
+  return m & valid;
+}
+
+// Postfix boolean program over leaf masks. The evaluation stack lives in ONE 64-bit register (8 bits per
+// level, depth ≤ 8), so there is no dynamically indexed register array and every branch is wave-uniform.
+template <int R>
+__device__ __forceinline__ uint32_t eval_filter(const FdbScanArgs& a, int64_t row0, const unsigned char* smem) {
+  constexpr uint32_t FULL = (1u << R) - 1u;
+  if (a.n_code == 0) return FULL;
+  unsigned long long st = 0;
+  for (int pc = 0; pc < a.n_code; pc++) {
+    const uint32_t c = a.code[pc];
+    if (c < 0x80u) {
+      st = (st << 8) | (unsigned long long)eval_leaf<R>(a.leaves[c], row0, smem);
+    } else {
+      const unsigned long long top = st & 0xFFull;
+      st >>= 8;
+      if (c == FDB_CODE_AND) st = (st & ~0xFFull) | ((st & 0xFFull) & top);
+      else st = st | top;
+    }
+  }
+  return (uint32_t)(st & FULL);
+}
+
+template <int R>
+__device__ __forceinline__ void group_slots(const FdbScanArgs& a, int64_t row0, const unsigned char* smem, uint32_t (&gid)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) gid[r] = 0;
+  for (int g = 0; g < a.n_gcols; g++) {
+    const FdbGroupCol& G = a.gcols[g];
+    uint32_t valid = (1u << R) - 1u;
+    if (G.validity != nullptr) valid = load_valid<R>(G.validity, row0);
+    uint32_t idx[R];
+    load_u32<R>(G.idx + row0, idx);
+    if (G.lut_lds != FDB_NO_LDS) {
+      const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + G.lut_lds);
+#pragma unroll
+      for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? lut[idx[r]] : 0u) * G.stride;
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? G.lut[idx[r]] : 0u) * G.stride;
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long agg_identity(int func, int type) {
+  if (func == AGG_MIN) return (unsigned long long)FDB_I64_MAX;
+  if (func == AGG_MAX) return (unsigned long long)FDB_I64_MIN;
+  return 0ull;  // SUM/COUNT: integer 0 and +0.0 share the all-zero pattern
+}
+
+// Fused scan. LDS = true: partial aggregates staged in the workgroup's LDS table and flushed once.
+template <int R, bool LDS>
+__global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr uint32_t FULL = (1u << R) - 1u;
+  const int tid = threadIdx.x;
+  const uint32_t n_slots = a.n_slots;
+
+  // ---- stage the per-dictionary LUTs in LDS ----------------------------------------------------------
+  for (int l = 0; l < a.n_leaves; l++) {
+    const FdbLeaf& L = a.leaves[l];
+    if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
+      for (uint32_t i = tid; i < L.lut_len; i += FDB_BLOCK) smem[L.lut_lds + i] = L.lut[i];
+  }
+  for (int g = 0; g < a.n_gcols; g++) {
+    const FdbGroupCol& G = a.gcols[g];
+    if (G.lut_lds != FDB_NO_LDS) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(smem + G.lut_lds);
+      for (uint32_t i = tid; i < G.lut_len; i += FDB_BLOCK) dst[i] = G.lut[i];
+    }
+  }
+  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(smem + a.lds_lut_bytes);
+  unsigned long long* l_acc =
+      reinterpret_cast<unsigned long long*>(smem + a.lds_lut_bytes + (((size_t)n_slots * 4 + 15) & ~(size_t)15));
+  if (LDS) {
+    for (uint32_t i = tid; i < n_slots; i += FDB_BLOCK) l_cnt[i] = 0;
+    for (int j = 0; j < a.n_aggs; j++) {
+      const unsigned long long ident = agg_identity(a.aggs[j].func, a.aggs[j].type);
+      for (uint32_t i = tid; i < n_slots; i += FDB_BLOCK) l_acc[(size_t)j * n_slots + i] = ident;
+    }
+  }
+  __syncthreads();
+
+  const int64_t tile_rows = (int64_t)FDB_BLOCK * R;
+  const int64_t n_tiles = (a.n_rows + tile_rows - 1) / tile_rows;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * tile_rows + (int64_t)tid * R;
+    uint32_t sel = 0;
+    if (row0 < a.n_rows) {
+      const int64_t left = a.n_rows - row0;
+      const uint32_t in_range = left >= R ? FULL : ((1u << (int)left) - 1u);
+      sel = eval_filter<R>(a, row0, smem) & in_range;
+    }
+    if (__ballot(sel != 0) == 0ull) continue;  // whole wave filtered out: skip the group/value columns
+    if (row0 >= a.n_rows) continue;            // (lanes past the end hold sel == 0; keep their loads in bounds)
+
+    uint32_t gid[R];
+    group_slots<R>(a, row0, smem, gid);
+
+    // occupancy / COUNT
+    if (LDS) {
+      if (a.need_count) {
+#pragma unroll
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&l_cnt[gid[r]], 1u);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) l_cnt[gid[r]] = 1u;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&a.cnt[gid[r]], 1ull);
+    }
+
+    for (int j = 0; j < a.n_aggs; j++) {
+      const FdbAgg& A = a.aggs[j];
+      if (A.func == AGG_COUNT) continue;  // served by the row count above (CountAggregation counts NULLs too)
+      uint32_t valid = FULL;
+      if (A.validity != nullptr) valid = load_valid<R>(A.validity, row0);
+      unsigned long long raw[R];
+      load_u64<R>(reinterpret_cast<const unsigned long long*>(A.values) + row0, raw);
+      // A NULL contributes the builder's zeroed slot: 0 to SUM *and* to MIN/MAX (aggregate.go:784-935 read raw
+      // values; pqarrow/builder/optbuilders.go:337-340 zero-fills).
+#pragma unroll
+      for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = 0ull;
+      unsigned long long* acc = LDS ? (l_acc + (size_t)j * n_slots) : A.acc;
+      if (A.func == AGG_SUM) {
+        if (A.type == FDB_T_F64) {
+#pragma unroll
+          for (int r = 0; r < R; r++)
+            if ((sel >> r) & 1u) atomicAdd(reinterpret_cast<double*>(acc) + gid[r], __longlong_as_double((long long)raw[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(acc + gid[r], raw[r]);
+        }
+      } else {
+        long long key[R];
+        if (A.type == FDB_T_F64) {
+#pragma unroll
+          for (int r = 0; r < R; r++) key[r] = f64_to_ordered(__longlong_as_double((long long)raw[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) key[r] = (long long)raw[r];
+        }
+        if (A.func == AGG_MIN) {
+#pragma unroll
+          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicMin(reinterpret_cast<long long*>(acc) + gid[r], key[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicMax(reinterpret_cast<long long*>(acc) + gid[r], key[r]);
+        }
+      }
+    }
+  }
+
+  if (LDS) {
+    __syncthreads();
+    for (uint32_t i = tid; i < n_slots; i += FDB_BLOCK) {
+      const uint32_t c = l_cnt[i];
+      if (c == 0) continue;
+      atomicAdd(&a.cnt[i], (unsigned long long)c);
+      for (int j = 0; j < a.n_aggs; j++) {
+        const FdbAgg& A = a.aggs[j];
+        if (A.func == AGG_COUNT) continue;
+        const unsigned long long v = l_acc[(size_t)j * n_slots + i];
+        if (A.func == AGG_SUM) {
+          if (A.type == FDB_T_F64) atomicAdd(reinterpret_cast<double*>(A.acc) + i, __longlong_as_double((long long)v));
+          else atomicAdd(A.acc + i, v);
+        } else if (A.func == AGG_MIN) {
+          atomicMin(reinterpret_cast<long long*>(A.acc) + i, (long long)v);
+        } else {
+          atomicMax(reinterpret_cast<long long*>(A.acc) + i, (long long)v);
+        }
+      }
+    }
+  }
+}
+
+__global__ void fill_u64_kernel(unsigned long long* dst, unsigned long long value, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = value;
+}
+
+__global__ void merge_u64_kernel(unsigned long long* dst, const unsigned long long* src, const uint32_t* map, int64_t n,
+                                 int32_t func, int32_t is_f64) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t d = map ? map[i] : (uint32_t)i;
+    if (d == 0xFFFFFFFFu) continue;
+    const unsigned long long v = src[i];
+    if (func == AGG_SUM || func == AGG_COUNT) {
+      if (is_f64) atomicAdd(reinterpret_cast<double*>(dst) + d, __longlong_as_double((long long)v));
+      else atomicAdd(dst + d, v);
+    } else if (func == AGG_MIN) {
+      atomicMin(reinterpret_cast<long long*>(dst) + d, (long long)v);
+    } else {
+      atomicMax(reinterpret_cast<long long*>(dst) + d, (long long)v);
+    }
+  }
+}
+
+// ---- selection vector (≙ bitmap.ToArray() of filter.go:286, built on the device) ---------------------------
+// Pass 1: evaluate the predicate, keep each lane's 8-row mask byte, count selected rows per tile.
+__global__ __launch_bounds__(FDB_BLOCK) void select_flags_kernel(const FdbScanArgs a, uint8_t* masks, uint32_t* tile_counts) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int R = 8;
+  const int tid = threadIdx.x;
+  for (int l = 0; l < a.n_leaves; l++) {
+    const FdbLeaf& L = a.leaves[l];
+    if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
+      for (uint32_t i = tid; i < L.lut_len; i += FDB_BLOCK) smem[L.lut_lds + i] = L.lut[i];
+  }
+  __shared__ uint32_t wave_cnt[FDB_BLOCK / 64];
+  __syncthreads();
+  const int64_t tile_rows = (int64_t)FDB_BLOCK * R;
+  const int64_t n_tiles = (a.n_rows + tile_rows - 1) / tile_rows;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * tile_rows + (int64_t)tid * R;
+    uint32_t sel = 0;
+    if (row0 < a.n_rows) {
+      const int64_t left = a.n_rows - row0;
+      const uint32_t in_range = left >= R ? 0xFFu : ((1u << (int)left) - 1u);
+      sel = eval_filter<R>(a, row0, smem) & in_range;
+      masks[row0 >> 3] = (uint8_t)sel;
+    }
+    // wave total via ballot-free popcount reduction: DPP row reductions are what __reduce would emit; keep it simple
+    uint32_t c = __popc(sel);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((tid & 63) == 0) wave_cnt[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < FDB_BLOCK / 64; w++) t += wave_cnt[w];
+      tile_counts[tile] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// Pass 2: exclusive scan of the per-tile counts (one workgroup; n_tiles is rows / 8192).
+__global__ __launch_bounds__(FDB_BLOCK) void scan_counts_kernel(uint32_t* tile_counts, int64_t n_tiles, unsigned long long* total) {
+  __shared__ unsigned long long part[FDB_BLOCK];
+  const int tid = threadIdx.x;
+  const int64_t per = (n_tiles + FDB_BLOCK - 1) / FDB_BLOCK;
+  const int64_t lo = (int64_t)tid * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  unsigned long long s = 0;
+  for (int64_t i = lo; i < hi; i++) s += tile_counts[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (int i = 0; i < FDB_BLOCK; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+    *total = run;
+  }
+  __syncthreads();
+  unsigned long long run = part[tid];
+  for (int64_t i = lo; i < hi; i++) { const uint32_t v = tile_counts[i]; tile_counts[i] = (uint32_t)run; run += v; }
+}
+
+// Pass 3: wave prefix sums of per-lane popcounts place every selected row: ascending indices, no atomics.
+__global__ __launch_bounds__(FDB_BLOCK) void select_write_kernel(const uint8_t* masks, const uint32_t* tile_offsets, int64_t n_rows,
+                                                                 uint32_t* indices) {
+  constexpr int R = 8;
+  __shared__ uint32_t wave_base[FDB_BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tile_rows = (int64_t)FDB_BLOCK * R;
+  const int64_t n_tiles = (n_rows + tile_rows - 1) / tile_rows;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * tile_rows + (int64_t)tid * R;
+    const uint32_t sel = row0 < n_rows ? masks[row0 >> 3] : 0u;
+    const uint32_t c = __popc(sel);
+    uint32_t incl = c;  // inclusive wave scan
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_base[wave] = incl;
+    __syncthreads();
+    uint32_t base = tile_offsets[tile];
+    for (int w = 0; w < wave; w++) base += wave_base[w];
+    uint32_t pos = base + incl - c;
+    uint32_t m = sel;
+    while (m) {
+      const int r = __ffs(m) - 1;
+      m &= m - 1;
+      indices[pos++] = (uint32_t)(row0 + r);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ void gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const uint32_t* __restrict__ idx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
+// Output validity bitmap: one lane per output row, ballot packs 64 rows into one 8-byte word.
+__global__ void gather_bits_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint32_t* __restrict__ idx, int64_t n) {
+  const int64_t n_round = (n + 63) & ~(int64_t)63;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * blockDim.x) {
+    bool bit = false;
+    if (i < n) { const uint32_t s = idx[i]; bit = (src[s >> 3] >> (s & 7)) & 1; }
+    const unsigned long long word = __ballot(bit);
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long*>(dst)[i >> 6] = word;
+  }
+}
+
+int g_cu_count[16] = {0};
+
+}  // namespace
+
+int fdb_scan_default_grid(int device) {
+  if (device < 0 || device >= 16) device = 0;
+  if (g_cu_count[device] == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 512;
+    g_cu_count[device] = prop.multiProcessorCount;
+  }
+  return 2 * g_cu_count[device];
+}
+
+hipError_t fdb_launch_scan_dense(const FdbScanArgs& args, int grid_blocks, size_t lds_bytes, int rows_per_thread, hipStream_t stream) {
+  const int64_t tile_rows = (int64_t)FDB_BLOCK * rows_per_thread;
+  const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
+  if (n_tiles == 0) return hipSuccess;
+  if (grid_blocks > n_tiles) grid_blocks = (int)n_tiles;
+  dim3 grid(grid_blocks), block(FDB_BLOCK);
+  if (rows_per_thread == 8) {
+    if (args.lds_acc) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_dense_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((scan_dense_kernel<8, true>), grid, block, lds_bytes, stream, args);
+    } else {
+      hipLaunchKernelGGL((scan_dense_kernel<8, false>), grid, block, lds_bytes, stream, args);
+    }
+  } else {
+    if (args.lds_acc) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_dense_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((scan_dense_kernel<4, true>), grid, block, lds_bytes, stream, args);
+    } else {
+      hipLaunchKernelGGL((scan_dense_kernel<4, false>), grid, block, lds_bytes, stream, args);
+    }
+  }
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(blocks), dim3(256), 0, stream, dst, value, n);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long long* src, const uint32_t* map, int64_t n, int32_t func,
+                                int32_t is_f64, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(merge_u64_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, map, n, func, is_f64);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_select(const FdbScanArgs& args, uint32_t* indices_out, unsigned long long* n_selected_out, uint32_t* tile_counts,
+                             hipStream_t stream) {
+  // `tile_counts` doubles as scratch: [n_tiles counts][mask bytes]
+  const int64_t tile_rows = (int64_t)FDB_BLOCK * 8;
+  const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
+  if (n_tiles == 0) return hipMemsetAsync(n_selected_out, 0, 8, stream);
+  uint8_t* masks = reinterpret_cast<uint8_t*>(tile_counts + ((n_tiles + 3) & ~(int64_t)3));
+  int grid = 512;
+  if (grid > n_tiles) grid = (int)n_tiles;
+  hipLaunchKernelGGL(select_flags_kernel, dim3(grid), dim3(FDB_BLOCK), args.lds_lut_bytes, stream, args, masks, tile_counts);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, tile_counts, n_tiles, n_selected_out);
+  hipLaunchKernelGGL(select_write_kernel, dim3(grid), dim3(FDB_BLOCK), 0, stream, masks, tile_counts, args.n_rows, indices_out);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_gather(const void* src, void* dst, const uint32_t* indices, int64_t n, int elem_bytes, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((gather_kernel<uint32_t>), dim3(blocks), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, indices, n);
+  else
+    hipLaunchKernelGGL((gather_kernel<unsigned long long>), dim3(blocks), dim3(256), 0, stream, (const unsigned long long*)src,
+                       (unsigned long long*)dst, indices, n);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_gather_bits(const uint8_t* src_bitmap, uint8_t* dst_bitmap, const uint32_t* indices, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gather_bits_kernel, dim3(blocks), dim3(256), 0, stream, src_bitmap, dst_bitmap, indices, n);
+  return hipGetLastError();
+}

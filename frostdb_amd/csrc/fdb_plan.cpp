@@ -1,0 +1,976 @@
+// fdb_plan.cpp — host side of the fused PredicateFilter → HashAggregate chain (see fdb_plan.h).
+//
+// Per batch the host does only per-DICTIONARY-ENTRY work (predicate LUTs, group-key id LUTs) and argument
+// marshalling; every per-ROW operation runs in fdb_kernels.hip. Reference behaviour mirrored here:
+//   * column lookup by exact name, every batch                 aggregate.go:286-361, binaryscalarexpr.go:22-29
+//   * missing-column predicate rules                           binaryscalarexpr.go:47-73, regexpfilter.go:23-33
+//   * dictionary ==/!=, NULL literal ⇒ IS [NOT] NULL           binaryscalarexpr.go:154-232
+//   * contains / regex evaluated on dictionary values          binaryscalarexpr.go:271-311, regexpfilter.go:142-166
+//   * group identity: NULL ≡ column absent, first-seen order   aggregate.go:398-409, :492-525, :568-575
+//   * result naming and schema                                 aggregate.go:47, :543-633
+#include "fdb_plan.h"
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+
+namespace fdb {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw Error(e == hipErrorOutOfMemory ? FDB_ERR_OOM : FDB_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t kTailPad = 256;  // bytes readable past every column so tail lanes may over-read
+
+const char* op_str(int32_t op) {  // logicalplan/expr.go:37-72
+  switch (op) {
+    case FDB_OP_EQ: return "=="; case FDB_OP_NOT_EQ: return "!="; case FDB_OP_LT: return "<"; case FDB_OP_LT_EQ: return "<=";
+    case FDB_OP_GT: return ">"; case FDB_OP_GT_EQ: return ">="; case FDB_OP_REGEX_MATCH: return "=~";
+    case FDB_OP_REGEX_NOT_MATCH: return "!~"; case FDB_OP_AND: return "&&"; case FDB_OP_OR: return "||";
+    case FDB_OP_CONTAINS: return "contains"; case FDB_OP_NOT_CONTAINS: return "not contains";
+  }
+  return "?";
+}
+
+const char* agg_name(int32_t f) {  // logicalplan/expr.go:731-750
+  switch (f) {
+    case FDB_AGG_SUM: return "sum"; case FDB_AGG_MIN: return "min"; case FDB_AGG_MAX: return "max"; case FDB_AGG_COUNT: return "count";
+    case FDB_AGG_AVG: return "avg"; case FDB_AGG_UNIQUE: return "unique"; case FDB_AGG_AND: return "and";
+  }
+  return "unknown";
+}
+
+bool is_leaf_op(int32_t op) {
+  return (op >= FDB_OP_EQ && op <= FDB_OP_REGEX_NOT_MATCH) || op == FDB_OP_CONTAINS || op == FDB_OP_NOT_CONTAINS;
+}
+
+bool match_group(const GroupMatcher& m, const std::string& field) {  // logicalplan/expr.go:353-355, :564-566
+  if (m.dynamic) return field.size() > m.name.size() && field.compare(0, m.name.size(), m.name) == 0 && field[m.name.size()] == '.';
+  return field == m.name;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// Pinned-host + device scratch. Small per-batch tables (LUTs, slot maps) are packed into one pinned block
+// and shipped with ONE hipMemcpyAsync; the pool is recycled whenever the stream has been synchronised.
+// ---------------------------------------------------------------------------------------------------------
+class BumpPool {
+ public:
+  explicit BumpPool(hipStream_t s) : stream_(s) {}
+  ~BumpPool() { release(); }
+  // two-step API used by Plan::upload
+  void* stage(const void* host, size_t payload) {
+    const size_t bytes = align_up(payload ? payload : 1, 256);
+    if (off_ + bytes > cap_) grow(bytes);
+    if (payload) std::memcpy(h_ + off_, host, payload);
+    void* dst = d_ + off_;
+    hip_check(hipMemcpyAsync(dst, h_ + off_, bytes, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(LUT upload)");
+    off_ += bytes;
+    return dst;
+  }
+  void reset() { off_ = 0; }  // caller guarantees the stream is idle
+ private:
+  void grow(size_t need) {
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(pool)");
+    if (need <= cap_) { off_ = 0; return; }
+    release();
+    cap_ = std::max<size_t>(align_up(need * 2, 1 << 20), 1 << 20);
+    hip_check(hipHostMalloc((void**)&h_, cap_, hipHostMallocDefault), "hipHostMalloc(pool)");
+    hip_check(hipMalloc((void**)&d_, cap_), "hipMalloc(pool)");
+    off_ = 0;
+  }
+  void release() {
+    if (h_) (void)hipHostFree(h_);
+    if (d_) (void)hipFree(d_);
+    h_ = nullptr; d_ = nullptr; cap_ = 0; off_ = 0;
+  }
+  hipStream_t stream_;
+  unsigned char* h_ = nullptr;
+  unsigned char* d_ = nullptr;
+  size_t cap_ = 0, off_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// DeviceBatch
+// ---------------------------------------------------------------------------------------------------------
+DeviceBatch::~DeviceBatch() {
+  if (arena) {
+    (void)hipSetDevice(device);
+    (void)hipFree(arena);
+  }
+}
+
+int DeviceBatch::find(const std::string& name) const {
+  int found = -1;
+  for (size_t i = 0; i < cols.size(); i++)
+    if (cols[i].name == name) { if (found >= 0) return -1; found = (int)i; }
+  return found;
+}
+
+std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device, const std::function<bool(const std::string&)>* want,
+                                          hipStream_t stream) {
+  std::unique_ptr<DeviceBatch> b(new DeviceBatch());
+  b->device = device;
+  b->rows = view.rows;
+  hip_check(hipSetDevice(device), "hipSetDevice");
+  // plan the arena
+  struct Piece { size_t col; bool validity; size_t off; size_t bytes; };
+  std::vector<Piece> pieces;
+  size_t total = 0;
+  for (size_t i = 0; i < view.cols.size(); i++) {
+    const HostColView& c = view.cols[i];
+    DevColumn d;
+    d.name = c.name; d.format = c.format; d.kind = c.kind; d.length = c.length; d.null_count = c.null_count;
+    const bool staged = (want == nullptr || (*want)(c.name));
+    if (staged) {
+      int64_t vb = 0;
+      if (c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64) vb = c.length * 8;
+      else if (c.kind == ColKind::DICT) vb = c.length * 4;
+      if (vb > 0 || ((c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::DICT))) {
+        d.value_bytes = vb;
+        pieces.push_back(Piece{i, false, total, (size_t)vb});
+        total += align_up((size_t)vb + kTailPad, 256);
+        if (c.null_count > 0) {
+          d.validity_bytes = (c.length + 7) / 8;
+          pieces.push_back(Piece{i, true, total, (size_t)d.validity_bytes});
+          total += align_up((size_t)d.validity_bytes + kTailPad, 256);
+        }
+      }
+      if (c.kind == ColKind::DICT) d.dict = read_dictionary(c);
+    } else {
+      d.kind = c.kind;  // present but not staged: d_values stays nullptr
+    }
+    b->cols.push_back(std::move(d));
+  }
+  if (total > 0) {
+    hip_check(hipMalloc(&b->arena, total), "hipMalloc(batch arena)");
+    b->arena_bytes = total;
+  }
+  std::vector<uint8_t> tmp;
+  for (const Piece& p : pieces) {
+    const HostColView& c = view.cols[p.col];
+    DevColumn& d = b->cols[p.col];
+    unsigned char* dst = (unsigned char*)b->arena + p.off;
+    if (p.validity) {
+      d.d_validity = dst;
+      if (p.bytes == 0) continue;
+      tmp.assign(p.bytes, 0);
+      copy_bits(c.validity, c.offset, c.length, tmp.data());
+      hip_check(hipMemcpy(dst, tmp.data(), p.bytes, hipMemcpyHostToDevice), "hipMemcpy(validity)");
+    } else {
+      d.d_values = dst;
+      if (p.bytes == 0) continue;
+      if (c.kind == ColKind::DICT && c.index_width != 4) {
+        std::vector<uint32_t> wide((size_t)c.length);
+        for (int64_t i = 0; i < c.length; i++) {
+          switch (c.index_width) {
+            case 1: wide[(size_t)i] = ((const uint8_t*)c.values)[c.offset + i]; break;
+            case 2: wide[(size_t)i] = ((const uint16_t*)c.values)[c.offset + i]; break;
+            default: wide[(size_t)i] = (uint32_t)((const uint64_t*)c.values)[c.offset + i]; break;
+          }
+        }
+        hip_check(hipMemcpy(dst, wide.data(), p.bytes, hipMemcpyHostToDevice), "hipMemcpy(indices)");
+      } else {
+        const size_t w = c.kind == ColKind::DICT ? 4 : 8;
+        hip_check(hipMemcpy(dst, (const unsigned char*)c.values + (size_t)c.offset * w, p.bytes, hipMemcpyHostToDevice), "hipMemcpy(values)");
+      }
+    }
+  }
+  for (const DevColumn& d : b->cols) b->payload_bytes += d.value_bytes + d.validity_bytes;
+  (void)stream;
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Plan
+// ---------------------------------------------------------------------------------------------------------
+std::string Literal::str() const {
+  switch (type) {
+    case FDB_LIT_NULL: return "null";
+    case FDB_LIT_INT64: return std::to_string(i64);
+    case FDB_LIT_UINT64: return std::to_string(u64);
+    case FDB_LIT_FLOAT64: return std::to_string(f64);
+    case FDB_LIT_BOOL: return i64 ? "true" : "false";
+    default: return bytes;
+  }
+}
+
+Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
+  if (d == nullptr) throw Error(FDB_ERR_INVALID, "null plan descriptor");
+  for (int32_t i = 0; i < d->n_filter; i++) {
+    const fdb_expr& fe = d->filter[i];
+    ExprNode e;
+    e.op = fe.op; e.left = fe.left; e.right = fe.right;
+    if (fe.column) e.column = fe.column;
+    e.lit.type = fe.literal.type; e.lit.i64 = fe.literal.i64; e.lit.u64 = fe.literal.u64; e.lit.f64 = fe.literal.f64;
+    if (fe.literal.data && fe.literal.len > 0) e.lit.bytes.assign(fe.literal.data, (size_t)fe.literal.len);
+    if (e.op == FDB_OP_AND || e.op == FDB_OP_OR) {
+      if (e.left < 0 || e.left >= d->n_filter || e.right < 0 || e.right >= d->n_filter) throw Error(FDB_ERR_INVALID, "filter child index out of range");
+    } else if (is_leaf_op(e.op)) {
+      if (e.column.empty()) throw Error(FDB_ERR_INVALID, "left side of binary expression must be a column");  // filter.go:91-93
+      if (e.op == FDB_OP_REGEX_MATCH || e.op == FDB_OP_REGEX_NOT_MATCH) {
+        if (e.lit.type != FDB_LIT_STRING && e.lit.type != FDB_LIT_BINARY) throw Error(FDB_ERR_INVALID, "regex literal must be a string");
+        try { e.re = std::make_shared<std::regex>(e.lit.bytes, std::regex::ECMAScript); }  // filter.go:105-124 compiles once per query
+        catch (const std::regex_error& ex) { throw Error(FDB_ERR_INVALID, std::string("regexp compile: ") + ex.what()); }
+      }
+    } else {
+      throw Error(FDB_ERR_UNSUPPORTED, std::string("binary expr ") + op_str(e.op) + ": unsupported boolean expression");  // filter.go:162-164
+    }
+    filter_.push_back(std::move(e));
+  }
+  filter_root_ = d->n_filter > 0 ? d->filter_root : -1;
+  if (d->n_filter > 0 && (filter_root_ < 0 || filter_root_ >= d->n_filter)) throw Error(FDB_ERR_INVALID, "filter_root out of range");
+  final_stage_ = d->final_stage != 0;
+  if (d->n_aggs > FDB_MAX_AGGS) throw Error(FDB_ERR_UNSUPPORTED, "too many aggregations");
+  for (int32_t i = 0; i < d->n_aggs; i++) {
+    AggState a;
+    a.func = d->aggs[i].func;
+    if (d->aggs[i].column == nullptr) throw Error(FDB_ERR_INVALID, "aggregation without a column");
+    a.column = d->aggs[i].column;
+    if (a.func != FDB_AGG_SUM && a.func != FDB_AGG_MIN && a.func != FDB_AGG_MAX && a.func != FDB_AGG_COUNT)
+      throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported aggregation function: ") + agg_name(a.func));  // aggregate.go:98-100
+    a.result_name = std::string(agg_name(a.func)) + "(" + a.column + ")";
+    aggs_.push_back(std::move(a));
+  }
+  for (int32_t i = 0; i < d->n_groups; i++) {
+    if (d->groups[i].name == nullptr) throw Error(FDB_ERR_INVALID, "group expression without a name");
+    matchers_.push_back(GroupMatcher{d->groups[i].name, d->groups[i].dynamic != 0});
+  }
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+  pool_.reset(new BumpPool(stream_));
+}
+
+Plan::~Plan() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  pool_.reset();
+  for (auto& a : aggs_) if (a.d_acc) (void)hipFree(a.d_acc);
+  if (d_cnt_) (void)hipFree(d_cnt_);
+  for (auto& p : pending_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  for (auto e : free_events_) (void)hipEventDestroy(e);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+bool Plan::references(const std::string& column) const {
+  for (const ExprNode& e : filter_) if (is_leaf_op(e.op) && e.column == column) return true;
+  for (const AggState& a : aggs_) if ((final_stage_ ? a.result_name : a.column) == column) return true;
+  for (const GroupMatcher& m : matchers_) if (match_group(m, column)) return true;
+  return false;
+}
+
+void Plan::sync() {
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  collect_timing();
+  pool_->reset();
+}
+
+void Plan::collect_timing() {
+  for (auto& p : pending_events_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) stat_ms += ms;
+    free_events_.push_back(p.first);
+    free_events_.push_back(p.second);
+  }
+  pending_events_.clear();
+}
+
+void* Plan::upload(const void* host, size_t bytes) { return pool_->stage(host, bytes); }
+
+const char* Plan::draw() {
+  if (draw_.empty()) {
+    std::function<std::string(int)> show = [&](int i) -> std::string {
+      const ExprNode& e = filter_[(size_t)i];
+      if (e.op == FDB_OP_AND) return "(" + show(e.left) + " AND " + show(e.right) + ")";  // filter.go:192-194
+      if (e.op == FDB_OP_OR) return "(" + show(e.left) + " OR " + show(e.right) + ")";
+      if (e.op == FDB_OP_REGEX_MATCH) return e.column + " =~ \"" + e.lit.bytes + "\"";     // regexpfilter.go:41-46
+      if (e.op == FDB_OP_REGEX_NOT_MATCH) return e.column + " !~ \"" + e.lit.bytes + "\"";
+      return e.column + " " + op_str(e.op) + " " + e.lit.str();                            // binaryscalarexpr.go:78-80
+    };
+    std::string s;
+    if (filter_root_ >= 0) s += "PredicateFilter (" + show(filter_root_) + ")";
+    if (!aggs_.empty()) {
+      if (!s.empty()) s += " - ";
+      s += "HashAggregate (";
+      for (size_t i = 0; i < aggs_.size(); i++) s += (i ? "," : "") + aggs_[i].result_name;
+      s += " by ";
+      for (size_t i = 0; i < matchers_.size(); i++) s += (i ? "," : "") + matchers_[i].name;
+      s += ")";
+    }
+    draw_ = s + " [gfx950]";
+  }
+  return draw_.c_str();
+}
+
+// ---- filter resolution ---------------------------------------------------------------------------------
+namespace {
+
+struct Blob {  // LUTs of one batch, shipped with one copy
+  std::vector<uint8_t> bytes;
+  size_t add(const void* p, size_t n) {
+    const size_t off = align_up(bytes.size(), 16);
+    bytes.resize(off + std::max<size_t>(n, 1), 0);
+    if (n) std::memcpy(bytes.data() + off, p, n);
+    return off;
+  }
+};
+
+struct PendingLut { int kind; int index; size_t blob_off; size_t len_bytes; };  // kind 0: leaf, 1: group col
+
+// The per-entry predicate of a dictionary leaf.
+std::vector<uint8_t> dict_pred_lut(const ExprNode& e, const HostDict& dict) {
+  std::vector<uint8_t> lut(std::max<size_t>(dict.values.size(), 1), 0);
+  for (size_t i = 0; i < dict.values.size(); i++) {
+    const std::string& v = dict.values[i];
+    bool m = false;
+    switch (e.op) {
+      case FDB_OP_EQ: m = (v == e.lit.bytes); break;          // non string/binary literals compare against "" (binaryscalarexpr.go:196-202)
+      case FDB_OP_NOT_EQ: m = (v != e.lit.bytes); break;
+      case FDB_OP_CONTAINS: m = v.find(e.lit.bytes) != std::string::npos; break;
+      case FDB_OP_NOT_CONTAINS: m = v.find(e.lit.bytes) == std::string::npos; break;
+      case FDB_OP_REGEX_MATCH: m = std::regex_search(v, *e.re); break;
+      case FDB_OP_REGEX_NOT_MATCH: m = !std::regex_search(v, *e.re); break;
+    }
+    lut[i] = m ? 1 : 0;
+  }
+  return lut;
+}
+
+}  // namespace
+
+struct Plan::Resolved {
+  FdbScanArgs args;
+  Blob blob;
+  std::vector<PendingLut> luts;
+  std::vector<char> counted;  // per batch column: already counted in algorithmic bytes
+  int64_t bytes = 0;
+  void count(const DeviceBatch& b, int ci) {
+    if (counted.empty()) counted.assign(b.cols.size(), 0);
+    if (counted[(size_t)ci]) return;
+    counted[(size_t)ci] = 1;
+    bytes += b.cols[(size_t)ci].value_bytes + b.cols[(size_t)ci].validity_bytes;
+  }
+};
+
+static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved* R, FdbLeaf* L);
+
+static void emit_filter(const std::vector<ExprNode>& nodes, int idx, const DeviceBatch& b, Plan::Resolved* R, int depth, int* max_depth) {
+  const ExprNode& e = nodes[(size_t)idx];
+  FdbScanArgs& a = R->args;
+  if (e.op == FDB_OP_AND || e.op == FDB_OP_OR) {
+    emit_filter(nodes, e.left, b, R, depth, max_depth);
+    emit_filter(nodes, e.right, b, R, depth + 1, max_depth);
+    if (a.n_code >= FDB_MAX_CODE) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too large");
+    a.code[a.n_code++] = e.op == FDB_OP_AND ? FDB_CODE_AND : FDB_CODE_OR;
+    return;
+  }
+  if (a.n_leaves >= FDB_MAX_LEAVES || a.n_code >= FDB_MAX_CODE) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too large");
+  if (depth + 1 > *max_depth) *max_depth = depth + 1;
+  if (*max_depth > 8) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too deep");
+  FdbLeaf L;
+  std::memset(&L, 0, sizeof(L));
+  L.lut_lds = FDB_NO_LDS;
+  R->luts.reserve(64);
+  const int li = a.n_leaves;
+  a.leaves[li] = L;
+  // resolve (may append a LUT that refers to leaf index li)
+  a.n_leaves++;
+  resolve_leaf(e, b, R, &a.leaves[li]);
+  a.code[a.n_code++] = (uint8_t)li;
+}
+
+static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved* R, FdbLeaf* L) {
+  const int li = (int)(L - R->args.leaves);
+  const bool is_regex = e.op == FDB_OP_REGEX_MATCH || e.op == FDB_OP_REGEX_NOT_MATCH;
+  const int ci = b.find(e.column);
+  auto set_const = [&](bool v) { L->kind = FDB_LEAF_CONST; L->op = v ? 1 : 0; };
+  if (ci < 0) {
+    if (is_regex) {  // regexpfilter.go:23-33
+      const bool empty_match = std::regex_search(std::string(), *e.re);
+      const bool neg = e.op == FDB_OP_REGEX_NOT_MATCH;
+      set_const((neg && !empty_match) || (!neg && empty_match));
+      return;
+    }
+    switch (e.op) {  // binaryscalarexpr.go:47-73
+      case FDB_OP_EQ:
+        if (e.lit.valid() && (e.lit.type == FDB_LIT_STRING || e.lit.type == FDB_LIT_BINARY) && !e.lit.bytes.empty()) { set_const(false); return; }
+        break;
+      case FDB_OP_NOT_EQ:
+        if (!e.lit.valid()) { set_const(false); return; }
+        break;
+      case FDB_OP_LT: case FDB_OP_LT_EQ: case FDB_OP_GT: case FDB_OP_GT_EQ:
+        set_const(false);
+        return;
+    }
+    set_const(true);
+    return;
+  }
+  const DevColumn& c = b.cols[(size_t)ci];
+  const bool is_contains = e.op == FDB_OP_CONTAINS || e.op == FDB_OP_NOT_CONTAINS;
+  if (c.kind == ColKind::DICT) {
+    if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
+    if (is_regex && c.dict->utf8())  // regexpfilter.go:55-61: only *array.Binary dictionaries
+      throw Error(FDB_ERR_UNSUPPORTED, "ArrayScalarRegexMatch: unsupported dictionary type: *array.String");
+    if (!is_regex && !is_contains && e.op != FDB_OP_EQ && e.op != FDB_OP_NOT_EQ)
+      throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported operator: ") + op_str(e.op));  // binaryscalarexpr.go:106-108
+    R->count(b, ci);
+    L->values = c.d_values;
+    L->validity = c.d_validity;
+    if (!is_regex && !e.lit.valid()) {
+      // == NULL ⇒ IS NULL, != NULL ⇒ IS NOT NULL (:165-172, :205-212); contains/not-contains NULL ⇒ every non-null row (:287-295)
+      L->kind = FDB_LEAF_VALIDITY;
+      L->op = (e.op == FDB_OP_EQ) ? 0 : 1;
+      // the index buffer is not read by this leaf: only the bitmap counts
+      return;
+    }
+    std::vector<uint8_t> lut = dict_pred_lut(e, *c.dict);
+    L->kind = FDB_LEAF_DICT_LUT;
+    L->lut_len = (uint32_t)lut.size();
+    const size_t off = R->blob.add(lut.data(), lut.size());
+    R->luts.push_back(PendingLut{0, li, off, lut.size()});
+    return;
+  }
+  if (is_regex) throw Error(FDB_ERR_UNSUPPORTED, "ArrayScalarRegexMatch: unsupported type on the device path: " + c.format);
+  if (is_contains) throw Error(FDB_ERR_UNSUPPORTED, "contains on a non-dictionary column is not supported on the device path: " + c.name);
+  if (!(e.op >= FDB_OP_EQ && e.op <= FDB_OP_GT_EQ)) throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation");
+  if (c.kind != ColKind::I64 && c.kind != ColKind::U64 && c.kind != ColKind::F64)
+    throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation: compare on column type " + c.format + " (" + c.name + ")");
+  if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
+  if (!e.lit.valid()) { set_const(false); return; }  // compare with a NULL scalar yields NULL for every row (binaryscalarexpr.go:143-146)
+  R->count(b, ci);
+  L->values = c.d_values;
+  L->validity = c.d_validity;
+  L->op = e.op;
+  auto dbits = [](double d) { int64_t v; std::memcpy(&v, &d, 8); return v; };
+  if (c.kind == ColKind::I64) {
+    if (e.lit.type == FDB_LIT_INT64) { L->kind = FDB_LEAF_CMP_I64; L->lit = e.lit.i64; return; }
+    if (e.lit.type == FDB_LIT_FLOAT64) { L->kind = FDB_LEAF_CMP_I64_F64; L->lit = dbits(e.lit.f64); return; }
+  } else if (c.kind == ColKind::U64) {
+    if (e.lit.type == FDB_LIT_UINT64) { L->kind = FDB_LEAF_CMP_U64; L->lit = (int64_t)e.lit.u64; return; }
+    if (e.lit.type == FDB_LIT_INT64 && e.lit.i64 >= 0) { L->kind = FDB_LEAF_CMP_U64; L->lit = e.lit.i64; return; }
+  } else {
+    if (e.lit.type == FDB_LIT_FLOAT64) { L->kind = FDB_LEAF_CMP_F64; L->lit = dbits(e.lit.f64); return; }
+    if (e.lit.type == FDB_LIT_INT64) { L->kind = FDB_LEAF_CMP_F64; L->lit = dbits((double)e.lit.i64); return; }
+  }
+  throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation (column/literal type combination) on " + c.name);
+}
+
+// ---- table layout ----------------------------------------------------------------------------------------
+void Plan::ensure_layout(const std::vector<uint32_t>& new_caps) {
+  // new_caps has one entry per gcols_ element (columns may have been appended since the last layout)
+  uint64_t n_new = 1;
+  std::vector<uint32_t> new_strides(new_caps.size());
+  for (size_t c = 0; c < new_caps.size(); c++) {
+    new_strides[c] = (uint32_t)n_new;
+    n_new *= new_caps[c];
+    if (n_new > (1ull << 26)) throw Error(FDB_ERR_UNSUPPORTED, "group-key space exceeds the dense table limit (2^26 slots); high-cardinality hash path not built yet");
+  }
+  // Slots keep their index unless a column that already holds non-NULL ids changes its multiplier.
+  bool remap = false;
+  for (size_t c = 0; c < gcols_.size(); c++)
+    if (gcols_[c].cap > 1 && gcols_[c].stride != new_strides[c]) remap = true;
+  const bool need_alloc = n_new > slots_alloc_ || d_cnt_ == nullptr || (remap && state_dirty_);
+  if (need_alloc) {
+    const uint64_t cap = std::max<uint64_t>(n_new, 64);
+    const uint64_t alloc = (remap && state_dirty_) ? cap : std::max<uint64_t>(cap, slots_alloc_ * 2);
+    unsigned long long* n_cnt = nullptr;
+    hip_check(hipMalloc((void**)&n_cnt, alloc * 8), "hipMalloc(cnt)");
+    hip_check(fdb_launch_fill_u64(n_cnt, 0ull, (int64_t)alloc, stream_), "fill");
+    std::vector<unsigned long long*> n_acc(aggs_.size(), nullptr);
+    for (size_t j = 0; j < aggs_.size(); j++) {
+      hip_check(hipMalloc((void**)&n_acc[j], alloc * 8), "hipMalloc(acc)");
+      const int32_t f = aggs_[j].func;
+      const unsigned long long ident = f == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : f == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
+      hip_check(fdb_launch_fill_u64(n_acc[j], ident, (int64_t)alloc, stream_), "fill");
+    }
+    if (state_dirty_ && d_cnt_ != nullptr) {
+      const uint32_t* d_map = nullptr;
+      std::vector<uint32_t> map;
+      if (remap) {
+        map.resize(n_slots_);
+        for (uint32_t s = 0; s < n_slots_; s++) {
+          uint64_t t = 0;
+          for (size_t c = 0; c < gcols_.size(); c++) {
+            if (gcols_[c].cap <= 1) continue;
+            const uint32_t digit = (s / gcols_[c].stride) % gcols_[c].cap;
+            t += (uint64_t)digit * new_strides[c];
+          }
+          map[s] = (uint32_t)t;
+        }
+        d_map = (const uint32_t*)upload(map.data(), map.size() * 4);
+      }
+      hip_check(fdb_launch_merge_u64(n_cnt, d_cnt_, d_map, n_slots_, FDB_AGG_SUM, 0, stream_), "remap cnt");
+      for (size_t j = 0; j < aggs_.size(); j++) {
+        const int32_t f = (aggs_[j].func == FDB_AGG_COUNT) ? FDB_AGG_SUM : aggs_[j].func;
+        hip_check(fdb_launch_merge_u64(n_acc[j], aggs_[j].d_acc, d_map, n_slots_, f, aggs_[j].type == FDB_T_F64 && f == FDB_AGG_SUM, stream_), "remap acc");
+      }
+      hip_check(hipStreamSynchronize(stream_), "sync(remap)");
+    }
+    if (d_cnt_) (void)hipFree(d_cnt_);
+    for (size_t j = 0; j < aggs_.size(); j++) { if (aggs_[j].d_acc) (void)hipFree(aggs_[j].d_acc); aggs_[j].d_acc = n_acc[j]; }
+    d_cnt_ = n_cnt;
+    slots_alloc_ = alloc;
+  }
+  for (size_t c = 0; c < gcols_.size(); c++) { gcols_[c].cap = new_caps[c]; gcols_[c].stride = new_strides[c]; }
+  n_slots_ = (uint32_t)n_new;
+}
+
+// ---- push -------------------------------------------------------------------------------------------------
+void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
+  HostRecordView view;
+  view_record(array, schema, &view);
+  std::function<bool(const std::string&)> want = [this](const std::string& n) { return references(n); };
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_);
+  push_batch(*b);
+  sync();  // the staged copy is freed when `b` goes out of scope
+}
+
+void Plan::push_batch(const DeviceBatch& b) {
+  if (finished_) throw Error(FDB_ERR_STATE, "push after finish");
+  if (aggs_.empty()) throw Error(FDB_ERR_STATE, "filter-only plan: use fdb_plan_filter / fdb_plan_select");
+  if (b.device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+
+  Resolved R;
+  std::memset(&R.args, 0, sizeof(R.args));
+  FdbScanArgs& a = R.args;
+  a.n_rows = b.rows;
+  int max_depth = 0;
+  if (filter_root_ >= 0) emit_filter(filter_, filter_root_, b, &R, 0, &max_depth);
+
+  // group columns: every field matched by a matcher, in the record's field order (aggregate.go:286-303)
+  std::vector<int> batch_gcols;  // index into gcols_ per FdbGroupCol
+  std::vector<uint32_t> caps;
+  for (const GroupColState& g : gcols_) caps.push_back((uint32_t)g.values.size() + 1);
+  for (size_t ci = 0; ci < b.cols.size(); ci++) {
+    const DevColumn& c = b.cols[ci];
+    bool matched = false;
+    for (const GroupMatcher& m : matchers_) if (match_group(m, c.name)) { matched = true; break; }
+    if (!matched) continue;
+    if (c.kind != ColKind::DICT)
+      throw Error(FDB_ERR_UNSUPPORTED, "group by on a non-dictionary column (" + c.name + ": " + c.format + ") is not supported on the device path yet");
+    if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
+    size_t gi = 0;
+    for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == c.name) break;
+    if (gi == gcols_.size()) {
+      GroupColState g;
+      g.name = c.name;
+      g.value_format = c.dict->value_format;
+      g.cap = 1;
+      g.stride = 0;
+      gcols_.push_back(std::move(g));
+      caps.push_back(1);
+    }
+    if (a.n_gcols >= FDB_MAX_DENSE_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "too many group-by columns for the dense path; hash path not built yet");
+    GroupColState& g = gcols_[gi];
+    std::vector<uint32_t> lut(std::max<size_t>(c.dict->values.size(), 1), 0);
+    for (size_t e = 0; e < c.dict->values.size(); e++) {
+      auto it = g.ids.find(c.dict->values[e]);
+      if (it == g.ids.end()) {
+        g.values.push_back(c.dict->values[e]);
+        it = g.ids.emplace(c.dict->values[e], (uint32_t)g.values.size()).first;
+      }
+      lut[e] = it->second;
+    }
+    caps[gi] = (uint32_t)g.values.size() + 1;
+    R.count(b, (int)ci);
+    FdbGroupCol& G = a.gcols[a.n_gcols];
+    G.idx = (const uint32_t*)c.d_values;
+    G.validity = c.d_validity;
+    G.lut_len = (uint32_t)lut.size();
+    G.lut_lds = FDB_NO_LDS;
+    const size_t off = R.blob.add(lut.data(), lut.size() * 4);
+    R.luts.push_back(PendingLut{1, a.n_gcols, off, lut.size() * 4});
+    batch_gcols.push_back((int)gi);
+    a.n_gcols++;
+  }
+
+  // aggregated columns, by exact name (aggregate.go:340-361); all must be present (:367-380)
+  a.n_aggs = (int32_t)aggs_.size();
+  int found = 0;
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    AggState& A = aggs_[j];
+    const int ci = b.find(final_stage_ ? A.result_name : A.column);
+    if (ci < 0) continue;
+    found++;
+  }
+  if (found == 0)
+    throw Error(FDB_ERR_NOT_FOUND, std::string("aggregate field(s) not found, ") + (final_stage_ ? "final " : "") + "aggregations are not possible without it");
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    AggState& A = aggs_[j];
+    const int ci = b.find(final_stage_ ? A.result_name : A.column);
+    if (ci < 0) throw Error(FDB_ERR_NOT_FOUND, "aggregate field not found: " + A.column);
+    const DevColumn& c = b.cols[(size_t)ci];
+    FdbAgg& K = a.aggs[j];
+    K.func = A.func;
+    K.type = FDB_T_NONE;
+    if (A.func == FDB_AGG_COUNT && !final_stage_) {
+      // CountAggregation = arr.Len(): only the row count matters; the column is not read (aggregate.go:937-950)
+      continue;
+    }
+    int32_t t = c.kind == ColKind::I64 ? FDB_T_I64 : c.kind == ColKind::F64 ? FDB_T_F64 : FDB_T_NONE;
+    if (t == FDB_T_NONE)  // ErrUnsupportedSumType / MinType / MaxType (aggregate.go:736, :782, :862)
+      throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported type for ") + agg_name(A.func) + " aggregation, expected int64 or float64");
+    if (A.type == FDB_T_NONE) A.type = t;
+    else if (A.type != t) throw Error(FDB_ERR_UNSUPPORTED, "aggregated column " + A.column + " changed type between batches");
+    if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
+    R.count(b, ci);
+    K.type = t;
+    K.values = c.d_values;
+    K.validity = c.d_validity;
+    if (A.func == FDB_AGG_COUNT) K.func = FDB_AGG_SUM;  // final stage: COUNT merges by SUM (aggregate.go:965-969)
+  }
+
+  if (b.rows == 0) return;
+  ensure_layout(caps);
+  for (int g = 0; g < a.n_gcols; g++) a.gcols[g].stride = gcols_[(size_t)batch_gcols[(size_t)g]].stride;
+  for (size_t j = 0; j < aggs_.size(); j++) a.aggs[j].acc = aggs_[j].d_acc;
+  a.cnt = d_cnt_;
+  a.n_slots = n_slots_;
+  a.need_count = 0;
+  int n_acc_lds = 0;
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    if (a.aggs[j].func == FDB_AGG_COUNT) a.need_count = 1; else n_acc_lds++;
+  }
+
+  // LDS plan: [LUT copies][cnt u32 × n_slots][acc u64 × n_slots × n_aggs]
+  size_t lds_off = 0;
+  unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
+  for (const PendingLut& p : R.luts) {
+    const bool in_lds = p.len_bytes <= 16384 && lds_off + p.len_bytes <= 32768;
+    uint32_t lds = FDB_NO_LDS;
+    if (in_lds) { lds = (uint32_t)lds_off; lds_off = align_up(lds_off + p.len_bytes, 16); }
+    if (p.kind == 0) { a.leaves[p.index].lut = d_blob + p.blob_off; a.leaves[p.index].lut_lds = lds; }
+    else { a.gcols[p.index].lut = (const uint32_t*)(d_blob + p.blob_off); a.gcols[p.index].lut_lds = lds; }
+  }
+  a.lds_lut_bytes = (uint32_t)align_up(lds_off, 16);
+  const size_t acc_bytes = align_up((size_t)n_slots_ * 4, 16) + (size_t)n_slots_ * 8 * aggs_.size();
+  size_t lds_bytes = a.lds_lut_bytes;
+  int grid = grid_override > 0 ? grid_override : fdb_scan_default_grid(device_);
+  if (a.lds_lut_bytes + acc_bytes <= FDB_LDS_BUDGET) {
+    a.lds_acc = 1;
+    lds_bytes += acc_bytes;
+  } else if (a.lds_lut_bytes + acc_bytes <= 150 * 1024) {
+    a.lds_acc = 1;  // one workgroup per CU
+    lds_bytes += acc_bytes;
+    if (grid_override <= 0) grid = grid / 2;
+  } else {
+    a.lds_acc = 0;
+  }
+
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timing) {
+    auto get = [&]() { hipEvent_t e; if (!free_events_.empty()) { e = free_events_.back(); free_events_.pop_back(); } else hip_check(hipEventCreate(&e), "hipEventCreate"); return e; };
+    e0 = get(); e1 = get();
+    hip_check(hipEventRecord(e0, stream_), "hipEventRecord");
+  }
+  hip_check(fdb_launch_scan_dense(a, grid, lds_bytes, rows_per_thread, stream_), "scan launch");
+  if (timing) {
+    hip_check(hipEventRecord(e1, stream_), "hipEventRecord");
+    pending_events_.emplace_back(e0, e1);
+  }
+  state_dirty_ = true;
+  stat_bytes += R.bytes;
+  stat_launches += 1;
+  stat_rows += b.rows;
+}
+
+// ---- finish / export ----------------------------------------------------------------------------------------
+void Plan::fetch_state(std::vector<unsigned long long>* cnt, std::vector<std::vector<unsigned long long>>* acc) {
+  sync();
+  cnt->assign(n_slots_, 0);
+  acc->assign(aggs_.size(), {});
+  if (d_cnt_ == nullptr) { cnt->clear(); return; }
+  hip_check(hipMemcpy(cnt->data(), d_cnt_, (size_t)n_slots_ * 8, hipMemcpyDeviceToHost), "hipMemcpy(cnt)");
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    (*acc)[j].assign(n_slots_, 0);
+    hip_check(hipMemcpy((*acc)[j].data(), aggs_[j].d_acc, (size_t)n_slots_ * 8, hipMemcpyDeviceToHost), "hipMemcpy(acc)");
+  }
+}
+
+void Plan::build_key_columns(const std::vector<uint32_t>& slots, std::vector<OutColumn>* cols) const {
+  const int64_t n = (int64_t)slots.size();
+  for (const GroupColState& g : gcols_) {
+    OutColumn c;
+    c.name = g.name;
+    c.format = "I";
+    c.is_dict = true;
+    c.dict_format = g.value_format;
+    c.length = n;
+    c.values.resize((size_t)n * 4);
+    c.validity.assign((size_t)(n + 7) / 8, 0);
+    uint32_t* idx = (uint32_t*)c.values.data();
+    for (int64_t i = 0; i < n; i++) {
+      const uint32_t id = g.cap > 1 ? (slots[(size_t)i] / g.stride) % g.cap : 0;
+      if (id == 0) { idx[i] = 0; c.null_count++; }
+      else { idx[i] = id - 1; c.validity[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); }
+    }
+    c.dict_offsets.resize(g.values.size() + 1);
+    int32_t off = 0;
+    for (size_t v = 0; v < g.values.size(); v++) {
+      c.dict_offsets[v] = off;
+      c.dict_data.insert(c.dict_data.end(), g.values[v].begin(), g.values[v].end());
+      off += (int32_t)g.values[v].size();
+    }
+    c.dict_offsets[g.values.size()] = off;
+    cols->push_back(std::move(c));
+  }
+}
+
+void Plan::build_agg_columns(const std::vector<uint32_t>& slots, const std::vector<unsigned long long>& cnt,
+                             const std::vector<std::vector<unsigned long long>>& acc, std::vector<OutColumn>* cols) const {
+  const int64_t n = (int64_t)slots.size();
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    const AggState& A = aggs_[j];
+    OutColumn c;
+    c.name = A.result_name;
+    c.length = n;
+    c.values.resize((size_t)n * 8);
+    const bool count_from_cnt = A.func == FDB_AGG_COUNT && !final_stage_;
+    const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
+    c.format = is_f64 ? "g" : "l";
+    for (int64_t i = 0; i < n; i++) {
+      const uint32_t s = slots[(size_t)i];
+      unsigned long long v;
+      if (count_from_cnt) v = cnt[s];
+      else {
+        v = acc[j][s];
+        if (is_f64 && (A.func == FDB_AGG_MIN || A.func == FDB_AGG_MAX)) {
+          const double d = fdb_ordered_to_f64_host((int64_t)v);
+          std::memcpy(&v, &d, 8);
+        }
+      }
+      std::memcpy(c.values.data() + (size_t)i * 8, &v, 8);
+    }
+    cols->push_back(std::move(c));
+  }
+}
+
+void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
+  std::vector<unsigned long long> cnt;
+  std::vector<std::vector<unsigned long long>> acc;
+  fetch_state(&cnt, &acc);
+  std::vector<uint32_t> slots;
+  for (uint32_t s = 0; s < cnt.size(); s++) if (cnt[s] != 0) slots.push_back(s);
+  std::vector<OutColumn> cols;
+  build_key_columns(slots, &cols);
+  build_agg_columns(slots, cnt, acc, &cols);
+  if (n_rows) *n_rows = (int64_t)slots.size();
+  export_record(std::move(cols), (int64_t)slots.size(), out, out_schema);
+  finished_ = true;
+}
+
+int64_t Plan::num_groups() {
+  std::vector<unsigned long long> cnt;
+  std::vector<std::vector<unsigned long long>> acc;
+  fetch_state(&cnt, &acc);
+  int64_t n = 0;
+  for (unsigned long long c : cnt) n += c != 0;
+  return n;
+}
+
+void Plan::partial_keys(ArrowArray* out, ArrowSchema* out_schema) {
+  std::vector<unsigned long long> cnt;
+  std::vector<std::vector<unsigned long long>> acc;
+  fetch_state(&cnt, &acc);
+  std::vector<uint32_t> slots;
+  for (uint32_t s = 0; s < cnt.size(); s++) if (cnt[s] != 0) slots.push_back(s);
+  std::vector<OutColumn> cols;
+  build_key_columns(slots, &cols);
+  export_record(std::move(cols), (int64_t)slots.size(), out, out_schema);
+}
+
+char Plan::agg_format(int32_t agg) const {
+  if (agg < 0 || agg >= (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "aggregation index out of range");
+  const AggState& A = aggs_[(size_t)agg];
+  if (A.func == FDB_AGG_COUNT && !final_stage_) return 'l';
+  if (A.type == FDB_T_NONE) return 0;
+  return A.type == FDB_T_F64 ? 'g' : 'l';
+}
+
+void Plan::partial_state(int32_t agg, void* dst, int64_t capacity_bytes) {
+  if (agg < 0 || agg >= (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "aggregation index out of range");
+  std::vector<unsigned long long> cnt;
+  std::vector<std::vector<unsigned long long>> acc;
+  fetch_state(&cnt, &acc);
+  std::vector<uint32_t> slots;
+  for (uint32_t s = 0; s < cnt.size(); s++) if (cnt[s] != 0) slots.push_back(s);
+  std::vector<OutColumn> cols;
+  build_agg_columns(slots, cnt, acc, &cols);
+  const OutColumn& c = cols[(size_t)agg];
+  if ((int64_t)c.values.size() > capacity_bytes) throw Error(FDB_ERR_INVALID, "partial_state: destination too small");
+  if (!c.values.empty()) hip_check(hipMemcpy(dst, c.values.data(), c.values.size(), hipMemcpyDefault), "hipMemcpy(partial_state)");
+}
+
+// ---- merge (≙ Synchronizer + final-stage HashAggregate, same device) -------------------------------------------
+void Plan::merge_from(Plan& src) {
+  if (&src == this) throw Error(FDB_ERR_INVALID, "cannot merge a plan into itself");
+  if (src.device_ != device_) throw Error(FDB_ERR_INVALID, "merge across devices goes through frostdb_amd.distributed (RCCL)");
+  if (src.aggs_.size() != aggs_.size()) throw Error(FDB_ERR_INVALID, "plans have different aggregations");
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    if (src.aggs_[j].func != aggs_[j].func || src.aggs_[j].column != aggs_[j].column) throw Error(FDB_ERR_INVALID, "plans have different aggregations");
+    if (aggs_[j].type == FDB_T_NONE) aggs_[j].type = src.aggs_[j].type;
+    else if (src.aggs_[j].type != FDB_T_NONE && src.aggs_[j].type != aggs_[j].type) throw Error(FDB_ERR_INVALID, "aggregation types differ between plans");
+  }
+  src.sync();
+  sync();
+  if (!src.state_dirty_) return;
+  std::vector<unsigned long long> scnt((size_t)src.n_slots_);
+  hip_check(hipMemcpy(scnt.data(), src.d_cnt_, (size_t)src.n_slots_ * 8, hipMemcpyDeviceToHost), "hipMemcpy(src cnt)");
+  // unify key ids
+  std::vector<size_t> col_map(src.gcols_.size());
+  std::vector<std::vector<uint32_t>> id_map(src.gcols_.size());
+  std::vector<uint32_t> caps;
+  for (const GroupColState& g : gcols_) caps.push_back(g.cap);
+  for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+    const GroupColState& sg = src.gcols_[sc];
+    size_t gi = 0;
+    for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == sg.name) break;
+    if (gi == gcols_.size()) {
+      GroupColState g;
+      g.name = sg.name; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      gcols_.push_back(std::move(g));
+      caps.push_back(1);
+    }
+    GroupColState& g = gcols_[gi];
+    col_map[sc] = gi;
+    id_map[sc].assign(sg.values.size() + 1, 0);
+    for (size_t v = 0; v < sg.values.size(); v++) {
+      auto it = g.ids.find(sg.values[v]);
+      if (it == g.ids.end()) { g.values.push_back(sg.values[v]); it = g.ids.emplace(sg.values[v], (uint32_t)g.values.size()).first; }
+      id_map[sc][v + 1] = it->second;
+    }
+    caps[gi] = (uint32_t)g.values.size() + 1;
+  }
+  ensure_layout(caps);
+  std::vector<uint32_t> map((size_t)src.n_slots_, 0xFFFFFFFFu);
+  for (uint32_t s = 0; s < src.n_slots_; s++) {
+    if (scnt[s] == 0) continue;
+    uint64_t t = 0;
+    for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+      const GroupColState& sg = src.gcols_[sc];
+      const uint32_t id = sg.cap > 1 ? (s / sg.stride) % sg.cap : 0;
+      t += (uint64_t)id_map[sc][id] * gcols_[col_map[sc]].stride;
+    }
+    map[s] = (uint32_t)t;
+  }
+  const uint32_t* d_map = (const uint32_t*)upload(map.data(), map.size() * 4);
+  hip_check(fdb_launch_merge_u64(d_cnt_, src.d_cnt_, d_map, src.n_slots_, FDB_AGG_SUM, 0, stream_), "merge cnt");
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    const int32_t f = aggs_[j].func == FDB_AGG_COUNT ? FDB_AGG_SUM : aggs_[j].func;
+    hip_check(fdb_launch_merge_u64(aggs_[j].d_acc, src.aggs_[j].d_acc, d_map, src.n_slots_, f, aggs_[j].type == FDB_T_F64 && f == FDB_AGG_SUM, stream_), "merge acc");
+  }
+  state_dirty_ = true;
+  sync();
+}
+
+// ---- selection / filter-only -------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  explicit DevBuf(size_t bytes) { hip_check(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc(scratch)"); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf(const DevBuf&) = delete;
+};
+}  // namespace
+
+void Plan::select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* indices, int64_t capacity, int64_t* n_selected) {
+  if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
+  HostRecordView view;
+  view_record(array, schema, &view);
+  if (capacity < view.rows) throw Error(FDB_ERR_INVALID, "indices capacity smaller than the record");
+  std::function<bool(const std::string&)> want = [this](const std::string& n) {
+    for (const ExprNode& e : filter_) if (is_leaf_op(e.op) && e.column == n) return true;
+    return false;
+  };
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_);
+  Resolved R;
+  std::memset(&R.args, 0, sizeof(R.args));
+  R.args.n_rows = b->rows;
+  int max_depth = 0;
+  emit_filter(filter_, filter_root_, *b, &R, 0, &max_depth);
+  *n_selected = 0;
+  if (b->rows == 0) return;
+  FdbScanArgs& a = R.args;
+  size_t lds_off = 0;
+  unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
+  for (const PendingLut& p : R.luts) {
+    const bool in_lds = p.len_bytes <= 16384 && lds_off + p.len_bytes <= 32768;
+    uint32_t lds = FDB_NO_LDS;
+    if (in_lds) { lds = (uint32_t)lds_off; lds_off = align_up(lds_off + p.len_bytes, 16); }
+    a.leaves[p.index].lut = d_blob + p.blob_off;
+    a.leaves[p.index].lut_lds = lds;
+  }
+  a.lds_lut_bytes = (uint32_t)align_up(lds_off, 16);
+  const int64_t n_tiles = (b->rows + FDB_BLOCK * 8 - 1) / (FDB_BLOCK * 8);
+  DevBuf scratch((size_t)((n_tiles + 3) & ~(int64_t)3) * 4 + (size_t)(b->rows + 7) / 8 + 64);
+  DevBuf d_idx((size_t)b->rows * 4);
+  DevBuf d_n(8);
+  hip_check(fdb_launch_select(a, (uint32_t*)d_idx.p, (unsigned long long*)d_n.p, (uint32_t*)scratch.p, stream_), "select launch");
+  unsigned long long n = 0;
+  hip_check(hipMemcpyAsync(&n, d_n.p, 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(n)");
+  sync();
+  *n_selected = (int64_t)n;
+  if (n) hip_check(hipMemcpy(indices, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost), "hipMemcpy(indices)");
+  stat_bytes += R.bytes;
+}
+
+void Plan::filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray* out, ArrowSchema* out_schema, int64_t* n_selected) {
+  if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
+  HostRecordView view;
+  view_record(array, schema, &view);
+  std::vector<uint32_t> idx((size_t)std::max<int64_t>(view.rows, 1));
+  select(array, schema, idx.data(), (int64_t)idx.size(), n_selected);
+  const int64_t n = *n_selected;
+  if (n == 0) return;  // filter.go:264-266
+  // compaction of every column of the record (≙ slice + array.Concatenate, filter.go:296-320)
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, nullptr, stream_);
+  DevBuf d_idx((size_t)n * 4);
+  hip_check(hipMemcpy(d_idx.p, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice), "hipMemcpy(indices)");
+  std::vector<OutColumn> cols;
+  for (const DevColumn& c : b->cols) {
+    if (c.d_values == nullptr)
+      throw Error(FDB_ERR_UNSUPPORTED, "filter output: column type " + c.format + " (" + c.name + ") is not supported on the device path");
+    OutColumn o;
+    o.name = c.name;
+    o.length = n;
+    const int w = c.kind == ColKind::DICT ? 4 : 8;
+    o.format = c.kind == ColKind::DICT ? "I" : c.format;
+    DevBuf d_out((size_t)n * w);
+    hip_check(fdb_launch_gather(c.d_values, d_out.p, (const uint32_t*)d_idx.p, n, w, stream_), "gather");
+    o.values.resize((size_t)n * w);
+    hip_check(hipMemcpyAsync(o.values.data(), d_out.p, (size_t)n * w, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(gather out)");
+    if (c.d_validity != nullptr) {
+      const size_t vb = (size_t)((n + 63) / 64) * 8;
+      DevBuf d_bits(vb);
+      hip_check(fdb_launch_gather_bits(c.d_validity, (uint8_t*)d_bits.p, (const uint32_t*)d_idx.p, n, stream_), "gather bits");
+      o.validity.resize(vb);
+      hip_check(hipMemcpyAsync(o.validity.data(), d_bits.p, vb, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(bits)");
+      hip_check(hipStreamSynchronize(stream_), "sync");
+      o.null_count = count_nulls(o.validity.data(), 0, n);
+    } else {
+      hip_check(hipStreamSynchronize(stream_), "sync");
+    }
+    if (c.kind == ColKind::DICT) {
+      o.is_dict = true;
+      o.dict_format = c.dict->value_format;
+      o.dict_offsets.resize(c.dict->values.size() + 1);
+      int32_t off = 0;
+      for (size_t v = 0; v < c.dict->values.size(); v++) {
+        o.dict_offsets[v] = off;
+        o.dict_data.insert(o.dict_data.end(), c.dict->values[v].begin(), c.dict->values[v].end());
+        off += (int32_t)c.dict->values[v].size();
+      }
+      o.dict_offsets[c.dict->values.size()] = off;
+    }
+    cols.push_back(std::move(o));
+  }
+  export_record(std::move(cols), n, out, out_schema);
+}
+
+}  // namespace fdb

@@ -1,0 +1,152 @@
+// fdb_plan.h — host side of the MI355X operator chain: the C++ mirror of the reference's push operators
+// (PhysicalPlan: Callback / Finish / Draw / Close, query/physicalplan/physicalplan.go:24-30) for the fused
+// PredicateFilter → HashAggregate(final=false) chain, plus the HBM-resident record (`DeviceBatch`).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <regex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "fdb_arrow.h"
+#include "fdb_kernels.h"
+
+namespace fdb {
+
+void hip_check(hipError_t e, const char* what);
+
+// One column of a record resident in HBM.
+struct DevColumn {
+  std::string name;
+  std::string format;           // Arrow format of the column as received (index format for DICT)
+  ColKind kind = ColKind::OTHER;
+  int64_t length = 0;
+  int64_t null_count = 0;
+  void* d_values = nullptr;     // int64/uint64/double values or uint32 dictionary indices; nullptr for STR/OTHER/BOOL
+  uint8_t* d_validity = nullptr;  // validity bitmap at bit offset 0; nullptr ⇔ null_count == 0
+  std::shared_ptr<HostDict> dict;
+  int64_t value_bytes = 0;      // algorithmic bytes: values/indices
+  int64_t validity_bytes = 0;   // algorithmic bytes: bitmap (0 when the column has no nulls)
+};
+
+struct DeviceBatch {
+  int device = 0;
+  int64_t rows = 0;
+  std::vector<DevColumn> cols;
+  void* arena = nullptr;        // one allocation per record
+  size_t arena_bytes = 0;
+  int64_t payload_bytes = 0;    // Σ value_bytes + validity_bytes
+  ~DeviceBatch();
+  // Exactly-one-field lookup like ArrayRef.ArrowArray (binaryscalarexpr.go:22-29): -1 if absent or ambiguous.
+  int find(const std::string& name) const;
+};
+
+// Stages the columns of `view` accepted by `want(name)` (nullptr ⇒ all) to the device.
+std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device,
+                                          const std::function<bool(const std::string&)>* want, hipStream_t stream);
+
+struct Literal {
+  int32_t type = FDB_LIT_NULL;
+  int64_t i64 = 0;
+  uint64_t u64 = 0;
+  double f64 = 0;
+  std::string bytes;
+  bool valid() const { return type != FDB_LIT_NULL; }
+  std::string str() const;
+};
+
+struct ExprNode {
+  int32_t op = 0, left = -1, right = -1;
+  std::string column;
+  Literal lit;
+  std::shared_ptr<std::regex> re;
+};
+
+struct AggState {
+  int32_t func = 0;
+  std::string column;
+  std::string result_name;        // "sum(value)" — AggregationFunction.Name() (logicalplan/expr.go:700-702)
+  int32_t type = FDB_T_NONE;      // FDB_T_I64 / FDB_T_F64 once a batch has shown the column; COUNT keeps NONE
+  unsigned long long* d_acc = nullptr;
+};
+
+// One concrete group-by column, in first-seen order (≙ hashAggregate.colOrdering, aggregate.go:155).
+struct GroupColState {
+  std::string name;
+  std::string index_format = "I";
+  std::string value_format = "z";
+  std::unordered_map<std::string, uint32_t> ids;  // dictionary value → key id (≥ 1); 0 is NULL / column absent
+  std::vector<std::string> values;                // id - 1 → value
+  uint32_t cap = 1;                               // ids live in [0, cap)
+  uint32_t stride = 1;
+};
+
+struct GroupMatcher { std::string name; bool dynamic; };
+
+class BumpPool;  // pinned-host + device scratch for LUT uploads
+
+class Plan {
+ public:
+  Plan(const fdb_plan_desc* desc, int device);
+  ~Plan();
+
+  void push(const ArrowArray* array, const ArrowSchema* schema);        // ≙ Callback
+  void push_batch(const DeviceBatch& batch);
+  void finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows);  // ≙ Finish
+  void merge_from(Plan& src);                                          // ≙ Synchronizer + final stage
+  void select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* indices, int64_t capacity, int64_t* n_selected);
+  void filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray* out, ArrowSchema* out_schema, int64_t* n_selected);
+  const char* draw();                                                  // ≙ Draw
+  int64_t num_groups();
+  void partial_keys(ArrowArray* out, ArrowSchema* out_schema);
+  void partial_state(int32_t agg, void* dst, int64_t capacity_bytes);
+  char agg_format(int32_t agg) const;
+
+  std::string error;
+  int device() const { return device_; }
+  hipStream_t stream() const { return stream_; }
+  bool timing = false;
+  int64_t stat_bytes = 0, stat_launches = 0, stat_rows = 0;
+  double stat_ms = 0;
+  int rows_per_thread = 8;
+  int grid_override = 0;
+  struct Resolved;  // per-batch kernel arguments (fdb_plan.cpp)
+
+ private:
+  bool references(const std::string& column) const;
+  void ensure_layout(const std::vector<uint32_t>& new_caps);
+  void sync();
+  void collect_timing();
+  void fetch_state(std::vector<unsigned long long>* cnt, std::vector<std::vector<unsigned long long>>* acc);
+  void build_key_columns(const std::vector<uint32_t>& slots, std::vector<OutColumn>* cols) const;
+  void build_agg_columns(const std::vector<uint32_t>& slots, const std::vector<unsigned long long>& cnt,
+                         const std::vector<std::vector<unsigned long long>>& acc, std::vector<OutColumn>* cols) const;
+  void* upload(const void* host, size_t bytes);  // async H2D through the pinned pool; returns device address
+
+  int device_;
+  hipStream_t stream_ = nullptr;
+  std::vector<ExprNode> filter_;
+  int32_t filter_root_ = -1;
+  std::vector<AggState> aggs_;
+  std::vector<GroupMatcher> matchers_;
+  bool final_stage_ = false;
+  bool finished_ = false;
+
+  std::vector<GroupColState> gcols_;
+  uint32_t n_slots_ = 1;            // Π cap
+  uint64_t slots_alloc_ = 0;        // allocated accumulator length
+  unsigned long long* d_cnt_ = nullptr;
+  bool state_dirty_ = false;        // any kernel has accumulated into the table
+
+  std::unique_ptr<BumpPool> pool_;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
+  std::vector<hipEvent_t> free_events_;
+  std::string draw_;
+};
+
+}  // namespace fdb

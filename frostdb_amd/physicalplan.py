@@ -1,0 +1,250 @@
+"""ctypes binding of the C ABI (include/frostdb_amd.h), shaped like the reference's push operators.
+
+``HashAggregatePlan`` stands where one chain ``PredicateFilter → HashAggregate(final=false)`` stands in
+``physicalplan.Build`` (query/physicalplan/physicalplan.go:417-474) and offers the same five verbs as
+``PhysicalPlan`` (physicalplan.go:24-30): ``Callback(record)``, ``Finish()``, ``SetNext(next)``, ``Draw()``,
+``Close()``. pyarrow plays the role arrow-go's ``cdata`` package plays in the Go shim.
+
+There is NO CPU fallback: if ``libfrostdb_amd.so`` is missing, or the HIP runtime reports an error, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Callable, List, Optional, Sequence
+
+import pyarrow as pa
+
+from .arrow_c import ArrowArray, ArrowSchema, ExportedBatch, import_batch
+from .logicalplan import AggregationFunction, Column, Expr, to_desc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrostdb_amd.so")
+
+FDB_OK, FDB_ERR_INVALID, FDB_ERR_UNSUPPORTED, FDB_ERR_NOT_FOUND, FDB_ERR_DEVICE, FDB_ERR_OOM, FDB_ERR_STATE = range(7)
+
+
+class FdbError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"frostdb_amd error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class UnsupportedError(FdbError):
+    """≙ ErrUnsupportedBooleanExpression / ErrUnsupportedBinaryOperation / ErrUnsupportedSumType."""
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    """Loads libfrostdb_amd.so (built in-tree by frostdb_amd.build / __graft_entry__.build). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -m frostdb_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    P = ctypes.POINTER
+    L.fdb_version.restype = ctypes.c_char_p
+    L.fdb_last_error.restype = ctypes.c_char_p
+    L.fdb_device_count.argtypes = [P(ctypes.c_int)]
+    L.fdb_plan_create.argtypes = [vp, ctypes.c_int, P(vp)]
+    L.fdb_plan_push.argtypes = [vp, vp, vp]
+    L.fdb_plan_push_batch.argtypes = [vp, vp]
+    L.fdb_plan_finish.argtypes = [vp, vp, vp, P(i64)]
+    L.fdb_plan_merge.argtypes = [vp, vp]
+    L.fdb_plan_filter.argtypes = [vp, vp, vp, vp, vp, P(i64)]
+    L.fdb_plan_select.argtypes = [vp, vp, vp, vp, i64, P(i64)]
+    L.fdb_plan_draw.restype = ctypes.c_char_p
+    L.fdb_plan_draw.argtypes = [vp]
+    L.fdb_plan_last_error.restype = ctypes.c_char_p
+    L.fdb_plan_last_error.argtypes = [vp]
+    L.fdb_plan_close.argtypes = [vp]
+    L.fdb_plan_close.restype = None
+    L.fdb_plan_num_groups.argtypes = [vp, P(i64)]
+    L.fdb_plan_partial_keys.argtypes = [vp, vp, vp]
+    L.fdb_plan_partial_state.argtypes = [vp, i32, vp, i64]
+    L.fdb_plan_agg_type.argtypes = [vp, i32, ctypes.c_char_p]
+    L.fdb_batch_import.argtypes = [vp, vp, ctypes.c_int, P(vp)]
+    L.fdb_batch_num_rows.restype = i64
+    L.fdb_batch_num_rows.argtypes = [vp]
+    L.fdb_batch_device_bytes.restype = i64
+    L.fdb_batch_device_bytes.argtypes = [vp]
+    L.fdb_batch_release.argtypes = [vp]
+    L.fdb_batch_release.restype = None
+    L.fdb_plan_stats.argtypes = [vp, P(i64), P(ctypes.c_double), P(i64), P(i64)]
+    L.fdb_plan_set_timing.argtypes = [vp, i32]
+    L.fdb_plan_stream.argtypes = [vp, P(vp)]
+    L.fdb_plan_set_tuning.argtypes = [vp, i32, i32]
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    lib().fdb_device_count(ctypes.byref(n))
+    return n.value
+
+
+def _raise(code: int, msg: str):
+    raise (UnsupportedError if code == FDB_ERR_UNSUPPORTED else FdbError)(code, msg)
+
+
+class ResidentBatch:
+    """An Arrow record kept in HBM between queries (``fdb_batch``)."""
+
+    def __init__(self, batch: pa.RecordBatch, device: int = 0):
+        out = ctypes.c_void_p()
+        with ExportedBatch(batch) as ex:
+            rc = lib().fdb_batch_import(ctypes.addressof(ex.array), ctypes.addressof(ex.schema), device, ctypes.byref(out))
+        if rc != 0:
+            _raise(rc, lib().fdb_last_error().decode())
+        self.handle = out.value
+        self.device = device
+
+    @property
+    def num_rows(self) -> int:
+        return lib().fdb_batch_num_rows(self.handle)
+
+    @property
+    def device_bytes(self) -> int:
+        return lib().fdb_batch_device_bytes(self.handle)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            lib().fdb_batch_release(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HashAggregatePlan:
+    """One fused ``PredicateFilter → HashAggregate`` chain on one GPU."""
+
+    def __init__(self, filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (),
+                 groups: Sequence[Column] = (), device: int = 0, final_stage: bool = False):
+        self._desc = to_desc(filter_expr, list(aggs), list(groups), final_stage)
+        self.aggs = list(aggs)
+        out = ctypes.c_void_p()
+        rc = lib().fdb_plan_create(ctypes.addressof(self._desc.desc), device, ctypes.byref(out))
+        if rc != 0:
+            _raise(rc, lib().fdb_last_error().decode())
+        self.handle = out.value
+        self.device = device
+        self._next: Optional[Callable[[pa.RecordBatch], None]] = None
+        self._next_finish: Optional[Callable[[], None]] = None
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            _raise(rc, lib().fdb_plan_last_error(self.handle).decode())
+
+    # ---- PhysicalPlan verbs --------------------------------------------------------------------------
+    def Callback(self, record) -> None:
+        if isinstance(record, ResidentBatch):
+            self._check(lib().fdb_plan_push_batch(self.handle, record.handle))
+            return
+        with ExportedBatch(record) as ex:
+            self._check(lib().fdb_plan_push(self.handle, ctypes.addressof(ex.array), ctypes.addressof(ex.schema)))
+
+    def Finish(self) -> pa.RecordBatch:
+        arr, sch = ArrowArray(), ArrowSchema()
+        n = ctypes.c_int64()
+        self._check(lib().fdb_plan_finish(self.handle, ctypes.addressof(arr), ctypes.addressof(sch), ctypes.byref(n)))
+        rec = import_batch(arr, sch)
+        if self._next is not None:  # ≙ next.Callback(record) then next.Finish() (aggregate.go:626, :540)
+            if rec.num_rows:
+                self._next(rec)
+            if self._next_finish is not None:
+                self._next_finish()
+        return rec
+
+    def SetNext(self, callback: Callable[[pa.RecordBatch], None], finish: Optional[Callable[[], None]] = None) -> None:
+        self._next, self._next_finish = callback, finish
+
+    def Draw(self) -> str:
+        return lib().fdb_plan_draw(self.handle).decode()
+
+    def Close(self) -> None:
+        if getattr(self, "handle", None):
+            lib().fdb_plan_close(self.handle)
+            self.handle = None
+
+    # ---- beyond the interface ---------------------------------------------------------------------------
+    def Merge(self, other: "HashAggregatePlan") -> None:
+        """≙ Synchronizer + final-stage HashAggregate on one device."""
+        self._check(lib().fdb_plan_merge(self.handle, other.handle))
+
+    def Select(self, record: pa.RecordBatch):
+        import numpy as np
+        idx = np.zeros(max(record.num_rows, 1), dtype=np.uint32)
+        n = ctypes.c_int64()
+        with ExportedBatch(record) as ex:
+            self._check(lib().fdb_plan_select(self.handle, ctypes.addressof(ex.array), ctypes.addressof(ex.schema),
+                                              idx.ctypes.data, idx.size, ctypes.byref(n)))
+        return idx[: n.value].copy()
+
+    def Filter(self, record: pa.RecordBatch) -> Optional[pa.RecordBatch]:
+        """≙ filter(): compacted record, or None when no row qualifies (filter.go:264-266)."""
+        arr, sch = ArrowArray(), ArrowSchema()
+        n = ctypes.c_int64()
+        with ExportedBatch(record) as ex:
+            self._check(lib().fdb_plan_filter(self.handle, ctypes.addressof(ex.array), ctypes.addressof(ex.schema),
+                                              ctypes.addressof(arr), ctypes.addressof(sch), ctypes.byref(n)))
+        if n.value == 0:
+            return None
+        return import_batch(arr, sch)
+
+    def num_groups(self) -> int:
+        n = ctypes.c_int64()
+        self._check(lib().fdb_plan_num_groups(self.handle, ctypes.byref(n)))
+        return n.value
+
+    def partial_keys(self) -> pa.RecordBatch:
+        arr, sch = ArrowArray(), ArrowSchema()
+        self._check(lib().fdb_plan_partial_keys(self.handle, ctypes.addressof(arr), ctypes.addressof(sch)))
+        return import_batch(arr, sch)
+
+    def agg_format(self, agg: int) -> str:
+        c = ctypes.create_string_buffer(2)
+        self._check(lib().fdb_plan_agg_type(self.handle, agg, c))
+        return c.value.decode() or "l"
+
+    def partial_state_into(self, agg: int, dst_ptr: int, capacity_bytes: int) -> None:
+        """Copies aggregation `agg`'s partial column (n_groups × 8 B) to a host or device pointer."""
+        self._check(lib().fdb_plan_partial_state(self.handle, agg, dst_ptr, capacity_bytes))
+
+    def set_timing(self, enabled: bool) -> None:
+        lib().fdb_plan_set_timing(self.handle, 1 if enabled else 0)
+
+    def set_tuning(self, rows_per_thread: int = 8, grid_blocks: int = 0) -> None:
+        lib().fdb_plan_set_tuning(self.handle, rows_per_thread, grid_blocks)
+
+    def stats(self) -> dict:
+        b, ms, n, r = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+        lib().fdb_plan_stats(self.handle, ctypes.byref(b), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(r))
+        return {"algorithmic_bytes": b.value, "kernel_ms": ms.value, "launches": n.value, "rows": r.value}
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass
+
+
+def execute(records: Sequence, filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction],
+            groups: Sequence[Column], device: int = 0) -> pa.RecordBatch:
+    """The engine-level shape of the path: scan `records` through one GPU chain and return the final record."""
+    plan = HashAggregatePlan(filter_expr, aggs, groups, device=device)
+    try:
+        for r in records:
+            plan.Callback(r)
+        return plan.Finish()
+    finally:
+        plan.Close()

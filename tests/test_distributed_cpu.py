@@ -1,0 +1,127 @@
+"""world_size-2 (and 3) gloo tests of the cross-rank merge (frostdb_amd/distributed.py) on CPU.
+
+Each rank aggregates its own shard of records (here: with the oracle, because there is no GPU in this
+container — on the GPU box the same merge code receives tensors filled by fdb_plan_partial_state), then the
+ranks unify keys and all-reduce. The merged record must equal the oracle run over ALL records.
+"""
+import os
+import socket
+
+import numpy as np
+import pyarrow as pa
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from frostdb_amd.logicalplan import AGG_COUNT, Col, Count, DynCol, Max, Min, Sum
+from tests.util import make_prometheus_batch, sort_key, batch_rows, dict_array
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_records(world, seed=123):
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(2 * world + 1):
+        b = make_prometheus_batch(rng, 3000 + 500 * i, n_path=10 + 7 * i, with_method=False)
+        if i % 2 == 1:  # some records carry an extra dynamic label column
+            b = b.append_column("labels.zone", dict_array([None if rng.random() < 0.4 else b"z%d" % rng.integers(3) for _ in range(b.num_rows)]))
+        recs.append(b)
+    return recs
+
+
+def _oracle(records, filter_expr, aggs, groups):
+    from oracle import OraclePlan
+    p = OraclePlan(filter_expr, aggs, groups)
+    for r in records:
+        p.push(r)
+    d = p.finish().to_pydict()
+    p.close()
+    return d
+
+
+def _partial_as_arrow(d, aggs):
+    """Oracle partial result → (keys RecordBatch, tensors) in the shape fdb_plan_partial_keys/state produce."""
+    key_names = [k for k in d.keys() if not any(k == a.Name() for a in aggs)]
+    n = len(next(iter(d.values()))) if d else 0
+    keys = pa.RecordBatch.from_arrays([dict_array(d[k]) for k in key_names], names=key_names) if key_names else \
+        pa.RecordBatch.from_arrays([pa.array([0] * n)], names=["_"]).select([])
+    tensors = []
+    for a in aggs:
+        v = d.get(a.Name(), [])
+        isf = any(isinstance(x, float) for x in v)
+        tensors.append(torch.tensor(v, dtype=torch.float64 if isf else torch.int64))
+    return keys, tensors
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from frostdb_amd.distributed import merge_partials
+        recs = _shard_records(world)
+        mine = [r for i, r in enumerate(recs) if i % world == rank]
+        f = Col("labels.code") == "200"
+        aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("timestamp")), Max(Col("timestamp"))]
+        groups = [DynCol("labels")]
+        if rank == world - 1 and world == 3:
+            mine = []  # one rank with an empty shard
+        d = _oracle(mine, f, aggs, groups) if mine else {}
+        keys, tensors = _partial_as_arrow(d, aggs)
+        if not mine:
+            keys = pa.RecordBatch.from_arrays([], names=[])
+            tensors = [torch.zeros(0, dtype=torch.int64) for _ in aggs]
+        out = merge_partials(keys, tensors, aggs)
+        if rank == 0:
+            cols = out.schema.names
+            res = {}
+            for n, c in zip(cols, out.columns):
+                if pa.types.is_dictionary(c.type):
+                    c = c.dictionary_decode()
+                res[n] = c.to_pylist()
+            q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_merge_partials_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    recs = _shard_records(world)
+    if world == 3:
+        recs = [r for i, r in enumerate(recs) if i % world != world - 1]
+    f = Col("labels.code") == "200"
+    aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("timestamp")), Max(Col("timestamp"))]
+    want = _oracle(recs, f, aggs, [DynCol("labels")])
+    cols = ["labels.code", "labels.path", "labels.zone"] + [a.Name() for a in aggs]
+    g = sorted(batch_rows(res, cols), key=lambda r: sort_key(r[:3]))
+    w = sorted(batch_rows(want, cols), key=lambda r: sort_key(r[:3]))
+    assert len(g) == len(w)
+    for a, b in zip(g, w):
+        assert a[:3] == b[:3] and a[4:] == b[4:]
+        assert abs(a[3] - b[3]) <= 1e-9 * abs(b[3])
+
+
+def test_unify_keys_handles_missing_columns_and_order():
+    from frostdb_amd.distributed import unify_keys
+    names, keys, perms = unify_keys([["a"], ["b", "a"]], [[(b"x",), (None,)], [(b"q", b"x"), (None, b"x"), (None, None)]])
+    assert names == ["a", "b"]
+    assert keys == [(b"x", None), (None, None), (b"x", b"q")]
+    assert perms == [[0, 1], [2, 0, 1]]

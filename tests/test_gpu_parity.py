@@ -1,0 +1,401 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors.
+
+Every test here needs a real MI355X: run with ``pytest -m gpu``. Bars: bit-exact for COUNT/MIN/MAX/int64 SUM
+and selection indices; float64 SUM within 1e-9 relative (BASELINE.json north_star).
+"""
+import math
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+from frostdb_amd.logicalplan import And, Col, Count, DynCol, Max, Min, Or, Sum, UInt64
+from tests.golden import logictest_cases as G
+from tests.util import (arrow_to_pydict, batch_rows, dict_array, fmt, make_prometheus_batch, parse_rows, record_from_rows,
+                        sort_key, table_records)
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def pp():
+    from frostdb_amd import physicalplan
+    assert physicalplan.device_count() >= 1, "no HIP device visible"
+    return physicalplan
+
+
+def rows_of(d, cols):
+    return sorted(batch_rows(d, cols), key=sort_key)
+
+
+def assert_same_result(got, want, cols, float_cols=()):
+    """got/want: {col: [values]}; compares as multisets of rows; floats with REL_TOL, everything else exactly."""
+    g, w = rows_of(got, cols), rows_of(want, cols)
+    assert len(g) == len(w), (len(g), len(w))
+    # sort by non-float columns only so that float noise cannot reorder rows
+    key_cols = [i for i, c in enumerate(cols) if c not in float_cols]
+    g.sort(key=lambda r: sort_key(tuple(r[i] for i in key_cols)))
+    w.sort(key=lambda r: sort_key(tuple(r[i] for i in key_cols)))
+    for rg, rw in zip(g, w):
+        for c, a, b in zip(cols, rg, rw):
+            if c in float_cols and a is not None and b is not None:
+                assert math.isclose(a, b, rel_tol=REL_TOL, abs_tol=0.0) or a == b, (c, a, b)
+            else:
+                assert a == b, (c, rg, rw)
+
+
+def run_gpu(pp, records, filter_expr, aggs, groups, resident=False):
+    plan = pp.HashAggregatePlan(filter_expr, aggs, groups)
+    keep = []
+    try:
+        for r in records:
+            if resident:
+                rb = pp.ResidentBatch(r)
+                keep.append(rb)
+                plan.Callback(rb)
+            else:
+                plan.Callback(r)
+        return arrow_to_pydict(plan.Finish())
+    finally:
+        plan.Close()
+        for k in keep:
+            k.close()
+
+
+def run_oracle(records, filter_expr, aggs, groups, nchains=1):
+    from oracle import OraclePlan
+    plan = OraclePlan(filter_expr, aggs, groups, nchains=nchains)
+    for r in records:
+        plan.push(r)
+    d = plan.finish().to_pydict()
+    plan.close()
+    return d
+
+
+# ---- golden vectors ---------------------------------------------------------------------------------------
+
+def check_golden(case, d):
+    d = dict(d)
+    if "avg_of" in case:
+        s, c = case["avg_of"]
+        d["avg"] = [(a // b if isinstance(a, int) else a / float(b)) for a, b in zip(d[s], d[c])]
+    got = sorted([tuple(fmt(v) for v in row) for row in batch_rows(d, case["out"])], key=sort_key)
+    assert got == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("case", G.AGG_CASES, ids=[c["id"] for c in G.AGG_CASES])
+def test_golden_aggregate(pp, case, resident):
+    d = run_gpu(pp, table_records(case["table"]), case.get("filter"), case["aggs"], case["groups"], resident=resident)
+    check_golden(case, d)
+
+
+@pytest.mark.parametrize("case", G.AGG_CASES, ids=[c["id"] for c in G.AGG_CASES])
+def test_golden_aggregate_two_chains_merged(pp, case):
+    """Two chains (one per insert) merged like Synchronizer + final stage (physicalplan.go:438-471)."""
+    recs = table_records(case["table"])
+    plans = [pp.HashAggregatePlan(case.get("filter"), case["aggs"], case["groups"]) for _ in range(2)]
+    try:
+        for i, r in enumerate(recs):
+            plans[i % 2].Callback(r)
+        plans[0].Merge(plans[1])
+        check_golden(case, arrow_to_pydict(plans[0].Finish()))
+    finally:
+        for p in plans:
+            p.Close()
+
+
+@pytest.mark.parametrize("case", G.FILTER_CASES, ids=[c["id"] for c in G.FILTER_CASES])
+def test_golden_filter(pp, case):
+    rec = table_records(G.FILTER_TABLE)[0]
+    plan = pp.HashAggregatePlan(case["filter"])
+    try:
+        idx = plan.Select(rec)
+        assert list(idx) == case["rows"], case["cite"]
+        out = plan.Filter(rec)
+        if not case["rows"]:
+            assert out is None
+        else:
+            d = arrow_to_pydict(out)
+            assert d["timestamp"] == [r + 1 for r in case["rows"]]
+            assert d["labels.label1"] == [b"value%d" % (r + 1) for r in case["rows"]]
+            assert out.schema.names == rec.schema.names
+            src = arrow_to_pydict(rec)
+            for name in rec.schema.names:
+                assert d[name] == [src[name][r] for r in case["rows"]], name
+    finally:
+        plan.Close()
+
+
+def test_golden_inconsistent_schema(pp):
+    spec = G.INCONSISTENT_SCHEMA
+    recs = [record_from_rows(r["cols"], parse_rows(r["cols"], r["rows"])) for r in spec["records"]]
+    fns = {"sum": [Sum], "min": [Min], "max": [Max], "count": [Count], "avg": [Sum, Count]}
+    for name, want in spec["expected"].items():
+        d = run_gpu(pp, recs, None, [f(Col("value")) for f in fns[name]], [Col("labels.label2")])
+        vals = [a // b for a, b in zip(d["sum(value)"], d["count(value)"])] if name == "avg" else d[f"{name}(value)"]
+        assert sorted(vals, reverse=True) == want, (spec["cite"], name)
+        assert sorted(d["labels.label2"], key=lambda x: (x is None, x)) == [b"value2", None]
+
+
+# ---- randomized parity against the oracle ---------------------------------------------------------------------
+
+CFG2 = dict(filter=Col("labels.code") == "200", aggs=[Sum(Col("value"))], groups=[Col("labels.path")])
+CFG3 = dict(
+    filter=And(Or(Col("labels.code") == "200", Col("labels.code") == "500"), Col("labels.method") == "GET",
+               Col("labels.instance") != None),  # noqa: E711
+    aggs=[Count(Col("value")), Min(Col("timestamp")), Max(Col("timestamp")), Sum(Col("value"))],
+    groups=[Col("labels.path")])
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 63, 64, 65, 1023, 1024, 8191, 8192, 8193, 100_003])
+def test_config2_sizes(pp, n):
+    rng = np.random.default_rng(1000 + n)
+    b = make_prometheus_batch(rng, n)
+    want = run_oracle([b], **CFG2) if n else {"labels.path": [], "sum(value)": []}
+    got = run_gpu(pp, [b], **CFG2)
+    if n == 0:
+        assert all(len(v) == 0 for v in got.values())
+        return
+    assert_same_result(got, want, ["labels.path", "sum(value)"], float_cols={"sum(value)"})
+
+
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("rpt", [4, 8])
+def test_config3_multibatch(pp, resident, rpt):
+    rng = np.random.default_rng(7)
+    batches = [make_prometheus_batch(rng, n, n_path=int(p)) for n, p in [(50_000, 64), (33_333, 200), (8192, 7), (1, 3)]]
+    want = run_oracle(batches, **CFG3, nchains=2)
+    plan = pp.HashAggregatePlan(CFG3["filter"], CFG3["aggs"], CFG3["groups"])
+    plan.set_tuning(rpt, 0)
+    keep = []
+    try:
+        for b in batches:
+            if resident:
+                keep.append(pp.ResidentBatch(b))
+                plan.Callback(keep[-1])
+            else:
+                plan.Callback(b)
+        got = arrow_to_pydict(plan.Finish())
+    finally:
+        plan.Close()
+    cols = ["labels.path", "count(value)", "min(timestamp)", "max(timestamp)", "sum(value)"]
+    assert_same_result(got, want, cols, float_cols={"sum(value)"})
+
+
+def test_group_by_dynamic_labels_with_growing_dictionaries(pp):
+    """Group by the whole dynamic column set; later batches add dictionary entries AND a new label column,
+    which forces the dense table to be re-laid-out (mixed-radix strides change)."""
+    rng = np.random.default_rng(11)
+
+    def batch(n, ncode, npath, with_zone):
+        cols = {
+            "labels.code": dict_array([None if rng.random() < 0.1 else b"c%d" % rng.integers(ncode) for _ in range(n)]),
+            "labels.path": dict_array([None if rng.random() < 0.1 else b"p%d" % rng.integers(npath) for _ in range(n)]),
+        }
+        if with_zone:
+            cols["labels.zone"] = dict_array([None if rng.random() < 0.5 else b"z%d" % rng.integers(3) for _ in range(n)])
+        cols["value"] = pa.array(rng.integers(-1000, 1000, size=n), type=pa.int64())
+        cols["floatvalue"] = pa.array(rng.normal(size=n))
+        return pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols.keys()))
+
+    batches = [batch(2000, 2, 3, False), batch(3000, 5, 3, False), batch(3000, 5, 9, True), batch(1000, 7, 12, True)]
+    aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("value")), Max(Col("value")), Sum(Col("floatvalue")),
+            Min(Col("floatvalue")), Max(Col("floatvalue"))]
+    want = run_oracle(batches, None, aggs, [DynCol("labels")])
+    got = run_gpu(pp, batches, None, aggs, [DynCol("labels")])
+    cols = ["labels.code", "labels.path", "labels.zone"] + [a.Name() for a in aggs]
+    assert_same_result(got, want, cols, float_cols={"sum(floatvalue)"})
+
+
+def test_nullable_aggregated_columns_match_reference_quirks(pp):
+    """NULLs inside an aggregated column: COUNT counts them, SUM adds 0, MIN/MAX see the builder's zeroed slot
+    (aggregate.go:784-950 + pqarrow/builder/optbuilders.go:337-340). Unpinned by reference tests —
+    this pins the HIP path to the oracle's restatement of it."""
+    rng = np.random.default_rng(5)
+    n = 20_000
+    g = dict_array([b"g%d" % rng.integers(5) for _ in range(n)])
+    iv = pa.array(rng.integers(5, 100, size=n), type=pa.int64(), mask=rng.random(n) < 0.3)
+    fv = pa.array(rng.uniform(1.0, 2.0, size=n), mask=rng.random(n) < 0.3)
+    neg = pa.array(-rng.uniform(1.0, 2.0, size=n), mask=rng.random(n) < 0.3)
+    b = pa.RecordBatch.from_arrays([g, iv, fv, neg], names=["labels.g", "value", "floatvalue", "neg"])
+    aggs = [Count(Col("value")), Sum(Col("value")), Min(Col("value")), Max(Col("value")), Sum(Col("floatvalue")),
+            Min(Col("floatvalue")), Max(Col("neg")), Count(Col("floatvalue"))]
+    want = run_oracle([b], None, aggs, [Col("labels.g")])
+    got = run_gpu(pp, [b], None, aggs, [Col("labels.g")])
+    assert want["min(value)"] == [0] * 5 and want["min(floatvalue)"] == [0.0] * 5 and want["max(neg)"] == [0.0] * 5
+    assert_same_result(got, want, ["labels.g"] + [a.Name() for a in aggs], float_cols={"sum(floatvalue)"})
+
+
+def test_numeric_predicates_and_no_groups(pp):
+    rng = np.random.default_rng(21)
+    n = 30_000
+    b = pa.RecordBatch.from_arrays(
+        [pa.array(rng.integers(0, 100, size=n), type=pa.int64(), mask=rng.random(n) < 0.05),
+         pa.array(rng.uniform(0, 1, size=n), mask=rng.random(n) < 0.05),
+         pa.array(rng.integers(0, 2**63, size=n, dtype=np.uint64), type=pa.uint64()),
+         pa.array(rng.integers(0, 1000, size=n), type=pa.int64())],
+        names=["timestamp", "floatvalue", "u", "value"])
+    for f in [Col("timestamp") == 5, Col("timestamp") != 5, Col("timestamp") < 50, Col("timestamp") <= 50,
+              Col("timestamp") > 50, Col("timestamp") >= 50, Col("floatvalue") < 0.25, Col("floatvalue") >= 0.5,
+              Col("timestamp") < 33.5, Col("floatvalue") > 0, Col("u") > UInt64(2**62), Col("u") <= 2**40,
+              And(Col("timestamp") > 10, Or(Col("floatvalue") < 0.1, Col("floatvalue") > 0.9)),
+              Col("timestamp") == None, Col("missing") < 3, Col("missing") != 3]:  # noqa: E711
+        aggs = [Count(Col("value")), Sum(Col("value")), Min(Col("value")), Max(Col("value"))]
+        want = run_oracle([b], f, aggs, [])
+        got = run_gpu(pp, [b], f, aggs, [])
+        if not want:  # no row selected: the reference emits nothing, the C ABI a zero-row record
+            assert all(len(v) == 0 for v in got.values()), str(f)
+        else:
+            assert got == want, str(f)
+
+
+def test_sliced_columns_with_unaligned_offsets(pp):
+    """Arrow slices carry a non-zero offset: validity bitmaps must be re-based bit-exactly at import."""
+    rng = np.random.default_rng(77)
+    b = make_prometheus_batch(rng, 50_000, null_frac=0.2)
+    for off, ln in [(3, 10_001), (8, 4096), (13, 8192), (49_990, 10)]:
+        s = b.slice(off, ln)
+        want = run_oracle([s], **CFG3)
+        for resident in (False, True):
+            got = run_gpu(pp, [s], **CFG3, resident=resident)
+            cols = ["labels.path", "count(value)", "min(timestamp)", "max(timestamp)", "sum(value)"]
+            if not want:
+                assert all(len(v) == 0 for v in got.values())
+            else:
+                assert_same_result(got, want, cols, float_cols={"sum(value)"})
+
+
+def test_selection_vector_matches_oracle_on_large_batch(pp):
+    from oracle import OraclePlan
+    rng = np.random.default_rng(3)
+    b = make_prometheus_batch(rng, 250_007)
+    f = CFG3["filter"]
+    plan = pp.HashAggregatePlan(f)
+    o = OraclePlan(f)
+    try:
+        got = plan.Select(b)
+        _, want = o.filter(b)
+        assert np.array_equal(got, want)
+        assert np.all(np.diff(got.astype(np.int64)) > 0)  # ascending, like bitmap.ToArray()
+        out = plan.Filter(b)
+        take = b.take(pa.array(want))
+        assert arrow_to_pydict(out) == arrow_to_pydict(take)
+    finally:
+        plan.Close()
+        o.close()
+
+
+def test_error_behaviour_mirrors_reference(pp):
+    rng = np.random.default_rng(4)
+    b = make_prometheus_batch(rng, 100)
+    # aggregate field not found (aggregate.go:367-380)
+    plan = pp.HashAggregatePlan(None, [Sum(Col("nope"))], [Col("labels.path")])
+    with pytest.raises(pp.FdbError) as e:
+        plan.Callback(b)
+    assert e.value.code == pp.FDB_ERR_NOT_FOUND and "aggregate field(s) not found" in e.value.msg
+    plan.Close()
+    # unsupported operator on a dictionary column (binaryscalarexpr.go:106-108)
+    plan = pp.HashAggregatePlan(Col("labels.code") < "3", [Sum(Col("value"))], [])
+    with pytest.raises(pp.UnsupportedError):
+        plan.Callback(b)
+    plan.Close()
+    # SUM over a uint64 column: ErrUnsupportedSumType (aggregate.go:743-751)
+    ub = pa.RecordBatch.from_arrays([pa.array([1, 2], type=pa.uint64())], names=["value"])
+    plan = pp.HashAggregatePlan(None, [Sum(Col("value"))], [])
+    with pytest.raises(pp.UnsupportedError) as e:
+        plan.Callback(ub)
+    assert "expected int64 or float64" in e.value.msg
+    plan.Close()
+    # regex on a dictionary<utf8> column is rejected like regexpfilter.go:55-61
+    sb = pa.RecordBatch.from_arrays([dict_array(["a", "b"], pa.dictionary(pa.uint32(), pa.string())), pa.array([1, 2])],
+                                    names=["labels.x", "value"])
+    plan = pp.HashAggregatePlan(Col("labels.x").RegexMatch("a"), [Sum(Col("value"))], [])
+    with pytest.raises(pp.UnsupportedError):
+        plan.Callback(sb)
+    plan.Close()
+    # push after finish
+    plan = pp.HashAggregatePlan(None, [Sum(Col("value"))], [Col("labels.path")])
+    plan.Callback(b)
+    plan.Finish()
+    with pytest.raises(pp.FdbError):
+        plan.Callback(b)
+    plan.Close()
+
+
+def test_draw(pp):
+    plan = pp.HashAggregatePlan(Col("labels.code") == "200", [Sum(Col("value"))], [Col("labels.path")])
+    assert plan.Draw().startswith("PredicateFilter (labels.code == 200) - HashAggregate (sum(value) by labels.path)")
+    plan.Close()
+
+
+def test_final_stage_plan_merges_partial_records(pp):
+    """A plan created with final_stage=1 consumes the records partial plans emit (columns named by result name)
+    and merges COUNT by SUM — the contract of HashAggregate(finalStage=true) (aggregate.go:340-348, :965-969)."""
+    rng = np.random.default_rng(9)
+    batches = [make_prometheus_batch(rng, 20_000, n_path=20) for _ in range(3)]
+    aggs = [Count(Col("value")), Sum(Col("value")), Min(Col("timestamp")), Max(Col("timestamp"))]
+    partials = [run_gpu_arrow(pp, [b], None, aggs, [Col("labels.path")]) for b in batches]
+    final = pp.HashAggregatePlan(None, aggs, [Col("labels.path")], final_stage=True)
+    for p in partials:
+        final.Callback(p)
+    got = arrow_to_pydict(final.Finish())
+    final.Close()
+    want = run_oracle(batches, None, aggs, [Col("labels.path")], nchains=3)
+    assert_same_result(got, want, ["labels.path"] + [a.Name() for a in aggs], float_cols={"sum(value)"})
+
+
+def run_gpu_arrow(pp, records, filter_expr, aggs, groups):
+    plan = pp.HashAggregatePlan(filter_expr, aggs, groups)
+    try:
+        for r in records:
+            plan.Callback(r)
+        return plan.Finish()
+    finally:
+        plan.Close()
+
+
+# ---- size-independent properties at a larger size ------------------------------------------------------------------
+
+def test_properties_at_scale(pp):
+    """4M rows: Σ count == selected rows, min ≤ max, group sums add up to the ungrouped sum, idempotent re-run,
+    partition invariance (one batch vs four)."""
+    rng = np.random.default_rng(2024)
+    n = 4_000_000
+    b = make_prometheus_batch(rng, n, n_path=1024, with_method=False)
+    f = Col("labels.code") == "200"
+    aggs = [Count(Col("value")), Sum(Col("value")), Min(Col("timestamp")), Max(Col("timestamp"))]
+    rb = pp.ResidentBatch(b)
+    plan = pp.HashAggregatePlan(f, aggs, [Col("labels.path")])
+    plan.Callback(rb)
+    grouped = arrow_to_pydict(plan.Finish())
+    plan.Close()
+    plan = pp.HashAggregatePlan(f, aggs, [])
+    plan.Callback(rb)
+    total = arrow_to_pydict(plan.Finish())
+    plan.Close()
+    code = b.column(0)
+    sel = pc.fill_null(pc.equal(code.dictionary_decode(), pa.scalar(b"200", pa.binary())), False)
+    n_sel = pc.sum(sel.cast(pa.int64())).as_py()
+    assert sum(grouped["count(value)"]) == n_sel == total["count(value)"][0]
+    assert all(lo <= hi for lo, hi in zip(grouped["min(timestamp)"], grouped["max(timestamp)"]))
+    assert min(grouped["min(timestamp)"]) == total["min(timestamp)"][0]
+    assert max(grouped["max(timestamp)"]) == total["max(timestamp)"][0]
+    assert math.isclose(math.fsum(grouped["sum(value)"]), total["sum(value)"][0], rel_tol=REL_TOL)
+    exact = math.fsum(pc.filter(b.column(b.schema.get_field_index("value")), sel).to_numpy())
+    assert math.isclose(total["sum(value)"][0], exact, rel_tol=REL_TOL)
+    # partition invariance
+    parts = [pp.ResidentBatch(b.slice(i * (n // 4), n // 4)) for i in range(4)]
+    plan = pp.HashAggregatePlan(f, aggs, [Col("labels.path")])
+    for p in parts:
+        plan.Callback(p)
+    again = arrow_to_pydict(plan.Finish())
+    plan.Close()
+    cols = ["labels.path"] + [a.Name() for a in aggs]
+    assert_same_result(again, grouped, cols, float_cols={"sum(value)"})
+    rb.close()
+    for p in parts:
+        p.close()
