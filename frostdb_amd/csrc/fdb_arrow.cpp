@@ -3,6 +3,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <string_view>
+#include <unordered_set>
 
 namespace fdb {
 
@@ -86,6 +88,16 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
     const int64_t* offs = (const int64_t*)da->buffers[1];
     for (int64_t i = 0; i < n; i++) d->values[(size_t)i].assign(data + offs[off + i], (size_t)(offs[off + i + 1] - offs[off + i]));
   }
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over (length, bytes) of every entry
+  std::unordered_set<std::string_view> seen;
+  seen.reserve(d->values.size() * 2);
+  for (const std::string& v : d->values) {
+    uint64_t len = v.size();
+    for (int k = 0; k < 8; k++) { h ^= (len >> (8 * k)) & 0xFF; h *= 1099511628211ull; }
+    for (unsigned char ch : v) { h ^= ch; h *= 1099511628211ull; }
+    if (!seen.insert(std::string_view(v)).second) d->unique = false;
+  }
+  d->hash = h;
   return d;
 }
 

@@ -23,7 +23,10 @@ enum class ColKind : int32_t { I64 = 1, U64 = 2, F64 = 3, BOOL = 4, STR = 5, DIC
 struct HostDict {
   std::vector<std::string> values;
   std::string value_format;  // "z" (binary) or "u" (utf8); large variants are narrowed on import
+  uint64_t hash = 0;         // content hash (lengths + bytes), computed at import
+  bool unique = true;        // no two entries hold the same bytes (Arrow allows duplicates)
   bool utf8() const { return value_format == "u"; }
+  bool same_content(const HostDict& o) const { return hash == o.hash && values == o.values; }
 };
 
 // A borrowed view of one column of an incoming record; valid only while the caller's ArrowArray is.

@@ -147,8 +147,10 @@ int fdb_plan_stream(fdb_plan* plan, void** stream_out) {
 // Tuning knobs used by bench.py's variant sweeps (not part of the Go binding).
 int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_blocks) {
   if (!plan) return FDB_ERR_INVALID;
-  if (rows_per_thread == 4 || rows_per_thread == 8) plan->plan.rows_per_thread = rows_per_thread;
-  plan->plan.grid_override = grid_blocks;
+  if (rows_per_thread == 0 || rows_per_thread == 4 || rows_per_thread == 8) plan->plan.rows_per_thread = rows_per_thread;
+  plan->plan.grid_override = grid_blocks & 0xFFFFF;
+  plan->plan.ablate = (grid_blocks >> 20) & 0xF;  // bench --ablate rides in the high bits (tuning aid only)
+  plan->plan.use_partials = ((grid_blocks >> 24) & 1) == 0;
   return FDB_OK;
 }
 

@@ -1,0 +1,117 @@
+// fdb_context.cpp — see fdb_context.h.
+#include "fdb_context.h"
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "fdb_plan.h"
+
+namespace fdb {
+
+namespace {
+std::mutex g_mu;
+std::vector<Context*> g_free[16];
+inline size_t round_block(size_t b) {
+  size_t r = 4096;
+  while (r < b) r <<= 1;
+  return r;
+}
+}  // namespace
+
+Context* Context::acquire(int device) {
+  if (device < 0 || device >= 16) throw Error(FDB_ERR_INVALID, "device index out of range");
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_free[device].empty()) {
+      Context* c = g_free[device].back();
+      g_free[device].pop_back();
+      return c;
+    }
+  }
+  hip_check(hipSetDevice(device), "hipSetDevice");
+  Context* c = new Context();
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; hip_check(e, "hipStreamCreate"); }
+  return c;
+}
+
+void Context::release(Context* c) {
+  if (c == nullptr) return;
+  c->stage_off_ = 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_free[c->device].push_back(c);
+}
+
+void* Context::dev_alloc(size_t bytes) {
+  bytes = round_block(bytes ? bytes : 1);
+  Block* best = nullptr;
+  for (Block& b : dev_blocks_)
+    if (!b.used && b.bytes >= bytes && (best == nullptr || b.bytes < best->bytes)) best = &b;
+  if (best != nullptr && best->bytes <= bytes * 4) { best->used = true; return best->p; }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e == hipErrorOutOfMemory) {  // drop the cache and retry once
+    (void)hipGetLastError();
+    for (Block& b : dev_blocks_) if (!b.used) { (void)hipFree(b.p); b.p = nullptr; }
+    dev_blocks_.erase(std::remove_if(dev_blocks_.begin(), dev_blocks_.end(), [](const Block& b) { return b.p == nullptr; }), dev_blocks_.end());
+    e = hipMalloc(&p, bytes);
+  }
+  hip_check(e, "hipMalloc");
+  dev_blocks_.push_back(Block{p, bytes, true});
+  return p;
+}
+
+void Context::dev_free(void* p) {
+  if (p == nullptr) return;
+  for (Block& b : dev_blocks_) if (b.p == p) { b.used = false; return; }
+}
+
+void* Context::host_alloc(size_t bytes) {
+  bytes = round_block(bytes ? bytes : 1);
+  Block* best = nullptr;
+  for (Block& b : host_blocks_)
+    if (!b.used && b.bytes >= bytes && (best == nullptr || b.bytes < best->bytes)) best = &b;
+  if (best != nullptr) { best->used = true; return best->p; }
+  void* p = nullptr;
+  hip_check(hipHostMalloc(&p, bytes, hipHostMallocDefault), "hipHostMalloc");
+  host_blocks_.push_back(Block{p, bytes, true});
+  return p;
+}
+
+void Context::host_free(void* p) {
+  if (p == nullptr) return;
+  for (Block& b : host_blocks_) if (b.p == p) { b.used = false; return; }
+}
+
+hipEvent_t Context::get_event() {
+  if (!events_.empty()) { hipEvent_t e = events_.back(); events_.pop_back(); return e; }
+  hipEvent_t e;
+  hip_check(hipEventCreate(&e), "hipEventCreate");
+  return e;
+}
+
+void Context::put_event(hipEvent_t e) { events_.push_back(e); }
+
+void* Context::stage(const void* host, size_t payload) {
+  const size_t bytes = (std::max<size_t>(payload, 1) + 255) / 256 * 256;
+  if (stage_off_ + bytes > stage_cap_) {
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(staging)");
+    stage_off_ = 0;
+    if (bytes > stage_cap_) {
+      if (stage_h_) (void)hipHostFree(stage_h_);
+      if (stage_d_) (void)hipFree(stage_d_);
+      stage_cap_ = std::max<size_t>(round_block(bytes * 2), 1 << 20);
+      hip_check(hipHostMalloc((void**)&stage_h_, stage_cap_, hipHostMallocDefault), "hipHostMalloc(staging)");
+      hip_check(hipMalloc((void**)&stage_d_, stage_cap_), "hipMalloc(staging)");
+    }
+  }
+  if (payload) std::memcpy(stage_h_ + stage_off_, host, payload);
+  void* dst = stage_d_ + stage_off_;
+  hip_check(hipMemcpyAsync(dst, stage_h_ + stage_off_, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(staging)");
+  stage_off_ += bytes;
+  return dst;
+}
+
+}  // namespace fdb

@@ -14,6 +14,8 @@
 #define FDB_MAX_DENSE_GCOLS 8
 #define FDB_MAX_HASH_GCOLS 64
 #define FDB_MAX_AGGS 8
+#define FDB_MAX_C4 4            // column slots of the load-hoisting kernel: 4-byte (dictionary index) columns
+#define FDB_MAX_C8 3            //                                           8-byte (int64/uint64/float64) columns
 #define FDB_BLOCK 1024          // 16 waves share one LDS partial table
 #define FDB_LDS_BUDGET 65536    // bytes of LDS per workgroup (2 workgroups/CU of the 160 KiB)
 #define FDB_NO_LDS 0xFFFFFFFFu
@@ -39,6 +41,8 @@ struct FdbLeaf {
   int32_t op;               // fdb_op for compares
   uint32_t lut_len;
   uint32_t lut_lds;         // byte offset of the LUT's LDS copy, or FDB_NO_LDS (too big: gather from L2)
+  int32_t slot;             // column slot (c4 for dictionary columns, c8 for 8-byte columns); -1: not slotted
+  int32_t wide;             // 1: the slot is in c8
 };
 
 struct FdbGroupCol {
@@ -48,7 +52,7 @@ struct FdbGroupCol {
   uint32_t lut_len;
   uint32_t lut_lds;
   uint32_t stride;          // dense path: mixed-radix multiplier of this column
-  uint32_t _pad;
+  int32_t slot;             // c4 slot
 };
 
 enum FdbAggType : int32_t { FDB_T_NONE = 0, FDB_T_I64 = 1, FDB_T_F64 = 2 };
@@ -59,6 +63,15 @@ struct FdbAgg {
   unsigned long long* acc;  // global accumulator array [n_slots] (int64 bits / double bits / ordered-f64 keys)
   int32_t func;             // fdb_agg_func (SUM/MIN/MAX/COUNT)
   int32_t type;             // FdbAggType of the input column
+  int32_t slot;             // c8 slot
+  int32_t _pad;
+};
+
+// One distinct referenced column of the batch. The slot kernel issues the loads of ALL slots of a tile before
+// it consumes any of them, so a wave keeps every referenced column in flight at once (memory-level parallelism).
+struct FdbColSlot {
+  const void* values;       // nullptr: only the validity bitmap is needed (IS [NOT] NULL leaves)
+  const uint8_t* validity;  // nullptr: no NULLs
 };
 
 struct FdbScanArgs {
@@ -72,6 +85,14 @@ struct FdbScanArgs {
   int32_t lds_acc;          // 1: stage partial aggregates in LDS, flush once per workgroup; 0: global atomics per row
   uint32_t lds_lut_bytes;   // bytes of LUT copies at the start of dynamic LDS
   int32_t need_count;       // 1: some aggregation is COUNT (exact per-slot row counts needed)
+  int32_t n_c4;             // > 0 or n_c8 > 0: slots are assigned (otherwise only the sequential kernel can run)
+  int32_t n_c8;
+  FdbColSlot c4[FDB_MAX_C4];
+  FdbColSlot c8[FDB_MAX_C8];
+  unsigned long long* partials;  // LDS mode: per-workgroup partial tables [grid][1 + n_aggs][n_slots], written with plain
+                                 // coalesced stores and folded by fdb_launch_reduce_partials (nullptr: flush with atomics)
+  int32_t ablate;           // tuning aid (bench --ablate): 1 skip occupancy, 2 skip aggregate atomics, 4 skip group LUTs, 8 skip filter
+  int32_t _pad0;
   uint8_t code[FDB_MAX_CODE];
   FdbLeaf leaves[FDB_MAX_LEAVES];
   FdbGroupCol gcols[FDB_MAX_DENSE_GCOLS];
@@ -97,9 +118,20 @@ static inline double fdb_ordered_to_f64_host(int64_t k) {
 
 // ---- launch wrappers (fdb_kernels.hip) ---------------------------------------------------------------
 // All launches are asynchronous on `stream`.
+// rows_per_thread: 4 or 8 → the sequential (one column at a time) kernel; 0 → the slot kernel (needs args.n_c4/n_c8).
 hipError_t fdb_launch_scan_dense(const FdbScanArgs& args, int grid_blocks, size_t lds_bytes, int rows_per_thread,
                                  hipStream_t stream);
+// Number of workgroups fdb_launch_scan_dense will actually launch for `grid_blocks` requested (clamped to the tile count).
+int fdb_scan_grid(const FdbScanArgs& args, int grid_blocks, int rows_per_thread);
+// Folds the per-workgroup partial tables into the global table: state[arr * state_stride + slot] (op)= Σ_b partials[b][arr][slot],
+// in workgroup order (deterministic). funcs[arr]: 0 skip, 1 add u64, 2 add f64, 3 min i64, 4 max i64.
+hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_blocks, int n_arrays, uint32_t n_slots,
+                                      unsigned long long* state, uint64_t state_stride, const int32_t* funcs, hipStream_t stream);
+int fdb_slot_kernel_block(void);      // threads per workgroup of the slot kernel
+int fdb_slot_kernel_blocks_per_cu(int n_c4, int n_c8);
 hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value, int64_t n, hipStream_t stream);
+// base[a * n + i] = idents[a] for a < n_arrays (≤ 1 + FDB_MAX_AGGS), i < n: the whole partial table in one launch.
+hipError_t fdb_launch_fill_state(unsigned long long* base, int64_t n, int n_arrays, const unsigned long long* idents, hipStream_t stream);
 // dst[map[i]] (op)= src[i] for i < n; op: fdb_agg_func (SUM/COUNT add, MIN/MAX signed 64-bit, f64 SUM when is_f64).
 hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long long* src, const uint32_t* map,
                                 int64_t n, int32_t func, int32_t is_f64, hipStream_t stream);

@@ -226,16 +226,22 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
     if (row0 < a.n_rows) {
       const int64_t left = a.n_rows - row0;
       const uint32_t in_range = left >= R ? FULL : ((1u << (int)left) - 1u);
-      sel = eval_filter<R>(a, row0, smem) & in_range;
+      sel = ((a.ablate & 8) ? FULL : eval_filter<R>(a, row0, smem)) & in_range;
     }
     if (__ballot(sel != 0) == 0ull) continue;  // whole wave filtered out: skip the group/value columns
     if (row0 >= a.n_rows) continue;            // (lanes past the end hold sel == 0; keep their loads in bounds)
 
     uint32_t gid[R];
-    group_slots<R>(a, row0, smem, gid);
+    if (a.ablate & 4) {
+#pragma unroll
+      for (int r = 0; r < R; r++) gid[r] = 0;
+    } else {
+      group_slots<R>(a, row0, smem, gid);
+    }
 
     // occupancy / COUNT
-    if (LDS) {
+    if (a.ablate & 1) {
+    } else if (LDS) {
       if (a.need_count) {
 #pragma unroll
         for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&l_cnt[gid[r]], 1u);
@@ -257,6 +263,278 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
       load_u64<R>(reinterpret_cast<const unsigned long long*>(A.values) + row0, raw);
       // A NULL contributes the builder's zeroed slot: 0 to SUM *and* to MIN/MAX (aggregate.go:784-935 read raw
       // values; pqarrow/builder/optbuilders.go:337-340 zero-fills).
+#pragma unroll
+      for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = 0ull;
+      unsigned long long* acc = LDS ? (l_acc + (size_t)j * n_slots) : A.acc;
+      if (a.ablate & 2) {
+        unsigned long long x = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) x ^= raw[r];
+        if (x == 0x123456789abcdefull) acc[0] = x;
+      } else if (A.func == AGG_SUM) {
+        if (A.type == FDB_T_F64) {
+#pragma unroll
+          for (int r = 0; r < R; r++)
+            if ((sel >> r) & 1u) atomicAdd(reinterpret_cast<double*>(acc) + gid[r], __longlong_as_double((long long)raw[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(acc + gid[r], raw[r]);
+        }
+      } else {
+        long long key[R];
+        if (A.type == FDB_T_F64) {
+#pragma unroll
+          for (int r = 0; r < R; r++) key[r] = f64_to_ordered(__longlong_as_double((long long)raw[r]));
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) key[r] = (long long)raw[r];
+        }
+        if (A.func == AGG_MIN) {
+#pragma unroll
+          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicMin(reinterpret_cast<long long*>(acc) + gid[r], key[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicMax(reinterpret_cast<long long*>(acc) + gid[r], key[r]);
+        }
+      }
+    }
+  }
+
+  if (LDS && a.partials != nullptr) {
+    // Flush without atomics: this workgroup's table goes out as plain coalesced stores; a small second kernel
+    // folds the tables in workgroup order (512 workgroups hammering 1 025 addresses with atomics cost ≈10 µs).
+    __syncthreads();
+    unsigned long long* out = a.partials + (size_t)blockIdx.x * (size_t)(1 + a.n_aggs) * n_slots;
+    for (uint32_t i = tid; i < n_slots; i += FDB_BLOCK) out[i] = (unsigned long long)l_cnt[i];
+    for (int j = 0; j < a.n_aggs; j++) {
+      if (a.aggs[j].func == AGG_COUNT) continue;
+      for (uint32_t i = tid; i < n_slots; i += FDB_BLOCK) out[(size_t)(1 + j) * n_slots + i] = l_acc[(size_t)j * n_slots + i];
+    }
+  } else if (LDS) {
+    __syncthreads();
+    for (uint32_t i = tid; i < n_slots; i += FDB_BLOCK) {
+      const uint32_t c = l_cnt[i];
+      if (c == 0) continue;
+      atomicAdd(&a.cnt[i], (unsigned long long)c);
+      for (int j = 0; j < a.n_aggs; j++) {
+        const FdbAgg& A = a.aggs[j];
+        if (A.func == AGG_COUNT) continue;
+        const unsigned long long v = l_acc[(size_t)j * n_slots + i];
+        if (A.func == AGG_SUM) {
+          if (A.type == FDB_T_F64) atomicAdd(reinterpret_cast<double*>(A.acc) + i, __longlong_as_double((long long)v));
+          else atomicAdd(A.acc + i, v);
+        } else if (A.func == AGG_MIN) {
+          atomicMin(reinterpret_cast<long long*>(A.acc) + i, (long long)v);
+        } else {
+          atomicMax(reinterpret_cast<long long*>(A.acc) + i, (long long)v);
+        }
+      }
+    }
+  }
+}
+
+
+// =========================================================================================================
+// Slot kernel: same semantics as scan_dense_kernel, but every referenced column of a tile is LOADED FIRST
+// (≤ FDB_MAX_C4 four-byte + FDB_MAX_C8 eight-byte column slots, fully unrolled, wave-uniform predicates) and
+// only then consumed. The sequential kernel keeps one column in flight per wave (16 B/lane): with 32 waves
+// per CU that is 32 KiB per CU, below the ≈50 KiB HBM latency×bandwidth product, and it measured 6.0 TB/s
+// whatever work was ablated. Here a cfg-2 wave has 66 B/lane in flight.
+// =========================================================================================================
+#define SLOT_BLOCK 512
+
+template <int NC4, int NC8>
+struct SlotRegs {
+  u32x4 r4[NC4];
+  u64x2 r8[NC8][2];
+  uint32_t v4[NC4];
+  uint32_t v8[NC8];
+};
+
+template <int NC4, int NC8>
+__device__ __forceinline__ void slot_load(const FdbScanArgs& a, int64_t row0, SlotRegs<NC4, NC8>& S) {
+#pragma unroll
+  for (int s = 0; s < NC4; s++) {
+    S.r4[s] = u32x4{0, 0, 0, 0};
+    S.v4[s] = 0xFu;
+    if (s < a.n_c4) {
+      if (a.c4[s].values != nullptr) S.r4[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(a.c4[s].values) + row0));
+      if (a.c4[s].validity != nullptr) S.v4[s] = load_valid<4>(a.c4[s].validity, row0);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NC8; s++) {
+    S.r8[s][0] = u64x2{0, 0};
+    S.r8[s][1] = u64x2{0, 0};
+    S.v8[s] = 0xFu;
+    if (s < a.n_c8) {
+      if (a.c8[s].values != nullptr) {
+        const u64x2* p = reinterpret_cast<const u64x2*>(reinterpret_cast<const unsigned long long*>(a.c8[s].values) + row0);
+        S.r8[s][0] = __builtin_nontemporal_load(p);
+        S.r8[s][1] = __builtin_nontemporal_load(p + 1);
+      }
+      if (a.c8[s].validity != nullptr) S.v8[s] = load_valid<4>(a.c8[s].validity, row0);
+    }
+  }
+}
+
+template <int NC4, int NC8>
+__device__ __forceinline__ void pick4(const SlotRegs<NC4, NC8>& S, int slot, uint32_t (&idx)[4], uint32_t& valid) {
+  u32x4 q = S.r4[0];
+  valid = S.v4[0];
+#pragma unroll
+  for (int s = 1; s < NC4; s++)
+    if (slot == s) { q = S.r4[s]; valid = S.v4[s]; }
+  idx[0] = q.x; idx[1] = q.y; idx[2] = q.z; idx[3] = q.w;
+}
+
+template <int NC4, int NC8>
+__device__ __forceinline__ void pick8(const SlotRegs<NC4, NC8>& S, int slot, unsigned long long (&raw)[4], uint32_t& valid) {
+  u64x2 q0 = S.r8[0][0], q1 = S.r8[0][1];
+  valid = S.v8[0];
+#pragma unroll
+  for (int s = 1; s < NC8; s++)
+    if (slot == s) { q0 = S.r8[s][0]; q1 = S.r8[s][1]; valid = S.v8[s]; }
+  raw[0] = q0.x; raw[1] = q0.y; raw[2] = q1.x; raw[3] = q1.y;
+}
+
+template <int NC4, int NC8>
+__device__ __forceinline__ uint32_t slot_eval_leaf(const FdbLeaf& L, const SlotRegs<NC4, NC8>& S, const unsigned char* smem) {
+  constexpr int R = 4;
+  constexpr uint32_t FULL = 0xFu;
+  if (L.kind == FDB_LEAF_CONST) return L.op ? FULL : 0u;
+  uint32_t valid, m = 0;
+  if (!L.wide) {
+    uint32_t idx[R];
+    pick4(S, L.slot, idx, valid);
+    if (L.kind == FDB_LEAF_VALIDITY) return L.op ? valid : (~valid & FULL);
+    if (L.lut_lds != FDB_NO_LDS) {
+      const unsigned char* lut = smem + L.lut_lds;
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)lut[((valid >> r) & 1u) ? idx[r] : 0u] << r;
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)L.lut[((valid >> r) & 1u) ? idx[r] : 0u] << r;
+    }
+    return m & valid;
+  }
+  unsigned long long raw[R];
+  pick8(S, L.slot, raw, valid);
+  if (L.kind == FDB_LEAF_VALIDITY) return L.op ? valid : (~valid & FULL);
+  if (L.kind == FDB_LEAF_CMP_I64) {
+    long long v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = (long long)raw[r];
+    m = cmp_mask<R, long long>(v, (long long)L.lit, L.op);
+  } else if (L.kind == FDB_LEAF_CMP_U64) {
+    m = cmp_mask<R, unsigned long long>(raw, (unsigned long long)L.lit, L.op);
+  } else if (L.kind == FDB_LEAF_CMP_F64) {
+    double v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = __longlong_as_double((long long)raw[r]);
+    m = cmp_mask<R, double>(v, __longlong_as_double(L.lit), L.op);
+  } else {
+    double v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = (double)(long long)raw[r];
+    m = cmp_mask<R, double>(v, __longlong_as_double(L.lit), L.op);
+  }
+  return m & valid;
+}
+
+template <bool LDS, int NC4, int NC8, int MINW>
+__global__ __launch_bounds__(SLOT_BLOCK, MINW) void scan_slots_kernel(const FdbScanArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int R = 4;
+  constexpr uint32_t FULL = 0xFu;
+  const int tid = threadIdx.x;
+  const uint32_t n_slots = a.n_slots;
+
+  for (int l = 0; l < a.n_leaves; l++) {
+    const FdbLeaf& L = a.leaves[l];
+    if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
+      for (uint32_t i = tid; i < L.lut_len; i += SLOT_BLOCK) smem[L.lut_lds + i] = L.lut[i];
+  }
+  for (int g = 0; g < a.n_gcols; g++) {
+    const FdbGroupCol& G = a.gcols[g];
+    if (G.lut_lds != FDB_NO_LDS) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(smem + G.lut_lds);
+      for (uint32_t i = tid; i < G.lut_len; i += SLOT_BLOCK) dst[i] = G.lut[i];
+    }
+  }
+  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(smem + a.lds_lut_bytes);
+  unsigned long long* l_acc =
+      reinterpret_cast<unsigned long long*>(smem + a.lds_lut_bytes + (((size_t)n_slots * 4 + 15) & ~(size_t)15));
+  if (LDS) {
+    for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) l_cnt[i] = 0;
+    for (int j = 0; j < a.n_aggs; j++) {
+      const unsigned long long ident = agg_identity(a.aggs[j].func, a.aggs[j].type);
+      for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) l_acc[(size_t)j * n_slots + i] = ident;
+    }
+  }
+  __syncthreads();
+
+  const int64_t tile_rows = (int64_t)SLOT_BLOCK * R;
+  const int64_t n_tiles = (a.n_rows + tile_rows - 1) / tile_rows;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * tile_rows + (int64_t)tid * R;
+    if (row0 >= a.n_rows) continue;
+    SlotRegs<NC4, NC8> S;
+    slot_load(a, row0, S);
+
+    const int64_t left = a.n_rows - row0;
+    uint32_t sel = left >= R ? FULL : ((1u << (int)left) - 1u);
+    if (a.n_code != 0) {
+      unsigned long long st = 0;
+      for (int pc = 0; pc < a.n_code; pc++) {
+        const uint32_t c = a.code[pc];
+        if (c < 0x80u) {
+          st = (st << 8) | (unsigned long long)slot_eval_leaf(a.leaves[c], S, smem);
+        } else {
+          const unsigned long long top = st & 0xFFull;
+          st >>= 8;
+          if (c == FDB_CODE_AND) st = (st & ~0xFFull) | ((st & 0xFFull) & top);
+          else st = st | top;
+        }
+      }
+      sel &= (uint32_t)st;
+    }
+    if (sel == 0) continue;
+
+    uint32_t gid[R] = {0, 0, 0, 0};
+    for (int g = 0; g < a.n_gcols; g++) {
+      const FdbGroupCol& G = a.gcols[g];
+      uint32_t idx[R], valid;
+      pick4(S, G.slot, idx, valid);
+      if (G.lut_lds != FDB_NO_LDS) {
+        const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + G.lut_lds);
+#pragma unroll
+        for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? lut[idx[r]] : 0u) * G.stride;
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? G.lut[idx[r]] : 0u) * G.stride;
+      }
+    }
+
+    if (LDS) {
+      if (a.need_count) {
+#pragma unroll
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&l_cnt[gid[r]], 1u);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) l_cnt[gid[r]] = 1u;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&a.cnt[gid[r]], 1ull);
+    }
+
+    for (int j = 0; j < a.n_aggs; j++) {
+      const FdbAgg& A = a.aggs[j];
+      if (A.func == AGG_COUNT) continue;
+      unsigned long long raw[R];
+      uint32_t valid;
+      pick8(S, A.slot, raw, valid);
 #pragma unroll
       for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = 0ull;
       unsigned long long* acc = LDS ? (l_acc + (size_t)j * n_slots) : A.acc;
@@ -289,9 +567,19 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
     }
   }
 
-  if (LDS) {
+  if (LDS && a.partials != nullptr) {
+    // Flush without atomics: this workgroup's table goes out as plain coalesced stores; a small second kernel
+    // folds the tables in workgroup order (512 workgroups hammering 1 025 addresses with atomics cost ≈10 µs).
     __syncthreads();
-    for (uint32_t i = tid; i < n_slots; i += FDB_BLOCK) {
+    unsigned long long* out = a.partials + (size_t)blockIdx.x * (size_t)(1 + a.n_aggs) * n_slots;
+    for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) out[i] = (unsigned long long)l_cnt[i];
+    for (int j = 0; j < a.n_aggs; j++) {
+      if (a.aggs[j].func == AGG_COUNT) continue;
+      for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) out[(size_t)(1 + j) * n_slots + i] = l_acc[(size_t)j * n_slots + i];
+    }
+  } else if (LDS) {
+    __syncthreads();
+    for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) {
       const uint32_t c = l_cnt[i];
       if (c == 0) continue;
       atomicAdd(&a.cnt[i], (unsigned long long)c);
@@ -314,6 +602,54 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
 
 __global__ void fill_u64_kernel(unsigned long long* dst, unsigned long long value, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = value;
+}
+
+struct FillIdents { unsigned long long v[1 + FDB_MAX_AGGS]; };
+__global__ void fill_state_kernel(unsigned long long* base, int64_t n, int n_arrays, FillIdents idents) {
+  const int64_t total = n * n_arrays;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) base[i] = idents.v[i / n];
+}
+
+// One workgroup = 64 consecutive slots of one array; its 16 waves each fold a contiguous run of workgroup
+// tables (loads are independent, so dozens are in flight per lane), then wave 0 folds the 16 results in order.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const unsigned long long* __restrict__ partials, int n_blocks, int n_arrays,
+                                                               uint32_t n_slots, unsigned long long* state, uint64_t state_stride,
+                                                               FillIdents funcs) {
+  __shared__ unsigned long long part[16][64];
+  const int arr = blockIdx.y;
+  const int f = (int)funcs.v[arr];
+  if (f == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t slot = blockIdx.x * 64 + lane;
+  const int per = (n_blocks + 15) / 16;
+  const int b0 = wave * per, b1 = min(n_blocks, b0 + per);
+  unsigned long long acc = f == 3 ? (unsigned long long)FDB_I64_MAX : f == 4 ? (unsigned long long)FDB_I64_MIN : 0ull;
+  if (slot < n_slots) {
+    const unsigned long long* p = partials + (size_t)arr * n_slots + slot;
+    const size_t stride = (size_t)n_arrays * n_slots;
+#pragma unroll 8
+    for (int b = b0; b < b1; b++) {
+      const unsigned long long v = p[(size_t)b * stride];
+      if (f == 1) acc += v;
+      else if (f == 2) acc = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)acc) + __longlong_as_double((long long)v));
+      else if (f == 3) acc = (unsigned long long)min((long long)acc, (long long)v);
+      else acc = (unsigned long long)max((long long)acc, (long long)v);
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && slot < n_slots) {
+    unsigned long long* dst = state + (size_t)arr * state_stride + slot;
+    unsigned long long t = *dst;
+    for (int w = 0; w < 16; w++) {
+      const unsigned long long v = part[w][lane];
+      if (f == 1) t += v;
+      else if (f == 2) t = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)t) + __longlong_as_double((long long)v));
+      else if (f == 3) t = (unsigned long long)min((long long)t, (long long)v);
+      else t = (unsigned long long)max((long long)t, (long long)v);
+    }
+    *dst = t;
+  }
 }
 
 __global__ void merge_u64_kernel(unsigned long long* dst, const unsigned long long* src, const uint32_t* map, int64_t n,
@@ -455,7 +791,50 @@ int fdb_scan_default_grid(int device) {
   return 2 * g_cu_count[device];
 }
 
+int fdb_slot_kernel_block(void) { return SLOT_BLOCK; }
+// Workgroups per CU the slot kernel instance for (n_c4, n_c8) is compiled for (register-bound).
+int fdb_slot_kernel_blocks_per_cu(int n_c4, int n_c8) {
+  if (n_c4 <= 2 && n_c8 <= 1) return 4;
+  return 3;
+}
+
+int fdb_scan_grid(const FdbScanArgs& args, int grid_blocks, int rows_per_thread) {
+  const int64_t tile_rows = rows_per_thread == 0 ? (int64_t)SLOT_BLOCK * 4 : (int64_t)FDB_BLOCK * rows_per_thread;
+  const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
+  return (int)(grid_blocks > n_tiles ? n_tiles : grid_blocks);
+}
+
+hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_blocks, int n_arrays, uint32_t n_slots,
+                                      unsigned long long* state, uint64_t state_stride, const int32_t* funcs, hipStream_t stream) {
+  if (n_blocks <= 0 || n_slots == 0) return hipSuccess;
+  FillIdents f;
+  for (int a = 0; a < 1 + FDB_MAX_AGGS; a++) f.v[a] = a < n_arrays ? (unsigned long long)funcs[a] : 0ull;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_slots + 63) / 64, n_arrays), dim3(1024), 0, stream, partials, n_blocks, n_arrays,
+                     n_slots, state, state_stride, f);
+  return hipGetLastError();
+}
+
 hipError_t fdb_launch_scan_dense(const FdbScanArgs& args, int grid_blocks, size_t lds_bytes, int rows_per_thread, hipStream_t stream) {
+  if (rows_per_thread == 0) {
+    const int64_t tile_rows = (int64_t)SLOT_BLOCK * 4;
+    const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
+    if (n_tiles == 0) return hipSuccess;
+    if (grid_blocks > n_tiles) grid_blocks = (int)n_tiles;
+    // the smallest register footprint that holds the plan's column slots (waves/SIMD: 8 / 8 / 6 / 5)
+#define FDB_SLOT_LAUNCH(NC4, NC8, MINW)                                                                                              \
+    if (args.lds_acc) {                                                                                                               \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_slots_kernel<true, NC4, NC8, MINW>),                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                               \
+      hipLaunchKernelGGL((scan_slots_kernel<true, NC4, NC8, MINW>), dim3(grid_blocks), dim3(SLOT_BLOCK), lds_bytes, stream, args);     \
+    } else {                                                                                                                          \
+      hipLaunchKernelGGL((scan_slots_kernel<false, NC4, NC8, MINW>), dim3(grid_blocks), dim3(SLOT_BLOCK), lds_bytes, stream, args);    \
+    }
+    if (args.n_c4 <= 2 && args.n_c8 <= 1) { FDB_SLOT_LAUNCH(2, 1, 8) }
+    else if (args.n_c4 <= 3 && args.n_c8 <= 2) { FDB_SLOT_LAUNCH(3, 2, 6) }
+    else { FDB_SLOT_LAUNCH(4, 3, 4) }
+#undef FDB_SLOT_LAUNCH
+    return hipGetLastError();
+  }
   const int64_t tile_rows = (int64_t)FDB_BLOCK * rows_per_thread;
   const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
   if (n_tiles == 0) return hipSuccess;
@@ -484,6 +863,16 @@ hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(fill_u64_kernel, dim3(blocks), dim3(256), 0, stream, dst, value, n);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_fill_state(unsigned long long* base, int64_t n, int n_arrays, const unsigned long long* idents, hipStream_t stream) {
+  if (n <= 0 || n_arrays <= 0) return hipSuccess;
+  FillIdents f;
+  for (int a = 0; a < 1 + FDB_MAX_AGGS; a++) f.v[a] = a < n_arrays ? idents[a] : 0ull;
+  int blocks = (int)((n * n_arrays + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_state_kernel, dim3(blocks), dim3(256), 0, stream, base, n, n_arrays, f);
   return hipGetLastError();
 }
 

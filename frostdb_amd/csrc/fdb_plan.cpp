@@ -10,11 +10,31 @@
 //   * result naming and schema                                 aggregate.go:47, :543-633
 #include "fdb_plan.h"
 
+#include "fdb_context.h"
+
 #include <algorithm>
 #include <cstring>
 #include <functional>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace fdb {
+
+namespace {
+struct PhaseTimer {  // FDB_PROFILE=1: per-phase host microseconds of push_batch on stderr (tuning aid)
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PhaseTimer() : on(std::getenv("FDB_PROFILE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[fdb] %-14s %8.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
+    t = n;
+  }
+};
+}  // namespace
 
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) throw Error(e == hipErrorOutOfMemory ? FDB_ERR_OOM : FDB_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
@@ -53,46 +73,6 @@ bool match_group(const GroupMatcher& m, const std::string& field) {  // logicalp
 }
 
 }  // namespace
-
-// ---------------------------------------------------------------------------------------------------------
-// Pinned-host + device scratch. Small per-batch tables (LUTs, slot maps) are packed into one pinned block
-// and shipped with ONE hipMemcpyAsync; the pool is recycled whenever the stream has been synchronised.
-// ---------------------------------------------------------------------------------------------------------
-class BumpPool {
- public:
-  explicit BumpPool(hipStream_t s) : stream_(s) {}
-  ~BumpPool() { release(); }
-  // two-step API used by Plan::upload
-  void* stage(const void* host, size_t payload) {
-    const size_t bytes = align_up(payload ? payload : 1, 256);
-    if (off_ + bytes > cap_) grow(bytes);
-    if (payload) std::memcpy(h_ + off_, host, payload);
-    void* dst = d_ + off_;
-    hip_check(hipMemcpyAsync(dst, h_ + off_, bytes, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(LUT upload)");
-    off_ += bytes;
-    return dst;
-  }
-  void reset() { off_ = 0; }  // caller guarantees the stream is idle
- private:
-  void grow(size_t need) {
-    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(pool)");
-    if (need <= cap_) { off_ = 0; return; }
-    release();
-    cap_ = std::max<size_t>(align_up(need * 2, 1 << 20), 1 << 20);
-    hip_check(hipHostMalloc((void**)&h_, cap_, hipHostMallocDefault), "hipHostMalloc(pool)");
-    hip_check(hipMalloc((void**)&d_, cap_), "hipMalloc(pool)");
-    off_ = 0;
-  }
-  void release() {
-    if (h_) (void)hipHostFree(h_);
-    if (d_) (void)hipFree(d_);
-    h_ = nullptr; d_ = nullptr; cap_ = 0; off_ = 0;
-  }
-  hipStream_t stream_;
-  unsigned char* h_ = nullptr;
-  unsigned char* d_ = nullptr;
-  size_t cap_ = 0, off_ = 0;
-};
 
 // ---------------------------------------------------------------------------------------------------------
 // DeviceBatch
@@ -241,19 +221,19 @@ Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
     matchers_.push_back(GroupMatcher{d->groups[i].name, d->groups[i].dynamic != 0});
   }
   hip_check(hipSetDevice(device_), "hipSetDevice");
-  hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
-  pool_.reset(new BumpPool(stream_));
+  ctx_ = Context::acquire(device_);
+  stream_ = ctx_->stream;
 }
 
 Plan::~Plan() {
+  if (ctx_ == nullptr) return;
   (void)hipSetDevice(device_);
-  if (stream_) (void)hipStreamSynchronize(stream_);
-  pool_.reset();
-  for (auto& a : aggs_) if (a.d_acc) (void)hipFree(a.d_acc);
-  if (d_cnt_) (void)hipFree(d_cnt_);
-  for (auto& p : pending_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-  for (auto e : free_events_) (void)hipEventDestroy(e);
-  if (stream_) (void)hipStreamDestroy(stream_);
+  (void)hipStreamSynchronize(stream_);
+  for (auto& p : pending_events_) { ctx_->put_event(p.first); ctx_->put_event(p.second); }
+  ctx_->dev_free(d_state_);
+  for (void* p : scratch_) ctx_->dev_free(p);
+  ctx_->reset_staging();
+  Context::release(ctx_);
 }
 
 bool Plan::references(const std::string& column) const {
@@ -267,20 +247,22 @@ void Plan::sync() {
   hip_check(hipSetDevice(device_), "hipSetDevice");
   hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   collect_timing();
-  pool_->reset();
+  ctx_->reset_staging();
+  for (void* p : scratch_) ctx_->dev_free(p);
+  scratch_.clear();
 }
 
 void Plan::collect_timing() {
   for (auto& p : pending_events_) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) stat_ms += ms;
-    free_events_.push_back(p.first);
-    free_events_.push_back(p.second);
+    ctx_->put_event(p.first);
+    ctx_->put_event(p.second);
   }
   pending_events_.clear();
 }
 
-void* Plan::upload(const void* host, size_t bytes) { return pool_->stage(host, bytes); }
+void* Plan::upload(const void* host, size_t bytes) { return ctx_->stage(host, bytes); }
 
 const char* Plan::draw() {
   if (draw_.empty()) {
@@ -347,13 +329,22 @@ struct Plan::Resolved {
   FdbScanArgs args;
   Blob blob;
   std::vector<PendingLut> luts;
-  std::vector<char> counted;  // per batch column: already counted in algorithmic bytes
+  std::vector<char> counted;  // per batch column: bit 0 values, bit 1 validity already counted in algorithmic bytes
   int64_t bytes = 0;
-  void count(const DeviceBatch& b, int ci) {
+  int leaf_col[FDB_MAX_LEAVES];           // batch column behind each leaf (-1: constant leaf)
+  int gcol_col[FDB_MAX_DENSE_GCOLS];
+  int agg_col[FDB_MAX_AGGS];
+  Resolved() {
+    for (int& v : leaf_col) v = -1;
+    for (int& v : gcol_col) v = -1;
+    for (int& v : agg_col) v = -1;
+  }
+  // Algorithmic bytes: each referenced buffer once per row, whatever the number of references.
+  void count(const DeviceBatch& b, int ci, bool values = true) {
     if (counted.empty()) counted.assign(b.cols.size(), 0);
-    if (counted[(size_t)ci]) return;
-    counted[(size_t)ci] = 1;
-    bytes += b.cols[(size_t)ci].value_bytes + b.cols[(size_t)ci].validity_bytes;
+    char& c = counted[(size_t)ci];
+    if (values && !(c & 1)) { c |= 1; bytes += b.cols[(size_t)ci].value_bytes; }
+    if (!(c & 2)) { c |= 2; bytes += b.cols[(size_t)ci].validity_bytes; }
   }
 };
 
@@ -375,6 +366,7 @@ static void emit_filter(const std::vector<ExprNode>& nodes, int idx, const Devic
   FdbLeaf L;
   std::memset(&L, 0, sizeof(L));
   L.lut_lds = FDB_NO_LDS;
+  L.slot = -1;
   R->luts.reserve(64);
   const int li = a.n_leaves;
   a.leaves[li] = L;
@@ -418,16 +410,19 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
       throw Error(FDB_ERR_UNSUPPORTED, "ArrayScalarRegexMatch: unsupported dictionary type: *array.String");
     if (!is_regex && !is_contains && e.op != FDB_OP_EQ && e.op != FDB_OP_NOT_EQ)
       throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported operator: ") + op_str(e.op));  // binaryscalarexpr.go:106-108
-    R->count(b, ci);
     L->values = c.d_values;
     L->validity = c.d_validity;
+    L->wide = 0;
+    R->leaf_col[li] = ci;
     if (!is_regex && !e.lit.valid()) {
       // == NULL ⇒ IS NULL, != NULL ⇒ IS NOT NULL (:165-172, :205-212); contains/not-contains NULL ⇒ every non-null row (:287-295)
+      if (c.d_validity == nullptr) { R->leaf_col[li] = -1; set_const(e.op != FDB_OP_EQ); return; }  // no NULLs in this record
       L->kind = FDB_LEAF_VALIDITY;
       L->op = (e.op == FDB_OP_EQ) ? 0 : 1;
-      // the index buffer is not read by this leaf: only the bitmap counts
+      R->count(b, ci, /*values=*/false);  // the index buffer is not read by this leaf: only the bitmap counts
       return;
     }
+    R->count(b, ci);
     std::vector<uint8_t> lut = dict_pred_lut(e, *c.dict);
     L->kind = FDB_LEAF_DICT_LUT;
     L->lut_len = (uint32_t)lut.size();
@@ -446,6 +441,8 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
   L->values = c.d_values;
   L->validity = c.d_validity;
   L->op = e.op;
+  L->wide = 1;
+  R->leaf_col[li] = ci;
   auto dbits = [](double d) { int64_t v; std::memcpy(&v, &d, 8); return v; };
   if (c.kind == ColKind::I64) {
     if (e.lit.type == FDB_LIT_INT64) { L->kind = FDB_LEAF_CMP_I64; L->lit = e.lit.i64; return; }
@@ -458,6 +455,41 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
     if (e.lit.type == FDB_LIT_INT64) { L->kind = FDB_LEAF_CMP_F64; L->lit = dbits((double)e.lit.i64); return; }
   }
   throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation (column/literal type combination) on " + c.name);
+}
+
+// ---- group-key dictionaries ---------------------------------------------------------------------------------
+void GroupColState::build_ids() {
+  if (ids_built_ == values.size()) return;
+  ids_.reserve(values.size() * 2);
+  for (; ids_built_ < values.size(); ids_built_++) ids_.emplace(values[ids_built_], (uint32_t)ids_built_ + 1);
+}
+
+uint32_t GroupColState::intern(std::string_view v) {
+  build_ids();
+  auto it = ids_.find(v);
+  if (it != ids_.end()) return it->second;
+  values.push_back(v);
+  ids_.emplace(v, (uint32_t)values.size());
+  ids_built_ = values.size();
+  return (uint32_t)values.size();
+}
+
+std::shared_ptr<const std::vector<uint32_t>> GroupColState::lut_for(const std::shared_ptr<HostDict>& d) {
+  auto range = lut_cache_.equal_range(d->hash);
+  for (auto it = range.first; it != range.second; ++it)
+    if (it->second.dict.get() == d.get() || it->second.dict->same_content(*d)) return it->second.lut;
+  auto lut = std::make_shared<std::vector<uint32_t>>(std::max<size_t>(d->values.size(), 1), 0u);
+  owners.push_back(d);
+  if (values.empty() && d->unique) {
+    // first dictionary of this column: ids are entry + 1, no hashing at all (the hash map is built only if a
+    // different dictionary ever shows up)
+    values.reserve(d->values.size());
+    for (size_t e = 0; e < d->values.size(); e++) { values.emplace_back(d->values[e]); (*lut)[e] = (uint32_t)e + 1; }
+  } else {
+    for (size_t e = 0; e < d->values.size(); e++) (*lut)[e] = intern(std::string_view(d->values[e]));
+  }
+  lut_cache_.emplace(d->hash, Cached{d, lut});
+  return lut;
 }
 
 // ---- table layout ----------------------------------------------------------------------------------------
@@ -474,21 +506,20 @@ void Plan::ensure_layout(const std::vector<uint32_t>& new_caps) {
   bool remap = false;
   for (size_t c = 0; c < gcols_.size(); c++)
     if (gcols_[c].cap > 1 && gcols_[c].stride != new_strides[c]) remap = true;
-  const bool need_alloc = n_new > slots_alloc_ || d_cnt_ == nullptr || (remap && state_dirty_);
+  const bool need_alloc = n_new > slots_alloc_ || d_state_ == nullptr || (remap && state_dirty_);
   if (need_alloc) {
+    // One block holds the whole table: [cnt | acc 0 | acc 1 | …], each `alloc` slots long, identity-filled.
     const uint64_t cap = std::max<uint64_t>(n_new, 64);
     const uint64_t alloc = (remap && state_dirty_) ? cap : std::max<uint64_t>(cap, slots_alloc_ * 2);
-    unsigned long long* n_cnt = nullptr;
-    hip_check(hipMalloc((void**)&n_cnt, alloc * 8), "hipMalloc(cnt)");
-    hip_check(fdb_launch_fill_u64(n_cnt, 0ull, (int64_t)alloc, stream_), "fill");
-    std::vector<unsigned long long*> n_acc(aggs_.size(), nullptr);
+    const size_t n_arrays = 1 + aggs_.size();
+    unsigned long long* n_state = (unsigned long long*)ctx_->dev_alloc(alloc * 8 * n_arrays);
+    unsigned long long idents[1 + FDB_MAX_AGGS] = {0};
     for (size_t j = 0; j < aggs_.size(); j++) {
-      hip_check(hipMalloc((void**)&n_acc[j], alloc * 8), "hipMalloc(acc)");
       const int32_t f = aggs_[j].func;
-      const unsigned long long ident = f == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : f == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
-      hip_check(fdb_launch_fill_u64(n_acc[j], ident, (int64_t)alloc, stream_), "fill");
+      idents[1 + j] = f == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : f == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
     }
-    if (state_dirty_ && d_cnt_ != nullptr) {
+    hip_check(fdb_launch_fill_state(n_state, (int64_t)alloc, (int)n_arrays, idents, stream_), "fill state");
+    if (state_dirty_ && d_state_ != nullptr) {
       const uint32_t* d_map = nullptr;
       std::vector<uint32_t> map;
       if (remap) {
@@ -504,16 +535,18 @@ void Plan::ensure_layout(const std::vector<uint32_t>& new_caps) {
         }
         d_map = (const uint32_t*)upload(map.data(), map.size() * 4);
       }
-      hip_check(fdb_launch_merge_u64(n_cnt, d_cnt_, d_map, n_slots_, FDB_AGG_SUM, 0, stream_), "remap cnt");
+      hip_check(fdb_launch_merge_u64(n_state, d_cnt_, d_map, n_slots_, FDB_AGG_SUM, 0, stream_), "remap cnt");
       for (size_t j = 0; j < aggs_.size(); j++) {
         const int32_t f = (aggs_[j].func == FDB_AGG_COUNT) ? FDB_AGG_SUM : aggs_[j].func;
-        hip_check(fdb_launch_merge_u64(n_acc[j], aggs_[j].d_acc, d_map, n_slots_, f, aggs_[j].type == FDB_T_F64 && f == FDB_AGG_SUM, stream_), "remap acc");
+        hip_check(fdb_launch_merge_u64(n_state + (1 + j) * alloc, aggs_[j].d_acc, d_map, n_slots_, f,
+                                       aggs_[j].type == FDB_T_F64 && f == FDB_AGG_SUM, stream_), "remap acc");
       }
       hip_check(hipStreamSynchronize(stream_), "sync(remap)");
     }
-    if (d_cnt_) (void)hipFree(d_cnt_);
-    for (size_t j = 0; j < aggs_.size(); j++) { if (aggs_[j].d_acc) (void)hipFree(aggs_[j].d_acc); aggs_[j].d_acc = n_acc[j]; }
-    d_cnt_ = n_cnt;
+    ctx_->dev_free(d_state_);  // same stream ⇒ any later reuse is ordered after the kernels above
+    d_state_ = n_state;
+    d_cnt_ = n_state;
+    for (size_t j = 0; j < aggs_.size(); j++) aggs_[j].d_acc = n_state + (1 + j) * alloc;
     slots_alloc_ = alloc;
   }
   for (size_t c = 0; c < gcols_.size(); c++) { gcols_[c].cap = new_caps[c]; gcols_[c].stride = new_strides[c]; }
@@ -536,12 +569,14 @@ void Plan::push_batch(const DeviceBatch& b) {
   if (b.device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
   hip_check(hipSetDevice(device_), "hipSetDevice");
 
+  PhaseTimer pt;
   Resolved R;
   std::memset(&R.args, 0, sizeof(R.args));
   FdbScanArgs& a = R.args;
   a.n_rows = b.rows;
   int max_depth = 0;
   if (filter_root_ >= 0) emit_filter(filter_, filter_root_, b, &R, 0, &max_depth);
+  pt.mark("filter luts");
 
   // group columns: every field matched by a matcher, in the record's field order (aggregate.go:286-303)
   std::vector<int> batch_gcols;  // index into gcols_ per FdbGroupCol
@@ -568,15 +603,8 @@ void Plan::push_batch(const DeviceBatch& b) {
     }
     if (a.n_gcols >= FDB_MAX_DENSE_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "too many group-by columns for the dense path; hash path not built yet");
     GroupColState& g = gcols_[gi];
-    std::vector<uint32_t> lut(std::max<size_t>(c.dict->values.size(), 1), 0);
-    for (size_t e = 0; e < c.dict->values.size(); e++) {
-      auto it = g.ids.find(c.dict->values[e]);
-      if (it == g.ids.end()) {
-        g.values.push_back(c.dict->values[e]);
-        it = g.ids.emplace(c.dict->values[e], (uint32_t)g.values.size()).first;
-      }
-      lut[e] = it->second;
-    }
+    const std::shared_ptr<const std::vector<uint32_t>> lut_ptr = g.lut_for(c.dict);
+    const std::vector<uint32_t>& lut = *lut_ptr;
     caps[gi] = (uint32_t)g.values.size() + 1;
     R.count(b, (int)ci);
     FdbGroupCol& G = a.gcols[a.n_gcols];
@@ -584,12 +612,15 @@ void Plan::push_batch(const DeviceBatch& b) {
     G.validity = c.d_validity;
     G.lut_len = (uint32_t)lut.size();
     G.lut_lds = FDB_NO_LDS;
+    G.slot = -1;
+    R.gcol_col[a.n_gcols] = (int)ci;
     const size_t off = R.blob.add(lut.data(), lut.size() * 4);
     R.luts.push_back(PendingLut{1, a.n_gcols, off, lut.size() * 4});
     batch_gcols.push_back((int)gi);
     a.n_gcols++;
   }
 
+  pt.mark("group luts");
   // aggregated columns, by exact name (aggregate.go:340-361); all must be present (:367-380)
   a.n_aggs = (int32_t)aggs_.size();
   int found = 0;
@@ -609,6 +640,7 @@ void Plan::push_batch(const DeviceBatch& b) {
     FdbAgg& K = a.aggs[j];
     K.func = A.func;
     K.type = FDB_T_NONE;
+    K.slot = -1;
     if (A.func == FDB_AGG_COUNT && !final_stage_) {
       // CountAggregation = arr.Len(): only the row count matters; the column is not read (aggregate.go:937-950)
       continue;
@@ -623,16 +655,20 @@ void Plan::push_batch(const DeviceBatch& b) {
     K.type = t;
     K.values = c.d_values;
     K.validity = c.d_validity;
+    R.agg_col[j] = ci;
     if (A.func == FDB_AGG_COUNT) K.func = FDB_AGG_SUM;  // final stage: COUNT merges by SUM (aggregate.go:965-969)
   }
 
   if (b.rows == 0) return;
+  pt.mark("aggs");
   ensure_layout(caps);
+  pt.mark("layout");
   for (int g = 0; g < a.n_gcols; g++) a.gcols[g].stride = gcols_[(size_t)batch_gcols[(size_t)g]].stride;
   for (size_t j = 0; j < aggs_.size(); j++) a.aggs[j].acc = aggs_[j].d_acc;
   a.cnt = d_cnt_;
   a.n_slots = n_slots_;
   a.need_count = 0;
+  a.ablate = ablate;
   int n_acc_lds = 0;
   for (size_t j = 0; j < aggs_.size(); j++) {
     if (a.aggs[j].func == FDB_AGG_COUNT) a.need_count = 1; else n_acc_lds++;
@@ -649,6 +685,7 @@ void Plan::push_batch(const DeviceBatch& b) {
     else { a.gcols[p.index].lut = (const uint32_t*)(d_blob + p.blob_off); a.gcols[p.index].lut_lds = lds; }
   }
   a.lds_lut_bytes = (uint32_t)align_up(lds_off, 16);
+  pt.mark("lut upload");
   const size_t acc_bytes = align_up((size_t)n_slots_ * 4, 16) + (size_t)n_slots_ * 8 * aggs_.size();
   size_t lds_bytes = a.lds_lut_bytes;
   int grid = grid_override > 0 ? grid_override : fdb_scan_default_grid(device_);
@@ -663,17 +700,73 @@ void Plan::push_batch(const DeviceBatch& b) {
     a.lds_acc = 0;
   }
 
+  // Column slots for the load-hoisting kernel; plans that reference more columns than there are slots (or ask
+  // for an explicit rows-per-thread) run on the sequential kernel.
+  int kernel_rpt = rows_per_thread;
+  if (rows_per_thread == 0) {
+    int c4_col[FDB_MAX_C4], c8_col[FDB_MAX_C8];
+    bool ok = true;
+    auto slot_of = [&](int ci, bool wide, bool need_values) -> int {
+      const DevColumn& c = b.cols[(size_t)ci];
+      FdbColSlot* pool = wide ? a.c8 : a.c4;
+      int* cols = wide ? c8_col : c4_col;
+      int32_t& n = wide ? a.n_c8 : a.n_c4;
+      const int cap = wide ? FDB_MAX_C8 : FDB_MAX_C4;
+      for (int s = 0; s < n; s++)
+        if (cols[s] == ci) { if (need_values) pool[s].values = c.d_values; return s; }
+      if (n >= cap) { ok = false; return -1; }
+      cols[n] = ci;
+      pool[n].values = need_values ? c.d_values : nullptr;
+      pool[n].validity = c.d_validity;
+      return n++;
+    };
+    for (int l = 0; l < a.n_leaves && ok; l++) {
+      if (R.leaf_col[l] < 0) continue;
+      a.leaves[l].slot = slot_of(R.leaf_col[l], a.leaves[l].wide != 0, a.leaves[l].kind != FDB_LEAF_VALIDITY);
+    }
+    for (int g = 0; g < a.n_gcols && ok; g++) a.gcols[g].slot = slot_of(R.gcol_col[g], false, true);
+    for (int j = 0; j < a.n_aggs && ok; j++)
+      if (R.agg_col[j] >= 0 && a.aggs[j].values != nullptr) a.aggs[j].slot = slot_of(R.agg_col[j], true, true);
+    if (!ok) { kernel_rpt = 4; a.n_c4 = a.n_c8 = 0; }
+  }
+  if (kernel_rpt == 0 && grid_override <= 0) {
+    // geometry of the slot kernel: workgroups per CU bounded by registers (5 waves/SIMD) and LDS
+    const int cus = fdb_scan_default_grid(device_) / 2;
+    const int per_cu_regs = fdb_slot_kernel_blocks_per_cu(a.n_c4, a.n_c8);
+    const int per_cu_lds = a.lds_acc ? (int)((150 * 1024) / std::max<size_t>(lds_bytes, 1)) : per_cu_regs;
+    grid = cus * std::max(1, std::min(per_cu_regs, per_cu_lds));
+  }
+
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing) {
-    auto get = [&]() { hipEvent_t e; if (!free_events_.empty()) { e = free_events_.back(); free_events_.pop_back(); } else hip_check(hipEventCreate(&e), "hipEventCreate"); return e; };
-    e0 = get(); e1 = get();
+    e0 = ctx_->get_event(); e1 = ctx_->get_event();
     hip_check(hipEventRecord(e0, stream_), "hipEventRecord");
   }
-  hip_check(fdb_launch_scan_dense(a, grid, lds_bytes, rows_per_thread, stream_), "scan launch");
+  grid = fdb_scan_grid(a, grid, kernel_rpt);
+  if (a.lds_acc && use_partials && grid > 0) {
+    const size_t n_arrays = 1 + aggs_.size();
+    void* p = ctx_->dev_alloc((size_t)grid * n_arrays * n_slots_ * 8);
+    scratch_.push_back(p);
+    a.partials = (unsigned long long*)p;
+  }
+  pt.mark("slots+scratch");
+  hip_check(fdb_launch_scan_dense(a, grid, lds_bytes, kernel_rpt, stream_), "scan launch");
+  pt.mark("scan launch");
   if (timing) {
     hip_check(hipEventRecord(e1, stream_), "hipEventRecord");
     pending_events_.emplace_back(e0, e1);
   }
+  if (a.partials != nullptr) {
+    int32_t funcs[1 + FDB_MAX_AGGS] = {0};
+    funcs[0] = 1;
+    for (size_t j = 0; j < aggs_.size(); j++) {
+      const int32_t f = a.aggs[j].func;
+      funcs[1 + j] = f == FDB_AGG_COUNT ? 0 : f == FDB_AGG_SUM ? (a.aggs[j].type == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
+    }
+    hip_check(fdb_launch_reduce_partials(a.partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, stream_),
+              "reduce partials");
+  }
+  pt.mark("reduce launch");
   state_dirty_ = true;
   stat_bytes += R.bytes;
   stat_launches += 1;
@@ -682,15 +775,19 @@ void Plan::push_batch(const DeviceBatch& b) {
 
 // ---- finish / export ----------------------------------------------------------------------------------------
 void Plan::fetch_state(std::vector<unsigned long long>* cnt, std::vector<std::vector<unsigned long long>>* acc) {
-  sync();
-  cnt->assign(n_slots_, 0);
+  hip_check(hipSetDevice(device_), "hipSetDevice");
   acc->assign(aggs_.size(), {});
-  if (d_cnt_ == nullptr) { cnt->clear(); return; }
-  hip_check(hipMemcpy(cnt->data(), d_cnt_, (size_t)n_slots_ * 8, hipMemcpyDeviceToHost), "hipMemcpy(cnt)");
-  for (size_t j = 0; j < aggs_.size(); j++) {
-    (*acc)[j].assign(n_slots_, 0);
-    hip_check(hipMemcpy((*acc)[j].data(), aggs_[j].d_acc, (size_t)n_slots_ * 8, hipMemcpyDeviceToHost), "hipMemcpy(acc)");
-  }
+  if (d_state_ == nullptr) { sync(); cnt->clear(); return; }
+  // one device→pinned copy of the whole table, then one wait
+  const size_t n_arrays = 1 + aggs_.size();
+  const size_t bytes = (size_t)slots_alloc_ * 8 * n_arrays;
+  unsigned long long* h = (unsigned long long*)ctx_->host_alloc(bytes);
+  hipError_t e = hipMemcpyAsync(h, d_state_, bytes, hipMemcpyDeviceToHost, stream_);
+  if (e != hipSuccess) { ctx_->host_free(h); hip_check(e, "hipMemcpyAsync(state)"); }
+  try { sync(); } catch (...) { ctx_->host_free(h); throw; }
+  cnt->assign(h, h + n_slots_);
+  for (size_t j = 0; j < aggs_.size(); j++) (*acc)[j].assign(h + (1 + j) * slots_alloc_, h + (1 + j) * slots_alloc_ + n_slots_);
+  ctx_->host_free(h);
 }
 
 void Plan::build_key_columns(const std::vector<uint32_t>& slots, std::vector<OutColumn>* cols) const {
@@ -752,9 +849,11 @@ void Plan::build_agg_columns(const std::vector<uint32_t>& slots, const std::vect
 }
 
 void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
+  PhaseTimer pt;
   std::vector<unsigned long long> cnt;
   std::vector<std::vector<unsigned long long>> acc;
   fetch_state(&cnt, &acc);
+  pt.mark("finish: fetch");
   std::vector<uint32_t> slots;
   for (uint32_t s = 0; s < cnt.size(); s++) if (cnt[s] != 0) slots.push_back(s);
   std::vector<OutColumn> cols;
@@ -762,6 +861,7 @@ void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
   build_agg_columns(slots, cnt, acc, &cols);
   if (n_rows) *n_rows = (int64_t)slots.size();
   export_record(std::move(cols), (int64_t)slots.size(), out, out_schema);
+  pt.mark("finish: export");
   finished_ = true;
 }
 
@@ -826,7 +926,7 @@ void Plan::merge_from(Plan& src) {
   std::vector<size_t> col_map(src.gcols_.size());
   std::vector<std::vector<uint32_t>> id_map(src.gcols_.size());
   std::vector<uint32_t> caps;
-  for (const GroupColState& g : gcols_) caps.push_back(g.cap);
+  for (const GroupColState& g : gcols_) caps.push_back((uint32_t)g.values.size() + 1);
   for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
     const GroupColState& sg = src.gcols_[sc];
     size_t gi = 0;
@@ -840,11 +940,8 @@ void Plan::merge_from(Plan& src) {
     GroupColState& g = gcols_[gi];
     col_map[sc] = gi;
     id_map[sc].assign(sg.values.size() + 1, 0);
-    for (size_t v = 0; v < sg.values.size(); v++) {
-      auto it = g.ids.find(sg.values[v]);
-      if (it == g.ids.end()) { g.values.push_back(sg.values[v]); it = g.ids.emplace(sg.values[v], (uint32_t)g.values.size()).first; }
-      id_map[sc][v + 1] = it->second;
-    }
+    g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());
+    for (size_t v = 0; v < sg.values.size(); v++) id_map[sc][v + 1] = g.intern(sg.values[v]);
     caps[gi] = (uint32_t)g.values.size() + 1;
   }
   ensure_layout(caps);
@@ -871,10 +968,11 @@ void Plan::merge_from(Plan& src) {
 
 // ---- selection / filter-only -------------------------------------------------------------------------------------
 namespace {
-struct DevBuf {
+struct DevBuf {  // scratch from the context's caching allocator; the plan's stream orders every reuse
+  Context* ctx;
   void* p = nullptr;
-  explicit DevBuf(size_t bytes) { hip_check(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc(scratch)"); }
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf(Context* c, size_t bytes) : ctx(c), p(c->dev_alloc(bytes)) {}
+  ~DevBuf() { ctx->dev_free(p); }
   DevBuf(const DevBuf&) = delete;
 };
 }  // namespace
@@ -908,9 +1006,9 @@ void Plan::select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* 
   }
   a.lds_lut_bytes = (uint32_t)align_up(lds_off, 16);
   const int64_t n_tiles = (b->rows + FDB_BLOCK * 8 - 1) / (FDB_BLOCK * 8);
-  DevBuf scratch((size_t)((n_tiles + 3) & ~(int64_t)3) * 4 + (size_t)(b->rows + 7) / 8 + 64);
-  DevBuf d_idx((size_t)b->rows * 4);
-  DevBuf d_n(8);
+  DevBuf scratch(ctx_, (size_t)((n_tiles + 3) & ~(int64_t)3) * 4 + (size_t)(b->rows + 7) / 8 + 64);
+  DevBuf d_idx(ctx_, (size_t)b->rows * 4);
+  DevBuf d_n(ctx_, 8);
   hip_check(fdb_launch_select(a, (uint32_t*)d_idx.p, (unsigned long long*)d_n.p, (uint32_t*)scratch.p, stream_), "select launch");
   unsigned long long n = 0;
   hip_check(hipMemcpyAsync(&n, d_n.p, 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(n)");
@@ -930,7 +1028,7 @@ void Plan::filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray
   if (n == 0) return;  // filter.go:264-266
   // compaction of every column of the record (≙ slice + array.Concatenate, filter.go:296-320)
   std::unique_ptr<DeviceBatch> b = import_batch(view, device_, nullptr, stream_);
-  DevBuf d_idx((size_t)n * 4);
+  DevBuf d_idx(ctx_, (size_t)n * 4);
   hip_check(hipMemcpy(d_idx.p, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice), "hipMemcpy(indices)");
   std::vector<OutColumn> cols;
   for (const DevColumn& c : b->cols) {
@@ -941,13 +1039,13 @@ void Plan::filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray
     o.length = n;
     const int w = c.kind == ColKind::DICT ? 4 : 8;
     o.format = c.kind == ColKind::DICT ? "I" : c.format;
-    DevBuf d_out((size_t)n * w);
+    DevBuf d_out(ctx_, (size_t)n * w);
     hip_check(fdb_launch_gather(c.d_values, d_out.p, (const uint32_t*)d_idx.p, n, w, stream_), "gather");
     o.values.resize((size_t)n * w);
     hip_check(hipMemcpyAsync(o.values.data(), d_out.p, (size_t)n * w, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(gather out)");
     if (c.d_validity != nullptr) {
       const size_t vb = (size_t)((n + 63) / 64) * 8;
-      DevBuf d_bits(vb);
+      DevBuf d_bits(ctx_, vb);
       hip_check(fdb_launch_gather_bits(c.d_validity, (uint8_t*)d_bits.p, (const uint32_t*)d_idx.p, n, stream_), "gather bits");
       o.validity.resize(vb);
       hip_check(hipMemcpyAsync(o.validity.data(), d_bits.p, vb, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(bits)");

@@ -10,6 +10,7 @@
 #include <memory>
 #include <regex>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -76,19 +77,31 @@ struct AggState {
 };
 
 // One concrete group-by column, in first-seen order (≙ hashAggregate.colOrdering, aggregate.go:155).
+// Key ids are assigned per distinct dictionary VALUE, first seen first (id 0 is NULL / column absent), and
+// never change, so the entry→id table of a given dictionary is computed once and cached by content.
 struct GroupColState {
   std::string name;
-  std::string index_format = "I";
   std::string value_format = "z";
-  std::unordered_map<std::string, uint32_t> ids;  // dictionary value → key id (≥ 1); 0 is NULL / column absent
-  std::vector<std::string> values;                // id - 1 → value
-  uint32_t cap = 1;                               // ids live in [0, cap)
+  std::vector<std::string_view> values;                     // id - 1 → value (views into `owners`)
+  std::vector<std::shared_ptr<const HostDict>> owners;      // keep the viewed strings alive
+  uint32_t cap = 1;                                         // ids live in [0, cap)
   uint32_t stride = 1;
+
+  // entry → id table for dictionary `d` (assigns ids to values not seen before).
+  std::shared_ptr<const std::vector<uint32_t>> lut_for(const std::shared_ptr<HostDict>& d);
+  uint32_t intern(std::string_view v);                      // id of `v`, assigning the next id if new (caller keeps v alive via owners)
+
+ private:
+  struct Cached { std::shared_ptr<const HostDict> dict; std::shared_ptr<const std::vector<uint32_t>> lut; };
+  std::unordered_map<std::string_view, uint32_t> ids_;      // built lazily: values[0 .. ids_built_) are present
+  size_t ids_built_ = 0;
+  std::unordered_multimap<uint64_t, Cached> lut_cache_;     // by HostDict::hash
+  void build_ids();
 };
 
 struct GroupMatcher { std::string name; bool dynamic; };
 
-class BumpPool;  // pinned-host + device scratch for LUT uploads
+class Context;  // per-device stream + cached device/pinned memory (fdb_context.h)
 
 class Plan {
  public:
@@ -113,8 +126,10 @@ class Plan {
   bool timing = false;
   int64_t stat_bytes = 0, stat_launches = 0, stat_rows = 0;
   double stat_ms = 0;
-  int rows_per_thread = 8;
+  int rows_per_thread = 0;  // 0: slot (load-hoisting) kernel; 4 / 8: sequential kernel
   int grid_override = 0;
+  int ablate = 0;
+  bool use_partials = true;  // LDS mode: flush workgroup tables with plain stores + a fold kernel instead of atomics
   struct Resolved;  // per-batch kernel arguments (fdb_plan.cpp)
 
  private:
@@ -140,12 +155,13 @@ class Plan {
   std::vector<GroupColState> gcols_;
   uint32_t n_slots_ = 1;            // Π cap
   uint64_t slots_alloc_ = 0;        // allocated accumulator length
+  unsigned long long* d_state_ = nullptr;  // one block: [cnt | acc 0 | acc 1 | …], slots_alloc_ entries each
   unsigned long long* d_cnt_ = nullptr;
   bool state_dirty_ = false;        // any kernel has accumulated into the table
 
-  std::unique_ptr<BumpPool> pool_;
+  Context* ctx_ = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
-  std::vector<hipEvent_t> free_events_;
+  std::vector<void*> scratch_;  // device blocks in use by in-flight kernels; returned to the context at the next sync
   std::string draw_;
 };
 

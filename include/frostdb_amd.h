@@ -204,8 +204,8 @@ int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms
 int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled);
 /* The hipStream_t the plan launches on, as an opaque pointer. */
 int fdb_plan_stream(fdb_plan* plan, void** stream_out);
-/* Kernel geometry knobs for bench.py's variant sweeps: rows per lane (4 or 8) and persistent grid size
- * (0 = default, 2 workgroups per CU). */
+/* Kernel geometry knobs for bench.py's variant sweeps: rows_per_thread 0 = load-hoisting slot kernel (default),
+ * 4 / 8 = sequential kernel with that many rows per lane; grid_blocks 0 = default persistent grid. */
 int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_blocks);
 
 #ifdef __cplusplus

@@ -143,9 +143,9 @@ def test_golden_inconsistent_schema(pp):
 
 # ---- randomized parity against the oracle ---------------------------------------------------------------------
 
-CFG2 = dict(filter=Col("labels.code") == "200", aggs=[Sum(Col("value"))], groups=[Col("labels.path")])
+CFG2 = dict(filter_expr=Col("labels.code") == "200", aggs=[Sum(Col("value"))], groups=[Col("labels.path")])
 CFG3 = dict(
-    filter=And(Or(Col("labels.code") == "200", Col("labels.code") == "500"), Col("labels.method") == "GET",
+    filter_expr=And(Or(Col("labels.code") == "200", Col("labels.code") == "500"), Col("labels.method") == "GET",
                Col("labels.instance") != None),  # noqa: E711
     aggs=[Count(Col("value")), Min(Col("timestamp")), Max(Col("timestamp")), Sum(Col("value"))],
     groups=[Col("labels.path")])
@@ -164,12 +164,12 @@ def test_config2_sizes(pp, n):
 
 
 @pytest.mark.parametrize("resident", [False, True])
-@pytest.mark.parametrize("rpt", [4, 8])
+@pytest.mark.parametrize("rpt", [0, 4, 8])
 def test_config3_multibatch(pp, resident, rpt):
     rng = np.random.default_rng(7)
     batches = [make_prometheus_batch(rng, n, n_path=int(p)) for n, p in [(50_000, 64), (33_333, 200), (8192, 7), (1, 3)]]
     want = run_oracle(batches, **CFG3, nchains=2)
-    plan = pp.HashAggregatePlan(CFG3["filter"], CFG3["aggs"], CFG3["groups"])
+    plan = pp.HashAggregatePlan(CFG3["filter_expr"], CFG3["aggs"], CFG3["groups"])
     plan.set_tuning(rpt, 0)
     keep = []
     try:
@@ -273,7 +273,7 @@ def test_selection_vector_matches_oracle_on_large_batch(pp):
     from oracle import OraclePlan
     rng = np.random.default_rng(3)
     b = make_prometheus_batch(rng, 250_007)
-    f = CFG3["filter"]
+    f = CFG3["filter_expr"]
     plan = pp.HashAggregatePlan(f)
     o = OraclePlan(f)
     try:
