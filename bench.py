@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--batch-rows", type=int, default=25_000_000, help="rows per resident record (part)")
     ap.add_argument("--rows-per-thread", type=int, default=0, help="0: slot kernel (default); 4/8: sequential kernel")
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--per-record-launch", action="store_true", help="one kernel launch per resident record instead of one per scan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=3.0)
     ap.add_argument("--sweep", action="store_true", help="kernel geometry sweep first (tuning aid; table on stderr)")
@@ -133,8 +134,11 @@ def main():
             plan.set_tuning(*tuning)
         else:
             plan.set_tuning(args.rows_per_thread, args.grid)
-        for rb in resident:
-            plan.Callback(rb)
+        if args.per_record_launch:
+            for rb in resident:
+                plan.Callback(rb)
+        else:
+            plan.CallbackResident(resident)
         out = merge_plan(plan) if world > 1 else plan.Finish()
         st = plan.stats() if timing else None
         plan.Close()
@@ -155,7 +159,7 @@ def main():
     if args.sweep:
         if rank == 0:
             print(f"# sweep: rows={rows} batch_rows={args.batch_rows} cfg={args.config}", file=sys.stderr)
-        for rpt, grid in [(4, 512), (4, 512 | (1 << 24)), (4, 1024), (0, 0), (0, 512), (0, 512 | (1 << 24)), (0, 1024)]:
+        for rpt, grid in [(4, 512), (0, 0), (0, 1024), (0, 1024 | (1 << 24)), (0, 2048)]:
             if True:
                 for _ in range(2):
                     step(tuning=(rpt, grid))
@@ -206,7 +210,7 @@ def main():
                        "parallelism": f"parts sharded over {world} GPU(s); RCCL all-reduce of partial tables" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "scan_dense_kernel", "avg_launch_ms": k_ms / max(k_launches, 1),
+                         "kernel": "scan_slots_kernel" if args.rows_per_thread == 0 else "scan_dense_kernel", "avg_launch_ms": k_ms / max(k_launches, 1),
                          "algorithmic_bytes_per_launch": k_bytes / max(k_launches, 1),
                          "bytes_per_row": k_bytes / max(rows * args.steps, 1)},
             "cpu_baseline": cpu,

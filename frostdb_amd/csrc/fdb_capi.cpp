@@ -2,6 +2,7 @@
 // exceptions into fdb_status codes (never aborts: the Go side wraps chains in recovery.Do, physicalplan.go:142).
 #include <new>
 #include <string>
+#include <vector>
 
 #include "fdb_plan.h"
 
@@ -61,6 +62,18 @@ int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* 
 int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch) {
   if (!plan || !batch) return FDB_ERR_INVALID;
   return guard(plan, [&] { plan->plan.push_batch(*batch->b); });
+}
+
+int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n) {
+  if (!plan || (n > 0 && !batches)) return FDB_ERR_INVALID;
+  return guard(plan, [&] {
+    std::vector<const fdb::DeviceBatch*> v;
+    for (int32_t i = 0; i < n; i++) {
+      if (batches[i] == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null batch");
+      v.push_back(batches[i]->b.get());
+    }
+    plan->plan.push_batches(v.data(), (int)v.size());
+  });
 }
 
 int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows) {
@@ -151,6 +164,7 @@ int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_bl
   plan->plan.grid_override = grid_blocks & 0xFFFFF;
   plan->plan.ablate = (grid_blocks >> 20) & 0xF;  // bench --ablate rides in the high bits (tuning aid only)
   plan->plan.use_partials = ((grid_blocks >> 24) & 1) == 0;
+  plan->plan.sub_tiles = (grid_blocks >> 25) & 7;
   return FDB_OK;
 }
 

@@ -15,14 +15,17 @@
 #define FDB_MAX_HASH_GCOLS 64
 #define FDB_MAX_AGGS 8
 #define FDB_MAX_C4 4            // column slots of the load-hoisting kernel: 4-byte (dictionary index) columns
-#define FDB_MAX_C8 3            //                                           8-byte (int64/uint64/float64) columns
+#define FDB_MAX_C8 2            //                                           8-byte (int64/uint64/float64) columns
+#define FDB_MAX_L4 2            // late (post-filter) slots of the two-phase kernel
+#define FDB_MAX_L8 3
 #define FDB_BLOCK 1024          // 16 waves share one LDS partial table
 #define FDB_LDS_BUDGET 65536    // bytes of LDS per workgroup (2 workgroups/CU of the 160 KiB)
 #define FDB_NO_LDS 0xFFFFFFFFu
 
 enum FdbLeafKind : int32_t {
   FDB_LEAF_CONST = 0,      // op = 0/1: no row / every row (missing-column rules, binaryscalarexpr.go:47-73)
-  FDB_LEAF_DICT_LUT = 1,   // values = uint32 indices; lut[idx] ∈ {0,1}
+  FDB_LEAF_DICT_LUT = 1,   // values = uint32 indices; lut[idx] ∈ {0,1}; entry lut_len-1 is the answer for a NULL row
+  FDB_LEAF_DICT_BITS = 7,  // same truth table packed in `lit` (≤ 63 dictionary entries + the NULL row): no LDS access
   FDB_LEAF_CMP_I64 = 2,    // values = int64;  lit = int64
   FDB_LEAF_CMP_U64 = 3,    // values = uint64; lit = uint64
   FDB_LEAF_CMP_F64 = 4,    // values = double; lit = double bits
@@ -76,6 +79,8 @@ struct FdbColSlot {
 
 struct FdbScanArgs {
   int64_t n_rows;
+  int64_t tile_begin;       // multi-record launch: this record owns global tiles [tile_begin, tile_end)
+  int64_t tile_end;
   unsigned long long* cnt;  // global selected-row count per slot (occupancy + COUNT)
   uint32_t n_slots;
   int32_t n_leaves;
@@ -87,12 +92,19 @@ struct FdbScanArgs {
   int32_t need_count;       // 1: some aggregation is COUNT (exact per-slot row counts needed)
   int32_t n_c4;             // > 0 or n_c8 > 0: slots are assigned (otherwise only the sequential kernel can run)
   int32_t n_c8;
+  // Two-phase plans (more columns than the single-phase register class holds): c4/c8 are the columns the FILTER
+  // reads (loaded first); l4/l8 the columns only the group-by and the aggregates read — late materialisation:
+  // loaded after the filter, and not at all for a lane group whose rows were all filtered out.
+  int32_t n_l4;
+  int32_t n_l8;
+  FdbColSlot l4[FDB_MAX_L4];
+  FdbColSlot l8[FDB_MAX_L8];
   FdbColSlot c4[FDB_MAX_C4];
   FdbColSlot c8[FDB_MAX_C8];
   unsigned long long* partials;  // LDS mode: per-workgroup partial tables [grid][1 + n_aggs][n_slots], written with plain
                                  // coalesced stores and folded by fdb_launch_reduce_partials (nullptr: flush with atomics)
   int32_t ablate;           // tuning aid (bench --ablate): 1 skip occupancy, 2 skip aggregate atomics, 4 skip group LUTs, 8 skip filter
-  int32_t _pad0;
+  int32_t lut_class;        // records with the same class carry byte-identical LUT sets at the same LDS offsets
   uint8_t code[FDB_MAX_CODE];
   FdbLeaf leaves[FDB_MAX_LEAVES];
   FdbGroupCol gcols[FDB_MAX_DENSE_GCOLS];
@@ -127,8 +139,14 @@ int fdb_scan_grid(const FdbScanArgs& args, int grid_blocks, int rows_per_thread)
 // in workgroup order (deterministic). funcs[arr]: 0 skip, 1 add u64, 2 add f64, 3 min i64, 4 max i64.
 hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_blocks, int n_arrays, uint32_t n_slots,
                                       unsigned long long* state, uint64_t state_stride, const int32_t* funcs, hipStream_t stream);
+// The slot kernel over `n_parts` records in ONE launch. `d_parts` is the device copy of the per-record argument
+// blocks (global tile ranges filled in, in units of fdb_slot_geometry's tile_rows); `common` = any of them (table
+// pointers, aggregation functions, LDS layout are identical across records). sub_tiles: 1 or 2.
+hipError_t fdb_launch_scan_slots(const FdbScanArgs* d_parts, int n_parts, const FdbScanArgs& common, int64_t total_tiles, int grid_blocks,
+                                 size_t lds_bytes, int two_phase, int mode, hipStream_t stream);
+// Rows per tile and resident workgroups per CU (occupancy query on the instance that will run) of the slot kernel.
+int fdb_slot_geometry(int two_phase, int mode, int lds_acc, size_t lds_bytes, int device, int* tile_rows, int* blocks_per_cu);
 int fdb_slot_kernel_block(void);      // threads per workgroup of the slot kernel
-int fdb_slot_kernel_blocks_per_cu(int n_c4, int n_c8);
 hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value, int64_t n, hipStream_t stream);
 // base[a * n + i] = idents[a] for a < n_arrays (≤ 1 + FDB_MAX_AGGS), i < n: the whole partial table in one launch.
 hipError_t fdb_launch_fill_state(unsigned long long* base, int64_t n, int n_arrays, const unsigned long long* idents, hipStream_t stream);

@@ -32,11 +32,20 @@ __device__ __forceinline__ long long f64_to_ordered(double d) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
+// Column, bitmap and LUT pointers reach the kernels inside argument blocks, so the compiler sees generic
+// pointers and would emit flat_load (LDS-aperture check, counts against lgkmcnt as well as vmcnt). They always
+// point to HBM: say so, and get global_load_dwordx4 … nt.
+#define FDB_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const FDB_GLOBAL T* as_global(const T* p) {
+  return (const FDB_GLOBAL T*)p;
+}
+
 template <int R>
 __device__ __forceinline__ void load_u32(const uint32_t* __restrict__ p, uint32_t (&v)[R]) {
 #pragma unroll
   for (int j = 0; j < R / 4; j++) {
-    const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + j);
+    const u32x4 q = __builtin_nontemporal_load(as_global(reinterpret_cast<const u32x4*>(p)) + j);
     v[4 * j + 0] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
   }
 }
@@ -45,7 +54,7 @@ template <int R>
 __device__ __forceinline__ void load_u64(const unsigned long long* __restrict__ p, unsigned long long (&v)[R]) {
 #pragma unroll
   for (int j = 0; j < R / 2; j++) {
-    const u64x2 q = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(p) + j);
+    const u64x2 q = __builtin_nontemporal_load(as_global(reinterpret_cast<const u64x2*>(p)) + j);
     v[2 * j + 0] = q.x; v[2 * j + 1] = q.y;
   }
 }
@@ -53,7 +62,7 @@ __device__ __forceinline__ void load_u64(const unsigned long long* __restrict__ 
 // R validity bits of rows [row0, row0+R); row0 is a multiple of R (R ∈ {4, 8}).
 template <int R>
 __device__ __forceinline__ uint32_t load_valid(const uint8_t* __restrict__ bm, int64_t row0) {
-  const uint32_t b = bm[row0 >> 3];
+  const uint32_t b = as_global(bm)[row0 >> 3];
   if (R == 8) return b;
   return (b >> (row0 & 4)) & 0xFu;
 }
@@ -101,17 +110,26 @@ __device__ __forceinline__ uint32_t eval_leaf(const FdbLeaf& L, int64_t row0, co
   if (L.validity != nullptr) valid = load_valid<R>(L.validity, row0);
   if (L.kind == FDB_LEAF_VALIDITY) return L.op ? valid : (~valid & FULL);
   uint32_t m = 0;
-  if (L.kind == FDB_LEAF_DICT_LUT) {
+  if (L.kind == FDB_LEAF_DICT_LUT || L.kind == FDB_LEAF_DICT_BITS) {
+    // Truth table per dictionary entry, evaluated on the host; its last entry answers for NULL rows.
     uint32_t idx[R];
     load_u32<R>(reinterpret_cast<const uint32_t*>(L.values) + row0, idx);
-    if (L.lut_lds != FDB_NO_LDS) {
+    const uint32_t null_at = L.lut_len - 1u;
+#pragma unroll
+    for (int r = 0; r < R; r++) idx[r] = ((valid >> r) & 1u) ? idx[r] : null_at;
+    if (L.kind == FDB_LEAF_DICT_BITS) {
+      const unsigned long long bits = (unsigned long long)L.lit;
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)((bits >> idx[r]) & 1ull) << r;
+    } else if (L.lut_lds != FDB_NO_LDS) {
       const unsigned char* lut = smem + L.lut_lds;
 #pragma unroll
-      for (int r = 0; r < R; r++) m |= (uint32_t)lut[((valid >> r) & 1u) ? idx[r] : 0u] << r;
+      for (int r = 0; r < R; r++) m |= (uint32_t)lut[idx[r]] << r;
     } else {
 #pragma unroll
-      for (int r = 0; r < R; r++) m |= (uint32_t)L.lut[((valid >> r) & 1u) ? idx[r] : 0u] << r;
+      for (int r = 0; r < R; r++) m |= (uint32_t)as_global(L.lut)[idx[r]] << r;
     }
+    return m;
   } else {
     unsigned long long raw[R];
     load_u64<R>(reinterpret_cast<const unsigned long long*>(L.values) + row0, raw);
@@ -174,7 +192,7 @@ __device__ __forceinline__ void group_slots(const FdbScanArgs& a, int64_t row0, 
       for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? lut[idx[r]] : 0u) * G.stride;
     } else {
 #pragma unroll
-      for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? G.lut[idx[r]] : 0u) * G.stride;
+      for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? as_global(G.lut)[idx[r]] : 0u) * G.stride;
     }
   }
 }
@@ -197,13 +215,13 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
   for (int l = 0; l < a.n_leaves; l++) {
     const FdbLeaf& L = a.leaves[l];
     if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
-      for (uint32_t i = tid; i < L.lut_len; i += FDB_BLOCK) smem[L.lut_lds + i] = L.lut[i];
+      for (uint32_t i = tid; i < L.lut_len; i += FDB_BLOCK) smem[L.lut_lds + i] = as_global(L.lut)[i];
   }
   for (int g = 0; g < a.n_gcols; g++) {
     const FdbGroupCol& G = a.gcols[g];
     if (G.lut_lds != FDB_NO_LDS) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(smem + G.lut_lds);
-      for (uint32_t i = tid; i < G.lut_len; i += FDB_BLOCK) dst[i] = G.lut[i];
+      for (uint32_t i = tid; i < G.lut_len; i += FDB_BLOCK) dst[i] = as_global(G.lut)[i];
     }
   }
   uint32_t* l_cnt = reinterpret_cast<uint32_t*>(smem + a.lds_lut_bytes);
@@ -345,21 +363,21 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
 
 template <int NC4, int NC8>
 struct SlotRegs {
-  u32x4 r4[NC4];
-  u64x2 r8[NC8][2];
-  uint32_t v4[NC4];
-  uint32_t v8[NC8];
+  u32x4 r4[NC4 > 0 ? NC4 : 1];
+  u64x2 r8[NC8 > 0 ? NC8 : 1][2];
+  uint32_t v4[NC4 > 0 ? NC4 : 1];
+  uint32_t v8[NC8 > 0 ? NC8 : 1];
 };
 
 template <int NC4, int NC8>
-__device__ __forceinline__ void slot_load(const FdbScanArgs& a, int64_t row0, SlotRegs<NC4, NC8>& S) {
+__device__ __forceinline__ void slot_load(const FdbColSlot* c4, int n_c4, const FdbColSlot* c8, int n_c8, int64_t row0, SlotRegs<NC4, NC8>& S) {
 #pragma unroll
   for (int s = 0; s < NC4; s++) {
     S.r4[s] = u32x4{0, 0, 0, 0};
     S.v4[s] = 0xFu;
-    if (s < a.n_c4) {
-      if (a.c4[s].values != nullptr) S.r4[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(a.c4[s].values) + row0));
-      if (a.c4[s].validity != nullptr) S.v4[s] = load_valid<4>(a.c4[s].validity, row0);
+    if (s < n_c4) {
+      if (c4[s].values != nullptr) S.r4[s] = __builtin_nontemporal_load(as_global(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(c4[s].values) + row0)));
+      if (c4[s].validity != nullptr) S.v4[s] = load_valid<4>(c4[s].validity, row0);
     }
   }
 #pragma unroll
@@ -367,13 +385,13 @@ __device__ __forceinline__ void slot_load(const FdbScanArgs& a, int64_t row0, Sl
     S.r8[s][0] = u64x2{0, 0};
     S.r8[s][1] = u64x2{0, 0};
     S.v8[s] = 0xFu;
-    if (s < a.n_c8) {
-      if (a.c8[s].values != nullptr) {
-        const u64x2* p = reinterpret_cast<const u64x2*>(reinterpret_cast<const unsigned long long*>(a.c8[s].values) + row0);
+    if (s < n_c8) {
+      if (c8[s].values != nullptr) {
+        const FDB_GLOBAL u64x2* p = as_global(reinterpret_cast<const u64x2*>(reinterpret_cast<const unsigned long long*>(c8[s].values) + row0));
         S.r8[s][0] = __builtin_nontemporal_load(p);
         S.r8[s][1] = __builtin_nontemporal_load(p + 1);
       }
-      if (a.c8[s].validity != nullptr) S.v8[s] = load_valid<4>(a.c8[s].validity, row0);
+      if (c8[s].validity != nullptr) S.v8[s] = load_valid<4>(c8[s].validity, row0);
     }
   }
 }
@@ -408,15 +426,22 @@ __device__ __forceinline__ uint32_t slot_eval_leaf(const FdbLeaf& L, const SlotR
     uint32_t idx[R];
     pick4(S, L.slot, idx, valid);
     if (L.kind == FDB_LEAF_VALIDITY) return L.op ? valid : (~valid & FULL);
-    if (L.lut_lds != FDB_NO_LDS) {
+    const uint32_t null_at = L.lut_len - 1u;
+#pragma unroll
+    for (int r = 0; r < R; r++) idx[r] = ((valid >> r) & 1u) ? idx[r] : null_at;
+    if (L.kind == FDB_LEAF_DICT_BITS) {
+      const unsigned long long bits = (unsigned long long)L.lit;
+#pragma unroll
+      for (int r = 0; r < R; r++) m |= (uint32_t)((bits >> idx[r]) & 1ull) << r;
+    } else if (L.lut_lds != FDB_NO_LDS) {
       const unsigned char* lut = smem + L.lut_lds;
 #pragma unroll
-      for (int r = 0; r < R; r++) m |= (uint32_t)lut[((valid >> r) & 1u) ? idx[r] : 0u] << r;
+      for (int r = 0; r < R; r++) m |= (uint32_t)lut[idx[r]] << r;
     } else {
 #pragma unroll
-      for (int r = 0; r < R; r++) m |= (uint32_t)L.lut[((valid >> r) & 1u) ? idx[r] : 0u] << r;
+      for (int r = 0; r < R; r++) m |= (uint32_t)as_global(L.lut)[idx[r]] << r;
     }
-    return m & valid;
+    return m;
   }
   unsigned long long raw[R];
   pick8(S, L.slot, raw, valid);
@@ -442,149 +467,211 @@ __device__ __forceinline__ uint32_t slot_eval_leaf(const FdbLeaf& L, const SlotR
   return m & valid;
 }
 
-template <bool LDS, int NC4, int NC8, int MINW>
-__global__ __launch_bounds__(SLOT_BLOCK, MINW) void scan_slots_kernel(const FdbScanArgs a) {
+template <bool LDS, int NC4, int NC8, int L4, int L8, int T, int BLK>
+__global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __restrict__ parts, const int n_parts,
+                                                                const int64_t total_tiles, const FdbScanArgs c) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int R = 4;
   constexpr uint32_t FULL = 0xFu;
   const int tid = threadIdx.x;
-  const uint32_t n_slots = a.n_slots;
+  const uint32_t n_slots = c.n_slots;
 
-  for (int l = 0; l < a.n_leaves; l++) {
-    const FdbLeaf& L = a.leaves[l];
-    if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
-      for (uint32_t i = tid; i < L.lut_len; i += SLOT_BLOCK) smem[L.lut_lds + i] = L.lut[i];
-  }
-  for (int g = 0; g < a.n_gcols; g++) {
-    const FdbGroupCol& G = a.gcols[g];
-    if (G.lut_lds != FDB_NO_LDS) {
-      uint32_t* dst = reinterpret_cast<uint32_t*>(smem + G.lut_lds);
-      for (uint32_t i = tid; i < G.lut_len; i += SLOT_BLOCK) dst[i] = G.lut[i];
-    }
-  }
-  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(smem + a.lds_lut_bytes);
+  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(smem + c.lds_lut_bytes);
   unsigned long long* l_acc =
-      reinterpret_cast<unsigned long long*>(smem + a.lds_lut_bytes + (((size_t)n_slots * 4 + 15) & ~(size_t)15));
+      reinterpret_cast<unsigned long long*>(smem + c.lds_lut_bytes + (((size_t)n_slots * 4 + 15) & ~(size_t)15));
   if (LDS) {
-    for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) l_cnt[i] = 0;
-    for (int j = 0; j < a.n_aggs; j++) {
-      const unsigned long long ident = agg_identity(a.aggs[j].func, a.aggs[j].type);
-      for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) l_acc[(size_t)j * n_slots + i] = ident;
+    for (uint32_t i = tid; i < n_slots; i += BLK) l_cnt[i] = 0;
+    for (int j = 0; j < c.n_aggs; j++) {
+      const unsigned long long ident = agg_identity(c.aggs[j].func, c.aggs[j].type);
+      for (uint32_t i = tid; i < n_slots; i += BLK) l_acc[(size_t)j * n_slots + i] = ident;
     }
   }
-  __syncthreads();
 
-  const int64_t tile_rows = (int64_t)SLOT_BLOCK * R;
-  const int64_t n_tiles = (a.n_rows + tile_rows - 1) / tile_rows;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * tile_rows + (int64_t)tid * R;
-    if (row0 >= a.n_rows) continue;
-    SlotRegs<NC4, NC8> S;
-    slot_load(a, row0, S);
-
-    const int64_t left = a.n_rows - row0;
-    uint32_t sel = left >= R ? FULL : ((1u << (int)left) - 1u);
-    if (a.n_code != 0) {
-      unsigned long long st = 0;
-      for (int pc = 0; pc < a.n_code; pc++) {
-        const uint32_t c = a.code[pc];
-        if (c < 0x80u) {
-          st = (st << 8) | (unsigned long long)slot_eval_leaf(a.leaves[c], S, smem);
-        } else {
-          const unsigned long long top = st & 0xFFull;
-          st >>= 8;
-          if (c == FDB_CODE_AND) st = (st & ~0xFFull) | ((st & 0xFFull) & top);
-          else st = st | top;
+  // Global tiles are numbered across the records of this launch; a workgroup walks them grid-stride, so it
+  // visits the records in order and re-stages the per-dictionary LUTs only when it crosses a record boundary.
+  // A tile is T sub-tiles of BLK × 4 rows: every lane owns 4 consecutive rows in each sub-tile, so each
+  // load instruction stays lane-contiguous (16 B per lane) while ONE pass of the plan interpreter (scalar
+  // descriptor loads, uniform branches) is amortised over 4·T rows per lane.
+  constexpr int64_t sub_rows = (int64_t)BLK * R;
+  constexpr int64_t tile_rows = sub_rows * T;
+  int part = -1, lut_class = -1;
+  for (int64_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    int np = part < 0 ? 0 : part;
+    while (np + 1 < n_parts && tile >= parts[np].tile_end) np++;
+    if (np != part) part = np;
+    if (parts[part].lut_class != lut_class) {
+      lut_class = parts[part].lut_class;
+      __syncthreads();  // every wave is done with the previous record's LUTs (and with the table init)
+      const FdbScanArgs& pa = parts[part];
+      for (int l = 0; l < pa.n_leaves; l++) {
+        const FdbLeaf& L = pa.leaves[l];
+        if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
+          for (uint32_t i = tid; i < L.lut_len; i += BLK) smem[L.lut_lds + i] = as_global(L.lut)[i];
+      }
+      for (int g = 0; g < pa.n_gcols; g++) {
+        const FdbGroupCol& G = pa.gcols[g];
+        if (G.lut_lds != FDB_NO_LDS) {
+          uint32_t* dst = reinterpret_cast<uint32_t*>(smem + G.lut_lds);
+          for (uint32_t i = tid; i < G.lut_len; i += BLK) dst[i] = as_global(G.lut)[i];
         }
       }
-      sel &= (uint32_t)st;
+      __syncthreads();
     }
-    if (sel == 0) continue;
+    const FdbScanArgs& a = parts[part];
+    const int64_t base = (tile - a.tile_begin) * tile_rows + (int64_t)tid * R;
+    if (base >= a.n_rows) continue;
 
-    uint32_t gid[R] = {0, 0, 0, 0};
+    // ---- issue every load of the tile --------------------------------------------------------------------
+    constexpr bool TWO_PHASE = (L4 + L8) > 0;
+    SlotRegs<NC4, NC8> S[T];
+    uint32_t sel[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int64_t row0 = base + t * sub_rows;
+      const int64_t left = a.n_rows - row0;
+      sel[t] = left >= R ? FULL : (left > 0 ? ((1u << (int)left) - 1u) : 0u);
+      slot_load<NC4, NC8>(a.c4, a.n_c4, a.c8, a.n_c8, left > 0 ? row0 : base, S[t]);  // (a dead sub-tile re-reads live rows: masked by sel)
+    }
+
+    // ---- filter ---------------------------------------------------------------------------------------------
+    if (a.n_code != 0) {
+      unsigned long long st[T];
+#pragma unroll
+      for (int t = 0; t < T; t++) st[t] = 0;
+      for (int pc = 0; pc < a.n_code; pc++) {
+        const uint32_t op = a.code[pc];
+        if (op < 0x80u) {
+          const FdbLeaf& L = a.leaves[op];
+#pragma unroll
+          for (int t = 0; t < T; t++) st[t] = (st[t] << 8) | (unsigned long long)slot_eval_leaf(L, S[t], smem);
+        } else {
+#pragma unroll
+          for (int t = 0; t < T; t++) {
+            const unsigned long long top = st[t] & 0xFFull;
+            st[t] >>= 8;
+            if (op == FDB_CODE_AND) st[t] = (st[t] & ~0xFFull) | ((st[t] & 0xFFull) & top);
+            else st[t] = st[t] | top;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; t++) sel[t] &= (uint32_t)st[t];
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int t = 0; t < T; t++) any |= sel[t];
+    if (any == 0) continue;
+    // ---- late materialisation: the columns only the group-by / aggregates read ------------------------------------
+    SlotRegs<L4, L8> SL[T];
+    if (TWO_PHASE) {
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const int64_t row0 = base + t * sub_rows;
+        slot_load<L4, L8>(a.l4, a.n_l4, a.l8, a.n_l8, row0 < a.n_rows ? row0 : base, SL[t]);
+      }
+    }
+
+    // ---- group slots ---------------------------------------------------------------------------------------
+    uint32_t gid[T][R];
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+      for (int r = 0; r < R; r++) gid[t][r] = 0;
     for (int g = 0; g < a.n_gcols; g++) {
       const FdbGroupCol& G = a.gcols[g];
-      uint32_t idx[R], valid;
-      pick4(S, G.slot, idx, valid);
-      if (G.lut_lds != FDB_NO_LDS) {
-        const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + G.lut_lds);
 #pragma unroll
-        for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? lut[idx[r]] : 0u) * G.stride;
-      } else {
+      for (int t = 0; t < T; t++) {
+        uint32_t idx[R], valid;
+        if (TWO_PHASE) pick4(SL[t], G.slot, idx, valid); else pick4(S[t], G.slot, idx, valid);
+        if (G.lut_lds != FDB_NO_LDS) {
+          const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + G.lut_lds);
 #pragma unroll
-        for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? G.lut[idx[r]] : 0u) * G.stride;
+          for (int r = 0; r < R; r++) gid[t][r] += (((valid >> r) & 1u) ? lut[idx[r]] : 0u) * G.stride;
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) gid[t][r] += (((valid >> r) & 1u) ? as_global(G.lut)[idx[r]] : 0u) * G.stride;
+        }
       }
     }
 
-    if (LDS) {
-      if (a.need_count) {
+    // ---- occupancy / COUNT ------------------------------------------------------------------------------------
 #pragma unroll
-        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&l_cnt[gid[r]], 1u);
+    for (int t = 0; t < T; t++) {
+      if (LDS) {
+        if (a.need_count) {
+#pragma unroll
+          for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicAdd(&l_cnt[gid[t][r]], 1u);
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) l_cnt[gid[t][r]] = 1u;
+        }
       } else {
 #pragma unroll
-        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) l_cnt[gid[r]] = 1u;
+        for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicAdd(&a.cnt[gid[t][r]], 1ull);
       }
-    } else {
-#pragma unroll
-      for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&a.cnt[gid[r]], 1ull);
     }
 
+    // ---- aggregates -------------------------------------------------------------------------------------------
     for (int j = 0; j < a.n_aggs; j++) {
       const FdbAgg& A = a.aggs[j];
       if (A.func == AGG_COUNT) continue;
-      unsigned long long raw[R];
-      uint32_t valid;
-      pick8(S, A.slot, raw, valid);
-#pragma unroll
-      for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = 0ull;
       unsigned long long* acc = LDS ? (l_acc + (size_t)j * n_slots) : A.acc;
-      if (A.func == AGG_SUM) {
-        if (A.type == FDB_T_F64) {
 #pragma unroll
-          for (int r = 0; r < R; r++)
-            if ((sel >> r) & 1u) atomicAdd(reinterpret_cast<double*>(acc) + gid[r], __longlong_as_double((long long)raw[r]));
+      for (int t = 0; t < T; t++) {
+        unsigned long long raw[R];
+        uint32_t valid;
+        if (TWO_PHASE) pick8(SL[t], A.slot, raw, valid); else pick8(S[t], A.slot, raw, valid);
+        // a NULL contributes the builder's zeroed slot (aggregate.go:784-935, optbuilders.go:337-340)
+#pragma unroll
+        for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = 0ull;
+        if (A.func == AGG_SUM) {
+          if (A.type == FDB_T_F64) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+              if ((sel[t] >> r) & 1u) atomicAdd(reinterpret_cast<double*>(acc) + gid[t][r], __longlong_as_double((long long)raw[r]));
+          } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicAdd(acc + gid[t][r], raw[r]);
+          }
         } else {
+          long long key[R];
+          if (A.type == FDB_T_F64) {
 #pragma unroll
-          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(acc + gid[r], raw[r]);
-        }
-      } else {
-        long long key[R];
-        if (A.type == FDB_T_F64) {
+            for (int r = 0; r < R; r++) key[r] = f64_to_ordered(__longlong_as_double((long long)raw[r]));
+          } else {
 #pragma unroll
-          for (int r = 0; r < R; r++) key[r] = f64_to_ordered(__longlong_as_double((long long)raw[r]));
-        } else {
+            for (int r = 0; r < R; r++) key[r] = (long long)raw[r];
+          }
+          if (A.func == AGG_MIN) {
 #pragma unroll
-          for (int r = 0; r < R; r++) key[r] = (long long)raw[r];
-        }
-        if (A.func == AGG_MIN) {
+            for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicMin(reinterpret_cast<long long*>(acc) + gid[t][r], key[r]);
+          } else {
 #pragma unroll
-          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicMin(reinterpret_cast<long long*>(acc) + gid[r], key[r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicMax(reinterpret_cast<long long*>(acc) + gid[r], key[r]);
+            for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicMax(reinterpret_cast<long long*>(acc) + gid[t][r], key[r]);
+          }
         }
       }
     }
   }
 
-  if (LDS && a.partials != nullptr) {
+  if (LDS && c.partials != nullptr) {
     // Flush without atomics: this workgroup's table goes out as plain coalesced stores; a small second kernel
     // folds the tables in workgroup order (512 workgroups hammering 1 025 addresses with atomics cost ≈10 µs).
     __syncthreads();
-    unsigned long long* out = a.partials + (size_t)blockIdx.x * (size_t)(1 + a.n_aggs) * n_slots;
-    for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) out[i] = (unsigned long long)l_cnt[i];
-    for (int j = 0; j < a.n_aggs; j++) {
-      if (a.aggs[j].func == AGG_COUNT) continue;
-      for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) out[(size_t)(1 + j) * n_slots + i] = l_acc[(size_t)j * n_slots + i];
+    unsigned long long* out = c.partials + (size_t)blockIdx.x * (size_t)(1 + c.n_aggs) * n_slots;
+    for (uint32_t i = tid; i < n_slots; i += BLK) out[i] = (unsigned long long)l_cnt[i];
+    for (int j = 0; j < c.n_aggs; j++) {
+      if (c.aggs[j].func == AGG_COUNT) continue;
+      for (uint32_t i = tid; i < n_slots; i += BLK) out[(size_t)(1 + j) * n_slots + i] = l_acc[(size_t)j * n_slots + i];
     }
   } else if (LDS) {
     __syncthreads();
-    for (uint32_t i = tid; i < n_slots; i += SLOT_BLOCK) {
-      const uint32_t c = l_cnt[i];
-      if (c == 0) continue;
-      atomicAdd(&a.cnt[i], (unsigned long long)c);
-      for (int j = 0; j < a.n_aggs; j++) {
-        const FdbAgg& A = a.aggs[j];
+    for (uint32_t i = tid; i < n_slots; i += BLK) {
+      const uint32_t n_sel = l_cnt[i];
+      if (n_sel == 0) continue;
+      atomicAdd(&c.cnt[i], (unsigned long long)n_sel);
+      for (int j = 0; j < c.n_aggs; j++) {
+        const FdbAgg& A = c.aggs[j];
         if (A.func == AGG_COUNT) continue;
         const unsigned long long v = l_acc[(size_t)j * n_slots + i];
         if (A.func == AGG_SUM) {
@@ -678,7 +765,7 @@ __global__ __launch_bounds__(FDB_BLOCK) void select_flags_kernel(const FdbScanAr
   for (int l = 0; l < a.n_leaves; l++) {
     const FdbLeaf& L = a.leaves[l];
     if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
-      for (uint32_t i = tid; i < L.lut_len; i += FDB_BLOCK) smem[L.lut_lds + i] = L.lut[i];
+      for (uint32_t i = tid; i < L.lut_len; i += FDB_BLOCK) smem[L.lut_lds + i] = as_global(L.lut)[i];
   }
   __shared__ uint32_t wave_cnt[FDB_BLOCK / 64];
   __syncthreads();
@@ -792,12 +879,6 @@ int fdb_scan_default_grid(int device) {
 }
 
 int fdb_slot_kernel_block(void) { return SLOT_BLOCK; }
-// Workgroups per CU the slot kernel instance for (n_c4, n_c8) is compiled for (register-bound).
-int fdb_slot_kernel_blocks_per_cu(int n_c4, int n_c8) {
-  if (n_c4 <= 2 && n_c8 <= 1) return 4;
-  return 3;
-}
-
 int fdb_scan_grid(const FdbScanArgs& args, int grid_blocks, int rows_per_thread) {
   const int64_t tile_rows = rows_per_thread == 0 ? (int64_t)SLOT_BLOCK * 4 : (int64_t)FDB_BLOCK * rows_per_thread;
   const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
@@ -814,27 +895,46 @@ hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_
   return hipGetLastError();
 }
 
+namespace {
+typedef void (*SlotKernel)(const FdbScanArgs*, int, int64_t, FdbScanArgs);
+struct SlotVariant { SlotKernel lds, nolds; int t, block; };
+#define FDB_SV(NC4, NC8, L4, L8, T, BLK) \
+  {scan_slots_kernel<true, NC4, NC8, L4, L8, T, BLK>, scan_slots_kernel<false, NC4, NC8, L4, L8, T, BLK>, T, BLK}
+// single phase: ≤ 2 four-byte + ≤ 1 eight-byte column in total, everything loaded up front
+const SlotVariant kSingle[] = {FDB_SV(2, 1, 0, 0, 1, 512), FDB_SV(2, 1, 0, 0, 1, 256), FDB_SV(2, 1, 0, 0, 1, 1024), FDB_SV(2, 1, 0, 0, 2, 512)};
+// two phase: filter columns (≤ 4 + 2) first, then group-by / aggregate columns (≤ 2 + 3)
+const SlotVariant kTwoPhase[] = {FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1, 512), FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1, 256),
+                                  FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1, 1024), FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1, 512)};
+#undef FDB_SV
+// mode: 0 = default, 1 = 512 threads, 2 = 256 threads, 3 = 1024 threads, 4 = 512 threads × 2 sub-tiles (single phase only)
+const SlotVariant& slot_variant(int two_phase, int mode) {
+  const int m = (mode >= 1 && mode <= 4) ? mode - 1 : 0;
+  return two_phase ? kTwoPhase[m] : kSingle[m];
+}
+}  // namespace
+
+int fdb_slot_geometry(int two_phase, int mode, int lds_acc, size_t lds_bytes, int device, int* tile_rows, int* blocks_per_cu) {
+  const SlotVariant& v = slot_variant(two_phase, mode);
+  *tile_rows = v.block * 4 * v.t;
+  const void* fn = reinterpret_cast<const void*>(lds_acc ? v.lds : v.nolds);
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, v.block, lds_bytes) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 1; }
+  if (occ > 2048 / v.block) occ = 2048 / v.block;  // 2048 threads per CU
+  *blocks_per_cu = occ;
+  return 0;
+}
+
+hipError_t fdb_launch_scan_slots(const FdbScanArgs* d_parts, int n_parts, const FdbScanArgs& common, int64_t total_tiles, int grid_blocks,
+                                 size_t lds_bytes, int two_phase, int mode, hipStream_t stream) {
+  if (total_tiles <= 0 || grid_blocks <= 0) return hipSuccess;
+  const SlotVariant& v = slot_variant(two_phase, mode);
+  SlotKernel fn = common.lds_acc ? v.lds : v.nolds;
+  hipLaunchKernelGGL(fn, dim3(grid_blocks), dim3(v.block), lds_bytes, stream, d_parts, n_parts, total_tiles, common);
+  return hipGetLastError();
+}
+
 hipError_t fdb_launch_scan_dense(const FdbScanArgs& args, int grid_blocks, size_t lds_bytes, int rows_per_thread, hipStream_t stream) {
-  if (rows_per_thread == 0) {
-    const int64_t tile_rows = (int64_t)SLOT_BLOCK * 4;
-    const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
-    if (n_tiles == 0) return hipSuccess;
-    if (grid_blocks > n_tiles) grid_blocks = (int)n_tiles;
-    // the smallest register footprint that holds the plan's column slots (waves/SIMD: 8 / 8 / 6 / 5)
-#define FDB_SLOT_LAUNCH(NC4, NC8, MINW)                                                                                              \
-    if (args.lds_acc) {                                                                                                               \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_slots_kernel<true, NC4, NC8, MINW>),                               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                               \
-      hipLaunchKernelGGL((scan_slots_kernel<true, NC4, NC8, MINW>), dim3(grid_blocks), dim3(SLOT_BLOCK), lds_bytes, stream, args);     \
-    } else {                                                                                                                          \
-      hipLaunchKernelGGL((scan_slots_kernel<false, NC4, NC8, MINW>), dim3(grid_blocks), dim3(SLOT_BLOCK), lds_bytes, stream, args);    \
-    }
-    if (args.n_c4 <= 2 && args.n_c8 <= 1) { FDB_SLOT_LAUNCH(2, 1, 8) }
-    else if (args.n_c4 <= 3 && args.n_c8 <= 2) { FDB_SLOT_LAUNCH(3, 2, 6) }
-    else { FDB_SLOT_LAUNCH(4, 3, 4) }
-#undef FDB_SLOT_LAUNCH
-    return hipGetLastError();
-  }
   const int64_t tile_rows = (int64_t)FDB_BLOCK * rows_per_thread;
   const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
   if (n_tiles == 0) return hipSuccess;

@@ -304,10 +304,21 @@ struct Blob {  // LUTs of one batch, shipped with one copy
 
 struct PendingLut { int kind; int index; size_t blob_off; size_t len_bytes; };  // kind 0: leaf, 1: group col
 
-// The per-entry predicate of a dictionary leaf.
-std::vector<uint8_t> dict_pred_lut(const ExprNode& e, const HostDict& dict) {
-  std::vector<uint8_t> lut(std::max<size_t>(dict.values.size(), 1), 0);
-  for (size_t i = 0; i < dict.values.size(); i++) {
+// Truth table of a predicate over ONE dictionary column: an answer per dictionary entry plus the answer for a NULL
+// row (last element). This is what replaces the reference's per-row string compare (binaryscalarexpr.go:154-311).
+typedef std::vector<uint8_t> Truth;
+
+Truth leaf_truth(const ExprNode& e, const HostDict& dict) {
+  const size_t n = dict.values.size();
+  Truth t(n + 1, 0);
+  if (!e.lit.valid() && (e.op == FDB_OP_EQ || e.op == FDB_OP_NOT_EQ || e.op == FDB_OP_CONTAINS || e.op == FDB_OP_NOT_CONTAINS)) {
+    // == NULL ⇒ IS NULL, != NULL ⇒ IS NOT NULL (:165-172, :205-212); (not) contains NULL ⇒ every non-null row (:287-295)
+    const bool on_value = e.op != FDB_OP_EQ;
+    for (size_t i = 0; i < n; i++) t[i] = on_value;
+    t[n] = e.op == FDB_OP_EQ;
+    return t;
+  }
+  for (size_t i = 0; i < n; i++) {
     const std::string& v = dict.values[i];
     bool m = false;
     switch (e.op) {
@@ -318,9 +329,42 @@ std::vector<uint8_t> dict_pred_lut(const ExprNode& e, const HostDict& dict) {
       case FDB_OP_REGEX_MATCH: m = std::regex_search(v, *e.re); break;
       case FDB_OP_REGEX_NOT_MATCH: m = !std::regex_search(v, *e.re); break;
     }
-    lut[i] = m ? 1 : 0;
+    t[i] = m ? 1 : 0;
   }
-  return lut;
+  t[n] = 0;  // NULL rows never satisfy a value predicate (:175-177, :215-217)
+  return t;
+}
+
+bool dict_leaf_op(int32_t op) {
+  return op == FDB_OP_EQ || op == FDB_OP_NOT_EQ || op == FDB_OP_CONTAINS || op == FDB_OP_NOT_CONTAINS || op == FDB_OP_REGEX_MATCH ||
+         op == FDB_OP_REGEX_NOT_MATCH;
+}
+
+// True if every leaf under `idx` tests the same dictionary column `*col` of `b` with an operator the dictionary
+// path supports; such a subtree collapses into ONE truth table (e.g. code=='200' OR code=='500').
+bool single_dict_subtree(const std::vector<ExprNode>& nodes, int idx, const DeviceBatch& b, int* col, int* n_leaves) {
+  const ExprNode& e = nodes[(size_t)idx];
+  if (e.op == FDB_OP_AND || e.op == FDB_OP_OR)
+    return single_dict_subtree(nodes, e.left, b, col, n_leaves) && single_dict_subtree(nodes, e.right, b, col, n_leaves);
+  if (!dict_leaf_op(e.op)) return false;
+  const int ci = b.find(e.column);
+  if (ci < 0 || b.cols[(size_t)ci].kind != ColKind::DICT || b.cols[(size_t)ci].d_values == nullptr) return false;
+  if ((e.op == FDB_OP_REGEX_MATCH || e.op == FDB_OP_REGEX_NOT_MATCH) && b.cols[(size_t)ci].dict->utf8()) return false;  // must raise, see resolve_leaf
+  if (*col >= 0 && *col != ci) return false;
+  *col = ci;
+  (*n_leaves)++;
+  return true;
+}
+
+Truth subtree_truth(const std::vector<ExprNode>& nodes, int idx, const HostDict& dict) {
+  const ExprNode& e = nodes[(size_t)idx];
+  if (e.op == FDB_OP_AND || e.op == FDB_OP_OR) {
+    Truth l = subtree_truth(nodes, e.left, dict);
+    const Truth r = subtree_truth(nodes, e.right, dict);
+    for (size_t i = 0; i < l.size(); i++) l[i] = e.op == FDB_OP_AND ? (l[i] & r[i]) : (l[i] | r[i]);
+    return l;
+  }
+  return leaf_truth(e, dict);
 }
 
 }  // namespace
@@ -350,10 +394,47 @@ struct Plan::Resolved {
 
 static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved* R, FdbLeaf* L);
 
+// Turns a truth table over dictionary column `ci` into a leaf: ≤ 64 answers ride in a 64-bit immediate (no LDS,
+// no memory access at all), larger tables become a byte LUT staged in LDS.
+static void emit_truth_leaf(const Truth& t, const DeviceBatch& b, int ci, Plan::Resolved* R, FdbLeaf* L) {
+  const int li = (int)(L - R->args.leaves);
+  const DevColumn& c = b.cols[(size_t)ci];
+  L->values = c.d_values;
+  L->validity = c.d_validity;
+  L->wide = 0;
+  L->lut_len = (uint32_t)t.size();
+  R->leaf_col[li] = ci;
+  R->count(b, ci);
+  if (t.size() <= 64) {
+    unsigned long long bits = 0;
+    for (size_t i = 0; i < t.size(); i++) if (t[i]) bits |= 1ull << i;
+    L->kind = FDB_LEAF_DICT_BITS;
+    L->lit = (int64_t)bits;
+    return;
+  }
+  L->kind = FDB_LEAF_DICT_LUT;
+  const size_t off = R->blob.add(t.data(), t.size());
+  R->luts.push_back(PendingLut{0, li, off, t.size()});
+}
+
 static void emit_filter(const std::vector<ExprNode>& nodes, int idx, const DeviceBatch& b, Plan::Resolved* R, int depth, int* max_depth) {
   const ExprNode& e = nodes[(size_t)idx];
   FdbScanArgs& a = R->args;
   if (e.op == FDB_OP_AND || e.op == FDB_OP_OR) {
+    int col = -1, n_sub = 0;
+    if (single_dict_subtree(nodes, idx, b, &col, &n_sub) && n_sub >= 2) {
+      if (a.n_leaves >= FDB_MAX_LEAVES || a.n_code >= FDB_MAX_CODE) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too large");
+      if (depth + 1 > *max_depth) *max_depth = depth + 1;
+      if (*max_depth > 8) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too deep");
+      const int li = a.n_leaves++;
+      FdbLeaf& L = a.leaves[li];
+      std::memset(&L, 0, sizeof(L));
+      L.lut_lds = FDB_NO_LDS;
+      L.slot = -1;
+      emit_truth_leaf(subtree_truth(nodes, idx, *b.cols[(size_t)col].dict), b, col, R, &L);
+      a.code[a.n_code++] = (uint8_t)li;
+      return;
+    }
     emit_filter(nodes, e.left, b, R, depth, max_depth);
     emit_filter(nodes, e.right, b, R, depth + 1, max_depth);
     if (a.n_code >= FDB_MAX_CODE) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too large");
@@ -422,12 +503,7 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
       R->count(b, ci, /*values=*/false);  // the index buffer is not read by this leaf: only the bitmap counts
       return;
     }
-    R->count(b, ci);
-    std::vector<uint8_t> lut = dict_pred_lut(e, *c.dict);
-    L->kind = FDB_LEAF_DICT_LUT;
-    L->lut_len = (uint32_t)lut.size();
-    const size_t off = R->blob.add(lut.data(), lut.size());
-    R->luts.push_back(PendingLut{0, li, off, lut.size()});
+    emit_truth_leaf(leaf_truth(e, *c.dict), b, ci, R, L);
     return;
   }
   if (is_regex) throw Error(FDB_ERR_UNSUPPORTED, "ArrayScalarRegexMatch: unsupported type on the device path: " + c.format);
@@ -564,24 +640,21 @@ void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
 }
 
 void Plan::push_batch(const DeviceBatch& b) {
-  if (finished_) throw Error(FDB_ERR_STATE, "push after finish");
-  if (aggs_.empty()) throw Error(FDB_ERR_STATE, "filter-only plan: use fdb_plan_filter / fdb_plan_select");
-  if (b.device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
-  hip_check(hipSetDevice(device_), "hipSetDevice");
+  const DeviceBatch* p = &b;
+  push_batches(&p, 1);
+}
 
-  PhaseTimer pt;
-  Resolved R;
+// Resolves one record against the plan (per-dictionary-entry work only): predicate program + LUTs, group columns
+// + key-id LUTs (may assign new key ids), aggregated columns. Nothing is launched.
+void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* batch_gcols) {
+  Resolved& R = *Rp;
   std::memset(&R.args, 0, sizeof(R.args));
   FdbScanArgs& a = R.args;
   a.n_rows = b.rows;
   int max_depth = 0;
   if (filter_root_ >= 0) emit_filter(filter_, filter_root_, b, &R, 0, &max_depth);
-  pt.mark("filter luts");
 
   // group columns: every field matched by a matcher, in the record's field order (aggregate.go:286-303)
-  std::vector<int> batch_gcols;  // index into gcols_ per FdbGroupCol
-  std::vector<uint32_t> caps;
-  for (const GroupColState& g : gcols_) caps.push_back((uint32_t)g.values.size() + 1);
   for (size_t ci = 0; ci < b.cols.size(); ci++) {
     const DevColumn& c = b.cols[ci];
     bool matched = false;
@@ -599,13 +672,11 @@ void Plan::push_batch(const DeviceBatch& b) {
       g.cap = 1;
       g.stride = 0;
       gcols_.push_back(std::move(g));
-      caps.push_back(1);
     }
     if (a.n_gcols >= FDB_MAX_DENSE_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "too many group-by columns for the dense path; hash path not built yet");
     GroupColState& g = gcols_[gi];
     const std::shared_ptr<const std::vector<uint32_t>> lut_ptr = g.lut_for(c.dict);
     const std::vector<uint32_t>& lut = *lut_ptr;
-    caps[gi] = (uint32_t)g.values.size() + 1;
     R.count(b, (int)ci);
     FdbGroupCol& G = a.gcols[a.n_gcols];
     G.idx = (const uint32_t*)c.d_values;
@@ -616,20 +687,15 @@ void Plan::push_batch(const DeviceBatch& b) {
     R.gcol_col[a.n_gcols] = (int)ci;
     const size_t off = R.blob.add(lut.data(), lut.size() * 4);
     R.luts.push_back(PendingLut{1, a.n_gcols, off, lut.size() * 4});
-    batch_gcols.push_back((int)gi);
+    batch_gcols->push_back((int)gi);
     a.n_gcols++;
   }
 
-  pt.mark("group luts");
   // aggregated columns, by exact name (aggregate.go:340-361); all must be present (:367-380)
   a.n_aggs = (int32_t)aggs_.size();
   int found = 0;
-  for (size_t j = 0; j < aggs_.size(); j++) {
-    AggState& A = aggs_[j];
-    const int ci = b.find(final_stage_ ? A.result_name : A.column);
-    if (ci < 0) continue;
-    found++;
-  }
+  for (size_t j = 0; j < aggs_.size(); j++)
+    if (b.find(final_stage_ ? aggs_[j].result_name : aggs_[j].column) >= 0) found++;
   if (found == 0)
     throw Error(FDB_ERR_NOT_FOUND, std::string("aggregate field(s) not found, ") + (final_stage_ ? "final " : "") + "aggregations are not possible without it");
   for (size_t j = 0; j < aggs_.size(); j++) {
@@ -641,10 +707,7 @@ void Plan::push_batch(const DeviceBatch& b) {
     K.func = A.func;
     K.type = FDB_T_NONE;
     K.slot = -1;
-    if (A.func == FDB_AGG_COUNT && !final_stage_) {
-      // CountAggregation = arr.Len(): only the row count matters; the column is not read (aggregate.go:937-950)
-      continue;
-    }
+    if (A.func == FDB_AGG_COUNT && !final_stage_) continue;  // CountAggregation = arr.Len(): the column is not read (aggregate.go:937-950)
     int32_t t = c.kind == ColKind::I64 ? FDB_T_I64 : c.kind == ColKind::F64 ? FDB_T_F64 : FDB_T_NONE;
     if (t == FDB_T_NONE)  // ErrUnsupportedSumType / MinType / MaxType (aggregate.go:736, :782, :862)
       throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported type for ") + agg_name(A.func) + " aggregation, expected int64 or float64");
@@ -658,119 +721,217 @@ void Plan::push_batch(const DeviceBatch& b) {
     R.agg_col[j] = ci;
     if (A.func == FDB_AGG_COUNT) K.func = FDB_AGG_SUM;  // final stage: COUNT merges by SUM (aggregate.go:965-969)
   }
+}
 
-  if (b.rows == 0) return;
-  pt.mark("aggs");
-  ensure_layout(caps);
-  pt.mark("layout");
-  for (int g = 0; g < a.n_gcols; g++) a.gcols[g].stride = gcols_[(size_t)batch_gcols[(size_t)g]].stride;
-  for (size_t j = 0; j < aggs_.size(); j++) a.aggs[j].acc = aggs_[j].d_acc;
-  a.cnt = d_cnt_;
-  a.n_slots = n_slots_;
-  a.need_count = 0;
-  a.ablate = ablate;
-  int n_acc_lds = 0;
-  for (size_t j = 0; j < aggs_.size(); j++) {
-    if (a.aggs[j].func == FDB_AGG_COUNT) a.need_count = 1; else n_acc_lds++;
-  }
-
-  // LDS plan: [LUT copies][cnt u32 × n_slots][acc u64 × n_slots × n_aggs]
-  size_t lds_off = 0;
-  unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
-  for (const PendingLut& p : R.luts) {
-    const bool in_lds = p.len_bytes <= 16384 && lds_off + p.len_bytes <= 32768;
-    uint32_t lds = FDB_NO_LDS;
-    if (in_lds) { lds = (uint32_t)lds_off; lds_off = align_up(lds_off + p.len_bytes, 16); }
-    if (p.kind == 0) { a.leaves[p.index].lut = d_blob + p.blob_off; a.leaves[p.index].lut_lds = lds; }
-    else { a.gcols[p.index].lut = (const uint32_t*)(d_blob + p.blob_off); a.gcols[p.index].lut_lds = lds; }
-  }
-  a.lds_lut_bytes = (uint32_t)align_up(lds_off, 16);
-  pt.mark("lut upload");
-  const size_t acc_bytes = align_up((size_t)n_slots_ * 4, 16) + (size_t)n_slots_ * 8 * aggs_.size();
-  size_t lds_bytes = a.lds_lut_bytes;
-  int grid = grid_override > 0 ? grid_override : fdb_scan_default_grid(device_);
-  if (a.lds_lut_bytes + acc_bytes <= FDB_LDS_BUDGET) {
-    a.lds_acc = 1;
-    lds_bytes += acc_bytes;
-  } else if (a.lds_lut_bytes + acc_bytes <= 150 * 1024) {
-    a.lds_acc = 1;  // one workgroup per CU
-    lds_bytes += acc_bytes;
-    if (grid_override <= 0) grid = grid / 2;
-  } else {
-    a.lds_acc = 0;
-  }
-
-  // Column slots for the load-hoisting kernel; plans that reference more columns than there are slots (or ask
-  // for an explicit rows-per-thread) run on the sequential kernel.
-  int kernel_rpt = rows_per_thread;
-  if (rows_per_thread == 0) {
-    int c4_col[FDB_MAX_C4], c8_col[FDB_MAX_C8];
+// Assigns the column slots of the load-hoisting kernel. Returns 0 if the record references more columns than the
+// kernel has slots (→ sequential kernel), 1 for the single-phase layout (≤ 2 four-byte + ≤ 1 eight-byte columns in
+// total, all in c4/c8), 2 for the two-phase layout (filter columns in c4/c8, group-by / aggregate columns in l4/l8).
+static int assign_slots(const DeviceBatch& b, Plan::Resolved& R, int first_layout = 1) {
+  FdbScanArgs& a = R.args;
+  struct Pool { FdbColSlot* slots; int32_t* n; int cap; int cols[8]; };
+  auto slot_in = [&](Pool& P, int ci, bool need_values) -> int {
+    const DevColumn& c = b.cols[(size_t)ci];
+    for (int s = 0; s < *P.n; s++)
+      if (P.cols[s] == ci) { if (need_values) P.slots[s].values = c.d_values; return s; }
+    if (*P.n >= P.cap) return -1;
+    P.cols[*P.n] = ci;
+    P.slots[*P.n].values = need_values ? c.d_values : nullptr;
+    P.slots[*P.n].validity = c.d_validity;
+    return (*P.n)++;
+  };
+  for (int layout = first_layout; layout <= 2; layout++) {
+    a.n_c4 = a.n_c8 = a.n_l4 = a.n_l8 = 0;
+    Pool e4{a.c4, &a.n_c4, layout == 1 ? 2 : FDB_MAX_C4, {0}}, e8{a.c8, &a.n_c8, layout == 1 ? 1 : FDB_MAX_C8, {0}};
+    Pool l4{a.l4, &a.n_l4, FDB_MAX_L4, {0}}, l8{a.l8, &a.n_l8, FDB_MAX_L8, {0}};
     bool ok = true;
-    auto slot_of = [&](int ci, bool wide, bool need_values) -> int {
-      const DevColumn& c = b.cols[(size_t)ci];
-      FdbColSlot* pool = wide ? a.c8 : a.c4;
-      int* cols = wide ? c8_col : c4_col;
-      int32_t& n = wide ? a.n_c8 : a.n_c4;
-      const int cap = wide ? FDB_MAX_C8 : FDB_MAX_C4;
-      for (int s = 0; s < n; s++)
-        if (cols[s] == ci) { if (need_values) pool[s].values = c.d_values; return s; }
-      if (n >= cap) { ok = false; return -1; }
-      cols[n] = ci;
-      pool[n].values = need_values ? c.d_values : nullptr;
-      pool[n].validity = c.d_validity;
-      return n++;
-    };
     for (int l = 0; l < a.n_leaves && ok; l++) {
       if (R.leaf_col[l] < 0) continue;
-      a.leaves[l].slot = slot_of(R.leaf_col[l], a.leaves[l].wide != 0, a.leaves[l].kind != FDB_LEAF_VALIDITY);
+      a.leaves[l].slot = slot_in(a.leaves[l].wide ? e8 : e4, R.leaf_col[l], a.leaves[l].kind != FDB_LEAF_VALIDITY);
+      ok = a.leaves[l].slot >= 0;
     }
-    for (int g = 0; g < a.n_gcols && ok; g++) a.gcols[g].slot = slot_of(R.gcol_col[g], false, true);
+    // group-by and aggregate columns: same pools in the single-phase layout, the late pools otherwise (a column the
+    // filter also reads is simply loaded a second time — it is in L2 by then)
+    for (int g = 0; g < a.n_gcols && ok; g++) { a.gcols[g].slot = slot_in(layout == 1 ? e4 : l4, R.gcol_col[g], true); ok = a.gcols[g].slot >= 0; }
     for (int j = 0; j < a.n_aggs && ok; j++)
-      if (R.agg_col[j] >= 0 && a.aggs[j].values != nullptr) a.aggs[j].slot = slot_of(R.agg_col[j], true, true);
-    if (!ok) { kernel_rpt = 4; a.n_c4 = a.n_c8 = 0; }
+      if (R.agg_col[j] >= 0 && a.aggs[j].values != nullptr) { a.aggs[j].slot = slot_in(layout == 1 ? e8 : l8, R.agg_col[j], true); ok = a.aggs[j].slot >= 0; }
+    if (ok) return layout;
   }
-  if (kernel_rpt == 0 && grid_override <= 0) {
-    // geometry of the slot kernel: workgroups per CU bounded by registers (5 waves/SIMD) and LDS
-    const int cus = fdb_scan_default_grid(device_) / 2;
-    const int per_cu_regs = fdb_slot_kernel_blocks_per_cu(a.n_c4, a.n_c8);
-    const int per_cu_lds = a.lds_acc ? (int)((150 * 1024) / std::max<size_t>(lds_bytes, 1)) : per_cu_regs;
-    grid = cus * std::max(1, std::min(per_cu_regs, per_cu_lds));
-  }
+  a.n_c4 = a.n_c8 = a.n_l4 = a.n_l8 = 0;
+  return 0;
+}
 
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (timing) {
-    e0 = ctx_->get_event(); e1 = ctx_->get_event();
-    hip_check(hipEventRecord(e0, stream_), "hipEventRecord");
-  }
-  grid = fdb_scan_grid(a, grid, kernel_rpt);
-  if (a.lds_acc && use_partials && grid > 0) {
-    const size_t n_arrays = 1 + aggs_.size();
-    void* p = ctx_->dev_alloc((size_t)grid * n_arrays * n_slots_ * 8);
-    scratch_.push_back(p);
-    a.partials = (unsigned long long*)p;
-  }
-  pt.mark("slots+scratch");
-  hip_check(fdb_launch_scan_dense(a, grid, lds_bytes, kernel_rpt, stream_), "scan launch");
-  pt.mark("scan launch");
-  if (timing) {
-    hip_check(hipEventRecord(e1, stream_), "hipEventRecord");
-    pending_events_.emplace_back(e0, e1);
-  }
-  if (a.partials != nullptr) {
-    int32_t funcs[1 + FDB_MAX_AGGS] = {0};
-    funcs[0] = 1;
-    for (size_t j = 0; j < aggs_.size(); j++) {
-      const int32_t f = a.aggs[j].func;
-      funcs[1 + j] = f == FDB_AGG_COUNT ? 0 : f == FDB_AGG_SUM ? (a.aggs[j].type == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
+// ≙ Callback for `n` resident records at once: ONE fused scan launch covers all of them (per-launch costs — LDS
+// table init, ramp-up, tail, table flush — are paid once per scan instead of once per record).
+void Plan::push_batches(const DeviceBatch* const* bs, int n) {
+  if (finished_) throw Error(FDB_ERR_STATE, "push after finish");
+  if (aggs_.empty()) throw Error(FDB_ERR_STATE, "filter-only plan: use fdb_plan_filter / fdb_plan_select");
+  for (int i = 0; i < n; i++)
+    if (bs[i]->device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  PhaseTimer pt;
+
+  std::vector<Resolved> Rs((size_t)n);
+  std::vector<std::vector<int>> part_gcols((size_t)n);
+  for (int i = 0; i < n; i++) resolve_batch(*bs[i], &Rs[(size_t)i], &part_gcols[(size_t)i]);
+  pt.mark("resolve");
+  std::vector<int> live;  // records with rows
+  for (int i = 0; i < n; i++) if (bs[i]->rows > 0) live.push_back(i);
+  if (live.empty()) return;
+
+  std::vector<uint32_t> caps;
+  for (const GroupColState& g : gcols_) caps.push_back((uint32_t)g.values.size() + 1);
+  ensure_layout(caps);
+  pt.mark("layout");
+
+  // one blob for every LUT of every record
+  Blob blob;
+  std::vector<size_t> blob_base((size_t)n, 0);
+  std::vector<int> lut_class((size_t)n, 0);
+  {
+    // records whose LUT sets are byte-identical (the usual case: parts of one table share dictionaries) share one
+    // device copy and one class id, so the kernel re-stages LUTs in LDS only when the class changes
+    std::vector<int> reps;
+    for (int i : live) {
+      const Resolved& R = Rs[(size_t)i];
+      int found = -1;
+      for (int r : reps) {
+        const Resolved& Q = Rs[(size_t)r];
+        if (Q.blob.bytes == R.blob.bytes && Q.luts.size() == R.luts.size()) {
+          bool same = true;
+          for (size_t k = 0; k < R.luts.size() && same; k++)
+            same = Q.luts[k].kind == R.luts[k].kind && Q.luts[k].index == R.luts[k].index && Q.luts[k].blob_off == R.luts[k].blob_off &&
+                   Q.luts[k].len_bytes == R.luts[k].len_bytes;
+          if (same) { found = r; break; }
+        }
+      }
+      if (found >= 0) { blob_base[(size_t)i] = blob_base[(size_t)found]; lut_class[(size_t)i] = lut_class[(size_t)found]; }
+      else { blob_base[(size_t)i] = blob.add(R.blob.bytes.data(), R.blob.bytes.size()); lut_class[(size_t)i] = (int)reps.size(); reps.push_back(i); }
     }
-    hip_check(fdb_launch_reduce_partials(a.partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, stream_),
-              "reduce partials");
+  }
+  unsigned char* d_blob = blob.bytes.empty() ? nullptr : (unsigned char*)upload(blob.bytes.data(), blob.bytes.size());
+
+  const size_t acc_bytes = align_up((size_t)n_slots_ * 4, 16) + (size_t)n_slots_ * 8 * aggs_.size();
+  size_t lut_lds_max = 0;
+  bool slots_ok = rows_per_thread == 0;
+  std::vector<int> layouts;
+  for (int i : live) {
+    Resolved& R = Rs[(size_t)i];
+    FdbScanArgs& a = R.args;
+    for (int g = 0; g < a.n_gcols; g++) a.gcols[g].stride = gcols_[(size_t)part_gcols[(size_t)i][(size_t)g]].stride;
+    for (size_t j = 0; j < aggs_.size(); j++) a.aggs[j].acc = aggs_[j].d_acc;
+    a.cnt = d_cnt_;
+    a.n_slots = n_slots_;
+    a.need_count = 0;
+    a.ablate = ablate;
+    for (size_t j = 0; j < aggs_.size(); j++) if (a.aggs[j].func == FDB_AGG_COUNT) a.need_count = 1;
+    a.lut_class = lut_class[(size_t)i];
+    // LDS plan: [LUT copies][cnt u32 × n_slots][acc u64 × n_slots × n_aggs]
+    size_t lds_off = 0;
+    for (const PendingLut& p : R.luts) {
+      const bool in_lds = p.len_bytes <= 16384 && lds_off + p.len_bytes <= 32768;
+      uint32_t lds = FDB_NO_LDS;
+      if (in_lds) { lds = (uint32_t)lds_off; lds_off = align_up(lds_off + p.len_bytes, 16); }
+      unsigned char* at = d_blob + blob_base[(size_t)i] + p.blob_off;
+      if (p.kind == 0) { a.leaves[p.index].lut = at; a.leaves[p.index].lut_lds = lds; }
+      else { a.gcols[p.index].lut = (const uint32_t*)at; a.gcols[p.index].lut_lds = lds; }
+    }
+    lut_lds_max = std::max(lut_lds_max, align_up(lds_off, 16));
+    if (slots_ok) {
+      const int layout = assign_slots(*bs[i], R);
+      if (layout == 0) slots_ok = false;
+      layouts.push_back(layout);
+    }
+  }
+  int lds_acc = 0;
+  size_t lds_bytes = lut_lds_max;
+  int base_grid = grid_override > 0 ? grid_override : fdb_scan_default_grid(device_);
+  if (lut_lds_max + acc_bytes <= FDB_LDS_BUDGET) { lds_acc = 1; lds_bytes += acc_bytes; }
+  else if (lut_lds_max + acc_bytes <= 150 * 1024) { lds_acc = 1; lds_bytes += acc_bytes; if (grid_override <= 0) base_grid /= 2; }
+  for (int i : live) { Rs[(size_t)i].args.lds_lut_bytes = (uint32_t)lut_lds_max; Rs[(size_t)i].args.lds_acc = lds_acc; }
+  pt.mark("lut upload");
+
+  int32_t funcs[1 + FDB_MAX_AGGS] = {0};
+  funcs[0] = 1;
+  {
+    const FdbScanArgs& a0 = Rs[(size_t)live[0]].args;
+    for (size_t j = 0; j < aggs_.size(); j++) {
+      const int32_t f = a0.aggs[j].func;
+      const int32_t ty = aggs_[j].type;
+      funcs[1 + j] = f == FDB_AGG_COUNT ? 0 : f == FDB_AGG_SUM ? (ty == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
+    }
+  }
+  auto timed_launch = [&](const std::function<void()>& launch) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) {
+      e0 = ctx_->get_event(); e1 = ctx_->get_event();
+      hip_check(hipEventRecord(e0, stream_), "hipEventRecord");
+    }
+    launch();
+    if (timing) {
+      hip_check(hipEventRecord(e1, stream_), "hipEventRecord");
+      pending_events_.emplace_back(e0, e1);
+    }
+  };
+  auto alloc_partials = [&](int grid) -> unsigned long long* {
+    if (!lds_acc || !use_partials || grid <= 0) return nullptr;
+    void* p = ctx_->dev_alloc((size_t)grid * (1 + aggs_.size()) * n_slots_ * 8);
+    scratch_.push_back(p);
+    return (unsigned long long*)p;
+  };
+
+  if (slots_ok) {
+    // ---- one launch of the slot kernel over every record -----------------------------------------------------
+    // records that fit the single-phase layout also fit the two-phase one: re-assign them if the launch is mixed
+    int two_phase = 0;
+    for (int l : layouts) if (l == 2) two_phase = 1;
+    if (two_phase) {
+      size_t k = 0;
+      for (int i : live)
+        if (layouts[k++] == 1 && assign_slots(*bs[i], Rs[(size_t)i], 2) != 2) throw Error(FDB_ERR_INVALID, "internal: slot re-assignment failed");
+    }
+    int tile_rows_i = 0, per_cu = 1;
+    const int sub = sub_tiles;  // slot-kernel variant mode (0 = default)
+    fdb_slot_geometry(two_phase, sub, lds_acc, lds_bytes, device_, &tile_rows_i, &per_cu);
+    int grid = grid_override > 0 ? grid_override : (fdb_scan_default_grid(device_) / 2) * per_cu;
+    const int64_t tile_rows = tile_rows_i;
+    int64_t total_tiles = 0;
+    std::vector<FdbScanArgs> parts;
+    for (int i : live) {
+      FdbScanArgs& a = Rs[(size_t)i].args;
+      a.tile_begin = total_tiles;
+      total_tiles += (a.n_rows + tile_rows - 1) / tile_rows;
+      a.tile_end = total_tiles;
+      parts.push_back(a);
+    }
+    if (grid > total_tiles) grid = (int)total_tiles;
+    unsigned long long* partials = alloc_partials(grid);
+    for (FdbScanArgs& a : parts) a.partials = partials;
+    const FdbScanArgs* d_parts = (const FdbScanArgs*)upload(parts.data(), parts.size() * sizeof(FdbScanArgs));
+    pt.mark("parts upload");
+    timed_launch([&] {
+      hip_check(fdb_launch_scan_slots(d_parts, (int)parts.size(), parts[0], total_tiles, grid, lds_bytes, two_phase, sub, stream_), "scan launch");
+    });
+    pt.mark("scan launch");
+    if (partials != nullptr)
+      hip_check(fdb_launch_reduce_partials(partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, stream_), "reduce partials");
+    stat_launches += 1;
+  } else {
+    // ---- sequential kernel, one launch per record ----------------------------------------------------------------
+    const int rpt = rows_per_thread == 8 ? 8 : 4;
+    for (int i : live) {
+      FdbScanArgs& a = Rs[(size_t)i].args;
+      a.n_c4 = a.n_c8 = 0;
+      const int grid = fdb_scan_grid(a, base_grid, rpt);
+      a.partials = alloc_partials(grid);
+      timed_launch([&] { hip_check(fdb_launch_scan_dense(a, grid, lds_bytes, rpt, stream_), "scan launch"); });
+      if (a.partials != nullptr)
+        hip_check(fdb_launch_reduce_partials(a.partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, stream_), "reduce partials");
+      stat_launches += 1;
+    }
   }
   pt.mark("reduce launch");
   state_dirty_ = true;
-  stat_bytes += R.bytes;
-  stat_launches += 1;
-  stat_rows += b.rows;
+  for (int i : live) { stat_bytes += Rs[(size_t)i].bytes; stat_rows += bs[i]->rows; }
 }
 
 // ---- finish / export ----------------------------------------------------------------------------------------

@@ -110,6 +110,7 @@ class Plan {
 
   void push(const ArrowArray* array, const ArrowSchema* schema);        // ≙ Callback
   void push_batch(const DeviceBatch& batch);
+  void push_batches(const DeviceBatch* const* batches, int n);         // one fused launch over n resident records
   void finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows);  // ≙ Finish
   void merge_from(Plan& src);                                          // ≙ Synchronizer + final stage
   void select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* indices, int64_t capacity, int64_t* n_selected);
@@ -129,11 +130,13 @@ class Plan {
   int rows_per_thread = 0;  // 0: slot (load-hoisting) kernel; 4 / 8: sequential kernel
   int grid_override = 0;
   int ablate = 0;
+  int sub_tiles = 0;  // slot kernel variant mode: 0 default, 1: 512 thr, 2: 256 thr, 3: 1024 thr, 4: 512 thr × 2 sub-tiles
   bool use_partials = true;  // LDS mode: flush workgroup tables with plain stores + a fold kernel instead of atomics
   struct Resolved;  // per-batch kernel arguments (fdb_plan.cpp)
 
  private:
   bool references(const std::string& column) const;
+  void resolve_batch(const DeviceBatch& b, Resolved* R, std::vector<int>* batch_gcols);
   void ensure_layout(const std::vector<uint32_t>& new_caps);
   void sync();
   void collect_timing();

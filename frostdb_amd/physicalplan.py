@@ -54,6 +54,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_create.argtypes = [vp, ctypes.c_int, P(vp)]
     L.fdb_plan_push.argtypes = [vp, vp, vp]
     L.fdb_plan_push_batch.argtypes = [vp, vp]
+    L.fdb_plan_push_batches.argtypes = [vp, P(vp), i32]
     L.fdb_plan_finish.argtypes = [vp, vp, vp, P(i64)]
     L.fdb_plan_merge.argtypes = [vp, vp]
     L.fdb_plan_filter.argtypes = [vp, vp, vp, vp, vp, P(i64)]
@@ -152,6 +153,11 @@ class HashAggregatePlan:
             return
         with ExportedBatch(record) as ex:
             self._check(lib().fdb_plan_push(self.handle, ctypes.addressof(ex.array), ctypes.addressof(ex.schema)))
+
+    def CallbackResident(self, records: Sequence[ResidentBatch]) -> None:
+        """Callback for several HBM-resident records at once: one fused kernel launch over all of them."""
+        arr = (ctypes.c_void_p * len(records))(*[r.handle for r in records])
+        self._check(lib().fdb_plan_push_batches(self.handle, arr, len(records)))
 
     def Finish(self) -> pa.RecordBatch:
         arr, sch = ArrowArray(), ArrowSchema()

@@ -154,6 +154,9 @@ int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
 int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema);
 /* Same, for a record that is already resident in HBM. */
 int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch);
+/* Same, for `n` resident records at once (≙ the TableScan handing a chain every part it owns): one fused kernel
+ * launch scans all of them, so per-launch costs are paid once per scan instead of once per record. */
+int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n);
 /* ≙ PhysicalPlan.Finish: waits for the device, emits ONE record (group columns in first-seen field
  * order with their input Arrow type, then one column per aggregation named "<func>(<column>)")
  * (aggregate.go:543-633). The caller owns `out`/`out_schema` and must call their release().

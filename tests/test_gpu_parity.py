@@ -186,6 +186,30 @@ def test_config3_multibatch(pp, resident, rpt):
     assert_same_result(got, want, cols, float_cols={"sum(value)"})
 
 
+def test_multi_record_single_launch(pp):
+    """fdb_plan_push_batches: records with different dictionaries, sizes (incl. empty and sub-tile) and column sets
+    scanned by ONE launch give the same result as the oracle fed record by record."""
+    rng = np.random.default_rng(99)
+    batches = [make_prometheus_batch(rng, n, n_path=int(p)) for n, p in
+               [(10_000, 30), (0, 5), (3, 50), (2048, 7), (2049, 90), (70_001, 64), (1, 1)]]
+    # one record lacks the filter column `labels.instance` entirely (missing-column rules) and has extra labels
+    b = make_prometheus_batch(rng, 5000, n_path=11)
+    b = b.drop_columns(["labels.instance"])
+    batches.insert(3, b)
+    for cfg in (CFG2, CFG3):
+        want = run_oracle(batches, **cfg)
+        plan = pp.HashAggregatePlan(cfg["filter_expr"], cfg["aggs"], cfg["groups"])
+        keep = [pp.ResidentBatch(x) for x in batches]
+        try:
+            plan.CallbackResident(keep[:5])
+            plan.CallbackResident(keep[5:])
+            got = arrow_to_pydict(plan.Finish())
+        finally:
+            plan.Close()
+        cols = ["labels.path"] + [a.Name() for a in cfg["aggs"]]
+        assert_same_result(got, want, cols, float_cols={"sum(value)"})
+
+
 def test_group_by_dynamic_labels_with_growing_dictionaries(pp):
     """Group by the whole dynamic column set; later batches add dictionary entries AND a new label column,
     which forces the dense table to be re-laid-out (mixed-radix strides change)."""
