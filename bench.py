@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--rows-per-thread", type=int, default=0, help="0: slot kernel (default); 4/8: sequential kernel")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--per-record-launch", action="store_true", help="one kernel launch per resident record instead of one per scan")
+    ap.add_argument("--force-merge", action="store_true", help="run the RCCL merge path even with one rank (functional check on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=3.0)
     ap.add_argument("--sweep", action="store_true", help="kernel geometry sweep first (tuning aid; table on stderr)")
@@ -87,8 +88,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or args.force_merge:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from frostdb_amd import build as fb
     if rank == 0:
@@ -139,7 +142,7 @@ def main():
                 plan.Callback(rb)
         else:
             plan.CallbackResident(resident)
-        out = merge_plan(plan) if world > 1 else plan.Finish()
+        out = merge_plan(plan) if (world > 1 or args.force_merge) else plan.Finish()
         st = plan.stats() if timing else None
         plan.Close()
         return out, st
@@ -147,7 +150,8 @@ def main():
     # ---- correctness of what is being timed -------------------------------------------------------------------
     out, _ = step()
     if args.config == 2 and world == 1:
-        got = {k: v for k, v in zip(out.column(0).dictionary_decode().to_pylist(), out.column(1).to_pylist())}
+        col0 = out.column(0).dictionary_decode() if hasattr(out.column(0), "dictionary_decode") else out.column(0)
+        got = {k: v for k, v in zip(col0.to_pylist(), out.column(1).to_pylist())}
         paths = synth.PATHS + [None]
         for i, p in enumerate(paths):
             if exp_cnt[i] == 0:
@@ -217,7 +221,7 @@ def main():
             "setup": {"gen_and_upload_s": t_gen, "hbm_resident_bytes": hbm_bytes},
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.force_merge:
         dist.destroy_process_group()
 
 

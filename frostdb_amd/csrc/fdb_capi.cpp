@@ -117,6 +117,21 @@ int fdb_plan_partial_state(fdb_plan* plan, int32_t agg, void* dst, int64_t capac
   return guard(plan, [&] { plan->plan.partial_state(agg, dst, capacity_bytes); });
 }
 
+int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slots) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { *signature = plan->plan.state_signature(n_slots); });
+}
+
+int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.state_read(array, dst, capacity_bytes); });
+}
+
+int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t bytes) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.state_write(array, src, bytes); });
+}
+
 int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out) {
   if (!plan) return FDB_ERR_INVALID;
   return guard(plan, [&] { *format_out = plan->plan.agg_format(agg); });

@@ -106,6 +106,8 @@ struct FdbScanArgs {
   int32_t ablate;           // tuning aid (bench --ablate): 1 skip occupancy, 2 skip aggregate atomics, 4 skip group LUTs, 8 skip filter
   int32_t lut_class;        // records with the same class carry byte-identical LUT sets at the same LDS offsets
   uint8_t code[FDB_MAX_CODE];
+  uint32_t ops_after[FDB_MAX_LEAVES];  // slot kernel: the AND/OR ops that follow leaf l in postfix order: [3:0] count, then 2 bits
+                                       // per op (1 AND, 2 OR); 0xFFFFFFFF if the program does not fit this form
   FdbLeaf leaves[FDB_MAX_LEAVES];
   FdbGroupCol gcols[FDB_MAX_DENSE_GCOLS];
   FdbAgg aggs[FDB_MAX_AGGS];
@@ -135,8 +137,8 @@ hipError_t fdb_launch_scan_dense(const FdbScanArgs& args, int grid_blocks, size_
                                  hipStream_t stream);
 // Number of workgroups fdb_launch_scan_dense will actually launch for `grid_blocks` requested (clamped to the tile count).
 int fdb_scan_grid(const FdbScanArgs& args, int grid_blocks, int rows_per_thread);
-// Folds the per-workgroup partial tables into the global table: state[arr * state_stride + slot] (op)= Σ_b partials[b][arr][slot],
-// in workgroup order (deterministic). funcs[arr]: 0 skip, 1 add u64, 2 add f64, 3 min i64, 4 max i64.
+// Folds the per-workgroup partial tables into the global table: state[arr * state_stride + slot] (op)= Σ_b partials[b][arr][slot].
+// funcs[arr]: 0 skip, 1 add u64, 2 add f64, 3 min i64, 4 max i64.
 hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_blocks, int n_arrays, uint32_t n_slots,
                                       unsigned long long* state, uint64_t state_stride, const int32_t* funcs, hipStream_t stream);
 // The slot kernel over `n_parts` records in ONE launch. `d_parts` is the device copy of the per-record argument

@@ -360,6 +360,9 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
 // whatever work was ablated. Here a cfg-2 wave has 66 B/lane in flight.
 // =========================================================================================================
 #define SLOT_BLOCK 512
+#define SLOT_MAX_LEAVES 6
+#define SLOT_MAX_GCOLS 2
+#define SLOT_MAX_AGGS 6
 
 template <int NC4, int NC8>
 struct SlotRegs {
@@ -369,30 +372,75 @@ struct SlotRegs {
   uint32_t v8[NC8 > 0 ? NC8 : 1];
 };
 
-template <int NC4, int NC8>
-__device__ __forceinline__ void slot_load(const FdbColSlot* c4, int n_c4, const FdbColSlot* c8, int n_c8, int64_t row0, SlotRegs<NC4, NC8>& S) {
+// The plan of ONE record, decoded once (when a workgroup enters the record) into wave-uniform values that
+// stay in scalar registers across the tile loop. Everything is indexed with compile-time constants, so the
+// per-tile code contains no descriptor loads at all: the sequential kernel and the first slot kernel spent
+// ≈40 dependent scalar loads and ≈300 scalar ALU instructions per 256-row tile re-reading their argument block.
+template <int NC4, int NC8, int L4, int L8>
+struct PlanRegs {
+  int64_t n_rows, tile_begin;
+  const void* v4[NC4 > 0 ? NC4 : 1]; const uint8_t* b4[NC4 > 0 ? NC4 : 1];
+  const void* v8[NC8 > 0 ? NC8 : 1]; const uint8_t* b8[NC8 > 0 ? NC8 : 1];
+  const void* lv4[L4 > 0 ? L4 : 1]; const uint8_t* lb4[L4 > 0 ? L4 : 1];
+  const void* lv8[L8 > 0 ? L8 : 1]; const uint8_t* lb8[L8 > 0 ? L8 : 1];
+  int n_leaves, n_gcols, need_count;
+  struct { int kind, slot, wide, op; uint32_t lut_lds, lut_len, ops_after; long long lit; const uint8_t* lut; } leaf[SLOT_MAX_LEAVES];
+  struct { int slot; uint32_t lut_lds, stride; const uint32_t* lut; } gcol[SLOT_MAX_GCOLS];
+  struct { int func, type, slot; unsigned long long* acc; } agg[SLOT_MAX_AGGS];
+  unsigned long long* cnt;
+};
+
+template <int NC4, int NC8, int L4, int L8>
+__device__ __forceinline__ void decode_plan(const FdbScanArgs& a, PlanRegs<NC4, NC8, L4, L8>& P) {
+  P.n_rows = a.n_rows; P.tile_begin = a.tile_begin;
 #pragma unroll
-  for (int s = 0; s < NC4; s++) {
-    S.r4[s] = u32x4{0, 0, 0, 0};
-    S.v4[s] = 0xFu;
-    if (s < n_c4) {
-      if (c4[s].values != nullptr) S.r4[s] = __builtin_nontemporal_load(as_global(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(c4[s].values) + row0)));
-      if (c4[s].validity != nullptr) S.v4[s] = load_valid<4>(c4[s].validity, row0);
-    }
+  for (int s = 0; s < NC4; s++) { P.v4[s] = s < a.n_c4 ? a.c4[s].values : nullptr; P.b4[s] = s < a.n_c4 ? a.c4[s].validity : nullptr; }
+#pragma unroll
+  for (int s = 0; s < NC8; s++) { P.v8[s] = s < a.n_c8 ? a.c8[s].values : nullptr; P.b8[s] = s < a.n_c8 ? a.c8[s].validity : nullptr; }
+#pragma unroll
+  for (int s = 0; s < L4; s++) { P.lv4[s] = s < a.n_l4 ? a.l4[s].values : nullptr; P.lb4[s] = s < a.n_l4 ? a.l4[s].validity : nullptr; }
+#pragma unroll
+  for (int s = 0; s < L8; s++) { P.lv8[s] = s < a.n_l8 ? a.l8[s].values : nullptr; P.lb8[s] = s < a.n_l8 ? a.l8[s].validity : nullptr; }
+  P.n_leaves = a.n_leaves; P.n_gcols = a.n_gcols; P.need_count = a.need_count; P.cnt = a.cnt;
+#pragma unroll
+  for (int l = 0; l < SLOT_MAX_LEAVES; l++) {
+    const FdbLeaf& L = a.leaves[l];
+    P.leaf[l].kind = L.kind; P.leaf[l].slot = L.slot; P.leaf[l].wide = L.wide; P.leaf[l].op = L.op;
+    P.leaf[l].lut_lds = L.lut_lds; P.leaf[l].lut_len = L.lut_len; P.leaf[l].ops_after = a.ops_after[l]; P.leaf[l].lit = L.lit;
+    P.leaf[l].lut = L.lut;
   }
 #pragma unroll
-  for (int s = 0; s < NC8; s++) {
+  for (int g = 0; g < SLOT_MAX_GCOLS; g++) {
+    P.gcol[g].slot = a.gcols[g].slot; P.gcol[g].lut_lds = a.gcols[g].lut_lds; P.gcol[g].stride = a.gcols[g].stride; P.gcol[g].lut = a.gcols[g].lut;
+  }
+#pragma unroll
+  for (int j = 0; j < SLOT_MAX_AGGS; j++) {
+    P.agg[j].func = a.aggs[j].func; P.agg[j].type = a.aggs[j].type; P.agg[j].slot = a.aggs[j].slot; P.agg[j].acc = a.aggs[j].acc;
+  }
+}
+
+template <int N4, int N8>
+__device__ __forceinline__ void slot_load(const void* const (&v4)[N4 > 0 ? N4 : 1], const uint8_t* const (&b4)[N4 > 0 ? N4 : 1],
+                                          const void* const (&v8)[N8 > 0 ? N8 : 1], const uint8_t* const (&b8)[N8 > 0 ? N8 : 1], int64_t row0,
+                                          SlotRegs<N4, N8>& S) {
+#pragma unroll
+  for (int s = 0; s < N4; s++) {
+    S.r4[s] = u32x4{0, 0, 0, 0};
+    S.v4[s] = 0xFu;
+    if (v4[s] != nullptr) S.r4[s] = __builtin_nontemporal_load(as_global(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(v4[s]) + row0)));
+    if (b4[s] != nullptr) S.v4[s] = load_valid<4>(b4[s], row0);
+  }
+#pragma unroll
+  for (int s = 0; s < N8; s++) {
     S.r8[s][0] = u64x2{0, 0};
     S.r8[s][1] = u64x2{0, 0};
     S.v8[s] = 0xFu;
-    if (s < n_c8) {
-      if (c8[s].values != nullptr) {
-        const FDB_GLOBAL u64x2* p = as_global(reinterpret_cast<const u64x2*>(reinterpret_cast<const unsigned long long*>(c8[s].values) + row0));
-        S.r8[s][0] = __builtin_nontemporal_load(p);
-        S.r8[s][1] = __builtin_nontemporal_load(p + 1);
-      }
-      if (c8[s].validity != nullptr) S.v8[s] = load_valid<4>(c8[s].validity, row0);
+    if (v8[s] != nullptr) {
+      const FDB_GLOBAL u64x2* p = as_global(reinterpret_cast<const u64x2*>(reinterpret_cast<const unsigned long long*>(v8[s]) + row0));
+      S.r8[s][0] = __builtin_nontemporal_load(p);
+      S.r8[s][1] = __builtin_nontemporal_load(p + 1);
     }
+    if (b8[s] != nullptr) S.v8[s] = load_valid<4>(b8[s], row0);
   }
 }
 
@@ -416,63 +464,74 @@ __device__ __forceinline__ void pick8(const SlotRegs<NC4, NC8>& S, int slot, uns
   raw[0] = q0.x; raw[1] = q0.y; raw[2] = q1.x; raw[3] = q1.y;
 }
 
+// One leaf over the 4 rows of a lane; every argument except S is wave-uniform and register-resident.
 template <int NC4, int NC8>
-__device__ __forceinline__ uint32_t slot_eval_leaf(const FdbLeaf& L, const SlotRegs<NC4, NC8>& S, const unsigned char* smem) {
+__device__ __forceinline__ uint32_t slot_eval_leaf(int kind, int slot, int wide, int op, uint32_t lut_lds, uint32_t lut_len, long long lit,
+                                                   const uint8_t* lut_g, const SlotRegs<NC4, NC8>& S, const unsigned char* smem) {
   constexpr int R = 4;
   constexpr uint32_t FULL = 0xFu;
-  if (L.kind == FDB_LEAF_CONST) return L.op ? FULL : 0u;
+  if (kind == FDB_LEAF_CONST) return op ? FULL : 0u;
   uint32_t valid, m = 0;
-  if (!L.wide) {
+  if (!wide) {
     uint32_t idx[R];
-    pick4(S, L.slot, idx, valid);
-    if (L.kind == FDB_LEAF_VALIDITY) return L.op ? valid : (~valid & FULL);
-    const uint32_t null_at = L.lut_len - 1u;
+    pick4(S, slot, idx, valid);
+    if (kind == FDB_LEAF_VALIDITY) return op ? valid : (~valid & FULL);
+    const uint32_t null_at = lut_len - 1u;
 #pragma unroll
     for (int r = 0; r < R; r++) idx[r] = ((valid >> r) & 1u) ? idx[r] : null_at;
-    if (L.kind == FDB_LEAF_DICT_BITS) {
-      const unsigned long long bits = (unsigned long long)L.lit;
+    if (kind == FDB_LEAF_DICT_BITS) {
+      const unsigned long long bits = (unsigned long long)lit;
 #pragma unroll
       for (int r = 0; r < R; r++) m |= (uint32_t)((bits >> idx[r]) & 1ull) << r;
-    } else if (L.lut_lds != FDB_NO_LDS) {
-      const unsigned char* lut = smem + L.lut_lds;
+    } else if (lut_lds != FDB_NO_LDS) {
+      const unsigned char* lut = smem + lut_lds;
 #pragma unroll
       for (int r = 0; r < R; r++) m |= (uint32_t)lut[idx[r]] << r;
     } else {
 #pragma unroll
-      for (int r = 0; r < R; r++) m |= (uint32_t)as_global(L.lut)[idx[r]] << r;
+      for (int r = 0; r < R; r++) m |= (uint32_t)as_global(lut_g)[idx[r]] << r;
     }
     return m;
   }
   unsigned long long raw[R];
-  pick8(S, L.slot, raw, valid);
-  if (L.kind == FDB_LEAF_VALIDITY) return L.op ? valid : (~valid & FULL);
-  if (L.kind == FDB_LEAF_CMP_I64) {
+  pick8(S, slot, raw, valid);
+  if (kind == FDB_LEAF_VALIDITY) return op ? valid : (~valid & FULL);
+  if (kind == FDB_LEAF_CMP_I64) {
     long long v[R];
 #pragma unroll
     for (int r = 0; r < R; r++) v[r] = (long long)raw[r];
-    m = cmp_mask<R, long long>(v, (long long)L.lit, L.op);
-  } else if (L.kind == FDB_LEAF_CMP_U64) {
-    m = cmp_mask<R, unsigned long long>(raw, (unsigned long long)L.lit, L.op);
-  } else if (L.kind == FDB_LEAF_CMP_F64) {
+    m = cmp_mask<R, long long>(v, lit, op);
+  } else if (kind == FDB_LEAF_CMP_U64) {
+    m = cmp_mask<R, unsigned long long>(raw, (unsigned long long)lit, op);
+  } else if (kind == FDB_LEAF_CMP_F64) {
     double v[R];
 #pragma unroll
     for (int r = 0; r < R; r++) v[r] = __longlong_as_double((long long)raw[r]);
-    m = cmp_mask<R, double>(v, __longlong_as_double(L.lit), L.op);
+    m = cmp_mask<R, double>(v, __longlong_as_double(lit), op);
   } else {
     double v[R];
 #pragma unroll
     for (int r = 0; r < R; r++) v[r] = (double)(long long)raw[r];
-    m = cmp_mask<R, double>(v, __longlong_as_double(L.lit), L.op);
+    m = cmp_mask<R, double>(v, __longlong_as_double(lit), op);
   }
   return m & valid;
 }
 
-template <bool LDS, int NC4, int NC8, int L4, int L8, int T, int BLK>
+// =========================================================================================================
+// Slot kernel. Per tile: (1) issue the loads of every column the FILTER reads (≤ NC4 four-byte + NC8 eight-byte
+// column slots, unrolled, wave-uniform predicates) — or of every column at all in the single-phase instance;
+// (2) evaluate the predicate; (3) two-phase instance only: load the group-by / aggregate columns (late
+// materialisation: nothing is fetched for a lane whose 4 rows were all filtered out); (4) accumulate into the
+// workgroup's LDS table. The sequential kernel above keeps ONE column in flight per wave; this one keeps all of
+// a phase's columns in flight, and carries its decoded plan in scalar registers.
+// =========================================================================================================
+template <bool LDS, int NC4, int NC8, int L4, int L8, int BLK>
 __global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __restrict__ parts, const int n_parts,
-                                                                const int64_t total_tiles, const FdbScanArgs c) {
+                                                         const int64_t total_tiles, const FdbScanArgs c) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int R = 4;
   constexpr uint32_t FULL = 0xFu;
+  constexpr bool TWO_PHASE = (L4 + L8) > 0;
   const int tid = threadIdx.x;
   const uint32_t n_slots = c.n_slots;
 
@@ -488,166 +547,135 @@ __global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __re
   }
 
   // Global tiles are numbered across the records of this launch; a workgroup walks them grid-stride, so it
-  // visits the records in order and re-stages the per-dictionary LUTs only when it crosses a record boundary.
-  // A tile is T sub-tiles of BLK × 4 rows: every lane owns 4 consecutive rows in each sub-tile, so each
-  // load instruction stays lane-contiguous (16 B per lane) while ONE pass of the plan interpreter (scalar
-  // descriptor loads, uniform branches) is amortised over 4·T rows per lane.
-  constexpr int64_t sub_rows = (int64_t)BLK * R;
-  constexpr int64_t tile_rows = sub_rows * T;
+  // visits the records in order; on entering a record it decodes that record's plan into registers and, if the
+  // record's LUT set differs from the one staged in LDS, re-stages it.
+  constexpr int64_t tile_rows = (int64_t)BLK * R;
+  PlanRegs<NC4, NC8, L4, L8> P;
   int part = -1, lut_class = -1;
+  int64_t tile_end = 0;
   for (int64_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    int np = part < 0 ? 0 : part;
-    while (np + 1 < n_parts && tile >= parts[np].tile_end) np++;
-    if (np != part) part = np;
-    if (parts[part].lut_class != lut_class) {
-      lut_class = parts[part].lut_class;
-      __syncthreads();  // every wave is done with the previous record's LUTs (and with the table init)
+    if (part < 0 || tile >= tile_end) {
+      int np = part < 0 ? 0 : part;
+      while (np + 1 < n_parts && tile >= parts[np].tile_end) np++;
+      part = np;
       const FdbScanArgs& pa = parts[part];
-      for (int l = 0; l < pa.n_leaves; l++) {
-        const FdbLeaf& L = pa.leaves[l];
-        if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
-          for (uint32_t i = tid; i < L.lut_len; i += BLK) smem[L.lut_lds + i] = as_global(L.lut)[i];
-      }
-      for (int g = 0; g < pa.n_gcols; g++) {
-        const FdbGroupCol& G = pa.gcols[g];
-        if (G.lut_lds != FDB_NO_LDS) {
-          uint32_t* dst = reinterpret_cast<uint32_t*>(smem + G.lut_lds);
-          for (uint32_t i = tid; i < G.lut_len; i += BLK) dst[i] = as_global(G.lut)[i];
+      tile_end = pa.tile_end;
+      decode_plan<NC4, NC8, L4, L8>(pa, P);
+      if (pa.lut_class != lut_class) {
+        lut_class = pa.lut_class;
+        __syncthreads();  // every wave is done with the previous record's LUTs (and with the table init)
+        for (int l = 0; l < pa.n_leaves; l++) {
+          const FdbLeaf& L = pa.leaves[l];
+          if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
+            for (uint32_t i = tid; i < L.lut_len; i += BLK) smem[L.lut_lds + i] = as_global(L.lut)[i];
         }
+        for (int g = 0; g < pa.n_gcols; g++) {
+          const FdbGroupCol& G = pa.gcols[g];
+          if (G.lut_lds != FDB_NO_LDS) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(smem + G.lut_lds);
+            for (uint32_t i = tid; i < G.lut_len; i += BLK) dst[i] = as_global(G.lut)[i];
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
-    const FdbScanArgs& a = parts[part];
-    const int64_t base = (tile - a.tile_begin) * tile_rows + (int64_t)tid * R;
-    if (base >= a.n_rows) continue;
+    const int64_t row0 = (tile - P.tile_begin) * tile_rows + (int64_t)tid * R;
+    if (row0 >= P.n_rows) continue;
 
-    // ---- issue every load of the tile --------------------------------------------------------------------
-    constexpr bool TWO_PHASE = (L4 + L8) > 0;
-    SlotRegs<NC4, NC8> S[T];
-    uint32_t sel[T];
-#pragma unroll
-    for (int t = 0; t < T; t++) {
-      const int64_t row0 = base + t * sub_rows;
-      const int64_t left = a.n_rows - row0;
-      sel[t] = left >= R ? FULL : (left > 0 ? ((1u << (int)left) - 1u) : 0u);
-      slot_load<NC4, NC8>(a.c4, a.n_c4, a.c8, a.n_c8, left > 0 ? row0 : base, S[t]);  // (a dead sub-tile re-reads live rows: masked by sel)
-    }
+    // ---- (1) loads of the filter's columns (single phase: of every column) ---------------------------------------
+    SlotRegs<NC4, NC8> S;
+    slot_load<NC4, NC8>(P.v4, P.b4, P.v8, P.b8, row0, S);
+    const int64_t left = P.n_rows - row0;
+    uint32_t sel = left >= R ? FULL : ((1u << (int)left) - 1u);
 
-    // ---- filter ---------------------------------------------------------------------------------------------
-    if (a.n_code != 0) {
-      unsigned long long st[T];
+    // ---- (2) predicate: leaves in postfix order, each followed by the AND/OR ops that consume it --------------------
+    if (P.n_leaves != 0) {
+      unsigned long long st = 0;
 #pragma unroll
-      for (int t = 0; t < T; t++) st[t] = 0;
-      for (int pc = 0; pc < a.n_code; pc++) {
-        const uint32_t op = a.code[pc];
-        if (op < 0x80u) {
-          const FdbLeaf& L = a.leaves[op];
-#pragma unroll
-          for (int t = 0; t < T; t++) st[t] = (st[t] << 8) | (unsigned long long)slot_eval_leaf(L, S[t], smem);
-        } else {
-#pragma unroll
-          for (int t = 0; t < T; t++) {
-            const unsigned long long top = st[t] & 0xFFull;
-            st[t] >>= 8;
-            if (op == FDB_CODE_AND) st[t] = (st[t] & ~0xFFull) | ((st[t] & 0xFFull) & top);
-            else st[t] = st[t] | top;
+      for (int l = 0; l < SLOT_MAX_LEAVES; l++) {
+        if (l < P.n_leaves) {
+          st = (st << 8) | (unsigned long long)slot_eval_leaf<NC4, NC8>(P.leaf[l].kind, P.leaf[l].slot, P.leaf[l].wide, P.leaf[l].op, P.leaf[l].lut_lds,
+                                                                        P.leaf[l].lut_len, P.leaf[l].lit, P.leaf[l].lut, S, smem);
+          uint32_t ops = P.leaf[l].ops_after >> 4;  // [3:0] count, then 2 bits per op: 1 AND, 2 OR
+          for (uint32_t k = P.leaf[l].ops_after & 0xFu; k != 0; k--, ops >>= 2) {
+            const unsigned long long top = st & 0xFFull;
+            st >>= 8;
+            if ((ops & 3u) == 1u) st = (st & ~0xFFull) | ((st & 0xFFull) & top);
+            else st = st | top;
           }
         }
       }
-#pragma unroll
-      for (int t = 0; t < T; t++) sel[t] &= (uint32_t)st[t];
+      sel &= (uint32_t)st;
     }
-    uint32_t any = 0;
-#pragma unroll
-    for (int t = 0; t < T; t++) any |= sel[t];
-    if (any == 0) continue;
-    // ---- late materialisation: the columns only the group-by / aggregates read ------------------------------------
-    SlotRegs<L4, L8> SL[T];
-    if (TWO_PHASE) {
-#pragma unroll
-      for (int t = 0; t < T; t++) {
-        const int64_t row0 = base + t * sub_rows;
-        slot_load<L4, L8>(a.l4, a.n_l4, a.l8, a.n_l8, row0 < a.n_rows ? row0 : base, SL[t]);
-      }
-    }
+    if (sel == 0) continue;
 
-    // ---- group slots ---------------------------------------------------------------------------------------
-    uint32_t gid[T][R];
+    // ---- (3) late materialisation ---------------------------------------------------------------------------------
+    SlotRegs<L4, L8> SL;
+    if (TWO_PHASE) slot_load<L4, L8>(P.lv4, P.lb4, P.lv8, P.lb8, row0, SL);
+
+    // ---- (4) group slot + aggregates -------------------------------------------------------------------------------
+    uint32_t gid[R] = {0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < T; t++)
-#pragma unroll
-      for (int r = 0; r < R; r++) gid[t][r] = 0;
-    for (int g = 0; g < a.n_gcols; g++) {
-      const FdbGroupCol& G = a.gcols[g];
-#pragma unroll
-      for (int t = 0; t < T; t++) {
+    for (int g = 0; g < SLOT_MAX_GCOLS; g++) {
+      if (g < P.n_gcols) {
         uint32_t idx[R], valid;
-        if (TWO_PHASE) pick4(SL[t], G.slot, idx, valid); else pick4(S[t], G.slot, idx, valid);
-        if (G.lut_lds != FDB_NO_LDS) {
-          const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + G.lut_lds);
+        if (TWO_PHASE) pick4(SL, P.gcol[g].slot, idx, valid); else pick4(S, P.gcol[g].slot, idx, valid);
+        if (P.gcol[g].lut_lds != FDB_NO_LDS) {
+          const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + P.gcol[g].lut_lds);
 #pragma unroll
-          for (int r = 0; r < R; r++) gid[t][r] += (((valid >> r) & 1u) ? lut[idx[r]] : 0u) * G.stride;
+          for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? lut[idx[r]] : 0u) * P.gcol[g].stride;
         } else {
 #pragma unroll
-          for (int r = 0; r < R; r++) gid[t][r] += (((valid >> r) & 1u) ? as_global(G.lut)[idx[r]] : 0u) * G.stride;
+          for (int r = 0; r < R; r++) gid[r] += (((valid >> r) & 1u) ? as_global(P.gcol[g].lut)[idx[r]] : 0u) * P.gcol[g].stride;
         }
       }
     }
-
-    // ---- occupancy / COUNT ------------------------------------------------------------------------------------
+    if (LDS) {
+      if (P.need_count) {
 #pragma unroll
-    for (int t = 0; t < T; t++) {
-      if (LDS) {
-        if (a.need_count) {
-#pragma unroll
-          for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicAdd(&l_cnt[gid[t][r]], 1u);
-        } else {
-#pragma unroll
-          for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) l_cnt[gid[t][r]] = 1u;
-        }
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&l_cnt[gid[r]], 1u);
       } else {
 #pragma unroll
-        for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicAdd(&a.cnt[gid[t][r]], 1ull);
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) l_cnt[gid[r]] = 1u;
       }
-    }
-
-    // ---- aggregates -------------------------------------------------------------------------------------------
-    for (int j = 0; j < a.n_aggs; j++) {
-      const FdbAgg& A = a.aggs[j];
-      if (A.func == AGG_COUNT) continue;
-      unsigned long long* acc = LDS ? (l_acc + (size_t)j * n_slots) : A.acc;
+    } else {
 #pragma unroll
-      for (int t = 0; t < T; t++) {
+      for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(&P.cnt[gid[r]], 1ull);
+    }
+#pragma unroll
+    for (int j = 0; j < SLOT_MAX_AGGS; j++) {
+      if (j < c.n_aggs && P.agg[j].func != AGG_COUNT) {
+        unsigned long long* acc = LDS ? (l_acc + (size_t)j * n_slots) : P.agg[j].acc;
         unsigned long long raw[R];
         uint32_t valid;
-        if (TWO_PHASE) pick8(SL[t], A.slot, raw, valid); else pick8(S[t], A.slot, raw, valid);
+        if (TWO_PHASE) pick8(SL, P.agg[j].slot, raw, valid); else pick8(S, P.agg[j].slot, raw, valid);
         // a NULL contributes the builder's zeroed slot (aggregate.go:784-935, optbuilders.go:337-340)
 #pragma unroll
         for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = 0ull;
-        if (A.func == AGG_SUM) {
-          if (A.type == FDB_T_F64) {
+        if (P.agg[j].func == AGG_SUM) {
+          if (P.agg[j].type == FDB_T_F64) {
 #pragma unroll
             for (int r = 0; r < R; r++)
-              if ((sel[t] >> r) & 1u) atomicAdd(reinterpret_cast<double*>(acc) + gid[t][r], __longlong_as_double((long long)raw[r]));
+              if ((sel >> r) & 1u) atomicAdd(reinterpret_cast<double*>(acc) + gid[r], __longlong_as_double((long long)raw[r]));
           } else {
 #pragma unroll
-            for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicAdd(acc + gid[t][r], raw[r]);
+            for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicAdd(acc + gid[r], raw[r]);
           }
         } else {
           long long key[R];
-          if (A.type == FDB_T_F64) {
+          if (P.agg[j].type == FDB_T_F64) {
 #pragma unroll
             for (int r = 0; r < R; r++) key[r] = f64_to_ordered(__longlong_as_double((long long)raw[r]));
           } else {
 #pragma unroll
             for (int r = 0; r < R; r++) key[r] = (long long)raw[r];
           }
-          if (A.func == AGG_MIN) {
+          if (P.agg[j].func == AGG_MIN) {
 #pragma unroll
-            for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicMin(reinterpret_cast<long long*>(acc) + gid[t][r], key[r]);
+            for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicMin(reinterpret_cast<long long*>(acc) + gid[r], key[r]);
           } else {
 #pragma unroll
-            for (int r = 0; r < R; r++) if ((sel[t] >> r) & 1u) atomicMax(reinterpret_cast<long long*>(acc) + gid[t][r], key[r]);
+            for (int r = 0; r < R; r++) if ((sel >> r) & 1u) atomicMax(reinterpret_cast<long long*>(acc) + gid[r], key[r]);
           }
         }
       }
@@ -656,7 +684,7 @@ __global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __re
 
   if (LDS && c.partials != nullptr) {
     // Flush without atomics: this workgroup's table goes out as plain coalesced stores; a small second kernel
-    // folds the tables in workgroup order (512 workgroups hammering 1 025 addresses with atomics cost ≈10 µs).
+    // folds the tables (1 024 workgroups hammering 1 025 addresses with atomics at the same moment is slower).
     __syncthreads();
     unsigned long long* out = c.partials + (size_t)blockIdx.x * (size_t)(1 + c.n_aggs) * n_slots;
     for (uint32_t i = tid; i < n_slots; i += BLK) out[i] = (unsigned long long)l_cnt[i];
@@ -697,24 +725,30 @@ __global__ void fill_state_kernel(unsigned long long* base, int64_t n, int n_arr
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) base[i] = idents.v[i / n];
 }
 
-// One workgroup = 64 consecutive slots of one array; its 16 waves each fold a contiguous run of workgroup
-// tables (loads are independent, so dozens are in flight per lane), then wave 0 folds the 16 results in order.
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const unsigned long long* __restrict__ partials, int n_blocks, int n_arrays,
-                                                               uint32_t n_slots, unsigned long long* state, uint64_t state_stride,
-                                                               FillIdents funcs) {
-  __shared__ unsigned long long part[16][64];
+// Folds the per-workgroup partial tables into the global table. grid = (slot tiles of 64, arrays, splits): one
+// workgroup covers 64 consecutive slots of one array for a contiguous run of tables; each of its 4 waves keeps
+// ≈16 independent coalesced loads in flight, the waves combine through LDS and ONE atomic per slot per split
+// lands in the table — the whole fold is one memory round trip wide (≈3 µs for 1 024 tables × 1 025 slots).
+#define REDUCE_SPLITS 16
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const unsigned long long* __restrict__ partials, int n_blocks, int n_arrays,
+                                                              uint32_t n_slots, unsigned long long* state, uint64_t state_stride,
+                                                              FillIdents funcs) {
+  __shared__ unsigned long long part[4][64];
   const int arr = blockIdx.y;
   const int f = (int)funcs.v[arr];
   if (f == 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t slot = blockIdx.x * 64 + lane;
-  const int per = (n_blocks + 15) / 16;
-  const int b0 = wave * per, b1 = min(n_blocks, b0 + per);
-  unsigned long long acc = f == 3 ? (unsigned long long)FDB_I64_MAX : f == 4 ? (unsigned long long)FDB_I64_MIN : 0ull;
+  const int per_split = (n_blocks + REDUCE_SPLITS - 1) / REDUCE_SPLITS;
+  const int s0 = blockIdx.z * per_split, s1 = min(n_blocks, s0 + per_split);
+  const int per_wave = (s1 - s0 + 3) / 4;
+  const int b0 = s0 + wave * per_wave, b1 = min(s1, b0 + per_wave);
+  const unsigned long long ident = f == 3 ? (unsigned long long)FDB_I64_MAX : f == 4 ? (unsigned long long)FDB_I64_MIN : 0ull;
+  unsigned long long acc = ident;
   if (slot < n_slots) {
     const unsigned long long* p = partials + (size_t)arr * n_slots + slot;
     const size_t stride = (size_t)n_arrays * n_slots;
-#pragma unroll 8
+#pragma unroll 16
     for (int b = b0; b < b1; b++) {
       const unsigned long long v = p[(size_t)b * stride];
       if (f == 1) acc += v;
@@ -726,16 +760,21 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const unsigned lo
   part[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && slot < n_slots) {
-    unsigned long long* dst = state + (size_t)arr * state_stride + slot;
-    unsigned long long t = *dst;
-    for (int w = 0; w < 16; w++) {
+    unsigned long long t = part[0][lane];
+    for (int w = 1; w < 4; w++) {
       const unsigned long long v = part[w][lane];
       if (f == 1) t += v;
       else if (f == 2) t = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)t) + __longlong_as_double((long long)v));
       else if (f == 3) t = (unsigned long long)min((long long)t, (long long)v);
       else t = (unsigned long long)max((long long)t, (long long)v);
     }
-    *dst = t;
+    unsigned long long* dst = state + (size_t)arr * state_stride + slot;
+    if (t != ident || f == 2) {
+      if (f == 1) atomicAdd(dst, t);
+      else if (f == 2) { if (__longlong_as_double((long long)t) != 0.0) atomicAdd(reinterpret_cast<double*>(dst), __longlong_as_double((long long)t)); }
+      else if (f == 3) atomicMin(reinterpret_cast<long long*>(dst), (long long)t);
+      else atomicMax(reinterpret_cast<long long*>(dst), (long long)t);
+    }
   }
 }
 
@@ -890,32 +929,31 @@ hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_
   if (n_blocks <= 0 || n_slots == 0) return hipSuccess;
   FillIdents f;
   for (int a = 0; a < 1 + FDB_MAX_AGGS; a++) f.v[a] = a < n_arrays ? (unsigned long long)funcs[a] : 0ull;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_slots + 63) / 64, n_arrays), dim3(1024), 0, stream, partials, n_blocks, n_arrays,
-                     n_slots, state, state_stride, f);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_slots + 63) / 64, n_arrays, REDUCE_SPLITS), dim3(256), 0, stream, partials, n_blocks,
+                     n_arrays, n_slots, state, state_stride, f);
   return hipGetLastError();
 }
 
 namespace {
 typedef void (*SlotKernel)(const FdbScanArgs*, int, int64_t, FdbScanArgs);
-struct SlotVariant { SlotKernel lds, nolds; int t, block; };
-#define FDB_SV(NC4, NC8, L4, L8, T, BLK) \
-  {scan_slots_kernel<true, NC4, NC8, L4, L8, T, BLK>, scan_slots_kernel<false, NC4, NC8, L4, L8, T, BLK>, T, BLK}
+struct SlotVariant { SlotKernel lds, nolds; int block; };
+#define FDB_SV(NC4, NC8, L4, L8, BLK) {scan_slots_kernel<true, NC4, NC8, L4, L8, BLK>, scan_slots_kernel<false, NC4, NC8, L4, L8, BLK>, BLK}
 // single phase: ≤ 2 four-byte + ≤ 1 eight-byte column in total, everything loaded up front
-const SlotVariant kSingle[] = {FDB_SV(2, 1, 0, 0, 1, 512), FDB_SV(2, 1, 0, 0, 1, 256), FDB_SV(2, 1, 0, 0, 1, 1024), FDB_SV(2, 1, 0, 0, 2, 512)};
+const SlotVariant kSingle[] = {FDB_SV(2, 1, 0, 0, 512), FDB_SV(2, 1, 0, 0, 256), FDB_SV(2, 1, 0, 0, 1024)};
 // two phase: filter columns (≤ 4 + 2) first, then group-by / aggregate columns (≤ 2 + 3)
-const SlotVariant kTwoPhase[] = {FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1, 512), FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1, 256),
-                                  FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1, 1024), FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1, 512)};
+const SlotVariant kTwoPhase[] = {FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 512), FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 256),
+                                  FDB_SV(FDB_MAX_C4, FDB_MAX_C8, FDB_MAX_L4, FDB_MAX_L8, 1024)};
 #undef FDB_SV
-// mode: 0 = default, 1 = 512 threads, 2 = 256 threads, 3 = 1024 threads, 4 = 512 threads × 2 sub-tiles (single phase only)
+// mode: 0 = default, 1 = 512 threads, 2 = 256 threads, 3 = 1024 threads
 const SlotVariant& slot_variant(int two_phase, int mode) {
-  const int m = (mode >= 1 && mode <= 4) ? mode - 1 : 0;
+  const int m = (mode >= 1 && mode <= 3) ? mode - 1 : 0;
   return two_phase ? kTwoPhase[m] : kSingle[m];
 }
 }  // namespace
 
 int fdb_slot_geometry(int two_phase, int mode, int lds_acc, size_t lds_bytes, int device, int* tile_rows, int* blocks_per_cu) {
   const SlotVariant& v = slot_variant(two_phase, mode);
-  *tile_rows = v.block * 4 * v.t;
+  *tile_rows = v.block * 4;
   const void* fn = reinterpret_cast<const void*>(lds_acc ? v.lds : v.nolds);
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   int occ = 0;

@@ -728,6 +728,22 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
 // total, all in c4/c8), 2 for the two-phase layout (filter columns in c4/c8, group-by / aggregate columns in l4/l8).
 static int assign_slots(const DeviceBatch& b, Plan::Resolved& R, int first_layout = 1) {
   FdbScanArgs& a = R.args;
+  // static limits of the slot kernel's register-resident plan
+  if (a.n_leaves > 6 || a.n_gcols > 2 || a.n_aggs > 6) return 0;
+  {
+    // postfix program → per-leaf trailing op lists (leaves are always pushed in index order)
+    int leaf = -1;
+    for (int l = 0; l < FDB_MAX_LEAVES; l++) a.ops_after[l] = 0;
+    for (int pc = 0; pc < a.n_code; pc++) {
+      const uint8_t op = a.code[pc];
+      if (op < 0x80) { if ((int)op != leaf + 1) return 0; leaf = op; continue; }
+      if (leaf < 0) return 0;
+      uint32_t& w = a.ops_after[leaf];
+      const uint32_t n = w & 0xFu;
+      if (n >= 7) return 0;
+      w = (w & ~0xFu) | (n + 1) | ((op == FDB_CODE_AND ? 1u : 2u) << (4 + 2 * n));
+    }
+  }
   struct Pool { FdbColSlot* slots; int32_t* n; int cap; int cols[8]; };
   auto slot_in = [&](Pool& P, int ci, bool need_values) -> int {
     const DevColumn& c = b.cols[(size_t)ci];
@@ -1066,6 +1082,42 @@ void Plan::partial_state(int32_t agg, void* dst, int64_t capacity_bytes) {
   const OutColumn& c = cols[(size_t)agg];
   if ((int64_t)c.values.size() > capacity_bytes) throw Error(FDB_ERR_INVALID, "partial_state: destination too small");
   if (!c.values.empty()) hip_check(hipMemcpy(dst, c.values.data(), c.values.size(), hipMemcpyDefault), "hipMemcpy(partial_state)");
+}
+
+// ---- raw table access for the aligned-layout all-reduce (frostdb_amd/distributed.py) ---------------------------------
+uint64_t Plan::state_signature(int64_t* n_slots_out) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+  auto mix64 = [&](uint64_t v) { mix(&v, 8); };
+  mix64(n_slots_);
+  mix64(d_state_ != nullptr);
+  for (const GroupColState& g : gcols_) {
+    mix(g.name.data(), g.name.size()); mix64(g.name.size());
+    mix64(g.cap); mix64(g.stride);
+    for (const std::string_view& v : g.values) { mix64(v.size()); mix(v.data(), v.size()); }
+  }
+  for (const AggState& a : aggs_) { mix64((uint64_t)a.func); mix64((uint64_t)a.type); mix(a.column.data(), a.column.size()); }
+  if (n_slots_out) *n_slots_out = d_state_ != nullptr ? (int64_t)n_slots_ : 0;
+  return h;
+}
+
+void Plan::state_read(int32_t array, void* dst, int64_t capacity_bytes) {
+  if (array < 0 || array > (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "table array index out of range");
+  if (d_state_ == nullptr) throw Error(FDB_ERR_STATE, "the plan has no table yet");
+  const size_t bytes = (size_t)n_slots_ * 8;
+  if ((int64_t)bytes > capacity_bytes) throw Error(FDB_ERR_INVALID, "state_read: destination too small");
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  hip_check(hipMemcpyAsync(dst, d_state_ + (size_t)array * slots_alloc_, bytes, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(state_read)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+void Plan::state_write(int32_t array, const void* src, int64_t bytes) {
+  if (array < 0 || array > (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "table array index out of range");
+  if (d_state_ == nullptr) throw Error(FDB_ERR_STATE, "the plan has no table yet");
+  if (bytes != (int64_t)n_slots_ * 8) throw Error(FDB_ERR_INVALID, "state_write: size mismatch");
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  hip_check(hipMemcpyAsync(d_state_ + (size_t)array * slots_alloc_, src, (size_t)bytes, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(state_write)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
 
 // ---- merge (≙ Synchronizer + final-stage HashAggregate, same device) -------------------------------------------

@@ -120,6 +120,9 @@ class Plan {
   void partial_keys(ArrowArray* out, ArrowSchema* out_schema);
   void partial_state(int32_t agg, void* dst, int64_t capacity_bytes);
   char agg_format(int32_t agg) const;
+  uint64_t state_signature(int64_t* n_slots);
+  void state_read(int32_t array, void* dst, int64_t capacity_bytes);
+  void state_write(int32_t array, const void* src, int64_t bytes);
 
   std::string error;
   int device() const { return device_; }

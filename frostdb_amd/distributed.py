@@ -116,9 +116,52 @@ def merge_partials(keys: pa.RecordBatch, partials: Sequence[torch.Tensor], aggs:
     return pa.RecordBatch.from_arrays(arrays, names=out_names)
 
 
+def merge_plan_aligned(plan, group=None, dst: int = 0, device: Optional[torch.device] = None):
+    """Fast path: if every rank's table has the same slot layout (checked with ONE tiny all-reduce of the layout
+    signature), the raw table arrays are all-reduced in place — SUM for counts and sums, integer MIN/MAX for
+    MIN/MAX (float64 MIN/MAX live as order-preserving int64 keys) — written back, and rank `dst` simply finishes its
+    plan. No key exchange, no host round trip: (2 + #aggregations) small RCCL collectives.
+    Returns (True, record-or-None) or (False, None) when layouts differ (caller falls back to merge_plan)."""
+    if device is None:
+        device = torch.device("cuda", plan.device)
+    sig, n_slots = plan.state_signature()
+    s = sig & ((1 << 62) - 1)  # keep it a positive int64
+    probe = torch.tensor([s, -s, n_slots, -n_slots], dtype=torch.int64, device=device)
+    dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+    mx, nmn, ns, nns = (int(x) for x in probe.tolist())
+    if mx != -nmn or ns != -nns or ns == 0:
+        return False, None
+    n_arrays = 1 + len(plan.aggs)
+    buf = torch.empty((n_arrays, n_slots), dtype=torch.int64, device=device)
+    for a in range(n_arrays):
+        plan.state_read(a, buf[a].data_ptr(), n_slots * 8)
+    for a in range(n_arrays):
+        if a == 0:
+            dist.all_reduce(buf[0], op=dist.ReduceOp.SUM, group=group)
+            continue
+        agg = plan.aggs[a - 1]
+        if agg.func == AGG_COUNT:
+            continue  # served by the count array
+        if agg.func == AGG_SUM and plan.agg_format(a - 1) == "g":
+            dist.all_reduce(buf[a].view(torch.float64), op=dist.ReduceOp.SUM, group=group)
+        else:
+            op = dist.ReduceOp.MIN if agg.func == AGG_MIN else dist.ReduceOp.MAX if agg.func == AGG_MAX else dist.ReduceOp.SUM
+            dist.all_reduce(buf[a], op=op, group=group)
+    if dist.get_rank(group) != dst:
+        return True, None
+    torch.cuda.current_stream(device).synchronize() if device.type == "cuda" else None
+    for a in range(n_arrays):
+        plan.state_write(a, buf[a].data_ptr(), n_slots * 8)
+    return True, plan.Finish()
+
+
 def merge_plan(plan, group=None, dst: int = 0, device: Optional[torch.device] = None) -> Optional[pa.RecordBatch]:
-    """Reads a HashAggregatePlan's partial table straight into torch tensors on `device` (device-to-device copy
-    through the C ABI: fdb_plan_partial_state) and merges it across the process group."""
+    """Merges a HashAggregatePlan's partial table across the process group: the aligned-layout fast path when all
+    ranks agree on the slot layout, otherwise key unification (device-to-device copies through the C ABI:
+    fdb_plan_partial_state, then merge_partials)."""
+    ok, rec = merge_plan_aligned(plan, group=group, dst=dst, device=device)
+    if ok:
+        return rec
     keys = plan.partial_keys()
     n = keys.num_rows
     if device is None:

@@ -69,6 +69,9 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_partial_keys.argtypes = [vp, vp, vp]
     L.fdb_plan_partial_state.argtypes = [vp, i32, vp, i64]
     L.fdb_plan_agg_type.argtypes = [vp, i32, ctypes.c_char_p]
+    L.fdb_plan_state_signature.argtypes = [vp, P(ctypes.c_uint64), P(i64)]
+    L.fdb_plan_state_read.argtypes = [vp, i32, vp, i64]
+    L.fdb_plan_state_write.argtypes = [vp, i32, vp, i64]
     L.fdb_batch_import.argtypes = [vp, vp, ctypes.c_int, P(vp)]
     L.fdb_batch_num_rows.restype = i64
     L.fdb_batch_num_rows.argtypes = [vp]
@@ -225,6 +228,18 @@ class HashAggregatePlan:
     def partial_state_into(self, agg: int, dst_ptr: int, capacity_bytes: int) -> None:
         """Copies aggregation `agg`'s partial column (n_groups × 8 B) to a host or device pointer."""
         self._check(lib().fdb_plan_partial_state(self.handle, agg, dst_ptr, capacity_bytes))
+
+    def state_signature(self):
+        """(layout signature, n_slots) of the plan's table — see fdb_plan_state_signature."""
+        sig, n = ctypes.c_uint64(), ctypes.c_int64()
+        self._check(lib().fdb_plan_state_signature(self.handle, ctypes.byref(sig), ctypes.byref(n)))
+        return sig.value, n.value
+
+    def state_read(self, array: int, dst_ptr: int, capacity_bytes: int) -> None:
+        self._check(lib().fdb_plan_state_read(self.handle, array, dst_ptr, capacity_bytes))
+
+    def state_write(self, array: int, src_ptr: int, nbytes: int) -> None:
+        self._check(lib().fdb_plan_state_write(self.handle, array, src_ptr, nbytes))
 
     def set_timing(self, enabled: bool) -> None:
         lib().fdb_plan_set_timing(self.handle, 1 if enabled else 0)

@@ -187,6 +187,16 @@ int fdb_plan_partial_keys(fdb_plan* plan, struct ArrowArray* out, struct ArrowSc
 /* Copies the partial accumulator of aggregation `agg` (n_groups × 8 bytes, slot order; int64 or
  * float64 per fdb_plan_agg_type) to `dst`, a host or device pointer (hipMemcpyDefault). */
 int fdb_plan_partial_state(fdb_plan* plan, int32_t agg, void* dst, int64_t capacity_bytes);
+/* Fast path of the cross-GPU merge: when every rank's table has the SAME slot layout (same group columns, same key
+ * dictionaries in the same order — the usual case for parts of one table), slot i means the same group everywhere
+ * and the raw table arrays can be all-reduced in place, with no key exchange. `signature` hashes the layout
+ * (group column names, key values in id order, radix strides, aggregations); equal signatures ⇔ equal layouts. */
+int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slots);
+/* Raw table array `array` (0: selected-row counts; 1 + j: accumulator of aggregation j) ⇄ `dst`/`src`, a DEVICE
+ * pointer of n_slots × 8 bytes. int64 everywhere except float64 SUM; float64 MIN/MAX are stored as order-preserving
+ * int64 keys, so integer MIN/MAX reductions are exact for them too. Both calls wait for the plan's stream. */
+int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes);
+int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t bytes);
 /* 'l' (int64) or 'g' (float64): the Arrow format of aggregation `agg`'s output column; 0 until the first push. */
 int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out);
 

@@ -423,3 +423,49 @@ def test_properties_at_scale(pp):
     rb.close()
     for p in parts:
         p.close()
+
+
+def test_rccl_merge_single_rank(pp):
+    """The cross-GPU merge (frostdb_amd/distributed.py) on a 1-rank RCCL group: both the aligned-layout fast path
+    (raw table all-reduce) and the key-unification path must reproduce what Finish() gives on the same table.
+    (World sizes 2 and 3 of the same code are covered on CPU/gloo in tests/test_distributed_cpu.py.)"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from frostdb_amd import distributed as fd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(31)
+        batches = [make_prometheus_batch(rng, 40_000, n_path=50), make_prometheus_batch(rng, 30_000, n_path=80)]
+        cols = ["labels.path"] + [a.Name() for a in CFG3["aggs"]]
+
+        def fresh():
+            plan = pp.HashAggregatePlan(CFG3["filter_expr"], CFG3["aggs"], CFG3["groups"])
+            for b in batches:
+                plan.Callback(b)
+            return plan
+
+        want = run_oracle(batches, **CFG3)
+        p1 = fresh()
+        ok, rec = fd.merge_plan_aligned(p1)
+        assert ok and rec is not None
+        assert_same_result(arrow_to_pydict(rec), want, cols, float_cols={"sum(value)"})
+        p1.Close()
+        p2 = fresh()
+        keys = p2.partial_keys()
+        tensors = []
+        for j in range(len(p2.aggs)):
+            t = torch.empty((keys.num_rows,), dtype=torch.float64 if p2.agg_format(j) == "g" else torch.int64, device="cuda:0")
+            p2.partial_state_into(j, t.data_ptr(), keys.num_rows * 8)
+            tensors.append(t)
+        rec2 = fd.merge_partials(keys, tensors, p2.aggs, key_types={f.name: f.type for f in keys.schema})
+        assert_same_result(arrow_to_pydict(rec2), want, cols, float_cols={"sum(value)"})
+        p2.Close()
+    finally:
+        if created:
+            dist.destroy_process_group()

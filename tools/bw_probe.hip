@@ -179,6 +179,53 @@ __global__ __launch_bounds__(BLOCK) void probe_hybrid(const uint32_t* a, const u
   if (acc == 0x123456789ull) out[0] = acc;
 }
 
+// V7: hand-specialised cfg-2 scan (what a JIT-specialised plan kernel would look like): code ∈ bitmask, path →
+// LDS LUT → slot, sum(value) into an LDS table, occupancy flags, plain-store flush. Measures the instruction-issue
+// headroom of specialisation over the interpreting kernels.
+template <int BLK>
+__global__ __launch_bounds__(BLK) void probe_cfg2(const uint32_t* __restrict__ code, const uint32_t* __restrict__ path, const double* __restrict__ val,
+                                                  const uint8_t* __restrict__ bcode, const uint8_t* __restrict__ bpath, const uint32_t* __restrict__ lut_g,
+                                                  uint32_t lut_len, unsigned long long code_bits, int64_t n_rows, unsigned long long* partials, uint32_t n_slots) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* l_cnt = lut + ((lut_len + 3) & ~3u);
+  double* l_sum = reinterpret_cast<double*>(l_cnt + ((n_slots + 3) & ~3u));
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < lut_len; i += BLK) lut[i] = lut_g[i];
+  for (uint32_t i = tid; i < n_slots; i += BLK) { l_cnt[i] = 0; l_sum[i] = 0.0; }
+  __syncthreads();
+  const int64_t tile_rows = (int64_t)BLK * 4;
+  const int64_t n_tiles = n_rows / tile_rows;
+  const uint32_t lane_off = tid * 16u;       // byte offset of this lane's 4 uint32 inside a tile
+  const uint32_t null_code = 63u, null_path = lut_len - 1u;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * tile_rows;     // wave-uniform
+    const char* pc = reinterpret_cast<const char*>(code + r0);
+    const char* pp = reinterpret_cast<const char*>(path + r0);
+    const char* pv = reinterpret_cast<const char*>(val + r0);
+    const u32x4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pc + lane_off));
+    const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pp + lane_off));
+    const u64x2 v0 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(pv + 2u * lane_off));
+    const u64x2 v1 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(pv + 2u * lane_off + 16u));
+    const uint32_t vc = (bcode[(r0 >> 3) + (tid >> 1)] >> ((tid & 1u) * 4u)) & 0xFu;
+    const uint32_t vp = (bpath[(r0 >> 3) + (tid >> 1)] >> ((tid & 1u) * 4u)) & 0xFu;
+    const uint32_t ci[4] = {c.x, c.y, c.z, c.w}, pi[4] = {q.x, q.y, q.z, q.w};
+    const double vv[4] = {__longlong_as_double((long long)v0.x), __longlong_as_double((long long)v0.y), __longlong_as_double((long long)v1.x), __longlong_as_double((long long)v1.y)};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t ce = ((vc >> r) & 1u) ? ci[r] : null_code;
+      if ((code_bits >> ce) & 1ull) {
+        const uint32_t slot = lut[((vp >> r) & 1u) ? pi[r] : null_path];
+        l_cnt[slot] = 1u;
+        atomicAdd(&l_sum[slot], vv[r]);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* out = partials + (size_t)blockIdx.x * 2 * n_slots;
+  for (uint32_t i = tid; i < n_slots; i += BLK) { out[i] = l_cnt[i]; out[n_slots + i] = (unsigned long long)__double_as_longlong(l_sum[i]); }
+}
+
 template <typename F>
 float time_it(F&& launch) {
   hipEvent_t e0, e1;
@@ -258,6 +305,26 @@ int main(int argc, char** argv) {
     REPORT("pipe block=256 stride", G * 4, ms);
     ms = time_it([&] { hipLaunchKernelGGL((probe_pipe<512, true, 0>), dim3(G * 2), dim3(512), 0, 0, a, b, v, ba, bb, n, out); });
     REPORT("pipe block=512 stride", G * 2, ms);
+  }
+  {
+    // realistic index contents for the specialised scan: code ∈ [0,6), path ∈ [0,1024)
+    std::vector<uint32_t> hc(n), hp(n), hl(1025);
+    uint64_t x = 88172645463325252ull;
+    for (int64_t i = 0; i < n; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; hc[i] = (x % 10) < 7 ? 0 : 1 + (x >> 8) % 5; hp[i] = (uint32_t)((x >> 20) % 1024); }
+    for (int i = 0; i < 1025; i++) hl[i] = i < 1024 ? i + 1 : 0;
+    CHECK(hipMemcpy(a, hc.data(), n * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(b, hp.data(), n * 4, hipMemcpyHostToDevice));
+    uint32_t* lut; CHECK(hipMalloc(&lut, 1025 * 4)); CHECK(hipMemcpy(lut, hl.data(), 1025 * 4, hipMemcpyHostToDevice));
+    unsigned long long* partials; CHECK(hipMalloc(&partials, (size_t)4096 * 2 * 1025 * 8));
+    const size_t lds = (1028 + 1028) * 4 + 1025 * 8;
+    for (int G : {cus * 2, cus * 4}) {
+      float ms = time_it([&] { hipLaunchKernelGGL((probe_cfg2<512>), dim3(G), dim3(512), lds, 0, a, b, (const double*)v, ba, bb, lut, 1025u, 1ull, n, partials, 1025u); });
+      REPORT("specialised cfg2 blk=512", G, ms);
+      ms = time_it([&] { hipLaunchKernelGGL((probe_cfg2<1024>), dim3(G / 2), dim3(1024), lds, 0, a, b, (const double*)v, ba, bb, lut, 1025u, 1ull, n, partials, 1025u); });
+      REPORT("specialised cfg2 blk=1024", G / 2, ms);
+      ms = time_it([&] { hipLaunchKernelGGL((probe_cfg2<256>), dim3(G * 2), dim3(256), lds, 0, a, b, (const double*)v, ba, bb, lut, 1025u, 1ull, n, partials, 1025u); });
+      REPORT("specialised cfg2 blk=256", G * 2, ms);
+    }
+    CHECK(hipMemset(a, 1, n * 4)); CHECK(hipMemset(b, 2, n * 4));
   }
   for (int G : {cus, cus * 2}) {
     const int64_t nt = n / 4096;

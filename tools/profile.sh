@@ -4,7 +4,7 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=gpurun_out/prof
+OUT=${PROF_OUT:-gpurun_out/prof}
 rm -rf $OUT; mkdir -p $OUT
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-}"
 echo "== kernel trace + stats: $CMD"
