@@ -1,0 +1,307 @@
+// fdb_hash.cpp — the high-cardinality table of the fused filter + aggregate chain (cfg 5, int64 keys).
+//
+// When the key space outgrows the dense mixed-radix table (more than 8 key columns, more than 2^22 slots, or an int64
+// key column such as a time bucket) the plan moves its state into a global open-addressing hash table keyed by a
+// 128-bit fingerprint of the key tuple (kernels and layout: fdb_kernels.hip / fdb_kernels.h "high-cardinality path").
+// This is the device replacement of the reference's `map[uint64]hashtuple` + per-group builders
+// (aggregate.go:130, :398-486), which allocates one builder per aggregation per new group.
+//
+// Sizing is conservative instead of transactional: a scan is cut into chunks of ≤ kChunkRows rows and, before each
+// chunk, the table is grown (device-side re-hash) so that capacity ≥ 2 × (groups so far + rows in the chunk). An insert
+// can therefore never fail and no row is ever applied twice.
+#include "fdb_context.h"
+#include "fdb_plan_internal.h"
+
+namespace fdb {
+
+namespace {
+constexpr int64_t kChunkRows = 4 << 20;
+inline uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
+}  // namespace
+
+// Key-tuple words: [valid mask lo, valid mask hi, then 1 word per dictionary column / 2 per int64 column].
+void Plan::hash_layout() {
+  int kw = 2;
+  for (GroupColState& g : gcols_) { g.word = kw; kw += g.kind == 0 ? 1 : 2; }
+  const int ew = (int)((3 + aggs_.size() + 3) / 4 * 4);
+  if (h_table_ == nullptr) { h_key_words_ = kw; h_entry_words_ = ew; return; }
+  if (kw != h_key_words_) {  // columns were added: widen the key store (same capacity, same fingerprints)
+    uint32_t* nk = (uint32_t*)ctx_->dev_alloc((size_t)h_capacity_ * kw * 4);
+    hip_check(hipMemsetAsync(nk, 0, (size_t)h_capacity_ * kw * 4, stream_), "hipMemsetAsync(keys)");
+    unsigned long long* nt = (unsigned long long*)ctx_->dev_alloc((size_t)h_capacity_ * ew * 8);
+    unsigned long long idents[FDB_MAX_AGGS] = {0};
+    for (size_t j = 0; j < aggs_.size(); j++)
+      idents[j] = aggs_[j].func == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : aggs_[j].func == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
+    hip_check(fdb_launch_hash_init(nt, h_capacity_, ew, (int)aggs_.size(), idents, stream_), "hash init");
+    hip_check(fdb_launch_hash_rehash(h_table_, h_keys_, h_capacity_, h_key_words_, nt, nk, h_capacity_ - 1, ew, kw, stream_), "hash rehash");
+    hip_check(hipStreamSynchronize(stream_), "sync(rehash)");
+    ctx_->dev_free(h_table_); ctx_->dev_free(h_keys_);
+    h_table_ = nt; h_keys_ = nk; h_key_words_ = kw;
+  }
+}
+
+uint64_t Plan::hash_groups() {
+  unsigned long long n = 0;
+  hip_check(hipMemcpyAsync(&n, h_count_dev_, 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(group count)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  h_groups_bound_ = n;
+  return n;
+}
+
+void Plan::hash_reserve(uint64_t extra) {
+  const uint64_t need = next_pow2(std::max<uint64_t>(2 * (h_groups_bound_ + extra), 1 << 16));
+  if (h_table_ != nullptr && need <= h_capacity_) return;
+  const int ew = h_entry_words_, kw = h_key_words_;
+  unsigned long long* nt = (unsigned long long*)ctx_->dev_alloc((size_t)need * ew * 8);
+  uint32_t* nk = (uint32_t*)ctx_->dev_alloc((size_t)need * kw * 4);
+  unsigned long long idents[FDB_MAX_AGGS] = {0};
+  for (size_t j = 0; j < aggs_.size(); j++)
+    idents[j] = aggs_[j].func == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : aggs_[j].func == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
+  hip_check(fdb_launch_hash_init(nt, need, ew, (int)aggs_.size(), idents, stream_), "hash init");
+  hip_check(hipMemsetAsync(nk, 0, (size_t)need * kw * 4, stream_), "hipMemsetAsync(keys)");
+  if (h_table_ != nullptr) {
+    hip_check(fdb_launch_hash_rehash(h_table_, h_keys_, h_capacity_, kw, nt, nk, need - 1, ew, kw, stream_), "hash rehash");
+    hip_check(hipStreamSynchronize(stream_), "sync(rehash)");
+    ctx_->dev_free(h_table_); ctx_->dev_free(h_keys_);
+  }
+  if (h_count_dev_ == nullptr) {
+    h_count_dev_ = (unsigned long long*)ctx_->dev_alloc(256);
+    hip_check(hipMemsetAsync(h_count_dev_, 0, 256, stream_), "hipMemsetAsync(counter)");
+  }
+  h_table_ = nt; h_keys_ = nk; h_capacity_ = need;
+}
+
+// Inserts pre-aggregated entries ({count, acc…} + key tuples of `in_kw` words, described by `cols`) into the table.
+void Plan::hash_insert_entries(const std::vector<unsigned long long>& entries, const std::vector<uint32_t>& keys, int64_t n, int in_kw,
+                               const std::vector<FdbHashCol>& cols) {
+  if (n == 0) return;
+  if (h_count_dev_ != nullptr) hash_groups();  // refresh the bound (waits for the stream)
+  hash_reserve((uint64_t)n);
+  const int in_ew = (int)(1 + aggs_.size());
+  void* d_entries = ctx_->dev_alloc(entries.size() * 8);
+  void* d_keys = ctx_->dev_alloc(keys.size() * 4);
+  scratch_.push_back(d_entries); scratch_.push_back(d_keys);
+  hip_check(hipMemcpyAsync(d_entries, entries.data(), entries.size() * 8, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(entries)");
+  hip_check(hipMemcpyAsync(d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(keys)");
+  FdbHashMergeArgs m;
+  std::memset(&m, 0, sizeof(m));
+  m.entries = (const unsigned long long*)d_entries; m.in_keys = (const uint32_t*)d_keys; m.n = n;
+  m.table = h_table_; m.keys = h_keys_; m.n_groups = h_count_dev_; m.mask = h_capacity_ - 1;
+  m.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
+  m.n_cols = (int)cols.size(); m.in_key_words = in_kw; m.in_entry_words = in_ew; m.entry_words = h_entry_words_; m.key_words = h_key_words_;
+  m.n_aggs = (int)aggs_.size();
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    const int32_t f = aggs_[j].func;
+    m.funcs[j] = f == FDB_AGG_COUNT ? (final_stage_ ? 1 : 0) : f == FDB_AGG_SUM ? (aggs_[j].type == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
+  }
+  hip_check(fdb_launch_hash_merge(m, stream_), "hash merge");
+  hip_check(hipStreamSynchronize(stream_), "sync(hash merge)");  // the host vectors must outlive the copies
+  state_dirty_ = true;
+}
+
+// Dense → hash migration: the occupied dense slots become pre-aggregated entries keyed by their per-column key ids.
+void Plan::switch_to_hash() {
+  CompactState cs;
+  const bool had_state = state_dirty_ && d_state_ != nullptr;
+  if (had_state) fetch_compact(&cs); else sync();
+  mode_ = TableMode::HASH;
+  hash_layout();
+  h_groups_bound_ = 0;
+  hash_reserve((uint64_t)std::max<int64_t>(cs.n, 1));
+  if (had_state && cs.n > 0) {
+    const int in_kw = (int)(2 + gcols_.size());  // dense tables only hold dictionary columns: one word each
+    std::vector<uint32_t> keys((size_t)cs.n * in_kw, 0);
+    std::vector<unsigned long long> entries((size_t)cs.n * (1 + aggs_.size()));
+    for (int64_t i = 0; i < cs.n; i++) {
+      for (size_t c = 0; c < gcols_.size(); c++) keys[(size_t)i * in_kw + 2 + c] = cs.ids[c].empty() ? 0u : cs.ids[c][(size_t)i];
+      entries[(size_t)i * (1 + aggs_.size())] = cs.cnt[(size_t)i];
+      for (size_t j = 0; j < aggs_.size(); j++) entries[(size_t)i * (1 + aggs_.size()) + 1 + j] = cs.acc[j][(size_t)i];
+    }
+    std::vector<FdbHashCol> cols(gcols_.size());
+    for (size_t c = 0; c < gcols_.size(); c++) {
+      std::memset(&cols[c], 0, sizeof(FdbHashCol));
+      cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c; cols[c].lut_lds = FDB_NO_LDS;
+      cols[c].src_word = gcols_[c].kind == 0 ? (int)(2 + c) : -1;  // a dense table never held int64 key columns
+    }
+    // COUNT accumulators of a dense table live in its count array: carry them as counts (funcs → skip) — the entry's
+    // first word already is the count.
+    hash_insert_entries(entries, keys, cs.n, in_kw, cols);
+  }
+  ctx_->dev_free(d_state_);
+  d_state_ = nullptr; d_cnt_ = nullptr;
+  for (AggState& a : aggs_) a.d_acc = nullptr;
+  slots_alloc_ = 0; n_slots_ = 1;
+}
+
+void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live) {
+  hash_layout();
+  for (int i : live) {
+    Resolved& R = Rs[(size_t)i];
+    const DeviceBatch& b = *bs[i];
+    FdbHashArgs h;
+    std::memset(&h, 0, sizeof(h));
+    h.base = R.args;
+    FdbScanArgs& a = h.base;
+    a.need_count = 1;
+    // LUTs: predicate LUTs from the record's blob, key-id LUTs appended
+    std::vector<FdbHashCol> hcols(R.groups.size());
+    std::vector<size_t> lut_off(R.groups.size(), 0);
+    for (size_t g = 0; g < R.groups.size(); g++) {
+      const GroupRes& gr = R.groups[g];
+      const DevColumn& c = b.cols[(size_t)gr.ci];
+      FdbHashCol& C = hcols[g];
+      std::memset(&C, 0, sizeof(C));
+      C.values = c.d_values; C.validity = c.d_validity; C.kind = gr.kind; C.gi = gr.gi; C.word = gcols_[(size_t)gr.gi].word;
+      C.lut_lds = FDB_NO_LDS; C.src_word = -1;
+      if (gr.kind == 0) { C.lut_len = (uint32_t)gr.lut->size(); lut_off[g] = R.blob.add(gr.lut->data(), gr.lut->size() * 4); }
+    }
+    unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
+    size_t lds_off = 0;
+    for (const PendingLut& p : R.luts) {  // predicate LUTs (kind 0 only: dense group LUTs were never added in this mode)
+      const bool in_lds = p.len_bytes <= 16384 && lds_off + p.len_bytes <= 32768;
+      uint32_t lds = FDB_NO_LDS;
+      if (in_lds) { lds = (uint32_t)lds_off; lds_off = align_up_sz(lds_off + p.len_bytes, 16); }
+      a.leaves[p.index].lut = d_blob + p.blob_off;
+      a.leaves[p.index].lut_lds = lds;
+    }
+    for (size_t g = 0; g < hcols.size(); g++) {
+      if (hcols[g].kind != 0) continue;
+      const size_t bytes = (size_t)hcols[g].lut_len * 4;
+      hcols[g].lut = (const uint32_t*)(d_blob + lut_off[g]);
+      if (bytes <= 8192 && lds_off + bytes <= 60 * 1024) { hcols[g].lut_lds = (uint32_t)lds_off; lds_off = align_up_sz(lds_off + bytes, 16); }
+    }
+    a.lds_lut_bytes = (uint32_t)align_up_sz(lds_off, 16);
+    h.hcols = (const FdbHashCol*)upload(hcols.data(), std::max<size_t>(hcols.size(), 1) * sizeof(FdbHashCol));
+    h.n_hcols = (int)hcols.size();
+    h.key_words = h_key_words_;
+    h.entry_words = h_entry_words_;
+    const int grid = fdb_scan_default_grid(device_) * 4;  // 256-thread workgroups, 8 per CU
+    for (int64_t r0 = 0; r0 < b.rows; r0 += kChunkRows) {
+      const int64_t r1 = std::min<int64_t>(b.rows, r0 + kChunkRows);
+      if (h_table_ != nullptr && state_dirty_) hash_groups();  // refresh the bound (waits for the previous chunk)
+      hash_reserve((uint64_t)(r1 - r0));
+      h.table = h_table_; h.keys = h_keys_; h.n_groups = h_count_dev_; h.mask = h_capacity_ - 1;
+      h.row_begin = r0; h.row_end = r1;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
+      hip_check(fdb_launch_scan_hash(h, grid, a.lds_lut_bytes, stream_), "hash scan launch");
+      if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
+      h_groups_bound_ += (uint64_t)(r1 - r0);
+      state_dirty_ = true;
+      stat_launches += 1;
+    }
+    stat_bytes += R.bytes;
+    stat_rows += b.rows;
+  }
+}
+
+void Plan::fetch_compact_hash(CompactState* cs) {
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  if (h_table_ == nullptr) { sync(); return; }
+  const uint64_t n = hash_groups();
+  cs->n = (int64_t)n;
+  if (n == 0) { sync(); return; }
+  const int ew = h_entry_words_, kw = h_key_words_, oew = ew - 2;
+  unsigned long long* d_entries = (unsigned long long*)ctx_->dev_alloc((size_t)n * oew * 8);
+  uint32_t* d_keys = (uint32_t*)ctx_->dev_alloc((size_t)n * kw * 4);
+  unsigned long long* d_n = (unsigned long long*)ctx_->dev_alloc(256);
+  hip_check(hipMemsetAsync(d_n, 0, 8, stream_), "hipMemsetAsync");
+  hip_check(fdb_launch_hash_compact(h_table_, h_keys_, h_capacity_, ew, kw, d_entries, d_keys, d_n, stream_), "hash compact");
+  std::vector<unsigned long long> entries((size_t)n * oew);
+  std::vector<uint32_t> keys((size_t)n * kw);
+  hip_check(hipMemcpyAsync(entries.data(), d_entries, entries.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(entries)");
+  hip_check(hipMemcpyAsync(keys.data(), d_keys, keys.size() * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(keys)");
+  sync();
+  ctx_->dev_free(d_entries); ctx_->dev_free(d_keys); ctx_->dev_free(d_n);
+  cs->cnt.resize(n);
+  for (uint64_t i = 0; i < n; i++) cs->cnt[i] = entries[i * oew];
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    cs->acc[j].resize(n);
+    for (uint64_t i = 0; i < n; i++) cs->acc[j][i] = entries[i * oew + 1 + j];
+  }
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    const GroupColState& g = gcols_[c];
+    if (g.kind == 0) {
+      cs->ids[c].resize(n);
+      for (uint64_t i = 0; i < n; i++) cs->ids[c][i] = keys[i * kw + g.word];
+    } else {
+      cs->ivals[c].resize(n); cs->ivalid[c].resize(n);
+      for (uint64_t i = 0; i < n; i++) {
+        const uint64_t vm = (uint64_t)keys[i * kw] | ((uint64_t)keys[i * kw + 1] << 32);
+        cs->ivalid[c][i] = (vm >> c) & 1;
+        cs->ivals[c][i] = (int64_t)((uint64_t)keys[i * kw + g.word] | ((uint64_t)keys[i * kw + g.word + 1] << 32));
+      }
+    }
+  }
+}
+
+// ≙ Synchronizer + final stage when either side holds a hash table: the source's occupied groups are re-keyed into
+// this plan's key ids on the device (per-column translation LUTs) and merged with atomics.
+void Plan::merge_hash(Plan& src) {
+  CompactState cs;
+  src.fetch_compact(&cs);
+  if (cs.n == 0) return;
+  // adopt the source's columns and dictionary values
+  std::vector<int> dst_of(src.gcols_.size());
+  std::vector<std::vector<uint32_t>> id_map(src.gcols_.size());
+  for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+    const GroupColState& sg = src.gcols_[sc];
+    size_t gi = 0;
+    for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == sg.name) break;
+    if (gi == gcols_.size()) {
+      GroupColState g;
+      g.name = sg.name; g.kind = sg.kind; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      gcols_.push_back(std::move(g));
+    }
+    GroupColState& g = gcols_[gi];
+    if (g.kind != sg.kind) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
+    dst_of[sc] = (int)gi;
+    if (sg.kind == 0) {
+      g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());
+      id_map[sc].assign(sg.values.size() + 1, 0);
+      for (size_t v = 0; v < sg.values.size(); v++) id_map[sc][v + 1] = g.intern(sg.values[v]);
+    }
+  }
+  if (mode_ == TableMode::DENSE) switch_to_hash();
+  hash_layout();
+  // incoming tuples: [mask lo, mask hi, per source column: 1 word (dictionary id) or 2 words (int64)]
+  std::vector<int> src_word(src.gcols_.size());
+  int in_kw = 2;
+  for (size_t sc = 0; sc < src.gcols_.size(); sc++) { src_word[sc] = in_kw; in_kw += src.gcols_[sc].kind == 0 ? 1 : 2; }
+  std::vector<uint32_t> keys((size_t)cs.n * in_kw, 0);
+  const size_t in_ew = 1 + aggs_.size();
+  std::vector<unsigned long long> entries((size_t)cs.n * in_ew);
+  for (int64_t i = 0; i < cs.n; i++) {
+    uint64_t vm = 0;
+    for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+      if (src.gcols_[sc].kind == 0) {
+        const uint32_t id = cs.ids[sc].empty() ? 0u : cs.ids[sc][(size_t)i];
+        keys[(size_t)i * in_kw + src_word[sc]] = id;
+        if (id) vm |= 1ull << sc;
+      } else if (!cs.ivalid[sc].empty() && cs.ivalid[sc][(size_t)i]) {
+        const uint64_t v = (uint64_t)cs.ivals[sc][(size_t)i];
+        keys[(size_t)i * in_kw + src_word[sc]] = (uint32_t)v;
+        keys[(size_t)i * in_kw + src_word[sc] + 1] = (uint32_t)(v >> 32);
+        vm |= 1ull << sc;
+      }
+    }
+    keys[(size_t)i * in_kw] = (uint32_t)vm; keys[(size_t)i * in_kw + 1] = (uint32_t)(vm >> 32);
+    entries[(size_t)i * in_ew] = cs.cnt[(size_t)i];
+    for (size_t j = 0; j < aggs_.size(); j++) entries[(size_t)i * in_ew + 1 + j] = cs.acc[j][(size_t)i];
+  }
+  std::vector<FdbHashCol> cols(gcols_.size());
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    std::memset(&cols[c], 0, sizeof(FdbHashCol));
+    cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c; cols[c].src_word = -1; cols[c].lut_lds = FDB_NO_LDS;
+  }
+  for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+    FdbHashCol& C = cols[(size_t)dst_of[sc]];
+    C.src_word = src_word[sc];
+    if (src.gcols_[sc].kind == 0) C.lut = (const uint32_t*)upload(id_map[sc].data(), id_map[sc].size() * 4);
+    else C.lut_len = (uint32_t)sc;  // the source plan's column index: selects the bit of the incoming valid mask
+  }
+  hash_insert_entries(entries, keys, cs.n, in_kw, cols);
+  sync();
+}
+
+}  // namespace fdb

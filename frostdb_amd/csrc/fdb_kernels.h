@@ -113,6 +113,67 @@ struct FdbScanArgs {
   FdbAgg aggs[FDB_MAX_AGGS];
 };
 
+// ---- high-cardinality path: global open-addressing hash table -------------------------------------------------
+// Key tuple layout (32-bit words): [valid mask lo | valid mask hi | column words …]; bit g of the mask = group column
+// g (plan-level index, stable for the life of the plan) is non-NULL in this group. A dictionary column owns one word
+// (its key id), an int64 column two (low, high). The fingerprint is a SUM of per-column mixes of the non-NULL columns
+// only, so it does not depend on column order and a column that shows up later (all earlier groups NULL in it)
+// leaves earlier fingerprints unchanged.
+struct FdbHashCol {
+  const void* values;       // uint32 indices (dictionary) or int64 values
+  const uint8_t* validity;
+  const uint32_t* lut;      // dictionary entry → key id (scan) / source key id → destination key id (merge; nullptr = identity)
+  uint32_t lut_len;
+  uint32_t lut_lds;         // byte offset of the LDS copy or FDB_NO_LDS
+  int32_t kind;             // 0 dictionary, 1 int64
+  int32_t word;             // first word of this column inside the key tuple
+  int32_t gi;               // plan-level group column index (fingerprint salt, valid-mask bit)
+  int32_t src_word;         // merge: first word of this column inside the INCOMING key tuple (-1: absent ⇒ NULL)
+};
+
+// Table entry = entry_words × 8 bytes: [fingerprint lo (0 = empty) | fingerprint hi | selected-row count | acc 0 … ]
+// padded to a multiple of 32 bytes so that probe, count and accumulators of a group share one 64-byte sector.
+struct FdbHashArgs {
+  FdbScanArgs base;         // n_rows, filter program, aggregates (values / validity / func / type); dense fields unused
+  const FdbHashCol* hcols;  // device array [n_hcols]
+  unsigned long long* table;
+  uint32_t* keys;           // [capacity][key_words]: the key tuple of each occupied slot (written once, by the inserter)
+  unsigned long long* n_groups;  // device counter of occupied slots
+  uint64_t mask;            // capacity - 1 (capacity is a power of two)
+  int64_t row_begin;        // the launch covers rows [row_begin, row_end) of the record (multiples of 8)
+  int64_t row_end;
+  int32_t n_hcols;
+  int32_t key_words;
+  int32_t entry_words;
+  int32_t _pad;
+};
+
+#define FDB_HASH_BLOCK 256
+hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t lds_bytes, hipStream_t stream);
+// table[i] = {0, 0, 0, idents…, 0 pad} for i < capacity
+hipError_t fdb_launch_hash_init(unsigned long long* table, uint64_t capacity, int entry_words, int n_aggs, const unsigned long long* idents,
+                                hipStream_t stream);
+// Moves every occupied entry of (old_table, old_keys) into the (empty-initialised) new table; key tuples are copied
+// word for word into the (possibly wider, zero-initialised) new key store.
+hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int old_key_words,
+                                  unsigned long long* new_table, uint32_t* new_keys, uint64_t new_mask, int entry_words, int new_key_words,
+                                  hipStream_t stream);
+// Compacts the occupied entries: out_entries[i][0..entry_words-2] = {count, acc…} (fingerprints dropped), out_keys[i][key_words];
+// *n_out = number of entries. Order is arbitrary.
+hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int entry_words, int key_words,
+                                   unsigned long long* out_entries, uint32_t* out_keys, unsigned long long* n_out, hipStream_t stream);
+// Inserts / merges `n` pre-aggregated entries (hash_compact's layout: {count, acc…} per entry + key tuples of
+// `in_key_words` words) into the table. cols[c] describes destination column c: where its words sit in the incoming
+// tuple (src_word), and a LUT translating incoming dictionary key ids. funcs[j]: 1 add u64, 2 add f64, 3 min i64, 4 max i64, 0 skip.
+struct FdbHashMergeArgs {
+  const unsigned long long* entries; const uint32_t* in_keys; int64_t n;
+  unsigned long long* table; uint32_t* keys; unsigned long long* n_groups; uint64_t mask;
+  const FdbHashCol* cols;   // device array [n_cols]
+  int32_t n_cols, in_key_words, in_entry_words, entry_words, key_words, n_aggs;
+  int32_t funcs[FDB_MAX_AGGS];
+};
+hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t stream);
+
 // Identity elements stored in accumulators. MIN/MAX over float64 run on order-preserving int64 keys
 // (fdb_f64_to_ordered) so one integer atomic serves both types.
 #define FDB_I64_MAX 0x7FFFFFFFFFFFFFFFLL

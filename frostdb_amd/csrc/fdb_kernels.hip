@@ -715,6 +715,286 @@ __global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __re
   }
 }
 
+// =========================================================================================================
+// High-cardinality path (cfg 5: 32 label columns, 10 M groups): a global open-addressing table keyed by a
+// 128-bit fingerprint of the key tuple. Per selected row: fold every group column's key id into two independent
+// 64-bit hashes, probe linearly with a 64-bit CAS on the low half, confirm on the high half, then update the
+// group's count and accumulators — which sit in the SAME 32/64-byte entry as the fingerprint, so a row costs one
+// random sector of table traffic. (The reference keys its Go map by a single 64-bit hash and never compares keys,
+// aggregate.go:130,:411; 128 bits make a false merge practically impossible: ≈ n²/2¹²⁹.) The inserting lane also
+// writes the group's key tuple (dictionary key ids / int64 values) once, for Finish.
+// No LDS staging of aggregates here: with ~10 rows per group spread uniformly, a per-workgroup cache never hits.
+// =========================================================================================================
+__device__ __forceinline__ unsigned long long fmix64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return k;
+}
+// Per-column contribution to the 128-bit fingerprint (summed over the non-NULL columns: order independent).
+__device__ __forceinline__ void fp_add(unsigned long long& h1, unsigned long long& h2, int gi, unsigned long long v) {
+  const unsigned long long s1 = fmix64(0x9E3779B97F4A7C15ULL * (unsigned long long)(gi + 1));
+  const unsigned long long s2 = fmix64(0xD6E8FEB86659FD93ULL * (unsigned long long)(gi + 1) + 0x632BE59BD9B4E019ULL);
+  h1 += fmix64(v ^ s1);
+  h2 += fmix64((v + 0x9FB21C651E98DF25ULL) ^ s2);
+}
+__device__ __forceinline__ void fp_final(unsigned long long& h1, unsigned long long& h2) {
+  h1 = fmix64(h1 + 0x243F6A8885A308D3ULL); h2 = fmix64(h2 ^ 0xA5A5A5A5A5A5A5A5ULL);
+  if (h1 == 0) h1 = 1;
+  if (h2 == 0) h2 = 1;
+}
+
+// Finds the entry of fingerprint (h1, h2), inserting it if absent. Returns the slot and whether THIS lane inserted.
+__device__ __forceinline__ uint64_t hash_find_or_insert(unsigned long long* table, uint64_t mask, int ew, unsigned long long h1,
+                                                        unsigned long long h2, bool& inserted) {
+  uint64_t slot = h1 & mask;
+  inserted = false;
+  for (;;) {
+    unsigned long long* e = table + slot * (uint64_t)ew;
+    unsigned long long prev = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == 0) prev = atomicCAS(e, 0ull, h1);
+    if (prev == 0) {  // this lane owns the slot: publish the high half right away
+      __hip_atomic_store(e + 1, h2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      inserted = true;
+      return slot;
+    }
+    if (prev == h1) {
+      const unsigned long long v = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v == h2) return slot;
+      if (v == 0) { __builtin_amdgcn_s_sleep(1); continue; }  // the owner has not published yet: look again
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+// The key tuple of one row (used by the inserting lane only: one row per NEW group).
+__device__ __forceinline__ void hash_write_key(const FdbHashArgs& h, int64_t row, uint32_t* dst) {
+  unsigned long long vmask = 0;
+  for (int c = 0; c < h.n_hcols; c++) {
+    const FdbHashCol& C = h.hcols[c];
+    const bool valid = C.validity == nullptr || ((as_global(C.validity)[row >> 3] >> (row & 7)) & 1);
+    if (C.kind == 0) {
+      const uint32_t id = valid ? as_global(C.lut)[as_global(reinterpret_cast<const uint32_t*>(C.values))[row]] : 0u;
+      dst[C.word] = id;
+      if (id != 0) vmask |= 1ull << C.gi;
+    } else {
+      const unsigned long long v = valid ? as_global(reinterpret_cast<const unsigned long long*>(C.values))[row] : 0ull;
+      dst[C.word] = (uint32_t)v; dst[C.word + 1] = (uint32_t)(v >> 32);
+      if (valid) vmask |= 1ull << C.gi;
+    }
+  }
+  dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);
+}
+
+__global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHashArgs h) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ unsigned int s_new;
+  constexpr int R = 4;
+  constexpr uint32_t FULL = 0xFu;
+  const FdbScanArgs& a = h.base;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_new = 0;
+  for (int l = 0; l < a.n_leaves; l++) {
+    const FdbLeaf& L = a.leaves[l];
+    if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
+      for (uint32_t i = tid; i < L.lut_len; i += FDB_HASH_BLOCK) smem[L.lut_lds + i] = as_global(L.lut)[i];
+  }
+  for (int c = 0; c < h.n_hcols; c++) {
+    const FdbHashCol& C = h.hcols[c];
+    if (C.kind == 0 && C.lut_lds != FDB_NO_LDS) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(smem + C.lut_lds);
+      for (uint32_t i = tid; i < C.lut_len; i += FDB_HASH_BLOCK) dst[i] = as_global(C.lut)[i];
+    }
+  }
+  __syncthreads();
+
+  const int ew = h.entry_words;
+  const int64_t tile_rows = (int64_t)FDB_HASH_BLOCK * R;
+  const int64_t n_tiles = (h.row_end - h.row_begin + tile_rows - 1) / tile_rows;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = h.row_begin + tile * tile_rows + (int64_t)tid * R;
+    uint32_t sel = 0;
+    if (row0 < h.row_end) {
+      const int64_t left = h.row_end - row0;
+      sel = eval_filter<R>(a, row0, smem) & (left >= R ? FULL : ((1u << (int)left) - 1u));
+    }
+    if (sel == 0) continue;
+
+    unsigned long long h1[R], h2[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { h1[r] = 0; h2[r] = 0; }
+    for (int c = 0; c < h.n_hcols; c++) {
+      const FdbHashCol& C = h.hcols[c];
+      uint32_t valid = FULL;
+      if (C.validity != nullptr) valid = load_valid<R>(C.validity, row0);
+      if (C.kind == 0) {
+        uint32_t idx[R];
+        load_u32<R>(reinterpret_cast<const uint32_t*>(C.values) + row0, idx);
+        if (C.lut_lds != FDB_NO_LDS) {
+          const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + C.lut_lds);
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const uint32_t id = ((valid >> r) & 1u) ? lut[idx[r]] : 0u;
+            if (id != 0) fp_add(h1[r], h2[r], C.gi, id);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const uint32_t id = ((valid >> r) & 1u) ? as_global(C.lut)[idx[r]] : 0u;
+            if (id != 0) fp_add(h1[r], h2[r], C.gi, id);
+          }
+        }
+      } else {
+        unsigned long long v[R];
+        load_u64<R>(reinterpret_cast<const unsigned long long*>(C.values) + row0, v);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if ((valid >> r) & 1u) fp_add(h1[r], h2[r], C.gi, v[r]);
+      }
+    }
+    uint64_t slot[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      slot[r] = 0;
+      if ((sel >> r) & 1u) {
+        fp_final(h1[r], h2[r]);
+        bool inserted;
+        slot[r] = hash_find_or_insert(h.table, h.mask, ew, h1[r], h2[r], inserted);
+        if (inserted) {
+          hash_write_key(h, row0 + r, h.keys + slot[r] * (uint64_t)h.key_words);
+          atomicAdd(&s_new, 1u);
+        }
+        atomicAdd(h.table + slot[r] * (uint64_t)ew + 2, 1ull);
+      }
+    }
+    for (int j = 0; j < a.n_aggs; j++) {
+      const FdbAgg& A = a.aggs[j];
+      if (A.func == AGG_COUNT) continue;
+      uint32_t valid = FULL;
+      if (A.validity != nullptr) valid = load_valid<R>(A.validity, row0);
+      unsigned long long raw[R];
+      load_u64<R>(reinterpret_cast<const unsigned long long*>(A.values) + row0, raw);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (!((sel >> r) & 1u)) continue;
+        const unsigned long long x = ((valid >> r) & 1u) ? raw[r] : 0ull;  // NULL ⇒ the builder's zeroed slot
+        unsigned long long* acc = h.table + slot[r] * (uint64_t)ew + 3 + j;
+        if (A.func == AGG_SUM) {
+          if (A.type == FDB_T_F64) atomicAdd(reinterpret_cast<double*>(acc), __longlong_as_double((long long)x));
+          else atomicAdd(acc, x);
+        } else {
+          const long long key = A.type == FDB_T_F64 ? f64_to_ordered(__longlong_as_double((long long)x)) : (long long)x;
+          if (A.func == AGG_MIN) atomicMin(reinterpret_cast<long long*>(acc), key);
+          else atomicMax(reinterpret_cast<long long*>(acc), key);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && s_new != 0) atomicAdd(h.n_groups, (unsigned long long)s_new);
+}
+
+struct HashIdents { unsigned long long v[FDB_MAX_AGGS]; };
+__global__ void hash_init_kernel(unsigned long long* table, uint64_t total_words, int ew, int n_aggs, HashIdents id) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_words; i += (uint64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % (uint64_t)ew);
+    table[i] = (w >= 3 && w < 3 + n_aggs) ? id.v[w - 3] : 0ull;
+  }
+}
+
+__global__ void hash_rehash_kernel(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int okw,
+                                   unsigned long long* new_table, uint32_t* new_keys, uint64_t new_mask, int ew, int kw) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < old_capacity; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long* e = old_table + i * (uint64_t)ew;
+    const unsigned long long h1 = e[0];
+    if (h1 == 0) continue;
+    uint64_t slot = h1 & new_mask;
+    for (;;) {  // fingerprints are unique in the old table: claim the first empty slot
+      if (atomicCAS(new_table + slot * (uint64_t)ew, 0ull, h1) == 0ull) break;
+      slot = (slot + 1) & new_mask;
+    }
+    unsigned long long* d = new_table + slot * (uint64_t)ew;
+    for (int w = 1; w < ew; w++) d[w] = e[w];
+    for (int w = 0; w < okw; w++) new_keys[slot * (uint64_t)kw + w] = old_keys[i * (uint64_t)okw + w];
+  }
+}
+
+__global__ void hash_compact_kernel(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int ew, int kw,
+                                    unsigned long long* out_entries, uint32_t* out_keys, unsigned long long* n_out) {
+  const uint64_t n_round = (capacity + 63) & ~(uint64_t)63;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
+    const bool occ = i < capacity && table[i * (uint64_t)ew] != 0ull;
+    const unsigned long long m = __ballot(occ);
+    if (m == 0ull) continue;
+    unsigned long long base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (occ) {
+      const uint64_t o = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 2; w < ew; w++) out_entries[o * (uint64_t)(ew - 2) + (w - 2)] = table[i * (uint64_t)ew + w];
+      for (int w = 0; w < kw; w++) out_keys[o * (uint64_t)kw + w] = keys[i * (uint64_t)kw + w];
+    }
+  }
+}
+
+__global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
+  __shared__ unsigned int s_new;
+  if (threadIdx.x == 0) s_new = 0;
+  __syncthreads();
+  const int ew = m.entry_words, kw = m.key_words, ikw = m.in_key_words;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t* in = m.in_keys + i * (int64_t)ikw;
+    unsigned long long h1 = 0, h2 = 0, vmask = 0;
+    for (int c = 0; c < m.n_cols; c++) {  // translate the incoming tuple column by column
+      const FdbHashCol& C = m.cols[c];
+      if (C.src_word < 0) continue;
+      if (C.kind == 0) {
+        uint32_t id = in[C.src_word];
+        if (id != 0 && C.lut != nullptr) id = C.lut[id];
+        if (id != 0) { fp_add(h1, h2, C.gi, id); vmask |= 1ull << C.gi; }
+      } else {
+        const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
+        if ((in_mask >> C.lut_len) & 1ull) {  // lut_len carries the SOURCE plan's column index for int64 columns
+          const unsigned long long v = (unsigned long long)in[C.src_word] | ((unsigned long long)in[C.src_word + 1] << 32);
+          fp_add(h1, h2, C.gi, v);
+          vmask |= 1ull << C.gi;
+        }
+      }
+    }
+    fp_final(h1, h2);
+    bool inserted;
+    const uint64_t slot = hash_find_or_insert(m.table, m.mask, ew, h1, h2, inserted);
+    if (inserted) {
+      uint32_t* dst = m.keys + slot * (uint64_t)kw;
+      dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);
+      for (int c = 0; c < m.n_cols; c++) {
+        const FdbHashCol& C = m.cols[c];
+        if (C.kind == 0) {
+          uint32_t id = C.src_word >= 0 ? in[C.src_word] : 0u;
+          if (id != 0 && C.lut != nullptr) id = C.lut[id];
+          dst[C.word] = id;
+        } else {
+          dst[C.word] = C.src_word >= 0 ? in[C.src_word] : 0u;
+          dst[C.word + 1] = C.src_word >= 0 ? in[C.src_word + 1] : 0u;
+        }
+      }
+      atomicAdd(&s_new, 1u);
+    }
+    const unsigned long long* e = m.entries + i * (int64_t)m.in_entry_words;
+    unsigned long long* d = m.table + slot * (uint64_t)ew;
+    atomicAdd(d + 2, e[0]);
+    for (int j = 0; j < m.n_aggs; j++) {
+      const int f = m.funcs[j];
+      const unsigned long long v = e[1 + j];
+      if (f == 1) atomicAdd(d + 3 + j, v);
+      else if (f == 2) atomicAdd(reinterpret_cast<double*>(d + 3 + j), __longlong_as_double((long long)v));
+      else if (f == 3) atomicMin(reinterpret_cast<long long*>(d + 3 + j), (long long)v);
+      else if (f == 4) atomicMax(reinterpret_cast<long long*>(d + 3 + j), (long long)v);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_new != 0) atomicAdd(m.n_groups, (unsigned long long)s_new);
+}
+
 __global__ void fill_u64_kernel(unsigned long long* dst, unsigned long long value, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = value;
 }
@@ -1055,5 +1335,46 @@ hipError_t fdb_launch_gather_bits(const uint8_t* src_bitmap, uint8_t* dst_bitmap
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(gather_bits_kernel, dim3(blocks), dim3(256), 0, stream, src_bitmap, dst_bitmap, indices, n);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t lds_bytes, hipStream_t stream) {
+  const int64_t tile_rows = (int64_t)FDB_HASH_BLOCK * 4;
+  const int64_t n_tiles = (args.row_end - args.row_begin + tile_rows - 1) / tile_rows;
+  if (n_tiles <= 0) return hipSuccess;
+  if (grid_blocks > n_tiles) grid_blocks = (int)n_tiles;
+  hipLaunchKernelGGL(scan_hash_kernel, dim3(grid_blocks), dim3(FDB_HASH_BLOCK), lds_bytes, stream, args);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_hash_init(unsigned long long* table, uint64_t capacity, int entry_words, int n_aggs, const unsigned long long* idents,
+                                hipStream_t stream) {
+  HashIdents id;
+  for (int j = 0; j < FDB_MAX_AGGS; j++) id.v[j] = j < n_aggs ? idents[j] : 0ull;
+  const uint64_t total = capacity * (uint64_t)entry_words;
+  hipLaunchKernelGGL(hash_init_kernel, dim3(4096), dim3(256), 0, stream, table, total, entry_words, n_aggs, id);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int old_key_words,
+                                  unsigned long long* new_table, uint32_t* new_keys, uint64_t new_mask, int entry_words, int new_key_words,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(hash_rehash_kernel, dim3(4096), dim3(256), 0, stream, old_table, old_keys, old_capacity, old_key_words, new_table, new_keys,
+                     new_mask, entry_words, new_key_words);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int entry_words, int key_words,
+                                   unsigned long long* out_entries, uint32_t* out_keys, unsigned long long* n_out, hipStream_t stream) {
+  hipLaunchKernelGGL(hash_compact_kernel, dim3(4096), dim3(256), 0, stream, table, keys, capacity, entry_words, key_words, out_entries, out_keys,
+                     n_out);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t stream) {
+  if (args.n <= 0) return hipSuccess;
+  int blocks = (int)((args.n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(hash_merge_kernel, dim3(blocks), dim3(256), 0, stream, args);
   return hipGetLastError();
 }

@@ -11,6 +11,7 @@
 #include "fdb_plan.h"
 
 #include "fdb_context.h"
+#include "fdb_plan_internal.h"
 
 #include <algorithm>
 #include <cstring>
@@ -231,6 +232,9 @@ Plan::~Plan() {
   (void)hipStreamSynchronize(stream_);
   for (auto& p : pending_events_) { ctx_->put_event(p.first); ctx_->put_event(p.second); }
   ctx_->dev_free(d_state_);
+  ctx_->dev_free(h_table_);
+  ctx_->dev_free(h_keys_);
+  ctx_->dev_free(h_count_dev_);
   for (void* p : scratch_) ctx_->dev_free(p);
   ctx_->reset_staging();
   Context::release(ctx_);
@@ -291,18 +295,6 @@ const char* Plan::draw() {
 
 // ---- filter resolution ---------------------------------------------------------------------------------
 namespace {
-
-struct Blob {  // LUTs of one batch, shipped with one copy
-  std::vector<uint8_t> bytes;
-  size_t add(const void* p, size_t n) {
-    const size_t off = align_up(bytes.size(), 16);
-    bytes.resize(off + std::max<size_t>(n, 1), 0);
-    if (n) std::memcpy(bytes.data() + off, p, n);
-    return off;
-  }
-};
-
-struct PendingLut { int kind; int index; size_t blob_off; size_t len_bytes; };  // kind 0: leaf, 1: group col
 
 // Truth table of a predicate over ONE dictionary column: an answer per dictionary entry plus the answer for a NULL
 // row (last element). This is what replaces the reference's per-row string compare (binaryscalarexpr.go:154-311).
@@ -368,29 +360,6 @@ Truth subtree_truth(const std::vector<ExprNode>& nodes, int idx, const HostDict&
 }
 
 }  // namespace
-
-struct Plan::Resolved {
-  FdbScanArgs args;
-  Blob blob;
-  std::vector<PendingLut> luts;
-  std::vector<char> counted;  // per batch column: bit 0 values, bit 1 validity already counted in algorithmic bytes
-  int64_t bytes = 0;
-  int leaf_col[FDB_MAX_LEAVES];           // batch column behind each leaf (-1: constant leaf)
-  int gcol_col[FDB_MAX_DENSE_GCOLS];
-  int agg_col[FDB_MAX_AGGS];
-  Resolved() {
-    for (int& v : leaf_col) v = -1;
-    for (int& v : gcol_col) v = -1;
-    for (int& v : agg_col) v = -1;
-  }
-  // Algorithmic bytes: each referenced buffer once per row, whatever the number of references.
-  void count(const DeviceBatch& b, int ci, bool values = true) {
-    if (counted.empty()) counted.assign(b.cols.size(), 0);
-    char& c = counted[(size_t)ci];
-    if (values && !(c & 1)) { c |= 1; bytes += b.cols[(size_t)ci].value_bytes; }
-    if (!(c & 2)) { c |= 2; bytes += b.cols[(size_t)ci].validity_bytes; }
-  }
-};
 
 static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved* R, FdbLeaf* L);
 
@@ -660,35 +629,30 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
     bool matched = false;
     for (const GroupMatcher& m : matchers_) if (match_group(m, c.name)) { matched = true; break; }
     if (!matched) continue;
-    if (c.kind != ColKind::DICT)
-      throw Error(FDB_ERR_UNSUPPORTED, "group by on a non-dictionary column (" + c.name + ": " + c.format + ") is not supported on the device path yet");
+    if (c.kind != ColKind::DICT && c.kind != ColKind::I64)  // HashArray panics on anything else it does not know (hashed.go:86-105)
+      throw Error(FDB_ERR_UNSUPPORTED, "group by on column type " + c.format + " (" + c.name + ") is not supported on the device path");
     if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
+    const int kind = c.kind == ColKind::DICT ? 0 : 1;
     size_t gi = 0;
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == c.name) break;
     if (gi == gcols_.size()) {
+      if (gcols_.size() >= FDB_MAX_HASH_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "more than 64 group-by columns");
       GroupColState g;
       g.name = c.name;
-      g.value_format = c.dict->value_format;
+      g.kind = kind;
+      if (kind == 0) g.value_format = c.dict->value_format;
       g.cap = 1;
       g.stride = 0;
       gcols_.push_back(std::move(g));
     }
-    if (a.n_gcols >= FDB_MAX_DENSE_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "too many group-by columns for the dense path; hash path not built yet");
     GroupColState& g = gcols_[gi];
-    const std::shared_ptr<const std::vector<uint32_t>> lut_ptr = g.lut_for(c.dict);
-    const std::vector<uint32_t>& lut = *lut_ptr;
+    if (g.kind != kind) throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + " changed type between batches");
+    GroupRes gr;
+    gr.gi = (int)gi; gr.ci = (int)ci; gr.kind = kind;
+    if (kind == 0) gr.lut = g.lut_for(c.dict);
+    R.groups.push_back(std::move(gr));
     R.count(b, (int)ci);
-    FdbGroupCol& G = a.gcols[a.n_gcols];
-    G.idx = (const uint32_t*)c.d_values;
-    G.validity = c.d_validity;
-    G.lut_len = (uint32_t)lut.size();
-    G.lut_lds = FDB_NO_LDS;
-    G.slot = -1;
-    R.gcol_col[a.n_gcols] = (int)ci;
-    const size_t off = R.blob.add(lut.data(), lut.size() * 4);
-    R.luts.push_back(PendingLut{1, a.n_gcols, off, lut.size() * 4});
-    batch_gcols->push_back((int)gi);
-    a.n_gcols++;
+    (void)batch_gcols;
   }
 
   // aggregated columns, by exact name (aggregate.go:340-361); all must be present (:367-380)
@@ -794,6 +758,41 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   for (int i = 0; i < n; i++) if (bs[i]->rows > 0) live.push_back(i);
   if (live.empty()) return;
 
+  // Dense (mixed-radix) table while the key space is small and every key column is a dictionary; otherwise the
+  // global hash table (cfg 5: tens of label columns, millions of groups; int64 keys such as time buckets).
+  if (mode_ == TableMode::DENSE) {
+    bool want_hash = gcols_.size() > FDB_MAX_DENSE_GCOLS;
+    uint64_t space = 1;
+    for (const GroupColState& g : gcols_) {
+      if (g.kind != 0) want_hash = true;
+      space *= (uint64_t)g.values.size() + 1;
+      if (space > (1ull << 22)) { want_hash = true; break; }
+    }
+    if (want_hash) switch_to_hash();
+  }
+  if (mode_ == TableMode::HASH) {
+    push_hash(bs, Rs, live);
+    pt.mark("hash scan");
+    return;
+  }
+  for (int i : live) {  // dense path: group columns → mixed-radix digits through per-dictionary LUTs
+    Resolved& R = Rs[(size_t)i];
+    FdbScanArgs& a = R.args;
+    for (const GroupRes& gr : R.groups) {
+      FdbGroupCol& G = a.gcols[a.n_gcols];
+      const DevColumn& c = bs[i]->cols[(size_t)gr.ci];
+      G.idx = (const uint32_t*)c.d_values;
+      G.validity = c.d_validity;
+      G.lut_len = (uint32_t)gr.lut->size();
+      G.lut_lds = FDB_NO_LDS;
+      G.slot = -1;
+      R.gcol_col[a.n_gcols] = gr.ci;
+      const size_t off = R.blob.add(gr.lut->data(), gr.lut->size() * 4);
+      R.luts.push_back(PendingLut{1, a.n_gcols, off, gr.lut->size() * 4});
+      part_gcols[(size_t)i].push_back(gr.gi);
+      a.n_gcols++;
+    }
+  }
   std::vector<uint32_t> caps;
   for (const GroupColState& g : gcols_) caps.push_back((uint32_t)g.values.size() + 1);
   ensure_layout(caps);
@@ -967,20 +966,62 @@ void Plan::fetch_state(std::vector<unsigned long long>* cnt, std::vector<std::ve
   ctx_->host_free(h);
 }
 
-void Plan::build_key_columns(const std::vector<uint32_t>& slots, std::vector<OutColumn>* cols) const {
-  const int64_t n = (int64_t)slots.size();
-  for (const GroupColState& g : gcols_) {
+// Occupied groups of the table, in a mode-independent host form (dense: enumerate slots with count > 0 and decode
+// the mixed-radix digits; hash: compact on the device, copy, decode key tuples).
+void Plan::fetch_compact(CompactState* cs) {
+  cs->n = 0;
+  cs->cnt.clear();
+  cs->acc.assign(aggs_.size(), {});
+  cs->ids.assign(gcols_.size(), {});
+  cs->ivals.assign(gcols_.size(), {});
+  cs->ivalid.assign(gcols_.size(), {});
+  if (mode_ == TableMode::HASH) { fetch_compact_hash(cs); return; }
+  std::vector<unsigned long long> cnt;
+  std::vector<std::vector<unsigned long long>> acc;
+  fetch_state(&cnt, &acc);
+  std::vector<uint32_t> slots;
+  for (uint32_t s = 0; s < cnt.size(); s++) if (cnt[s] != 0) slots.push_back(s);
+  const size_t n = slots.size();
+  cs->n = (int64_t)n;
+  cs->cnt.resize(n);
+  for (size_t i = 0; i < n; i++) cs->cnt[i] = cnt[slots[i]];
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    cs->acc[j].resize(n);
+    for (size_t i = 0; i < n; i++) cs->acc[j][i] = acc[j][slots[i]];
+  }
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    const GroupColState& g = gcols_[c];
+    cs->ids[c].resize(n);
+    for (size_t i = 0; i < n; i++) cs->ids[c][i] = g.cap > 1 ? (slots[i] / g.stride) % g.cap : 0;
+  }
+}
+
+void Plan::build_key_columns(const CompactState& cs, std::vector<OutColumn>* cols) const {
+  const int64_t n = cs.n;
+  for (size_t gc = 0; gc < gcols_.size(); gc++) {
+    const GroupColState& g = gcols_[gc];
     OutColumn c;
     c.name = g.name;
+    c.length = n;
+    c.validity.assign((size_t)(n + 7) / 8, 0);
+    if (g.kind == 1) {  // int64 key column
+      c.format = "l";
+      c.values.resize((size_t)n * 8);
+      for (int64_t i = 0; i < n; i++) {
+        const int64_t v = cs.ivalid[gc][(size_t)i] ? cs.ivals[gc][(size_t)i] : 0;
+        std::memcpy(c.values.data() + (size_t)i * 8, &v, 8);
+        if (cs.ivalid[gc][(size_t)i]) c.validity[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); else c.null_count++;
+      }
+      cols->push_back(std::move(c));
+      continue;
+    }
     c.format = "I";
     c.is_dict = true;
     c.dict_format = g.value_format;
-    c.length = n;
     c.values.resize((size_t)n * 4);
-    c.validity.assign((size_t)(n + 7) / 8, 0);
     uint32_t* idx = (uint32_t*)c.values.data();
     for (int64_t i = 0; i < n; i++) {
-      const uint32_t id = g.cap > 1 ? (slots[(size_t)i] / g.stride) % g.cap : 0;
+      const uint32_t id = cs.ids[gc][(size_t)i];
       if (id == 0) { idx[i] = 0; c.null_count++; }
       else { idx[i] = id - 1; c.validity[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); }
     }
@@ -996,9 +1037,8 @@ void Plan::build_key_columns(const std::vector<uint32_t>& slots, std::vector<Out
   }
 }
 
-void Plan::build_agg_columns(const std::vector<uint32_t>& slots, const std::vector<unsigned long long>& cnt,
-                             const std::vector<std::vector<unsigned long long>>& acc, std::vector<OutColumn>* cols) const {
-  const int64_t n = (int64_t)slots.size();
+void Plan::build_agg_columns(const CompactState& cs, std::vector<OutColumn>* cols) const {
+  const int64_t n = cs.n;
   for (size_t j = 0; j < aggs_.size(); j++) {
     const AggState& A = aggs_[j];
     OutColumn c;
@@ -1009,11 +1049,10 @@ void Plan::build_agg_columns(const std::vector<uint32_t>& slots, const std::vect
     const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
     c.format = is_f64 ? "g" : "l";
     for (int64_t i = 0; i < n; i++) {
-      const uint32_t s = slots[(size_t)i];
       unsigned long long v;
-      if (count_from_cnt) v = cnt[s];
+      if (count_from_cnt) v = cs.cnt[(size_t)i];
       else {
-        v = acc[j][s];
+        v = cs.acc[j][(size_t)i];
         if (is_f64 && (A.func == FDB_AGG_MIN || A.func == FDB_AGG_MAX)) {
           const double d = fdb_ordered_to_f64_host((int64_t)v);
           std::memcpy(&v, &d, 8);
@@ -1027,39 +1066,30 @@ void Plan::build_agg_columns(const std::vector<uint32_t>& slots, const std::vect
 
 void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
   PhaseTimer pt;
-  std::vector<unsigned long long> cnt;
-  std::vector<std::vector<unsigned long long>> acc;
-  fetch_state(&cnt, &acc);
+  CompactState cs;
+  fetch_compact(&cs);
   pt.mark("finish: fetch");
-  std::vector<uint32_t> slots;
-  for (uint32_t s = 0; s < cnt.size(); s++) if (cnt[s] != 0) slots.push_back(s);
   std::vector<OutColumn> cols;
-  build_key_columns(slots, &cols);
-  build_agg_columns(slots, cnt, acc, &cols);
-  if (n_rows) *n_rows = (int64_t)slots.size();
-  export_record(std::move(cols), (int64_t)slots.size(), out, out_schema);
+  build_key_columns(cs, &cols);
+  build_agg_columns(cs, &cols);
+  if (n_rows) *n_rows = cs.n;
+  export_record(std::move(cols), cs.n, out, out_schema);
   pt.mark("finish: export");
   finished_ = true;
 }
 
 int64_t Plan::num_groups() {
-  std::vector<unsigned long long> cnt;
-  std::vector<std::vector<unsigned long long>> acc;
-  fetch_state(&cnt, &acc);
-  int64_t n = 0;
-  for (unsigned long long c : cnt) n += c != 0;
-  return n;
+  CompactState cs;
+  fetch_compact(&cs);
+  return cs.n;
 }
 
 void Plan::partial_keys(ArrowArray* out, ArrowSchema* out_schema) {
-  std::vector<unsigned long long> cnt;
-  std::vector<std::vector<unsigned long long>> acc;
-  fetch_state(&cnt, &acc);
-  std::vector<uint32_t> slots;
-  for (uint32_t s = 0; s < cnt.size(); s++) if (cnt[s] != 0) slots.push_back(s);
+  CompactState cs;
+  fetch_compact(&cs);
   std::vector<OutColumn> cols;
-  build_key_columns(slots, &cols);
-  export_record(std::move(cols), (int64_t)slots.size(), out, out_schema);
+  build_key_columns(cs, &cols);
+  export_record(std::move(cols), cs.n, out, out_schema);
 }
 
 char Plan::agg_format(int32_t agg) const {
@@ -1072,13 +1102,10 @@ char Plan::agg_format(int32_t agg) const {
 
 void Plan::partial_state(int32_t agg, void* dst, int64_t capacity_bytes) {
   if (agg < 0 || agg >= (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "aggregation index out of range");
-  std::vector<unsigned long long> cnt;
-  std::vector<std::vector<unsigned long long>> acc;
-  fetch_state(&cnt, &acc);
-  std::vector<uint32_t> slots;
-  for (uint32_t s = 0; s < cnt.size(); s++) if (cnt[s] != 0) slots.push_back(s);
+  CompactState cs;
+  fetch_compact(&cs);
   std::vector<OutColumn> cols;
-  build_agg_columns(slots, cnt, acc, &cols);
+  build_agg_columns(cs, &cols);
   const OutColumn& c = cols[(size_t)agg];
   if ((int64_t)c.values.size() > capacity_bytes) throw Error(FDB_ERR_INVALID, "partial_state: destination too small");
   if (!c.values.empty()) hip_check(hipMemcpy(dst, c.values.data(), c.values.size(), hipMemcpyDefault), "hipMemcpy(partial_state)");
@@ -1097,11 +1124,12 @@ uint64_t Plan::state_signature(int64_t* n_slots_out) {
     for (const std::string_view& v : g.values) { mix64(v.size()); mix(v.data(), v.size()); }
   }
   for (const AggState& a : aggs_) { mix64((uint64_t)a.func); mix64((uint64_t)a.type); mix(a.column.data(), a.column.size()); }
-  if (n_slots_out) *n_slots_out = d_state_ != nullptr ? (int64_t)n_slots_ : 0;
+  if (n_slots_out) *n_slots_out = (d_state_ != nullptr && mode_ == TableMode::DENSE) ? (int64_t)n_slots_ : 0;
   return h;
 }
 
 void Plan::state_read(int32_t array, void* dst, int64_t capacity_bytes) {
+  if (mode_ != TableMode::DENSE) throw Error(FDB_ERR_STATE, "raw table access needs the dense table");
   if (array < 0 || array > (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "table array index out of range");
   if (d_state_ == nullptr) throw Error(FDB_ERR_STATE, "the plan has no table yet");
   const size_t bytes = (size_t)n_slots_ * 8;
@@ -1112,6 +1140,7 @@ void Plan::state_read(int32_t array, void* dst, int64_t capacity_bytes) {
 }
 
 void Plan::state_write(int32_t array, const void* src, int64_t bytes) {
+  if (mode_ != TableMode::DENSE) throw Error(FDB_ERR_STATE, "raw table access needs the dense table");
   if (array < 0 || array > (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "table array index out of range");
   if (d_state_ == nullptr) throw Error(FDB_ERR_STATE, "the plan has no table yet");
   if (bytes != (int64_t)n_slots_ * 8) throw Error(FDB_ERR_INVALID, "state_write: size mismatch");
@@ -1133,6 +1162,7 @@ void Plan::merge_from(Plan& src) {
   src.sync();
   sync();
   if (!src.state_dirty_) return;
+  if (mode_ == TableMode::HASH || src.mode_ == TableMode::HASH) { merge_hash(src); return; }
   std::vector<unsigned long long> scnt((size_t)src.n_slots_);
   hip_check(hipMemcpy(scnt.data(), src.d_cnt_, (size_t)src.n_slots_ * 8, hipMemcpyDeviceToHost), "hipMemcpy(src cnt)");
   // unify key ids

@@ -81,6 +81,8 @@ struct AggState {
 // never change, so the entry→id table of a given dictionary is computed once and cached by content.
 struct GroupColState {
   std::string name;
+  int kind = 0;                                             // 0 dictionary column, 1 int64 column (hash table only)
+  int word = -1;                                            // hash table: first word of this column in the key tuple
   std::string value_format = "z";
   std::vector<std::string_view> values;                     // id - 1 → value (views into `owners`)
   std::vector<std::shared_ptr<const HostDict>> owners;      // keep the viewed strings alive
@@ -100,6 +102,18 @@ struct GroupColState {
 };
 
 struct GroupMatcher { std::string name; bool dynamic; };
+
+enum class TableMode { DENSE, HASH };
+
+// Occupied groups of a plan's table in host memory, independent of the table's device representation.
+struct CompactState {
+  int64_t n = 0;
+  std::vector<unsigned long long> cnt;                  // [n]
+  std::vector<std::vector<unsigned long long>> acc;     // [aggregation][n]
+  std::vector<std::vector<uint32_t>> ids;               // [group column][n] dictionary key ids (0 = NULL)
+  std::vector<std::vector<int64_t>> ivals;              // [group column][n] int64 keys
+  std::vector<std::vector<uint8_t>> ivalid;
+};
 
 class Context;  // per-device stream + cached device/pinned memory (fdb_context.h)
 
@@ -144,9 +158,19 @@ class Plan {
   void sync();
   void collect_timing();
   void fetch_state(std::vector<unsigned long long>* cnt, std::vector<std::vector<unsigned long long>>* acc);
-  void build_key_columns(const std::vector<uint32_t>& slots, std::vector<OutColumn>* cols) const;
-  void build_agg_columns(const std::vector<uint32_t>& slots, const std::vector<unsigned long long>& cnt,
-                         const std::vector<std::vector<unsigned long long>>& acc, std::vector<OutColumn>* cols) const;
+  void fetch_compact(CompactState* cs);
+  void build_key_columns(const CompactState& cs, std::vector<OutColumn>* cols) const;
+  void build_agg_columns(const CompactState& cs, std::vector<OutColumn>* cols) const;
+  // high-cardinality path (fdb_hash.cpp)
+  void switch_to_hash();
+  void hash_layout();                                   // (re)assign key-tuple words; widen the key store if columns were added
+  void hash_reserve(uint64_t extra_groups);             // capacity ≥ 2 × (groups + extra): grow + rehash on the device
+  void push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live);
+  void fetch_compact_hash(CompactState* cs);
+  void merge_hash(Plan& src);
+  uint64_t hash_groups();                               // occupied slots (reads the device counter; waits for the stream)
+  void hash_insert_entries(const std::vector<unsigned long long>& entries, const std::vector<uint32_t>& keys, int64_t n, int in_kw,
+                           const std::vector<FdbHashCol>& cols);
   void* upload(const void* host, size_t bytes);  // async H2D through the pinned pool; returns device address
 
   int device_;
@@ -164,6 +188,14 @@ class Plan {
   unsigned long long* d_state_ = nullptr;  // one block: [cnt | acc 0 | acc 1 | …], slots_alloc_ entries each
   unsigned long long* d_cnt_ = nullptr;
   bool state_dirty_ = false;        // any kernel has accumulated into the table
+  TableMode mode_ = TableMode::DENSE;
+  // hash table: entries [capacity][entry_words] u64, key tuples [capacity][key_words] u32
+  unsigned long long* h_table_ = nullptr;
+  uint32_t* h_keys_ = nullptr;
+  unsigned long long* h_count_dev_ = nullptr;
+  uint64_t h_capacity_ = 0;
+  int h_entry_words_ = 0, h_key_words_ = 2;
+  uint64_t h_groups_bound_ = 0;     // upper bound of occupied slots known on the host
 
   Context* ctx_ = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;

@@ -1,0 +1,58 @@
+// fdb_plan_internal.h — per-record resolution state shared by fdb_plan.cpp and fdb_hash.cpp (not part of any API).
+#pragma once
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "fdb_plan.h"
+
+namespace fdb {
+
+inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Blob {  // LUTs of one batch, shipped with one copy
+  std::vector<uint8_t> bytes;
+  size_t add(const void* p, size_t n) {
+    const size_t off = align_up_sz(bytes.size(), 16);
+    bytes.resize(off + std::max<size_t>(n, 1), 0);
+    if (n) std::memcpy(bytes.data() + off, p, n);
+    return off;
+  }
+};
+
+struct PendingLut { int kind; int index; size_t blob_off; size_t len_bytes; };  // kind 0: leaf, 1: group col
+
+
+struct GroupRes {
+  int gi, ci, kind;
+  std::shared_ptr<const std::vector<uint32_t>> lut;
+};
+
+struct Plan::Resolved {
+  FdbScanArgs args;
+  Blob blob;
+  std::vector<PendingLut> luts;
+  std::vector<char> counted;  // per batch column: bit 0 values, bit 1 validity already counted in algorithmic bytes
+  int64_t bytes = 0;
+  int leaf_col[FDB_MAX_LEAVES];           // batch column behind each leaf (-1: constant leaf)
+  int gcol_col[FDB_MAX_DENSE_GCOLS];
+  int agg_col[FDB_MAX_AGGS];
+  std::vector<GroupRes> groups;           // group-by columns of this record (plan-level index, record column, kind, key-id LUT)
+  Resolved() {
+    for (int& v : leaf_col) v = -1;
+    for (int& v : gcol_col) v = -1;
+    for (int& v : agg_col) v = -1;
+  }
+  // Algorithmic bytes: each referenced buffer once per row, whatever the number of references.
+  void count(const DeviceBatch& b, int ci, bool values = true) {
+    if (counted.empty()) counted.assign(b.cols.size(), 0);
+    char& c = counted[(size_t)ci];
+    if (values && !(c & 1)) { c |= 1; bytes += b.cols[(size_t)ci].value_bytes; }
+    if (!(c & 2)) { c |= 2; bytes += b.cols[(size_t)ci].validity_bytes; }
+  }
+};
+
+
+}  // namespace fdb

@@ -469,3 +469,137 @@ def test_rccl_merge_single_rank(pp):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ---- high-cardinality path: global hash table (many key columns, int64 keys, growth, migration, merge) -------------
+
+def window_records_gpu(bucket):
+    rec = table_records(G.WINDOW_TABLE)[0]
+    ts = rec.column(rec.schema.get_field_index("timestamp"))
+    b = pc.multiply(pc.divide(ts, pa.scalar(bucket, pa.int64())), pa.scalar(bucket, pa.int64()))
+    return [rec.append_column("timestamp_bucket", b)]
+
+
+@pytest.mark.parametrize("case", G.WINDOW_CASES, ids=[c["id"] for c in G.WINDOW_CASES])
+def test_golden_window_int64_group_keys(pp, case):
+    """logictest/testdata/exec/aggregate/window: GROUP BY an int64 time bucket (the bucket column is materialised by
+    the harness the way the reference's pre-aggregate Projection would) — exercises int64 keys in the hash table."""
+    d = run_gpu(pp, window_records_gpu(case["bucket"]), None, case["aggs"], case["groups"])
+    got = sorted(batch_rows(d, case["out"]), key=sort_key)
+    assert got == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+def many_label_batch(rng, n, n_cols, card, n_groups=None, null_frac=0.03, int_key=False):
+    """n rows over `n_cols` dictionary label columns; if n_groups is given rows are drawn from that many distinct
+    label tuples (mixed-radix digits of a group id, some digits NULL), like BASELINE.json's cfg 5."""
+    if n_groups is None:
+        digits = rng.integers(0, card, size=(n, n_cols))
+        nulls = rng.random((n, n_cols)) < null_frac
+    else:
+        gid = rng.integers(0, n_groups, size=n)
+        tab = rng.integers(0, card, size=(n_groups, n_cols))
+        tnull = rng.random((n_groups, n_cols)) < null_frac
+        digits, nulls = tab[gid], tnull[gid]
+    arrays, names = [], []
+    for c in range(n_cols):
+        idx = pa.array(digits[:, c].astype(np.uint32), type=pa.uint32(), mask=nulls[:, c])
+        arrays.append(pa.DictionaryArray.from_arrays(idx, pa.array([b"v%d_%d" % (c, k) for k in range(card)], type=pa.binary())))
+        names.append("labels.l%02d" % c)
+    if int_key:
+        arrays.append(pa.array(rng.integers(1, 50, size=n) * 1000, type=pa.int64()))
+        names.append("bucket")
+    arrays += [pa.array(rng.integers(-100, 100, size=n), type=pa.int64()), pa.array(rng.uniform(0, 10, size=n))]
+    names += ["value", "floatvalue"]
+    return pa.RecordBatch.from_arrays(arrays, names=names)
+
+
+def key_cols_of(batches, extra=()):
+    names = []
+    for b in batches:
+        for n in b.schema.names:
+            if (n.startswith("labels.") or n in extra) and n not in names:
+                names.append(n)
+    return names
+
+
+def test_hash_path_many_columns_vs_oracle(pp):
+    rng = np.random.default_rng(404)
+    aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("value")), Max(Col("value")), Sum(Col("floatvalue")), Min(Col("floatvalue"))]
+    batches = [many_label_batch(rng, 30_000, 12, 3, n_groups=4000), many_label_batch(rng, 20_000, 12, 3, n_groups=3000)]
+    want = run_oracle(batches, None, aggs, [DynCol("labels")])
+    for resident in (False, True):
+        got = run_gpu(pp, batches, None, aggs, [DynCol("labels")], resident=resident)
+        cols = key_cols_of(batches) + [a.Name() for a in aggs]
+        assert_same_result(got, want, cols, float_cols={"sum(floatvalue)"})
+
+
+def test_hash_path_growth_and_filter(pp):
+    """> 100 k distinct groups: the table grows (device re-hash) several times while batches arrive; a filter runs in
+    front of the hash scan; string + int64 key columns together."""
+    rng = np.random.default_rng(405)
+    aggs = [Sum(Col("value")), Count(Col("value")), Max(Col("floatvalue"))]
+    batches = [many_label_batch(rng, 120_000, 10, 4, int_key=True), many_label_batch(rng, 90_000, 10, 4, int_key=True)]
+    f = And(Col("labels.l00") != "v0_1", Col("value") > -50)
+    groups = [DynCol("labels"), Col("bucket")]
+    want = run_oracle(batches, f, aggs, groups)
+    got = run_gpu(pp, batches, f, aggs, groups, resident=True)
+    cols = key_cols_of(batches, extra=("bucket",)) + [a.Name() for a in aggs]
+    assert len(want["value" if False else "sum(value)"]) > 100_000
+    assert_same_result(got, want, cols)
+
+
+def test_dense_to_hash_migration_and_merge(pp):
+    """First record: two label columns (dense table). Second record brings ten more label columns → the plan migrates
+    its dense state into the hash table. Then a second chain in hash mode is merged in (Synchronizer + final stage)."""
+    rng = np.random.default_rng(406)
+    aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("floatvalue")), Max(Col("value"))]
+    b1 = many_label_batch(rng, 20_000, 2, 5)
+    b2 = many_label_batch(rng, 20_000, 12, 3, n_groups=2500)
+    b3 = many_label_batch(rng, 15_000, 12, 3, n_groups=2500)
+    want = run_oracle([b1, b2, b3], None, aggs, [DynCol("labels")])
+    p1 = pp.HashAggregatePlan(None, aggs, [DynCol("labels")])
+    p2 = pp.HashAggregatePlan(None, aggs, [DynCol("labels")])
+    try:
+        p1.Callback(b1)
+        p1.Callback(b2)
+        p2.Callback(b3)
+        p1.Merge(p2)
+        got = arrow_to_pydict(p1.Finish())
+    finally:
+        p1.Close(); p2.Close()
+    cols = key_cols_of([b1, b2, b3]) + [a.Name() for a in aggs]
+    assert_same_result(got, want, cols)
+    # merging a hash-mode chain INTO a dense one
+    p1 = pp.HashAggregatePlan(None, aggs, [DynCol("labels")])
+    p2 = pp.HashAggregatePlan(None, aggs, [DynCol("labels")])
+    try:
+        p1.Callback(b1)
+        p2.Callback(b2)
+        p2.Callback(b3)
+        p1.Merge(p2)
+        got = arrow_to_pydict(p1.Finish())
+    finally:
+        p1.Close(); p2.Close()
+    assert_same_result(got, want, cols)
+
+
+def test_hash_path_properties_at_scale(pp):
+    """2 M rows, 16 label columns, 300 k groups: Σcount = rows, group count = distinct tuples, sums add up."""
+    rng = np.random.default_rng(407)
+    n, n_groups = 2_000_000, 300_000
+    b = many_label_batch(rng, n, 16, 4, n_groups=n_groups)
+    aggs = [Count(Col("value")), Sum(Col("value")), Sum(Col("floatvalue"))]
+    rb = pp.ResidentBatch(b)
+    plan = pp.HashAggregatePlan(None, aggs, [DynCol("labels")])
+    plan.Callback(rb)
+    out = plan.Finish()
+    plan.Close(); rb.close()
+    d = {k: v for k, v in zip(out.schema.names, out.columns)}
+    assert pc.sum(d["count(value)"]).as_py() == n
+    assert pc.sum(d["sum(value)"]).as_py() == pc.sum(b.column(b.schema.get_field_index("value"))).as_py()
+    exact = math.fsum(b.column(b.schema.get_field_index("floatvalue")).to_numpy())
+    assert math.isclose(math.fsum(d["sum(floatvalue)"].to_numpy()), exact, rel_tol=REL_TOL)
+    keys = pa.table([c for n_, c in d.items() if n_.startswith("labels.")], names=[n_ for n_ in d if n_.startswith("labels.")])
+    distinct_in = pa.table([b.column(i) for i, n_ in enumerate(b.schema.names) if n_.startswith("labels.")],
+                           names=[n_ for n_ in b.schema.names if n_.startswith("labels.")]).group_by(keys.column_names).aggregate([]).num_rows
+    assert out.num_rows == distinct_in
