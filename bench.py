@@ -34,9 +34,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3], help="BASELINE.json config (2: bench line; 3: multi-predicate)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE.json config (2: bench line; 3: multi-predicate)")
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: 100M at N=1, 125M per GPU at N>1)")
     ap.add_argument("--batch-rows", type=int, default=25_000_000, help="rows per resident record (part)")
+    ap.add_argument("--groups", type=int, default=10_000_000, help="cfg 5: distinct groups")
     ap.add_argument("--rows-per-thread", type=int, default=0, help="0: slot kernel (default); 4/8: sequential kernel")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--per-record-launch", action="store_true", help="one kernel launch per resident record instead of one per scan")
@@ -52,6 +53,9 @@ def query(config):
     if config == 2:
         return (Col("labels.code") == "200", [Sum(Col("value"))], [Col("labels.path")],
                 "labels.code=='200' + SUM(value) GROUP BY labels.path")
+    if config == 5:
+        from frostdb_amd.logicalplan import DynCol
+        return (None, [Sum(Col("value"))], [DynCol("labels")], "SUM(value) GROUP BY all 32 labels.* columns (10 M distinct groups)")
     f = And(Or(Col("labels.code") == "200", Col("labels.code") == "500"), Col("labels.method") == "GET",
             Col("labels.instance") != None)  # noqa: E711
     return (f, [Count(Col("value")), Min(Col("timestamp")), Max(Col("timestamp")), Sum(Col("value"))], [Col("labels.path")],
@@ -112,8 +116,12 @@ def main():
     sizes = [min(args.batch_rows, rows - i * args.batch_rows) for i in range(n_chunks)]
 
     def gen(i):
+        if args.config == 5:
+            return synth.cfg5_chunk(rank, i, sizes[i], n_groups=args.groups)
         return synth.prometheus_chunk(rank, i, sizes[i], row_base=i * args.batch_rows, cfg3=cfg3)
 
+    if args.config == 5:
+        synth.cfg5_chunk(rank, 0, 8, n_groups=args.groups)  # builds the per-group digit tables once, before the thread pool
     resident = []
     exp_sum = exp_cnt = None
     sample_for_cpu = []
@@ -210,11 +218,11 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cfg{args.config if world == 1 else 4}: Prometheus schema, {rows} rows/GPU × {world} GPU, {qdesc}",
-                       "rows_per_gpu": rows, "records_per_gpu": n_chunks, "groups": 1025,
+                       "rows_per_gpu": rows, "records_per_gpu": n_chunks, "groups": args.groups if args.config == 5 else 1025,
                        "parallelism": f"parts sharded over {world} GPU(s); RCCL all-reduce of partial tables" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "scan_slots_kernel" if args.rows_per_thread == 0 else "scan_dense_kernel", "avg_launch_ms": k_ms / max(k_launches, 1),
+                         "kernel": "scan_hash_kernel" if args.config == 5 else "scan_slots_kernel" if args.rows_per_thread == 0 else "scan_dense_kernel", "avg_launch_ms": k_ms / max(k_launches, 1),
                          "algorithmic_bytes_per_launch": k_bytes / max(k_launches, 1),
                          "bytes_per_row": k_bytes / max(rows * args.steps, 1)},
             "cpu_baseline": cpu,

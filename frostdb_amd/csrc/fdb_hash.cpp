@@ -207,32 +207,33 @@ void Plan::fetch_compact_hash(CompactState* cs) {
   unsigned long long* d_n = (unsigned long long*)ctx_->dev_alloc(256);
   hip_check(hipMemsetAsync(d_n, 0, 8, stream_), "hipMemsetAsync");
   hip_check(fdb_launch_hash_compact(h_table_, h_keys_, h_capacity_, ew, kw, d_entries, d_keys, d_n, stream_), "hash compact");
-  std::vector<unsigned long long> entries((size_t)n * oew);
-  std::vector<uint32_t> keys((size_t)n * kw);
-  hip_check(hipMemcpyAsync(entries.data(), d_entries, entries.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(entries)");
-  hip_check(hipMemcpyAsync(keys.data(), d_keys, keys.size() * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(keys)");
+  // pinned staging (cached by the context): pageable destinations would cap the copy at a few GB/s
+  unsigned long long* entries = (unsigned long long*)ctx_->host_alloc((size_t)n * oew * 8);
+  uint32_t* keys = (uint32_t*)ctx_->host_alloc((size_t)n * kw * 4);
+  hip_check(hipMemcpyAsync(entries, d_entries, (size_t)n * oew * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(entries)");
+  hip_check(hipMemcpyAsync(keys, d_keys, (size_t)n * kw * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(keys)");
   sync();
   ctx_->dev_free(d_entries); ctx_->dev_free(d_keys); ctx_->dev_free(d_n);
   cs->cnt.resize(n);
-  for (uint64_t i = 0; i < n; i++) cs->cnt[i] = entries[i * oew];
-  for (size_t j = 0; j < aggs_.size(); j++) {
-    cs->acc[j].resize(n);
-    for (uint64_t i = 0; i < n; i++) cs->acc[j][i] = entries[i * oew + 1 + j];
-  }
+  for (size_t j = 0; j < aggs_.size(); j++) cs->acc[j].resize(n);
   for (size_t c = 0; c < gcols_.size(); c++) {
-    const GroupColState& g = gcols_[c];
-    if (g.kind == 0) {
-      cs->ids[c].resize(n);
-      for (uint64_t i = 0; i < n; i++) cs->ids[c][i] = keys[i * kw + g.word];
-    } else {
-      cs->ivals[c].resize(n); cs->ivalid[c].resize(n);
-      for (uint64_t i = 0; i < n; i++) {
-        const uint64_t vm = (uint64_t)keys[i * kw] | ((uint64_t)keys[i * kw + 1] << 32);
-        cs->ivalid[c][i] = (vm >> c) & 1;
-        cs->ivals[c][i] = (int64_t)((uint64_t)keys[i * kw + g.word] | ((uint64_t)keys[i * kw + g.word + 1] << 32));
-      }
+    if (gcols_[c].kind == 0) cs->ids[c].resize(n);
+    else { cs->ivals[c].resize(n); cs->ivalid[c].resize(n); }
+  }
+  const size_t n_aggs = aggs_.size(), n_cols = gcols_.size();
+  for (uint64_t i = 0; i < n; i++) {  // one pass, row-major over the compacted entries
+    const unsigned long long* e = entries + i * oew;
+    cs->cnt[i] = e[0];
+    for (size_t j = 0; j < n_aggs; j++) cs->acc[j][i] = e[1 + j];
+    const uint32_t* k = keys + i * kw;
+    const uint64_t vm = (uint64_t)k[0] | ((uint64_t)k[1] << 32);
+    for (size_t c = 0; c < n_cols; c++) {
+      const GroupColState& g = gcols_[c];
+      if (g.kind == 0) cs->ids[c][i] = k[g.word];
+      else { cs->ivalid[c][i] = (vm >> c) & 1; cs->ivals[c][i] = (int64_t)((uint64_t)k[g.word] | ((uint64_t)k[g.word + 1] << 32)); }
     }
   }
+  ctx_->host_free(entries); ctx_->host_free(keys);
 }
 
 // ≙ Synchronizer + final stage when either side holds a hash table: the source's occupied groups are re-keyed into

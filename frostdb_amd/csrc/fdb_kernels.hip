@@ -43,6 +43,7 @@ __device__ __forceinline__ const FDB_GLOBAL T* as_global(const T* p) {
 
 template <int R>
 __device__ __forceinline__ void load_u32(const uint32_t* __restrict__ p, uint32_t (&v)[R]) {
+  if (R == 1) { v[0] = __builtin_nontemporal_load(as_global(p)); return; }
 #pragma unroll
   for (int j = 0; j < R / 4; j++) {
     const u32x4 q = __builtin_nontemporal_load(as_global(reinterpret_cast<const u32x4*>(p)) + j);
@@ -52,6 +53,7 @@ __device__ __forceinline__ void load_u32(const uint32_t* __restrict__ p, uint32_
 
 template <int R>
 __device__ __forceinline__ void load_u64(const unsigned long long* __restrict__ p, unsigned long long (&v)[R]) {
+  if (R == 1) { v[0] = __builtin_nontemporal_load(as_global(p)); return; }
 #pragma unroll
   for (int j = 0; j < R / 2; j++) {
     const u64x2 q = __builtin_nontemporal_load(as_global(reinterpret_cast<const u64x2*>(p)) + j);
@@ -63,6 +65,7 @@ __device__ __forceinline__ void load_u64(const unsigned long long* __restrict__ 
 template <int R>
 __device__ __forceinline__ uint32_t load_valid(const uint8_t* __restrict__ bm, int64_t row0) {
   const uint32_t b = as_global(bm)[row0 >> 3];
+  if (R == 1) return (b >> (row0 & 7)) & 1u;
   if (R == 8) return b;
   return (b >> (row0 & 4)) & 0xFu;
 }
@@ -729,12 +732,20 @@ __device__ __forceinline__ unsigned long long fmix64(unsigned long long k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
   return k;
 }
-// Per-column contribution to the 128-bit fingerprint (summed over the non-NULL columns: order independent).
+// Per-column contribution to the 128-bit fingerprint, summed over the non-NULL columns (order independent; a column
+// that appears later leaves older fingerprints unchanged). Multilinear hashing: Σ_c x_c · K_c mod 2^64 with one odd
+// 64-bit constant per column and per half — strongly universal, and one v_mad_u64_u32 pair per half for a 32-bit key
+// id. int64 keys go through fmix64 first. fp_final adds the avalanche.
+__device__ __forceinline__ unsigned long long fp_k1(int gi) { return fmix64(0x9E3779B97F4A7C15ULL * (unsigned long long)(gi + 1)) | 1ull; }
+__device__ __forceinline__ unsigned long long fp_k2(int gi) { return fmix64(0xD6E8FEB86659FD93ULL * (unsigned long long)(gi + 1) + 0x632BE59BD9B4E019ULL) | 1ull; }
+__device__ __forceinline__ void fp_add32(unsigned long long& h1, unsigned long long& h2, unsigned long long k1, unsigned long long k2, uint32_t id) {
+  h1 += (unsigned long long)id * k1;
+  h2 += (unsigned long long)id * k2;
+}
 __device__ __forceinline__ void fp_add(unsigned long long& h1, unsigned long long& h2, int gi, unsigned long long v) {
-  const unsigned long long s1 = fmix64(0x9E3779B97F4A7C15ULL * (unsigned long long)(gi + 1));
-  const unsigned long long s2 = fmix64(0xD6E8FEB86659FD93ULL * (unsigned long long)(gi + 1) + 0x632BE59BD9B4E019ULL);
-  h1 += fmix64(v ^ s1);
-  h2 += fmix64((v + 0x9FB21C651E98DF25ULL) ^ s2);
+  const unsigned long long x = fmix64(v ^ 0x9FB21C651E98DF25ULL) | 1ull;
+  h1 += x * fp_k1(gi);
+  h2 += fmix64(x) * fp_k2(gi);
 }
 __device__ __forceinline__ void fp_final(unsigned long long& h1, unsigned long long& h2) {
   h1 = fmix64(h1 + 0x243F6A8885A308D3ULL); h2 = fmix64(h2 ^ 0xA5A5A5A5A5A5A5A5ULL);
@@ -765,30 +776,14 @@ __device__ __forceinline__ uint64_t hash_find_or_insert(unsigned long long* tabl
   }
 }
 
-// The key tuple of one row (used by the inserting lane only: one row per NEW group).
-__device__ __forceinline__ void hash_write_key(const FdbHashArgs& h, int64_t row, uint32_t* dst) {
-  unsigned long long vmask = 0;
-  for (int c = 0; c < h.n_hcols; c++) {
-    const FdbHashCol& C = h.hcols[c];
-    const bool valid = C.validity == nullptr || ((as_global(C.validity)[row >> 3] >> (row & 7)) & 1);
-    if (C.kind == 0) {
-      const uint32_t id = valid ? as_global(C.lut)[as_global(reinterpret_cast<const uint32_t*>(C.values))[row]] : 0u;
-      dst[C.word] = id;
-      if (id != 0) vmask |= 1ull << C.gi;
-    } else {
-      const unsigned long long v = valid ? as_global(reinterpret_cast<const unsigned long long*>(C.values))[row] : 0ull;
-      dst[C.word] = (uint32_t)v; dst[C.word + 1] = (uint32_t)(v >> 32);
-      if (valid) vmask |= 1ull << C.gi;
-    }
-  }
-  dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);
-}
-
+// One row per lane. While folding the key columns into the fingerprint each lane also parks its key tuple in LDS
+// ([word][lane], conflict-free), so that a lane that turns out to be the FIRST to see its group can write the tuple to
+// the key store without re-reading 32 columns (≈10 % of the rows of cfg 5 create a group).
+#define HASH_UNROLL 8
 __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHashArgs h) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ unsigned int s_new;
-  constexpr int R = 4;
-  constexpr uint32_t FULL = 0xFu;
+  constexpr int R = 1;
   const FdbScanArgs& a = h.base;
   const int tid = threadIdx.x;
   if (tid == 0) s_new = 0;
@@ -804,87 +799,84 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
       for (uint32_t i = tid; i < C.lut_len; i += FDB_HASH_BLOCK) dst[i] = as_global(C.lut)[i];
     }
   }
+  uint32_t* kstage = reinterpret_cast<uint32_t*>(smem + a.lds_lut_bytes);  // [key_words][FDB_HASH_BLOCK]
   __syncthreads();
 
-  const int ew = h.entry_words;
-  const int64_t tile_rows = (int64_t)FDB_HASH_BLOCK * R;
-  const int64_t n_tiles = (h.row_end - h.row_begin + tile_rows - 1) / tile_rows;
+  const int ew = h.entry_words, kw = h.key_words;
+  const int64_t n_tiles = (h.row_end - h.row_begin + FDB_HASH_BLOCK - 1) / FDB_HASH_BLOCK;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row0 = h.row_begin + tile * tile_rows + (int64_t)tid * R;
-    uint32_t sel = 0;
-    if (row0 < h.row_end) {
-      const int64_t left = h.row_end - row0;
-      sel = eval_filter<R>(a, row0, smem) & (left >= R ? FULL : ((1u << (int)left) - 1u));
-    }
-    if (sel == 0) continue;
+    const int64_t row = h.row_begin + tile * FDB_HASH_BLOCK + tid;
+    if (row >= h.row_end) continue;
+    if (a.n_code != 0 && (eval_filter<R>(a, row, smem) & 1u) == 0u) continue;
 
-    unsigned long long h1[R], h2[R];
+    unsigned long long h1 = 0, h2 = 0, vmask = 0;
+    for (int w = 2; w < kw; w++) kstage[w * FDB_HASH_BLOCK + tid] = 0u;  // columns this record does not carry are NULL
+    // Key columns in groups of HASH_UNROLL: the descriptors of a group are fetched together (one scalar-load latency),
+    // then all its index / validity loads are issued together (one HBM latency), then the group is folded in. One
+    // column at a time this loop was a chain of 32 × (descriptor → load → LUT) latencies per row.
+    for (int c0 = 0; c0 < h.n_hcols; c0 += HASH_UNROLL) {
+      const void* vals[HASH_UNROLL]; const uint8_t* vbm[HASH_UNROLL]; const uint32_t* lutg[HASH_UNROLL];
+      uint32_t lds[HASH_UNROLL]; int kind[HASH_UNROLL], word[HASH_UNROLL], gi[HASH_UNROLL];
 #pragma unroll
-    for (int r = 0; r < R; r++) { h1[r] = 0; h2[r] = 0; }
-    for (int c = 0; c < h.n_hcols; c++) {
-      const FdbHashCol& C = h.hcols[c];
-      uint32_t valid = FULL;
-      if (C.validity != nullptr) valid = load_valid<R>(C.validity, row0);
-      if (C.kind == 0) {
-        uint32_t idx[R];
-        load_u32<R>(reinterpret_cast<const uint32_t*>(C.values) + row0, idx);
-        if (C.lut_lds != FDB_NO_LDS) {
-          const uint32_t* lut = reinterpret_cast<const uint32_t*>(smem + C.lut_lds);
+      for (int u = 0; u < HASH_UNROLL; u++) {
+        const FdbHashCol& C = h.hcols[c0 + u < h.n_hcols ? c0 + u : h.n_hcols - 1];
+        vals[u] = C.values; vbm[u] = C.validity; lutg[u] = C.lut; lds[u] = C.lut_lds; kind[u] = c0 + u < h.n_hcols ? C.kind : -1;
+        word[u] = C.word; gi[u] = C.gi;
+      }
+      uint32_t idx[HASH_UNROLL], vb[HASH_UNROLL];
+      unsigned long long wide[HASH_UNROLL];
 #pragma unroll
-          for (int r = 0; r < R; r++) {
-            const uint32_t id = ((valid >> r) & 1u) ? lut[idx[r]] : 0u;
-            if (id != 0) fp_add(h1[r], h2[r], C.gi, id);
-          }
+      for (int u = 0; u < HASH_UNROLL; u++) {
+        idx[u] = 0; vb[u] = 1; wide[u] = 0;
+        if (kind[u] < 0) continue;
+        if (vbm[u] != nullptr) vb[u] = as_global(vbm[u])[row >> 3];
+        if (kind[u] == 0) idx[u] = __builtin_nontemporal_load(as_global(reinterpret_cast<const uint32_t*>(vals[u]) + row));
+        else wide[u] = __builtin_nontemporal_load(as_global(reinterpret_cast<const unsigned long long*>(vals[u]) + row));
+      }
+#pragma unroll
+      for (int u = 0; u < HASH_UNROLL; u++) {
+        if (kind[u] < 0) continue;
+        const bool valid = vbm[u] == nullptr || ((vb[u] >> (row & 7)) & 1u);
+        if (kind[u] == 0) {
+          uint32_t id = 0;
+          if (valid) id = lds[u] != FDB_NO_LDS ? reinterpret_cast<const uint32_t*>(smem + lds[u])[idx[u]] : as_global(lutg[u])[idx[u]];
+          kstage[word[u] * FDB_HASH_BLOCK + tid] = id;
+          fp_add32(h1, h2, fp_k1(gi[u]), fp_k2(gi[u]), id);  // id 0 (NULL) contributes nothing
+          if (id != 0) vmask |= 1ull << gi[u];
         } else {
-#pragma unroll
-          for (int r = 0; r < R; r++) {
-            const uint32_t id = ((valid >> r) & 1u) ? as_global(C.lut)[idx[r]] : 0u;
-            if (id != 0) fp_add(h1[r], h2[r], C.gi, id);
-          }
+          const unsigned long long x = valid ? wide[u] : 0ull;
+          kstage[word[u] * FDB_HASH_BLOCK + tid] = (uint32_t)x;
+          kstage[(word[u] + 1) * FDB_HASH_BLOCK + tid] = (uint32_t)(x >> 32);
+          if (valid) { fp_add(h1, h2, gi[u], x); vmask |= 1ull << gi[u]; }
         }
-      } else {
-        unsigned long long v[R];
-        load_u64<R>(reinterpret_cast<const unsigned long long*>(C.values) + row0, v);
-#pragma unroll
-        for (int r = 0; r < R; r++)
-          if ((valid >> r) & 1u) fp_add(h1[r], h2[r], C.gi, v[r]);
       }
     }
-    uint64_t slot[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      slot[r] = 0;
-      if ((sel >> r) & 1u) {
-        fp_final(h1[r], h2[r]);
-        bool inserted;
-        slot[r] = hash_find_or_insert(h.table, h.mask, ew, h1[r], h2[r], inserted);
-        if (inserted) {
-          hash_write_key(h, row0 + r, h.keys + slot[r] * (uint64_t)h.key_words);
-          atomicAdd(&s_new, 1u);
-        }
-        atomicAdd(h.table + slot[r] * (uint64_t)ew + 2, 1ull);
-      }
+    fp_final(h1, h2);
+    bool inserted;
+    const uint64_t slot = hash_find_or_insert(h.table, h.mask, ew, h1, h2, inserted);
+    if (inserted) {
+      uint32_t* dst = h.keys + slot * (uint64_t)kw;
+      dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);
+      for (int w = 2; w < kw; w++) dst[w] = kstage[w * FDB_HASH_BLOCK + tid];
+      atomicAdd(&s_new, 1u);
     }
+    unsigned long long* e = h.table + slot * (uint64_t)ew;
+    atomicAdd(e + 2, 1ull);
     for (int j = 0; j < a.n_aggs; j++) {
       const FdbAgg& A = a.aggs[j];
       if (A.func == AGG_COUNT) continue;
-      uint32_t valid = FULL;
-      if (A.validity != nullptr) valid = load_valid<R>(A.validity, row0);
+      const bool valid = A.validity == nullptr || load_valid<R>(A.validity, row) != 0u;
       unsigned long long raw[R];
-      load_u64<R>(reinterpret_cast<const unsigned long long*>(A.values) + row0, raw);
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        if (!((sel >> r) & 1u)) continue;
-        const unsigned long long x = ((valid >> r) & 1u) ? raw[r] : 0ull;  // NULL ⇒ the builder's zeroed slot
-        unsigned long long* acc = h.table + slot[r] * (uint64_t)ew + 3 + j;
-        if (A.func == AGG_SUM) {
-          if (A.type == FDB_T_F64) atomicAdd(reinterpret_cast<double*>(acc), __longlong_as_double((long long)x));
-          else atomicAdd(acc, x);
-        } else {
-          const long long key = A.type == FDB_T_F64 ? f64_to_ordered(__longlong_as_double((long long)x)) : (long long)x;
-          if (A.func == AGG_MIN) atomicMin(reinterpret_cast<long long*>(acc), key);
-          else atomicMax(reinterpret_cast<long long*>(acc), key);
-        }
+      load_u64<R>(reinterpret_cast<const unsigned long long*>(A.values) + row, raw);
+      const unsigned long long x = valid ? raw[0] : 0ull;  // NULL ⇒ the builder's zeroed slot
+      unsigned long long* acc = e + 3 + j;
+      if (A.func == AGG_SUM) {
+        if (A.type == FDB_T_F64) atomicAdd(reinterpret_cast<double*>(acc), __longlong_as_double((long long)x));
+        else atomicAdd(acc, x);
+      } else {
+        const long long key = A.type == FDB_T_F64 ? f64_to_ordered(__longlong_as_double((long long)x)) : (long long)x;
+        if (A.func == AGG_MIN) atomicMin(reinterpret_cast<long long*>(acc), key);
+        else atomicMax(reinterpret_cast<long long*>(acc), key);
       }
     }
   }
@@ -950,7 +942,7 @@ __global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
       if (C.kind == 0) {
         uint32_t id = in[C.src_word];
         if (id != 0 && C.lut != nullptr) id = C.lut[id];
-        if (id != 0) { fp_add(h1, h2, C.gi, id); vmask |= 1ull << C.gi; }
+        if (id != 0) { fp_add32(h1, h2, fp_k1(C.gi), fp_k2(C.gi), id); vmask |= 1ull << C.gi; }
       } else {
         const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
         if ((in_mask >> C.lut_len) & 1ull) {  // lut_len carries the SOURCE plan's column index for int64 columns
@@ -1339,10 +1331,14 @@ hipError_t fdb_launch_gather_bits(const uint8_t* src_bitmap, uint8_t* dst_bitmap
 }
 
 hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t lds_bytes, hipStream_t stream) {
-  const int64_t tile_rows = (int64_t)FDB_HASH_BLOCK * 4;
+  const int64_t tile_rows = (int64_t)FDB_HASH_BLOCK;
   const int64_t n_tiles = (args.row_end - args.row_begin + tile_rows - 1) / tile_rows;
   if (n_tiles <= 0) return hipSuccess;
   if (grid_blocks > n_tiles) grid_blocks = (int)n_tiles;
+  lds_bytes = (size_t)args.base.lds_lut_bytes + (size_t)args.key_words * FDB_HASH_BLOCK * 4;  // LUT copies + key staging
+  if (lds_bytes > 48 * 1024)  // (the kernel also has 4 bytes of static LDS: stay below the 160 KiB total)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_hash_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void)hipGetLastError();
   hipLaunchKernelGGL(scan_hash_kernel, dim3(grid_blocks), dim3(FDB_HASH_BLOCK), lds_bytes, stream, args);
   return hipGetLastError();
 }

@@ -77,3 +77,43 @@ def prometheus_batches(shard: int, total_rows: int, batch_rows: int, cfg3: bool 
         yield prometheus_chunk(shard, chunk, n, row_base=done, cfg3=cfg3)
         done += n
         chunk += 1
+
+
+# ---- cfg 5: 32 dynamic label columns, 10 M distinct groups -----------------------------------------------------------
+CFG5_COLS = 32
+CFG5_CARD = 4
+
+
+def _cfg5_tables(n_groups: int):
+    """Per-group label digits: group g ↦ 32 digits in [0, 4); columns 0-11 are the base-4 digits of g (so distinct g give
+    distinct tuples), columns 12-31 a hash of (g, column); ≈3 % of the digits are NULL (a function of (g, column) only)."""
+    g = np.arange(n_groups, dtype=np.uint64)
+    digits = np.empty((CFG5_COLS, n_groups), dtype=np.uint8)
+    nulls = np.empty((CFG5_COLS, n_groups), dtype=bool)
+    for c in range(CFG5_COLS):
+        h = (g + np.uint64(c + 1)) * np.uint64(0x9E3779B97F4A7C15)
+        h ^= h >> np.uint64(29)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(32)
+        digits[c] = ((g >> np.uint64(2 * c)) & np.uint64(3)) if c < 12 else (h & np.uint64(3))
+        nulls[c] = ((h >> np.uint64(8)) % np.uint64(100)) < 3 if c >= 12 else False  # keep the identifying digits non-NULL
+    return digits, nulls
+
+
+_CFG5_CACHE = {}
+
+
+def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000) -> pa.RecordBatch:
+    if n_groups not in _CFG5_CACHE:
+        _CFG5_CACHE[n_groups] = _cfg5_tables(n_groups)
+    digits, nulls = _CFG5_CACHE[n_groups]
+    rng = np.random.Generator(np.random.Philox(key=SEED + 5 + shard, counter=[0, 0, 0, chunk]))
+    gid = rng.integers(0, n_groups, size=rows, dtype=np.int64)
+    arrays, names = [], []
+    for c in range(CFG5_COLS):
+        idx = pa.array(digits[c][gid].astype(np.uint32), type=pa.uint32(), mask=nulls[c][gid] if c >= 12 else None)
+        arrays.append(pa.DictionaryArray.from_arrays(idx, pa.array([b"l%02d=%d" % (c, k) for k in range(CFG5_CARD)], type=pa.binary())))
+        names.append("labels.l%02d" % c)
+    arrays.append(pa.array(rng.random(rows) * 1000.0))
+    names.append("value")
+    return pa.RecordBatch.from_arrays(arrays, names=names)
