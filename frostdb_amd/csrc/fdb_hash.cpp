@@ -236,6 +236,113 @@ void Plan::fetch_compact_hash(CompactState* cs) {
   ctx_->host_free(entries); ctx_->host_free(keys);
 }
 
+// Finish on the device: occupied entries → Arrow-shaped column buffers (dictionary indices, int64 keys, validity bitmaps,
+// aggregate columns) → one device-to-host copy per buffer. Returns the number of groups.
+int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  const uint64_t n = hash_groups();
+  const size_t n_cols = gcols_.size(), n_vals = 1 + aggs_.size();
+  const size_t np = (size_t)((n + 63) & ~(uint64_t)63) + 64;  // padded row count of the scratch buffers
+  // scratch: key buffers (8 B/row each, enough for either kind), validity bytes, value columns, validity bitmaps
+  std::vector<void*> d_key(n_cols), d_bits(n_cols);
+  std::vector<uint8_t*> d_valid(n_cols);
+  std::vector<unsigned long long*> d_vals(n_vals);
+  std::vector<void*> owned;
+  auto alloc = [&](size_t bytes) { void* p = ctx_->dev_alloc(bytes); owned.push_back(p); return p; };
+  for (size_t c = 0; c < n_cols; c++) {
+    d_key[c] = alloc(np * (gcols_[c].kind == 0 ? 4 : 8));
+    d_valid[c] = (uint8_t*)alloc(np);
+    d_bits[c] = alloc(np / 8 + 64);
+  }
+  for (size_t v = 0; v < n_vals; v++) d_vals[v] = (unsigned long long*)alloc(np * 8);
+  unsigned long long* d_n = (unsigned long long*)alloc(256);
+  hip_check(hipMemsetAsync(d_n, 0, 8, stream_), "hipMemsetAsync");
+  std::vector<FdbHashCol> cols(std::max<size_t>(n_cols, 1));
+  for (size_t c = 0; c < n_cols; c++) {
+    std::memset(&cols[c], 0, sizeof(FdbHashCol));
+    cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c;
+  }
+  FdbHashColumnsArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.table = h_table_; a.keys = h_keys_; a.capacity = h_capacity_;
+  a.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
+  a.out_key = (void* const*)upload(d_key.data(), std::max<size_t>(n_cols, 1) * sizeof(void*));
+  a.out_valid = (uint8_t* const*)upload(d_valid.data(), std::max<size_t>(n_cols, 1) * sizeof(void*));
+  a.out_vals = (unsigned long long* const*)upload(d_vals.data(), n_vals * sizeof(void*));
+  a.n_out = d_n;
+  a.n_cols = (int)n_cols; a.entry_words = h_entry_words_; a.key_words = h_key_words_; a.n_vals = (int)n_vals;
+  if (n > 0) {
+    hip_check(fdb_launch_hash_columns(a, stream_), "hash columns");
+    for (size_t c = 0; c < n_cols; c++) hip_check(fdb_launch_pack_bits(d_valid[c], (uint8_t*)d_bits[c], (int64_t)n, stream_), "pack bits");
+  }
+  // host buffers
+  out->clear();
+  for (size_t c = 0; c < n_cols; c++) {
+    const GroupColState& g = gcols_[c];
+    OutColumn oc;
+    oc.name = g.name;
+    oc.length = (int64_t)n;
+    const size_t w = g.kind == 0 ? 4 : 8;
+    oc.format = g.kind == 0 ? "I" : "l";
+    oc.values.resize((size_t)n * w);
+    oc.validity.resize((size_t)(n + 7) / 8);
+    if (n > 0) {
+      hip_check(hipMemcpyAsync(oc.values.data(), d_key[c], (size_t)n * w, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(key column)");
+      hip_check(hipMemcpyAsync(oc.validity.data(), d_bits[c], oc.validity.size(), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(validity)");
+    }
+    if (g.kind == 0) {
+      oc.is_dict = true;
+      oc.dict_format = g.value_format;
+      oc.dict_offsets.resize(g.values.size() + 1);
+      int32_t off = 0;
+      for (size_t v = 0; v < g.values.size(); v++) {
+        oc.dict_offsets[v] = off;
+        oc.dict_data.insert(oc.dict_data.end(), g.values[v].begin(), g.values[v].end());
+        off += (int32_t)g.values[v].size();
+      }
+      oc.dict_offsets[g.values.size()] = off;
+    }
+    out->push_back(std::move(oc));
+  }
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    const AggState& A = aggs_[j];
+    OutColumn oc;
+    oc.name = A.result_name;
+    oc.length = (int64_t)n;
+    const bool count_from_cnt = A.func == FDB_AGG_COUNT && !final_stage_;
+    const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
+    oc.format = is_f64 ? "g" : "l";
+    oc.values.resize((size_t)n * 8);
+    if (n > 0)
+      hip_check(hipMemcpyAsync(oc.values.data(), d_vals[count_from_cnt ? 0 : 1 + j], (size_t)n * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(agg column)");
+    out->push_back(std::move(oc));
+  }
+  sync();
+  for (void* p : owned) ctx_->dev_free(p);
+  // post-processing that needs the data on the host: NULL counts, float64 MIN/MAX key decoding
+  for (size_t c = 0; c < n_cols; c++) {
+    OutColumn& oc = (*out)[c];
+    int64_t set = 0;
+    const uint64_t* w64 = (const uint64_t*)oc.validity.data();
+    const size_t full = oc.validity.size() / 8;
+    for (size_t i = 0; i < full; i++) set += __builtin_popcountll(w64[i]);
+    for (size_t i = full * 8; i < oc.validity.size(); i++) set += __builtin_popcount(oc.validity[i]);
+    oc.null_count = (int64_t)n - set;
+  }
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    const AggState& A = aggs_[j];
+    if (A.type == FDB_T_F64 && (A.func == FDB_AGG_MIN || A.func == FDB_AGG_MAX)) {
+      OutColumn& oc = (*out)[n_cols + j];
+      for (uint64_t i = 0; i < n; i++) {
+        int64_t k; std::memcpy(&k, oc.values.data() + i * 8, 8);
+        const double d = fdb_ordered_to_f64_host(k);
+        std::memcpy(oc.values.data() + i * 8, &d, 8);
+      }
+    }
+  }
+  return (int64_t)n;
+}
+
 // ≙ Synchronizer + final stage when either side holds a hash table: the source's occupied groups are re-keyed into
 // this plan's key ids on the device (per-column translation LUTs) and merged with atomics.
 void Plan::merge_hash(Plan& src) {

@@ -162,6 +162,20 @@ hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uin
 // *n_out = number of entries. Order is arbitrary.
 hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int entry_words, int key_words,
                                    unsigned long long* out_entries, uint32_t* out_keys, unsigned long long* n_out, hipStream_t stream);
+// Finish for big tables: the occupied entries go straight into Arrow-shaped COLUMN buffers on the device (uint32 dictionary
+// indices = key id - 1, int64 key values, one validity BYTE per row and column, count and accumulator columns), so the
+// host only copies finished buffers. cols[c].word/kind/gi describe the key tuple; out_key[c] points to the column's value
+// buffer (4 or 8 bytes per row), out_valid[c] to its validity bytes. out_vals[0] = counts, out_vals[1 + j] = accumulator j.
+struct FdbHashColumnsArgs {
+  const unsigned long long* table; const uint32_t* keys; uint64_t capacity;
+  const FdbHashCol* cols; void* const* out_key; uint8_t* const* out_valid; unsigned long long* const* out_vals;
+  unsigned long long* n_out;
+  int32_t n_cols, entry_words, key_words, n_vals;
+};
+hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, hipStream_t stream);
+// bits[i / 8] bit (i % 8) = bytes[i] != 0, for i < n (n rounded up to 8 inside; bytes must be readable up to the rounding).
+hipError_t fdb_launch_pack_bits(const uint8_t* bytes, uint8_t* bits, int64_t n, hipStream_t stream);
+
 // Inserts / merges `n` pre-aggregated entries (hash_compact's layout: {count, acc…} per entry + key tuples of
 // `in_key_words` words) into the table. cols[c] describes destination column c: where its words sit in the incoming
 // tuple (src_word), and a LUT translating incoming dictionary key ids. funcs[j]: 1 add u64, 2 add f64, 3 min i64, 4 max i64, 0 skip.

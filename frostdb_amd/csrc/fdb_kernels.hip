@@ -928,6 +928,47 @@ __global__ void hash_compact_kernel(const unsigned long long* table, const uint3
   }
 }
 
+__global__ void hash_columns_kernel(const FdbHashColumnsArgs a) {
+  const uint64_t n_round = (a.capacity + 63) & ~(uint64_t)63;
+  const int ew = a.entry_words, kw = a.key_words;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
+    const bool occ = i < a.capacity && a.table[i * (uint64_t)ew] != 0ull;
+    const unsigned long long m = __ballot(occ);
+    if (m == 0ull) continue;
+    unsigned long long base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) base = atomicAdd(a.n_out, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (!occ) continue;
+    const uint64_t o = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    const unsigned long long* e = a.table + i * (uint64_t)ew;
+    for (int v = 0; v < a.n_vals; v++) a.out_vals[v][o] = e[2 + v];
+    const uint32_t* k = a.keys + i * (uint64_t)kw;
+    const unsigned long long vm = (unsigned long long)k[0] | ((unsigned long long)k[1] << 32);
+    for (int c = 0; c < a.n_cols; c++) {
+      const FdbHashCol& C = a.cols[c];
+      if (C.kind == 0) {
+        const uint32_t id = k[C.word];
+        reinterpret_cast<uint32_t*>(a.out_key[c])[o] = id ? id - 1u : 0u;
+        a.out_valid[c][o] = id != 0u;
+      } else {
+        const bool ok = (vm >> C.gi) & 1ull;
+        reinterpret_cast<unsigned long long*>(a.out_key[c])[o] = ok ? ((unsigned long long)k[C.word] | ((unsigned long long)k[C.word + 1] << 32)) : 0ull;
+        a.out_valid[c][o] = ok;
+      }
+    }
+  }
+}
+
+__global__ void pack_bits_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bits, int64_t n_bytes_out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes_out; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int64_t r = i * 8 + k; if (r < n && bytes[r]) b |= 1u << k; }
+    bits[i] = (uint8_t)b;
+  }
+}
+
 __global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
   __shared__ unsigned int s_new;
   if (threadIdx.x == 0) s_new = 0;
@@ -1372,5 +1413,19 @@ hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t strea
   int blocks = (int)((args.n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(hash_merge_kernel, dim3(blocks), dim3(256), 0, stream, args);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, hipStream_t stream) {
+  hipLaunchKernelGGL(hash_columns_kernel, dim3(4096), dim3(256), 0, stream, args);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_pack_bits(const uint8_t* bytes, uint8_t* bits, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const int64_t nb = (n + 7) / 8;
+  int blocks = (int)((nb + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_bits_kernel, dim3(blocks), dim3(256), 0, stream, bytes, bits, nb, n);
   return hipGetLastError();
 }

@@ -1066,6 +1066,17 @@ void Plan::build_agg_columns(const CompactState& cs, std::vector<OutColumn>* col
 
 void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
   PhaseTimer pt;
+  if (mode_ == TableMode::HASH && h_table_ != nullptr) {
+    // big result sets: columns are materialised on the device, the host only copies finished Arrow buffers
+    std::vector<OutColumn> cols;
+    const int64_t n = finish_columns_hash(&cols);
+    pt.mark("finish: columns");
+    if (n_rows) *n_rows = n;
+    export_record(std::move(cols), n, out, out_schema);
+    pt.mark("finish: export");
+    finished_ = true;
+    return;
+  }
   CompactState cs;
   fetch_compact(&cs);
   pt.mark("finish: fetch");

@@ -167,6 +167,7 @@ class Plan {
   void hash_reserve(uint64_t extra_groups);             // capacity ≥ 2 × (groups + extra): grow + rehash on the device
   void push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live);
   void fetch_compact_hash(CompactState* cs);
+  int64_t finish_columns_hash(std::vector<OutColumn>* cols);  // device-side column materialisation (big result sets)
   void merge_hash(Plan& src);
   uint64_t hash_groups();                               // occupied slots (reads the device counter; waits for the stream)
   void hash_insert_entries(const std::vector<unsigned long long>& entries, const std::vector<uint32_t>& keys, int64_t n, int in_kw,
