@@ -104,7 +104,7 @@ def main():
         dist.barrier()
     from frostdb_amd import physicalplan as pp
     from frostdb_amd import synth
-    from frostdb_amd.distributed import merge_plan
+    from frostdb_amd.distributed import layout_probe, merge_plan
 
     rows = args.rows or (100_000_000 if world == 1 else 125_000_000)
     cfg3 = args.config == 3
@@ -150,7 +150,11 @@ def main():
                 plan.Callback(rb)
         else:
             plan.CallbackResident(resident)
-        out = merge_plan(plan) if (world > 1 or args.force_merge) else plan.Finish()
+        if world > 1 or args.force_merge:
+            probe = layout_probe(plan, torch.device("cuda", local_rank))  # overlaps with the scan kernel
+            out = merge_plan(plan, probe=probe)
+        else:
+            out = plan.Finish()
         st = plan.stats() if timing else None
         plan.Close()
         return out, st

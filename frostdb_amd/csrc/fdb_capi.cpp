@@ -122,6 +122,11 @@ int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slo
   return guard(plan, [&] { *signature = plan->plan.state_signature(n_slots); });
 }
 
+int fdb_plan_state_pointers(fdb_plan* plan, void** base, int64_t* array_stride, int64_t* n_slots) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.state_pointers(base, array_stride, n_slots); });
+}
+
 int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes) {
   if (!plan) return FDB_ERR_INVALID;
   return guard(plan, [&] { plan->plan.state_read(array, dst, capacity_bytes); });

@@ -1139,6 +1139,13 @@ uint64_t Plan::state_signature(int64_t* n_slots_out) {
   return h;
 }
 
+void Plan::state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) const {
+  const bool ok = mode_ == TableMode::DENSE && d_state_ != nullptr;
+  *base = ok ? (void*)d_state_ : nullptr;
+  *array_stride = ok ? (int64_t)slots_alloc_ : 0;
+  *n_slots = ok ? (int64_t)n_slots_ : 0;
+}
+
 void Plan::state_read(int32_t array, void* dst, int64_t capacity_bytes) {
   if (mode_ != TableMode::DENSE) throw Error(FDB_ERR_STATE, "raw table access needs the dense table");
   if (array < 0 || array > (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "table array index out of range");

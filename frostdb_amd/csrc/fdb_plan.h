@@ -136,6 +136,7 @@ class Plan {
   char agg_format(int32_t agg) const;
   uint64_t state_signature(int64_t* n_slots);
   void state_read(int32_t array, void* dst, int64_t capacity_bytes);
+  void state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) const;
   void state_write(int32_t array, const void* src, int64_t bytes);
 
   std::string error;

@@ -116,50 +116,65 @@ def merge_partials(keys: pa.RecordBatch, partials: Sequence[torch.Tensor], aggs:
     return pa.RecordBatch.from_arrays(arrays, names=out_names)
 
 
-def merge_plan_aligned(plan, group=None, dst: int = 0, device: Optional[torch.device] = None):
-    """Fast path: if every rank's table has the same slot layout (checked with ONE tiny all-reduce of the layout
-    signature), the raw table arrays are all-reduced in place — SUM for counts and sums, integer MIN/MAX for
-    MIN/MAX (float64 MIN/MAX live as order-preserving int64 keys) — written back, and rank `dst` simply finishes its
-    plan. No key exchange, no host round trip: (2 + #aggregations) small RCCL collectives.
-    Returns (True, record-or-None) or (False, None) when layouts differ (caller falls back to merge_plan)."""
-    if device is None:
-        device = torch.device("cuda", plan.device)
+class _DeviceArray:
+    """Zero-copy view of plan-owned device memory for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def layout_probe(plan, device: torch.device, group=None) -> torch.Tensor:
+    """Starts the ONE tiny all-reduce that tells whether every rank's table has the same slot layout. Issue it right
+    after the scan has been launched: it runs on torch's stream, next to the scan kernel, so its latency is hidden."""
     sig, n_slots = plan.state_signature()
     s = sig & ((1 << 62) - 1)  # keep it a positive int64
     probe = torch.tensor([s, -s, n_slots, -n_slots], dtype=torch.int64, device=device)
     dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+    return probe
+
+
+def merge_plan_aligned(plan, group=None, dst: int = 0, device: Optional[torch.device] = None, probe: Optional[torch.Tensor] = None):
+    """Fast path of the cross-GPU merge. If every rank's table has the same slot layout (`layout_probe`), slot i means
+    the same group everywhere and the table arrays are all-reduced IN PLACE, on the plan's own stream, through zero-copy
+    tensor views of the plan's device memory: SUM for counts and sums, integer MIN/MAX for MIN/MAX (float64 MIN/MAX live
+    as order-preserving int64 keys, so the integer reduction is exact). No key exchange, no copies, no host
+    synchronisation besides the one Finish does anyway. Returns (True, record-or-None), or (False, None) when layouts
+    differ (the caller falls back to key unification)."""
+    if device is None:
+        device = torch.device("cuda", plan.device)
+    if probe is None:
+        probe = layout_probe(plan, device, group)
     mx, nmn, ns, nns = (int(x) for x in probe.tolist())
     if mx != -nmn or ns != -nns or ns == 0:
         return False, None
-    n_arrays = 1 + len(plan.aggs)
-    buf = torch.empty((n_arrays, n_slots), dtype=torch.int64, device=device)
-    for a in range(n_arrays):
-        plan.state_read(a, buf[a].data_ptr(), n_slots * 8)
-    for a in range(n_arrays):
-        if a == 0:
-            dist.all_reduce(buf[0], op=dist.ReduceOp.SUM, group=group)
-            continue
-        agg = plan.aggs[a - 1]
-        if agg.func == AGG_COUNT:
-            continue  # served by the count array
-        if agg.func == AGG_SUM and plan.agg_format(a - 1) == "g":
-            dist.all_reduce(buf[a].view(torch.float64), op=dist.ReduceOp.SUM, group=group)
-        else:
-            op = dist.ReduceOp.MIN if agg.func == AGG_MIN else dist.ReduceOp.MAX if agg.func == AGG_MAX else dist.ReduceOp.SUM
-            dist.all_reduce(buf[a], op=op, group=group)
+    base, stride, n_slots = plan.state_pointers()
+    ext = torch.cuda.ExternalStream(plan.stream_ptr(), device=device)
+    with torch.cuda.stream(ext):  # ordered after the scan and the fold kernel; Finish then waits for this stream
+        for a in range(1 + len(plan.aggs)):
+            ptr = base + a * stride * 8
+            if a == 0:
+                dist.all_reduce(torch.as_tensor(_DeviceArray(ptr, n_slots, "<i8"), device=device), op=dist.ReduceOp.SUM, group=group)
+                continue
+            agg = plan.aggs[a - 1]
+            if agg.func == AGG_COUNT:
+                continue  # served by the count array
+            if agg.func == AGG_SUM and plan.agg_format(a - 1) == "g":
+                dist.all_reduce(torch.as_tensor(_DeviceArray(ptr, n_slots, "<f8"), device=device), op=dist.ReduceOp.SUM, group=group)
+            else:
+                op = dist.ReduceOp.MIN if agg.func == AGG_MIN else dist.ReduceOp.MAX if agg.func == AGG_MAX else dist.ReduceOp.SUM
+                dist.all_reduce(torch.as_tensor(_DeviceArray(ptr, n_slots, "<i8"), device=device), op=op, group=group)
     if dist.get_rank(group) != dst:
+        ext.synchronize()  # the plan is about to be closed: its memory must outlive the collectives
         return True, None
-    torch.cuda.current_stream(device).synchronize() if device.type == "cuda" else None
-    for a in range(n_arrays):
-        plan.state_write(a, buf[a].data_ptr(), n_slots * 8)
     return True, plan.Finish()
 
 
-def merge_plan(plan, group=None, dst: int = 0, device: Optional[torch.device] = None) -> Optional[pa.RecordBatch]:
+def merge_plan(plan, group=None, dst: int = 0, device: Optional[torch.device] = None,
+               probe: Optional[torch.Tensor] = None) -> Optional[pa.RecordBatch]:
     """Merges a HashAggregatePlan's partial table across the process group: the aligned-layout fast path when all
     ranks agree on the slot layout, otherwise key unification (device-to-device copies through the C ABI:
     fdb_plan_partial_state, then merge_partials)."""
-    ok, rec = merge_plan_aligned(plan, group=group, dst=dst, device=device)
+    ok, rec = merge_plan_aligned(plan, group=group, dst=dst, device=device, probe=probe)
     if ok:
         return rec
     keys = plan.partial_keys()

@@ -70,6 +70,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_partial_state.argtypes = [vp, i32, vp, i64]
     L.fdb_plan_agg_type.argtypes = [vp, i32, ctypes.c_char_p]
     L.fdb_plan_state_signature.argtypes = [vp, P(ctypes.c_uint64), P(i64)]
+    L.fdb_plan_state_pointers.argtypes = [vp, P(vp), P(i64), P(i64)]
     L.fdb_plan_state_read.argtypes = [vp, i32, vp, i64]
     L.fdb_plan_state_write.argtypes = [vp, i32, vp, i64]
     L.fdb_batch_import.argtypes = [vp, vp, ctypes.c_int, P(vp)]
@@ -234,6 +235,17 @@ class HashAggregatePlan:
         sig, n = ctypes.c_uint64(), ctypes.c_int64()
         self._check(lib().fdb_plan_state_signature(self.handle, ctypes.byref(sig), ctypes.byref(n)))
         return sig.value, n.value
+
+    def state_pointers(self):
+        """(device address of array 0, stride between arrays in elements, n_slots) — zero-copy view of the dense table."""
+        base, stride, n = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(lib().fdb_plan_state_pointers(self.handle, ctypes.byref(base), ctypes.byref(stride), ctypes.byref(n)))
+        return base.value or 0, stride.value, n.value
+
+    def stream_ptr(self) -> int:
+        s = ctypes.c_void_p()
+        self._check(lib().fdb_plan_stream(self.handle, ctypes.byref(s)))
+        return s.value or 0
 
     def state_read(self, array: int, dst_ptr: int, capacity_bytes: int) -> None:
         self._check(lib().fdb_plan_state_read(self.handle, array, dst_ptr, capacity_bytes))

@@ -195,6 +195,10 @@ int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slo
 /* Raw table array `array` (0: selected-row counts; 1 + j: accumulator of aggregation j) ⇄ `dst`/`src`, a DEVICE
  * pointer of n_slots × 8 bytes. int64 everywhere except float64 SUM; float64 MIN/MAX are stored as order-preserving
  * int64 keys, so integer MIN/MAX reductions are exact for them too. Both calls wait for the plan's stream. */
+/* Zero-copy variant: the device address of array 0, the distance between consecutive arrays (in 8-byte elements) and
+ * the slot count, so that a collective library can reduce the arrays IN PLACE on the plan's stream (fdb_plan_stream);
+ * nothing is synchronised. Dense tables only (n_slots = 0 otherwise). */
+int fdb_plan_state_pointers(fdb_plan* plan, void** base, int64_t* array_stride, int64_t* n_slots);
 int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes);
 int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t bytes);
 /* 'l' (int64) or 'g' (float64): the Arrow format of aggregation `agg`'s output column; 0 until the first push. */
