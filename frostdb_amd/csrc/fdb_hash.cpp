@@ -121,6 +121,7 @@ void Plan::switch_to_hash() {
     for (size_t c = 0; c < gcols_.size(); c++) {
       std::memset(&cols[c], 0, sizeof(FdbHashCol));
       cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c; cols[c].lut_lds = FDB_NO_LDS;
+      cols[c].k1 = fdb_fp_k1((int)c); cols[c].k2 = fdb_fp_k2((int)c);
       cols[c].src_word = gcols_[c].kind == 0 ? (int)(2 + c) : -1;  // a dense table never held int64 key columns
     }
     // COUNT accumulators of a dense table live in its count array: carry them as counts (funcs → skip) — the entry's
@@ -153,6 +154,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       std::memset(&C, 0, sizeof(C));
       C.values = c.d_values; C.validity = c.d_validity; C.kind = gr.kind; C.gi = gr.gi; C.word = gcols_[(size_t)gr.gi].word;
       C.lut_lds = FDB_NO_LDS; C.src_word = -1;
+      C.k1 = fdb_fp_k1(gr.gi); C.k2 = fdb_fp_k2(gr.gi);
       if (gr.kind == 0) { C.lut_len = (uint32_t)gr.lut->size(); lut_off[g] = R.blob.add(gr.lut->data(), gr.lut->size() * 4); }
     }
     unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
@@ -401,6 +403,7 @@ void Plan::merge_hash(Plan& src) {
   for (size_t c = 0; c < gcols_.size(); c++) {
     std::memset(&cols[c], 0, sizeof(FdbHashCol));
     cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c; cols[c].src_word = -1; cols[c].lut_lds = FDB_NO_LDS;
+    cols[c].k1 = fdb_fp_k1((int)c); cols[c].k2 = fdb_fp_k2((int)c);
   }
   for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
     FdbHashCol& C = cols[(size_t)dst_of[sc]];

@@ -129,7 +129,18 @@ struct FdbHashCol {
   int32_t word;             // first word of this column inside the key tuple
   int32_t gi;               // plan-level group column index (fingerprint salt, valid-mask bit)
   int32_t src_word;         // merge: first word of this column inside the INCOMING key tuple (-1: absent ⇒ NULL)
+  unsigned long long k1;    // fdb_fp_k1(gi), fdb_fp_k2(gi): this column's multipliers of the multilinear fingerprint,
+  unsigned long long k2;    // computed once on the host (recomputing them per row cost ≈1 000 scalar instructions per wave tile)
 };
+
+static inline unsigned long long fdb_fmix64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return k;
+}
+static inline unsigned long long fdb_fp_k1(int gi) { return fdb_fmix64(0x9E3779B97F4A7C15ULL * (unsigned long long)(gi + 1)) | 1ull; }
+static inline unsigned long long fdb_fp_k2(int gi) {
+  return fdb_fmix64(0xD6E8FEB86659FD93ULL * (unsigned long long)(gi + 1) + 0x632BE59BD9B4E019ULL) | 1ull;
+}
 
 // Table entry = entry_words × 8 bytes: [fingerprint lo (0 = empty) | fingerprint hi | selected-row count | acc 0 … ]
 // padded to a multiple of 32 bytes so that probe, count and accumulators of a group share one 64-byte sector.

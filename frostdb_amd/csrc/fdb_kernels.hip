@@ -736,16 +736,14 @@ __device__ __forceinline__ unsigned long long fmix64(unsigned long long k) {
 // that appears later leaves older fingerprints unchanged). Multilinear hashing: Σ_c x_c · K_c mod 2^64 with one odd
 // 64-bit constant per column and per half — strongly universal, and one v_mad_u64_u32 pair per half for a 32-bit key
 // id. int64 keys go through fmix64 first. fp_final adds the avalanche.
-__device__ __forceinline__ unsigned long long fp_k1(int gi) { return fmix64(0x9E3779B97F4A7C15ULL * (unsigned long long)(gi + 1)) | 1ull; }
-__device__ __forceinline__ unsigned long long fp_k2(int gi) { return fmix64(0xD6E8FEB86659FD93ULL * (unsigned long long)(gi + 1) + 0x632BE59BD9B4E019ULL) | 1ull; }
 __device__ __forceinline__ void fp_add32(unsigned long long& h1, unsigned long long& h2, unsigned long long k1, unsigned long long k2, uint32_t id) {
   h1 += (unsigned long long)id * k1;
   h2 += (unsigned long long)id * k2;
 }
-__device__ __forceinline__ void fp_add(unsigned long long& h1, unsigned long long& h2, int gi, unsigned long long v) {
+__device__ __forceinline__ void fp_add(unsigned long long& h1, unsigned long long& h2, unsigned long long k1, unsigned long long k2, unsigned long long v) {
   const unsigned long long x = fmix64(v ^ 0x9FB21C651E98DF25ULL) | 1ull;
-  h1 += x * fp_k1(gi);
-  h2 += fmix64(x) * fp_k2(gi);
+  h1 += x * k1;
+  h2 += fmix64(x) * k2;
 }
 __device__ __forceinline__ void fp_final(unsigned long long& h1, unsigned long long& h2) {
   h1 = fmix64(h1 + 0x243F6A8885A308D3ULL); h2 = fmix64(h2 ^ 0xA5A5A5A5A5A5A5A5ULL);
@@ -817,11 +815,12 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
     for (int c0 = 0; c0 < h.n_hcols; c0 += HASH_UNROLL) {
       const void* vals[HASH_UNROLL]; const uint8_t* vbm[HASH_UNROLL]; const uint32_t* lutg[HASH_UNROLL];
       uint32_t lds[HASH_UNROLL]; int kind[HASH_UNROLL], word[HASH_UNROLL], gi[HASH_UNROLL];
+      unsigned long long k1[HASH_UNROLL], k2[HASH_UNROLL];
 #pragma unroll
       for (int u = 0; u < HASH_UNROLL; u++) {
         const FdbHashCol& C = h.hcols[c0 + u < h.n_hcols ? c0 + u : h.n_hcols - 1];
         vals[u] = C.values; vbm[u] = C.validity; lutg[u] = C.lut; lds[u] = C.lut_lds; kind[u] = c0 + u < h.n_hcols ? C.kind : -1;
-        word[u] = C.word; gi[u] = C.gi;
+        word[u] = C.word; gi[u] = C.gi; k1[u] = C.k1; k2[u] = C.k2;
       }
       uint32_t idx[HASH_UNROLL], vb[HASH_UNROLL];
       unsigned long long wide[HASH_UNROLL];
@@ -841,13 +840,13 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
           uint32_t id = 0;
           if (valid) id = lds[u] != FDB_NO_LDS ? reinterpret_cast<const uint32_t*>(smem + lds[u])[idx[u]] : as_global(lutg[u])[idx[u]];
           kstage[word[u] * FDB_HASH_BLOCK + tid] = id;
-          fp_add32(h1, h2, fp_k1(gi[u]), fp_k2(gi[u]), id);  // id 0 (NULL) contributes nothing
+          fp_add32(h1, h2, k1[u], k2[u], id);  // id 0 (NULL) contributes nothing
           if (id != 0) vmask |= 1ull << gi[u];
         } else {
           const unsigned long long x = valid ? wide[u] : 0ull;
           kstage[word[u] * FDB_HASH_BLOCK + tid] = (uint32_t)x;
           kstage[(word[u] + 1) * FDB_HASH_BLOCK + tid] = (uint32_t)(x >> 32);
-          if (valid) { fp_add(h1, h2, gi[u], x); vmask |= 1ull << gi[u]; }
+          if (valid) { fp_add(h1, h2, k1[u], k2[u], x); vmask |= 1ull << gi[u]; }
         }
       }
     }
@@ -983,12 +982,12 @@ __global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
       if (C.kind == 0) {
         uint32_t id = in[C.src_word];
         if (id != 0 && C.lut != nullptr) id = C.lut[id];
-        if (id != 0) { fp_add32(h1, h2, fp_k1(C.gi), fp_k2(C.gi), id); vmask |= 1ull << C.gi; }
+        if (id != 0) { fp_add32(h1, h2, C.k1, C.k2, id); vmask |= 1ull << C.gi; }
       } else {
         const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
         if ((in_mask >> C.lut_len) & 1ull) {  // lut_len carries the SOURCE plan's column index for int64 columns
           const unsigned long long v = (unsigned long long)in[C.src_word] | ((unsigned long long)in[C.src_word + 1] << 32);
-          fp_add(h1, h2, C.gi, v);
+          fp_add(h1, h2, C.k1, C.k2, v);
           vmask |= 1ull << C.gi;
         }
       }
