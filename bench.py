@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--groups", type=int, default=10_000_000, help="cfg 5: distinct groups")
     ap.add_argument("--rows-per-thread", type=int, default=0, help="0: slot kernel (default); 4/8: sequential kernel")
     ap.add_argument("--grid", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant: 0 default (run-time specialised, 512 threads), 2: 256 threads, 3: 1024 threads, 4: interpreting kernel only")
     ap.add_argument("--per-record-launch", action="store_true", help="one kernel launch per resident record instead of one per scan")
     ap.add_argument("--force-merge", action="store_true", help="run the RCCL merge path even with one rank (functional check on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,7 +145,7 @@ def main():
         if tuning:
             plan.set_tuning(*tuning)
         else:
-            plan.set_tuning(args.rows_per_thread, args.grid)
+            plan.set_tuning(args.rows_per_thread, args.grid | (args.variant << 25))
         if args.per_record_launch:
             for rb in resident:
                 plan.Callback(rb)
@@ -156,6 +157,8 @@ def main():
         else:
             out = plan.Finish()
         st = plan.stats() if timing else None
+        if st is not None:
+            st["kernel"] = plan.last_kernel()
         plan.Close()
         return out, st
 
@@ -198,6 +201,7 @@ def main():
     for _ in range(args.steps):
         _, st = step(timing=True)
         k_ms += st["kernel_ms"]; k_bytes += st["algorithmic_bytes"]; k_launches += st["launches"]
+        kernel_name = st["kernel"]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -226,7 +230,7 @@ def main():
                        "parallelism": f"parts sharded over {world} GPU(s); RCCL all-reduce of partial tables" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "scan_hash_kernel" if args.config == 5 else "scan_slots_kernel" if args.rows_per_thread == 0 else "scan_dense_kernel", "avg_launch_ms": k_ms / max(k_launches, 1),
+                         "kernel": kernel_name, "avg_launch_ms": k_ms / max(k_launches, 1),
                          "algorithmic_bytes_per_launch": k_bytes / max(k_launches, 1),
                          "bytes_per_row": k_bytes / max(rows * args.steps, 1)},
             "cpu_baseline": cpu,

@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfrostdb_amd.so")
-SOURCES = ["fdb_kernels.hip", "fdb_arrow.cpp", "fdb_context.cpp", "fdb_plan.cpp", "fdb_hash.cpp", "fdb_capi.cpp"]
-HEADERS = ["fdb_kernels.h", "fdb_arrow.h", "fdb_context.h", "fdb_plan.h", "fdb_plan_internal.h", "../../include/frostdb_amd.h", "../../include/arrow_c_data.h"]
+SOURCES = ["fdb_kernels.hip", "fdb_arrow.cpp", "fdb_context.cpp", "fdb_plan.cpp", "fdb_hash.cpp", "fdb_jit.cpp", "fdb_capi.cpp"]
+HEADERS = ["fdb_kernels.h", "fdb_arrow.h", "fdb_context.h", "fdb_plan.h", "fdb_plan_internal.h", "fdb_jit.h", "../../include/frostdb_amd.h", "../../include/arrow_c_data.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-result"]
 
 
@@ -28,6 +28,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # the argument-block header, embedded as a string for the run-time (hiprtc) compiled plan kernels
+    with open(os.path.join(CSRC, "fdb_kernels.h")) as f:
+        text = f.read()
+    assert ')FDBH"' not in text
+    inc = os.path.join(CSRC, "fdb_kernels_h.inc")
+    new = 'R"FDBH(' + text + ')FDBH"\n'
+    if not os.path.exists(inc) or open(inc).read() != new:
+        with open(inc, "w") as f:
+            f.write(new)
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
@@ -36,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhiprtc"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -188,4 +188,6 @@ int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_bl
   return FDB_OK;
 }
 
+const char* fdb_plan_last_kernel(fdb_plan* plan) { return plan ? plan->plan.last_kernel() : ""; }
+
 }  // extern "C"

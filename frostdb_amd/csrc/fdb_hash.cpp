@@ -187,6 +187,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
       hip_check(fdb_launch_scan_hash(h, grid, a.lds_lut_bytes, stream_), "hash scan launch");
+      last_kernel_ = "scan_hash_kernel";
       if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
       h_groups_bound_ += (uint64_t)(r1 - r0);
       state_dirty_ = true;

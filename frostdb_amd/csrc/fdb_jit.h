@@ -1,0 +1,46 @@
+// fdb_jit.h — plan-specialised scan kernels (fdb_jit.cpp).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fdb_kernels.h"
+
+namespace fdb {
+
+struct JitSlot { bool has_values = false; int has_validity = 0; };  // has_validity: 0 no record has a bitmap, 1 every record, 2 some (checked per record)
+struct JitLeaf { int kind = 0, slot = -1, wide = 0, op = 0; bool lut_in_lds = false; };
+struct JitGroup { int slot = -1; bool lut_in_lds = false; };
+struct JitAgg { int func = 0, type = 0, slot = -1; };
+
+// Everything that changes the generated CODE. Pointers, literals, truth-table bits, LUT offsets, strides and row counts
+// are run-time arguments and deliberately absent, so that queries of the same shape share one compiled kernel.
+struct JitShape {
+  int block = 512;
+  bool lds_acc = true, need_count = false, two_phase = false;
+  int n_c4 = 0, n_c8 = 0, n_l4 = 0, n_l8 = 0;
+  JitSlot c4[FDB_MAX_C4], c8[FDB_MAX_C8], l4[FDB_MAX_L4], l8[FDB_MAX_L8];
+  std::vector<JitLeaf> leaves;
+  std::vector<uint8_t> code;  // postfix program over the leaves
+  std::vector<JitGroup> gcols;
+  std::vector<JitAgg> aggs;
+  std::string key(bool with_validity = true) const;
+};
+
+// The shape of one record's slot-assigned argument block.
+JitShape jit_shape(const FdbScanArgs& a, bool two_phase, int block);
+// Folds `other` into `into` when the two differ at most in which slots carry validity bitmaps; false otherwise.
+bool jit_shape_merge(JitShape* into, const JitShape& other);
+// Workgroups of `block` threads with `lds_bytes` of dynamic LDS that fit one CU (≥ 1).
+int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes);
+
+std::string jit_source(const JitShape& shape);
+// The compiled kernel for `shape` (cached in the process and on disk), or nullptr if specialisation is unavailable.
+hipFunction_t jit_get(const JitShape& shape);
+hipError_t jit_launch(hipFunction_t fn, const FdbScanArgs* d_parts, int n_parts, int64_t total_tiles, const FdbScanArgs& common, int grid, int block,
+                      size_t lds_bytes, hipStream_t stream);
+
+}  // namespace fdb

@@ -6,8 +6,13 @@
 // (binaryscalarexpr.go:214-229, dynparquet/hashed.go:201-216).
 #pragma once
 
+#ifndef FDB_DEVICE_ONLY  // (the run-time compiled plan kernels include this header through hiprtc, without host headers)
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#else
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;
+#endif
 
 #define FDB_MAX_LEAVES 12
 #define FDB_MAX_CODE 32
@@ -160,6 +165,7 @@ struct FdbHashArgs {
 };
 
 #define FDB_HASH_BLOCK 256
+#ifndef FDB_DEVICE_ONLY
 hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t lds_bytes, hipStream_t stream);
 // table[i] = {0, 0, 0, idents…, 0 pad} for i < capacity
 hipError_t fdb_launch_hash_init(unsigned long long* table, uint64_t capacity, int entry_words, int n_aggs, const unsigned long long* idents,
@@ -198,6 +204,7 @@ struct FdbHashMergeArgs {
   int32_t funcs[FDB_MAX_AGGS];
 };
 hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t stream);
+#endif  // FDB_DEVICE_ONLY
 
 // Identity elements stored in accumulators. MIN/MAX over float64 run on order-preserving int64 keys
 // (fdb_f64_to_ordered) so one integer atomic serves both types.
@@ -216,6 +223,7 @@ static inline double fdb_ordered_to_f64_host(int64_t k) {
   return d;
 }
 
+#ifndef FDB_DEVICE_ONLY
 // ---- launch wrappers (fdb_kernels.hip) ---------------------------------------------------------------
 // All launches are asynchronous on `stream`.
 // rows_per_thread: 4 or 8 → the sequential (one column at a time) kernel; 0 → the slot kernel (needs args.n_c4/n_c8).
@@ -251,3 +259,4 @@ hipError_t fdb_launch_gather(const void* src, void* dst, const uint32_t* indices
 hipError_t fdb_launch_gather_bits(const uint8_t* src_bitmap, uint8_t* dst_bitmap, const uint32_t* indices, int64_t n,
                                   hipStream_t stream);
 int fdb_scan_default_grid(int device);
+#endif  // FDB_DEVICE_ONLY

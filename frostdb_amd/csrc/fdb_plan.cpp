@@ -9,6 +9,7 @@
 //   * group identity: NULL ≡ column absent, first-seen order   aggregate.go:398-409, :492-525, :568-575
 //   * result naming and schema                                 aggregate.go:47, :543-633
 #include "fdb_plan.h"
+#include "fdb_jit.h"
 
 #include "fdb_context.h"
 #include "fdb_plan_internal.h"
@@ -905,8 +906,27 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
         if (layouts[k++] == 1 && assign_slots(*bs[i], Rs[(size_t)i], 2) != 2) throw Error(FDB_ERR_INVALID, "internal: slot re-assignment failed");
     }
     int tile_rows_i = 0, per_cu = 1;
-    const int sub = sub_tiles;  // slot-kernel variant mode (0 = default)
-    fdb_slot_geometry(two_phase, sub, lds_acc, lds_bytes, device_, &tile_rows_i, &per_cu);
+    const int sub = sub_tiles == 4 ? 0 : sub_tiles;  // kernel variant mode (0 = default, 4 = interpreting kernel only)
+    // A kernel specialised for this plan shape (fdb_jit.cpp), when every record of the launch has the same shape;
+    // otherwise (or when hiprtc is unavailable) the interpreting slot kernel.
+    hipFunction_t jit_fn = nullptr;
+    const int jit_block = sub == 2 ? 256 : sub == 3 ? 1024 : 512;
+    if (sub_tiles != 4 && ablate == 0 && lds_bytes <= FDB_LDS_BUDGET) {
+      JitShape shape;
+      bool same = true, first = true;
+      for (int i : live) {
+        const JitShape si = jit_shape(Rs[(size_t)i].args, two_phase != 0, jit_block);
+        if (first) { shape = si; first = false; }
+        else if (!jit_shape_merge(&shape, si)) { same = false; break; }
+      }
+      if (same) jit_fn = jit_get(shape);
+    }
+    if (jit_fn != nullptr) {
+      tile_rows_i = jit_block * 4;
+      per_cu = jit_blocks_per_cu(jit_fn, jit_block, lds_bytes);
+    } else {
+      fdb_slot_geometry(two_phase, sub, lds_acc, lds_bytes, device_, &tile_rows_i, &per_cu);
+    }
     int grid = grid_override > 0 ? grid_override : (fdb_scan_default_grid(device_) / 2) * per_cu;
     const int64_t tile_rows = tile_rows_i;
     int64_t total_tiles = 0;
@@ -924,8 +944,10 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     const FdbScanArgs* d_parts = (const FdbScanArgs*)upload(parts.data(), parts.size() * sizeof(FdbScanArgs));
     pt.mark("parts upload");
     timed_launch([&] {
-      hip_check(fdb_launch_scan_slots(d_parts, (int)parts.size(), parts[0], total_tiles, grid, lds_bytes, two_phase, sub, stream_), "scan launch");
+      if (jit_fn != nullptr) hip_check(jit_launch(jit_fn, d_parts, (int)parts.size(), total_tiles, parts[0], grid, jit_block, lds_bytes, stream_), "scan launch");
+      else hip_check(fdb_launch_scan_slots(d_parts, (int)parts.size(), parts[0], total_tiles, grid, lds_bytes, two_phase, sub, stream_), "scan launch");
     });
+    last_kernel_ = jit_fn != nullptr ? "fdb_plan_kernel" : "scan_slots_kernel";
     pt.mark("scan launch");
     if (partials != nullptr)
       hip_check(fdb_launch_reduce_partials(partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, stream_), "reduce partials");
@@ -939,6 +961,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
       const int grid = fdb_scan_grid(a, base_grid, rpt);
       a.partials = alloc_partials(grid);
       timed_launch([&] { hip_check(fdb_launch_scan_dense(a, grid, lds_bytes, rpt, stream_), "scan launch"); });
+      last_kernel_ = "scan_dense_kernel";
       if (a.partials != nullptr)
         hip_check(fdb_launch_reduce_partials(a.partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, stream_), "reduce partials");
       stat_launches += 1;

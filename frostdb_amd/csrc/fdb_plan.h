@@ -148,11 +148,13 @@ class Plan {
   int rows_per_thread = 0;  // 0: slot (load-hoisting) kernel; 4 / 8: sequential kernel
   int grid_override = 0;
   int ablate = 0;
-  int sub_tiles = 0;  // slot kernel variant mode: 0 default, 1: 512 thr, 2: 256 thr, 3: 1024 thr, 4: 512 thr × 2 sub-tiles
+  int sub_tiles = 0;  // kernel variant mode: 0 default, 1: 512 thr, 2: 256 thr, 3: 1024 thr, 4: interpreting kernel only (no plan specialisation)
+  const char* last_kernel() const { return last_kernel_; }
   bool use_partials = true;  // LDS mode: flush workgroup tables with plain stores + a fold kernel instead of atomics
   struct Resolved;  // per-batch kernel arguments (fdb_plan.cpp)
 
  private:
+  const char* last_kernel_ = "";  // name of the scan kernel of the latest push
   bool references(const std::string& column) const;
   void resolve_batch(const DeviceBatch& b, Resolved* R, std::vector<int>* batch_gcols);
   void ensure_layout(const std::vector<uint32_t>& new_caps);

@@ -84,6 +84,8 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_set_timing.argtypes = [vp, i32]
     L.fdb_plan_stream.argtypes = [vp, P(vp)]
     L.fdb_plan_set_tuning.argtypes = [vp, i32, i32]
+    L.fdb_plan_last_kernel.argtypes = [vp]
+    L.fdb_plan_last_kernel.restype = ctypes.c_char_p
     _lib = L
     return L
 
@@ -258,6 +260,10 @@ class HashAggregatePlan:
 
     def set_tuning(self, rows_per_thread: int = 8, grid_blocks: int = 0) -> None:
         lib().fdb_plan_set_tuning(self.handle, rows_per_thread, grid_blocks)
+
+    def last_kernel(self) -> str:
+        """Name of the scan kernel the latest push launched (``fdb_plan_kernel`` = run-time specialised)."""
+        return (lib().fdb_plan_last_kernel(self.handle) or b"").decode()
 
     def stats(self) -> dict:
         b, ms, n, r = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()

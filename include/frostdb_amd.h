@@ -222,8 +222,13 @@ int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled);
 /* The hipStream_t the plan launches on, as an opaque pointer. */
 int fdb_plan_stream(fdb_plan* plan, void** stream_out);
 /* Kernel geometry knobs for bench.py's variant sweeps: rows_per_thread 0 = load-hoisting slot kernel (default),
- * 4 / 8 = sequential kernel with that many rows per lane; grid_blocks 0 = default persistent grid. */
+ * 4 / 8 = sequential kernel with that many rows per lane; grid_blocks bits 0-19 = persistent grid size (0 = default),
+ * bits 25-27 = variant (1/2/3: 512/256/1024-thread workgroups, 4: interpreting kernels only, no run-time specialisation). */
 int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_blocks);
+/* Name of the scan kernel the latest push launched ("fdb_plan_kernel" = the run-time specialised kernel,
+ * "scan_slots_kernel" / "scan_dense_kernel" = the interpreting kernels, "scan_hash_kernel" = the hash-table path);
+ * "" before the first push. The string is static. */
+const char* fdb_plan_last_kernel(fdb_plan* plan);
 
 #ifdef __cplusplus
 }

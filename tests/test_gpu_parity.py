@@ -27,6 +27,17 @@ def pp():
     return physicalplan
 
 
+@pytest.fixture(params=["specialised", "interpreted"])
+def variant(request, monkeypatch):
+    """Runs a test once with the run-time specialised plan kernel (the default) and once with the interpreting
+    kernels only (FDB_NO_JIT is read at every launch)."""
+    if request.param == "interpreted":
+        monkeypatch.setenv("FDB_NO_JIT", "1")
+    else:
+        monkeypatch.delenv("FDB_NO_JIT", raising=False)
+    return request.param
+
+
 def rows_of(d, cols):
     return sorted(batch_rows(d, cols), key=sort_key)
 
@@ -88,7 +99,7 @@ def check_golden(case, d):
 
 @pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("case", G.AGG_CASES, ids=[c["id"] for c in G.AGG_CASES])
-def test_golden_aggregate(pp, case, resident):
+def test_golden_aggregate(pp, variant, case, resident):
     d = run_gpu(pp, table_records(case["table"]), case.get("filter"), case["aggs"], case["groups"], resident=resident)
     check_golden(case, d)
 
@@ -130,7 +141,7 @@ def test_golden_filter(pp, case):
         plan.Close()
 
 
-def test_golden_inconsistent_schema(pp):
+def test_golden_inconsistent_schema(pp, variant):
     spec = G.INCONSISTENT_SCHEMA
     recs = [record_from_rows(r["cols"], parse_rows(r["cols"], r["rows"])) for r in spec["records"]]
     fns = {"sum": [Sum], "min": [Min], "max": [Max], "count": [Count], "avg": [Sum, Count]}
@@ -152,7 +163,7 @@ CFG3 = dict(
 
 
 @pytest.mark.parametrize("n", [0, 1, 7, 8, 63, 64, 65, 1023, 1024, 8191, 8192, 8193, 100_003])
-def test_config2_sizes(pp, n):
+def test_config2_sizes(pp, variant, n):
     rng = np.random.default_rng(1000 + n)
     b = make_prometheus_batch(rng, n)
     want = run_oracle([b], **CFG2) if n else {"labels.path": [], "sum(value)": []}
@@ -165,7 +176,7 @@ def test_config2_sizes(pp, n):
 
 @pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("rpt", [0, 4, 8])
-def test_config3_multibatch(pp, resident, rpt):
+def test_config3_multibatch(pp, variant, resident, rpt):
     rng = np.random.default_rng(7)
     batches = [make_prometheus_batch(rng, n, n_path=int(p)) for n, p in [(50_000, 64), (33_333, 200), (8192, 7), (1, 3)]]
     want = run_oracle(batches, **CFG3, nchains=2)
@@ -186,7 +197,7 @@ def test_config3_multibatch(pp, resident, rpt):
     assert_same_result(got, want, cols, float_cols={"sum(value)"})
 
 
-def test_multi_record_single_launch(pp):
+def test_multi_record_single_launch(pp, variant):
     """fdb_plan_push_batches: records with different dictionaries, sizes (incl. empty and sub-tile) and column sets
     scanned by ONE launch give the same result as the oracle fed record by record."""
     rng = np.random.default_rng(99)
@@ -210,7 +221,42 @@ def test_multi_record_single_launch(pp):
         assert_same_result(got, want, cols, float_cols={"sum(value)"})
 
 
-def test_group_by_dynamic_labels_with_growing_dictionaries(pp):
+def test_specialised_kernel_is_the_one_that_runs(pp, monkeypatch):
+    """Default: the scan is the run-time compiled fdb_plan_kernel; FDB_NO_JIT / tuning mode 4: the interpreting kernel.
+    Queries of the same shape but different literals share one compiled kernel (the literal is a run-time argument)."""
+    rng = np.random.default_rng(5)
+    b = make_prometheus_batch(rng, 20_000)
+    monkeypatch.delenv("FDB_NO_JIT", raising=False)
+    for cfg in (CFG2, CFG3):
+        want = run_oracle([b], **cfg)
+        cols = ["labels.path"] + [a.Name() for a in cfg["aggs"]]
+        for mode, kernel in ((0, "fdb_plan_kernel"), (4, "scan_slots_kernel")):
+            plan = pp.HashAggregatePlan(cfg["filter_expr"], cfg["aggs"], cfg["groups"])
+            plan.set_tuning(0, mode << 25)
+            try:
+                plan.Callback(b)
+                assert plan.last_kernel() == kernel
+                got = arrow_to_pydict(plan.Finish())
+            finally:
+                plan.Close()
+            assert_same_result(got, want, cols, float_cols={"sum(value)"})
+    for code in ("404", "500"):
+        cfg = dict(CFG2, filter_expr=Col("labels.code") == code)
+        want = run_oracle([b], **cfg)
+        plan = pp.HashAggregatePlan(cfg["filter_expr"], cfg["aggs"], cfg["groups"])
+        try:
+            plan.Callback(b)
+            assert plan.last_kernel() == "fdb_plan_kernel"
+            got = arrow_to_pydict(plan.Finish())
+        finally:
+            plan.Close()
+        if want["labels.path"]:
+            assert_same_result(got, want, ["labels.path", "sum(value)"], float_cols={"sum(value)"})
+        else:
+            assert all(len(v) == 0 for v in got.values())
+
+
+def test_group_by_dynamic_labels_with_growing_dictionaries(pp, variant):
     """Group by the whole dynamic column set; later batches add dictionary entries AND a new label column,
     which forces the dense table to be re-laid-out (mixed-radix strides change)."""
     rng = np.random.default_rng(11)
@@ -235,7 +281,7 @@ def test_group_by_dynamic_labels_with_growing_dictionaries(pp):
     assert_same_result(got, want, cols, float_cols={"sum(floatvalue)"})
 
 
-def test_nullable_aggregated_columns_match_reference_quirks(pp):
+def test_nullable_aggregated_columns_match_reference_quirks(pp, variant):
     """NULLs inside an aggregated column: COUNT counts them, SUM adds 0, MIN/MAX see the builder's zeroed slot
     (aggregate.go:784-950 + pqarrow/builder/optbuilders.go:337-340). Unpinned by reference tests —
     this pins the HIP path to the oracle's restatement of it."""
@@ -254,7 +300,7 @@ def test_nullable_aggregated_columns_match_reference_quirks(pp):
     assert_same_result(got, want, ["labels.g"] + [a.Name() for a in aggs], float_cols={"sum(floatvalue)"})
 
 
-def test_numeric_predicates_and_no_groups(pp):
+def test_numeric_predicates_and_no_groups(pp, variant):
     rng = np.random.default_rng(21)
     n = 30_000
     b = pa.RecordBatch.from_arrays(
@@ -277,7 +323,7 @@ def test_numeric_predicates_and_no_groups(pp):
             assert got == want, str(f)
 
 
-def test_sliced_columns_with_unaligned_offsets(pp):
+def test_sliced_columns_with_unaligned_offsets(pp, variant):
     """Arrow slices carry a non-zero offset: validity bitmaps must be re-based bit-exactly at import."""
     rng = np.random.default_rng(77)
     b = make_prometheus_batch(rng, 50_000, null_frac=0.2)

@@ -226,6 +226,81 @@ __global__ __launch_bounds__(BLK) void probe_cfg2(const uint32_t* __restrict__ c
   for (uint32_t i = tid; i < n_slots; i += BLK) { out[i] = l_cnt[i]; out[n_slots + i] = (unsigned long long)__double_as_longlong(l_sum[i]); }
 }
 
+// V8: hand-specialised cfg-3 scan: (code ∈ bits) AND (method ∈ bits) AND instance IS NOT NULL; COUNT, MIN(ts), MAX(ts),
+// SUM(value) BY path. Two-phase: the three filter inputs first, then path / value / timestamp for lanes with a hit.
+template <int BLK, bool TWO_PHASE>
+__global__ __launch_bounds__(BLK) void probe_cfg3(const uint32_t* __restrict__ code, const uint32_t* __restrict__ method, const uint32_t* __restrict__ path,
+                                                  const double* __restrict__ val, const long long* __restrict__ ts, const uint8_t* __restrict__ bcode,
+                                                  const uint8_t* __restrict__ bmethod, const uint8_t* __restrict__ binst, const uint8_t* __restrict__ bpath,
+                                                  const uint32_t* __restrict__ lut_g, uint32_t lut_len, unsigned long long code_bits,
+                                                  unsigned long long method_bits, int64_t n_rows, unsigned long long* partials, uint32_t n_slots) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* l_cnt = lut + ((lut_len + 3) & ~3u);
+  double* l_sum = reinterpret_cast<double*>(l_cnt + ((n_slots + 3) & ~3u));
+  long long* l_min = reinterpret_cast<long long*>(l_sum + n_slots);
+  long long* l_max = l_min + n_slots;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < lut_len; i += BLK) lut[i] = lut_g[i];
+  for (uint32_t i = tid; i < n_slots; i += BLK) { l_cnt[i] = 0; l_sum[i] = 0.0; l_min[i] = 0x7FFFFFFFFFFFFFFFLL; l_max[i] = -0x7FFFFFFFFFFFFFFFLL - 1; }
+  __syncthreads();
+  const int64_t tile_rows = (int64_t)BLK * 4;
+  const int64_t n_tiles = n_rows / tile_rows;
+  const uint32_t lane_off = tid * 16u;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * tile_rows;
+    const u32x4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(code + r0) + lane_off));
+    const u32x4 m = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(method + r0) + lane_off));
+    const uint32_t bsh = (tid & 1u) * 4u;
+    const int64_t boff = (r0 >> 3) + (tid >> 1);
+    const uint32_t vc = (bcode[boff] >> bsh) & 0xFu, vm = (bmethod[boff] >> bsh) & 0xFu, vi = (binst[boff] >> bsh) & 0xFu;
+    u32x4 q; u64x2 v0, v1, t0, t1; uint32_t vp;
+    if (!TWO_PHASE) {
+      q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(path + r0) + lane_off));
+      v0 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(val + r0) + 2u * lane_off));
+      v1 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(val + r0) + 2u * lane_off + 16u));
+      t0 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(ts + r0) + 2u * lane_off));
+      t1 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(ts + r0) + 2u * lane_off + 16u));
+      vp = (bpath[boff] >> bsh) & 0xFu;
+    }
+    const uint32_t ci[4] = {c.x, c.y, c.z, c.w}, mi[4] = {m.x, m.y, m.z, m.w};
+    uint32_t sel = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t ce = ((vc >> r) & 1u) ? ci[r] : 63u, me = ((vm >> r) & 1u) ? mi[r] : 63u;
+      sel |= (uint32_t)(((code_bits >> ce) & 1ull) & ((method_bits >> me) & 1ull) & ((vi >> r) & 1u)) << r;
+    }
+    if (sel == 0) continue;
+    if (TWO_PHASE) {
+      q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(path + r0) + lane_off));
+      v0 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(val + r0) + 2u * lane_off));
+      v1 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(val + r0) + 2u * lane_off + 16u));
+      t0 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(ts + r0) + 2u * lane_off));
+      t1 = __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(ts + r0) + 2u * lane_off + 16u));
+      vp = (bpath[boff] >> bsh) & 0xFu;
+    }
+    const uint32_t pi[4] = {q.x, q.y, q.z, q.w};
+    const double vv[4] = {__longlong_as_double((long long)v0.x), __longlong_as_double((long long)v0.y), __longlong_as_double((long long)v1.x), __longlong_as_double((long long)v1.y)};
+    const long long tt[4] = {(long long)t0.x, (long long)t0.y, (long long)t1.x, (long long)t1.y};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if ((sel >> r) & 1u) {
+        const uint32_t slot = lut[((vp >> r) & 1u) ? pi[r] : lut_len - 1u];
+        atomicAdd(&l_cnt[slot], 1u);
+        atomicAdd(&l_sum[slot], vv[r]);
+        atomicMin(&l_min[slot], tt[r]);
+        atomicMax(&l_max[slot], tt[r]);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* out = partials + (size_t)blockIdx.x * 4 * n_slots;
+  for (uint32_t i = tid; i < n_slots; i += BLK) {
+    out[i] = l_cnt[i]; out[n_slots + i] = (unsigned long long)__double_as_longlong(l_sum[i]);
+    out[2 * n_slots + i] = (unsigned long long)l_min[i]; out[3 * n_slots + i] = (unsigned long long)l_max[i];
+  }
+}
+
 template <typename F>
 float time_it(F&& launch) {
   hipEvent_t e0, e1;
@@ -323,6 +398,24 @@ int main(int argc, char** argv) {
       REPORT("specialised cfg2 blk=1024", G / 2, ms);
       ms = time_it([&] { hipLaunchKernelGGL((probe_cfg2<256>), dim3(G * 2), dim3(256), lds, 0, a, b, (const double*)v, ba, bb, lut, 1025u, 1ull, n, partials, 1025u); });
       REPORT("specialised cfg2 blk=256", G * 2, ms);
+    }
+    {
+      // cfg 3: + method (4 values), instance validity (5 % NULL), timestamp
+      uint32_t* meth; long long* tsd; uint8_t* binst;
+      CHECK(hipMalloc(&meth, n * 4 + 4096)); CHECK(hipMalloc(&tsd, n * 8 + 4096)); CHECK(hipMalloc(&binst, n / 8 + 4096));
+      std::vector<uint32_t> hm(n); std::vector<uint8_t> hb(n / 8 + 1, 0xFF);
+      uint64_t y = 0x9E3779B97F4A7C15ull;
+      for (int64_t i = 0; i < n; i++) { y ^= y << 13; y ^= y >> 7; y ^= y << 17; hm[i] = (uint32_t)(y & 3); if ((y >> 10) % 20 == 0) hb[i >> 3] &= ~(1u << (i & 7)); }
+      CHECK(hipMemcpy(meth, hm.data(), n * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(binst, hb.data(), n / 8, hipMemcpyHostToDevice));
+      CHECK(hipMemset(tsd, 5, n * 8));
+      const double bytes3 = (double)n * 28.5;
+      const size_t lds3 = (1028 + 1028) * 4 + 1025 * 8 * 3;
+      for (int G : {cus * 2, cus * 3, cus * 4}) {
+        float ms = time_it([&] { hipLaunchKernelGGL((probe_cfg3<512, true>), dim3(G), dim3(512), lds3, 0, a, meth, b, (const double*)v, tsd, ba, bb, binst, bb, lut, 1025u, 5ull, 1ull, n, partials, 1025u); });
+        printf("%-28s grid=%5d  %.4f ms  %.1f GB/s\n", "specialised cfg3 2-phase", G, ms, bytes3 / ms / 1e6);
+        ms = time_it([&] { hipLaunchKernelGGL((probe_cfg3<512, false>), dim3(G), dim3(512), lds3, 0, a, meth, b, (const double*)v, tsd, ba, bb, binst, bb, lut, 1025u, 5ull, 1ull, n, partials, 1025u); });
+        printf("%-28s grid=%5d  %.4f ms  %.1f GB/s\n", "specialised cfg3 1-phase", G, ms, bytes3 / ms / 1e6);
+      }
     }
     CHECK(hipMemset(a, 1, n * 4)); CHECK(hipMemset(b, 2, n * 4));
   }
