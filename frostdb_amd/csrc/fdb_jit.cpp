@@ -17,6 +17,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,7 +72,7 @@ template <int OP, typename T> __device__ __forceinline__ uint32_t cmp4(T a, T b,
 )HIP";
 
 std::mutex g_mu;
-std::unordered_map<std::string, hipFunction_t> g_cache;  // source text → function
+std::unordered_map<std::string, hipFunction_t> g_cache;  // device | shape key → function
 bool g_disabled = false;
 
 uint64_t fnv(const std::string& s) {
@@ -365,16 +366,16 @@ int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes) {
 
 hipFunction_t jit_get(const JitShape& shape) {
   if (g_disabled || std::getenv("FDB_NO_JIT") != nullptr) return nullptr;
-  const std::string src = jit_source(shape);
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const std::string ckey = std::to_string(dev) + "|" + src;  // a loaded module belongs to one device
+  const std::string ckey = std::to_string(dev) + "|" + shape.key();  // a loaded module belongs to one device
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_cache.find(ckey);
   if (it != g_cache.end()) return it->second;
+  const std::string src = jit_source(shape);
   std::vector<char> code;
   char name[64];
-  std::snprintf(name, sizeof name, "/k_%016llx_%zu.hsaco", (unsigned long long)fnv(src), src.size());
+  std::snprintf(name, sizeof name, "/k_%016llx_%zu.hsaco", (unsigned long long)(fnv(src) ^ (fnv(kKernelsHeader) * 31)), src.size());
   const std::string path = cache_dir() + name;
   {
     std::ifstream f(path, std::ios::binary);
@@ -400,6 +401,26 @@ hipFunction_t jit_get(const JitShape& shape) {
     fn = nullptr;
   }
   g_cache.emplace(ckey, fn);
+  return fn;
+}
+
+// Geometry for `shape`. Measured on MI355X (tools/sweep_geometry.sh): a streaming scan is fastest when ≈64 KB of loads
+// are in flight per CU (Little's law for ≈8 TB/s × ≈2 µs over 256 CUs) — 16 waves for cfg 2 (64 B per lane and tile),
+// 8 for cfg 3 (128 B) — and gets SLOWER with more resident waves (cfg 2: 6.75 TB/s at 16 waves/CU, 6.0 at 32), so the
+// persistent grid is sized from the bytes one lane requests per tile, not from the occupancy limit.
+hipFunction_t jit_select(JitShape shape, size_t lds_bytes, int row_bytes, int* block_out, int* blocks_per_cu_out) {
+  int waves = row_bytes > 0 ? (65536 / (64 * 4)) / row_bytes : 16;  // 64 lanes × 4 rows per lane and tile
+  waves = std::max(8, std::min(32, waves));
+  const int block = waves % 8 == 0 ? 512 : 256;
+  shape.block = block;
+  hipFunction_t fn = jit_get(shape);
+  if (fn == nullptr) return nullptr;
+  const int fit = jit_blocks_per_cu(fn, block, lds_bytes);
+  *block_out = block;
+  *blocks_per_cu_out = std::max(1, std::min(fit, (waves + block / 128) / (block / 64)));
+  if (std::getenv("FDB_JIT_DEBUG"))
+    std::fprintf(stderr, "[frostdb_amd] plan kernel %s: %d B/row, %zu B LDS -> %d-thread workgroups, %d per CU (%d fit)\n", shape.key().c_str(), row_bytes,
+                 lds_bytes, block, *blocks_per_cu_out, fit);
   return fn;
 }
 

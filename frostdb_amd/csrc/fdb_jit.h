@@ -40,6 +40,9 @@ int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes);
 std::string jit_source(const JitShape& shape);
 // The compiled kernel for `shape` (cached in the process and on disk), or nullptr if specialisation is unavailable.
 hipFunction_t jit_get(const JitShape& shape);
+// jit_get plus the launch geometry: workgroup size and workgroups per CU such that ≈64 KB of loads are in flight per CU
+// (`row_bytes` = bytes of column data the scan reads per row).
+hipFunction_t jit_select(JitShape shape, size_t lds_bytes, int row_bytes, int* block_out, int* blocks_per_cu_out);
 hipError_t jit_launch(hipFunction_t fn, const FdbScanArgs* d_parts, int n_parts, int64_t total_tiles, const FdbScanArgs& common, int grid, int block,
                       size_t lds_bytes, hipStream_t stream);
 

@@ -910,20 +910,29 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     // A kernel specialised for this plan shape (fdb_jit.cpp), when every record of the launch has the same shape;
     // otherwise (or when hiprtc is unavailable) the interpreting slot kernel.
     hipFunction_t jit_fn = nullptr;
-    const int jit_block = sub == 2 ? 256 : sub == 3 ? 1024 : 512;
+    int jit_block = sub == 1 ? 512 : sub == 2 ? 256 : sub == 3 ? 1024 : 0;  // 0: picked by occupancy
     if (sub_tiles != 4 && ablate == 0 && lds_bytes <= FDB_LDS_BUDGET) {
       JitShape shape;
       bool same = true, first = true;
       for (int i : live) {
-        const JitShape si = jit_shape(Rs[(size_t)i].args, two_phase != 0, jit_block);
+        const JitShape si = jit_shape(Rs[(size_t)i].args, two_phase != 0, jit_block ? jit_block : 256);
         if (first) { shape = si; first = false; }
         else if (!jit_shape_merge(&shape, si)) { same = false; break; }
       }
-      if (same) jit_fn = jit_get(shape);
+      if (same) {
+        if (jit_block != 0) { jit_fn = jit_get(shape); if (jit_fn != nullptr) per_cu = jit_blocks_per_cu(jit_fn, jit_block, lds_bytes); }
+        else {
+          int row_bytes = 0;
+          for (int k = 0; k < shape.n_c4; k++) row_bytes += shape.c4[k].has_values ? 4 : 0;
+          for (int k = 0; k < shape.n_l4; k++) row_bytes += shape.l4[k].has_values ? 4 : 0;
+          for (int k = 0; k < shape.n_c8; k++) row_bytes += shape.c8[k].has_values ? 8 : 0;
+          for (int k = 0; k < shape.n_l8; k++) row_bytes += shape.l8[k].has_values ? 8 : 0;
+          jit_fn = jit_select(shape, lds_bytes, row_bytes, &jit_block, &per_cu);
+        }
+      }
     }
     if (jit_fn != nullptr) {
       tile_rows_i = jit_block * 4;
-      per_cu = jit_blocks_per_cu(jit_fn, jit_block, lds_bytes);
     } else {
       fdb_slot_geometry(two_phase, sub, lds_acc, lds_bytes, device_, &tile_rows_i, &per_cu);
     }
