@@ -218,6 +218,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sample_for_cpu[0], filt, aggs, groups, args.cpu_sample_seconds)
 
+    ceiling = None
+    if rank == 0 and world == 1:
+        ceiling = pp.read_ceiling(local_rank, 2 << 30, 5)  # plain read kernel on this box, this run
+
+    # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the timed process)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"round1_cfg{args.config}_traffic.json")
+    if os.path.exists(tpath) and not args.per_record_launch:
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        if tj.get("rows") == rows and tj.get("kernel") == kernel_name:
+            traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
+            traffic_src = os.path.relpath(tpath, os.path.dirname(os.path.abspath(__file__)))
+
     if rank == 0:
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         line = {
@@ -229,10 +243,11 @@ def main():
                        "rows_per_gpu": rows, "records_per_gpu": n_chunks, "groups": args.groups if args.config == 5 else 1025,
                        "parallelism": f"parts sharded over {world} GPU(s); RCCL all-reduce of partial tables" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "avg_launch_ms": k_ms / max(k_launches, 1),
                          "algorithmic_bytes_per_launch": k_bytes / max(k_launches, 1),
-                         "bytes_per_row": k_bytes / max(rows * args.steps, 1)},
+                         "bytes_per_row": k_bytes / max(rows * args.steps, 1),
+                         "measured_read_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling else None},
             "cpu_baseline": cpu,
             "setup": {"gen_and_upload_s": t_gen, "hbm_resident_bytes": hbm_bytes},
         }

@@ -47,6 +47,38 @@ int fdb_device_count(int* n_devices) {
   });
 }
 
+int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s) {
+  return guard(nullptr, [&] {
+    if (gb_per_s == nullptr || bytes < (1 << 20) || reps < 1) throw fdb::Error(FDB_ERR_INVALID, "fdb_read_ceiling: bytes >= 1 MiB, reps >= 1");
+    *gb_per_s = 0;
+    bytes &= ~(int64_t)4095;
+    if (hipSetDevice(device) != hipSuccess) throw fdb::Error(FDB_ERR_DEVICE, "hipSetDevice failed");
+    void* buf = nullptr;
+    unsigned long long* out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&] { if (buf) (void)hipFree(buf); if (out) (void)hipFree(out); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
+    auto ck = [&](hipError_t e, const char* what) { if (e != hipSuccess) { cleanup(); throw fdb::Error(e == hipErrorOutOfMemory ? FDB_ERR_OOM : FDB_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); } };
+    ck(hipMalloc(&buf, (size_t)bytes), "hipMalloc");
+    ck(hipMalloc((void**)&out, 64), "hipMalloc");
+    ck(hipMemset(buf, 0, (size_t)bytes), "hipMemset");
+    ck(hipEventCreate(&e0), "hipEventCreate");
+    ck(hipEventCreate(&e1), "hipEventCreate");
+    ck(fdb_launch_stream_read(buf, bytes, out, nullptr), "launch");  // warm-up
+    float best = 0;
+    for (int r = 0; r < reps; r++) {
+      ck(hipEventRecord(e0, nullptr), "hipEventRecord");
+      ck(fdb_launch_stream_read(buf, bytes, out, nullptr), "launch");
+      ck(hipEventRecord(e1, nullptr), "hipEventRecord");
+      ck(hipEventSynchronize(e1), "hipEventSynchronize");
+      float ms = 0;
+      ck(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+      if (ms > 0 && (best == 0 || ms < best)) best = ms;
+    }
+    cleanup();
+    if (best > 0) *gb_per_s = (double)bytes / (best * 1e-3) / 1e9;
+  });
+}
+
 int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out) {
   return guard(nullptr, [&] {
     if (out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null out pointer");

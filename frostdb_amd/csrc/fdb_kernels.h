@@ -238,6 +238,8 @@ hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_
 // The slot kernel over `n_parts` records in ONE launch. `d_parts` is the device copy of the per-record argument
 // blocks (global tile ranges filled in, in units of fdb_slot_geometry's tile_rows); `common` = any of them (table
 // pointers, aggregation functions, LDS layout are identical across records). sub_tiles: 1 or 2.
+// Measurement only: reads `bytes` (multiple of 16) once with the best streaming pattern of this box.
+hipError_t fdb_launch_stream_read(const void* src, int64_t bytes, unsigned long long* out, hipStream_t stream);
 hipError_t fdb_launch_scan_slots(const FdbScanArgs* d_parts, int n_parts, const FdbScanArgs& common, int64_t total_tiles, int grid_blocks,
                                  size_t lds_bytes, int two_phase, int mode, hipStream_t stream);
 // Rows per tile and resident workgroups per CU (occupancy query on the instance that will run) of the slot kernel.

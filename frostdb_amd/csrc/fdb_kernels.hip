@@ -1308,6 +1308,22 @@ hipError_t fdb_launch_scan_dense(const FdbScanArgs& args, int grid_blocks, size_
   return hipGetLastError();
 }
 
+// Plain streaming read (measurement only, fdb_read_ceiling): one 4 KiB tile per workgroup, 16 bytes per lane, `nt` loads —
+// the access pattern with the highest read rate found on this box (tools/bw_probe.hip).
+__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restrict__ src, int64_t n_vec, unsigned long long* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_vec) return;
+  const u32x4 v = __builtin_nontemporal_load(as_global(src + i));
+  if ((v.x ^ v.y ^ v.z ^ v.w) == 0x9E3779B9u) out[0] = 1;  // keeps the load alive; never true for the zero-filled buffer
+}
+
+hipError_t fdb_launch_stream_read(const void* src, int64_t bytes, unsigned long long* out, hipStream_t stream) {
+  const int64_t n_vec = bytes / 16;
+  if (n_vec <= 0) return hipSuccess;
+  hipLaunchKernelGGL(stream_read_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const u32x4*>(src), n_vec, out);
+  return hipGetLastError();
+}
+
 hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value, int64_t n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   int blocks = (int)((n + 255) / 256);

@@ -84,10 +84,20 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_set_timing.argtypes = [vp, i32]
     L.fdb_plan_stream.argtypes = [vp, P(vp)]
     L.fdb_plan_set_tuning.argtypes = [vp, i32, i32]
+    L.fdb_read_ceiling.argtypes = [ctypes.c_int, ctypes.c_int64, i32, ctypes.POINTER(ctypes.c_double)]
     L.fdb_plan_last_kernel.argtypes = [vp]
     L.fdb_plan_last_kernel.restype = ctypes.c_char_p
     _lib = L
     return L
+
+
+def read_ceiling(device: int = 0, nbytes: int = 1 << 31, reps: int = 5) -> float:
+    """Best GB/s of a load-only streaming kernel over `nbytes` of HBM on this box (measurement aid)."""
+    out = ctypes.c_double(0.0)
+    rc = lib().fdb_read_ceiling(device, ctypes.c_int64(nbytes), reps, ctypes.byref(out))
+    if rc != 0:
+        raise FdbError(rc, lib().fdb_last_error().decode())
+    return out.value
 
 
 def device_count() -> int:

@@ -145,6 +145,9 @@ const char* fdb_version(void);
 /* Text of the last error raised on the calling thread by a call that had no plan handle. */
 const char* fdb_last_error(void);
 int fdb_device_count(int* n_devices);
+/* Measurement aid ("the measured ceiling of a plain read kernel on the same box in the same run"): streams
+ * `bytes` of HBM through a load-only kernel `reps` times (hipEvent-timed, one launch each) and returns the best rate. */
+int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s);
 
 /* ---- plan life cycle (≙ physicalplan.Build for one chain, physicalplan.go:417-474) -------------- */
 int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
