@@ -191,9 +191,14 @@ void export_record(std::vector<OutColumn>&& cols_in, int64_t rows, ArrowArray* o
     a.n_buffers = 2;
     std::vector<const void*>& b = h->buffers[i];
     b.resize(2);
-    b[0] = (c.null_count > 0 && !c.validity.empty()) ? (const void*)c.validity.data() : nullptr;
     static const uint64_t kEmpty = 0;
-    b[1] = c.values.empty() ? (const void*)&kEmpty : (const void*)c.values.data();
+    if (c.backing) {
+      b[0] = c.null_count > 0 ? (const void*)c.ext_validity : nullptr;
+      b[1] = c.ext_values != nullptr ? (const void*)c.ext_values : (const void*)&kEmpty;
+    } else {
+      b[0] = (c.null_count > 0 && !c.validity.empty()) ? (const void*)c.validity.data() : nullptr;
+      b[1] = c.values.empty() ? (const void*)&kEmpty : (const void*)c.values.data();
+    }
     a.buffers = b.data();
     a.release = noop_release_array;
     ArrowSchema& s = h->child_schemas[i];

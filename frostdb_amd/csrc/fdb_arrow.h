@@ -62,6 +62,11 @@ struct OutColumn {
   int64_t null_count = 0;
   std::vector<uint8_t> validity;      // empty ⇒ no validity buffer
   std::vector<uint8_t> values;        // fixed-width values / uint32 indices
+  // Big results: the buffers live in one block shared by every column of the record (pinned, filled by ONE device→host
+  // copy) instead of the vectors above; `backing` returns the block to its pool when the last column is released.
+  const uint8_t* ext_validity = nullptr;
+  const uint8_t* ext_values = nullptr;
+  std::shared_ptr<void> backing;
   // dictionary columns:
   bool is_dict = false;
   std::string dict_format;            // "z" / "u"

@@ -85,6 +85,53 @@ void Context::host_free(void* p) {
   for (Block& b : host_blocks_) if (b.p == p) { b.used = false; return; }
 }
 
+namespace {
+struct PinnedBlock { void* p; size_t bytes; bool used; };
+std::mutex g_pin_mu;
+std::vector<PinnedBlock> g_pinned;
+constexpr size_t kPinnedCacheBudget = (size_t)8 << 30;  // idle pinned bytes kept for re-use
+}  // namespace
+
+void* pinned_pool_alloc(size_t bytes) {
+  const size_t want = (std::max<size_t>(bytes, 1) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);  // 2 MiB granules
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    PinnedBlock* best = nullptr;
+    for (PinnedBlock& b : g_pinned)
+      if (!b.used && b.bytes >= want && b.bytes <= want * 2 && (best == nullptr || b.bytes < best->bytes)) best = &b;
+    if (best != nullptr) { best->used = true; return best->p; }
+  }
+  void* p = nullptr;
+  hip_check(hipHostMalloc(&p, want, hipHostMallocDefault), "hipHostMalloc(result)");
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pinned.push_back(PinnedBlock{p, want, true});
+  return p;
+}
+
+void pinned_pool_free(void* p) {
+  if (p == nullptr) return;
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    size_t idle = 0;
+    for (PinnedBlock& b : g_pinned) {
+      if (b.p == p) b.used = false;
+      if (!b.used) idle += b.bytes;
+    }
+    // over budget: give the largest idle blocks back to the OS
+    while (idle > kPinnedCacheBudget) {
+      size_t k = g_pinned.size();
+      for (size_t i = 0; i < g_pinned.size(); i++)
+        if (!g_pinned[i].used && (k == g_pinned.size() || g_pinned[i].bytes > g_pinned[k].bytes)) k = i;
+      if (k == g_pinned.size()) break;
+      idle -= g_pinned[k].bytes;
+      drop.push_back(g_pinned[k].p);
+      g_pinned.erase(g_pinned.begin() + (long)k);
+    }
+  }
+  for (void* q : drop) (void)hipHostFree(q);
+}
+
 hipEvent_t Context::get_event() {
   if (!events_.empty()) { hipEvent_t e = events_.back(); events_.pop_back(); return e; }
   hipEvent_t e;

@@ -11,6 +11,7 @@
 // can therefore never fail and no row is ever applied twice.
 #include "fdb_context.h"
 #include "fdb_plan_internal.h"
+#include "fdb_jit.h"
 
 namespace fdb {
 
@@ -144,6 +145,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     h.base = R.args;
     FdbScanArgs& a = h.base;
     a.need_count = 1;
+    a.ablate = ablate;
     // LUTs: predicate LUTs from the record's blob, key-id LUTs appended
     std::vector<FdbHashCol> hcols(R.groups.size());
     std::vector<size_t> lut_off(R.groups.size(), 0);
@@ -178,6 +180,16 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     h.key_words = h_key_words_;
     h.entry_words = h_entry_words_;
     const int grid = fdb_scan_default_grid(device_) * 4;  // 256-thread workgroups, 8 per CU
+    // The run-time specialised kernel for this record's shape (fdb_jit.cpp), or the interpreting scan_hash_kernel
+    hipFunction_t jit_fn = nullptr;
+    int jit_grid = 0;
+    if (sub_tiles != 4 && a.lds_lut_bytes <= FDB_LDS_BUDGET) {
+      JitHashShape shape = jit_hash_shape(h, hcols.data());
+      shape.ablate = ablate & 3;
+      jit_fn = jit_hash_get(shape);
+      if (jit_fn != nullptr)
+        jit_grid = grid_override > 0 ? grid_override : (fdb_scan_default_grid(device_) / 2) * std::min(4, jit_blocks_per_cu(jit_fn, 256, a.lds_lut_bytes));
+    }
     for (int64_t r0 = 0; r0 < b.rows; r0 += kChunkRows) {
       const int64_t r1 = std::min<int64_t>(b.rows, r0 + kChunkRows);
       if (h_table_ != nullptr && state_dirty_) hash_groups();  // refresh the bound (waits for the previous chunk)
@@ -186,8 +198,14 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       h.row_begin = r0; h.row_end = r1;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
-      hip_check(fdb_launch_scan_hash(h, grid, a.lds_lut_bytes, stream_), "hash scan launch");
-      last_kernel_ = "scan_hash_kernel";
+      if (jit_fn != nullptr) {
+        const int64_t n_tiles = (r1 - r0 + 1023) / 1024;
+        hip_check(jit_hash_launch(jit_fn, h, (int)std::min<int64_t>(jit_grid, n_tiles), a.lds_lut_bytes, stream_), "hash scan launch");
+        last_kernel_ = "fdb_hash_kernel";
+      } else {
+        hip_check(fdb_launch_scan_hash(h, grid, a.lds_lut_bytes, stream_), "hash scan launch");
+        last_kernel_ = "scan_hash_kernel";
+      }
       if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
       h_groups_bound_ += (uint64_t)(r1 - r0);
       state_dirty_ = true;
@@ -243,21 +261,27 @@ void Plan::fetch_compact_hash(CompactState* cs) {
 // aggregate columns) → one device-to-host copy per buffer. Returns the number of groups.
 int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   hip_check(hipSetDevice(device_), "hipSetDevice");
+  PhaseTimer pt;
   const uint64_t n = hash_groups();
   const size_t n_cols = gcols_.size(), n_vals = 1 + aggs_.size();
-  const size_t np = (size_t)((n + 63) & ~(uint64_t)63) + 64;  // padded row count of the scratch buffers
-  // scratch: key buffers (8 B/row each, enough for either kind), validity bytes, value columns, validity bitmaps
-  std::vector<void*> d_key(n_cols), d_bits(n_cols);
+  const size_t np = (size_t)((n + 63) & ~(uint64_t)63) + 64;  // padded row count of the buffers
+  // One result block with the layout of the final record — per group column [values | validity bitmap], then one
+  // 8-byte column per emitted value array — exists twice: in HBM (filled by the kernels below) and in pinned host memory
+  // (filled by ONE device→host copy, then handed to the caller as the record's buffers).
+  std::vector<size_t> off_key(n_cols), off_bits(n_cols), off_val(n_vals);
+  size_t total = 0;
+  auto place = [&](size_t bytes) { const size_t o = total; total = align_up_sz(total + bytes, 256); return o; };
+  for (size_t c = 0; c < n_cols; c++) { off_key[c] = place(np * (gcols_[c].kind == 0 ? 4 : 8)); off_bits[c] = place(np / 8 + 64); }
+  for (size_t v = 0; v < n_vals; v++) off_val[v] = place(np * 8);
+  unsigned char* d_block = (unsigned char*)ctx_->dev_alloc(total);
+  std::vector<void*> owned{d_block};
+  auto alloc = [&](size_t bytes) { void* p = ctx_->dev_alloc(bytes); owned.push_back(p); return p; };
+  std::vector<void*> d_key(n_cols);
   std::vector<uint8_t*> d_valid(n_cols);
   std::vector<unsigned long long*> d_vals(n_vals);
-  std::vector<void*> owned;
-  auto alloc = [&](size_t bytes) { void* p = ctx_->dev_alloc(bytes); owned.push_back(p); return p; };
-  for (size_t c = 0; c < n_cols; c++) {
-    d_key[c] = alloc(np * (gcols_[c].kind == 0 ? 4 : 8));
-    d_valid[c] = (uint8_t*)alloc(np);
-    d_bits[c] = alloc(np / 8 + 64);
-  }
-  for (size_t v = 0; v < n_vals; v++) d_vals[v] = (unsigned long long*)alloc(np * 8);
+  uint8_t* d_valid_all = (uint8_t*)alloc(std::max<size_t>(n_cols, 1) * np);  // one validity byte per row and column (packed below)
+  for (size_t c = 0; c < n_cols; c++) { d_key[c] = d_block + off_key[c]; d_valid[c] = d_valid_all + c * np; }
+  for (size_t v = 0; v < n_vals; v++) d_vals[v] = (unsigned long long*)(d_block + off_val[v]);
   unsigned long long* d_n = (unsigned long long*)alloc(256);
   hip_check(hipMemsetAsync(d_n, 0, 8, stream_), "hipMemsetAsync");
   std::vector<FdbHashCol> cols(std::max<size_t>(n_cols, 1));
@@ -274,25 +298,25 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   a.out_vals = (unsigned long long* const*)upload(d_vals.data(), n_vals * sizeof(void*));
   a.n_out = d_n;
   a.n_cols = (int)n_cols; a.entry_words = h_entry_words_; a.key_words = h_key_words_; a.n_vals = (int)n_vals;
+  std::shared_ptr<void> backing;
+  unsigned char* h_block = nullptr;
   if (n > 0) {
     hip_check(fdb_launch_hash_columns(a, stream_), "hash columns");
-    for (size_t c = 0; c < n_cols; c++) hip_check(fdb_launch_pack_bits(d_valid[c], (uint8_t*)d_bits[c], (int64_t)n, stream_), "pack bits");
+    for (size_t c = 0; c < n_cols; c++) hip_check(fdb_launch_pack_bits(d_valid[c], d_block + off_bits[c], (int64_t)n, stream_), "pack bits");
+    h_block = (unsigned char*)pinned_pool_alloc(total);
+    backing = std::shared_ptr<void>(h_block, [](void* p) { pinned_pool_free(p); });
+    hip_check(hipMemcpyAsync(h_block, d_block, total, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(result block)");
   }
-  // host buffers
+  pt.mark("finish: launch");
+  // column descriptors (dictionaries are rebuilt on the host while the copy is in flight)
   out->clear();
   for (size_t c = 0; c < n_cols; c++) {
     const GroupColState& g = gcols_[c];
     OutColumn oc;
     oc.name = g.name;
     oc.length = (int64_t)n;
-    const size_t w = g.kind == 0 ? 4 : 8;
     oc.format = g.kind == 0 ? "I" : "l";
-    oc.values.resize((size_t)n * w);
-    oc.validity.resize((size_t)(n + 7) / 8);
-    if (n > 0) {
-      hip_check(hipMemcpyAsync(oc.values.data(), d_key[c], (size_t)n * w, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(key column)");
-      hip_check(hipMemcpyAsync(oc.validity.data(), d_bits[c], oc.validity.size(), hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(validity)");
-    }
+    if (n > 0) { oc.backing = backing; oc.ext_values = h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }
     if (g.kind == 0) {
       oc.is_dict = true;
       oc.dict_format = g.value_format;
@@ -315,34 +339,35 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     const bool count_from_cnt = A.func == FDB_AGG_COUNT && !final_stage_;
     const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
     oc.format = is_f64 ? "g" : "l";
-    oc.values.resize((size_t)n * 8);
-    if (n > 0)
-      hip_check(hipMemcpyAsync(oc.values.data(), d_vals[count_from_cnt ? 0 : 1 + j], (size_t)n * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(agg column)");
+    if (n > 0) { oc.backing = backing; oc.ext_values = h_block + off_val[count_from_cnt ? 0 : 1 + j]; }
     out->push_back(std::move(oc));
   }
   sync();
+  pt.mark("finish: copy");
   for (void* p : owned) ctx_->dev_free(p);
   // post-processing that needs the data on the host: NULL counts, float64 MIN/MAX key decoding
-  for (size_t c = 0; c < n_cols; c++) {
+  for (size_t c = 0; c < n_cols && n > 0; c++) {
     OutColumn& oc = (*out)[c];
+    const size_t bytes = (size_t)(n + 7) / 8;
     int64_t set = 0;
-    const uint64_t* w64 = (const uint64_t*)oc.validity.data();
-    const size_t full = oc.validity.size() / 8;
+    const uint64_t* w64 = (const uint64_t*)oc.ext_validity;
+    const size_t full = bytes / 8;
     for (size_t i = 0; i < full; i++) set += __builtin_popcountll(w64[i]);
-    for (size_t i = full * 8; i < oc.validity.size(); i++) set += __builtin_popcount(oc.validity[i]);
+    for (size_t i = full * 8; i < bytes; i++) set += __builtin_popcount(oc.ext_validity[i]);
     oc.null_count = (int64_t)n - set;
   }
-  for (size_t j = 0; j < aggs_.size(); j++) {
+  for (size_t j = 0; j < aggs_.size() && n > 0; j++) {
     const AggState& A = aggs_[j];
     if (A.type == FDB_T_F64 && (A.func == FDB_AGG_MIN || A.func == FDB_AGG_MAX)) {
-      OutColumn& oc = (*out)[n_cols + j];
+      unsigned char* v = h_block + off_val[1 + j];
       for (uint64_t i = 0; i < n; i++) {
-        int64_t k; std::memcpy(&k, oc.values.data() + i * 8, 8);
+        int64_t k; std::memcpy(&k, v + i * 8, 8);
         const double d = fdb_ordered_to_f64_host(k);
-        std::memcpy(oc.values.data() + i * 8, &d, 8);
+        std::memcpy(v + i * 8, &d, 8);
       }
     }
   }
+  pt.mark("finish: host post");
   return (int64_t)n;
 }
 

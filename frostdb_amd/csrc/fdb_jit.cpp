@@ -141,9 +141,10 @@ struct Gen {
     else o << "    const uint32_t " << r << "_m = 0xFu;\n";
   }
 
-  std::string leaf_expr(int l) {
-    const JitLeaf& L = s.leaves[l];
-    const std::string r = reg(L.wide, false, L.slot);
+  std::string leaf_expr(int l) { return leaf_expr_of(s.leaves[l], l, reg(s.leaves[l].wide, false, s.leaves[l].slot)); }
+
+  // 4-bit match mask of leaf `l` over the registers `r` (values r / r+"a", r+"b"; validity nibble r+"_m")
+  static std::string leaf_expr_of(const JitLeaf& L, int l, const std::string& r) {
     const std::string li = std::to_string(l);
     std::ostringstream e;
     switch (L.kind) {
@@ -173,9 +174,13 @@ struct Gen {
   }
 
   std::string filter_expr() {  // postfix program → infix C expression
+    return filter_expr_of(s.code, [&](int l) { return leaf_expr(l); });
+  }
+  template <typename F>
+  static std::string filter_expr_of(const std::vector<uint8_t>& code, F leaf) {
     std::vector<std::string> st;
-    for (uint8_t c : s.code) {
-      if (c < 0x80) { st.push_back(leaf_expr(c)); continue; }
+    for (uint8_t c : code) {
+      if (c < 0x80) { st.push_back(leaf(c)); continue; }
       const std::string b = st.back(); st.pop_back();
       const std::string a = st.back(); st.pop_back();
       st.push_back("(" + a + (c == FDB_CODE_AND ? " & " : " | ") + b + ")");
@@ -309,6 +314,192 @@ struct Gen {
   }
 };
 
+
+// ---- high-cardinality path: fdb_hash_kernel -----------------------------------------------------------------------------
+// Same job as scan_hash_kernel (fdb_kernels.hip) with the plan's shape baked in: 4 consecutive rows per lane (every index
+// column is one 16-byte load per lane), key columns folded into the fingerprint 8 at a time with all 8 loads in flight,
+// no per-row staging of the key tuple (the rare lane that creates a group re-reads its row's columns instead).
+const char* kHashPreamble = "";
+
+struct HashGen {
+  std::ostringstream o;
+  const JitHashShape& s;
+  explicit HashGen(const JitHashShape& sh) : s(sh) {}
+  static const char* comp4(int k) { static const char* c[4] = {".x", ".y", ".z", ".w"}; return c[k]; }
+  static std::string comp8(const std::string& r, int k) { return r + (k < 2 ? "a" : "b") + (k % 2 == 0 ? ".x" : ".y"); }
+
+  // The lane that created a group writes its key tuple: the row's columns are re-read (all loads of 16 columns in flight
+  // at once, then their key-id lookups, then the stores — two memory round trips per 16 columns instead of three per column).
+  void write_key_fn() {
+    o << "__device__ __forceinline__ void write_key(const FdbHashArgs& h, const unsigned char* smem, long long row, uint64_t slot, unsigned long long vmask) {\n";
+    o << "  const __attribute__((address_space(4))) FdbHashCol* hc = (const __attribute__((address_space(4))) FdbHashCol*)h.hcols;\n";
+    o << "  uint32_t* dst = h.keys + slot * (uint64_t)h.key_words;\n";
+    o << "  for (int w = 2; w < h.key_words; w++) dst[w] = 0u;  // columns this record does not carry are NULL\n";
+    o << "  dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);\n";
+    o << "  const uint32_t vsh = (uint32_t)(row & 7);\n";
+    const size_t G = 16;
+    for (size_t c0 = 0; c0 < s.cols.size(); c0 += G) {
+      const size_t c1 = std::min(s.cols.size(), c0 + G);
+      o << "  {\n";
+      for (size_t c = c0; c < c1; c++) {
+        if (s.cols[c].kind == 0) o << "    const uint32_t x" << c << " = as_global(reinterpret_cast<const uint32_t*>(hc[" << c << "].values))[row];\n";
+        else o << "    const unsigned long long x" << c << " = as_global(reinterpret_cast<const unsigned long long*>(hc[" << c << "].values))[row];\n";
+        if (s.cols[c].has_validity) o << "    const uint32_t v" << c << " = as_global(hc[" << c << "].validity)[row >> 3];\n";
+      }
+      for (size_t c = c0; c < c1; c++) {
+        const std::string ok = s.cols[c].has_validity ? ("((v" + std::to_string(c) + " >> vsh) & 1u)") : "true";
+        if (s.cols[c].kind == 0) {
+          const std::string lut = s.cols[c].lut_in_lds ? ("reinterpret_cast<const uint32_t*>(smem + hc[" + std::to_string(c) + "].lut_lds)") : ("as_global(hc[" + std::to_string(c) + "].lut)");
+          o << "    const uint32_t i" << c << " = " << ok << " ? " << lut << "[x" << c << "] : 0u;\n";
+        }
+      }
+      for (size_t c = c0; c < c1; c++) {
+        const std::string ok = s.cols[c].has_validity ? ("((v" + std::to_string(c) + " >> vsh) & 1u)") : "true";
+        if (s.cols[c].kind == 0) o << "    dst[hc[" << c << "].word] = i" << c << ";\n";
+        else o << "    { const unsigned long long y = " << ok << " ? x" << c << " : 0ull; dst[hc[" << c << "].word] = (uint32_t)y; dst[hc[" << c << "].word + 1] = (uint32_t)(y >> 32); }\n";
+      }
+      o << "  }\n";
+    }
+    o << "}\n";
+  }
+
+  std::string source() {
+    const int BLK = 256, TILE = BLK * 4, GROUP = 8;
+    o << "#define FDB_DEVICE_HELPERS 1\n#include \"fdb_kernels.h\"\n" << kPreamble << kHashPreamble;
+    write_key_fn();
+    o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") void fdb_hash_kernel(const FdbHashArgs h) {\n";
+    o << "  extern __shared__ __align__(16) unsigned char smem[];\n  __shared__ unsigned int s_new;\n";
+    o << "  const FdbScanArgs& a = h.base;\n  // descriptors are read through the constant address space: scalar loads, no vector registers\n  const __attribute__((address_space(4))) FdbHashCol* hc = (const __attribute__((address_space(4))) FdbHashCol*)h.hcols;\n  const uint32_t tid = threadIdx.x;\n  if (tid == 0) s_new = 0;\n";
+    for (size_t l = 0; l < s.leaves.size(); l++) {
+      o << "  const long long K_lit" << l << " = a.leaves[" << l << "].lit; const uint32_t K_len" << l << " = a.leaves[" << l << "].lut_len, K_lds" << l << " = a.leaves[" << l
+        << "].lut_lds; const int K_op" << l << " = a.leaves[" << l << "].op; const uint8_t* K_lut" << l << " = a.leaves[" << l << "].lut;\n";
+      o << "  (void)K_lit" << l << "; (void)K_len" << l << "; (void)K_lds" << l << "; (void)K_op" << l << "; (void)K_lut" << l << ";\n";
+      if (s.leaves[l].kind == FDB_LEAF_DICT_LUT && s.leaves[l].lut_in_lds)
+        o << "  for (uint32_t i = tid; i < K_len" << l << "; i += " << BLK << ") smem[K_lds" << l << " + i] = as_global(K_lut" << l << ")[i];\n";
+    }
+    for (size_t c = 0; c < s.cols.size(); c++)
+      if (s.cols[c].kind == 0 && s.cols[c].lut_in_lds)
+        o << "  { uint32_t* dst = reinterpret_cast<uint32_t*>(smem + hc[" << c << "].lut_lds); const uint32_t n = hc[" << c << "].lut_len; const uint32_t* src = hc[" << c
+          << "].lut; for (uint32_t i = tid; i < n; i += " << BLK << ") dst[i] = as_global(src)[i]; }\n";
+    o << "  __syncthreads();\n";
+    o << "  const int ew = h.entry_words;\n  const long long n_tiles = (h.row_end - h.row_begin + " << TILE - 1 << ") / " << TILE << ";\n";
+    o << "  const uint32_t lane_shb = (tid & 1u) * 4u;\n";
+    o << "  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {\n";
+    o << "    const long long r0 = h.row_begin + tile * " << TILE << "LL;\n    const long long left = h.row_end - r0 - (long long)tid * 4;\n    if (left <= 0) continue;\n";
+    o << "    const size_t o4 = (size_t)r0 * 4, o8 = (size_t)r0 * 8, ob = (size_t)(r0 >> 3);\n";
+    // The lane offsets are made opaque per tile: otherwise the compiler pre-computes one 64-bit (column base + lane offset)
+    // address pair per column and validity bitmap outside the loop (≈130 VGPRs for 32 columns) instead of using the
+    // scalar-base + 32-bit-vector-offset form of global_load.
+    o << "    uint32_t lane_off4 = tid * 16u, lane_off8 = tid * 32u, lane_offb = tid >> 1;\n    asm volatile(\"\" : \"+v\"(lane_off4), \"+v\"(lane_off8), \"+v\"(lane_offb));\n";
+    o << "    uint32_t sel = left >= 4 ? 0xFu : ((1u << (int)left) - 1u);\n";
+    // filter: one register set per leaf
+    for (size_t l = 0; l < s.leaves.size(); l++) {
+      const JitLeaf& L = s.leaves[l];
+      if (L.kind == FDB_LEAF_CONST) continue;
+      const std::string r = "f" + std::to_string(l);
+      if (L.kind != FDB_LEAF_VALIDITY) {
+        if (L.wide) {
+          o << "    const u64x2 " << r << "a = ld8(reinterpret_cast<const char*>(a.leaves[" << l << "].values) + o8, lane_off8);\n";
+          o << "    const u64x2 " << r << "b = ld8(reinterpret_cast<const char*>(a.leaves[" << l << "].values) + o8, lane_off8 + 16u);\n";
+        } else {
+          o << "    const u32x4 " << r << " = ld4(reinterpret_cast<const char*>(a.leaves[" << l << "].values) + o4, lane_off4);\n";
+        }
+      }
+      if (s.leaf_validity[l]) o << "    const uint32_t " << r << "_m = ldv(a.leaves[" << l << "].validity + ob, lane_offb, lane_shb);\n";
+      else o << "    const uint32_t " << r << "_m = 0xFu;\n";
+    }
+    if (!s.code.empty()) {
+      o << "    sel &= " << Gen::filter_expr_of(s.code, [&](int l) { return Gen::leaf_expr_of(s.leaves[(size_t)l], l, "f" + std::to_string(l)); }) << ";\n";
+      o << "    if (sel == 0u) continue;\n";
+    }
+    // aggregated columns: requested now, consumed after the probe
+    for (size_t j = 0; j < s.aggs.size(); j++) {
+      if (s.aggs[j].func == FDB_AGG_COUNT) continue;
+      const std::string r = "g" + std::to_string(j);
+      o << "    const u64x2 " << r << "a = ld8(reinterpret_cast<const char*>(a.aggs[" << j << "].values) + o8, lane_off8);\n";
+      o << "    const u64x2 " << r << "b = ld8(reinterpret_cast<const char*>(a.aggs[" << j << "].values) + o8, lane_off8 + 16u);\n";
+      if (s.agg_validity[j]) o << "    const uint32_t " << r << "_m = ldv(a.aggs[" << j << "].validity + ob, lane_offb, lane_shb);\n";
+      else o << "    const uint32_t " << r << "_m = 0xFu;\n";
+    }
+    o << "    unsigned long long h1_0 = 0, h1_1 = 0, h1_2 = 0, h1_3 = 0, h2_0 = 0, h2_1 = 0, h2_2 = 0, h2_3 = 0, vm_0 = 0, vm_1 = 0, vm_2 = 0, vm_3 = 0;\n";
+    for (size_t c0 = 0; c0 < s.cols.size(); c0 += GROUP) {
+      const size_t c1 = std::min(s.cols.size(), c0 + GROUP);
+      o << "    {\n";
+      for (size_t c = c0; c < c1; c++) {
+        const JitHashCol& C = s.cols[c];
+        const std::string r = "k" + std::to_string(c);
+        if (C.kind == 0) o << "      const u32x4 " << r << " = ld4(reinterpret_cast<const char*>(hc[" << c << "].values) + o4, lane_off4);\n";
+        else {
+          o << "      const u64x2 " << r << "a = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, lane_off8);\n";
+          o << "      const u64x2 " << r << "b = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, lane_off8 + 16u);\n";
+        }
+        if (C.has_validity) o << "      const uint32_t " << r << "_m = ldv(hc[" << c << "].validity + ob, lane_offb, lane_shb);\n";
+        else o << "      const uint32_t " << r << "_m = 0xFu;\n";
+      }
+      for (size_t c = c0; c < c1; c++) {
+        const JitHashCol& C = s.cols[c];
+        const std::string r = "k" + std::to_string(c);
+        // (the multipliers are made opaque per tile for the same reason as the lane offsets: their VGPR copies — 4 per column —
+        // would otherwise be hoisted out of the tile loop and stay live across it)
+        o << "      {\n        unsigned long long K1 = hc[" << c << "].k1, K2 = hc[" << c << "].k2; asm volatile(\"\" : \"+s\"(K1), \"+s\"(K2));\n        const unsigned long long bit = 1ull << hc[" << c
+          << "].gi;\n";
+        if (C.kind == 0) {
+          if (C.lut_in_lds) o << "        const uint32_t* L = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
+          else o << "        const uint32_t* L = hc[" << c << "].lut;\n";
+          for (int k = 0; k < 4; k++) {
+            o << "        { const uint32_t id = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_in_lds ? "L" : "as_global(L)") << "[" << r << comp4(k) << "] : 0u; fp_add32(h1_" << k << ", h2_"
+              << k << ", K1, K2, id); if (id != 0u) vm_" << k << " |= bit; }\n";
+          }
+        } else {
+          for (int k = 0; k < 4; k++)
+            o << "        if ((" << r << "_m >> " << k << ") & 1u) { fp_add(h1_" << k << ", h2_" << k << ", K1, K2, " << comp8(r, k) << "); vm_" << k << " |= bit; }\n";
+        }
+        o << "      }\n";
+      }
+      // keep the next group's loads below this point: hoisting all 32 columns' loads to the top of the tile costs ≈390 VGPRs
+      // and force the fingerprint updates to happen HERE: LLVM otherwise sinks all 32 columns' multiply-adds into the per-row
+      // `if (selected)` blocks below and keeps 4 × 32 key ids live until then
+      o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3), \"+v\"(vm_0), \"+v\"(vm_1), \"+v\"(vm_2), \"+v\"(vm_3) :: \"memory\");\n    }\n";
+    }
+    for (int k = 0; k < 4; k++) o << "    fp_final(h1_" << k << ", h2_" << k << ");\n";
+    if (s.ablate & 1) o << "    if ((h1_0 ^ h2_0 ^ h1_1 ^ h2_1 ^ h1_2 ^ h2_2 ^ h1_3 ^ h2_3) == 0x1234567ull) h.table[0] = vm_0 ^ vm_1 ^ vm_2 ^ vm_3;\n    continue;\n";  // tuning aid
+    // Probe: the home entries of the 4 rows are requested together (one memory round trip for the common case "group exists
+    // and sits in its home slot"); rows that miss there take the general find-or-insert path.
+    for (int k = 0; k < 4; k++) o << "    uint64_t slot_" << k << " = h1_" << k << " & h.mask; unsigned long long p_" << k << " = 0, q_" << k << " = 0;\n";
+    for (int k = 0; k < 4; k++)
+      o << "    if ((sel >> " << k << ") & 1u) { p_" << k << " = __hip_atomic_load(h.table + slot_" << k << " * (uint64_t)ew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q_" << k
+        << " = __hip_atomic_load(h.table + slot_" << k << " * (uint64_t)ew + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n";
+    o << "    uint32_t ins_mask = 0;\n";
+    for (int k = 0; k < 4; k++) {
+      o << "    if ((sel >> " << k << ") & 1u) {\n";
+      o << "      if (!(p_" << k << " == h1_" << k << " && q_" << k << " == h2_" << k << ")) { bool ins; slot_" << k << " = hash_find_or_insert(h.table, h.mask, ew, h1_" << k << ", h2_" << k
+        << ", ins); if (ins) ins_mask |= " << (1 << k) << "u; }\n";
+      o << "      unsigned long long* e = h.table + slot_" << k << " * (uint64_t)ew;\n";
+      if (!(s.ablate & 2)) o << "      atomicAdd(e + 2, 1ull);\n";
+      for (size_t j = 0; j < s.aggs.size(); j++) {
+        const JitAgg& A = s.aggs[j];
+        if (A.func == FDB_AGG_COUNT || (s.ablate & 2)) continue;
+        const std::string r = "g" + std::to_string(j);
+        const std::string raw = "(((" + r + "_m >> " + std::to_string(k) + ") & 1u) ? " + comp8(r, k) + " : 0ull)";
+        const std::string acc = "(e + " + std::to_string(3 + j) + ")";
+        if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      atomicAdd(reinterpret_cast<double*>" << acc << ", __longlong_as_double((long long)" << raw << "));\n";
+        else if (A.func == FDB_AGG_SUM) o << "      atomicAdd(" << acc << ", " << raw << ");\n";
+        else {
+          const std::string key = A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw);
+          o << "      " << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>" << acc << ", " << key << ");\n";
+        }
+      }
+      o << "    }\n";
+    }
+    // key tuples of the groups this lane created
+    o << "    while (ins_mask != 0u) {\n      const int k = __builtin_ctz(ins_mask);\n      ins_mask &= ins_mask - 1u;\n";
+    o << "      const uint64_t slot = k == 0 ? slot_0 : k == 1 ? slot_1 : k == 2 ? slot_2 : slot_3;\n      const unsigned long long vm = k == 0 ? vm_0 : k == 1 ? vm_1 : k == 2 ? vm_2 : vm_3;\n";
+    o << "      write_key(h, smem, r0 + (long long)tid * 4 + k, slot, vm);\n      atomicAdd(&s_new, 1u);\n    }\n";
+    o << "  }\n  __syncthreads();\n  if (tid == 0 && s_new != 0) atomicAdd(h.n_groups, (unsigned long long)s_new);\n}\n";
+    return o.str();
+  }
+};
+
 }  // namespace
 
 std::string JitShape::key(bool with_validity) const {
@@ -364,15 +555,18 @@ int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes) {
   return occ;
 }
 
-hipFunction_t jit_get(const JitShape& shape) {
+namespace {
+// Process cache → disk cache → hiprtc; `key` identifies the shape, `make_source` is only called on a process-cache miss.
+template <typename F>
+hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make_source) {
   if (g_disabled || std::getenv("FDB_NO_JIT") != nullptr) return nullptr;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const std::string ckey = std::to_string(dev) + "|" + shape.key();  // a loaded module belongs to one device
+  const std::string ckey = std::to_string(dev) + "|" + kernel_name + "|" + key;  // a loaded module belongs to one device
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_cache.find(ckey);
   if (it != g_cache.end()) return it->second;
-  const std::string src = jit_source(shape);
+  const std::string src = make_source();
   std::vector<char> code;
   char name[64];
   std::snprintf(name, sizeof name, "/k_%016llx_%zu.hsaco", (unsigned long long)(fnv(src) ^ (fnv(kKernelsHeader) * 31)), src.size());
@@ -384,7 +578,7 @@ hipFunction_t jit_get(const JitShape& shape) {
   if (code.empty()) {
     std::string log;
     if (!compile(src, &code, &log)) {
-      std::fprintf(stderr, "[frostdb_amd] plan kernel specialisation failed, using the interpreting kernel: %s\n", log.c_str());
+      std::fprintf(stderr, "[frostdb_amd] %s specialisation failed, using the interpreting kernel: %s\n", kernel_name, log.c_str());
       if (std::getenv("FDB_JIT_DEBUG")) std::fprintf(stderr, "%s\n", src.c_str());
       g_cache.emplace(ckey, nullptr);
       return nullptr;
@@ -395,13 +589,63 @@ hipFunction_t jit_get(const JitShape& shape) {
   }
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, "fdb_plan_kernel") != hipSuccess) {
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, kernel_name) != hipSuccess) {
     (void)hipGetLastError();
-    std::fprintf(stderr, "[frostdb_amd] could not load a specialised plan kernel, using the interpreting kernel\n");
+    std::fprintf(stderr, "[frostdb_amd] could not load a specialised %s, using the interpreting kernel\n", kernel_name);
     fn = nullptr;
   }
   g_cache.emplace(ckey, fn);
   return fn;
+}
+}  // namespace
+
+hipFunction_t jit_get(const JitShape& shape) {
+  return get_kernel(shape.key(), "fdb_plan_kernel", [&] { return jit_source(shape); });
+}
+
+std::string JitHashShape::key() const {
+  std::ostringstream k;
+  k << "a" << ablate << "|";
+  for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g');
+  k << '|';
+  for (size_t l = 0; l < leaves.size(); l++) {
+    const JitLeaf& L = leaves[l];
+    k << L.kind << ',' << L.wide << ',' << (L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64 ? L.op : 0) << ',' << L.lut_in_lds << ',' << leaf_validity[l] << ';';
+  }
+  k << '|';
+  for (uint8_t c : code) k << (int)c << ',';
+  k << '|';
+  for (size_t j = 0; j < aggs.size(); j++) k << aggs[j].func << ',' << aggs[j].type << ',' << agg_validity[j] << ';';
+  return k.str();
+}
+
+JitHashShape jit_hash_shape(const FdbHashArgs& h, const FdbHashCol* hcols) {
+  JitHashShape s;
+  const FdbScanArgs& a = h.base;
+  for (int c = 0; c < h.n_hcols; c++) s.cols.push_back({hcols[c].kind, hcols[c].validity != nullptr, hcols[c].kind == 0 && hcols[c].lut_lds != FDB_NO_LDS});
+  for (int l = 0; l < a.n_leaves; l++) {
+    const FdbLeaf& L = a.leaves[l];
+    const bool wide = L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64;
+    s.leaves.push_back({L.kind, 0, wide ? 1 : 0, L.op, L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS});
+    s.leaf_validity.push_back(L.validity != nullptr);
+  }
+  s.code.assign(a.code, a.code + a.n_code);
+  for (int j = 0; j < a.n_aggs; j++) {
+    s.aggs.push_back({a.aggs[j].func, a.aggs[j].type, -1});
+    s.agg_validity.push_back(a.aggs[j].validity != nullptr);
+  }
+  return s;
+}
+
+std::string jit_hash_source(const JitHashShape& shape) { return HashGen(shape).source(); }
+
+hipFunction_t jit_hash_get(const JitHashShape& shape) {
+  return get_kernel(shape.key(), "fdb_hash_kernel", [&] { return jit_hash_source(shape); });
+}
+
+hipError_t jit_hash_launch(hipFunction_t fn, const FdbHashArgs& args, int grid, size_t lds_bytes, hipStream_t stream) {
+  void* kargs[] = {(void*)&args};
+  return hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds_bytes, stream, kargs, nullptr);
 }
 
 // Geometry for `shape`. Measured on MI355X (tools/sweep_geometry.sh): a streaming scan is fastest when ≈64 KB of loads

@@ -30,6 +30,25 @@ struct JitShape {
   std::string key(bool with_validity = true) const;
 };
 
+// Shape of a high-cardinality (hash table) scan: fdb_hash_kernel.
+struct JitHashCol { int kind = 0; bool has_validity = false, lut_in_lds = false; };
+struct JitHashShape {
+  std::vector<JitHashCol> cols;
+  std::vector<JitLeaf> leaves;  // slot / wide describe the leaf's own column (wide = 8-byte values)
+  std::vector<bool> leaf_validity;
+  std::vector<uint8_t> code;
+  std::vector<JitAgg> aggs;
+  std::vector<bool> agg_validity;
+  int ablate = 0;  // tuning aid (tools/cfg5_ablate.py): 1 = stream + fingerprint only, 2 = no count / aggregate atomics
+  std::string key() const;
+};
+// `hcols` = host copy of args.hcols.
+JitHashShape jit_hash_shape(const FdbHashArgs& args, const FdbHashCol* hcols);
+std::string jit_hash_source(const JitHashShape& shape);
+hipFunction_t jit_hash_get(const JitHashShape& shape);
+// 256-thread workgroups, 1 024-row tiles.
+hipError_t jit_hash_launch(hipFunction_t fn, const FdbHashArgs& args, int grid, size_t lds_bytes, hipStream_t stream);
+
 // The shape of one record's slot-assigned argument block.
 JitShape jit_shape(const FdbScanArgs& a, bool two_phase, int block);
 // Folds `other` into `into` when the two differ at most in which slots carry validity bitmaps; false otherwise.

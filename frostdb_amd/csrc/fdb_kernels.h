@@ -164,6 +164,56 @@ struct FdbHashArgs {
   int32_t _pad;
 };
 
+// ---- device helpers of the hash path (shared by fdb_kernels.hip and the kernels fdb_jit.cpp generates) ---------------
+#ifdef FDB_DEVICE_HELPERS  // defined by translation units that hold device code
+__device__ __forceinline__ unsigned long long fmix64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return k;
+}
+// Per-column contribution to the 128-bit fingerprint, summed over the non-NULL columns (order independent; a column
+// that appears later leaves older fingerprints unchanged). Multilinear hashing: Σ_c x_c · K_c mod 2^64 with one odd
+// 64-bit constant per column and per half — strongly universal, and one v_mad_u64_u32 pair per half for a 32-bit key
+// id. int64 keys go through fmix64 first. fp_final adds the avalanche.
+__device__ __forceinline__ void fp_add32(unsigned long long& h1, unsigned long long& h2, unsigned long long k1, unsigned long long k2, uint32_t id) {
+  h1 += (unsigned long long)id * k1;
+  h2 += (unsigned long long)id * k2;
+}
+__device__ __forceinline__ void fp_add(unsigned long long& h1, unsigned long long& h2, unsigned long long k1, unsigned long long k2, unsigned long long v) {
+  const unsigned long long x = fmix64(v ^ 0x9FB21C651E98DF25ULL) | 1ull;
+  h1 += x * k1;
+  h2 += fmix64(x) * k2;
+}
+__device__ __forceinline__ void fp_final(unsigned long long& h1, unsigned long long& h2) {
+  h1 = fmix64(h1 + 0x243F6A8885A308D3ULL); h2 = fmix64(h2 ^ 0xA5A5A5A5A5A5A5A5ULL);
+  if (h1 == 0) h1 = 1;
+  if (h2 == 0) h2 = 1;
+}
+
+// Finds the entry of fingerprint (h1, h2), inserting it if absent. Returns the slot and whether THIS lane inserted.
+__device__ __forceinline__ uint64_t hash_find_or_insert(unsigned long long* table, uint64_t mask, int ew, unsigned long long h1,
+                                                        unsigned long long h2, bool& inserted) {
+  uint64_t slot = h1 & mask;
+  inserted = false;
+  for (;;) {
+    unsigned long long* e = table + slot * (uint64_t)ew;
+    unsigned long long prev = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == 0) prev = atomicCAS(e, 0ull, h1);
+    if (prev == 0) {  // this lane owns the slot: publish the high half right away
+      __hip_atomic_store(e + 1, h2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      inserted = true;
+      return slot;
+    }
+    if (prev == h1) {
+      const unsigned long long v = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v == h2) return slot;
+      if (v == 0) { __builtin_amdgcn_s_sleep(1); continue; }  // the owner has not published yet: look again
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+#endif  // FDB_DEVICE_HELPERS
+
 #define FDB_HASH_BLOCK 256
 #ifndef FDB_DEVICE_ONLY
 hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t lds_bytes, hipStream_t stream);

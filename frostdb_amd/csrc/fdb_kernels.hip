@@ -16,6 +16,7 @@
 // an 8-byte value column R/2 of them, a validity bitmap one byte.
 #include <hip/hip_runtime.h>
 
+#define FDB_DEVICE_HELPERS 1
 #include "fdb_kernels.h"
 
 namespace {
@@ -728,52 +729,7 @@ __global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __re
 // writes the group's key tuple (dictionary key ids / int64 values) once, for Finish.
 // No LDS staging of aggregates here: with ~10 rows per group spread uniformly, a per-workgroup cache never hits.
 // =========================================================================================================
-__device__ __forceinline__ unsigned long long fmix64(unsigned long long k) {
-  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
-  return k;
-}
-// Per-column contribution to the 128-bit fingerprint, summed over the non-NULL columns (order independent; a column
-// that appears later leaves older fingerprints unchanged). Multilinear hashing: Σ_c x_c · K_c mod 2^64 with one odd
-// 64-bit constant per column and per half — strongly universal, and one v_mad_u64_u32 pair per half for a 32-bit key
-// id. int64 keys go through fmix64 first. fp_final adds the avalanche.
-__device__ __forceinline__ void fp_add32(unsigned long long& h1, unsigned long long& h2, unsigned long long k1, unsigned long long k2, uint32_t id) {
-  h1 += (unsigned long long)id * k1;
-  h2 += (unsigned long long)id * k2;
-}
-__device__ __forceinline__ void fp_add(unsigned long long& h1, unsigned long long& h2, unsigned long long k1, unsigned long long k2, unsigned long long v) {
-  const unsigned long long x = fmix64(v ^ 0x9FB21C651E98DF25ULL) | 1ull;
-  h1 += x * k1;
-  h2 += fmix64(x) * k2;
-}
-__device__ __forceinline__ void fp_final(unsigned long long& h1, unsigned long long& h2) {
-  h1 = fmix64(h1 + 0x243F6A8885A308D3ULL); h2 = fmix64(h2 ^ 0xA5A5A5A5A5A5A5A5ULL);
-  if (h1 == 0) h1 = 1;
-  if (h2 == 0) h2 = 1;
-}
-
-// Finds the entry of fingerprint (h1, h2), inserting it if absent. Returns the slot and whether THIS lane inserted.
-__device__ __forceinline__ uint64_t hash_find_or_insert(unsigned long long* table, uint64_t mask, int ew, unsigned long long h1,
-                                                        unsigned long long h2, bool& inserted) {
-  uint64_t slot = h1 & mask;
-  inserted = false;
-  for (;;) {
-    unsigned long long* e = table + slot * (uint64_t)ew;
-    unsigned long long prev = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == 0) prev = atomicCAS(e, 0ull, h1);
-    if (prev == 0) {  // this lane owns the slot: publish the high half right away
-      __hip_atomic_store(e + 1, h2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      inserted = true;
-      return slot;
-    }
-    if (prev == h1) {
-      const unsigned long long v = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (v == h2) return slot;
-      if (v == 0) { __builtin_amdgcn_s_sleep(1); continue; }  // the owner has not published yet: look again
-    }
-    slot = (slot + 1) & mask;
-  }
-}
-
+// (fingerprint and probe helpers: fdb_kernels.h, shared with the run-time generated hash kernels)
 // One row per lane. While folding the key columns into the fingerprint each lane also parks its key tuple in LDS
 // ([word][lane], conflict-free), so that a lane that turns out to be the FIRST to see its group can write the tuple to
 // the key store without re-reading 32 columns (≈10 % of the rows of cfg 5 create a group).
@@ -839,7 +795,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
         if (kind[u] == 0) {
           uint32_t id = 0;
           if (valid) id = lds[u] != FDB_NO_LDS ? reinterpret_cast<const uint32_t*>(smem + lds[u])[idx[u]] : as_global(lutg[u])[idx[u]];
-          kstage[word[u] * FDB_HASH_BLOCK + tid] = id;
+          if (!(a.ablate & 4)) kstage[word[u] * FDB_HASH_BLOCK + tid] = id;
           fp_add32(h1, h2, k1[u], k2[u], id);  // id 0 (NULL) contributes nothing
           if (id != 0) vmask |= 1ull << gi[u];
         } else {
@@ -851,6 +807,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
       }
     }
     fp_final(h1, h2);
+    if (a.ablate & 1) { if ((h1 ^ h2) == 0x1234567ull) h.table[0] = vmask; continue; }  // tuning aid: stream + fingerprint only
     bool inserted;
     const uint64_t slot = hash_find_or_insert(h.table, h.mask, ew, h1, h2, inserted);
     if (inserted) {
@@ -860,6 +817,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
       atomicAdd(&s_new, 1u);
     }
     unsigned long long* e = h.table + slot * (uint64_t)ew;
+    if (a.ablate & 2) continue;  // tuning aid: probe only
     atomicAdd(e + 2, 1ull);
     for (int j = 0; j < a.n_aggs; j++) {
       const FdbAgg& A = a.aggs[j];

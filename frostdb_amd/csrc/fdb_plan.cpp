@@ -24,19 +24,6 @@
 
 namespace fdb {
 
-namespace {
-struct PhaseTimer {  // FDB_PROFILE=1: per-phase host microseconds of push_batch on stderr (tuning aid)
-  bool on;
-  std::chrono::steady_clock::time_point t;
-  PhaseTimer() : on(std::getenv("FDB_PROFILE") != nullptr), t(std::chrono::steady_clock::now()) {}
-  void mark(const char* what) {
-    if (!on) return;
-    auto n = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[fdb] %-14s %8.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
-    t = n;
-  }
-};
-}  // namespace
 
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) throw Error(e == hipErrorOutOfMemory ? FDB_ERR_OOM : FDB_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));

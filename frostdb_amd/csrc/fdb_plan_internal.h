@@ -2,6 +2,9 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -11,6 +14,18 @@
 namespace fdb {
 
 inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PhaseTimer {  // FDB_PROFILE=1: per-phase host microseconds on stderr (tuning aid)
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PhaseTimer() : on(std::getenv("FDB_PROFILE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[fdb] %-20s %8.1f us\n", what, std::chrono::duration<double, std::micro>(n - t).count());
+    t = n;
+  }
+};
 
 struct Blob {  // LUTs of one batch, shipped with one copy
   std::vector<uint8_t> bytes;

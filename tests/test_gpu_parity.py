@@ -527,7 +527,7 @@ def window_records_gpu(bucket):
 
 
 @pytest.mark.parametrize("case", G.WINDOW_CASES, ids=[c["id"] for c in G.WINDOW_CASES])
-def test_golden_window_int64_group_keys(pp, case):
+def test_golden_window_int64_group_keys(pp, variant, case):
     """logictest/testdata/exec/aggregate/window: GROUP BY an int64 time bucket (the bucket column is materialised by
     the harness the way the reference's pre-aggregate Projection would) — exercises int64 keys in the hash table."""
     d = run_gpu(pp, window_records_gpu(case["bucket"]), None, case["aggs"], case["groups"])
@@ -568,7 +568,7 @@ def key_cols_of(batches, extra=()):
     return names
 
 
-def test_hash_path_many_columns_vs_oracle(pp):
+def test_hash_path_many_columns_vs_oracle(pp, variant):
     rng = np.random.default_rng(404)
     aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("value")), Max(Col("value")), Sum(Col("floatvalue")), Min(Col("floatvalue"))]
     batches = [many_label_batch(rng, 30_000, 12, 3, n_groups=4000), many_label_batch(rng, 20_000, 12, 3, n_groups=3000)]
@@ -579,7 +579,7 @@ def test_hash_path_many_columns_vs_oracle(pp):
         assert_same_result(got, want, cols, float_cols={"sum(floatvalue)"})
 
 
-def test_hash_path_growth_and_filter(pp):
+def test_hash_path_growth_and_filter(pp, variant):
     """> 100 k distinct groups: the table grows (device re-hash) several times while batches arrive; a filter runs in
     front of the hash scan; string + int64 key columns together."""
     rng = np.random.default_rng(405)
@@ -594,7 +594,7 @@ def test_hash_path_growth_and_filter(pp):
     assert_same_result(got, want, cols)
 
 
-def test_dense_to_hash_migration_and_merge(pp):
+def test_dense_to_hash_migration_and_merge(pp, variant):
     """First record: two label columns (dense table). Second record brings ten more label columns → the plan migrates
     its dense state into the hash table. Then a second chain in hash mode is merged in (Synchronizer + final stage)."""
     rng = np.random.default_rng(406)
@@ -629,7 +629,7 @@ def test_dense_to_hash_migration_and_merge(pp):
     assert_same_result(got, want, cols)
 
 
-def test_hash_path_properties_at_scale(pp):
+def test_hash_path_properties_at_scale(pp, variant):
     """2 M rows, 16 label columns, 300 k groups: Σcount = rows, group count = distinct tuples, sums add up."""
     rng = np.random.default_rng(407)
     n, n_groups = 2_000_000, 300_000
