@@ -67,10 +67,10 @@ bool match_group(const GroupMatcher& m, const std::string& field) {  // logicalp
 // DeviceBatch
 // ---------------------------------------------------------------------------------------------------------
 DeviceBatch::~DeviceBatch() {
-  if (arena) {
-    (void)hipSetDevice(device);
-    (void)hipFree(arena);
-  }
+  if (arena == nullptr) return;
+  if (arena_ctx != nullptr) { arena_ctx->dev_free(arena); return; }
+  (void)hipSetDevice(device);
+  (void)hipFree(arena);
 }
 
 int DeviceBatch::find(const std::string& name) const {
@@ -81,7 +81,7 @@ int DeviceBatch::find(const std::string& name) const {
 }
 
 std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device, const std::function<bool(const std::string&)>* want,
-                                          hipStream_t stream) {
+                                          hipStream_t stream, Context* ctx) {
   std::unique_ptr<DeviceBatch> b(new DeviceBatch());
   b->device = device;
   b->rows = view.rows;
@@ -116,10 +116,17 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     b->cols.push_back(std::move(d));
   }
   if (total > 0) {
-    hip_check(hipMalloc(&b->arena, total), "hipMalloc(batch arena)");
+    if (ctx != nullptr) { b->arena = ctx->dev_alloc(total); b->arena_ctx = ctx; }
+    else hip_check(hipMalloc(&b->arena, total), "hipMalloc(batch arena)");
     b->arena_bytes = total;
   }
-  std::vector<uint8_t> tmp;
+  // transient batches: every copy is queued on `stream`; re-packed buffers stay alive until the one wait at the end
+  std::vector<std::vector<uint8_t>> keep_bits;
+  std::vector<std::vector<uint32_t>> keep_idx;
+  auto h2d = [&](void* dst, const void* src, size_t bytes, const char* what) {
+    if (ctx != nullptr) hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream), what);
+    else hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), what);
+  };
   for (const Piece& p : pieces) {
     const HostColView& c = view.cols[p.col];
     DevColumn& d = b->cols[p.col];
@@ -127,14 +134,19 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     if (p.validity) {
       d.d_validity = dst;
       if (p.bytes == 0) continue;
-      tmp.assign(p.bytes, 0);
-      copy_bits(c.validity, c.offset, c.length, tmp.data());
-      hip_check(hipMemcpy(dst, tmp.data(), p.bytes, hipMemcpyHostToDevice), "hipMemcpy(validity)");
+      if ((c.offset & 7) == 0) {  // byte-aligned bitmap: copied as is (bits past `length` are never looked at)
+        h2d(dst, c.validity + (c.offset >> 3), p.bytes, "hipMemcpy(validity)");
+      } else {
+        keep_bits.emplace_back(p.bytes, 0);
+        copy_bits(c.validity, c.offset, c.length, keep_bits.back().data());
+        h2d(dst, keep_bits.back().data(), p.bytes, "hipMemcpy(validity)");
+      }
     } else {
       d.d_values = dst;
       if (p.bytes == 0) continue;
       if (c.kind == ColKind::DICT && c.index_width != 4) {
-        std::vector<uint32_t> wide((size_t)c.length);
+        keep_idx.emplace_back((size_t)c.length);
+        std::vector<uint32_t>& wide = keep_idx.back();
         for (int64_t i = 0; i < c.length; i++) {
           switch (c.index_width) {
             case 1: wide[(size_t)i] = ((const uint8_t*)c.values)[c.offset + i]; break;
@@ -142,15 +154,15 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
             default: wide[(size_t)i] = (uint32_t)((const uint64_t*)c.values)[c.offset + i]; break;
           }
         }
-        hip_check(hipMemcpy(dst, wide.data(), p.bytes, hipMemcpyHostToDevice), "hipMemcpy(indices)");
+        h2d(dst, wide.data(), p.bytes, "hipMemcpy(indices)");
       } else {
         const size_t w = c.kind == ColKind::DICT ? 4 : 8;
-        hip_check(hipMemcpy(dst, (const unsigned char*)c.values + (size_t)c.offset * w, p.bytes, hipMemcpyHostToDevice), "hipMemcpy(values)");
+        h2d(dst, (const unsigned char*)c.values + (size_t)c.offset * w, p.bytes, "hipMemcpy(values)");
       }
     }
   }
   for (const DevColumn& d : b->cols) b->payload_bytes += d.value_bytes + d.validity_bytes;
-  (void)stream;
+  if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty())) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
   return b;
 }
 
@@ -591,9 +603,9 @@ void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
   HostRecordView view;
   view_record(array, schema, &view);
   std::function<bool(const std::string&)> want = [this](const std::string& n) { return references(n); };
-  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_);
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_, ctx_);
   push_batch(*b);
-  sync();  // the staged copy is freed when `b` goes out of scope
+  sync();  // the caller's buffers are only borrowed (table.go:808): every copy has landed; the arena returns to the block cache
 }
 
 void Plan::push_batch(const DeviceBatch& b) {

@@ -41,6 +41,7 @@ struct DeviceBatch {
   std::vector<DevColumn> cols;
   void* arena = nullptr;        // one allocation per record
   size_t arena_bytes = 0;
+  class Context* arena_ctx = nullptr;  // transient batches (fdb_plan_push): the arena is borrowed from the plan's block cache
   int64_t payload_bytes = 0;    // Σ value_bytes + validity_bytes
   ~DeviceBatch();
   // Exactly-one-field lookup like ArrayRef.ArrowArray (binaryscalarexpr.go:22-29): -1 if absent or ambiguous.
@@ -48,8 +49,11 @@ struct DeviceBatch {
 };
 
 // Stages the columns of `view` accepted by `want(name)` (nullptr ⇒ all) to the device.
+// With `ctx`, the arena comes from (and returns to) that context's block cache and the copies are asynchronous on
+// `stream` (one synchronisation at the end) — the per-record cost of fdb_plan_push; without, a private hipMalloc
+// (resident batches, which outlive any plan).
 std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device,
-                                          const std::function<bool(const std::string&)>* want, hipStream_t stream);
+                                          const std::function<bool(const std::string&)>* want, hipStream_t stream, class Context* ctx = nullptr);
 
 struct Literal {
   int32_t type = FDB_LIT_NULL;
