@@ -118,6 +118,26 @@ int fdb_plan_merge(fdb_plan* dst, fdb_plan* src) {
   return guard(dst, [&] { dst->plan.merge_from(src->plan); });
 }
 
+int fdb_plan_group_schema(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  if (!plan || !out || !out_schema) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.group_schema(out, out_schema); });
+}
+
+int fdb_plan_seed_groups(fdb_plan* plan, struct ArrowArray* schema_record, struct ArrowSchema* schema) {
+  if (!plan || !schema_record || !schema) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.seed_groups(schema_record, schema); });
+}
+
+int fdb_plan_hash_export(fdb_plan* src, fdb_plan* layout, int32_t n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32) {
+  if (!src || !layout || !dev_rows || !counts || !row_words32) return FDB_ERR_INVALID;
+  return guard(src, [&] { src->plan.hash_export(layout->plan, n_parts, dev_rows, counts, row_words32); });
+}
+
+int fdb_plan_hash_import(fdb_plan* plan, const void* dev_rows, int64_t n_rows) {
+  if (!plan || (n_rows > 0 && !dev_rows)) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.hash_import(dev_rows, n_rows); });
+}
+
 int fdb_plan_filter(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out,
                     struct ArrowSchema* out_schema, int64_t* n_selected) {
   if (!plan) return FDB_ERR_INVALID;

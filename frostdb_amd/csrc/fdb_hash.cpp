@@ -371,9 +371,202 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   return (int64_t)n;
 }
 
+// ---- exchange of hash tables ----------------------------------------------------------------------------------------------
+void Plan::group_schema(ArrowArray* out, ArrowSchema* out_schema) {
+  std::vector<OutColumn> cols;
+  for (const GroupColState& g : gcols_) {
+    OutColumn oc;
+    oc.name = g.name;
+    oc.length = 0;
+    if (g.kind == 0) {
+      oc.format = "I";
+      oc.is_dict = true;
+      oc.dict_format = g.value_format;
+      oc.dict_offsets.resize(g.values.size() + 1);
+      int32_t off = 0;
+      for (size_t v = 0; v < g.values.size(); v++) {
+        oc.dict_offsets[v] = off;
+        oc.dict_data.insert(oc.dict_data.end(), g.values[v].begin(), g.values[v].end());
+        off += (int32_t)g.values[v].size();
+      }
+      oc.dict_offsets[g.values.size()] = off;
+    } else {
+      oc.format = "l";
+    }
+    cols.push_back(std::move(oc));
+  }
+  // the value types of the aggregated columns travel with the schema (a rank that saw no record does not know them)
+  for (const AggState& A : aggs_) {
+    if (A.func == FDB_AGG_COUNT || A.type == FDB_T_NONE) continue;
+    OutColumn oc;
+    oc.name = A.result_name;
+    oc.length = 0;
+    oc.format = A.type == FDB_T_F64 ? "g" : "l";
+    cols.push_back(std::move(oc));
+  }
+  export_record(std::move(cols), 0, out, out_schema);
+}
+
+void Plan::seed_groups(const ArrowArray* array, const ArrowSchema* schema) {
+  HostRecordView view;
+  view_record(array, schema, &view);
+  if (mode_ == TableMode::DENSE) switch_to_hash();  // (before the column set changes)
+  for (const HostColView& c : view.cols) {
+    bool is_agg = false;
+    for (AggState& A : aggs_) {
+      if (A.func == FDB_AGG_COUNT || c.name != A.result_name) continue;
+      const int32_t t = c.kind == ColKind::F64 ? FDB_T_F64 : c.kind == ColKind::I64 ? FDB_T_I64 : FDB_T_NONE;
+      if (t == FDB_T_NONE) throw Error(FDB_ERR_INVALID, "aggregate column " + c.name + " has an unsupported type");
+      if (A.type != FDB_T_NONE && A.type != t) throw Error(FDB_ERR_INVALID, "aggregation types differ between plans");
+      A.type = t;
+      is_agg = true;
+    }
+    if (is_agg) continue;
+    if (c.kind != ColKind::DICT && c.kind != ColKind::I64) throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + ": only dictionary and int64 columns can be group keys");
+    const int kind = c.kind == ColKind::DICT ? 0 : 1;
+    size_t gi = 0;
+    for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == c.name) break;
+    if (gi == gcols_.size()) {
+      GroupColState g;
+      g.name = c.name; g.kind = kind; g.cap = 1; g.stride = 0;
+      gcols_.push_back(std::move(g));
+    }
+    GroupColState& g = gcols_[gi];
+    if (g.kind != kind) throw Error(FDB_ERR_INVALID, "group column " + c.name + " has a different type in this plan");
+    if (kind == 0) {
+      std::shared_ptr<HostDict> d = read_dictionary(c);
+      g.value_format = d->value_format;
+      g.owners.push_back(d);
+      for (const std::string& v : d->values) g.intern(std::string_view(v));
+    }
+  }
+  if (gcols_.size() > FDB_MAX_HASH_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "too many group columns");
+  hash_layout();
+  hash_reserve(0);
+}
+
+void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32) {
+  if (n_parts < 1 || n_parts > FDB_MAX_PARTS) throw Error(FDB_ERR_INVALID, "partition count out of range");
+  if (layout.device_ != device_) throw Error(FDB_ERR_INVALID, "layout plan lives on another device");
+  if (layout.aggs_.size() != aggs_.size()) throw Error(FDB_ERR_INVALID, "plans have different aggregations");
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  if (mode_ == TableMode::DENSE) switch_to_hash();
+  hash_layout();
+  hash_reserve(0);
+  if (&layout != this && layout.mode_ == TableMode::DENSE) layout.switch_to_hash();  // (before its column set changes: the dense slot decoding needs the old one)
+  // the layout plan adopts our columns / dictionary values (a no-op when it was seeded with the global schema)
+  std::vector<FdbHashCol> cols(std::max<size_t>(gcols_.size(), 1));
+  std::vector<std::vector<uint32_t>> id_map(gcols_.size());
+  for (size_t sc = 0; sc < gcols_.size(); sc++) {
+    const GroupColState& sg = gcols_[sc];
+    size_t gi = 0;
+    for (; gi < layout.gcols_.size(); gi++) if (layout.gcols_[gi].name == sg.name) break;
+    if (gi == layout.gcols_.size()) {
+      GroupColState g;
+      g.name = sg.name; g.kind = sg.kind; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      layout.gcols_.push_back(std::move(g));
+    }
+    GroupColState& g = layout.gcols_[gi];
+    if (g.kind != sg.kind) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
+    if (sg.kind == 0) {
+      g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());
+      id_map[sc].assign(sg.values.size() + 1, 0);
+      for (size_t v = 0; v < sg.values.size(); v++) id_map[sc][v + 1] = g.intern(sg.values[v]);
+    }
+  }
+  if (layout.gcols_.size() > FDB_MAX_HASH_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "too many group columns");
+  if (&layout != this) layout.hash_layout();
+  for (size_t sc = 0; sc < gcols_.size(); sc++) {
+    size_t gi = 0;
+    for (; gi < layout.gcols_.size(); gi++) if (layout.gcols_[gi].name == gcols_[sc].name) break;
+    FdbHashCol& C = cols[sc];
+    std::memset(&C, 0, sizeof(C));
+    C.kind = gcols_[sc].kind; C.word = gcols_[sc].word; C.src_word = layout.gcols_[gi].word; C.gi = (int)gi; C.lut_len = (uint32_t)sc;
+    C.lut_lds = FDB_NO_LDS; C.k1 = fdb_fp_k1((int)gi); C.k2 = fdb_fp_k2((int)gi);
+    if (C.kind == 0) C.lut = (const uint32_t*)upload(id_map[sc].data(), id_map[sc].size() * 4);
+  }
+  const int dkw = layout.h_key_words_;
+  const int n_vals = (int)(1 + aggs_.size());
+  const int rw = ((dkw + 1) & ~1) + 2 * n_vals;
+  *row_words32 = rw;
+  const uint64_t n = hash_groups();
+  for (int p = 0; p < n_parts; p++) counts[p] = 0;
+  *dev_rows = nullptr;
+  if (n == 0) return;
+  unsigned long long* d_counts = (unsigned long long*)ctx_->dev_alloc(FDB_MAX_PARTS * 8);
+  uint32_t* d_rows = (uint32_t*)ctx_->dev_alloc((size_t)n * rw * 4);
+  scratch_.push_back(d_counts); scratch_.push_back(d_rows);
+  FdbHashPartArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.table = h_table_; a.keys = h_keys_; a.capacity = h_capacity_;
+  a.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
+  a.out = d_rows; a.counts = d_counts;
+  a.n_cols = (int)gcols_.size(); a.entry_words = h_entry_words_; a.key_words = h_key_words_; a.dst_key_words = dkw; a.row_words32 = rw;
+  a.n_vals = n_vals; a.n_parts = n_parts;
+  // pass 1: rows per partition
+  hip_check(hipMemsetAsync(d_counts, 0, FDB_MAX_PARTS * 8, stream_), "hipMemsetAsync(partition counts)");
+  a.scatter = 0;
+  hip_check(fdb_launch_hash_partition(a, stream_), "hash partition (count)");
+  unsigned long long h_counts[FDB_MAX_PARTS];
+  hip_check(hipMemcpyAsync(h_counts, d_counts, (size_t)n_parts * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(partition counts)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  // pass 2: region bases become the running cursors
+  unsigned long long bases[FDB_MAX_PARTS] = {0};
+  unsigned long long run = 0;
+  for (int p = 0; p < n_parts; p++) { bases[p] = run; run += h_counts[p]; counts[p] = (int64_t)h_counts[p]; }
+  if (run != n) throw Error(FDB_ERR_DEVICE, "internal: partition counts do not add up to the group count");
+  hip_check(hipMemcpyAsync(d_counts, bases, (size_t)n_parts * 8, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(partition bases)");
+  a.scatter = 1;
+  hip_check(fdb_launch_hash_partition(a, stream_), "hash partition (scatter)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // `bases` is a stack array; the caller reads the rows next
+  *dev_rows = d_rows;
+}
+
+void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
+  if (n_rows <= 0) return;
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  if (mode_ == TableMode::DENSE) switch_to_hash();
+  hash_layout();
+  if (h_count_dev_ != nullptr) hash_groups();
+  hash_reserve((uint64_t)n_rows);
+  const int kw = h_key_words_, n_vals = (int)(1 + aggs_.size());
+  const int rw = ((kw + 1) & ~1) + 2 * n_vals;
+  std::vector<FdbHashCol> cols(std::max<size_t>(gcols_.size(), 1));
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    FdbHashCol& C = cols[c];
+    std::memset(&C, 0, sizeof(C));
+    C.kind = gcols_[c].kind; C.word = gcols_[c].word; C.src_word = gcols_[c].word; C.gi = (int)c; C.lut_len = (uint32_t)c; C.lut_lds = FDB_NO_LDS;
+    C.k1 = fdb_fp_k1((int)c); C.k2 = fdb_fp_k2((int)c);
+  }
+  FdbHashMergeArgs m;
+  std::memset(&m, 0, sizeof(m));
+  m.in_keys = (const uint32_t*)dev_rows;
+  m.entries = (const unsigned long long*)((const uint32_t*)dev_rows + ((kw + 1) & ~1));
+  m.n = n_rows;
+  m.table = h_table_; m.keys = h_keys_; m.n_groups = h_count_dev_; m.mask = h_capacity_ - 1;
+  m.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
+  m.n_cols = (int)gcols_.size(); m.in_key_words = rw; m.in_entry_words = rw / 2; m.entry_words = h_entry_words_; m.key_words = h_key_words_;
+  m.n_aggs = (int)aggs_.size();
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    const int32_t f = aggs_[j].func;
+    m.funcs[j] = f == FDB_AGG_COUNT ? (final_stage_ ? 1 : 0) : f == FDB_AGG_SUM ? (aggs_[j].type == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
+  }
+  hip_check(fdb_launch_hash_merge(m, stream_), "hash merge");
+  hip_check(hipStreamSynchronize(stream_), "sync(hash import)");  // the caller may free `dev_rows` when this returns
+  state_dirty_ = true;
+}
+
 // ≙ Synchronizer + final stage when either side holds a hash table: the source's occupied groups are re-keyed into
 // this plan's key ids on the device (per-column translation LUTs) and merged with atomics.
 void Plan::merge_hash(Plan& src) {
+  if (src.mode_ == TableMode::HASH) {  // device only: re-key + pack on the source, merge here
+    void* rows = nullptr;
+    int64_t n = 0;
+    int32_t rw = 0;
+    src.hash_export(*this, 1, &rows, &n, &rw);
+    hash_import(rows, n);
+    return;
+  }
   CompactState cs;
   src.fetch_compact(&cs);
   if (cs.n == 0) return;

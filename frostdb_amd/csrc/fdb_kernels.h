@@ -254,6 +254,24 @@ struct FdbHashMergeArgs {
   int32_t funcs[FDB_MAX_AGGS];
 };
 hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t stream);
+
+// Export of a hash table for a merge elsewhere (another plan on this device, or — hash-partitioned — other ranks over RCCL):
+// every occupied entry is re-keyed into the DESTINATION layout (per-column id translation, destination word positions and
+// column indices), its fingerprint is recomputed there, and the entry is written as one packed row
+//   [destination key tuple: dst_key_words × u32, padded to an even count | count | accumulators … ]   (row_words32 words)
+// into the region of the partition that owns it: partition = (fingerprint hi >> 32) % n_parts. The table slot uses the low
+// bits of the OTHER fingerprint half, so partitions stay uniformly spread inside each receiver's table.
+// cols[c] describes SOURCE column c: kind, word (source), src_word (DESTINATION word), gi (DESTINATION column index),
+// lut (source id → destination id, nullptr = identity), lut_len (SOURCE column index: bit of the source valid mask), k1/k2 (of gi).
+#define FDB_MAX_PARTS 64
+struct FdbHashPartArgs {
+  const unsigned long long* table; const uint32_t* keys; uint64_t capacity;
+  const FdbHashCol* cols;       // device array [n_cols]
+  uint32_t* out;                // packed rows (scatter pass)
+  unsigned long long* counts;   // [n_parts] rows per partition (count pass: incremented; scatter pass: running cursors, start = region base)
+  int32_t n_cols, entry_words, key_words, dst_key_words, row_words32, n_vals, n_parts, scatter;
+};
+hipError_t fdb_launch_hash_partition(const FdbHashPartArgs& args, hipStream_t stream);
 #endif  // FDB_DEVICE_ONLY
 
 // Identity elements stored in accumulators. MIN/MAX over float64 run on order-preserving int64 keys

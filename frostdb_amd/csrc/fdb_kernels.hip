@@ -985,6 +985,67 @@ __global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
   if (threadIdx.x == 0 && s_new != 0) atomicAdd(m.n_groups, (unsigned long long)s_new);
 }
 
+// See FdbHashPartArgs. Two launches: scatter = 0 counts rows per partition, scatter = 1 writes them (the host turns the
+// counts into region bases in between). Per-partition positions are reserved per workgroup (LDS histogram → one global
+// atomic per partition and workgroup), so 10 M entries do not fight over ≤ 64 counters.
+__global__ __launch_bounds__(256) void hash_partition_kernel(const FdbHashPartArgs p) {
+  __shared__ unsigned int s_cnt[FDB_MAX_PARTS];
+  __shared__ unsigned long long s_base[FDB_MAX_PARTS];
+  const int ew = p.entry_words, kw = p.key_words;
+  const uint64_t per_block = (p.capacity + gridDim.x - 1) / gridDim.x;
+  const uint64_t b0 = (uint64_t)blockIdx.x * per_block, b1 = min(p.capacity, b0 + per_block);
+  for (uint64_t base = b0; base < b1; base += 256) {  // one batch of 256 slots at a time (block-uniform trip count)
+    if (threadIdx.x < FDB_MAX_PARTS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = base + threadIdx.x;
+    const bool occ = i < b1 && p.table[i * (uint64_t)ew] != 0ull;
+    unsigned long long h1 = 0, h2 = 0, vmask = 0;
+    uint32_t part = 0, local = 0;
+    const uint32_t* in = p.keys + i * (uint64_t)kw;
+    if (occ) {
+      const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
+      for (int c = 0; c < p.n_cols; c++) {
+        const FdbHashCol& C = p.cols[c];
+        if (C.kind == 0) {
+          uint32_t id = in[C.word];
+          if (id != 0 && C.lut != nullptr) id = C.lut[id];
+          if (id != 0) { fp_add32(h1, h2, C.k1, C.k2, id); vmask |= 1ull << C.gi; }
+        } else if ((in_mask >> C.lut_len) & 1ull) {
+          const unsigned long long v = (unsigned long long)in[C.word] | ((unsigned long long)in[C.word + 1] << 32);
+          fp_add(h1, h2, C.k1, C.k2, v);
+          vmask |= 1ull << C.gi;
+        }
+      }
+      fp_final(h1, h2);
+      part = (uint32_t)((h2 >> 32) % (unsigned long long)p.n_parts);
+      local = atomicAdd(&s_cnt[part], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.n_parts && s_cnt[threadIdx.x] != 0) s_base[threadIdx.x] = atomicAdd(&p.counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (occ && p.scatter) {
+      uint32_t* row = p.out + (s_base[part] + local) * (unsigned long long)p.row_words32;
+      for (int w = 0; w < p.dst_key_words; w++) row[w] = 0u;
+      row[0] = (uint32_t)vmask; row[1] = (uint32_t)(vmask >> 32);
+      const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
+      for (int c = 0; c < p.n_cols; c++) {
+        const FdbHashCol& C = p.cols[c];
+        if (C.kind == 0) {
+          uint32_t id = in[C.word];
+          if (id != 0 && C.lut != nullptr) id = C.lut[id];
+          row[C.src_word] = id;
+        } else if ((in_mask >> C.lut_len) & 1ull) {
+          row[C.src_word] = in[C.word]; row[C.src_word + 1] = in[C.word + 1];
+        }
+      }
+      unsigned long long* vals = reinterpret_cast<unsigned long long*>(row + ((p.dst_key_words + 1) & ~1));
+      const unsigned long long* e = p.table + i * (uint64_t)ew;
+      for (int v = 0; v < p.n_vals; v++) vals[v] = e[2 + v];
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void fill_u64_kernel(unsigned long long* dst, unsigned long long value, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = value;
 }
@@ -1354,6 +1415,13 @@ hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_hash_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   (void)hipGetLastError();
   hipLaunchKernelGGL(scan_hash_kernel, dim3(grid_blocks), dim3(FDB_HASH_BLOCK), lds_bytes, stream, args);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_hash_partition(const FdbHashPartArgs& args, hipStream_t stream) {
+  if (args.capacity == 0) return hipSuccess;
+  int blocks = (int)std::min<uint64_t>((args.capacity + 255) / 256, 4096);
+  hipLaunchKernelGGL(hash_partition_kernel, dim3(blocks), dim3(256), 0, stream, args);
   return hipGetLastError();
 }
 

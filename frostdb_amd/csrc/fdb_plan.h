@@ -143,6 +143,15 @@ class Plan {
   void state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) const;
   void state_write(int32_t array, const void* src, int64_t bytes);
 
+  // Hash-table exchange (fdb_hash.cpp): merge of high-cardinality partial tables without a host round trip — between two plans
+  // of one device (merge_from) and, hash-partitioned, between ranks (frostdb_amd/distributed.py: merge_plan_alltoall).
+  void group_schema(ArrowArray* out, ArrowSchema* out_schema);  // zero-row record: one column per group column, carrying its dictionary
+  void seed_groups(const ArrowArray* array, const ArrowSchema* schema);  // adopt those columns and dictionary values, in that order
+  // Re-keys every occupied entry into `layout`'s columns / key ids and packs it into partition (fingerprint % n_parts);
+  // *dev_rows (owned by this plan until its next push / close) holds the partitions back to back, counts[p] rows each.
+  void hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32);
+  void hash_import(const void* dev_rows, int64_t n_rows);       // rows packed for THIS plan's layout
+
   std::string error;
   int device() const { return device_; }
   hipStream_t stream() const { return stream_; }

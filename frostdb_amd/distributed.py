@@ -11,7 +11,10 @@ the fused filter+aggregate kernel over its own resident parts. The only exchange
   3. rank ``dst`` materialises the final Arrow record.
 
 Messages are G × 8 bytes per aggregation (8 KiB for the 1 024-path configs): latency-bound, microseconds.
-The high-cardinality variant (hash-partitioned all-to-all over the 7 xGMI links) is a later row.
+High-cardinality tables (cfg 5: millions of groups) take `merge_plan_alltoall` instead: no rank could hold every other
+rank's table, and a ring all-reduce / all-gather would be bound by ONE xGMI link. Groups are hash-partitioned by their
+128-bit fingerprint; each rank ships 1/N-th of its table straight to the owner of each partition (`all_to_all_single`:
+7 point-to-point xGMI links busy at once), owners merge on the device, and the result stays sharded.
 """
 from __future__ import annotations
 
@@ -191,3 +194,85 @@ def merge_plan(plan, group=None, dst: int = 0, device: Optional[torch.device] = 
         partials.append(t)
     key_types = {f.name: f.type for f in keys.schema}
     return merge_partials(keys, partials, plan.aggs, key_types=key_types, group=group, dst=dst)
+
+
+# ---- high-cardinality merge: hash-partitioned all-to-all ---------------------------------------------------------------
+def _schema_to_obj(schema: pa.RecordBatch):
+    """Picklable form of a plan's zero-row group schema: [(name, 'dict', value type, values) | (name, 'plain', type)]."""
+    out = []
+    for f, c in zip(schema.schema, schema.columns):
+        if pa.types.is_dictionary(f.type):
+            out.append((f.name, "dict", str(f.type.value_type), c.dictionary.to_pylist()))
+        else:
+            out.append((f.name, "plain", str(f.type), None))
+    return out
+
+
+def unify_group_schemas(objs: Sequence[Sequence[tuple]]) -> pa.RecordBatch:
+    """One global schema from every rank's: columns in first-seen order (rank order, like the Synchronizer's arrival order
+    but deterministic); a dictionary column's global dictionary is the union of the ranks' values, first seen first. Key
+    ids assigned from it mean the same group on every rank."""
+    order: List[str] = []
+    cols: Dict[str, list] = {}
+    for obj in objs:
+        for name, kind, ty, values in obj:
+            if name not in cols:
+                order.append(name)
+                cols[name] = [kind, ty, [], set()]
+            e = cols[name]
+            if e[0] != kind or e[1] != ty:
+                raise ValueError(f"group column {name!r} has different types on different ranks: {e[0]} {e[1]} vs {kind} {ty}")
+            if kind == "dict":
+                for v in values:
+                    if v not in e[3]:
+                        e[3].add(v)
+                        e[2].append(v)
+    arrays, names = [], []
+    for name in order:
+        kind, ty, values, _ = cols[name]
+        if kind == "dict":
+            vt = pa.string() if ty in ("string", "utf8") else pa.binary()
+            arrays.append(pa.DictionaryArray.from_arrays(pa.array([], type=pa.uint32()), pa.array(values, type=vt)))
+        else:
+            arrays.append(pa.array([], type=pa.float64() if ty == "double" else pa.int64()))
+        names.append(name)
+    return pa.RecordBatch.from_arrays(arrays, names=names)
+
+
+def exchange_rows(send: torch.Tensor, counts: Sequence[int], words: int, group=None):
+    """The exchange step alone: `send` holds the packed rows (int64 words, `words` per row) of N partitions back to back,
+    counts[p] rows for rank p. Returns (received rows, rows received from each rank)."""
+    send_counts = torch.tensor(list(counts), dtype=torch.int64, device=send.device)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    rc = [int(x) for x in recv_counts.tolist()]
+    recv = torch.empty((sum(rc) * words,), dtype=torch.int64, device=send.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[c * words for c in rc], input_split_sizes=[int(c) * words for c in counts], group=group)
+    return recv, rc
+
+
+def merge_plan_alltoall(plan, group=None, device: Optional[torch.device] = None):
+    """Merges high-cardinality partial tables across the process group and returns a NEW plan holding this rank's shard of
+    the final groups (fingerprint % world == rank); the caller calls Finish() / Close() on it. Works for any table mode
+    (a dense table is migrated to a hash table first)."""
+    world = dist.get_world_size(group)
+    if device is None:
+        device = torch.device("cuda", plan.device)
+    gathered: List = [None] * world
+    dist.all_gather_object(gathered, _schema_to_obj(plan.group_schema()), group=group)
+    shard = plan.clone_empty()
+    try:
+        shard.seed_groups(unify_group_schemas(gathered))
+        ptr, counts, row_bytes = plan.hash_export(shard, world)  # synchronised: the rows are complete when this returns
+        words = row_bytes // 8
+        n_send = sum(counts)
+        send = (torch.as_tensor(_DeviceArray(ptr, n_send * words, "<i8"), device=device) if n_send
+                else torch.empty((0,), dtype=torch.int64, device=device))
+        recv, rc = exchange_rows(send, counts, words, group=group)
+        if device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()
+        shard.hash_import(recv.data_ptr(), sum(rc))
+    except Exception:
+        shard.Close()
+        raise
+    return shard

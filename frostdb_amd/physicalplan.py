@@ -84,6 +84,10 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_set_timing.argtypes = [vp, i32]
     L.fdb_plan_stream.argtypes = [vp, P(vp)]
     L.fdb_plan_set_tuning.argtypes = [vp, i32, i32]
+    L.fdb_plan_group_schema.argtypes = [vp, vp, vp]
+    L.fdb_plan_seed_groups.argtypes = [vp, vp, vp]
+    L.fdb_plan_hash_export.argtypes = [vp, vp, i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(i32)]
+    L.fdb_plan_hash_import.argtypes = [vp, vp, ctypes.c_int64]
     L.fdb_read_ceiling.argtypes = [ctypes.c_int, ctypes.c_int64, i32, ctypes.POINTER(ctypes.c_double)]
     L.fdb_plan_last_kernel.argtypes = [vp]
     L.fdb_plan_last_kernel.restype = ctypes.c_char_p
@@ -149,6 +153,7 @@ class HashAggregatePlan:
                  groups: Sequence[Column] = (), device: int = 0, final_stage: bool = False):
         self._desc = to_desc(filter_expr, list(aggs), list(groups), final_stage)
         self.aggs = list(aggs)
+        self._ctor = (filter_expr, list(aggs), list(groups), device, final_stage)
         out = ctypes.c_void_p()
         rc = lib().fdb_plan_create(ctypes.addressof(self._desc.desc), device, ctypes.byref(out))
         if rc != 0:
@@ -161,6 +166,11 @@ class HashAggregatePlan:
     def _check(self, rc: int) -> None:
         if rc != 0:
             _raise(rc, lib().fdb_plan_last_error(self.handle).decode())
+
+    def clone_empty(self) -> "HashAggregatePlan":
+        """A fresh plan with the same descriptor on the same device (no state)."""
+        f, a, g, d, fs = self._ctor
+        return HashAggregatePlan(f, a, g, device=d, final_stage=fs)
 
     # ---- PhysicalPlan verbs --------------------------------------------------------------------------
     def Callback(self, record) -> None:
@@ -232,6 +242,28 @@ class HashAggregatePlan:
         arr, sch = ArrowArray(), ArrowSchema()
         self._check(lib().fdb_plan_partial_keys(self.handle, ctypes.addressof(arr), ctypes.addressof(sch)))
         return import_batch(arr, sch)
+
+    # ---- hash-partitioned exchange of high-cardinality partial tables (see include/frostdb_amd.h) -------------------
+    def group_schema(self) -> pa.RecordBatch:
+        """Zero-row record: dictionary columns carry this plan's distinct key values, plus one column per typed aggregate."""
+        arr, sch = ArrowArray(), ArrowSchema()
+        self._check(lib().fdb_plan_group_schema(self.handle, ctypes.addressof(arr), ctypes.addressof(sch)))
+        return import_batch(arr, sch)
+
+    def seed_groups(self, schema_record: pa.RecordBatch) -> None:
+        with ExportedBatch(schema_record) as ex:
+            self._check(lib().fdb_plan_seed_groups(self.handle, ctypes.addressof(ex.array), ctypes.addressof(ex.schema)))
+
+    def hash_export(self, layout: "HashAggregatePlan", n_parts: int):
+        """(device pointer, rows per partition, bytes per row): this plan's groups re-keyed for `layout`, packed by
+        destination partition. The buffer belongs to this plan until its next push or Close."""
+        ptr, rw = ctypes.c_void_p(), ctypes.c_int32()
+        counts = (ctypes.c_int64 * n_parts)()
+        self._check(lib().fdb_plan_hash_export(self.handle, layout.handle, n_parts, ctypes.byref(ptr), counts, ctypes.byref(rw)))
+        return ptr.value or 0, list(counts), rw.value * 4
+
+    def hash_import(self, dev_ptr: int, n_rows: int) -> None:
+        self._check(lib().fdb_plan_hash_import(self.handle, ctypes.c_void_p(dev_ptr), n_rows))
 
     def agg_format(self, agg: int) -> str:
         c = ctypes.create_string_buffer(2)

@@ -207,6 +207,26 @@ int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t
 /* 'l' (int64) or 'g' (float64): the Arrow format of aggregation `agg`'s output column; 0 until the first push. */
 int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out);
 
+/* ---- high-cardinality merge: hash-partitioned exchange of partial hash tables ("G large") -------------
+ * ≙ Synchronizer + HashAggregate(final=true) (synchronize.go:31-53, aggregate.go:340-348) when the partial tables hold
+ * millions of groups: no rank can afford every other rank's table, so each group is sent to the ONE rank that owns
+ * fingerprint % n_ranks (all-to-all over the 7 xGMI links), merged there, and the result stays sharded.
+ *   1. every rank exports its group schema (fdb_plan_group_schema: a zero-row record whose dictionary columns carry the
+ *      distinct key values seen so far, int64 key columns as plain int64, plus one zero-row column per typed aggregate),
+ *      the host side agrees on one global schema (frostdb_amd/distributed.py) and seeds a fresh plan of the same
+ *      descriptor with it (fdb_plan_seed_groups) — now key ids mean the same thing on every rank;
+ *   2. fdb_plan_hash_export(local, layout = the seeded plan, n_parts) re-keys and packs the local table on the device into
+ *      n_parts contiguous partitions of fixed-size rows (row_words32 × 4 bytes each; counts[p] rows in partition p);
+ *   3. after the exchange, fdb_plan_hash_import(seeded plan, rows, n) merges the received rows (SUM/COUNT add, MIN, MAX);
+ *   4. fdb_plan_finish on the seeded plan emits this rank's shard of the final groups.
+ * The same two calls with n_parts = 1 are the device-only path of fdb_plan_merge between two plans of one GPU. */
+int fdb_plan_group_schema(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema);
+int fdb_plan_seed_groups(fdb_plan* plan, struct ArrowArray* schema_record, struct ArrowSchema* schema);
+/* *dev_rows: DEVICE pointer owned by `src` until its next push or close (NULL if the table is empty). */
+int fdb_plan_hash_export(fdb_plan* src, fdb_plan* layout, int32_t n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32);
+/* dev_rows: DEVICE pointer to n_rows rows packed for `plan`'s layout; may be released when the call returns. */
+int fdb_plan_hash_import(fdb_plan* plan, const void* dev_rows, int64_t n_rows);
+
 /* ---- resident batches (a part kept in HBM between queries; 288 GB per GPU) ---------------------- */
 int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int device, fdb_batch** out);
 int64_t fdb_batch_num_rows(const fdb_batch* batch);

@@ -125,3 +125,68 @@ def test_unify_keys_handles_missing_columns_and_order():
     assert names == ["a", "b"]
     assert keys == [(b"x", None), (None, None), (b"x", b"q")]
     assert perms == [[0, 1], [2, 0, 1]]
+
+
+# ---- hash-partitioned all-to-all (high-cardinality merge): schema agreement + exchange bookkeeping on gloo ----------------
+
+def _alltoall_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from frostdb_amd.distributed import exchange_rows, unify_group_schemas
+        # (1) schema agreement: every rank contributes different dictionaries / columns and all must derive the same global schema
+        mine = [("labels.a", "dict", "binary", [b"r%d" % rank, b"shared"]), ("ts", "plain", "int64", None)]
+        if rank % 2 == 1:
+            mine.append(("labels.odd", "dict", "binary", [b"o%d" % rank]))
+        if rank == 0:
+            mine.append(("sum(value)", "plain", "double", None))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        schema = unify_group_schemas(gathered)
+        sig = [(f.name, str(f.type), c.dictionary.to_pylist() if pa.types.is_dictionary(f.type) else None) for f, c in zip(schema.schema, schema.columns)]
+        # (2) exchange: rows [key, count, sum-as-int], key k is owned by rank k % world; rows are sent grouped by owner
+        rng = np.random.default_rng(1000 + rank)
+        n = 5000 + 700 * rank
+        keys = rng.integers(0, 3000, size=n)
+        order = np.argsort(keys % world, kind="stable")
+        keys = keys[order]
+        rows = np.stack([keys, np.ones(n, dtype=np.int64), keys * 3 + rank], axis=1).astype(np.int64)
+        counts = np.bincount(keys % world, minlength=world).tolist()
+        recv, rc = exchange_rows(torch.from_numpy(rows.reshape(-1).copy()), counts, 3)
+        got = recv.numpy().reshape(-1, 3)
+        assert sum(rc) == got.shape[0]
+        assert np.all(got[:, 0] % world == rank)  # only keys this rank owns arrive here
+        q.put((rank, sig, rc, int(got[:, 1].sum()), int(got[:, 2].sum()), counts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_alltoall_exchange_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_alltoall_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sigs = [r[1] for r in res]
+    assert all(s == sigs[0] for s in sigs)  # identical global schema everywhere
+    names = [s[0] for s in sigs[0]]
+    assert names[:2] == ["labels.a", "ts"] and "sum(value)" in names and "labels.odd" in names
+    a_vals = sigs[0][0][2]
+    assert a_vals == [b"r0", b"shared"] + [b"r%d" % r for r in range(1, world)]
+    # what rank r received from rank s is what s counted for r; nothing is lost
+    for r in range(world):
+        assert res[r][2] == [res[s][5][r] for s in range(world)]
+    total_rows = sum(5000 + 700 * r for r in range(world))
+    assert sum(r[3] for r in res) == total_rows
+    expect_sum = 0
+    for r in range(world):
+        k = np.random.default_rng(1000 + r).integers(0, 3000, size=5000 + 700 * r)
+        expect_sum += int((k * 3 + r).sum())
+    assert sum(r[4] for r in res) == expect_sum

@@ -649,3 +649,89 @@ def test_hash_path_properties_at_scale(pp, variant):
     distinct_in = pa.table([b.column(i) for i, n_ in enumerate(b.schema.names) if n_.startswith("labels.")],
                            names=[n_ for n_ in b.schema.names if n_.startswith("labels.")]).group_by(keys.column_names).aggregate([]).num_rows
     assert out.num_rows == distinct_in
+
+
+# ---- hash-partitioned exchange of high-cardinality tables ("G large") ----------------------------------------
+
+def _concat_results(recs):
+    out = {}
+    for r in recs:
+        d = arrow_to_pydict(r)
+        for k, v in d.items():
+            out.setdefault(k, []).extend(v)
+    return out
+
+
+def test_hash_exchange_two_virtual_ranks(pp):
+    """Two 'ranks' (two plans on this GPU) with different data, different dictionaries and a column only one of them has:
+    schema agreement → each exports its table hash-partitioned for 2 owners → each owner imports its partition from both.
+    The union of the two shards equals the oracle over all the data, and no group appears in both shards."""
+    from frostdb_amd import distributed as fd
+    rng = np.random.default_rng(777)
+    aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("value")), Max(Col("floatvalue")), Sum(Col("floatvalue"))]
+    groups = [DynCol("labels"), Col("bucket")]
+    ba = [many_label_batch(rng, 40_000, 10, 4, n_groups=9000, int_key=True), many_label_batch(rng, 10_000, 10, 4, n_groups=500, int_key=True)]
+    bb = [many_label_batch(rng, 35_000, 11, 5, n_groups=8000, int_key=True)]  # one more label column, one more value per dictionary
+    want = run_oracle(ba + bb, None, aggs, groups)
+    plans = []
+    for batches in (ba, bb):
+        p = pp.HashAggregatePlan(None, aggs, groups)
+        for b in batches:
+            p.Callback(b)
+        plans.append(p)
+    schema = fd.unify_group_schemas([fd._schema_to_obj(p.group_schema()) for p in plans])
+    shards = [plans[0].clone_empty(), plans[0].clone_empty()]
+    try:
+        for s in shards:
+            s.seed_groups(schema)
+        for p in plans:
+            ptr, counts, row_bytes = p.hash_export(shards[0], 2)
+            assert sum(counts) == p.num_groups() and min(counts) > 0.3 * sum(counts) / 2
+            shards[0].hash_import(ptr, counts[0])
+            shards[1].hash_import(ptr + counts[0] * row_bytes, counts[1])
+        recs = [s.Finish() for s in shards]
+    finally:
+        for p in plans + shards:
+            p.Close()
+    cols = key_cols_of(ba + bb, extra=("bucket",)) + [a.Name() for a in aggs]
+    got = _concat_results(recs)
+    assert_same_result(got, want, cols, float_cols={"sum(floatvalue)"})
+    keysets = [set(rows_of(arrow_to_pydict(r), key_cols_of(ba + bb, extra=("bucket",)))) if r.num_rows else set() for r in recs]
+    assert not (keysets[0] & keysets[1])
+
+
+def test_hash_exchange_rccl_single_rank_and_dense_source(pp):
+    """merge_plan_alltoall on a 1-rank RCCL group: the shard is the whole result; the source table may be dense (cfg 3) —
+    it is migrated to a hash table — or already a hash table."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from frostdb_amd import distributed as fd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(32)
+        dense_batches = [make_prometheus_batch(rng, 40_000, n_path=50), make_prometheus_batch(rng, 30_000, n_path=80)]
+        aggs_h = [Sum(Col("value")), Count(Col("value")), Max(Col("floatvalue"))]
+        hash_batches = [many_label_batch(rng, 60_000, 12, 4, n_groups=20_000)]
+        for batches, cfg, cols in (
+                (dense_batches, CFG3, ["labels.path"] + [a.Name() for a in CFG3["aggs"]]),
+                (hash_batches, dict(filter_expr=None, aggs=aggs_h, groups=[DynCol("labels")]), key_cols_of(hash_batches) + [a.Name() for a in aggs_h])):
+            want = run_oracle(batches, **cfg)
+            plan = pp.HashAggregatePlan(cfg["filter_expr"], cfg["aggs"], cfg["groups"])
+            for b in batches:
+                plan.Callback(b)
+            shard = fd.merge_plan_alltoall(plan)
+            try:
+                got = arrow_to_pydict(shard.Finish())
+            finally:
+                shard.Close()
+                plan.Close()
+            assert_same_result(got, want, cols, float_cols={"sum(value)", "sum(floatvalue)"})
+    finally:
+        if created:
+            dist.destroy_process_group()
