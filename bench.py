@@ -107,7 +107,7 @@ def main():
         dist.barrier()
     from frostdb_amd import physicalplan as pp
     from frostdb_amd import synth
-    from frostdb_amd.distributed import layout_probe, merge_plan
+    from frostdb_amd.distributed import layout_probe, merge_plan, merge_plan_alltoall
 
     rows = args.rows or (100_000_000 if world == 1 else 125_000_000)
     cfg3 = args.config == 3
@@ -160,7 +160,14 @@ def main():
                 plan.Callback(rb)
         else:
             plan.CallbackResident(resident)
-        if world > 1 or args.force_merge:
+        if (world > 1 or args.force_merge) and args.config == 5:
+            # high cardinality: hash-partitioned all-to-all; every rank finishes its own shard of the groups
+            shard = merge_plan_alltoall(plan, device=torch.device("cuda", local_rank))
+            try:
+                out = shard.Finish()
+            finally:
+                shard.Close()
+        elif world > 1 or args.force_merge:
             probe = layout_probe(plan, torch.device("cuda", local_rank))  # overlaps with the scan kernel
             out = merge_plan(plan, probe=probe)
         else:
@@ -183,6 +190,17 @@ def main():
             else:
                 assert math.isclose(got[p], exp_sum[i], rel_tol=1e-9), (p, got[p], exp_sum[i])
         assert len(got) == int((exp_cnt > 0).sum())
+
+    if args.config == 5:
+        # every group of the synthetic table shows up (rows ≫ groups): the scan / merge must find exactly that many
+        n_out = out.num_rows
+        if world > 1:
+            t = torch.tensor([n_out], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t)  # shards of the all-to-all merge are disjoint
+            n_out = int(t.item())
+        if rank == 0:
+            print(f"# cfg5: {n_out} groups in the result ({args.groups} distinct label tuples generated, {rows * world} rows)", file=sys.stderr)
+        assert n_out <= args.groups and (rows * world < 5 * args.groups or n_out > 0.99 * args.groups), n_out
 
     if args.sweep:
         if rank == 0:
@@ -250,7 +268,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cfg{args.config if world == 1 else 4}: Prometheus schema, {rows} rows/GPU × {world} GPU, {qdesc}",
                        "rows_per_gpu": rows, "records_per_gpu": n_chunks, "groups": args.groups if args.config == 5 else 1025,
-                       "parallelism": f"parts sharded over {world} GPU(s); RCCL all-reduce of partial tables" if world > 1 else "1 GPU"},
+                       "parallelism": (f"parts sharded over {world} GPU(s); " + ("RCCL all-to-all of hash-partitioned partial tables, result sharded" if args.config == 5 else "RCCL all-reduce of partial tables")) if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "avg_launch_ms": k_ms / max(k_launches, 1),

@@ -525,10 +525,12 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
 void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
   if (n_rows <= 0) return;
   hip_check(hipSetDevice(device_), "hipSetDevice");
+  PhaseTimer pt;
   if (mode_ == TableMode::DENSE) switch_to_hash();
   hash_layout();
   if (h_count_dev_ != nullptr) hash_groups();
   hash_reserve((uint64_t)n_rows);
+  if (pt.on) { hip_check(hipStreamSynchronize(stream_), "sync"); pt.mark("import: reserve"); }
   const int kw = h_key_words_, n_vals = (int)(1 + aggs_.size());
   const int rw = ((kw + 1) & ~1) + 2 * n_vals;
   std::vector<FdbHashCol> cols(std::max<size_t>(gcols_.size(), 1));
@@ -553,6 +555,7 @@ void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
   }
   hip_check(fdb_launch_hash_merge(m, stream_), "hash merge");
   hip_check(hipStreamSynchronize(stream_), "sync(hash import)");  // the caller may free `dev_rows` when this returns
+  pt.mark("import: merge kernel");
   state_dirty_ = true;
 }
 

@@ -730,6 +730,17 @@ __global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __re
 // No LDS staging of aggregates here: with ~10 rows per group spread uniformly, a per-workgroup cache never hits.
 // =========================================================================================================
 // (fingerprint and probe helpers: fdb_kernels.h, shared with the run-time generated hash kernels)
+// Column descriptors are read through the constant address space: the index is wave-uniform, so every field becomes a
+// scalar load (SGPR) instead of a 64-lane vector load of one address — the per-thread descriptor walk of the merge
+// kernel was 99 % of its time (136 ms → ≈2 ms for 5 M entries × 32 columns).
+typedef const __attribute__((address_space(4))) FdbHashCol* ConstHashCols;
+__device__ __forceinline__ FdbHashCol load_col(const FdbHashCol* cols, int c) {
+  ConstHashCols q = (ConstHashCols)cols;
+  FdbHashCol C;
+  C.values = q[c].values; C.validity = q[c].validity; C.lut = q[c].lut; C.lut_len = q[c].lut_len; C.lut_lds = q[c].lut_lds;
+  C.kind = q[c].kind; C.word = q[c].word; C.gi = q[c].gi; C.src_word = q[c].src_word; C.k1 = q[c].k1; C.k2 = q[c].k2;
+  return C;
+}
 // One row per lane. While folding the key columns into the fingerprint each lane also parks its key tuple in LDS
 // ([word][lane], conflict-free), so that a lane that turns out to be the FIRST to see its group can write the tuple to
 // the key store without re-reading 32 columns (≈10 % of the rows of cfg 5 create a group).
@@ -747,7 +758,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
       for (uint32_t i = tid; i < L.lut_len; i += FDB_HASH_BLOCK) smem[L.lut_lds + i] = as_global(L.lut)[i];
   }
   for (int c = 0; c < h.n_hcols; c++) {
-    const FdbHashCol& C = h.hcols[c];
+    const FdbHashCol C = load_col(h.hcols, c);
     if (C.kind == 0 && C.lut_lds != FDB_NO_LDS) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(smem + C.lut_lds);
       for (uint32_t i = tid; i < C.lut_len; i += FDB_HASH_BLOCK) dst[i] = as_global(C.lut)[i];
@@ -774,7 +785,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
       unsigned long long k1[HASH_UNROLL], k2[HASH_UNROLL];
 #pragma unroll
       for (int u = 0; u < HASH_UNROLL; u++) {
-        const FdbHashCol& C = h.hcols[c0 + u < h.n_hcols ? c0 + u : h.n_hcols - 1];
+        const FdbHashCol C = load_col(h.hcols, c0 + u < h.n_hcols ? c0 + u : h.n_hcols - 1);
         vals[u] = C.values; vbm[u] = C.validity; lutg[u] = C.lut; lds[u] = C.lut_lds; kind[u] = c0 + u < h.n_hcols ? C.kind : -1;
         word[u] = C.word; gi[u] = C.gi; k1[u] = C.k1; k2[u] = C.k2;
       }
@@ -903,7 +914,7 @@ __global__ void hash_columns_kernel(const FdbHashColumnsArgs a) {
     const uint32_t* k = a.keys + i * (uint64_t)kw;
     const unsigned long long vm = (unsigned long long)k[0] | ((unsigned long long)k[1] << 32);
     for (int c = 0; c < a.n_cols; c++) {
-      const FdbHashCol& C = a.cols[c];
+      const FdbHashCol C = load_col(a.cols, c);
       if (C.kind == 0) {
         const uint32_t id = k[C.word];
         reinterpret_cast<uint32_t*>(a.out_key[c])[o] = id ? id - 1u : 0u;
@@ -935,7 +946,7 @@ __global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
     const uint32_t* in = m.in_keys + i * (int64_t)ikw;
     unsigned long long h1 = 0, h2 = 0, vmask = 0;
     for (int c = 0; c < m.n_cols; c++) {  // translate the incoming tuple column by column
-      const FdbHashCol& C = m.cols[c];
+      const FdbHashCol C = load_col(m.cols, c);
       if (C.src_word < 0) continue;
       if (C.kind == 0) {
         uint32_t id = in[C.src_word];
@@ -957,7 +968,7 @@ __global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
       uint32_t* dst = m.keys + slot * (uint64_t)kw;
       dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);
       for (int c = 0; c < m.n_cols; c++) {
-        const FdbHashCol& C = m.cols[c];
+        const FdbHashCol C = load_col(m.cols, c);
         if (C.kind == 0) {
           uint32_t id = C.src_word >= 0 ? in[C.src_word] : 0u;
           if (id != 0 && C.lut != nullptr) id = C.lut[id];
@@ -1005,7 +1016,7 @@ __global__ __launch_bounds__(256) void hash_partition_kernel(const FdbHashPartAr
     if (occ) {
       const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
       for (int c = 0; c < p.n_cols; c++) {
-        const FdbHashCol& C = p.cols[c];
+        const FdbHashCol C = load_col(p.cols, c);
         if (C.kind == 0) {
           uint32_t id = in[C.word];
           if (id != 0 && C.lut != nullptr) id = C.lut[id];
@@ -1029,7 +1040,7 @@ __global__ __launch_bounds__(256) void hash_partition_kernel(const FdbHashPartAr
       row[0] = (uint32_t)vmask; row[1] = (uint32_t)(vmask >> 32);
       const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
       for (int c = 0; c < p.n_cols; c++) {
-        const FdbHashCol& C = p.cols[c];
+        const FdbHashCol C = load_col(p.cols, c);
         if (C.kind == 0) {
           uint32_t id = in[C.word];
           if (id != 0 && C.lut != nullptr) id = C.lut[id];

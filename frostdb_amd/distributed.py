@@ -239,39 +239,88 @@ def unify_group_schemas(objs: Sequence[Sequence[tuple]]) -> pa.RecordBatch:
     return pa.RecordBatch.from_arrays(arrays, names=names)
 
 
-def exchange_rows(send: torch.Tensor, counts: Sequence[int], words: int, group=None):
+# Bytes one rank sends to one peer per all_to_all call. Measured on MI355X / RCCL 2.26: a single all_to_all_single moving
+# 1.4 GB silently delivered only the first ≈0.69 GB (tools/dbg history in DESIGN.md §7), so big tables go in slices.
+EXCHANGE_CHUNK_BYTES = 128 << 20
+
+
+def exchange_rows(send: torch.Tensor, counts: Sequence[int], words: int, group=None, chunk_bytes: int = EXCHANGE_CHUNK_BYTES):
     """The exchange step alone: `send` holds the packed rows (int64 words, `words` per row) of N partitions back to back,
-    counts[p] rows for rank p. Returns (received rows, rows received from each rank)."""
-    send_counts = torch.tensor(list(counts), dtype=torch.int64, device=send.device)
+    counts[p] rows for rank p. Returns (received rows grouped by source rank, rows received from each rank). Large
+    partitions travel in slices of at most `chunk_bytes` per peer and call."""
+    world = len(counts)
+    counts = [int(c) for c in counts]
+    send_counts = torch.tensor(counts, dtype=torch.int64, device=send.device)
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
     rc = [int(x) for x in recv_counts.tolist()]
     recv = torch.empty((sum(rc) * words,), dtype=torch.int64, device=send.device)
-    dist.all_to_all_single(recv, send, output_split_sizes=[c * words for c in rc], input_split_sizes=[int(c) * words for c in counts], group=group)
+    send_off = [0] * world
+    recv_off = [0] * world
+    for p in range(1, world):
+        send_off[p] = send_off[p - 1] + counts[p - 1]
+        recv_off[p] = recv_off[p - 1] + rc[p - 1]
+    rows_per_slice = max(1, chunk_bytes // (8 * max(words, 1)))
+    # every rank must issue the same number of collectives: agree on the largest slice count
+    n_slices_local = max([(c + rows_per_slice - 1) // rows_per_slice for c in counts + rc] + [0])
+    t = torch.tensor([n_slices_local], dtype=torch.int64, device=send.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    n_slices = int(t.item())
+    if n_slices <= 1:
+        if n_slices == 1:
+            dist.all_to_all_single(recv, send, output_split_sizes=[c * words for c in rc], input_split_sizes=[c * words for c in counts], group=group)
+        return recv, rc
+    for k in range(n_slices):
+        lo = k * rows_per_slice
+        in_rows = [max(0, min(rows_per_slice, c - lo)) for c in counts]
+        out_rows = [max(0, min(rows_per_slice, c - lo)) for c in rc]
+        inp = torch.cat([send[(send_off[p] + lo) * words:(send_off[p] + lo + in_rows[p]) * words] for p in range(world)]) if sum(in_rows) else send[:0]
+        out = torch.empty((sum(out_rows) * words,), dtype=torch.int64, device=send.device)
+        dist.all_to_all_single(out, inp, output_split_sizes=[r * words for r in out_rows], input_split_sizes=[r * words for r in in_rows], group=group)
+        o = 0
+        for p in range(world):
+            n = out_rows[p] * words
+            if n:
+                recv[(recv_off[p] + lo) * words:(recv_off[p] + lo) * words + n] = out[o:o + n]
+            o += n
     return recv, rc
 
 
-def merge_plan_alltoall(plan, group=None, device: Optional[torch.device] = None):
+def merge_plan_alltoall(plan, group=None, device: Optional[torch.device] = None, chunk_bytes: int = EXCHANGE_CHUNK_BYTES):
     """Merges high-cardinality partial tables across the process group and returns a NEW plan holding this rank's shard of
     the final groups (fingerprint % world == rank); the caller calls Finish() / Close() on it. Works for any table mode
     (a dense table is migrated to a hash table first)."""
+    import os, sys, time
+    prof = os.environ.get("FDB_PROFILE") is not None
+    t = [time.perf_counter()]
+
+    def mark(what):
+        if prof:
+            t.append(time.perf_counter())
+            print(f"[fdb] alltoall {what:18s} {1e3 * (t[-1] - t[-2]):8.2f} ms", file=sys.stderr)
+
     world = dist.get_world_size(group)
     if device is None:
         device = torch.device("cuda", plan.device)
     gathered: List = [None] * world
     dist.all_gather_object(gathered, _schema_to_obj(plan.group_schema()), group=group)
+    mark("schema gather")
     shard = plan.clone_empty()
     try:
         shard.seed_groups(unify_group_schemas(gathered))
+        mark("seed")
         ptr, counts, row_bytes = plan.hash_export(shard, world)  # synchronised: the rows are complete when this returns
+        mark("export")
         words = row_bytes // 8
         n_send = sum(counts)
         send = (torch.as_tensor(_DeviceArray(ptr, n_send * words, "<i8"), device=device) if n_send
                 else torch.empty((0,), dtype=torch.int64, device=device))
-        recv, rc = exchange_rows(send, counts, words, group=group)
+        recv, rc = exchange_rows(send, counts, words, group=group, chunk_bytes=chunk_bytes)
         if device.type == "cuda":
             torch.cuda.current_stream(device).synchronize()
+        mark("exchange")
         shard.hash_import(recv.data_ptr(), sum(rc))
+        mark("import")
     except Exception:
         shard.Close()
         raise

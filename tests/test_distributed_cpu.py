@@ -153,7 +153,10 @@ def _alltoall_worker(rank, world, port, q):
         keys = keys[order]
         rows = np.stack([keys, np.ones(n, dtype=np.int64), keys * 3 + rank], axis=1).astype(np.int64)
         counts = np.bincount(keys % world, minlength=world).tolist()
-        recv, rc = exchange_rows(torch.from_numpy(rows.reshape(-1).copy()), counts, 3)
+        send = torch.from_numpy(rows.reshape(-1).copy())
+        recv, rc = exchange_rows(send, counts, 3)
+        recv_sliced, rc2 = exchange_rows(send, counts, 3, chunk_bytes=24 * 700)  # many slices, uneven tails
+        assert rc2 == rc and torch.equal(recv, recv_sliced)
         got = recv.numpy().reshape(-1, 3)
         assert sum(rc) == got.shape[0]
         assert np.all(got[:, 0] % world == rank)  # only keys this rank owns arrive here

@@ -725,7 +725,7 @@ def test_hash_exchange_rccl_single_rank_and_dense_source(pp):
             plan = pp.HashAggregatePlan(cfg["filter_expr"], cfg["aggs"], cfg["groups"])
             for b in batches:
                 plan.Callback(b)
-            shard = fd.merge_plan_alltoall(plan)
+            shard = fd.merge_plan_alltoall(plan, chunk_bytes=(128 << 20) if cfg is CFG3 else 100_000)  # second case: ≈30 slices
             try:
                 got = arrow_to_pydict(shard.Finish())
             finally:
