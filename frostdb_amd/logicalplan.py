@@ -27,7 +27,9 @@ _OP_STR = {
     OP_EQ: "==", OP_NOT_EQ: "!=", OP_LT: "<", OP_LT_EQ: "<=", OP_GT: ">", OP_GT_EQ: ">=",
     OP_REGEX_MATCH: "=~", OP_REGEX_NOT_MATCH: "!~", OP_AND: "&&", OP_OR: "||",
     OP_CONTAINS: "contains", OP_NOT_CONTAINS: "not contains",
+    OP_ADD: "+", OP_SUB: "-", OP_MUL: "*", OP_DIV: "/",
 }
+_ARITH = (OP_ADD, OP_SUB, OP_MUL, OP_DIV)
 
 # logicalplan.AggFunc (expr.go:718-729)
 AGG_SUM, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_AVG, AGG_UNIQUE, AGG_AND = 1, 2, 3, 4, 5, 6, 7
@@ -66,6 +68,19 @@ class Literal:
     def __str__(self) -> str:
         return "null" if self.value is None else str(self.value)
 
+    # a literal may be the LEFT operand of an arithmetic expression (`2 * 3`, `2 - 1` in logictest/testdata/exec/aggregate/math)
+    def __add__(self, other: Any) -> "BinaryExpr":
+        return BinaryExpr(self, OP_ADD, _operand(other))
+
+    def __sub__(self, other: Any) -> "BinaryExpr":
+        return BinaryExpr(self, OP_SUB, _operand(other))
+
+    def __mul__(self, other: Any) -> "BinaryExpr":
+        return BinaryExpr(self, OP_MUL, _operand(other))
+
+    def __truediv__(self, other: Any) -> "BinaryExpr":
+        return BinaryExpr(self, OP_DIV, _operand(other))
+
 
 class Expr:
     def __and__(self, other: "Expr") -> "BinaryExpr":
@@ -73,6 +88,27 @@ class Expr:
 
     def __or__(self, other: "Expr") -> "BinaryExpr":
         return BinaryExpr(self, OP_OR, other)
+
+    # arithmetic builders (logicalplan/expr.go: Add/Sub/Mul/Div → BinaryExpr with OpAdd … OpDiv); the operand may be
+    # another expression or a Python int / float (a literal)
+    def __add__(self, other: Any) -> "BinaryExpr":
+        return BinaryExpr(self, OP_ADD, _operand(other))
+
+    def __sub__(self, other: Any) -> "BinaryExpr":
+        return BinaryExpr(self, OP_SUB, _operand(other))
+
+    def __mul__(self, other: Any) -> "BinaryExpr":
+        return BinaryExpr(self, OP_MUL, _operand(other))
+
+    def __truediv__(self, other: Any) -> "BinaryExpr":
+        return BinaryExpr(self, OP_DIV, _operand(other))
+
+    def Alias(self, alias: str) -> "AliasExpr":
+        return AliasExpr(self, alias)
+
+
+def _operand(v: Any):
+    return v if isinstance(v, (Expr, Literal)) else Literal(v)
 
 
 def _lit(v: Any) -> Literal:
@@ -147,6 +183,33 @@ class BinaryExpr(Expr):
             return f"({self.left} {'AND' if self.op == OP_AND else 'OR'} {self.right})"
         return f"{self.left} {_OP_STR[self.op]} {self.right}"
 
+    @property
+    def name(self) -> str:
+        """BinaryExpr.Name(): left.Name() + " " + op + " " + right.Name() (logicalplan/expr.go:181-183) — no parentheses."""
+        return str(self)
+
+    @property
+    def dynamic(self) -> bool:
+        return False
+
+
+@dataclass(frozen=True, eq=False)
+class AliasExpr(Expr):
+    """logicalplan.AliasExpr: Name() is the alias (expr.go:1029-1031)."""
+    expr: Any
+    alias: str
+
+    @property
+    def name(self) -> str:
+        return self.alias
+
+    @property
+    def dynamic(self) -> bool:
+        return False
+
+    def __str__(self) -> str:
+        return f"{self.expr} as {self.alias}"
+
 
 def And(*exprs: Expr) -> Expr:
     """logicalplan.And: folds left-deep (expr.go:472-495)."""
@@ -166,7 +229,7 @@ def Or(*exprs: Expr) -> Expr:
 @dataclass(frozen=True)
 class AggregationFunction:
     func: int
-    expr: Column
+    expr: Any  # Column, or an arithmetic BinaryExpr over columns and literals (sum(value * timestamp))
 
     def Name(self) -> str:
         return f"{_AGG_STR[self.func]}({self.expr.name})"
@@ -212,10 +275,20 @@ class CGroupExpr(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("dynamic", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
+class CProjNode(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("op", ctypes.c_int32), ("left", ctypes.c_int32), ("right", ctypes.c_int32),
+                ("column", ctypes.c_char_p), ("literal", CLiteral)]
+
+
+class CProjection(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("nodes", ctypes.POINTER(CProjNode)), ("n_nodes", ctypes.c_int32), ("root", ctypes.c_int32)]
+
+
 class CPlanDesc(ctypes.Structure):
     _fields_ = [("filter", ctypes.POINTER(CExpr)), ("n_filter", ctypes.c_int32), ("filter_root", ctypes.c_int32),
                 ("aggs", ctypes.POINTER(CAggregation)), ("n_aggs", ctypes.c_int32), ("n_groups", ctypes.c_int32),
-                ("groups", ctypes.POINTER(CGroupExpr)), ("final_stage", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+                ("groups", ctypes.POINTER(CGroupExpr)), ("final_stage", ctypes.c_int32), ("n_projections", ctypes.c_int32),
+                ("projections", ctypes.POINTER(CProjection))]
 
 
 @dataclass
@@ -298,4 +371,49 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
         d.groups = ctypes.cast(cg, ctypes.POINTER(CGroupExpr))
     d.n_groups = len(groups)
     d.final_stage = 1 if final_stage else 0
+    # computed columns: every aggregated expression / group expression that is arithmetic (or an alias of one) becomes a
+    # projection named like the reference names it
+    projs: List[CProjection] = []
+    seen = set()
+
+    def flatten(e, nodes: List[CProjNode]) -> int:
+        if isinstance(e, AliasExpr):
+            return flatten(e.expr, nodes)
+        if isinstance(e, Column):
+            nm = e.name.encode()
+            keep.append(nm)
+            nodes.append(CProjNode(kind=0, op=0, left=-1, right=-1, column=nm))
+        elif isinstance(e, Literal):
+            cl = CLiteral(type=e.lit_type())
+            if cl.type == LIT_INT64:
+                cl.i64 = int(e.value)
+            elif cl.type == LIT_FLOAT64:
+                cl.f64 = float(e.value)
+            else:
+                raise TypeError(f"unsupported literal in arithmetic: {e.value!r}")
+            nodes.append(CProjNode(kind=1, op=0, left=-1, right=-1, column=None, literal=cl))
+        elif isinstance(e, BinaryExpr) and e.op in _ARITH:
+            l = flatten(e.left, nodes)
+            r = flatten(e.right, nodes)
+            nodes.append(CProjNode(kind=2, op=e.op, left=l, right=r, column=None))
+        else:
+            raise TypeError(f"unsupported expression in projection: {e}")
+        return len(nodes) - 1
+
+    for e in [a.expr for a in aggs] + list(groups):
+        inner = e.expr if isinstance(e, AliasExpr) else e
+        if not (isinstance(inner, BinaryExpr) and inner.op in _ARITH) or e.name in seen:
+            continue
+        seen.add(e.name)
+        nodes: List[CProjNode] = []
+        root = flatten(inner, nodes)
+        arr = (CProjNode * len(nodes))(*nodes)
+        nm = e.name.encode()
+        keep += [arr, nm]
+        projs.append(CProjection(name=nm, nodes=ctypes.cast(arr, ctypes.POINTER(CProjNode)), n_nodes=len(nodes), root=root))
+    if projs:
+        pa_ = (CProjection * len(projs))(*projs)
+        keep.append(pa_)
+        d.projections = ctypes.cast(pa_, ctypes.POINTER(CProjection))
+    d.n_projections = len(projs)
     return PlanDescHolder(d, keep)

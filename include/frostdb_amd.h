@@ -124,6 +124,33 @@ typedef struct fdb_group_expr {
   int32_t _pad;
 } fdb_group_expr;
 
+/* ---- pre-aggregate Projection (physicalplan/project.go:58-395) --------------------------------------
+ * `Projection (value * timestamp, stacktrace) - HashAggregate (sum(value * timestamp) by stacktrace)` and
+ * `Projection (value, timestamp / 1000 * 1000 as timestamp_bucket) - HashAggregate (sum(value) by timestamp_bucket)`
+ * (logictest/testdata/plan/aggregate/aggregate:66-69, plan/aggregate/window) are fused into the scan: a projection gives a
+ * NAME to an arithmetic expression over int64 / float64 columns and literals; an aggregation whose `column`, or a plain
+ * (non-dynamic) group matcher whose `name`, equals that name reads the computed value instead of a stored column.
+ * Semantics of binaryExprProjection (project.go:73-161 and the Add/Sub/Mul/Div loops :163-399): both operands have the same
+ * type (int64 or float64; a literal is a constant array of its own type); + - * use the RAW slot values of their operands
+ * and always produce a valid value; / yields NULL where the divisor is 0, else Go's quotient (integers truncate toward
+ * zero, MinInt64 / -1 wraps). Only the outermost operation's validity survives: a NULL produced by an inner division is
+ * read back as its raw slot (0) by the enclosing + - *. */
+typedef struct fdb_proj_node {
+  int32_t kind;        /* 0 column, 1 literal, 2 binary */
+  int32_t op;          /* binary: FDB_OP_ADD / SUB / MUL / DIV */
+  int32_t left;        /* binary: child indices into the projection's node array */
+  int32_t right;
+  const char* column;  /* column: exact name (ArrayRef.ColumnName) */
+  fdb_literal literal; /* literal: INT64 or FLOAT64 */
+} fdb_proj_node;
+
+typedef struct fdb_projection {
+  const char* name;    /* BinaryExpr.Name() = "value * timestamp" (logicalplan/expr.go:181-183) or the alias (AliasExpr.Name, :1029-1031) */
+  const fdb_proj_node* nodes;
+  int32_t n_nodes;
+  int32_t root;
+} fdb_projection;
+
 typedef struct fdb_plan_desc {
   const fdb_expr* filter;      /* NULL / n_filter == 0 ⇒ no PredicateFilter in the chain */
   int32_t n_filter;
@@ -134,7 +161,8 @@ typedef struct fdb_plan_desc {
   const fdb_group_expr* groups;
   int32_t final_stage;         /* 1 ⇒ behave like HashAggregate(finalStage=true): aggregate columns are matched
                                   by result name and COUNT merges by SUM (aggregate.go:340-348, :965-969) */
-  int32_t _pad;
+  int32_t n_projections;       /* computed columns of the Projection between filter and aggregate (0 ⇒ none) */
+  const fdb_projection* projections;
 } fdb_plan_desc;
 
 typedef struct fdb_plan fdb_plan;   /* one operator chain; push is single-threaded per handle (table.go:783-860) */

@@ -247,10 +247,14 @@ const char* agg_func_name(int32_t f) {  // logicalplan/expr.go:731-750
   return "unknown";
 }
 
+struct ProjNode { int32_t kind = 0, op = 0, left = -1, right = -1; std::string column; Literal lit; };
+struct ProjDesc { std::string name; std::vector<ProjNode> nodes; int32_t root = -1; };
+
 struct PlanDesc {
   std::vector<Expr> filter; int32_t root = -1;
   std::vector<AggDesc> aggs;
   std::vector<GroupDesc> groups;
+  std::vector<ProjDesc> projs;  // computed columns of the Projection between filter and aggregate
 };
 
 using Bitmap = std::vector<uint8_t>;  // stand-in for roaring.Bitmap: one byte per row
@@ -400,6 +404,83 @@ bool eval_expr(const PlanDesc& p, int32_t node, const Record& r, Bitmap* res, Ev
     return true;
   }
   return eval_leaf(e, r, res, err);
+}
+
+// ---- pre-aggregate Projection: binaryExprProjection.Project (physicalplan/project.go:73-161) ------------------------------
+// Both sides are projected to one array each; the result has the LEFT side's type; the right side is type-asserted to the
+// same array type (a mismatch panics in the reference → an error here). Add/Sub/Mul append left.Value(i) op right.Value(i)
+// for every row — raw slots, validity ignored, result always valid (:163-205, :207-...). Div appends NULL where
+// right.Value(i) == 0 (:207-222, :265-280). A literal side is literalProjection's constant array (:700-760).
+bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, EvalError* err) {
+  const ProjNode& n = pd.nodes[(size_t)ni];
+  const int64_t rows = r.rows;
+  if (n.kind == 0) {
+    const int ci = r.find(n.column);
+    if (ci < 0) { *err = {FDB_ERR_NOT_FOUND, "projection: column " + n.column + " not found"}; return false; }
+    const Col& c = r.cols[(size_t)ci];
+    if (c.type != T_I64 && c.type != T_F64) { *err = {FDB_ERR_UNSUPPORTED, "unsupported type in arithmetic projection: " + n.column}; return false; }
+    *out = c;
+    return true;
+  }
+  if (n.kind == 1) {
+    out->len = rows;
+    out->valid.assign((size_t)rows, 1);
+    if (n.lit.type == FDB_LIT_INT64) { out->type = T_I64; out->i64.assign((size_t)rows, n.lit.i64); }
+    else if (n.lit.type == FDB_LIT_FLOAT64) { out->type = T_F64; out->f64.assign((size_t)rows, n.lit.f64); }
+    else { *err = {FDB_ERR_UNSUPPORTED, "unsupported literal in arithmetic projection"}; return false; }
+    return true;
+  }
+  Col a, b;
+  if (!project_node(pd, n.left, r, &a, err) || !project_node(pd, n.right, r, &b, err)) return false;
+  if (a.type != b.type) { *err = {FDB_ERR_INVALID, "arithmetic projection: operand types differ (the reference's type assertion panics)"}; return false; }
+  out->type = a.type;
+  out->len = rows;
+  out->valid.assign((size_t)rows, 1);
+  if (a.type == T_I64) {
+    out->i64.assign((size_t)rows, 0);
+    for (int64_t i = 0; i < rows; i++) {
+      const uint64_t x = (uint64_t)a.i64[(size_t)i], y = (uint64_t)b.i64[(size_t)i];  // wrap-around like Go's int64
+      switch (n.op) {
+        case FDB_OP_ADD: out->i64[(size_t)i] = (int64_t)(x + y); break;
+        case FDB_OP_SUB: out->i64[(size_t)i] = (int64_t)(x - y); break;
+        case FDB_OP_MUL: out->i64[(size_t)i] = (int64_t)(x * y); break;
+        case FDB_OP_DIV:
+          if (y == 0) out->valid[(size_t)i] = 0;                          // AppendNull (slot left 0)
+          else if ((int64_t)y == -1) out->i64[(size_t)i] = (int64_t)(0 - x);  // MinInt64 / -1 wraps in Go; idiv would trap
+          else out->i64[(size_t)i] = (int64_t)x / (int64_t)y;
+          break;
+        default: *err = {FDB_ERR_UNSUPPORTED, "unsupported binary expression in projection"}; return false;
+      }
+    }
+  } else {
+    out->f64.assign((size_t)rows, 0.0);
+    for (int64_t i = 0; i < rows; i++) {
+      const double x = a.f64[(size_t)i], y = b.f64[(size_t)i];
+      switch (n.op) {
+        case FDB_OP_ADD: out->f64[(size_t)i] = x + y; break;
+        case FDB_OP_SUB: out->f64[(size_t)i] = x - y; break;
+        case FDB_OP_MUL: out->f64[(size_t)i] = x * y; break;
+        case FDB_OP_DIV:
+          if (y == 0) out->valid[(size_t)i] = 0; else out->f64[(size_t)i] = x / y;
+          break;
+        default: *err = {FDB_ERR_UNSUPPORTED, "unsupported binary expression in projection"}; return false;
+      }
+    }
+  }
+  return true;
+}
+
+// The record HashAggregate sees: the incoming columns plus one computed column per projection, named like the reference
+// names it (the plain, column-selecting part of the Projection is a no-op for an operator that finds columns by name).
+bool project_record(const PlanDesc& p, const Record& r, Record* out, EvalError* err) {
+  *out = r;
+  for (const ProjDesc& pd : p.projs) {
+    Col c;
+    if (!project_node(pd, pd.root, r, &c, err)) return false;
+    c.name = pd.name;
+    out->cols.push_back(std::move(c));
+  }
+  return true;
 }
 
 // filter.go:276-323 — bitmap → indices → contiguous ranges → slice + concatenate every column.
@@ -743,6 +824,18 @@ int oracle_plan_create(const fdb_plan_desc* d, int32_t nchains, uint64_t seed, o
     p->desc.aggs.push_back(a);
   }
   for (int32_t i = 0; i < d->n_groups; i++) p->desc.groups.push_back(GroupDesc{d->groups[i].name, d->groups[i].dynamic != 0});
+  for (int32_t i = 0; i < d->n_projections; i++) {
+    const fdb_projection& fp = d->projections[i];
+    ProjDesc pd; pd.name = fp.name; pd.root = fp.root;
+    for (int32_t k = 0; k < fp.n_nodes; k++) {
+      const fdb_proj_node& fn = fp.nodes[k];
+      ProjNode n; n.kind = fn.kind; n.op = fn.op; n.left = fn.left; n.right = fn.right;
+      if (fn.column) n.column = fn.column;
+      n.lit.type = fn.literal.type; n.lit.i64 = fn.literal.i64; n.lit.f64 = fn.literal.f64;
+      pd.nodes.push_back(std::move(n));
+    }
+    p->desc.projs.push_back(std::move(pd));
+  }
   p->partial.resize(p->nchains);
   for (auto& h : p->partial) h.init(&p->desc, false, seed);
   p->final_agg.init(&p->desc, true, seed);
@@ -763,6 +856,11 @@ int oracle_plan_push(oracle_plan* p, int32_t chain, const oracle_batch* b) {
     if (!filter_record(p->desc, b->rec, &filtered, &empty, nullptr, &err)) { p->error = err.msg; return err.code; }
     if (empty) return FDB_OK;  // filter.go:264-266
     r = &filtered;
+  }
+  Record projected;
+  if (!p->desc.projs.empty()) {  // Filter → Projection → HashAggregate (logictest/testdata/plan/aggregate/aggregate:66-69)
+    if (!project_record(p->desc, *r, &projected, &err)) { p->error = err.msg; return err.code; }
+    r = &projected;
   }
   if (!p->partial[chain].callback(*r, &err)) { p->error = err.msg; return err.code; }
   return FDB_OK;

@@ -14,13 +14,14 @@ Schema "default" = dynparquet.SampleDefinitionWithFloat() (logictest/logic_test.
 stacktrace are RLE-dictionary strings (→ Arrow dictionary<uint32, binary>, pqarrow/convert/convert.go:64-70),
 timestamp/value int64, floatvalue nullable float64. One ``insert`` = one Arrow record (an L0 part).
 """
-from frostdb_amd.logicalplan import And, Col, Count, DynCol, Max, Min, Or, Sum
+from frostdb_amd.logicalplan import Literal, And, Col, Count, DynCol, Max, Min, Or, Sum
 
 AGG_FILE = "logictest/testdata/exec/aggregate/aggregate"
 NULLS_FILE = "logictest/testdata/exec/aggregate/aggregate_nulls"
 FILTER_FILE = "logictest/testdata/exec/filter/filter"
 FPROJ_FILE = "logictest/testdata/exec/filter/filter_projection"
 WINDOW_FILE = "logictest/testdata/exec/aggregate/window"
+MATH_FILE = "logictest/testdata/exec/aggregate/math"
 
 # ---- tables -------------------------------------------------------------------------------------
 
@@ -179,6 +180,33 @@ WINDOW_CASES = [
     dict(id="window_3000_count_ts", cite=f"{WINDOW_FILE}:59-63", bucket=3000, aggs=[Count(Col("timestamp"))],
          groups=[Col("timestamp_bucket")], out=["timestamp_bucket", "count(timestamp)"],
          expected=[(120000, 3), (123000, 1)]),
+]
+
+# ---- arithmetic projections (math:4-9 table; expected = the per-row results the reference prints, in insert order) ----
+# The fused operator only sees projections under an aggregate, so each case is run as `sum(<expr>) group by timestamp`
+# (timestamps 1, 3, 5, 11 are unique: one group per row ⇒ the sums ARE the per-row values), and NULL-ness of a division by
+# zero — invisible in a SUM — as `count(value) group by <expr>`.
+MATH_TABLE = dict(
+    cols=["labels.label1", "timestamp", "value"],
+    inserts=[
+        """
+        value1 1 2
+        value1 3 4
+        value1 5 6
+        value1 11 0
+        """,
+    ],
+)
+V, T = Col("value"), Col("timestamp")
+MATH_CASES = [
+    dict(id="value_times_timestamp", cite=f"{MATH_FILE}:11-17", expr=V * T, expected=[2, 12, 30, 0]),
+    dict(id="value_times_2", cite=f"{MATH_FILE}:19-25", expr=V * 2, expected=[4, 8, 12, 0]),
+    dict(id="value_times_lit_product", cite=f"{MATH_FILE}:35-41", expr=V * (Literal(2) * 3), expected=[12, 24, 36, 0]),
+    dict(id="value_times_ts_times_2_nested", cite=f"{MATH_FILE}:43-49", expr=V * (T * 2), expected=[4, 24, 60, 0]),
+    dict(id="value_times_ts_times_2", cite=f"{MATH_FILE}:51-57", expr=V * T * 2, expected=[4, 24, 60, 0]),
+    dict(id="value_times_ts_plus_2_minus_1", cite=f"{MATH_FILE}:59-65", expr=V * T + 2 - 1, expected=[3, 13, 31, 1]),
+    dict(id="value_times_ts_times_diff", cite=f"{MATH_FILE}:67-73", expr=V * T * (Literal(2) - 1), expected=[2, 12, 30, 0]),
+    dict(id="timestamp_div_value", cite=f"{MATH_FILE}:132-138", expr=T / V, expected=[0, 0, 0, None]),
 ]
 
 # ---- filter cases: (id, cite, filter, expected selected row numbers of FILTER_TABLE (0-based)) ------

@@ -8,6 +8,7 @@ import pytest
 
 import oracle
 from oracle import OraclePlan
+from frostdb_amd.logicalplan import Col, Count, Sum
 from tests.golden import logictest_cases as G
 from tests.util import batch_rows, fmt, parse_rows, record_from_rows, sort_key, table_records
 
@@ -119,3 +120,58 @@ def test_oracle_filter_contains_on_plain_binary():
     assert list(p.filter(rec)[1]) == [0]  # filter_contains:21-24
     p = OraclePlan(Col("timestamp") == UInt64(2))
     assert list(p.filter(rec)[1]) == [1]  # filter_contains:10-13
+
+
+# ---- pre-aggregate Projection (project.go:73-399) pinned on the reference's math and window vectors --------------------
+
+def run_math_case(make_plan, case):
+    """`sum(<expr>) group by timestamp` (one group per row ⇒ per-row values) and, for NULL-ness, `count(value) group by <expr>`."""
+    recs = table_records(G.MATH_TABLE)
+    ts_order = [1, 3, 5, 11]
+    expected = case["expected"]
+    plan = make_plan(None, [Sum(case["expr"])], [Col("timestamp")])
+    d = plan(recs)
+    name = f"sum({case['expr'].name})"
+    by_ts = dict(zip(d["timestamp"], d[name]))
+    assert [by_ts[t] for t in ts_order] == [0 if e is None else e for e in expected], case["cite"]  # a NULL adds the builder's zero slot
+    # NULL-ness of the computed value as a group KEY. Group identity in the reference is the hash alone, and both NULL and
+    # the int64 value 0 hash to 0 (dynparquet/hashed.go:254-272 + the "skip zero hashes" fold, aggregate.go:398-409), so a
+    # key of 0 and a NULL key are ONE group whose printed key is whichever row arrived first. Row by row (filter
+    # timestamp == t ⇒ one row ⇒ "first" is unambiguous) the key must be exactly the golden value, NULL included.
+    alias = case["expr"].Alias("q")
+    for t, e in zip(ts_order, expected):
+        d = make_plan(Col("timestamp") == t, [Count(Col("value"))], [alias])(recs)
+        assert list(zip(d["q"], d["count(value)"])) == [(e, 1)], (case["cite"], t)
+    d = make_plan(None, [Count(Col("value"))], [alias])(recs)
+    got = sorted(((0 if k is None else k), n) for k, n in zip(d["q"], d["count(value)"]))
+    want = {}
+    for e in expected:
+        want[e or 0] = want.get(e or 0, 0) + 1
+    assert got == sorted(want.items()), case["cite"]
+
+
+def _oracle_runner(filter_expr, aggs, groups):
+    def run(recs):
+        plan = OraclePlan(filter_expr, aggs, groups, nchains=1)
+        for r in recs:
+            plan.push(r)
+        d = plan.finish().to_pydict()
+        plan.close()
+        return d
+    return run
+
+
+@pytest.mark.parametrize("case", G.MATH_CASES, ids=[c["id"] for c in G.MATH_CASES])
+def test_oracle_math_projection_golden(case):
+    run_math_case(_oracle_runner, case)
+
+
+@pytest.mark.parametrize("case", G.WINDOW_CASES, ids=[c["id"] for c in G.WINDOW_CASES])
+def test_oracle_window_golden_with_fused_projection(case):
+    """The window vectors again, but `(timestamp/bucket)*bucket as timestamp_bucket` is evaluated by the operator
+    (plan/aggregate/window: `Projection (value, timestamp / 1000 * 1000 as timestamp_bucket) - HashAggregate (… by timestamp_bucket)`)."""
+    bucket = (Col("timestamp") / case["bucket"] * case["bucket"]).Alias("timestamp_bucket")
+    groups = [bucket if g.name == "timestamp_bucket" else g for g in case["groups"]]
+    res = _oracle_runner(None, case["aggs"], groups)(table_records(G.WINDOW_TABLE))
+    got = sorted(batch_rows(res, case["out"]), key=sort_key)
+    assert got == sorted(case["expected"], key=sort_key), case["cite"]
