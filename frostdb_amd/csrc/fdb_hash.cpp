@@ -146,17 +146,39 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     FdbScanArgs& a = h.base;
     a.need_count = 1;
     a.ablate = ablate;
+    // columns read by computed aggregate inputs / keys go into base.l8 (the hash scan has no other use for the slot pools)
+    bool has_expr = a.n_expr > 0;
+    a.n_c4 = a.n_c8 = a.n_l4 = a.n_l8 = 0;
+    {
+      int pool_col[FDB_MAX_L8];
+      for (int k = 0; k < a.n_expr; k++) {
+        if (a.expr[k].kind != 0) continue;
+        const int ci = R.expr_col[k];
+        int slot = -1;
+        for (int x = 0; x < a.n_l8; x++) if (pool_col[x] == ci) slot = x;
+        if (slot < 0) {
+          if (a.n_l8 >= FDB_MAX_L8) throw Error(FDB_ERR_UNSUPPORTED, "computed columns read more than 3 distinct stored columns");
+          slot = a.n_l8++;
+          pool_col[slot] = ci;
+          a.l8[slot].values = b.cols[(size_t)ci].d_values;
+          a.l8[slot].validity = b.cols[(size_t)ci].d_validity;
+        }
+        a.expr[k].slot = slot;
+      }
+    }
     // LUTs: predicate LUTs from the record's blob, key-id LUTs appended
     std::vector<FdbHashCol> hcols(R.groups.size());
     std::vector<size_t> lut_off(R.groups.size(), 0);
     for (size_t g = 0; g < R.groups.size(); g++) {
       const GroupRes& gr = R.groups[g];
-      const DevColumn& c = b.cols[(size_t)gr.ci];
       FdbHashCol& C = hcols[g];
       std::memset(&C, 0, sizeof(C));
-      C.values = c.d_values; C.validity = c.d_validity; C.kind = gr.kind; C.gi = gr.gi; C.word = gcols_[(size_t)gr.gi].word;
+      C.kind = gr.kind; C.gi = gr.gi; C.word = gcols_[(size_t)gr.gi].word;
       C.lut_lds = FDB_NO_LDS; C.src_word = -1;
       C.k1 = fdb_fp_k1(gr.gi); C.k2 = fdb_fp_k2(gr.gi);
+      if (gr.kind == 2) { C.src_word = gr.expr_root; has_expr = true; continue; }  // computed int64 key: no stored column
+      const DevColumn& c = b.cols[(size_t)gr.ci];
+      C.values = c.d_values; C.validity = c.d_validity;
       if (gr.kind == 0) { C.lut_len = (uint32_t)gr.lut->size(); lut_off[g] = R.blob.add(gr.lut->data(), gr.lut->size() * 4); }
     }
     unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
@@ -198,6 +220,8 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       h.row_begin = r0; h.row_end = r1;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
+      if (jit_fn == nullptr && has_expr)
+        throw Error(FDB_ERR_UNSUPPORTED, "computed (projected) columns need the run-time specialised kernel (hiprtc unavailable or disabled)");
       if (jit_fn != nullptr) {
         const int64_t n_tiles = (r1 - r0 + 1023) / 1024;
         hip_check(jit_hash_launch(jit_fn, h, (int)std::min<int64_t>(jit_grid, n_tiles), a.lds_lut_bytes, stream_), "hash scan launch");

@@ -63,6 +63,13 @@ __device__ __forceinline__ uint32_t leaf_lut(u32x4 idx, uint32_t valid, LUT lut,
   const uint32_t i0 = (valid & 1u) ? idx.x : null_at, i1 = (valid & 2u) ? idx.y : null_at, i2 = (valid & 4u) ? idx.z : null_at, i3 = (valid & 8u) ? idx.w : null_at;
   return (uint32_t)lut[i0] | ((uint32_t)lut[i1] << 1) | ((uint32_t)lut[i2] << 2) | ((uint32_t)lut[i3] << 3);
 }
+// pre-aggregate arithmetic (project.go:163-399): Go int64 semantics — wrap-around, quotient truncated toward zero,
+// MinInt64 / -1 wraps; a division by zero yields NULL, whose raw slot reads 0.
+__device__ __forceinline__ long long i64_add(long long a, long long b) { return (long long)((unsigned long long)a + (unsigned long long)b); }
+__device__ __forceinline__ long long i64_sub(long long a, long long b) { return (long long)((unsigned long long)a - (unsigned long long)b); }
+__device__ __forceinline__ long long i64_mul(long long a, long long b) { return (long long)((unsigned long long)a * (unsigned long long)b); }
+__device__ __forceinline__ long long i64_div(long long a, long long b) { return b == 0 ? 0 : b == -1 ? (long long)(0ull - (unsigned long long)a) : a / b; }
+__device__ __forceinline__ double f64_div(double a, double b) { return b == 0.0 ? 0.0 : a / b; }
 template <int OP, typename T> __device__ __forceinline__ bool cmp1(T a, T b) {
   return OP == 1 ? a == b : OP == 2 ? a != b : OP == 3 ? a < b : OP == 4 ? a <= b : OP == 5 ? a > b : a >= b;
 }
@@ -108,6 +115,36 @@ bool compile(const std::string& src, std::vector<char>* code, std::string* log) 
 }
 
 // ---- code generation ---------------------------------------------------------------------------------------------------
+// C expression of node `ni` (typed: long long or double); `col(node)` gives the unsigned 64-bit raw value of a column node,
+// literals are the run-time variables K_elit<i>.
+template <typename F>
+std::string expr_value(const std::vector<JitExprNode>& ex, int ni, F col) {
+  const JitExprNode& n = ex[(size_t)ni];
+  const bool f = n.type == FDB_T_F64;
+  if (n.kind == 0) return f ? ("__longlong_as_double((long long)" + col(ni) + ")") : ("(long long)" + col(ni));
+  if (n.kind == 1) return f ? ("__longlong_as_double(K_elit" + std::to_string(ni) + ")") : ("K_elit" + std::to_string(ni));
+  const std::string a = expr_value(ex, n.left, col), b = expr_value(ex, n.right, col);
+  if (f) {
+    if (n.op == FDB_OP_DIV) return "f64_div(" + a + ", " + b + ")";
+    return "(" + a + (n.op == FDB_OP_ADD ? " + " : n.op == FDB_OP_SUB ? " - " : " * ") + b + ")";
+  }
+  return std::string(n.op == FDB_OP_ADD ? "i64_add(" : n.op == FDB_OP_SUB ? "i64_sub(" : n.op == FDB_OP_MUL ? "i64_mul(" : "i64_div(") + a + ", " + b + ")";
+}
+// Validity of the ROOT value: only an outermost division can be NULL (divisor 0); `colvalid(node)` for a bare column.
+template <typename F, typename V>
+std::string expr_valid(const std::vector<JitExprNode>& ex, int root, F col, V colvalid) {
+  const JitExprNode& n = ex[(size_t)root];
+  if (n.kind == 0) return colvalid(root);
+  if (n.kind == 2 && n.op == FDB_OP_DIV) {
+    const std::string d = expr_value(ex, n.right, col);
+    return n.type == FDB_T_F64 ? ("(" + d + " != 0.0)") : ("(" + d + " != 0)");
+  }
+  return "true";
+}
+inline std::string expr_bits(const std::vector<JitExprNode>& ex, int root, const std::string& v) {
+  return ex[(size_t)root].type == FDB_T_F64 ? ("(unsigned long long)__double_as_longlong(" + v + ")") : ("(unsigned long long)" + v);
+}
+
 struct Gen {
   std::ostringstream o;
   const JitShape& s;
@@ -214,6 +251,7 @@ struct Gen {
     for (size_t l = 0; l < s.leaves.size(); l++)
       o << "  long long K_lit" << l << " = 0; uint32_t K_len" << l << " = 1, K_lds" << l << " = 0; int K_op" << l << " = 0; const uint8_t* K_lut" << l << " = nullptr;\n";
     for (size_t g = 0; g < s.gcols.size(); g++) o << "  uint32_t G_lds" << g << " = 0, G_stride" << g << " = 0; const uint32_t* G_lut" << g << " = nullptr;\n";
+    for (size_t i = 0; i < s.exprs.size(); i++) if (s.exprs[i].kind == 1) o << "  long long K_elit" << i << " = 0;\n";
     o << "  long long n_rows = 0, tile_begin = 0, tile_end = 0; int part = -1, lut_class = -1;\n";
     o << "  const uint32_t lane_off4 = tid * 16u, lane_off8 = tid * 32u, lane_offb = tid >> 1, lane_shb = (tid & 1u) * 4u;\n";
     o << "  for (long long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {\n";
@@ -233,6 +271,7 @@ struct Gen {
         << " = pa.leaves[" << l << "].op; K_lut" << l << " = pa.leaves[" << l << "].lut;\n";
     for (size_t g = 0; g < s.gcols.size(); g++)
       o << "      G_lds" << g << " = pa.gcols[" << g << "].lut_lds; G_stride" << g << " = pa.gcols[" << g << "].stride; G_lut" << g << " = pa.gcols[" << g << "].lut;\n";
+    for (size_t i = 0; i < s.exprs.size(); i++) if (s.exprs[i].kind == 1) o << "      K_elit" << i << " = pa.expr[" << i << "].lit;\n";
     o << "      if (pa.lut_class != lut_class) {\n        lut_class = pa.lut_class;\n        __syncthreads();\n";
     for (size_t l = 0; l < s.leaves.size(); l++)
       if (s.leaves[l].kind == FDB_LEAF_DICT_LUT && s.leaves[l].lut_in_lds)
@@ -272,9 +311,16 @@ struct Gen {
       for (size_t j = 0; j < s.aggs.size(); j++) {
         const JitAgg& A = s.aggs[j];
         if (A.func == FDB_AGG_COUNT) continue;
-        const std::string r = reg(true, s.two_phase, A.slot);
         const std::string comp = std::string(k < 2 ? "a" : "b") + (k % 2 == 0 ? ".x" : ".y");
-        const std::string raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : 0ull)";
+        std::string raw;
+        if (A.expr != 0) {  // computed input: the expression over this row's raw column values; a NULL (÷ 0) adds the zero slot
+          auto col = [&](int ni) { return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
+          auto colvalid = [&](int ni) { return "((" + reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
+          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col)) + " : 0ull)";
+        } else {
+          const std::string r = reg(true, s.two_phase, A.slot);
+          raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : 0ull)";
+        }
         const std::string acc = s.lds_acc ? ("(l_acc + (size_t)" + std::to_string(j) + " * n_slots + gid" + std::to_string(k) + ")")
                                            : ("(c.aggs[" + std::to_string(j) + "].acc + gid" + std::to_string(k) + ")");
         if (A.func == FDB_AGG_SUM) {
@@ -337,13 +383,23 @@ struct HashGen {
     o << "  for (int w = 2; w < h.key_words; w++) dst[w] = 0u;  // columns this record does not carry are NULL\n";
     o << "  dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);\n";
     o << "  const uint32_t vsh = (uint32_t)(row & 7);\n";
+    for (size_t i = 0; i < s.exprs.size(); i++) if (s.exprs[i].kind == 1) o << "  const long long K_elit" << i << " = h.base.expr[" << i << "].lit; (void)K_elit" << i << ";\n";
     const size_t G = 16;
     for (size_t c0 = 0; c0 < s.cols.size(); c0 += G) {
       const size_t c1 = std::min(s.cols.size(), c0 + G);
       o << "  {\n";
       for (size_t c = c0; c < c1; c++) {
         if (s.cols[c].kind == 0) o << "    const uint32_t x" << c << " = as_global(reinterpret_cast<const uint32_t*>(hc[" << c << "].values))[row];\n";
-        else o << "    const unsigned long long x" << c << " = as_global(reinterpret_cast<const unsigned long long*>(hc[" << c << "].values))[row];\n";
+        else if (s.cols[c].kind == 1) o << "    const unsigned long long x" << c << " = as_global(reinterpret_cast<const unsigned long long*>(hc[" << c << "].values))[row];\n";
+        else {  // computed key: evaluate its expression for this row again
+          auto col = [&](int ni) { return "as_global(reinterpret_cast<const unsigned long long*>(h.base.l8[" + std::to_string(s.exprs[(size_t)ni].slot) + "].values))[row]"; };
+          auto colvalid = [&](int ni) {
+            const std::string b = "h.base.l8[" + std::to_string(s.exprs[(size_t)ni].slot) + "].validity";
+            return "(" + b + " == nullptr || ((as_global(" + b + ")[row >> 3] >> vsh) & 1u))";
+          };
+          o << "    const bool ok" << c << " = " << expr_valid(s.exprs, s.cols[c].expr_root, col, colvalid) << ";\n";
+          o << "    const unsigned long long x" << c << " = " << expr_bits(s.exprs, s.cols[c].expr_root, expr_value(s.exprs, s.cols[c].expr_root, col)) << ";\n";
+        }
         if (s.cols[c].has_validity) o << "    const uint32_t v" << c << " = as_global(hc[" << c << "].validity)[row >> 3];\n";
       }
       for (size_t c = c0; c < c1; c++) {
@@ -354,7 +410,7 @@ struct HashGen {
         }
       }
       for (size_t c = c0; c < c1; c++) {
-        const std::string ok = s.cols[c].has_validity ? ("((v" + std::to_string(c) + " >> vsh) & 1u)") : "true";
+        const std::string ok = s.cols[c].kind == 2 ? ("ok" + std::to_string(c)) : s.cols[c].has_validity ? ("((v" + std::to_string(c) + " >> vsh) & 1u)") : "true";
         if (s.cols[c].kind == 0) o << "    dst[hc[" << c << "].word] = i" << c << ";\n";
         else o << "    { const unsigned long long y = " << ok << " ? x" << c << " : 0ull; dst[hc[" << c << "].word] = (uint32_t)y; dst[hc[" << c << "].word + 1] = (uint32_t)(y >> 32); }\n";
       }
@@ -382,6 +438,7 @@ struct HashGen {
         o << "  { uint32_t* dst = reinterpret_cast<uint32_t*>(smem + hc[" << c << "].lut_lds); const uint32_t n = hc[" << c << "].lut_len; const uint32_t* src = hc[" << c
           << "].lut; for (uint32_t i = tid; i < n; i += " << BLK << ") dst[i] = as_global(src)[i]; }\n";
     o << "  __syncthreads();\n";
+    for (size_t i = 0; i < s.exprs.size(); i++) if (s.exprs[i].kind == 1) o << "  const long long K_elit" << i << " = a.expr[" << i << "].lit; (void)K_elit" << i << ";\n";
     o << "  const int ew = h.entry_words;\n  const long long n_tiles = (h.row_end - h.row_begin + " << TILE - 1 << ") / " << TILE << ";\n";
     o << "  const uint32_t lane_shb = (tid & 1u) * 4u;\n";
     o << "  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {\n";
@@ -412,9 +469,14 @@ struct HashGen {
       o << "    sel &= " << Gen::filter_expr_of(s.code, [&](int l) { return Gen::leaf_expr_of(s.leaves[(size_t)l], l, "f" + std::to_string(l)); }) << ";\n";
       o << "    if (sel == 0u) continue;\n";
     }
-    // aggregated columns: requested now, consumed after the probe
+    // columns read by computed inputs / keys (base.l8), then the aggregated columns: requested now, consumed after the probe
+    for (int x = 0; x < s.n_expr_cols; x++) {
+      o << "    const u64x2 x" << x << "a = ld8(reinterpret_cast<const char*>(a.l8[" << x << "].values) + o8, lane_off8);\n";
+      o << "    const u64x2 x" << x << "b = ld8(reinterpret_cast<const char*>(a.l8[" << x << "].values) + o8, lane_off8 + 16u);\n";
+      o << "    const uint32_t x" << x << "_m = a.l8[" << x << "].validity != nullptr ? ldv(a.l8[" << x << "].validity + ob, lane_offb, lane_shb) : 0xFu; (void)x" << x << "_m;\n";
+    }
     for (size_t j = 0; j < s.aggs.size(); j++) {
-      if (s.aggs[j].func == FDB_AGG_COUNT) continue;
+      if (s.aggs[j].func == FDB_AGG_COUNT || s.aggs[j].expr != 0) continue;
       const std::string r = "g" + std::to_string(j);
       o << "    const u64x2 " << r << "a = ld8(reinterpret_cast<const char*>(a.aggs[" << j << "].values) + o8, lane_off8);\n";
       o << "    const u64x2 " << r << "b = ld8(reinterpret_cast<const char*>(a.aggs[" << j << "].values) + o8, lane_off8 + 16u);\n";
@@ -428,6 +490,7 @@ struct HashGen {
       for (size_t c = c0; c < c1; c++) {
         const JitHashCol& C = s.cols[c];
         const std::string r = "k" + std::to_string(c);
+        if (C.kind == 2) continue;
         if (C.kind == 0) o << "      const u32x4 " << r << " = ld4(reinterpret_cast<const char*>(hc[" << c << "].values) + o4, lane_off4);\n";
         else {
           o << "      const u64x2 " << r << "a = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, lane_off8);\n";
@@ -450,9 +513,18 @@ struct HashGen {
             o << "        { const uint32_t id = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_in_lds ? "L" : "as_global(L)") << "[" << r << comp4(k) << "] : 0u; fp_add32(h1_" << k << ", h2_"
               << k << ", K1, K2, id); if (id != 0u) vm_" << k << " |= bit; }\n";
           }
-        } else {
+        } else if (C.kind == 1) {
+          // int64 keys: NULL and the value 0 hash alike in the reference (dynparquet/hashed.go:254-272, zero hashes are skipped by
+          // aggregate.go:398-409), so neither contributes to the fingerprint; the valid bit records which of the two this row is
           for (int k = 0; k < 4; k++)
-            o << "        if ((" << r << "_m >> " << k << ") & 1u) { fp_add(h1_" << k << ", h2_" << k << ", K1, K2, " << comp8(r, k) << "); vm_" << k << " |= bit; }\n";
+            o << "        if ((" << r << "_m >> " << k << ") & 1u) { if (" << comp8(r, k) << " != 0ull) fp_add(h1_" << k << ", h2_" << k << ", K1, K2, " << comp8(r, k) << "); vm_" << k << " |= bit; }\n";
+        } else {
+          for (int k = 0; k < 4; k++) {
+            auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
+            auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
+            o << "        if (" << expr_valid(s.exprs, C.expr_root, col, colvalid) << ") { const unsigned long long y = " << expr_bits(s.exprs, C.expr_root, expr_value(s.exprs, C.expr_root, col))
+              << "; if (y != 0ull) fp_add(h1_" << k << ", h2_" << k << ", K1, K2, y); vm_" << k << " |= bit; }\n";
+          }
         }
         o << "      }\n";
       }
@@ -480,7 +552,12 @@ struct HashGen {
         const JitAgg& A = s.aggs[j];
         if (A.func == FDB_AGG_COUNT || (s.ablate & 2)) continue;
         const std::string r = "g" + std::to_string(j);
-        const std::string raw = "(((" + r + "_m >> " + std::to_string(k) + ") & 1u) ? " + comp8(r, k) + " : 0ull)";
+        std::string raw = "(((" + r + "_m >> " + std::to_string(k) + ") & 1u) ? " + comp8(r, k) + " : 0ull)";
+        if (A.expr != 0) {
+          auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
+          auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
+          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col)) + " : 0ull)";
+        }
         const std::string acc = "(e + " + std::to_string(3 + j) + ")";
         if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      atomicAdd(reinterpret_cast<double*>" << acc << ", __longlong_as_double((long long)" << raw << "));\n";
         else if (A.func == FDB_AGG_SUM) o << "      atomicAdd(" << acc << ", " << raw << ");\n";
@@ -513,7 +590,9 @@ std::string JitShape::key(bool with_validity) const {
   k << '|';
   for (const JitGroup& G : gcols) k << G.slot << ',' << G.lut_in_lds << ';';
   k << '|';
-  for (const JitAgg& A : aggs) k << A.func << ',' << A.type << ',' << A.slot << ';';
+  for (const JitAgg& A : aggs) k << A.func << ',' << A.type << ',' << A.slot << ',' << A.expr << ';';
+  k << '|';
+  for (const JitExprNode& e : exprs) k << e.kind << ',' << e.op << ',' << e.left << ',' << e.right << ',' << e.slot << ',' << e.type << ';';
   return k.str();
 }
 
@@ -537,7 +616,8 @@ JitShape jit_shape(const FdbScanArgs& a, bool two_phase, int block) {
   }
   s.code.assign(a.code, a.code + a.n_code);
   for (int g = 0; g < a.n_gcols; g++) s.gcols.push_back({a.gcols[g].slot, a.gcols[g].lut_lds != FDB_NO_LDS});
-  for (int j = 0; j < a.n_aggs; j++) s.aggs.push_back({a.aggs[j].func, a.aggs[j].type, a.aggs[j].slot});
+  for (int j = 0; j < a.n_aggs; j++) s.aggs.push_back({a.aggs[j].func, a.aggs[j].type, a.aggs[j].slot, a.aggs[j].expr});
+  for (int i = 0; i < a.n_expr; i++) s.exprs.push_back({a.expr[i].kind, a.expr[i].op, a.expr[i].left, a.expr[i].right, a.expr[i].slot, a.expr[i].type});
   return s;
 }
 
@@ -606,7 +686,7 @@ hipFunction_t jit_get(const JitShape& shape) {
 std::string JitHashShape::key() const {
   std::ostringstream k;
   k << "a" << ablate << "|";
-  for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g');
+  for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
   k << '|';
   for (size_t l = 0; l < leaves.size(); l++) {
     const JitLeaf& L = leaves[l];
@@ -615,14 +695,19 @@ std::string JitHashShape::key() const {
   k << '|';
   for (uint8_t c : code) k << (int)c << ',';
   k << '|';
-  for (size_t j = 0; j < aggs.size(); j++) k << aggs[j].func << ',' << aggs[j].type << ',' << agg_validity[j] << ';';
+  for (size_t j = 0; j < aggs.size(); j++) k << aggs[j].func << ',' << aggs[j].type << ',' << agg_validity[j] << ',' << aggs[j].expr << ';';
+  k << '|' << n_expr_cols << '|';
+  for (const JitExprNode& e : exprs) k << e.kind << ',' << e.op << ',' << e.left << ',' << e.right << ',' << e.slot << ',' << e.type << ';';
   return k.str();
 }
 
 JitHashShape jit_hash_shape(const FdbHashArgs& h, const FdbHashCol* hcols) {
   JitHashShape s;
   const FdbScanArgs& a = h.base;
-  for (int c = 0; c < h.n_hcols; c++) s.cols.push_back({hcols[c].kind, hcols[c].validity != nullptr, hcols[c].kind == 0 && hcols[c].lut_lds != FDB_NO_LDS});
+  for (int c = 0; c < h.n_hcols; c++)
+    s.cols.push_back({hcols[c].kind, hcols[c].validity != nullptr, hcols[c].kind == 0 && hcols[c].lut_lds != FDB_NO_LDS, hcols[c].kind == 2 ? hcols[c].src_word : -1});
+  for (int i = 0; i < a.n_expr; i++) s.exprs.push_back({a.expr[i].kind, a.expr[i].op, a.expr[i].left, a.expr[i].right, a.expr[i].slot, a.expr[i].type});
+  s.n_expr_cols = a.n_l8;
   for (int l = 0; l < a.n_leaves; l++) {
     const FdbLeaf& L = a.leaves[l];
     const bool wide = L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64;
@@ -631,7 +716,7 @@ JitHashShape jit_hash_shape(const FdbHashArgs& h, const FdbHashCol* hcols) {
   }
   s.code.assign(a.code, a.code + a.n_code);
   for (int j = 0; j < a.n_aggs; j++) {
-    s.aggs.push_back({a.aggs[j].func, a.aggs[j].type, -1});
+    s.aggs.push_back({a.aggs[j].func, a.aggs[j].type, -1, a.aggs[j].expr});
     s.agg_validity.push_back(a.aggs[j].validity != nullptr);
   }
   return s;

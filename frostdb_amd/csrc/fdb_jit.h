@@ -14,7 +14,8 @@ namespace fdb {
 struct JitSlot { bool has_values = false; int has_validity = 0; };  // has_validity: 0 no record has a bitmap, 1 every record, 2 some (checked per record)
 struct JitLeaf { int kind = 0, slot = -1, wide = 0, op = 0; bool lut_in_lds = false; };
 struct JitGroup { int slot = -1; bool lut_in_lds = false; };
-struct JitAgg { int func = 0, type = 0, slot = -1; };
+struct JitAgg { int func = 0, type = 0, slot = -1; int expr = 0; };  // expr: 1 + root node of a computed input, 0 = stored column
+struct JitExprNode { int kind = 0, op = 0, left = -1, right = -1, slot = -1, type = 0; };  // literal values stay run-time arguments
 
 // Everything that changes the generated CODE. Pointers, literals, truth-table bits, LUT offsets, strides and row counts
 // are run-time arguments and deliberately absent, so that queries of the same shape share one compiled kernel.
@@ -27,11 +28,12 @@ struct JitShape {
   std::vector<uint8_t> code;  // postfix program over the leaves
   std::vector<JitGroup> gcols;
   std::vector<JitAgg> aggs;
+  std::vector<JitExprNode> exprs;  // pre-aggregate arithmetic (FdbScanArgs.expr)
   std::string key(bool with_validity = true) const;
 };
 
 // Shape of a high-cardinality (hash table) scan: fdb_hash_kernel.
-struct JitHashCol { int kind = 0; bool has_validity = false, lut_in_lds = false; };
+struct JitHashCol { int kind = 0; bool has_validity = false, lut_in_lds = false; int expr_root = -1; };  // kind 2: computed int64 key
 struct JitHashShape {
   std::vector<JitHashCol> cols;
   std::vector<JitLeaf> leaves;  // slot / wide describe the leaf's own column (wide = 8-byte values)
@@ -39,6 +41,8 @@ struct JitHashShape {
   std::vector<uint8_t> code;
   std::vector<JitAgg> aggs;
   std::vector<bool> agg_validity;
+  std::vector<JitExprNode> exprs;  // column nodes read base.l8[slot]
+  int n_expr_cols = 0;
   int ablate = 0;  // tuning aid (tools/cfg5_ablate.py): 1 = stream + fingerprint only, 2 = no count / aggregate atomics
   std::string key() const;
 };

@@ -66,13 +66,26 @@ struct FdbGroupCol {
 enum FdbAggType : int32_t { FDB_T_NONE = 0, FDB_T_I64 = 1, FDB_T_F64 = 2 };
 
 struct FdbAgg {
-  const void* values;       // nullptr for COUNT (row count only)
+  const void* values;       // nullptr for COUNT (row count only) and for computed inputs
   const uint8_t* validity;
   unsigned long long* acc;  // global accumulator array [n_slots] (int64 bits / double bits / ordered-f64 keys)
   int32_t func;             // fdb_agg_func (SUM/MIN/MAX/COUNT)
-  int32_t type;             // FdbAggType of the input column
+  int32_t type;             // FdbAggType of the input column / expression
   int32_t slot;             // c8 slot
-  int32_t _pad;
+  int32_t expr;             // 1 + root node (FdbScanArgs.expr) of a computed input (pre-aggregate Projection); 0: stored column
+};
+
+// One node of a pre-aggregate arithmetic expression (physicalplan/project.go:73-161), evaluated per row inside the run-time
+// specialised kernels only (the interpreting kernels reject such plans). Structure and types are part of the kernel's
+// shape; literal VALUES are read from here at run time, so `timestamp / 1000 * 1000` and `timestamp / 5000 * 5000` share a kernel.
+#define FDB_MAX_EXPR_NODES 40
+struct FdbExprNode {
+  int64_t lit;              // literal: int64 value / float64 bits
+  int32_t kind;             // 0 column, 1 literal, 2 binary
+  int32_t op;               // binary: fdb_op (ADD 11, SUB 12, MUL 13, DIV 14)
+  int32_t left, right;      // binary: child node indices
+  int32_t slot;             // column: 8-byte slot in the pool the aggregates use (dense single-phase: c8, two-phase: l8; hash scan: l8)
+  int32_t type;             // FdbAggType of the node's value
 };
 
 // One distinct referenced column of the batch. The slot kernel issues the loads of ALL slots of a tile before
@@ -116,6 +129,9 @@ struct FdbScanArgs {
   FdbLeaf leaves[FDB_MAX_LEAVES];
   FdbGroupCol gcols[FDB_MAX_DENSE_GCOLS];
   FdbAgg aggs[FDB_MAX_AGGS];
+  int32_t n_expr;           // nodes of computed aggregate inputs / group keys (0: none)
+  int32_t _pad_expr;
+  FdbExprNode expr[FDB_MAX_EXPR_NODES];
 };
 
 // ---- high-cardinality path: global open-addressing hash table -------------------------------------------------
@@ -130,7 +146,7 @@ struct FdbHashCol {
   const uint32_t* lut;      // dictionary entry → key id (scan) / source key id → destination key id (merge; nullptr = identity)
   uint32_t lut_len;
   uint32_t lut_lds;         // byte offset of the LDS copy or FDB_NO_LDS
-  int32_t kind;             // 0 dictionary, 1 int64
+  int32_t kind;             // 0 dictionary, 1 int64, 2 computed int64 (src_word = root node of its expression; specialised scan only)
   int32_t word;             // first word of this column inside the key tuple
   int32_t gi;               // plan-level group column index (fingerprint salt, valid-mask bit)
   int32_t src_word;         // merge: first word of this column inside the INCOMING key tuple (-1: absent ⇒ NULL)

@@ -813,7 +813,9 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
           const unsigned long long x = valid ? wide[u] : 0ull;
           kstage[word[u] * FDB_HASH_BLOCK + tid] = (uint32_t)x;
           kstage[(word[u] + 1) * FDB_HASH_BLOCK + tid] = (uint32_t)(x >> 32);
-          if (valid) { fp_add(h1, h2, k1[u], k2[u], x); vmask |= 1ull << gi[u]; }
+          // (NULL and the value 0 hash alike in the reference — dynparquet/hashed.go:254-272, aggregate.go:398-409 — so neither
+          // contributes to the fingerprint; the valid bit keeps which of the two the inserting row was)
+          if (valid) { if (x != 0ull) fp_add(h1, h2, k1[u], k2[u], x); vmask |= 1ull << gi[u]; }
         }
       }
     }
@@ -956,7 +958,7 @@ __global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
         const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
         if ((in_mask >> C.lut_len) & 1ull) {  // lut_len carries the SOURCE plan's column index for int64 columns
           const unsigned long long v = (unsigned long long)in[C.src_word] | ((unsigned long long)in[C.src_word + 1] << 32);
-          fp_add(h1, h2, C.k1, C.k2, v);
+          if (v != 0ull) fp_add(h1, h2, C.k1, C.k2, v);
           vmask |= 1ull << C.gi;
         }
       }
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(256) void hash_partition_kernel(const FdbHashPartAr
           if (id != 0) { fp_add32(h1, h2, C.k1, C.k2, id); vmask |= 1ull << C.gi; }
         } else if ((in_mask >> C.lut_len) & 1ull) {
           const unsigned long long v = (unsigned long long)in[C.word] | ((unsigned long long)in[C.word + 1] << 32);
-          fp_add(h1, h2, C.k1, C.k2, v);
+          if (v != 0ull) fp_add(h1, h2, C.k1, C.k2, v);
           vmask |= 1ull << C.gi;
         }
       }

@@ -221,6 +221,33 @@ Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
     if (d->groups[i].name == nullptr) throw Error(FDB_ERR_INVALID, "group expression without a name");
     matchers_.push_back(GroupMatcher{d->groups[i].name, d->groups[i].dynamic != 0});
   }
+  for (int32_t i = 0; i < d->n_projections; i++) {
+    const fdb_projection& fp = d->projections[i];
+    if (fp.name == nullptr || fp.nodes == nullptr || fp.n_nodes <= 0 || fp.root < 0 || fp.root >= fp.n_nodes) throw Error(FDB_ERR_INVALID, "malformed projection");
+    if (final_stage_) throw Error(FDB_ERR_INVALID, "a final-stage plan has no pre-aggregate projection");
+    Projection P;
+    P.name = fp.name;
+    P.root = fp.root;
+    for (int32_t k = 0; k < fp.n_nodes; k++) {
+      const fdb_proj_node& fn = fp.nodes[k];
+      ProjNode n;
+      n.kind = fn.kind; n.op = fn.op; n.left = fn.left; n.right = fn.right;
+      if (fn.kind == 0) {
+        if (fn.column == nullptr) throw Error(FDB_ERR_INVALID, "projection column node without a name");
+        n.column = fn.column;
+      } else if (fn.kind == 1) {
+        if (fn.literal.type != FDB_LIT_INT64 && fn.literal.type != FDB_LIT_FLOAT64) throw Error(FDB_ERR_UNSUPPORTED, "projection literals must be int64 or float64");
+        n.lit_type = fn.literal.type; n.i64 = fn.literal.i64; n.f64 = fn.literal.f64;
+      } else if (fn.kind == 2) {
+        if (fn.op < FDB_OP_ADD || fn.op > FDB_OP_DIV) throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary expression in projection");  // project.go:122-123
+        if (fn.left < 0 || fn.left >= k || fn.right < 0 || fn.right >= k) throw Error(FDB_ERR_INVALID, "projection nodes must be in post-order");
+      } else {
+        throw Error(FDB_ERR_INVALID, "unknown projection node kind");
+      }
+      P.nodes.push_back(std::move(n));
+    }
+    projs_.push_back(std::move(P));
+  }
   hip_check(hipSetDevice(device_), "hipSetDevice");
   ctx_ = Context::acquire(device_);
   stream_ = ctx_->stream;
@@ -240,7 +267,49 @@ Plan::~Plan() {
   Context::release(ctx_);
 }
 
+const Projection* Plan::find_projection(const std::string& name) const {
+  for (const Projection& p : projs_) if (p.name == name) return &p;
+  return nullptr;
+}
+
+// One expression becomes a run of FdbExprNode in the record's argument block (children before parents). Types follow
+// binaryExprProjection.Project: the result has the left operand's type and the right operand must have the same one
+// (project.go:104-160 type-switches on the left array and type-asserts the right one).
+int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved* R) {
+  FdbScanArgs& a = R->args;
+  const int base = a.n_expr;
+  if (base + (int)p.nodes.size() > FDB_MAX_EXPR_NODES) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + " is too large for the device path");
+  for (size_t k = 0; k < p.nodes.size(); k++) {
+    const ProjNode& n = p.nodes[k];
+    FdbExprNode& e = a.expr[base + (int)k];
+    std::memset(&e, 0, sizeof(e));
+    e.kind = n.kind; e.op = n.op; e.left = e.right = -1; e.slot = -1;
+    if (n.kind == 0) {
+      const int ci = b.find(n.column);
+      if (ci < 0) throw Error(FDB_ERR_NOT_FOUND, "projection " + p.name + ": column " + n.column + " not found");
+      const DevColumn& c = b.cols[(size_t)ci];
+      e.type = c.kind == ColKind::I64 ? FDB_T_I64 : c.kind == ColKind::F64 ? FDB_T_F64 : FDB_T_NONE;
+      if (e.type == FDB_T_NONE) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": unsupported type of column " + n.column);  // project.go:157-159
+      if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
+      R->count(b, ci);
+      R->expr_col[base + (int)k] = ci;
+    } else if (n.kind == 1) {
+      e.type = n.lit_type == FDB_LIT_INT64 ? FDB_T_I64 : FDB_T_F64;
+      if (e.type == FDB_T_I64) e.lit = n.i64; else std::memcpy(&e.lit, &n.f64, 8);
+    } else {
+      e.left = base + n.left; e.right = base + n.right;
+      if (a.expr[e.left].type != a.expr[e.right].type)
+        throw Error(FDB_ERR_INVALID, "projection " + p.name + ": operand types differ (int64 vs float64)");
+      e.type = a.expr[e.left].type;
+    }
+  }
+  a.n_expr = base + (int)p.nodes.size();
+  return base + p.root;
+}
+
 bool Plan::references(const std::string& column) const {
+  for (const Projection& p : projs_)
+    for (const ProjNode& n : p.nodes) if (n.kind == 0 && n.column == column) return true;
   for (const ExprNode& e : filter_) if (is_leaf_op(e.op) && e.column == column) return true;
   for (const AggState& a : aggs_) if ((final_stage_ ? a.result_name : a.column) == column) return true;
   for (const GroupMatcher& m : matchers_) if (match_group(m, column)) return true;
@@ -655,22 +724,56 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
     (void)batch_gcols;
   }
 
+  // computed group keys: a plain matcher that names a projection (`… timestamp / 1000 * 1000 as timestamp_bucket` grouped by
+  // timestamp_bucket, logictest/testdata/plan/aggregate/window); the Projection appends its columns after the stored ones
+  for (const GroupMatcher& m : matchers_) {
+    if (m.dynamic) continue;
+    const Projection* P = find_projection(m.name);
+    if (P == nullptr) continue;
+    const int root = resolve_projection(*P, b, &R);
+    if (a.expr[root].type != FDB_T_I64)  // HashArray panics on float64 (dynparquet/hashed.go:102-103)
+      throw Error(FDB_ERR_UNSUPPORTED, "group by on a float64 expression (" + m.name + ") is not supported");
+    size_t gi = 0;
+    for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == m.name) break;
+    if (gi == gcols_.size()) {
+      if (gcols_.size() >= FDB_MAX_HASH_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "more than 64 group-by columns");
+      GroupColState g;
+      g.name = m.name; g.kind = 1; g.cap = 1; g.stride = 0;
+      gcols_.push_back(std::move(g));
+    }
+    if (gcols_[gi].kind != 1) throw Error(FDB_ERR_UNSUPPORTED, "group column " + m.name + " changed type between batches");
+    GroupRes gr;
+    gr.gi = (int)gi; gr.ci = -1; gr.kind = 2; gr.expr_root = root;
+    R.groups.push_back(std::move(gr));
+  }
+
   // aggregated columns, by exact name (aggregate.go:340-361); all must be present (:367-380)
   a.n_aggs = (int32_t)aggs_.size();
   int found = 0;
   for (size_t j = 0; j < aggs_.size(); j++)
-    if (b.find(final_stage_ ? aggs_[j].result_name : aggs_[j].column) >= 0) found++;
+    if (find_projection(aggs_[j].column) != nullptr || b.find(final_stage_ ? aggs_[j].result_name : aggs_[j].column) >= 0) found++;
   if (found == 0)
     throw Error(FDB_ERR_NOT_FOUND, std::string("aggregate field(s) not found, ") + (final_stage_ ? "final " : "") + "aggregations are not possible without it");
   for (size_t j = 0; j < aggs_.size(); j++) {
     AggState& A = aggs_[j];
-    const int ci = b.find(final_stage_ ? A.result_name : A.column);
-    if (ci < 0) throw Error(FDB_ERR_NOT_FOUND, "aggregate field not found: " + A.column);
-    const DevColumn& c = b.cols[(size_t)ci];
     FdbAgg& K = a.aggs[j];
     K.func = A.func;
     K.type = FDB_T_NONE;
     K.slot = -1;
+    K.expr = 0;
+    if (const Projection* P = find_projection(A.column)) {  // sum(value * timestamp): the aggregate reads a computed column
+      if (A.func == FDB_AGG_COUNT) continue;  // arr.Len(): nothing is read
+      const int root = resolve_projection(*P, b, &R);
+      const int32_t t = a.expr[root].type;
+      if (A.type == FDB_T_NONE) A.type = t;
+      else if (A.type != t) throw Error(FDB_ERR_UNSUPPORTED, "aggregated column " + A.column + " changed type between batches");
+      K.type = t;
+      K.expr = 1 + root;
+      continue;
+    }
+    const int ci = b.find(final_stage_ ? A.result_name : A.column);
+    if (ci < 0) throw Error(FDB_ERR_NOT_FOUND, "aggregate field not found: " + A.column);
+    const DevColumn& c = b.cols[(size_t)ci];
     if (A.func == FDB_AGG_COUNT && !final_stage_) continue;  // CountAggregation = arr.Len(): the column is not read (aggregate.go:937-950)
     int32_t t = c.kind == ColKind::I64 ? FDB_T_I64 : c.kind == ColKind::F64 ? FDB_T_F64 : FDB_T_NONE;
     if (t == FDB_T_NONE)  // ErrUnsupportedSumType / MinType / MaxType (aggregate.go:736, :782, :862)
@@ -690,24 +793,30 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
 // Assigns the column slots of the load-hoisting kernel. Returns 0 if the record references more columns than the
 // kernel has slots (→ sequential kernel), 1 for the single-phase layout (≤ 2 four-byte + ≤ 1 eight-byte columns in
 // total, all in c4/c8), 2 for the two-phase layout (filter columns in c4/c8, group-by / aggregate columns in l4/l8).
-static int assign_slots(const DeviceBatch& b, Plan::Resolved& R, int first_layout = 1) {
+// `relaxed`: only the limits of the argument block apply (the run-time specialised kernel has no register-resident plan);
+// *interp_ok then tells whether the interpreting slot kernel could run this record too.
+static int assign_slots(const DeviceBatch& b, Plan::Resolved& R, int first_layout = 1, bool relaxed = false, bool* interp_ok = nullptr) {
   FdbScanArgs& a = R.args;
   // static limits of the slot kernel's register-resident plan
-  if (a.n_leaves > 6 || a.n_gcols > 2 || a.n_aggs > 6) return 0;
+  bool strict = !(a.n_leaves > 6 || a.n_gcols > 2 || a.n_aggs > 6 || a.n_expr > 0);
+  if (!strict && !relaxed) return 0;
+  if (a.n_leaves > FDB_MAX_LEAVES || a.n_gcols > FDB_MAX_DENSE_GCOLS || a.n_aggs > FDB_MAX_AGGS) return 0;
+  auto fail_strict = [&]() -> bool { strict = false; return !relaxed; };
   {
     // postfix program → per-leaf trailing op lists (leaves are always pushed in index order)
     int leaf = -1;
     for (int l = 0; l < FDB_MAX_LEAVES; l++) a.ops_after[l] = 0;
     for (int pc = 0; pc < a.n_code; pc++) {
       const uint8_t op = a.code[pc];
-      if (op < 0x80) { if ((int)op != leaf + 1) return 0; leaf = op; continue; }
-      if (leaf < 0) return 0;
+      if (op < 0x80) { if ((int)op != leaf + 1) { if (fail_strict()) return 0; break; } leaf = op; continue; }
+      if (leaf < 0) { if (fail_strict()) return 0; break; }
       uint32_t& w = a.ops_after[leaf];
       const uint32_t n = w & 0xFu;
-      if (n >= 7) return 0;
+      if (n >= 7) { if (fail_strict()) return 0; break; }
       w = (w & ~0xFu) | (n + 1) | ((op == FDB_CODE_AND ? 1u : 2u) << (4 + 2 * n));
     }
   }
+  if (interp_ok != nullptr) *interp_ok = strict;
   struct Pool { FdbColSlot* slots; int32_t* n; int cap; int cols[8]; };
   auto slot_in = [&](Pool& P, int ci, bool need_values) -> int {
     const DevColumn& c = b.cols[(size_t)ci];
@@ -734,6 +843,8 @@ static int assign_slots(const DeviceBatch& b, Plan::Resolved& R, int first_layou
     for (int g = 0; g < a.n_gcols && ok; g++) { a.gcols[g].slot = slot_in(layout == 1 ? e4 : l4, R.gcol_col[g], true); ok = a.gcols[g].slot >= 0; }
     for (int j = 0; j < a.n_aggs && ok; j++)
       if (R.agg_col[j] >= 0 && a.aggs[j].values != nullptr) { a.aggs[j].slot = slot_in(layout == 1 ? e8 : l8, R.agg_col[j], true); ok = a.aggs[j].slot >= 0; }
+    for (int k = 0; k < a.n_expr && ok; k++)  // the columns computed aggregate inputs read share the aggregates' pool
+      if (a.expr[k].kind == 0) { a.expr[k].slot = slot_in(layout == 1 ? e8 : l8, R.expr_col[k], true); ok = a.expr[k].slot >= 0; }
     if (ok) return layout;
   }
   a.n_c4 = a.n_c8 = a.n_l4 = a.n_l8 = 0;
@@ -828,6 +939,8 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   const size_t acc_bytes = align_up((size_t)n_slots_ * 4, 16) + (size_t)n_slots_ * 8 * aggs_.size();
   size_t lut_lds_max = 0;
   bool slots_ok = rows_per_thread == 0;
+  const bool jit_possible = sub_tiles != 4 && ablate == 0 && std::getenv("FDB_NO_JIT") == nullptr;
+  bool interp_ok = true;  // every record also fits the interpreting slot kernel's limits
   std::vector<int> layouts;
   for (int i : live) {
     Resolved& R = Rs[(size_t)i];
@@ -852,8 +965,10 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     }
     lut_lds_max = std::max(lut_lds_max, align_up(lds_off, 16));
     if (slots_ok) {
-      const int layout = assign_slots(*bs[i], R);
+      bool strict = true;
+      const int layout = assign_slots(*bs[i], R, 1, jit_possible, &strict);
       if (layout == 0) slots_ok = false;
+      interp_ok = interp_ok && strict;
       layouts.push_back(layout);
     }
   }
@@ -894,22 +1009,21 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     return (unsigned long long*)p;
   };
 
+  // ---- choose the scan kernel: run-time specialised (fdb_jit.cpp) → interpreting slot kernel → sequential kernel ----------
+  int two_phase = 0, tile_rows_i = 0, per_cu = 1;
+  const int sub = sub_tiles == 4 ? 0 : sub_tiles;  // kernel variant mode (0 = default, 4 = interpreting kernel only)
+  hipFunction_t jit_fn = nullptr;
+  int jit_block = sub == 1 ? 512 : sub == 2 ? 256 : sub == 3 ? 1024 : 0;  // 0: picked by occupancy
   if (slots_ok) {
-    // ---- one launch of the slot kernel over every record -----------------------------------------------------
     // records that fit the single-phase layout also fit the two-phase one: re-assign them if the launch is mixed
-    int two_phase = 0;
     for (int l : layouts) if (l == 2) two_phase = 1;
     if (two_phase) {
       size_t k = 0;
       for (int i : live)
-        if (layouts[k++] == 1 && assign_slots(*bs[i], Rs[(size_t)i], 2) != 2) throw Error(FDB_ERR_INVALID, "internal: slot re-assignment failed");
+        if (layouts[k++] == 1 && assign_slots(*bs[i], Rs[(size_t)i], 2, jit_possible) != 2) throw Error(FDB_ERR_INVALID, "internal: slot re-assignment failed");
     }
-    int tile_rows_i = 0, per_cu = 1;
-    const int sub = sub_tiles == 4 ? 0 : sub_tiles;  // kernel variant mode (0 = default, 4 = interpreting kernel only)
     // A kernel specialised for this plan shape (fdb_jit.cpp), when every record of the launch has the same shape;
     // otherwise (or when hiprtc is unavailable) the interpreting slot kernel.
-    hipFunction_t jit_fn = nullptr;
-    int jit_block = sub == 1 ? 512 : sub == 2 ? 256 : sub == 3 ? 1024 : 0;  // 0: picked by occupancy
     if (sub_tiles != 4 && ablate == 0 && lds_bytes <= FDB_LDS_BUDGET) {
       JitShape shape;
       bool same = true, first = true;
@@ -930,6 +1044,13 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
         }
       }
     }
+    // a launch only the specialised kernel could serve (more leaves / aggregates than the interpreting kernel's register-resident
+    // plan holds, computed columns) falls back to the sequential kernel when specialisation is unavailable
+    if (jit_fn == nullptr && !interp_ok) slots_ok = false;
+  }
+
+  if (slots_ok) {
+    // ---- one launch of the slot kernel (specialised or interpreting) over every record -------------------------------------
     if (jit_fn != nullptr) {
       tile_rows_i = jit_block * 4;
     } else {
@@ -965,6 +1086,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     const int rpt = rows_per_thread == 8 ? 8 : 4;
     for (int i : live) {
       FdbScanArgs& a = Rs[(size_t)i].args;
+      if (a.n_expr > 0) throw Error(FDB_ERR_UNSUPPORTED, "computed (projected) columns are not supported by the sequential kernel (too many referenced columns)");
       a.n_c4 = a.n_c8 = 0;
       const int grid = fdb_scan_grid(a, base_grid, rpt);
       a.partials = alloc_partials(grid);

@@ -107,6 +107,10 @@ struct GroupColState {
 
 struct GroupMatcher { std::string name; bool dynamic; };
 
+// A computed column of the Projection between filter and aggregate (fdb_projection; project.go:58-161).
+struct ProjNode { int32_t kind = 0, op = 0, left = -1, right = -1; std::string column; int32_t lit_type = 0; int64_t i64 = 0; double f64 = 0; };
+struct Projection { std::string name; std::vector<ProjNode> nodes; int32_t root = -1; };
+
 enum class TableMode { DENSE, HASH };
 
 // Occupied groups of a plan's table in host memory, independent of the table's device representation.
@@ -169,6 +173,10 @@ class Plan {
  private:
   const char* last_kernel_ = "";  // name of the scan kernel of the latest push
   bool references(const std::string& column) const;
+  std::vector<Projection> projs_;
+  const Projection* find_projection(const std::string& name) const;
+  // Appends the nodes of `p` to R->args.expr (columns resolved against `b`, types checked); returns the root's index.
+  int resolve_projection(const Projection& p, const DeviceBatch& b, Resolved* R);
   void resolve_batch(const DeviceBatch& b, Resolved* R, std::vector<int>* batch_gcols);
   void ensure_layout(const std::vector<uint32_t>& new_caps);
   void sync();

@@ -41,7 +41,8 @@ struct PendingLut { int kind; int index; size_t blob_off; size_t len_bytes; };  
 
 
 struct GroupRes {
-  int gi, ci, kind;
+  int gi, ci, kind;      // kind 2: computed int64 key (ci = -1, expr_root = root node in the record's args.expr)
+  int expr_root = -1;
   std::shared_ptr<const std::vector<uint32_t>> lut;
 };
 
@@ -54,11 +55,13 @@ struct Plan::Resolved {
   int leaf_col[FDB_MAX_LEAVES];           // batch column behind each leaf (-1: constant leaf)
   int gcol_col[FDB_MAX_DENSE_GCOLS];
   int agg_col[FDB_MAX_AGGS];
+  int expr_col[FDB_MAX_EXPR_NODES];       // batch column behind each expression column node
   std::vector<GroupRes> groups;           // group-by columns of this record (plan-level index, record column, kind, key-id LUT)
   Resolved() {
     for (int& v : leaf_col) v = -1;
     for (int& v : gcol_col) v = -1;
     for (int& v : agg_col) v = -1;
+    for (int& v : expr_col) v = -1;
   }
   // Algorithmic bytes: each referenced buffer once per row, whatever the number of references.
   void count(const DeviceBatch& b, int ci, bool values = true) {

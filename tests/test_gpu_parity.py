@@ -735,3 +735,73 @@ def test_hash_exchange_rccl_single_rank_and_dense_source(pp):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ---- pre-aggregate Projection fused into the scan (project.go:73-399) ----------------------------------------
+
+def _gpu_runner(pp):
+    def make(filter_expr, aggs, groups):
+        def run(recs):
+            return run_gpu(pp, recs, filter_expr, aggs, groups)
+        return run
+    return make
+
+
+@pytest.mark.parametrize("case", G.MATH_CASES, ids=[c["id"] for c in G.MATH_CASES])
+def test_golden_math_projection(pp, case):
+    """The reference's arithmetic vectors (logictest/testdata/exec/aggregate/math) through the fused operator: computed
+    aggregate inputs (`sum(<expr>) group by timestamp`) and computed group keys (`count(value) group by <expr>`)."""
+    from tests.test_oracle_golden import run_math_case
+    run_math_case(_gpu_runner(pp), case)
+
+
+@pytest.mark.parametrize("case", G.WINDOW_CASES, ids=[c["id"] for c in G.WINDOW_CASES])
+def test_golden_window_fused_projection(pp, case):
+    """window:13-63 with `(timestamp/bucket)*bucket as timestamp_bucket` computed inside the scan kernel."""
+    bucket = (Col("timestamp") / case["bucket"] * case["bucket"]).Alias("timestamp_bucket")
+    groups = [bucket if g.name == "timestamp_bucket" else g for g in case["groups"]]
+    d = run_gpu(pp, table_records(G.WINDOW_TABLE), None, case["aggs"], groups)
+    assert sorted(batch_rows(d, case["out"]), key=sort_key) == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+def test_projection_dense_and_hash_vs_oracle(pp):
+    """Computed aggregate inputs on the dense path (two label columns) and computed int64 keys on the hash path, random data,
+    int64 and float64 arithmetic, division by zero (value == 0 occurs), a filter in front; checked against the oracle."""
+    rng = np.random.default_rng(91)
+    batches = [many_label_batch(rng, 60_000, 2, 5, int_key=True), many_label_batch(rng, 45_001, 2, 5, int_key=True)]
+    V, F, B = Col("value"), Col("floatvalue"), Col("bucket")
+    aggs = [Sum(V * B), Count(V), Min(V * V - B), Max(B / V), Sum(F * 2.5), Max(F / F), Min((F + 1.0) * F), Sum(V)]
+    filt = V > -50
+    for groups, float_cols in (([DynCol("labels")], {"sum(floatvalue * 2.5)"}),
+                               ([Col("labels.l00"), (B / 7000 * 7000).Alias("b7")], {"sum(floatvalue * 2.5)"}),
+                               ([(V / 10).Alias("tens"), (B - B).Alias("zero")], {"sum(floatvalue * 2.5)"})):
+        want = run_oracle(batches, filt, aggs, groups)
+        got = run_gpu(pp, batches, filt, aggs, groups, resident=True)
+        keys = [g.name for g in groups if not g.dynamic] if not any(g.dynamic for g in groups) else ["labels.l00", "labels.l01"]
+        cols = keys + [a.Name() for a in aggs]
+        # an int64 key of 0 and a NULL key are one group in the reference (hash 0 for both); which of the two is printed depends on
+        # arrival order, so compare with NULL folded into 0 for computed keys
+        for d in (want, got):
+            for k in keys:
+                if not k.startswith("labels."):
+                    d[k] = [0 if v is None else v for v in d[k]]
+        assert_same_result(got, want, cols, float_cols=float_cols)
+
+
+def test_projection_needs_specialised_kernel(pp, monkeypatch):
+    monkeypatch.setenv("FDB_NO_JIT", "1")
+    rng = np.random.default_rng(92)
+    b = many_label_batch(rng, 1000, 2, 3, int_key=True)
+    plan = pp.HashAggregatePlan(None, [Sum(Col("value") * Col("bucket"))], [DynCol("labels")])
+    try:
+        with pytest.raises(pp.UnsupportedError):
+            plan.Callback(b)
+    finally:
+        plan.Close()
+    plan = pp.HashAggregatePlan(None, [Sum(Col("value") * Col("floatvalue"))], [DynCol("labels")])  # int64 * float64: the reference panics
+    monkeypatch.delenv("FDB_NO_JIT")
+    try:
+        with pytest.raises(pp.FdbError):
+            plan.Callback(b)
+    finally:
+        plan.Close()
