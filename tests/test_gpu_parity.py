@@ -805,3 +805,18 @@ def test_projection_needs_specialised_kernel(pp, monkeypatch):
             plan.Callback(b)
     finally:
         plan.Close()
+
+
+def test_config1_simple_schema(pp, variant):
+    """BASELINE.json configs[0] (examples/simple schema: utf8 dictionaries, names.middle_name only in some records, int64 value):
+    `names.first_name == 'Frederic'` + SUM(value), ungrouped, by surname, and by every names.* column — vs the oracle."""
+    from tests.util import make_simple_batches
+    batches = make_simple_batches(np.random.default_rng(1), 10_000, 3)
+    f = Col("names.first_name") == "Frederic"
+    for aggs, groups, cols in (([Sum(Col("value")), Count(Col("value"))], [], ["sum(value)", "count(value)"]),
+                               ([Sum(Col("value"))], [Col("names.surname")], ["names.surname", "sum(value)"]),
+                               ([Sum(Col("value")), Max(Col("value"))], [DynCol("names")],
+                                ["names.first_name", "names.surname", "names.middle_name", "sum(value)", "max(value)"])):
+        want = run_oracle(batches, f, aggs, groups)
+        got = run_gpu(pp, batches, f, aggs, groups)
+        assert_same_result(got, want, cols)

@@ -175,3 +175,26 @@ def test_oracle_window_golden_with_fused_projection(case):
     res = _oracle_runner(None, case["aggs"], groups)(table_records(G.WINDOW_TABLE))
     got = sorted(batch_rows(res, case["out"]), key=sort_key)
     assert got == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+def test_config1_simple_schema_known_answer():
+    """BASELINE.json configs[0]: examples/simple schema, 10 k rows, `names.first_name == 'Frederic'` + SUM(value) — the
+    reference's own CPU-runnable case (examples/simple/simple.go:66-75 filters exactly this). Known answer from numpy."""
+    import numpy as np
+    from tests.util import make_simple_batches
+    batches = make_simple_batches(np.random.default_rng(1), 10_000, 3)
+    want_sum, want_rows, by_surname = 0, 0, {}
+    for b in batches:
+        first = b.column(0).to_pylist()
+        sur = b.column(1).to_pylist()
+        val = b.column(b.schema.get_field_index("value")).to_pylist()
+        for f, s, v in zip(first, sur, val):
+            if f == "Frederic":
+                want_sum += v; want_rows += 1
+                by_surname[s] = by_surname.get(s, 0) + v
+    run = _oracle_runner(Col("names.first_name") == "Frederic", [Sum(Col("value")), Count(Col("value"))], [])
+    d = run(batches)
+    assert d["sum(value)"] == [want_sum] and d["count(value)"] == [want_rows]
+    d = _oracle_runner(Col("names.first_name") == "Frederic", [Sum(Col("value"))], [Col("names.surname")])(batches)
+    got = {k.decode() if isinstance(k, bytes) else k: v for k, v in zip(d["names.surname"], d["sum(value)"])}
+    assert got == by_surname

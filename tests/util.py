@@ -122,3 +122,26 @@ def make_prometheus_batch(rng: np.random.Generator, n: int, n_path: int = 64, nu
     arrays += [pa.array(ts), pa.array(value)]
     names += ["timestamp", "value"]
     return pa.RecordBatch.from_arrays(arrays, names=names)
+
+
+def make_simple_batches(rng, total_rows=10_000, n_records=3):
+    """BASELINE.json config 1: the `examples/simple` schema (examples/simple/simple.go:24-27) — dynamic `names.*` label columns
+    (the struct-tag ingest path yields dictionary<uint32, utf8>, internal/records/record_builder.go:510-524) + `value int64`.
+    Like the example, only some records carry `names.middle_name` (schema drift between records)."""
+    firsts = ["Frederic", "Thor", "Matthias", "Ada", "Grace"]
+    surnames = ["Brancz", "Hansen", "Loibl", "Lovelace", "Hopper", "Ritchie", "Pike"]
+    middles = ["Oliver Rainer", "B.", "M."]
+    utf8_dict = pa.dictionary(pa.uint32(), pa.string())
+    out = []
+    per = total_rows // n_records
+    for r in range(n_records):
+        n = per if r < n_records - 1 else total_rows - per * (n_records - 1)
+        cols = {
+            "names.first_name": dict_array([firsts[i] for i in rng.integers(0, len(firsts), size=n)], utf8_dict),
+            "names.surname": dict_array([surnames[i] for i in rng.integers(0, len(surnames), size=n)], utf8_dict),
+        }
+        if r % 2 == 1:
+            cols["names.middle_name"] = dict_array([None if rng.random() < 0.5 else middles[rng.integers(0, len(middles))] for _ in range(n)], utf8_dict)
+        cols["value"] = pa.array(rng.integers(90, 110, size=n), type=pa.int64())
+        out.append(pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols.keys())))
+    return out
