@@ -356,6 +356,11 @@ const char* Plan::draw() {
       s += " by ";
       for (size_t i = 0; i < matchers_.size(); i++) s += (i ? "," : "") + matchers_[i].name;
       s += ")";
+    } else if (!matchers_.empty()) {  // distinct.go:32-45
+      if (!s.empty()) s += " - ";
+      s += "Distinction (";
+      for (size_t i = 0; i < matchers_.size(); i++) s += (i ? "," : "") + matchers_[i].name;
+      s += ")";
     }
     draw_ = s + " [gfx950]";
   }
@@ -752,7 +757,7 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
   int found = 0;
   for (size_t j = 0; j < aggs_.size(); j++)
     if (find_projection(aggs_[j].column) != nullptr || b.find(final_stage_ ? aggs_[j].result_name : aggs_[j].column) >= 0) found++;
-  if (found == 0)
+  if (found == 0 && !aggs_.empty())
     throw Error(FDB_ERR_NOT_FOUND, std::string("aggregate field(s) not found, ") + (final_stage_ ? "final " : "") + "aggregations are not possible without it");
   for (size_t j = 0; j < aggs_.size(); j++) {
     AggState& A = aggs_[j];
@@ -855,7 +860,9 @@ static int assign_slots(const DeviceBatch& b, Plan::Resolved& R, int first_layou
 // table init, ramp-up, tail, table flush — are paid once per scan instead of once per record).
 void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   if (finished_) throw Error(FDB_ERR_STATE, "push after finish");
-  if (aggs_.empty()) throw Error(FDB_ERR_STATE, "filter-only plan: use fdb_plan_filter / fdb_plan_select");
+  // no aggregations but group matchers: `Filter → Distinction` (distinct.go:21-170) — the table only records which key tuples
+  // exist; Finish emits them (the reference emits them record by record as they are first seen; the set is the same)
+  if (aggs_.empty() && matchers_.empty()) throw Error(FDB_ERR_STATE, "filter-only plan: use fdb_plan_filter / fdb_plan_select");
   for (int i = 0; i < n; i++)
     if (bs[i]->device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
   hip_check(hipSetDevice(device_), "hipSetDevice");

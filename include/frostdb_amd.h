@@ -155,7 +155,8 @@ typedef struct fdb_plan_desc {
   const fdb_expr* filter;      /* NULL / n_filter == 0 ⇒ no PredicateFilter in the chain */
   int32_t n_filter;
   int32_t filter_root;         /* index of the root node */
-  const fdb_aggregation* aggs; /* n_aggs == 0 ⇒ filter-only plan (only fdb_plan_filter is valid) */
+  const fdb_aggregation* aggs; /* n_aggs == 0: with n_groups > 0 the chain is Filter → Distinction (distinct.go:21-170; push/finish emit
+                                  the distinct key tuples), with n_groups == 0 a filter-only plan (only fdb_plan_filter / _select) */
   int32_t n_aggs;
   int32_t n_groups;
   const fdb_group_expr* groups;

@@ -255,6 +255,11 @@ struct PlanDesc {
   std::vector<AggDesc> aggs;
   std::vector<GroupDesc> groups;
   std::vector<ProjDesc> projs;  // computed columns of the Projection between filter and aggregate
+  // No aggregations, only group columns ⇒ the chain is `Filter → Distinction` (physicalplan/distinct.go:21-170): the same
+  // hash-of-selected-columns identity as the aggregate (hashCombine(fieldNameHash, colHash), zero hashes skipped, :108-124)
+  // with a `seen` set instead of builders per group; per chain a Distinction, then Synchronizer + one more Distinction
+  // (physicalplan.go:365-388) — modelled by the partial / final HashAggregate pair with an empty aggregation list.
+  bool distinct = false;
 };
 
 using Bitmap = std::vector<uint8_t>;  // stand-in for roaring.Bitmap: one byte per row
@@ -610,7 +615,7 @@ struct HashAggregate {
         if (final_stage ? (a.result_name == fname) : (a.column == fname)) { column_to_aggregate[j] = &r.cols[i]; concrete_found++; }
       }
     }
-    if (concrete_found == 0 || plan->aggs.empty()) {  // aggregate.go:367-380
+    if (!plan->distinct && (concrete_found == 0 || plan->aggs.empty())) {  // aggregate.go:367-380
       *err = {FDB_ERR_NOT_FOUND, "aggregate field(s) not found, aggregations are not possible without it"};
       return false;
     }
@@ -836,6 +841,7 @@ int oracle_plan_create(const fdb_plan_desc* d, int32_t nchains, uint64_t seed, o
     }
     p->desc.projs.push_back(std::move(pd));
   }
+  p->desc.distinct = d->n_aggs == 0 && d->n_groups > 0;
   p->partial.resize(p->nchains);
   for (auto& h : p->partial) h.init(&p->desc, false, seed);
   p->final_agg.init(&p->desc, true, seed);

@@ -22,6 +22,7 @@ FILTER_FILE = "logictest/testdata/exec/filter/filter"
 FPROJ_FILE = "logictest/testdata/exec/filter/filter_projection"
 WINDOW_FILE = "logictest/testdata/exec/aggregate/window"
 MATH_FILE = "logictest/testdata/exec/aggregate/math"
+DISTINCT_FILE = "logictest/testdata/exec/distinct/distinct"
 
 # ---- tables -------------------------------------------------------------------------------------
 
@@ -271,3 +272,40 @@ INCONSISTENT_SCHEMA = dict(
     cite="aggregate_test.go:85-114",
     expected={"sum": [5, 1], "min": [2, 1], "max": [3, 1], "count": [2, 1], "avg": [2, 1]},
 )
+
+
+# ---- Distinct (distinct:4-8 table): `select distinct(cols…) [where …]` = TableScan → Filter → Distinction ------------------
+# A plan with NO aggregations and the distinct columns as group matchers; expected = the distinct rows, in the SELECT's order.
+DISTINCT_TABLE = dict(
+    cols=["labels.label1", "labels.label2", "labels.label3", "labels.label4", "labels.label5"],
+    inserts=[
+        """
+        value1  value1  null    null    value1
+        value2  value2  value3  null    value1
+        value3  value1  null    value4  value1
+        """,
+    ],
+)
+_b = lambda *xs: tuple(None if x is None else x.encode() for x in xs)  # noqa: E731
+DISTINCT_CASES = [
+    dict(id="label1", cite=f"{DISTINCT_FILE}:10-15", filter=None, groups=[L(1)], out=["labels.label1"],
+         expected=[_b("value1"), _b("value2"), _b("value3")]),
+    dict(id="label2", cite=f"{DISTINCT_FILE}:17-21", filter=None, groups=[L(2)], out=["labels.label2"], expected=[_b("value1"), _b("value2")]),
+    dict(id="label3_with_null", cite=f"{DISTINCT_FILE}:23-27", filter=None, groups=[L(3)], out=["labels.label3"], expected=[_b(None), _b("value3")]),
+    dict(id="label1_label2", cite=f"{DISTINCT_FILE}:29-34", filter=None, groups=[L(1), L(2)], out=["labels.label1", "labels.label2"],
+         expected=[_b("value1", "value1"), _b("value2", "value2"), _b("value3", "value1")]),
+    dict(id="label1_2_3", cite=f"{DISTINCT_FILE}:38-43", filter=None, groups=[L(1), L(2), L(3)], out=["labels.label1", "labels.label2", "labels.label3"],
+         expected=[_b("value1", "value1", None), _b("value2", "value2", "value3"), _b("value3", "value1", None)]),
+    dict(id="label1_2_4", cite=f"{DISTINCT_FILE}:45-50", filter=None, groups=[L(1), L(2), L(4)], out=["labels.label1", "labels.label2", "labels.label4"],
+         expected=[_b("value1", "value1", None), _b("value2", "value2", None), _b("value3", "value1", "value4")]),
+    dict(id="label1_2_5", cite=f"{DISTINCT_FILE}:52-57", filter=None, groups=[L(1), L(2), L(5)], out=["labels.label1", "labels.label2", "labels.label5"],
+         expected=[_b("value1", "value1", "value1"), _b("value2", "value2", "value1"), _b("value3", "value1", "value1")]),
+    dict(id="label1_2_3_4", cite=f"{DISTINCT_FILE}:59-64", filter=None, groups=[L(1), L(2), L(3), L(4)],
+         out=["labels.label1", "labels.label2", "labels.label3", "labels.label4"],
+         expected=[_b("value1", "value1", None, None), _b("value2", "value2", "value3", None), _b("value3", "value1", None, "value4")]),
+    dict(id="dynamic_labels", cite=f"{DISTINCT_FILE}:67-72", filter=None, groups=[DynCol("labels")],
+         out=["labels.label1", "labels.label2", "labels.label3", "labels.label4", "labels.label5"],
+         expected=[_b("value1", "value1", None, None, "value1"), _b("value2", "value2", "value3", None, "value1"), _b("value3", "value1", None, "value4", "value1")]),
+    dict(id="with_filter", cite=f"{DISTINCT_FILE}:75-78", filter=And(L(2) == "value1", L(4) == "value4"), groups=[L(1)], out=["labels.label1"],
+         expected=[_b("value3")]),
+]

@@ -820,3 +820,33 @@ def test_config1_simple_schema(pp, variant):
         want = run_oracle(batches, f, aggs, groups)
         got = run_gpu(pp, batches, f, aggs, groups)
         assert_same_result(got, want, cols)
+
+
+# ---- Distinct = a plan without aggregations (distinct.go:21-170) ---------------------------------------------
+
+@pytest.mark.parametrize("case", G.DISTINCT_CASES, ids=[c["id"] for c in G.DISTINCT_CASES])
+def test_golden_distinct(pp, case, variant):
+    d = run_gpu(pp, table_records(G.DISTINCT_TABLE), case["filter"], [], case["groups"])
+    assert sorted(batch_rows(d, case["out"]), key=sort_key) == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+def test_distinct_at_scale_dense_and_hash(pp):
+    """Distinct label tuples of random data: dense table (2 columns), hash table (12 columns + an int64 key), with a filter,
+    two chains merged — vs the oracle."""
+    rng = np.random.default_rng(515)
+    for n_cols, n_groups, int_key in ((2, None, False), (12, 30_000, True)):
+        batches = [many_label_batch(rng, 80_000, n_cols, 4, n_groups=n_groups, int_key=int_key), many_label_batch(rng, 50_000, n_cols, 4, n_groups=n_groups, int_key=int_key)]
+        groups = [DynCol("labels")] + ([Col("bucket")] if int_key else [])
+        filt = Col("value") >= 0
+        want = run_oracle(batches, filt, [], groups, nchains=2)
+        p1 = pp.HashAggregatePlan(filt, [], groups)
+        p2 = pp.HashAggregatePlan(filt, [], groups)
+        try:
+            assert "Distinction (labels" in p1.Draw()
+            p1.Callback(batches[0]); p2.Callback(batches[1])
+            p1.Merge(p2)
+            got = arrow_to_pydict(p1.Finish())
+        finally:
+            p1.Close(); p2.Close()
+        cols = key_cols_of(batches, extra=("bucket",) if int_key else ())
+        assert_same_result(got, want, cols)

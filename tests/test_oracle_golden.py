@@ -198,3 +198,17 @@ def test_config1_simple_schema_known_answer():
     d = _oracle_runner(Col("names.first_name") == "Frederic", [Sum(Col("value"))], [Col("names.surname")])(batches)
     got = {k.decode() if isinstance(k, bytes) else k: v for k, v in zip(d["names.surname"], d["sum(value)"])}
     assert got == by_surname
+
+
+@pytest.mark.parametrize("nchains", [1, 2])
+@pytest.mark.parametrize("case", G.DISTINCT_CASES, ids=[c["id"] for c in G.DISTINCT_CASES])
+def test_oracle_distinct_golden(case, nchains):
+    """Distinction (distinct.go:72-170) = a plan without aggregations; per chain, then Synchronizer + a final Distinction."""
+    recs = table_records(G.DISTINCT_TABLE)
+    plan = OraclePlan(case["filter"], [], case["groups"], nchains=nchains)
+    for i, r in enumerate(recs):
+        plan.push(r, chain=i % nchains)
+    d = plan.finish().to_pydict()
+    plan.close()
+    got = sorted(batch_rows(d, case["out"]), key=sort_key)
+    assert got == sorted(case["expected"], key=sort_key), case["cite"]
