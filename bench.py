@@ -144,8 +144,11 @@ def main():
     t_gen = time.time() - t_gen
     hbm_bytes = sum(r.device_bytes for r in resident)
 
+    from frostdb_amd.logicalplan import to_desc
+    desc = to_desc(filt, aggs, groups)  # the query is planned once; every step instantiates and runs a fresh operator chain
+
     def step(timing=False, tuning=None):
-        plan = pp.HashAggregatePlan(filt, aggs, groups, device=local_rank)
+        plan = pp.HashAggregatePlan(filt, aggs, groups, device=local_rank, desc=desc)
         if timing:
             plan.set_timing(True)
         if tuning:

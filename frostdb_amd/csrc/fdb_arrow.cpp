@@ -5,6 +5,9 @@
 #include <cstring>
 #include <string_view>
 #include <unordered_set>
+#include <memory>
+#include <unordered_map>
+#include <mutex>
 
 namespace fdb {
 
@@ -98,6 +101,20 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
     if (!seen.insert(std::string_view(v)).second) d->unique = false;
   }
   d->hash = h;
+  // Dictionaries with identical content are shared: the parts of one table usually carry the same dictionary, and one object
+  // for all of them turns every later "same dictionary?" test (key-id LUT cache, LUT de-duplication across the records of a
+  // launch) into a pointer compare instead of thousands of string compares per record and query.
+  static std::mutex mu;
+  static std::unordered_multimap<uint64_t, std::weak_ptr<HostDict>> live;
+  std::lock_guard<std::mutex> lk(mu);
+  auto range = live.equal_range(h);
+  for (auto it = range.first; it != range.second;) {
+    std::shared_ptr<HostDict> other = it->second.lock();
+    if (!other) { it = live.erase(it); continue; }
+    if (other->value_format == d->value_format && other->values == d->values) return other;
+    ++it;
+  }
+  live.emplace(h, d);
   return d;
 }
 

@@ -150,10 +150,12 @@ class HashAggregatePlan:
     """One fused ``PredicateFilter → HashAggregate`` chain on one GPU."""
 
     def __init__(self, filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (),
-                 groups: Sequence[Column] = (), device: int = 0, final_stage: bool = False):
-        self._desc = to_desc(filter_expr, list(aggs), list(groups), final_stage)
+                 groups: Sequence[Column] = (), device: int = 0, final_stage: bool = False, desc=None):
+        """`desc`: a descriptor built once with `to_desc(filter_expr, aggs, groups, final_stage)` and shared by every chain /
+        execution of the same query (≙ the logical plan being built once and `physicalplan.Build` instantiating N chains)."""
+        self._desc = desc if desc is not None else to_desc(filter_expr, list(aggs), list(groups), final_stage)
         self.aggs = list(aggs)
-        self._ctor = (filter_expr, list(aggs), list(groups), device, final_stage)
+        self._ctor = (filter_expr, list(aggs), list(groups), device, final_stage, self._desc)
         out = ctypes.c_void_p()
         rc = lib().fdb_plan_create(ctypes.addressof(self._desc.desc), device, ctypes.byref(out))
         if rc != 0:
@@ -169,8 +171,8 @@ class HashAggregatePlan:
 
     def clone_empty(self) -> "HashAggregatePlan":
         """A fresh plan with the same descriptor on the same device (no state)."""
-        f, a, g, d, fs = self._ctor
-        return HashAggregatePlan(f, a, g, device=d, final_stage=fs)
+        f, a, g, d, fs, desc = self._ctor
+        return HashAggregatePlan(f, a, g, device=d, final_stage=fs, desc=desc)
 
     # ---- PhysicalPlan verbs --------------------------------------------------------------------------
     def Callback(self, record) -> None:
