@@ -144,7 +144,8 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     std::memset(&h, 0, sizeof(h));
     h.base = R.args;
     FdbScanArgs& a = h.base;
-    a.need_count = 1;
+    a.need_count = 0;  // the row count of an entry is only read back for COUNT aggregations (occupancy is "fingerprint ≠ 0")
+    for (size_t j = 0; j < aggs_.size(); j++) if (aggs_[j].func == FDB_AGG_COUNT && !final_stage_) a.need_count = 1;
     a.ablate = ablate;
     // columns read by computed aggregate inputs / keys go into base.l8 (the hash scan has no other use for the slot pools)
     bool has_expr = a.n_expr > 0;

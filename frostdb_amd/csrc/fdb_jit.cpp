@@ -538,16 +538,18 @@ struct HashGen {
     // Probe: the home entries of the 4 rows are requested together (one memory round trip for the common case "group exists
     // and sits in its home slot"); rows that miss there take the general find-or-insert path.
     for (int k = 0; k < 4; k++) o << "    uint64_t slot_" << k << " = h1_" << k << " & h.mask; unsigned long long p_" << k << " = 0, q_" << k << " = 0;\n";
+    // (one plain 16-byte load per row: a fingerprint never changes once written, so a stale cached copy can only make the row
+    // miss here and take the general path, whose loads are coherent — never match wrongly)
     for (int k = 0; k < 4; k++)
-      o << "    if ((sel >> " << k << ") & 1u) { p_" << k << " = __hip_atomic_load(h.table + slot_" << k << " * (uint64_t)ew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); q_" << k
-        << " = __hip_atomic_load(h.table + slot_" << k << " * (uint64_t)ew + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n";
+      o << "    if ((sel >> " << k << ") & 1u) { const u64x2 pq = *as_global(reinterpret_cast<const u64x2*>(h.table + slot_" << k << " * (uint64_t)ew)); p_" << k << " = pq.x; q_" << k
+        << " = pq.y; }\n";
     o << "    uint32_t ins_mask = 0;\n";
     for (int k = 0; k < 4; k++) {
       o << "    if ((sel >> " << k << ") & 1u) {\n";
       o << "      if (!(p_" << k << " == h1_" << k << " && q_" << k << " == h2_" << k << ")) { bool ins; slot_" << k << " = hash_find_or_insert(h.table, h.mask, ew, h1_" << k << ", h2_" << k
         << ", ins); if (ins) ins_mask |= " << (1 << k) << "u; }\n";
       o << "      unsigned long long* e = h.table + slot_" << k << " * (uint64_t)ew;\n";
-      if (!(s.ablate & 2)) o << "      atomicAdd(e + 2, 1ull);\n";
+      if (!(s.ablate & 2) && s.need_count) o << "      atomicAdd(e + 2, 1ull);\n";
       for (size_t j = 0; j < s.aggs.size(); j++) {
         const JitAgg& A = s.aggs[j];
         if (A.func == FDB_AGG_COUNT || (s.ablate & 2)) continue;
@@ -685,7 +687,7 @@ hipFunction_t jit_get(const JitShape& shape) {
 
 std::string JitHashShape::key() const {
   std::ostringstream k;
-  k << "a" << ablate << "|";
+  k << "a" << ablate << "c" << need_count << "|";
   for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
   k << '|';
   for (size_t l = 0; l < leaves.size(); l++) {
@@ -708,6 +710,7 @@ JitHashShape jit_hash_shape(const FdbHashArgs& h, const FdbHashCol* hcols) {
     s.cols.push_back({hcols[c].kind, hcols[c].validity != nullptr, hcols[c].kind == 0 && hcols[c].lut_lds != FDB_NO_LDS, hcols[c].kind == 2 ? hcols[c].src_word : -1});
   for (int i = 0; i < a.n_expr; i++) s.exprs.push_back({a.expr[i].kind, a.expr[i].op, a.expr[i].left, a.expr[i].right, a.expr[i].slot, a.expr[i].type});
   s.n_expr_cols = a.n_l8;
+  s.need_count = a.need_count != 0;
   for (int l = 0; l < a.n_leaves; l++) {
     const FdbLeaf& L = a.leaves[l];
     const bool wide = L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64;

@@ -43,6 +43,7 @@ struct JitHashShape {
   std::vector<bool> agg_validity;
   std::vector<JitExprNode> exprs;  // column nodes read base.l8[slot]
   int n_expr_cols = 0;
+  bool need_count = true;  // some aggregation is COUNT: otherwise the per-entry row count is never read (occupancy = fingerprint ≠ 0) and its atomic is skipped
   int ablate = 0;  // tuning aid (tools/cfg5_ablate.py): 1 = stream + fingerprint only, 2 = no count / aggregate atomics
   std::string key() const;
 };

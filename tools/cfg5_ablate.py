@@ -38,13 +38,15 @@ for ablate, what in modes:
     print(f"{kern:18s} {what:50s} kernel {st['kernel_ms'] / st['launches']:.3f} ms/launch x {st['launches']}  {st['algorithmic_bytes'] / st['kernel_ms'] / 1e6:8.1f} GB/s  "
           f"push {1e3 * (t1 - t0):.1f} ms  finish {1e3 * (t3 - t2):.1f} ms  groups {n}", flush=True)
 # steady state: a second pass over the same rows finds every group (no inserts, no key-store writes)
-for mode, what in [(0, "specialised"), (4 << 25, "interpreting")]:
+for mode, what in [(0, "specialised"), (2 << 20, "specialised, probe only"), (1 << 20, "specialised, stream only"), (4 << 25, "interpreting")]:
     plan = pp.HashAggregatePlan(None, aggs, G)
     plan.set_timing(True)
     plan.set_tuning(0, mode)
+    plan.set_tuning(0, mode & ~(15 << 20))  # first pass always builds the table
     plan.CallbackResident(resident)
     plan.num_groups()
     st0 = plan.stats()
+    plan.set_tuning(0, mode)
     plan.CallbackResident(resident)
     plan.num_groups()
     st1 = plan.stats()
