@@ -50,8 +50,11 @@ uint64_t Plan::hash_groups() {
 }
 
 void Plan::hash_reserve(uint64_t extra) {
-  const uint64_t need = next_pow2(std::max<uint64_t>(2 * (h_groups_bound_ + extra), 1 << 16));
+  uint64_t need = next_pow2(std::max<uint64_t>(2 * (h_groups_bound_ + extra), 1 << 16));
   if (h_table_ != nullptr && need <= h_capacity_) return;
+  // A table that has to grow while it already holds groups is still filling up: grow by two steps at once, a re-hash moves
+  // every entry and its key tuple (cfg 5: 3 re-hashes of up to 5.5 M entries per scan became 1–2).
+  if (h_table_ != nullptr && h_groups_bound_ > 0) need *= 2;
   const int ew = h_entry_words_, kw = h_key_words_;
   unsigned long long* nt = (unsigned long long*)ctx_->dev_alloc((size_t)need * ew * 8);
   uint32_t* nk = (uint32_t*)ctx_->dev_alloc((size_t)need * kw * 4);
