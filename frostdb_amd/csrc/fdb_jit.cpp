@@ -252,6 +252,16 @@ struct Gen {
       o << "  long long K_lit" << l << " = 0; uint32_t K_len" << l << " = 1, K_lds" << l << " = 0; int K_op" << l << " = 0; const uint8_t* K_lut" << l << " = nullptr;\n";
     for (size_t g = 0; g < s.gcols.size(); g++) o << "  uint32_t G_lds" << g << " = 0, G_stride" << g << " = 0; const uint32_t* G_lut" << g << " = nullptr;\n";
     for (size_t i = 0; i < s.exprs.size(); i++) if (s.exprs[i].kind == 1) o << "  long long K_elit" << i << " = 0;\n";
+    for (int t = 0; t < s.reg_slots; t++) {  // the lane-private table
+      o << "  unsigned long long R_cnt" << t << " = 0ull;\n";
+      for (size_t j = 0; j < s.aggs.size(); j++) {
+        const JitAgg& A = s.aggs[j];
+        if (A.func == FDB_AGG_COUNT) continue;
+        if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "  double R_a" << j << "_" << t << " = 0.0;\n";
+        else if (A.func == FDB_AGG_SUM) o << "  unsigned long long R_a" << j << "_" << t << " = 0ull;\n";
+        else o << "  long long R_a" << j << "_" << t << " = " << (A.func == FDB_AGG_MIN ? "0x7FFFFFFFFFFFFFFFLL" : "(-0x7FFFFFFFFFFFFFFFLL - 1)") << ";\n";
+      }
+    }
     o << "  long long n_rows = 0, tile_begin = 0, tile_end = 0; int part = -1, lut_class = -1;\n";
     o << "  const uint32_t lane_off4 = tid * 16u, lane_off8 = tid * 32u, lane_offb = tid >> 1, lane_shb = (tid & 1u) * 4u;\n";
     o << "  for (long long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {\n";
@@ -300,7 +310,44 @@ struct Gen {
         o << "    gid" << k << " += ((" << r << "_m >> " << k << ") & 1u ? " << lut << "[" << r << "." << comp[k] << "] : 0u) * G_stride" << g << ";\n";
     }
     // accumulate, row by row (one divergent region per row, every aggregate inside it)
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 4 && s.reg_slots > 0; k++) {  // lane-private table: predicated updates, no memory traffic at all
+      const std::string comp = std::string(k < 2 ? "a" : "b") + (k % 2 == 0 ? ".x" : ".y");
+      o << "    {\n      const bool on = (sel >> " << k << ") & 1u;\n";
+      std::vector<std::string> val(s.aggs.size());
+      for (size_t j = 0; j < s.aggs.size(); j++) {
+        const JitAgg& A = s.aggs[j];
+        if (A.func == FDB_AGG_COUNT) continue;
+        std::string raw;
+        if (A.expr != 0) {
+          auto col = [&](int ni) { return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
+          auto colvalid = [&](int ni) { return "((" + reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
+          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col)) + " : 0ull)";
+        } else {
+          const std::string r = reg(true, s.two_phase, A.slot);
+          raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : 0ull)";
+        }
+        const std::string v = "v" + std::to_string(j);
+        if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      const double " << v << " = __longlong_as_double((long long)" << raw << ");\n";
+        else if (A.func == FDB_AGG_SUM) o << "      const unsigned long long " << v << " = " << raw << ";\n";
+        else o << "      const long long " << v << " = " << (A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw)) << ";\n";
+        val[j] = v;
+      }
+      for (int t = 0; t < s.reg_slots; t++) {
+        const std::string m = s.reg_slots == 1 ? std::string("on") : ("(on && gid" + std::to_string(k) + " == " + std::to_string(t) + "u)");
+        o << "      R_cnt" << t << " += " << m << " ? 1ull : 0ull;\n";
+        for (size_t j = 0; j < s.aggs.size(); j++) {
+          const JitAgg& A = s.aggs[j];
+          if (A.func == FDB_AGG_COUNT) continue;
+          const std::string acc = "R_a" + std::to_string(j) + "_" + std::to_string(t);
+          if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      " << acc << " += " << m << " ? " << val[j] << " : 0.0;\n";
+          else if (A.func == FDB_AGG_SUM) o << "      " << acc << " += " << m << " ? " << val[j] << " : 0ull;\n";
+          else if (A.func == FDB_AGG_MIN) o << "      " << acc << " = (" << m << " && " << val[j] << " < " << acc << ") ? " << val[j] << " : " << acc << ";\n";
+          else o << "      " << acc << " = (" << m << " && " << val[j] << " > " << acc << ") ? " << val[j] << " : " << acc << ";\n";
+        }
+      }
+      o << "    }\n";
+    }
+    for (int k = 0; k < 4 && s.reg_slots == 0; k++) {
       o << "    if ((sel >> " << k << ") & 1u) {\n";
       if (s.lds_acc) {
         if (s.need_count) o << "      atomicAdd(&l_cnt[gid" << k << "], 1u);\n";
@@ -334,6 +381,39 @@ struct Gen {
       o << "    }\n";
     }
     o << "  }\n";
+    if (s.reg_slots > 0) {
+      // lane-private tables → one value per wave (butterfly over the 64 lanes) → one update per wave and slot
+      o << "  for (int sh = 32; sh > 0; sh >>= 1) {\n";
+      for (int t = 0; t < s.reg_slots; t++) {
+        o << "    R_cnt" << t << " += (unsigned long long)__shfl_xor((long long)R_cnt" << t << ", sh, 64);\n";
+        for (size_t j = 0; j < s.aggs.size(); j++) {
+          const JitAgg& A = s.aggs[j];
+          if (A.func == FDB_AGG_COUNT) continue;
+          const std::string acc = "R_a" + std::to_string(j) + "_" + std::to_string(t);
+          if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "    " << acc << " += __shfl_xor(" << acc << ", sh, 64);\n";
+          else if (A.func == FDB_AGG_SUM) o << "    " << acc << " += (unsigned long long)__shfl_xor((long long)" << acc << ", sh, 64);\n";
+          else if (A.func == FDB_AGG_MIN) o << "    { const long long y = __shfl_xor(" << acc << ", sh, 64); " << acc << " = y < " << acc << " ? y : " << acc << "; }\n";
+          else o << "    { const long long y = __shfl_xor(" << acc << ", sh, 64); " << acc << " = y > " << acc << " ? y : " << acc << "; }\n";
+        }
+      }
+      o << "  }\n  if ((tid & 63u) == 0u) {\n";
+      for (int t = 0; t < s.reg_slots; t++) {
+        o << "    if (R_cnt" << t << " != 0ull) {\n";
+        if (s.lds_acc) o << "      atomicAdd(&l_cnt[" << t << "], (uint32_t)(R_cnt" << t << " > 0xFFFFFFFFull ? 0xFFFFFFFFull : R_cnt" << t << "));\n";
+        else o << "      atomicAdd(&c.cnt[" << t << "], R_cnt" << t << ");\n";
+        for (size_t j = 0; j < s.aggs.size(); j++) {
+          const JitAgg& A = s.aggs[j];
+          if (A.func == FDB_AGG_COUNT) continue;
+          const std::string v = "R_a" + std::to_string(j) + "_" + std::to_string(t);
+          const std::string acc = s.lds_acc ? ("(l_acc + (size_t)" + std::to_string(j) + " * n_slots + " + std::to_string(t) + ")") : ("(c.aggs[" + std::to_string(j) + "].acc + " + std::to_string(t) + ")");
+          if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      atomicAdd(reinterpret_cast<double*>" << acc << ", " << v << ");\n";
+          else if (A.func == FDB_AGG_SUM) o << "      atomicAdd(" << acc << ", " << v << ");\n";
+          else o << "      " << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>" << acc << ", " << v << ");\n";
+        }
+        o << "    }\n";
+      }
+      o << "  }\n";
+    }
     // flush
     if (s.lds_acc) {
       o << "  __syncthreads();\n";
@@ -583,7 +663,7 @@ struct HashGen {
 
 std::string JitShape::key(bool with_validity) const {
   std::ostringstream k;
-  k << "b" << block << "l" << lds_acc << "c" << need_count << "t" << two_phase << "|";
+  k << "b" << block << "l" << lds_acc << "c" << need_count << "t" << two_phase << "r" << reg_slots << "|";
   auto slots = [&](const JitSlot* p, int n) { for (int i = 0; i < n; i++) k << (p[i].has_values ? 'v' : '-') << (with_validity ? p[i].has_validity : 0); k << '|'; };
   slots(c4, n_c4); slots(c8, n_c8); slots(l4, n_l4); slots(l8, n_l8);
   for (const JitLeaf& L : leaves) k << L.kind << ',' << L.slot << ',' << L.wide << ',' << (L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64 ? L.op : 0) << ',' << L.lut_in_lds << ';';

@@ -1031,13 +1031,19 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     }
     // A kernel specialised for this plan shape (fdb_jit.cpp), when every record of the launch has the same shape;
     // otherwise (or when hiprtc is unavailable) the interpreting slot kernel.
-    if (sub_tiles != 4 && ablate == 0 && lds_bytes <= FDB_LDS_BUDGET) {
+    if (sub_tiles != 4 && ablate == 0 && lds_bytes <= 150 * 1024) {  // (gfx950: up to 160 KiB of LDS per workgroup)
       JitShape shape;
       bool same = true, first = true;
       for (int i : live) {
         const JitShape si = jit_shape(Rs[(size_t)i].args, two_phase != 0, jit_block ? jit_block : 256);
         if (first) { shape = si; first = false; }
         else if (!jit_shape_merge(&shape, si)) { same = false; break; }
+      }
+      {
+        // tiny tables live in registers (JitShape::reg_slots): ≤ 8 slots and ≤ 48 accumulator registers per lane
+        int regs_per_slot = 2;
+        for (const AggState& A : aggs_) if (A.func != FDB_AGG_COUNT || final_stage_) regs_per_slot += 2;
+        if (n_slots_ >= 1 && n_slots_ <= 8 && (int)n_slots_ * regs_per_slot <= 48) shape.reg_slots = (int)n_slots_;
       }
       if (same) {
         if (jit_block != 0) { jit_fn = jit_get(shape); if (jit_fn != nullptr) per_cu = jit_blocks_per_cu(jit_fn, jit_block, lds_bytes); }
