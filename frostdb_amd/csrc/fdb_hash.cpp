@@ -154,14 +154,14 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     bool has_expr = a.n_expr > 0;
     a.n_c4 = a.n_c8 = a.n_l4 = a.n_l8 = 0;
     {
-      int pool_col[FDB_MAX_L8];
+      int pool_col[FDB_ARG_L8];
       for (int k = 0; k < a.n_expr; k++) {
         if (a.expr[k].kind != 0) continue;
         const int ci = R.expr_col[k];
         int slot = -1;
         for (int x = 0; x < a.n_l8; x++) if (pool_col[x] == ci) slot = x;
         if (slot < 0) {
-          if (a.n_l8 >= FDB_MAX_L8) throw Error(FDB_ERR_UNSUPPORTED, "computed columns read more than 3 distinct stored columns");
+          if (a.n_l8 >= FDB_ARG_L8) throw Error(FDB_ERR_UNSUPPORTED, "computed columns read more than 4 distinct stored columns");
           slot = a.n_l8++;
           pool_col[slot] = ci;
           a.l8[slot].values = b.cols[(size_t)ci].d_values;

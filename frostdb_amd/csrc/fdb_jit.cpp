@@ -241,6 +241,18 @@ struct Gen {
         o << "  for (uint32_t i = tid; i < n_slots; i += " << BLK << ") l_acc[(size_t)" << j << " * n_slots + i] = " << ident << ";\n";
       }
     }
+    if (s.cache) {
+      o << "  const uint32_t CS = (uint32_t)c.cache_slots;\n";
+      o << "  uint32_t* t_tag = reinterpret_cast<uint32_t*>(smem + c.lds_lut_bytes);\n  uint32_t* t_cnt = t_tag + CS;\n";
+      o << "  unsigned long long* t_acc = reinterpret_cast<unsigned long long*>(t_cnt + CS);\n";
+      o << "  for (uint32_t i = tid; i < CS; i += " << BLK << ") { t_tag[i] = 0u; t_cnt[i] = 0u; }\n";
+      for (size_t j = 0; j < s.aggs.size(); j++) {
+        const JitAgg& A = s.aggs[j];
+        if (A.func == FDB_AGG_COUNT) continue;
+        const char* ident = A.func == FDB_AGG_MIN ? "0x7FFFFFFFFFFFFFFFull" : A.func == FDB_AGG_MAX ? "0x8000000000000000ull" : "0ull";
+        o << "  for (uint32_t i = tid; i < CS; i += " << BLK << ") t_acc[(size_t)" << j << " * CS + i] = " << ident << ";\n";
+      }
+    }
     // per-record values, decoded when the workgroup enters a record
     auto decl_slots = [&](bool late) {
       const int n4 = late ? s.n_l4 : s.n_c4, n8 = late ? s.n_l8 : s.n_c8;
@@ -349,7 +361,15 @@ struct Gen {
     }
     for (int k = 0; k < 4 && s.reg_slots == 0; k++) {
       o << "    if ((sel >> " << k << ") & 1u) {\n";
-      if (s.lds_acc) {
+      if (s.cache) {
+        // cached = this row's slot owns (or just claimed) its direct-mapped place in the workgroup's combining cache
+        o << "      const uint32_t ch = ((gid" << k << " * 0x9E3779B1u) >> 12) & (CS - 1u);\n";
+        o << "      uint32_t tg = t_tag[ch];\n      if (tg == 0u) { tg = atomicCAS(&t_tag[ch], 0u, gid" << k << " + 1u); if (tg == 0u) tg = gid" << k << " + 1u; }\n";
+        o << "      const bool cached = tg == gid" << k << " + 1u;\n";
+        o << "      if (cached) atomicAdd(&t_cnt[ch], 1u);\n";
+        if (s.need_count) o << "      else atomicAdd(&c.cnt[gid" << k << "], 1ull);\n";
+        else o << "      else c.cnt[gid" << k << "] = 1ull;\n";  // occupancy flag only: a plain store (every writer stores the same value)
+      } else if (s.lds_acc) {
         if (s.need_count) o << "      atomicAdd(&l_cnt[gid" << k << "], 1u);\n";
         else o << "      l_cnt[gid" << k << "] = 1u;\n";
       } else {
@@ -368,14 +388,25 @@ struct Gen {
           const std::string r = reg(true, s.two_phase, A.slot);
           raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : 0ull)";
         }
-        const std::string acc = s.lds_acc ? ("(l_acc + (size_t)" + std::to_string(j) + " * n_slots + gid" + std::to_string(k) + ")")
-                                           : ("(c.aggs[" + std::to_string(j) + "].acc + gid" + std::to_string(k) + ")");
-        if (A.func == FDB_AGG_SUM) {
-          if (A.type == FDB_T_F64) o << "      atomicAdd(reinterpret_cast<double*>" << acc << ", __longlong_as_double((long long)" << raw << "));\n";
-          else o << "      atomicAdd" << acc.substr(0, 0) << "(" << acc << ", " << raw << ");\n";
+        const std::string gacc = "(c.aggs[" + std::to_string(j) + "].acc + gid" + std::to_string(k) + ")";
+        const std::string acc = s.lds_acc ? ("(l_acc + (size_t)" + std::to_string(j) + " * n_slots + gid" + std::to_string(k) + ")") : gacc;
+        auto emit = [&](const std::string& where, const char* ind) {
+          if (A.func == FDB_AGG_SUM) {
+            if (A.type == FDB_T_F64) o << ind << "atomicAdd(reinterpret_cast<double*>" << where << ", __longlong_as_double((long long)" << raw << "));\n";
+            else o << ind << "atomicAdd(" << where << ", " << raw << ");\n";
+          } else {
+            const std::string key = A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw);
+            o << ind << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>" << where << ", " << key << ");\n";
+          }
+        };
+        if (s.cache) {
+          o << "      if (cached) {\n";
+          emit("(t_acc + (size_t)" + std::to_string(j) + " * CS + ch)", "        ");
+          o << "      } else {\n";
+          emit(gacc, "        ");
+          o << "      }\n";
         } else {
-          const std::string key = A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw);
-          o << "      " << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>" << acc << ", " << key << ");\n";
+          emit(acc, "      ");
         }
       }
       o << "    }\n";
@@ -411,6 +442,21 @@ struct Gen {
           else o << "      " << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>" << acc << ", " << v << ");\n";
         }
         o << "    }\n";
+      }
+      o << "  }\n";
+    }
+    if (s.cache) {  // the combining cache goes to the global table: one atomic per entry and aggregate
+      o << "  __syncthreads();\n  for (uint32_t i = tid; i < CS; i += " << BLK << ") {\n    const uint32_t tg = t_tag[i];\n    if (tg == 0u) continue;\n    const uint32_t g = tg - 1u;\n";
+      if (s.need_count) o << "    atomicAdd(&c.cnt[g], (unsigned long long)t_cnt[i]);\n";
+      else o << "    c.cnt[g] = 1ull;\n";
+      for (size_t j = 0; j < s.aggs.size(); j++) {
+        const JitAgg& A = s.aggs[j];
+        if (A.func == FDB_AGG_COUNT) continue;
+        const std::string v = "t_acc[(size_t)" + std::to_string(j) + " * CS + i]";
+        const std::string dst = "c.aggs[" + std::to_string(j) + "].acc + g";
+        if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "    atomicAdd(reinterpret_cast<double*>(" << dst << "), __longlong_as_double((long long)" << v << "));\n";
+        else if (A.func == FDB_AGG_SUM) o << "    atomicAdd(" << dst << ", " << v << ");\n";
+        else o << "    " << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>(" << dst << "), (long long)" << v << ");\n";
       }
       o << "  }\n";
     }
@@ -663,7 +709,7 @@ struct HashGen {
 
 std::string JitShape::key(bool with_validity) const {
   std::ostringstream k;
-  k << "b" << block << "l" << lds_acc << "c" << need_count << "t" << two_phase << "r" << reg_slots << "|";
+  k << "b" << block << "l" << lds_acc << "c" << need_count << "t" << two_phase << "r" << reg_slots << "h" << cache << "|";
   auto slots = [&](const JitSlot* p, int n) { for (int i = 0; i < n; i++) k << (p[i].has_values ? 'v' : '-') << (with_validity ? p[i].has_validity : 0); k << '|'; };
   slots(c4, n_c4); slots(c8, n_c8); slots(l4, n_l4); slots(l8, n_l8);
   for (const JitLeaf& L : leaves) k << L.kind << ',' << L.slot << ',' << L.wide << ',' << (L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64 ? L.op : 0) << ',' << L.lut_in_lds << ';';
@@ -700,6 +746,7 @@ JitShape jit_shape(const FdbScanArgs& a, bool two_phase, int block) {
   for (int g = 0; g < a.n_gcols; g++) s.gcols.push_back({a.gcols[g].slot, a.gcols[g].lut_lds != FDB_NO_LDS});
   for (int j = 0; j < a.n_aggs; j++) s.aggs.push_back({a.aggs[j].func, a.aggs[j].type, a.aggs[j].slot, a.aggs[j].expr});
   for (int i = 0; i < a.n_expr; i++) s.exprs.push_back({a.expr[i].kind, a.expr[i].op, a.expr[i].left, a.expr[i].right, a.expr[i].slot, a.expr[i].type});
+  s.cache = !s.lds_acc && a.cache_slots > 0;
   return s;
 }
 

@@ -23,6 +23,12 @@ typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typede
 #define FDB_MAX_C8 2            //                                           8-byte (int64/uint64/float64) columns
 #define FDB_MAX_L4 2            // late (post-filter) slots of the two-phase kernel
 #define FDB_MAX_L8 3
+// Sizes of the slot arrays in the argument block: what the run-time specialised kernels can take (they have no
+// register-resident plan); the FDB_MAX_* values above stay the limits of the interpreting slot kernel's template instances.
+#define FDB_ARG_C4 6
+#define FDB_ARG_C8 4
+#define FDB_ARG_L4 6
+#define FDB_ARG_L8 4
 #define FDB_BLOCK 1024          // 16 waves share one LDS partial table
 #define FDB_LDS_BUDGET 65536    // bytes of LDS per workgroup (2 workgroups/CU of the 160 KiB)
 #define FDB_NO_LDS 0xFFFFFFFFu
@@ -115,10 +121,10 @@ struct FdbScanArgs {
   // loaded after the filter, and not at all for a lane group whose rows were all filtered out.
   int32_t n_l4;
   int32_t n_l8;
-  FdbColSlot l4[FDB_MAX_L4];
-  FdbColSlot l8[FDB_MAX_L8];
-  FdbColSlot c4[FDB_MAX_C4];
-  FdbColSlot c8[FDB_MAX_C8];
+  FdbColSlot l4[FDB_ARG_L4];
+  FdbColSlot l8[FDB_ARG_L8];
+  FdbColSlot c4[FDB_ARG_C4];
+  FdbColSlot c8[FDB_ARG_C8];
   unsigned long long* partials;  // LDS mode: per-workgroup partial tables [grid][1 + n_aggs][n_slots], written with plain
                                  // coalesced stores and folded by fdb_launch_reduce_partials (nullptr: flush with atomics)
   int32_t ablate;           // tuning aid (bench --ablate): 1 skip occupancy, 2 skip aggregate atomics, 4 skip group LUTs, 8 skip filter
@@ -130,7 +136,8 @@ struct FdbScanArgs {
   FdbGroupCol gcols[FDB_MAX_DENSE_GCOLS];
   FdbAgg aggs[FDB_MAX_AGGS];
   int32_t n_expr;           // nodes of computed aggregate inputs / group keys (0: none)
-  int32_t _pad_expr;
+  int32_t cache_slots;      // lds_acc == 0 (table too big for LDS), specialised kernel only: entries (a power of two) of the workgroup's
+                            // LDS combining cache [tag u32 | count u32 | acc u64 × n_aggs] placed after the LUT copies; 0: none
   FdbExprNode expr[FDB_MAX_EXPR_NODES];
 };
 

@@ -835,8 +835,8 @@ static int assign_slots(const DeviceBatch& b, Plan::Resolved& R, int first_layou
   };
   for (int layout = first_layout; layout <= 2; layout++) {
     a.n_c4 = a.n_c8 = a.n_l4 = a.n_l8 = 0;
-    Pool e4{a.c4, &a.n_c4, layout == 1 ? 2 : FDB_MAX_C4, {0}}, e8{a.c8, &a.n_c8, layout == 1 ? 1 : FDB_MAX_C8, {0}};
-    Pool l4{a.l4, &a.n_l4, FDB_MAX_L4, {0}}, l8{a.l8, &a.n_l8, FDB_MAX_L8, {0}};
+    Pool e4{a.c4, &a.n_c4, layout == 1 ? 2 : (relaxed ? FDB_ARG_C4 : FDB_MAX_C4), {0}}, e8{a.c8, &a.n_c8, layout == 1 ? 1 : (relaxed ? FDB_ARG_C8 : FDB_MAX_C8), {0}};
+    Pool l4{a.l4, &a.n_l4, relaxed ? FDB_ARG_L4 : FDB_MAX_L4, {0}}, l8{a.l8, &a.n_l8, relaxed ? FDB_ARG_L8 : FDB_MAX_L8, {0}};
     bool ok = true;
     for (int l = 0; l < a.n_leaves && ok; l++) {
       if (R.leaf_col[l] < 0) continue;
@@ -850,7 +850,11 @@ static int assign_slots(const DeviceBatch& b, Plan::Resolved& R, int first_layou
       if (R.agg_col[j] >= 0 && a.aggs[j].values != nullptr) { a.aggs[j].slot = slot_in(layout == 1 ? e8 : l8, R.agg_col[j], true); ok = a.aggs[j].slot >= 0; }
     for (int k = 0; k < a.n_expr && ok; k++)  // the columns computed aggregate inputs read share the aggregates' pool
       if (a.expr[k].kind == 0) { a.expr[k].slot = slot_in(layout == 1 ? e8 : l8, R.expr_col[k], true); ok = a.expr[k].slot >= 0; }
-    if (ok) return layout;
+    if (ok) {
+      if (a.n_c4 > FDB_MAX_C4 || a.n_c8 > FDB_MAX_C8 || a.n_l4 > FDB_MAX_L4 || a.n_l8 > FDB_MAX_L8) strict = false;
+      if (interp_ok != nullptr) *interp_ok = strict;
+      return layout;
+    }
   }
   a.n_c4 = a.n_c8 = a.n_l4 = a.n_l8 = 0;
   return 0;
@@ -984,7 +988,17 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   int base_grid = grid_override > 0 ? grid_override : fdb_scan_default_grid(device_);
   if (lut_lds_max + acc_bytes <= FDB_LDS_BUDGET) { lds_acc = 1; lds_bytes += acc_bytes; }
   else if (lut_lds_max + acc_bytes <= 150 * 1024) { lds_acc = 1; lds_bytes += acc_bytes; if (grid_override <= 0) base_grid /= 2; }
-  for (int i : live) { Rs[(size_t)i].args.lds_lut_bytes = (uint32_t)lut_lds_max; Rs[(size_t)i].args.lds_acc = lds_acc; }
+  // table too big for LDS: the specialised kernel gets a combining cache instead (JitShape::cache), ≤ 48 KiB per workgroup
+  int cache_slots = 0;
+  if (!lds_acc && jit_possible) {
+    const size_t entry = 8 + 8 * aggs_.size();
+    cache_slots = 1;
+    while ((size_t)cache_slots * 2 * entry <= 48 * 1024) cache_slots *= 2;
+    lds_bytes = lut_lds_max + (size_t)cache_slots * entry;
+  }
+  for (int i : live) {
+    Rs[(size_t)i].args.lds_lut_bytes = (uint32_t)lut_lds_max; Rs[(size_t)i].args.lds_acc = lds_acc; Rs[(size_t)i].args.cache_slots = cache_slots;
+  }
   pt.mark("lut upload");
 
   int32_t funcs[1 + FDB_MAX_AGGS] = {0};

@@ -850,3 +850,29 @@ def test_distinct_at_scale_dense_and_hash(pp):
             p1.Close(); p2.Close()
         cols = key_cols_of(batches, extra=("bucket",) if int_key else ())
         assert_same_result(got, want, cols)
+
+
+def test_dense_table_too_big_for_lds(pp, variant):
+    """Group by (path × instance × code): 2 001 × 17 × 7 ≈ 238 k dense slots — the table does not fit in LDS, so rows go to the global
+    table with atomics; the specialised kernel puts a per-workgroup combining cache in front (hot keys: path is Zipf-like here).
+    With and without a COUNT aggregation (the count array is only an occupancy flag in the second case)."""
+    rng = np.random.default_rng(77)
+    batches = []
+    for n in (120_000, 90_001):
+        b = make_prometheus_batch(rng, n, n_path=2000)
+        hot = pa.array(np.minimum(rng.zipf(1.3, size=n) - 1, 1999).astype(np.uint32), type=pa.uint32(), mask=rng.random(n) < 0.01)
+        path = pa.DictionaryArray.from_arrays(hot, b.column(1).dictionary)
+        batches.append(b.set_column(1, "labels.path", path))
+    groups = [Col("labels.path"), Col("labels.instance"), Col("labels.code")]
+    for aggs in ([Count(Col("value")), Min(Col("timestamp")), Max(Col("value")), Sum(Col("value"))], [Sum(Col("value")), Min(Col("value"))]):
+        want = run_oracle(batches, Col("labels.method") != "PUT", aggs, groups)
+        plan = pp.HashAggregatePlan(Col("labels.method") != "PUT", aggs, groups)
+        keep = [pp.ResidentBatch(x) for x in batches]
+        try:
+            plan.CallbackResident(keep)
+            assert plan.last_kernel() == ("fdb_plan_kernel" if variant == "specialised" else "scan_dense_kernel") or variant == "interpreted"
+            got = arrow_to_pydict(plan.Finish())
+        finally:
+            plan.Close()
+        cols = ["labels.path", "labels.instance", "labels.code"] + [a.Name() for a in aggs]
+        assert_same_result(got, want, cols, float_cols={"sum(value)"})

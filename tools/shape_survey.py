@@ -28,9 +28,13 @@ cases = {
     "sum(value * 2.0) by path": (C == "200", [Sum(V * 2.0)], [P]),
     "min/max(ts - 1000) by path": (C == "200", [Min(T - 1000), Max(T - 1000)], [P]),
     "distinct path": (None, [], [P]),
+    "sum by instance (513 slots, 5 % NULL)": (None, [Sum(V)], [I]),
+    "sum by (path, instance) 526k slots": (None, [Sum(V)], [P, I]),
+    "4 aggs by (path, instance) 526k slots": (C == "200", [Count(V), Min(T), Max(T), Sum(V)], [P, I]),
+    "sum by (path, instance, method) hash": (None, [Sum(V)], [P, I, M]),
     "by all labels (hash: 4 cols)": (None, [Sum(V)], [DynCol("labels")]),
 }
-only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+only = sys.argv[2].split("|") if len(sys.argv) > 2 else None
 for name, (f, aggs, G) in cases.items():
     if only is not None and name not in only:
         continue
