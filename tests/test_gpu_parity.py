@@ -876,3 +876,59 @@ def test_dense_table_too_big_for_lds(pp, variant):
             plan.Close()
         cols = ["labels.path", "labels.instance", "labels.code"] + [a.Name() for a in aggs]
         assert_same_result(got, want, cols, float_cols={"sum(value)"})
+
+
+def test_full_size_configs_2_and_3_properties(pp):
+    """BASELINE.json's full single-GPU size — 100 M synthetic Prometheus rows in 4 resident records, one launch per query — checked
+    through size-independent properties against numpy on the raw columns: Σ count = selected rows, per-path counts and sums
+    (cfg 2), min/max of the selected timestamps, group sums add up to the total within 1e-9 (cfg 3)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from frostdb_amd import synth
+    n_rec, rows = 4, 25_000_000
+    with ThreadPoolExecutor(4) as ex:
+        recs = list(ex.map(lambda i: synth.prometheus_chunk(0, i, rows, row_base=i * rows, cfg3=True), range(n_rec)))
+    keep = [pp.ResidentBatch(r) for r in recs]
+
+    def np_idx(col):
+        return col.indices.fill_null(len(col.dictionary)).to_numpy(zero_copy_only=False).astype(np.int64)
+
+    code = np.concatenate([np_idx(r.column(0)) for r in recs])
+    path = np.concatenate([np_idx(r.column(1)) for r in recs])
+    method = np.concatenate([np_idx(r.column(2)) for r in recs])
+    inst_valid = np.concatenate([np.asarray(r.column(3).is_valid()) for r in recs])
+    ts = np.concatenate([r.column(4).to_numpy() for r in recs])
+    val = np.concatenate([r.column(5).to_numpy() for r in recs])
+    n_path = len(recs[0].column(1).dictionary)
+    try:
+        # cfg 2
+        plan = pp.HashAggregatePlan(CFG2["filter_expr"], [Sum(Col("value")), Count(Col("value"))], CFG2["groups"])
+        plan.CallbackResident(keep)
+        assert plan.last_kernel() == "fdb_plan_kernel"
+        d = arrow_to_pydict(plan.Finish())
+        plan.Close()
+        sel = code == synth.CODES.index(b"200")
+        want_cnt = np.bincount(path[sel], minlength=n_path + 1)
+        want_sum = np.bincount(path[sel], weights=val[sel], minlength=n_path + 1)
+        names = synth.PATHS + [None]
+        got = {p: (c, s) for p, c, s in zip(d["labels.path"], d["count(value)"], d["sum(value)"])}
+        assert sum(c for c, _ in got.values()) == int(sel.sum())
+        for i, p in enumerate(names):
+            if want_cnt[i] == 0:
+                assert p not in got
+            else:
+                assert got[p][0] == want_cnt[i] and math.isclose(got[p][1], want_sum[i], rel_tol=REL_TOL), p
+        # cfg 3
+        plan = pp.HashAggregatePlan(CFG3["filter_expr"], CFG3["aggs"], CFG3["groups"])
+        plan.CallbackResident(keep)
+        d = arrow_to_pydict(plan.Finish())
+        plan.Close()
+        sel = ((code == synth.CODES.index(b"200")) | (code == synth.CODES.index(b"500"))) & (method == synth.METHODS.index(b"GET")) & inst_valid
+        assert sum(d["count(value)"]) == int(sel.sum())
+        assert min(d["min(timestamp)"]) == int(ts[sel].min()) and max(d["max(timestamp)"]) == int(ts[sel].max())
+        assert math.isclose(math.fsum(d["sum(value)"]), math.fsum(val[sel]), rel_tol=REL_TOL)
+        want_cnt = np.bincount(path[sel], minlength=n_path + 1)
+        got_cnt = dict(zip(d["labels.path"], d["count(value)"]))
+        assert all(got_cnt.get(p, 0) == want_cnt[i] for i, p in enumerate(names))
+    finally:
+        for k in keep:
+            k.close()
