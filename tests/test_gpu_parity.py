@@ -932,3 +932,46 @@ def test_full_size_configs_2_and_3_properties(pp):
     finally:
         for k in keep:
             k.close()
+
+
+def test_concurrent_chains_on_threads(pp):
+    """N chains = N plans driven from N OS threads at once (≙ the reference's N scan workers calling Callback concurrently, one
+    chain each, then Finish on all chains concurrently — table.go:783-860, physicalplan.go:157-165; ctypes drops the GIL during the
+    C calls). Then Synchronizer + final stage = fdb_plan_merge. Dense and hash tables, several rounds to shake out races in the
+    shared caches (contexts, compiled kernels, dictionaries, pinned result blocks)."""
+    import threading
+    rng = np.random.default_rng(4242)
+    n_chains = 6
+    for make, filt, aggs, groups, cols in (
+            (lambda: make_prometheus_batch(rng, 30_000, n_path=100), CFG3["filter_expr"], CFG3["aggs"], CFG3["groups"],
+             ["labels.path"] + [a.Name() for a in CFG3["aggs"]]),
+            (lambda: many_label_batch(rng, 20_000, 10, 3, n_groups=3000), None, [Sum(Col("value")), Count(Col("value"))], [DynCol("labels")], None)):
+        for _ in range(3):
+            shards = [[make() for _ in range(3)] for _ in range(n_chains)]
+            want = run_oracle([b for s in shards for b in s], filt, aggs, groups, nchains=n_chains)
+            plans = [pp.HashAggregatePlan(filt, aggs, groups) for _ in range(n_chains)]
+            errors = []
+
+            def work(i):
+                try:
+                    for b in shards[i]:
+                        plans[i].Callback(b)
+                    plans[i].num_groups()
+                except Exception as e:  # noqa: BLE001
+                    errors.append(e)
+
+            threads = [threading.Thread(target=work, args=(i,)) for i in range(n_chains)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            try:
+                assert not errors, errors
+                for p in plans[1:]:
+                    plans[0].Merge(p)
+                got = arrow_to_pydict(plans[0].Finish())
+            finally:
+                for p in plans:
+                    p.Close()
+            c = cols or (key_cols_of([b for s in shards for b in s]) + [a.Name() for a in aggs])
+            assert_same_result(got, want, c, float_cols={"sum(value)"})
