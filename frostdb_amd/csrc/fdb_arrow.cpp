@@ -77,43 +77,55 @@ void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordV
 }
 
 std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
-  auto d = std::make_shared<HostDict>();
   const ArrowArray* da = col.array->dictionary;
   const std::string df = col.schema->dictionary->format;
-  d->value_format = (df == "u" || df == "U") ? "u" : "z";
+  const std::string value_format = (df == "u" || df == "U") ? "u" : "z";
   const int64_t n = da->length, off = da->offset;
-  d->values.resize((size_t)n);
   const char* data = (const char*)da->buffers[2];
-  if (df == "u" || df == "z") {
-    const int32_t* offs = (const int32_t*)da->buffers[1];
-    for (int64_t i = 0; i < n; i++) d->values[(size_t)i].assign(data + offs[off + i], (size_t)(offs[off + i + 1] - offs[off + i]));
-  } else {
-    const int64_t* offs = (const int64_t*)da->buffers[1];
-    for (int64_t i = 0; i < n; i++) d->values[(size_t)i].assign(data + offs[off + i], (size_t)(offs[off + i + 1] - offs[off + i]));
-  }
-  uint64_t h = 1469598103934665603ull;  // FNV-1a over (length, bytes) of every entry
-  std::unordered_set<std::string_view> seen;
-  seen.reserve(d->values.size() * 2);
-  for (const std::string& v : d->values) {
-    uint64_t len = v.size();
+  const bool wide = !(df == "u" || df == "z");
+  const int32_t* o32 = (const int32_t*)da->buffers[1];
+  const int64_t* o64 = (const int64_t*)da->buffers[1];
+  auto begin = [&](int64_t i) -> int64_t { return wide ? o64[off + i] : (int64_t)o32[off + i]; };
+  // content hash straight over the Arrow buffers: FNV-1a over (length, bytes) of every entry
+  uint64_t h = 1469598103934665603ull;
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t b0 = begin(i), b1 = begin(i + 1);
+    const uint64_t len = (uint64_t)(b1 - b0);
     for (int k = 0; k < 8; k++) { h ^= (len >> (8 * k)) & 0xFF; h *= 1099511628211ull; }
-    for (unsigned char ch : v) { h ^= ch; h *= 1099511628211ull; }
-    if (!seen.insert(std::string_view(v)).second) d->unique = false;
+    for (int64_t p = b0; p < b1; p++) { h ^= (unsigned char)data[p]; h *= 1099511628211ull; }
   }
-  d->hash = h;
   // Dictionaries with identical content are shared: the parts of one table usually carry the same dictionary, and one object
   // for all of them turns every later "same dictionary?" test (key-id LUT cache, LUT de-duplication across the records of a
-  // launch) into a pointer compare instead of thousands of string compares per record and query.
+  // launch) into a pointer compare — and a record whose dictionary is already known costs one pass over its bytes here,
+  // no string allocations.
   static std::mutex mu;
   static std::unordered_multimap<uint64_t, std::weak_ptr<HostDict>> live;
-  std::lock_guard<std::mutex> lk(mu);
-  auto range = live.equal_range(h);
-  for (auto it = range.first; it != range.second;) {
-    std::shared_ptr<HostDict> other = it->second.lock();
-    if (!other) { it = live.erase(it); continue; }
-    if (other->value_format == d->value_format && other->values == d->values) return other;
-    ++it;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto range = live.equal_range(h);
+    for (auto it = range.first; it != range.second;) {
+      std::shared_ptr<HostDict> other = it->second.lock();
+      if (!other) { it = live.erase(it); continue; }
+      bool same = other->value_format == value_format && (int64_t)other->values.size() == n;
+      for (int64_t i = 0; i < n && same; i++) {
+        const int64_t b0 = begin(i), len = begin(i + 1) - b0;
+        const std::string& v = other->values[(size_t)i];
+        same = (int64_t)v.size() == len && (len == 0 || std::memcmp(v.data(), data + b0, (size_t)len) == 0);
+      }
+      if (same) return other;
+      ++it;
+    }
   }
+  auto d = std::make_shared<HostDict>();
+  d->value_format = value_format;
+  d->hash = h;
+  d->values.resize((size_t)n);
+  for (int64_t i = 0; i < n; i++) d->values[(size_t)i].assign(data + begin(i), (size_t)(begin(i + 1) - begin(i)));
+  std::unordered_set<std::string_view> seen;
+  seen.reserve(d->values.size() * 2);
+  for (const std::string& v : d->values)
+    if (!seen.insert(std::string_view(v)).second) d->unique = false;
+  std::lock_guard<std::mutex> lk(mu);
   live.emplace(h, d);
   return d;
 }

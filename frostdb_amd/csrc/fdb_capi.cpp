@@ -93,7 +93,7 @@ int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* 
 
 int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch) {
   if (!plan || !batch) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.push_batch(*batch->b); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.push_batch(*batch->b); });
 }
 
 int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n) {
@@ -104,38 +104,39 @@ int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32
       if (batches[i] == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null batch");
       v.push_back(batches[i]->b.get());
     }
+    plan->plan.settle();
     plan->plan.push_batches(v.data(), (int)v.size());
   });
 }
 
 int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.finish(out, out_schema, n_rows); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.finish(out, out_schema, n_rows); });
 }
 
 int fdb_plan_merge(fdb_plan* dst, fdb_plan* src) {
   if (!dst || !src) return FDB_ERR_INVALID;
-  return guard(dst, [&] { dst->plan.merge_from(src->plan); });
+  return guard(dst, [&] { src->plan.settle(); dst->plan.settle(); dst->plan.merge_from(src->plan); });
 }
 
 int fdb_plan_group_schema(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema) {
   if (!plan || !out || !out_schema) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.group_schema(out, out_schema); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.group_schema(out, out_schema); });
 }
 
 int fdb_plan_seed_groups(fdb_plan* plan, struct ArrowArray* schema_record, struct ArrowSchema* schema) {
   if (!plan || !schema_record || !schema) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.seed_groups(schema_record, schema); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.seed_groups(schema_record, schema); });
 }
 
 int fdb_plan_hash_export(fdb_plan* src, fdb_plan* layout, int32_t n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32) {
   if (!src || !layout || !dev_rows || !counts || !row_words32) return FDB_ERR_INVALID;
-  return guard(src, [&] { src->plan.hash_export(layout->plan, n_parts, dev_rows, counts, row_words32); });
+  return guard(src, [&] { src->plan.settle(); layout->plan.settle(); src->plan.hash_export(layout->plan, n_parts, dev_rows, counts, row_words32); });
 }
 
 int fdb_plan_hash_import(fdb_plan* plan, const void* dev_rows, int64_t n_rows) {
   if (!plan || (n_rows > 0 && !dev_rows)) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.hash_import(dev_rows, n_rows); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.hash_import(dev_rows, n_rows); });
 }
 
 int fdb_plan_filter(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out,
@@ -156,42 +157,42 @@ void fdb_plan_close(fdb_plan* plan) { delete plan; }
 
 int fdb_plan_num_groups(fdb_plan* plan, int64_t* n_groups) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { *n_groups = plan->plan.num_groups(); });
+  return guard(plan, [&] { plan->plan.settle(); *n_groups = plan->plan.num_groups(); });
 }
 
 int fdb_plan_partial_keys(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.partial_keys(out, out_schema); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.partial_keys(out, out_schema); });
 }
 
 int fdb_plan_partial_state(fdb_plan* plan, int32_t agg, void* dst, int64_t capacity_bytes) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.partial_state(agg, dst, capacity_bytes); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.partial_state(agg, dst, capacity_bytes); });
 }
 
 int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slots) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { *signature = plan->plan.state_signature(n_slots); });
+  return guard(plan, [&] { plan->plan.settle(); *signature = plan->plan.state_signature(n_slots); });
 }
 
 int fdb_plan_state_pointers(fdb_plan* plan, void** base, int64_t* array_stride, int64_t* n_slots) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.state_pointers(base, array_stride, n_slots); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.state_pointers(base, array_stride, n_slots); });
 }
 
 int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.state_read(array, dst, capacity_bytes); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.state_read(array, dst, capacity_bytes); });
 }
 
 int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t bytes) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.state_write(array, src, bytes); });
+  return guard(plan, [&] { plan->plan.settle(); plan->plan.state_write(array, src, bytes); });
 }
 
 int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { *format_out = plan->plan.agg_format(agg); });
+  return guard(plan, [&] { plan->plan.settle(); *format_out = plan->plan.agg_format(agg); });
 }
 
 int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int device, fdb_batch** out) {
@@ -210,11 +211,13 @@ void fdb_batch_release(fdb_batch* batch) { delete batch; }
 
 int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms, int64_t* n_launches, int64_t* rows_scanned) {
   if (!plan) return FDB_ERR_INVALID;
-  if (algorithmic_bytes) *algorithmic_bytes = plan->plan.stat_bytes;
-  if (kernel_ms) *kernel_ms = plan->plan.stat_ms;
-  if (n_launches) *n_launches = plan->plan.stat_launches;
-  if (rows_scanned) *rows_scanned = plan->plan.stat_rows;
-  return FDB_OK;
+  return guard(plan, [&] {
+    plan->plan.settle();  // queued small records count once they are scanned
+    if (algorithmic_bytes) *algorithmic_bytes = plan->plan.stat_bytes;
+    if (kernel_ms) *kernel_ms = plan->plan.stat_ms;
+    if (n_launches) *n_launches = plan->plan.stat_launches;
+    if (rows_scanned) *rows_scanned = plan->plan.stat_rows;
+  });
 }
 
 int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled) {
@@ -240,6 +243,10 @@ int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_bl
   return FDB_OK;
 }
 
-const char* fdb_plan_last_kernel(fdb_plan* plan) { return plan ? plan->plan.last_kernel() : ""; }
+const char* fdb_plan_last_kernel(fdb_plan* plan) {
+  if (!plan) return "";
+  (void)guard(plan, [&] { plan->plan.settle(); });
+  return plan->plan.last_kernel();
+}
 
 }  // extern "C"

@@ -161,4 +161,32 @@ void* Context::stage(const void* host, size_t payload) {
   return dst;
 }
 
+unsigned char* Context::copy_reserve(size_t payload) {
+  const size_t bytes = (std::max<size_t>(payload, 1) + 255) / 256 * 256;
+  if (copy_off_ + bytes > copy_cap_) {
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(copy ring)");  // every DMA out of the ring has finished
+    copy_off_ = 0;
+    if (bytes > copy_cap_) {
+      if (copy_h_) (void)hipHostFree(copy_h_);
+      copy_cap_ = std::max<size_t>(round_block(bytes * 2), (size_t)32 << 20);
+      hip_check(hipHostMalloc((void**)&copy_h_, copy_cap_, hipHostMallocDefault), "hipHostMalloc(copy ring)");
+    }
+  }
+  unsigned char* p = copy_h_ + copy_off_;
+  copy_off_ += bytes;
+  return p;
+}
+
+void Context::copy_commit(void* dst, const unsigned char* ring_ptr, size_t bytes) {
+  if (bytes == 0) return;
+  hip_check(hipMemcpyAsync(dst, ring_ptr, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(copy ring)");
+}
+
+void Context::copy_in(void* dst, const void* host, size_t payload) {
+  if (payload == 0) return;
+  unsigned char* p = copy_reserve(payload);
+  std::memcpy(p, host, payload);
+  copy_commit(dst, p, payload);
+}
+
 }  // namespace fdb

@@ -30,7 +30,13 @@ class Context {
 
   // Small host→device tables (LUTs, slot maps): staged in pinned memory, shipped with one async copy each.
   void* stage(const void* host, size_t bytes);
-  void reset_staging() { stage_off_ = 0; }  // stream is idle
+  void reset_staging() { stage_off_ = 0; copy_off_ = 0; }  // stream is idle
+  // Copies `bytes` of pageable host memory to `dst` (device) through the pinned ring: the source is fully read when this
+  // returns (the caller may free it), the DMA runs asynchronously on `stream`.
+  void copy_in(void* dst, const void* host, size_t bytes);
+  // The same in two steps, for several host buffers that go to ONE device block: reserve ring space, fill it, commit one DMA.
+  unsigned char* copy_reserve(size_t bytes);
+  void copy_commit(void* dst, const unsigned char* ring_ptr, size_t bytes);
 
  private:
   Context() = default;
@@ -40,6 +46,8 @@ class Context {
   unsigned char* stage_h_ = nullptr;
   unsigned char* stage_d_ = nullptr;
   size_t stage_cap_ = 0, stage_off_ = 0;
+  unsigned char* copy_h_ = nullptr;  // pinned ring of copy_in (separate from the LUT staging ring: a wrap here never touches staged LUTs)
+  size_t copy_cap_ = 0, copy_off_ = 0;
 };
 
 // Process-wide, thread-safe pool of pinned host blocks for RESULT records (their Arrow release callback can run on any

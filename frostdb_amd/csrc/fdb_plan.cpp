@@ -81,7 +81,7 @@ int DeviceBatch::find(const std::string& name) const {
 }
 
 std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device, const std::function<bool(const std::string&)>* want,
-                                          hipStream_t stream, Context* ctx) {
+                                          hipStream_t stream, Context* ctx, bool via_ring) {
   std::unique_ptr<DeviceBatch> b(new DeviceBatch());
   b->device = device;
   b->rows = view.rows;
@@ -123,8 +123,11 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
   // transient batches: every copy is queued on `stream`; re-packed buffers stay alive until the one wait at the end
   std::vector<std::vector<uint8_t>> keep_bits;
   std::vector<std::vector<uint32_t>> keep_idx;
+  // via_ring: the whole arena is assembled in ONE piece of the pinned ring and shipped with one DMA
+  unsigned char* ring = (ctx != nullptr && via_ring && total > 0) ? ctx->copy_reserve(total) : nullptr;
   auto h2d = [&](void* dst, const void* src, size_t bytes, const char* what) {
-    if (ctx != nullptr) hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream), what);
+    if (ring != nullptr) std::memcpy(ring + ((unsigned char*)dst - (unsigned char*)b->arena), src, bytes);
+    else if (ctx != nullptr) hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream), what);
     else hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), what);
   };
   for (const Piece& p : pieces) {
@@ -162,7 +165,8 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     }
   }
   for (const DevColumn& d : b->cols) b->payload_bytes += d.value_bytes + d.validity_bytes;
-  if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty())) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
+  if (ring != nullptr) ctx->copy_commit(b->arena, ring, total);
+  else if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty())) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
   return b;
 }
 
@@ -263,6 +267,8 @@ Plan::~Plan() {
   ctx_->dev_free(h_keys_);
   ctx_->dev_free(h_count_dev_);
   for (void* p : scratch_) ctx_->dev_free(p);
+  pending_.clear();   // (queued / in-flight records hand their arenas back to this context: before it is released)
+  inflight_.clear();
   ctx_->reset_staging();
   Context::release(ctx_);
 }
@@ -323,6 +329,7 @@ void Plan::sync() {
   ctx_->reset_staging();
   for (void* p : scratch_) ctx_->dev_free(p);
   scratch_.clear();
+  inflight_.clear();  // (their arenas go back to the block cache)
 }
 
 void Plan::collect_timing() {
@@ -673,13 +680,65 @@ void Plan::ensure_layout(const std::vector<uint32_t>& new_caps) {
 }
 
 // ---- push -------------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kCoalesceMaxBytes = (size_t)8 << 20;   // records above this are scanned right away (the copy dominates anyway)
+constexpr int64_t kFlushRows = 2 << 20;                 // pending rows that justify a launch
+constexpr size_t kFlushBytes = (size_t)96 << 20;
+constexpr size_t kFlushRecords = 1024;
+}  // namespace
+
+bool Plan::jit_possible() const { return sub_tiles != 4 && ablate == 0 && std::getenv("FDB_NO_JIT") == nullptr; }
+
 void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
+  if (finished_) throw Error(FDB_ERR_STATE, "push after finish");
+  if (aggs_.empty() && matchers_.empty()) throw Error(FDB_ERR_STATE, "filter-only plan: use fdb_plan_filter / fdb_plan_select");
   HostRecordView view;
   view_record(array, schema, &view);
   std::function<bool(const std::string&)> want = [this](const std::string& n) { return references(n); };
-  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_, ctx_);
-  push_batch(*b);
-  sync();  // the caller's buffers are only borrowed (table.go:808): every copy has landed; the arena returns to the block cache
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  size_t payload = 0;
+  for (const HostColView& c : view.cols)
+    if (want(c.name)) payload += (size_t)c.length * (c.kind == ColKind::DICT ? 4 : 8) + (size_t)(c.length + 7) / 8;
+  if (payload > kCoalesceMaxBytes) {
+    settle();  // keep arrival order (it fixes the first-seen order of group columns and key ids)
+    std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_, ctx_);
+    push_batch(*b);
+    sync();  // the caller's buffers are only borrowed (table.go:808): every copy has landed; the arena returns to the block cache
+    return;
+  }
+  // small record: copy now (through pinned staging — the source is not touched after this call), scan later
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_, ctx_, /*via_ring=*/true);
+  {
+    // errors the record would raise surface here, at its own Callback, not at some later launch
+    Resolved R;
+    std::vector<int> gc;
+    resolve_batch(*b, &R, &gc);
+    if (R.args.n_expr > 0 && !jit_possible())
+      throw Error(FDB_ERR_UNSUPPORTED, "computed (projected) columns need the run-time specialised kernel (hiprtc unavailable or disabled)");
+  }
+  pending_rows_ += b->rows;
+  pending_bytes_ += b->arena_bytes;
+  pending_.push_back(std::move(b));
+  if (pending_rows_ >= kFlushRows || pending_bytes_ >= kFlushBytes || pending_.size() >= kFlushRecords) settle();
+}
+
+void Plan::settle() {
+  if (pending_.empty()) return;
+  // The queued records must outlive the launch (until the next sync), and push_batches itself may synchronise (table
+  // migration, growth) — which empties inflight_ — so they are held here until it returns.
+  std::vector<std::unique_ptr<DeviceBatch>> batch = std::move(pending_);
+  pending_.clear();
+  pending_rows_ = 0;
+  pending_bytes_ = 0;
+  std::vector<const DeviceBatch*> ptrs;
+  for (const auto& b : batch) ptrs.push_back(b.get());
+  try {
+    push_batches(ptrs.data(), (int)ptrs.size());
+  } catch (...) {
+    (void)hipStreamSynchronize(stream_);  // nothing may still be reading the arenas when `batch` is destroyed
+    throw;
+  }
+  for (auto& b : batch) inflight_.push_back(std::move(b));
 }
 
 void Plan::push_batch(const DeviceBatch& b) {
@@ -1052,6 +1111,16 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
         const JitShape si = jit_shape(Rs[(size_t)i].args, two_phase != 0, jit_block ? jit_block : 256);
         if (first) { shape = si; first = false; }
         else if (!jit_shape_merge(&shape, si)) { same = false; break; }
+      }
+      if (!same && live.size() > 1) {
+        // records of different shapes (schema drift: a filter column missing here, NULLs there) cannot share a specialised kernel.
+        // Plans that NEED one (computed columns) scan them one by one; the others take the interpreting kernel below.
+        bool need_jit = false;
+        for (int i : live) need_jit = need_jit || Rs[(size_t)i].args.n_expr > 0;
+        if (need_jit) {
+          for (int i : live) { const DeviceBatch* one = bs[i]; push_batches(&one, 1); }
+          return;
+        }
       }
       {
         // tiny tables live in registers (JitShape::reg_slots): ≤ 8 slots and ≤ 48 accumulator registers per lane

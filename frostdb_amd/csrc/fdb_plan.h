@@ -52,8 +52,11 @@ struct DeviceBatch {
 // With `ctx`, the arena comes from (and returns to) that context's block cache and the copies are asynchronous on
 // `stream` (one synchronisation at the end) — the per-record cost of fdb_plan_push; without, a private hipMalloc
 // (resident batches, which outlive any plan).
+// `via_ring` (with ctx): every buffer is first copied into the context's pinned ring (the source is fully read when the call
+// returns, nothing is waited for) — the deferred, coalescing mode of fdb_plan_push for small records.
 std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device,
-                                          const std::function<bool(const std::string&)>* want, hipStream_t stream, class Context* ctx = nullptr);
+                                          const std::function<bool(const std::string&)>* want, hipStream_t stream, class Context* ctx = nullptr,
+                                          bool via_ring = false);
 
 struct Literal {
   int32_t type = FDB_LIT_NULL;
@@ -131,6 +134,10 @@ class Plan {
   ~Plan();
 
   void push(const ArrowArray* array, const ArrowSchema* schema);        // ≙ Callback
+  // Small host records are not scanned one by one: push validates them, copies what the plan references into pinned staging
+  // (the caller's buffers are only borrowed) and queues the copy; ONE launch covers the queued records once enough rows are
+  // pending. settle() launches whatever is queued — every entry point that reads or merges state calls it first.
+  void settle();
   void push_batch(const DeviceBatch& batch);
   void push_batches(const DeviceBatch* const* batches, int n);         // one fused launch over n resident records
   void finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows);  // ≙ Finish
@@ -225,6 +232,11 @@ class Plan {
   Context* ctx_ = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
   std::vector<void*> scratch_;  // device blocks in use by in-flight kernels; returned to the context at the next sync
+  std::vector<std::unique_ptr<DeviceBatch>> pending_;   // queued small records (copies in flight or done), not scanned yet
+  std::vector<std::unique_ptr<DeviceBatch>> inflight_;  // records a launched kernel may still be reading; dropped at the next sync
+  int64_t pending_rows_ = 0;
+  size_t pending_bytes_ = 0;
+  bool jit_possible() const;
   std::string draw_;
 };
 

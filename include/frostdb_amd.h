@@ -181,8 +181,11 @@ int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s);
 /* ---- plan life cycle (≙ physicalplan.Build for one chain, physicalplan.go:417-474) -------------- */
 int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
 /* ≙ PhysicalPlan.Callback: borrows `batch` for the duration of the call only (the reference releases
- * the record right after Callback returns, table.go:808,:827); the columns the plan references are
- * staged to HBM, filtered and aggregated before returning control (kernels may still be in flight). */
+ * the record right after Callback returns, table.go:808,:827). The record is validated against the plan (errors it
+ * would raise are returned by THIS call) and the columns the plan references are copied out before returning. Records
+ * above 8 MiB of referenced data are scanned right away; smaller ones — the reference hands records of ≥ 1 024 rows
+ * (table.go:780) — are queued in HBM and scanned together, ONE launch per ≈2 M pending rows, or when the plan's state
+ * is next needed (finish, merge, num_groups, state_*, push of resident batches …). */
 int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema);
 /* Same, for a record that is already resident in HBM. */
 int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch);

@@ -975,3 +975,19 @@ def test_concurrent_chains_on_threads(pp):
                     p.Close()
             c = cols or (key_cols_of([b for s in shards for b in s]) + [a.Name() for a in aggs])
             assert_same_result(got, want, c, float_cols={"sum(value)"})
+
+
+def test_projection_with_schema_drift_between_queued_records(pp):
+    """Small host records are queued and scanned together; records of different SHAPES (the filter column is missing in one —
+    missing-column rules turn its leaf into a constant) cannot share one specialised kernel, and a plan with computed columns
+    has no interpreting fallback: such a launch is split per record instead of failing."""
+    rng = np.random.default_rng(93)
+    b1 = many_label_batch(rng, 5000, 3, 4, int_key=True)
+    b2 = many_label_batch(rng, 4000, 3, 4, int_key=True).drop_columns(["labels.l02"])
+    b3 = many_label_batch(rng, 3000, 3, 4, int_key=True)
+    filt = Col("labels.l02") != "v2_1"
+    aggs = [Sum(Col("value") * Col("bucket")), Count(Col("value"))]
+    groups = [Col("labels.l00")]
+    want = run_oracle([b1, b2, b3], filt, aggs, groups)
+    got = run_gpu(pp, [b1, b2, b3], filt, aggs, groups)
+    assert_same_result(got, want, ["labels.l00"] + [a.Name() for a in aggs])
