@@ -991,3 +991,20 @@ def test_projection_with_schema_drift_between_queued_records(pp):
     want = run_oracle([b1, b2, b3], filt, aggs, groups)
     got = run_gpu(pp, [b1, b2, b3], filt, aggs, groups)
     assert_same_result(got, want, ["labels.l00"] + [a.Name() for a in aggs])
+
+
+def test_maximum_group_columns(pp, variant):
+    """64 group-by columns is the limit of the key tuple's valid mask: 64 work (hash path), 65 are refused loudly."""
+    rng = np.random.default_rng(64)
+    b = many_label_batch(rng, 20_000, 64, 2, n_groups=3000)
+    aggs = [Sum(Col("value")), Count(Col("value"))]
+    want = run_oracle([b], None, aggs, [DynCol("labels")])
+    got = run_gpu(pp, [b], None, aggs, [DynCol("labels")])
+    assert_same_result(got, want, key_cols_of([b]) + [a.Name() for a in aggs])
+    b65 = many_label_batch(rng, 1000, 65, 2, n_groups=100)
+    plan = pp.HashAggregatePlan(None, aggs, [DynCol("labels")])
+    try:
+        with pytest.raises(pp.UnsupportedError):
+            plan.Callback(b65)
+    finally:
+        plan.Close()
