@@ -46,6 +46,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_metro_hash64.argtypes = [ctypes.c_char_p, i64, u64]
         L.oracle_hash_combine.restype = u64
         L.oracle_hash_combine.argtypes = [u64, u64]
+        L.oracle_build_index_ranges.restype = i64
+        L.oracle_build_index_ranges.argtypes = [ctypes.POINTER(ctypes.c_uint32), i64, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
         L.oracle_batch_import.argtypes = [vp, vp, ctypes.POINTER(vp)]
         L.oracle_batch_release.argtypes = [vp]
         L.oracle_batch_num_rows.restype = i64
@@ -80,6 +82,15 @@ class OracleError(RuntimeError):
 
 def metro_hash64(data: bytes, seed: int = 0) -> int:
     return lib().oracle_metro_hash64(data, len(data), seed)
+
+
+def build_index_ranges(indices):
+    """buildIndexRanges (filter.go:332-354): sorted row indices → [(start, end)) runs."""
+    n = len(indices)
+    arr = (ctypes.c_uint32 * max(n, 1))(*indices)
+    st, en = (ctypes.c_uint32 * max(n, 1))(), (ctypes.c_uint32 * max(n, 1))()
+    k = lib().oracle_build_index_ranges(arr, n, st, en)
+    return [(st[i], en[i]) for i in range(k)]
 
 
 class OracleBatch:

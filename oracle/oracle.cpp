@@ -780,6 +780,13 @@ const char* oracle_last_error(void) { return g_err.c_str(); }
 
 uint64_t oracle_metro_hash64(const uint8_t* data, int64_t len, uint64_t seed) { return metro_hash64(data, (size_t)len, seed); }
 uint64_t oracle_hash_combine(uint64_t l, uint64_t r) { return hash_combine(l, r); }
+// buildIndexRanges (filter.go:332-354), exposed so that filter_test.go's vectors can pin it. `starts`/`ends` hold up to n entries.
+int64_t oracle_build_index_ranges(const uint32_t* indices, int64_t n, uint32_t* starts, uint32_t* ends) {
+  if (n <= 0) return 0;
+  const std::vector<IndexRange> r = build_index_ranges(std::vector<uint32_t>(indices, indices + n));
+  for (size_t i = 0; i < r.size(); i++) { starts[i] = r[i].start; ends[i] = r[i].end; }
+  return (int64_t)r.size();
+}
 
 int oracle_batch_import(struct ArrowArray* a, struct ArrowSchema* s, oracle_batch** out) {
   std::unique_ptr<oracle_batch> b(new oracle_batch());

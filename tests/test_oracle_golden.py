@@ -212,3 +212,14 @@ def test_oracle_distinct_golden(case, nchains):
     plan.close()
     got = sorted(batch_rows(d, case["out"]), key=sort_key)
     assert got == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+@pytest.mark.parametrize("indices,expected", [
+    ([4, 6, 7, 8, 10], [(4, 5), (6, 9), (10, 11)]),                       # filter_test.go:10-20 TestBuildIndexRanges
+    ([1, 3, 5, 7, 9], [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10)]),         # filter_test.go:27-30 "no consecutive"
+    ([1, 2], [(1, 3)]),                                                   # :31-34 "only consecutive"
+    ([1], [(1, 2)]),                                                      # :35-38 "only 1"
+    ([1, 2, 7, 8, 9], [(1, 3), (7, 10)]),                                 # :39-42 "multiple"
+])
+def test_oracle_build_index_ranges_golden(indices, expected):
+    assert oracle.build_index_ranges(indices) == expected
