@@ -223,3 +223,19 @@ def test_oracle_distinct_golden(case, nchains):
 ])
 def test_oracle_build_index_ranges_golden(indices, expected):
     assert oracle.build_index_ranges(indices) == expected
+
+
+def test_oracle_and_short_circuits_like_the_reference():
+    """filter_test.go:66-82 TestAndExprShortCircuits: when the left side of an AND selects nothing the right side is not evaluated —
+    observable as "no error" for a right side that would raise (here: `<` on a dictionary column, binaryscalarexpr.go:106-108)."""
+    from frostdb_amd.logicalplan import And
+    rec = table_records(G.FILTER_TABLE)[0]
+    bad = Col("labels.label1") < "x"
+    plan = OraclePlan(bad)
+    with pytest.raises(Exception):
+        plan.filter(rec)
+    plan.close()
+    plan = OraclePlan(And(Col("labels.label1") == "no such value", bad))
+    out, idx = plan.filter(rec)
+    assert out is None and list(idx) == []
+    plan.close()
