@@ -1008,3 +1008,26 @@ def test_maximum_group_columns(pp, variant):
             plan.Callback(b65)
     finally:
         plan.Close()
+
+
+def test_large_dictionary_columns(pp, variant):
+    """A label with 60 000 distinct values: its predicate truth table (regex → byte LUT) and its key-id LUT are too big for LDS and
+    are gathered from global memory; the dense table (60 001 × 3 slots) does not fit LDS either. Second query: group by it alone."""
+    rng = np.random.default_rng(606)
+    n, card = 150_000, 60_000
+    names = [b"series-%06d" % i for i in range(card)]
+    recs = []
+    for _ in range(2):
+        idx = pa.array(rng.integers(0, card, size=n).astype(np.uint32), type=pa.uint32(), mask=rng.random(n) < 0.02)
+        small = pa.array(rng.integers(0, 2, size=n).astype(np.uint32), type=pa.uint32())
+        recs.append(pa.RecordBatch.from_arrays(
+            [pa.DictionaryArray.from_arrays(idx, pa.array(names, type=pa.binary())),
+             pa.DictionaryArray.from_arrays(small, pa.array([b"x", b"y"], type=pa.binary())),
+             pa.array(rng.integers(0, 1000, size=n).astype(np.int64)), pa.array(rng.uniform(0, 1, size=n))],
+            names=["labels.series", "labels.kind", "value", "floatvalue"]))
+    filt = And(Col("labels.series").RegexMatch("series-0[0-3]"), Col("labels.kind") != "y")
+    for aggs, groups in (([Sum(Col("value")), Count(Col("value")), Max(Col("floatvalue"))], [Col("labels.series"), Col("labels.kind")]),
+                         ([Sum(Col("floatvalue"))], [Col("labels.series")])):
+        want = run_oracle(recs, filt, aggs, groups)
+        got = run_gpu(pp, recs, filt, aggs, groups, resident=True)
+        assert_same_result(got, want, [g.name for g in groups] + [a.Name() for a in aggs], float_cols={"sum(floatvalue)"})
