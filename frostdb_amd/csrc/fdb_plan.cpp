@@ -1112,13 +1112,21 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
         if (first) { shape = si; first = false; }
         else if (!jit_shape_merge(&shape, si)) { same = false; break; }
       }
-      if (!same && live.size() > 1) {
-        // records of different shapes (schema drift: a filter column missing here, NULLs there) cannot share a specialised kernel.
-        // Plans that NEED one (computed columns) scan them one by one; the others take the interpreting kernel below.
-        bool need_jit = false;
-        for (int i : live) need_jit = need_jit || Rs[(size_t)i].args.n_expr > 0;
-        if (need_jit) {
-          for (int i : live) { const DeviceBatch* one = bs[i]; push_batches(&one, 1); }
+      if (!same && live.size() > 1 && jit_possible) {
+        // Records of different shapes (schema drift: a filter column missing here, a predicate value absent from that part's
+        // dictionary there) cannot share one specialised kernel: the launch is split into one launch per shape, so that a
+        // few odd parts do not push the whole scan onto the interpreting kernel.
+        std::vector<std::string> keys;
+        std::vector<std::vector<const DeviceBatch*>> groups;
+        for (int i : live) {
+          const std::string k = jit_shape(Rs[(size_t)i].args, two_phase != 0, 256).key(false);
+          size_t g = 0;
+          for (; g < keys.size(); g++) if (keys[g] == k) break;
+          if (g == keys.size()) { keys.push_back(k); groups.emplace_back(); }
+          groups[g].push_back(bs[i]);
+        }
+        if (groups.size() > 1) {
+          for (auto& g : groups) push_batches(g.data(), (int)g.size());
           return;
         }
       }

@@ -1031,3 +1031,27 @@ def test_large_dictionary_columns(pp, variant):
         want = run_oracle(recs, filt, aggs, groups)
         got = run_gpu(pp, recs, filt, aggs, groups, resident=True)
         assert_same_result(got, want, [g.name for g in groups] + [a.Name() for a in aggs], float_cols={"sum(floatvalue)"})
+
+
+def test_mixed_shape_parts_in_one_scan(pp):
+    """Resident parts of one table whose shapes differ — a predicate value missing from one part's dictionary (its leaf folds to
+    a constant), a label column absent from another, NULL-free columns in a third — pushed in ONE call: the scan is split per
+    shape and every group still runs a specialised kernel; the result equals the oracle's."""
+    rng = np.random.default_rng(808)
+    parts = [make_prometheus_batch(rng, 30_000, n_path=40) for _ in range(5)]
+    # part 1: no row has code 500 and its dictionary does not even contain it
+    codes = parts[1].column(0)
+    keep = pa.array([b"200", b"404"], type=pa.binary())
+    parts[1] = parts[1].set_column(0, "labels.code", pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 2, size=30_000).astype(np.uint32)), keep))
+    parts[2] = parts[2].drop_columns(["labels.instance"])
+    parts[3] = make_prometheus_batch(rng, 30_000, n_path=40, null_frac=0.0)
+    want = run_oracle(parts, **CFG3)
+    plan = pp.HashAggregatePlan(CFG3["filter_expr"], CFG3["aggs"], CFG3["groups"])
+    keep_alive = [pp.ResidentBatch(p) for p in parts]
+    try:
+        plan.CallbackResident(keep_alive)
+        assert plan.last_kernel() == "fdb_plan_kernel"
+        got = arrow_to_pydict(plan.Finish())
+    finally:
+        plan.Close()
+    assert_same_result(got, want, ["labels.path"] + [a.Name() for a in CFG3["aggs"]], float_cols={"sum(value)"})
