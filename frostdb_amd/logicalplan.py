@@ -254,6 +254,16 @@ def Count(c: Column) -> AggregationFunction:
     return AggregationFunction(AGG_COUNT, c)
 
 
+def Unique(c: Column) -> AggregationFunction:
+    """logicalplan.Unique (expr.go:780-785): the group's value if all its rows carry the same non-NULL int64, else NULL."""
+    return AggregationFunction(AGG_UNIQUE, c)
+
+
+def AndAgg(c: Column) -> AggregationFunction:
+    """logicalplan.AndAgg (expr.go:787-792): logical AND over a bool column's valid values."""
+    return AggregationFunction(AGG_AND, c)
+
+
 # ---- C structs of include/frostdb_amd.h ---------------------------------------------------------
 
 class CLiteral(ctypes.Structure):

@@ -742,6 +742,22 @@ struct HashAggregate {
           *err = {FDB_ERR_UNSUPPORTED, std::string("unsupported type for ") + agg_func_name(fn) + " aggregation, expected int64 or float64"};
           return false;
         }
+      } else if (fn == FDB_AGG_UNIQUE) {  // UniqueAggregation (aggregate.go:677-732): the group's single value, NULL if it has a NULL or two values
+        if (t != T_I64) { *err = {FDB_ERR_UNSUPPORTED, "unsupported type for is unique aggregation, expected int64"}; return false; }
+        c.type = T_I64; c.i64.assign(row_count, 0);
+        for (int64_t g = 0; g < row_count; g++) {
+          const ValueBuilder& b = arrays[j][g];
+          bool unique = !b.valid.empty() && b.valid[0];
+          for (size_t i = 1; i < b.valid.size() && unique; i++) unique = b.valid[i] && b.i64[i] == b.i64[0];
+          if (unique) c.i64[g] = b.i64[0]; else c.valid[g] = 0;
+        }
+      } else if (fn == FDB_AGG_AND) {  // AndAggregation (aggregate.go:635-675): AND over the valid values; no valid value ⇒ true
+        if (t != T_BOOL) { *err = {FDB_ERR_UNSUPPORTED, "unsupported type for is and aggregation, expected bool"}; return false; }
+        c.type = T_BOOL; c.i64.assign(row_count, 1);
+        for (int64_t g = 0; g < row_count; g++) {
+          const ValueBuilder& b = arrays[j][g];
+          for (size_t i = 0; i < b.valid.size(); i++) if (b.valid[i] && !b.i64[i]) c.i64[g] = 0;
+        }
       } else {
         *err = {FDB_ERR_UNSUPPORTED, std::string("unsupported aggregation function: ") + agg_func_name(fn)};
         return false;

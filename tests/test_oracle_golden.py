@@ -239,3 +239,33 @@ def test_oracle_and_short_circuits_like_the_reference():
     out, idx = plan.filter(rec)
     assert out is None and list(idx) == []
     plan.close()
+
+
+# ---- UniqueAggregation / AndAggregation (aggregate.go:635-732), vectors of query/engine_test.go ------------------------------
+
+def unique_and_cases():
+    import pyarrow as pa
+    from frostdb_amd.logicalplan import AndAgg, Unique
+    uniq = pa.RecordBatch.from_arrays([pa.array([1, 2, 3], pa.int64()), pa.array([1, 1, 3], pa.int64())], names=["example", "timestamp"])
+    andr = pa.RecordBatch.from_arrays([pa.array([True, False, True, True]), pa.array([1, 1, 3, 3], pa.int64())], names=["example", "timestamp"])
+    return [
+        # engine_test.go:19-74 TestUniqueAggregation: timestamps [1, 3]; unique(example) NULL for ts 1 (values 1 and 2), 3 for ts 3
+        dict(id="unique", cite="query/engine_test.go:19-74", rec=uniq, agg=Unique(Col("example")), out="unique(example)", expected={1: None, 3: 3}),
+        # engine_test.go:76-131 TestAndAggregation: and(example) false for ts 1 (true, false), true for ts 3
+        dict(id="and", cite="query/engine_test.go:76-131", rec=andr, agg=AndAgg(Col("example")), out="and(example)", expected={1: False, 3: True}),
+    ]
+
+
+@pytest.mark.parametrize("nchains", [1, 2])
+@pytest.mark.parametrize("case", unique_and_cases(), ids=lambda c: c["id"])
+def test_oracle_unique_and_golden(case, nchains):
+    plan = OraclePlan(None, [case["agg"]], [Col("timestamp")], nchains=nchains)
+    rec = case["rec"]
+    if nchains == 1:
+        plan.push(rec)
+    else:  # the rows of one group land on different chains: the final stage must still see them as one group
+        plan.push(rec.slice(0, 1), chain=0)
+        plan.push(rec.slice(1), chain=1)
+    d = plan.finish().to_pydict()
+    plan.close()
+    assert dict(zip(d["timestamp"], d[case["out"]])) == case["expected"], case["cite"]
