@@ -221,13 +221,10 @@ void export_record(std::vector<OutColumn>&& cols_in, int64_t rows, ArrowArray* o
     std::vector<const void*>& b = h->buffers[i];
     b.resize(2);
     static const uint64_t kEmpty = 0;
-    if (c.backing) {
-      b[0] = c.null_count > 0 ? (const void*)c.ext_validity : nullptr;
-      b[1] = c.ext_values != nullptr ? (const void*)c.ext_values : (const void*)&kEmpty;
-    } else {
-      b[0] = (c.null_count > 0 && !c.validity.empty()) ? (const void*)c.validity.data() : nullptr;
-      b[1] = c.values.empty() ? (const void*)&kEmpty : (const void*)c.values.data();
-    }
+    // each buffer is either external (inside the record's shared block) or the column's own vector
+    const void* vbits = c.ext_validity != nullptr ? (const void*)c.ext_validity : (c.validity.empty() ? nullptr : (const void*)c.validity.data());
+    b[0] = c.null_count > 0 ? vbits : nullptr;
+    b[1] = c.ext_values != nullptr ? (const void*)c.ext_values : (c.values.empty() ? (const void*)&kEmpty : (const void*)c.values.data());
     a.buffers = b.data();
     a.release = noop_release_array;
     ArrowSchema& s = h->child_schemas[i];

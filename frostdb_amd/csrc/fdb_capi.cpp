@@ -190,6 +190,16 @@ int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t
   return guard(plan, [&] { plan->plan.settle(); plan->plan.state_write(array, src, bytes); });
 }
 
+int fdb_plan_state_arrays(fdb_plan* plan, int32_t* n_arrays) {
+  if (!plan || !n_arrays) return FDB_ERR_INVALID;
+  return guard(plan, [&] { *n_arrays = plan->plan.num_state_arrays(); });
+}
+
+int fdb_plan_state_array_op(fdb_plan* plan, int32_t array, int32_t* op) {
+  if (!plan || !op) return FDB_ERR_INVALID;
+  return guard(plan, [&] { plan->plan.settle(); *op = plan->plan.state_array_op(array); });
+}
+
 int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out) {
   if (!plan) return FDB_ERR_INVALID;
   return guard(plan, [&] { plan->plan.settle(); *format_out = plan->plan.agg_format(agg); });

@@ -359,15 +359,18 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     }
     out->push_back(std::move(oc));
   }
+  std::vector<size_t> out_of_agg(aggs_.size(), (size_t)-1);  // physical aggregate → its output column
   for (size_t j = 0; j < aggs_.size(); j++) {
     const AggState& A = aggs_[j];
+    if (A.role == 2) continue;  // MAX half of UNIQUE
     OutColumn oc;
     oc.name = A.result_name;
     oc.length = (int64_t)n;
     const bool count_from_cnt = A.func == FDB_AGG_COUNT && !final_stage_;
     const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
-    oc.format = is_f64 ? "g" : "l";
-    if (n > 0) { oc.backing = backing; oc.ext_values = h_block + off_val[count_from_cnt ? 0 : 1 + j]; }
+    oc.format = A.role == 3 ? "b" : is_f64 ? "g" : "l";
+    if (n > 0 && A.role != 3) { oc.backing = backing; oc.ext_values = h_block + off_val[count_from_cnt ? 0 : 1 + j]; }
+    out_of_agg[j] = out->size();
     out->push_back(std::move(oc));
   }
   sync();
@@ -383,6 +386,24 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     for (size_t i = 0; i < full; i++) set += __builtin_popcountll(w64[i]);
     for (size_t i = full * 8; i < bytes; i++) set += __builtin_popcount(oc.ext_validity[i]);
     oc.null_count = (int64_t)n - set;
+  }
+  for (size_t j = 0; j < aggs_.size() && n > 0; j++) {  // composite reducers: UNIQUE's validity, AND's bits
+    const AggState& A = aggs_[j];
+    if (A.role == 1) {
+      OutColumn& oc = (*out)[out_of_agg[j]];
+      const unsigned long long* lo = (const unsigned long long*)(h_block + off_val[1 + j]);
+      const unsigned long long* hi = (const unsigned long long*)(h_block + off_val[2 + j]);
+      oc.validity.assign((size_t)(n + 7) / 8, 0);
+      for (uint64_t i = 0; i < n; i++) {
+        if (lo[i] == hi[i]) oc.validity[i >> 3] |= (uint8_t)(1u << (i & 7));
+        else { oc.null_count++; std::memset(h_block + off_val[1 + j] + i * 8, 0, 8); }
+      }
+    } else if (A.role == 3) {
+      OutColumn& oc = (*out)[out_of_agg[j]];
+      const unsigned long long* v = (const unsigned long long*)(h_block + off_val[1 + j]);
+      oc.values.assign((size_t)(n + 7) / 8 + 8, 0);
+      for (uint64_t i = 0; i < n; i++) if (v[i] != 0ull) oc.values[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
   }
   for (size_t j = 0; j < aggs_.size() && n > 0; j++) {
     const AggState& A = aggs_[j];
@@ -425,7 +446,7 @@ void Plan::group_schema(ArrowArray* out, ArrowSchema* out_schema) {
   }
   // the value types of the aggregated columns travel with the schema (a rank that saw no record does not know them)
   for (const AggState& A : aggs_) {
-    if (A.func == FDB_AGG_COUNT || A.type == FDB_T_NONE) continue;
+    if (A.func == FDB_AGG_COUNT || A.type == FDB_T_NONE || A.role == 2) continue;
     OutColumn oc;
     oc.name = A.result_name;
     oc.length = 0;

@@ -336,7 +336,7 @@ struct Gen {
           raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col)) + " : 0ull)";
         } else {
           const std::string r = reg(true, s.two_phase, A.slot);
-          raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : 0ull)";
+          raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : c.aggs[" + std::to_string(j) + "].null_value)";
         }
         const std::string v = "v" + std::to_string(j);
         if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      const double " << v << " = __longlong_as_double((long long)" << raw << ");\n";
@@ -386,7 +386,7 @@ struct Gen {
           raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col)) + " : 0ull)";
         } else {
           const std::string r = reg(true, s.two_phase, A.slot);
-          raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : 0ull)";
+          raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : c.aggs[" + std::to_string(j) + "].null_value)";
         }
         const std::string gacc = "(c.aggs[" + std::to_string(j) + "].acc + gid" + std::to_string(k) + ")";
         const std::string acc = s.lds_acc ? ("(l_acc + (size_t)" + std::to_string(j) + " * n_slots + gid" + std::to_string(k) + ")") : gacc;
@@ -680,7 +680,7 @@ struct HashGen {
         const JitAgg& A = s.aggs[j];
         if (A.func == FDB_AGG_COUNT || (s.ablate & 2)) continue;
         const std::string r = "g" + std::to_string(j);
-        std::string raw = "(((" + r + "_m >> " + std::to_string(k) + ") & 1u) ? " + comp8(r, k) + " : 0ull)";
+        std::string raw = "(((" + r + "_m >> " + std::to_string(k) + ") & 1u) ? " + comp8(r, k) + " : a.aggs[" + std::to_string(j) + "].null_value)";
         if (A.expr != 0) {
           auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
           auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };

@@ -79,6 +79,9 @@ struct FdbAgg {
   int32_t type;             // FdbAggType of the input column / expression
   int32_t slot;             // c8 slot
   int32_t expr;             // 1 + root node (FdbScanArgs.expr) of a computed input (pre-aggregate Projection); 0: stored column
+  unsigned long long null_value;  // what a NULL row contributes: 0 (the builder's zeroed slot: SUM/MIN/MAX, aggregate.go:784-935), or the
+                                  // value that makes a NULL decisive / neutral for the composite reducers built on MIN and MAX
+                                  // (UNIQUE: INT64_MIN for its MIN half, INT64_MAX for its MAX half; AND: 1)
 };
 
 // One node of a pre-aggregate arithmetic expression (physicalplan/project.go:73-161), evaluated per row inside the run-time

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
       // A NULL contributes the builder's zeroed slot: 0 to SUM *and* to MIN/MAX (aggregate.go:784-935 read raw
       // values; pqarrow/builder/optbuilders.go:337-340 zero-fills).
 #pragma unroll
-      for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = 0ull;
+      for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = A.null_value;
       unsigned long long* acc = LDS ? (l_acc + (size_t)j * n_slots) : A.acc;
       if (a.ablate & 2) {
         unsigned long long x = 0;
@@ -390,7 +390,7 @@ struct PlanRegs {
   int n_leaves, n_gcols, need_count;
   struct { int kind, slot, wide, op; uint32_t lut_lds, lut_len, ops_after; long long lit; const uint8_t* lut; } leaf[SLOT_MAX_LEAVES];
   struct { int slot; uint32_t lut_lds, stride; const uint32_t* lut; } gcol[SLOT_MAX_GCOLS];
-  struct { int func, type, slot; unsigned long long* acc; } agg[SLOT_MAX_AGGS];
+  struct { int func, type, slot; unsigned long long* acc; unsigned long long null_value; } agg[SLOT_MAX_AGGS];
   unsigned long long* cnt;
 };
 
@@ -419,7 +419,7 @@ __device__ __forceinline__ void decode_plan(const FdbScanArgs& a, PlanRegs<NC4, 
   }
 #pragma unroll
   for (int j = 0; j < SLOT_MAX_AGGS; j++) {
-    P.agg[j].func = a.aggs[j].func; P.agg[j].type = a.aggs[j].type; P.agg[j].slot = a.aggs[j].slot; P.agg[j].acc = a.aggs[j].acc;
+    P.agg[j].func = a.aggs[j].func; P.agg[j].type = a.aggs[j].type; P.agg[j].slot = a.aggs[j].slot; P.agg[j].acc = a.aggs[j].acc; P.agg[j].null_value = a.aggs[j].null_value;
   }
 }
 
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __re
         if (TWO_PHASE) pick8(SL, P.agg[j].slot, raw, valid); else pick8(S, P.agg[j].slot, raw, valid);
         // a NULL contributes the builder's zeroed slot (aggregate.go:784-935, optbuilders.go:337-340)
 #pragma unroll
-        for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = 0ull;
+        for (int r = 0; r < R; r++) if (!((valid >> r) & 1u)) raw[r] = P.agg[j].null_value;
         if (P.agg[j].func == AGG_SUM) {
           if (P.agg[j].type == FDB_T_F64) {
 #pragma unroll
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
       const bool valid = A.validity == nullptr || load_valid<R>(A.validity, row) != 0u;
       unsigned long long raw[R];
       load_u64<R>(reinterpret_cast<const unsigned long long*>(A.values) + row, raw);
-      const unsigned long long x = valid ? raw[0] : 0ull;  // NULL ⇒ the builder's zeroed slot
+      const unsigned long long x = valid ? raw[0] : A.null_value;  // NULL ⇒ the builder's zeroed slot (or the composite reducers' value)
       unsigned long long* acc = e + 3 + j;
       if (A.func == AGG_SUM) {
         if (A.type == FDB_T_F64) atomicAdd(reinterpret_cast<double*>(acc), __longlong_as_double((long long)x));

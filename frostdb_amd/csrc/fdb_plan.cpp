@@ -97,9 +97,9 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     const bool staged = (want == nullptr || (*want)(c.name));
     if (staged) {
       int64_t vb = 0;
-      if (c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64) vb = c.length * 8;
+      if (c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::BOOL) vb = c.length * 8;  // (bool: widened to int64 0 / 1)
       else if (c.kind == ColKind::DICT) vb = c.length * 4;
-      if (vb > 0 || ((c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::DICT))) {
+      if (vb > 0 || ((c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::DICT || c.kind == ColKind::BOOL))) {
         d.value_bytes = vb;
         pieces.push_back(Piece{i, false, total, (size_t)vb});
         total += align_up((size_t)vb + kTailPad, 256);
@@ -123,6 +123,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
   // transient batches: every copy is queued on `stream`; re-packed buffers stay alive until the one wait at the end
   std::vector<std::vector<uint8_t>> keep_bits;
   std::vector<std::vector<uint32_t>> keep_idx;
+  std::vector<std::vector<int64_t>> keep_i64;
   // via_ring: the whole arena is assembled in ONE piece of the pinned ring and shipped with one DMA
   unsigned char* ring = (ctx != nullptr && via_ring && total > 0) ? ctx->copy_reserve(total) : nullptr;
   auto h2d = [&](void* dst, const void* src, size_t bytes, const char* what) {
@@ -147,7 +148,13 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     } else {
       d.d_values = dst;
       if (p.bytes == 0) continue;
-      if (c.kind == ColKind::DICT && c.index_width != 4) {
+      if (c.kind == ColKind::BOOL) {  // Arrow booleans are bit-packed: the AND reducer reads them as int64 0 / 1
+        keep_i64.emplace_back((size_t)c.length);
+        std::vector<int64_t>& wide = keep_i64.back();
+        const uint8_t* bits = (const uint8_t*)c.values;
+        for (int64_t i = 0; i < c.length; i++) wide[(size_t)i] = (bits[(c.offset + i) >> 3] >> ((c.offset + i) & 7)) & 1;
+        h2d(dst, wide.data(), p.bytes, "hipMemcpy(bool values)");
+      } else if (c.kind == ColKind::DICT && c.index_width != 4) {
         keep_idx.emplace_back((size_t)c.length);
         std::vector<uint32_t>& wide = keep_idx.back();
         for (int64_t i = 0; i < c.length; i++) {
@@ -166,7 +173,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
   }
   for (const DevColumn& d : b->cols) b->payload_bytes += d.value_bytes + d.validity_bytes;
   if (ring != nullptr) ctx->copy_commit(b->arena, ring, total);
-  else if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty())) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
+  else if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty() || !keep_i64.empty())) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
   return b;
 }
 
@@ -210,17 +217,28 @@ Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
   filter_root_ = d->n_filter > 0 ? d->filter_root : -1;
   if (d->n_filter > 0 && (filter_root_ < 0 || filter_root_ >= d->n_filter)) throw Error(FDB_ERR_INVALID, "filter_root out of range");
   final_stage_ = d->final_stage != 0;
-  if (d->n_aggs > FDB_MAX_AGGS) throw Error(FDB_ERR_UNSUPPORTED, "too many aggregations");
   for (int32_t i = 0; i < d->n_aggs; i++) {
     AggState a;
     a.func = d->aggs[i].func;
     if (d->aggs[i].column == nullptr) throw Error(FDB_ERR_INVALID, "aggregation without a column");
     a.column = d->aggs[i].column;
-    if (a.func != FDB_AGG_SUM && a.func != FDB_AGG_MIN && a.func != FDB_AGG_MAX && a.func != FDB_AGG_COUNT)
-      throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported aggregation function: ") + agg_name(a.func));  // aggregate.go:98-100
     a.result_name = std::string(agg_name(a.func)) + "(" + a.column + ")";
-    aggs_.push_back(std::move(a));
+    if (a.func == FDB_AGG_UNIQUE) {  // two physical accumulators, see AggState::role
+      AggState lo = a, hi = a;
+      lo.func = FDB_AGG_MIN; lo.role = 1; lo.null_value = (unsigned long long)FDB_I64_MIN;
+      hi.func = FDB_AGG_MAX; hi.role = 2; hi.null_value = (unsigned long long)FDB_I64_MAX;
+      aggs_.push_back(std::move(lo));
+      aggs_.push_back(std::move(hi));
+    } else if (a.func == FDB_AGG_AND) {
+      a.func = FDB_AGG_MIN; a.role = 3; a.null_value = 1ull;
+      aggs_.push_back(std::move(a));
+    } else if (a.func == FDB_AGG_SUM || a.func == FDB_AGG_MIN || a.func == FDB_AGG_MAX || a.func == FDB_AGG_COUNT) {
+      aggs_.push_back(std::move(a));
+    } else {
+      throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported aggregation function: ") + agg_name(a.func));  // aggregate.go:98-100
+    }
   }
+  if (aggs_.size() > FDB_MAX_AGGS) throw Error(FDB_ERR_UNSUPPORTED, "too many aggregations");
   for (int32_t i = 0; i < d->n_groups; i++) {
     if (d->groups[i].name == nullptr) throw Error(FDB_ERR_INVALID, "group expression without a name");
     matchers_.push_back(GroupMatcher{d->groups[i].name, d->groups[i].dynamic != 0});
@@ -359,7 +377,7 @@ const char* Plan::draw() {
     if (!aggs_.empty()) {
       if (!s.empty()) s += " - ";
       s += "HashAggregate (";
-      for (size_t i = 0; i < aggs_.size(); i++) s += (i ? "," : "") + aggs_[i].result_name;
+      for (size_t i = 0, shown = 0; i < aggs_.size(); i++) if (aggs_[i].role != 2) s += (shown++ ? "," : "") + aggs_[i].result_name;
       s += " by ";
       for (size_t i = 0; i < matchers_.size(); i++) s += (i ? "," : "") + matchers_[i].name;
       s += ")";
@@ -825,6 +843,7 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
     K.type = FDB_T_NONE;
     K.slot = -1;
     K.expr = 0;
+    K.null_value = A.null_value;
     if (const Projection* P = find_projection(A.column)) {  // sum(value * timestamp): the aggregate reads a computed column
       if (A.func == FDB_AGG_COUNT) continue;  // arr.Len(): nothing is read
       const int root = resolve_projection(*P, b, &R);
@@ -840,6 +859,12 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
     const DevColumn& c = b.cols[(size_t)ci];
     if (A.func == FDB_AGG_COUNT && !final_stage_) continue;  // CountAggregation = arr.Len(): the column is not read (aggregate.go:937-950)
     int32_t t = c.kind == ColKind::I64 ? FDB_T_I64 : c.kind == ColKind::F64 ? FDB_T_F64 : FDB_T_NONE;
+    if (A.role == 1 || A.role == 2) {  // ErrUnsupportedIsUniqueType (aggregate.go:679)
+      if (c.kind != ColKind::I64) throw Error(FDB_ERR_UNSUPPORTED, "unsupported type for is unique aggregation, expected int64");
+    } else if (A.role == 3) {          // ErrUnsupportedAndType (aggregate.go:637); bool columns are staged as int64 0 / 1
+      if (c.kind != ColKind::BOOL) throw Error(FDB_ERR_UNSUPPORTED, "unsupported type for is and aggregation, expected bool");
+      t = FDB_T_I64;
+    }
     if (t == FDB_T_NONE)  // ErrUnsupportedSumType / MinType / MaxType (aggregate.go:736, :782, :862)
       throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported type for ") + agg_name(A.func) + " aggregation, expected int64 or float64");
     if (A.type == FDB_T_NONE) A.type = t;
@@ -1298,9 +1323,30 @@ void Plan::build_agg_columns(const CompactState& cs, std::vector<OutColumn>* col
   const int64_t n = cs.n;
   for (size_t j = 0; j < aggs_.size(); j++) {
     const AggState& A = aggs_[j];
+    if (A.role == 2) continue;  // the MAX half of UNIQUE: consumed with its MIN half
     OutColumn c;
     c.name = A.result_name;
     c.length = n;
+    if (A.role == 1) {  // UNIQUE: min == max ⇒ the value, else NULL (uniqueInt64arrays, aggregate.go:694-710)
+      c.format = "l";
+      c.values.assign((size_t)n * 8, 0);
+      c.validity.assign((size_t)(n + 7) / 8, 0);
+      for (int64_t i = 0; i < n; i++) {
+        const unsigned long long lo = cs.acc[j][(size_t)i], hi = cs.acc[j + 1][(size_t)i];
+        if (lo == hi) { std::memcpy(c.values.data() + (size_t)i * 8, &lo, 8); c.validity[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7)); }
+        else c.null_count++;
+      }
+      cols->push_back(std::move(c));
+      continue;
+    }
+    if (A.role == 3) {  // AND: a bool column (AndArrays, aggregate.go:654-675); no valid value ⇒ true
+      c.format = "b";
+      c.values.assign((size_t)(n + 7) / 8 + 8, 0);
+      for (int64_t i = 0; i < n; i++)
+        if (cs.acc[j][(size_t)i] != 0ull) c.values[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
+      cols->push_back(std::move(c));
+      continue;
+    }
     c.values.resize((size_t)n * 8);
     const bool count_from_cnt = A.func == FDB_AGG_COUNT && !final_stage_;
     const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
@@ -1368,7 +1414,17 @@ char Plan::agg_format(int32_t agg) const {
   return A.type == FDB_T_F64 ? 'g' : 'l';
 }
 
+int32_t Plan::state_array_op(int32_t array) const {
+  if (array < 0 || array > (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "table array index out of range");
+  if (array == 0) return 1;
+  const AggState& A = aggs_[(size_t)array - 1];
+  if (A.func == FDB_AGG_COUNT) return final_stage_ ? 1 : 0;
+  if (A.func == FDB_AGG_SUM) return A.type == FDB_T_F64 ? 2 : 1;
+  return A.func == FDB_AGG_MIN ? 3 : 4;
+}
+
 void Plan::partial_state(int32_t agg, void* dst, int64_t capacity_bytes) {
+  if (has_composite_aggs()) throw Error(FDB_ERR_UNSUPPORTED, "partial_state: not available for plans with UNIQUE / AND aggregations (merge them through the table arrays)");
   if (agg < 0 || agg >= (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "aggregation index out of range");
   CompactState cs;
   fetch_compact(&cs);

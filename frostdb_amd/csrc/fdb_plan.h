@@ -81,6 +81,12 @@ struct AggState {
   std::string result_name;        // "sum(value)" — AggregationFunction.Name() (logicalplan/expr.go:700-702)
   int32_t type = FDB_T_NONE;      // FDB_T_I64 / FDB_T_F64 once a batch has shown the column; COUNT keeps NONE
   unsigned long long* d_acc = nullptr;
+  // Composite reducers ride on MIN / MAX accumulators (aggs_ is the PHYSICAL list, one accumulator array each):
+  //   UNIQUE(x) (aggregate.go:677-732) = MIN(x) with NULL ↦ INT64_MIN  +  MAX(x) with NULL ↦ INT64_MAX: the group has one
+  //     non-NULL value iff min == max (a NULL row drives the two apart); role 1 = the MIN half (emits the column), 2 = the MAX half
+  //   AND(x)    (aggregate.go:635-675) = MIN over the bool column widened to 0 / 1 with NULL ↦ 1 (NULLs are skipped); role 3
+  int32_t role = 0;
+  unsigned long long null_value = 0;  // what a NULL row contributes (FdbAgg::null_value)
 };
 
 // One concrete group-by column, in first-seen order (≙ hashAggregate.colOrdering, aggregate.go:155).
@@ -153,6 +159,11 @@ class Plan {
   void state_read(int32_t array, void* dst, int64_t capacity_bytes);
   void state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) const;
   void state_write(int32_t array, const void* src, int64_t bytes);
+  // Reduction that merges table array `array` (0 = row counts, 1 + j = physical accumulator j) across plans / ranks:
+  // 0 none (unused array), 1 integer sum, 2 float64 sum, 3 integer min, 4 integer max.
+  int32_t state_array_op(int32_t array) const;
+  int32_t num_state_arrays() const { return (int32_t)(1 + aggs_.size()); }
+  bool has_composite_aggs() const { for (const AggState& a : aggs_) if (a.role != 0) return true; return false; }
 
   // Hash-table exchange (fdb_hash.cpp): merge of high-cardinality partial tables without a host round trip — between two plans
   // of one device (merge_from) and, hash-partitioned, between ranks (frostdb_amd/distributed.py: merge_plan_alltoall).

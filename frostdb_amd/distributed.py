@@ -152,20 +152,17 @@ def merge_plan_aligned(plan, group=None, dst: int = 0, device: Optional[torch.de
         return False, None
     base, stride, n_slots = plan.state_pointers()
     ext = torch.cuda.ExternalStream(plan.stream_ptr(), device=device)
+    ops = plan.state_array_ops()  # per PHYSICAL table array (UNIQUE owns a MIN and a MAX array, AND a MIN array)
     with torch.cuda.stream(ext):  # ordered after the scan and the fold kernel; Finish then waits for this stream
-        for a in range(1 + len(plan.aggs)):
+        for a, op in enumerate(ops):
+            if op == 0:
+                continue  # COUNT is served by the row-count array
             ptr = base + a * stride * 8
-            if a == 0:
-                dist.all_reduce(torch.as_tensor(_DeviceArray(ptr, n_slots, "<i8"), device=device), op=dist.ReduceOp.SUM, group=group)
-                continue
-            agg = plan.aggs[a - 1]
-            if agg.func == AGG_COUNT:
-                continue  # served by the count array
-            if agg.func == AGG_SUM and plan.agg_format(a - 1) == "g":
+            if op == 2:
                 dist.all_reduce(torch.as_tensor(_DeviceArray(ptr, n_slots, "<f8"), device=device), op=dist.ReduceOp.SUM, group=group)
             else:
-                op = dist.ReduceOp.MIN if agg.func == AGG_MIN else dist.ReduceOp.MAX if agg.func == AGG_MAX else dist.ReduceOp.SUM
-                dist.all_reduce(torch.as_tensor(_DeviceArray(ptr, n_slots, "<i8"), device=device), op=op, group=group)
+                red = dist.ReduceOp.MIN if op == 3 else dist.ReduceOp.MAX if op == 4 else dist.ReduceOp.SUM
+                dist.all_reduce(torch.as_tensor(_DeviceArray(ptr, n_slots, "<i8"), device=device), op=red, group=group)
     if dist.get_rank(group) != dst:
         ext.synchronize()  # the plan is about to be closed: its memory must outlive the collectives
         return True, None
@@ -180,6 +177,8 @@ def merge_plan(plan, group=None, dst: int = 0, device: Optional[torch.device] = 
     ok, rec = merge_plan_aligned(plan, group=group, dst=dst, device=device, probe=probe)
     if ok:
         return rec
+    if any(a.func not in (AGG_SUM, AGG_MIN, AGG_MAX, AGG_COUNT) for a in plan.aggs):
+        raise NotImplementedError("UNIQUE / AND aggregations merge through the table arrays only (aligned layouts or merge_plan_alltoall)")
     keys = plan.partial_keys()
     n = keys.num_rows
     if device is None:

@@ -84,6 +84,8 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_set_timing.argtypes = [vp, i32]
     L.fdb_plan_stream.argtypes = [vp, P(vp)]
     L.fdb_plan_set_tuning.argtypes = [vp, i32, i32]
+    L.fdb_plan_state_arrays.argtypes = [vp, P(i32)]
+    L.fdb_plan_state_array_op.argtypes = [vp, i32, P(i32)]
     L.fdb_plan_group_schema.argtypes = [vp, vp, vp]
     L.fdb_plan_seed_groups.argtypes = [vp, vp, vp]
     L.fdb_plan_hash_export.argtypes = [vp, vp, i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(i32)]
@@ -266,6 +268,17 @@ class HashAggregatePlan:
 
     def hash_import(self, dev_ptr: int, n_rows: int) -> None:
         self._check(lib().fdb_plan_hash_import(self.handle, ctypes.c_void_p(dev_ptr), n_rows))
+
+    def state_array_ops(self) -> List[int]:
+        """Merge operation of every table array (0 unused, 1 int sum, 2 float64 sum, 3 int min, 4 int max); array 0 = row counts."""
+        n = ctypes.c_int32()
+        self._check(lib().fdb_plan_state_arrays(self.handle, ctypes.byref(n)))
+        ops = []
+        for a in range(n.value):
+            op = ctypes.c_int32()
+            self._check(lib().fdb_plan_state_array_op(self.handle, a, ctypes.byref(op)))
+            ops.append(op.value)
+        return ops
 
     def agg_format(self, agg: int) -> str:
         c = ctypes.create_string_buffer(2)

@@ -70,8 +70,8 @@ typedef enum fdb_agg_func {
   FDB_AGG_MAX = 3,
   FDB_AGG_COUNT = 4,
   FDB_AGG_AVG = 5,    /* never reaches the operator: lowered to SUM+COUNT+Projection (logicalplan/builder.go:205-238) */
-  FDB_AGG_UNIQUE = 6,
-  FDB_AGG_AND = 7
+  FDB_AGG_UNIQUE = 6, /* int64 only: the group's value if all its rows carry the same non-NULL value, else NULL (aggregate.go:677-732) */
+  FDB_AGG_AND = 7     /* bool only: AND over the valid values, true if there is none (aggregate.go:635-675) */
 } fdb_agg_func;
 
 /* scalar.Scalar of a LiteralExpr (the right-hand side of a filter leaf, filter.go:95-103). */
@@ -236,6 +236,10 @@ int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slo
 int fdb_plan_state_pointers(fdb_plan* plan, void** base, int64_t* array_stride, int64_t* n_slots);
 int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes);
 int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t bytes);
+/* How table array `array` merges across plans / ranks (0 = the row counts, 1 + j = PHYSICAL accumulator j — UNIQUE owns two,
+ * see DESIGN.md §3): 0 unused, 1 integer sum, 2 float64 sum, 3 integer min, 4 integer max. *n_arrays = 1 + accumulators. */
+int fdb_plan_state_arrays(fdb_plan* plan, int32_t* n_arrays);
+int fdb_plan_state_array_op(fdb_plan* plan, int32_t array, int32_t* op);
 /* 'l' (int64) or 'g' (float64): the Arrow format of aggregation `agg`'s output column; 0 until the first push. */
 int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out);
 

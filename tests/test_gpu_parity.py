@@ -1055,3 +1055,59 @@ def test_mixed_shape_parts_in_one_scan(pp):
     finally:
         plan.Close()
     assert_same_result(got, want, ["labels.path"] + [a.Name() for a in CFG3["aggs"]], float_cols={"sum(value)"})
+
+
+# ---- UniqueAggregation / AndAggregation (aggregate.go:635-732) ------------------------------------------
+
+def test_golden_unique_and_and_aggregations(pp, variant):
+    """query/engine_test.go TestUniqueAggregation (:19-74) and TestAndAggregation (:76-131), one chain and two chains merged."""
+    from tests.test_oracle_golden import unique_and_cases
+    for case in unique_and_cases():
+        rec = case["rec"]
+        d = run_gpu(pp, [rec], None, [case["agg"]], [Col("timestamp")])
+        assert dict(zip(d["timestamp"], d[case["out"]])) == case["expected"], case["cite"]
+        p1 = pp.HashAggregatePlan(None, [case["agg"]], [Col("timestamp")])
+        p2 = pp.HashAggregatePlan(None, [case["agg"]], [Col("timestamp")])
+        try:
+            p1.Callback(rec.slice(0, 1)); p2.Callback(rec.slice(1))
+            p1.Merge(p2)
+            d = arrow_to_pydict(p1.Finish())
+        finally:
+            p1.Close(); p2.Close()
+        assert dict(zip(d["timestamp"], d[case["out"]])) == case["expected"], case["cite"]
+
+
+def test_unique_and_and_vs_oracle_at_scale(pp, variant):
+    """UNIQUE over int64 with NULLs (groups with one value, several values, a NULL among equal values) and AND over a nullable bool
+    column, next to ordinary aggregates, dense table (label keys) and hash table (int64 key), against the oracle; plus the
+    reference's type errors."""
+    from frostdb_amd.logicalplan import AndAgg, Unique
+    rng = np.random.default_rng(1919)
+    n = 60_000
+    lab = rng.integers(0, 40, size=n)
+    recs = []
+    for lo in (0, n // 2):
+        sl = slice(lo, lo + n // 2)
+        labs = lab[sl]
+        u = np.where(labs % 3 == 0, labs * 7, rng.integers(0, 3, size=n // 2) + labs)  # a third of the groups have ONE value
+        umask = (rng.random(n // 2) < 0.02) & (labs % 5 == 0)                                # … some of those also see a NULL
+        flag = (labs % 2 == 0) | (rng.random(n // 2) < 0.7)
+        recs.append(pa.RecordBatch.from_arrays(
+            [pa.DictionaryArray.from_arrays(pa.array(labs.astype(np.uint32)), pa.array([b"g%02d" % i for i in range(40)], type=pa.binary())),
+             pa.array((labs * 10).astype(np.int64)), pa.array(u.astype(np.int64), mask=umask), pa.array(flag, mask=rng.random(n // 2) < 0.1),
+             pa.array(rng.integers(0, 100, size=n // 2).astype(np.int64))],
+            names=["labels.g", "bucket", "u", "flag", "value"]))
+    aggs = [Unique(Col("u")), AndAgg(Col("flag")), Sum(Col("value")), Count(Col("value")), Unique(Col("bucket"))]
+    for groups in ([Col("labels.g")], [Col("bucket")]):
+        want = run_oracle(recs, Col("value") >= 5, aggs, groups)
+        got = run_gpu(pp, recs, Col("value") >= 5, aggs, groups)
+        assert_same_result(got, want, [g.name for g in groups] + [a.Name() for a in aggs])
+        assert any(v is None for v in got["unique(u)"]) and any(v is not None for v in got["unique(u)"])
+        assert any(v is False for v in got["and(flag)"]) and any(v is True for v in got["and(flag)"])
+    for bad in (Unique(Col("flag")), AndAgg(Col("value"))):
+        plan = pp.HashAggregatePlan(None, [bad], [Col("labels.g")])
+        try:
+            with pytest.raises(pp.UnsupportedError):
+                plan.Callback(recs[0])
+        finally:
+            plan.Close()
