@@ -7,7 +7,7 @@ import numpy as np
 import pyarrow as pa
 import pytest
 
-from frostdb_amd.logicalplan import And, Col, Count, DynCol, Max, Min, Or, Sum
+from frostdb_amd.logicalplan import And, AndAgg, Col, Count, DynCol, Max, Min, Or, Sum, Unique
 from tests.util import arrow_to_pydict, batch_rows, sort_key
 
 pytestmark = pytest.mark.gpu
@@ -39,6 +39,7 @@ def random_batch(rng, n, drop=()):
         "ival": pa.array(rng.integers(-20, 20, size=n).astype(np.int64), mask=rng.random(n) < 0.1),
         "fval": pa.array(rng.uniform(-5, 5, size=n), mask=rng.random(n) < 0.1),
         "small": pa.array(rng.integers(0, 4, size=n).astype(np.int64)),
+        "flag": pa.array(rng.random(n) < 0.9, mask=rng.random(n) < 0.15),
     }
     for d in drop:
         cols.pop(d, None)
@@ -79,7 +80,7 @@ def random_plan(rng):
     filt = random_filter(rng) if rng.random() < 0.8 else None
     I, F, T = Col("ival"), Col("fval"), Col("ts")
     agg_pool = [Sum(I), Min(I), Max(I), Count(I), Sum(F), Min(F), Max(F), Count(F), Sum(T), Max(T),
-                Sum(I * T), Min(I - T), Max(T / Col("small")), Sum(F * 2.0), Min(F / F)]
+                Sum(I * T), Min(I - T), Max(T / Col("small")), Sum(F * 2.0), Min(F / F), Unique(Col("small")), Unique(I), AndAgg(Col("flag"))]
     n_aggs = int(rng.integers(0, 6))
     aggs = [agg_pool[i] for i in rng.choice(len(agg_pool), size=n_aggs, replace=False)]
     group_pool = [[], [Col("labels.a")], [Col("labels.d")], [Col("labels.a"), Col("labels.d")], [Col("labels.b"), Col("labels.a")],
