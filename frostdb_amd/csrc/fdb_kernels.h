@@ -69,7 +69,7 @@ struct FdbGroupCol {
   int32_t slot;             // c4 slot
 };
 
-enum FdbAggType : int32_t { FDB_T_NONE = 0, FDB_T_I64 = 1, FDB_T_F64 = 2 };
+enum FdbAggType : int32_t { FDB_T_NONE = 0, FDB_T_I64 = 1, FDB_T_F64 = 2, FDB_T_BOOL = 3 /* expression nodes only: a comparison's 0 / 1 */ };
 
 struct FdbAgg {
   const void* values;       // nullptr for COUNT (row count only) and for computed inputs
@@ -90,8 +90,8 @@ struct FdbAgg {
 #define FDB_MAX_EXPR_NODES 40
 struct FdbExprNode {
   int64_t lit;              // literal: int64 value / float64 bits
-  int32_t kind;             // 0 column, 1 literal, 2 binary
-  int32_t op;               // binary: fdb_op (ADD 11, SUB 12, MUL 13, DIV 14)
+  int32_t kind;             // 0 column, 1 literal, 2 binary arithmetic, 3 comparison (boolExprProjection: NULL operand ⇒ false)
+  int32_t op;               // binary: fdb_op (ADD 11, SUB 12, MUL 13, DIV 14); comparison: EQ 1 … GT_EQ 6
   int32_t left, right;      // binary: child node indices
   int32_t slot;             // column: 8-byte slot in the pool the aggregates use (dense single-phase: c8, two-phase: l8; hash scan: l8)
   int32_t type;             // FdbAggType of the node's value

@@ -406,13 +406,18 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
             l = flatten(e.left, nodes)
             r = flatten(e.right, nodes)
             nodes.append(CProjNode(kind=2, op=e.op, left=l, right=r, column=None))
+        elif isinstance(e, BinaryExpr) and OP_EQ <= e.op <= OP_GT_EQ:  # boolean projection: `value > 0` as a distinct / group key
+            l = flatten(e.left, nodes)
+            r = flatten(e.right, nodes)
+            nodes.append(CProjNode(kind=3, op=e.op, left=l, right=r, column=None))
         else:
             raise TypeError(f"unsupported expression in projection: {e}")
         return len(nodes) - 1
 
     for e in [a.expr for a in aggs] + list(groups):
         inner = e.expr if isinstance(e, AliasExpr) else e
-        if not (isinstance(inner, BinaryExpr) and inner.op in _ARITH) or e.name in seen:
+        computed = isinstance(inner, BinaryExpr) and (inner.op in _ARITH or OP_EQ <= inner.op <= OP_GT_EQ)
+        if not computed or e.name in seen:
             continue
         seen.add(e.name)
         nodes: List[CProjNode] = []

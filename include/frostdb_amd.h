@@ -136,8 +136,9 @@ typedef struct fdb_group_expr {
  * zero, MinInt64 / -1 wraps). Only the outermost operation's validity survives: a NULL produced by an inner division is
  * read back as its raw slot (0) by the enclosing + - *. */
 typedef struct fdb_proj_node {
-  int32_t kind;        /* 0 column, 1 literal, 2 binary */
-  int32_t op;          /* binary: FDB_OP_ADD / SUB / MUL / DIV */
+  int32_t kind;        /* 0 column, 1 literal, 2 binary arithmetic, 3 comparison → bool (boolExprProjection, project.go:401-470:
+                          `distinct(labels.label1, value > 0)`; a NULL operand compares false; usable as a group / distinct key) */
+  int32_t op;          /* binary: FDB_OP_ADD / SUB / MUL / DIV; comparison: FDB_OP_EQ … FDB_OP_GT_EQ */
   int32_t left;        /* binary: child indices into the projection's node array */
   int32_t right;
   const char* column;  /* column: exact name (ArrayRef.ColumnName) */

@@ -437,6 +437,19 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
   }
   Col a, b;
   if (!project_node(pd, n.left, r, &a, err) || !project_node(pd, n.right, r, &b, err)) return false;
+  if (n.kind == 3) {
+    // boolExprProjection.Project (project.go:409-470): the comparison is evaluated like a filter leaf (binaryscalarexpr.go:119-152:
+    // a NULL never matches) and EVERY row gets a valid bool — bitmap.Contains(i)
+    out->type = T_BOOL; out->len = rows; out->valid.assign((size_t)rows, 1); out->i64.assign((size_t)rows, 0);
+    for (int64_t i = 0; i < rows; i++) {
+      if (!a.valid[(size_t)i] || !b.valid[(size_t)i]) continue;
+      bool m;
+      if (a.type == T_I64 && b.type == T_I64) m = cmp_op<int64_t>(n.op, a.i64[(size_t)i], b.i64[(size_t)i]);
+      else m = cmp_op<double>(n.op, a.type == T_I64 ? (double)a.i64[(size_t)i] : a.f64[(size_t)i], b.type == T_I64 ? (double)b.i64[(size_t)i] : b.f64[(size_t)i]);
+      out->i64[(size_t)i] = m ? 1 : 0;
+    }
+    return true;
+  }
   if (a.type != b.type) { *err = {FDB_ERR_INVALID, "arithmetic projection: operand types differ (the reference's type assertion panics)"}; return false; }
   out->type = a.type;
   out->len = rows;

@@ -309,3 +309,36 @@ DISTINCT_CASES = [
     dict(id="with_filter", cite=f"{DISTINCT_FILE}:75-78", filter=And(L(2) == "value1", L(4) == "value4"), groups=[L(1)], out=["labels.label1"],
          expected=[_b("value3")]),
 ]
+
+
+# ---- Distinct over boolean projections (distinct_proj, distinct_partial_scan_opt): `select distinct(l1, l2, value > 0)` ----------
+DPROJ_FILE = "logictest/testdata/exec/distinct/distinct_proj"
+DPART_FILE = "logictest/testdata/exec/distinct/distinct_partial_scan_opt"
+DPROJ_INSERT_1 = """
+        value1  value2  1   0
+        value1  value2  2   0
+        """
+DPROJ_INSERT_2 = """
+        value2  value2  1   1
+        value2  value2  2   2
+        """
+DPROJ_COLS = ["labels.label1", "labels.label2", "timestamp", "value"]
+DISTINCT_PROJ_CASES = [
+    dict(id="always_true", cite=f"{DPROJ_FILE}:9-13", table=dict(cols=DPROJ_COLS, inserts=[DPROJ_INSERT_1]),
+         groups=[L(1), L(2), TS > 0], out=["labels.label1", "labels.label2", "timestamp > 0"], expected=[(b"value1", b"value2", True)]),
+    dict(id="always_false", cite=f"{DPROJ_FILE}:15-19", table=dict(cols=DPROJ_COLS, inserts=[DPROJ_INSERT_1]),
+         groups=[L(1), L(2), Col("value") > 0], out=["labels.label1", "labels.label2", "value > 0"], expected=[(b"value1", b"value2", False)]),
+    dict(id="mixed", cite=f"{DPROJ_FILE}:21-32", table=dict(cols=DPROJ_COLS, inserts=[DPROJ_INSERT_1, DPROJ_INSERT_2]),
+         groups=[L(1), L(2), Col("value") > 0], out=["labels.label1", "labels.label2", "value > 0"],
+         expected=[(b"value1", b"value2", False), (b"value2", b"value2", True)]),
+    dict(id="partial_scan_opt", cite=f"{DPART_FILE}:5-25",
+         table=dict(cols=["labels.label1", "timestamp", "value"], inserts=["""
+        value1  0   1
+        value2  1   1
+        """, """
+        value2  1   1
+        value2  1   1
+        """]),
+         groups=[L(1), TS, Col("value") > 0], out=["labels.label1", "timestamp", "value > 0"],
+         expected=[(b"value1", 0, True), (b"value2", 1, True)]),
+]
