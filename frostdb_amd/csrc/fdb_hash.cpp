@@ -343,8 +343,8 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     OutColumn oc;
     oc.name = g.name;
     oc.length = (int64_t)n;
-    oc.format = g.kind == 0 ? "I" : "l";
-    if (n > 0) { oc.backing = backing; oc.ext_values = h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }
+    oc.format = g.kind == 0 ? "I" : g.is_bool ? "b" : "l";
+    if (n > 0 && !g.is_bool) { oc.backing = backing; oc.ext_values = h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }
     if (g.kind == 0) {
       oc.is_dict = true;
       oc.dict_format = g.value_format;
@@ -379,6 +379,13 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   // post-processing that needs the data on the host: NULL counts, float64 MIN/MAX key decoding
   for (size_t c = 0; c < n_cols && n > 0; c++) {
     OutColumn& oc = (*out)[c];
+    if (gcols_[c].is_bool) {  // boolean projection key: 8-byte 0 / 1 on the device → Arrow's bit-packed bool, never NULL
+      const unsigned long long* v = (const unsigned long long*)(h_block + off_key[c]);
+      oc.values.assign((size_t)(n + 7) / 8 + 8, 0);
+      for (uint64_t i = 0; i < n; i++) if (v[i] != 0ull) oc.values[i >> 3] |= (uint8_t)(1u << (i & 7));
+      oc.null_count = 0;
+      continue;
+    }
     const size_t bytes = (size_t)(n + 7) / 8;
     int64_t set = 0;
     const uint64_t* w64 = (const uint64_t*)oc.ext_validity;
@@ -440,7 +447,7 @@ void Plan::group_schema(ArrowArray* out, ArrowSchema* out_schema) {
       }
       oc.dict_offsets[g.values.size()] = off;
     } else {
-      oc.format = "l";
+      oc.format = g.is_bool ? "b" : "l";
     }
     cols.push_back(std::move(oc));
   }
@@ -471,17 +478,18 @@ void Plan::seed_groups(const ArrowArray* array, const ArrowSchema* schema) {
       is_agg = true;
     }
     if (is_agg) continue;
-    if (c.kind != ColKind::DICT && c.kind != ColKind::I64) throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + ": only dictionary and int64 columns can be group keys");
+    if (c.kind != ColKind::DICT && c.kind != ColKind::I64 && c.kind != ColKind::BOOL)
+      throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + ": only dictionary, int64 and computed bool columns can be group keys");
     const int kind = c.kind == ColKind::DICT ? 0 : 1;
     size_t gi = 0;
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == c.name) break;
     if (gi == gcols_.size()) {
       GroupColState g;
-      g.name = c.name; g.kind = kind; g.cap = 1; g.stride = 0;
+      g.name = c.name; g.kind = kind; g.is_bool = c.kind == ColKind::BOOL; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
     GroupColState& g = gcols_[gi];
-    if (g.kind != kind) throw Error(FDB_ERR_INVALID, "group column " + c.name + " has a different type in this plan");
+    if (g.kind != kind || g.is_bool != (c.kind == ColKind::BOOL)) throw Error(FDB_ERR_INVALID, "group column " + c.name + " has a different type in this plan");
     if (kind == 0) {
       std::shared_ptr<HostDict> d = read_dictionary(c);
       g.value_format = d->value_format;
@@ -512,7 +520,7 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
     for (; gi < layout.gcols_.size(); gi++) if (layout.gcols_[gi].name == sg.name) break;
     if (gi == layout.gcols_.size()) {
       GroupColState g;
-      g.name = sg.name; g.kind = sg.kind; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
       layout.gcols_.push_back(std::move(g));
     }
     GroupColState& g = layout.gcols_[gi];
@@ -631,7 +639,7 @@ void Plan::merge_hash(Plan& src) {
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == sg.name) break;
     if (gi == gcols_.size()) {
       GroupColState g;
-      g.name = sg.name; g.kind = sg.kind; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
     GroupColState& g = gcols_[gi];

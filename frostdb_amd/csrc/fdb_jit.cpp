@@ -117,13 +117,23 @@ bool compile(const std::string& src, std::vector<char>* code, std::string* log) 
 // ---- code generation ---------------------------------------------------------------------------------------------------
 // C expression of node `ni` (typed: long long or double); `col(node)` gives the unsigned 64-bit raw value of a column node,
 // literals are the run-time variables K_elit<i>.
-template <typename F>
-std::string expr_value(const std::vector<JitExprNode>& ex, int ni, F col) {
+template <typename F, typename V>
+std::string expr_valid(const std::vector<JitExprNode>& ex, int root, F col, V colvalid);
+template <typename F, typename V>
+std::string expr_value(const std::vector<JitExprNode>& ex, int ni, F col, V colvalid) {
   const JitExprNode& n = ex[(size_t)ni];
   const bool f = n.type == FDB_T_F64;
   if (n.kind == 0) return f ? ("__longlong_as_double((long long)" + col(ni) + ")") : ("(long long)" + col(ni));
   if (n.kind == 1) return f ? ("__longlong_as_double(K_elit" + std::to_string(ni) + ")") : ("K_elit" + std::to_string(ni));
-  const std::string a = expr_value(ex, n.left, col), b = expr_value(ex, n.right, col);
+  std::string a = expr_value(ex, n.left, col, colvalid), b = expr_value(ex, n.right, col, colvalid);
+  if (n.kind == 3) {
+    // comparison → 0 / 1, never NULL: a NULL operand compares false like in a filter leaf (project.go:409-470); mixed
+    // int64 / float64 operands compare as doubles
+    if (n.op == FDB_OP_AND || n.op == FDB_OP_OR) return "((" + a + (n.op == FDB_OP_AND ? " & " : " | ") + b + ") & 1ll)";
+    if (ex[(size_t)n.left].type != ex[(size_t)n.right].type) { a = "(double)" + a; b = "(double)" + b; }
+    const char* op = n.op == FDB_OP_EQ ? " == " : n.op == FDB_OP_NOT_EQ ? " != " : n.op == FDB_OP_LT ? " < " : n.op == FDB_OP_LT_EQ ? " <= " : n.op == FDB_OP_GT ? " > " : " >= ";
+    return "((" + expr_valid(ex, n.left, col, colvalid) + " && " + expr_valid(ex, n.right, col, colvalid) + " && (" + a + op + b + ")) ? 1ll : 0ll)";
+  }
   if (f) {
     if (n.op == FDB_OP_DIV) return "f64_div(" + a + ", " + b + ")";
     return "(" + a + (n.op == FDB_OP_ADD ? " + " : n.op == FDB_OP_SUB ? " - " : " * ") + b + ")";
@@ -136,7 +146,7 @@ std::string expr_valid(const std::vector<JitExprNode>& ex, int root, F col, V co
   const JitExprNode& n = ex[(size_t)root];
   if (n.kind == 0) return colvalid(root);
   if (n.kind == 2 && n.op == FDB_OP_DIV) {
-    const std::string d = expr_value(ex, n.right, col);
+    const std::string d = expr_value(ex, n.right, col, colvalid);
     return n.type == FDB_T_F64 ? ("(" + d + " != 0.0)") : ("(" + d + " != 0)");
   }
   return "true";
@@ -333,7 +343,7 @@ struct Gen {
         if (A.expr != 0) {
           auto col = [&](int ni) { return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
           auto colvalid = [&](int ni) { return "((" + reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
-          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col)) + " : 0ull)";
+          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
         } else {
           const std::string r = reg(true, s.two_phase, A.slot);
           raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : c.aggs[" + std::to_string(j) + "].null_value)";
@@ -383,7 +393,7 @@ struct Gen {
         if (A.expr != 0) {  // computed input: the expression over this row's raw column values; a NULL (÷ 0) adds the zero slot
           auto col = [&](int ni) { return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
           auto colvalid = [&](int ni) { return "((" + reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
-          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col)) + " : 0ull)";
+          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
         } else {
           const std::string r = reg(true, s.two_phase, A.slot);
           raw = "((" + r + "_m >> " + std::to_string(k) + ") & 1u ? " + r + comp + " : c.aggs[" + std::to_string(j) + "].null_value)";
@@ -524,7 +534,7 @@ struct HashGen {
             return "(" + b + " == nullptr || ((as_global(" + b + ")[row >> 3] >> vsh) & 1u))";
           };
           o << "    const bool ok" << c << " = " << expr_valid(s.exprs, s.cols[c].expr_root, col, colvalid) << ";\n";
-          o << "    const unsigned long long x" << c << " = " << expr_bits(s.exprs, s.cols[c].expr_root, expr_value(s.exprs, s.cols[c].expr_root, col)) << ";\n";
+          o << "    const unsigned long long x" << c << " = " << expr_bits(s.exprs, s.cols[c].expr_root, expr_value(s.exprs, s.cols[c].expr_root, col, colvalid)) << ";\n";
         }
         if (s.cols[c].has_validity) o << "    const uint32_t v" << c << " = as_global(hc[" << c << "].validity)[row >> 3];\n";
       }
@@ -648,7 +658,7 @@ struct HashGen {
           for (int k = 0; k < 4; k++) {
             auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
             auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
-            o << "        if (" << expr_valid(s.exprs, C.expr_root, col, colvalid) << ") { const unsigned long long y = " << expr_bits(s.exprs, C.expr_root, expr_value(s.exprs, C.expr_root, col))
+            o << "        if (" << expr_valid(s.exprs, C.expr_root, col, colvalid) << ") { const unsigned long long y = " << expr_bits(s.exprs, C.expr_root, expr_value(s.exprs, C.expr_root, col, colvalid))
               << "; if (y != 0ull) fp_add(h1_" << k << ", h2_" << k << ", K1, K2, y); vm_" << k << " |= bit; }\n";
           }
         }
@@ -684,7 +694,7 @@ struct HashGen {
         if (A.expr != 0) {
           auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
           auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
-          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col)) + " : 0ull)";
+          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
         }
         const std::string acc = "(e + " + std::to_string(3 + j) + ")";
         if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      atomicAdd(reinterpret_cast<double*>" << acc << ", __longlong_as_double((long long)" << raw << "));\n";

@@ -260,8 +260,9 @@ Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
       } else if (fn.kind == 1) {
         if (fn.literal.type != FDB_LIT_INT64 && fn.literal.type != FDB_LIT_FLOAT64) throw Error(FDB_ERR_UNSUPPORTED, "projection literals must be int64 or float64");
         n.lit_type = fn.literal.type; n.i64 = fn.literal.i64; n.f64 = fn.literal.f64;
-      } else if (fn.kind == 2) {
-        if (fn.op < FDB_OP_ADD || fn.op > FDB_OP_DIV) throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary expression in projection");  // project.go:122-123
+      } else if (fn.kind == 2 || fn.kind == 3) {
+        if (fn.kind == 2 && (fn.op < FDB_OP_ADD || fn.op > FDB_OP_DIV)) throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary expression in projection");  // project.go:122-123
+        if (fn.kind == 3 && (fn.op < FDB_OP_EQ || fn.op > FDB_OP_GT_EQ) && fn.op != FDB_OP_AND && fn.op != FDB_OP_OR) throw Error(FDB_ERR_UNSUPPORTED, "unsupported comparison in projection");
         if (fn.left < 0 || fn.left >= k || fn.right < 0 || fn.right >= k) throw Error(FDB_ERR_INVALID, "projection nodes must be in post-order");
       } else {
         throw Error(FDB_ERR_INVALID, "unknown projection node kind");
@@ -320,9 +321,17 @@ int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved
     } else if (n.kind == 1) {
       e.type = n.lit_type == FDB_LIT_INT64 ? FDB_T_I64 : FDB_T_F64;
       if (e.type == FDB_T_I64) e.lit = n.i64; else std::memcpy(&e.lit, &n.f64, 8);
+    } else if (n.kind == 3) {  // comparison → bool; int64 / float64 operands may mix like in a filter leaf (compared as doubles)
+      e.left = base + n.left; e.right = base + n.right;
+      const bool logical = n.op == FDB_OP_AND || n.op == FDB_OP_OR;
+      if (logical && (a.expr[e.left].type != FDB_T_BOOL || a.expr[e.right].type != FDB_T_BOOL))
+        throw Error(FDB_ERR_INVALID, "projection " + p.name + ": AND / OR need boolean operands");
+      if (!logical && (a.expr[e.left].type == FDB_T_BOOL || a.expr[e.right].type == FDB_T_BOOL))
+        throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": comparison of boolean values");
+      e.type = FDB_T_BOOL;
     } else {
       e.left = base + n.left; e.right = base + n.right;
-      if (a.expr[e.left].type != a.expr[e.right].type)
+      if (a.expr[e.left].type != a.expr[e.right].type || a.expr[e.left].type == FDB_T_BOOL)
         throw Error(FDB_ERR_INVALID, "projection " + p.name + ": operand types differ (int64 vs float64)");
       e.type = a.expr[e.left].type;
     }
@@ -813,17 +822,18 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
     const Projection* P = find_projection(m.name);
     if (P == nullptr) continue;
     const int root = resolve_projection(*P, b, &R);
-    if (a.expr[root].type != FDB_T_I64)  // HashArray panics on float64 (dynparquet/hashed.go:102-103)
+    if (a.expr[root].type != FDB_T_I64 && a.expr[root].type != FDB_T_BOOL)  // HashArray panics on float64 (dynparquet/hashed.go:102-103)
       throw Error(FDB_ERR_UNSUPPORTED, "group by on a float64 expression (" + m.name + ") is not supported");
+    const bool is_bool = a.expr[root].type == FDB_T_BOOL;
     size_t gi = 0;
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == m.name) break;
     if (gi == gcols_.size()) {
       if (gcols_.size() >= FDB_MAX_HASH_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "more than 64 group-by columns");
       GroupColState g;
-      g.name = m.name; g.kind = 1; g.cap = 1; g.stride = 0;
+      g.name = m.name; g.kind = 1; g.is_bool = is_bool; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
-    if (gcols_[gi].kind != 1) throw Error(FDB_ERR_UNSUPPORTED, "group column " + m.name + " changed type between batches");
+    if (gcols_[gi].kind != 1 || gcols_[gi].is_bool != is_bool) throw Error(FDB_ERR_UNSUPPORTED, "group column " + m.name + " changed type between batches");
     GroupRes gr;
     gr.gi = (int)gi; gr.ci = -1; gr.kind = 2; gr.expr_root = root;
     R.groups.push_back(std::move(gr));
@@ -848,6 +858,7 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
       if (A.func == FDB_AGG_COUNT) continue;  // arr.Len(): nothing is read
       const int root = resolve_projection(*P, b, &R);
       const int32_t t = a.expr[root].type;
+      if (t == FDB_T_BOOL) throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported type for ") + agg_name(A.func) + " aggregation, expected int64 or float64");
       if (A.type == FDB_T_NONE) A.type = t;
       else if (A.type != t) throw Error(FDB_ERR_UNSUPPORTED, "aggregated column " + A.column + " changed type between batches");
       K.type = t;
@@ -1286,6 +1297,15 @@ void Plan::build_key_columns(const CompactState& cs, std::vector<OutColumn>* col
     c.name = g.name;
     c.length = n;
     c.validity.assign((size_t)(n + 7) / 8, 0);
+    if (g.kind == 1 && g.is_bool) {  // boolean projection: always valid (project.go:409-470), bit-packed values
+      c.format = "b";
+      c.validity.clear();
+      c.values.assign((size_t)(n + 7) / 8 + 8, 0);
+      for (int64_t i = 0; i < n; i++)
+        if (cs.ivalid[gc][(size_t)i] && cs.ivals[gc][(size_t)i] != 0) c.values[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+      cols->push_back(std::move(c));
+      continue;
+    }
     if (g.kind == 1) {  // int64 key column
       c.format = "l";
       c.values.resize((size_t)n * 8);

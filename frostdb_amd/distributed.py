@@ -233,7 +233,7 @@ def unify_group_schemas(objs: Sequence[Sequence[tuple]]) -> pa.RecordBatch:
             vt = pa.string() if ty in ("string", "utf8") else pa.binary()
             arrays.append(pa.DictionaryArray.from_arrays(pa.array([], type=pa.uint32()), pa.array(values, type=vt)))
         else:
-            arrays.append(pa.array([], type=pa.float64() if ty == "double" else pa.int64()))
+            arrays.append(pa.array([], type=pa.float64() if ty == "double" else pa.bool_() if ty == "bool" else pa.int64()))
         names.append(name)
     return pa.RecordBatch.from_arrays(arrays, names=names)
 

@@ -406,7 +406,7 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
             l = flatten(e.left, nodes)
             r = flatten(e.right, nodes)
             nodes.append(CProjNode(kind=2, op=e.op, left=l, right=r, column=None))
-        elif isinstance(e, BinaryExpr) and OP_EQ <= e.op <= OP_GT_EQ:  # boolean projection: `value > 0` as a distinct / group key
+        elif isinstance(e, BinaryExpr) and (OP_EQ <= e.op <= OP_GT_EQ or e.op in (OP_AND, OP_OR)):  # boolean projection: `value > 0` as a distinct / group key
             l = flatten(e.left, nodes)
             r = flatten(e.right, nodes)
             nodes.append(CProjNode(kind=3, op=e.op, left=l, right=r, column=None))
@@ -416,7 +416,7 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
 
     for e in [a.expr for a in aggs] + list(groups):
         inner = e.expr if isinstance(e, AliasExpr) else e
-        computed = isinstance(inner, BinaryExpr) and (inner.op in _ARITH or OP_EQ <= inner.op <= OP_GT_EQ)
+        computed = isinstance(inner, BinaryExpr) and (inner.op in _ARITH or OP_EQ <= inner.op <= OP_GT_EQ or inner.op in (OP_AND, OP_OR))
         if not computed or e.name in seen:
             continue
         seen.add(e.name)

@@ -138,7 +138,8 @@ typedef struct fdb_group_expr {
 typedef struct fdb_proj_node {
   int32_t kind;        /* 0 column, 1 literal, 2 binary arithmetic, 3 comparison → bool (boolExprProjection, project.go:401-470:
                           `distinct(labels.label1, value > 0)`; a NULL operand compares false; usable as a group / distinct key) */
-  int32_t op;          /* binary: FDB_OP_ADD / SUB / MUL / DIV; comparison: FDB_OP_EQ … FDB_OP_GT_EQ */
+  int32_t op;          /* binary: FDB_OP_ADD / SUB / MUL / DIV; comparison: FDB_OP_EQ … FDB_OP_GT_EQ over numeric children,
+                          or FDB_OP_AND / FDB_OP_OR over two comparison nodes (AndExpr / OrExpr, filter.go:172-220) */
   int32_t left;        /* binary: child indices into the projection's node array */
   int32_t right;
   const char* column;  /* column: exact name (ArrayRef.ColumnName) */

@@ -441,6 +441,12 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
     // boolExprProjection.Project (project.go:409-470): the comparison is evaluated like a filter leaf (binaryscalarexpr.go:119-152:
     // a NULL never matches) and EVERY row gets a valid bool — bitmap.Contains(i)
     out->type = T_BOOL; out->len = rows; out->valid.assign((size_t)rows, 1); out->i64.assign((size_t)rows, 0);
+    if (n.op == FDB_OP_AND || n.op == FDB_OP_OR) {  // AndExpr / OrExpr over two bitmaps (filter.go:172-220)
+      if (a.type != T_BOOL || b.type != T_BOOL) { *err = {FDB_ERR_INVALID, "boolean projection: AND / OR need boolean operands"}; return false; }
+      for (int64_t i = 0; i < rows; i++) out->i64[(size_t)i] = n.op == FDB_OP_AND ? (a.i64[(size_t)i] & b.i64[(size_t)i]) : (a.i64[(size_t)i] | b.i64[(size_t)i]);
+      return true;
+    }
+    if (a.type == T_BOOL || b.type == T_BOOL) { *err = {FDB_ERR_UNSUPPORTED, "boolean projection: comparison of boolean values"}; return false; }
     for (int64_t i = 0; i < rows; i++) {
       if (!a.valid[(size_t)i] || !b.valid[(size_t)i]) continue;
       bool m;

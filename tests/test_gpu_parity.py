@@ -10,7 +10,7 @@ import pyarrow as pa
 import pyarrow.compute as pc
 import pytest
 
-from frostdb_amd.logicalplan import And, Col, Count, DynCol, Max, Min, Or, Sum, UInt64
+from frostdb_amd.logicalplan import OP_LT_EQ, OP_NOT_EQ, And, BinaryExpr, Col, Count, DynCol, Literal, Max, Min, Or, Sum, UInt64
 from tests.golden import logictest_cases as G
 from tests.util import (arrow_to_pydict, batch_rows, dict_array, fmt, make_prometheus_batch, parse_rows, record_from_rows,
                         sort_key, table_records)
@@ -828,6 +828,64 @@ def test_config1_simple_schema(pp, variant):
 def test_golden_distinct(pp, case, variant):
     d = run_gpu(pp, table_records(G.DISTINCT_TABLE), case["filter"], [], case["groups"])
     assert sorted(batch_rows(d, case["out"]), key=sort_key) == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+@pytest.mark.parametrize("case", G.DISTINCT_PROJ_CASES, ids=[c["id"] for c in G.DISTINCT_PROJ_CASES])
+def test_golden_distinct_bool_projection(pp, case):
+    """distinct over a boolean projection (`timestamp > 0` as a key; boolExprProjection, project.go:401-470): every row gets a
+    valid bool — computed per row in the hash kernel, emitted as an Arrow bool column."""
+    d = run_gpu(pp, table_records(case["table"]), None, [], case["groups"])
+    rows = [tuple(0 if (v is None and c == "timestamp") else v for c, v in zip(case["out"], r)) for r in batch_rows(d, case["out"])]
+    assert sorted(rows, key=sort_key) == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+def test_bool_projection_key_at_scale(pp):
+    """A comparison as a group key next to label columns: NULLs in the compared column, int64 vs float64 operands, an arithmetic
+    operand, AND / OR, aggregations beside it, two chains merged — vs the oracle."""
+    from frostdb_amd import distributed as fd
+    rng = np.random.default_rng(9901)
+    batches = []
+    for n in (70_000, 30_000):
+        b = many_label_batch(rng, n, 3, 4, n_groups=500, int_key=True)
+        ts = pa.array(rng.integers(-5, 6, n), type=pa.int64(), mask=rng.random(n) < 0.1)
+        batches.append(b.append_column("timestamp", ts))
+    keys = (Col("timestamp") > 0, BinaryExpr(Col("timestamp") * 10000, OP_LT_EQ, Col("bucket")), Col("floatvalue") >= 5,
+            BinaryExpr(Col("timestamp") + Col("value"), OP_NOT_EQ, Literal(3)),
+            And(Col("timestamp") > -2, Or(Col("floatvalue") < 2.5, Col("value") == 7)))
+    for key in keys:
+        groups = [DynCol("labels"), key]
+        aggs = [Sum(Col("value")), Count(Col("value"))]
+        want = run_oracle(batches, None, aggs, groups, nchains=2)
+        p1 = pp.HashAggregatePlan(None, aggs, groups)
+        p2 = pp.HashAggregatePlan(None, aggs, groups)
+        try:
+            p1.Callback(batches[0]); p2.Callback(batches[1])
+            p1.Merge(p2)
+            got = arrow_to_pydict(p1.Finish())
+        finally:
+            p1.Close(); p2.Close()
+        assert set(want[key.name]) == {True, False}
+        cols = key_cols_of(batches) + [key.name] + [a.Name() for a in aggs]
+        assert_same_result(got, want, cols)
+        # the same through the hash-partitioned exchange: schema agreement carries the bool column, two owners import their partitions
+        plans = [pp.HashAggregatePlan(None, aggs, groups), pp.HashAggregatePlan(None, aggs, groups)]
+        shards = [plans[0].clone_empty(), plans[0].clone_empty()]
+        try:
+            for p, b in zip(plans, batches):
+                p.Callback(b)
+            schema = fd.unify_group_schemas([fd._schema_to_obj(p.group_schema()) for p in plans])
+            assert schema.schema.field(key.name).type == pa.bool_()
+            for sh in shards:
+                sh.seed_groups(schema)
+            for p in plans:
+                ptr, counts, row_bytes = p.hash_export(shards[0], 2)
+                shards[0].hash_import(ptr, counts[0])
+                shards[1].hash_import(ptr + counts[0] * row_bytes, counts[1])
+            got2 = _concat_results([sh.Finish() for sh in shards])
+        finally:
+            for p in plans + shards:
+                p.Close()
+        assert_same_result(got2, want, cols)
 
 
 def test_distinct_at_scale_dense_and_hash(pp):
