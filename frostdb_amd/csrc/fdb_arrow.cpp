@@ -106,7 +106,7 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
     for (auto it = range.first; it != range.second;) {
       std::shared_ptr<HostDict> other = it->second.lock();
       if (!other) { it = live.erase(it); continue; }
-      bool same = other->value_format == value_format && (int64_t)other->values.size() == n;
+      bool same = !other->plain && other->value_format == value_format && (int64_t)other->values.size() == n;
       for (int64_t i = 0; i < n && same; i++) {
         const int64_t b0 = begin(i), len = begin(i + 1) - b0;
         const std::string& v = other->values[(size_t)i];
@@ -129,6 +129,118 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
   live.emplace(h, d);
   return d;
 }
+
+std::shared_ptr<HostDict> encode_plain(const HostColView& col, std::vector<uint32_t>* idx) {
+  const ArrowArray* a = col.array;
+  const bool wide = col.format == "U" || col.format == "Z";
+  const int64_t n = col.length, off = col.offset;
+  if (n > 0 && (a->n_buffers < 3 || a->buffers[1] == nullptr)) throw Error(FDB_ERR_INVALID, "string column without offsets: " + col.name);
+  const char* data = (const char*)a->buffers[2];
+  const int32_t* o32 = (const int32_t*)a->buffers[1];
+  const int64_t* o64 = (const int64_t*)a->buffers[1];
+  auto begin = [&](int64_t i) -> int64_t { return wide ? o64[off + i] : (int64_t)o32[off + i]; };
+  auto d = std::make_shared<HostDict>();
+  d->value_format = col.format;  // the column's own type, large or not: key columns and filter output keep it
+  d->plain = true;
+  idx->assign((size_t)n, 0u);
+  // views into the record's own bytes while encoding; the distinct values are copied once at the end
+  std::unordered_map<std::string_view, uint32_t> ids;
+  std::vector<std::string_view> order;
+  for (int64_t i = 0; i < n; i++) {
+    if (col.null_count > 0 && col.validity != nullptr && !((col.validity[(off + i) >> 3] >> ((off + i) & 7)) & 1)) continue;
+    const int64_t b0 = begin(i), b1 = begin(i + 1);
+    if (b1 < b0) throw Error(FDB_ERR_INVALID, "string column with decreasing offsets: " + col.name);
+    const std::string_view v(b1 > b0 ? data + b0 : "", (size_t)(b1 - b0));
+    auto it = ids.find(v);
+    if (it == ids.end()) {
+      if (order.size() >= 0xFFFFFFFEull) throw Error(FDB_ERR_UNSUPPORTED, "more than 2^32 distinct values in string column " + col.name);
+      it = ids.emplace(v, (uint32_t)order.size()).first;
+      order.push_back(v);
+    }
+    (*idx)[(size_t)i] = it->second;
+  }
+  uint64_t h = 1469598103934665603ull;
+  for (const std::string_view& v : order) {
+    const uint64_t len = v.size();
+    for (int k = 0; k < 8; k++) { h ^= (len >> (8 * k)) & 0xFF; h *= 1099511628211ull; }
+    for (unsigned char ch : v) { h ^= ch; h *= 1099511628211ull; }
+  }
+  d->hash = h ^ 0x9E3779B97F4A7C15ull;  // (never equal to the hash of a real dictionary with the same entries)
+  // share with an earlier record's encoding when the distinct values came out the same (same order): downstream caches
+  // (key-id LUTs, truth tables) are keyed by the dictionary object
+  static std::mutex mu;
+  static std::unordered_multimap<uint64_t, std::weak_ptr<HostDict>> live;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto range = live.equal_range(d->hash);
+    for (auto it = range.first; it != range.second;) {
+      std::shared_ptr<HostDict> other = it->second.lock();
+      if (!other) { it = live.erase(it); continue; }
+      bool same = other->value_format == d->value_format && other->values.size() == order.size();
+      for (size_t i = 0; i < order.size() && same; i++) same = std::string_view(other->values[i]) == order[i];
+      if (same) return other;
+      ++it;
+    }
+  }
+  d->values.reserve(order.size());
+  for (const std::string_view& v : order) d->values.emplace_back(v);
+  std::lock_guard<std::mutex> lk(mu);
+  live.emplace(d->hash, d);
+  return d;
+}
+
+template <typename S>
+void set_dictionary(OutColumn* oc, const std::vector<S>& values, const std::string& value_format) {
+  const bool large = value_format == "U" || value_format == "Z";
+  uint64_t total = 0;
+  for (const S& v : values) total += v.size();
+  if (!large && total > 0x7FFFFFFFull) throw Error(FDB_ERR_UNSUPPORTED, "group column " + oc->name + ": more than 2 GiB of distinct key bytes in one dictionary");
+  oc->is_dict = true;
+  oc->dict_format = value_format;
+  oc->dict_offsets.clear();
+  oc->dict_offsets64.clear();
+  if (large) oc->dict_offsets64.resize(values.size() + 1); else oc->dict_offsets.resize(values.size() + 1);
+  oc->dict_data.clear();
+  oc->dict_data.reserve((size_t)total);
+  uint64_t off = 0;
+  for (size_t v = 0; v <= values.size(); v++) {
+    if (large) oc->dict_offsets64[v] = (int64_t)off; else oc->dict_offsets[v] = (int32_t)off;
+    if (v == values.size()) break;
+    oc->dict_data.insert(oc->dict_data.end(), values[v].begin(), values[v].end());
+    off += values[v].size();
+  }
+}
+
+template <typename S>
+void set_plain_strings(OutColumn* oc, const uint32_t* idx, const uint8_t* valid_bits, int64_t n, const std::vector<S>& values,
+                       const std::string& value_format) {
+  auto valid = [&](int64_t i) { return valid_bits == nullptr || ((valid_bits[i >> 3] >> (i & 7)) & 1); };  // (no bitmap: no NULLs)
+  uint64_t total = 0;
+  for (int64_t i = 0; i < n; i++) if (valid(i)) total += values[idx[i]].size();
+  // the reference starts a new record when a key builder passes 2 GiB (aggregate.go:426-468); one record here, 64-bit offsets
+  const bool utf8 = value_format == "u" || value_format == "U";
+  const bool large = total > 0x7FFFFFFFull || value_format == "U" || value_format == "Z";
+  std::vector<uint8_t> offsets((size_t)(n + 1) * (large ? 8 : 4));
+  std::vector<char> data;
+  data.reserve((size_t)total);
+  uint64_t off = 0;
+  for (int64_t i = 0; i <= n; i++) {
+    if (large) { const int64_t o = (int64_t)off; std::memcpy(offsets.data() + (size_t)i * 8, &o, 8); }
+    else { const int32_t o = (int32_t)off; std::memcpy(offsets.data() + (size_t)i * 4, &o, 4); }
+    if (i < n && valid(i)) { const S& v = values[idx[i]]; data.insert(data.end(), v.begin(), v.end()); off += v.size(); }
+  }
+  oc->is_dict = false;
+  oc->is_str = true;
+  oc->format = utf8 ? (large ? "U" : "u") : (large ? "Z" : "z");
+  oc->values = std::move(offsets);
+  oc->ext_values = nullptr;
+  oc->str_data = std::move(data);
+}
+
+template void set_dictionary<std::string>(OutColumn*, const std::vector<std::string>&, const std::string&);
+template void set_dictionary<std::string_view>(OutColumn*, const std::vector<std::string_view>&, const std::string&);
+template void set_plain_strings<std::string>(OutColumn*, const uint32_t*, const uint8_t*, int64_t, const std::vector<std::string>&, const std::string&);
+template void set_plain_strings<std::string_view>(OutColumn*, const uint32_t*, const uint8_t*, int64_t, const std::vector<std::string_view>&, const std::string&);
 
 int64_t count_nulls(const uint8_t* validity, int64_t offset, int64_t length) {
   int64_t set = 0;
@@ -225,6 +337,11 @@ void export_record(std::vector<OutColumn>&& cols_in, int64_t rows, ArrowArray* o
     const void* vbits = c.ext_validity != nullptr ? (const void*)c.ext_validity : (c.validity.empty() ? nullptr : (const void*)c.validity.data());
     b[0] = c.null_count > 0 ? vbits : nullptr;
     b[1] = c.ext_values != nullptr ? (const void*)c.ext_values : (c.values.empty() ? (const void*)&kEmpty : (const void*)c.values.data());
+    if (c.is_str) {
+      static const char kNoBytes = 0;
+      a.n_buffers = 3;
+      b.push_back(c.str_data.empty() ? (const void*)&kNoBytes : (const void*)c.str_data.data());
+    }
     a.buffers = b.data();
     a.release = noop_release_array;
     ArrowSchema& s = h->child_schemas[i];
@@ -236,13 +353,14 @@ void export_record(std::vector<OutColumn>&& cols_in, int64_t rows, ArrowArray* o
     if (c.is_dict) {
       ArrowArray& d = h->dict_arrays[i];
       std::memset(&d, 0, sizeof(d));
-      d.length = (int64_t)c.dict_offsets.size() - 1;
+      const bool wide = !c.dict_offsets64.empty();
+      d.length = (int64_t)(wide ? c.dict_offsets64.size() : c.dict_offsets.size()) - 1;
       d.null_count = 0;
       d.n_buffers = 3;
       std::vector<const void*>& db = h->buffers[n + i];
       db.resize(3);
       db[0] = nullptr;
-      db[1] = c.dict_offsets.data();
+      db[1] = wide ? (const void*)c.dict_offsets64.data() : (const void*)c.dict_offsets.data();
       static const char kNoData = 0;
       db[2] = c.dict_data.empty() ? (const void*)&kNoData : (const void*)c.dict_data.data();
       d.buffers = db.data();

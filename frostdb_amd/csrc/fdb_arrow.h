@@ -6,6 +6,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "../../include/frostdb_amd.h"
@@ -22,11 +23,12 @@ enum class ColKind : int32_t { I64 = 1, U64 = 2, F64 = 3, BOOL = 4, STR = 5, DIC
 // The dictionary of one dictionary-encoded column, kept on the host (strings never go to the device).
 struct HostDict {
   std::vector<std::string> values;
-  std::string value_format;  // "z" (binary) or "u" (utf8); large variants are narrowed on import
+  std::string value_format;  // "z" (binary) or "u" (utf8); large dictionaries are narrowed on import, a plain column keeps "Z" / "U"
   uint64_t hash = 0;         // content hash (lengths + bytes), computed at import
   bool unique = true;        // no two entries hold the same bytes (Arrow allows duplicates)
-  bool utf8() const { return value_format == "u"; }
-  bool same_content(const HostDict& o) const { return hash == o.hash && values == o.values; }
+  bool plain = false;        // not an Arrow dictionary: the distinct values of a plain string / binary column, encoded by encode_plain
+  bool utf8() const { return value_format == "u" || value_format == "U"; }
+  bool same_content(const HostDict& o) const { return hash == o.hash && plain == o.plain && values == o.values; }
 };
 
 // A borrowed view of one column of an incoming record; valid only while the caller's ArrowArray is.
@@ -50,6 +52,10 @@ struct HostRecordView {
 // Throws fdb::Error(FDB_ERR_INVALID) on a malformed record.
 void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordView* out);
 std::shared_ptr<HostDict> read_dictionary(const HostColView& col);
+// A plain string / binary column (formats u, z, U, Z) never reaches the device as bytes: its distinct values become a HostDict
+// (first-seen order, `plain` set) and `idx` gets one uint32 per row (0 for NULL rows) — from there on the column travels like
+// a dictionary column, and the filter / group-key code asks `dict->plain` where the reference treats the two differently.
+std::shared_ptr<HostDict> encode_plain(const HostColView& col, std::vector<uint32_t>* idx);
 int64_t count_nulls(const uint8_t* validity, int64_t offset, int64_t length);
 // Copies `length` bits starting at bit `offset` of `src` to bit 0 of `dst` (dst has (length+7)/8 bytes, zero padded).
 void copy_bits(const uint8_t* src, int64_t offset, int64_t length, uint8_t* dst);
@@ -71,8 +77,21 @@ struct OutColumn {
   bool is_dict = false;
   std::string dict_format;            // "z" / "u"
   std::vector<int32_t> dict_offsets;  // n_dict + 1
+  std::vector<int64_t> dict_offsets64;  // … for the large formats "Z" / "U" (instead of dict_offsets)
   std::vector<char> dict_data;
+  // plain string / binary columns (format u / z, or U / Z with 64-bit offsets past 2 GiB of data): `values` holds the offsets
+  bool is_str = false;
+  std::vector<char> str_data;
 };
+
+// Fills the dictionary of `oc` (format `value_format`, "u" / "z") with `values`.
+template <typename S>
+void set_dictionary(OutColumn* oc, const std::vector<S>& values, const std::string& value_format);
+// Turns `oc` into a plain string / binary column of `n` rows: row i holds values[idx[i]] where bit i of `valid_bits` is set
+// (nullptr: everywhere), NULL elsewhere. `oc`'s validity (own or external) is kept; its value buffer is replaced by offsets + data.
+template <typename S>
+void set_plain_strings(OutColumn* oc, const uint32_t* idx, const uint8_t* valid_bits, int64_t n, const std::vector<S>& values,
+                       const std::string& value_format);
 
 // Moves `cols` into a heap holder and fills `out`/`out_schema` (struct-typed record, `rows` long) whose
 // release callbacks free that holder.

@@ -345,18 +345,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     oc.length = (int64_t)n;
     oc.format = g.kind == 0 ? "I" : g.is_bool ? "b" : "l";
     if (n > 0 && !g.is_bool) { oc.backing = backing; oc.ext_values = h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }
-    if (g.kind == 0) {
-      oc.is_dict = true;
-      oc.dict_format = g.value_format;
-      oc.dict_offsets.resize(g.values.size() + 1);
-      int32_t off = 0;
-      for (size_t v = 0; v < g.values.size(); v++) {
-        oc.dict_offsets[v] = off;
-        oc.dict_data.insert(oc.dict_data.end(), g.values[v].begin(), g.values[v].end());
-        off += (int32_t)g.values[v].size();
-      }
-      oc.dict_offsets[g.values.size()] = off;
-    }
+    if (g.kind == 0 && !g.plain) set_dictionary(&oc, g.values, g.value_format);
     out->push_back(std::move(oc));
   }
   std::vector<size_t> out_of_agg(aggs_.size(), (size_t)-1);  // physical aggregate → its output column
@@ -386,6 +375,8 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
       oc.null_count = 0;
       continue;
     }
+    if (gcols_[c].kind == 0 && gcols_[c].plain)  // plain string / binary key column: entry indices → offsets + bytes
+      set_plain_strings(&oc, (const uint32_t*)(h_block + off_key[c]), h_block + off_bits[c], (int64_t)n, gcols_[c].values, gcols_[c].value_format);
     const size_t bytes = (size_t)(n + 7) / 8;
     int64_t set = 0;
     const uint64_t* w64 = (const uint64_t*)oc.ext_validity;
@@ -435,17 +426,10 @@ void Plan::group_schema(ArrowArray* out, ArrowSchema* out_schema) {
     oc.name = g.name;
     oc.length = 0;
     if (g.kind == 0) {
-      oc.format = "I";
-      oc.is_dict = true;
-      oc.dict_format = g.value_format;
-      oc.dict_offsets.resize(g.values.size() + 1);
-      int32_t off = 0;
-      for (size_t v = 0; v < g.values.size(); v++) {
-        oc.dict_offsets[v] = off;
-        oc.dict_data.insert(oc.dict_data.end(), g.values[v].begin(), g.values[v].end());
-        off += (int32_t)g.values[v].size();
-      }
-      oc.dict_offsets[g.values.size()] = off;
+      // a plain string / binary key column also travels as its value set; the SIGNED index type marks it (columns of real
+      // dictionaries are always described with uint32 indices)
+      oc.format = g.plain ? "i" : "I";
+      set_dictionary(&oc, g.values, g.value_format);
     } else {
       oc.format = g.is_bool ? "b" : "l";
     }
@@ -485,14 +469,14 @@ void Plan::seed_groups(const ArrowArray* array, const ArrowSchema* schema) {
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == c.name) break;
     if (gi == gcols_.size()) {
       GroupColState g;
-      g.name = c.name; g.kind = kind; g.is_bool = c.kind == ColKind::BOOL; g.cap = 1; g.stride = 0;
+      g.name = c.name; g.kind = kind; g.is_bool = c.kind == ColKind::BOOL; g.plain = kind == 0 && c.format == "i"; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
     GroupColState& g = gcols_[gi];
-    if (g.kind != kind || g.is_bool != (c.kind == ColKind::BOOL)) throw Error(FDB_ERR_INVALID, "group column " + c.name + " has a different type in this plan");
+    if (g.kind != kind || g.is_bool != (c.kind == ColKind::BOOL) || g.plain != (kind == 0 && c.format == "i")) throw Error(FDB_ERR_INVALID, "group column " + c.name + " has a different type in this plan");
     if (kind == 0) {
       std::shared_ptr<HostDict> d = read_dictionary(c);
-      g.value_format = d->value_format;
+      g.value_format = g.plain ? std::string(c.schema->dictionary->format) : d->value_format;  // (a plain column keeps a large type)
       g.owners.push_back(d);
       for (const std::string& v : d->values) g.intern(std::string_view(v));
     }
@@ -520,11 +504,11 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
     for (; gi < layout.gcols_.size(); gi++) if (layout.gcols_[gi].name == sg.name) break;
     if (gi == layout.gcols_.size()) {
       GroupColState g;
-      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.plain = sg.plain; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
       layout.gcols_.push_back(std::move(g));
     }
     GroupColState& g = layout.gcols_[gi];
-    if (g.kind != sg.kind) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
+    if (g.kind != sg.kind || g.plain != sg.plain || g.is_bool != sg.is_bool) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
     if (sg.kind == 0) {
       g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());
       id_map[sc].assign(sg.values.size() + 1, 0);
@@ -639,11 +623,11 @@ void Plan::merge_hash(Plan& src) {
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == sg.name) break;
     if (gi == gcols_.size()) {
       GroupColState g;
-      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.plain = sg.plain; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
     GroupColState& g = gcols_[gi];
-    if (g.kind != sg.kind) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
+    if (g.kind != sg.kind || g.plain != sg.plain || g.is_bool != sg.is_bool) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
     dst_of[sc] = (int)gi;
     if (sg.kind == 0) {
       g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());

@@ -89,6 +89,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
   // plan the arena
   struct Piece { size_t col; bool validity; size_t off; size_t bytes; };
   std::vector<Piece> pieces;
+  std::vector<std::pair<size_t, std::vector<uint32_t>>> plain_idx;  // (column, encoded indices) of plain string columns
   size_t total = 0;
   for (size_t i = 0; i < view.cols.size(); i++) {
     const HostColView& c = view.cols[i];
@@ -98,9 +99,9 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     if (staged) {
       int64_t vb = 0;
       if (c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::BOOL) vb = c.length * 8;  // (bool: widened to int64 0 / 1)
-      else if (c.kind == ColKind::DICT) vb = c.length * 4;
-      if (vb > 0 || ((c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::DICT || c.kind == ColKind::BOOL))) {
-        d.value_bytes = vb;
+      else if (c.kind == ColKind::DICT || c.kind == ColKind::STR) vb = c.length * 4;  // (plain strings: encoded below, one uint32 per row)
+      if (vb > 0 || ((c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::DICT || c.kind == ColKind::BOOL || c.kind == ColKind::STR))) {
+        d.value_bytes = c.kind == ColKind::BOOL ? (c.length + 7) / 8 : vb;  // (algorithmic bytes: Arrow's bit-packed buffer)
         pieces.push_back(Piece{i, false, total, (size_t)vb});
         total += align_up((size_t)vb + kTailPad, 256);
         if (c.null_count > 0) {
@@ -110,6 +111,11 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
         }
       }
       if (c.kind == ColKind::DICT) d.dict = read_dictionary(c);
+      if (c.kind == ColKind::STR) {  // from here on a dictionary column whose dictionary says `plain`
+        plain_idx.emplace_back(i, std::vector<uint32_t>());
+        d.dict = encode_plain(c, &plain_idx.back().second);
+        d.kind = ColKind::DICT;
+      }
     } else {
       d.kind = c.kind;  // present but not staged: d_values stays nullptr
     }
@@ -154,6 +160,10 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
         const uint8_t* bits = (const uint8_t*)c.values;
         for (int64_t i = 0; i < c.length; i++) wide[(size_t)i] = (bits[(c.offset + i) >> 3] >> ((c.offset + i) & 7)) & 1;
         h2d(dst, wide.data(), p.bytes, "hipMemcpy(bool values)");
+      } else if (c.kind == ColKind::STR) {
+        const std::vector<uint32_t>* enc = nullptr;
+        for (const auto& pi : plain_idx) if (pi.first == p.col) enc = &pi.second;
+        h2d(dst, enc->data(), p.bytes, "hipMemcpy(encoded strings)");
       } else if (c.kind == ColKind::DICT && c.index_width != 4) {
         keep_idx.emplace_back((size_t)c.length);
         std::vector<uint32_t>& wide = keep_idx.back();
@@ -173,7 +183,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
   }
   for (const DevColumn& d : b->cols) b->payload_bytes += d.value_bytes + d.validity_bytes;
   if (ring != nullptr) ctx->copy_commit(b->arena, ring, total);
-  else if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty() || !keep_i64.empty())) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
+  else if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty() || !keep_i64.empty() || !plain_idx.empty())) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
   return b;
 }
 
@@ -411,7 +421,7 @@ typedef std::vector<uint8_t> Truth;
 Truth leaf_truth(const ExprNode& e, const HostDict& dict) {
   const size_t n = dict.values.size();
   Truth t(n + 1, 0);
-  if (!e.lit.valid() && (e.op == FDB_OP_EQ || e.op == FDB_OP_NOT_EQ || e.op == FDB_OP_CONTAINS || e.op == FDB_OP_NOT_CONTAINS)) {
+  if (!dict.plain && !e.lit.valid() && (e.op == FDB_OP_EQ || e.op == FDB_OP_NOT_EQ || e.op == FDB_OP_CONTAINS || e.op == FDB_OP_NOT_CONTAINS)) {
     // == NULL ⇒ IS NULL, != NULL ⇒ IS NOT NULL (:165-172, :205-212); (not) contains NULL ⇒ every non-null row (:287-295)
     const bool on_value = e.op != FDB_OP_EQ;
     for (size_t i = 0; i < n; i++) t[i] = on_value;
@@ -426,6 +436,11 @@ Truth leaf_truth(const ExprNode& e, const HostDict& dict) {
       case FDB_OP_NOT_EQ: m = (v != e.lit.bytes); break;
       case FDB_OP_CONTAINS: m = v.find(e.lit.bytes) != std::string::npos; break;
       case FDB_OP_NOT_CONTAINS: m = v.find(e.lit.bytes) == std::string::npos; break;
+      // order comparisons exist for plain columns only (resolve_leaf rejects them on dictionaries): bytewise, like Arrow's
+      case FDB_OP_LT: m = v.compare(e.lit.bytes) < 0; break;
+      case FDB_OP_LT_EQ: m = v.compare(e.lit.bytes) <= 0; break;
+      case FDB_OP_GT: m = v.compare(e.lit.bytes) > 0; break;
+      case FDB_OP_GT_EQ: m = v.compare(e.lit.bytes) >= 0; break;
       case FDB_OP_REGEX_MATCH: m = std::regex_search(v, *e.re); break;
       case FDB_OP_REGEX_NOT_MATCH: m = !std::regex_search(v, *e.re); break;
     }
@@ -449,7 +464,11 @@ bool single_dict_subtree(const std::vector<ExprNode>& nodes, int idx, const Devi
   if (!dict_leaf_op(e.op)) return false;
   const int ci = b.find(e.column);
   if (ci < 0 || b.cols[(size_t)ci].kind != ColKind::DICT || b.cols[(size_t)ci].d_values == nullptr) return false;
-  if ((e.op == FDB_OP_REGEX_MATCH || e.op == FDB_OP_REGEX_NOT_MATCH) && b.cols[(size_t)ci].dict->utf8()) return false;  // must raise, see resolve_leaf
+  const bool is_regex = e.op == FDB_OP_REGEX_MATCH || e.op == FDB_OP_REGEX_NOT_MATCH;
+  const HostDict& d = *b.cols[(size_t)ci].dict;
+  if (is_regex && !d.plain && d.utf8()) return false;  // must raise, see resolve_leaf
+  // plain columns: = / != with a NULL or non-string literal have their own rules (resolve_leaf), not a truth table
+  if (d.plain && (e.op == FDB_OP_EQ || e.op == FDB_OP_NOT_EQ) && e.lit.type != FDB_LIT_STRING && e.lit.type != FDB_LIT_BINARY) return false;
   if (*col >= 0 && *col != ci) return false;
   *col = ci;
   (*n_leaves)++;
@@ -562,6 +581,21 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
   }
   const DevColumn& c = b.cols[(size_t)ci];
   const bool is_contains = e.op == FDB_OP_CONTAINS || e.op == FDB_OP_NOT_CONTAINS;
+  if (c.kind == ColKind::DICT && c.dict->plain) {
+    // A plain string / binary column (encoded on import). Not the dictionary rules: regex and contains take both String and
+    // Binary arrays (regexpfilter.go:48-54, binaryscalarexpr.go:87-89, :234-270 — a NULL literal searches for ""), and
+    // = != < <= > >= go to Arrow's compare kernels (binaryscalarexpr.go:116, :119-152): bytewise order, a NULL scalar
+    // yields NULL for every row ⇒ no row, a non-string scalar has no kernel.
+    if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
+    if (!is_regex && !is_contains) {
+      if (!(e.op >= FDB_OP_EQ && e.op <= FDB_OP_GT_EQ)) throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation");
+      if (!e.lit.valid()) { set_const(false); return; }
+      if (e.lit.type != FDB_LIT_STRING && e.lit.type != FDB_LIT_BINARY)
+        throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation (column/literal type combination) on " + c.name);
+    }
+    emit_truth_leaf(leaf_truth(e, *c.dict), b, ci, R, L);
+    return;
+  }
   if (c.kind == ColKind::DICT) {
     if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
     if (is_regex && c.dict->utf8())  // regexpfilter.go:55-61: only *array.Binary dictionaries
@@ -586,7 +620,7 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
   if (is_regex) throw Error(FDB_ERR_UNSUPPORTED, "ArrayScalarRegexMatch: unsupported type on the device path: " + c.format);
   if (is_contains) throw Error(FDB_ERR_UNSUPPORTED, "contains on a non-dictionary column is not supported on the device path: " + c.name);
   if (!(e.op >= FDB_OP_EQ && e.op <= FDB_OP_GT_EQ)) throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation");
-  if (c.kind != ColKind::I64 && c.kind != ColKind::U64 && c.kind != ColKind::F64)
+  if (c.kind != ColKind::I64 && c.kind != ColKind::U64 && c.kind != ColKind::F64 && c.kind != ColKind::BOOL)
     throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation: compare on column type " + c.format + " (" + c.name + ")");
   if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
   if (!e.lit.valid()) { set_const(false); return; }  // compare with a NULL scalar yields NULL for every row (binaryscalarexpr.go:143-146)
@@ -597,7 +631,9 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
   L->wide = 1;
   R->leaf_col[li] = ci;
   auto dbits = [](double d) { int64_t v; std::memcpy(&v, &d, 8); return v; };
-  if (c.kind == ColKind::I64) {
+  if (c.kind == ColKind::BOOL) {  // staged as int64 0 / 1; Arrow orders false < true
+    if (e.lit.type == FDB_LIT_BOOL) { L->kind = FDB_LEAF_CMP_I64; L->lit = e.lit.i64 ? 1 : 0; return; }
+  } else if (c.kind == ColKind::I64) {
     if (e.lit.type == FDB_LIT_INT64) { L->kind = FDB_LEAF_CMP_I64; L->lit = e.lit.i64; return; }
     if (e.lit.type == FDB_LIT_FLOAT64) { L->kind = FDB_LEAF_CMP_I64_F64; L->lit = dbits(e.lit.f64); return; }
   } else if (c.kind == ColKind::U64) {
@@ -800,13 +836,14 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
       GroupColState g;
       g.name = c.name;
       g.kind = kind;
-      if (kind == 0) g.value_format = c.dict->value_format;
+      if (kind == 0) { g.value_format = c.dict->value_format; g.plain = c.dict->plain; }
       g.cap = 1;
       g.stride = 0;
       gcols_.push_back(std::move(g));
     }
     GroupColState& g = gcols_[gi];
-    if (g.kind != kind) throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + " changed type between batches");
+    if (g.kind != kind || g.is_bool || (kind == 0 && g.plain != c.dict->plain))  // (the reference's key builder is typed by the first batch)
+      throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + " changed type between batches");
     GroupRes gr;
     gr.gi = (int)gi; gr.ci = (int)ci; gr.kind = kind;
     if (kind == 0) gr.lut = g.lut_for(c.dict);
@@ -1318,8 +1355,6 @@ void Plan::build_key_columns(const CompactState& cs, std::vector<OutColumn>* col
       continue;
     }
     c.format = "I";
-    c.is_dict = true;
-    c.dict_format = g.value_format;
     c.values.resize((size_t)n * 4);
     uint32_t* idx = (uint32_t*)c.values.data();
     for (int64_t i = 0; i < n; i++) {
@@ -1327,14 +1362,12 @@ void Plan::build_key_columns(const CompactState& cs, std::vector<OutColumn>* col
       if (id == 0) { idx[i] = 0; c.null_count++; }
       else { idx[i] = id - 1; c.validity[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); }
     }
-    c.dict_offsets.resize(g.values.size() + 1);
-    int32_t off = 0;
-    for (size_t v = 0; v < g.values.size(); v++) {
-      c.dict_offsets[v] = off;
-      c.dict_data.insert(c.dict_data.end(), g.values[v].begin(), g.values[v].end());
-      off += (int32_t)g.values[v].size();
+    if (g.plain) {  // the key column keeps its input type (array.NewBuilder(type), pqarrow/builder/utils.go:12-52)
+      const std::vector<uint8_t> idx_bytes = std::move(c.values);
+      set_plain_strings(&c, (const uint32_t*)idx_bytes.data(), c.validity.data(), n, g.values, g.value_format);
+    } else {
+      set_dictionary(&c, g.values, g.value_format);
     }
-    c.dict_offsets[g.values.size()] = off;
     cols->push_back(std::move(c));
   }
 }
@@ -1527,11 +1560,12 @@ void Plan::merge_from(Plan& src) {
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == sg.name) break;
     if (gi == gcols_.size()) {
       GroupColState g;
-      g.name = sg.name; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      g.name = sg.name; g.value_format = sg.value_format; g.plain = sg.plain; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
       caps.push_back(1);
     }
     GroupColState& g = gcols_[gi];
+    if (g.plain != sg.plain) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
     col_map[sc] = gi;
     id_map[sc].assign(sg.values.size() + 1, 0);
     g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());
@@ -1648,17 +1682,15 @@ void Plan::filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray
     } else {
       hip_check(hipStreamSynchronize(stream_), "sync");
     }
-    if (c.kind == ColKind::DICT) {
-      o.is_dict = true;
-      o.dict_format = c.dict->value_format;
-      o.dict_offsets.resize(c.dict->values.size() + 1);
-      int32_t off = 0;
-      for (size_t v = 0; v < c.dict->values.size(); v++) {
-        o.dict_offsets[v] = off;
-        o.dict_data.insert(o.dict_data.end(), c.dict->values[v].begin(), c.dict->values[v].end());
-        off += (int32_t)c.dict->values[v].size();
-      }
-      o.dict_offsets[c.dict->values.size()] = off;
+    if (c.kind == ColKind::DICT && c.dict->plain) {  // a plain string / binary column leaves as one
+      const std::vector<uint8_t> idx_bytes = std::move(o.values);
+      set_plain_strings(&o, (const uint32_t*)idx_bytes.data(), o.validity.empty() ? nullptr : o.validity.data(), n, c.dict->values, c.dict->value_format);
+    } else if (c.kind == ColKind::DICT) {
+      set_dictionary(&o, c.dict->values, c.dict->value_format);
+    } else if (c.kind == ColKind::BOOL) {  // staged as int64 0 / 1, Arrow wants bits
+      std::vector<uint8_t> bits((size_t)(n + 7) / 8 + 8, 0);
+      for (int64_t i = 0; i < n; i++) { int64_t v; std::memcpy(&v, o.values.data() + (size_t)i * 8, 8); if (v) bits[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); }
+      o.values = std::move(bits);
     }
     cols.push_back(std::move(o));
   }

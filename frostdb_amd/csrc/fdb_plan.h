@@ -95,6 +95,7 @@ struct AggState {
 struct GroupColState {
   std::string name;
   int kind = 0;                                             // 0 dictionary column, 1 int64 column (hash table only)
+  bool plain = false;                                       // kind 0 fed by a plain string / binary column: emitted as one, not as a dictionary
   bool is_bool = false;                                     // kind 1 holding a boolean projection's 0 / 1: emitted as an Arrow bool column
   int word = -1;                                            // hash table: first word of this column in the key tuple
   std::string value_format = "z";

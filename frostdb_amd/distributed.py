@@ -197,11 +197,14 @@ def merge_plan(plan, group=None, dst: int = 0, device: Optional[torch.device] = 
 
 # ---- high-cardinality merge: hash-partitioned all-to-all ---------------------------------------------------------------
 def _schema_to_obj(schema: pa.RecordBatch):
-    """Picklable form of a plan's zero-row group schema: [(name, 'dict', value type, values) | (name, 'plain', type)]."""
+    """Picklable form of a plan's zero-row group schema: [(name, 'dict' | 'strs', value type, values) | (name, 'plain', type)].
+    'strs' is a plain string / binary key column: fdb_plan_group_schema describes it by its value set too, with a SIGNED
+    index type as the marker."""
     out = []
     for f, c in zip(schema.schema, schema.columns):
         if pa.types.is_dictionary(f.type):
-            out.append((f.name, "dict", str(f.type.value_type), c.dictionary.to_pylist()))
+            kind = "strs" if pa.types.is_signed_integer(f.type.index_type) else "dict"
+            out.append((f.name, kind, str(f.type.value_type), c.dictionary.to_pylist()))
         else:
             out.append((f.name, "plain", str(f.type), None))
     return out
@@ -221,7 +224,7 @@ def unify_group_schemas(objs: Sequence[Sequence[tuple]]) -> pa.RecordBatch:
             e = cols[name]
             if e[0] != kind or e[1] != ty:
                 raise ValueError(f"group column {name!r} has different types on different ranks: {e[0]} {e[1]} vs {kind} {ty}")
-            if kind == "dict":
+            if kind in ("dict", "strs"):
                 for v in values:
                     if v not in e[3]:
                         e[3].add(v)
@@ -229,9 +232,11 @@ def unify_group_schemas(objs: Sequence[Sequence[tuple]]) -> pa.RecordBatch:
     arrays, names = [], []
     for name in order:
         kind, ty, values, _ = cols[name]
-        if kind == "dict":
-            vt = pa.string() if ty in ("string", "utf8") else pa.binary()
-            arrays.append(pa.DictionaryArray.from_arrays(pa.array([], type=pa.uint32()), pa.array(values, type=vt)))
+        if kind in ("dict", "strs"):
+            vt = {"string": pa.string(), "utf8": pa.string(), "large_string": pa.large_string(), "large_utf8": pa.large_string(),
+                  "large_binary": pa.large_binary()}.get(ty, pa.binary())
+            it = pa.uint32() if kind == "dict" else pa.int32()
+            arrays.append(pa.DictionaryArray.from_arrays(pa.array([], type=it), pa.array(values, type=vt)))
         else:
             arrays.append(pa.array([], type=pa.float64() if ty == "double" else pa.bool_() if ty == "bool" else pa.int64()))
         names.append(name)

@@ -737,6 +737,183 @@ def test_hash_exchange_rccl_single_rank_and_dense_source(pp):
             dist.destroy_process_group()
 
 
+# ---- plain string / binary columns (not dictionary-encoded): filter leaves and group keys ---------------------------------
+
+def plain_batch(rng, n, typ=None, n_vals=40, null_frac=0.1, extra_null_col=False):
+    """`name` : plain string / binary (typ), `tag` : the other one, `code` : dictionary, `flag` : bool, `value` / `floatvalue`."""
+    typ = typ or pa.string()
+    other = pa.binary() if typ in (pa.string(), pa.large_string()) else pa.string()
+    words = ["", "a", "ab", "abc", "b", "ba", "zeta", "Zeta", "é", "abc\x00", "value1", "value10", "value2"] + ["w%03d" % k for k in range(n_vals)]
+    pick = rng.integers(0, len(words), n)
+    name = pa.array([words[k] for k in pick], type=pa.string(), mask=rng.random(n) < null_frac).cast(typ)
+    tag = pa.array([("t%d" % (k % 7)) for k in rng.integers(0, 1000, n)], type=pa.string(), mask=rng.random(n) < null_frac).cast(other)
+    code = dict_array([None if rng.random() < 0.05 else b"c%d" % k for k in rng.integers(0, 5, n)])
+    flag = pa.array(rng.integers(0, 2, n).astype(bool), mask=rng.random(n) < null_frac)
+    arrays = [name, tag, code, flag, pa.array(rng.integers(-50, 50, n), type=pa.int64()), pa.array(rng.uniform(0, 10, n))]
+    names = ["name", "tag", "labels.code", "flag", "value", "floatvalue"]
+    return pa.RecordBatch.from_arrays(arrays, names=names)
+
+
+PLAIN_FILTERS = [
+    Col("name") == "abc", Col("name") != "abc", Col("name") < "b", Col("name") <= "ab", Col("name") > "value1", Col("name") >= "w010",
+    Col("name") == "", Col("name") != "", Col("name") == None, Col("name") != None,  # noqa: E711  (a NULL scalar: no row either way)
+    Col("name").RegexMatch("^value1"), Col("name").RegexNotMatch("^w0[0-3]"), Col("name").Contains("a"), Col("name").NotContains("b"),
+    Col("name").Contains(None), Col("name").NotContains(None),
+    Or(Col("name") == "abc", Col("name") == "zeta"), And(Col("name") >= "a", Col("name") < "c"),
+    And(Or(Col("name") < "b", Col("tag") == "t3"), Col("labels.code") != "c1", Col("value") > -20),
+    Or(Col("name") == None, Col("name") > "w"),  # noqa: E711
+]
+
+
+@pytest.mark.parametrize("typ", [pa.string(), pa.binary(), pa.large_string(), pa.large_binary()], ids=["utf8", "binary", "large_utf8", "large_binary"])
+def test_plain_string_filter_leaves_vs_oracle(pp, typ):
+    """Every operator the reference accepts on *array.String / *array.Binary (Arrow compare kernels, contains, regex) — selection
+    vector and filtered record (plain columns leave as plain columns, bools as bools) against the oracle."""
+    from oracle import OraclePlan
+    rng = np.random.default_rng(8101)
+    b = plain_batch(rng, 20_011, typ)
+    for f in PLAIN_FILTERS:
+        plan = pp.HashAggregatePlan(f)
+        o = OraclePlan(f)
+        try:
+            got = plan.Select(b)
+            _, want = o.filter(b)
+            assert np.array_equal(got, want), str(f)
+            out = plan.Filter(b)
+            if len(want) == 0:
+                assert out is None
+            else:
+                take = b.take(pa.array(want))
+                assert out.schema.field("name").type == typ and out.schema.field("flag").type == pa.bool_()
+                assert arrow_to_pydict(out) == arrow_to_pydict(take), str(f)
+        finally:
+            plan.Close()
+            o.close()
+
+
+def test_bool_column_filter_vs_oracle(pp):
+    """Arrow's compare kernels on a boolean column with a boolean scalar (false < true); NULL rows never match."""
+    from oracle import OraclePlan
+    rng = np.random.default_rng(8106)
+    b = plain_batch(rng, 30_003)
+    for f in (Col("flag") == True, Col("flag") != True, Col("flag") == False, Col("flag") < True, Col("flag") >= False,  # noqa: E712
+              And(Col("flag") == True, Col("value") > 0), Or(Col("flag") == False, Col("name") == "abc")):  # noqa: E712
+        plan = pp.HashAggregatePlan(f, [Sum(Col("value")), Count(Col("value"))], [Col("labels.code")])
+        o = OraclePlan(f)
+        try:
+            _, want = o.filter(b)
+            assert np.array_equal(plan.Select(b), want), str(f)
+            plan.Callback(b)
+            got = arrow_to_pydict(plan.Finish())
+        finally:
+            plan.Close()
+            o.close()
+        assert_same_result(got, run_oracle([b], f, [Sum(Col("value")), Count(Col("value"))], [Col("labels.code")]), ["labels.code", "sum(value)", "count(value)"])
+
+
+def test_plain_string_filter_errors(pp):
+    rng = np.random.default_rng(8102)
+    b = plain_batch(rng, 100)
+    # a string array against a number: Arrow has no such compare kernel → ErrUnsupportedBinaryOperation (binaryscalarexpr.go:126-129)
+    plan = pp.HashAggregatePlan(Col("name") == 3, [Count(Col("value"))], [])
+    with pytest.raises(pp.UnsupportedError):
+        plan.Callback(b)
+    plan.Close()
+
+
+@pytest.mark.parametrize("typ", [pa.string(), pa.binary(), pa.large_string()], ids=["utf8", "binary", "large_utf8"])
+def test_plain_string_group_keys_vs_oracle(pp, typ, variant):
+    """Group by plain string columns (the reference's own Test_Aggregate_ArrayOverflow groups by a *array.Binary column,
+    aggregate_test.go:60-118): NULL keys, "" ≠ NULL, two chains merged, the key columns come back as plain columns of the input type."""
+    rng = np.random.default_rng(8103)
+    batches = [plain_batch(rng, 60_000, typ), plain_batch(rng, 45_000, typ, n_vals=70)]
+    aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("floatvalue")), Max(Col("value"))]
+    for groups, filt in (([Col("name")], None), ([Col("name"), Col("tag"), Col("labels.code")], Col("name") != "ab"), ([Col("tag")], Col("name") < "w")):
+        want = run_oracle(batches, filt, aggs, groups, nchains=2)
+        p1 = pp.HashAggregatePlan(filt, aggs, groups)
+        p2 = pp.HashAggregatePlan(filt, aggs, groups)
+        try:
+            p1.Callback(batches[0]); p2.Callback(batches[1])
+            p1.Merge(p2)
+            rec = p1.Finish()
+        finally:
+            p1.Close(); p2.Close()
+        for g in groups:
+            assert rec.schema.field(g.name).type == batches[0].schema.field(g.name).type
+        cols = [g.name for g in groups] + [a.Name() for a in aggs]
+        assert_same_result(arrow_to_pydict(rec), want, cols, float_cols={"min(floatvalue)"})
+
+
+def test_plain_string_keys_hash_table_and_exchange(pp):
+    """A high-cardinality plain string key (hash table path) plus a dictionary key: resident and pushed records, then the
+    hash-partitioned exchange between two plans whose value sets differ (the schema agreement carries the plain column's values)."""
+    from frostdb_amd import distributed as fd
+    rng = np.random.default_rng(8104)
+
+    def big(n, lo, hi):
+        ids = rng.integers(lo, hi, n)
+        user = pa.array(["user-%07d" % k for k in ids], type=pa.string(), mask=rng.random(n) < 0.02)
+        b = many_label_batch(rng, n, 9, 4, n_groups=3000)
+        return b.append_column("user", user)
+
+    batches = [big(80_000, 0, 60_000), big(60_000, 40_000, 120_000)]
+    aggs = [Sum(Col("value")), Count(Col("value")), Max(Col("floatvalue"))]
+    groups = [DynCol("labels"), Col("user")]
+    want = run_oracle(batches, None, aggs, groups)
+    cols = key_cols_of(batches, extra=("user",)) + [a.Name() for a in aggs]
+    assert len(want["user"]) > 100_000
+    for resident in (False, True):
+        got_rec = None
+        plan = pp.HashAggregatePlan(None, aggs, groups)
+        keep = []
+        try:
+            for b in batches:
+                if resident:
+                    keep.append(pp.ResidentBatch(b))
+                    plan.Callback(keep[-1])
+                else:
+                    plan.Callback(b)
+            got_rec = plan.Finish()
+        finally:
+            plan.Close()
+        assert got_rec.schema.field("user").type == pa.string()
+        assert_same_result(arrow_to_pydict(got_rec), want, cols)
+    plans = [pp.HashAggregatePlan(None, aggs, groups), pp.HashAggregatePlan(None, aggs, groups)]
+    shards = [plans[0].clone_empty(), plans[0].clone_empty()]
+    try:
+        for p, b in zip(plans, batches):
+            p.Callback(b)
+        schema = fd.unify_group_schemas([fd._schema_to_obj(p.group_schema()) for p in plans])
+        for sh in shards:
+            sh.seed_groups(schema)
+        for p in plans:
+            ptr, counts, row_bytes = p.hash_export(shards[0], 2)
+            shards[0].hash_import(ptr, counts[0])
+            shards[1].hash_import(ptr + counts[0] * row_bytes, counts[1])
+        recs = [sh.Finish() for sh in shards]
+    finally:
+        for p in plans + shards:
+            p.Close()
+    assert all(r.schema.field("user").type == pa.string() for r in recs)
+    assert_same_result(_concat_results(recs), want, cols)
+
+
+def test_plain_and_dictionary_key_types_do_not_mix(pp):
+    """The reference's key builder is typed by the first batch it sees; a column that arrives as a dictionary in one record and
+    as plain strings in the next is an error, not a silent re-encoding."""
+    rng = np.random.default_rng(8105)
+    b1 = plain_batch(rng, 500)
+    b2 = b1.set_column(0, "name", b1.column(0).dictionary_encode().cast(pa.dictionary(pa.uint32(), pa.string())))
+    plan = pp.HashAggregatePlan(None, [Count(Col("value"))], [Col("name")])
+    try:
+        plan.Callback(b1)
+        with pytest.raises(pp.FdbError):
+            plan.Callback(b2)
+            plan.Finish()
+    finally:
+        plan.Close()
+
+
 # ---- pre-aggregate Projection fused into the scan (SURVEY §8f.1; project.go:73-399) ----------------------------------------
 
 def _gpu_runner(pp):
