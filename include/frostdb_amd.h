@@ -187,7 +187,11 @@ int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
  * would raise are returned by THIS call) and the columns the plan references are copied out before returning. Records
  * above 8 MiB of referenced data are scanned right away; smaller ones — the reference hands records of ≥ 1 024 rows
  * (table.go:780) — are queued in HBM and scanned together, ONE launch per ≈2 M pending rows, or when the plan's state
- * is next needed (finish, merge, num_groups, state_*, push of resident batches …). */
+ * is next needed (finish, merge, num_groups, state_*, push of resident batches …).
+ * Column types (Arrow C data formats) the plan can reference: int64 "l", uint64 "L" (filter only), float64 "g", bool "b"
+ * (filter leaves, AND aggregation), dictionary<any integer index, utf8 / binary / large variants> (filter leaves, group keys),
+ * and plain utf8 / binary / large_utf8 / large_binary "u" "z" "U" "Z" (filter leaves, group keys: encoded to key ids on the host
+ * during this call, emitted with their input type). Columns the plan does not reference may have any type: they are not read. */
 int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema);
 /* Same, for a record that is already resident in HBM. */
 int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch);
