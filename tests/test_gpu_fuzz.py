@@ -7,7 +7,7 @@ import numpy as np
 import pyarrow as pa
 import pytest
 
-from frostdb_amd.logicalplan import And, AndAgg, Col, Count, DynCol, Max, Min, Or, Sum, Unique
+from frostdb_amd.logicalplan import OP_LT_EQ, And, AndAgg, BinaryExpr, Col, Count, DynCol, Max, Min, Or, Sum, Unique
 from tests.util import arrow_to_pydict, batch_rows, sort_key
 
 pytestmark = pytest.mark.gpu
@@ -101,7 +101,6 @@ def canon(d, key_cols, computed_keys):
 
 @pytest.mark.parametrize("seed", range(160))
 def test_fuzz_plan_vs_oracle(pp, seed, monkeypatch):
-    from oracle import OraclePlan
     rng = np.random.default_rng(10_000 + seed)
     if seed % 4 == 3:
         monkeypatch.setenv("FDB_NO_JIT", "1")
@@ -117,6 +116,11 @@ def test_fuzz_plan_vs_oracle(pp, seed, monkeypatch):
     for r in range(n_rec):
         drop = [c for c in ("labels.c", "labels.d") if rng.random() < 0.15]
         recs.append(random_batch(rng, int(rng.integers(1, 30_000)), drop=drop))
+    check_against_oracle(pp, filt, aggs, groups, recs, resident=seed % 2 == 0)
+
+
+def check_against_oracle(pp, filt, aggs, groups, recs, resident):
+    from oracle import OraclePlan
     o = OraclePlan(filt, aggs, groups, nchains=1)
     oracle_err = None
     try:
@@ -135,7 +139,6 @@ def test_fuzz_plan_vs_oracle(pp, seed, monkeypatch):
                     plan.Callback(r)
                 plan.Finish()
             return
-        resident = seed % 2 == 0
         keep = []
         for r in recs:
             if resident:
@@ -152,7 +155,7 @@ def test_fuzz_plan_vs_oracle(pp, seed, monkeypatch):
     agg_names = [a.Name() for a in aggs]
     key_cols = [c for c in want if c not in agg_names]
     assert sorted(got.keys()) == sorted(want.keys()), (got.keys(), want.keys())
-    computed = [g.name for g in groups if g.__class__.__name__ == "AliasExpr"] + [g.name for g in groups if g.name == "ts"]
+    computed = [g.name for g in groups if g.__class__.__name__ == "AliasExpr"] + [g.name for g in groups if g.name in ("ts", "small")]
     a, b = canon(got, key_cols, computed), canon(want, key_cols, computed)
     assert len(a) == len(b), (len(a), len(b), str(filt), agg_names, [g.name for g in groups])
     cols = key_cols + [c for c in got if c not in key_cols]
@@ -165,3 +168,80 @@ def test_fuzz_plan_vs_oracle(pp, seed, monkeypatch):
                 assert (x is None and y is None) or math.isclose(x, y, rel_tol=REL_TOL, abs_tol=1e-12), (c, x, y, str(filt))
             else:
                 assert x == y, (c, x, y, str(filt), agg_names)
+
+
+# ---- second family: plain string / binary columns, boolean columns and boolean projections ---------------------------------
+
+WORDS = ["", "a", "ab", "abc", "b", "ba", "zeta", "Zeta", "é", "value1", "value10", "value2"] + ["w%02d" % k for k in range(30)]
+
+
+def random_batch2(rng, n, drop=()):
+    def sarr(typ, nf, lo, hi):
+        pick = rng.integers(lo, hi, size=n)
+        return pa.array([WORDS[k] for k in pick], type=pa.string(), mask=rng.random(n) < nf).cast(typ)
+
+    lo = int(rng.integers(0, 10))
+    cols = {
+        "s.name": sarr([pa.string(), pa.large_string()][int(rng.integers(0, 2))], 0.1, lo, len(WORDS)),
+        "s.raw": sarr(pa.binary(), 0.0, 0, 8),
+        "labels.a": pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 4, size=n).astype(np.uint32), mask=rng.random(n) < 0.05),
+                                                   pa.array([b"a0", b"a1", b"a2", b"a3"], type=pa.binary())),
+        "ts": pa.array((1000 + rng.integers(0, 30, size=n) * 10).astype(np.int64)),
+        "ival": pa.array(rng.integers(-20, 20, size=n).astype(np.int64), mask=rng.random(n) < 0.1),
+        "fval": pa.array(rng.uniform(-5, 5, size=n), mask=rng.random(n) < 0.1),
+        "flag": pa.array(rng.random(n) < 0.6, mask=rng.random(n) < 0.15),
+    }
+    for d in drop:
+        cols.pop(d, None)
+    return pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols.keys()))
+
+
+def random_leaf2(rng):
+    k = int(rng.integers(0, 10))
+    w = WORDS[int(rng.integers(0, len(WORDS)))]
+    N = Col("s.name")
+    if k == 0:
+        return [N == w, N != w, N < w, N <= w, N > w, N >= w][int(rng.integers(0, 6))]
+    if k == 1:
+        return N.RegexMatch("^w[0-%d]" % rng.integers(0, 3)) if rng.random() < 0.5 else N.RegexNotMatch("a")
+    if k == 2:
+        return N.Contains(w) if rng.random() < 0.5 else N.NotContains("a")
+    if k == 3:
+        return [N == None, N != None, N.Contains(None)][int(rng.integers(0, 3))]  # noqa: E711
+    if k == 4:
+        return [Col("s.raw") == b"ab", Col("s.raw") > b"a", Col("s.raw").RegexMatch("^b")][int(rng.integers(0, 3))]
+    if k == 5:
+        return [Col("flag") == True, Col("flag") != True, Col("flag") == False, Col("flag") > False][int(rng.integers(0, 4))]  # noqa: E712
+    if k == 6:
+        return Col("s.missing") == "x" if rng.random() < 0.5 else Col("s.missing") < "x"
+    if k == 7:
+        return Col("labels.a") == "a1"
+    if k == 8:
+        return Col("ts") >= 1100
+    return Col("fval") > 0.0
+
+
+def random_filter2(rng, depth=0):
+    r = rng.random()
+    if depth >= 3 or r < 0.4:
+        return random_leaf2(rng)
+    if r < 0.7:
+        return And(random_filter2(rng, depth + 1), random_filter2(rng, depth + 1))
+    return Or(random_filter2(rng, depth + 1), random_filter2(rng, depth + 1))
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_fuzz_plain_strings_and_bools_vs_oracle(pp, seed):
+    rng = np.random.default_rng(20_000 + seed)
+    filt = random_filter2(rng) if rng.random() < 0.8 else None
+    I, F, T = Col("ival"), Col("fval"), Col("ts")
+    agg_pool = [Sum(I), Min(I), Max(F), Count(I), Sum(F), Sum(I * T), AndAgg(Col("flag")), Unique(I)]
+    aggs = [agg_pool[i] for i in rng.choice(len(agg_pool), size=int(rng.integers(0, 4)), replace=False)]
+    group_pool = [[Col("s.name")], [Col("s.raw")], [DynCol("s")], [Col("s.name"), Col("labels.a")], [DynCol("s"), Col("ts")],
+                  [Col("labels.a"), T > 1100], [Col("s.name"), And(I > 0, F < 1.5)], [Or(T == 1000, BinaryExpr(I, OP_LT_EQ, F))], [Col("s.raw"), (T / 100).Alias("h")]]
+    groups = group_pool[int(rng.integers(0, len(group_pool)))]
+    recs = []
+    for r in range(int(rng.integers(1, 4))):
+        drop = [c for c in ("s.raw",) if rng.random() < 0.15]
+        recs.append(random_batch2(rng, int(rng.integers(1, 20_000)), drop=drop))
+    check_against_oracle(pp, filt, aggs, groups, recs, resident=seed % 2 == 0)
