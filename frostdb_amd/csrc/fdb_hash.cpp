@@ -343,8 +343,8 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     OutColumn oc;
     oc.name = g.name;
     oc.length = (int64_t)n;
-    oc.format = g.kind == 0 ? "I" : g.is_bool ? "b" : "l";
-    if (n > 0 && !g.is_bool) { oc.backing = backing; oc.ext_values = h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }
+    oc.format = g.kind == 0 ? "I" : g.is_bool ? "b" : g.is_u64 ? "L" : "l";
+    if (n > 0) { oc.backing = backing; oc.ext_values = g.is_bool ? nullptr : h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }
     if (g.kind == 0 && !g.plain) set_dictionary(&oc, g.values, g.value_format);
     out->push_back(std::move(oc));
   }
@@ -368,12 +368,10 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   // post-processing that needs the data on the host: NULL counts, float64 MIN/MAX key decoding
   for (size_t c = 0; c < n_cols && n > 0; c++) {
     OutColumn& oc = (*out)[c];
-    if (gcols_[c].is_bool) {  // boolean projection key: 8-byte 0 / 1 on the device → Arrow's bit-packed bool, never NULL
+    if (gcols_[c].is_bool) {  // bool key: 8-byte 1 (false) / 2 (true) on the device → Arrow's bit-packed bool
       const unsigned long long* v = (const unsigned long long*)(h_block + off_key[c]);
       oc.values.assign((size_t)(n + 7) / 8 + 8, 0);
-      for (uint64_t i = 0; i < n; i++) if (v[i] != 0ull) oc.values[i >> 3] |= (uint8_t)(1u << (i & 7));
-      oc.null_count = 0;
-      continue;
+      for (uint64_t i = 0; i < n; i++) if (v[i] >= 2ull) oc.values[i >> 3] |= (uint8_t)(1u << (i & 7));
     }
     if (gcols_[c].kind == 0 && gcols_[c].plain)  // plain string / binary key column: entry indices → offsets + bytes
       set_plain_strings(&oc, (const uint32_t*)(h_block + off_key[c]), h_block + off_bits[c], (int64_t)n, gcols_[c].values, gcols_[c].value_format);
@@ -400,7 +398,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
       OutColumn& oc = (*out)[out_of_agg[j]];
       const unsigned long long* v = (const unsigned long long*)(h_block + off_val[1 + j]);
       oc.values.assign((size_t)(n + 7) / 8 + 8, 0);
-      for (uint64_t i = 0; i < n; i++) if (v[i] != 0ull) oc.values[i >> 3] |= (uint8_t)(1u << (i & 7));
+      for (uint64_t i = 0; i < n; i++) if (v[i] >= 2ull) oc.values[i >> 3] |= (uint8_t)(1u << (i & 7));  // MIN over 1 (false) / 2 (true)
     }
   }
   for (size_t j = 0; j < aggs_.size() && n > 0; j++) {
@@ -431,7 +429,7 @@ void Plan::group_schema(ArrowArray* out, ArrowSchema* out_schema) {
       oc.format = g.plain ? "i" : "I";
       set_dictionary(&oc, g.values, g.value_format);
     } else {
-      oc.format = g.is_bool ? "b" : "l";
+      oc.format = g.is_bool ? "b" : g.is_u64 ? "L" : "l";
     }
     cols.push_back(std::move(oc));
   }
@@ -462,18 +460,18 @@ void Plan::seed_groups(const ArrowArray* array, const ArrowSchema* schema) {
       is_agg = true;
     }
     if (is_agg) continue;
-    if (c.kind != ColKind::DICT && c.kind != ColKind::I64 && c.kind != ColKind::BOOL)
-      throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + ": only dictionary, int64 and computed bool columns can be group keys");
+    if (c.kind != ColKind::DICT && c.kind != ColKind::I64 && c.kind != ColKind::U64 && c.kind != ColKind::BOOL)
+      throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + ": only dictionary, string, int64, uint64 and bool columns can be group keys");
     const int kind = c.kind == ColKind::DICT ? 0 : 1;
     size_t gi = 0;
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == c.name) break;
     if (gi == gcols_.size()) {
       GroupColState g;
-      g.name = c.name; g.kind = kind; g.is_bool = c.kind == ColKind::BOOL; g.plain = kind == 0 && c.format == "i"; g.cap = 1; g.stride = 0;
+      g.name = c.name; g.kind = kind; g.is_bool = c.kind == ColKind::BOOL; g.is_u64 = c.kind == ColKind::U64; g.plain = kind == 0 && c.format == "i"; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
     GroupColState& g = gcols_[gi];
-    if (g.kind != kind || g.is_bool != (c.kind == ColKind::BOOL) || g.plain != (kind == 0 && c.format == "i")) throw Error(FDB_ERR_INVALID, "group column " + c.name + " has a different type in this plan");
+    if (g.kind != kind || g.is_bool != (c.kind == ColKind::BOOL) || g.is_u64 != (c.kind == ColKind::U64) || g.plain != (kind == 0 && c.format == "i")) throw Error(FDB_ERR_INVALID, "group column " + c.name + " has a different type in this plan");
     if (kind == 0) {
       std::shared_ptr<HostDict> d = read_dictionary(c);
       g.value_format = g.plain ? std::string(c.schema->dictionary->format) : d->value_format;  // (a plain column keeps a large type)
@@ -504,11 +502,11 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
     for (; gi < layout.gcols_.size(); gi++) if (layout.gcols_[gi].name == sg.name) break;
     if (gi == layout.gcols_.size()) {
       GroupColState g;
-      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.plain = sg.plain; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.is_u64 = sg.is_u64; g.plain = sg.plain; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
       layout.gcols_.push_back(std::move(g));
     }
     GroupColState& g = layout.gcols_[gi];
-    if (g.kind != sg.kind || g.plain != sg.plain || g.is_bool != sg.is_bool) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
+    if (g.kind != sg.kind || g.plain != sg.plain || g.is_bool != sg.is_bool || g.is_u64 != sg.is_u64) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
     if (sg.kind == 0) {
       g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());
       id_map[sc].assign(sg.values.size() + 1, 0);
@@ -623,11 +621,11 @@ void Plan::merge_hash(Plan& src) {
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == sg.name) break;
     if (gi == gcols_.size()) {
       GroupColState g;
-      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.plain = sg.plain; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.is_u64 = sg.is_u64; g.plain = sg.plain; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
     GroupColState& g = gcols_[gi];
-    if (g.kind != sg.kind || g.plain != sg.plain || g.is_bool != sg.is_bool) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
+    if (g.kind != sg.kind || g.plain != sg.plain || g.is_bool != sg.is_bool || g.is_u64 != sg.is_u64) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
     dst_of[sc] = (int)gi;
     if (sg.kind == 0) {
       g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());

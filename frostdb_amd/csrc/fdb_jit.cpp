@@ -152,6 +152,7 @@ std::string expr_valid(const std::vector<JitExprNode>& ex, int root, F col, V co
   return "true";
 }
 inline std::string expr_bits(const std::vector<JitExprNode>& ex, int root, const std::string& v) {
+  if (ex[(size_t)root].type == FDB_T_BOOL) return "(unsigned long long)(" + v + " + 1ll)";  // a bool key is 1 (false) / 2 (true), like a stored bool column
   return ex[(size_t)root].type == FDB_T_F64 ? ("(unsigned long long)__double_as_longlong(" + v + ")") : ("(unsigned long long)" + v);
 }
 

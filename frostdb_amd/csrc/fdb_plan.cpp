@@ -98,7 +98,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     const bool staged = (want == nullptr || (*want)(c.name));
     if (staged) {
       int64_t vb = 0;
-      if (c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::BOOL) vb = c.length * 8;  // (bool: widened to int64 0 / 1)
+      if (c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::BOOL) vb = c.length * 8;  // (bool: widened to int64 1 / 2)
       else if (c.kind == ColKind::DICT || c.kind == ColKind::STR) vb = c.length * 4;  // (plain strings: encoded below, one uint32 per row)
       if (vb > 0 || ((c.kind == ColKind::I64 || c.kind == ColKind::U64 || c.kind == ColKind::F64 || c.kind == ColKind::DICT || c.kind == ColKind::BOOL || c.kind == ColKind::STR))) {
         d.value_bytes = c.kind == ColKind::BOOL ? (c.length + 7) / 8 : vb;  // (algorithmic bytes: Arrow's bit-packed buffer)
@@ -154,11 +154,14 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     } else {
       d.d_values = dst;
       if (p.bytes == 0) continue;
-      if (c.kind == ColKind::BOOL) {  // Arrow booleans are bit-packed: the AND reducer reads them as int64 0 / 1
+      if (c.kind == ColKind::BOOL) {
+        // Arrow booleans are bit-packed; on the device a bool is an int64 holding 1 (false) or 2 (true) — the reference's own
+        // hash of a bool key (dynparquet/hashed.go:228-242; 0 is NULL), so a bool group key is an ordinary int64 key, a filter
+        // leaf an int64 compare and AND a MIN
         keep_i64.emplace_back((size_t)c.length);
         std::vector<int64_t>& wide = keep_i64.back();
         const uint8_t* bits = (const uint8_t*)c.values;
-        for (int64_t i = 0; i < c.length; i++) wide[(size_t)i] = (bits[(c.offset + i) >> 3] >> ((c.offset + i) & 7)) & 1;
+        for (int64_t i = 0; i < c.length; i++) wide[(size_t)i] = 1 + ((bits[(c.offset + i) >> 3] >> ((c.offset + i) & 7)) & 1);
         h2d(dst, wide.data(), p.bytes, "hipMemcpy(bool values)");
       } else if (c.kind == ColKind::STR) {
         const std::vector<uint32_t>* enc = nullptr;
@@ -240,7 +243,7 @@ Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
       aggs_.push_back(std::move(lo));
       aggs_.push_back(std::move(hi));
     } else if (a.func == FDB_AGG_AND) {
-      a.func = FDB_AGG_MIN; a.role = 3; a.null_value = 1ull;
+      a.func = FDB_AGG_MIN; a.role = 3; a.null_value = 2ull;  // (a NULL row counts as true = 2)
       aggs_.push_back(std::move(a));
     } else if (a.func == FDB_AGG_SUM || a.func == FDB_AGG_MIN || a.func == FDB_AGG_MAX || a.func == FDB_AGG_COUNT) {
       aggs_.push_back(std::move(a));
@@ -631,8 +634,8 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
   L->wide = 1;
   R->leaf_col[li] = ci;
   auto dbits = [](double d) { int64_t v; std::memcpy(&v, &d, 8); return v; };
-  if (c.kind == ColKind::BOOL) {  // staged as int64 0 / 1; Arrow orders false < true
-    if (e.lit.type == FDB_LIT_BOOL) { L->kind = FDB_LEAF_CMP_I64; L->lit = e.lit.i64 ? 1 : 0; return; }
+  if (c.kind == ColKind::BOOL) {  // staged as int64 1 (false) / 2 (true); Arrow orders false < true
+    if (e.lit.type == FDB_LIT_BOOL) { L->kind = FDB_LEAF_CMP_I64; L->lit = e.lit.i64 ? 2 : 1; return; }
   } else if (c.kind == ColKind::I64) {
     if (e.lit.type == FDB_LIT_INT64) { L->kind = FDB_LEAF_CMP_I64; L->lit = e.lit.i64; return; }
     if (e.lit.type == FDB_LIT_FLOAT64) { L->kind = FDB_LEAF_CMP_I64_F64; L->lit = dbits(e.lit.f64); return; }
@@ -825,10 +828,12 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
     bool matched = false;
     for (const GroupMatcher& m : matchers_) if (match_group(m, c.name)) { matched = true; break; }
     if (!matched) continue;
-    if (c.kind != ColKind::DICT && c.kind != ColKind::I64)  // HashArray panics on anything else it does not know (hashed.go:86-105)
-      throw Error(FDB_ERR_UNSUPPORTED, "group by on column type " + c.format + " (" + c.name + ") is not supported on the device path");
+    // HashArray (hashed.go:86-105): dictionary / string / binary by value, int64 / uint64 by identity, bool as 1 / 2; anything else panics
+    if (c.kind != ColKind::DICT && c.kind != ColKind::I64 && c.kind != ColKind::U64 && c.kind != ColKind::BOOL)
+      throw Error(FDB_ERR_UNSUPPORTED, "group by on column type " + c.format + " (" + c.name + ") is not supported");
     if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
     const int kind = c.kind == ColKind::DICT ? 0 : 1;
+    const bool key_bool = c.kind == ColKind::BOOL, key_u64 = c.kind == ColKind::U64;
     size_t gi = 0;
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == c.name) break;
     if (gi == gcols_.size()) {
@@ -837,12 +842,13 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
       g.name = c.name;
       g.kind = kind;
       if (kind == 0) { g.value_format = c.dict->value_format; g.plain = c.dict->plain; }
+      g.is_bool = key_bool; g.is_u64 = key_u64;
       g.cap = 1;
       g.stride = 0;
       gcols_.push_back(std::move(g));
     }
     GroupColState& g = gcols_[gi];
-    if (g.kind != kind || g.is_bool || (kind == 0 && g.plain != c.dict->plain))  // (the reference's key builder is typed by the first batch)
+    if (g.kind != kind || g.is_bool != key_bool || g.is_u64 != key_u64 || (kind == 0 && g.plain != c.dict->plain))  // (the reference's key builder is typed by the first batch)
       throw Error(FDB_ERR_UNSUPPORTED, "group column " + c.name + " changed type between batches");
     GroupRes gr;
     gr.gi = (int)gi; gr.ci = (int)ci; gr.kind = kind;
@@ -870,7 +876,7 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
       g.name = m.name; g.kind = 1; g.is_bool = is_bool; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
-    if (gcols_[gi].kind != 1 || gcols_[gi].is_bool != is_bool) throw Error(FDB_ERR_UNSUPPORTED, "group column " + m.name + " changed type between batches");
+    if (gcols_[gi].kind != 1 || gcols_[gi].is_bool != is_bool || gcols_[gi].is_u64) throw Error(FDB_ERR_UNSUPPORTED, "group column " + m.name + " changed type between batches");
     GroupRes gr;
     gr.gi = (int)gi; gr.ci = -1; gr.kind = 2; gr.expr_root = root;
     R.groups.push_back(std::move(gr));
@@ -909,7 +915,7 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
     int32_t t = c.kind == ColKind::I64 ? FDB_T_I64 : c.kind == ColKind::F64 ? FDB_T_F64 : FDB_T_NONE;
     if (A.role == 1 || A.role == 2) {  // ErrUnsupportedIsUniqueType (aggregate.go:679)
       if (c.kind != ColKind::I64) throw Error(FDB_ERR_UNSUPPORTED, "unsupported type for is unique aggregation, expected int64");
-    } else if (A.role == 3) {          // ErrUnsupportedAndType (aggregate.go:637); bool columns are staged as int64 0 / 1
+    } else if (A.role == 3) {          // ErrUnsupportedAndType (aggregate.go:637); bool columns are staged as int64 1 / 2
       if (c.kind != ColKind::BOOL) throw Error(FDB_ERR_UNSUPPORTED, "unsupported type for is and aggregation, expected bool");
       t = FDB_T_I64;
     }
@@ -1334,17 +1340,19 @@ void Plan::build_key_columns(const CompactState& cs, std::vector<OutColumn>* col
     c.name = g.name;
     c.length = n;
     c.validity.assign((size_t)(n + 7) / 8, 0);
-    if (g.kind == 1 && g.is_bool) {  // boolean projection: always valid (project.go:409-470), bit-packed values
+    if (g.kind == 1 && g.is_bool) {  // bool key (stored column or boolean projection): 1 = false, 2 = true on the device → bits
       c.format = "b";
-      c.validity.clear();
       c.values.assign((size_t)(n + 7) / 8 + 8, 0);
-      for (int64_t i = 0; i < n; i++)
-        if (cs.ivalid[gc][(size_t)i] && cs.ivals[gc][(size_t)i] != 0) c.values[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+      for (int64_t i = 0; i < n; i++) {
+        if (!cs.ivalid[gc][(size_t)i]) { c.null_count++; continue; }
+        c.validity[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+        if (cs.ivals[gc][(size_t)i] >= 2) c.values[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+      }
       cols->push_back(std::move(c));
       continue;
     }
-    if (g.kind == 1) {  // int64 key column
-      c.format = "l";
+    if (g.kind == 1) {  // int64 / uint64 key column
+      c.format = g.is_u64 ? "L" : "l";
       c.values.resize((size_t)n * 8);
       for (int64_t i = 0; i < n; i++) {
         const int64_t v = cs.ivalid[gc][(size_t)i] ? cs.ivals[gc][(size_t)i] : 0;
@@ -1396,7 +1404,7 @@ void Plan::build_agg_columns(const CompactState& cs, std::vector<OutColumn>* col
       c.format = "b";
       c.values.assign((size_t)(n + 7) / 8 + 8, 0);
       for (int64_t i = 0; i < n; i++)
-        if (cs.acc[j][(size_t)i] != 0ull) c.values[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));
+        if (cs.acc[j][(size_t)i] >= 2ull) c.values[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7));  // MIN over 1 (false) / 2 (true)
       cols->push_back(std::move(c));
       continue;
     }
@@ -1687,9 +1695,9 @@ void Plan::filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray
       set_plain_strings(&o, (const uint32_t*)idx_bytes.data(), o.validity.empty() ? nullptr : o.validity.data(), n, c.dict->values, c.dict->value_format);
     } else if (c.kind == ColKind::DICT) {
       set_dictionary(&o, c.dict->values, c.dict->value_format);
-    } else if (c.kind == ColKind::BOOL) {  // staged as int64 0 / 1, Arrow wants bits
+    } else if (c.kind == ColKind::BOOL) {  // staged as int64 1 / 2, Arrow wants bits
       std::vector<uint8_t> bits((size_t)(n + 7) / 8 + 8, 0);
-      for (int64_t i = 0; i < n; i++) { int64_t v; std::memcpy(&v, o.values.data() + (size_t)i * 8, 8); if (v) bits[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); }
+      for (int64_t i = 0; i < n; i++) { int64_t v; std::memcpy(&v, o.values.data() + (size_t)i * 8, 8); if (v >= 2) bits[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); }
       o.values = std::move(bits);
     }
     cols.push_back(std::move(o));

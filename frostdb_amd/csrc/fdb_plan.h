@@ -84,7 +84,7 @@ struct AggState {
   // Composite reducers ride on MIN / MAX accumulators (aggs_ is the PHYSICAL list, one accumulator array each):
   //   UNIQUE(x) (aggregate.go:677-732) = MIN(x) with NULL ↦ INT64_MIN  +  MAX(x) with NULL ↦ INT64_MAX: the group has one
   //     non-NULL value iff min == max (a NULL row drives the two apart); role 1 = the MIN half (emits the column), 2 = the MAX half
-  //   AND(x)    (aggregate.go:635-675) = MIN over the bool column widened to 0 / 1 with NULL ↦ 1 (NULLs are skipped); role 3
+  //   AND(x)    (aggregate.go:635-675) = MIN over the bool column widened to 1 (false) / 2 (true) with NULL ↦ 2 (NULLs are skipped); role 3
   int32_t role = 0;
   unsigned long long null_value = 0;  // what a NULL row contributes (FdbAgg::null_value)
 };
@@ -96,7 +96,8 @@ struct GroupColState {
   std::string name;
   int kind = 0;                                             // 0 dictionary column, 1 int64 column (hash table only)
   bool plain = false;                                       // kind 0 fed by a plain string / binary column: emitted as one, not as a dictionary
-  bool is_bool = false;                                     // kind 1 holding a boolean projection's 0 / 1: emitted as an Arrow bool column
+  bool is_u64 = false;                                      // kind 1 fed by a uint64 column: emitted as one
+  bool is_bool = false;                                     // kind 1 holding a bool (1 = false, 2 = true; a stored column or a boolean projection): emitted as an Arrow bool column
   int word = -1;                                            // hash table: first word of this column in the key tuple
   std::string value_format = "z";
   std::vector<std::string_view> values;                     // id - 1 → value (views into `owners`)

@@ -238,7 +238,7 @@ def unify_group_schemas(objs: Sequence[Sequence[tuple]]) -> pa.RecordBatch:
             it = pa.uint32() if kind == "dict" else pa.int32()
             arrays.append(pa.DictionaryArray.from_arrays(pa.array([], type=it), pa.array(values, type=vt)))
         else:
-            arrays.append(pa.array([], type=pa.float64() if ty == "double" else pa.bool_() if ty == "bool" else pa.int64()))
+            arrays.append(pa.array([], type=pa.float64() if ty == "double" else pa.bool_() if ty == "bool" else pa.uint64() if ty == "uint64" else pa.int64()))
         names.append(name)
     return pa.RecordBatch.from_arrays(arrays, names=names)
 

@@ -155,7 +155,7 @@ def check_against_oracle(pp, filt, aggs, groups, recs, resident):
     agg_names = [a.Name() for a in aggs]
     key_cols = [c for c in want if c not in agg_names]
     assert sorted(got.keys()) == sorted(want.keys()), (got.keys(), want.keys())
-    computed = [g.name for g in groups if g.__class__.__name__ == "AliasExpr"] + [g.name for g in groups if g.name in ("ts", "small")]
+    computed = [g.name for g in groups if g.__class__.__name__ == "AliasExpr"] + [g.name for g in groups if g.name in ("ts", "small", "u")]
     a, b = canon(got, key_cols, computed), canon(want, key_cols, computed)
     assert len(a) == len(b), (len(a), len(b), str(filt), agg_names, [g.name for g in groups])
     cols = key_cols + [c for c in got if c not in key_cols]
@@ -190,6 +190,7 @@ def random_batch2(rng, n, drop=()):
         "ival": pa.array(rng.integers(-20, 20, size=n).astype(np.int64), mask=rng.random(n) < 0.1),
         "fval": pa.array(rng.uniform(-5, 5, size=n), mask=rng.random(n) < 0.1),
         "flag": pa.array(rng.random(n) < 0.6, mask=rng.random(n) < 0.15),
+        "u": pa.array(rng.integers(0, 6, size=n).astype(np.uint64), mask=rng.random(n) < 0.1),
     }
     for d in drop:
         cols.pop(d, None)
@@ -238,6 +239,7 @@ def test_fuzz_plain_strings_and_bools_vs_oracle(pp, seed):
     agg_pool = [Sum(I), Min(I), Max(F), Count(I), Sum(F), Sum(I * T), AndAgg(Col("flag")), Unique(I)]
     aggs = [agg_pool[i] for i in rng.choice(len(agg_pool), size=int(rng.integers(0, 4)), replace=False)]
     group_pool = [[Col("s.name")], [Col("s.raw")], [DynCol("s")], [Col("s.name"), Col("labels.a")], [DynCol("s"), Col("ts")],
+                  [Col("flag")], [Col("flag"), Col("s.name")], [Col("u")], [Col("u"), Col("labels.a")],
                   [Col("labels.a"), T > 1100], [Col("s.name"), And(I > 0, F < 1.5)], [Or(T == 1000, BinaryExpr(I, OP_LT_EQ, F))], [Col("s.raw"), (T / 100).Alias("h")]]
     groups = group_pool[int(rng.integers(0, len(group_pool)))]
     recs = []

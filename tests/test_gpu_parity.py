@@ -811,6 +811,34 @@ def test_bool_column_filter_vs_oracle(pp):
         assert_same_result(got, run_oracle([b], f, [Sum(Col("value")), Count(Col("value"))], [Col("labels.code")]), ["labels.code", "sum(value)", "count(value)"])
 
 
+def test_bool_and_uint64_group_keys_vs_oracle(pp):
+    """HashArray hashes a bool key as 1 / 2 and NULL as 0 (dynparquet/hashed.go:228-242): false, true and NULL are three groups;
+    a uint64 key hashes by identity (0 ≡ NULL like int64). Key columns keep their type. Two chains merged, and AND() beside them."""
+    from frostdb_amd.logicalplan import AndAgg
+    rng = np.random.default_rng(8107)
+    batches = []
+    for n in (40_000, 25_000):
+        b = plain_batch(rng, n)
+        u = pa.array(rng.integers(1, 2000, n).astype(np.uint64) * np.uint64(1 << 53), type=pa.uint64(), mask=rng.random(n) < 0.05)
+        batches.append(b.append_column("shard", u))
+    aggs = [Sum(Col("value")), Count(Col("value")), AndAgg(Col("flag"))]
+    for groups in ([Col("flag")], [Col("flag"), Col("labels.code")], [Col("shard")], [Col("shard"), Col("flag"), Col("name")]):
+        want = run_oracle(batches, Col("value") > -40, aggs, groups, nchains=2)
+        p1 = pp.HashAggregatePlan(Col("value") > -40, aggs, groups)
+        p2 = pp.HashAggregatePlan(Col("value") > -40, aggs, groups)
+        try:
+            p1.Callback(batches[0]); p2.Callback(batches[1])
+            p1.Merge(p2)
+            rec = p1.Finish()
+        finally:
+            p1.Close(); p2.Close()
+        for g in groups:
+            assert rec.schema.field(g.name).type == batches[0].schema.field(g.name).type
+        if groups[0].name == "flag":
+            assert set(want["flag"]) == {True, False, None}
+        assert_same_result(arrow_to_pydict(rec), want, [g.name for g in groups] + [a.Name() for a in aggs])
+
+
 def test_plain_string_filter_errors(pp):
     rng = np.random.default_rng(8102)
     b = plain_batch(rng, 100)
