@@ -204,6 +204,13 @@ std::string Literal::str() const {
   }
 }
 
+bool ExprNode::regex_matches(const std::string& v) const {
+  if (re_fn == nullptr) return std::regex_search(v, *re);
+  const int32_t r = re_fn(re_user, lit.bytes.data(), (int64_t)lit.bytes.size(), (const uint8_t*)v.data(), (int64_t)v.size());
+  if (r < 0) throw Error(FDB_ERR_INVALID, "regexp: the host matcher rejected pattern " + lit.bytes);
+  return r != 0;
+}
+
 Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
   if (d == nullptr) throw Error(FDB_ERR_INVALID, "null plan descriptor");
   for (int32_t i = 0; i < d->n_filter; i++) {
@@ -219,8 +226,13 @@ Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
       if (e.column.empty()) throw Error(FDB_ERR_INVALID, "left side of binary expression must be a column");  // filter.go:91-93
       if (e.op == FDB_OP_REGEX_MATCH || e.op == FDB_OP_REGEX_NOT_MATCH) {
         if (e.lit.type != FDB_LIT_STRING && e.lit.type != FDB_LIT_BINARY) throw Error(FDB_ERR_INVALID, "regex literal must be a string");
-        try { e.re = std::make_shared<std::regex>(e.lit.bytes, std::regex::ECMAScript); }  // filter.go:105-124 compiles once per query
-        catch (const std::regex_error& ex) { throw Error(FDB_ERR_INVALID, std::string("regexp compile: ") + ex.what()); }
+        if (d->regex_match != nullptr) {
+          e.re_fn = d->regex_match; e.re_user = d->regex_user;
+          (void)e.regex_matches(std::string());  // surfaces a pattern that does not compile now, like regexp.Compile at plan build (filter.go:105-124)
+        } else {
+          try { e.re = std::make_shared<std::regex>(e.lit.bytes, std::regex::ECMAScript); }  // compiled once per query
+          catch (const std::regex_error& ex) { throw Error(FDB_ERR_INVALID, std::string("regexp compile: ") + ex.what()); }
+        }
       }
     } else {
       throw Error(FDB_ERR_UNSUPPORTED, std::string("binary expr ") + op_str(e.op) + ": unsupported boolean expression");  // filter.go:162-164
@@ -444,8 +456,8 @@ Truth leaf_truth(const ExprNode& e, const HostDict& dict) {
       case FDB_OP_LT_EQ: m = v.compare(e.lit.bytes) <= 0; break;
       case FDB_OP_GT: m = v.compare(e.lit.bytes) > 0; break;
       case FDB_OP_GT_EQ: m = v.compare(e.lit.bytes) >= 0; break;
-      case FDB_OP_REGEX_MATCH: m = std::regex_search(v, *e.re); break;
-      case FDB_OP_REGEX_NOT_MATCH: m = !std::regex_search(v, *e.re); break;
+      case FDB_OP_REGEX_MATCH: m = e.regex_matches(v); break;
+      case FDB_OP_REGEX_NOT_MATCH: m = !e.regex_matches(v); break;
     }
     t[i] = m ? 1 : 0;
   }
@@ -563,7 +575,7 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
   auto set_const = [&](bool v) { L->kind = FDB_LEAF_CONST; L->op = v ? 1 : 0; };
   if (ci < 0) {
     if (is_regex) {  // regexpfilter.go:23-33
-      const bool empty_match = std::regex_search(std::string(), *e.re);
+      const bool empty_match = e.regex_matches(std::string());
       const bool neg = e.op == FDB_OP_REGEX_NOT_MATCH;
       set_const((neg && !empty_match) || (!neg && empty_match));
       return;

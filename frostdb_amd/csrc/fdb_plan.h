@@ -72,7 +72,10 @@ struct ExprNode {
   int32_t op = 0, left = -1, right = -1;
   std::string column;
   Literal lit;
-  std::shared_ptr<std::regex> re;
+  std::shared_ptr<std::regex> re;                           // std::regex engine (no host matcher given)
+  fdb_regex_match_fn re_fn = nullptr;                       // the host application's engine (fdb_plan_desc.regex_match)
+  void* re_user = nullptr;
+  bool regex_matches(const std::string& v) const;           // unanchored match of this leaf's pattern against `v`
 };
 
 struct AggState {

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import ctypes
 from dataclasses import dataclass, field
-from typing import Any, List, Optional, Sequence, Union
+from typing import Any, Callable, List, Optional, Sequence, Union
 
 # logicalplan.Op (expr.go:17-35)
 OP_EQ, OP_NOT_EQ, OP_LT, OP_LT_EQ, OP_GT, OP_GT_EQ = 1, 2, 3, 4, 5, 6
@@ -298,7 +298,23 @@ class CPlanDesc(ctypes.Structure):
     _fields_ = [("filter", ctypes.POINTER(CExpr)), ("n_filter", ctypes.c_int32), ("filter_root", ctypes.c_int32),
                 ("aggs", ctypes.POINTER(CAggregation)), ("n_aggs", ctypes.c_int32), ("n_groups", ctypes.c_int32),
                 ("groups", ctypes.POINTER(CGroupExpr)), ("final_stage", ctypes.c_int32), ("n_projections", ctypes.c_int32),
-                ("projections", ctypes.POINTER(CProjection))]
+                ("projections", ctypes.POINTER(CProjection)), ("regex_match", ctypes.c_void_p), ("regex_user", ctypes.c_void_p)]
+
+
+# fdb_regex_match_fn: int32 (*)(void* user, const char* pattern, int64 pattern_len, const uint8* value, int64 value_len)
+REGEX_MATCH_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_char), ctypes.c_int64,
+                                  ctypes.POINTER(ctypes.c_char), ctypes.c_int64)
+
+
+def regex_matcher(search: Callable[[bytes, bytes], bool]):
+    """Wraps `search(pattern, value) -> bool` (unanchored; raise to reject the pattern) as the descriptor's host regex engine —
+    what the Go shim does with regexp.Regexp.Match. Keep the returned object alive as long as plans use it (to_desc does)."""
+    def fn(_user, pat, pat_len, val, val_len):
+        try:
+            return 1 if search(ctypes.string_at(pat, pat_len), ctypes.string_at(val, val_len) if val_len else b"") else 0
+        except Exception:  # noqa: BLE001 — a pattern the engine rejects
+            return -1
+    return REGEX_MATCH_FN(fn)
 
 
 @dataclass
@@ -312,7 +328,8 @@ class PlanDescHolder:
 
 
 def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], groups: Sequence[Column],
-            final_stage: bool = False) -> PlanDescHolder:
+            final_stage: bool = False, regex=None) -> PlanDescHolder:
+    """`regex`: a `regex_matcher(...)` object — the host application's regular-expression engine (fdb_plan_desc.regex_match)."""
     keep: List[Any] = []
     nodes: List[CExpr] = []
 
@@ -431,4 +448,7 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
         keep.append(pa_)
         d.projections = ctypes.cast(pa_, ctypes.POINTER(CProjection))
     d.n_projections = len(projs)
+    if regex is not None:
+        keep.append(regex)
+        d.regex_match = ctypes.cast(regex, ctypes.c_void_p)
     return PlanDescHolder(d, keep)

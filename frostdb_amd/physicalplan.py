@@ -152,10 +152,11 @@ class HashAggregatePlan:
     """One fused ``PredicateFilter → HashAggregate`` chain on one GPU."""
 
     def __init__(self, filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (),
-                 groups: Sequence[Column] = (), device: int = 0, final_stage: bool = False, desc=None):
+                 groups: Sequence[Column] = (), device: int = 0, final_stage: bool = False, desc=None, regex=None):
         """`desc`: a descriptor built once with `to_desc(filter_expr, aggs, groups, final_stage)` and shared by every chain /
-        execution of the same query (≙ the logical plan being built once and `physicalplan.Build` instantiating N chains)."""
-        self._desc = desc if desc is not None else to_desc(filter_expr, list(aggs), list(groups), final_stage)
+        execution of the same query (≙ the logical plan being built once and `physicalplan.Build` instantiating N chains).
+        `regex`: the host application's regex engine (`logicalplan.regex_matcher`), else std::regex."""
+        self._desc = desc if desc is not None else to_desc(filter_expr, list(aggs), list(groups), final_stage, regex=regex)
         self.aggs = list(aggs)
         self._ctor = (filter_expr, list(aggs), list(groups), device, final_stage, self._desc)
         out = ctypes.c_void_p()

@@ -153,6 +153,16 @@ typedef struct fdb_projection {
   int32_t root;
 } fdb_projection;
 
+/* Optional regular-expression engine of the HOST application. The reference compiles `=~` / `!~` literals with Go's regexp
+ * (RE2 syntax, filter.go:105-124) and matches unanchored (regexpfilter.go:84-166). The library evaluates a regex leaf once per
+ * DISTINCT value (dictionary entry) on the host — never per row, never on the device — so handing that evaluation back to the
+ * caller costs one call per distinct value and makes the result identical to the reference's by construction: the Go shim passes
+ * a cgo-exported function around regexp.Regexp.Match. Returns 1 = matches, 0 = does not, < 0 = the pattern
+ * does not compile / internal error (the call that triggered it fails with FDB_ERR_INVALID). Without one (NULL) the library
+ * uses std::regex (ECMAScript syntax): identical on the patterns both dialects share, RE2-only syntax ((?i), \pL, …) is
+ * rejected at fdb_plan_create. Must be callable from any thread that calls into the plan. */
+typedef int32_t (*fdb_regex_match_fn)(void* user, const char* pattern, int64_t pattern_len, const uint8_t* value, int64_t value_len);
+
 typedef struct fdb_plan_desc {
   const fdb_expr* filter;      /* NULL / n_filter == 0 ⇒ no PredicateFilter in the chain */
   int32_t n_filter;
@@ -166,6 +176,8 @@ typedef struct fdb_plan_desc {
                                   by result name and COUNT merges by SUM (aggregate.go:340-348, :965-969) */
   int32_t n_projections;       /* computed columns of the Projection between filter and aggregate (0 ⇒ none) */
   const fdb_projection* projections;
+  fdb_regex_match_fn regex_match;  /* NULL ⇒ std::regex */
+  void* regex_user;                /* passed back as `user` */
 } fdb_plan_desc;
 
 typedef struct fdb_plan fdb_plan;   /* one operator chain; push is single-threaded per handle (table.go:783-860) */

@@ -839,6 +839,47 @@ def test_bool_and_uint64_group_keys_vs_oracle(pp):
         assert_same_result(arrow_to_pydict(rec), want, [g.name for g in groups] + [a.Name() for a in aggs])
 
 
+def test_host_regex_engine_decides_regex_leaves(pp):
+    """fdb_plan_desc.regex_match: the host application's regex engine is asked once per distinct value (the Go shim passes
+    regexp.Regexp.Match, so `=~` means exactly what it means in the reference). Python's `re` plays the host here — its syntax
+    has (?i) and (?P<name>…), which std::regex does not: without the engine such a plan is rejected at create, with it the
+    selection equals re.search per row, on dictionary and plain columns, and for the missing-column rule (matches iff the
+    pattern matches the empty string, regexpfilter.go:23-33)."""
+    import re
+    from frostdb_amd.logicalplan import regex_matcher
+    calls = []
+
+    def search(pattern, value):
+        calls.append(value)
+        return re.search(pattern, value) is not None
+
+    engine = regex_matcher(search)
+    rng = np.random.default_rng(8108)
+    b = plain_batch(rng, 50_000, pa.binary())
+    names = b.column(0).to_pylist()
+    codes = b.column(2).to_pylist()
+    for pat in (b"(?i)^ZETA$", b"(?P<head>w0)[0-4]", b"^$", b"b+a?"):
+        with_engine = pp.HashAggregatePlan(Col("name").RegexMatch(pat.decode()), regex=engine)
+        try:
+            calls.clear()
+            got = with_engine.Select(b)
+            want = np.array([i for i, v in enumerate(names) if v is not None and re.search(pat, v)], dtype=np.uint32)
+            assert np.array_equal(got, want), pat
+            assert 0 < len(calls) <= len(set(names)) + 1  # per distinct value (+ the compile probe), not per row
+        finally:
+            with_engine.Close()
+    p = pp.HashAggregatePlan(And(Col("labels.code").RegexNotMatch("(?i)C[12]"), Col("labels.absent").RegexMatch("(?i)x*")), regex=engine)
+    try:
+        want = np.array([i for i, v in enumerate(codes) if v is not None and not re.search(b"(?i)C[12]", v)], dtype=np.uint32)
+        assert np.array_equal(p.Select(b), want)
+    finally:
+        p.Close()
+    with pytest.raises(pp.FdbError):  # std::regex (ECMAScript) has no inline flags
+        pp.HashAggregatePlan(Col("name").RegexMatch("(?i)^ZETA$"))
+    with pytest.raises(pp.FdbError):  # the host engine rejects the pattern: surfaces at create, like regexp.Compile at plan build
+        pp.HashAggregatePlan(Col("name").RegexMatch("(unclosed"), regex=engine)
+
+
 def test_plain_string_filter_errors(pp):
     rng = np.random.default_rng(8102)
     b = plain_batch(rng, 100)
