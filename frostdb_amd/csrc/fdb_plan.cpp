@@ -505,6 +505,18 @@ Truth subtree_truth(const std::vector<ExprNode>& nodes, int idx, const HostDict&
 
 static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved* R, FdbLeaf* L);
 
+// The truth table of filter node `node` over `dict`: computed by `make` once per (node, dictionary object).
+template <typename F>
+static std::shared_ptr<const Truth> cached_truth(Plan::Resolved* R, int node, const std::shared_ptr<HostDict>& dict, F make) {
+  if (R->truths != nullptr && node >= 0) {
+    std::shared_ptr<const Truth> t = R->truths->find(node, dict.get());
+    if (t) return t;
+  }
+  std::shared_ptr<const Truth> t = std::make_shared<const Truth>(make());
+  if (R->truths != nullptr && node >= 0) R->truths->put(node, dict, t);
+  return t;
+}
+
 // Turns a truth table over dictionary column `ci` into a leaf: ≤ 64 answers ride in a 64-bit immediate (no LDS,
 // no memory access at all), larger tables become a byte LUT staged in LDS.
 static void emit_truth_leaf(const Truth& t, const DeviceBatch& b, int ci, Plan::Resolved* R, FdbLeaf* L) {
@@ -542,7 +554,8 @@ static void emit_filter(const std::vector<ExprNode>& nodes, int idx, const Devic
       std::memset(&L, 0, sizeof(L));
       L.lut_lds = FDB_NO_LDS;
       L.slot = -1;
-      emit_truth_leaf(subtree_truth(nodes, idx, *b.cols[(size_t)col].dict), b, col, R, &L);
+      const std::shared_ptr<HostDict>& dict = b.cols[(size_t)col].dict;
+      emit_truth_leaf(*cached_truth(R, idx, dict, [&] { return subtree_truth(nodes, idx, *dict); }), b, col, R, &L);
       a.code[a.n_code++] = (uint8_t)li;
       return;
     }
@@ -564,6 +577,7 @@ static void emit_filter(const std::vector<ExprNode>& nodes, int idx, const Devic
   a.leaves[li] = L;
   // resolve (may append a LUT that refers to leaf index li)
   a.n_leaves++;
+  R->cur_node = idx;
   resolve_leaf(e, b, R, &a.leaves[li]);
   a.code[a.n_code++] = (uint8_t)li;
 }
@@ -608,7 +622,7 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
       if (e.lit.type != FDB_LIT_STRING && e.lit.type != FDB_LIT_BINARY)
         throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary operation (column/literal type combination) on " + c.name);
     }
-    emit_truth_leaf(leaf_truth(e, *c.dict), b, ci, R, L);
+    emit_truth_leaf(*cached_truth(R, R->cur_node, c.dict, [&] { return leaf_truth(e, *c.dict); }), b, ci, R, L);
     return;
   }
   if (c.kind == ColKind::DICT) {
@@ -629,7 +643,7 @@ static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved
       R->count(b, ci, /*values=*/false);  // the index buffer is not read by this leaf: only the bitmap counts
       return;
     }
-    emit_truth_leaf(leaf_truth(e, *c.dict), b, ci, R, L);
+    emit_truth_leaf(*cached_truth(R, R->cur_node, c.dict, [&] { return leaf_truth(e, *c.dict); }), b, ci, R, L);
     return;
   }
   if (is_regex) throw Error(FDB_ERR_UNSUPPORTED, "ArrayScalarRegexMatch: unsupported type on the device path: " + c.format);
@@ -832,6 +846,7 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
   FdbScanArgs& a = R.args;
   a.n_rows = b.rows;
   int max_depth = 0;
+  R.truths = &truth_cache_;
   if (filter_root_ >= 0) emit_filter(filter_, filter_root_, b, &R, 0, &max_depth);
 
   // group columns: every field matched by a matcher, in the record's field order (aggregate.go:286-303)
@@ -1639,6 +1654,7 @@ void Plan::select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* 
   std::memset(&R.args, 0, sizeof(R.args));
   R.args.n_rows = b->rows;
   int max_depth = 0;
+  R.truths = &truth_cache_;
   emit_filter(filter_, filter_root_, *b, &R, 0, &max_depth);
   *n_selected = 0;
   if (b->rows == 0) return;

@@ -68,6 +68,28 @@ struct Literal {
   std::string str() const;
 };
 
+// Truth tables of filter leaves (one answer per dictionary entry + one for NULL) are kept per (filter node, dictionary):
+// dictionaries with equal content are ONE object (read_dictionary / encode_plain intern them), the parts of a table mostly share
+// theirs, and a regex leaf costs a regex match per entry — with the host's engine (fdb_plan_desc.regex_match) a call back into
+// the application per entry.
+struct TruthCache {
+  struct Entry { std::shared_ptr<HostDict> dict; std::shared_ptr<const std::vector<uint8_t>> truth; };
+  std::unordered_map<uint64_t, std::vector<Entry>> by_key;  // key = node index mixed with the dictionary's address
+  size_t entries = 0;
+  static uint64_t key(int node, const HostDict* d) { return (uint64_t)(uintptr_t)d * 0x9E3779B97F4A7C15ull + (uint64_t)node; }
+  std::shared_ptr<const std::vector<uint8_t>> find(int node, const HostDict* d) const {
+    auto it = by_key.find(key(node, d));
+    if (it == by_key.end()) return nullptr;
+    for (const Entry& e : it->second) if (e.dict.get() == d) return e.truth;
+    return nullptr;
+  }
+  void put(int node, const std::shared_ptr<HostDict>& d, std::shared_ptr<const std::vector<uint8_t>> t) {
+    if (entries >= 4096) { by_key.clear(); entries = 0; }  // (bounded: a scan over parts with ever-changing dictionaries)
+    by_key[key(node, d.get())].push_back(Entry{d, std::move(t)});
+    entries++;
+  }
+};
+
 struct ExprNode {
   int32_t op = 0, left = -1, right = -1;
   std::string column;
@@ -197,6 +219,7 @@ class Plan {
  private:
   const char* last_kernel_ = "";  // name of the scan kernel of the latest push
   bool references(const std::string& column) const;
+  TruthCache truth_cache_;
   std::vector<Projection> projs_;
   const Projection* find_projection(const std::string& name) const;
   // Appends the nodes of `p` to R->args.expr (columns resolved against `b`, types checked); returns the root's index.

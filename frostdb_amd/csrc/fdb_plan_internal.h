@@ -47,6 +47,8 @@ struct GroupRes {
 };
 
 struct Plan::Resolved {
+  TruthCache* truths = nullptr;           // the plan's cache
+  int cur_node = -1;                      // filter node being resolved
   FdbScanArgs args;
   Blob blob;
   std::vector<PendingLut> luts;

@@ -866,6 +866,8 @@ def test_host_regex_engine_decides_regex_leaves(pp):
             want = np.array([i for i, v in enumerate(names) if v is not None and re.search(pat, v)], dtype=np.uint32)
             assert np.array_equal(got, want), pat
             assert 0 < len(calls) <= len(set(names)) + 1  # per distinct value (+ the compile probe), not per row
+            calls.clear()
+            assert np.array_equal(with_engine.Select(b), want) and not calls  # same values again: the truth table is remembered
         finally:
             with_engine.Close()
     p = pp.HashAggregatePlan(And(Col("labels.code").RegexNotMatch("(?i)C[12]"), Col("labels.absent").RegexMatch("(?i)x*")), regex=engine)
