@@ -397,4 +397,56 @@ void export_record(std::vector<OutColumn>&& cols_in, int64_t rows, ArrowArray* o
   out_schema->private_data = h;
 }
 
+void roundtrip_record(const HostRecordView& view, ArrowArray* out, ArrowSchema* out_schema) {
+  std::vector<OutColumn> cols;
+  for (const HostColView& c : view.cols) {
+    OutColumn o;
+    o.name = c.name;
+    o.length = c.length;
+    o.null_count = c.null_count;
+    if (c.null_count > 0) {
+      o.validity.assign((size_t)(c.length + 7) / 8 + 8, 0);
+      copy_bits(c.validity, c.offset, c.length, o.validity.data());
+    }
+    switch (c.kind) {
+      case ColKind::I64: case ColKind::U64: case ColKind::F64:
+        o.format = c.format;
+        o.values.resize((size_t)c.length * 8);
+        if (c.length > 0) std::memcpy(o.values.data(), (const unsigned char*)c.values + (size_t)c.offset * 8, (size_t)c.length * 8);
+        break;
+      case ColKind::BOOL:
+        o.format = "b";
+        o.values.assign((size_t)(c.length + 7) / 8 + 8, 0);
+        if (c.length > 0) copy_bits((const uint8_t*)c.values, c.offset, c.length, o.values.data());
+        break;
+      case ColKind::DICT: {
+        const std::shared_ptr<HostDict> d = read_dictionary(c);
+        o.format = "I";
+        o.values.resize((size_t)c.length * 4);
+        uint32_t* idx = (uint32_t*)o.values.data();
+        for (int64_t i = 0; i < c.length; i++) {
+          switch (c.index_width) {
+            case 1: idx[i] = ((const uint8_t*)c.values)[c.offset + i]; break;
+            case 2: idx[i] = ((const uint16_t*)c.values)[c.offset + i]; break;
+            case 4: idx[i] = ((const uint32_t*)c.values)[c.offset + i]; break;
+            default: idx[i] = (uint32_t)((const uint64_t*)c.values)[c.offset + i]; break;
+          }
+        }
+        set_dictionary(&o, d->values, d->value_format);
+        break;
+      }
+      case ColKind::STR: {
+        std::vector<uint32_t> idx;
+        const std::shared_ptr<HostDict> d = encode_plain(c, &idx);
+        set_plain_strings(&o, idx.data(), o.validity.empty() ? nullptr : o.validity.data(), c.length, d->values, d->value_format);
+        break;
+      }
+      default:
+        throw Error(FDB_ERR_UNSUPPORTED, "column type " + c.format + " (" + c.name + ") is not supported");
+    }
+    cols.push_back(std::move(o));
+  }
+  export_record(std::move(cols), view.rows, out, out_schema);
+}
+
 }  // namespace fdb

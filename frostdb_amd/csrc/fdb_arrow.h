@@ -97,4 +97,8 @@ void set_plain_strings(OutColumn* oc, const uint32_t* idx, const uint8_t* valid_
 // release callbacks free that holder.
 void export_record(std::vector<OutColumn>&& cols, int64_t rows, ArrowArray* out, ArrowSchema* out_schema);
 
+// Host-only: `view` → OutColumns through the same code push / finish use (read_dictionary, encode_plain, copy_bits,
+// set_dictionary, set_plain_strings) → exported record. Throws FDB_ERR_UNSUPPORTED for column types the path does not handle.
+void roundtrip_record(const HostRecordView& view, ArrowArray* out, ArrowSchema* out_schema);
+
 }  // namespace fdb

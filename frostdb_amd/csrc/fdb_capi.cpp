@@ -47,6 +47,15 @@ int fdb_device_count(int* n_devices) {
   });
 }
 
+int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  return guard(nullptr, [&] {
+    if (out == nullptr || out_schema == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null output");
+    fdb::HostRecordView view;
+    fdb::view_record(batch, schema, &view);
+    fdb::roundtrip_record(view, out, out_schema);
+  });
+}
+
 int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s) {
   return guard(nullptr, [&] {
     if (gb_per_s == nullptr || bytes < (1 << 20) || reps < 1) throw fdb::Error(FDB_ERR_INVALID, "fdb_read_ceiling: bytes >= 1 MiB, reps >= 1");

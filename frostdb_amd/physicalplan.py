@@ -92,6 +92,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_hash_import.argtypes = [vp, vp, ctypes.c_int64]
     L.fdb_read_ceiling.argtypes = [ctypes.c_int, ctypes.c_int64, i32, ctypes.POINTER(ctypes.c_double)]
     L.fdb_plan_last_kernel.argtypes = [vp]
+    L.fdb_arrow_roundtrip.argtypes = [vp, vp, vp, vp]
     L.fdb_plan_last_kernel.restype = ctypes.c_char_p
     _lib = L
     return L
@@ -104,6 +105,16 @@ def read_ceiling(device: int = 0, nbytes: int = 1 << 31, reps: int = 5) -> float
     if rc != 0:
         raise FdbError(rc, lib().fdb_last_error().decode())
     return out.value
+
+
+def arrow_roundtrip(record: pa.RecordBatch) -> pa.RecordBatch:
+    """Host-only self-check (fdb_arrow_roundtrip): the record through the library's Arrow import and export code, no device."""
+    arr, sch = ArrowArray(), ArrowSchema()
+    with ExportedBatch(record) as ex:
+        rc = lib().fdb_arrow_roundtrip(ctypes.addressof(ex.array), ctypes.addressof(ex.schema), ctypes.addressof(arr), ctypes.addressof(sch))
+    if rc != 0:
+        _raise(rc, lib().fdb_last_error().decode())
+    return import_batch(arr, sch)
 
 
 def device_count() -> int:

@@ -192,6 +192,13 @@ int fdb_device_count(int* n_devices);
  * `bytes` of HBM through a load-only kernel `reps` times (hipEvent-timed, one launch each) and returns the best rate. */
 int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s);
 
+/* Host-only self-check of the Arrow C data code every entry point below relies on — what fdb_plan_push reads (column views
+ * at any offset, dictionaries with any index width, plain string / binary columns encoded to distinct values + one id per row)
+ * and what fdb_plan_finish / fdb_plan_filter write (dictionary, plain string, bool and fixed-width columns): `batch` comes back
+ * in `out` with every column's type, values and NULLs unchanged, except that dictionary indices are uint32 and dictionaries with
+ * large value types are narrowed. No device is touched, so it runs where there is no GPU. */
+int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out, struct ArrowSchema* out_schema);
+
 /* ---- plan life cycle (≙ physicalplan.Build for one chain, physicalplan.go:417-474) -------------- */
 int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
 /* ≙ PhysicalPlan.Callback: borrows `batch` for the duration of the call only (the reference releases

@@ -79,3 +79,50 @@ def test_invalid_descriptors_are_rejected_without_a_gpu(built_lib):
     out = ctypes.c_void_p()
     rc = L.fdb_plan_create(ctypes.byref(d), 0, ctypes.byref(out))
     assert rc == 2 and b"unsupported boolean expression" in L.fdb_last_error()
+
+
+def test_arrow_import_export_roundtrip_without_a_gpu(built_lib):
+    """fdb_arrow_roundtrip: the host code behind push (column views at an offset, dictionaries of any index width, plain string
+    columns encoded to distinct values + ids) and behind finish / filter (dictionary, plain string, bool, fixed-width output) —
+    values, NULLs and types survive; dictionary indices come back as uint32."""
+    import numpy as np
+    import pyarrow as pa
+    from frostdb_amd import physicalplan as pp
+    rng = np.random.default_rng(5)
+    n = 1003
+    words = ["", "a", "é", "abc\x00d", "zeta"] + ["w%d" % k for k in range(50)]
+
+    def strs(typ, null_frac):
+        return pa.array([words[k] for k in rng.integers(0, len(words), n)], type=pa.string(), mask=rng.random(n) < null_frac).cast(typ)
+
+    def dic(index_type, value_type, null_frac):
+        idx = pa.array(rng.integers(0, 7, n), type=index_type, mask=rng.random(n) < null_frac)
+        return pa.DictionaryArray.from_arrays(idx, pa.array(["v%d" % k for k in range(7)], type=pa.string()).cast(value_type))
+
+    cols = {
+        "i": pa.array(rng.integers(-9, 9, n), type=pa.int64(), mask=rng.random(n) < 0.1),
+        "u": pa.array(rng.integers(0, 9, n).astype(np.uint64) << np.uint64(60), type=pa.uint64()),
+        "f": pa.array(rng.normal(size=n), mask=rng.random(n) < 0.5),
+        "b": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.2),
+        "s": strs(pa.string(), 0.1), "z": strs(pa.binary(), 0.0), "S": strs(pa.large_string(), 0.3), "Z": strs(pa.large_binary(), 1.0),
+        "d8": dic(pa.int8(), pa.binary(), 0.1), "d16": dic(pa.uint16(), pa.string(), 0.0),
+        "d32": dic(pa.uint32(), pa.large_string(), 0.2), "d64": dic(pa.int64(), pa.large_binary(), 0.05),
+    }
+    full = pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols.keys()))
+    for rec in (full, full.slice(0, 0), full.slice(13, 700), full.slice(1001, 2)):  # column offsets, byte-unaligned bitmaps, empty
+        out = pp.arrow_roundtrip(rec)
+        assert out.num_rows == rec.num_rows and out.schema.names == rec.schema.names
+        for name in rec.schema.names:
+            a, b = rec.column(name), out.column(name)
+            if pa.types.is_dictionary(a.type):
+                assert b.type.index_type == pa.uint32()
+                assert pa.types.is_string(b.type.value_type) == (pa.types.is_string(a.type.value_type) or pa.types.is_large_string(a.type.value_type))
+                a, b = a.dictionary_decode(), b.dictionary_decode()
+                assert [None if v is None else (v.encode() if isinstance(v, str) else v) for v in a.to_pylist()] == \
+                       [None if v is None else (v.encode() if isinstance(v, str) else v) for v in b.to_pylist()], name
+            else:
+                assert b.type == a.type, (name, a.type, b.type)
+                assert a.to_pylist() == b.to_pylist(), name
+            assert b.null_count == a.null_count, name
+    with pytest.raises(pp.FdbError):
+        pp.arrow_roundtrip(pa.RecordBatch.from_arrays([pa.array([[1], [2]])], names=["list"]))
