@@ -47,6 +47,19 @@ int fdb_device_count(int* n_devices) {
   });
 }
 
+int fdb_plan_explain(const fdb_plan_desc* desc, char* buf, int64_t capacity, int64_t* needed) {
+  return guard(nullptr, [&] {
+    fdb::Plan plan(desc, 0, /*explain_only=*/true);
+    const std::string s = plan.draw();
+    if (needed != nullptr) *needed = (int64_t)s.size() + 1;
+    if (buf != nullptr && capacity > 0) {
+      const size_t n = std::min((size_t)capacity - 1, s.size());
+      std::memcpy(buf, s.data(), n);
+      buf[n] = 0;
+    }
+  });
+}
+
 int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out, struct ArrowSchema* out_schema) {
   return guard(nullptr, [&] {
     if (out == nullptr || out_schema == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null output");

@@ -211,7 +211,7 @@ bool ExprNode::regex_matches(const std::string& v) const {
   return r != 0;
 }
 
-Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
+Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(device) {
   if (d == nullptr) throw Error(FDB_ERR_INVALID, "null plan descriptor");
   for (int32_t i = 0; i < d->n_filter; i++) {
     const fdb_expr& fe = d->filter[i];
@@ -296,6 +296,7 @@ Plan::Plan(const fdb_plan_desc* d, int device) : device_(device) {
     }
     projs_.push_back(std::move(P));
   }
+  if (explain_only) return;  // fdb_plan_explain: the descriptor is validated and drawn, nothing can be pushed
   hip_check(hipSetDevice(device_), "hipSetDevice");
   ctx_ = Context::acquire(device_);
   stream_ = ctx_->stream;

@@ -164,7 +164,7 @@ class Context;  // per-device stream + cached device/pinned memory (fdb_context.
 
 class Plan {
  public:
-  Plan(const fdb_plan_desc* desc, int device);
+  Plan(const fdb_plan_desc* desc, int device, bool explain_only = false);
   ~Plan();
 
   void push(const ArrowArray* array, const ArrowSchema* schema);        // ≙ Callback

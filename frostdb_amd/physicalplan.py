@@ -93,6 +93,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_read_ceiling.argtypes = [ctypes.c_int, ctypes.c_int64, i32, ctypes.POINTER(ctypes.c_double)]
     L.fdb_plan_last_kernel.argtypes = [vp]
     L.fdb_arrow_roundtrip.argtypes = [vp, vp, vp, vp]
+    L.fdb_plan_explain.argtypes = [vp, ctypes.c_char_p, i64, P(i64)]
     L.fdb_plan_last_kernel.restype = ctypes.c_char_p
     _lib = L
     return L
@@ -105,6 +106,17 @@ def read_ceiling(device: int = 0, nbytes: int = 1 << 31, reps: int = 5) -> float
     if rc != 0:
         raise FdbError(rc, lib().fdb_last_error().decode())
     return out.value
+
+
+def explain(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (), groups: Sequence[Column] = (), final_stage: bool = False) -> str:
+    """≙ Draw() of the operators this descriptor builds (`PredicateFilter (…) - HashAggregate (… by …)`), no device needed."""
+    desc = to_desc(filter_expr, list(aggs), list(groups), final_stage)
+    buf = ctypes.create_string_buffer(4096)
+    need = ctypes.c_int64()
+    rc = lib().fdb_plan_explain(ctypes.addressof(desc.desc), buf, len(buf), ctypes.byref(need))
+    if rc != 0:
+        _raise(rc, lib().fdb_last_error().decode())
+    return buf.value.decode()
 
 
 def arrow_roundtrip(record: pa.RecordBatch) -> pa.RecordBatch:

@@ -235,6 +235,10 @@ int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema
                     uint32_t* indices, int64_t capacity, int64_t* n_selected);
 /* ≙ PhysicalPlan.Draw: "PredicateFilter (…) - HashAggregate (sum(value) by labels.path)". Owned by the plan. */
 const char* fdb_plan_draw(fdb_plan* plan);
+/* The same string for a descriptor, without creating a plan or touching a device (≙ `explain`: the operator strings of
+ * logictest/testdata/plan/{aggregate,filter}/…): validates `desc` like fdb_plan_create, writes at most `capacity` bytes
+ * (NUL-terminated) to `buf` and the size needed to `*needed`. */
+int fdb_plan_explain(const fdb_plan_desc* desc, char* buf, int64_t capacity, int64_t* needed);
 const char* fdb_plan_last_error(const fdb_plan* plan);
 /* ≙ PhysicalPlan.Close: frees every host and device buffer of the plan. NULL is a no-op. */
 void fdb_plan_close(fdb_plan* plan);

@@ -342,3 +342,48 @@ DISTINCT_PROJ_CASES = [
          groups=[L(1), TS, Col("value") > 0], out=["labels.label1", "timestamp", "value > 0"],
          expected=[(b"value1", 0, True), (b"value2", 1, True)]),
 ]
+
+
+# ---- explain vectors: the operator strings (PhysicalPlan.Draw) of the fused operators -------------------------------------
+# logictest/testdata/plan/{aggregate/aggregate, aggregate/window, filter/filter}: each expected string is the fragment(s) of the
+# reference's explain line that belong to the operators this library replaces (PredicateFilter, the per-chain HashAggregate).
+def _explain_cases():
+    from frostdb_amd.logicalplan import And, Col, Count, DynCol, Max, Min, Sum
+    V, T = Col("value"), Col("timestamp")
+    A = "logictest/testdata/plan/aggregate/aggregate"
+    return [
+        dict(id="static_and_dynamic_member", cite=A + ":8-10", filter=None, aggs=[Sum(V)], groups=[Col("example_type"), Col("labels.label1")],
+             expected="HashAggregate (sum(value) by example_type,labels.label1)"),
+        dict(id="static_and_dynamic_set", cite=A + ":14-16", filter=None, aggs=[Sum(V)], groups=[Col("example_type"), DynCol("labels")],
+             expected="HashAggregate (sum(value) by example_type,labels)"),
+        dict(id="dynamic_set_first", cite=A + ":21-23", filter=None, aggs=[Sum(V)], groups=[DynCol("labels"), Col("example_type")],
+             expected="HashAggregate (sum(value) by labels,example_type)"),
+        dict(id="eq_filter", cite=A + ":35-37", filter=Col("example_type") == "some_value", aggs=[Sum(V)], groups=[DynCol("labels")],
+             expected="PredicateFilter (example_type == some_value) - HashAggregate (sum(value) by labels)"),
+        dict(id="eq_filter_two_groups", cite=A + ":40-42", filter=Col("example_type") == "some_value", aggs=[Sum(V)], groups=[DynCol("labels"), T],
+             expected="PredicateFilter (example_type == some_value) - HashAggregate (sum(value) by labels,timestamp)"),
+        dict(id="gt_filter", cite=A + ":46-48", filter=Col("example_type") > "some_value", aggs=[Sum(V)], groups=[DynCol("labels")],
+             expected="PredicateFilter (example_type > some_value) - HashAggregate (sum(value) by labels)"),
+        dict(id="int_filter", cite=A + ":52-54", filter=T >= 1, aggs=[Sum(V)], groups=[Col("labels.label1")],
+             expected="PredicateFilter (timestamp >= 1) - HashAggregate (sum(value) by labels.label1)"),
+        dict(id="two_aggs", cite=A + ":57-59", filter=None, aggs=[Sum(V), Count(V)], groups=[Col("labels.label2")],
+             expected="HashAggregate (sum(value),count(value) by labels.label2)"),
+        dict(id="math_agg", cite=A + ":67-69", filter=None, aggs=[Sum(V * T)], groups=[Col("stacktrace")],
+             expected="HashAggregate (sum(value * timestamp) by stacktrace)"),
+        dict(id="avg_lowered", cite=A + ":72-74", filter=None, aggs=[Sum(V), Count(V)], groups=[Col("stacktrace")],
+             expected="HashAggregate (sum(value),count(value) by stacktrace)"),
+        dict(id="four_aggs", cite=A + ":77-79", filter=None, aggs=[Max(V), Min(V), Sum(V), Count(V)], groups=[Col("labels.label1")],
+             expected="HashAggregate (max(value),min(value),sum(value),count(value) by labels.label1)"),
+        dict(id="window_alias_key", cite="logictest/testdata/plan/aggregate/window:7-9", filter=None, aggs=[Sum(V)],
+             groups=[(T / 1000 * 1000).Alias("timestamp_bucket")], expected="HashAggregate (sum(value) by timestamp_bucket)"),
+        dict(id="contains", cite="logictest/testdata/plan/filter/filter:5-7", filter=Col("stacktrace").Contains("ack"), aggs=[], groups=[],
+             expected="PredicateFilter (stacktrace contains ack)"),
+        dict(id="not_contains", cite="logictest/testdata/plan/filter/filter:10-12", filter=Col("stacktrace").NotContains("ack"), aggs=[], groups=[],
+             expected="PredicateFilter (stacktrace not contains ack)"),
+        dict(id="and_of_contains", cite="logictest/testdata/plan/filter/filter:15-17",
+             filter=And(Col("labels.label1").NotContains("ue2"), Col("stacktrace").Contains("ack")), aggs=[], groups=[],
+             expected="PredicateFilter ((labels.label1 not contains ue2 AND stacktrace contains ack))"),
+    ]
+
+
+EXPLAIN_CASES = _explain_cases()

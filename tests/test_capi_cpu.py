@@ -126,3 +126,24 @@ def test_arrow_import_export_roundtrip_without_a_gpu(built_lib):
             assert b.null_count == a.null_count, name
     with pytest.raises(pp.FdbError):
         pp.arrow_roundtrip(pa.RecordBatch.from_arrays([pa.array([[1], [2]])], names=["list"]))
+
+
+def _explain_cases():
+    from tests.golden import logictest_cases as G
+    return G.EXPLAIN_CASES
+
+
+@pytest.mark.parametrize("case", _explain_cases(), ids=[c["id"] for c in _explain_cases()])
+def test_explain_strings_match_the_reference_plan_vectors(built_lib, case):
+    """PhysicalPlan.Draw of the fused operators vs the reference's `explain` vectors (logictest/testdata/plan/…): the operator
+    strings a FrostDB user sees for the part of the plan this library replaces. Host-only (fdb_plan_explain)."""
+    from frostdb_amd import physicalplan as pp
+    got = pp.explain(case["filter"], case["aggs"], case["groups"])
+    assert got == case["expected"] + " [gfx950]", case["cite"]  # (the suffix names the executor, like the reference's "[concurrent]")
+
+
+def test_explain_validates_like_create(built_lib):
+    from frostdb_amd import physicalplan as pp
+    from frostdb_amd.logicalplan import Col, Sum
+    with pytest.raises(pp.FdbError):  # a regex std::regex cannot compile is rejected at plan build, without a device too
+        pp.explain(Col("labels.x").RegexMatch("(unclosed"), [Sum(Col("value"))], [])
