@@ -165,6 +165,38 @@ def _alltoall_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def test_group_schema_agreement_keeps_key_column_types():
+    """Schema agreement for the hash-partitioned exchange (host logic): dictionary columns unite their value sets; a PLAIN string /
+    binary key column travels as its value set too (signed index type is the marker fdb_plan_group_schema / fdb_plan_seed_groups
+    use) and keeps its own type, large or not; int64 / uint64 / bool key columns and the aggregate value types pass through."""
+    from frostdb_amd.distributed import _schema_to_obj, unify_group_schemas
+
+    def rec(cols):
+        return pa.RecordBatch.from_arrays([c for _, c in cols], names=[n for n, _ in cols])
+
+    def dic(index_type, values, value_type):
+        return pa.DictionaryArray.from_arrays(pa.array([], type=index_type), pa.array(values, type=value_type))
+
+    r0 = rec([("labels.a", dic(pa.uint32(), [b"x", b"y"], pa.binary())), ("user", dic(pa.int32(), ["u1", "u2"], pa.string())),
+              ("raw", dic(pa.int32(), [b"r"], pa.large_binary())), ("flag", pa.array([], type=pa.bool_())),
+              ("shard", pa.array([], type=pa.uint64())), ("sum(value)", pa.array([], type=pa.float64()))])
+    r1 = rec([("user", dic(pa.int32(), ["u2", "u3"], pa.string())), ("labels.a", dic(pa.uint32(), [b"y", b"z"], pa.binary())),
+              ("ts", pa.array([], type=pa.int64())), ("flag", pa.array([], type=pa.bool_()))])
+    objs = [_schema_to_obj(r0), _schema_to_obj(r1)]
+    assert [o[1] for o in objs[0]] == ["dict", "strs", "strs", "plain", "plain", "plain"]
+    s = unify_group_schemas(objs)
+    assert s.num_rows == 0 and s.schema.names == ["labels.a", "user", "raw", "flag", "shard", "sum(value)", "ts"]
+    t = {f.name: f.type for f in s.schema}
+    assert t["labels.a"] == pa.dictionary(pa.uint32(), pa.binary()) and s.column(0).dictionary.to_pylist() == [b"x", b"y", b"z"]
+    assert t["user"] == pa.dictionary(pa.int32(), pa.string()) and s.column(1).dictionary.to_pylist() == ["u1", "u2", "u3"]
+    assert t["raw"] == pa.dictionary(pa.int32(), pa.large_binary())
+    assert (t["flag"], t["shard"], t["sum(value)"], t["ts"]) == (pa.bool_(), pa.uint64(), pa.float64(), pa.int64())
+    # a column that is a dictionary on one rank and plain strings on another cannot be merged
+    bad = rec([("user", dic(pa.uint32(), ["u9"], pa.string()))])
+    with pytest.raises(ValueError):
+        unify_group_schemas([objs[0], _schema_to_obj(bad)])
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_alltoall_exchange_gloo(world):
     ctx = mp.get_context("spawn")
