@@ -144,8 +144,10 @@ void Context::put_event(hipEvent_t e) { events_.push_back(e); }
 void* Context::stage(const void* host, size_t payload) {
   const size_t bytes = (std::max<size_t>(payload, 1) + 255) / 256 * 256;
   if (stage_off_ + bytes > stage_cap_) {
+    flush_staging();  // (what is staged but not shipped goes out before the ring restarts)
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(staging)");
     stage_off_ = 0;
+    stage_sent_ = 0;
     if (bytes > stage_cap_) {
       if (stage_h_) (void)hipHostFree(stage_h_);
       if (stage_d_) (void)hipFree(stage_d_);
@@ -156,9 +158,15 @@ void* Context::stage(const void* host, size_t payload) {
   }
   if (payload) std::memcpy(stage_h_ + stage_off_, host, payload);
   void* dst = stage_d_ + stage_off_;
-  hip_check(hipMemcpyAsync(dst, stage_h_ + stage_off_, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(staging)");
   stage_off_ += bytes;
+  if (!defer_) flush_staging();
   return dst;
+}
+
+void Context::flush_staging() {
+  if (stage_sent_ >= stage_off_) return;
+  hip_check(hipMemcpyAsync(stage_d_ + stage_sent_, stage_h_ + stage_sent_, stage_off_ - stage_sent_, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(staging)");
+  stage_sent_ = stage_off_;
 }
 
 unsigned char* Context::copy_reserve(size_t payload) {

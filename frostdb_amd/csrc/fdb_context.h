@@ -30,7 +30,15 @@ class Context {
 
   // Small host→device tables (LUTs, slot maps): staged in pinned memory, shipped with one async copy each.
   void* stage(const void* host, size_t bytes);
-  void reset_staging() { stage_off_ = 0; copy_off_ = 0; }  // stream is idle
+  void reset_staging() {  // the stream is idle (tables staged but not yet shipped — a deferred batch — stay where they are)
+    if (stage_sent_ == stage_off_) stage_off_ = stage_sent_ = 0;
+    copy_off_ = 0;
+  }
+  // Several tables that feed ONE launch: between defer_staging(true) and flush_staging() stage() only fills the pinned ring
+  // (the device address it returns is final), and flush_staging() ships everything staged since with one copy command —
+  // each small copy is a few µs on the stream's critical path in front of the kernel.
+  void defer_staging(bool on) { if (!on) flush_staging(); defer_ = on; }
+  void flush_staging();
   // Copies `bytes` of pageable host memory to `dst` (device) through the pinned ring: the source is fully read when this
   // returns (the caller may free it), the DMA runs asynchronously on `stream`.
   void copy_in(void* dst, const void* host, size_t bytes);
@@ -45,7 +53,8 @@ class Context {
   std::vector<hipEvent_t> events_;
   unsigned char* stage_h_ = nullptr;
   unsigned char* stage_d_ = nullptr;
-  size_t stage_cap_ = 0, stage_off_ = 0;
+  size_t stage_cap_ = 0, stage_off_ = 0, stage_sent_ = 0;  // [stage_sent_, stage_off_) is staged but not shipped yet
+  bool defer_ = false;
   unsigned char* copy_h_ = nullptr;  // pinned ring of copy_in (separate from the LUT staging ring: a wrap here never touches staged LUTs)
   size_t copy_cap_ = 0, copy_off_ = 0;
 };

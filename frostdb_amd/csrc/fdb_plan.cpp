@@ -1111,6 +1111,12 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
       else { blob_base[(size_t)i] = blob.add(R.blob.bytes.data(), R.blob.bytes.size()); lut_class[(size_t)i] = (int)reps.size(); reps.push_back(i); }
     }
   }
+  // the LUT blob and the argument blocks below go to the device with ONE copy command, issued right before the launch
+  struct StageScope {
+    Context* c;
+    explicit StageScope(Context* ctx) : c(ctx) { c->defer_staging(true); }
+    ~StageScope() { try { c->defer_staging(false); } catch (...) {} }
+  } stage_scope(ctx_);
   unsigned char* d_blob = blob.bytes.empty() ? nullptr : (unsigned char*)upload(blob.bytes.data(), blob.bytes.size());
 
   const size_t acc_bytes = align_up((size_t)n_slots_ * 4, 16) + (size_t)n_slots_ * 8 * aggs_.size();
@@ -1233,6 +1239,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
           groups[g].push_back(bs[i]);
         }
         if (groups.size() > 1) {
+          ctx_->defer_staging(false);  // (each group stages its own tables)
           for (auto& g : groups) push_batches(g.data(), (int)g.size());
           return;
         }
@@ -1282,6 +1289,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     unsigned long long* partials = alloc_partials(grid);
     for (FdbScanArgs& a : parts) a.partials = partials;
     const FdbScanArgs* d_parts = (const FdbScanArgs*)upload(parts.data(), parts.size() * sizeof(FdbScanArgs));
+    ctx_->flush_staging();
     pt.mark("parts upload");
     timed_launch([&] {
       if (jit_fn != nullptr) hip_check(jit_launch(jit_fn, d_parts, (int)parts.size(), total_tiles, parts[0], grid, jit_block, lds_bytes, stream_), "scan launch");
@@ -1295,6 +1303,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   } else {
     // ---- sequential kernel, one launch per record ----------------------------------------------------------------
     const int rpt = rows_per_thread == 8 ? 8 : 4;
+    ctx_->flush_staging();
     for (int i : live) {
       FdbScanArgs& a = Rs[(size_t)i].args;
       if (a.n_expr > 0) throw Error(FDB_ERR_UNSUPPORTED, "computed (projected) columns are not supported by the sequential kernel (too many referenced columns)");
