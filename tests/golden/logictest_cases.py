@@ -344,6 +344,30 @@ DISTINCT_PROJ_CASES = [
 ]
 
 
+# ---- logictest/testdata/exec/projection: the two vectors that run through this path ---------------------------------------
+PMATH_FILE = "logictest/testdata/exec/projection/math_projection"
+PBOOL_FILE = "logictest/testdata/exec/projection/bool"
+PROJ_MATH_TABLE = dict(
+    cols=["labels.label1", "stacktrace", "timestamp", "value"],
+    inserts=[
+        """
+        value1 stack1 1 2
+        value1 stack1 3 4
+        value1 stack2 5 6
+        """,
+    ],
+)
+# `select stacktrace, sum(value * timestamp) group by stacktrace` (math_projection:17-21)
+PROJ_MATH_GROUPED = dict(cite=f"{PMATH_FILE}:17-21", aggs=[Sum(V * T)], groups=[Col("stacktrace")], out=["stacktrace", "sum(value * timestamp)"],
+                         expected=[(b"stack1", 14), (b"stack2", 30)])
+# schema simple_bool (logictest/logic_test.go:43-60): name string (dictionary), found bool; `select name where found = 'true'`
+# — the SQL front end turns the quoted true into a boolean literal (sqlparse/visitor.go:265-271) (bool:10-14)
+BOOL_TABLE_ROWS = [(b"test0", True), (b"test1", True), (b"test2", False)]
+BOOL_FILTER_CASES = [
+    dict(id="found_eq_true", cite=f"{PBOOL_FILE}:10-14", filter=Col("found") == True, rows=[0, 1]),  # noqa: E712
+]
+
+
 # ---- explain vectors: the operator strings (PhysicalPlan.Draw) of the fused operators -------------------------------------
 # logictest/testdata/plan/{aggregate/aggregate, aggregate/window, filter/filter}: each expected string is the fragment(s) of the
 # reference's explain line that belong to the operators this library replaces (PredicateFilter, the per-chain HashAggregate).

@@ -791,6 +791,23 @@ def test_plain_string_filter_leaves_vs_oracle(pp, typ):
             o.close()
 
 
+def test_golden_projection_vectors_on_this_path(pp):
+    """exec/projection/math_projection:17-21 and exec/projection/bool:10-14 through the device path."""
+    from tests.test_oracle_golden import bool_table_record
+    c = G.PROJ_MATH_GROUPED
+    d = run_gpu(pp, table_records(G.PROJ_MATH_TABLE), None, c["aggs"], c["groups"])
+    assert sorted(batch_rows(d, c["out"]), key=sort_key) == sorted(c["expected"], key=sort_key), c["cite"]
+    rec = bool_table_record()
+    for case in G.BOOL_FILTER_CASES:
+        plan = pp.HashAggregatePlan(case["filter"])
+        try:
+            assert list(plan.Select(rec)) == case["rows"], case["cite"]
+            out = plan.Filter(rec)
+            assert arrow_to_pydict(out)["name"] == [G.BOOL_TABLE_ROWS[r][0] for r in case["rows"]]
+        finally:
+            plan.Close()
+
+
 def test_bool_column_filter_vs_oracle(pp):
     """Arrow's compare kernels on a boolean column with a boolean scalar (false < true); NULL rows never match."""
     from oracle import OraclePlan

@@ -278,3 +278,27 @@ def test_oracle_distinct_bool_projection_golden(case):
     # `timestamp 0` is an int64 key of 0: printed as 0 or NULL depending on which row came first (hash identity), fold for comparison
     rows = [tuple(0 if (v is None and c == "timestamp") else v for c, v in zip(case["out"], r)) for r in batch_rows(d, case["out"])]
     assert sorted(rows, key=sort_key) == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+def bool_table_record():
+    import pyarrow as pa
+    from tests.util import dict_array
+    return pa.RecordBatch.from_arrays([dict_array([n for n, _ in G.BOOL_TABLE_ROWS]), pa.array([f for _, f in G.BOOL_TABLE_ROWS], type=pa.bool_())],
+                                      names=["name", "found"])
+
+
+def test_oracle_projection_vectors_on_this_path():
+    """exec/projection/math_projection:17-21 (a grouped sum over a computed column) and exec/projection/bool:10-14 (a boolean
+    column compared with a boolean literal)."""
+    from oracle import OraclePlan
+    c = G.PROJ_MATH_GROUPED
+    d = _oracle_runner(None, c["aggs"], c["groups"])(table_records(G.PROJ_MATH_TABLE))
+    assert sorted(batch_rows(d, c["out"]), key=sort_key) == sorted(c["expected"], key=sort_key), c["cite"]
+    rec = bool_table_record()
+    for case in G.BOOL_FILTER_CASES:
+        o = OraclePlan(case["filter"])
+        try:
+            _, idx = o.filter(rec)
+            assert list(idx) == case["rows"], case["cite"]
+        finally:
+            o.close()
