@@ -246,6 +246,8 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
     AggState a;
     a.func = d->aggs[i].func;
     if (d->aggs[i].column == nullptr) throw Error(FDB_ERR_INVALID, "aggregation without a column");
+    if (d->aggs[i].dynamic != 0)  // aggregate.go:38-46, :306-336 — see fdb_aggregation.dynamic
+      throw Error(FDB_ERR_UNSUPPORTED, std::string("aggregation over the dynamic column set ") + d->aggs[i].column + ".* is not supported");
     a.column = d->aggs[i].column;
     a.result_name = std::string(agg_name(a.func)) + "(" + a.column + ")";
     if (a.func == FDB_AGG_UNIQUE) {  // two physical accumulators, see AggState::role

@@ -278,7 +278,7 @@ class CExpr(ctypes.Structure):
 
 
 class CAggregation(ctypes.Structure):
-    _fields_ = [("func", ctypes.c_int32), ("_pad", ctypes.c_int32), ("column", ctypes.c_char_p)]
+    _fields_ = [("func", ctypes.c_int32), ("dynamic", ctypes.c_int32), ("column", ctypes.c_char_p)]
 
 
 class CGroupExpr(ctypes.Structure):
@@ -383,6 +383,7 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
             nm = a.expr.name.encode()
             keep.append(nm)
             ca[i].func = a.func
+            ca[i].dynamic = 1 if isinstance(a.expr, Column) and a.expr.dynamic else 0  # ≙ the DynamicColumn visitor of Aggregate(), aggregate.go:38-46
             ca[i].column = nm
         keep.append(ca)
         d.aggs = ctypes.cast(ca, ctypes.POINTER(CAggregation))

@@ -112,7 +112,10 @@ typedef struct fdb_expr {
  * "<func>(<column>)" exactly like AggregationFunction.Name() (logicalplan/expr.go:700-702). */
 typedef struct fdb_aggregation {
   int32_t func;        /* fdb_agg_func */
-  int32_t _pad;
+  int32_t dynamic;     /* 1 ⇔ the aggregated expression contains a DynamicColumn (`max(foo)` over every `foo.*` column; Aggregate()
+                          marks these, aggregate.go:38-46, and HashAggregate expands them per concrete column as records arrive,
+                          :306-336). NOT BUILT: fdb_plan_create returns FDB_ERR_UNSUPPORTED — keep the Go operator for such plans
+                          (DESIGN.md §8). 0 for an ordinary aggregation. */
   const char* column;
 } fdb_aggregation;
 

@@ -867,6 +867,8 @@ int oracle_plan_create(const fdb_plan_desc* d, int32_t nchains, uint64_t seed, o
   p->desc.root = d->filter_root;
   for (int32_t i = 0; i < d->n_aggs; i++) {
     AggDesc a; a.func = d->aggs[i].func; a.column = d->aggs[i].column;
+    // Aggregations over a DynamicColumn (expanded per concrete column at Callback, aggregate.go:306-336) are not restated.
+    if (d->aggs[i].dynamic != 0) { g_err = "dynamic aggregations are not restated by the oracle"; return FDB_ERR_UNSUPPORTED; }
     a.result_name = std::string(agg_func_name(a.func)) + "(" + a.column + ")";
     p->desc.aggs.push_back(a);
   }

@@ -147,3 +147,14 @@ def test_explain_validates_like_create(built_lib):
     from frostdb_amd.logicalplan import Col, Sum
     with pytest.raises(pp.FdbError):  # a regex std::regex cannot compile is rejected at plan build, without a device too
         pp.explain(Col("labels.x").RegexMatch("(unclosed"), [Sum(Col("value"))], [])
+
+
+def test_dynamic_aggregations_are_rejected_loudly(built_lib):
+    """`max(DynCol("foo"))` (Test_Aggregation_DynCol, aggregate_test.go:436-519; expanded per concrete column at Callback,
+    query/physicalplan/aggregate.go:306-336) is not built: the descriptor says so and create / explain refuse it — no silent
+    mis-aggregation of a column literally named "foo"."""
+    from frostdb_amd import physicalplan as pp
+    from frostdb_amd.logicalplan import DynCol, Max
+    with pytest.raises(pp.UnsupportedError) as e:
+        pp.explain(None, [Max(DynCol("foo"))], [])
+    assert "dynamic column set foo.*" in str(e.value)

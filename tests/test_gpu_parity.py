@@ -912,7 +912,7 @@ def test_plain_string_filter_errors(pp):
 @pytest.mark.parametrize("typ", [pa.string(), pa.binary(), pa.large_string()], ids=["utf8", "binary", "large_utf8"])
 def test_plain_string_group_keys_vs_oracle(pp, typ, variant):
     """Group by plain string columns (the reference's own Test_Aggregate_ArrayOverflow groups by a *array.Binary column,
-    aggregate_test.go:60-118): NULL keys, "" ≠ NULL, two chains merged, the key columns come back as plain columns of the input type."""
+    query/physicalplan/aggregate_test.go:28-118): NULL keys, "" ≠ NULL, two chains merged, the key columns come back as plain columns of the input type."""
     rng = np.random.default_rng(8103)
     batches = [plain_batch(rng, 60_000, typ), plain_batch(rng, 45_000, typ, n_vals=70)]
     aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("floatvalue")), Max(Col("value"))]
