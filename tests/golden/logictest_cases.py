@@ -368,6 +368,31 @@ BOOL_FILTER_CASES = [
 ]
 
 
+# ---- root aggregate_test.go: end-to-end known answers that run through this path ------------------------------------------
+# TestDurationAggregation (aggregate_test.go:260-343): group by logicalplan.Duration(time.Second) — HashAggregate only uses the
+# expression's MatchColumn, i.e. it groups by the stored `timestamp` column (logicalplan/expr.go:1127-1129); sums 16 and 5.
+DURATION_CASE = dict(
+    cite="aggregate_test.go:260-343",
+    rows=[(1_000_000_000, b"stack1", 3), (1_000_000_000, b"stack2", 5), (1_000_000_000, b"stack3", 8), (2_000_000_000, b"stack1", 2), (2_000_000_000, b"stack2", 3)],
+    aggs=[Sum(Col("value"))], groups=[Col("timestamp")], out=["timestamp", "sum(value)"],
+    expected=[(1_000_000_000, 16), (2_000_000_000, 5)],
+)
+# TestAggregationProjection (aggregate_test.go:150-258): three single-row records with different label sets, sum + max by
+# (labels, timestamp): 3 rows; every label column seen, timestamp and both aggregates are in the result.
+AGG_PROJECTION_CASE = dict(
+    cite="aggregate_test.go:150-258",
+    records=[
+        dict(cols=["labels.label1", "labels.label2", "timestamp", "value"], rows="value1 value2 1 1"),
+        dict(cols=["labels.label1", "labels.label2", "labels.label3", "timestamp", "value"], rows="value2 value2 value3 2 2"),
+        dict(cols=["labels.label1", "labels.label2", "labels.label4", "timestamp", "value"], rows="value3 value2 value4 3 3"),
+    ],
+    aggs=[Sum(Col("value")), Max(Col("value"))], groups=[DynCol("labels"), Col("timestamp")],
+    fields=["labels.label1", "labels.label2", "labels.label3", "labels.label4", "timestamp", "sum(value)", "max(value)"],
+    out=["labels.label1", "labels.label2", "labels.label3", "labels.label4", "timestamp", "sum(value)", "max(value)"],
+    expected=[(b"value1", b"value2", None, None, 1, 1, 1), (b"value2", b"value2", b"value3", None, 2, 2, 2), (b"value3", b"value2", None, b"value4", 3, 3, 3)],
+)
+
+
 # ---- explain vectors: the operator strings (PhysicalPlan.Draw) of the fused operators -------------------------------------
 # logictest/testdata/plan/{aggregate/aggregate, aggregate/window, filter/filter}: each expected string is the fragment(s) of the
 # reference's explain line that belong to the operators this library replaces (PredicateFilter, the per-chain HashAggregate).

@@ -808,6 +808,12 @@ def test_golden_projection_vectors_on_this_path(pp):
             plan.Close()
 
 
+def test_golden_root_aggregate_tests(pp):
+    """TestDurationAggregation / TestAggregationProjection (root aggregate_test.go:150-343) through the device path."""
+    from tests.test_oracle_golden import check_root_aggregate_cases
+    check_root_aggregate_cases(_gpu_runner(pp))
+
+
 def test_bool_column_filter_vs_oracle(pp):
     """Arrow's compare kernels on a boolean column with a boolean scalar (false < true); NULL rows never match."""
     from oracle import OraclePlan

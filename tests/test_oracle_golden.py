@@ -302,3 +302,30 @@ def test_oracle_projection_vectors_on_this_path():
             assert list(idx) == case["rows"], case["cite"]
         finally:
             o.close()
+
+
+def duration_record():
+    import pyarrow as pa
+    from tests.util import dict_array
+    rows = G.DURATION_CASE["rows"]
+    return pa.RecordBatch.from_arrays([pa.array([r[0] for r in rows], type=pa.int64()), dict_array([r[1] for r in rows]),
+                                       pa.array([r[2] for r in rows], type=pa.int64())], names=["timestamp", "stacktrace", "value"])
+
+
+def agg_projection_records():
+    return [record_from_rows(r["cols"], parse_rows(r["cols"], r["rows"])) for r in G.AGG_PROJECTION_CASE["records"]]
+
+
+def check_root_aggregate_cases(make_plan):
+    c = G.DURATION_CASE
+    d = make_plan(None, c["aggs"], c["groups"])([duration_record()])
+    assert sorted(batch_rows(d, c["out"]), key=sort_key) == sorted(c["expected"], key=sort_key), c["cite"]
+    c = G.AGG_PROJECTION_CASE
+    d = make_plan(None, c["aggs"], c["groups"])(agg_projection_records())
+    assert sorted(d.keys()) == sorted(c["fields"]), c["cite"]
+    assert sorted(batch_rows(d, c["out"]), key=sort_key) == sorted(c["expected"], key=sort_key), c["cite"]
+
+
+def test_oracle_root_aggregate_tests():
+    """TestDurationAggregation and TestAggregationProjection (root aggregate_test.go) restated as known answers."""
+    check_root_aggregate_cases(_oracle_runner)
