@@ -4,9 +4,20 @@
 #include <string>
 #include <vector>
 
+#include "fdb_dynamic.h"
 #include "fdb_plan.h"
 
-struct fdb_plan { fdb::Plan plan; fdb_plan(const fdb_plan_desc* d, int dev) : plan(d, dev) {} };
+// A plan handle: one operator chain. With aggregations over a DynamicColumn (fdb_dynamic.h) `plan` is the family's main plan
+// (static aggregations / group keys) and `dyn` holds the children.
+struct fdb_plan {
+  std::unique_ptr<fdb::DynamicAggs> dyn;
+  fdb_plan_desc main_desc;
+  fdb::Plan plan;
+  fdb_plan(const fdb_plan_desc* d, int dev)
+      : dyn(fdb::DynamicAggs::wanted(d) ? new fdb::DynamicAggs(d, dev) : nullptr),
+        main_desc(dyn ? dyn->main_desc() : (d ? *d : fdb_plan_desc())),
+        plan(d ? &main_desc : nullptr, dev) {}
+};
 struct fdb_batch { std::unique_ptr<fdb::DeviceBatch> b; };
 
 namespace {
@@ -31,6 +42,10 @@ int guard(fdb_plan* p, F&& f) {
     return FDB_ERR_INVALID;
   }
 }
+// Entry points that expose ONE table (state arrays for the RCCL merges, the hash exchange) do not apply to a family of plans.
+void single_table_only(const fdb_plan* p) {
+  if (p->dyn) throw fdb::Error(FDB_ERR_UNSUPPORTED, "not available for a plan with aggregations over a dynamic column set (merge such plans with fdb_plan_merge)");
+}
 }  // namespace
 
 extern "C" {
@@ -49,8 +64,16 @@ int fdb_device_count(int* n_devices) {
 
 int fdb_plan_explain(const fdb_plan_desc* desc, char* buf, int64_t capacity, int64_t* needed) {
   return guard(nullptr, [&] {
-    fdb::Plan plan(desc, 0, /*explain_only=*/true);
-    const std::string s = plan.draw();
+    std::string s;
+    if (fdb::DynamicAggs::wanted(desc)) {
+      fdb::DynamicAggs dyn(desc, 0);
+      const fdb_plan_desc md = dyn.main_desc();
+      fdb::Plan plan(&md, 0, /*explain_only=*/true);
+      s = dyn.draw(plan);
+    } else {
+      fdb::Plan plan(desc, 0, /*explain_only=*/true);
+      s = plan.draw();
+    }
     if (needed != nullptr) *needed = (int64_t)s.size() + 1;
     if (buf != nullptr && capacity > 0) {
       const size_t n = std::min((size_t)capacity - 1, s.size());
@@ -110,12 +133,16 @@ int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out) {
 
 int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.push(batch, schema); });
+  return guard(plan, [&] { if (plan->dyn) plan->dyn->push(plan->plan, batch, schema); else plan->plan.push(batch, schema); });
 }
 
 int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch) {
   if (!plan || !batch) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.push_batch(*batch->b); });
+  return guard(plan, [&] {
+    if (plan->dyn) { const fdb::DeviceBatch* b = batch->b.get(); plan->dyn->push_batches(plan->plan, &b, 1); return; }
+    plan->plan.settle();
+    plan->plan.push_batch(*batch->b);
+  });
 }
 
 int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n) {
@@ -126,6 +153,7 @@ int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32
       if (batches[i] == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null batch");
       v.push_back(batches[i]->b.get());
     }
+    if (plan->dyn) { plan->dyn->push_batches(plan->plan, v.data(), (int)v.size()); return; }
     plan->plan.settle();
     plan->plan.push_batches(v.data(), (int)v.size());
   });
@@ -133,32 +161,42 @@ int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32
 
 int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.finish(out, out_schema, n_rows); });
+  return guard(plan, [&] {
+    if (plan->dyn) { plan->dyn->finish(plan->plan, out, out_schema, n_rows); return; }
+    plan->plan.settle();
+    plan->plan.finish(out, out_schema, n_rows);
+  });
 }
 
 int fdb_plan_merge(fdb_plan* dst, fdb_plan* src) {
   if (!dst || !src) return FDB_ERR_INVALID;
-  return guard(dst, [&] { src->plan.settle(); dst->plan.settle(); dst->plan.merge_from(src->plan); });
+  return guard(dst, [&] {
+    if ((dst->dyn != nullptr) != (src->dyn != nullptr)) throw fdb::Error(FDB_ERR_INVALID, "plans have different aggregations");
+    if (dst->dyn) { dst->dyn->merge_from(dst->plan, *src->dyn, src->plan); return; }
+    src->plan.settle();
+    dst->plan.settle();
+    dst->plan.merge_from(src->plan);
+  });
 }
 
 int fdb_plan_group_schema(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema) {
   if (!plan || !out || !out_schema) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.group_schema(out, out_schema); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); plan->plan.group_schema(out, out_schema); });
 }
 
 int fdb_plan_seed_groups(fdb_plan* plan, struct ArrowArray* schema_record, struct ArrowSchema* schema) {
   if (!plan || !schema_record || !schema) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.seed_groups(schema_record, schema); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); plan->plan.seed_groups(schema_record, schema); });
 }
 
 int fdb_plan_hash_export(fdb_plan* src, fdb_plan* layout, int32_t n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32) {
   if (!src || !layout || !dev_rows || !counts || !row_words32) return FDB_ERR_INVALID;
-  return guard(src, [&] { src->plan.settle(); layout->plan.settle(); src->plan.hash_export(layout->plan, n_parts, dev_rows, counts, row_words32); });
+  return guard(src, [&] { single_table_only(src); single_table_only(layout); src->plan.settle(); layout->plan.settle(); src->plan.hash_export(layout->plan, n_parts, dev_rows, counts, row_words32); });
 }
 
 int fdb_plan_hash_import(fdb_plan* plan, const void* dev_rows, int64_t n_rows) {
   if (!plan || (n_rows > 0 && !dev_rows)) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.hash_import(dev_rows, n_rows); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); plan->plan.hash_import(dev_rows, n_rows); });
 }
 
 int fdb_plan_filter(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out,
@@ -173,58 +211,62 @@ int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema
   return guard(plan, [&] { plan->plan.select(batch, schema, indices, capacity, n_selected); });
 }
 
-const char* fdb_plan_draw(fdb_plan* plan) { return plan ? plan->plan.draw() : ""; }
+const char* fdb_plan_draw(fdb_plan* plan) { return !plan ? "" : plan->dyn ? plan->dyn->draw(plan->plan) : plan->plan.draw(); }
 const char* fdb_plan_last_error(const fdb_plan* plan) { return plan ? plan->plan.error.c_str() : g_last_error.c_str(); }
 void fdb_plan_close(fdb_plan* plan) { delete plan; }
 
 int fdb_plan_num_groups(fdb_plan* plan, int64_t* n_groups) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); *n_groups = plan->plan.num_groups(); });
+  return guard(plan, [&] {
+    if (plan->dyn) { *n_groups = plan->dyn->num_groups(plan->plan); return; }
+    plan->plan.settle();
+    *n_groups = plan->plan.num_groups();
+  });
 }
 
 int fdb_plan_partial_keys(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.partial_keys(out, out_schema); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); plan->plan.partial_keys(out, out_schema); });
 }
 
 int fdb_plan_partial_state(fdb_plan* plan, int32_t agg, void* dst, int64_t capacity_bytes) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.partial_state(agg, dst, capacity_bytes); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); plan->plan.partial_state(agg, dst, capacity_bytes); });
 }
 
 int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slots) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); *signature = plan->plan.state_signature(n_slots); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); *signature = plan->plan.state_signature(n_slots); });
 }
 
 int fdb_plan_state_pointers(fdb_plan* plan, void** base, int64_t* array_stride, int64_t* n_slots) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.state_pointers(base, array_stride, n_slots); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); plan->plan.state_pointers(base, array_stride, n_slots); });
 }
 
 int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.state_read(array, dst, capacity_bytes); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); plan->plan.state_read(array, dst, capacity_bytes); });
 }
 
 int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t bytes) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); plan->plan.state_write(array, src, bytes); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); plan->plan.state_write(array, src, bytes); });
 }
 
 int fdb_plan_state_arrays(fdb_plan* plan, int32_t* n_arrays) {
   if (!plan || !n_arrays) return FDB_ERR_INVALID;
-  return guard(plan, [&] { *n_arrays = plan->plan.num_state_arrays(); });
+  return guard(plan, [&] { single_table_only(plan); *n_arrays = plan->plan.num_state_arrays(); });
 }
 
 int fdb_plan_state_array_op(fdb_plan* plan, int32_t array, int32_t* op) {
   if (!plan || !op) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); *op = plan->plan.state_array_op(array); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); *op = plan->plan.state_array_op(array); });
 }
 
 int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out) {
   if (!plan) return FDB_ERR_INVALID;
-  return guard(plan, [&] { plan->plan.settle(); *format_out = plan->plan.agg_format(agg); });
+  return guard(plan, [&] { single_table_only(plan); plan->plan.settle(); *format_out = plan->plan.agg_format(agg); });
 }
 
 int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int device, fdb_batch** out) {

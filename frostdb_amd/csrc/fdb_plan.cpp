@@ -246,8 +246,8 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
     AggState a;
     a.func = d->aggs[i].func;
     if (d->aggs[i].column == nullptr) throw Error(FDB_ERR_INVALID, "aggregation without a column");
-    if (d->aggs[i].dynamic != 0)  // aggregate.go:38-46, :306-336 — see fdb_aggregation.dynamic
-      throw Error(FDB_ERR_UNSUPPORTED, std::string("aggregation over the dynamic column set ") + d->aggs[i].column + ".* is not supported");
+    if (d->aggs[i].dynamic != 0)  // (fdb_plan_create expands these into a family of plans, fdb_dynamic.h; one Plan never sees them)
+      throw Error(FDB_ERR_INVALID, std::string("internal: aggregation over the dynamic column set ") + d->aggs[i].column + ".* reached a single plan");
     a.column = d->aggs[i].column;
     a.result_name = std::string(agg_name(a.func)) + "(" + a.column + ")";
     if (a.func == FDB_AGG_UNIQUE) {  // two physical accumulators, see AggState::role
@@ -1467,29 +1467,33 @@ void Plan::build_agg_columns(const CompactState& cs, std::vector<OutColumn>* col
   }
 }
 
-void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
+int64_t Plan::finish_columns(std::vector<OutColumn>* cols) {
   PhaseTimer pt;
+  cols->clear();
+  int64_t n = 0;
   if (mode_ == TableMode::HASH && h_table_ != nullptr) {
     // big result sets: columns are materialised on the device, the host only copies finished Arrow buffers
-    std::vector<OutColumn> cols;
-    const int64_t n = finish_columns_hash(&cols);
+    n = finish_columns_hash(cols);
     pt.mark("finish: columns");
-    if (n_rows) *n_rows = n;
-    export_record(std::move(cols), n, out, out_schema);
-    pt.mark("finish: export");
-    finished_ = true;
-    return;
+  } else {
+    CompactState cs;
+    fetch_compact(&cs);
+    pt.mark("finish: fetch");
+    build_key_columns(cs, cols);
+    build_agg_columns(cs, cols);
+    n = cs.n;
   }
-  CompactState cs;
-  fetch_compact(&cs);
-  pt.mark("finish: fetch");
-  std::vector<OutColumn> cols;
-  build_key_columns(cs, &cols);
-  build_agg_columns(cs, &cols);
-  if (n_rows) *n_rows = cs.n;
-  export_record(std::move(cols), cs.n, out, out_schema);
-  pt.mark("finish: export");
   finished_ = true;
+  return n;
+}
+
+void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
+  PhaseTimer pt;
+  std::vector<OutColumn> cols;
+  const int64_t n = finish_columns(&cols);
+  if (n_rows) *n_rows = n;
+  export_record(std::move(cols), n, out, out_schema);
+  pt.mark("finish: export");
 }
 
 int64_t Plan::num_groups() {

@@ -175,6 +175,9 @@ class Plan {
   void push_batch(const DeviceBatch& batch);
   void push_batches(const DeviceBatch* const* batches, int n);         // one fused launch over n resident records
   void finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows);  // ≙ Finish
+  // The result as column descriptors (group-key columns first — n_key_columns() of them — then one column per aggregation).
+  int64_t finish_columns(std::vector<OutColumn>* cols);
+  size_t n_key_columns() const { return gcols_.size(); }
   void merge_from(Plan& src);                                          // ≙ Synchronizer + final stage
   void select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* indices, int64_t capacity, int64_t* n_selected);
   void filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray* out, ArrowSchema* out_schema, int64_t* n_selected);

@@ -112,10 +112,13 @@ typedef struct fdb_expr {
  * "<func>(<column>)" exactly like AggregationFunction.Name() (logicalplan/expr.go:700-702). */
 typedef struct fdb_aggregation {
   int32_t func;        /* fdb_agg_func */
-  int32_t dynamic;     /* 1 ⇔ the aggregated expression contains a DynamicColumn (`max(foo)` over every `foo.*` column; Aggregate()
-                          marks these, aggregate.go:38-46, and HashAggregate expands them per concrete column as records arrive,
-                          :306-336). NOT BUILT: fdb_plan_create returns FDB_ERR_UNSUPPORTED — keep the Go operator for such plans
-                          (DESIGN.md §8). 0 for an ordinary aggregation. */
+  int32_t dynamic;     /* 1 ⇔ the aggregated expression is a DynamicColumn: `column` is the set's name and `max(foo)` means max over
+                          every `foo.*` column (Aggregate() marks these, aggregate.go:38-46; HashAggregate turns each matching field
+                          into a concrete aggregation when a record first carries it, :306-336). The result column is named after
+                          the FIELD by a partial-stage plan and `max(foo.bar)` by a final-stage one; a record without a field adds
+                          nothing to it; a record with no field of the set is FDB_ERR_NOT_FOUND. sum / min / max / count only.
+                          Such a plan is a family of ordinary plans (one more scan per concrete column): fdb_plan_merge works, the
+                          single-table entry points (state arrays, hash exchange) return FDB_ERR_UNSUPPORTED. 0 otherwise. */
   const char* column;
 } fdb_aggregation;
 

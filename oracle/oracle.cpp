@@ -42,6 +42,7 @@
 #include <memory>
 #include <mutex>
 #include <regex>
+#include <set>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -235,7 +236,7 @@ struct Expr {
   Literal lit;
   std::shared_ptr<std::regex> re;
 };
-struct AggDesc { int32_t func; std::string column; std::string result_name; };
+struct AggDesc { int32_t func; std::string column; std::string result_name; bool dynamic = false; };
 struct GroupDesc { std::string name; bool dynamic; };
 
 const char* agg_func_name(int32_t f) {  // logicalplan/expr.go:731-750
@@ -252,7 +253,8 @@ struct ProjDesc { std::string name; std::vector<ProjNode> nodes; int32_t root = 
 
 struct PlanDesc {
   std::vector<Expr> filter; int32_t root = -1;
-  std::vector<AggDesc> aggs;
+  std::vector<AggDesc> aggs;      // static aggregations (aggregate.go:160-175)
+  std::vector<AggDesc> dyn_aggs;  // aggregations over a DynamicColumn: `column` is the prefix, expanded per concrete field at Callback
   std::vector<GroupDesc> groups;
   std::vector<ProjDesc> projs;  // computed columns of the Projection between filter and aggregate
   // No aggregations, only group columns ⇒ the chain is `Filter → Distinction` (physicalplan/distinct.go:21-170): the same
@@ -578,6 +580,8 @@ struct HashAggregate {
   bool final_stage = false;
   uint64_t seed = 0;
   std::unordered_map<uint64_t, uint32_t> hash_to_group;  // hashToAggregate (single aggregate: no 2 GiB spill modelled)
+  std::vector<AggDesc> aggs;                             // aggregate.aggregations: the static ones, then dynamic ones as they are converted
+  std::set<std::string> dyn_converted;                   // dynamicAggregationsConverted
   std::vector<std::vector<ValueBuilder>> arrays;         // [aggregation][group]
   std::vector<ColType> agg_types;                        // type of each aggregation's input column
   std::unordered_map<std::string, KeyBuilder> group_cols;
@@ -587,8 +591,9 @@ struct HashAggregate {
 
   void init(const PlanDesc* p, bool fin, uint64_t s) {
     plan = p; final_stage = fin; seed = s;
-    arrays.assign(p->aggs.size(), {});
-    agg_types.assign(p->aggs.size(), (ColType)0);
+    aggs = p->aggs;
+    arrays.assign(aggs.size(), {});
+    agg_types.assign(aggs.size(), (ColType)0);
   }
 
   // dynparquet/hashed.go:86-272
@@ -619,8 +624,8 @@ struct HashAggregate {
   bool callback(const Record& r, EvalError* err) {  // aggregate.go:263-490
     std::vector<int> group_fields;
     std::vector<uint64_t> field_hashes;
-    std::vector<const Col*> column_to_aggregate(plan->aggs.size(), nullptr);
-    int concrete_found = 0;
+    std::vector<const Col*> column_to_aggregate(aggs.size(), nullptr);
+    int concrete_found = 0, dynamic_found = 0;
     for (size_t i = 0; i < r.cols.size(); i++) {
       const std::string& fname = r.cols[i].name;
       for (const GroupDesc& m : plan->groups) {
@@ -629,17 +634,40 @@ struct HashAggregate {
           field_hashes.push_back(metro_hash64((const uint8_t*)fname.data(), fname.size(), seed));  // scalar.Hash(seed, name): unobservable
         }
       }
-      for (size_t j = 0; j < plan->aggs.size(); j++) {
-        const AggDesc& a = plan->aggs[j];
-        if (final_stage ? (a.result_name == fname) : (a.column == fname)) { column_to_aggregate[j] = &r.cols[i]; concrete_found++; }
+      // aggregate.go:306-336: a field matched by a dynamic aggregation becomes a concrete aggregation the first time it is seen;
+      // the partial stage names its result after the FIELD, the final stage `max(<field>)` (resultNameWithConcreteColumn, :973-990)
+      if (dyn_converted.find(fname) == dyn_converted.end()) {
+        for (const AggDesc& d : plan->dyn_aggs) {
+          if (!match_group(GroupDesc{d.column, true}, fname)) continue;
+          AggDesc a;
+          a.func = d.func; a.column = fname; a.dynamic = true;
+          a.result_name = final_stage ? std::string(agg_func_name(d.func)) + "(" + fname + ")" : fname;
+          aggs.push_back(a);
+          arrays.emplace_back();  // arrays == nil: no builder for any existing group yet
+          agg_types.push_back((ColType)0);
+          column_to_aggregate.push_back(nullptr);
+          dyn_converted.insert(fname);
+        }
+      }
+      for (size_t j = 0; j < aggs.size(); j++) {
+        const AggDesc& a = aggs[j];
+        const bool hit = final_stage ? (a.result_name == fname || (a.dynamic && a.column == fname)) : (a.column == fname);  // :338-361
+        if (hit) { column_to_aggregate[j] = &r.cols[i]; if (a.dynamic) dynamic_found++; else concrete_found++; }
       }
     }
-    if (!plan->distinct && (concrete_found == 0 || plan->aggs.empty())) {  // aggregate.go:367-380
+    const bool have_dyn = !plan->dyn_aggs.empty();
+    if (!plan->distinct && (((concrete_found == 0 || plan->aggs.empty()) && !have_dyn) || (have_dyn && dynamic_found == 0))) {  // aggregate.go:367-380
       *err = {FDB_ERR_NOT_FOUND, "aggregate field(s) not found, aggregations are not possible without it"};
       return false;
     }
-    for (size_t j = 0; j < plan->aggs.size(); j++) {
-      if (column_to_aggregate[j] == nullptr) { *err = {FDB_ERR_NOT_FOUND, "aggregate field not found: " + plan->aggs[j].column}; return false; }
+    for (size_t j = 0; j < aggs.size(); j++) {
+      if (column_to_aggregate[j] == nullptr) {
+        // With dynamic aggregations in the plan an unmatched aggregation is skipped for this record (:471-475) — as long as the
+        // record creates no new group (see below). Without them every static aggregation must be found.
+        if (have_dyn) continue;
+        *err = {FDB_ERR_NOT_FOUND, "aggregate field not found: " + aggs[j].column};
+        return false;
+      }
       agg_types[j] = column_to_aggregate[j]->type;
     }
     const int64_t n = r.rows;
@@ -663,7 +691,12 @@ struct HashAggregate {
       uint32_t group;
       auto it = hash_to_group.find(hash);
       if (it == hash_to_group.end()) {
-        for (size_t j = 0; j < arrays.size(); j++) arrays[j].emplace_back();
+        for (size_t j = 0; j < arrays.size(); j++) {
+          // `builder.NewBuilder(a.pool, col.DataType())` for EVERY aggregation (:413-417): an aggregation without a column in
+          // this record makes that a nil dereference — the reference panics (recovered into an error by recovery.Do)
+          if (column_to_aggregate[j] == nullptr) { *err = {FDB_ERR_INVALID, "panic: a record without the column of aggregation " + aggs[j].column + " creates a new group (aggregate.go:413-417)"}; return false; }
+          arrays[j].emplace_back();
+        }
         group = (uint32_t)(arrays.empty() ? row_count : arrays[0].size() - 1);
         hash_to_group.emplace(hash, group);
         group_hashes.push_back(hash);
@@ -673,6 +706,9 @@ struct HashAggregate {
         group = it->second;
       }
       for (size_t j = 0; j < arrays.size(); j++) {  // builder.AppendValue (utils.go:54-58): null ⇒ AppendNull (slot = 0)
+        if (column_to_aggregate[j] == nullptr) continue;  // :472-475
+        if (arrays[j].empty()) arrays[j].emplace_back();  // :476-482: "the group exists, but the array to append to does not"
+        if (group >= arrays[j].size()) { *err = {FDB_ERR_INVALID, "panic: index out of range — a dynamic aggregation column that appears after a second group exists (aggregate.go:483)"}; return false; }
         const Col& c = *column_to_aggregate[j];
         ValueBuilder& b = arrays[j][group];
         const bool v = c.valid[i];
@@ -731,8 +767,9 @@ struct HashAggregate {
         out->cols.push_back(std::move(h));
       }
     }
-    for (size_t j = 0; j < plan->aggs.size(); j++) {
-      const AggDesc& a = plan->aggs[j];
+    for (size_t j = 0; j < aggs.size(); j++) {
+      const AggDesc& a = aggs[j];
+      arrays[j].resize((size_t)row_count);  // (a dynamic aggregation's builders can be fewer than the groups only in the panic cases above)
       int32_t fn = a.func;
       if (fn == FDB_AGG_COUNT && final_stage) fn = FDB_AGG_SUM;  // runAggregation (aggregate.go:965-969)
       Col c; c.name = a.result_name; c.len = row_count; c.valid.assign(row_count, 1);
@@ -746,6 +783,7 @@ struct HashAggregate {
           for (int64_t g = 0; g < row_count; g++) {
             const std::vector<int64_t>& v = arrays[j][g].i64;  // raw slots: nulls are 0 (optbuilders.go:337-340)
             if (fn == FDB_AGG_SUM) { uint64_t s = 0; for (int64_t x : v) s += (uint64_t)x; c.i64[g] = (int64_t)s; }
+            else if (v.empty()) { c.i64[g] = 0; c.valid[g] = 0; }  // MIN / MAX of an empty array: AppendNull (aggregate.go:806-809, :884-887)
             else if (fn == FDB_AGG_MIN) { int64_t m = v[0]; for (int64_t x : v) if (x < m) m = x; c.i64[g] = m; }
             else { int64_t m = v[0]; for (int64_t x : v) if (x > m) m = x; c.i64[g] = m; }
           }
@@ -754,6 +792,7 @@ struct HashAggregate {
           for (int64_t g = 0; g < row_count; g++) {
             const std::vector<double>& v = arrays[j][g].f64;
             if (fn == FDB_AGG_SUM) { double s = 0; for (double x : v) s += x; c.f64[g] = s; }
+            else if (v.empty()) { c.f64[g] = 0; c.valid[g] = 0; }
             else if (fn == FDB_AGG_MIN) { double m = v[0]; for (double x : v) if (x < m) m = x; c.f64[g] = m; }
             else { double m = v[0]; for (double x : v) if (x > m) m = x; c.f64[g] = m; }
           }
@@ -867,10 +906,9 @@ int oracle_plan_create(const fdb_plan_desc* d, int32_t nchains, uint64_t seed, o
   p->desc.root = d->filter_root;
   for (int32_t i = 0; i < d->n_aggs; i++) {
     AggDesc a; a.func = d->aggs[i].func; a.column = d->aggs[i].column;
-    // Aggregations over a DynamicColumn (expanded per concrete column at Callback, aggregate.go:306-336) are not restated.
-    if (d->aggs[i].dynamic != 0) { g_err = "dynamic aggregations are not restated by the oracle"; return FDB_ERR_UNSUPPORTED; }
     a.result_name = std::string(agg_func_name(a.func)) + "(" + a.column + ")";
-    p->desc.aggs.push_back(a);
+    if (d->aggs[i].dynamic != 0) { a.dynamic = true; p->desc.dyn_aggs.push_back(a); }  // NewHashAggregate splits them (aggregate.go:168-176)
+    else p->desc.aggs.push_back(a);
   }
   for (int32_t i = 0; i < d->n_groups; i++) p->desc.groups.push_back(GroupDesc{d->groups[i].name, d->groups[i].dynamic != 0});
   for (int32_t i = 0; i < d->n_projections; i++) {

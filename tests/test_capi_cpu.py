@@ -149,12 +149,14 @@ def test_explain_validates_like_create(built_lib):
         pp.explain(Col("labels.x").RegexMatch("(unclosed"), [Sum(Col("value"))], [])
 
 
-def test_dynamic_aggregations_are_rejected_loudly(built_lib):
-    """`max(DynCol("foo"))` (Test_Aggregation_DynCol, aggregate_test.go:436-519; expanded per concrete column at Callback,
-    query/physicalplan/aggregate.go:306-336) is not built: the descriptor says so and create / explain refuse it — no silent
-    mis-aggregation of a column literally named "foo"."""
+def test_dynamic_aggregations_explain_and_validation(built_lib):
+    """`max(DynCol("foo"))` (Test_Aggregation_DynCol, aggregate_test.go:436-519): the concrete aggregations only come into being
+    as records arrive (query/physicalplan/aggregate.go:306-336), so Draw lists the static ones (HashAggregate.Draw, :226-243);
+    functions other than sum / min / max / count over a dynamic column set are refused."""
     from frostdb_amd import physicalplan as pp
-    from frostdb_amd.logicalplan import DynCol, Max
-    with pytest.raises(pp.UnsupportedError) as e:
-        pp.explain(None, [Max(DynCol("foo"))], [])
-    assert "dynamic column set foo.*" in str(e.value)
+    from frostdb_amd.logicalplan import Col, DynCol, Max, Sum, Unique
+    assert pp.explain(None, [Max(DynCol("foo"))], []) == "HashAggregate ( by ) [gfx950]"
+    assert pp.explain(Col("ts") > 1, [Max(DynCol("foo"))], [DynCol("labels")]) == "PredicateFilter (ts > 1) - HashAggregate ( by labels) [gfx950]"
+    assert pp.explain(None, [Sum(Col("value")), Max(DynCol("foo"))], [Col("a")]) == "HashAggregate (sum(value) by a) [gfx950]"
+    with pytest.raises(pp.UnsupportedError):
+        pp.explain(None, [Unique(DynCol("foo"))], [])

@@ -1008,6 +1008,131 @@ def test_plain_and_dictionary_key_types_do_not_mix(pp):
         plan.Close()
 
 
+# ---- aggregations over a DynamicColumn: max(foo) over every foo.* column (aggregate.go:38-46, :306-336) ---------------------------
+
+def _final_over_partials(pp, filt, aggs, groups, chains):
+    """Partial plans (one per chain) → their records into a final-stage plan, like Synchronizer + HashAggregate(final)."""
+    partials = []
+    for recs in chains:
+        p = pp.HashAggregatePlan(filt, aggs, groups)
+        try:
+            for r in recs:
+                p.Callback(r)
+            partials.append(p.Finish())
+        finally:
+            p.Close()
+    f = pp.HashAggregatePlan(None, aggs, groups, final_stage=True)
+    try:
+        for r in partials:
+            if r.num_rows:
+                f.Callback(r)
+        return f.Finish()
+    finally:
+        f.Close()
+
+
+def test_golden_dynamic_column_aggregation(pp):
+    """Test_Aggregation_DynCol (root aggregate_test.go:436-519): one record per column foo.bar / foo.baz / foo.bah plus one with
+    all three, `max(DynCol("foo"))` without grouping → 1 row, 3 columns. The partial stage names them after the fields, the final
+    stage max(<field>) (aggregate.go:313-334)."""
+    from frostdb_amd.logicalplan import DynCol as D
+    recs = [pa.RecordBatch.from_arrays([pa.array([7], type=pa.int64())], names=["foo.bar"]),
+            pa.RecordBatch.from_arrays([pa.array([9], type=pa.int64())], names=["foo.baz"]),
+            pa.RecordBatch.from_arrays([pa.array([3], type=pa.int64())], names=["foo.bah"]),
+            pa.RecordBatch.from_arrays([pa.array([5]), pa.array([11]), pa.array([1])], names=["foo.bar", "foo.baz", "foo.bah"])]
+    aggs = [Max(D("foo"))]
+    assert arrow_to_pydict(_final_over_partials(pp, None, aggs, [], [recs])) == {"max(foo.bar)": [7], "max(foo.baz)": [11], "max(foo.bah)": [3]}
+    assert arrow_to_pydict(_final_over_partials(pp, None, aggs, [], [recs[:2], recs[2:]])) == run_oracle(recs, None, aggs, [], nchains=1)
+    p = pp.HashAggregatePlan(None, aggs, [])
+    try:
+        assert p.Draw().startswith("HashAggregate ( by )")
+        for r in recs:
+            p.Callback(r)
+        assert p.num_groups() == 1
+        assert arrow_to_pydict(p.Finish()) == {"foo.bar": [7], "foo.baz": [11], "foo.bah": [3]}
+    finally:
+        p.Close()
+    # a record without any column of the dynamic set (aggregate.go:366-380)
+    p = pp.HashAggregatePlan(None, aggs, [])
+    try:
+        with pytest.raises(pp.FdbError) as e:
+            p.Callback(pa.RecordBatch.from_arrays([pa.array([1])], names=["other"]))
+        assert e.value.code == pp.FDB_ERR_NOT_FOUND
+    finally:
+        p.Close()
+
+
+def test_dynamic_column_aggregations_vs_oracle(pp):
+    """Columns of the dynamic set come and go between records; sum / min / max / count over them next to a static aggregation and a
+    filter; ungrouped (the only shape the reference survives when columns appear late) and grouped with every column in every
+    record; pushed and resident; two chains → final stage. NULLs inside the aggregated columns."""
+    from frostdb_amd.logicalplan import DynCol as D
+    rng = np.random.default_rng(8201)
+
+    def rec(n, cols, with_labels):
+        arrays, names = [], []
+        if with_labels:
+            arrays.append(dict_array([None if rng.random() < 0.1 else b"g%d" % k for k in rng.integers(0, 40, n)]))
+            names.append("labels.g")
+        for c in cols:
+            if c == "m.f":
+                arrays.append(pa.array(rng.uniform(-5, 5, n), mask=rng.random(n) < 0.1))
+            else:
+                arrays.append(pa.array(rng.integers(-100, 100, n), type=pa.int64(), mask=rng.random(n) < 0.1))
+            names.append(c)
+        arrays.append(pa.array(rng.integers(0, 10, n), type=pa.int64()))
+        names.append("value")
+        return pa.RecordBatch.from_arrays(arrays, names=names)
+
+    filt = Col("value") > 2
+    # ungrouped: the column set changes from record to record. ONE dynamic aggregation per plan, like the reference's test: with
+    # several over the same set the partial stage names all their results after the field and the final stage reads the last
+    # column of that name for every one of them (aggregate.go:313-334, :338-361)
+    recs = [rec(5000, ["m.a"], False), rec(3000, ["m.b", "m.f"], False), rec(20_000, ["m.a", "m.f"], False), rec(10, ["m.c"], False)]
+    for fn in (Sum, Min, Max, Count):
+        aggs = [fn(D("m")), Count(Col("value"))]
+        want = run_oracle(recs, filt, aggs, [], nchains=1)
+        assert len(want) == 5
+        for chains in ([recs], [recs[:2], recs[2:]]):
+            got = arrow_to_pydict(_final_over_partials(pp, filt, aggs, [], chains))
+            assert sorted(got) == sorted(want)
+            for k in want:
+                if isinstance(want[k][0], float):
+                    assert got[k] == pytest.approx(want[k], rel=1e-9), k
+                else:
+                    assert got[k] == want[k], k
+    # a filter that selects nothing in the only record carrying m.c: that record never reaches the aggregate, no column for it
+    none_of_c = And(filt, Or(Col("value") < 9, Col("value") > 9))  # (all rows of the other records keep some selected rows)
+    tiny = pa.RecordBatch.from_arrays([pa.array([1, 2], type=pa.int64()), pa.array([0, 1], type=pa.int64())], names=["m.z", "value"])
+    want = run_oracle(recs[:1] + [tiny], none_of_c, [Max(D("m"))], [], nchains=1)
+    assert sorted(want) == ["max(m.a)"]
+    assert arrow_to_pydict(_final_over_partials(pp, none_of_c, [Max(D("m"))], [], [recs[:1] + [tiny]])) == want
+    # grouped: every record carries every column (a record lacking one that creates a new group panics in the reference, :413-417)
+    grecs = [rec(30_000, ["m.a", "m.f"], True), rec(20_000, ["m.a", "m.f"], True)]
+    for fn in (Sum, Max):
+        gaggs = [fn(D("m")), Count(Col("value"))]
+        name = fn(Col("x")).Name()[:3]
+        want = run_oracle(grecs, filt, gaggs, [DynCol("labels")], nchains=1)
+        got_rec = _final_over_partials(pp, filt, gaggs, [DynCol("labels")], [grecs[:1], grecs[1:]])
+        cols = ["labels.g", f"{name}(m.a)", f"{name}(m.f)", "count(value)"]
+        assert sorted(got_rec.schema.names) == sorted(cols)
+        assert_same_result(arrow_to_pydict(got_rec), want, cols, float_cols={"sum(m.f)"})
+    # resident records + same-stage merge of two chains: the partial stage's naming (the fields themselves)
+    gaggs = [Sum(D("m")), Count(Col("value"))]
+    want = run_oracle(grecs, filt, gaggs, [DynCol("labels")], nchains=1)
+    p1, p2 = pp.HashAggregatePlan(filt, gaggs, [DynCol("labels")]), pp.HashAggregatePlan(filt, gaggs, [DynCol("labels")])
+    keep = [pp.ResidentBatch(r) for r in grecs]
+    try:
+        p1.Callback(keep[0]); p2.CallbackResident(keep[1:])
+        p1.Merge(p2)
+        got = arrow_to_pydict(p1.Finish())
+    finally:
+        p1.Close(); p2.Close()
+    renamed = {"labels.g": want["labels.g"], "m.a": want["sum(m.a)"], "m.f": want["sum(m.f)"], "count(value)": want["count(value)"]}
+    assert sorted(got) == sorted(renamed)
+    assert_same_result(got, renamed, list(renamed), float_cols={"m.f"})
+
+
 # ---- pre-aggregate Projection fused into the scan (SURVEY §8f.1; project.go:73-399) ----------------------------------------
 
 def _gpu_runner(pp):
