@@ -329,3 +329,36 @@ def check_root_aggregate_cases(make_plan):
 def test_oracle_root_aggregate_tests():
     """TestDurationAggregation and TestAggregationProjection (root aggregate_test.go) restated as known answers."""
     check_root_aggregate_cases(_oracle_runner)
+
+
+def test_oracle_dynamic_column_aggregation():
+    """Test_Aggregation_DynCol (root aggregate_test.go:436-519): one record per column of the dynamic set plus one with all three,
+    `max(DynCol("foo"))`, no grouping → 3 columns, 1 row (the test's own assertion), with the values a max must have. And the
+    reference's limits, restated as errors: a record lacking an aggregated column that creates a new group (nil dereference,
+    aggregate.go:413-417); a record with no column of the set (:366-380)."""
+    from frostdb_amd.logicalplan import DynCol, Max
+    one = lambda name, v: pa.RecordBatch.from_arrays([pa.array([v], type=pa.int64())], names=[name])  # noqa: E731
+    recs = [one("foo.bar", 7), one("foo.baz", 9), one("foo.bah", 3),
+            pa.RecordBatch.from_arrays([pa.array([5]), pa.array([11]), pa.array([1])], names=["foo.bar", "foo.baz", "foo.bah"])]
+    for nchains in (1, 2, 3):
+        d = _oracle_runner_n(None, [Max(DynCol("foo"))], [], nchains)(recs)
+        assert len(d) == 3 and all(len(v) == 1 for v in d.values())
+        assert d == {"max(foo.bar)": [7], "max(foo.baz)": [11], "max(foo.bah)": [3]}
+    with pytest.raises(Exception, match="not found"):
+        _oracle_runner_n(None, [Max(DynCol("foo"))], [], 1)([one("other", 1)])
+    grouped = [pa.RecordBatch.from_arrays([pa.array([1, 2]), pa.array([10, 20])], names=["k", "foo.a"]),
+               pa.RecordBatch.from_arrays([pa.array([3]), pa.array([30])], names=["k", "foo.b"])]  # new group 3 without foo.a
+    with pytest.raises(Exception, match="panic"):
+        _oracle_runner_n(None, [Max(DynCol("foo"))], [Col("k")], 1)(grouped)
+
+
+def _oracle_runner_n(filter_expr, aggs, groups, nchains):
+    def run(recs):
+        plan = OraclePlan(filter_expr, aggs, groups, nchains=nchains)
+        try:
+            for r in recs:
+                plan.push(r)
+            return plan.finish().to_pydict()
+        finally:
+            plan.close()
+    return run
