@@ -403,3 +403,30 @@ def test_oracle_agrees_with_pyarrow_on_the_quirk_free_cases(seed):
                 assert x == pytest.approx(y, rel=1e-9, abs=1e-9)
             else:
                 assert x == y, (a, b)
+
+
+@pytest.mark.parametrize("typ", [pa.string(), pa.binary(), pa.large_string()], ids=["utf8", "binary", "large_utf8"])
+def test_oracle_plain_string_leaves_agree_with_pyarrow(typ):
+    """The reference sends = != < <= > >= on a plain string / binary column to Arrow's compare kernels
+    (binaryscalarexpr.go:116-152) and contains to bytes.Contains (:234-270): the oracle's restatement against pyarrow's own
+    kernels (bytewise order, NULL rows never match)."""
+    rng = np.random.default_rng(77)
+    words = ["", "a", "ab", "abc", "b", "ba", "zeta", "Zeta", "é", "value1", "value10", "value2"] + ["w%02d" % k for k in range(20)]
+    n = 5000
+    arr = pa.array([words[k] for k in rng.integers(0, len(words), n)], type=pa.string(), mask=rng.random(n) < 0.15).cast(typ)
+    rec = pa.RecordBatch.from_arrays([arr], names=["name"])
+    as_bin = arr.cast(pa.large_binary() if typ == pa.large_string() else pa.binary())
+    N = Col("name")
+    for lit in ("", "ab", "value1", "w10", "zz"):
+        b = pa.scalar(lit.encode(), as_bin.type)
+        cases = [(N == lit, pc.equal(as_bin, b)), (N != lit, pc.not_equal(as_bin, b)), (N < lit, pc.less(as_bin, b)), (N <= lit, pc.less_equal(as_bin, b)),
+                 (N > lit, pc.greater(as_bin, b)), (N >= lit, pc.greater_equal(as_bin, b)),
+                 (N.Contains(lit), pc.match_substring(as_bin, lit.encode())), (N.NotContains(lit), pc.invert(pc.match_substring(as_bin, lit.encode())))]
+        for f, mask in cases:
+            o = OraclePlan(f)
+            try:
+                _, idx = o.filter(rec)
+            finally:
+                o.close()
+            want = np.flatnonzero(np.array(pc.fill_null(mask, False).to_pylist(), dtype=bool))
+            assert np.array_equal(idx, want), (str(f), lit)
