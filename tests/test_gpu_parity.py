@@ -1133,6 +1133,34 @@ def test_dynamic_column_aggregations_vs_oracle(pp):
     assert_same_result(got, renamed, list(renamed), float_cols={"m.f"})
 
 
+def test_dynamic_column_aggregation_over_hash_tables(pp):
+    """The family's join at Finish when main and children are hash tables (12 label columns + an int64 key whose 0 ≡ NULL + a plain
+    string key; results come back in the shared pinned block): a dynamic MAX and a static SUM vs the oracle, two chains merged
+    through a final-stage plan."""
+    from frostdb_amd.logicalplan import DynCol as D
+    rng = np.random.default_rng(8202)
+
+    def rec(n):
+        b = many_label_batch(rng, n, 12, 3, n_groups=4000)
+        b = b.append_column("bucket", pa.array(rng.integers(0, 3, n) * 500, type=pa.int64(), mask=rng.random(n) < 0.05))
+        b = b.append_column("host", pa.array(["h%d" % k for k in rng.integers(0, 5, n)], type=pa.string(), mask=rng.random(n) < 0.05))
+        b = b.append_column("m.a", pa.array(rng.integers(-50, 50, n), type=pa.int64()))
+        return b.append_column("m.b", pa.array(rng.uniform(-1, 1, n)))
+
+    recs = [rec(40_000), rec(30_000)]
+    aggs = [Max(D("m")), Sum(Col("value"))]
+    groups = [DynCol("labels"), Col("bucket"), Col("host")]
+    want = run_oracle(recs, None, aggs, groups, nchains=1)
+    assert len(want["sum(value)"]) > 10_000
+    got = arrow_to_pydict(_final_over_partials(pp, None, aggs, groups, [recs[:1], recs[1:]]))
+    # int64 key 0 ≡ NULL: which of the two is printed depends on arrival order — fold for comparison
+    for d in (got, want):
+        d["bucket"] = [0 if v is None else v for v in d["bucket"]]
+    cols = key_cols_of(recs, extra=("bucket", "host")) + ["max(m.a)", "max(m.b)", "sum(value)"]
+    assert sorted(got) == sorted(cols)
+    assert_same_result(got, want, cols)
+
+
 # ---- pre-aggregate Projection fused into the scan (SURVEY §8f.1; project.go:73-399) ----------------------------------------
 
 def _gpu_runner(pp):
