@@ -160,3 +160,20 @@ def test_dynamic_aggregations_explain_and_validation(built_lib):
     assert pp.explain(None, [Sum(Col("value")), Max(DynCol("foo"))], [Col("a")]) == "HashAggregate (sum(value) by a) [gfx950]"
     with pytest.raises(pp.UnsupportedError):
         pp.explain(None, [Unique(DynCol("foo"))], [])
+
+
+def test_every_entry_point_has_a_typed_binding(built_lib):
+    """The ctypes binding declares argument types for every function of the header that takes arguments, and a return type
+    for every one that does not return int: an untyped call passes 64-bit addresses as C ints (it crashed once)."""
+    from frostdb_amd.physicalplan import lib
+    L = lib()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "frostdb_amd.h")).read(), flags=re.S)
+    protos = re.findall(r"\b([A-Za-z_0-9 ]+?\**)\s*\b(fdb_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", text)
+    assert len(protos) >= 40
+    for ret, name, args in protos:
+        fn = getattr(L, name)
+        if args.strip() not in ("void", ""):
+            assert fn.argtypes is not None, name
+        ret = ret.strip()
+        if ret.endswith("*") or "int64_t" in ret:
+            assert fn.restype is not ctypes.c_int, name
