@@ -30,6 +30,8 @@ namespace fdb {
 class DescCopy {
  public:
   explicit DescCopy(const fdb_plan_desc* d);
+  DescCopy(const DescCopy&) = delete;             // (the copied nodes point into this object's own strings)
+  DescCopy& operator=(const DescCopy&) = delete;
   // The descriptor again with `aggs` as its aggregation list (pointers stay valid as long as *this and `aggs` do).
   fdb_plan_desc view(const std::vector<fdb_aggregation>& aggs, bool final_stage) const;
   const char* keep(const std::string& s) { strs_.push_back(s); return strs_.back().c_str(); }
