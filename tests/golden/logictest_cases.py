@@ -5,6 +5,9 @@ Source: /root/reference/logictest/testdata/exec/{filter,aggregate}/* (cockroachd
 logictest/runner.go:27). The SQL of each ``exec`` is transcribed by hand into the logicalplan builders the
 SQL front end (sqlparse/) would produce; the expected rows are copied verbatim. Each case cites file:line.
 
+Also here: exec/distinct/* (incl. boolean projections), the two exec/projection vectors that run through the aggregate,
+the operator strings of plan/{aggregate,filter}/* (explain), and known answers of the root aggregate_test.go
+(TestAggregateInconsistentSchema, TestDurationAggregation, TestAggregationProjection).
 Only queries the hot path serves are listed (filter leaves / AND / OR, SUM/MIN/MAX/COUNT by label columns).
 AVG is lowered by the reference to SUM + COUNT + a Projection (logicalplan/builder.go:205-238); its cases
 carry ``avg_of=(sum_col, count_col)`` and the harness performs the reference's division (integer division
