@@ -430,3 +430,22 @@ def test_oracle_plain_string_leaves_agree_with_pyarrow(typ):
                 o.close()
             want = np.flatnonzero(np.array(pc.fill_null(mask, False).to_pylist(), dtype=bool))
             assert np.array_equal(idx, want), (str(f), lit)
+
+
+def test_oracle_prehashed_columns_replace_the_hash_not_the_keys():
+    """FindHashedColumn (dynparquet/hashed.go:27-35, aggregate.go:386-392): a stored `hashed.<col>` int64 column is used as the
+    group column's hash; with hashes that are a function of the value the groups and their printed keys are the same as without."""
+    from tests.util import dict_array
+    rng = np.random.default_rng(12)
+    n = 5000
+    vals = [None if rng.random() < 0.1 else b"p%d" % k for k in rng.integers(0, 20, n)]
+    hashed = pa.array([0 if v is None else 1000 + int(v[1:]) for v in vals], type=pa.int64())  # NULL hashes to 0 (hashed.go:86-105)
+    value = pa.array(rng.integers(0, 100, n), type=pa.int64())
+    plain = pa.RecordBatch.from_arrays([dict_array(vals), value], names=["labels.path", "value"])
+    pre = pa.RecordBatch.from_arrays([dict_array(vals), hashed, value], names=["labels.path", "hashed.labels.path", "value"])
+    aggs, groups = [Sum(Col("value")), Count(Col("value"))], [Col("labels.path")]
+    a = _oracle_runner_n(None, aggs, groups, 2)([plain.slice(0, 2000), plain.slice(2000)])
+    b = _oracle_runner_n(None, aggs, groups, 2)([pre.slice(0, 2000), pre.slice(2000)])
+    cols = ["labels.path", "sum(value)", "count(value)"]
+    assert sorted(batch_rows(a, cols), key=sort_key) == sorted(batch_rows(b, cols), key=sort_key)
+    assert sorted(b) == sorted(cols)  # the final stage drops the hashed.* helper columns (aggregate.go:561-563)
