@@ -4,6 +4,8 @@
 #include <string>
 #include <vector>
 
+#include "fdb_comm.h"
+#include "fdb_context.h"
 #include "fdb_dynamic.h"
 #include "fdb_plan.h"
 
@@ -17,7 +19,10 @@ struct fdb_plan {
       : dyn(fdb::DynamicAggs::wanted(d) ? new fdb::DynamicAggs(d, dev) : nullptr),
         main_desc(dyn ? dyn->main_desc() : (d ? *d : fdb_plan_desc())),
         plan(d ? &main_desc : nullptr, dev) {}
+  // a fresh plan of `proto`'s descriptor (the shard of fdb_plan_exchange)
+  explicit fdb_plan(const fdb::Plan& proto) : main_desc(), plan(proto, fdb::Plan::CloneTag()) {}
 };
+struct fdb_comm { std::unique_ptr<fdb::Comm> c; };
 struct fdb_batch { std::unique_ptr<fdb::DeviceBatch> b; };
 
 namespace {
@@ -45,6 +50,31 @@ int guard(fdb_plan* p, F&& f) {
 // Entry points that expose ONE table (state arrays for the RCCL merges, the hash exchange) do not apply to a family of plans.
 void single_table_only(const fdb_plan* p) {
   if (p->dyn) throw fdb::Error(FDB_ERR_UNSUPPORTED, "not available for a plan with aggregations over a dynamic column set (merge such plans with fdb_plan_merge)");
+}
+}  // namespace
+
+namespace {
+template <typename F>
+int comm_guard(fdb_comm* c, F&& f) {
+  try {
+    f();
+    return FDB_OK;
+  } catch (const fdb::Error& e) {
+    if (c && c->c) c->c->error = e.what();
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    g_last_error = "out of host memory";
+    return FDB_ERR_OOM;
+  } catch (const std::exception& e) {
+    if (c && c->c) c->c->error = e.what();
+    g_last_error = e.what();
+    return FDB_ERR_INVALID;
+  }
+}
+int wrap_all(std::vector<std::unique_ptr<fdb::Comm>>&& v, fdb_comm** out) {
+  for (size_t i = 0; i < v.size(); i++) { out[i] = new fdb_comm(); out[i]->c = std::move(v[i]); }
+  return FDB_OK;
 }
 }  // namespace
 
@@ -321,6 +351,69 @@ const char* fdb_plan_last_kernel(fdb_plan* plan) {
   if (!plan) return "";
   (void)guard(plan, [&] { plan->plan.settle(); });
   return plan->plan.last_kernel();
+}
+
+// ---- cross-GPU merge ---------------------------------------------------------------------------------------------------------
+
+int fdb_comm_unique_id(uint8_t id[FDB_COMM_ID_BYTES]) {
+  return comm_guard(nullptr, [&] {
+    if (id == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null id");
+    fdb::rccl_unique_id(id);
+  });
+}
+
+int fdb_comm_init_rank(const uint8_t id[FDB_COMM_ID_BYTES], int32_t n_ranks, int32_t rank, int device, fdb_comm** out) {
+  return comm_guard(nullptr, [&] {
+    if (id == nullptr || out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::unique_ptr<fdb::Comm> c = fdb::rccl_init_rank(id, n_ranks, rank, device);
+    *out = new fdb_comm();
+    (*out)->c = std::move(c);
+  });
+}
+
+int fdb_comm_init_all(const int* devices, int32_t n, fdb_comm** out) {
+  return comm_guard(nullptr, [&] {
+    if (devices == nullptr || out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    wrap_all(fdb::rccl_init_all(devices, n), out);
+  });
+}
+
+int fdb_comm_init_local(const int* devices, int32_t n, fdb_comm** out) {
+  return comm_guard(nullptr, [&] {
+    if (devices == nullptr || out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    wrap_all(fdb::local_init(devices, n), out);
+  });
+}
+
+int32_t fdb_comm_rank(const fdb_comm* comm) { return comm && comm->c ? comm->c->rank : -1; }
+int32_t fdb_comm_size(const fdb_comm* comm) { return comm && comm->c ? comm->c->size : 0; }
+const char* fdb_comm_last_error(const fdb_comm* comm) { return comm && comm->c ? comm->c->error.c_str() : g_last_error.c_str(); }
+void fdb_comm_destroy(fdb_comm* comm) { delete comm; }
+
+int fdb_plan_allreduce(fdb_plan* plan, fdb_comm* comm, int32_t* aligned) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] {
+    if (comm == nullptr || !comm->c || aligned == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    single_table_only(plan);
+    *aligned = plan->plan.comm_allreduce(*comm->c) ? 1 : 0;
+  });
+}
+
+int fdb_plan_exchange(fdb_plan* plan, fdb_comm* comm, fdb_plan** shard) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] {
+    if (comm == nullptr || !comm->c || shard == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    single_table_only(plan);
+    *shard = nullptr;
+    std::unique_ptr<fdb_plan> s(new fdb_plan(plan->plan));
+    plan->plan.comm_exchange(*comm->c, s->plan);
+    *shard = s.release();
+  });
+}
+
+int fdb_live_allocations(int64_t* device_blocks, int64_t* device_bytes, int64_t* pinned_blocks) {
+  return guard(nullptr, [&] { fdb::live_allocations(device_blocks, device_bytes, pinned_blocks); });
 }
 
 }  // extern "C"

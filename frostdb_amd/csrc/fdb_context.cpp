@@ -2,6 +2,7 @@
 #include "fdb_context.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 
@@ -12,6 +13,7 @@ namespace fdb {
 namespace {
 std::mutex g_mu;
 std::vector<Context*> g_free[16];
+std::atomic<int64_t> g_live_dev_blocks{0}, g_live_dev_bytes{0}, g_live_pinned{0};
 inline size_t round_block(size_t b) {
   size_t r = 4096;
   while (r < b) r <<= 1;
@@ -49,7 +51,7 @@ void* Context::dev_alloc(size_t bytes) {
   Block* best = nullptr;
   for (Block& b : dev_blocks_)
     if (!b.used && b.bytes >= bytes && (best == nullptr || b.bytes < best->bytes)) best = &b;
-  if (best != nullptr && best->bytes <= bytes * 4) { best->used = true; return best->p; }
+  if (best != nullptr && best->bytes <= bytes * 4) { best->used = true; note_device_alloc(best->bytes); return best->p; }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes);
   if (e == hipErrorOutOfMemory) {  // drop the cache and retry once
@@ -60,12 +62,21 @@ void* Context::dev_alloc(size_t bytes) {
   }
   hip_check(e, "hipMalloc");
   dev_blocks_.push_back(Block{p, bytes, true});
+  note_device_alloc(bytes);
   return p;
 }
 
 void Context::dev_free(void* p) {
   if (p == nullptr) return;
-  for (Block& b : dev_blocks_) if (b.p == p) { b.used = false; return; }
+  for (Block& b : dev_blocks_) if (b.p == p) { if (b.used) note_device_free(b.bytes); b.used = false; return; }
+}
+
+void note_device_alloc(size_t bytes) { g_live_dev_blocks++; g_live_dev_bytes += (int64_t)bytes; }
+void note_device_free(size_t bytes) { g_live_dev_blocks--; g_live_dev_bytes -= (int64_t)bytes; }
+void live_allocations(int64_t* device_blocks, int64_t* device_bytes, int64_t* pinned_blocks) {
+  if (device_blocks) *device_blocks = g_live_dev_blocks.load();
+  if (device_bytes) *device_bytes = g_live_dev_bytes.load();
+  if (pinned_blocks) *pinned_blocks = g_live_pinned.load();
 }
 
 void* Context::host_alloc(size_t bytes) {
@@ -99,12 +110,13 @@ void* pinned_pool_alloc(size_t bytes) {
     PinnedBlock* best = nullptr;
     for (PinnedBlock& b : g_pinned)
       if (!b.used && b.bytes >= want && b.bytes <= want * 2 && (best == nullptr || b.bytes < best->bytes)) best = &b;
-    if (best != nullptr) { best->used = true; return best->p; }
+    if (best != nullptr) { best->used = true; g_live_pinned++; return best->p; }
   }
   void* p = nullptr;
   hip_check(hipHostMalloc(&p, want, hipHostMallocDefault), "hipHostMalloc(result)");
   std::lock_guard<std::mutex> lk(g_pin_mu);
   g_pinned.push_back(PinnedBlock{p, want, true});
+  g_live_pinned++;
   return p;
 }
 
@@ -115,7 +127,7 @@ void pinned_pool_free(void* p) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     size_t idle = 0;
     for (PinnedBlock& b : g_pinned) {
-      if (b.p == p) b.used = false;
+      if (b.p == p) { if (b.used) g_live_pinned--; b.used = false; }
       if (!b.used) idle += b.bytes;
     }
     // over budget: give the largest idle blocks back to the OS

@@ -65,4 +65,10 @@ class Context {
 void* pinned_pool_alloc(size_t bytes);
 void pinned_pool_free(void* p);
 
+// Live-allocation accounting (fdb_live_allocations): device blocks handed out by dev_alloc and not returned, arenas of
+// resident batches (note_device_alloc / _free), result blocks of the pinned pool not yet released.
+void note_device_alloc(size_t bytes);
+void note_device_free(size_t bytes);
+void live_allocations(int64_t* device_blocks, int64_t* device_bytes, int64_t* pinned_blocks);
+
 }  // namespace fdb

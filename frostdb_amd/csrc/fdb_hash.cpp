@@ -254,15 +254,17 @@ void Plan::fetch_compact_hash(CompactState* cs) {
   unsigned long long* d_entries = (unsigned long long*)ctx_->dev_alloc((size_t)n * oew * 8);
   uint32_t* d_keys = (uint32_t*)ctx_->dev_alloc((size_t)n * kw * 4);
   unsigned long long* d_n = (unsigned long long*)ctx_->dev_alloc(256);
-  hip_check(hipMemsetAsync(d_n, 0, 8, stream_), "hipMemsetAsync");
-  hip_check(fdb_launch_hash_compact(h_table_, h_keys_, h_capacity_, ew, kw, d_entries, d_keys, d_n, stream_), "hash compact");
+  uint32_t* d_bases = (uint32_t*)ctx_->dev_alloc((size_t)((h_capacity_ + 63) / 64 + 4) * 4);
+  // slot order: repeated calls on an unchanged table (partial_keys, then partial_state per aggregation) line up row by row
+  hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, ew, d_bases, d_n, stream_), "hash chunk bases");
+  hip_check(fdb_launch_hash_compact(h_table_, h_keys_, h_capacity_, ew, kw, d_entries, d_keys, d_bases, stream_), "hash compact");
   // pinned staging (cached by the context): pageable destinations would cap the copy at a few GB/s
   unsigned long long* entries = (unsigned long long*)ctx_->host_alloc((size_t)n * oew * 8);
   uint32_t* keys = (uint32_t*)ctx_->host_alloc((size_t)n * kw * 4);
   hip_check(hipMemcpyAsync(entries, d_entries, (size_t)n * oew * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(entries)");
   hip_check(hipMemcpyAsync(keys, d_keys, (size_t)n * kw * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(keys)");
   sync();
-  ctx_->dev_free(d_entries); ctx_->dev_free(d_keys); ctx_->dev_free(d_n);
+  ctx_->dev_free(d_entries); ctx_->dev_free(d_keys); ctx_->dev_free(d_n); ctx_->dev_free(d_bases);
   cs->cnt.resize(n);
   for (size_t j = 0; j < aggs_.size(); j++) cs->acc[j].resize(n);
   for (size_t c = 0; c < gcols_.size(); c++) {
@@ -311,7 +313,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   for (size_t c = 0; c < n_cols; c++) { d_key[c] = d_block + off_key[c]; d_valid[c] = d_valid_all + c * np; }
   for (size_t v = 0; v < n_vals; v++) d_vals[v] = (unsigned long long*)(d_block + off_val[v]);
   unsigned long long* d_n = (unsigned long long*)alloc(256);
-  hip_check(hipMemsetAsync(d_n, 0, 8, stream_), "hipMemsetAsync");
+  uint32_t* d_bases = (uint32_t*)alloc((size_t)((h_capacity_ + 63) / 64 + 4) * 4);
   std::vector<FdbHashCol> cols(std::max<size_t>(n_cols, 1));
   for (size_t c = 0; c < n_cols; c++) {
     std::memset(&cols[c], 0, sizeof(FdbHashCol));
@@ -324,11 +326,12 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   a.out_key = (void* const*)upload(d_key.data(), std::max<size_t>(n_cols, 1) * sizeof(void*));
   a.out_valid = (uint8_t* const*)upload(d_valid.data(), std::max<size_t>(n_cols, 1) * sizeof(void*));
   a.out_vals = (unsigned long long* const*)upload(d_vals.data(), n_vals * sizeof(void*));
-  a.n_out = d_n;
+  a.bases = d_bases;
   a.n_cols = (int)n_cols; a.entry_words = h_entry_words_; a.key_words = h_key_words_; a.n_vals = (int)n_vals;
   std::shared_ptr<void> backing;
   unsigned char* h_block = nullptr;
   if (n > 0) {
+    hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, h_entry_words_, d_bases, d_n, stream_), "hash chunk bases");
     hip_check(fdb_launch_hash_columns(a, stream_), "hash columns");
     for (size_t c = 0; c < n_cols; c++) hip_check(fdb_launch_pack_bits(d_valid[c], d_block + off_bits[c], (int64_t)n, stream_), "pack bits");
     h_block = (unsigned char*)pinned_pool_alloc(total);

@@ -88,10 +88,24 @@ uint64_t fnv(const std::string& s) {
   return h;
 }
 
+// Directory of the on-disk code-object cache, or "" when there is none that can be trusted: cached .hsaco files are loaded as GPU
+// code, so the directory must be a real directory (not a symlink) owned by this user and closed to everybody else — another
+// local user must not be able to plant code objects under a predictable name. $FDB_JIT_CACHE, else $XDG_CACHE_HOME/frostdb_amd,
+// else ~/.cache/frostdb_amd, else /tmp/frostdb_amd_jit_<uid> (all subject to the same check).
 std::string cache_dir() {
-  const char* e = std::getenv("FDB_JIT_CACHE");
-  std::string d = e ? e : ("/tmp/frostdb_amd_jit_" + std::to_string((long)getuid()));
-  ::mkdir(d.c_str(), 0700);
+  std::string d;
+  if (const char* e = std::getenv("FDB_JIT_CACHE")) d = e;
+  else if (const char* x = std::getenv("XDG_CACHE_HOME"); x != nullptr && *x) d = std::string(x) + "/frostdb_amd";
+  else if (const char* h = std::getenv("HOME"); h != nullptr && *h) { ::mkdir((std::string(h) + "/.cache").c_str(), 0700); d = std::string(h) + "/.cache/frostdb_amd"; }
+  else d = "/tmp/frostdb_amd_jit_" + std::to_string((long)getuid());
+  if (d.empty()) return "";
+  (void)::mkdir(d.c_str(), 0700);
+  struct stat st;
+  if (::lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 077) != 0) {
+    static bool warned = false;
+    if (!warned) { warned = true; std::fprintf(stderr, "[frostdb_amd] JIT disk cache disabled: %s is not a private directory of this user\n", d.c_str()); }
+    return "";
+  }
   return d;
 }
 
@@ -790,10 +804,27 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
   std::vector<char> code;
   char name[64];
   std::snprintf(name, sizeof name, "/k_%016llx_%zu.hsaco", (unsigned long long)(fnv(src) ^ (fnv(kKernelsHeader) * 31)), src.size());
-  const std::string path = cache_dir() + name;
-  {
+  const std::string dir = cache_dir();
+  const std::string path = dir.empty() ? std::string() : dir + name;
+  bool from_disk = false;
+  if (!path.empty()) {
     std::ifstream f(path, std::ios::binary);
     if (f) code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    from_disk = !code.empty();
+  }
+  auto load = [&](hipFunction_t* fn) {
+    hipModule_t mod = nullptr;
+    *fn = nullptr;
+    if (hipModuleLoadData(&mod, code.data()) == hipSuccess && hipModuleGetFunction(fn, mod, kernel_name) == hipSuccess) return true;
+    (void)hipGetLastError();
+    *fn = nullptr;
+    return false;
+  };
+  hipFunction_t fn = nullptr;
+  if (from_disk && !load(&fn)) {  // truncated / stale / foreign file: drop it and compile afresh instead of living on the fallback forever
+    (void)::unlink(path.c_str());
+    code.clear();
+    from_disk = false;
   }
   if (code.empty()) {
     std::string log;
@@ -803,14 +834,17 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
       g_cache.emplace(ckey, nullptr);
       return nullptr;
     }
-    const std::string tmp = path + "." + std::to_string((long)getpid());
-    std::ofstream f(tmp, std::ios::binary);
-    if (f) { f.write(code.data(), (std::streamsize)code.size()); f.close(); ::rename(tmp.c_str(), path.c_str()); }
+    if (!path.empty()) {  // publish atomically, and only a file that was written completely
+      const std::string tmp = path + "." + std::to_string((long)getpid());
+      bool ok = false;
+      {
+        std::ofstream f(tmp, std::ios::binary);
+        if (f) { f.write(code.data(), (std::streamsize)code.size()); f.close(); ok = !f.fail(); }
+      }
+      if (!ok || ::rename(tmp.c_str(), path.c_str()) != 0) (void)::unlink(tmp.c_str());
+    }
   }
-  hipModule_t mod = nullptr;
-  hipFunction_t fn = nullptr;
-  if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, kernel_name) != hipSuccess) {
-    (void)hipGetLastError();
+  if (fn == nullptr && !load(&fn)) {
     std::fprintf(stderr, "[frostdb_amd] could not load a specialised %s, using the interpreting kernel\n", kernel_name);
     fn = nullptr;
   }

@@ -251,10 +251,14 @@ hipError_t fdb_launch_hash_init(unsigned long long* table, uint64_t capacity, in
 hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int old_key_words,
                                   unsigned long long* new_table, uint32_t* new_keys, uint64_t new_mask, int entry_words, int new_key_words,
                                   hipStream_t stream);
-// Compacts the occupied entries: out_entries[i][0..entry_words-2] = {count, acc…} (fingerprints dropped), out_keys[i][key_words];
-// *n_out = number of entries. Order is arbitrary.
+// First output row of every 64-slot chunk of the table (bases[(capacity + 63) / 64], exclusive prefix sums of the occupied
+// entries per chunk) and *n_out = occupied entries: what makes the two compactions below deterministic — SLOT ORDER, no atomics.
+hipError_t fdb_launch_hash_chunk_bases(const unsigned long long* table, uint64_t capacity, int entry_words, uint32_t* bases, unsigned long long* n_out,
+                                       hipStream_t stream);
+// Compacts the occupied entries in slot order: out_entries[i][0..entry_words-2] = {count, acc…} (fingerprints dropped),
+// out_keys[i][key_words].
 hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int entry_words, int key_words,
-                                   unsigned long long* out_entries, uint32_t* out_keys, unsigned long long* n_out, hipStream_t stream);
+                                   unsigned long long* out_entries, uint32_t* out_keys, const uint32_t* bases, hipStream_t stream);
 // Finish for big tables: the occupied entries go straight into Arrow-shaped COLUMN buffers on the device (uint32 dictionary
 // indices = key id - 1, int64 key values, one validity BYTE per row and column, count and accumulator columns), so the
 // host only copies finished buffers. cols[c].word/kind/gi describe the key tuple; out_key[c] points to the column's value
@@ -262,7 +266,7 @@ hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32
 struct FdbHashColumnsArgs {
   const unsigned long long* table; const uint32_t* keys; uint64_t capacity;
   const FdbHashCol* cols; void* const* out_key; uint8_t* const* out_valid; unsigned long long* const* out_vals;
-  unsigned long long* n_out;
+  const uint32_t* bases;  // fdb_launch_hash_chunk_bases
   int32_t n_cols, entry_words, key_words, n_vals;
 };
 hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, hipStream_t stream);
@@ -355,4 +359,8 @@ hipError_t fdb_launch_gather(const void* src, void* dst, const uint32_t* indices
 hipError_t fdb_launch_gather_bits(const uint8_t* src_bitmap, uint8_t* dst_bitmap, const uint32_t* indices, int64_t n,
                                   hipStream_t stream);
 int fdb_scan_default_grid(int device);
+// Local (in-process) communicator: dst[i] = reduce over r < n_srcs, in rank order, of srcs[r][i] for lo ≤ i < hi (8-byte elements;
+// op 1 int64 sum, 2 float64 sum, 3 int64 min, 4 int64 max). `srcs` are device pointers of this or of peer devices; dst may be
+// one of them (each element is read from every source before it is written).
+hipError_t fdb_launch_peer_reduce(unsigned long long* dst, const void* const* srcs, int n_srcs, int64_t lo, int64_t hi, int op, hipStream_t stream);
 #endif  // FDB_DEVICE_ONLY

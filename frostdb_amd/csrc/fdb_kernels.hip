@@ -879,25 +879,33 @@ __global__ void hash_rehash_kernel(const unsigned long long* old_table, const ui
   }
 }
 
+// Occupied entries per 64-slot chunk (one wave per chunk): the exclusive scan of these counts (hash_scan_chunks) gives every
+// chunk its first output row, so compaction places entries in SLOT ORDER — the same order for every call on an unchanged table
+// (keys and every aggregate column of a merge line up), with no atomics.
+__global__ void hash_chunk_counts_kernel(const unsigned long long* table, uint64_t capacity, int ew, uint32_t* counts) {
+  const uint64_t n_round = (capacity + 63) & ~(uint64_t)63;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
+    const bool occ = i < capacity && table[i * (uint64_t)ew] != 0ull;
+    const unsigned long long m = __ballot(occ);
+    if ((threadIdx.x & 63) == 0) counts[i >> 6] = (uint32_t)__popcll(m);
+  }
+}
+
 __global__ void hash_compact_kernel(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int ew, int kw,
-                                    unsigned long long* out_entries, uint32_t* out_keys, unsigned long long* n_out) {
+                                    unsigned long long* out_entries, uint32_t* out_keys, const uint32_t* bases) {
   const uint64_t n_round = (capacity + 63) & ~(uint64_t)63;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
     const bool occ = i < capacity && table[i * (uint64_t)ew] != 0ull;
     const unsigned long long m = __ballot(occ);
     if (m == 0ull) continue;
-    unsigned long long base = 0;
     const int lane = threadIdx.x & 63;
-    if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
-    base = __shfl(base, 0, 64);
     if (occ) {
-      const uint64_t o = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+      const uint64_t o = (uint64_t)bases[i >> 6] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
       for (int w = 2; w < ew; w++) out_entries[o * (uint64_t)(ew - 2) + (w - 2)] = table[i * (uint64_t)ew + w];
       for (int w = 0; w < kw; w++) out_keys[o * (uint64_t)kw + w] = keys[i * (uint64_t)kw + w];
     }
   }
 }
-
 __global__ void hash_columns_kernel(const FdbHashColumnsArgs a) {
   const uint64_t n_round = (a.capacity + 63) & ~(uint64_t)63;
   const int ew = a.entry_words, kw = a.key_words;
@@ -905,12 +913,9 @@ __global__ void hash_columns_kernel(const FdbHashColumnsArgs a) {
     const bool occ = i < a.capacity && a.table[i * (uint64_t)ew] != 0ull;
     const unsigned long long m = __ballot(occ);
     if (m == 0ull) continue;
-    unsigned long long base = 0;
     const int lane = threadIdx.x & 63;
-    if (lane == 0) base = atomicAdd(a.n_out, (unsigned long long)__popcll(m));
-    base = __shfl(base, 0, 64);
     if (!occ) continue;
-    const uint64_t o = base + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint64_t o = (uint64_t)a.bases[i >> 6] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));  // slot order, see hash_chunk_counts_kernel
     const unsigned long long* e = a.table + i * (uint64_t)ew;
     for (int v = 0; v < a.n_vals; v++) a.out_vals[v][o] = e[2 + v];
     const uint32_t* k = a.keys + i * (uint64_t)kw;
@@ -1136,6 +1141,22 @@ __global__ void merge_u64_kernel(unsigned long long* dst, const unsigned long lo
     } else {
       atomicMax(reinterpret_cast<long long*>(dst) + d, (long long)v);
     }
+  }
+}
+
+// ---- local communicator: reduce one slice of an array across the ranks' buffers (peer loads) --------------------------------
+struct PeerSrcs { const unsigned long long* p[FDB_MAX_PARTS]; };
+__global__ void peer_reduce_kernel(unsigned long long* dst, const PeerSrcs srcs, int n_srcs, int64_t lo, int64_t hi, int op) {
+  for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long acc = srcs.p[0][i];
+    for (int r = 1; r < n_srcs; r++) {
+      const unsigned long long v = srcs.p[r][i];
+      if (op == 1) acc += v;
+      else if (op == 2) acc = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)acc) + __longlong_as_double((long long)v));
+      else if (op == 3) acc = (unsigned long long)min((long long)acc, (long long)v);
+      else acc = (unsigned long long)max((long long)acc, (long long)v);
+    }
+    dst[i] = acc;
   }
 }
 
@@ -1383,6 +1404,17 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
   return hipGetLastError();
 }
 
+hipError_t fdb_launch_peer_reduce(unsigned long long* dst, const void* const* srcs, int n_srcs, int64_t lo, int64_t hi, int op, hipStream_t stream) {
+  if (hi <= lo) return hipSuccess;
+  if (n_srcs < 1 || n_srcs > FDB_MAX_PARTS) return hipErrorInvalidValue;
+  PeerSrcs S;
+  for (int r = 0; r < n_srcs; r++) S.p[r] = (const unsigned long long*)srcs[r];
+  int blocks = (int)((hi - lo + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(peer_reduce_kernel, dim3(blocks), dim3(256), 0, stream, dst, S, n_srcs, lo, hi, op);
+  return hipGetLastError();
+}
+
 hipError_t fdb_launch_select(const FdbScanArgs& args, uint32_t* indices_out, unsigned long long* n_selected_out, uint32_t* tile_counts,
                              hipStream_t stream) {
   // `tile_counts` doubles as scratch: [n_tiles counts][mask bytes]
@@ -1455,10 +1487,19 @@ hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uin
   return hipGetLastError();
 }
 
+hipError_t fdb_launch_hash_chunk_bases(const unsigned long long* table, uint64_t capacity, int entry_words, uint32_t* bases, unsigned long long* n_out,
+                                       hipStream_t stream) {
+  const int64_t n_chunks = (int64_t)((capacity + 63) / 64);
+  if (n_chunks == 0) return hipMemsetAsync(n_out, 0, 8, stream);
+  hipLaunchKernelGGL(hash_chunk_counts_kernel, dim3(4096), dim3(256), 0, stream, table, capacity, entry_words, bases);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, bases, n_chunks, n_out);  // in place: counts → exclusive prefix sums
+  return hipGetLastError();
+}
+
 hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int entry_words, int key_words,
-                                   unsigned long long* out_entries, uint32_t* out_keys, unsigned long long* n_out, hipStream_t stream) {
+                                   unsigned long long* out_entries, uint32_t* out_keys, const uint32_t* bases, hipStream_t stream) {
   hipLaunchKernelGGL(hash_compact_kernel, dim3(4096), dim3(256), 0, stream, table, keys, capacity, entry_words, key_words, out_entries, out_keys,
-                     n_out);
+                     bases);
   return hipGetLastError();
 }
 

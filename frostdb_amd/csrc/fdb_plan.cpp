@@ -71,6 +71,7 @@ DeviceBatch::~DeviceBatch() {
   if (arena_ctx != nullptr) { arena_ctx->dev_free(arena); return; }
   (void)hipSetDevice(device);
   (void)hipFree(arena);
+  note_device_free(arena_bytes);
 }
 
 int DeviceBatch::find(const std::string& name) const {
@@ -123,7 +124,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
   }
   if (total > 0) {
     if (ctx != nullptr) { b->arena = ctx->dev_alloc(total); b->arena_ctx = ctx; }
-    else hip_check(hipMalloc(&b->arena, total), "hipMalloc(batch arena)");
+    else { hip_check(hipMalloc(&b->arena, total), "hipMalloc(batch arena)"); note_device_alloc(total); }
     b->arena_bytes = total;
   }
   // transient batches: every copy is queued on `stream`; re-packed buffers stay alive until the one wait at the end
@@ -241,6 +242,21 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
   }
   filter_root_ = d->n_filter > 0 ? d->filter_root : -1;
   if (d->n_filter > 0 && (filter_root_ < 0 || filter_root_ >= d->n_filter)) throw Error(FDB_ERR_INVALID, "filter_root out of range");
+  if (filter_root_ >= 0) {
+    // The nodes may come in any order, but they must form a TREE below the root: a node that names itself or an ancestor as a
+    // child would send every recursive walk over the expression (resolution, truth tables, Draw) into the ground.
+    std::vector<char> state(filter_.size(), 0);  // 0 unvisited, 1 on the current path, 2 done
+    std::function<void(int, int)> walk = [&](int i, int depth) {
+      if (depth > 64) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too deep");
+      if (state[(size_t)i] == 1) throw Error(FDB_ERR_INVALID, "filter expression is not a tree: node " + std::to_string(i) + " is its own ancestor");
+      if (state[(size_t)i] == 2) throw Error(FDB_ERR_INVALID, "filter expression is not a tree: node " + std::to_string(i) + " has two parents");
+      state[(size_t)i] = 1;
+      const ExprNode& e = filter_[(size_t)i];
+      if (e.op == FDB_OP_AND || e.op == FDB_OP_OR) { walk(e.left, depth + 1); walk(e.right, depth + 1); }
+      state[(size_t)i] = 2;
+    };
+    walk(filter_root_, 0);
+  }
   final_stage_ = d->final_stage != 0;
   for (int32_t i = 0; i < d->n_aggs; i++) {
     AggState a;
@@ -299,6 +315,15 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
     projs_.push_back(std::move(P));
   }
   if (explain_only) return;  // fdb_plan_explain: the descriptor is validated and drawn, nothing can be pushed
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  ctx_ = Context::acquire(device_);
+  stream_ = ctx_->stream;
+}
+
+Plan::Plan(const Plan& proto, CloneTag)
+    : projs_(proto.projs_), device_(proto.device_), filter_(proto.filter_), filter_root_(proto.filter_root_), aggs_(proto.aggs_),
+      matchers_(proto.matchers_), final_stage_(proto.final_stage_) {
+  for (AggState& a : aggs_) a.d_acc = nullptr;  // (value types are kept: a clone merges with its prototype)
   hip_check(hipSetDevice(device_), "hipSetDevice");
   ctx_ = Context::acquire(device_);
   stream_ = ctx_->stream;

@@ -161,10 +161,26 @@ struct CompactState {
 };
 
 class Context;  // per-device stream + cached device/pinned memory (fdb_context.h)
+class Comm;     // one rank's endpoint of a cross-GPU communicator (fdb_comm.h)
+
+// The group columns of a plan — names, kinds, distinct key values in id order — and the value types of its aggregations: what
+// ranks exchange to agree on one key-id space before a hash-partitioned merge (fdb_plan_exchange).
+struct GroupSchemaCol {
+  std::string name;
+  int kind = 0;
+  bool is_bool = false, is_u64 = false, plain = false;
+  std::string value_format = "z";
+  std::vector<std::string> values;
+};
+struct GroupSchema { std::vector<GroupSchemaCol> cols; std::vector<int32_t> agg_types; };
 
 class Plan {
  public:
   Plan(const fdb_plan_desc* desc, int device, bool explain_only = false);
+  struct CloneTag {};
+  Plan(const Plan& proto, CloneTag);  // a fresh plan of the same descriptor on the same device (no state)
+  Plan(const Plan&) = delete;
+  Plan& operator=(const Plan&) = delete;
   ~Plan();
 
   void push(const ArrowArray* array, const ArrowSchema* schema);        // ≙ Callback
@@ -204,6 +220,11 @@ class Plan {
   // *dev_rows (owned by this plan until its next push / close) holds the partitions back to back, counts[p] rows each.
   void hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32);
   void hash_import(const void* dev_rows, int64_t n_rows);       // rows packed for THIS plan's layout
+  // Cross-GPU merges over a communicator (fdb_comm.cpp; ≙ Synchronizer + final stage, synchronize.go:31-53). Collective calls.
+  bool comm_allreduce(Comm& comm);               // aligned dense tables: in-place all-reduce on this plan's stream; false = layouts differ, nothing changed
+  void comm_exchange(Comm& comm, Plan& shard);   // any tables: schema agreement + hash-partitioned exchange into `shard` (a fresh clone)
+  GroupSchema export_schema() const;
+  void adopt_schema(const GroupSchema& s);       // adopt columns / key values in that order (switches to the hash table)
 
   std::string error;
   int device() const { return device_; }

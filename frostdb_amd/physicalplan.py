@@ -95,6 +95,21 @@ def lib() -> ctypes.CDLL:
     L.fdb_arrow_roundtrip.argtypes = [vp, vp, vp, vp]
     L.fdb_plan_explain.argtypes = [vp, ctypes.c_char_p, i64, P(i64)]
     L.fdb_plan_last_kernel.restype = ctypes.c_char_p
+    L.fdb_comm_unique_id.argtypes = [vp]
+    L.fdb_comm_init_rank.argtypes = [vp, i32, i32, ctypes.c_int, P(vp)]
+    L.fdb_comm_init_all.argtypes = [P(ctypes.c_int), i32, P(vp)]
+    L.fdb_comm_init_local.argtypes = [P(ctypes.c_int), i32, P(vp)]
+    L.fdb_comm_rank.argtypes = [vp]
+    L.fdb_comm_rank.restype = i32
+    L.fdb_comm_size.argtypes = [vp]
+    L.fdb_comm_size.restype = i32
+    L.fdb_comm_last_error.argtypes = [vp]
+    L.fdb_comm_last_error.restype = ctypes.c_char_p
+    L.fdb_comm_destroy.argtypes = [vp]
+    L.fdb_comm_destroy.restype = None
+    L.fdb_plan_allreduce.argtypes = [vp, vp, P(i32)]
+    L.fdb_plan_exchange.argtypes = [vp, vp, P(vp)]
+    L.fdb_live_allocations.argtypes = [P(i64), P(i64), P(i64)]
     _lib = L
     return L
 
@@ -127,6 +142,13 @@ def arrow_roundtrip(record: pa.RecordBatch) -> pa.RecordBatch:
     if rc != 0:
         _raise(rc, lib().fdb_last_error().decode())
     return import_batch(arr, sch)
+
+
+def live_allocations() -> dict:
+    """Device blocks / bytes and pinned result blocks the library owns right now (0 once everything is closed and released)."""
+    a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    lib().fdb_live_allocations(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    return {"device_blocks": a.value, "device_bytes": b.value, "pinned_blocks": c.value}
 
 
 def device_count() -> int:
@@ -190,6 +212,19 @@ class HashAggregatePlan:
         self.device = device
         self._next: Optional[Callable[[pa.RecordBatch], None]] = None
         self._next_finish: Optional[Callable[[], None]] = None
+
+    @classmethod
+    def _adopt(cls, handle: int, proto: "HashAggregatePlan") -> "HashAggregatePlan":
+        """Wraps a plan handle the library created itself (the shard of fdb_plan_exchange) with `proto`'s descriptor."""
+        self = cls.__new__(cls)
+        self._desc = proto._desc
+        self.aggs = list(proto.aggs)
+        self._ctor = proto._ctor
+        self.handle = handle
+        self.device = proto.device
+        self._next = None
+        self._next_finish = None
+        return self
 
     def _check(self, rc: int) -> None:
         if rc != 0:

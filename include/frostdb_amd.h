@@ -298,6 +298,50 @@ int fdb_plan_hash_export(fdb_plan* src, fdb_plan* layout, int32_t n_parts, void*
 /* dev_rows: DEVICE pointer to n_rows rows packed for `plan`'s layout; may be released when the call returns. */
 int fdb_plan_hash_import(fdb_plan* plan, const void* dev_rows, int64_t n_rows);
 
+/* ---- cross-GPU merge behind the C ABI: RCCL over xGMI, no Python in the loop -------------------------------
+ * ≙ Synchronizer + HashAggregate(final=true) (synchronize.go:31-53, physicalplan.go:438-471) when the N chains of a query run
+ * on N GPUs. The reference runs its N chains in ONE process (physicalplan.go:22, :337-347); both deployment shapes exist here:
+ *   one process, N devices:  fdb_comm_init_all(devices, n, comms)   → ncclCommInitAll; each chain's goroutine / thread drives
+ *                                                                     its own handle (collective calls block until all joined)
+ *   one process per GPU:     rank 0 calls fdb_comm_unique_id, the host ships the 128 bytes over whatever it already has
+ *                            (FrostDB: its own control plane; bench.py: the launcher's rendezvous), every rank calls
+ *                            fdb_comm_init_rank.
+ *   fdb_comm_init_local is the same interface over direct peer-to-peer loads / copies between the ranks' buffers inside one
+ *   process — no RCCL: the ranks may share a device (RCCL refuses two ranks on one GPU), which is how the multi-rank paths are
+ *   tested on a 1-GPU box, and on an xGMI node it is the low-latency route for the 8 KiB tables of low-cardinality queries.
+ * librccl is bound at run time (dlopen: the copy already in the process, else librccl.so.1, else $FDB_RCCL_LIB), so a host
+ * without RCCL can still load this library; fdb_comm_unique_id / _init_rank / _init_all then fail with FDB_ERR_UNSUPPORTED. */
+typedef struct fdb_comm fdb_comm;
+#define FDB_COMM_ID_BYTES 128
+int fdb_comm_unique_id(uint8_t id[FDB_COMM_ID_BYTES]);
+int fdb_comm_init_rank(const uint8_t id[FDB_COMM_ID_BYTES], int32_t n_ranks, int32_t rank, int device, fdb_comm** out);
+int fdb_comm_init_all(const int* devices, int32_t n, fdb_comm** out /* [n] */);
+int fdb_comm_init_local(const int* devices, int32_t n, fdb_comm** out /* [n] */);
+int32_t fdb_comm_rank(const fdb_comm* comm);
+int32_t fdb_comm_size(const fdb_comm* comm);
+const char* fdb_comm_last_error(const fdb_comm* comm);
+void fdb_comm_destroy(fdb_comm* comm);
+/* Low-cardinality merge (cfgs 2-4): when every rank's dense table has the same slot layout (fdb_plan_state_signature — parts of
+ * one table share their dictionaries), slot i means the same group everywhere and the table arrays are all-reduced IN PLACE on
+ * the plan's own stream: SUM for counts and sums, integer MIN / MAX for MIN / MAX (float64 MIN / MAX live as order-preserving
+ * int64 keys). One grouped launch of 1 + #aggregations collectives of n_slots × 8 bytes; the layout check is one tiny MAX
+ * all-reduce issued on the communicator's own stream, so it overlaps the scan kernel. *aligned = 1: every rank now holds the
+ * merged table (call fdb_plan_finish on the rank that emits; the others just close). *aligned = 0: layouts differ (or the plan
+ * is in hash mode) — nothing was changed, use fdb_plan_exchange. Collective: every rank of `comm` must call it. */
+int fdb_plan_allreduce(fdb_plan* plan, fdb_comm* comm, int32_t* aligned);
+/* General merge (any table mode, any key sets; cfg 5): ranks agree on one group schema (all-gather of column names + distinct key
+ * values, union in rank order), every table is re-keyed and hash-partitioned on the device (fdb_plan_hash_export), partitions
+ * travel point-to-point to their owners (grouped send / recv: all 7 xGMI links of a GPU busy at once; slices of ≤ 128 MiB per
+ * peer), owners merge on the device. The result STAYS SHARDED: *shard is a new plan of the same descriptor holding this rank's
+ * share of the final groups (fingerprint % n_ranks == rank) — fdb_plan_finish + fdb_plan_close it. Collective. */
+int fdb_plan_exchange(fdb_plan* plan, fdb_comm* comm, fdb_plan** shard);
+
+/* Device memory owned by the library right now (≙ the reference's leak-checked allocator, memory.CheckedAllocator.AssertSize(0),
+ * logictest/logic_test.go:169-177): blocks handed out by the per-device caching allocator and not yet returned, plus the arenas
+ * of live resident batches; `pinned` counts result blocks whose Arrow release callback has not run. Cached-but-idle blocks are
+ * not counted. All three are 0 once every plan, batch, communicator and result record has been closed / released. */
+int fdb_live_allocations(int64_t* device_blocks, int64_t* device_bytes, int64_t* pinned_blocks);
+
 /* ---- resident batches (a part kept in HBM between queries; 288 GB per GPU) ---------------------- */
 int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int device, fdb_batch** out);
 int64_t fdb_batch_num_rows(const fdb_batch* batch);

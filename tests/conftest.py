@@ -16,3 +16,18 @@ def pytest_configure(config):
 def _build_oracle():
     import oracle
     oracle.build()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _no_device_allocation_outlives_a_test_module():
+    """≙ memory.CheckedAllocator.AssertSize(0) after every logictest file (logictest/logic_test.go:169-177): once a test module is
+    done — every plan closed, every resident batch and result record released — the library owns no device block and no pinned
+    result block (fdb_live_allocations; idle blocks of the caching allocator are not counted)."""
+    yield
+    import gc
+    from frostdb_amd import physicalplan as pp
+    if pp._lib is None:
+        return
+    gc.collect()
+    live = pp.live_allocations()
+    assert live == {"device_blocks": 0, "device_bytes": 0, "pinned_blocks": 0}, f"device allocations leaked by this test module: {live}"

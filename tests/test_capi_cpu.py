@@ -221,3 +221,17 @@ def test_arrow_roundtrip_random_shapes(built_lib):
             assert norm(out.column("c")) == norm(r.column("c")), (trial, kind, lo, hi)
             assert out.column("row").to_pylist() == r.column("row").to_pylist()
             assert out.column("c").null_count == r.column("c").null_count
+
+
+def test_local_communicator_endpoints_and_allocation_counters_without_a_gpu():
+    """fdb_comm_init_local for ranks that share a device needs no HIP call: endpoints report their rank / size; the live-allocation
+    counters (the leak check of the GPU suite) read zero in a process that allocated nothing."""
+    from frostdb_amd import comm as fcomm
+    from frostdb_amd import physicalplan as pp
+    comms = fcomm.Comm.init_local([0, 0, 0])
+    assert [c.rank for c in comms] == [0, 1, 2] and all(c.size == 3 for c in comms)
+    for c in comms:
+        c.close()
+    assert pp.live_allocations() == {"device_blocks": 0, "device_bytes": 0, "pinned_blocks": 0}
+    with pytest.raises(ValueError):
+        fcomm.Comm(b"short", 2, 0, 0)

@@ -1593,3 +1593,38 @@ def test_unique_and_and_vs_oracle_at_scale(pp, variant):
                 plan.Callback(recs[0])
         finally:
             plan.Close()
+
+
+def test_hash_mode_partial_keys_and_states_line_up(pp):
+    """Slot-order compaction of a hash table: fdb_plan_partial_keys and one fdb_plan_partial_state call per aggregation each run
+    their own compaction — rows must mean the same group in all of them (the cross-rank key-unification merge relies on it), and
+    repeated calls must return the same order. 30 000 int64-keyed groups (hash mode), checked against Finish of a twin plan."""
+    import ctypes
+    rng = np.random.default_rng(123)
+    n = 200_000
+    rec = pa.RecordBatch.from_arrays(
+        [pa.array(rng.integers(1, 30_000, n).astype(np.int64)), dict_array([b"a", b"b", None][i % 3] for i in range(n)),
+         pa.array(rng.integers(-50, 50, n).astype(np.int64)), pa.array(rng.uniform(0, 1, n))],
+        names=["bucket", "labels.x", "ival", "value"])
+    aggs = [Sum(Col("value")), Min(Col("ival")), Count(Col("value")), Max(Col("ival"))]
+    groups = [Col("bucket"), Col("labels.x")]
+    plan = pp.HashAggregatePlan(None, aggs, groups)
+    twin = pp.HashAggregatePlan(None, aggs, groups)
+    try:
+        plan.Callback(rec)
+        twin.Callback(rec)
+        want = arrow_to_pydict(twin.Finish())
+        k1, k2 = arrow_to_pydict(plan.partial_keys()), arrow_to_pydict(plan.partial_keys())
+        assert k1 == k2
+        g = len(k1["bucket"])
+        assert g == len(want["bucket"]) and g > 30_000
+        got = dict(k1)
+        for j, a in enumerate(aggs):
+            buf = np.zeros(g, dtype=np.float64 if plan.agg_format(j) == "g" else np.int64)
+            plan.partial_state_into(j, buf.ctypes.data, g * 8)
+            got[a.Name()] = buf.tolist()
+        cols = ["bucket", "labels.x"] + [a.Name() for a in aggs]
+        assert_same_result(got, want, cols, float_cols={"sum(value)"})
+    finally:
+        plan.Close()
+        twin.Close()
