@@ -34,6 +34,38 @@ int index_width_of(const std::string& f) {
   return 0;
 }
 
+
+// Interning tables of read_dictionary / encode_plain: content hash → weak reference. Candidates are compared OUTSIDE the lock (a
+// full-content memcmp under a process-wide mutex would serialise concurrent scan chains), and expired entries are swept whenever
+// the table has doubled since the last sweep, so a long-running process that sees an endless stream of distinct dictionaries
+// (one per part / row group) keeps the table proportional to the LIVE dictionaries. HostDicts are allocated with `new` (not
+// make_shared), so their memory goes when the last strong reference does, whatever weak references remain.
+struct InternTable {
+  std::mutex mu;
+  std::unordered_multimap<uint64_t, std::weak_ptr<HostDict>> live;
+  size_t sweep_at = 1024;
+  std::vector<std::shared_ptr<HostDict>> candidates(uint64_t h) {
+    std::vector<std::shared_ptr<HostDict>> out;
+    std::lock_guard<std::mutex> lk(mu);
+    auto range = live.equal_range(h);
+    for (auto it = range.first; it != range.second;) {
+      std::shared_ptr<HostDict> other = it->second.lock();
+      if (!other) { it = live.erase(it); continue; }
+      out.push_back(std::move(other));
+      ++it;
+    }
+    return out;
+  }
+  void insert(uint64_t h, const std::shared_ptr<HostDict>& d) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (live.size() >= sweep_at) {
+      for (auto it = live.begin(); it != live.end();) { if (it->second.expired()) it = live.erase(it); else ++it; }
+      sweep_at = std::max<size_t>(1024, live.size() * 2);
+    }
+    live.emplace(h, d);
+  }
+};
+
 }  // namespace
 
 void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordView* out) {
@@ -71,6 +103,8 @@ void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordV
         c.kind == ColKind::BOOL) {
       if (ca->n_buffers < 2) throw Error(FDB_ERR_INVALID, "missing values buffer: " + c.name);
       c.values = ca->buffers[1];
+      if (c.values == nullptr && c.length > 0) throw Error(FDB_ERR_INVALID, "NULL values buffer in a column with rows: " + c.name);
+      if (c.kind == ColKind::DICT && (ca->dictionary == nullptr || cs->dictionary == nullptr)) throw Error(FDB_ERR_INVALID, "dictionary column without a dictionary array: " + c.name);
     }
     out->cols.push_back(std::move(c));
   }
@@ -78,14 +112,23 @@ void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordV
 
 std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
   const ArrowArray* da = col.array->dictionary;
+  if (da == nullptr || col.schema->dictionary == nullptr || col.schema->dictionary->format == nullptr)
+    throw Error(FDB_ERR_INVALID, "dictionary column without a dictionary array: " + col.name);
   const std::string df = col.schema->dictionary->format;
   const std::string value_format = (df == "u" || df == "U") ? "u" : "z";
   const int64_t n = da->length, off = da->offset;
-  const char* data = (const char*)da->buffers[2];
+  if (n < 0 || off < 0) throw Error(FDB_ERR_INVALID, "dictionary with a negative length / offset: " + col.name);
+  if (n > 0 && (da->n_buffers < 3 || da->buffers[1] == nullptr)) throw Error(FDB_ERR_INVALID, "dictionary without an offsets buffer: " + col.name);
+  const char* data = da->n_buffers >= 3 ? (const char*)da->buffers[2] : nullptr;
   const bool wide = !(df == "u" || df == "z");
   const int32_t* o32 = (const int32_t*)da->buffers[1];
   const int64_t* o64 = (const int64_t*)da->buffers[1];
   auto begin = [&](int64_t i) -> int64_t { return wide ? o64[off + i] : (int64_t)o32[off + i]; };
+  // offsets must not decrease, and a dictionary with bytes needs a data buffer (a NULL entry reads as "", like arrow-go's
+  // Binary.Value of a null slot)
+  for (int64_t i = 0; i < n; i++)
+    if (begin(i + 1) < begin(i) || begin(i) < 0) throw Error(FDB_ERR_INVALID, "dictionary with decreasing offsets: " + col.name);
+  if (n > 0 && begin(n) > begin(0) && data == nullptr) throw Error(FDB_ERR_INVALID, "dictionary without a data buffer: " + col.name);
   // content hash straight over the Arrow buffers: FNV-1a over (length, bytes) of every entry
   uint64_t h = 1469598103934665603ull;
   for (int64_t i = 0; i < n; i++) {
@@ -98,25 +141,17 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
   // for all of them turns every later "same dictionary?" test (key-id LUT cache, LUT de-duplication across the records of a
   // launch) into a pointer compare — and a record whose dictionary is already known costs one pass over its bytes here,
   // no string allocations.
-  static std::mutex mu;
-  static std::unordered_multimap<uint64_t, std::weak_ptr<HostDict>> live;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    auto range = live.equal_range(h);
-    for (auto it = range.first; it != range.second;) {
-      std::shared_ptr<HostDict> other = it->second.lock();
-      if (!other) { it = live.erase(it); continue; }
-      bool same = !other->plain && other->value_format == value_format && (int64_t)other->values.size() == n;
-      for (int64_t i = 0; i < n && same; i++) {
-        const int64_t b0 = begin(i), len = begin(i + 1) - b0;
-        const std::string& v = other->values[(size_t)i];
-        same = (int64_t)v.size() == len && (len == 0 || std::memcmp(v.data(), data + b0, (size_t)len) == 0);
-      }
-      if (same) return other;
-      ++it;
+  static InternTable table;
+  for (const std::shared_ptr<HostDict>& other : table.candidates(h)) {
+    bool same = !other->plain && other->value_format == value_format && (int64_t)other->values.size() == n;
+    for (int64_t i = 0; i < n && same; i++) {
+      const int64_t b0 = begin(i), len = begin(i + 1) - b0;
+      const std::string& v = other->values[(size_t)i];
+      same = (int64_t)v.size() == len && (len == 0 || std::memcmp(v.data(), data + b0, (size_t)len) == 0);
     }
+    if (same) return other;
   }
-  auto d = std::make_shared<HostDict>();
+  std::shared_ptr<HostDict> d(new HostDict());
   d->value_format = value_format;
   d->hash = h;
   d->values.resize((size_t)n);
@@ -125,8 +160,7 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
   seen.reserve(d->values.size() * 2);
   for (const std::string& v : d->values)
     if (!seen.insert(std::string_view(v)).second) d->unique = false;
-  std::lock_guard<std::mutex> lk(mu);
-  live.emplace(h, d);
+  table.insert(h, d);
   return d;
 }
 
@@ -139,7 +173,7 @@ std::shared_ptr<HostDict> encode_plain(const HostColView& col, std::vector<uint3
   const int32_t* o32 = (const int32_t*)a->buffers[1];
   const int64_t* o64 = (const int64_t*)a->buffers[1];
   auto begin = [&](int64_t i) -> int64_t { return wide ? o64[off + i] : (int64_t)o32[off + i]; };
-  auto d = std::make_shared<HostDict>();
+  std::shared_ptr<HostDict> d(new HostDict());
   d->value_format = col.format;  // the column's own type, large or not: key columns and filter output keep it
   d->plain = true;
   idx->assign((size_t)n, 0u);
@@ -168,24 +202,15 @@ std::shared_ptr<HostDict> encode_plain(const HostColView& col, std::vector<uint3
   d->hash = h ^ 0x9E3779B97F4A7C15ull;  // (never equal to the hash of a real dictionary with the same entries)
   // share with an earlier record's encoding when the distinct values came out the same (same order): downstream caches
   // (key-id LUTs, truth tables) are keyed by the dictionary object
-  static std::mutex mu;
-  static std::unordered_multimap<uint64_t, std::weak_ptr<HostDict>> live;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    auto range = live.equal_range(d->hash);
-    for (auto it = range.first; it != range.second;) {
-      std::shared_ptr<HostDict> other = it->second.lock();
-      if (!other) { it = live.erase(it); continue; }
-      bool same = other->value_format == d->value_format && other->values.size() == order.size();
-      for (size_t i = 0; i < order.size() && same; i++) same = std::string_view(other->values[i]) == order[i];
-      if (same) return other;
-      ++it;
-    }
+  static InternTable table;
+  for (const std::shared_ptr<HostDict>& other : table.candidates(d->hash)) {
+    bool same = other->plain && other->value_format == d->value_format && other->values.size() == order.size();
+    for (size_t i = 0; i < order.size() && same; i++) same = std::string_view(other->values[i]) == order[i];
+    if (same) return other;
   }
   d->values.reserve(order.size());
   for (const std::string_view& v : order) d->values.emplace_back(v);
-  std::lock_guard<std::mutex> lk(mu);
-  live.emplace(d->hash, d);
+  table.insert(d->hash, d);
   return d;
 }
 

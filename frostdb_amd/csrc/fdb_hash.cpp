@@ -13,6 +13,8 @@
 #include "fdb_plan_internal.h"
 #include "fdb_jit.h"
 
+#include <cmath>
+
 namespace fdb {
 
 namespace {
@@ -27,8 +29,7 @@ void Plan::hash_layout() {
   const int ew = (int)((3 + aggs_.size() + 3) / 4 * 4);
   if (h_table_ == nullptr) { h_key_words_ = kw; h_entry_words_ = ew; return; }
   if (kw != h_key_words_) {  // columns were added: widen the key store (same capacity, same fingerprints)
-    uint32_t* nk = (uint32_t*)ctx_->dev_alloc((size_t)h_capacity_ * kw * 4);
-    hip_check(hipMemsetAsync(nk, 0, (size_t)h_capacity_ * kw * 4, stream_), "hipMemsetAsync(keys)");
+    uint32_t* nk = (uint32_t*)ctx_->dev_alloc((size_t)h_capacity_ * kw * 4);  // (no initialisation needed, see fdb_launch_hash_rehash)
     unsigned long long* nt = (unsigned long long*)ctx_->dev_alloc((size_t)h_capacity_ * ew * 8);
     unsigned long long idents[FDB_MAX_AGGS] = {0};
     for (size_t j = 0; j < aggs_.size(); j++)
@@ -49,20 +50,20 @@ uint64_t Plan::hash_groups() {
   return n;
 }
 
-void Plan::hash_reserve(uint64_t extra) {
-  uint64_t need = next_pow2(std::max<uint64_t>(2 * (h_groups_bound_ + extra), 1 << 16));
+void Plan::hash_reserve(uint64_t extra, uint64_t expected_groups) {
+  // capacity ≥ 2 × (groups + extra) is what makes an insert unable to fail; `expected_groups` (the cardinality estimate of
+  // push_hash) only ever raises the target, so that a table that is still filling up is grown ONCE to its final size instead of
+  // doubling its way there (cfg 5: 15 re-hashes per scan became 1)
+  uint64_t need = next_pow2(std::max<uint64_t>(2 * (std::max(h_groups_bound_, expected_groups) + extra), 1 << 16));
   if (h_table_ != nullptr && need <= h_capacity_) return;
-  // A table that has to grow while it already holds groups is still filling up: grow by two steps at once, a re-hash moves
-  // every entry and its key tuple (cfg 5: 3 re-hashes of up to 5.5 M entries per scan became 1–2).
-  if (h_table_ != nullptr && h_groups_bound_ > 0) need *= 2;
+  if (h_table_ != nullptr && h_groups_bound_ > 0 && expected_groups == 0) need *= 2;  // no estimate: grow by two steps at once
   const int ew = h_entry_words_, kw = h_key_words_;
   unsigned long long* nt = (unsigned long long*)ctx_->dev_alloc((size_t)need * ew * 8);
-  uint32_t* nk = (uint32_t*)ctx_->dev_alloc((size_t)need * kw * 4);
+  uint32_t* nk = (uint32_t*)ctx_->dev_alloc((size_t)need * kw * 4);  // (no initialisation needed, see fdb_launch_hash_rehash)
   unsigned long long idents[FDB_MAX_AGGS] = {0};
   for (size_t j = 0; j < aggs_.size(); j++)
     idents[j] = aggs_[j].func == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : aggs_[j].func == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
   hip_check(fdb_launch_hash_init(nt, need, ew, (int)aggs_.size(), idents, stream_), "hash init");
-  hip_check(hipMemsetAsync(nk, 0, (size_t)need * kw * 4, stream_), "hipMemsetAsync(keys)");
   if (h_table_ != nullptr) {
     hip_check(fdb_launch_hash_rehash(h_table_, h_keys_, h_capacity_, kw, nt, nk, need - 1, ew, kw, stream_), "hash rehash");
     hip_check(hipStreamSynchronize(stream_), "sync(rehash)");
@@ -73,6 +74,20 @@ void Plan::hash_reserve(uint64_t extra) {
     hip_check(hipMemsetAsync(h_count_dev_, 0, 256, stream_), "hipMemsetAsync(counter)");
   }
   h_table_ = nt; h_keys_ = nk; h_capacity_ = need;
+}
+
+// Groups the scan will end with, estimated from what it has seen: `d` distinct groups after `n` rows. Under a uniform draw from G
+// groups d = G·(1 − e^(−n/G)); G is found by bisection and pushed forward to n_total rows. A skewed key distribution makes this
+// an UNDER-estimate (then the table simply grows again, the ≥ 2 × invariant is kept by hash_reserve regardless); nearly-all-new
+// rows (d ≥ 0.98 n) mean "no saturation in sight": every remaining row may be a new group.
+static uint64_t estimate_final_groups(uint64_t d, uint64_t n, uint64_t n_total) {
+  if (d == 0 || n == 0 || n_total <= n) return d;
+  if ((double)d >= 0.98 * (double)n) return d + (n_total - n);
+  auto f = [&](double G) { return G * (1.0 - std::exp(-(double)n / G)); };
+  double lo = (double)d, hi = (double)d * 1e4;
+  for (int it = 0; it < 60; it++) { const double mid = std::sqrt(lo * hi); if (f(mid) < (double)d) lo = mid; else hi = mid; }
+  const double G = hi;
+  return (uint64_t)std::min((double)(d + (n_total - n)), G * (1.0 - std::exp(-(double)n_total / G)) + 1.0);
 }
 
 // Inserts pre-aggregated entries ({count, acc…} + key tuples of `in_kw` words, described by `cols`) into the table.
@@ -140,6 +155,8 @@ void Plan::switch_to_hash() {
 
 void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live) {
   hash_layout();
+  uint64_t rows_left_total = 0;  // rows this call will still put into the table (what the cardinality estimate extrapolates to)
+  for (int i : live) rows_left_total += (uint64_t)bs[i]->rows;
   for (int i : live) {
     Resolved& R = Rs[(size_t)i];
     const DeviceBatch& b = *bs[i];
@@ -216,10 +233,42 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       if (jit_fn != nullptr)
         jit_grid = grid_override > 0 ? grid_override : (fdb_scan_default_grid(device_) / 2) * std::min(4, jit_blocks_per_cu(jit_fn, 256, a.lds_lut_bytes));
     }
-    for (int64_t r0 = 0; r0 < b.rows; r0 += kChunkRows) {
-      const int64_t r1 = std::min<int64_t>(b.rows, r0 + kChunkRows);
-      if (h_table_ != nullptr && state_dirty_) hash_groups();  // refresh the bound (waits for the previous chunk)
-      hash_reserve((uint64_t)(r1 - r0));
+    for (int64_t r0 = 0; r0 < b.rows;) {
+      // How many rows may go into the table before the next look at its group count: capacity / 2 − groups (every one of them
+      // could be a new group). The first chunk of a fresh table is small; from what it finds the final cardinality is
+      // estimated, the table grown ONCE to hold it, and the rest of the scan runs in a few big chunks.
+      const uint64_t left_here = (uint64_t)(b.rows - r0);
+      const uint64_t min_chunk = std::min<uint64_t>(left_here, (uint64_t)kChunkRows);
+      auto room_now = [&]() -> uint64_t { return h_table_ != nullptr && h_capacity_ / 2 > h_groups_bound_ ? h_capacity_ / 2 - h_groups_bound_ : 0; };
+      uint64_t room = room_now();  // with the pessimistic bound (groups at the last look + every row scanned since): no wait
+      if (room < min_chunk && h_table_ != nullptr && h_bound_stale_) {
+        hash_groups();  // the exact count (waits for the previous chunk)
+        h_bound_stale_ = false;
+        room = room_now();
+      }
+      if (room < min_chunk) {
+        uint64_t expected = 0;
+        static const bool no_estimate = std::getenv("FDB_HASH_NO_ESTIMATE") != nullptr;  // (tuning / debugging aid)
+        if (!no_estimate && !h_bound_stale_ && h_rows_seen_ >= (uint64_t)(1 << 20) && h_groups_bound_ > 0) {
+          expected = estimate_final_groups(h_groups_bound_, h_rows_seen_, h_rows_seen_ + rows_left_total);
+          expected += expected / 4;  // head-room for the estimate's error
+          const uint64_t bytes_per_slot = (uint64_t)h_entry_words_ * 8 + (uint64_t)h_key_words_ * 4;
+          if (next_pow2(2 * (expected + (uint64_t)kChunkRows)) * bytes_per_slot > ((uint64_t)64 << 30)) expected = 0;  // (beyond a sane budget: grow step by step)
+        }
+        // room for a decent next chunk on top of the expected groups: 1/8 of what is left, 4 M … 32 M rows
+        const uint64_t want_chunk = expected == 0 ? min_chunk
+                                                  : std::min<uint64_t>(left_here, std::max<uint64_t>((uint64_t)kChunkRows, std::min<uint64_t>(rows_left_total / 8, (uint64_t)32 << 20)));
+        hash_reserve(want_chunk, expected);
+        room = room_now();
+      }
+      static const char* cap_env = std::getenv("FDB_HASH_MAX_CHUNK");  // (tuning / debugging aid)
+      if (cap_env != nullptr && std::atoll(cap_env) > 0) room = std::min<uint64_t>(room, (uint64_t)std::atoll(cap_env));
+      // chunk boundaries inside a record stay on tile boundaries (1 024 rows): the kernels address 4-row lane groups with 16-byte
+      // loads and read validity bitmaps bytewise from the chunk's first row
+      if (room < left_here) room &= ~(uint64_t)1023;
+      const int64_t r1 = r0 + (int64_t)std::min<uint64_t>(left_here, room);
+      if (std::getenv("FDB_PROFILE")) std::fprintf(stderr, "[fdb] hash chunk rows [%lld, %lld) capacity %llu bound %llu seen %llu\n", (long long)r0, (long long)r1,
+                                                  (unsigned long long)h_capacity_, (unsigned long long)h_groups_bound_, (unsigned long long)h_rows_seen_);
       h.table = h_table_; h.keys = h_keys_; h.n_groups = h_count_dev_; h.mask = h_capacity_ - 1;
       h.row_begin = r0; h.row_end = r1;
       hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -236,8 +285,12 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       }
       if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
       h_groups_bound_ += (uint64_t)(r1 - r0);
+      h_bound_stale_ = true;
+      h_rows_seen_ += (uint64_t)(r1 - r0);
+      rows_left_total -= (uint64_t)(r1 - r0);
       state_dirty_ = true;
       stat_launches += 1;
+      r0 = r1;
     }
     stat_bytes += R.bytes;
     stat_rows += b.rows;

@@ -247,7 +247,8 @@ hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t
 hipError_t fdb_launch_hash_init(unsigned long long* table, uint64_t capacity, int entry_words, int n_aggs, const unsigned long long* idents,
                                 hipStream_t stream);
 // Moves every occupied entry of (old_table, old_keys) into the (empty-initialised) new table; key tuples are copied
-// word for word into the (possibly wider, zero-initialised) new key store.
+// word for word into the (possibly wider) new key store, new words zeroed. The key store itself needs NO initialisation: a
+// tuple is only ever read where the entry is occupied, and every insert writes all of its words.
 hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int old_key_words,
                                   unsigned long long* new_table, uint32_t* new_keys, uint64_t new_mask, int entry_words, int new_key_words,
                                   hipStream_t stream);
@@ -352,6 +353,31 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
 // Selection: flags → ascending row indices (wave ballot + prefix sums). Two passes over per-tile counts.
 hipError_t fdb_launch_select(const FdbScanArgs& args, uint32_t* indices_out, unsigned long long* n_selected_out,
                              uint32_t* tile_counts, hipStream_t stream);
+
+// ---- filter() on the device: predicate + stream compaction of every column in ONE pass (≙ filter.go:276-323) ------------------
+// One launch evaluates the filter of `args` over rows [0, args.n_rows), gives every selected row its output position (tile totals
+// chained through a decoupled look-back over `tile_state`: each tile publishes its total, then the inclusive prefix of everything
+// before it — tiles are handed out in order by an atomic ticket, so a tile only ever waits for tiles that are already running)
+// and copies the selected values of each column to its compacted buffer: the input columns are streamed once, nothing is gathered
+// through an index vector, no mask is round-tripped through memory. Output rows keep their input order.
+struct FdbCompactCol {
+  const void* src; void* dst;               // values: `width` bytes per row (4: dictionary indices, 8: int64 / uint64 / float64 / widened bool)
+  const uint8_t* src_valid; uint8_t* dst_valid;  // validity: bitmap in (nullptr: no NULLs), one BYTE per output row out (fdb_launch_pack_bits packs them)
+  int32_t width; int32_t _pad;
+};
+struct FdbCompactArgs {
+  const FdbCompactCol* cols;         // device array [n_cols]
+  int32_t n_cols; int32_t _pad;
+  uint32_t* out_indices;             // optional: the selection vector (ascending row numbers)
+  unsigned long long* tile_state;    // [ceil(n_rows / FDB_COMPACT_TILE)] zeroed; (flag << 62) | value
+  uint32_t* ticket;                  // zeroed
+  unsigned long long* total;         // out: number of selected rows
+  unsigned long long* null_counts;   // [n_cols] zeroed; out: NULLs among the selected rows of each column
+  unsigned long long capacity;       // rows the dst buffers hold: rows at positions ≥ capacity are counted but not written
+};
+#define FDB_COMPACT_BLOCK 256
+#define FDB_COMPACT_TILE (FDB_COMPACT_BLOCK * 4)
+hipError_t fdb_launch_compact(const FdbScanArgs& args, const FdbCompactArgs& c, int device, hipStream_t stream);
 // Gather for the compacted record of fdb_plan_filter: dst[i] = src[indices[i]] for 4/8-byte values, and
 // validity bits packed from src bitmap.
 hipError_t fdb_launch_gather(const void* src, void* dst, const uint32_t* indices, int64_t n, int elem_bytes,
@@ -359,6 +385,8 @@ hipError_t fdb_launch_gather(const void* src, void* dst, const uint32_t* indices
 hipError_t fdb_launch_gather_bits(const uint8_t* src_bitmap, uint8_t* dst_bitmap, const uint32_t* indices, int64_t n,
                                   hipStream_t stream);
 int fdb_scan_default_grid(int device);
+// *flag |= 1 if a row i < n has idx[i] >= limit while its validity bit (validity == nullptr: every row) is set.
+hipError_t fdb_launch_validate_indices(const uint32_t* idx, const uint8_t* validity, int64_t n, uint32_t limit, uint32_t* flag, hipStream_t stream);
 // Local (in-process) communicator: dst[i] = reduce over r < n_srcs, in rank order, of srcs[r][i] for lo ≤ i < hi (8-byte elements;
 // op 1 int64 sum, 2 float64 sum, 3 int64 min, 4 int64 max). `srcs` are device pointers of this or of peer devices; dst may be
 // one of them (each element is read from every source before it is written).

@@ -876,6 +876,7 @@ __global__ void hash_rehash_kernel(const unsigned long long* old_table, const ui
     unsigned long long* d = new_table + slot * (uint64_t)ew;
     for (int w = 1; w < ew; w++) d[w] = e[w];
     for (int w = 0; w < okw; w++) new_keys[slot * (uint64_t)kw + w] = old_keys[i * (uint64_t)okw + w];
+    for (int w = okw; w < kw; w++) new_keys[slot * (uint64_t)kw + w] = 0u;  // columns added since: NULL for the groups that exist
   }
 }
 
@@ -1144,6 +1145,17 @@ __global__ void merge_u64_kernel(unsigned long long* dst, const unsigned long lo
   }
 }
 
+// ---- import validation: every dictionary index of a VALID row must be below the dictionary's length ----------------------------
+// (Arrow forbids anything else; the scan kernels index LUTs with these values, so a malformed record must become an error code
+// at import — ≙ the reference's recovered panic, recovery/recovery.go:13-30 — not an out-of-bounds read on the device.)
+__global__ void validate_indices_kernel(const uint32_t* __restrict__ idx, const uint8_t* __restrict__ validity, int64_t n, uint32_t limit,
+                                        uint32_t* flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (idx[i] >= limit && (validity == nullptr || ((validity[i >> 3] >> (i & 7)) & 1))) bad = true;
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 // ---- local communicator: reduce one slice of an array across the ranks' buffers (peer loads) --------------------------------
 struct PeerSrcs { const unsigned long long* p[FDB_MAX_PARTS]; };
 __global__ void peer_reduce_kernel(unsigned long long* dst, const PeerSrcs srcs, int n_srcs, int64_t lo, int64_t hi, int op) {
@@ -1250,6 +1262,127 @@ __global__ __launch_bounds__(FDB_BLOCK) void select_write_kernel(const uint8_t* 
     }
     __syncthreads();
   }
+}
+
+
+// ---- filter() in one pass: predicate → output position (decoupled look-back) → compacted columns -----------------------------
+__global__ __launch_bounds__(FDB_COMPACT_BLOCK) void compact_kernel(const FdbScanArgs a, const FdbCompactArgs c) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int R = 4, NW = FDB_COMPACT_BLOCK / 64;
+  constexpr unsigned long long VAL = (1ull << 62) - 1ull;
+  __shared__ uint32_t s_wave[NW];
+  __shared__ unsigned long long s_prefix;
+  __shared__ uint32_t s_tile;
+  __shared__ unsigned int s_nulls[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int l = 0; l < a.n_leaves; l++) {
+    const FdbLeaf& L = a.leaves[l];
+    if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
+      for (uint32_t i = tid; i < L.lut_len; i += FDB_COMPACT_BLOCK) smem[L.lut_lds + i] = as_global(L.lut)[i];
+  }
+  for (int k = tid; k < 128; k += FDB_COMPACT_BLOCK) s_nulls[k] = 0;
+  const int64_t n_tiles = (a.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
+  for (;;) {
+    __syncthreads();  // (also orders the LUT staging / the previous tile's use of the shared variables)
+    if (tid == 0) s_tile = atomicAdd(c.ticket, 1u);
+    __syncthreads();
+    const int64_t tile = (int64_t)s_tile;
+    if (tile >= n_tiles) break;
+    const int64_t row0 = tile * FDB_COMPACT_TILE + (int64_t)tid * R;
+    uint32_t sel = 0;
+    if (row0 < a.n_rows) {
+      const int64_t left = a.n_rows - row0;
+      sel = eval_filter<R>(a, row0, smem) & (left >= R ? 0xFu : ((1u << (int)left) - 1u));
+    }
+    const uint32_t cnt = __popc(sel);
+    uint32_t incl = cnt;  // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { if (w < wave) wave_base += s_wave[w]; tile_total += s_wave[w]; }
+    // ---- decoupled look-back (wave 0): publish this tile's total, add up the totals of the tiles before it until one of them
+    // already knows its inclusive prefix, publish ours. State words: flag 1 = total only, 2 = inclusive prefix.
+    if (wave == 0) {
+      unsigned long long excl = 0;
+      if (tile > 0) {
+        if (lane == 0) __hip_atomic_store(c.tile_state + tile, (1ull << 62) | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int64_t base = tile - 1;
+        for (;;) {
+          const int64_t t = base - lane;
+          unsigned long long st = t >= 0 ? __hip_atomic_load(c.tile_state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
+          while (__any((st >> 62) == 0ull)) {  // predecessors hold earlier tickets: they are running and will publish
+            __builtin_amdgcn_s_sleep(1);
+            if ((st >> 62) == 0ull) st = __hip_atomic_load(c.tile_state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          const unsigned long long have_prefix = __ballot((st >> 62) == 2ull);
+          const int first = have_prefix ? __ffsll((long long)have_prefix) - 1 : 64;
+          unsigned long long v = lane <= first ? (st & VAL) : 0ull;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+          excl += v;
+          if (have_prefix) break;
+          base -= 64;
+        }
+      }
+      if (lane == 0) {
+        __hip_atomic_store(c.tile_state + tile, (2ull << 62) | (excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix = excl;
+        if (tile == n_tiles - 1) *c.total = excl + tile_total;
+      }
+    }
+    __syncthreads();
+    const unsigned long long pos0 = s_prefix + wave_base + (incl - cnt);
+    if (sel != 0u) {
+      if (c.out_indices != nullptr) {
+        unsigned long long p = pos0;
+#pragma unroll
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) { if (p < c.capacity) c.out_indices[p] = (uint32_t)(row0 + r); p++; }
+      }
+    }
+    for (int k = 0; k < c.n_cols; k++) {
+      const FdbCompactCol C = c.cols[k];
+      uint32_t valid = 0xFu;
+      if (C.src_valid != nullptr && row0 < a.n_rows) valid = load_valid<R>(C.src_valid, row0);
+      if (C.src_valid != nullptr) {
+        const uint32_t nulls = __popc(sel & ~valid);
+        if (__any(nulls != 0u)) {
+          uint32_t t = nulls;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+          if (lane == 0) atomicAdd(&s_nulls[k & 127], t);
+        }
+      }
+      if (sel == 0u) continue;
+      unsigned long long p = pos0;
+      if (C.width == 4) {
+        uint32_t v[R];
+        load_u32<R>(reinterpret_cast<const uint32_t*>(C.src) + row0, v);
+#pragma unroll
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) {
+          if (p < c.capacity) { reinterpret_cast<uint32_t*>(C.dst)[p] = ((valid >> r) & 1u) ? v[r] : 0u; if (C.dst_valid != nullptr) C.dst_valid[p] = (uint8_t)((valid >> r) & 1u); }
+          p++;
+        }
+      } else {
+        unsigned long long v[R];
+        load_u64<R>(reinterpret_cast<const unsigned long long*>(C.src) + row0, v);
+#pragma unroll
+        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) {
+          if (p < c.capacity) { reinterpret_cast<unsigned long long*>(C.dst)[p] = v[r]; if (C.dst_valid != nullptr) C.dst_valid[p] = (uint8_t)((valid >> r) & 1u); }
+          p++;
+        }
+      }
+    }
+  }
+  // (the loop was left right after a barrier)
+  if (c.null_counts != nullptr)
+    for (int k = tid; k < c.n_cols && k < 128; k += FDB_COMPACT_BLOCK)
+      if (s_nulls[k] != 0) atomicAdd(c.null_counts + k, (unsigned long long)s_nulls[k]);
 }
 
 template <typename T>
@@ -1404,6 +1537,14 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
   return hipGetLastError();
 }
 
+hipError_t fdb_launch_validate_indices(const uint32_t* idx, const uint8_t* validity, int64_t n, uint32_t limit, uint32_t* flag, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (int)((n + 1023) / 1024);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(validate_indices_kernel, dim3(blocks), dim3(256), 0, stream, idx, validity, n, limit, flag);
+  return hipGetLastError();
+}
+
 hipError_t fdb_launch_peer_reduce(unsigned long long* dst, const void* const* srcs, int n_srcs, int64_t lo, int64_t hi, int op, hipStream_t stream) {
   if (hi <= lo) return hipSuccess;
   if (n_srcs < 1 || n_srcs > FDB_MAX_PARTS) return hipErrorInvalidValue;
@@ -1427,6 +1568,17 @@ hipError_t fdb_launch_select(const FdbScanArgs& args, uint32_t* indices_out, uns
   hipLaunchKernelGGL(select_flags_kernel, dim3(grid), dim3(FDB_BLOCK), args.lds_lut_bytes, stream, args, masks, tile_counts);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, tile_counts, n_tiles, n_selected_out);
   hipLaunchKernelGGL(select_write_kernel, dim3(grid), dim3(FDB_BLOCK), 0, stream, masks, tile_counts, args.n_rows, indices_out);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_compact(const FdbScanArgs& args, const FdbCompactArgs& c, int device, hipStream_t stream) {
+  const int64_t n_tiles = (args.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
+  if (n_tiles == 0) return hipMemsetAsync(c.total, 0, 8, stream);
+  if (c.n_cols > 128) return hipErrorInvalidValue;
+  // persistent grid: tiles are taken by ticket; ≈8 workgroups (32 waves) per CU keep enough loads in flight for a streaming copy
+  int64_t grid = (int64_t)fdb_scan_default_grid(device) * 4;
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)grid), dim3(FDB_COMPACT_BLOCK), args.lds_lut_bytes, stream, args, c);
   return hipGetLastError();
 }
 

@@ -81,6 +81,23 @@ int DeviceBatch::find(const std::string& name) const {
   return found;
 }
 
+namespace {
+// Dictionary indices of valid rows must be below the dictionary's length (Arrow's own rule). The scan kernels index LUTs with
+// them, so a malformed record is refused here — FDB_ERR_INVALID, ≙ the reference's recovered panic (recovery/recovery.go:13-30) —
+// instead of reading out of bounds on the device. Host version (small records, which are copied through the pinned ring by the
+// CPU anyway): one vectorisable max over all rows; only if that fails, a second pass that skips NULL rows (whose slots may
+// hold anything).
+void check_indices_host(const uint32_t* idx, const uint8_t* validity_bit0, int64_t n, size_t limit, const std::string& name) {
+  uint32_t mx = 0;
+  for (int64_t i = 0; i < n; i++) mx = idx[i] > mx ? idx[i] : mx;
+  if (n == 0 || (size_t)mx < limit) return;
+  for (int64_t i = 0; i < n; i++)
+    if ((size_t)idx[i] >= limit && (validity_bit0 == nullptr || ((validity_bit0[i >> 3] >> (i & 7)) & 1)))
+      throw Error(FDB_ERR_INVALID, "dictionary index out of range in column " + name + ": row " + std::to_string(i) + " holds " + std::to_string(idx[i]) +
+                                       ", the dictionary has " + std::to_string(limit) + " entries");
+}
+}  // namespace
+
 std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device, const std::function<bool(const std::string&)>* want,
                                           hipStream_t stream, Context* ctx, bool via_ring) {
   std::unique_ptr<DeviceBatch> b(new DeviceBatch());
@@ -186,8 +203,43 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     }
   }
   for (const DevColumn& d : b->cols) b->payload_bytes += d.value_bytes + d.validity_bytes;
-  if (ring != nullptr) ctx->copy_commit(b->arena, ring, total);
-  else if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty() || !keep_i64.empty() || !plain_idx.empty())) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
+  // dictionary indices are validated before anything can scan the record (see check_indices_host)
+  std::vector<size_t> dict_cols;
+  for (size_t i = 0; i < b->cols.size(); i++)
+    if (b->cols[i].kind == ColKind::DICT && b->cols[i].d_values != nullptr && b->cols[i].dict && !b->cols[i].dict->plain && b->rows > 0) dict_cols.push_back(i);
+  if (ring != nullptr) {
+    for (size_t i : dict_cols) {  // the bytes are in the pinned ring: checked by the CPU that just copied them
+      const DevColumn& d = b->cols[i];
+      const unsigned char* base = ring;
+      check_indices_host((const uint32_t*)(base + ((unsigned char*)d.d_values - (unsigned char*)b->arena)),
+                         d.d_validity ? base + (d.d_validity - (unsigned char*)b->arena) : nullptr, b->rows, d.dict->values.size(), d.name);
+    }
+    ctx->copy_commit(b->arena, ring, total);
+    return b;
+  }
+  if (!dict_cols.empty()) {  // big records: one streaming pass on the device behind the copies (4 B/row at HBM speed), one flag word per column
+    uint32_t* d_flags = nullptr;
+    if (ctx != nullptr) d_flags = (uint32_t*)ctx->dev_alloc(dict_cols.size() * 4);
+    else hip_check(hipMalloc((void**)&d_flags, dict_cols.size() * 4), "hipMalloc(index check)");
+    std::vector<uint32_t> flags(dict_cols.size(), 0);
+    hipError_t e = hipMemsetAsync(d_flags, 0, dict_cols.size() * 4, stream);
+    for (size_t k = 0; k < dict_cols.size() && e == hipSuccess; k++) {
+      const DevColumn& d = b->cols[dict_cols[k]];
+      e = fdb_launch_validate_indices((const uint32_t*)d.d_values, d.d_validity, b->rows, (uint32_t)std::min<size_t>(d.dict->values.size(), 0xFFFFFFFFu), d_flags + k, stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), d_flags, dict_cols.size() * 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (ctx != nullptr) ctx->dev_free(d_flags); else (void)hipFree(d_flags);
+    hip_check(e, "dictionary index check");
+    for (size_t k = 0; k < dict_cols.size(); k++)
+      if (flags[k] != 0) {
+        const DevColumn& d = b->cols[dict_cols[k]];
+        throw Error(FDB_ERR_INVALID, "dictionary index out of range in column " + d.name + ": a valid row holds an index ≥ the dictionary's " +
+                                         std::to_string(d.dict->values.size()) + " entries");
+      }
+  } else if (ctx != nullptr && (!keep_bits.empty() || !keep_idx.empty() || !keep_i64.empty() || !plain_idx.empty())) {
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(import)");
+  }
   return b;
 }
 

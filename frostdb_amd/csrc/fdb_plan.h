@@ -259,7 +259,7 @@ class Plan {
   // high-cardinality path (fdb_hash.cpp)
   void switch_to_hash();
   void hash_layout();                                   // (re)assign key-tuple words; widen the key store if columns were added
-  void hash_reserve(uint64_t extra_groups);             // capacity ≥ 2 × (groups + extra): grow + rehash on the device
+  void hash_reserve(uint64_t extra_groups, uint64_t expected_groups = 0);  // capacity ≥ 2 × (max(groups, expected) + extra): grow + rehash on the device
   void push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live);
   void fetch_compact_hash(CompactState* cs);
   int64_t finish_columns_hash(std::vector<OutColumn>* cols);  // device-side column materialisation (big result sets)
@@ -292,6 +292,8 @@ class Plan {
   uint64_t h_capacity_ = 0;
   int h_entry_words_ = 0, h_key_words_ = 2;
   uint64_t h_groups_bound_ = 0;     // upper bound of occupied slots known on the host
+  bool h_bound_stale_ = false;      // rows were scanned since the bound was last read from the device (it is groups + those rows)
+  uint64_t h_rows_seen_ = 0;        // rows scanned into the hash table so far (input of the cardinality estimate)
 
   Context* ctx_ = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;

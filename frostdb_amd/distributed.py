@@ -43,7 +43,9 @@ def _keys_to_tuples(keys: pa.RecordBatch) -> Tuple[List[str], List[Tuple]]:
 
 def unify_keys(all_names: Sequence[Sequence[str]], all_rows: Sequence[Sequence[Tuple]]):
     """Global column order (first seen, rank order) and global id of every rank's local row.
-    A column a rank never saw is NULL for all of its groups (aggregate.go:568-575)."""
+    A column a rank never saw is NULL for all of its groups (aggregate.go:568-575). An integer key of 0 and a NULL key are
+    ONE group, as on a single GPU and in the reference (both hash to 0, dynparquet/hashed.go:254-272); the key printed for it
+    is the first one seen in rank order."""
     gnames: List[str] = []
     for names in all_names:
         for n in names:
@@ -57,9 +59,10 @@ def unify_keys(all_names: Sequence[Sequence[str]], all_rows: Sequence[Sequence[T
         perm = []
         for r in rows:
             k = tuple(r[p] if p >= 0 else None for p in pos)
-            g = index.get(k)
+            ident = tuple(None if (isinstance(v, int) and not isinstance(v, bool) and v == 0) else v for v in k)
+            g = index.get(ident)
             if g is None:
-                g = index[k] = len(gkeys)
+                g = index[ident] = len(gkeys)
                 gkeys.append(k)
             perm.append(g)
         perms.append(perm)

@@ -103,6 +103,25 @@ def _cfg5_tables(n_groups: int):
 _CFG5_CACHE = {}
 
 
+def cfg5_group_ids(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000) -> np.ndarray:
+    """The group id of every row of `cfg5_chunk(shard, chunk, rows, n_groups)` (its first draw from the chunk's generator): lets a
+    test compute the expected per-group answer with numpy, without a group-by over 32 string columns."""
+    rng = np.random.Generator(np.random.Philox(key=SEED + 5 + shard, counter=[0, 0, 0, chunk]))
+    return rng.integers(0, n_groups, size=rows, dtype=np.int64)
+
+
+def cfg5_decode_group_ids(batch: pa.RecordBatch) -> np.ndarray:
+    """Group id of every row of a record that carries cfg 5's label columns (input or result): columns 0-11 hold the base-4
+    digits of the id as the dictionary values b"lCC=D"."""
+    gid = np.zeros(batch.num_rows, dtype=np.int64)
+    for c in range(12):
+        col = batch.column(batch.schema.get_field_index("labels.l%02d" % c))
+        assert col.null_count == 0
+        digit_of_entry = np.array([int(v.rsplit(b"=", 1)[1]) for v in col.dictionary.to_pylist()], dtype=np.int64)
+        gid |= digit_of_entry[col.indices.to_numpy(zero_copy_only=False).astype(np.int64)] << (2 * c)
+    return gid
+
+
 def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000) -> pa.RecordBatch:
     if n_groups not in _CFG5_CACHE:
         _CFG5_CACHE[n_groups] = _cfg5_tables(n_groups)

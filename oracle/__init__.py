@@ -62,6 +62,9 @@ def lib() -> ctypes.CDLL:
         L.oracle_batch_col_i64.argtypes = [vp, i32, vp]
         L.oracle_batch_col_f64.argtypes = [vp, i32, vp]
         L.oracle_batch_col_str.argtypes = [vp, i32, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64)]
+        L.oracle_batch_col_codes.restype = i64
+        L.oracle_batch_col_codes.argtypes = [vp, i32, vp]
+        L.oracle_batch_col_code_value.argtypes = [vp, i32, i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i64)]
         L.oracle_plan_create.argtypes = [vp, i32, u64, ctypes.POINTER(vp)]
         L.oracle_plan_close.argtypes = [vp]
         L.oracle_plan_last_error.restype = ctypes.c_char_p
@@ -145,6 +148,41 @@ class OracleBatch:
                     vals.append(ctypes.string_at(p, ln.value))
             out[name] = vals
         return out
+
+    def to_arrow(self) -> pa.RecordBatch:
+        """The record as Arrow, built column-wise (big results: millions of groups): string-like columns become
+        dictionary<uint32, binary> over the oracle's value table, int64 / uint64 / bool / float64 columns plain arrays."""
+        L = lib()
+        n = self.num_rows
+        arrays, names = [], []
+        for c in range(L.oracle_batch_num_cols(self.handle)):
+            names.append(L.oracle_batch_col_name(self.handle, c).decode())
+            t = L.oracle_batch_col_type(self.handle, c)
+            valid = np.zeros(n, dtype=np.uint8)
+            if n:
+                L.oracle_batch_col_valid(self.handle, c, valid.ctypes.data)
+            mask = valid == 0
+            if t in (T_I64, T_U64, T_BOOL):
+                v = np.zeros(n, dtype=np.int64)
+                if n:
+                    L.oracle_batch_col_i64(self.handle, c, v.ctypes.data)
+                arr = pa.array(v.view(np.uint64) if t == T_U64 else v.astype(bool) if t == T_BOOL else v, mask=mask)
+            elif t == T_F64:
+                v = np.zeros(n, dtype=np.float64)
+                if n:
+                    L.oracle_batch_col_f64(self.handle, c, v.ctypes.data)
+                arr = pa.array(v, mask=mask)
+            else:
+                codes = np.zeros(max(n, 1), dtype=np.uint32)
+                k = L.oracle_batch_col_codes(self.handle, c, codes.ctypes.data)
+                vals = []
+                p, ln = ctypes.c_char_p(), ctypes.c_int64()
+                for i in range(k):
+                    L.oracle_batch_col_code_value(self.handle, c, i, ctypes.byref(p), ctypes.byref(ln))
+                    vals.append(ctypes.string_at(p, ln.value))
+                arr = pa.DictionaryArray.from_arrays(pa.array(codes[:n], mask=mask), pa.array(vals, type=pa.binary()))
+            arrays.append(arr)
+        return pa.RecordBatch.from_arrays(arrays, names=names)
 
     def close(self) -> None:
         if self.handle:

@@ -834,7 +834,7 @@ struct HashAggregate {
 // ------------------------------------------------------------------------------------------------
 // C interface (used through ctypes by tests/ and bench.py's cpu_baseline leg).
 // ------------------------------------------------------------------------------------------------
-struct oracle_batch { Record rec; };
+struct oracle_batch { Record rec; std::unordered_map<int32_t, std::vector<std::string>> code_values; };  // (code tables of plain string columns, built on demand)
 
 struct oracle_plan {
   PlanDesc desc;
@@ -877,6 +877,30 @@ int32_t oracle_batch_col_type(const oracle_batch* b, int32_t c) { return (int32_
 void oracle_batch_col_valid(const oracle_batch* b, int32_t c, uint8_t* out) { const Col& col = b->rec.cols[c]; if (col.len) memcpy(out, col.valid.data(), col.len); }
 void oracle_batch_col_i64(const oracle_batch* b, int32_t c, int64_t* out) { const Col& col = b->rec.cols[c]; if (col.len) memcpy(out, col.i64.data(), col.len * 8); }
 void oracle_batch_col_f64(const oracle_batch* b, int32_t c, double* out) { const Col& col = b->rec.cols[c]; if (col.len) memcpy(out, col.f64.data(), col.len * 8); }
+// String-like columns as integer codes + a value table (what tests/ compares big results with — one call per column instead of
+// one per row): codes[i] indexes the table for valid rows; returns the table's size.
+int64_t oracle_batch_col_codes(oracle_batch* b, int32_t c, uint32_t* codes) {
+  const Col& col = b->rec.cols[c];
+  if (col.type == T_DICT) {
+    for (int64_t i = 0; i < col.len; i++) codes[i] = col.valid[i] ? col.idx[i] : 0u;
+    return (int64_t)col.dict->values.size();
+  }
+  std::vector<std::string>& table = b->code_values[c];
+  table.clear();
+  std::unordered_map<std::string, uint32_t> ids;
+  for (int64_t i = 0; i < col.len; i++) {
+    if (!col.valid[i]) { codes[i] = 0u; continue; }
+    auto it = ids.find(col.strs[i]);
+    if (it == ids.end()) { it = ids.emplace(col.strs[i], (uint32_t)table.size()).first; table.push_back(col.strs[i]); }
+    codes[i] = it->second;
+  }
+  return (int64_t)table.size();
+}
+void oracle_batch_col_code_value(const oracle_batch* b, int32_t c, int64_t k, const char** p, int64_t* len) {
+  const Col& col = b->rec.cols[c];
+  const std::string& s = col.type == T_DICT ? col.dict->values[k] : b->code_values.at(c)[k];
+  *p = s.data(); *len = (int64_t)s.size();
+}
 void oracle_batch_col_str(const oracle_batch* b, int32_t c, int64_t row, const char** p, int64_t* len) {
   const Col& col = b->rec.cols[c];
   const std::string& s = col.type == T_DICT ? col.dict->values[col.idx[row]] : col.strs[row];

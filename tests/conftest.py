@@ -8,6 +8,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# One ROCm stack per test process: torch carries its own libamdhip64 / librccl, and a process that maps the system copies first
+# (through libfrostdb_amd.so / fdb_comm's dlopen) and torch's afterwards ends up with two RCCLs and handles that belong to the
+# wrong runtime ("invalid resource handle" in the torch.distributed tests). bench.py imports torch first for the same reason; a Go
+# host has no torch and simply uses the system libraries.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -225,3 +225,15 @@ def test_alltoall_exchange_gloo(world):
         k = np.random.default_rng(1000 + r).integers(0, 3000, size=5000 + 700 * r)
         expect_sum += int((k * 3 + r).sum())
     assert sum(r[4] for r in res) == expect_sum
+
+
+def test_unify_keys_merges_integer_zero_with_null():
+    """int64 key 0 ≡ NULL (both hash to 0 in the reference, dynparquet/hashed.go:254-272; one group on a single GPU): ranks that
+    print the group differently still land on ONE global id; strings are untouched ('' stays distinct from NULL)."""
+    from frostdb_amd.distributed import unify_keys
+    names = [["bucket", "labels.a"], ["bucket", "labels.a"]]
+    rows = [[(0, b"x"), (5, b""), (7, None)], [(None, b"x"), (5, None), (7, None)]]
+    gnames, gkeys, perms = unify_keys(names, rows)
+    assert gnames == ["bucket", "labels.a"]
+    assert perms[0] == [0, 1, 2] and perms[1] == [0, 3, 2]
+    assert gkeys == [(0, b"x"), (5, b""), (7, None), (5, None)]

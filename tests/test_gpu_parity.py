@@ -1628,3 +1628,191 @@ def test_hash_mode_partial_keys_and_states_line_up(pp):
     finally:
         plan.Close()
         twin.Close()
+
+
+def test_out_of_range_dictionary_index_is_an_error_not_a_fault(pp):
+    """A malformed record — a VALID row whose dictionary index is past the dictionary — is refused with FDB_ERR_INVALID at import
+    (small pushed record: checked on the host; big pushed record and resident import: checked by a device pass before anything
+    scans it), ≙ the reference's recovered panic (recovery/recovery.go:13-30). A NULL row may hold any index (Arrow leaves the
+    slot undefined) and is accepted. The process keeps working afterwards."""
+    rng = np.random.default_rng(8)
+
+    def rec(n, bad_at=None, bad_is_null=False):
+        idx = rng.integers(0, 3, n).astype(np.uint32)
+        mask = np.zeros(n, dtype=bool)
+        if bad_at is not None:
+            idx[bad_at] = 1_000_000
+            mask[bad_at] = bad_is_null
+        path = pa.DictionaryArray.from_arrays(pa.array(idx, mask=mask if bad_is_null else None), pa.array([b"a", b"b", b"c"], type=pa.binary()), safe=False)
+        code = pa.DictionaryArray.from_arrays(pa.array(np.zeros(n, dtype=np.uint32)), pa.array([b"200"], type=pa.binary()))
+        return pa.RecordBatch.from_arrays([code, path, pa.array(rng.uniform(0, 1, n))], names=["labels.code", "labels.path", "value"])
+
+    for n in (5_000, 3_000_000):  # via the pinned ring / direct copy + device check
+        plan = pp.HashAggregatePlan(**CFG2)
+        with pytest.raises(pp.FdbError) as ei:
+            plan.Callback(rec(n, bad_at=n // 2))
+        assert ei.value.code == pp.FDB_ERR_INVALID and "labels.path" in str(ei.value) and "out of range" in str(ei.value)
+        good = rec(n, bad_at=n // 3, bad_is_null=True)  # the same wild index under a NULL: fine
+        plan.Callback(good)
+        d = arrow_to_pydict(plan.Finish())
+        assert_same_result(d, run_oracle([good], **CFG2), ["labels.path", "sum(value)"], float_cols={"sum(value)"})
+        plan.Close()
+    with pytest.raises(pp.FdbError) as ei:
+        pp.ResidentBatch(rec(200_000, bad_at=7))
+    assert ei.value.code == pp.FDB_ERR_INVALID
+    # filter / select import the record through the same code
+    plan = pp.HashAggregatePlan(Col("labels.path") == "a")
+    with pytest.raises(pp.FdbError):
+        plan.Select(rec(10_000, bad_at=9_999))
+    plan.Close()
+
+
+# ---- BASELINE.json config 5 at its own shape: 32 dynamic label columns, millions of groups -----------------------------------
+
+def _cfg5_canonical(batch):
+    """A cfg 5 result in comparable form: rows sorted by group id; per label column the digit (0-3) or 255 for NULL."""
+    from frostdb_amd import synth
+    gid = synth.cfg5_decode_group_ids(batch)
+    order = np.argsort(gid, kind="stable")
+    labels = []
+    for c in range(synth.CFG5_COLS):
+        col = batch.column(batch.schema.get_field_index("labels.l%02d" % c))
+        digit_of_entry = np.array([int(v.rsplit(b"=", 1)[1]) for v in col.dictionary.to_pylist()] + [255], dtype=np.uint8)
+        idx = col.indices.fill_null(len(col.dictionary)).to_numpy(zero_copy_only=False).astype(np.int64)
+        labels.append(digit_of_entry[idx][order])
+    out = {"gid": gid[order], "labels": labels}
+    for name in batch.schema.names:
+        if not name.startswith("labels."):
+            out[name] = batch.column(batch.schema.get_field_index(name)).to_numpy(zero_copy_only=False)[order]
+    return out
+
+
+def test_cfg5_shape_against_the_oracle_over_a_million_groups(pp):
+    """cfg 5's own shape — SUM / COUNT grouped by ALL 32 labels.* columns (DynCol), ≈3 % NULL digits — with 1.2 M distinct
+    groups over 3 M rows (3 resident records, so the cardinality estimate and the one-step table growth are exercised):
+    every group's 32 key values (NULLs included), count and sum against the oracle."""
+    from frostdb_amd import synth
+    from oracle import OraclePlan
+    n_groups, per = 1_200_000, 1_000_000
+    recs = [synth.cfg5_chunk(3, i, per, n_groups=n_groups) for i in range(3)]
+    aggs, groups = [Sum(Col("value")), Count(Col("value"))], [DynCol("labels")]
+    keep = [pp.ResidentBatch(r) for r in recs]
+    plan = pp.HashAggregatePlan(None, aggs, groups)
+    try:
+        plan.CallbackResident(keep)
+        assert plan.last_kernel() == "fdb_hash_kernel"
+        got = _cfg5_canonical(plan.Finish())
+    finally:
+        plan.Close()
+        for k in keep:
+            k.close()
+    o = OraclePlan(None, aggs, groups)
+    for r in recs:
+        o.push(r)
+    ob = o.finish()
+    want = _cfg5_canonical(ob.to_arrow())
+    ob.close(); o.close()
+    assert len(got["gid"]) == len(want["gid"]) > 1_000_000
+    assert np.array_equal(got["gid"], want["gid"])
+    for c in range(synth.CFG5_COLS):
+        assert np.array_equal(got["labels"][c], want["labels"][c]), c
+    assert np.array_equal(got["count(value)"], want["count(value)"])
+    assert np.allclose(got["sum(value)"], want["sum(value)"], rtol=REL_TOL, atol=0.0)
+
+
+def test_cfg5_full_size_every_group_checked(pp):
+    """BASELINE.json config 5 at full size — 100 M rows, 32 label columns, 10 M distinct groups — with EVERY group checked: the
+    generator's group ids give the expected count and sum per group through numpy's bincount (no 32-column group-by on the
+    host); the result's ids are decoded from its first 12 label columns, its other 20 label columns (incl. NULLs) must be the
+    function of the id the generator used. Also Σ count = rows and the number of groups = numpy's count of distinct ids."""
+    from frostdb_amd import synth
+    n_groups, rows, per = 10_000_000, 100_000_000, 12_500_000
+    exp_cnt = np.zeros(n_groups, dtype=np.int64)
+    exp_sum = np.zeros(n_groups, dtype=np.float64)
+    keep = []
+    try:
+        for i in range(rows // per):
+            rec = synth.cfg5_chunk(0, i, per, n_groups=n_groups)
+            gid = synth.cfg5_group_ids(0, i, per, n_groups=n_groups)
+            val = rec.column(rec.schema.get_field_index("value")).to_numpy()
+            exp_cnt += np.bincount(gid, minlength=n_groups)
+            exp_sum += np.bincount(gid, weights=val, minlength=n_groups)
+            keep.append(pp.ResidentBatch(rec))
+            del rec, gid, val
+        plan = pp.HashAggregatePlan(None, [Sum(Col("value")), Count(Col("value"))], [DynCol("labels")])
+        try:
+            plan.CallbackResident(keep)
+            out = plan.Finish()
+        finally:
+            plan.Close()
+    finally:
+        for k in keep:
+            k.close()
+    got = _cfg5_canonical(out)
+    present = np.flatnonzero(exp_cnt)
+    assert len(got["gid"]) == len(present) and np.array_equal(got["gid"], present)
+    assert int(got["count(value)"].sum()) == rows
+    assert np.array_equal(got["count(value)"], exp_cnt[present])
+    assert np.allclose(got["sum(value)"], exp_sum[present], rtol=REL_TOL, atol=0.0)
+    digits, nulls = synth._cfg5_tables(n_groups)
+    for c in range(synth.CFG5_COLS):
+        want = np.where(nulls[c][present], 255, digits[c][present]).astype(np.uint8)
+        assert np.array_equal(got["labels"][c], want), c
+
+
+def test_hash_table_growth_when_the_cardinality_estimate_is_too_low(pp):
+    """A skewed key distribution (Zipf over 2 M int64 keys, 3 M rows in three records) makes the uniform-draw estimate an
+    UNDER-estimate: the table must keep growing on its own and the result must still be exact."""
+    rng = np.random.default_rng(99)
+    recs = []
+    for _ in range(3):
+        k = np.minimum(rng.zipf(1.3, 1_000_000), 2_000_000).astype(np.int64)
+        recs.append(pa.RecordBatch.from_arrays([pa.array(k), pa.array(rng.integers(0, 100, 1_000_000).astype(np.int64))], names=["k", "v"]))
+    aggs, groups = [Sum(Col("v")), Count(Col("v")), Max(Col("v"))], [Col("k")]
+    keep = [pp.ResidentBatch(r) for r in recs]
+    plan = pp.HashAggregatePlan(None, aggs, groups)
+    try:
+        plan.CallbackResident(keep)
+        out = plan.Finish()
+    finally:
+        plan.Close()
+        for k_ in keep:
+            k_.close()
+    allk = np.concatenate([r.column(0).to_numpy() for r in recs])
+    allv = np.concatenate([r.column(1).to_numpy() for r in recs])
+    uk, inv = np.unique(allk, return_inverse=True)
+    order = np.argsort(out.column("k").to_numpy())
+    assert np.array_equal(out.column("k").to_numpy()[order], uk)
+    assert np.array_equal(out.column("sum(v)").to_numpy()[order], np.bincount(inv, weights=allv).astype(np.int64))
+    assert np.array_equal(out.column("count(v)").to_numpy()[order], np.bincount(inv))
+    mx = np.full(len(uk), -1, dtype=np.int64)
+    np.maximum.at(mx, inv, allv)
+    assert np.array_equal(out.column("max(v)").to_numpy()[order], mx)
+
+
+def test_records_carrying_prehashed_columns_give_the_same_result(pp, variant):
+    """with `Prehash: true` a table's records carry `hashed.<col>` int64 columns (dynparquet/hashed.go:27-84)
+    which the reference uses INSTEAD of hashing the key column (aggregate.go:386-392). Group identity here is the key tuple
+    itself, so such records must simply work: no matcher — not even DynCol("labels") — picks the helper columns up as keys,
+    and the result equals both the oracle's (which takes the stored hashes, like the reference) and the result without them."""
+    import oracle
+    rng = np.random.default_rng(17)
+    base = [make_prometheus_batch(rng, 30_000, n_path=37), make_prometheus_batch(rng, 20_000, n_path=53)]
+
+    def with_hashes(rec):
+        out = rec
+        for name in ("labels.path", "labels.code"):
+            col = rec.column(rec.schema.get_field_index(name)).dictionary_decode().to_pylist()
+            h = np.array([oracle.metro_hash64(v) if v is not None else 0 for v in col], dtype=np.uint64).view(np.int64)
+            out = out.append_column("hashed." + name, pa.array(h))
+        return out
+
+    hashed = [with_hashes(r) for r in base]
+    for q in (CFG2, CFG3, dict(filter_expr=None, aggs=[Count(Col("value")), Sum(Col("value"))], groups=[DynCol("labels")])):
+        cols = sorted(c for c in base[0].schema.names if c.startswith("labels.")) if q["groups"][0].dynamic else ["labels.path"]
+        cols = cols + [a.Name() for a in q["aggs"]]
+        got_h = run_gpu(pp, hashed, q["filter_expr"], q["aggs"], q["groups"], resident=True)
+        got = run_gpu(pp, base, q["filter_expr"], q["aggs"], q["groups"], resident=True)
+        assert not any(k.startswith("hashed.") for k in got_h)
+        assert_same_result(got_h, got, cols, float_cols={"sum(value)"})
+        assert_same_result(got_h, run_oracle(hashed, **q), cols, float_cols={"sum(value)"})
