@@ -241,6 +241,31 @@ int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema
   return guard(plan, [&] { plan->plan.select(batch, schema, indices, capacity, n_selected); });
 }
 
+int fdb_plan_filter_batch(fdb_plan* plan, const fdb_batch* batch, fdb_batch** out, int64_t* n_selected) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] {
+    if (batch == nullptr || !batch->b || out == nullptr || n_selected == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::unique_ptr<fdb::DeviceBatch> r = plan->plan.filter_batch(*batch->b, n_selected);
+    *out = new fdb_batch{std::move(r)};
+  });
+}
+
+int fdb_plan_select_batch(fdb_plan* plan, const fdb_batch* batch, uint32_t* dev_indices, int64_t capacity, int64_t* n_selected) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] {
+    if (batch == nullptr || !batch->b || dev_indices == nullptr || n_selected == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    *n_selected = plan->plan.select_batch(*batch->b, dev_indices, capacity);
+  });
+}
+
+int fdb_batch_export(const fdb_batch* batch, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  return guard(nullptr, [&] {
+    if (batch == nullptr || !batch->b || out == nullptr || out_schema == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    fdb::export_batch(*batch->b, out, out_schema);
+  });
+}
+
 const char* fdb_plan_draw(fdb_plan* plan) { return !plan ? "" : plan->dyn ? plan->dyn->draw(plan->plan) : plan->plan.draw(); }
 const char* fdb_plan_last_error(const fdb_plan* plan) { return plan ? plan->plan.error.c_str() : g_last_error.c_str(); }
 void fdb_plan_close(fdb_plan* plan) { delete plan; }

@@ -144,6 +144,68 @@ void pinned_pool_free(void* p) {
   for (void* q : drop) (void)hipHostFree(q);
 }
 
+namespace {
+struct PoolBlock { void* p; size_t bytes; bool used; };
+std::mutex g_dpool_mu;
+std::vector<PoolBlock> g_dpool[16];
+constexpr size_t kDevicePoolIdleBudget = (size_t)16 << 30;
+}  // namespace
+
+void* device_pool_alloc(int device, size_t bytes) {
+  if (device < 0 || device >= 16) throw Error(FDB_ERR_INVALID, "device index out of range");
+  const size_t want = (std::max<size_t>(bytes, 1) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  {
+    std::lock_guard<std::mutex> lk(g_dpool_mu);
+    PoolBlock* best = nullptr;
+    for (PoolBlock& b : g_dpool[device])
+      if (!b.used && b.bytes >= want && b.bytes <= want + want / 4 && (best == nullptr || b.bytes < best->bytes)) best = &b;
+    if (best != nullptr) { best->used = true; note_device_alloc(best->bytes); return best->p; }
+  }
+  hip_check(hipSetDevice(device), "hipSetDevice");
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e == hipErrorOutOfMemory) {  // give the idle blocks back and retry once
+    (void)hipGetLastError();
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> lk(g_dpool_mu);
+      auto& v = g_dpool[device];
+      for (PoolBlock& b : v) if (!b.used) drop.push_back(b.p);
+      v.erase(std::remove_if(v.begin(), v.end(), [](const PoolBlock& b) { return !b.used; }), v.end());
+    }
+    for (void* q : drop) (void)hipFree(q);
+    e = hipMalloc(&p, want);
+  }
+  hip_check(e, "hipMalloc(resident record)");
+  std::lock_guard<std::mutex> lk(g_dpool_mu);
+  g_dpool[device].push_back(PoolBlock{p, want, true});
+  note_device_alloc(want);
+  return p;
+}
+
+void device_pool_free(int device, void* p) {
+  if (p == nullptr || device < 0 || device >= 16) return;
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_dpool_mu);
+    auto& v = g_dpool[device];
+    size_t idle = 0;
+    for (PoolBlock& b : v) {
+      if (b.p == p && b.used) { b.used = false; note_device_free(b.bytes); }
+      if (!b.used) idle += b.bytes;
+    }
+    while (idle > kDevicePoolIdleBudget) {
+      size_t k = v.size();
+      for (size_t i = 0; i < v.size(); i++) if (!v[i].used && (k == v.size() || v[i].bytes > v[k].bytes)) k = i;
+      if (k == v.size()) break;
+      idle -= v[k].bytes;
+      drop.push_back(v[k].p);
+      v.erase(v.begin() + (long)k);
+    }
+  }
+  if (!drop.empty()) { (void)hipSetDevice(device); for (void* q : drop) (void)hipFree(q); }
+}
+
 hipEvent_t Context::get_event() {
   if (!events_.empty()) { hipEvent_t e = events_.back(); events_.pop_back(); return e; }
   hipEvent_t e;

@@ -65,6 +65,13 @@ class Context {
 void* pinned_pool_alloc(size_t bytes);
 void pinned_pool_free(void* p);
 
+// Process-wide, thread-safe pool of DEVICE blocks for records that outlive any plan (resident batches, resident filter results):
+// hipMalloc / hipFree cost hundreds of microseconds and hipFree synchronises the whole device, which a chain that filters one
+// record after another must not pay per record. Blocks are 2 MiB granules, re-used when an idle one is at most 25 % larger than
+// the request; idle bytes per device are capped (the largest idle blocks go back to the driver first).
+void* device_pool_alloc(int device, size_t bytes);
+void device_pool_free(int device, void* p);
+
 // Live-allocation accounting (fdb_live_allocations): device blocks handed out by dev_alloc and not returned, arenas of
 // resident batches (note_device_alloc / _free), result blocks of the pinned pool not yet released.
 void note_device_alloc(size_t bytes);

@@ -1173,231 +1173,176 @@ __global__ void peer_reduce_kernel(unsigned long long* dst, const PeerSrcs srcs,
 }
 
 // ---- selection vector (≙ bitmap.ToArray() of filter.go:286, built on the device) ---------------------------
-// Pass 1: evaluate the predicate, keep each lane's 8-row mask byte, count selected rows per tile.
-__global__ __launch_bounds__(FDB_BLOCK) void select_flags_kernel(const FdbScanArgs a, uint8_t* masks, uint32_t* tile_counts) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int R = 8;
-  const int tid = threadIdx.x;
-  for (int l = 0; l < a.n_leaves; l++) {
-    const FdbLeaf& L = a.leaves[l];
-    if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
-      for (uint32_t i = tid; i < L.lut_len; i += FDB_BLOCK) smem[L.lut_lds + i] = as_global(L.lut)[i];
-  }
-  __shared__ uint32_t wave_cnt[FDB_BLOCK / 64];
-  __syncthreads();
-  const int64_t tile_rows = (int64_t)FDB_BLOCK * R;
-  const int64_t n_tiles = (a.n_rows + tile_rows - 1) / tile_rows;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * tile_rows + (int64_t)tid * R;
-    uint32_t sel = 0;
-    if (row0 < a.n_rows) {
-      const int64_t left = a.n_rows - row0;
-      const uint32_t in_range = left >= R ? 0xFFu : ((1u << (int)left) - 1u);
-      sel = eval_filter<R>(a, row0, smem) & in_range;
-      masks[row0 >> 3] = (uint8_t)sel;
-    }
-    // wave total via ballot-free popcount reduction: DPP row reductions are what __reduce would emit; keep it simple
-    uint32_t c = __popc(sel);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((tid & 63) == 0) wave_cnt[tid >> 6] = c;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t t = 0;
-      for (int w = 0; w < FDB_BLOCK / 64; w++) t += wave_cnt[w];
-      tile_counts[tile] = t;
-    }
-    __syncthreads();
-  }
-}
-
-// Pass 2: exclusive scan of the per-tile counts (one workgroup; n_tiles is rows / 8192).
+// In-place exclusive scan of per-tile counts (one workgroup; n_tiles is rows / 8192) + their total.
 __global__ __launch_bounds__(FDB_BLOCK) void scan_counts_kernel(uint32_t* tile_counts, int64_t n_tiles, unsigned long long* total) {
-  __shared__ unsigned long long part[FDB_BLOCK];
-  const int tid = threadIdx.x;
+  __shared__ unsigned long long wave_sum[FDB_BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t per = (n_tiles + FDB_BLOCK - 1) / FDB_BLOCK;
   const int64_t lo = (int64_t)tid * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
   unsigned long long s = 0;
   for (int64_t i = lo; i < hi; i++) s += tile_counts[i];
-  part[tid] = s;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned long long run = 0;
-    for (int i = 0; i < FDB_BLOCK; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
-    *total = run;
+  unsigned long long incl = s;  // inclusive scan of the per-thread sums over the wave, then over the 16 wave totals
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
   }
+  if (lane == 63) wave_sum[wave] = incl;
   __syncthreads();
-  unsigned long long run = part[tid];
+  unsigned long long before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < FDB_BLOCK / 64; w++) { if (w < wave) before += wave_sum[w]; all += wave_sum[w]; }
+  if (tid == 0) *total = all;
+  unsigned long long run = before + incl - s;
   for (int64_t i = lo; i < hi; i++) { const uint32_t v = tile_counts[i]; tile_counts[i] = (uint32_t)run; run += v; }
 }
 
-// Pass 3: wave prefix sums of per-lane popcounts place every selected row: ascending indices, no atomics.
-__global__ __launch_bounds__(FDB_BLOCK) void select_write_kernel(const uint8_t* masks, const uint32_t* tile_offsets, int64_t n_rows,
-                                                                 uint32_t* indices) {
-  constexpr int R = 8;
-  __shared__ uint32_t wave_base[FDB_BLOCK / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t tile_rows = (int64_t)FDB_BLOCK * R;
-  const int64_t n_tiles = (n_rows + tile_rows - 1) / tile_rows;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * tile_rows + (int64_t)tid * R;
-    const uint32_t sel = row0 < n_rows ? masks[row0 >> 3] : 0u;
-    const uint32_t c = __popc(sel);
-    uint32_t incl = c;  // inclusive wave scan
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) wave_base[wave] = incl;
-    __syncthreads();
-    uint32_t base = tile_offsets[tile];
-    for (int w = 0; w < wave; w++) base += wave_base[w];
-    uint32_t pos = base + incl - c;
-    uint32_t m = sel;
-    while (m) {
-      const int r = __ffs(m) - 1;
-      m &= m - 1;
-      indices[pos++] = (uint32_t)(row0 + r);
-    }
-    __syncthreads();
-  }
-}
-
-
-// ---- filter() in one pass: predicate → output position (decoupled look-back) → compacted columns -----------------------------
-__global__ __launch_bounds__(FDB_COMPACT_BLOCK) void compact_kernel(const FdbScanArgs a, const FdbCompactArgs c) {
+// Step 1 of filter(): one mask byte per lane (8 consecutive rows), selected rows per 2 048-row tile. Grid-stride over chunks of
+// 256 lanes × 8 rows; a wave's 512 rows lie inside one tile, so its count is one atomic.
+__global__ __launch_bounds__(FDB_COMPACT_BLOCK) void filter_flags_kernel(const FdbScanArgs a, uint8_t* masks, uint32_t* tile_counts) {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int R = 4, NW = FDB_COMPACT_BLOCK / 64;
-  constexpr unsigned long long VAL = (1ull << 62) - 1ull;
-  __shared__ uint32_t s_wave[NW];
-  __shared__ unsigned long long s_prefix;
-  __shared__ uint32_t s_tile;
-  __shared__ unsigned int s_nulls[128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int R = 8;
+  const int tid = threadIdx.x;
   for (int l = 0; l < a.n_leaves; l++) {
     const FdbLeaf& L = a.leaves[l];
     if (L.kind == FDB_LEAF_DICT_LUT && L.lut_lds != FDB_NO_LDS)
       for (uint32_t i = tid; i < L.lut_len; i += FDB_COMPACT_BLOCK) smem[L.lut_lds + i] = as_global(L.lut)[i];
   }
-  for (int k = tid; k < 128; k += FDB_COMPACT_BLOCK) s_nulls[k] = 0;
-  const int64_t n_tiles = (a.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
-  for (;;) {
-    __syncthreads();  // (also orders the LUT staging / the previous tile's use of the shared variables)
-    if (tid == 0) s_tile = atomicAdd(c.ticket, 1u);
-    __syncthreads();
-    const int64_t tile = (int64_t)s_tile;
-    if (tile >= n_tiles) break;
-    const int64_t row0 = tile * FDB_COMPACT_TILE + (int64_t)tid * R;
+  __syncthreads();
+  const int64_t chunk_rows = (int64_t)FDB_COMPACT_BLOCK * R;
+  const int64_t n_chunks = (a.n_rows + chunk_rows - 1) / chunk_rows;
+  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const int64_t row0 = ch * chunk_rows + (int64_t)tid * R;
     uint32_t sel = 0;
     if (row0 < a.n_rows) {
       const int64_t left = a.n_rows - row0;
-      sel = eval_filter<R>(a, row0, smem) & (left >= R ? 0xFu : ((1u << (int)left) - 1u));
+      sel = eval_filter<R>(a, row0, smem) & (left >= R ? 0xFFu : ((1u << (int)left) - 1u));
+      masks[row0 >> 3] = (uint8_t)sel;
     }
-    const uint32_t cnt = __popc(sel);
-    uint32_t incl = cnt;  // inclusive scan over the wave
+    uint32_t cnt = __popc(sel);
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t wave_base = 0, tile_total = 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((tid & 63) == 0 && cnt != 0u) atomicAdd(&tile_counts[(ch * chunk_rows + (int64_t)(tid & ~63) * R) / FDB_COMPACT_TILE], cnt);
+  }
+}
+
+// Step 3 of filter(): ONE column compacted per launch (see fdb_kernels.h). One wave per 2 048-row tile, no workgroup barriers:
+// the tile's first output row comes from the prefix sums of step 2, everything else is wave-local (shuffles + the wave's own LDS
+// region). W = 4 / 8: bytes per value; W = 0: the selection vector itself (row numbers). A pair of sub-tiles (512 rows) at a
+// time: mask nibbles → wave prefix sums → load (2 × 16 or 32 bytes per lane) → scatter into the staging buffer → coalesced
+// store. The kernel is deliberately small: ≈40 VGPRs, 8 waves per SIMD — memory-level parallelism comes from the 32 waves a CU
+// holds. (A version that handled all columns of a tile in one launch needed 130–250 VGPRs whichever way it was written and ran
+// at 1–3 waves per SIMD: 0.27–0.34 ms per 25 M rows against 0.1 ms for this one.)
+template <int W>
+__global__ __launch_bounds__(FDB_COMPACT_BLOCK, 5) void compact_col_kernel(const void* __restrict__ src, const uint8_t* __restrict__ src_valid, void* __restrict__ dst,
+                                                                           uint8_t* __restrict__ dst_valid, const uint8_t* __restrict__ masks,
+                                                                           const uint32_t* __restrict__ tile_offsets, int64_t n_rows, unsigned long long* null_count) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  // NS sub-tiles (of 64 lanes × 4 rows) per step: 64 bytes of value loads per lane in flight either way
+  constexpr int R = 4, NW = FDB_COMPACT_BLOCK / 64, NS = W == 8 ? 2 : 4, STEP_ROWS = NS * FDB_COMPACT_SUBTILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* stage = smem + (size_t)wave * FDB_COMPACT_WAVE_LDS;  // this wave's region: ≤ 4 KiB of values, then ≤ 1 KiB of validity bytes
+  uint8_t* stage_valid = stage + 4096;
+  const int64_t n_tiles = (n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
+  uint32_t my_nulls = 0;
+  for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NW) {
+    // the tile's 2 048 mask bits: 64 words, one per lane (bits past n_rows were never written: masked below)
+    const int64_t mw = tile * (FDB_COMPACT_TILE / 32) + lane;
+    const uint32_t word = mw * 32 < n_rows ? as_global(reinterpret_cast<const uint32_t*>(masks))[mw] : 0u;
+    if (__ballot(word != 0u) == 0ull) continue;
+    unsigned long long out = tile_offsets[tile];  // wave-uniform: next output row
+#pragma unroll 1
+    for (int q = 0; q < FDB_COMPACT_TILE / STEP_ROWS; q++) {
+      // rows of this lane in the step: tile·2048 + q·STEP_ROWS + u·256 + lane·4 … + 3 for u < NS
+      const int64_t row0 = tile * FDB_COMPACT_TILE + (int64_t)q * STEP_ROWS + (int64_t)lane * R;
+      uint32_t sel[NS], any = 0;
 #pragma unroll
-    for (int w = 0; w < NW; w++) { if (w < wave) wave_base += s_wave[w]; tile_total += s_wave[w]; }
-    // ---- decoupled look-back (wave 0): publish this tile's total, add up the totals of the tiles before it until one of them
-    // already knows its inclusive prefix, publish ours. State words: flag 1 = total only, 2 = inclusive prefix.
-    if (wave == 0) {
-      unsigned long long excl = 0;
-      if (tile > 0) {
-        if (lane == 0) __hip_atomic_store(c.tile_state + tile, (1ull << 62) | (unsigned long long)tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int64_t base = tile - 1;
-        for (;;) {
-          const int64_t t = base - lane;
-          unsigned long long st = t >= 0 ? __hip_atomic_load(c.tile_state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
-          while (__any((st >> 62) == 0ull)) {  // predecessors hold earlier tickets: they are running and will publish
-            __builtin_amdgcn_s_sleep(1);
-            if ((st >> 62) == 0ull) st = __hip_atomic_load(c.tile_state + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          const unsigned long long have_prefix = __ballot((st >> 62) == 2ull);
-          const int first = have_prefix ? __ffsll((long long)have_prefix) - 1 : 64;
-          unsigned long long v = lane <= first ? (st & VAL) : 0ull;
+      for (int u = 0; u < NS; u++) {
+        const uint32_t w = __shfl(word, (q * NS + u) * 8 + (lane >> 3), 64);
+        const int64_t left = n_rows - (row0 + (int64_t)u * FDB_COMPACT_SUBTILE);
+        sel[u] = (w >> ((lane & 7) * 4)) & (left >= R ? 0xFu : left > 0 ? ((1u << (int)left) - 1u) : 0u);
+        any |= sel[u];
+      }
+      if (__ballot(any != 0u) == 0ull) continue;
+      // every load of the step is issued before anything is consumed: validity bytes and values
+      uint32_t valid[NS];
+      uint32_t x4[W == 4 ? NS : 1][R];
+      unsigned long long x8[W == 8 ? NS : 1][R];
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-          excl += v;
-          if (have_prefix) break;
-          base -= 64;
+      for (int u = 0; u < NS; u++) {
+        valid[u] = 0xFu;
+        if (W != 0 && src_valid != nullptr && sel[u]) valid[u] = load_valid<R>(src_valid, row0 + (int64_t)u * FDB_COMPACT_SUBTILE);
+        if (W == 4 && sel[u]) load_u32<R>(reinterpret_cast<const uint32_t*>(src) + row0 + (int64_t)u * FDB_COMPACT_SUBTILE, x4[u]);
+        if (W == 8 && sel[u]) load_u64<R>(reinterpret_cast<const unsigned long long*>(src) + row0 + (int64_t)u * FDB_COMPACT_SUBTILE, x8[u]);
+      }
+      // Output slots without a scan: the rows before this lane's are the set bits of the four per-row ballots in lower lanes
+      // (v_mbcnt: no LDS traffic, no 6-step shuffle chain), a sub-tile's total is their population count.
+      uint32_t pos[NS], total = 0;
+#pragma unroll
+      for (int u = 0; u < NS; u++) {
+        uint32_t p = total;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const unsigned long long b = __ballot((sel[u] >> r) & 1u);
+          p += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+          total += (uint32_t)__popcll(b);
         }
+        pos[u] = p;
       }
-      if (lane == 0) {
-        __hip_atomic_store(c.tile_state + tile, (2ull << 62) | (excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_prefix = excl;
-        if (tile == n_tiles - 1) *c.total = excl + tile_total;
-      }
-    }
-    __syncthreads();
-    const unsigned long long pos0 = s_prefix + wave_base + (incl - cnt);
-    if (sel != 0u) {
-      if (c.out_indices != nullptr) {
-        unsigned long long p = pos0;
 #pragma unroll
-        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) { if (p < c.capacity) c.out_indices[p] = (uint32_t)(row0 + r); p++; }
-      }
-    }
-    for (int k = 0; k < c.n_cols; k++) {
-      const FdbCompactCol C = c.cols[k];
-      uint32_t valid = 0xFu;
-      if (C.src_valid != nullptr && row0 < a.n_rows) valid = load_valid<R>(C.src_valid, row0);
-      if (C.src_valid != nullptr) {
-        const uint32_t nulls = __popc(sel & ~valid);
-        if (__any(nulls != 0u)) {
-          uint32_t t = nulls;
+      for (int u = 0; u < NS; u++) {
+        if (W != 0) my_nulls += __popc(sel[u] & ~valid[u]);
+        uint32_t p = pos[u];
 #pragma unroll
-          for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-          if (lane == 0) atomicAdd(&s_nulls[k & 127], t);
-        }
-      }
-      if (sel == 0u) continue;
-      unsigned long long p = pos0;
-      if (C.width == 4) {
-        uint32_t v[R];
-        load_u32<R>(reinterpret_cast<const uint32_t*>(C.src) + row0, v);
-#pragma unroll
-        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) {
-          if (p < c.capacity) { reinterpret_cast<uint32_t*>(C.dst)[p] = ((valid >> r) & 1u) ? v[r] : 0u; if (C.dst_valid != nullptr) C.dst_valid[p] = (uint8_t)((valid >> r) & 1u); }
+        for (int r = 0; r < R; r++) if ((sel[u] >> r) & 1u) {
+          if (W == 4) reinterpret_cast<uint32_t*>(stage)[p] = ((valid[u] >> r) & 1u) ? x4[u][r] : 0u;
+          else if (W == 8) reinterpret_cast<unsigned long long*>(stage)[p] = x8[u][r];
+          else reinterpret_cast<uint32_t*>(stage)[p] = (uint32_t)(row0 + (int64_t)u * FDB_COMPACT_SUBTILE + r);
+          if (W != 0 && dst_valid != nullptr) stage_valid[p] = (uint8_t)((valid[u] >> r) & 1u);
           p++;
         }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (W == 8) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(dst) + out;
+#pragma unroll 2
+        for (uint32_t i = lane; i < total; i += 64) d[i] = reinterpret_cast<const unsigned long long*>(stage)[i];
       } else {
-        unsigned long long v[R];
-        load_u64<R>(reinterpret_cast<const unsigned long long*>(C.src) + row0, v);
-#pragma unroll
-        for (int r = 0; r < R; r++) if ((sel >> r) & 1u) {
-          if (p < c.capacity) { reinterpret_cast<unsigned long long*>(C.dst)[p] = v[r]; if (C.dst_valid != nullptr) C.dst_valid[p] = (uint8_t)((valid >> r) & 1u); }
-          p++;
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst) + out;
+#pragma unroll 2
+        for (uint32_t i = lane; i < total; i += 64) d[i] = reinterpret_cast<const uint32_t*>(stage)[i];
+      }
+      if (W != 0 && dst_valid != nullptr) {
+        // validity bits of the rows just written: 64 output rows per ballot, OR-ed into the (zeroed) output bitmap — the run
+        // starts at an arbitrary bit, so it touches two words
+        unsigned long long* bits = reinterpret_cast<unsigned long long*>(dst_valid);
+#pragma unroll 1
+        for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          const unsigned long long w = __ballot(i < total && stage_valid[i] != 0);
+          if (lane == 0 && w != 0ull) {
+            const unsigned long long at = out + i0;
+            const uint32_t sh = (uint32_t)(at & 63ull);
+            atomicOr(bits + (at >> 6), w << sh);
+            if (sh != 0u && (w >> (64u - sh)) != 0ull) atomicOr(bits + (at >> 6) + 1, w >> (64u - sh));
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();
+      out += total;
     }
   }
-  // (the loop was left right after a barrier)
-  if (c.null_counts != nullptr)
-    for (int k = tid; k < c.n_cols && k < 128; k += FDB_COMPACT_BLOCK)
-      if (s_nulls[k] != 0) atomicAdd(c.null_counts + k, (unsigned long long)s_nulls[k]);
-}
-
-template <typename T>
-__global__ void gather_kernel(const T* __restrict__ src, T* __restrict__ dst, const uint32_t* __restrict__ idx, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
-}
-
-// Output validity bitmap: one lane per output row, ballot packs 64 rows into one 8-byte word.
-__global__ void gather_bits_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint32_t* __restrict__ idx, int64_t n) {
-  const int64_t n_round = (n + 63) & ~(int64_t)63;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * blockDim.x) {
-    bool bit = false;
-    if (i < n) { const uint32_t s = idx[i]; bit = (src[s >> 3] >> (s & 7)) & 1; }
-    const unsigned long long word = __ballot(bit);
-    if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned long long*>(dst)[i >> 6] = word;
+  if (W != 0 && null_count != nullptr && src_valid != nullptr) {
+    // one atomic per WORKGROUP, spread over 64 counters (the caller adds them up): thousands of waves adding to one address
+    // serialise in the L2 — 8 192 atomics on one word cost 80 µs, more than the compaction itself
+    __shared__ unsigned int s_nulls;
+    if (tid == 0) s_nulls = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my_nulls += __shfl_xor(my_nulls, o, 64);
+    if (lane == 0 && my_nulls != 0u) atomicAdd(&s_nulls, my_nulls);
+    __syncthreads();
+    if (tid == 0 && s_nulls != 0u) atomicAdd(null_count + (blockIdx.x & 63), (unsigned long long)s_nulls);
   }
 }
 
@@ -1556,51 +1501,38 @@ hipError_t fdb_launch_peer_reduce(unsigned long long* dst, const void* const* sr
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_select(const FdbScanArgs& args, uint32_t* indices_out, unsigned long long* n_selected_out, uint32_t* tile_counts,
-                             hipStream_t stream) {
-  // `tile_counts` doubles as scratch: [n_tiles counts][mask bytes]
-  const int64_t tile_rows = (int64_t)FDB_BLOCK * 8;
-  const int64_t n_tiles = (args.n_rows + tile_rows - 1) / tile_rows;
-  if (n_tiles == 0) return hipMemsetAsync(n_selected_out, 0, 8, stream);
-  uint8_t* masks = reinterpret_cast<uint8_t*>(tile_counts + ((n_tiles + 3) & ~(int64_t)3));
-  int grid = 512;
-  if (grid > n_tiles) grid = (int)n_tiles;
-  hipLaunchKernelGGL(select_flags_kernel, dim3(grid), dim3(FDB_BLOCK), args.lds_lut_bytes, stream, args, masks, tile_counts);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, tile_counts, n_tiles, n_selected_out);
-  hipLaunchKernelGGL(select_write_kernel, dim3(grid), dim3(FDB_BLOCK), 0, stream, masks, tile_counts, args.n_rows, indices_out);
+hipError_t fdb_launch_filter_flags(const FdbScanArgs& args, uint8_t* masks, uint32_t* tile_counts, int device, hipStream_t stream) {
+  const int64_t chunk_rows = (int64_t)FDB_COMPACT_BLOCK * 8;
+  const int64_t n_chunks = (args.n_rows + chunk_rows - 1) / chunk_rows;
+  if (n_chunks == 0) return hipSuccess;
+  int64_t grid = (int64_t)fdb_scan_default_grid(device) * 4;  // 8 workgroups (32 waves) per CU: latency hiding by occupancy
+  if (grid > n_chunks) grid = n_chunks;
+  hipLaunchKernelGGL(filter_flags_kernel, dim3((unsigned)grid), dim3(FDB_COMPACT_BLOCK), args.lds_lut_bytes, stream, args, masks, tile_counts);
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_compact(const FdbScanArgs& args, const FdbCompactArgs& c, int device, hipStream_t stream) {
-  const int64_t n_tiles = (args.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
-  if (n_tiles == 0) return hipMemsetAsync(c.total, 0, 8, stream);
-  if (c.n_cols > 128) return hipErrorInvalidValue;
-  // persistent grid: tiles are taken by ticket; ≈8 workgroups (32 waves) per CU keep enough loads in flight for a streaming copy
+hipError_t fdb_launch_tile_offsets(uint32_t* tile_counts, int64_t n_tiles, unsigned long long* total, hipStream_t stream) {
+  if (n_tiles <= 0) return hipMemsetAsync(total, 0, 8, stream);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, tile_counts, n_tiles, total);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_compact_col(int width, const void* src, const uint8_t* src_valid, void* dst, uint8_t* dst_valid, const uint8_t* masks,
+                                  const uint32_t* tile_offsets, int64_t n_rows, unsigned long long* null_count, int device, hipStream_t stream) {
+  const int64_t n_tiles = (n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
+  if (n_tiles == 0) return hipSuccess;
+  // 5 workgroups (20 independent waves) per CU — 5 KiB of staging LDS per wave
   int64_t grid = (int64_t)fdb_scan_default_grid(device) * 4;
-  if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)grid), dim3(FDB_COMPACT_BLOCK), args.lds_lut_bytes, stream, args, c);
+  const int64_t need = (n_tiles + 3) / 4;
+  if (grid > need) grid = need;
+  const size_t lds = (size_t)(FDB_COMPACT_BLOCK / 64) * FDB_COMPACT_WAVE_LDS;
+  if (width == 4) hipLaunchKernelGGL(compact_col_kernel<4>, dim3((unsigned)grid), dim3(FDB_COMPACT_BLOCK), lds, stream, src, src_valid, dst, dst_valid, masks, tile_offsets, n_rows, null_count);
+  else if (width == 8) hipLaunchKernelGGL(compact_col_kernel<8>, dim3((unsigned)grid), dim3(FDB_COMPACT_BLOCK), lds, stream, src, src_valid, dst, dst_valid, masks, tile_offsets, n_rows, null_count);
+  else if (width == 0) hipLaunchKernelGGL(compact_col_kernel<0>, dim3((unsigned)grid), dim3(FDB_COMPACT_BLOCK), lds, stream, src, src_valid, dst, dst_valid, masks, tile_offsets, n_rows, null_count);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_gather(const void* src, void* dst, const uint32_t* indices, int64_t n, int elem_bytes, hipStream_t stream) {
-  if (n <= 0) return hipSuccess;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  if (elem_bytes == 4)
-    hipLaunchKernelGGL((gather_kernel<uint32_t>), dim3(blocks), dim3(256), 0, stream, (const uint32_t*)src, (uint32_t*)dst, indices, n);
-  else
-    hipLaunchKernelGGL((gather_kernel<unsigned long long>), dim3(blocks), dim3(256), 0, stream, (const unsigned long long*)src,
-                       (unsigned long long*)dst, indices, n);
-  return hipGetLastError();
-}
-
-hipError_t fdb_launch_gather_bits(const uint8_t* src_bitmap, uint8_t* dst_bitmap, const uint32_t* indices, int64_t n, hipStream_t stream) {
-  if (n <= 0) return hipSuccess;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gather_bits_kernel, dim3(blocks), dim3(256), 0, stream, src_bitmap, dst_bitmap, indices, n);
-  return hipGetLastError();
-}
 
 hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t lds_bytes, hipStream_t stream) {
   const int64_t tile_rows = (int64_t)FDB_HASH_BLOCK;

@@ -69,9 +69,7 @@ bool match_group(const GroupMatcher& m, const std::string& field) {  // logicalp
 DeviceBatch::~DeviceBatch() {
   if (arena == nullptr) return;
   if (arena_ctx != nullptr) { arena_ctx->dev_free(arena); return; }
-  (void)hipSetDevice(device);
-  (void)hipFree(arena);
-  note_device_free(arena_bytes);
+  device_pool_free(device, arena);
 }
 
 int DeviceBatch::find(const std::string& name) const {
@@ -141,7 +139,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
   }
   if (total > 0) {
     if (ctx != nullptr) { b->arena = ctx->dev_alloc(total); b->arena_ctx = ctx; }
-    else { hip_check(hipMalloc(&b->arena, total), "hipMalloc(batch arena)"); note_device_alloc(total); }
+    else b->arena = device_pool_alloc(device, total);
     b->arena_bytes = total;
   }
   // transient batches: every copy is queued on `stream`; re-packed buffers stay alive until the one wait at the end
@@ -1722,7 +1720,6 @@ void Plan::merge_from(Plan& src) {
   sync();
 }
 
-// ---- selection / filter-only -------------------------------------------------------------------------------------
 namespace {
 struct DevBuf {  // scratch from the context's caching allocator; the plan's stream orders every reuse
   Context* ctx;
@@ -1733,24 +1730,17 @@ struct DevBuf {  // scratch from the context's caching allocator; the plan's str
 };
 }  // namespace
 
-void Plan::select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* indices, int64_t capacity, int64_t* n_selected) {
-  if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
-  HostRecordView view;
-  view_record(array, schema, &view);
-  if (capacity < view.rows) throw Error(FDB_ERR_INVALID, "indices capacity smaller than the record");
-  std::function<bool(const std::string&)> want = [this](const std::string& n) {
-    for (const ExprNode& e : filter_) if (is_leaf_op(e.op) && e.column == n) return true;
-    return false;
-  };
-  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_);
-  Resolved R;
+// ---- selection / filter-only -------------------------------------------------------------------------------------
+// ≙ filter() (filter.go:276-323): the reference turns the predicate's bitmap into index ranges, slices every column per range
+// and concatenates the slices. Here ONE kernel pass evaluates the predicate, gives every selected row its output position
+// (decoupled look-back over per-tile totals) and writes the compacted columns — see fdb_launch_compact.
+void Plan::resolve_filter_only(const DeviceBatch& b, Resolved* Rp) {
+  Resolved& R = *Rp;
   std::memset(&R.args, 0, sizeof(R.args));
-  R.args.n_rows = b->rows;
+  R.args.n_rows = b.rows;
   int max_depth = 0;
   R.truths = &truth_cache_;
-  emit_filter(filter_, filter_root_, *b, &R, 0, &max_depth);
-  *n_selected = 0;
-  if (b->rows == 0) return;
+  emit_filter(filter_, filter_root_, b, &R, 0, &max_depth);
   FdbScanArgs& a = R.args;
   size_t lds_off = 0;
   unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
@@ -1762,61 +1752,165 @@ void Plan::select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* 
     a.leaves[p.index].lut_lds = lds;
   }
   a.lds_lut_bytes = (uint32_t)align_up(lds_off, 16);
-  const int64_t n_tiles = (b->rows + FDB_BLOCK * 8 - 1) / (FDB_BLOCK * 8);
-  DevBuf scratch(ctx_, (size_t)((n_tiles + 3) & ~(int64_t)3) * 4 + (size_t)(b->rows + 7) / 8 + 64);
-  DevBuf d_idx(ctx_, (size_t)b->rows * 4);
-  DevBuf d_n(ctx_, 8);
-  hip_check(fdb_launch_select(a, (uint32_t*)d_idx.p, (unsigned long long*)d_n.p, (uint32_t*)scratch.p, stream_), "select launch");
-  unsigned long long n = 0;
-  hip_check(hipMemcpyAsync(&n, d_n.p, 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(n)");
-  sync();
-  *n_selected = (int64_t)n;
-  if (n) hip_check(hipMemcpy(indices, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost), "hipMemcpy(indices)");
-  stat_bytes += R.bytes;
 }
 
-void Plan::filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray* out, ArrowSchema* out_schema, int64_t* n_selected) {
+// Steps 1 + 2 of filter(): selection bitmap and per-tile output offsets on the device (scratch of this plan until its next
+// sync()), number of selected rows on the host.
+int64_t Plan::run_flags(const FdbScanArgs& a, uint8_t** d_masks, uint32_t** d_offsets) {
+  const int64_t n_tiles = (a.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
+  uint8_t* masks = (uint8_t*)ctx_->dev_alloc((size_t)n_tiles * (FDB_COMPACT_TILE / 8) + 64);
+  uint32_t* offs = (uint32_t*)ctx_->dev_alloc((size_t)(n_tiles + 4) * 4 + 64);
+  unsigned long long* d_total = (unsigned long long*)ctx_->dev_alloc(64);
+  scratch_.push_back(masks); scratch_.push_back(offs); scratch_.push_back(d_total);
+  hip_check(hipMemsetAsync(offs, 0, (size_t)(n_tiles + 4) * 4, stream_), "hipMemsetAsync(tile counts)");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
+  hip_check(fdb_launch_filter_flags(a, masks, offs, device_, stream_), "filter flags launch");
+  hip_check(fdb_launch_tile_offsets(offs, n_tiles, d_total, stream_), "tile offsets launch");
+  if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
+  unsigned long long total = 0;
+  hip_check(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(total)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  *d_masks = masks; *d_offsets = offs;
+  stat_launches += 1;
+  return (int64_t)total;
+}
+
+int64_t Plan::select_batch(const DeviceBatch& in, uint32_t* d_indices, int64_t capacity) {
   if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
-  HostRecordView view;
-  view_record(array, schema, &view);
-  std::vector<uint32_t> idx((size_t)std::max<int64_t>(view.rows, 1));
-  select(array, schema, idx.data(), (int64_t)idx.size(), n_selected);
-  const int64_t n = *n_selected;
-  if (n == 0) return;  // filter.go:264-266
-  // compaction of every column of the record (≙ slice + array.Concatenate, filter.go:296-320)
-  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, nullptr, stream_);
-  DevBuf d_idx(ctx_, (size_t)n * 4);
-  hip_check(hipMemcpy(d_idx.p, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice), "hipMemcpy(indices)");
-  std::vector<OutColumn> cols;
-  for (const DevColumn& c : b->cols) {
-    if (c.d_values == nullptr)
+  if (in.device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
+  if (capacity < in.rows) throw Error(FDB_ERR_INVALID, "indices capacity smaller than the record");
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  if (in.rows == 0) return 0;
+  Resolved R;
+  resolve_filter_only(in, &R);
+  uint8_t* masks = nullptr;
+  uint32_t* offs = nullptr;
+  const int64_t n = run_flags(R.args, &masks, &offs);
+  if (n > 0) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
+    hip_check(fdb_launch_compact_col(0, nullptr, nullptr, d_indices, nullptr, masks, offs, in.rows, nullptr, device_, stream_), "compact launch");
+    if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
+  }
+  last_kernel_ = "compact_col_kernel";
+  sync();
+  stat_bytes += R.bytes + n * 4;
+  stat_rows += in.rows;
+  return n;
+}
+
+std::unique_ptr<DeviceBatch> Plan::filter_batch(const DeviceBatch& in, int64_t* n_selected) {
+  if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
+  if (in.device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
+  if (in.cols.size() > 128) throw Error(FDB_ERR_UNSUPPORTED, "filter output: more than 128 columns");
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  std::unique_ptr<DeviceBatch> out(new DeviceBatch());
+  out->device = device_;
+  for (const DevColumn& c : in.cols) {
+    if (c.d_values == nullptr && in.rows > 0)
       throw Error(FDB_ERR_UNSUPPORTED, "filter output: column type " + c.format + " (" + c.name + ") is not supported on the device path");
+    DevColumn d;
+    d.name = c.name; d.format = c.format; d.kind = c.kind; d.dict = c.dict;
+    out->cols.push_back(std::move(d));
+  }
+  *n_selected = 0;
+  if (in.rows == 0) return out;
+  Resolved R;
+  resolve_filter_only(in, &R);
+  uint8_t* masks = nullptr;
+  uint32_t* offs = nullptr;
+  const int64_t total = run_flags(R.args, &masks, &offs);  // (one host round trip: the output is allocated at its exact size)
+  *n_selected = total;
+  out->rows = total;
+  stat_bytes += R.bytes;
+  stat_rows += in.rows;
+  if (total == 0) { sync(); return out; }
+  const uint64_t cap = (uint64_t)total;
+  struct Piece { size_t val_off, bit_off; };
+  std::vector<Piece> pieces(in.cols.size());
+  size_t total_bytes = 0;
+  for (size_t k = 0; k < in.cols.size(); k++) {
+    const DevColumn& c = in.cols[k];
+    const size_t w = c.kind == ColKind::DICT ? 4 : 8;
+    pieces[k].val_off = total_bytes;
+    total_bytes += align_up(cap * w + kTailPad, 256);
+    pieces[k].bit_off = total_bytes;
+    if (c.d_validity != nullptr) total_bytes += align_up((cap + 7) / 8 + kTailPad, 256);
+  }
+  out->arena = device_pool_alloc(device_, std::max<size_t>(total_bytes, 256));
+  out->arena_bytes = std::max<size_t>(total_bytes, 256);
+  unsigned long long* d_nulls = (unsigned long long*)ctx_->dev_alloc(128 * 64 * 8);  // 64 partial counts per column
+  scratch_.push_back(d_nulls);
+  hip_check(hipMemsetAsync(d_nulls, 0, in.cols.size() * 64 * 8, stream_), "hipMemsetAsync(null counts)");
+  struct OutCol { void* dst; uint8_t* dst_valid; int width; };
+  std::vector<OutCol> cols(in.cols.size());
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
+  for (size_t k = 0; k < in.cols.size(); k++) {  // one streaming pass per column (fdb_launch_compact_col)
+    const DevColumn& c = in.cols[k];
+    OutCol& C = cols[k];
+    C.dst = (unsigned char*)out->arena + pieces[k].val_off;
+    C.width = c.kind == ColKind::DICT ? 4 : 8;
+    C.dst_valid = nullptr;
+    if (c.d_validity != nullptr) {  // the output bitmap is OR-ed into: zero it first
+      C.dst_valid = (uint8_t*)out->arena + pieces[k].bit_off;
+      hip_check(hipMemsetAsync(C.dst_valid, 0, align_up((cap + 7) / 8 + kTailPad, 256), stream_), "hipMemsetAsync(validity)");
+    }
+    hip_check(fdb_launch_compact_col(C.width, c.d_values, c.d_validity, C.dst, C.dst_valid, masks, offs, in.rows, d_nulls + k * 64, device_, stream_), "compact launch");
+  }
+  if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
+  last_kernel_ = "compact_col_kernel";
+  std::vector<unsigned long long> h_parts(cols.size() * 64), h_nulls(cols.size(), 0);
+  hip_check(hipMemcpyAsync(h_parts.data(), d_nulls, cols.size() * 64 * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  for (size_t k = 0; k < cols.size(); k++) for (int i = 0; i < 64; i++) h_nulls[k] += h_parts[k * 64 + (size_t)i];
+  for (size_t k = 0; k < in.cols.size(); k++) {
+    const DevColumn& c = in.cols[k];
+    DevColumn& d = out->cols[k];
+    d.length = total;
+    d.null_count = (int64_t)h_nulls[k];
+    d.d_values = cols[k].dst;
+    d.value_bytes = c.kind == ColKind::BOOL ? (total + 7) / 8 : total * cols[k].width;
+    if (c.d_validity != nullptr && d.null_count > 0) {
+      d.d_validity = cols[k].dst_valid;
+      d.validity_bytes = (total + 7) / 8;
+    }
+    out->payload_bytes += d.value_bytes + d.validity_bytes;
+    // algorithmic bytes of the compaction: every selected value read once and written once, validity likewise
+    stat_bytes += 2 * (total * cols[k].width) + (c.d_validity != nullptr ? 2 * ((total + 7) / 8) : 0);
+  }
+  sync();
+  return out;
+}
+
+// The record of a resident batch as Arrow in host memory (one device→host copy per buffer).
+void export_batch(const DeviceBatch& b, ArrowArray* out, ArrowSchema* out_schema) {
+  hip_check(hipSetDevice(b.device), "hipSetDevice");
+  const int64_t n = b.rows;
+  std::vector<OutColumn> cols;
+  for (const DevColumn& c : b.cols) {
+    if (c.d_values == nullptr && n > 0)
+      throw Error(FDB_ERR_UNSUPPORTED, "export: column type " + c.format + " (" + c.name + ") is not held on the device");
     OutColumn o;
     o.name = c.name;
     o.length = n;
     const int w = c.kind == ColKind::DICT ? 4 : 8;
     o.format = c.kind == ColKind::DICT ? "I" : c.format;
-    DevBuf d_out(ctx_, (size_t)n * w);
-    hip_check(fdb_launch_gather(c.d_values, d_out.p, (const uint32_t*)d_idx.p, n, w, stream_), "gather");
     o.values.resize((size_t)n * w);
-    hip_check(hipMemcpyAsync(o.values.data(), d_out.p, (size_t)n * w, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(gather out)");
-    if (c.d_validity != nullptr) {
-      const size_t vb = (size_t)((n + 63) / 64) * 8;
-      DevBuf d_bits(ctx_, vb);
-      hip_check(fdb_launch_gather_bits(c.d_validity, (uint8_t*)d_bits.p, (const uint32_t*)d_idx.p, n, stream_), "gather bits");
-      o.validity.resize(vb);
-      hip_check(hipMemcpyAsync(o.validity.data(), d_bits.p, vb, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(bits)");
-      hip_check(hipStreamSynchronize(stream_), "sync");
+    if (n > 0) hip_check(hipMemcpy(o.values.data(), c.d_values, (size_t)n * w, hipMemcpyDeviceToHost), "hipMemcpy(export values)");
+    if (c.d_validity != nullptr && n > 0) {
+      o.validity.assign((size_t)((n + 63) / 64) * 8, 0);
+      hip_check(hipMemcpy(o.validity.data(), c.d_validity, (size_t)(n + 7) / 8, hipMemcpyDeviceToHost), "hipMemcpy(export validity)");
       o.null_count = count_nulls(o.validity.data(), 0, n);
-    } else {
-      hip_check(hipStreamSynchronize(stream_), "sync");
     }
-    if (c.kind == ColKind::DICT && c.dict->plain) {  // a plain string / binary column leaves as one
+    if (c.kind == ColKind::DICT && c.dict && c.dict->plain) {  // a plain string / binary column leaves as one
       const std::vector<uint8_t> idx_bytes = std::move(o.values);
       set_plain_strings(&o, (const uint32_t*)idx_bytes.data(), o.validity.empty() ? nullptr : o.validity.data(), n, c.dict->values, c.dict->value_format);
     } else if (c.kind == ColKind::DICT) {
+      if (!c.dict) throw Error(FDB_ERR_INVALID, "export: dictionary column without its dictionary: " + c.name);
       set_dictionary(&o, c.dict->values, c.dict->value_format);
-    } else if (c.kind == ColKind::BOOL) {  // staged as int64 1 / 2, Arrow wants bits
+    } else if (c.kind == ColKind::BOOL) {  // held as int64 1 / 2, Arrow wants bits
       std::vector<uint8_t> bits((size_t)(n + 7) / 8 + 8, 0);
       for (int64_t i = 0; i < n; i++) { int64_t v; std::memcpy(&v, o.values.data() + (size_t)i * 8, 8); if (v >= 2) bits[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7)); }
       o.values = std::move(bits);
@@ -1824,6 +1918,34 @@ void Plan::filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray
     cols.push_back(std::move(o));
   }
   export_record(std::move(cols), n, out, out_schema);
+}
+
+void Plan::select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* indices, int64_t capacity, int64_t* n_selected) {
+  if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
+  HostRecordView view;
+  view_record(array, schema, &view);
+  if (capacity < view.rows) throw Error(FDB_ERR_INVALID, "indices capacity smaller than the record");
+  std::function<bool(const std::string&)> want = [this](const std::string& n) {
+    for (const ExprNode& e : filter_) if (is_leaf_op(e.op) && e.column == n) return true;
+    return false;
+  };
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_);
+  *n_selected = 0;
+  if (b->rows == 0) return;
+  DevBuf d_idx(ctx_, (size_t)b->rows * 4);
+  const int64_t n = select_batch(*b, (uint32_t*)d_idx.p, b->rows);
+  *n_selected = n;
+  if (n) hip_check(hipMemcpy(indices, d_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost), "hipMemcpy(indices)");
+}
+
+void Plan::filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray* out, ArrowSchema* out_schema, int64_t* n_selected) {
+  if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
+  HostRecordView view;
+  view_record(array, schema, &view);
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, nullptr, stream_);
+  std::unique_ptr<DeviceBatch> f = filter_batch(*b, n_selected);
+  if (*n_selected == 0) return;  // filter.go:264-266
+  export_batch(*f, out, out_schema);
 }
 
 }  // namespace fdb

@@ -58,6 +58,9 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
                                           const std::function<bool(const std::string&)>* want, hipStream_t stream, class Context* ctx = nullptr,
                                           bool via_ring = false);
 
+// The record of a resident batch as Arrow in host memory.
+void export_batch(const DeviceBatch& b, ArrowArray* out, ArrowSchema* out_schema);
+
 struct Literal {
   int32_t type = FDB_LIT_NULL;
   int64_t i64 = 0;
@@ -197,6 +200,10 @@ class Plan {
   void merge_from(Plan& src);                                          // ≙ Synchronizer + final stage
   void select(const ArrowArray* array, const ArrowSchema* schema, uint32_t* indices, int64_t capacity, int64_t* n_selected);
   void filter(const ArrowArray* array, const ArrowSchema* schema, ArrowArray* out, ArrowSchema* out_schema, int64_t* n_selected);
+  // The same for a record resident in HBM, results staying in HBM: the compacted record as a new resident batch / the
+  // selection vector in a DEVICE buffer of `capacity` ≥ rows entries.
+  std::unique_ptr<DeviceBatch> filter_batch(const DeviceBatch& in, int64_t* n_selected);
+  int64_t select_batch(const DeviceBatch& in, uint32_t* d_indices, int64_t capacity);
   const char* draw();                                                  // ≙ Draw
   int64_t num_groups();
   void partial_keys(ArrowArray* out, ArrowSchema* out_schema);
@@ -249,6 +256,8 @@ class Plan {
   // Appends the nodes of `p` to R->args.expr (columns resolved against `b`, types checked); returns the root's index.
   int resolve_projection(const Projection& p, const DeviceBatch& b, Resolved* R);
   void resolve_batch(const DeviceBatch& b, Resolved* R, std::vector<int>* batch_gcols);
+  void resolve_filter_only(const DeviceBatch& b, Resolved* R);  // predicate program + LUTs (staged), nothing else
+  int64_t run_flags(const FdbScanArgs& a, uint8_t** d_masks, uint32_t** d_offsets);  // selection bitmap + tile offsets; returns the number selected
   void ensure_layout(const std::vector<uint32_t>& new_caps);
   void sync();
   void collect_timing();

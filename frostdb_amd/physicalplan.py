@@ -110,6 +110,9 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_allreduce.argtypes = [vp, vp, P(i32)]
     L.fdb_plan_exchange.argtypes = [vp, vp, P(vp)]
     L.fdb_live_allocations.argtypes = [P(i64), P(i64), P(i64)]
+    L.fdb_plan_filter_batch.argtypes = [vp, vp, P(vp), P(i64)]
+    L.fdb_plan_select_batch.argtypes = [vp, vp, vp, i64, P(i64)]
+    L.fdb_batch_export.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -164,7 +167,10 @@ def _raise(code: int, msg: str):
 class ResidentBatch:
     """An Arrow record kept in HBM between queries (``fdb_batch``)."""
 
-    def __init__(self, batch: pa.RecordBatch, device: int = 0):
+    def __init__(self, batch: Optional[pa.RecordBatch], device: int = 0, _handle=None):
+        if _handle is not None:  # a batch the library made itself (fdb_plan_filter_batch)
+            self.handle, self.device = _handle, device
+            return
         out = ctypes.c_void_p()
         with ExportedBatch(batch) as ex:
             rc = lib().fdb_batch_import(ctypes.addressof(ex.array), ctypes.addressof(ex.schema), device, ctypes.byref(out))
@@ -172,6 +178,14 @@ class ResidentBatch:
             _raise(rc, lib().fdb_last_error().decode())
         self.handle = out.value
         self.device = device
+
+    def to_arrow(self) -> pa.RecordBatch:
+        """The resident record copied back to the host as Arrow (fdb_batch_export)."""
+        arr, sch = ArrowArray(), ArrowSchema()
+        rc = lib().fdb_batch_export(self.handle, ctypes.addressof(arr), ctypes.addressof(sch))
+        if rc != 0:
+            _raise(rc, lib().fdb_last_error().decode())
+        return import_batch(arr, sch)
 
     @property
     def num_rows(self) -> int:
@@ -295,6 +309,18 @@ class HashAggregatePlan:
         if n.value == 0:
             return None
         return import_batch(arr, sch)
+
+    def FilterResident(self, record: "ResidentBatch") -> "ResidentBatch":
+        """≙ filter() on a record resident in HBM: the compacted record, resident too (zero rows when nothing qualifies)."""
+        out, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._check(lib().fdb_plan_filter_batch(self.handle, record.handle, ctypes.byref(out), ctypes.byref(n)))
+        return ResidentBatch(None, device=self.device, _handle=out.value)
+
+    def SelectResident(self, record: "ResidentBatch", dev_ptr: int, capacity: int) -> int:
+        """Selection vector of a resident record into a DEVICE buffer (uint32 × capacity ≥ rows); returns the number selected."""
+        n = ctypes.c_int64()
+        self._check(lib().fdb_plan_select_batch(self.handle, record.handle, ctypes.c_void_p(dev_ptr), capacity, ctypes.byref(n)))
+        return n.value
 
     def num_groups(self) -> int:
         n = ctypes.c_int64()

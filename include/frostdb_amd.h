@@ -239,6 +239,14 @@ int fdb_plan_filter(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema
  * caller's host buffer `indices` (capacity ≥ batch length). */
 int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema,
                     uint32_t* indices, int64_t capacity, int64_t* n_selected);
+/* The same two for a record that is resident in HBM, with results that STAY in HBM (a PredicateFilter whose consumer is another
+ * device stage; also what the compaction is measured with — inputs and outputs resident): *out is a new resident
+ * batch holding the compacted record (same columns, types and dictionaries; release it with fdb_batch_release; zero rows when
+ * nothing qualifies); `dev_indices` is a DEVICE buffer of `capacity` ≥ fdb_batch_num_rows entries. Three launches: selection
+ * bitmap + per-tile counts, their prefix sums, and ONE streaming pass that compacts every column (wave prefix sums, LDS staging,
+ * coalesced stores) — rows keep their order, the output is allocated at its exact size. */
+int fdb_plan_filter_batch(fdb_plan* plan, const fdb_batch* batch, fdb_batch** out, int64_t* n_selected);
+int fdb_plan_select_batch(fdb_plan* plan, const fdb_batch* batch, uint32_t* dev_indices, int64_t capacity, int64_t* n_selected);
 /* ≙ PhysicalPlan.Draw: "PredicateFilter (…) - HashAggregate (sum(value) by labels.path)". Owned by the plan. */
 const char* fdb_plan_draw(fdb_plan* plan);
 /* The same string for a descriptor, without creating a plan or touching a device (≙ `explain`: the operator strings of
@@ -348,6 +356,8 @@ int64_t fdb_batch_num_rows(const fdb_batch* batch);
 /* Bytes this batch occupies in HBM (values/indices + validity bitmaps; dictionaries stay on the host). */
 int64_t fdb_batch_device_bytes(const fdb_batch* batch);
 void fdb_batch_release(fdb_batch* batch);
+/* The record of a resident batch as Arrow in host memory (the caller owns `out` / `out_schema` and calls their release()). */
+int fdb_batch_export(const fdb_batch* batch, struct ArrowArray* out, struct ArrowSchema* out_schema);
 
 /* ---- measurement hooks (bench.py / rocprof correlation; not needed by the Go shim) -------------- */
 /* Algorithmic bytes (values-or-indices + validity of every referenced column, once per

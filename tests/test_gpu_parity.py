@@ -1816,3 +1816,76 @@ def test_records_carrying_prehashed_columns_give_the_same_result(pp, variant):
         assert not any(k.startswith("hashed.") for k in got_h)
         assert_same_result(got_h, got, cols, float_cols={"sum(value)"})
         assert_same_result(got_h, run_oracle(hashed, **q), cols, float_cols={"sum(value)"})
+
+
+# ---- filter() on resident records: one-pass compaction (fdb_plan_filter_batch / fdb_plan_select_batch) -----------------------
+
+def _oracle_filter(rec, filt):
+    from oracle import OraclePlan
+    o = OraclePlan(filt)
+    out, idx = o.filter(rec)
+    d = out.to_pydict() if out is not None else None
+    if out is not None:
+        out.close()
+    o.close()
+    return d, idx
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 1023, 1024, 1025, 4097, 65_537, 1_000_003])
+def test_resident_filter_compaction_matches_the_oracle(pp, n):
+    """The compacted record of fdb_plan_filter_batch (every column type the path stages: dictionary, nullable dictionary, int64,
+    float64 with NULLs, bool, plain string) against the oracle's filter() — values, NULLs and row ORDER — across tile edges."""
+    rng = np.random.default_rng(n + 3)
+    rec = make_prometheus_batch(rng, n, n_path=300, null_frac=0.03) if n else make_prometheus_batch(rng, 1, n_path=3).slice(0, 0)
+    fv = pa.array(rng.uniform(0, 1, n), mask=(rng.random(n) < 0.1) if n else None)
+    rec = rec.append_column("fnull", fv).append_column("flag", pa.array(rng.random(n) < 0.5)).append_column(
+        "plain", pa.array([b"s%d" % (i % 7) if i % 11 else None for i in range(n)], type=pa.binary()))
+    filt = And(Or(Col("labels.code") == "200", Col("labels.code") == "404"), Col("value") > 250.0)
+    plan = pp.HashAggregatePlan(filt)
+    rb = pp.ResidentBatch(rec)
+    try:
+        out = plan.FilterResident(rb)
+        got = out.to_arrow()
+        want, idx = _oracle_filter(rec, filt)
+        assert got.num_rows == out.num_rows == len(idx)
+        assert got.schema.names == rec.schema.names
+        if len(idx):
+            g = arrow_to_pydict(got)
+            for name in rec.schema.names:
+                assert g[name] == want[name], name
+            assert got.schema.field("labels.path").type == rec.schema.field("labels.path").type
+            assert got.schema.field("plain").type == pa.binary() and got.schema.field("flag").type == pa.bool_()
+        out.close()
+    finally:
+        plan.Close()
+        rb.close()
+
+
+def test_resident_selection_vector_and_capacity_retry(pp):
+    """fdb_plan_select_batch writes the ascending selection vector into a device buffer; a 12 M-row record with a predicate that
+    only matches in its second half defeats the strided sample less than it defeats a prefix sample — either way the result must
+    be exact (the pass is repeated with the exact size when the estimate was short)."""
+    import torch
+    n = 12_000_000
+    rng = np.random.default_rng(2)
+    ts = np.arange(n, dtype=np.int64)
+    code = pa.DictionaryArray.from_arrays(pa.array((rng.random(n) < 0.5).astype(np.uint32)), pa.array([b"200", b"500"], type=pa.binary()))
+    rec = pa.RecordBatch.from_arrays([code, pa.array(ts), pa.array(rng.uniform(0, 1, n))], names=["labels.code", "timestamp", "value"])
+    filt = And(Col("labels.code") == "200", Col("timestamp") >= n // 2 + 12345)
+    plan = pp.HashAggregatePlan(filt)
+    rb = pp.ResidentBatch(rec)
+    try:
+        want = np.flatnonzero((code.indices.to_numpy() == 0) & (ts >= n // 2 + 12345)).astype(np.uint32)
+        buf = torch.empty(n, dtype=torch.int32, device="cuda:0")
+        k = plan.SelectResident(rb, buf.data_ptr(), n)
+        assert k == len(want)
+        assert np.array_equal(buf[:k].cpu().numpy().view(np.uint32), want)
+        out = plan.FilterResident(rb)
+        got = out.to_arrow()
+        assert got.num_rows == len(want)
+        assert np.array_equal(got.column("timestamp").to_numpy(), ts[want])
+        assert np.array_equal(got.column("value").to_numpy(), rec.column("value").to_numpy()[want])
+        out.close()
+    finally:
+        plan.Close()
+        rb.close()
