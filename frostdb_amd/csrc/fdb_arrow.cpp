@@ -66,7 +66,33 @@ struct InternTable {
   }
 };
 
+InternTable& dict_table() { static InternTable t; return t; }  // real dictionaries (read_dictionary, make_dictionary)
+
 }  // namespace
+
+// A dictionary from values that did not arrive as an Arrow array (a Parquet dictionary page): same content hash, same interning
+// as read_dictionary, so a part decoded from Parquet and one imported from Arrow share their HostDict when the values agree.
+std::shared_ptr<HostDict> make_dictionary(std::vector<std::string>&& values, const std::string& value_format) {
+  uint64_t h = 1469598103934665603ull;
+  for (const std::string& v : values) {
+    const uint64_t len = v.size();
+    for (int k = 0; k < 8; k++) { h ^= (len >> (8 * k)) & 0xFF; h *= 1099511628211ull; }
+    for (unsigned char ch : v) { h ^= ch; h *= 1099511628211ull; }
+  }
+  InternTable& table = dict_table();
+  for (const std::shared_ptr<HostDict>& other : table.candidates(h))
+    if (!other->plain && other->value_format == value_format && other->values == values) return other;
+  std::shared_ptr<HostDict> d(new HostDict());
+  d->value_format = value_format;
+  d->hash = h;
+  d->values = std::move(values);
+  std::unordered_set<std::string_view> seen;
+  seen.reserve(d->values.size() * 2);
+  for (const std::string& v : d->values)
+    if (!seen.insert(std::string_view(v)).second) d->unique = false;
+  table.insert(h, d);
+  return d;
+}
 
 void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordView* out) {
   if (array == nullptr || schema == nullptr) throw Error(FDB_ERR_INVALID, "null record");
@@ -141,7 +167,7 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
   // for all of them turns every later "same dictionary?" test (key-id LUT cache, LUT de-duplication across the records of a
   // launch) into a pointer compare — and a record whose dictionary is already known costs one pass over its bytes here,
   // no string allocations.
-  static InternTable table;
+  InternTable& table = dict_table();
   for (const std::shared_ptr<HostDict>& other : table.candidates(h)) {
     bool same = !other->plain && other->value_format == value_format && (int64_t)other->values.size() == n;
     for (int64_t i = 0; i < n && same; i++) {

@@ -52,6 +52,7 @@ struct HostRecordView {
 // Throws fdb::Error(FDB_ERR_INVALID) on a malformed record.
 void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordView* out);
 std::shared_ptr<HostDict> read_dictionary(const HostColView& col);
+std::shared_ptr<HostDict> make_dictionary(std::vector<std::string>&& values, const std::string& value_format);  // same interning, values from elsewhere
 // A plain string / binary column (formats u, z, U, Z) never reaches the device as bytes: its distinct values become a HostDict
 // (first-seen order, `plain` set) and `idx` gets one uint32 per row (0 for NULL rows) — from there on the column travels like
 // a dictionary column, and the filter / group-key code asks `dict->plain` where the reference treats the two differently.

@@ -334,6 +334,16 @@ int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int d
   });
 }
 
+int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device, fdb_batch** out) {
+  return guard(nullptr, [&] {
+    if (out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null output");
+    *out = nullptr;
+    std::unique_ptr<fdb_batch> b(new fdb_batch());
+    b->b = fdb::batch_from_parquet(chunks, n_chunks, n_rows, device);
+    *out = b.release();
+  });
+}
+
 int64_t fdb_batch_num_rows(const fdb_batch* batch) { return batch ? batch->b->rows : 0; }
 int64_t fdb_batch_device_bytes(const fdb_batch* batch) { return batch ? (int64_t)batch->b->arena_bytes : 0; }
 void fdb_batch_release(fdb_batch* batch) { delete batch; }

@@ -376,6 +376,27 @@ hipError_t fdb_launch_tile_offsets(uint32_t* tile_counts, int64_t n_tiles, unsig
 hipError_t fdb_launch_compact_col(int width, const void* src, const uint8_t* src_valid, void* dst, uint8_t* dst_valid, const uint8_t* masks,
                                   const uint32_t* tile_offsets, int64_t n_rows, unsigned long long* null_count, int device, hipStream_t stream);
 int fdb_scan_default_grid(int device);
+// ---- Parquet pages → columns in HBM (≙ pqarrow/arrow.go:711-823 writeColumnToArray + parquet-go's page decoders) ----
+// The host parses page headers and run headers only (fdb_parquet.cpp); every per-row step runs here, gather-style: a thread owns
+// output rows, finds the run that holds its level / value by binary search in the run tables and extracts it from the chunk's bytes.
+// A run of the RLE / bit-packed hybrid encoding (definition levels, dictionary indices), in chunk-global numbering.
+struct FdbPqRun {
+  int64_t start;        // first row (definition-level runs) / first value rank (index runs) the run covers
+  uint64_t payload;     // RLE: the repeated value; bit-packed: BIT offset of the run's first value in the chunk
+  uint32_t bit_width;   // bits per bit-packed value (0 for RLE)
+  uint32_t kind;        // 0 RLE, 1 bit-packed
+};
+// A data page with PLAIN fixed-width values: value ranks [rank_start, next page's rank_start) live at byte_off + 8·(rank − rank_start).
+struct FdbPqPlainPage { int64_t rank_start; int64_t byte_off; };
+// validity[w] = the 32 definition levels (max level 1) of rows 32w … 32w+31, counts[w] = popcount; rows ≥ n_rows are 0.
+hipError_t fdb_launch_pq_validity(const uint8_t* chunk, const FdbPqRun* def_runs, int32_t n_runs, int64_t n_rows, uint32_t* validity, uint32_t* counts,
+                                  hipStream_t stream);
+// out[r] = the value of row r (0 for NULL rows). rank(r) = prefix[r / 32] + popcount(validity word below r) (prefix = exclusive
+// scan of the counts); validity == nullptr: required column, rank(r) = r. kind 0: PLAIN 8-byte values (pages[]); kind 1: dictionary
+// indices through idx_runs[] (uint32 out).
+hipError_t fdb_launch_pq_decode(int kind, const uint8_t* chunk, const uint32_t* validity, const uint32_t* prefix, const FdbPqPlainPage* pages, int32_t n_pages,
+                                const FdbPqRun* idx_runs, int32_t n_idx_runs, int64_t n_rows, void* out, hipStream_t stream);
+
 // *flag |= 1 if a row i < n has idx[i] >= limit while its validity bit (validity == nullptr: every row) is set.
 hipError_t fdb_launch_validate_indices(const uint32_t* idx, const uint8_t* validity, int64_t n, uint32_t limit, uint32_t* flag, hipStream_t stream);
 // Local (in-process) communicator: dst[i] = reduce over r < n_srcs, in rank order, of srcs[r][i] for lo ≤ i < hi (8-byte elements;

@@ -1145,6 +1145,84 @@ __global__ void merge_u64_kernel(unsigned long long* dst, const unsigned long lo
   }
 }
 
+// ---- Parquet pages → columns (see fdb_kernels.h) -----------------------------------------------------------------------------
+// 64 bits starting at an arbitrary byte of a buffer whose base is 8-byte aligned and padded by ≥ 16 readable bytes
+__device__ __forceinline__ unsigned long long pq_load64(const uint8_t* __restrict__ base, uint64_t byte_off) {
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(base) + (byte_off >> 3);
+  const uint32_t sh = (uint32_t)(byte_off & 7u) * 8u;
+  const unsigned long long lo = w[0];
+  if (sh == 0u) return lo;
+  return (lo >> sh) | (w[1] << (64u - sh));
+}
+// index of the last run whose start is ≤ x (runs sorted by start, runs[0].start ≤ x)
+__device__ __forceinline__ int pq_find_run(const FdbPqRun* __restrict__ runs, int n, int64_t x) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (runs[mid].start <= x) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t pq_run_value(const uint8_t* __restrict__ chunk, const FdbPqRun& R, int64_t x) {
+  if (R.kind == 0u) return (uint32_t)R.payload;
+  const uint64_t bit = R.payload + (uint64_t)(x - R.start) * R.bit_width;
+  const unsigned long long wnd = pq_load64(chunk, bit >> 3) >> (bit & 7u);
+  return (uint32_t)(wnd & ((R.bit_width >= 32u) ? 0xFFFFFFFFull : ((1ull << R.bit_width) - 1ull)));
+}
+
+__global__ void pq_validity_kernel(const uint8_t* __restrict__ chunk, const FdbPqRun* __restrict__ runs, int n_runs, int64_t n_rows,
+                                   uint32_t* __restrict__ validity, uint32_t* __restrict__ counts) {
+  const int64_t n_words = (n_rows + 31) / 32;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r0 = w * 32;
+    int ri = pq_find_run(runs, n_runs, r0);
+    uint32_t bits = 0;
+    for (int b = 0; b < 32 && r0 + b < n_rows; b++) {
+      const int64_t r = r0 + b;
+      while (ri + 1 < n_runs && runs[ri + 1].start <= r) ri++;
+      const FdbPqRun R = runs[ri];
+      if (R.kind == 0u) {  // a repeated level: fill up to the end of the run (or of the word) at once
+        const int64_t end = ri + 1 < n_runs ? runs[ri + 1].start : n_rows;
+        const int take = (int)((end < r0 + 32 ? end : r0 + 32) - r);
+        if (R.payload & 1ull) bits |= (take >= 32 ? 0xFFFFFFFFu : ((1u << take) - 1u)) << b;
+        b += take - 1;
+      } else {
+        bits |= (pq_run_value(chunk, R, r) & 1u) << b;
+      }
+    }
+    validity[w] = bits;
+    counts[w] = (uint32_t)__popc(bits);
+  }
+}
+
+template <int KIND>
+__global__ void pq_decode_kernel(const uint8_t* __restrict__ chunk, const uint32_t* __restrict__ validity, const uint32_t* __restrict__ prefix,
+                                 const FdbPqPlainPage* __restrict__ pages, int n_pages, const FdbPqRun* __restrict__ idx_runs, int n_idx_runs,
+                                 int64_t n_rows, void* __restrict__ out) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+    bool valid = true;
+    int64_t rank = r;
+    if (validity != nullptr) {
+      const uint32_t word = validity[r >> 5], b = (uint32_t)(r & 31);
+      valid = (word >> b) & 1u;
+      rank = (int64_t)prefix[r >> 5] + (int64_t)__popc(word & ((1u << b) - 1u));
+    }
+    if (KIND == 0) {
+      unsigned long long v = 0;
+      if (valid) {
+        int lo = 0, hi = n_pages - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pages[mid].rank_start <= rank) lo = mid; else hi = mid - 1; }
+        v = pq_load64(chunk, (uint64_t)pages[lo].byte_off + (uint64_t)(rank - pages[lo].rank_start) * 8u);
+      }
+      reinterpret_cast<unsigned long long*>(out)[r] = v;
+    } else {
+      uint32_t v = 0;
+      if (valid) { const int ri = pq_find_run(idx_runs, n_idx_runs, rank); v = pq_run_value(chunk, idx_runs[ri], rank); }
+      reinterpret_cast<uint32_t*>(out)[r] = v;
+    }
+  }
+}
+
 // ---- import validation: every dictionary index of a VALID row must be below the dictionary's length ----------------------------
 // (Arrow forbids anything else; the scan kernels index LUTs with these values, so a malformed record must become an error code
 // at import — ≙ the reference's recovered panic, recovery/recovery.go:13-30 — not an out-of-bounds read on the device.)
@@ -1479,6 +1557,26 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(merge_u64_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, map, n, func, is_f64);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_pq_validity(const uint8_t* chunk, const FdbPqRun* def_runs, int32_t n_runs, int64_t n_rows, uint32_t* validity, uint32_t* counts,
+                                  hipStream_t stream) {
+  const int64_t n_words = (n_rows + 31) / 32;
+  if (n_words == 0) return hipSuccess;
+  int64_t blocks = (n_words + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pq_validity_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, chunk, def_runs, n_runs, n_rows, validity, counts);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_pq_decode(int kind, const uint8_t* chunk, const uint32_t* validity, const uint32_t* prefix, const FdbPqPlainPage* pages, int32_t n_pages,
+                                const FdbPqRun* idx_runs, int32_t n_idx_runs, int64_t n_rows, void* out, hipStream_t stream) {
+  if (n_rows == 0) return hipSuccess;
+  int64_t blocks = (n_rows + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (kind == 0) hipLaunchKernelGGL(pq_decode_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, chunk, validity, prefix, pages, n_pages, idx_runs, n_idx_runs, n_rows, out);
+  else hipLaunchKernelGGL(pq_decode_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, chunk, validity, prefix, pages, n_pages, idx_runs, n_idx_runs, n_rows, out);
   return hipGetLastError();
 }
 

@@ -58,6 +58,8 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
                                           const std::function<bool(const std::string&)>* want, hipStream_t stream, class Context* ctx = nullptr,
                                           bool via_ring = false);
 
+// Parquet column chunks of one row group → a resident batch (fdb_parquet.cpp).
+std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device);
 // The record of a resident batch as Arrow in host memory.
 void export_batch(const DeviceBatch& b, ArrowArray* out, ArrowSchema* out_schema);
 

@@ -113,6 +113,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_filter_batch.argtypes = [vp, vp, P(vp), P(i64)]
     L.fdb_plan_select_batch.argtypes = [vp, vp, vp, i64, P(i64)]
     L.fdb_batch_export.argtypes = [vp, vp, vp]
+    L.fdb_batch_from_parquet.argtypes = [vp, i32, i64, ctypes.c_int, P(vp)]
     _lib = L
     return L
 
@@ -164,8 +165,40 @@ def _raise(code: int, msg: str):
     raise (UnsupportedError if code == FDB_ERR_UNSUPPORTED else FdbError)(code, msg)
 
 
+class ParquetChunk(ctypes.Structure):
+    """fdb_parquet_chunk: one column chunk of a row group, bytes as they sit in the file."""
+    _fields_ = [("name", ctypes.c_char_p), ("physical_type", ctypes.c_int32), ("optional", ctypes.c_int32), ("utf8", ctypes.c_int32),
+                ("_pad", ctypes.c_int32), ("data", ctypes.c_void_p), ("n_bytes", ctypes.c_int64)]
+
+
+PARQUET_INT64, PARQUET_DOUBLE, PARQUET_BYTE_ARRAY = 2, 5, 6
+
+
 class ResidentBatch:
     """An Arrow record kept in HBM between queries (``fdb_batch``)."""
+
+    @classmethod
+    def from_parquet(cls, chunks: Sequence[tuple], n_rows: int, device: int = 0) -> "ResidentBatch":
+        """`chunks`: (name, physical type, optional, utf8, bytes-like) per column of ONE row group — decoded on the device
+        (fdb_batch_from_parquet). The byte buffers only need to stay alive for the duration of the call."""
+        arr = (ParquetChunk * len(chunks))()
+        keep = []
+        for i, (name, ptype, optional, utf8, data) in enumerate(chunks):
+            if isinstance(data, tuple):      # (address, length): bytes that already sit somewhere stable, e.g. a pinned file buffer
+                addr, size = data
+            elif isinstance(data, bytes):    # no copy: the bytes object is kept alive for the call
+                addr, size = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value, len(data)
+            else:
+                data = bytes(data)
+                addr, size = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value, len(data)
+            nm = name.encode()
+            keep += [data, nm]
+            arr[i] = ParquetChunk(nm, ptype, 1 if optional else 0, 1 if utf8 else 0, 0, addr, size)
+        out = ctypes.c_void_p()
+        rc = lib().fdb_batch_from_parquet(arr, len(chunks), n_rows, device, ctypes.byref(out))
+        if rc != 0:
+            _raise(rc, lib().fdb_last_error().decode())
+        return cls(None, device=device, _handle=out.value)
 
     def __init__(self, batch: Optional[pa.RecordBatch], device: int = 0, _handle=None):
         if _handle is not None:  # a batch the library made itself (fdb_plan_filter_batch)

@@ -359,6 +359,27 @@ void fdb_batch_release(fdb_batch* batch);
 /* The record of a resident batch as Arrow in host memory (the caller owns `out` / `out_schema` and calls their release()). */
 int fdb_batch_export(const fdb_batch* batch, struct ArrowArray* out, struct ArrowSchema* out_schema);
 
+/* ---- Parquet column chunks decoded on the device ------------------------------------------------------------
+ * ≙ pqarrow/arrow.go:711-823 (writeColumnToArray) + pqarrow/writer/writer.go:391-405: instead of decoding a row group into an
+ * arrow.Record on the CPU (one dictionary-builder probe per row) and pushing that, the host hands over the column chunks'
+ * BYTES as they sit in the file and gets a resident batch with the layout fdb_batch_import produces — usable with
+ * fdb_plan_push_batch(es), fdb_plan_filter_batch, fdb_batch_export. The host side of this call reads page headers, the dictionary
+ * page and the headers of RLE / bit-packed runs; definition levels → validity bitmaps, value ranks and the per-row dictionary
+ * indices / values are computed in HBM. First slice: flat schemas; INT64 / DOUBLE with PLAIN data pages; BYTE_ARRAY with a
+ * dictionary page + RLE_DICTIONARY data pages (→ dictionary<uint32, binary>, pqarrow/convert/convert.go:64-70; utf8 = 1 →
+ * dictionary<uint32, utf8>); required or optional; data pages V1 / V2; codec UNCOMPRESSED. Everything else: FDB_ERR_UNSUPPORTED
+ * (the caller falls back to its Arrow path for that row group). */
+typedef struct fdb_parquet_chunk {
+  const char* name;        /* field name of the column in the record */
+  int32_t physical_type;   /* parquet Type: 2 INT64, 5 DOUBLE, 6 BYTE_ARRAY */
+  int32_t optional;        /* max definition level: 0 required, 1 optional */
+  int32_t utf8;            /* BYTE_ARRAY: logical type String */
+  int32_t _pad;
+  const uint8_t* data;     /* [dictionary page] data pages …, each preceded by its thrift PageHeader, exactly as in the file */
+  int64_t n_bytes;         /* ColumnMetaData.total_compressed_size */
+} fdb_parquet_chunk;
+int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device, fdb_batch** out);
+
 /* ---- measurement hooks (bench.py / rocprof correlation; not needed by the Go shim) -------------- */
 /* Algorithmic bytes (values-or-indices + validity of every referenced column, once per
  * row) and accumulated device time in ms (hipEvent pairs on the plan's stream around each scan

@@ -235,3 +235,35 @@ def test_local_communicator_endpoints_and_allocation_counters_without_a_gpu():
     assert pp.live_allocations() == {"device_blocks": 0, "device_bytes": 0, "pinned_blocks": 0}
     with pytest.raises(ValueError):
         fcomm.Comm(b"short", 2, 0, 0)
+
+
+def test_parquet_chunks_are_parsed_and_refused_on_the_host():
+    """fdb_batch_from_parquet reads page headers / run headers on the host BEFORE it touches a device: chunks outside the first
+    slice (compressed pages, DELTA encodings, truncated bytes) come back as FDB_ERR_UNSUPPORTED / FDB_ERR_INVALID here, without
+    a GPU; a well-formed chunk gets as far as the device call (FDB_ERR_DEVICE on this box)."""
+    import numpy as np
+    import pyarrow as pa
+    from frostdb_amd import physicalplan as pp
+    from tests.parquet_util import row_group_chunks, write_parquet
+    n = 5000
+    rng = np.random.default_rng(0)
+    t = pa.table({"labels.a": pa.array([None if i % 9 == 0 else b"v%d" % (i % 13) for i in range(n)], type=pa.binary()),
+                  "ts": pa.array(np.arange(n, dtype=np.int64)), "value": pa.array(rng.random(n), mask=rng.random(n) < 0.1)})
+    good, rows = row_group_chunks(write_parquet(t), 0)
+    assert rows == n and [c[1] for c in good] == [6, 2, 5]
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet(good, rows)
+    assert e.value.code == pp.FDB_ERR_DEVICE  # parsed fine, then no GPU
+    for kw, code in ((dict(compression="SNAPPY"), pp.FDB_ERR_UNSUPPORTED),
+                     (dict(use_dictionary=False, column_encoding={"ts": "DELTA_BINARY_PACKED", "labels.a": "PLAIN", "value": "PLAIN"}), pp.FDB_ERR_UNSUPPORTED)):
+        bad, rows = row_group_chunks(write_parquet(t, **kw), 0)
+        with pytest.raises(pp.FdbError) as e:
+            pp.ResidentBatch.from_parquet(bad, rows)
+        assert e.value.code == code, kw
+    cut = [(nm, ty, opt, u8, data[: len(data) // 2]) for nm, ty, opt, u8, data in good]
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet(cut, rows)
+    assert e.value.code == pp.FDB_ERR_INVALID
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet(good, rows + 1)
+    assert e.value.code == pp.FDB_ERR_INVALID

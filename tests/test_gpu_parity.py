@@ -1889,3 +1889,51 @@ def test_resident_selection_vector_and_capacity_retry(pp):
     finally:
         plan.Close()
         rb.close()
+
+
+def test_float_sums_with_heavy_cancellation_state_the_contract(pp, variant):
+    """float64 SUM over values of mixed sign and magnitude (±1e12 next to O(1)): the reference adds in row order within a chain
+    (possibly in SIMD lanes) and in arrival order across chains — its own result is order-dependent, and so is
+    any parallel reduction's (LDS / global atomics here, rank order in the cross-GPU merge). What CAN be promised, and what
+    north_star's "1e-9 relative" means once terms cancel, is an error bound relative to the magnitudes that were added:
+    |got − exact| ≤ 1e-9 · Σ|x| per group (every summation order is within n·ε·Σ|x| ≈ 1e-11 · Σ|x| at this size). exact = math.fsum."""
+    rng = np.random.default_rng(4242)
+    n = 200_000
+    big = rng.choice([-1.0, 1.0], n) * 1e12 * rng.random(n)
+    val = np.where(rng.random(n) < 0.5, big, rng.normal(0, 1, n))
+    # make every group's big terms cancel almost exactly: pair each big value with its negation elsewhere in the group
+    val[1::2] = -val[0::2]
+    val += rng.normal(0, 1e-3, n)
+    path = rng.integers(0, 50, n).astype(np.uint32)
+    path[1::2] = path[0::2]
+    rec = pa.RecordBatch.from_arrays(
+        [pa.DictionaryArray.from_arrays(pa.array(path), pa.array([b"p%02d" % i for i in range(50)], type=pa.binary())), pa.array(val)],
+        names=["labels.path", "value"])
+    got = run_gpu(pp, [rec.slice(0, 120_001), rec.slice(120_001)], None, [Sum(Col("value")), Count(Col("value"))], [Col("labels.path")], resident=True)
+    by_path = dict(zip(got["labels.path"], got["sum(value)"]))
+    for g in range(50):
+        x = val[path == g]
+        exact, mag = math.fsum(x), float(np.abs(x).sum())
+        assert abs(by_path[b"p%02d" % g] - exact) <= 1e-9 * mag, (g, by_path[b"p%02d" % g], exact, mag)
+        assert abs(exact) < 1e-6 * mag  # (the test really is cancellation-heavy)
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_oracle_sees_ten_million_rows_of_the_benchmark_workloads(pp, cfg):
+    """BASELINE.json configs 2 and 3 at 10 M rows (bench.py's generator, 4 resident records in one launch) against the ORACLE —
+    the restatement that carries the reference's quirks — not just against numpy."""
+    from frostdb_amd import synth
+    q = CFG2 if cfg == "cfg2" else CFG3
+    recs = [synth.prometheus_chunk(1, i, 2_500_000, row_base=i * 2_500_000, cfg3=(cfg == "cfg3")) for i in range(4)]
+    keep = [pp.ResidentBatch(r) for r in recs]
+    plan = pp.HashAggregatePlan(q["filter_expr"], q["aggs"], q["groups"])
+    try:
+        plan.CallbackResident(keep)
+        assert plan.last_kernel() == "fdb_plan_kernel"
+        got = arrow_to_pydict(plan.Finish())
+    finally:
+        plan.Close()
+        for k in keep:
+            k.close()
+    want = run_oracle(recs, **q, nchains=4)
+    assert_same_result(got, want, ["labels.path"] + [a.Name() for a in q["aggs"]], float_cols={"sum(value)"})
