@@ -157,6 +157,8 @@ int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s) 
 int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out) {
   return guard(nullptr, [&] {
     if (out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null out pointer");
+    if (desc != nullptr && desc->ordered != 0 && fdb::DynamicAggs::wanted(desc))
+      throw fdb::Error(FDB_ERR_UNSUPPORTED, "OrderedAggregate over a dynamic column set is not supported");
     *out = new fdb_plan(desc, device);
   });
 }

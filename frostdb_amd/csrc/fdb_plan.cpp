@@ -308,6 +308,9 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
     walk(filter_root_, 0);
   }
   final_stage_ = d->final_stage != 0;
+  ordered_ = d->ordered != 0;
+  if (ordered_ && d->n_aggs != 1)  // the operator takes ONE Aggregation (NewOrderedAggregate, ordered_aggregate.go:116-122; shouldPlanOrderedAggregate, physicalplan.go:525-528)
+    throw Error(FDB_ERR_UNSUPPORTED, "OrderedAggregate: exactly one aggregation is supported");
   for (int32_t i = 0; i < d->n_aggs; i++) {
     AggState a;
     a.func = d->aggs[i].func;
@@ -316,6 +319,7 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
       throw Error(FDB_ERR_INVALID, std::string("internal: aggregation over the dynamic column set ") + d->aggs[i].column + ".* reached a single plan");
     a.column = d->aggs[i].column;
     a.result_name = std::string(agg_name(a.func)) + "(" + a.column + ")";
+    a.emit_name = (ordered_ && !final_stage_) ? a.column : a.result_name;  // OrderedAggregate.getResultColumnName (ordered_aggregate.go:551-557)
     if (a.func == FDB_AGG_UNIQUE) {  // two physical accumulators, see AggState::role
       AggState lo = a, hi = a;
       lo.func = FDB_AGG_MIN; lo.role = 1; lo.null_value = (unsigned long long)FDB_I64_MIN;
@@ -372,7 +376,7 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
 
 Plan::Plan(const Plan& proto, CloneTag)
     : projs_(proto.projs_), device_(proto.device_), filter_(proto.filter_), filter_root_(proto.filter_root_), aggs_(proto.aggs_),
-      matchers_(proto.matchers_), final_stage_(proto.final_stage_) {
+      matchers_(proto.matchers_), final_stage_(proto.final_stage_), ordered_(proto.ordered_) {
   for (AggState& a : aggs_) a.d_acc = nullptr;  // (value types are kept: a clone merges with its prototype)
   hip_check(hipSetDevice(device_), "hipSetDevice");
   ctx_ = Context::acquire(device_);
@@ -486,7 +490,12 @@ const char* Plan::draw() {
     };
     std::string s;
     if (filter_root_ >= 0) s += "PredicateFilter (" + show(filter_root_) + ")";
-    if (!aggs_.empty()) {
+    if (!aggs_.empty() && ordered_) {  // "OrderedAggregate (%s by %s)" with the aggregated COLUMN's name (ordered_aggregate.go:154-158)
+      if (!s.empty()) s += " - ";
+      s += "OrderedAggregate (" + aggs_[0].column + " by ";
+      for (size_t i = 0; i < matchers_.size(); i++) s += (i ? "," : "") + matchers_[i].name;
+      s += ")";
+    } else if (!aggs_.empty()) {
       if (!s.empty()) s += " - ";
       s += "HashAggregate (";
       for (size_t i = 0, shown = 0; i < aggs_.size(); i++) if (aggs_[i].role != 2) s += (shown++ ? "," : "") + aggs_[i].result_name;
@@ -1446,6 +1455,53 @@ void Plan::fetch_compact(CompactState* cs) {
   }
 }
 
+// OrderedAggregate emits its groups in key order: the merge of its ordered sets sorts by every group column in first-seen
+// order, ascending, NULLs last (ordered_aggregate.go:449-470; cursorHeap.Less, arrowutils/merge.go:84-112: SortingColumn's zero
+// value is ascending / NullsFirst = false; binary and string keys compare bytewise, int64 numerically). Dictionary keys are
+// compared through the RANK of their key id among the column's distinct values, computed once per column.
+void Plan::sort_compact(CompactState* cs) const {
+  const size_t n = (size_t)cs->n;
+  if (n < 2) return;
+  std::vector<std::vector<uint32_t>> rank(gcols_.size());
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    const GroupColState& g = gcols_[c];
+    if (g.kind != 0) continue;
+    std::vector<uint32_t> order(g.values.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g.values[a] < g.values[b]; });
+    rank[c].assign(g.values.size() + 1, 0xFFFFFFFFu);  // id 0 (NULL) sorts last
+    for (size_t r = 0; r < order.size(); r++) rank[c][order[r] + 1] = (uint32_t)r;
+  }
+  std::vector<size_t> perm(n);
+  for (size_t i = 0; i < n; i++) perm[i] = i;
+  std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) {
+    for (size_t c = 0; c < gcols_.size(); c++) {
+      const GroupColState& g = gcols_[c];
+      if (g.kind == 0) {
+        const uint32_t ra = cs->ids[c].empty() ? 0xFFFFFFFFu : rank[c][cs->ids[c][a]], rb = cs->ids[c].empty() ? 0xFFFFFFFFu : rank[c][cs->ids[c][b]];
+        if (ra != rb) return ra < rb;
+      } else {
+        const bool va = !cs->ivalid[c].empty() && cs->ivalid[c][a], vb = !cs->ivalid[c].empty() && cs->ivalid[c][b];
+        if (va != vb) return va;  // NULLs last
+        if (!va) continue;
+        const int64_t xa = cs->ivals[c][a], xb = cs->ivals[c][b];
+        if (xa != xb) return g.is_u64 ? (uint64_t)xa < (uint64_t)xb : xa < xb;
+      }
+    }
+    return false;
+  });
+  auto apply = [&](auto& v) {
+    if (v.empty()) return;
+    auto copy = v;
+    for (size_t i = 0; i < n; i++) v[i] = copy[perm[i]];
+  };
+  apply(cs->cnt);
+  for (auto& a : cs->acc) apply(a);
+  for (auto& a : cs->ids) apply(a);
+  for (auto& a : cs->ivals) apply(a);
+  for (auto& a : cs->ivalid) apply(a);
+}
+
 void Plan::build_key_columns(const CompactState& cs, std::vector<OutColumn>* cols) const {
   const int64_t n = cs.n;
   for (size_t gc = 0; gc < gcols_.size(); gc++) {
@@ -1500,7 +1556,7 @@ void Plan::build_agg_columns(const CompactState& cs, std::vector<OutColumn>* col
     const AggState& A = aggs_[j];
     if (A.role == 2) continue;  // the MAX half of UNIQUE: consumed with its MIN half
     OutColumn c;
-    c.name = A.result_name;
+    c.name = A.emit_name;
     c.length = n;
     if (A.role == 1) {  // UNIQUE: min == max ⇒ the value, else NULL (uniqueInt64arrays, aggregate.go:694-710)
       c.format = "l";
@@ -1546,7 +1602,7 @@ int64_t Plan::finish_columns(std::vector<OutColumn>* cols) {
   PhaseTimer pt;
   cols->clear();
   int64_t n = 0;
-  if (mode_ == TableMode::HASH && h_table_ != nullptr) {
+  if (mode_ == TableMode::HASH && h_table_ != nullptr && !ordered_) {
     // big result sets: columns are materialised on the device, the host only copies finished Arrow buffers
     n = finish_columns_hash(cols);
     pt.mark("finish: columns");
@@ -1554,6 +1610,7 @@ int64_t Plan::finish_columns(std::vector<OutColumn>* cols) {
     CompactState cs;
     fetch_compact(&cs);
     pt.mark("finish: fetch");
+    if (ordered_) sort_compact(&cs);
     build_key_columns(cs, cols);
     build_agg_columns(cs, cols);
     n = cs.n;

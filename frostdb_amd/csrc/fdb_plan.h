@@ -109,6 +109,7 @@ struct AggState {
   int32_t func = 0;
   std::string column;
   std::string result_name;        // "sum(value)" — AggregationFunction.Name() (logicalplan/expr.go:700-702)
+  std::string emit_name;          // the result column's name: result_name, except a partial-stage OrderedAggregate's (the column's own)
   int32_t type = FDB_T_NONE;      // FDB_T_I64 / FDB_T_F64 once a batch has shown the column; COUNT keeps NONE
   unsigned long long* d_acc = nullptr;
   // Composite reducers ride on MIN / MAX accumulators (aggs_ is the PHYSICAL list, one accumulator array each):
@@ -267,6 +268,7 @@ class Plan {
   void fetch_compact(CompactState* cs);
   void build_key_columns(const CompactState& cs, std::vector<OutColumn>* cols) const;
   void build_agg_columns(const CompactState& cs, std::vector<OutColumn>* cols) const;
+  void sort_compact(CompactState* cs) const;  // rows in ascending group-key order, NULLs last (OrderedAggregate's output order)
   // high-cardinality path (fdb_hash.cpp)
   void switch_to_hash();
   void hash_layout();                                   // (re)assign key-tuple words; widen the key store if columns were added
@@ -287,6 +289,7 @@ class Plan {
   std::vector<AggState> aggs_;
   std::vector<GroupMatcher> matchers_;
   bool final_stage_ = false;
+  bool ordered_ = false;            // OrderedAggregate: one aggregation, result sorted by the group columns
   bool finished_ = false;
 
   std::vector<GroupColState> gcols_;

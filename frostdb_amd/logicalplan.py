@@ -298,7 +298,8 @@ class CPlanDesc(ctypes.Structure):
     _fields_ = [("filter", ctypes.POINTER(CExpr)), ("n_filter", ctypes.c_int32), ("filter_root", ctypes.c_int32),
                 ("aggs", ctypes.POINTER(CAggregation)), ("n_aggs", ctypes.c_int32), ("n_groups", ctypes.c_int32),
                 ("groups", ctypes.POINTER(CGroupExpr)), ("final_stage", ctypes.c_int32), ("n_projections", ctypes.c_int32),
-                ("projections", ctypes.POINTER(CProjection)), ("regex_match", ctypes.c_void_p), ("regex_user", ctypes.c_void_p)]
+                ("projections", ctypes.POINTER(CProjection)), ("regex_match", ctypes.c_void_p), ("regex_user", ctypes.c_void_p),
+                ("ordered", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
 
 
 # fdb_regex_match_fn: int32 (*)(void* user, const char* pattern, int64 pattern_len, const uint8* value, int64 value_len)
@@ -328,7 +329,7 @@ class PlanDescHolder:
 
 
 def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], groups: Sequence[Column],
-            final_stage: bool = False, regex=None) -> PlanDescHolder:
+            final_stage: bool = False, regex=None, ordered: bool = False) -> PlanDescHolder:
     """`regex`: a `regex_matcher(...)` object — the host application's regular-expression engine (fdb_plan_desc.regex_match)."""
     keep: List[Any] = []
     nodes: List[CExpr] = []
@@ -399,6 +400,7 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
         d.groups = ctypes.cast(cg, ctypes.POINTER(CGroupExpr))
     d.n_groups = len(groups)
     d.final_stage = 1 if final_stage else 0
+    d.ordered = 1 if ordered else 0
     # computed columns: every aggregated expression / group expression that is arithmetic (or an alias of one) becomes a
     # projection named like the reference names it
     projs: List[CProjection] = []

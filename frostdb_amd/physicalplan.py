@@ -127,9 +127,10 @@ def read_ceiling(device: int = 0, nbytes: int = 1 << 31, reps: int = 5) -> float
     return out.value
 
 
-def explain(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (), groups: Sequence[Column] = (), final_stage: bool = False) -> str:
+def explain(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (), groups: Sequence[Column] = (), final_stage: bool = False,
+            ordered: bool = False) -> str:
     """≙ Draw() of the operators this descriptor builds (`PredicateFilter (…) - HashAggregate (… by …)`), no device needed."""
-    desc = to_desc(filter_expr, list(aggs), list(groups), final_stage)
+    desc = to_desc(filter_expr, list(aggs), list(groups), final_stage, ordered=ordered)
     buf = ctypes.create_string_buffer(4096)
     need = ctypes.c_int64()
     rc = lib().fdb_plan_explain(ctypes.addressof(desc.desc), buf, len(buf), ctypes.byref(need))
@@ -244,11 +245,11 @@ class HashAggregatePlan:
     """One fused ``PredicateFilter → HashAggregate`` chain on one GPU."""
 
     def __init__(self, filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (),
-                 groups: Sequence[Column] = (), device: int = 0, final_stage: bool = False, desc=None, regex=None):
+                 groups: Sequence[Column] = (), device: int = 0, final_stage: bool = False, desc=None, regex=None, ordered: bool = False):
         """`desc`: a descriptor built once with `to_desc(filter_expr, aggs, groups, final_stage)` and shared by every chain /
         execution of the same query (≙ the logical plan being built once and `physicalplan.Build` instantiating N chains).
         `regex`: the host application's regex engine (`logicalplan.regex_matcher`), else std::regex."""
-        self._desc = desc if desc is not None else to_desc(filter_expr, list(aggs), list(groups), final_stage, regex=regex)
+        self._desc = desc if desc is not None else to_desc(filter_expr, list(aggs), list(groups), final_stage, regex=regex, ordered=ordered)
         self.aggs = list(aggs)
         self._ctor = (filter_expr, list(aggs), list(groups), device, final_stage, self._desc)
         out = ctypes.c_void_p()

@@ -184,6 +184,15 @@ typedef struct fdb_plan_desc {
   const fdb_projection* projections;
   fdb_regex_match_fn regex_match;  /* NULL ⇒ std::regex */
   void* regex_user;                /* passed back as `user` */
+  int32_t ordered;                 /* 1 ⇒ the chain's aggregate is an OrderedAggregate (ordered_aggregate.go; planned by
+                                      physicalplan.go:433-449 when the scan is ordered by the group columns): exactly ONE aggregation;
+                                      the result record is emitted SORTED by the group columns (first-seen column order, bytewise /
+                                      numeric ascending, NULLs last — the order of the reference's merge of its ordered sets,
+                                      ordered_aggregate.go:449-470, arrowutils/merge.go:84-112); a partial-stage plan names its result
+                                      column after the aggregated COLUMN, a final-stage one after the aggregation (:551-557). The
+                                      groups and their values are those of the hash aggregate: the reference's ordered sets merge by
+                                      key. */
+  int32_t _pad2;
 } fdb_plan_desc;
 
 typedef struct fdb_plan fdb_plan;   /* one operator chain; push is single-threaded per handle (table.go:783-860) */
