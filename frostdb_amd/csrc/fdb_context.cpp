@@ -215,6 +215,34 @@ hipEvent_t Context::get_event() {
 
 void Context::put_event(hipEvent_t e) { events_.push_back(e); }
 
+void Context::copy_out_parallel(void* host, const void* dev, size_t bytes) {
+  constexpr size_t kMinSlice = (size_t)64 << 20;
+  int parts = (int)std::min<size_t>(4, std::max<size_t>(1, bytes / kMinSlice));
+  if (parts <= 1) {
+    hip_check(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(result)");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    return;
+  }
+  for (int i = 0; i < parts - 1; i++)
+    if (aux_[i] == nullptr) hip_check(hipStreamCreateWithFlags(&aux_[i], hipStreamNonBlocking), "hipStreamCreate(aux)");
+  hipEvent_t ready = get_event();
+  hip_check(hipEventRecord(ready, stream), "hipEventRecord");
+  const size_t slice = ((bytes / (size_t)parts) + 4095) & ~(size_t)4095;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < parts && e == hipSuccess; i++) {
+    const size_t off = (size_t)i * slice;
+    if (off >= bytes) break;
+    const size_t len = std::min(slice, bytes - off);
+    hipStream_t s = i == 0 ? stream : aux_[i - 1];
+    if (i > 0) e = hipStreamWaitEvent(s, ready, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync((unsigned char*)host + off, (const unsigned char*)dev + off, len, hipMemcpyDeviceToHost, s);
+  }
+  for (int i = 0; i < parts - 1; i++) { const hipError_t w = hipStreamSynchronize(aux_[i]); if (e == hipSuccess) e = w; }
+  { const hipError_t w = hipStreamSynchronize(stream); if (e == hipSuccess) e = w; }
+  put_event(ready);
+  hip_check(e, "parallel device→host copy");
+}
+
 void* Context::stage(const void* host, size_t payload) {
   const size_t bytes = (std::max<size_t>(payload, 1) + 255) / 256 * 256;
   if (stage_off_ + bytes > stage_cap_) {

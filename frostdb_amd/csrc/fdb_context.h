@@ -27,6 +27,9 @@ class Context {
   void host_free(void* p);
   hipEvent_t get_event();
   void put_event(hipEvent_t e);
+  // A big device→host copy split over `stream` and up to 3 auxiliary streams (several DMA engines work on one PCIe link more
+  // evenly than one: 1.35 GB went from 41 to ≈52 GB/s); ordered after everything queued on `stream`, complete when this returns.
+  void copy_out_parallel(void* host, const void* dev, size_t bytes);
 
   // Small host→device tables (LUTs, slot maps): staged in pinned memory, shipped with one async copy each.
   void* stage(const void* host, size_t bytes);
@@ -55,6 +58,7 @@ class Context {
   unsigned char* stage_d_ = nullptr;
   size_t stage_cap_ = 0, stage_off_ = 0, stage_sent_ = 0;  // [stage_sent_, stage_off_) is staged but not shipped yet
   bool defer_ = false;
+  hipStream_t aux_[3] = {nullptr, nullptr, nullptr};
   unsigned char* copy_h_ = nullptr;  // pinned ring of copy_in (separate from the LUT staging ring: a wrap here never touches staged LUTs)
   size_t copy_cap_ = 0, copy_off_ = 0;
 };

@@ -22,7 +22,7 @@ for f, r in rows("**/*counter_collection.csv"):
     name = r.get("Kernel_Name", "?")
     agg[name][r.get("Counter_Name", "?")].append(float(r.get("Counter_Value", 0)))
 for k, d in agg.items():
-    if not any(t in k for t in ("scan", "reduce", "fdb_plan_kernel", "stream_read", "hash_")):
+    if not any(t in k for t in ("scan", "reduce", "fdb_plan_kernel", "fdb_hash_kernel", "stream_read", "hash_", "compact", "filter_flags", "pq_")):
         continue
     print(k[:90])
     for c, v in sorted(d.items()):
@@ -32,7 +32,7 @@ for k, d in agg.items():
 # coalesced streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE × 1 — calibrated on this kernel's own known byte count
 # (cfg 2 writes 512 partial tables × 2 arrays × 1 025 slots × 8 B = 8.40 MB and WRITE_SIZE reports 8 208 KiB = 8.40 MB).
 for k, d in agg.items():
-    if any(t in k for t in ("fdb_plan_kernel", "scan_slots", "scan_dense", "scan_hash")) and "FETCH_SIZE" in d:
+    if any(t in k for t in ("fdb_plan_kernel", "fdb_hash_kernel", "scan_slots", "scan_dense", "scan_hash", "compact", "filter_flags")) and "FETCH_SIZE" in d:
         f = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
         w = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) if "WRITE_SIZE" in d else 0.0
         print(f"# traffic {k[:40]}: FETCH_SIZE mean {f:.1f} KiB x2 (gfx950) = {f * 1024 * 2 / 1e9:.4f} GB read/launch; WRITE_SIZE mean {w:.1f} KiB x1 = {w * 1024 / 1e9:.4f} GB written/launch")
