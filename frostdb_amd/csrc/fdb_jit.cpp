@@ -139,6 +139,10 @@ std::string expr_value(const std::vector<JitExprNode>& ex, int ni, F col, V colv
   const bool f = n.type == FDB_T_F64;
   if (n.kind == 0) return f ? ("__longlong_as_double((long long)" + col(ni) + ")") : ("(long long)" + col(ni));
   if (n.kind == 1) return f ? ("__longlong_as_double(K_elit" + std::to_string(ni) + ")") : ("K_elit" + std::to_string(ni));
+  if (n.kind == 4) return "(double)(" + expr_value(ex, n.left, col, colvalid) + ")";  // float64(c.Value(i)): the raw slot (project.go:523-535)
+  if (n.kind == 5) return "(" + colvalid(n.left) + " ? 0ll : 1ll)";                     // cols[0].IsNull(i) (project.go:588-590)
+  if (n.kind == 6)  // cond.IsValid(i) && cond.Value(i) ? a.Value(i) : b.Value(i) (project.go:685-701); conditions here are never NULL
+    return "((" + expr_value(ex, n.op, col, colvalid) + " != 0ll) ? " + expr_value(ex, n.left, col, colvalid) + " : " + expr_value(ex, n.right, col, colvalid) + ")";
   std::string a = expr_value(ex, n.left, col, colvalid), b = expr_value(ex, n.right, col, colvalid);
   if (n.kind == 3) {
     // comparison → 0 / 1, never NULL: a NULL operand compares false like in a filter leaf (project.go:409-470); mixed

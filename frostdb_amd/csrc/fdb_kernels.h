@@ -90,8 +90,9 @@ struct FdbAgg {
 #define FDB_MAX_EXPR_NODES 40
 struct FdbExprNode {
   int64_t lit;              // literal: int64 value / float64 bits
-  int32_t kind;             // 0 column, 1 literal, 2 binary arithmetic, 3 comparison (boolExprProjection: NULL operand ⇒ false)
-  int32_t op;               // binary: fdb_op (ADD 11, SUB 12, MUL 13, DIV 14); comparison: EQ 1 … GT_EQ 6
+  int32_t kind;             // 0 column, 1 literal, 2 binary arithmetic, 3 comparison (boolExprProjection: NULL operand ⇒ false),
+                            // 4 convert int64 → float64 (left), 5 isnull (left = a column node), 6 if (cond = node `op`) left else right
+  int32_t op;               // binary: fdb_op (ADD 11, SUB 12, MUL 13, DIV 14); comparison: EQ 1 … GT_EQ 6; if: index of the condition node
   int32_t left, right;      // binary: child node indices
   int32_t slot;             // column: 8-byte slot in the pool the aggregates use (dense single-phase: c8, two-phase: l8; hash scan: l8)
   int32_t type;             // FdbAggType of the node's value

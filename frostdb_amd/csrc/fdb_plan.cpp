@@ -361,6 +361,11 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
         if (fn.kind == 2 && (fn.op < FDB_OP_ADD || fn.op > FDB_OP_DIV)) throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary expression in projection");  // project.go:122-123
         if (fn.kind == 3 && (fn.op < FDB_OP_EQ || fn.op > FDB_OP_GT_EQ) && fn.op != FDB_OP_AND && fn.op != FDB_OP_OR) throw Error(FDB_ERR_UNSUPPORTED, "unsupported comparison in projection");
         if (fn.left < 0 || fn.left >= k || fn.right < 0 || fn.right >= k) throw Error(FDB_ERR_INVALID, "projection nodes must be in post-order");
+      } else if (fn.kind == 4 || fn.kind == 5) {  // convert(left, float64) / isnull(left)
+        if (fn.left < 0 || fn.left >= k) throw Error(FDB_ERR_INVALID, "projection nodes must be in post-order");
+        n.right = -1;
+      } else if (fn.kind == 6) {  // if(cond = node `op`) { left } else { right }
+        if (fn.left < 0 || fn.left >= k || fn.right < 0 || fn.right >= k || fn.op < 0 || fn.op >= k) throw Error(FDB_ERR_INVALID, "projection nodes must be in post-order");
       } else {
         throw Error(FDB_ERR_INVALID, "unknown projection node kind");
       }
@@ -428,6 +433,20 @@ int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved
     } else if (n.kind == 1) {
       e.type = n.lit_type == FDB_LIT_INT64 ? FDB_T_I64 : FDB_T_F64;
       if (e.type == FDB_T_I64) e.lit = n.i64; else std::memcpy(&e.lit, &n.f64, 8);
+    } else if (n.kind == 4) {  // convertProjection.convert (project.go:507-521): only int64 → float64 exists
+      e.left = base + n.left;
+      if (a.expr[e.left].type != FDB_T_I64) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": unsupported conversion (only int64 to float64)");
+      e.type = FDB_T_F64;
+    } else if (n.kind == 5) {  // isNullProjection (project.go:571-601): the validity of a COLUMN
+      e.left = base + n.left;
+      if (a.expr[e.left].kind != 0) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": isnull takes a column");
+      e.type = FDB_T_BOOL;
+    } else if (n.kind == 6) {  // ifExprProjection (project.go:619-683): boolean condition, int64 branches
+      e.left = base + n.left; e.right = base + n.right; e.op = base + n.op;
+      if (a.expr[e.op].type != FDB_T_BOOL) throw Error(FDB_ERR_INVALID, "projection " + p.name + ": invalid projection for if: condition column must be of type boolean");
+      if (a.expr[e.left].type != a.expr[e.right].type) throw Error(FDB_ERR_INVALID, "projection " + p.name + ": invalid projection for if: then and else columns must be of the same type");
+      if (a.expr[e.left].type != FDB_T_I64) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": unsupported if expression type (int64 only)");
+      e.type = FDB_T_I64;
     } else if (n.kind == 3) {  // comparison → bool; int64 / float64 operands may mix like in a filter leaf (compared as doubles)
       e.left = base + n.left; e.right = base + n.right;
       const bool logical = n.op == FDB_OP_AND || n.op == FDB_OP_OR;

@@ -211,6 +211,67 @@ class AliasExpr(Expr):
         return f"{self.expr} as {self.alias}"
 
 
+@dataclass(frozen=True, eq=False)
+class ConvertExpr(Expr):
+    """logicalplan.ConvertExpr (expr.go:250-300): only int64 → float64 exists (physicalplan/project.go:507-521)."""
+    expr: Any
+    to: str = "float64"
+
+    @property
+    def name(self) -> str:
+        return f"convert({self.expr.name if hasattr(self.expr, 'name') else self.expr}, {self.to})"
+
+    dynamic = False
+
+    def __str__(self) -> str:
+        return self.name
+
+
+@dataclass(frozen=True, eq=False)
+class IsNullExpr(Expr):
+    """logicalplan.IsNullExpr: Name() = "isnull(<expr>)" (expr.go:862-864)."""
+    expr: Any
+
+    @property
+    def name(self) -> str:
+        return f"isnull({self.expr.name})"
+
+    dynamic = False
+
+    def __str__(self) -> str:
+        return self.name
+
+
+@dataclass(frozen=True, eq=False)
+class IfExpr(Expr):
+    """logicalplan.IfExpr: Name() = "if(<cond>) { <then> } else { <else>}" (expr.go:982-984, missing space included)."""
+    cond: Any
+    then: Any
+    els: Any
+
+    @property
+    def name(self) -> str:
+        n = lambda e: e.name if hasattr(e, "name") else str(e)  # noqa: E731
+        return "if(" + n(self.cond) + ") { " + n(self.then) + " } else { " + n(self.els) + "}"
+
+    dynamic = False
+
+    def __str__(self) -> str:
+        return self.name
+
+
+def Convert(e, to: str = "float64") -> ConvertExpr:
+    return ConvertExpr(e, to)
+
+
+def IsNull(e) -> IsNullExpr:
+    return IsNullExpr(e)
+
+
+def If(cond, then, els) -> IfExpr:
+    return IfExpr(cond, _lit(then) if not isinstance(then, Expr) else then, _lit(els) if not isinstance(els, Expr) else els)
+
+
 def And(*exprs: Expr) -> Expr:
     """logicalplan.And: folds left-deep (expr.go:472-495)."""
     out = exprs[0]
@@ -430,13 +491,27 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
             l = flatten(e.left, nodes)
             r = flatten(e.right, nodes)
             nodes.append(CProjNode(kind=3, op=e.op, left=l, right=r, column=None))
+        elif isinstance(e, ConvertExpr):
+            if e.to not in ("float64", "double", "float"):
+                raise TypeError(f"unsupported conversion to {e.to}")
+            l = flatten(e.expr, nodes)
+            nodes.append(CProjNode(kind=4, op=0, left=l, right=-1, column=None))
+        elif isinstance(e, IsNullExpr):
+            l = flatten(e.expr, nodes)
+            nodes.append(CProjNode(kind=5, op=0, left=l, right=-1, column=None))
+        elif isinstance(e, IfExpr):
+            c = flatten(e.cond, nodes)
+            l = flatten(e.then, nodes)
+            r = flatten(e.els, nodes)
+            nodes.append(CProjNode(kind=6, op=c, left=l, right=r, column=None))
         else:
             raise TypeError(f"unsupported expression in projection: {e}")
         return len(nodes) - 1
 
     for e in [a.expr for a in aggs] + list(groups):
         inner = e.expr if isinstance(e, AliasExpr) else e
-        computed = isinstance(inner, BinaryExpr) and (inner.op in _ARITH or OP_EQ <= inner.op <= OP_GT_EQ or inner.op in (OP_AND, OP_OR))
+        computed = isinstance(inner, (ConvertExpr, IsNullExpr, IfExpr)) or (
+            isinstance(inner, BinaryExpr) and (inner.op in _ARITH or OP_EQ <= inner.op <= OP_GT_EQ or inner.op in (OP_AND, OP_OR)))
         if not computed or e.name in seen:
             continue
         seen.add(e.name)

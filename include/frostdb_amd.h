@@ -143,7 +143,12 @@ typedef struct fdb_group_expr {
  * read back as its raw slot (0) by the enclosing + - *. */
 typedef struct fdb_proj_node {
   int32_t kind;        /* 0 column, 1 literal, 2 binary arithmetic, 3 comparison → bool (boolExprProjection, project.go:401-470:
-                          `distinct(labels.label1, value > 0)`; a NULL operand compares false; usable as a group / distinct key) */
+                          `distinct(labels.label1, value > 0)`; a NULL operand compares false; usable as a group / distinct key),
+                          4 convert(left, float64): int64 → float64 of the RAW slot, always valid (convertProjection, project.go:493-556),
+                          5 isnull(left) → bool, always valid; `left` must be a column node (isNullProjection, :558-601),
+                          6 if(cond) { left } else { right }: int64 branches; cond (node index in `op`) is a comparison / isnull
+                            node; a row takes `left`'s raw slot where cond is true, else `right`'s; always valid
+                            (ifExprProjection + conditionalAddInt64, :603-702) */
   int32_t op;          /* binary: FDB_OP_ADD / SUB / MUL / DIV; comparison: FDB_OP_EQ … FDB_OP_GT_EQ over numeric children,
                           or FDB_OP_AND / FDB_OP_OR over two comparison nodes (AndExpr / OrExpr, filter.go:172-220) */
   int32_t left;        /* binary: child indices into the projection's node array */

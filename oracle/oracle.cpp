@@ -437,6 +437,37 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
     else { *err = {FDB_ERR_UNSUPPORTED, "unsupported literal in arithmetic projection"}; return false; }
     return true;
   }
+  if (n.kind == 4) {
+    // convertProjection.convert (project.go:507-535): only *array.Int64 → float64; Append(float64(c.Value(i))) for EVERY row:
+    // the raw slot of a NULL row converts too and the result has no NULLs
+    Col c;
+    if (!project_node(pd, n.left, r, &c, err)) return false;
+    if (c.type != T_I64) { *err = {FDB_ERR_UNSUPPORTED, "unsupported conversion (only int64 to float64)"}; return false; }
+    out->type = T_F64; out->len = rows; out->valid.assign((size_t)rows, 1); out->f64.assign((size_t)rows, 0.0);
+    for (int64_t i = 0; i < rows; i++) out->f64[(size_t)i] = (double)c.i64[(size_t)i];
+    return true;
+  }
+  if (n.kind == 5) {
+    // isNullProjection.Project (project.go:571-601): b.Append(cols[0].IsNull(i)) — a valid bool per row
+    if (pd.nodes[(size_t)n.left].kind != 0) { *err = {FDB_ERR_UNSUPPORTED, "isnull takes a column"}; return false; }
+    Col c;
+    if (!project_node(pd, n.left, r, &c, err)) return false;
+    out->type = T_BOOL; out->len = rows; out->valid.assign((size_t)rows, 1); out->i64.assign((size_t)rows, 0);
+    for (int64_t i = 0; i < rows; i++) out->i64[(size_t)i] = c.valid[(size_t)i] ? 0 : 1;
+    return true;
+  }
+  if (n.kind == 6) {
+    // ifExprProjection.Project (project.go:619-683) + conditionalAddInt64 (:685-701): the condition must be a boolean array,
+    // then / else of the same type, and only int64 is implemented; row i takes a.Value(i) where cond is valid and true
+    Col c, t, e;
+    if (!project_node(pd, n.op, r, &c, err) || !project_node(pd, n.left, r, &t, err) || !project_node(pd, n.right, r, &e, err)) return false;
+    if (c.type != T_BOOL) { *err = {FDB_ERR_INVALID, "invalid projection for if: condition column must be of type boolean"}; return false; }
+    if (t.type != e.type) { *err = {FDB_ERR_INVALID, "invalid projection for if: then and else columns must be of the same type"}; return false; }
+    if (t.type != T_I64) { *err = {FDB_ERR_UNSUPPORTED, "unsupported if expression type"}; return false; }
+    out->type = T_I64; out->len = rows; out->valid.assign((size_t)rows, 1); out->i64.assign((size_t)rows, 0);
+    for (int64_t i = 0; i < rows; i++) out->i64[(size_t)i] = (c.valid[(size_t)i] && c.i64[(size_t)i]) ? t.i64[(size_t)i] : e.i64[(size_t)i];
+    return true;
+  }
   Col a, b;
   if (!project_node(pd, n.left, r, &a, err) || !project_node(pd, n.right, r, &b, err)) return false;
   if (n.kind == 3) {

@@ -1937,3 +1937,29 @@ def test_oracle_sees_ten_million_rows_of_the_benchmark_workloads(pp, cfg):
             k.close()
     want = run_oracle(recs, **q, nchains=4)
     assert_same_result(got, want, ["labels.path"] + [a.Name() for a in q["aggs"]], float_cols={"sum(value)"})
+
+
+def test_convert_isnull_if_projections_on_the_device(pp):
+    """convertProjection / isNullProjection / ifExprProjection (project.go:493-702) fused into the scan: as aggregate inputs
+    (`sum(convert(ivalue, float64) * value)`, `sum(if(ivalue > 10) { ivalue } else { 1})`) and as group keys (`isnull(ivalue)`,
+    an if-bucket), on columns with NULLs, dense and hash tables — against the oracle's restatement."""
+    from frostdb_amd.logicalplan import BinaryExpr, Convert, If, IsNull, Literal, OP_GT, OP_MUL
+    rng = np.random.default_rng(77)
+    recs = []
+    for n in (30_000, 17_001):
+        base = make_prometheus_batch(rng, n, n_path=20)
+        iv = pa.array(rng.integers(-50, 50, n), mask=rng.random(n) < 0.2)
+        recs.append(base.append_column("ivalue", iv))
+    conv = BinaryExpr(Convert(Col("ivalue")), OP_MUL, Col("value"))
+    pick = If(BinaryExpr(Col("ivalue"), OP_GT, Literal(10)), Col("ivalue"), Literal(1))
+    cases = [
+        (CFG2["filter_expr"], [Sum(conv), Sum(pick), Count(Col("value"))], [Col("labels.path")]),
+        (None, [Sum(pick), Max(pick)], [IsNull(Col("ivalue")), Col("labels.code")]),
+        (None, [Sum(conv)], [If(BinaryExpr(Col("ivalue"), OP_GT, Literal(0)), Col("ivalue"), Literal(-1))]),
+    ]
+    for filt, aggs, groups in cases:
+        cols = [g.name for g in groups] + [a.Name() for a in aggs]
+        for resident in (False, True):
+            got = run_gpu(pp, recs, filt, aggs, groups, resident=resident)
+            want = run_oracle(recs, filt, aggs, groups)
+            assert_same_result(got, want, cols, float_cols={a.Name() for a in aggs if "convert" in a.Name()})

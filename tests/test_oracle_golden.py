@@ -449,3 +449,33 @@ def test_oracle_prehashed_columns_replace_the_hash_not_the_keys():
     cols = ["labels.path", "sum(value)", "count(value)"]
     assert sorted(batch_rows(a, cols), key=sort_key) == sorted(batch_rows(b, cols), key=sort_key)
     assert sorted(b) == sorted(cols)  # the final stage drops the hashed.* helper columns (aggregate.go:561-563)
+
+
+def test_convert_isnull_if_projections_follow_the_reference():
+    """convertProjection / isNullProjection / ifExprProjection (physicalplan/project.go:493-702) as aggregate inputs and group keys.
+    The convert case is logictest/testdata/exec/projection/convert's table and expression (`convert(value, float) * floatvalue`
+    → 2.2, 4.4, 6.6 per row, :10-16) summed per stacktrace; isnull / if have no logictest vectors (parity unpinned beyond the
+    code as read): a NULL row's RAW slot converts (no NULLs come out), isnull is a valid bool per row, if takes `then` only where
+    the condition is valid and true."""
+    import pyarrow as pa
+    from frostdb_amd.logicalplan import BinaryExpr, Col, Convert, Count, If, IsNull, Literal, OP_GT, OP_MUL, Sum
+    from oracle import OraclePlan
+    from tests.util import dict_array
+    rec = pa.RecordBatch.from_arrays([dict_array([b"value1"] * 3), dict_array([b"stack1", b"stack1", b"stack2"]), pa.array([1, 3, 5]), pa.array([2, 4, 6]),
+                                      pa.array([1.1, 1.1, 1.1])], names=["labels.label1", "stacktrace", "timestamp", "value", "floatvalue"])
+    e = BinaryExpr(Convert(Col("value")), OP_MUL, Col("floatvalue"))
+    assert e.name == "convert(value, float64) * floatvalue"
+    o = OraclePlan(None, [Sum(e)], [Col("stacktrace")])
+    o.push(rec)
+    d = o.finish().to_pydict()
+    got = dict(zip(d["stacktrace"], d["sum(convert(value, float64) * floatvalue)"]))
+    assert set(got) == {b"stack1", b"stack2"} and abs(got[b"stack1"] - 6.6) < 1e-9 and abs(got[b"stack2"] - 6.6) < 1e-9
+    o.close()
+    # isnull as a group key, if as an aggregate input, over a column with NULLs
+    rec2 = pa.RecordBatch.from_arrays([pa.array([5, None, 7, None, 1]), pa.array([10, 20, 30, 40, 50])], names=["a", "b"])
+    o = OraclePlan(None, [Sum(If(BinaryExpr(Col("a"), OP_GT, Literal(4)), Col("b"), Literal(1))), Count(Col("b"))], [IsNull(Col("a"))])
+    o.push(rec2)
+    d = o.finish().to_pydict()
+    rows = sorted(zip(d["isnull(a)"], d["sum(if(a > 4) { b } else { 1})"], d["count(b)"]))
+    assert rows == [(False, 10 + 30 + 1, 3), (True, 2, 2)]
+    o.close()
