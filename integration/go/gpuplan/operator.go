@@ -1,0 +1,226 @@
+// Package gpuplan binds libfrostdb_amd.so (include/frostdb_amd.h) into FrostDB's physical plan: one Operator replaces one
+// chain's PredicateFilter + HashAggregate(final=false) (query/physicalplan/physicalplan.go:417-474).
+//
+// This file lives at query/physicalplan/gpuplan/operator.go in a FrostDB checkout. It is real source, not pseudo-code, but this
+// repository's build image has no Go toolchain, so it has never been compiled here; it is written against arrow-go v18's
+// arrow/cdata and the header in ../../../include. See INTEGRATION.md for the option in physicalplan.Build that installs it.
+package gpuplan
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../third_party/frostdb_amd/include
+#cgo LDFLAGS: -L${SRCDIR}/../../../third_party/frostdb_amd -lfrostdb_amd
+#include <stdlib.h>
+#include "frostdb_amd.h"
+extern int32_t fdbRegexMatch(void*, char*, int64_t, uint8_t*, int64_t);
+*/
+import "C"
+
+import (
+	"context"
+	"errors"
+	"runtime"
+	"unsafe"
+
+	"github.com/apache/arrow-go/v18/arrow"
+	"github.com/apache/arrow-go/v18/arrow/cdata"
+
+	"github.com/polarsignals/frostdb/query/logicalplan"
+	"github.com/polarsignals/frostdb/query/physicalplan"
+)
+
+// Operator implements physicalplan.PhysicalPlan (physicalplan.go:24-30) for one chain.
+type Operator struct {
+	plan *C.fdb_plan
+	next physicalplan.PhysicalPlan
+	pin  runtime.Pinner // keeps the descriptor's C strings alive until Close
+}
+
+// New flattens the logical expressions into fdb_plan_desc. Op and AggFunc values are passed through unchanged:
+// fdb_op == logicalplan.Op and fdb_agg_func == logicalplan.AggFunc numerically (logicalplan/expr.go:17-35, :718-729).
+func New(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation) (*Operator, error) {
+	var nodes []C.fdb_expr
+	root := C.int32_t(-1)
+	if filter != nil {
+		r, err := flatten(filter, &nodes) // BinaryExpr{Column, Op, Literal} | And | Or  →  post-order array
+		if err != nil {
+			return nil, err // ≙ ErrUnsupportedBooleanExpression (filter.go:46)
+		}
+		root = C.int32_t(r)
+	}
+	aggs := make([]C.fdb_aggregation, len(agg.AggExprs))
+	for i, a := range agg.AggExprs {
+		aggs[i]._func = C.int32_t(a.Func)
+		aggs[i].column = C.CString(a.Expr.Name())
+		if _, dyn := a.Expr.(*logicalplan.DynamicColumn); dyn { // `max(foo)` over every foo.* column (aggregate.go:38-46)
+			aggs[i].dynamic = 1
+		}
+	}
+	groups := make([]C.fdb_group_expr, len(agg.GroupExprs))
+	for i, g := range agg.GroupExprs {
+		_, dyn := g.(*logicalplan.DynamicColumn)
+		groups[i].name = C.CString(g.Name())
+		if dyn {
+			groups[i].dynamic = 1
+		}
+	}
+	desc := C.fdb_plan_desc{n_filter: C.int32_t(len(nodes)), filter_root: root,
+		n_aggs: C.int32_t(len(aggs)), n_groups: C.int32_t(len(groups)),
+		regex_match: C.fdb_regex_match_fn(C.fdbRegexMatch)} // `=~` / `!~` keep Go's regexp semantics, see below
+	if len(nodes) > 0 { desc.filter = &nodes[0] }
+	if len(aggs) > 0 { desc.aggs = &aggs[0] }
+	if len(groups) > 0 { desc.groups = &groups[0] }
+	op := &Operator{}
+	if rc := C.fdb_plan_create(&desc, C.int(device), &op.plan); rc != C.FDB_OK {
+		return nil, errors.New(C.GoString(C.fdb_last_error()))
+	}
+	return op, nil
+}
+
+// fdbRegexMatch is the library's regex engine: it is called once per DISTINCT value of the filtered column (per dictionary
+// entry), never per row, so `labels.x =~ "(?i)foo.*"` selects exactly the rows the reference's RegExpFilter would
+// (regexpfilter.go:84-166: unanchored regexp.Match on the value's bytes; patterns compiled once, filter.go:105-124).
+// In the cgo preamble: `extern int32_t fdbRegexMatch(void*, char*, int64_t, uint8_t*, int64_t);`
+//
+//export fdbRegexMatch
+func fdbRegexMatch(_ unsafe.Pointer, pat *C.char, patLen C.int64_t, val *C.uint8_t, valLen C.int64_t) C.int32_t {
+	re, err := compiled(C.GoStringN(pat, C.int(patLen))) // sync.Map[string]*regexp.Regexp
+	if err != nil {
+		return -1 // fdb_plan_create fails with FDB_ERR_INVALID, like regexp.Compile failing in physicalplan.Build
+	}
+	if re.Match(unsafe.Slice((*byte)(unsafe.Pointer(val)), int(valLen))) {
+		return 1
+	}
+	return 0
+}
+
+// Callback ≙ PredicateFilter.Callback + HashAggregate.Callback. The record is only borrowed (table.go:808,:827):
+// fdb_plan_push stages what it needs before returning.
+func (o *Operator) Callback(_ context.Context, r arrow.Record) error {
+	var arr cdata.CArrowArray
+	var sch cdata.CArrowSchema
+	cdata.ExportArrowRecordBatch(r, &arr, &sch)
+	defer cdata.ReleaseCArrowArray(&arr)
+	defer cdata.ReleaseCArrowSchema(&sch)
+	if rc := C.fdb_plan_push(o.plan, (*C.struct_ArrowArray)(unsafe.Pointer(&arr)), (*C.struct_ArrowSchema)(unsafe.Pointer(&sch))); rc != C.FDB_OK {
+		return errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))
+	}
+	return nil
+}
+
+// Finish ≙ HashAggregate.Finish: emit the partial record downstream, then propagate Finish (aggregate.go:527-541).
+func (o *Operator) Finish(ctx context.Context) error {
+	var arr cdata.CArrowArray
+	var sch cdata.CArrowSchema
+	var n C.int64_t
+	if rc := C.fdb_plan_finish(o.plan, (*C.struct_ArrowArray)(unsafe.Pointer(&arr)), (*C.struct_ArrowSchema)(unsafe.Pointer(&sch)), &n); rc != C.FDB_OK {
+		return errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))
+	}
+	rec, err := cdata.ImportCRecordBatch(&arr, &sch) // takes ownership; release() frees the C++ holder
+	if err != nil {
+		return err
+	}
+	defer rec.Release()
+	if n > 0 { // finishAggregate skips empty aggregates (aggregate.go:547-549)
+		if err := o.next.Callback(ctx, rec); err != nil {
+			return err
+		}
+	}
+	return o.next.Finish(ctx)
+}
+
+func (o *Operator) SetNext(next physicalplan.PhysicalPlan) { o.next = next }
+func (o *Operator) Draw() *physicalplan.Diagram {
+	var child *physicalplan.Diagram
+	if o.next != nil { child = o.next.Draw() }
+	return &physicalplan.Diagram{Details: C.GoString(C.fdb_plan_draw(o.plan)), Child: child}
+}
+func (o *Operator) Close() { C.fdb_plan_close(o.plan); o.plan = nil; o.next.Close() }
+
+// flatten turns a boolean logicalplan.Expr into the post-order fdb_expr array the descriptor carries: leaves are
+// BinaryExpr{Column, Op, Literal} (filter.go:79-103), branches And / Or (filter.go:129-160). Anything else is
+// ErrUnsupportedBooleanExpression and the caller keeps the Go operators for that plan.
+func flatten(e logicalplan.Expr, out *[]C.fdb_expr) (int, error) {
+	b, ok := e.(*logicalplan.BinaryExpr)
+	if !ok {
+		return -1, physicalplan.ErrUnsupportedBooleanExpression
+	}
+	if b.Op == logicalplan.OpAnd || b.Op == logicalplan.OpOr {
+		l, err := flatten(b.Left, out)
+		if err != nil {
+			return -1, err
+		}
+		r, err := flatten(b.Right, out)
+		if err != nil {
+			return -1, err
+		}
+		*out = append(*out, C.fdb_expr{op: C.int32_t(b.Op), left: C.int32_t(l), right: C.int32_t(r)})
+		return len(*out) - 1, nil
+	}
+	col, ok := b.Left.(*logicalplan.Column)
+	if !ok {
+		return -1, errors.New("left side of binary expression must be a column") // filter.go:91-93
+	}
+	lit, ok := b.Right.(*logicalplan.LiteralExpr)
+	if !ok {
+		return -1, physicalplan.ErrUnsupportedBooleanExpression
+	}
+	n := C.fdb_expr{op: C.int32_t(b.Op), left: -1, right: -1, column: C.CString(col.ColumnName)}
+	setLiteral(&n.literal, lit.Value) // scalar.Int64 → FDB_LIT_INT64, scalar.String → FDB_LIT_STRING (data, len), scalar.Null → FDB_LIT_NULL, …
+	*out = append(*out, n)
+	return len(*out) - 1, nil
+}
+
+// ---- more than one GPU in this process (the reference's N chains live in ONE process, physicalplan.go:22, :337-347) ------------
+
+// Comms is one RCCL communicator over the node's GPUs: ncclCommInitAll behind fdb_comm_init_all; comms[d] belongs to device d.
+type Comms []*C.fdb_comm
+
+func NewComms(devices []int) (Comms, error) {
+	devs := make([]C.int, len(devices))
+	for i, d := range devices {
+		devs[i] = C.int(d)
+	}
+	out := make([]*C.fdb_comm, len(devices))
+	if rc := C.fdb_comm_init_all(&devs[0], C.int32_t(len(devs)), &out[0]); rc != C.FDB_OK {
+		return nil, errors.New(C.GoString(C.fdb_last_error()))
+	}
+	return out, nil
+}
+
+// MergeAcrossDevices is ≙ Synchronizer + HashAggregate(final=true) for chains on different GPUs: every chain's goroutine calls it
+// with its own endpoint (the calls are collective). With equal table layouts — parts of one table — the per-GPU tables are
+// all-reduced in place over xGMI and the chain on comms[0] emits the final record; otherwise the tables are hash-partitioned,
+// exchanged, merged, and EVERY chain emits its shard of the groups (OutputPlan's callback takes several records).
+func (o *Operator) MergeAcrossDevices(ctx context.Context, comm *C.fdb_comm) error {
+	var aligned C.int32_t
+	if rc := C.fdb_plan_allreduce(o.plan, comm, &aligned); rc != C.FDB_OK {
+		return errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))
+	}
+	if aligned == 1 {
+		if C.fdb_comm_rank(comm) != 0 {
+			return o.next.Finish(ctx) // the merged table is emitted by rank 0's chain only
+		}
+		return o.Finish(ctx)
+	}
+	var shard *C.fdb_plan
+	if rc := C.fdb_plan_exchange(o.plan, comm, &shard); rc != C.FDB_OK {
+		return errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))
+	}
+	C.fdb_plan_close(o.plan)
+	o.plan = shard
+	return o.Finish(ctx)
+}
+
+// ---- parts that never become Arrow on the host (pqarrow/arrow.go:711-823 is today's producer) ---------------------------------
+
+// ResidentRowGroup decodes one Parquet row group on the device (fdb_batch_from_parquet) from the column chunks' bytes as
+// parquet-go's file metadata locates them; the batch can be pushed to any number of queries (fdb_plan_push_batches) and stays
+// in HBM until released. Row groups the first slice does not cover (compressed pages, DELTA encodings) return
+// FDB_ERR_UNSUPPORTED: convert those with pqarrow as before and use fdb_batch_import.
+func ResidentRowGroup(device int, chunks []C.fdb_parquet_chunk, rows int64) (*C.fdb_batch, error) {
+	var b *C.fdb_batch
+	if rc := C.fdb_batch_from_parquet(&chunks[0], C.int32_t(len(chunks)), C.int64_t(rows), C.int(device), &b); rc != C.FDB_OK {
+		return nil, errors.New(C.GoString(C.fdb_last_error()))
+	}
+	return b, nil
+}
