@@ -18,7 +18,9 @@
 namespace fdb {
 
 namespace {
-constexpr int64_t kChunkRows = 4 << 20;
+constexpr int64_t kChunkRows = 4 << 20;   // a decent launch: what the table makes room for when there is no estimate
+constexpr int64_t kFirstChunkRows = 1 << 20;  // the first chunk of a fresh table: just enough rows to estimate the cardinality from (what
+                                              // it inserts is re-hashed once, when the table takes its final size)
 inline uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 }  // namespace
 
@@ -238,7 +240,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       // could be a new group). The first chunk of a fresh table is small; from what it finds the final cardinality is
       // estimated, the table grown ONCE to hold it, and the rest of the scan runs in a few big chunks.
       const uint64_t left_here = (uint64_t)(b.rows - r0);
-      const uint64_t min_chunk = std::min<uint64_t>(left_here, (uint64_t)kChunkRows);
+      const uint64_t min_chunk = std::min<uint64_t>(left_here, (uint64_t)(h_rows_seen_ == 0 && h_groups_bound_ == 0 ? kFirstChunkRows : kChunkRows));
       auto room_now = [&]() -> uint64_t { return h_table_ != nullptr && h_capacity_ / 2 > h_groups_bound_ ? h_capacity_ / 2 - h_groups_bound_ : 0; };
       uint64_t room = room_now();  // with the pessimistic bound (groups at the last look + every row scanned since): no wait
       if (room < min_chunk && h_table_ != nullptr && h_bound_stale_) {
