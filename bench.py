@@ -47,6 +47,7 @@ def parse_args(argv=None):
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: 1 B for the headline, 100 M for --config 2/3/5)")
     ap.add_argument("--batch-rows", type=int, default=25_000_000, help="rows per resident record (part)")
     ap.add_argument("--groups", type=int, default=10_000_000, help="cfg 5: distinct groups")
+    ap.add_argument("--cfg5-sorted", action="store_true", help="cfg 5: every record's rows ordered by group (a scan of a table sorted by its label columns)")
     ap.add_argument("--rows-per-thread", type=int, default=0, help="0: slot kernel (default); 4/8: sequential kernel")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--host-records", action="store_true",
@@ -157,7 +158,7 @@ class Workload:
 
         def gen(i):
             if config == 5:
-                b = synth.cfg5_chunk(rank, i, sizes[i], n_groups=args.groups)
+                b = synth.cfg5_chunk(rank, i, sizes[i], n_groups=args.groups, sorted_rows=args.cfg5_sorted)
                 return b, expected_cfg5(b)
             b = synth.prometheus_chunk(rank, i, sizes[i], row_base=i * br, cfg3=(config == 3))
             return b, (expected_cfg2(b) if config == 2 else expected_cfg3(b))

@@ -690,6 +690,44 @@ struct HashGen {
     }
     for (int k = 0; k < 4; k++) o << "    fp_final(h1_" << k << ", h2_" << k << ");\n";
     if (s.ablate & 1) o << "    if ((h1_0 ^ h2_0 ^ h1_1 ^ h2_1 ^ h1_2 ^ h2_2 ^ h1_3 ^ h2_3) == 0x1234567ull) h.table[0] = vm_0 ^ vm_1 ^ vm_2 ^ vm_3;\n    continue;\n";  // tuning aid
+    // Run combining: a lane owns 4 CONSECUTIVE rows, and scans of tables sorted by their label columns (FrostDB's sorting columns)
+    // bring rows of one group next to each other. Rows of the lane with the same fingerprint as the row before them are folded
+    // into it — count and every aggregate — and only the LAST row of such a run goes to the table: one probe + one set of atomics
+    // per run instead of per row. Costs a few compares on unsorted input.
+    const bool combine = !(s.ablate & 2);
+    if (combine) {
+      for (int k = 0; k < 4; k++) o << "    unsigned long long cnt_" << k << " = 1ull;\n";
+      for (size_t j = 0; j < s.aggs.size(); j++) {
+        const JitAgg& A = s.aggs[j];
+        if (A.func == FDB_AGG_COUNT) continue;
+        for (int k = 0; k < 4; k++) {
+          const std::string r = "g" + std::to_string(j);
+          std::string raw = "(((" + r + "_m >> " + std::to_string(k) + ") & 1u) ? " + comp8(r, k) + " : a.aggs[" + std::to_string(j) + "].null_value)";
+          if (A.expr != 0) {
+            auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
+            auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
+            raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
+          }
+          const std::string v = "v" + std::to_string(j) + "_" + std::to_string(k);
+          if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "    double " << v << " = __longlong_as_double((long long)" << raw << ");\n";
+          else if (A.func == FDB_AGG_SUM) o << "    unsigned long long " << v << " = " << raw << ";\n";
+          else o << "    long long " << v << " = " << (A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw)) << ";\n";
+        }
+      }
+      for (int k = 1; k < 4; k++) {
+        o << "    if (((sel >> " << (k - 1) << ") & 3u) == 3u && h1_" << (k - 1) << " == h1_" << k << " && h2_" << (k - 1) << " == h2_" << k << ") {\n";
+        o << "      cnt_" << k << " += cnt_" << (k - 1) << ";\n";
+        for (size_t j = 0; j < s.aggs.size(); j++) {
+          const JitAgg& A = s.aggs[j];
+          if (A.func == FDB_AGG_COUNT) continue;
+          const std::string a = "v" + std::to_string(j) + "_" + std::to_string(k - 1), b = "v" + std::to_string(j) + "_" + std::to_string(k);
+          if (A.func == FDB_AGG_SUM) o << "      " << b << " += " << a << ";\n";
+          else if (A.func == FDB_AGG_MIN) o << "      " << b << " = " << a << " < " << b << " ? " << a << " : " << b << ";\n";
+          else o << "      " << b << " = " << a << " > " << b << " ? " << a << " : " << b << ";\n";
+        }
+        o << "      sel &= ~" << (1u << (k - 1)) << "u;\n    }\n";
+      }
+    }
     // Probe: the home entries of the 4 rows are requested together (one memory round trip for the common case "group exists
     // and sits in its home slot"); rows that miss there take the general find-or-insert path.
     for (int k = 0; k < 4; k++) o << "    uint64_t slot_" << k << " = h1_" << k << " & h.mask; unsigned long long p_" << k << " = 0, q_" << k << " = 0;\n";
@@ -704,24 +742,15 @@ struct HashGen {
       o << "      if (!(p_" << k << " == h1_" << k << " && q_" << k << " == h2_" << k << ")) { bool ins; slot_" << k << " = hash_find_or_insert(h.table, h.mask, ew, h1_" << k << ", h2_" << k
         << ", ins); if (ins) ins_mask |= " << (1 << k) << "u; }\n";
       o << "      unsigned long long* e = h.table + slot_" << k << " * (uint64_t)ew;\n";
-      if (!(s.ablate & 2) && s.need_count) o << "      atomicAdd(e + 2, 1ull);\n";
+      if (!(s.ablate & 2) && s.need_count) o << "      atomicAdd(e + 2, cnt_" << k << ");\n";
       for (size_t j = 0; j < s.aggs.size(); j++) {
         const JitAgg& A = s.aggs[j];
         if (A.func == FDB_AGG_COUNT || (s.ablate & 2)) continue;
-        const std::string r = "g" + std::to_string(j);
-        std::string raw = "(((" + r + "_m >> " + std::to_string(k) + ") & 1u) ? " + comp8(r, k) + " : a.aggs[" + std::to_string(j) + "].null_value)";
-        if (A.expr != 0) {
-          auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
-          auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
-          raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
-        }
+        const std::string v = "v" + std::to_string(j) + "_" + std::to_string(k);
         const std::string acc = "(e + " + std::to_string(3 + j) + ")";
-        if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      atomicAdd(reinterpret_cast<double*>" << acc << ", __longlong_as_double((long long)" << raw << "));\n";
-        else if (A.func == FDB_AGG_SUM) o << "      atomicAdd(" << acc << ", " << raw << ");\n";
-        else {
-          const std::string key = A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw);
-          o << "      " << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>" << acc << ", " << key << ");\n";
-        }
+        if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      atomicAdd(reinterpret_cast<double*>" << acc << ", " << v << ");\n";
+        else if (A.func == FDB_AGG_SUM) o << "      atomicAdd(" << acc << ", " << v << ");\n";
+        else o << "      " << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>" << acc << ", " << v << ");\n";
       }
       o << "    }\n";
     }

@@ -122,12 +122,16 @@ def cfg5_decode_group_ids(batch: pa.RecordBatch) -> np.ndarray:
     return gid
 
 
-def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000) -> pa.RecordBatch:
+def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000, sorted_rows: bool = False) -> pa.RecordBatch:
+    """`sorted_rows`: the record's rows ordered by group id — what a scan of a table SORTED by its label columns (FrostDB's sorting
+    columns) hands the aggregate: rows of one group arrive next to each other."""
     if n_groups not in _CFG5_CACHE:
         _CFG5_CACHE[n_groups] = _cfg5_tables(n_groups)
     digits, nulls = _CFG5_CACHE[n_groups]
     rng = np.random.Generator(np.random.Philox(key=SEED + 5 + shard, counter=[0, 0, 0, chunk]))
     gid = rng.integers(0, n_groups, size=rows, dtype=np.int64)
+    if sorted_rows:
+        gid.sort()
     arrays, names = [], []
     for c in range(CFG5_COLS):
         idx = pa.array(digits[c][gid].astype(np.uint32), type=pa.uint32(), mask=nulls[c][gid] if c >= 12 else None)
