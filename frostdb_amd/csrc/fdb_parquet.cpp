@@ -10,8 +10,11 @@
 //
 // First slice (what FrostDB's default layouts produce, dynparquet/schema.go:508-560): flat schemas; INT64 / DOUBLE columns with
 // PLAIN data pages; BYTE_ARRAY columns with a PLAIN dictionary page + RLE_DICTIONARY data pages (→ dictionary<uint32, binary>,
-// pqarrow/convert/convert.go:64-70); required or optional (max definition level 1); data pages V1 and V2; codec UNCOMPRESSED.
+// pqarrow/convert/convert.go:64-70); required or optional (max definition level 1); data pages V1 and V2; pages UNCOMPRESSED, or SNAPPY / GZIP / ZSTD / LZ4_RAW (inflated on the host while the page headers are walked).
 // Anything else (DELTA_* encodings, compressed pages, dictionary fallback to PLAIN, nested columns) is FDB_ERR_UNSUPPORTED.
+#include <dlfcn.h>
+#include <zlib.h>
+
 #include <algorithm>
 #include <cstring>
 
@@ -179,7 +182,112 @@ void scan_runs(const uint8_t* chunk, size_t off, size_t len, int bw, int64_t n_v
   }
 }
 
+// ---- page decompression (host): the device decodes VALUES; inflating a page is a byte-serial job the host does while it walks
+// the page headers anyway. The decompressed pages of a chunk are laid end to end in one image that goes to HBM instead of the
+// file's bytes. Codec numbers are parquet.thrift's CompressionCodec.
+enum { CODEC_NONE = 0, CODEC_SNAPPY = 1, CODEC_GZIP = 2, CODEC_LZ4_HADOOP = 5, CODEC_ZSTD = 6, CODEC_LZ4_RAW = 7 };
+
+bool snappy_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {  // the Snappy block format (format_description.txt)
+  size_t ip = 0, op = 0;
+  uint64_t len = 0;
+  for (int shift = 0;; shift += 7) {  // preamble: uncompressed length as a varint
+    if (ip >= n || shift > 35) return false;
+    const uint8_t b = src[ip++];
+    len |= (uint64_t)(b & 0x7F) << shift;
+    if (!(b & 0x80)) break;
+  }
+  if (len != cap) return false;
+  while (ip < n) {
+    const uint8_t tag = src[ip++];
+    if ((tag & 3) == 0) {  // literal
+      size_t l = (size_t)(tag >> 2) + 1;
+      if (l > 60) {
+        const size_t extra = l - 60;
+        if (ip + extra > n) return false;
+        l = 0;
+        for (size_t i = 0; i < extra; i++) l |= (size_t)src[ip + i] << (8 * i);
+        l += 1;
+        ip += extra;
+      }
+      if (ip + l > n || op + l > cap) return false;
+      std::memcpy(dst + op, src + ip, l);
+      ip += l; op += l;
+      continue;
+    }
+    size_t l, off;
+    if ((tag & 3) == 1) { if (ip + 1 > n) return false; l = 4 + ((tag >> 2) & 7); off = ((size_t)(tag >> 5) << 8) | src[ip]; ip += 1; }
+    else if ((tag & 3) == 2) { if (ip + 2 > n) return false; l = (size_t)(tag >> 2) + 1; off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8); ip += 2; }
+    else { if (ip + 4 > n) return false; l = (size_t)(tag >> 2) + 1; off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8) | ((size_t)src[ip + 2] << 16) | ((size_t)src[ip + 3] << 24); ip += 4; }
+    if (off == 0 || off > op || op + l > cap) return false;
+    for (size_t i = 0; i < l; i++) dst[op + i] = dst[op - off + i];  // (may overlap: byte by byte)
+    op += l;
+  }
+  return op == cap;
+}
+
+typedef int (*lz4_fn)(const char*, char*, int, int);
+typedef size_t (*zstd_fn)(void*, size_t, const void*, size_t);
+typedef unsigned (*zstd_err_fn)(size_t);
+lz4_fn lz4_decompress() {
+  static lz4_fn f = [] { void* h = dlopen("liblz4.so.1", RTLD_NOW | RTLD_LOCAL); return h ? (lz4_fn)dlsym(h, "LZ4_decompress_safe") : (lz4_fn) nullptr; }();
+  return f;
+}
+std::pair<zstd_fn, zstd_err_fn> zstd_decompress() {
+  static std::pair<zstd_fn, zstd_err_fn> f = [] {
+    void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+    return h ? std::make_pair((zstd_fn)dlsym(h, "ZSTD_decompress"), (zstd_err_fn)dlsym(h, "ZSTD_isError")) : std::make_pair((zstd_fn) nullptr, (zstd_err_fn) nullptr);
+  }();
+  return f;
+}
+
+// dst[0, cap) = the decompressed bytes of src[0, n); throws on a codec that is not available or on corrupt input.
+void inflate_page(int codec, const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+  if (cap == 0) return;
+  switch (codec) {
+    case CODEC_SNAPPY:
+      if (!snappy_raw(src, n, dst, cap)) throw Error(FDB_ERR_INVALID, "parquet: corrupt Snappy page");
+      return;
+    case CODEC_GZIP: {
+      z_stream z;
+      std::memset(&z, 0, sizeof(z));
+      if (inflateInit2(&z, 15 + 32) != Z_OK) throw Error(FDB_ERR_OOM, "parquet: zlib init failed");
+      z.next_in = const_cast<Bytef*>(src); z.avail_in = (uInt)n; z.next_out = dst; z.avail_out = (uInt)cap;
+      const int rc = inflate(&z, Z_FINISH);
+      const size_t got = cap - z.avail_out;
+      inflateEnd(&z);
+      if (rc != Z_STREAM_END || got != cap) throw Error(FDB_ERR_INVALID, "parquet: corrupt GZIP page");
+      return;
+    }
+    case CODEC_ZSTD: {
+      auto f = zstd_decompress();
+      if (f.first == nullptr || f.second == nullptr) throw Error(FDB_ERR_UNSUPPORTED, "parquet: ZSTD pages need libzstd.so.1 on this host");
+      const size_t got = f.first(dst, cap, src, n);
+      if (f.second(got) || got != cap) throw Error(FDB_ERR_INVALID, "parquet: corrupt ZSTD page");
+      return;
+    }
+    case CODEC_LZ4_RAW: case CODEC_LZ4_HADOOP: {
+      lz4_fn f = lz4_decompress();
+      if (f == nullptr) throw Error(FDB_ERR_UNSUPPORTED, "parquet: LZ4 pages need liblz4.so.1 on this host");
+      if (f((const char*)src, (char*)dst, (int)n, (int)cap) == (int)cap) return;
+      // the deprecated "LZ4" codec may carry Hadoop's framing: [uncompressed size BE32][compressed size BE32][block] …
+      size_t ip = 0, op = 0;
+      while (ip + 8 <= n && op < cap) {
+        const size_t ul = ((size_t)src[ip] << 24) | ((size_t)src[ip + 1] << 16) | ((size_t)src[ip + 2] << 8) | src[ip + 3];
+        const size_t cl = ((size_t)src[ip + 4] << 24) | ((size_t)src[ip + 5] << 16) | ((size_t)src[ip + 6] << 8) | src[ip + 7];
+        ip += 8;
+        if (ip + cl > n || op + ul > cap || f((const char*)src + ip, (char*)dst + op, (int)cl, (int)ul) != (int)ul) break;
+        ip += cl; op += ul;
+      }
+      if (op != cap) throw Error(FDB_ERR_INVALID, "parquet: corrupt LZ4 page");
+      return;
+    }
+    default:
+      throw Error(FDB_ERR_UNSUPPORTED, "parquet: compression codec " + std::to_string(codec) + " is not supported (UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4_RAW are)");
+  }
+}
+
 struct ParsedChunk {
+  std::vector<uint8_t> image;              // compressed chunks: the decompressed page bodies end to end (what goes to HBM); else empty
   std::shared_ptr<HostDict> dict;          // BYTE_ARRAY columns
   std::vector<FdbPqRun> def_runs;          // optional columns: one entry per run, row-numbered
   std::vector<FdbPqRun> idx_runs;          // dictionary-encoded columns: rank-numbered
@@ -194,17 +302,36 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
   const bool is_bytes = c.physical_type == 6, is_fixed8 = c.physical_type == 2 || c.physical_type == 5;
   if (!is_bytes && !is_fixed8) throw Error(FDB_ERR_UNSUPPORTED, "parquet: only INT64, DOUBLE and BYTE_ARRAY columns are decoded on the device");
   ParsedChunk out;
-  const uint8_t* base = c.data;
-  Thrift t{base, base + c.n_bytes};
+  const uint8_t* base = c.data;  // what run / page offsets are relative to: the chunk's bytes, or the image of its decompressed pages
+  Thrift t{c.data, c.data + c.n_bytes};
   int64_t rows_done = 0, rank_done = 0;
   bool have_dict = false;
   while (t.p < t.end && rows_done < n_rows) {
     const PageHeader h = read_page_header(t);
-    if (h.compressed != h.uncompressed) throw Error(FDB_ERR_UNSUPPORTED, "parquet: compressed pages are not supported on the device path (codec must be UNCOMPRESSED)");
-    if (h.compressed < 0 || (size_t)(t.end - t.p) < (size_t)h.compressed) throw Error(FDB_ERR_INVALID, "parquet: page runs past the end of the column chunk");
-    const uint8_t* body = t.p;
-    const size_t body_off = (size_t)(body - base), body_len = (size_t)h.compressed;
-    t.p += body_len;
+    if (h.compressed < 0 || h.uncompressed < 0 || (size_t)(t.end - t.p) < (size_t)h.compressed) throw Error(FDB_ERR_INVALID, "parquet: page runs past the end of the column chunk");
+    if (c.codec == CODEC_NONE && h.compressed != h.uncompressed) throw Error(FDB_ERR_INVALID, "parquet: page sizes disagree in an UNCOMPRESSED chunk");
+    const uint8_t* raw = t.p;  // the page's bytes in the file
+    t.p += (size_t)h.compressed;
+    // `body` = the page's UNCOMPRESSED bytes: in place for an uncompressed chunk, else appended to the image. A V2 page keeps its
+    // levels uncompressed in front of the (possibly) compressed values.
+    std::vector<uint8_t> dict_tmp;
+    const uint8_t* body = raw;
+    size_t body_off = (size_t)(raw - c.data), body_len = (size_t)h.compressed;
+    if (c.codec != CODEC_NONE) {
+      body_len = (size_t)h.uncompressed;
+      const size_t plain_prefix = h.type == PQ_DATA_PAGE_V2 ? (size_t)h.v2_def_bytes + (size_t)h.v2_rep_bytes : 0;
+      if (plain_prefix > (size_t)h.compressed || plain_prefix > body_len) throw Error(FDB_ERR_INVALID, "parquet: levels run past the page");
+      const bool packed = h.type != PQ_DATA_PAGE_V2 || h.v2_compressed;
+      std::vector<uint8_t>& dst = h.type == PQ_DICTIONARY_PAGE ? dict_tmp : out.image;
+      const size_t at = dst.size();
+      dst.resize(at + body_len + 8);  // (+8: the next page starts 8 bytes on; keeps every 64-bit window inside the image)
+      std::memcpy(dst.data() + at, raw, plain_prefix);
+      if (packed) inflate_page(c.codec, raw + plain_prefix, (size_t)h.compressed - plain_prefix, dst.data() + at + plain_prefix, body_len - plain_prefix);
+      else { if ((size_t)h.compressed != body_len) throw Error(FDB_ERR_INVALID, "parquet: uncompressed V2 page with differing sizes"); std::memcpy(dst.data() + at + plain_prefix, raw + plain_prefix, body_len - plain_prefix); }
+      body = dst.data() + at;
+      body_off = at;
+    }
+    base = c.codec != CODEC_NONE ? out.image.data() : c.data;  // (the image may have moved)
     if (h.type == PQ_DICTIONARY_PAGE) {
       if (!is_bytes) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary-encoded numeric columns are not supported on the device path");
       if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary page encoding");
@@ -306,10 +433,13 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
   for (int32_t i = 0; i < n_chunks && n_rows > 0; i++) {
     const fdb_parquet_chunk& c = chunks[i];
     const ParsedChunk& P = parsed[(size_t)i];
-    // the chunk's bytes as they are, padded so that 8-byte windows at the very end stay inside the allocation
-    uint8_t* d_chunk = (uint8_t*)ctx->dev_alloc((size_t)c.n_bytes + 64);
+    // the chunk's bytes as they are (or the image of its decompressed pages), padded so that 8-byte windows at the very end stay
+    // inside the allocation
+    const uint8_t* src = P.image.empty() ? c.data : P.image.data();
+    const size_t src_bytes = c.codec == 0 ? (size_t)c.n_bytes : P.image.size();
+    uint8_t* d_chunk = (uint8_t*)ctx->dev_alloc(src_bytes + 64);
     scratch.push_back(d_chunk);
-    hip_check(hipMemcpyAsync(d_chunk, c.data, (size_t)c.n_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
+    if (src_bytes) hip_check(hipMemcpyAsync(d_chunk, src, src_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
     auto to_device = [&](const void* host, size_t bytes) -> void* {
       void* d = ctx->dev_alloc(std::max<size_t>(bytes, 16));
       scratch.push_back(d);

@@ -169,10 +169,11 @@ def _raise(code: int, msg: str):
 class ParquetChunk(ctypes.Structure):
     """fdb_parquet_chunk: one column chunk of a row group, bytes as they sit in the file."""
     _fields_ = [("name", ctypes.c_char_p), ("physical_type", ctypes.c_int32), ("optional", ctypes.c_int32), ("utf8", ctypes.c_int32),
-                ("_pad", ctypes.c_int32), ("data", ctypes.c_void_p), ("n_bytes", ctypes.c_int64)]
+                ("codec", ctypes.c_int32), ("data", ctypes.c_void_p), ("n_bytes", ctypes.c_int64)]
 
 
 PARQUET_INT64, PARQUET_DOUBLE, PARQUET_BYTE_ARRAY = 2, 5, 6
+PARQUET_CODECS = {"UNCOMPRESSED": 0, "SNAPPY": 1, "GZIP": 2, "LZO": 3, "BROTLI": 4, "LZ4": 5, "ZSTD": 6, "LZ4_RAW": 7}  # parquet.thrift CompressionCodec
 
 
 class ResidentBatch:
@@ -180,11 +181,14 @@ class ResidentBatch:
 
     @classmethod
     def from_parquet(cls, chunks: Sequence[tuple], n_rows: int, device: int = 0) -> "ResidentBatch":
-        """`chunks`: (name, physical type, optional, utf8, bytes-like) per column of ONE row group — decoded on the device
-        (fdb_batch_from_parquet). The byte buffers only need to stay alive for the duration of the call."""
+        """`chunks`: (name, physical type, optional, utf8, bytes-like[, codec]) per column of ONE row group — decoded on the device
+        (fdb_batch_from_parquet); `codec` is a CompressionCodec number or name (default UNCOMPRESSED). The byte buffers only need
+        to stay alive for the duration of the call."""
         arr = (ParquetChunk * len(chunks))()
         keep = []
-        for i, (name, ptype, optional, utf8, data) in enumerate(chunks):
+        for i, (name, ptype, optional, utf8, data, *rest) in enumerate(chunks):
+            codec = rest[0] if rest else 0
+            codec = PARQUET_CODECS[codec.upper()] if isinstance(codec, str) else int(codec)
             if isinstance(data, tuple):      # (address, length): bytes that already sit somewhere stable, e.g. a pinned file buffer
                 addr, size = data
             elif isinstance(data, bytes):    # no copy: the bytes object is kept alive for the call
@@ -194,7 +198,7 @@ class ResidentBatch:
                 addr, size = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value, len(data)
             nm = name.encode()
             keep += [data, nm]
-            arr[i] = ParquetChunk(nm, ptype, 1 if optional else 0, 1 if utf8 else 0, 0, addr, size)
+            arr[i] = ParquetChunk(nm, ptype, 1 if optional else 0, 1 if utf8 else 0, codec, addr, size)
         out = ctypes.c_void_p()
         rc = lib().fdb_batch_from_parquet(arr, len(chunks), n_rows, device, ctypes.byref(out))
         if rc != 0:

@@ -381,14 +381,16 @@ int fdb_batch_export(const fdb_batch* batch, struct ArrowArray* out, struct Arro
  * page and the headers of RLE / bit-packed runs; definition levels → validity bitmaps, value ranks and the per-row dictionary
  * indices / values are computed in HBM. First slice: flat schemas; INT64 / DOUBLE with PLAIN data pages; BYTE_ARRAY with a
  * dictionary page + RLE_DICTIONARY data pages (→ dictionary<uint32, binary>, pqarrow/convert/convert.go:64-70; utf8 = 1 →
- * dictionary<uint32, utf8>); required or optional; data pages V1 / V2; codec UNCOMPRESSED. Everything else: FDB_ERR_UNSUPPORTED
+ * dictionary<uint32, utf8>); required or optional; data pages V1 / V2; codecs as listed at `codec`. Everything else: FDB_ERR_UNSUPPORTED
  * (the caller falls back to its Arrow path for that row group). */
 typedef struct fdb_parquet_chunk {
   const char* name;        /* field name of the column in the record */
   int32_t physical_type;   /* parquet Type: 2 INT64, 5 DOUBLE, 6 BYTE_ARRAY */
   int32_t optional;        /* max definition level: 0 required, 1 optional */
   int32_t utf8;            /* BYTE_ARRAY: logical type String */
-  int32_t _pad;
+  int32_t codec;           /* parquet CompressionCodec of the chunk's pages: 0 UNCOMPRESSED, 1 SNAPPY, 2 GZIP, 6 ZSTD, 7 LZ4_RAW
+                              (5, the deprecated LZ4, is read as raw blocks or Hadoop-framed blocks). Pages are inflated on the host
+                              while their headers are walked; the device decodes the values. */
   const uint8_t* data;     /* [dictionary page] data pages …, each preceded by its thrift PageHeader, exactly as in the file */
   int64_t n_bytes;         /* ColumnMetaData.total_compressed_size */
 } fdb_parquet_chunk;

@@ -18,7 +18,7 @@ def write_parquet(table: pa.Table, **kw) -> bytes:
 
 
 def row_group_chunks(data: bytes, rg: int):
-    """[(name, physical type, optional, utf8, chunk bytes)] and the row count of row group `rg`."""
+    """[(name, physical type, optional, utf8, chunk bytes, codec name)] and the row count of row group `rg`."""
     pf = pq.ParquetFile(io.BytesIO(data))
     md = pf.metadata.row_group(rg)
     out = []
@@ -29,5 +29,5 @@ def row_group_chunks(data: bytes, rg: int):
         start = min(offs)
         chunk = data[start:start + col.total_compressed_size]
         utf8 = str(sc.logical_type).lower().startswith("string")
-        out.append((col.path_in_schema, PHYSICAL.get(col.physical_type, -1), sc.max_definition_level, utf8, chunk))
+        out.append((col.path_in_schema, PHYSICAL.get(col.physical_type, -1), sc.max_definition_level, utf8, chunk, col.compression))
     return out, md.num_rows

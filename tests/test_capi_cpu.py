@@ -239,7 +239,7 @@ def test_local_communicator_endpoints_and_allocation_counters_without_a_gpu():
 
 def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     """fdb_batch_from_parquet reads page headers / run headers on the host BEFORE it touches a device: chunks outside the first
-    slice (compressed pages, DELTA encodings, truncated bytes) come back as FDB_ERR_UNSUPPORTED / FDB_ERR_INVALID here, without
+    slice (BROTLI pages, DELTA encodings, truncated bytes) come back as FDB_ERR_UNSUPPORTED / FDB_ERR_INVALID here, without
     a GPU; a well-formed chunk gets as far as the device call (FDB_ERR_DEVICE on this box)."""
     import numpy as np
     import pyarrow as pa
@@ -254,16 +254,38 @@ def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(good, rows)
     assert e.value.code == pp.FDB_ERR_DEVICE  # parsed fine, then no GPU
-    for kw, code in ((dict(compression="SNAPPY"), pp.FDB_ERR_UNSUPPORTED),
+    for kw, code in ((dict(compression="BROTLI"), pp.FDB_ERR_UNSUPPORTED),
                      (dict(use_dictionary=False, column_encoding={"ts": "DELTA_BINARY_PACKED", "labels.a": "PLAIN", "value": "PLAIN"}), pp.FDB_ERR_UNSUPPORTED)):
         bad, rows = row_group_chunks(write_parquet(t, **kw), 0)
         with pytest.raises(pp.FdbError) as e:
             pp.ResidentBatch.from_parquet(bad, rows)
         assert e.value.code == code, kw
-    cut = [(nm, ty, opt, u8, data[: len(data) // 2]) for nm, ty, opt, u8, data in good]
+    cut = [(nm, ty, opt, u8, data[: len(data) // 2]) for nm, ty, opt, u8, data, _ in good]
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(cut, rows)
     assert e.value.code == pp.FDB_ERR_INVALID
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(good, rows + 1)
     assert e.value.code == pp.FDB_ERR_INVALID
+    # compressed pages are inflated on the host while the headers are walked: a sound chunk reaches the device call, a chunk
+    # whose compressed bytes were damaged (or that names the wrong codec) is refused before it
+    for codec in ("SNAPPY", "GZIP", "ZSTD", "LZ4"):
+        for version in ("1.0", "2.0"):
+            packed, rows = row_group_chunks(write_parquet(t, compression=codec, data_page_version=version), 0)
+            assert {c[5] for c in packed} == {codec}
+            with pytest.raises(pp.FdbError) as e:
+                pp.ResidentBatch.from_parquet(packed, rows)
+            assert e.value.code == pp.FDB_ERR_DEVICE, (codec, version, str(e.value))
+        hurt = []
+        for nm, ty, opt, u8, data, cd in packed:
+            b = bytearray(data)
+            for k in range(len(b) // 2, min(len(b) // 2 + 64, len(b))):
+                b[k] ^= 0xA5
+            hurt.append((nm, ty, opt, u8, bytes(b), cd))
+        with pytest.raises(pp.FdbError) as e:
+            pp.ResidentBatch.from_parquet(hurt, rows)
+        assert e.value.code == pp.FDB_ERR_INVALID, codec
+        wrong = [(nm, ty, opt, u8, data, "GZIP" if cd != "GZIP" else "ZSTD") for nm, ty, opt, u8, data, cd in packed]
+        with pytest.raises(pp.FdbError) as e:
+            pp.ResidentBatch.from_parquet(wrong, rows)
+        assert e.value.code == pp.FDB_ERR_INVALID, codec

@@ -85,6 +85,20 @@ def test_decoded_row_group_is_bit_identical_to_pyarrow(pp, n, version):
     rb.close()
 
 
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+@pytest.mark.parametrize("codec", ["SNAPPY", "GZIP", "ZSTD", "LZ4"])
+def test_compressed_pages_decode_bit_identically(pp, codec, version):
+    """Pages are inflated on the host into one image per chunk (V2: levels stay as they are, values are inflated behind them);
+    run and page offsets then point into the image. Small pages → many pages per chunk, and a second row group."""
+    rng = np.random.default_rng(len(codec))
+    data = write_parquet(prometheus_table(rng, 120_001), compression=codec, data_page_version=version, data_page_size=16 * 1024, row_group_size=70_000)
+    for rg in range(2):
+        chunks, _ = row_group_chunks(data, rg)
+        assert {c[5] for c in chunks} == {codec}
+        rb, _ = decoded_equals_pyarrow(pp, data, rg)
+        rb.close()
+
+
 def test_several_row_groups_all_null_columns_and_wide_dictionaries(pp):
     """Row groups are decoded one by one; a column that is entirely NULL, a dictionary of 70 000 entries (17-bit indices) and a
     required column whose pages carry no definition levels."""

@@ -24,10 +24,10 @@ pinned = torch.empty(len(data), dtype=torch.uint8, pin_memory=True)
 pinned.numpy()[:] = np.frombuffer(data, dtype=np.uint8)
 def _pin(ch):
     out = []
-    for nm, ty, opt, u8, b in ch:
+    for nm, ty, opt, u8, b, cd in ch:
         off = data.find(b[:64]) if len(b) >= 64 else data.find(b)
         assert data[off:off + len(b)] == b
-        out.append((nm, ty, opt, u8, (pinned.data_ptr() + off, len(b))))
+        out.append((nm, ty, opt, u8, (pinned.data_ptr() + off, len(b)), cd))
     return out
 groups = [(_pin(ch), n) for ch, n in groups]
 q = (Col("labels.code") == "200", [Sum(Col("value"))], [Col("labels.path")])
