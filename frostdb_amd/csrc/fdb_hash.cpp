@@ -13,7 +13,11 @@
 #include "fdb_plan_internal.h"
 #include "fdb_jit.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 
 namespace fdb {
 
@@ -309,9 +313,10 @@ void Plan::fetch_compact_hash(CompactState* cs) {
   unsigned long long* d_entries = (unsigned long long*)ctx_->dev_alloc((size_t)n * oew * 8);
   uint32_t* d_keys = (uint32_t*)ctx_->dev_alloc((size_t)n * kw * 4);
   unsigned long long* d_n = (unsigned long long*)ctx_->dev_alloc(256);
-  uint32_t* d_bases = (uint32_t*)ctx_->dev_alloc((size_t)((h_capacity_ + 63) / 64 + 4) * 4);
+  const size_t n_chunks = (size_t)((h_capacity_ + 63) / 64);
+  uint32_t* d_bases = (uint32_t*)ctx_->dev_alloc((n_chunks + 4 + n_chunks / 1024 + 8) * 4);  // (+ the scan's per-1024 sums)
   // slot order: repeated calls on an unchanged table (partial_keys, then partial_state per aggregation) line up row by row
-  hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, ew, d_bases, d_n, stream_), "hash chunk bases");
+  hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, ew, d_bases, d_bases + n_chunks + 4, d_n, stream_), "hash chunk bases");
   hip_check(fdb_launch_hash_compact(h_table_, h_keys_, h_capacity_, ew, kw, d_entries, d_keys, d_bases, stream_), "hash compact");
   // pinned staging (cached by the context): pageable destinations would cap the copy at a few GB/s
   unsigned long long* entries = (unsigned long long*)ctx_->host_alloc((size_t)n * oew * 8);
@@ -342,56 +347,103 @@ void Plan::fetch_compact_hash(CompactState* cs) {
   ctx_->host_free(entries); ctx_->host_free(keys);
 }
 
-// Finish on the device: occupied entries → Arrow-shaped column buffers (dictionary indices, int64 keys, validity bitmaps,
-// aggregate columns) → one device-to-host copy per buffer. Returns the number of groups.
+// Finish on the device: occupied entries → column buffers (dictionary indices at their transport width, int64 keys, validity
+// bitmaps, aggregate columns) → device-to-host copies → Arrow buffers. PCIe is the narrowest link of a big Finish (cfg 5:
+// 10 M groups × 32 label columns = 1.28 GB of uint32 indices at ≈56 GB/s), so indices of small dictionaries cross it as uint8 /
+// uint16, in slices of 2^20 rows, and host threads widen slice k into the record's uint32 buffers while slice k + 1 is in flight.
+// Returns the number of groups.
+void widen_indices(const void* src, int width, uint32_t* dst, size_t n);  // fdb_widen.cc
+
+namespace {
+int host_threads_for(size_t elements) {
+  if (elements < ((size_t)4 << 20)) return 0;  // small results: widened inline
+  if (const char* e = std::getenv("FDB_HOST_THREADS")) return std::max(0, std::min(64, std::atoi(e)));
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::max(1u, std::min(32u, hw / 4));
+}
+}  // namespace
+
 int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   hip_check(hipSetDevice(device_), "hipSetDevice");
   PhaseTimer pt;
   const uint64_t n = hash_groups();
   const size_t n_cols = gcols_.size(), n_vals = 1 + aggs_.size();
   const size_t np = (size_t)((n + 63) & ~(uint64_t)63) + 64;  // padded row count of the buffers
-  // One result block with the layout of the final record — per group column [values | validity bitmap], then one
-  // 8-byte column per emitted value array — exists twice: in HBM (filled by the kernels below) and in pinned host memory
-  // (filled by ONE device→host copy, then handed to the caller as the record's buffers).
-  std::vector<size_t> off_key(n_cols), off_bits(n_cols), off_val(n_vals);
+  int kSliceShift = 6;  // 2^20 rows per slice; a smaller result is one slice of the next power of two
+  while (kSliceShift < 20 && ((uint64_t)1 << kSliceShift) < n) kSliceShift++;
+  const size_t kSliceRows = (size_t)1 << kSliceShift;
+  const size_t n_slices = (size_t)((n + kSliceRows - 1) >> kSliceShift);
+  // transport width per group column: 1 / 2 bytes for dictionaries that fit, else the column's own width
+  std::vector<int> width(n_cols);
+  std::vector<bool> narrow(n_cols);
+  size_t n_narrow = 0, last_narrow = 0;
+  for (size_t c = 0; c < n_cols; c++) {
+    const GroupColState& g = gcols_[c];
+    width[c] = g.kind != 0 ? 8 : g.values.size() <= 256 ? 1 : g.values.size() <= 65536 ? 2 : 4;
+    narrow[c] = g.kind == 0 && width[c] < 4;
+    if (narrow[c]) { n_narrow++; last_narrow = c; }
+  }
+  // Host block (pinned, handed to the caller as the record's buffers): [uint32 arrays of the narrow columns — written by the
+  // widening threads][direct part: wide key columns, one validity bitmap per column, one 8-byte column per value array].
+  // Device block: [direct part, same layout][narrow columns, slice-major: slice s = rows [s·2^20, (s+1)·2^20) of every narrow
+  // column back to back]; row masks on the side.
+  std::vector<size_t> off_key(n_cols), off_bits(n_cols), off_val(n_vals), off_narrow(n_cols, 0);
   size_t total = 0;
   auto place = [&](size_t bytes) { const size_t o = total; total = align_up_sz(total + bytes, 256); return o; };
-  for (size_t c = 0; c < n_cols; c++) { off_key[c] = place(np * (gcols_[c].kind == 0 ? 4 : 8)); off_bits[c] = place(np / 8 + 64); }
+  for (size_t c = 0; c < n_cols; c++) if (narrow[c]) off_key[c] = place(np * 4);
+  const size_t direct_begin = total;
+  for (size_t c = 0; c < n_cols; c++) if (!narrow[c]) off_key[c] = place(np * (size_t)width[c]);
+  for (size_t c = 0; c < n_cols; c++) off_bits[c] = place(np / 8 + 64);
   for (size_t v = 0; v < n_vals; v++) off_val[v] = place(np * 8);
-  unsigned char* d_block = (unsigned char*)ctx_->dev_alloc(total);
+  const size_t direct_bytes = total - direct_begin;
+  size_t slice_stride = 0;
+  for (size_t c = 0; c < n_cols; c++) if (narrow[c]) { off_narrow[c] = slice_stride; slice_stride += kSliceRows * (size_t)width[c]; }
+  const size_t narrow_bytes = slice_stride * std::max<size_t>(n_slices, 1);
+  unsigned char* d_block = (unsigned char*)ctx_->dev_alloc(direct_bytes + narrow_bytes + 256);
+  unsigned char* d_narrow = d_block + direct_bytes;
   std::vector<void*> owned{d_block};
   auto alloc = [&](size_t bytes) { void* p = ctx_->dev_alloc(bytes); owned.push_back(p); return p; };
-  std::vector<void*> d_key(n_cols);
-  std::vector<uint8_t*> d_valid(n_cols);
+  std::vector<void*> d_key(std::max<size_t>(n_cols, 1));
+  std::vector<uint8_t*> d_bits(std::max<size_t>(n_cols, 1));
   std::vector<unsigned long long*> d_vals(n_vals);
-  uint8_t* d_valid_all = (uint8_t*)alloc(std::max<size_t>(n_cols, 1) * np);  // one validity byte per row and column (packed below)
-  for (size_t c = 0; c < n_cols; c++) { d_key[c] = d_block + off_key[c]; d_valid[c] = d_valid_all + c * np; }
-  for (size_t v = 0; v < n_vals; v++) d_vals[v] = (unsigned long long*)(d_block + off_val[v]);
+  for (size_t c = 0; c < n_cols; c++) {
+    d_key[c] = narrow[c] ? d_narrow + off_narrow[c] : d_block + (off_key[c] - direct_begin);
+    d_bits[c] = d_block + (off_bits[c] - direct_begin);
+  }
+  for (size_t v = 0; v < n_vals; v++) d_vals[v] = (unsigned long long*)(d_block + (off_val[v] - direct_begin));
+  unsigned long long* d_mask = (unsigned long long*)alloc(np * 8);
   unsigned long long* d_n = (unsigned long long*)alloc(256);
-  uint32_t* d_bases = (uint32_t*)alloc((size_t)((h_capacity_ + 63) / 64 + 4) * 4);
+  const size_t n_chunks = (size_t)((h_capacity_ + 63) / 64);
+  uint32_t* d_bases = (uint32_t*)alloc((n_chunks + 4 + n_chunks / 1024 + 8) * 4);
   std::vector<FdbHashCol> cols(std::max<size_t>(n_cols, 1));
   for (size_t c = 0; c < n_cols; c++) {
     std::memset(&cols[c], 0, sizeof(FdbHashCol));
     cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c;
+    cols[c].src_word = width[c]; cols[c].lut_len = narrow[c] ? 1u : 0u;
   }
   FdbHashColumnsArgs a;
   std::memset(&a, 0, sizeof(a));
   a.table = h_table_; a.keys = h_keys_; a.capacity = h_capacity_;
   a.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
-  a.out_key = (void* const*)upload(d_key.data(), std::max<size_t>(n_cols, 1) * sizeof(void*));
-  a.out_valid = (uint8_t* const*)upload(d_valid.data(), std::max<size_t>(n_cols, 1) * sizeof(void*));
+  a.out_key = (void* const*)upload(d_key.data(), d_key.size() * sizeof(void*));
   a.out_vals = (unsigned long long* const*)upload(d_vals.data(), n_vals * sizeof(void*));
+  uint8_t* const* d_bits_dev = (uint8_t* const*)upload(d_bits.data(), d_bits.size() * sizeof(void*));
+  a.out_mask = d_mask;
   a.bases = d_bases;
+  a.slice_stride = slice_stride; a.slice_shift = kSliceShift;
   a.n_cols = (int)n_cols; a.entry_words = h_entry_words_; a.key_words = h_key_words_; a.n_vals = (int)n_vals;
   std::shared_ptr<void> backing;
   unsigned char* h_block = nullptr;
+  unsigned char* h_narrow = nullptr;  // pinned landing area of the narrow slices
   if (n > 0) {
-    hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, h_entry_words_, d_bases, d_n, stream_), "hash chunk bases");
-    hip_check(fdb_launch_hash_columns(a, stream_), "hash columns");
-    for (size_t c = 0; c < n_cols; c++) hip_check(fdb_launch_pack_bits(d_valid[c], d_block + off_bits[c], (int64_t)n, stream_), "pack bits");
+    hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, h_entry_words_, d_bases, d_bases + n_chunks + 4, d_n, stream_), "hash chunk bases");
+    hip_check(fdb_launch_hash_columns(a, device_, stream_), "hash columns");
+    hip_check(fdb_launch_hash_row_bitmaps(d_mask, (int64_t)n, (int)n_cols, d_bits_dev, stream_), "hash row bitmaps");
     h_block = (unsigned char*)pinned_pool_alloc(total);
     backing = std::shared_ptr<void>(h_block, [](void* p) { pinned_pool_free(p); });
+    if (n_narrow > 0) h_narrow = (unsigned char*)pinned_pool_alloc(narrow_bytes);
   }
+  struct FreeNarrow { unsigned char* p; ~FreeNarrow() { if (p) pinned_pool_free(p); } } free_narrow{h_narrow};
   pt.mark("finish: launch");
   // column descriptors (dictionaries are rebuilt on the host while the copy is in flight)
   out->clear();
@@ -401,7 +453,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     oc.name = g.name;
     oc.length = (int64_t)n;
     oc.format = g.kind == 0 ? "I" : g.is_bool ? "b" : g.is_u64 ? "L" : "l";
-    if (n > 0) { oc.backing = backing; oc.ext_values = g.is_bool ? nullptr : h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }
+    if (n > 0) { oc.backing = backing; oc.ext_values = g.is_bool ? nullptr : h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }  // (narrow columns: the widened array)
     if (g.kind == 0 && !g.plain) set_dictionary(&oc, g.values, g.value_format);
     out->push_back(std::move(oc));
   }
@@ -419,7 +471,63 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     out_of_agg[j] = out->size();
     out->push_back(std::move(oc));
   }
-  if (n > 0) ctx_->copy_out_parallel(h_block, d_block, total);  // (1.35 GB for cfg 5: PCIe-bound, the biggest item of the whole step)
+  if (n > 0) {
+    // narrow slices first (the widening threads start on slice 0 while the rest is still crossing), the direct part last
+    std::vector<hipEvent_t> landed(n_narrow > 0 ? n_slices : 0);
+    struct PutEvents { Context* c; std::vector<hipEvent_t>* v; ~PutEvents() { for (hipEvent_t e : *v) if (e) c->put_event(e); } } put_events{ctx_, &landed};
+    for (size_t sl = 0; sl < landed.size(); sl++) {
+      const size_t rows = std::min<size_t>(kSliceRows, (size_t)n - sl * kSliceRows);
+      const size_t bytes = rows == kSliceRows ? slice_stride : off_narrow[last_narrow] + rows * (size_t)width[last_narrow];  // (short last slice)
+      hip_check(hipMemcpyAsync(h_narrow + sl * slice_stride, d_narrow + sl * slice_stride, bytes, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(narrow slice)");
+      landed[sl] = ctx_->get_event();
+      hip_check(hipEventRecord(landed[sl], stream_), "hipEventRecord");
+    }
+    hip_check(hipMemcpyAsync(h_block + direct_begin, d_block, direct_bytes, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(result)");
+    if (n_narrow > 0) {
+      // one task = one narrow column of one slice
+      std::vector<size_t> narrow_cols;
+      for (size_t c = 0; c < n_cols; c++) if (narrow[c]) narrow_cols.push_back(c);
+      const size_t n_tasks = n_slices * narrow_cols.size();
+      auto run_task = [&](size_t t) {
+        const size_t sl = t / narrow_cols.size(), c = narrow_cols[t % narrow_cols.size()];
+        const size_t rows = std::min<size_t>(kSliceRows, (size_t)n - sl * kSliceRows);
+        widen_indices(h_narrow + sl * slice_stride + off_narrow[c], width[c], (uint32_t*)(h_block + off_key[c]) + sl * kSliceRows, rows);
+      };
+      const int n_threads = host_threads_for((size_t)n * n_narrow);
+      if (n_threads <= 0) {
+        sync();
+        for (size_t t = 0; t < n_tasks; t++) run_task(t);
+      } else {
+        std::atomic<size_t> next{0}, ready_slices{0};
+        std::atomic<bool> failed{false};
+        std::vector<std::thread> workers;
+        auto work = [&] {
+          for (;;) {
+            const size_t t = next.fetch_add(1);
+            if (t >= n_tasks) return;
+            const size_t sl = t / narrow_cols.size();
+            while (ready_slices.load(std::memory_order_acquire) <= sl) {
+              if (failed.load()) return;
+              std::this_thread::yield();
+            }
+            run_task(t);
+          }
+        };
+        hipError_t err = hipSuccess;
+        try {
+          for (int i = 0; i < n_threads; i++) workers.emplace_back(work);
+        } catch (...) { /* fewer threads than asked for: the ones that started (or this thread, below) do the work */ }
+        for (size_t sl = 0; sl < n_slices && err == hipSuccess; sl++) {
+          err = hipEventSynchronize(landed[sl]);
+          if (err == hipSuccess) ready_slices.store(sl + 1, std::memory_order_release);
+        }
+        if (err != hipSuccess) failed.store(true);
+        else work();  // this thread helps with what is left
+        for (std::thread& w : workers) w.join();
+        hip_check(err, "hipEventSynchronize(narrow slice)");
+      }
+    }
+  }
   sync();
   pt.mark("finish: copy");
   for (void* p : owned) ctx_->dev_free(p);

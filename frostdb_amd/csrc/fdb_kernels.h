@@ -255,23 +255,34 @@ hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uin
                                   hipStream_t stream);
 // First output row of every 64-slot chunk of the table (bases[(capacity + 63) / 64], exclusive prefix sums of the occupied
 // entries per chunk) and *n_out = occupied entries: what makes the two compactions below deterministic — SLOT ORDER, no atomics.
-hipError_t fdb_launch_hash_chunk_bases(const unsigned long long* table, uint64_t capacity, int entry_words, uint32_t* bases, unsigned long long* n_out,
-                                       hipStream_t stream);
+hipError_t fdb_launch_hash_chunk_bases(const unsigned long long* table, uint64_t capacity, int entry_words, uint32_t* bases, uint32_t* block_sums,
+                                       unsigned long long* n_out, hipStream_t stream);
+// In-place exclusive prefix sums of n 32-bit counts and their total. `block_sums`: scratch of (n + 1023) / 1024 + 1 words (counts are
+// summed per 1 024, the sums scanned by one workgroup, then every block scans its own part: three launches); nullptr or
+// n ≤ 4 096: one workgroup does everything.
+hipError_t fdb_launch_exclusive_scan(uint32_t* counts, int64_t n, uint32_t* block_sums, unsigned long long* total, hipStream_t stream);
 // Compacts the occupied entries in slot order: out_entries[i][0..entry_words-2] = {count, acc…} (fingerprints dropped),
 // out_keys[i][key_words].
 hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int entry_words, int key_words,
                                    unsigned long long* out_entries, uint32_t* out_keys, const uint32_t* bases, hipStream_t stream);
-// Finish for big tables: the occupied entries go straight into Arrow-shaped COLUMN buffers on the device (uint32 dictionary
-// indices = key id - 1, int64 key values, one validity BYTE per row and column, count and accumulator columns), so the
-// host only copies finished buffers. cols[c].word/kind/gi describe the key tuple; out_key[c] points to the column's value
-// buffer (4 or 8 bytes per row), out_valid[c] to its validity bytes. out_vals[0] = counts, out_vals[1 + j] = accumulator j.
+// Finish for big tables: the occupied entries go straight into COLUMN buffers on the device, so the host only copies (and, for
+// narrow dictionary columns, widens) finished buffers. cols[c].word / kind / gi describe the key tuple, cols[c].src_word the
+// TRANSPORT width of the column in bytes — dictionary indices (= key id - 1) travel as uint8 / uint16 when the dictionary has
+// ≤ 256 / ≤ 65 536 entries and are widened to Arrow's uint32 on the host (PCIe is the narrowest link of Finish), int64 keys are
+// 8 bytes — and cols[c].lut_len != 0 marks a SLICED column: out_key[c] + slice · slice_stride + (row in slice) · width with
+// 2^slice_shift rows per slice, so that one slice of all narrow columns is a contiguous run for the copy engine and the host can
+// widen slice k while slice k + 1 is in flight. Other columns: out_key[c] + row · width. out_vals[0] = counts, out_vals[1 + j] =
+// accumulator j (8 bytes per row); out_mask[row] bit c = column c of the row is valid (→ fdb_launch_hash_row_bitmaps).
 struct FdbHashColumnsArgs {
   const unsigned long long* table; const uint32_t* keys; uint64_t capacity;
-  const FdbHashCol* cols; void* const* out_key; uint8_t* const* out_valid; unsigned long long* const* out_vals;
+  const FdbHashCol* cols; void* const* out_key; unsigned long long* out_mask; unsigned long long* const* out_vals;
   const uint32_t* bases;  // fdb_launch_hash_chunk_bases
-  int32_t n_cols, entry_words, key_words, n_vals;
+  uint64_t slice_stride;
+  int32_t n_cols, entry_words, key_words, n_vals, slice_shift;
 };
-hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, hipStream_t stream);
+hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream);
+// bitmaps[c][row / 8] bit (row % 8) = bit c of row_mask[row]; whole 8-byte words are written (bitmaps padded to a multiple of 8 bytes).
+hipError_t fdb_launch_hash_row_bitmaps(const unsigned long long* row_mask, int64_t n, int n_cols, uint8_t* const* bitmaps, hipStream_t stream);
 // bits[i / 8] bit (i % 8) = bytes[i] != 0, for i < n (n rounded up to 8 inside; bytes must be readable up to the rounding).
 hipError_t fdb_launch_pack_bits(const uint8_t* bytes, uint8_t* bits, int64_t n, hipStream_t stream);
 
@@ -356,7 +367,7 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
 //    bitmap = row i selected) and the number of selected rows per tile of FDB_COMPACT_TILE (2 048) rows (`tile_counts`, zeroed by the
 //    caller). No barriers, no LDS beyond the filter's LUTs: it runs at full occupancy, which is what hides the latency of the
 //    predicate interpreter's dependent loads.
-// 2. fdb_launch_tile_offsets turns the counts into exclusive prefix sums in place and writes the total.
+// 2. fdb_launch_exclusive_scan turns the counts into exclusive prefix sums in place and writes the total.
 // 3. fdb_launch_compact_col streams one column per launch. A tile belongs to ONE WAVE (no workgroup barriers anywhere: 32 independent
 //    waves per CU overlap each other's load → stage → store phases): its lanes read their mask bits, find their output positions
 //    with wave prefix sums, scatter the selected values into the wave's LDS staging buffer and write the buffer to its place in the
@@ -370,7 +381,6 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
 #define FDB_COMPACT_TILE (FDB_COMPACT_SUBTILE * FDB_COMPACT_SUB)  // 2 048 rows, owned by one wave
 #define FDB_COMPACT_WAVE_LDS 5120                          // staging bytes per wave: 4 KiB of values + 1 KiB of validity bytes
 hipError_t fdb_launch_filter_flags(const FdbScanArgs& args, uint8_t* masks, uint32_t* tile_counts, int device, hipStream_t stream);
-hipError_t fdb_launch_tile_offsets(uint32_t* tile_counts, int64_t n_tiles, unsigned long long* total, hipStream_t stream);
 // One column per launch. width 4 / 8: values of that many bytes (`src` → `dst`, validity bitmap `src_valid` (nullptr: no NULLs) →
 // validity BITMAP of the output in `dst_valid` (nullptr: not wanted; 8-byte aligned and ZEROED by the caller), null_count[0 … 63] (zeroed) receive the
 // NULLs among the selected rows — the caller adds the 64 partial counts); width 0: the selection vector — ascending row numbers — into `dst` (uint32).

@@ -924,33 +924,115 @@ __global__ void hash_compact_kernel(const unsigned long long* table, const uint3
     }
   }
 }
-__global__ void hash_columns_kernel(const FdbHashColumnsArgs a) {
-  const uint64_t n_round = (a.capacity + 63) & ~(uint64_t)63;
-  const int ew = a.entry_words, kw = a.key_words;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * blockDim.x) {
-    const bool occ = i < a.capacity && a.table[i * (uint64_t)ew] != 0ull;
+// Finish for big tables, one WAVE per 64-slot chunk. The occupied entries' key tuples are fetched cooperatively (lane ↦ word of
+// the chunk's tuples laid end to end: full 128-byte lines instead of 34 strided 4-byte loads per lane) into the wave's LDS tile
+// [row][key_words | 1] (odd pitch: conflict-free when lanes = rows), then every lane r < n_occ emits row base + r of each
+// column — dictionary indices at the column's transport width, int64 keys, count and accumulators — and ONE 64-bit word with
+// the row's validity bits of all columns (hash_row_bitmaps_kernel turns those into Arrow bitmaps). No workgroup barrier.
+__global__ __launch_bounds__(256) void hash_columns_kernel(const FdbHashColumnsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int ew = a.entry_words, kw = a.key_words, kwp = kw | 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem + (size_t)wave * ((size_t)64 * kwp * 4 + 64));
+  uint8_t* slot_of = reinterpret_cast<uint8_t*>(tile + 64 * kwp);
+  const uint32_t magic = (uint32_t)((0x100000000ull + (unsigned)kw - 1ull) / (unsigned)kw);  // t / kw for t < 64 · kw
+  const uint64_t n_chunks = (a.capacity + 63) >> 6;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  for (uint64_t chunk = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; chunk < n_chunks; chunk += n_waves) {
+    const uint64_t i = chunk * 64 + lane;
+    const unsigned long long* e = a.table + i * (uint64_t)ew;
+    const bool occ = i < a.capacity && e[0] != 0ull;
     const unsigned long long m = __ballot(occ);
     if (m == 0ull) continue;
-    const int lane = threadIdx.x & 63;
-    if (!occ) continue;
-    const uint64_t o = (uint64_t)a.bases[i >> 6] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));  // slot order, see hash_chunk_counts_kernel
-    const unsigned long long* e = a.table + i * (uint64_t)ew;
-    for (int v = 0; v < a.n_vals; v++) a.out_vals[v][o] = e[2 + v];
-    const uint32_t* k = a.keys + i * (uint64_t)kw;
-    const unsigned long long vm = (unsigned long long)k[0] | ((unsigned long long)k[1] << 32);
-    for (int c = 0; c < a.n_cols; c++) {
-      const FdbHashCol C = load_col(a.cols, c);
-      if (C.kind == 0) {
-        const uint32_t id = k[C.word];
-        reinterpret_cast<uint32_t*>(a.out_key[c])[o] = id ? id - 1u : 0u;
-        a.out_valid[c][o] = id != 0u;
-      } else {
-        const bool ok = (vm >> C.gi) & 1ull;
-        reinterpret_cast<unsigned long long*>(a.out_key[c])[o] = ok ? ((unsigned long long)k[C.word] | ((unsigned long long)k[C.word + 1] << 32)) : 0ull;
-        a.out_valid[c][o] = ok;
+    const uint32_t n_occ = (uint32_t)__popcll(m);
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const uint64_t base = a.bases[chunk];
+    if (occ) {
+      slot_of[r] = (uint8_t)lane;
+      for (int v = 0; v < a.n_vals; v++) a.out_vals[v][base + r] = e[2 + v];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t* kchunk = a.keys + chunk * 64 * (uint64_t)kw;
+    const uint32_t n_words = n_occ * (uint32_t)kw;
+    for (uint32_t t = lane; t < n_words; t += 64) {
+      const uint32_t rr = __umulhi(t, magic), w = t - rr * (uint32_t)kw;
+      tile[rr * kwp + w] = kchunk[(uint32_t)slot_of[rr] * (uint32_t)kw + w];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < n_occ) {
+      const uint32_t* k = tile + lane * kwp;
+      const uint64_t o = base + lane;
+      const unsigned long long vm = (unsigned long long)k[0] | ((unsigned long long)k[1] << 32);
+      unsigned long long row_mask = 0;
+      for (int c = 0; c < a.n_cols; c++) {
+        const FdbHashCol C = load_col(a.cols, c);
+        unsigned char* out = reinterpret_cast<unsigned char*>(a.out_key[c]);
+        const int width = C.src_word;  // (transport width of the column: 1, 2, 4 or 8 bytes)
+        // sliced columns: [slice][column][row in slice] — a slice of all narrow columns is one contiguous run for the copy engine
+        const uint64_t at = C.lut_len ? (o >> a.slice_shift) * a.slice_stride + (o & ((1ull << a.slice_shift) - 1ull)) * (uint64_t)width : o * (uint64_t)width;
+        if (C.kind == 0) {
+          const uint32_t id = k[C.word];
+          const uint32_t idx = id ? id - 1u : 0u;
+          if (width == 1) out[at] = (uint8_t)idx;
+          else if (width == 2) *reinterpret_cast<uint16_t*>(out + at) = (uint16_t)idx;
+          else *reinterpret_cast<uint32_t*>(out + at) = idx;
+          row_mask |= (unsigned long long)(id != 0u) << c;
+        } else {
+          const bool ok = (vm >> C.gi) & 1ull;
+          *reinterpret_cast<unsigned long long*>(out + at) = ok ? ((unsigned long long)k[C.word] | ((unsigned long long)k[C.word + 1] << 32)) : 0ull;
+          row_mask |= (unsigned long long)ok << c;
+        }
       }
+      a.out_mask[o] = row_mask;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Row masks (bit c = column c of the row is valid) → one Arrow validity bitmap per column: a wave takes 64 rows, one ballot and
+// one 8-byte store per column.
+__global__ __launch_bounds__(256) void hash_row_bitmaps_kernel(const unsigned long long* __restrict__ row_mask, int64_t n, int n_cols, uint8_t* const* bitmaps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_groups = (n + 63) >> 6;
+  for (int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < n_groups; g += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int64_t row = g * 64 + lane;
+    const unsigned long long m = row < n ? row_mask[row] : 0ull;
+    for (int c = 0; c < n_cols; c++) {
+      const unsigned long long w = __ballot((m >> c) & 1ull);
+      if (lane == 0) reinterpret_cast<unsigned long long*>(bitmaps[c])[g] = w;
     }
   }
+}
+
+// Multi-workgroup exclusive scan, step 1 and 3 (step 2 = scan_counts_kernel over the per-1024 sums).
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint32_t* __restrict__ counts, int64_t n, uint32_t* __restrict__ sums) {
+  __shared__ unsigned int wave_sum[4];
+  const int64_t i0 = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (i0 + k < n) s += counts[i0 + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+__global__ __launch_bounds__(256) void scan_apply_kernel(uint32_t* __restrict__ counts, int64_t n, const uint32_t* __restrict__ block_offsets) {
+  __shared__ unsigned int wave_sum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
+  uint32_t v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { v[k] = i0 + k < n ? counts[i0 + k] : 0u; s += v[k]; }
+  uint32_t incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  uint32_t run = block_offsets[blockIdx.x] + incl - s;
+  for (int w = 0; w < wave; w++) run += wave_sum[w];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { if (i0 + k < n) counts[i0 + k] = run; run += v[k]; }
 }
 
 __global__ void pack_bits_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bits, int64_t n_bytes_out, int64_t n) {
@@ -1626,9 +1708,17 @@ hipError_t fdb_launch_filter_flags(const FdbScanArgs& args, uint8_t* masks, uint
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_tile_offsets(uint32_t* tile_counts, int64_t n_tiles, unsigned long long* total, hipStream_t stream) {
-  if (n_tiles <= 0) return hipMemsetAsync(total, 0, 8, stream);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, tile_counts, n_tiles, total);
+
+hipError_t fdb_launch_exclusive_scan(uint32_t* counts, int64_t n, uint32_t* block_sums, unsigned long long* total, hipStream_t stream) {
+  if (n <= 0) return hipMemsetAsync(total, 0, 8, stream);
+  if (n <= 4096 || block_sums == nullptr) {  // small: one workgroup
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, counts, n, total);
+    return hipGetLastError();
+  }
+  const int64_t n_blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, counts, n, block_sums);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, block_sums, n_blocks, total);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, counts, n, block_sums);
   return hipGetLastError();
 }
 
@@ -1686,13 +1776,12 @@ hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uin
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_hash_chunk_bases(const unsigned long long* table, uint64_t capacity, int entry_words, uint32_t* bases, unsigned long long* n_out,
-                                       hipStream_t stream) {
+hipError_t fdb_launch_hash_chunk_bases(const unsigned long long* table, uint64_t capacity, int entry_words, uint32_t* bases, uint32_t* block_sums,
+                                       unsigned long long* n_out, hipStream_t stream) {
   const int64_t n_chunks = (int64_t)((capacity + 63) / 64);
   if (n_chunks == 0) return hipMemsetAsync(n_out, 0, 8, stream);
   hipLaunchKernelGGL(hash_chunk_counts_kernel, dim3(4096), dim3(256), 0, stream, table, capacity, entry_words, bases);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(FDB_BLOCK), 0, stream, bases, n_chunks, n_out);  // in place: counts → exclusive prefix sums
-  return hipGetLastError();
+  return fdb_launch_exclusive_scan(bases, n_chunks, block_sums, n_out, stream);  // in place: counts → exclusive prefix sums
 }
 
 hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32_t* keys, uint64_t capacity, int entry_words, int key_words,
@@ -1710,8 +1799,25 @@ hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t strea
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, hipStream_t stream) {
-  hipLaunchKernelGGL(hash_columns_kernel, dim3(4096), dim3(256), 0, stream, args);
+hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream) {
+  const int64_t n_chunks = (int64_t)((args.capacity + 63) / 64);
+  if (n_chunks == 0) return hipSuccess;
+  const size_t lds = 4 * ((size_t)64 * (size_t)(args.key_words | 1) * 4 + 64);  // one tile per wave
+  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_columns_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(150 * 1024 / lds)));
+  const int64_t grid = std::min<int64_t>((n_chunks + 3) / 4, (int64_t)fdb_scan_default_grid(device) * per_cu);
+  hipLaunchKernelGGL(hash_columns_kernel, dim3((unsigned)grid), dim3(256), lds, stream, args);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_hash_row_bitmaps(const unsigned long long* row_mask, int64_t n, int n_cols, uint8_t* const* bitmaps, hipStream_t stream) {
+  if (n <= 0 || n_cols <= 0) return hipSuccess;
+  const int64_t groups = (n + 63) / 64;
+  hipLaunchKernelGGL(hash_row_bitmaps_kernel, dim3((unsigned)std::min<int64_t>((groups + 3) / 4, 8192)), dim3(256), 0, stream, row_mask, n, n_cols, bitmaps);
   return hipGetLastError();
 }
 

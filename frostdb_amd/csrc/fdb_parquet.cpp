@@ -452,12 +452,12 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
       if (P.def_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: optional column without definition levels");
       const FdbPqRun* d_runs = (const FdbPqRun*)to_device(P.def_runs.data(), P.def_runs.size() * sizeof(FdbPqRun));
       d_valid = (uint32_t*)((unsigned char*)b->arena + pieces[(size_t)i].bit_off);
-      d_prefix = (uint32_t*)ctx->dev_alloc((size_t)(n_words + 4) * 4);
+      d_prefix = (uint32_t*)ctx->dev_alloc((size_t)(n_words + 4 + n_words / 1024 + 8) * 4);  // (+ the scan's per-1024 sums)
       scratch.push_back(d_prefix);
       d_totals[(size_t)i] = (unsigned long long*)ctx->dev_alloc(64);
       scratch.push_back(d_totals[(size_t)i]);
       hip_check(fdb_launch_pq_validity(d_chunk, d_runs, (int32_t)P.def_runs.size(), n_rows, d_valid, d_prefix, stream), "parquet validity");
-      hip_check(fdb_launch_tile_offsets(d_prefix, n_words, d_totals[(size_t)i], stream), "parquet rank scan");
+      hip_check(fdb_launch_exclusive_scan(d_prefix, n_words, d_prefix + n_words + 4, d_totals[(size_t)i], stream), "parquet rank scan");
     }
     void* d_out = (unsigned char*)b->arena + pieces[(size_t)i].val_off;
     if (c.physical_type == 6) {

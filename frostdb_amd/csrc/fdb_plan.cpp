@@ -1835,14 +1835,14 @@ void Plan::resolve_filter_only(const DeviceBatch& b, Resolved* Rp) {
 int64_t Plan::run_flags(const FdbScanArgs& a, uint8_t** d_masks, uint32_t** d_offsets) {
   const int64_t n_tiles = (a.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
   uint8_t* masks = (uint8_t*)ctx_->dev_alloc((size_t)n_tiles * (FDB_COMPACT_TILE / 8) + 64);
-  uint32_t* offs = (uint32_t*)ctx_->dev_alloc((size_t)(n_tiles + 4) * 4 + 64);
+  uint32_t* offs = (uint32_t*)ctx_->dev_alloc((size_t)(n_tiles + 4 + n_tiles / 1024 + 8) * 4 + 64);  // (+ the scan's per-1024 sums)
   unsigned long long* d_total = (unsigned long long*)ctx_->dev_alloc(64);
   scratch_.push_back(masks); scratch_.push_back(offs); scratch_.push_back(d_total);
   hip_check(hipMemsetAsync(offs, 0, (size_t)(n_tiles + 4) * 4, stream_), "hipMemsetAsync(tile counts)");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
   hip_check(fdb_launch_filter_flags(a, masks, offs, device_, stream_), "filter flags launch");
-  hip_check(fdb_launch_tile_offsets(offs, n_tiles, d_total, stream_), "tile offsets launch");
+  hip_check(fdb_launch_exclusive_scan(offs, n_tiles, offs + n_tiles + 4, d_total, stream_), "tile offsets launch");
   if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
   unsigned long long total = 0;
   hip_check(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(total)");
