@@ -215,6 +215,12 @@ hipEvent_t Context::get_event() {
 
 void Context::put_event(hipEvent_t e) { events_.push_back(e); }
 
+hipStream_t Context::aux_stream(int i) {
+  if (i < 0 || i >= 3) i = 0;
+  if (aux_[i] == nullptr) hip_check(hipStreamCreateWithFlags(&aux_[i], hipStreamNonBlocking), "hipStreamCreate(aux)");
+  return aux_[i];
+}
+
 void Context::copy_out_parallel(void* host, const void* dev, size_t bytes) {
   constexpr size_t kMinSlice = (size_t)64 << 20;
   int parts = (int)std::min<size_t>(4, std::max<size_t>(1, bytes / kMinSlice));

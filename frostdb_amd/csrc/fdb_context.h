@@ -30,6 +30,7 @@ class Context {
   // A big device→host copy split over `stream` and up to 3 auxiliary streams (several DMA engines work on one PCIe link more
   // evenly than one: 1.35 GB went from 41 to ≈52 GB/s); ordered after everything queued on `stream`, complete when this returns.
   void copy_out_parallel(void* host, const void* dev, size_t bytes);
+  hipStream_t aux_stream(int i);  // a second queue of this context (copies that overlap kernels on `stream`); created on first use
 
   // Small host→device tables (LUTs, slot maps): staged in pinned memory, shipped with one async copy each.
   void* stage(const void* host, size_t bytes);

@@ -367,6 +367,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   hip_check(hipSetDevice(device_), "hipSetDevice");
   PhaseTimer pt;
   const uint64_t n = hash_groups();
+  if (pt.on) pt.mark("finish: group count");
   const size_t n_cols = gcols_.size(), n_vals = 1 + aggs_.size();
   const size_t np = (size_t)((n + 63) & ~(uint64_t)63) + 64;  // padded row count of the buffers
   int kSliceShift = 6;  // 2^20 rows per slice; a smaller result is one slice of the next power of two
@@ -395,6 +396,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   for (size_t c = 0; c < n_cols; c++) if (!narrow[c]) off_key[c] = place(np * (size_t)width[c]);
   for (size_t c = 0; c < n_cols; c++) off_bits[c] = place(np / 8 + 64);
   for (size_t v = 0; v < n_vals; v++) off_val[v] = place(np * 8);
+  const size_t off_nulls = place(std::max<size_t>(n_cols, 1) * 8);  // NULLs per group column, counted by the kernel
   const size_t direct_bytes = total - direct_begin;
   size_t slice_stride = 0;
   for (size_t c = 0; c < n_cols; c++) if (narrow[c]) { off_narrow[c] = slice_stride; slice_stride += kSliceRows * (size_t)width[c]; }
@@ -411,7 +413,6 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     d_bits[c] = d_block + (off_bits[c] - direct_begin);
   }
   for (size_t v = 0; v < n_vals; v++) d_vals[v] = (unsigned long long*)(d_block + (off_val[v] - direct_begin));
-  unsigned long long* d_mask = (unsigned long long*)alloc(np * 8);
   unsigned long long* d_n = (unsigned long long*)alloc(256);
   const size_t n_chunks = (size_t)((h_capacity_ + 63) / 64);
   uint32_t* d_bases = (uint32_t*)alloc((n_chunks + 4 + n_chunks / 1024 + 8) * 4);
@@ -427,23 +428,29 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   a.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
   a.out_key = (void* const*)upload(d_key.data(), d_key.size() * sizeof(void*));
   a.out_vals = (unsigned long long* const*)upload(d_vals.data(), n_vals * sizeof(void*));
-  uint8_t* const* d_bits_dev = (uint8_t* const*)upload(d_bits.data(), d_bits.size() * sizeof(void*));
-  a.out_mask = d_mask;
+  a.out_bits = (uint8_t* const*)upload(d_bits.data(), d_bits.size() * sizeof(void*));
   a.bases = d_bases;
   a.slice_stride = slice_stride; a.slice_shift = kSliceShift;
+  a.n_rows = n;
+  a.out_nulls = (unsigned long long*)(d_block + (off_nulls - direct_begin));
+  a.dense_keys = (uint32_t*)alloc(std::max<size_t>((size_t)n, 1) * (size_t)h_key_words_ * 4 + 256);
   a.n_cols = (int)n_cols; a.entry_words = h_entry_words_; a.key_words = h_key_words_; a.n_vals = (int)n_vals;
   std::shared_ptr<void> backing;
   unsigned char* h_block = nullptr;
   unsigned char* h_narrow = nullptr;  // pinned landing area of the narrow slices
   if (n > 0) {
     hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, h_entry_words_, d_bases, d_bases + n_chunks + 4, d_n, stream_), "hash chunk bases");
-    hip_check(fdb_launch_hash_columns(a, device_, stream_), "hash columns");
-    hip_check(fdb_launch_hash_row_bitmaps(d_mask, (int64_t)n, (int)n_cols, d_bits_dev, stream_), "hash row bitmaps");
+    hip_check(hipMemsetAsync(a.out_nulls, 0, std::max<size_t>(n_cols, 1) * 8, stream_), "hipMemsetAsync(null counts)");
+    hip_check(fdb_launch_hash_gather_rows(a, device_, stream_), "hash gather rows");
     h_block = (unsigned char*)pinned_pool_alloc(total);
     backing = std::shared_ptr<void>(h_block, [](void* p) { pinned_pool_free(p); });
     if (n_narrow > 0) h_narrow = (unsigned char*)pinned_pool_alloc(narrow_bytes);
   }
   struct FreeNarrow { unsigned char* p; ~FreeNarrow() { if (p) pinned_pool_free(p); } } free_narrow{h_narrow};
+  // copies run on a second queue: slice k crosses PCIe while pass 2 produces slice k + 1. Whatever happens below, nothing is
+  // still writing into the host blocks when they go back to their pools.
+  hipStream_t copy_stream = n > 0 ? ctx_->aux_stream(0) : nullptr;
+  struct Quiesce { hipStream_t a, b; ~Quiesce() { if (a) (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); } } quiesce{copy_stream, stream_};
   pt.mark("finish: launch");
   // column descriptors (dictionaries are rebuilt on the host while the copy is in flight)
   out->clear();
@@ -472,17 +479,24 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     out->push_back(std::move(oc));
   }
   if (n > 0) {
-    // narrow slices first (the widening threads start on slice 0 while the rest is still crossing), the direct part last
-    std::vector<hipEvent_t> landed(n_narrow > 0 ? n_slices : 0);
-    struct PutEvents { Context* c; std::vector<hipEvent_t>* v; ~PutEvents() { for (hipEvent_t e : *v) if (e) c->put_event(e); } } put_events{ctx_, &landed};
-    for (size_t sl = 0; sl < landed.size(); sl++) {
+    // per slice of 2^20 rows: pass 2 on the plan's stream, then — on the copy queue — the slice's narrow columns; the direct
+    // part (wide keys, bitmaps, value columns, NULL counts) follows the last slice
+    std::vector<hipEvent_t> landed(n_narrow > 0 ? n_slices : 0), produced(n_slices);
+    struct PutEvents { Context* c; std::vector<hipEvent_t>* v; ~PutEvents() { for (hipEvent_t e : *v) if (e) c->put_event(e); } } put_landed{ctx_, &landed}, put_produced{ctx_, &produced};
+    for (size_t sl = 0; sl < n_slices; sl++) {
       const size_t rows = std::min<size_t>(kSliceRows, (size_t)n - sl * kSliceRows);
+      a.row_begin = sl * kSliceRows; a.row_end = a.row_begin + rows;
+      hip_check(fdb_launch_hash_rows_to_columns(a, device_, stream_), "hash rows to columns");
+      produced[sl] = ctx_->get_event();
+      hip_check(hipEventRecord(produced[sl], stream_), "hipEventRecord");
+      hip_check(hipStreamWaitEvent(copy_stream, produced[sl], 0), "hipStreamWaitEvent");
+      if (n_narrow == 0) continue;
       const size_t bytes = rows == kSliceRows ? slice_stride : off_narrow[last_narrow] + rows * (size_t)width[last_narrow];  // (short last slice)
-      hip_check(hipMemcpyAsync(h_narrow + sl * slice_stride, d_narrow + sl * slice_stride, bytes, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(narrow slice)");
+      hip_check(hipMemcpyAsync(h_narrow + sl * slice_stride, d_narrow + sl * slice_stride, bytes, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(narrow slice)");
       landed[sl] = ctx_->get_event();
-      hip_check(hipEventRecord(landed[sl], stream_), "hipEventRecord");
+      hip_check(hipEventRecord(landed[sl], copy_stream), "hipEventRecord");
     }
-    hip_check(hipMemcpyAsync(h_block + direct_begin, d_block, direct_bytes, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(result)");
+    hip_check(hipMemcpyAsync(h_block + direct_begin, d_block, direct_bytes, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(result)");
     if (n_narrow > 0) {
       // one task = one narrow column of one slice
       std::vector<size_t> narrow_cols;
@@ -495,7 +509,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
       };
       const int n_threads = host_threads_for((size_t)n * n_narrow);
       if (n_threads <= 0) {
-        sync();
+        hip_check(hipStreamSynchronize(copy_stream), "hipStreamSynchronize(copy queue)");
         for (size_t t = 0; t < n_tasks; t++) run_task(t);
       } else {
         std::atomic<size_t> next{0}, ready_slices{0};
@@ -521,6 +535,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
           err = hipEventSynchronize(landed[sl]);
           if (err == hipSuccess) ready_slices.store(sl + 1, std::memory_order_release);
         }
+        if (pt.on) pt.mark("finish: slices landed");
         if (err != hipSuccess) failed.store(true);
         else work();  // this thread helps with what is left
         for (std::thread& w : workers) w.join();
@@ -528,9 +543,12 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
       }
     }
   }
+  if (pt.on) pt.mark("finish: widened");
+  if (copy_stream) hip_check(hipStreamSynchronize(copy_stream), "hipStreamSynchronize(copy queue)");
   sync();
   pt.mark("finish: copy");
   for (void* p : owned) ctx_->dev_free(p);
+  if (pt.on) pt.mark("finish: dev_free");
   // post-processing that needs the data on the host: NULL counts, float64 MIN/MAX key decoding
   for (size_t c = 0; c < n_cols && n > 0; c++) {
     OutColumn& oc = (*out)[c];
@@ -541,13 +559,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     }
     if (gcols_[c].kind == 0 && gcols_[c].plain)  // plain string / binary key column: entry indices → offsets + bytes
       set_plain_strings(&oc, (const uint32_t*)(h_block + off_key[c]), h_block + off_bits[c], (int64_t)n, gcols_[c].values, gcols_[c].value_format);
-    const size_t bytes = (size_t)(n + 7) / 8;
-    int64_t set = 0;
-    const uint64_t* w64 = (const uint64_t*)oc.ext_validity;
-    const size_t full = bytes / 8;
-    for (size_t i = 0; i < full; i++) set += __builtin_popcountll(w64[i]);
-    for (size_t i = full * 8; i < bytes; i++) set += __builtin_popcount(oc.ext_validity[i]);
-    oc.null_count = (int64_t)n - set;
+    oc.null_count = (int64_t)((const unsigned long long*)(h_block + off_nulls))[c];
   }
   for (size_t j = 0; j < aggs_.size() && n > 0; j++) {  // composite reducers: UNIQUE's validity, AND's bits
     const AggState& A = aggs_[j];

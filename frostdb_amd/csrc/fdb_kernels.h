@@ -272,17 +272,20 @@ hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32
 // 8 bytes — and cols[c].lut_len != 0 marks a SLICED column: out_key[c] + slice · slice_stride + (row in slice) · width with
 // 2^slice_shift rows per slice, so that one slice of all narrow columns is a contiguous run for the copy engine and the host can
 // widen slice k while slice k + 1 is in flight. Other columns: out_key[c] + row · width. out_vals[0] = counts, out_vals[1 + j] =
-// accumulator j (8 bytes per row); out_mask[row] bit c = column c of the row is valid (→ fdb_launch_hash_row_bitmaps).
+// accumulator j (8 bytes per row); out_bits[c] = the column's Arrow validity bitmap, padded to a multiple of 8 bytes (whole
+// 64-row words are stored); out_nulls[c] = its NULL count, ZEROED by the caller (n_cols ≤ 64). dense_keys: scratch of n_rows × key_words words (the occupied entries' key tuples as dense rows in
+// slot order: pass 1 gathers them from the slot-indexed key store, pass 2 transposes 64 rows at a time into the columns).
 struct FdbHashColumnsArgs {
   const unsigned long long* table; const uint32_t* keys; uint64_t capacity;
-  const FdbHashCol* cols; void* const* out_key; unsigned long long* out_mask; unsigned long long* const* out_vals;
+  const FdbHashCol* cols; void* const* out_key; uint8_t* const* out_bits; unsigned long long* const* out_vals;
   const uint32_t* bases;  // fdb_launch_hash_chunk_bases
+  uint32_t* dense_keys; uint64_t n_rows; unsigned long long* out_nulls;
+  uint64_t row_begin, row_end;  // pass 2 only: the output rows of this launch (row_begin a multiple of 64)
   uint64_t slice_stride;
   int32_t n_cols, entry_words, key_words, n_vals, slice_shift;
 };
-hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream);
-// bitmaps[c][row / 8] bit (row % 8) = bit c of row_mask[row]; whole 8-byte words are written (bitmaps padded to a multiple of 8 bytes).
-hipError_t fdb_launch_hash_row_bitmaps(const unsigned long long* row_mask, int64_t n, int n_cols, uint8_t* const* bitmaps, hipStream_t stream);
+hipError_t fdb_launch_hash_gather_rows(const FdbHashColumnsArgs& args, int device, hipStream_t stream);      // pass 1: all rows
+hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream);  // pass 2: rows [row_begin, row_end)
 // bits[i / 8] bit (i % 8) = bytes[i] != 0, for i < n (n rounded up to 8 inside; bytes must be readable up to the rounding).
 hipError_t fdb_launch_pack_bits(const uint8_t* bytes, uint8_t* bits, int64_t n, hipStream_t stream);
 

@@ -924,84 +924,125 @@ __global__ void hash_compact_kernel(const unsigned long long* table, const uint3
     }
   }
 }
-// Finish for big tables, one WAVE per 64-slot chunk. The occupied entries' key tuples are fetched cooperatively (lane ↦ word of
-// the chunk's tuples laid end to end: full 128-byte lines instead of 34 strided 4-byte loads per lane) into the wave's LDS tile
-// [row][key_words | 1] (odd pitch: conflict-free when lanes = rows), then every lane r < n_occ emits row base + r of each
-// column — dictionary indices at the column's transport width, int64 keys, count and accumulators — and ONE 64-bit word with
-// the row's validity bits of all columns (hash_row_bitmaps_kernel turns those into Arrow bitmaps). No workgroup barrier.
-__global__ __launch_bounds__(256) void hash_columns_kernel(const FdbHashColumnsArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int ew = a.entry_words, kw = a.key_words, kwp = kw | 1;
+// Finish for big tables, in two fully parallel passes (every wave-task is independent, so HBM latency is hidden by occupancy):
+//   1. hash_gather_rows_kernel: one wave per 64-slot chunk (grid-stride). The occupied entries' key tuples are fetched
+//      cooperatively — lane ↦ word of the chunk's tuples laid end to end, 16 loads in flight per lane — and stored as ROWS of a
+//      dense row-major scratch array in slot order (one contiguous run per chunk); count and accumulators go to their columns.
+//   2. hash_rows_to_columns_kernel: one wave per group of 64 OUTPUT rows: the group's rows (one contiguous read) are parked in
+//      the wave's LDS tile [64][key_words | 1] (odd pitch: conflict-free when lanes = rows), then each column leaves as one
+//      aligned 64 / 128 / 256 / 512-byte store (uint8 / uint16 / uint32 indices, 8-byte keys) plus one ballot = one 8-byte word of
+//      its validity bitmap.
+// History (cfg 5, 10 M groups × 32 columns, table of 33.5 M slots): one lane per slot writing 32 columns itself: 4.5 ms; one wave
+// per chunk emitting its ≈19 rows per column (44 M partial-line writes): 6.2 ms; a wave walking a contiguous range of chunks with an
+// LDS ring to emit aligned 64-row groups: 4.4 ms — 20 KB of LDS per wave left 6 waves per CU to hide a chain of dependent loads.
+__global__ __launch_bounds__(256) void hash_gather_rows_kernel(const FdbHashColumnsArgs a) {
+  __shared__ uint8_t slot_of_all[4][64];
+  const int ew = a.entry_words, kw = a.key_words, nv = a.n_vals;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* tile = reinterpret_cast<uint32_t*>(smem + (size_t)wave * ((size_t)64 * kwp * 4 + 64));
-  uint8_t* slot_of = reinterpret_cast<uint8_t*>(tile + 64 * kwp);
+  uint8_t* slot_of = slot_of_all[wave];
   const uint32_t magic = (uint32_t)((0x100000000ull + (unsigned)kw - 1ull) / (unsigned)kw);  // t / kw for t < 64 · kw
   const uint64_t n_chunks = (a.capacity + 63) >> 6;
-  const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-  for (uint64_t chunk = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave; chunk < n_chunks; chunk += n_waves) {
+  const uint64_t n_waves = (uint64_t)gridDim.x * 4;
+  for (uint64_t chunk = (uint64_t)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += n_waves) {
     const uint64_t i = chunk * 64 + lane;
     const unsigned long long* e = a.table + i * (uint64_t)ew;
     const bool occ = i < a.capacity && e[0] != 0ull;
     const unsigned long long m = __ballot(occ);
     if (m == 0ull) continue;
     const uint32_t n_occ = (uint32_t)__popcll(m);
-    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     const uint64_t base = a.bases[chunk];
     if (occ) {
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       slot_of[r] = (uint8_t)lane;
-      for (int v = 0; v < a.n_vals; v++) a.out_vals[v][base + r] = e[2 + v];
+      for (int v = 0; v < nv; v++) a.out_vals[v][base + r] = e[2 + v];
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t* kchunk = a.keys + chunk * 64 * (uint64_t)kw;
+    const uint32_t* src = a.keys + chunk * 64 * (uint64_t)kw;
+    uint32_t* dst = a.dense_keys + base * (uint64_t)kw;
     const uint32_t n_words = n_occ * (uint32_t)kw;
-    for (uint32_t t = lane; t < n_words; t += 64) {
-      const uint32_t rr = __umulhi(t, magic), w = t - rr * (uint32_t)kw;
-      tile[rr * kwp + w] = kchunk[(uint32_t)slot_of[rr] * (uint32_t)kw + w];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < n_occ) {
-      const uint32_t* k = tile + lane * kwp;
-      const uint64_t o = base + lane;
-      const unsigned long long vm = (unsigned long long)k[0] | ((unsigned long long)k[1] << 32);
-      unsigned long long row_mask = 0;
-      for (int c = 0; c < a.n_cols; c++) {
-        const FdbHashCol C = load_col(a.cols, c);
-        unsigned char* out = reinterpret_cast<unsigned char*>(a.out_key[c]);
-        const int width = C.src_word;  // (transport width of the column: 1, 2, 4 or 8 bytes)
-        // sliced columns: [slice][column][row in slice] — a slice of all narrow columns is one contiguous run for the copy engine
-        const uint64_t at = C.lut_len ? (o >> a.slice_shift) * a.slice_stride + (o & ((1ull << a.slice_shift) - 1ull)) * (uint64_t)width : o * (uint64_t)width;
-        if (C.kind == 0) {
-          const uint32_t id = k[C.word];
-          const uint32_t idx = id ? id - 1u : 0u;
-          if (width == 1) out[at] = (uint8_t)idx;
-          else if (width == 2) *reinterpret_cast<uint16_t*>(out + at) = (uint16_t)idx;
-          else *reinterpret_cast<uint32_t*>(out + at) = idx;
-          row_mask |= (unsigned long long)(id != 0u) << c;
-        } else {
-          const bool ok = (vm >> C.gi) & 1ull;
-          *reinterpret_cast<unsigned long long*>(out + at) = ok ? ((unsigned long long)k[C.word] | ((unsigned long long)k[C.word + 1] << 32)) : 0ull;
-          row_mask |= (unsigned long long)ok << c;
+    for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
+      uint32_t val[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+        if (t < n_words) {
+          const uint32_t rr = __umulhi(t, magic), w = t - rr * (uint32_t)kw;
+          val[u] = src[(uint32_t)slot_of[rr] * (uint32_t)kw + w];
         }
       }
-      a.out_mask[o] = row_mask;
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+        if (t < n_words) dst[t] = val[u];
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-// Row masks (bit c = column c of the row is valid) → one Arrow validity bitmap per column: a wave takes 64 rows, one ballot and
-// one 8-byte store per column.
-__global__ __launch_bounds__(256) void hash_row_bitmaps_kernel(const unsigned long long* __restrict__ row_mask, int64_t n, int n_cols, uint8_t* const* bitmaps) {
-  const int lane = threadIdx.x & 63;
-  const int64_t n_groups = (n + 63) >> 6;
-  for (int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < n_groups; g += ((int64_t)gridDim.x * blockDim.x) >> 6) {
-    const int64_t row = g * 64 + lane;
-    const unsigned long long m = row < n ? row_mask[row] : 0ull;
-    for (int c = 0; c < n_cols; c++) {
-      const unsigned long long w = __ballot((m >> c) & 1ull);
-      if (lane == 0) reinterpret_cast<unsigned long long*>(bitmaps[c])[g] = w;
+__global__ __launch_bounds__(256) void hash_rows_to_columns_kernel(const FdbHashColumnsArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ unsigned int s_nulls[64];  // NULLs per column seen by this workgroup (flushed once at the end)
+  if (threadIdx.x < 64) s_nulls[threadIdx.x] = 0u;
+  __syncthreads();
+  const int kw = a.key_words, pitch = kw | 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * 64 * pitch;
+  const uint32_t magic = (uint32_t)((0x100000000ull + (unsigned)kw - 1ull) / (unsigned)kw);
+  const uint64_t n_groups = ((a.row_end < a.n_rows ? a.row_end : a.n_rows) + 63) >> 6;
+  for (uint64_t G = (a.row_begin >> 6) + (uint64_t)blockIdx.x * 4 + wave; G < n_groups; G += (uint64_t)gridDim.x * 4) {
+    const uint32_t rows = (uint32_t)(a.n_rows - G * 64 < 64 ? a.n_rows - G * 64 : 64);
+    const uint32_t* src = a.dense_keys + G * 64 * (uint64_t)kw;
+    const uint32_t n_words = rows * (uint32_t)kw;
+    for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
+      uint32_t val[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+        if (t < n_words) val[u] = src[t];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+        if (t < n_words) { const uint32_t rr = __umulhi(t, magic); tile[rr * pitch + (t - rr * (uint32_t)kw)] = val[u]; }
+      }
     }
+    __builtin_amdgcn_wave_barrier();
+    const bool active = (uint32_t)lane < rows;
+    const uint64_t o = G * 64 + lane;
+    const uint32_t* k = tile + lane * pitch;
+    const unsigned long long vm = active ? (unsigned long long)k[0] | ((unsigned long long)k[1] << 32) : 0ull;
+    for (int c = 0; c < a.n_cols; c++) {
+      const FdbHashCol C = load_col(a.cols, c);
+      unsigned char* out = reinterpret_cast<unsigned char*>(a.out_key[c]);
+      const int width = C.src_word;  // (transport width of the column: 1, 2, 4 or 8 bytes)
+      // sliced columns: [slice][column][row in slice] — a slice of all narrow columns is one contiguous run for the copy engine
+      const uint64_t at = C.lut_len ? (o >> a.slice_shift) * a.slice_stride + (o & ((1ull << a.slice_shift) - 1ull)) * (uint64_t)width : o * (uint64_t)width;
+      bool ok = false;
+      if (active) {
+        if (C.kind == 0) {
+          const uint32_t id = k[C.word];
+          const uint32_t idx = id ? id - 1u : 0u;
+          ok = id != 0u;
+          if (width == 1) out[at] = (uint8_t)idx;
+          else if (width == 2) *reinterpret_cast<uint16_t*>(out + at) = (uint16_t)idx;
+          else *reinterpret_cast<uint32_t*>(out + at) = idx;
+        } else {
+          ok = (vm >> C.gi) & 1ull;
+          *reinterpret_cast<unsigned long long*>(out + at) = ok ? ((unsigned long long)k[C.word] | ((unsigned long long)k[C.word + 1] << 32)) : 0ull;
+        }
+      }
+      const unsigned long long w = __ballot(ok);
+      if (lane == 0) {
+        reinterpret_cast<unsigned long long*>(a.out_bits[c])[G] = w;
+        const uint32_t nulls = rows - (uint32_t)__popcll(w);
+        if (nulls != 0u) atomicAdd(&s_nulls[c], nulls);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();
+  if ((int)threadIdx.x < a.n_cols && s_nulls[threadIdx.x] != 0u) atomicAdd(a.out_nulls + threadIdx.x, (unsigned long long)s_nulls[threadIdx.x]);
 }
 
 // Multi-workgroup exclusive scan, step 1 and 3 (step 2 = scan_counts_kernel over the per-1024 sums).
@@ -1799,25 +1840,27 @@ hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t strea
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_hash_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream) {
+hipError_t fdb_launch_hash_gather_rows(const FdbHashColumnsArgs& args, int device, hipStream_t stream) {
   const int64_t n_chunks = (int64_t)((args.capacity + 63) / 64);
-  if (n_chunks == 0) return hipSuccess;
-  const size_t lds = 4 * ((size_t)64 * (size_t)(args.key_words | 1) * 4 + 64);  // one tile per wave
-  if (lds > 150 * 1024) return hipErrorInvalidValue;
-  if (lds > 48 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_columns_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return e;
-  }
-  const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)(150 * 1024 / lds)));
-  const int64_t grid = std::min<int64_t>((n_chunks + 3) / 4, (int64_t)fdb_scan_default_grid(device) * per_cu);
-  hipLaunchKernelGGL(hash_columns_kernel, dim3((unsigned)grid), dim3(256), lds, stream, args);
+  if (n_chunks == 0 || args.n_rows == 0) return hipSuccess;
+  const int64_t cus = fdb_scan_default_grid(device) / 2;
+  hipLaunchKernelGGL(hash_gather_rows_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + 3) / 4, cus * 16)), dim3(256), 0, stream, args);
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_hash_row_bitmaps(const unsigned long long* row_mask, int64_t n, int n_cols, uint8_t* const* bitmaps, hipStream_t stream) {
-  if (n <= 0 || n_cols <= 0) return hipSuccess;
-  const int64_t groups = (n + 63) / 64;
-  hipLaunchKernelGGL(hash_row_bitmaps_kernel, dim3((unsigned)std::min<int64_t>((groups + 3) / 4, 8192)), dim3(256), 0, stream, row_mask, n, n_cols, bitmaps);
+hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream) {
+  const uint64_t end = std::min<uint64_t>(args.row_end, args.n_rows);
+  if (args.row_begin >= end) return hipSuccess;
+  if ((args.row_begin & 63u) != 0u) return hipErrorInvalidValue;
+  const size_t lds = (size_t)4 * 64 * (size_t)(args.key_words | 1) * 4;  // one tile per wave
+  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_rows_to_columns_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  const int64_t cus = fdb_scan_default_grid(device) / 2;
+  const int64_t n_groups = (int64_t)((end - args.row_begin + 63) / 64);
+  hipLaunchKernelGGL(hash_rows_to_columns_kernel, dim3((unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * 16)), dim3(256), lds, stream, args);
   return hipGetLastError();
 }
 
