@@ -402,6 +402,20 @@ struct FdbPqRun {
 };
 // A data page with PLAIN fixed-width values: value ranks [rank_start, next page's rank_start) live at byte_off + 8·(rank − rank_start).
 struct FdbPqPlainPage { int64_t rank_start; int64_t byte_off; };
+// DELTA_BINARY_PACKED (INT64): a page's values are first + prefix sums of (min_delta of the block + bit-packed delta). The host
+// reads the page / block headers only; a miniblock = `vpm` deltas packed at one bit width.
+struct FdbPqDeltaMini { uint64_t bit_off; uint64_t min_delta; uint32_t width; uint32_t _pad; };  // bit_off: of its first delta, in the chunk
+struct FdbPqDeltaPage {
+  int64_t rank_start;    // rank (index among the column's non-NULL values) of the page's first value
+  int64_t n_values;      // values in the page (≥ 1)
+  uint64_t first_value;
+  int32_t mini_begin;    // the page's miniblocks are minis[mini_begin …]; delta d of the page lives in miniblock d / vpm
+  int32_t vpm;           // deltas per miniblock
+};
+// dense[rank] = value for every non-NULL value of the column (one workgroup per page: unpack, add min_delta, block-wide inclusive
+// scan with the running total of the page carried from tile to tile; int64 arithmetic wraps like the reference's decoder).
+hipError_t fdb_launch_pq_delta(const uint8_t* chunk, const FdbPqDeltaPage* pages, int32_t n_pages, const FdbPqDeltaMini* minis, unsigned long long* dense,
+                               hipStream_t stream);
 // validity[w] = the 32 definition levels (max level 1) of rows 32w … 32w+31, counts[w] = popcount; rows ≥ n_rows are 0.
 hipError_t fdb_launch_pq_validity(const uint8_t* chunk, const FdbPqRun* def_runs, int32_t n_runs, int64_t n_rows, uint32_t* validity, uint32_t* counts,
                                   hipStream_t stream);

@@ -1363,6 +1363,58 @@ __global__ void pq_decode_kernel(const uint8_t* __restrict__ chunk, const uint32
   }
 }
 
+// One workgroup per page (grid-stride), 1 024 values per step: 4 consecutive values per thread.
+__global__ __launch_bounds__(256) void pq_delta_kernel(const uint8_t* __restrict__ chunk, const FdbPqDeltaPage* __restrict__ pages, int n_pages,
+                                                       const FdbPqDeltaMini* __restrict__ minis, unsigned long long* __restrict__ dense) {
+  __shared__ unsigned long long wave_sum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int pg = blockIdx.x; pg < n_pages; pg += gridDim.x) {
+    const FdbPqDeltaPage P = pages[pg];
+    unsigned long long carry = 0;  // sum of everything before this step (wave-uniform)
+    for (int64_t j0 = 0; j0 < P.n_values; j0 += 1024) {
+      unsigned long long x[4], s = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int64_t j = j0 + (int64_t)tid * 4 + u;
+        x[u] = 0;
+        if (j < P.n_values) {
+          if (j == 0) x[u] = P.first_value;
+          else {
+            const int64_t d = j - 1;
+            const FdbPqDeltaMini M = minis[P.mini_begin + (int)(d / P.vpm)];
+            unsigned long long v = 0;
+            if (M.width != 0u) {
+              const uint64_t bit = M.bit_off + (uint64_t)(d % P.vpm) * M.width;
+              const uint32_t sh = (uint32_t)(bit & 7u);
+              v = pq_load64(chunk, bit >> 3) >> sh;
+              if (sh + M.width > 64u) v |= (pq_load64(chunk, (bit >> 3) + 8) & 0xFFull) << (64u - sh);
+              if (M.width < 64u) v &= (1ull << M.width) - 1ull;
+            }
+            x[u] = M.min_delta + v;
+          }
+        }
+        s += x[u];
+      }
+      unsigned long long incl = s;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+      __syncthreads();  // (wave_sum of the previous step has been read by everyone)
+      if (lane == 63) wave_sum[wave] = incl;
+      __syncthreads();
+      unsigned long long run = carry + incl - s;
+      for (int w = 0; w < wave; w++) run += wave_sum[w];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int64_t j = j0 + (int64_t)tid * 4 + u;
+        run += x[u];
+        if (j < P.n_values) dense[P.rank_start + j] = run;
+      }
+      carry += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- import validation: every dictionary index of a VALID row must be below the dictionary's length ----------------------------
 // (Arrow forbids anything else; the scan kernels index LUTs with these values, so a malformed record must become an error code
 // at import — ≙ the reference's recovered panic, recovery/recovery.go:13-30 — not an out-of-bounds read on the device.)
@@ -1717,6 +1769,13 @@ hipError_t fdb_launch_pq_decode(int kind, const uint8_t* chunk, const uint32_t* 
   if (blocks > 16384) blocks = 16384;
   if (kind == 0) hipLaunchKernelGGL(pq_decode_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, chunk, validity, prefix, pages, n_pages, idx_runs, n_idx_runs, n_rows, out);
   else hipLaunchKernelGGL(pq_decode_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, chunk, validity, prefix, pages, n_pages, idx_runs, n_idx_runs, n_rows, out);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_pq_delta(const uint8_t* chunk, const FdbPqDeltaPage* pages, int32_t n_pages, const FdbPqDeltaMini* minis, unsigned long long* dense,
+                               hipStream_t stream) {
+  if (n_pages <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pq_delta_kernel, dim3((unsigned)std::min(n_pages, 8192)), dim3(256), 0, stream, chunk, pages, n_pages, minis, dense);
   return hipGetLastError();
 }
 

@@ -10,7 +10,7 @@
 //
 // First slice (what FrostDB's default layouts produce, dynparquet/schema.go:508-560): flat schemas; INT64 / DOUBLE columns with
 // PLAIN data pages; BYTE_ARRAY columns with a PLAIN dictionary page + RLE_DICTIONARY data pages (→ dictionary<uint32, binary>,
-// pqarrow/convert/convert.go:64-70); required or optional (max definition level 1); data pages V1 and V2; pages UNCOMPRESSED, or SNAPPY / GZIP / ZSTD / LZ4_RAW (inflated on the host while the page headers are walked).
+// pqarrow/convert/convert.go:64-70); required or optional (max definition level 1); data pages V1 and V2; INT64 also DELTA_BINARY_PACKED (the reference's default for struct-tag schemas, internal/records/record_builder.go:146-148); pages UNCOMPRESSED, or SNAPPY / GZIP / ZSTD / LZ4_RAW (inflated on the host while the page headers are walked).
 // Anything else (DELTA_* encodings, compressed pages, dictionary fallback to PLAIN, nested columns) is FDB_ERR_UNSUPPORTED.
 #include <dlfcn.h>
 #include <zlib.h>
@@ -89,7 +89,7 @@ struct Thrift {
 };
 
 enum { PQ_DATA_PAGE = 0, PQ_DICTIONARY_PAGE = 2, PQ_DATA_PAGE_V2 = 3 };
-enum { ENC_PLAIN = 0, ENC_PLAIN_DICTIONARY = 2, ENC_RLE = 3, ENC_RLE_DICTIONARY = 8 };
+enum { ENC_PLAIN = 0, ENC_PLAIN_DICTIONARY = 2, ENC_RLE = 3, ENC_DELTA_BINARY_PACKED = 5, ENC_RLE_DICTIONARY = 8 };
 
 struct PageHeader {
   int32_t type = -1, uncompressed = 0, compressed = 0;
@@ -292,6 +292,8 @@ struct ParsedChunk {
   std::vector<FdbPqRun> def_runs;          // optional columns: one entry per run, row-numbered
   std::vector<FdbPqRun> idx_runs;          // dictionary-encoded columns: rank-numbered
   std::vector<FdbPqPlainPage> plain_pages; // PLAIN fixed-width columns
+  std::vector<FdbPqDeltaPage> delta_pages; // DELTA_BINARY_PACKED INT64 columns
+  std::vector<FdbPqDeltaMini> delta_minis;
   int64_t non_null = 0;
   uint32_t max_index_bits = 0;
 };
@@ -370,9 +372,44 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
       voff += 4 + dl; vlen -= 4 + dl;
     }
     if (is_fixed8) {
-      if (h.encoding != ENC_PLAIN) throw Error(FDB_ERR_UNSUPPORTED, "parquet: INT64 / DOUBLE pages must be PLAIN (DELTA_BINARY_PACKED is not decoded on the device yet)");
-      if ((size_t)page_non_null * 8 > vlen) throw Error(FDB_ERR_INVALID, "parquet: PLAIN page shorter than its values");
-      out.plain_pages.push_back(FdbPqPlainPage{rank_done, (int64_t)voff});
+      if (h.encoding == ENC_DELTA_BINARY_PACKED && c.physical_type == 2) {
+        // <block size> <miniblocks per block> <total value count> <first value> then per block <min delta> <bit widths> <miniblocks>
+        // (parquet-format Encodings.md): only the headers are read here, the deltas are unpacked and summed on the device
+        if (!out.plain_pages.empty()) throw Error(FDB_ERR_UNSUPPORTED, "parquet: PLAIN and DELTA_BINARY_PACKED pages in one column chunk");
+        if (page_non_null > 0) {
+          Thrift d{base + voff, base + voff + vlen};
+          const uint64_t block = d.varint(), n_mini = d.varint(), count = d.varint();
+          const uint64_t first = (uint64_t)d.zigzag();
+          if (block == 0 || block % 128 != 0 || n_mini == 0 || block % n_mini != 0 || (block / n_mini) % 32 != 0 || block > (1u << 24))
+            throw Error(FDB_ERR_INVALID, "parquet: malformed DELTA_BINARY_PACKED header");
+          if ((int64_t)count != page_non_null) throw Error(FDB_ERR_INVALID, "parquet: DELTA_BINARY_PACKED value count differs from the page's");
+          const uint64_t vpm = block / n_mini;
+          FdbPqDeltaPage P{rank_done, page_non_null, first, (int32_t)out.delta_minis.size(), (int32_t)vpm};
+          uint64_t left = count - 1;  // deltas still to be located
+          while (left > 0) {
+            const uint64_t min_delta = (uint64_t)d.zigzag();
+            if ((size_t)(d.end - d.p) < n_mini) throw Error(FDB_ERR_INVALID, "parquet: DELTA_BINARY_PACKED block truncated");
+            const uint8_t* widths = d.p;
+            d.p += n_mini;
+            for (uint64_t m = 0; m < n_mini && left > 0; m++) {  // (miniblocks past the last value have no body)
+              const uint32_t w = widths[m];
+              if (w > 64) throw Error(FDB_ERR_INVALID, "parquet: DELTA_BINARY_PACKED bit width > 64");
+              const size_t bytes = (size_t)(vpm / 8) * w;
+              if ((size_t)(d.end - d.p) < bytes) throw Error(FDB_ERR_INVALID, "parquet: DELTA_BINARY_PACKED miniblock truncated");
+              out.delta_minis.push_back(FdbPqDeltaMini{(uint64_t)(d.p - base) * 8u, min_delta, w, 0u});
+              d.p += bytes;
+              left -= std::min<uint64_t>(left, vpm);
+            }
+          }
+          if (out.delta_minis.size() > 0x7FFFFFF0u) throw Error(FDB_ERR_UNSUPPORTED, "parquet: too many DELTA_BINARY_PACKED miniblocks");
+          out.delta_pages.push_back(P);
+        }
+      } else {
+        if (h.encoding != ENC_PLAIN) throw Error(FDB_ERR_UNSUPPORTED, "parquet: INT64 pages must be PLAIN or DELTA_BINARY_PACKED, DOUBLE pages PLAIN");
+        if (!out.delta_pages.empty()) throw Error(FDB_ERR_UNSUPPORTED, "parquet: PLAIN and DELTA_BINARY_PACKED pages in one column chunk");
+        if ((size_t)page_non_null * 8 > vlen) throw Error(FDB_ERR_INVALID, "parquet: PLAIN page shorter than its values");
+        out.plain_pages.push_back(FdbPqPlainPage{rank_done, (int64_t)voff});
+      }
     } else {
       if (h.encoding != ENC_RLE_DICTIONARY && h.encoding != ENC_PLAIN_DICTIONARY)
         throw Error(FDB_ERR_UNSUPPORTED, "parquet: BYTE_ARRAY pages must be dictionary-encoded (a writer that fell back to PLAIN is not supported on the device path)");
@@ -466,9 +503,25 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
       if (P.idx_runs.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 4, stream), "hipMemsetAsync");
       else hip_check(fdb_launch_pq_decode(1, d_chunk, d_valid, d_prefix, nullptr, 0, d_idx, (int32_t)P.idx_runs.size(), n_rows, d_out, stream), "parquet decode");
     } else {
+      if (!P.delta_pages.empty()) {
+        // DELTA_BINARY_PACKED: the non-NULL values are decoded densely (rank order) — straight into the column when it is
+        // required (rank = row), else into a scratch array that the row kernel then reads like one PLAIN page
+        const FdbPqDeltaPage* d_dp = (const FdbPqDeltaPage*)to_device(P.delta_pages.data(), P.delta_pages.size() * sizeof(FdbPqDeltaPage));
+        const FdbPqDeltaMini* d_dm = (const FdbPqDeltaMini*)to_device(P.delta_minis.data(), P.delta_minis.size() * sizeof(FdbPqDeltaMini));
+        unsigned long long* dense = (unsigned long long*)d_out;
+        if (c.optional) { dense = (unsigned long long*)ctx->dev_alloc((size_t)P.non_null * 8 + 64); scratch.push_back(dense); }
+        else if (P.non_null != n_rows) throw Error(FDB_ERR_INVALID, "parquet: required column with fewer values than rows");
+        hip_check(fdb_launch_pq_delta(d_chunk, d_dp, (int32_t)P.delta_pages.size(), d_dm, dense, stream), "parquet delta decode");
+        if (c.optional) {
+          static const FdbPqPlainPage kWhole{0, 0};  // (static: the copy below is asynchronous)
+          const FdbPqPlainPage* d_one = (const FdbPqPlainPage*)to_device(&kWhole, sizeof(kWhole));
+          hip_check(fdb_launch_pq_decode(0, (const uint8_t*)dense, d_valid, d_prefix, d_one, 1, nullptr, 0, n_rows, d_out, stream), "parquet decode");
+        }
+      } else {
       const FdbPqPlainPage* d_pages = (const FdbPqPlainPage*)to_device(P.plain_pages.data(), P.plain_pages.size() * sizeof(FdbPqPlainPage));
       if (P.plain_pages.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 8, stream), "hipMemsetAsync");
       else hip_check(fdb_launch_pq_decode(0, d_chunk, d_valid, d_prefix, d_pages, (int32_t)P.plain_pages.size(), nullptr, 0, n_rows, d_out, stream), "parquet decode");
+      }
     }
     if (d_totals[(size_t)i] != nullptr)
       hip_check(hipMemcpyAsync(&h_totals[(size_t)i], d_totals[(size_t)i], 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(non-null count)");

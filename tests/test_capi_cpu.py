@@ -267,6 +267,15 @@ def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(good, rows + 1)
     assert e.value.code == pp.FDB_ERR_INVALID
+    # DELTA_BINARY_PACKED INT64 pages: block / miniblock headers are walked on the host (the deltas are unpacked on the device)
+    delta, rows = row_group_chunks(write_parquet(t, use_dictionary=["labels.a"], column_encoding={"ts": "DELTA_BINARY_PACKED"}), 0)
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet(delta, rows)
+    assert e.value.code == pp.FDB_ERR_DEVICE, str(e.value)
+    short = [(nm, ty, opt, u8, data[: len(data) - 40] if nm == "ts" else data, cd) for nm, ty, opt, u8, data, cd in delta]
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet(short, rows)
+    assert e.value.code == pp.FDB_ERR_INVALID
     # compressed pages are inflated on the host while the headers are walked: a sound chunk reaches the device call, a chunk
     # whose compressed bytes were damaged (or that names the wrong codec) is refused before it
     for codec in ("SNAPPY", "GZIP", "ZSTD", "LZ4"):

@@ -99,6 +99,31 @@ def test_compressed_pages_decode_bit_identically(pp, codec, version):
         rb.close()
 
 
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+@pytest.mark.parametrize("n", [1, 2, 33, 129, 1025, 70_001, 300_000])
+def test_delta_binary_packed_int64_columns(pp, n, version):
+    """DELTA_BINARY_PACKED (the reference's default encoding for int64 fields of struct-tag schemas): regular timestamps (narrow
+    deltas), a constant column (width 0), random int64 values (64-bit deltas that wrap), an optional column with NULLs (values are
+    packed by rank) and an all-NULL one; several pages and, for the big case, two row groups; SNAPPY on top for one size."""
+    rng = np.random.default_rng(n)
+    t = pa.table({
+        "labels.a": pa.array([b"v%d" % (i % 7) for i in range(n)], type=pa.binary()),
+        "ts": pa.array(1_700_000_000_000 + np.cumsum(rng.integers(0, 30, n)).astype(np.int64)),
+        "const": pa.array(np.full(n, -42, dtype=np.int64)),
+        "wild": pa.array(rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64)),
+        "opt": pa.array(rng.integers(-10**9, 10**9, n), mask=rng.random(n) < 0.3),
+        "none": pa.array([None] * n, type=pa.int64()),
+        "value": pa.array(rng.normal(size=n)),
+    }, schema=pa.schema([pa.field("labels.a", pa.binary()), pa.field("ts", pa.int64(), nullable=False), pa.field("const", pa.int64(), nullable=False),
+                         pa.field("wild", pa.int64(), nullable=False), pa.field("opt", pa.int64()), pa.field("none", pa.int64()), pa.field("value", pa.float64())]))
+    enc = {c: "DELTA_BINARY_PACKED" for c in ("ts", "const", "wild", "opt", "none")}
+    data = write_parquet(t, use_dictionary=["labels.a"], column_encoding=enc, data_page_version=version, data_page_size=8 * 1024,
+                         row_group_size=200_000, compression="SNAPPY" if n == 70_001 else "NONE")
+    for rg in range(pq.ParquetFile(io.BytesIO(data)).metadata.num_row_groups):
+        rb, _ = decoded_equals_pyarrow(pp, data, rg)
+        rb.close()
+
+
 def test_several_row_groups_all_null_columns_and_wide_dictionaries(pp):
     """Row groups are decoded one by one; a column that is entirely NULL, a dictionary of 70 000 entries (17-bit indices) and a
     required column whose pages carry no definition levels."""
