@@ -529,55 +529,9 @@ struct HashGen {
   static const char* comp4(int k) { static const char* c[4] = {".x", ".y", ".z", ".w"}; return c[k]; }
   static std::string comp8(const std::string& r, int k) { return r + (k < 2 ? "a" : "b") + (k % 2 == 0 ? ".x" : ".y"); }
 
-  // The lane that created a group writes its key tuple: the row's columns are re-read (all loads of 16 columns in flight
-  // at once, then their key-id lookups, then the stores — two memory round trips per 16 columns instead of three per column).
-  void write_key_fn() {
-    o << "__device__ __forceinline__ void write_key(const FdbHashArgs& h, const unsigned char* smem, long long row, uint64_t slot, unsigned long long vmask) {\n";
-    o << "  const __attribute__((address_space(4))) FdbHashCol* hc = (const __attribute__((address_space(4))) FdbHashCol*)h.hcols;\n";
-    o << "  uint32_t* dst = h.keys + slot * (uint64_t)h.key_words;\n";
-    o << "  for (int w = 2; w < h.key_words; w++) dst[w] = 0u;  // columns this record does not carry are NULL\n";
-    o << "  dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);\n";
-    o << "  const uint32_t vsh = (uint32_t)(row & 7);\n";
-    for (size_t i = 0; i < s.exprs.size(); i++) if (s.exprs[i].kind == 1) o << "  const long long K_elit" << i << " = h.base.expr[" << i << "].lit; (void)K_elit" << i << ";\n";
-    const size_t G = 16;
-    for (size_t c0 = 0; c0 < s.cols.size(); c0 += G) {
-      const size_t c1 = std::min(s.cols.size(), c0 + G);
-      o << "  {\n";
-      for (size_t c = c0; c < c1; c++) {
-        if (s.cols[c].kind == 0) o << "    const uint32_t x" << c << " = as_global(reinterpret_cast<const uint32_t*>(hc[" << c << "].values))[row];\n";
-        else if (s.cols[c].kind == 1) o << "    const unsigned long long x" << c << " = as_global(reinterpret_cast<const unsigned long long*>(hc[" << c << "].values))[row];\n";
-        else {  // computed key: evaluate its expression for this row again
-          auto col = [&](int ni) { return "as_global(reinterpret_cast<const unsigned long long*>(h.base.l8[" + std::to_string(s.exprs[(size_t)ni].slot) + "].values))[row]"; };
-          auto colvalid = [&](int ni) {
-            const std::string b = "h.base.l8[" + std::to_string(s.exprs[(size_t)ni].slot) + "].validity";
-            return "(" + b + " == nullptr || ((as_global(" + b + ")[row >> 3] >> vsh) & 1u))";
-          };
-          o << "    const bool ok" << c << " = " << expr_valid(s.exprs, s.cols[c].expr_root, col, colvalid) << ";\n";
-          o << "    const unsigned long long x" << c << " = " << expr_bits(s.exprs, s.cols[c].expr_root, expr_value(s.exprs, s.cols[c].expr_root, col, colvalid)) << ";\n";
-        }
-        if (s.cols[c].has_validity) o << "    const uint32_t v" << c << " = as_global(hc[" << c << "].validity)[row >> 3];\n";
-      }
-      for (size_t c = c0; c < c1; c++) {
-        const std::string ok = s.cols[c].has_validity ? ("((v" + std::to_string(c) + " >> vsh) & 1u)") : "true";
-        if (s.cols[c].kind == 0) {
-          const std::string lut = s.cols[c].lut_in_lds ? ("reinterpret_cast<const uint32_t*>(smem + hc[" + std::to_string(c) + "].lut_lds)") : ("as_global(hc[" + std::to_string(c) + "].lut)");
-          o << "    const uint32_t i" << c << " = " << ok << " ? " << lut << "[x" << c << "] : 0u;\n";
-        }
-      }
-      for (size_t c = c0; c < c1; c++) {
-        const std::string ok = s.cols[c].kind == 2 ? ("ok" + std::to_string(c)) : s.cols[c].has_validity ? ("((v" + std::to_string(c) + " >> vsh) & 1u)") : "true";
-        if (s.cols[c].kind == 0) o << "    dst[hc[" << c << "].word] = i" << c << ";\n";
-        else o << "    { const unsigned long long y = " << ok << " ? x" << c << " : 0ull; dst[hc[" << c << "].word] = (uint32_t)y; dst[hc[" << c << "].word + 1] = (uint32_t)(y >> 32); }\n";
-      }
-      o << "  }\n";
-    }
-    o << "}\n";
-  }
-
   std::string source() {
     const int BLK = 256, TILE = BLK * 4, GROUP = 8;
     o << "#define FDB_DEVICE_HELPERS 1\n#include \"fdb_kernels.h\"\n" << kPreamble << kHashPreamble;
-    write_key_fn();
     o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") void fdb_hash_kernel(const FdbHashArgs h) {\n";
     o << "  extern __shared__ __align__(16) unsigned char smem[];\n  __shared__ unsigned int s_new;\n";
     o << "  const FdbScanArgs& a = h.base;\n  // descriptors are read through the constant address space: scalar loads, no vector registers\n  const __attribute__((address_space(4))) FdbHashCol* hc = (const __attribute__((address_space(4))) FdbHashCol*)h.hcols;\n  const uint32_t tid = threadIdx.x;\n  if (tid == 0) s_new = 0;\n";
@@ -736,10 +690,19 @@ struct HashGen {
     for (int k = 0; k < 4; k++)
       o << "    if ((sel >> " << k << ") & 1u) { const u64x2 pq = *as_global(reinterpret_cast<const u64x2*>(h.table + slot_" << k << " * (uint64_t)ew)); p_" << k << " = pq.x; q_" << k
         << " = pq.y; }\n";
+    // Rows whose home entry looked EMPTY claim it right away — the (up to) four compare-and-swaps of a lane are in flight together
+    // instead of one dependent load + CAS per row — and every winner publishes the high half of its fingerprint before any lane
+    // of the wave enters the general path below (a lane that lost to a lane of its own wave spins there until it sees the
+    // published half: the publication must not sit behind that loop in a sibling branch).
     o << "    uint32_t ins_mask = 0;\n";
+    for (int k = 0; k < 4; k++) o << "    unsigned long long c_" << k << " = ~0ull;\n";
+    for (int k = 0; k < 4; k++)
+      o << "    if (((sel >> " << k << ") & 1u) && p_" << k << " == 0ull) c_" << k << " = atomicCAS(h.table + slot_" << k << " * (uint64_t)ew, 0ull, h1_" << k << ");\n";
+    for (int k = 0; k < 4; k++)
+      o << "    if (c_" << k << " == 0ull) { __hip_atomic_store(h.table + slot_" << k << " * (uint64_t)ew + 1, h2_" << k << ", __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ins_mask |= " << (1 << k) << "u; }\n";
     for (int k = 0; k < 4; k++) {
       o << "    if ((sel >> " << k << ") & 1u) {\n";
-      o << "      if (!(p_" << k << " == h1_" << k << " && q_" << k << " == h2_" << k << ")) { bool ins; slot_" << k << " = hash_find_or_insert(h.table, h.mask, ew, h1_" << k << ", h2_" << k
+      o << "      if (c_" << k << " != 0ull && !(p_" << k << " == h1_" << k << " && q_" << k << " == h2_" << k << ")) { bool ins; slot_" << k << " = hash_find_or_insert(h.table, h.mask, ew, h1_" << k << ", h2_" << k
         << ", ins); if (ins) ins_mask |= " << (1 << k) << "u; }\n";
       o << "      unsigned long long* e = h.table + slot_" << k << " * (uint64_t)ew;\n";
       if (!(s.ablate & 2) && s.need_count) o << "      atomicAdd(e + 2, cnt_" << k << ");\n";
@@ -754,10 +717,64 @@ struct HashGen {
       }
       o << "    }\n";
     }
-    // key tuples of the groups this lane created
-    o << "    while (ins_mask != 0u) {\n      const int k = __builtin_ctz(ins_mask);\n      ins_mask &= ins_mask - 1u;\n";
-    o << "      const uint64_t slot = k == 0 ? slot_0 : k == 1 ? slot_1 : k == 2 ? slot_2 : slot_3;\n      const unsigned long long vm = k == 0 ? vm_0 : k == 1 ? vm_1 : k == 2 ? vm_2 : vm_3;\n";
-    o << "      write_key(h, smem, r0 + (long long)tid * 4 + k, slot, vm);\n      atomicAdd(&s_new, 1u);\n    }\n";
+    // Key tuples of the groups this lane created. The lane's 4 rows are consecutive, so one 16-byte load per column (two for
+    // 8-byte keys) brings the values of all of them; 8 columns' loads are in flight together, then their key-id lookups, then
+    // the stores — 4 memory round trips for 32 columns however many of the lane's rows inserted (one row at a time, re-reading
+    // column by column, cost 2 round trips per 16 columns and inserted row and made insert-heavy launches 5 × slower per row).
+    int covered = 2;
+    for (const JitHashCol& C : s.cols) covered += C.kind == 0 ? 1 : 2;
+    o << "    if (ins_mask != 0u) {\n";
+    o << "      atomicAdd(&s_new, (unsigned int)__builtin_popcount(ins_mask));\n";
+    // (fresh opaque lane offsets: with the tile's own the compiler recognises these loads as the fingerprint phase's and keeps
+    // all 32 columns' values — 128 VGPRs — alive from there to here instead of re-loading)
+    o << "      uint32_t ioff4 = lane_off4, ioff8 = lane_off8, ioffb = lane_offb;\n      asm volatile(\"\" : \"+v\"(ioff4), \"+v\"(ioff8), \"+v\"(ioffb));\n";
+    for (int k = 0; k < 4; k++) o << "      uint32_t* d_" << k << " = h.keys + slot_" << k << " * (uint64_t)h.key_words;\n";
+    o << "      if (h.key_words != " << covered << ") {  // columns this record does not carry are NULL\n";
+    for (int k = 0; k < 4; k++) o << "        if (ins_mask & " << (1 << k) << "u) for (int w = 2; w < h.key_words; w++) d_" << k << "[w] = 0u;\n";
+    o << "      }\n";
+    for (int k = 0; k < 4; k++) o << "      if (ins_mask & " << (1 << k) << "u) { d_" << k << "[0] = (uint32_t)vm_" << k << "; d_" << k << "[1] = (uint32_t)(vm_" << k << " >> 32); }\n";
+    for (size_t c0 = 0; c0 < s.cols.size(); c0 += GROUP) {
+      const size_t c1 = std::min(s.cols.size(), c0 + GROUP);
+      o << "      {\n";
+      for (size_t c = c0; c < c1; c++) {
+        const JitHashCol& C = s.cols[c];
+        const std::string r = "w" + std::to_string(c);
+        if (C.kind == 2) continue;
+        if (C.kind == 0) o << "        const u32x4 " << r << " = ld4(reinterpret_cast<const char*>(hc[" << c << "].values) + o4, ioff4);\n";
+        else {
+          o << "        const u64x2 " << r << "a = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, ioff8);\n";
+          o << "        const u64x2 " << r << "b = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, ioff8 + 16u);\n";
+        }
+        if (C.has_validity) o << "        const uint32_t " << r << "_m = ldv(hc[" << c << "].validity + ob, ioffb, lane_shb);\n";
+        else o << "        const uint32_t " << r << "_m = 0xFu;\n";
+      }
+      for (size_t c = c0; c < c1; c++) {
+        const JitHashCol& C = s.cols[c];
+        const std::string r = "w" + std::to_string(c);
+        o << "        {\n          const int W = hc[" << c << "].word;\n";
+        if (C.kind == 0) {
+          if (C.lut_in_lds) o << "          const uint32_t* L = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
+          else o << "          const uint32_t* L = hc[" << c << "].lut;\n";
+          for (int k = 0; k < 4; k++)
+            o << "          if (ins_mask & " << (1 << k) << "u) d_" << k << "[W] = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_in_lds ? "L" : "as_global(L)") << "[" << r << comp4(k) << "] : 0u;\n";
+        } else if (C.kind == 1) {
+          for (int k = 0; k < 4; k++)
+            o << "          if (ins_mask & " << (1 << k) << "u) { const unsigned long long y = ((" << r << "_m >> " << k << ") & 1u) ? " << comp8(r, k) << " : 0ull; d_" << k << "[W] = (uint32_t)y; d_" << k
+              << "[W + 1] = (uint32_t)(y >> 32); }\n";
+        } else {
+          for (int k = 0; k < 4; k++) {
+            auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
+            auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
+            o << "          if (ins_mask & " << (1 << k) << "u) { const unsigned long long y = " << expr_valid(s.exprs, C.expr_root, col, colvalid) << " ? "
+              << expr_bits(s.exprs, C.expr_root, expr_value(s.exprs, C.expr_root, col, colvalid)) << " : 0ull; d_" << k << "[W] = (uint32_t)y; d_" << k << "[W + 1] = (uint32_t)(y >> 32); }\n";
+          }
+        }
+        o << "        }\n";
+      }
+      // (keep the next group's loads below this point: all 32 columns' loads hoisted to the top cost ≈100 more VGPRs)
+      o << "        asm volatile(\"\" ::: \"memory\");\n      }\n";
+    }
+    o << "    }\n";
     o << "  }\n  __syncthreads();\n  if (tid == 0 && s_new != 0) atomicAdd(h.n_groups, (unsigned long long)s_new);\n}\n";
     return o.str();
   }
