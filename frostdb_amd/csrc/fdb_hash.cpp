@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <thread>
@@ -28,12 +29,17 @@ constexpr int64_t kFirstChunkRows = 1 << 20;  // the first chunk of a fresh tabl
 inline uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 }  // namespace
 
-// Key-tuple words: [valid mask lo, valid mask hi, then 1 word per dictionary column / 2 per int64 column].
+// Key-tuple words: [valid mask lo, valid mask hi, 2 words of padding, then 1 word per dictionary column / 2 per int64 column],
+// rounded up to a multiple of 4 words: tuples and the first column start on 16-byte boundaries, so the inserting lane writes a
+// tuple with 16-byte stores (9 for cfg 5's 32 label columns instead of 34 four-byte ones — every store of a scattered tuple is
+// its own write request, and those were most of what an insert cost).
 void Plan::hash_layout() {
-  int kw = 2;
+  int kw = 4;
   for (GroupColState& g : gcols_) { g.word = kw; kw += g.kind == 0 ? 1 : 2; }
+  const int used = kw;
+  kw = (kw + 3) & ~3;
   const int ew = (int)((3 + aggs_.size() + 3) / 4 * 4);
-  if (h_table_ == nullptr) { h_key_words_ = kw; h_entry_words_ = ew; return; }
+  if (h_table_ == nullptr) { h_key_words_ = kw; h_key_used_ = used; h_entry_words_ = ew; return; }
   if (kw != h_key_words_) {  // columns were added: widen the key store (same capacity, same fingerprints)
     uint32_t* nk = (uint32_t*)ctx_->dev_alloc((size_t)h_capacity_ * kw * 4);  // (no initialisation needed, see fdb_launch_hash_rehash)
     unsigned long long* nt = (unsigned long long*)ctx_->dev_alloc((size_t)h_capacity_ * ew * 8);
@@ -41,11 +47,12 @@ void Plan::hash_layout() {
     for (size_t j = 0; j < aggs_.size(); j++)
       idents[j] = aggs_[j].func == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : aggs_[j].func == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
     hip_check(fdb_launch_hash_init(nt, h_capacity_, ew, (int)aggs_.size(), idents, stream_), "hash init");
-    hip_check(fdb_launch_hash_rehash(h_table_, h_keys_, h_capacity_, h_key_words_, nt, nk, h_capacity_ - 1, ew, kw, stream_), "hash rehash");
+    hip_check(fdb_launch_hash_rehash(h_table_, h_keys_, h_capacity_, h_key_words_, h_key_used_, nt, nk, h_capacity_ - 1, ew, kw, stream_), "hash rehash");
     hip_check(hipStreamSynchronize(stream_), "sync(rehash)");
     ctx_->dev_free(h_table_); ctx_->dev_free(h_keys_);
     h_table_ = nt; h_keys_ = nk; h_key_words_ = kw;
   }
+  h_key_used_ = used;
 }
 
 uint64_t Plan::hash_groups() {
@@ -71,7 +78,7 @@ void Plan::hash_reserve(uint64_t extra, uint64_t expected_groups) {
     idents[j] = aggs_[j].func == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : aggs_[j].func == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
   hip_check(fdb_launch_hash_init(nt, need, ew, (int)aggs_.size(), idents, stream_), "hash init");
   if (h_table_ != nullptr) {
-    hip_check(fdb_launch_hash_rehash(h_table_, h_keys_, h_capacity_, kw, nt, nk, need - 1, ew, kw, stream_), "hash rehash");
+    hip_check(fdb_launch_hash_rehash(h_table_, h_keys_, h_capacity_, kw, h_key_used_, nt, nk, need - 1, ew, kw, stream_), "hash rehash");
     hip_check(hipStreamSynchronize(stream_), "sync(rehash)");
     ctx_->dev_free(h_table_); ctx_->dev_free(h_keys_);
   }
@@ -208,6 +215,12 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       C.values = c.d_values; C.validity = c.d_validity;
       if (gr.kind == 0) { C.lut_len = (uint32_t)gr.lut->size(); lut_off[g] = R.blob.add(gr.lut->data(), gr.lut->size() * 4); }
     }
+    // canonical: the record carries every group column of the plan, in the plan's order — then column c's word is a
+    // compile-time constant of the specialised kernel (4 + the widths before it) and aligned quads of dictionary columns are
+    // written with one 16-byte store
+    bool canonical = hcols.size() == gcols_.size();
+    { int w = 4; for (size_t g = 0; g < hcols.size() && canonical; g++) { canonical = hcols[g].word == w; w += hcols[g].kind == 0 ? 1 : 2; } }
+    h.canonical = canonical ? 1 : 0;
     unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
     size_t lds_off = 0;
     for (const PendingLut& p : R.luts) {  // predicate LUTs (kind 0 only: dense group LUTs were never added in this mode)
@@ -290,6 +303,11 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
         last_kernel_ = "scan_hash_kernel";
       }
       if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
+      if (std::getenv("FDB_PROFILE_CHUNKS")) {  // tuning aid: per-launch time (serialises the scan)
+        const auto t0 = std::chrono::steady_clock::now();
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        std::fprintf(stderr, "[fdb] hash chunk of %lld rows: %.1f us\n", (long long)(r1 - r0), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+      }
       h_groups_bound_ += (uint64_t)(r1 - r0);
       h_bound_stale_ = true;
       h_rows_seen_ += (uint64_t)(r1 - r0);

@@ -721,18 +721,24 @@ struct HashGen {
     // 8-byte keys) brings the values of all of them; 8 columns' loads are in flight together, then their key-id lookups, then
     // the stores — 4 memory round trips for 32 columns however many of the lane's rows inserted (one row at a time, re-reading
     // column by column, cost 2 round trips per 16 columns and inserted row and made insert-heavy launches 5 × slower per row).
-    int covered = 2;
-    for (const JitHashCol& C : s.cols) covered += C.kind == 0 ? 1 : 2;
+    // Canonical layout (h.canonical: the record carries every group column of the table, in order): column c's word is the
+    // constant 4 + Σ widths before it, tuples are 16-byte aligned, and an aligned quad of dictionary columns is ONE 16-byte store —
+    // every store of a scattered tuple is its own write request, and with 34 four-byte stores those were most of an insert's cost.
+    std::vector<int> cword(s.cols.size());
+    { int w = 4; for (size_t c = 0; c < s.cols.size(); c++) { cword[c] = w; w += s.cols[c].kind == 0 ? 1 : 2; } }
     o << "    if (ins_mask != 0u) {\n";
     o << "      atomicAdd(&s_new, (unsigned int)__builtin_popcount(ins_mask));\n";
     // (fresh opaque lane offsets: with the tile's own the compiler recognises these loads as the fingerprint phase's and keeps
     // all 32 columns' values — 128 VGPRs — alive from there to here instead of re-loading)
     o << "      uint32_t ioff4 = lane_off4, ioff8 = lane_off8, ioffb = lane_offb;\n      asm volatile(\"\" : \"+v\"(ioff4), \"+v\"(ioff8), \"+v\"(ioffb));\n";
     for (int k = 0; k < 4; k++) o << "      uint32_t* d_" << k << " = h.keys + slot_" << k << " * (uint64_t)h.key_words;\n";
-    o << "      if (h.key_words != " << covered << ") {  // columns this record does not carry are NULL\n";
+    o << "      const bool canon = h.canonical != 0;\n";
+    o << "      if (!canon) {  // columns this record does not carry are NULL\n";
     for (int k = 0; k < 4; k++) o << "        if (ins_mask & " << (1 << k) << "u) for (int w = 2; w < h.key_words; w++) d_" << k << "[w] = 0u;\n";
     o << "      }\n";
-    for (int k = 0; k < 4; k++) o << "      if (ins_mask & " << (1 << k) << "u) { d_" << k << "[0] = (uint32_t)vm_" << k << "; d_" << k << "[1] = (uint32_t)(vm_" << k << " >> 32); }\n";
+    for (int k = 0; k < 4; k++)
+      o << "      if (ins_mask & " << (1 << k) << "u) { if (canon) *reinterpret_cast<u32x4*>(d_" << k << ") = u32x4{(uint32_t)vm_" << k << ", (uint32_t)(vm_" << k << " >> 32), 0u, 0u}; else { d_" << k
+        << "[0] = (uint32_t)vm_" << k << "; d_" << k << "[1] = (uint32_t)(vm_" << k << " >> 32); } }\n";
     for (size_t c0 = 0; c0 < s.cols.size(); c0 += GROUP) {
       const size_t c1 = std::min(s.cols.size(), c0 + GROUP);
       o << "      {\n";
@@ -748,15 +754,36 @@ struct HashGen {
         if (C.has_validity) o << "        const uint32_t " << r << "_m = ldv(hc[" << c << "].validity + ob, ioffb, lane_shb);\n";
         else o << "        const uint32_t " << r << "_m = 0xFu;\n";
       }
+      // key ids of the dictionary columns (only for rows that inserted: other rows of the tile's tail may hold anything)
+      for (size_t c = c0; c < c1; c++) {
+        const JitHashCol& C = s.cols[c];
+        if (C.kind != 0) continue;
+        const std::string r = "w" + std::to_string(c);
+        if (C.lut_in_lds) o << "        const uint32_t* L" << c << " = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
+        else o << "        const uint32_t* L" << c << " = hc[" << c << "].lut;\n";
+        for (int k = 0; k < 4; k++)
+          o << "        const uint32_t i" << c << "_" << k << " = ((ins_mask & " << (1 << k) << "u) && ((" << r << "_m >> " << k << ") & 1u)) ? " << (C.lut_in_lds ? "L" : "as_global(L") << c
+            << (C.lut_in_lds ? "" : ")") << "[" << r << comp4(k) << "] : 0u;\n";
+      }
+      // stores: aligned quads of dictionary columns as one 16-byte store when the layout is canonical
+      std::vector<bool> in_quad(s.cols.size(), false);
+      o << "        if (canon) {\n";
+      for (size_t c = c0; c + 4 <= c1; ) {
+        const bool quad = cword[c] % 4 == 0 && s.cols[c].kind == 0 && s.cols[c + 1].kind == 0 && s.cols[c + 2].kind == 0 && s.cols[c + 3].kind == 0;
+        if (!quad) { c++; continue; }
+        for (int k = 0; k < 4; k++)
+          o << "          if (ins_mask & " << (1 << k) << "u) *reinterpret_cast<u32x4*>(d_" << k << " + " << cword[c] << ") = u32x4{i" << c << "_" << k << ", i" << c + 1 << "_" << k << ", i" << c + 2 << "_" << k
+            << ", i" << c + 3 << "_" << k << "};\n";
+        in_quad[c] = in_quad[c + 1] = in_quad[c + 2] = in_quad[c + 3] = true;
+        c += 4;
+      }
+      o << "        }\n";
       for (size_t c = c0; c < c1; c++) {
         const JitHashCol& C = s.cols[c];
         const std::string r = "w" + std::to_string(c);
-        o << "        {\n          const int W = hc[" << c << "].word;\n";
+        o << "        " << (in_quad[c] ? "if (!canon) " : "") << "{\n          const int W = hc[" << c << "].word;\n";
         if (C.kind == 0) {
-          if (C.lut_in_lds) o << "          const uint32_t* L = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
-          else o << "          const uint32_t* L = hc[" << c << "].lut;\n";
-          for (int k = 0; k < 4; k++)
-            o << "          if (ins_mask & " << (1 << k) << "u) d_" << k << "[W] = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_in_lds ? "L" : "as_global(L)") << "[" << r << comp4(k) << "] : 0u;\n";
+          for (int k = 0; k < 4; k++) o << "          if (ins_mask & " << (1 << k) << "u) d_" << k << "[W] = i" << c << "_" << k << ";\n";
         } else if (C.kind == 1) {
           for (int k = 0; k < 4; k++)
             o << "          if (ins_mask & " << (1 << k) << "u) { const unsigned long long y = ((" << r << "_m >> " << k << ") & 1u) ? " << comp8(r, k) << " : 0ull; d_" << k << "[W] = (uint32_t)y; d_" << k

@@ -188,7 +188,7 @@ struct FdbHashArgs {
   int32_t n_hcols;
   int32_t key_words;
   int32_t entry_words;
-  int32_t _pad;
+  int32_t canonical;        // 1: hcols[c].word == 4 + Σ widths of the columns before c and every column of the table is present
 };
 
 // ---- device helpers of the hash path (shared by fdb_kernels.hip and the kernels fdb_jit.cpp generates) ---------------
@@ -247,10 +247,11 @@ hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t
 // table[i] = {0, 0, 0, idents…, 0 pad} for i < capacity
 hipError_t fdb_launch_hash_init(unsigned long long* table, uint64_t capacity, int entry_words, int n_aggs, const unsigned long long* idents,
                                 hipStream_t stream);
-// Moves every occupied entry of (old_table, old_keys) into the (empty-initialised) new table; key tuples are copied
-// word for word into the (possibly wider) new key store, new words zeroed. The key store itself needs NO initialisation: a
+// Moves every occupied entry of (old_table, old_keys) into the (empty-initialised) new table; the first `old_used_words` words of
+// each key tuple (valid mask + columns, without the tail padding of its stride `old_key_words`) are copied word for word into the
+// (possibly wider) new key store, the other words zeroed. The key store itself needs NO initialisation: a
 // tuple is only ever read where the entry is occupied, and every insert writes all of its words.
-hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int old_key_words,
+hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int old_key_words, int old_used_words,
                                   unsigned long long* new_table, uint32_t* new_keys, uint64_t new_mask, int entry_words, int new_key_words,
                                   hipStream_t stream);
 // First output row of every 64-slot chunk of the table (bases[(capacity + 63) / 64], exclusive prefix sums of the occupied

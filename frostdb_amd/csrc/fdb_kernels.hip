@@ -862,7 +862,7 @@ __global__ void hash_init_kernel(unsigned long long* table, uint64_t total_words
   }
 }
 
-__global__ void hash_rehash_kernel(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int okw,
+__global__ void hash_rehash_kernel(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int okw, int oused,
                                    unsigned long long* new_table, uint32_t* new_keys, uint64_t new_mask, int ew, int kw) {
   // A lane claims the new slot of "its" old entry (CAS on the fingerprint, linear probing) and copies the entry's words; the KEY
   // TUPLES — tens of words each — are then copied by the whole wave, one tuple at a time with lane w on word w: coalesced reads and
@@ -892,7 +892,7 @@ __global__ void hash_rehash_kernel(const unsigned long long* old_table, const ui
       todo &= todo - 1ull;
       const uint64_t src = wave_first + (uint64_t)src_lane;
       const uint64_t dst = (uint64_t)__shfl((unsigned long long)slot, src_lane, 64);
-      for (int w = lane; w < kw; w += 64) new_keys[dst * (uint64_t)kw + w] = w < okw ? old_keys[src * (uint64_t)okw + w] : 0u;  // columns added since: NULL
+      for (int w = lane; w < kw; w += 64) new_keys[dst * (uint64_t)kw + w] = w < oused ? old_keys[src * (uint64_t)okw + w] : 0u;  // columns added since: NULL (the old tuple's tail padding is not a column)
     }
   }
 }
@@ -1868,10 +1868,10 @@ hipError_t fdb_launch_hash_init(unsigned long long* table, uint64_t capacity, in
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int old_key_words,
+hipError_t fdb_launch_hash_rehash(const unsigned long long* old_table, const uint32_t* old_keys, uint64_t old_capacity, int old_key_words, int old_used_words,
                                   unsigned long long* new_table, uint32_t* new_keys, uint64_t new_mask, int entry_words, int new_key_words,
                                   hipStream_t stream) {
-  hipLaunchKernelGGL(hash_rehash_kernel, dim3(4096), dim3(256), 0, stream, old_table, old_keys, old_capacity, old_key_words, new_table, new_keys,
+  hipLaunchKernelGGL(hash_rehash_kernel, dim3(4096), dim3(256), 0, stream, old_table, old_keys, old_capacity, old_key_words, old_used_words, new_table, new_keys,
                      new_mask, entry_words, new_key_words);
   return hipGetLastError();
 }

@@ -304,7 +304,7 @@ class Plan {
   uint32_t* h_keys_ = nullptr;
   unsigned long long* h_count_dev_ = nullptr;
   uint64_t h_capacity_ = 0;
-  int h_entry_words_ = 0, h_key_words_ = 2;
+  int h_entry_words_ = 0, h_key_words_ = 4, h_key_used_ = 4;  // key tuple stride (multiple of 4 words) and its used prefix (valid mask + padding + columns)
   uint64_t h_groups_bound_ = 0;     // upper bound of occupied slots known on the host
   bool h_bound_stale_ = false;      // rows were scanned since the bound was last read from the device (it is groups + those rows)
   uint64_t h_rows_seen_ = 0;        // rows scanned into the hash table so far (input of the cardinality estimate)

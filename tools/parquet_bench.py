@@ -15,7 +15,11 @@ rows, rg_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000, 5_000_000
 rec = synth.prometheus_chunk(0, 0, rows)
 t = pa.Table.from_batches([rec])
 t = t.set_column(0, "labels.code", t.column(0).cast(pa.binary())).set_column(1, "labels.path", t.column(1).cast(pa.binary()))
-data = write_parquet(t, row_group_size=rg_rows, data_page_size=1 << 20)
+variant = os.environ.get("PQ_VARIANT", "plain")  # "plain": UNCOMPRESSED, PLAIN int64; "delta_snappy": timestamp DELTA_BINARY_PACKED, pages SNAPPY
+kw = {}
+if variant == "delta_snappy":
+    kw = dict(compression="SNAPPY", column_encoding={"timestamp": "DELTA_BINARY_PACKED"}, use_dictionary=["labels.code", "labels.path"])
+data = write_parquet(t, row_group_size=rg_rows, data_page_size=1 << 20, **kw)
 n_rg = pq.ParquetFile(io.BytesIO(data)).metadata.num_row_groups
 groups = [row_group_chunks(data, g) for g in range(n_rg)]
 # the file's bytes in PINNED host memory (what a host that reads parts for the GPU would read into); chunks are (address, length)
@@ -58,4 +62,4 @@ for name, fn in (("device_decode", run_device), ("host_decode_pyarrow", run_host
     for _ in range(n): fn()
     dt = (time.perf_counter() - t0) / n
     res[name] = {"s_per_pass": dt, "rows_per_s": rows / dt, "parquet_GB_per_s": len(data) / dt / 1e9}
-print(json.dumps({"metric": "rows/sec parquet bytes (host memory) → filter + aggregate result", "rows": rows, "row_groups": n_rg, "parquet_bytes": len(data), **res}))
+print(json.dumps({"metric": "rows/sec parquet bytes (host memory) → filter + aggregate result", "variant": variant, "rows": rows, "row_groups": n_rg, "parquet_bytes": len(data), **res}))
