@@ -16,6 +16,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <exception>
+#include <system_error>
+#include <thread>
+#include <cstdlib>
 #include <cstring>
 
 #include "fdb_context.h"
@@ -219,7 +223,9 @@ bool snappy_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {  // th
     else if ((tag & 3) == 2) { if (ip + 2 > n) return false; l = (size_t)(tag >> 2) + 1; off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8); ip += 2; }
     else { if (ip + 4 > n) return false; l = (size_t)(tag >> 2) + 1; off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8) | ((size_t)src[ip + 2] << 16) | ((size_t)src[ip + 3] << 24); ip += 4; }
     if (off == 0 || off > op || op + l > cap) return false;
-    for (size_t i = 0; i < l; i++) dst[op + i] = dst[op - off + i];  // (may overlap: byte by byte)
+    if (off >= l) std::memcpy(dst + op, dst + op - off, l);  // disjoint
+    else if (off >= 8) { for (size_t i = 0; i < l; i += 8) std::memcpy(dst + op + i, dst + op - off + i, std::min<size_t>(8, l - i)); }  // a pattern of ≥ 8 bytes: 8 at a time
+    else for (size_t i = 0; i < l; i++) dst[op + i] = dst[op - off + i];  // short pattern repeated: byte by byte
     op += l;
   }
   return op == cap;
@@ -286,8 +292,34 @@ void inflate_page(int codec, const uint8_t* src, size_t n, uint8_t* dst, size_t 
   }
 }
 
+// The image of a compressed chunk's inflated pages: sized by a first walk over the page headers, in pinned memory when the process
+// has a device (the copy engine reads it directly; the pool re-uses blocks, so no page faults after the first row group), in plain
+// memory otherwise (parsing must work — and refuse bad chunks — without a GPU).
+struct Image {
+  uint8_t* p = nullptr;
+  size_t cap = 0, used = 0;
+  bool pinned = false;
+  Image() = default;
+  Image(const Image&) = delete;
+  Image& operator=(const Image&) = delete;
+  Image(Image&& o) noexcept : p(o.p), cap(o.cap), used(o.used), pinned(o.pinned) { o.p = nullptr; o.cap = o.used = 0; }
+  Image& operator=(Image&& o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; used = o.used; pinned = o.pinned; o.p = nullptr; o.cap = o.used = 0; } return *this; }
+  ~Image() { release(); }
+  void release() { if (p == nullptr) return; if (pinned) pinned_pool_free(p); else std::free(p); p = nullptr; }
+  void allocate(size_t bytes) {
+    release();
+    cap = bytes; used = 0;
+    static const bool no_pinned = std::getenv("FDB_PARQUET_NO_PINNED") != nullptr;  // (measurement aid)
+    try { if (no_pinned) throw Error(FDB_ERR_DEVICE, "off"); p = (uint8_t*)pinned_pool_alloc(bytes); pinned = true; }
+    catch (const Error&) { (void)hipGetLastError(); p = (uint8_t*)std::malloc(std::max<size_t>(bytes, 1)); pinned = false; if (p == nullptr) throw Error(FDB_ERR_OOM, "parquet: out of host memory"); }
+  }
+  bool empty() const { return used == 0; }
+  const uint8_t* data() const { return p; }
+  size_t size() const { return used; }
+};
+
 struct ParsedChunk {
-  std::vector<uint8_t> image;              // compressed chunks: the decompressed page bodies end to end (what goes to HBM); else empty
+  Image image;                             // compressed chunks: the decompressed page bodies end to end (what goes to HBM); else empty
   std::shared_ptr<HostDict> dict;          // BYTE_ARRAY columns
   std::vector<FdbPqRun> def_runs;          // optional columns: one entry per run, row-numbered
   std::vector<FdbPqRun> idx_runs;          // dictionary-encoded columns: rank-numbered
@@ -304,6 +336,18 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
   const bool is_bytes = c.physical_type == 6, is_fixed8 = c.physical_type == 2 || c.physical_type == 5;
   if (!is_bytes && !is_fixed8) throw Error(FDB_ERR_UNSUPPORTED, "parquet: only INT64, DOUBLE and BYTE_ARRAY columns are decoded on the device");
   ParsedChunk out;
+  if (c.codec != CODEC_NONE) {  // first walk: how big is the image
+    Thrift w{c.data, c.data + c.n_bytes};
+    size_t need = 0;
+    int64_t values = 0;
+    while (w.p < w.end && values < n_rows) {
+      const PageHeader h = read_page_header(w);
+      if (h.compressed < 0 || h.uncompressed < 0 || (size_t)(w.end - w.p) < (size_t)h.compressed) throw Error(FDB_ERR_INVALID, "parquet: page runs past the end of the column chunk");
+      w.p += (size_t)h.compressed;
+      if (h.type == PQ_DATA_PAGE || h.type == PQ_DATA_PAGE_V2) { need += (size_t)h.uncompressed + 8; values += std::max(h.num_values, 0); }
+    }
+    out.image.allocate(need + 64);
+  }
   const uint8_t* base = c.data;  // what run / page offsets are relative to: the chunk's bytes, or the image of its decompressed pages
   Thrift t{c.data, c.data + c.n_bytes};
   int64_t rows_done = 0, rank_done = 0;
@@ -324,16 +368,25 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
       const size_t plain_prefix = h.type == PQ_DATA_PAGE_V2 ? (size_t)h.v2_def_bytes + (size_t)h.v2_rep_bytes : 0;
       if (plain_prefix > (size_t)h.compressed || plain_prefix > body_len) throw Error(FDB_ERR_INVALID, "parquet: levels run past the page");
       const bool packed = h.type != PQ_DATA_PAGE_V2 || h.v2_compressed;
-      std::vector<uint8_t>& dst = h.type == PQ_DICTIONARY_PAGE ? dict_tmp : out.image;
-      const size_t at = dst.size();
-      dst.resize(at + body_len + 8);  // (+8: the next page starts 8 bytes on; keeps every 64-bit window inside the image)
-      std::memcpy(dst.data() + at, raw, plain_prefix);
-      if (packed) inflate_page(c.codec, raw + plain_prefix, (size_t)h.compressed - plain_prefix, dst.data() + at + plain_prefix, body_len - plain_prefix);
-      else { if ((size_t)h.compressed != body_len) throw Error(FDB_ERR_INVALID, "parquet: uncompressed V2 page with differing sizes"); std::memcpy(dst.data() + at + plain_prefix, raw + plain_prefix, body_len - plain_prefix); }
-      body = dst.data() + at;
+      uint8_t* dst;
+      size_t at = 0;
+      if (h.type == PQ_DICTIONARY_PAGE) { dict_tmp.resize(body_len + 8); dst = dict_tmp.data(); }
+      else {
+        // (+8: the next page starts 8 bytes on; keeps every 64-bit window inside the image). Pages that are neither dictionary nor
+        // data pages were not counted by the first walk and are not needed: skipped
+        if (h.type != PQ_DATA_PAGE && h.type != PQ_DATA_PAGE_V2) continue;
+        at = out.image.used;
+        if (at + body_len + 8 > out.image.cap) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
+        out.image.used = at + body_len + 8;
+        dst = out.image.p + at;
+      }
+      std::memcpy(dst, raw, plain_prefix);
+      if (packed) inflate_page(c.codec, raw + plain_prefix, (size_t)h.compressed - plain_prefix, dst + plain_prefix, body_len - plain_prefix);
+      else { if ((size_t)h.compressed != body_len) throw Error(FDB_ERR_INVALID, "parquet: uncompressed V2 page with differing sizes"); std::memcpy(dst + plain_prefix, raw + plain_prefix, body_len - plain_prefix); }
+      body = dst;
       body_off = at;
     }
-    base = c.codec != CODEC_NONE ? out.image.data() : c.data;  // (the image may have moved)
+    base = c.codec != CODEC_NONE ? out.image.data() : c.data;
     if (h.type == PQ_DICTIONARY_PAGE) {
       if (!is_bytes) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary-encoded numeric columns are not supported on the device path");
       if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary page encoding");
@@ -438,9 +491,24 @@ constexpr size_t kTailPad = 256;
 
 std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device) {
   if (chunks == nullptr || n_chunks <= 0 || n_rows < 0) throw Error(FDB_ERR_INVALID, "parquet: no column chunks");
-  std::vector<ParsedChunk> parsed;  // (host-only: malformed / unsupported chunks are refused before any device call)
-  parsed.reserve((size_t)n_chunks);
-  for (int32_t i = 0; i < n_chunks; i++) parsed.push_back(parse_chunk(chunks[i], n_rows));
+  // (host-only: malformed / unsupported chunks are refused before any device call). Column chunks are independent: big ones —
+  // inflating pages is the expensive part — are parsed on one thread each; the first failure in column order is reported.
+  std::vector<ParsedChunk> parsed((size_t)n_chunks);
+  size_t packed_bytes = 0;
+  for (int32_t i = 0; i < n_chunks; i++) if (chunks[i].codec != 0 && chunks[i].n_bytes > 0) packed_bytes += (size_t)chunks[i].n_bytes;
+  if (n_chunks > 1 && packed_bytes >= ((size_t)1 << 20)) {
+    std::vector<std::exception_ptr> errs((size_t)n_chunks);
+    std::vector<std::thread> workers;
+    auto work = [&](int32_t i) { try { parsed[(size_t)i] = parse_chunk(chunks[i], n_rows); } catch (...) { errs[(size_t)i] = std::current_exception(); } };
+    for (int32_t i = 1; i < n_chunks; i++) {
+      try { workers.emplace_back(work, i); } catch (const std::system_error&) { work(i); }
+    }
+    work(0);
+    for (std::thread& w : workers) w.join();
+    for (const std::exception_ptr& e : errs) if (e) std::rethrow_exception(e);
+  } else {
+    for (int32_t i = 0; i < n_chunks; i++) parsed[(size_t)i] = parse_chunk(chunks[i], n_rows);
+  }
   hip_check(hipSetDevice(device), "hipSetDevice");
 
   std::unique_ptr<DeviceBatch> b(new DeviceBatch());
