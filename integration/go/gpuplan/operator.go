@@ -215,8 +215,10 @@ func (o *Operator) MergeAcrossDevices(ctx context.Context, comm *C.fdb_comm) err
 
 // ResidentRowGroup decodes one Parquet row group on the device (fdb_batch_from_parquet) from the column chunks' bytes as
 // parquet-go's file metadata locates them; the batch can be pushed to any number of queries (fdb_plan_push_batches) and stays
-// in HBM until released. Row groups the first slice does not cover (compressed pages, DELTA encodings) return
-// FDB_ERR_UNSUPPORTED: convert those with pqarrow as before and use fdb_batch_import.
+// in HBM until released. Each chunk names its pages' codec (fdb_parquet_chunk.codec = format.CompressionCodec of the column's
+// metadata: UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4_RAW are inflated by the library). Row groups outside the covered encodings
+// (nested columns, PLAIN byte arrays, BROTLI, …) return FDB_ERR_UNSUPPORTED: convert those with pqarrow as before and use
+// fdb_batch_import.
 func ResidentRowGroup(device int, chunks []C.fdb_parquet_chunk, rows int64) (*C.fdb_batch, error) {
 	var b *C.fdb_batch
 	if rc := C.fdb_batch_from_parquet(&chunks[0], C.int32_t(len(chunks)), C.int64_t(rows), C.int(device), &b); rc != C.FDB_OK {
