@@ -935,7 +935,16 @@ __global__ void hash_compact_kernel(const unsigned long long* table, const uint3
 // History (cfg 5, 10 M groups × 32 columns, table of 33.5 M slots): one lane per slot writing 32 columns itself: 4.5 ms; one wave
 // per chunk emitting its ≈19 rows per column (44 M partial-line writes): 6.2 ms; a wave walking a contiguous range of chunks with an
 // LDS ring to emit aligned 64-row groups: 4.4 ms — 20 KB of LDS per wave left 6 waves per CU to hide a chain of dependent loads.
-__global__ __launch_bounds__(256) void hash_gather_rows_kernel(const FdbHashColumnsArgs a) {
+// (The arrays are separate __restrict__ kernel parameters and the pointer tables are read through the constant address space on
+// purpose: with everything behind one by-value struct the compiler has to assume that the stores of one step may alias the loads
+// of the next — `keys` vs `dense_keys`, the pointer tables vs the byte stores of pass 2 — and waits for every store to complete
+// before the next dependent load: ≈2.5 µs per column and group, 6.6 ms per Finish for pass 2 alone.)
+typedef unsigned long long* U64Ptr;
+typedef unsigned char* BytePtr;
+__global__ __launch_bounds__(256) void hash_gather_rows_kernel(const unsigned long long* __restrict__ table, const uint32_t* __restrict__ keys,
+                                                               const uint32_t* __restrict__ bases, uint32_t* __restrict__ dense_keys,
+                                                               const FdbHashColumnsArgs a) {
+  const __attribute__((address_space(4))) U64Ptr* out_vals = (const __attribute__((address_space(4))) U64Ptr*)a.out_vals;
   __shared__ uint8_t slot_of_all[4][64];
   const int ew = a.entry_words, kw = a.key_words, nv = a.n_vals;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -945,20 +954,20 @@ __global__ __launch_bounds__(256) void hash_gather_rows_kernel(const FdbHashColu
   const uint64_t n_waves = (uint64_t)gridDim.x * 4;
   for (uint64_t chunk = (uint64_t)blockIdx.x * 4 + wave; chunk < n_chunks; chunk += n_waves) {
     const uint64_t i = chunk * 64 + lane;
-    const unsigned long long* e = a.table + i * (uint64_t)ew;
+    const unsigned long long* e = table + i * (uint64_t)ew;
     const bool occ = i < a.capacity && e[0] != 0ull;
     const unsigned long long m = __ballot(occ);
     if (m == 0ull) continue;
     const uint32_t n_occ = (uint32_t)__popcll(m);
-    const uint64_t base = a.bases[chunk];
+    const uint64_t base = bases[chunk];
     if (occ) {
       const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       slot_of[r] = (uint8_t)lane;
-      for (int v = 0; v < nv; v++) a.out_vals[v][base + r] = e[2 + v];
+      for (int v = 0; v < nv; v++) out_vals[v][base + r] = e[2 + v];
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t* src = a.keys + chunk * 64 * (uint64_t)kw;
-    uint32_t* dst = a.dense_keys + base * (uint64_t)kw;
+    const uint32_t* src = keys + chunk * 64 * (uint64_t)kw;
+    uint32_t* dst = dense_keys + base * (uint64_t)kw;
     const uint32_t n_words = n_occ * (uint32_t)kw;
     for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
       uint32_t val[16];
@@ -980,8 +989,10 @@ __global__ __launch_bounds__(256) void hash_gather_rows_kernel(const FdbHashColu
   }
 }
 
-__global__ __launch_bounds__(256) void hash_rows_to_columns_kernel(const FdbHashColumnsArgs a) {
+__global__ __launch_bounds__(256) void hash_rows_to_columns_kernel(const uint32_t* __restrict__ dense_keys, const FdbHashColumnsArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const __attribute__((address_space(4))) BytePtr* out_key = (const __attribute__((address_space(4))) BytePtr*)a.out_key;
+  const __attribute__((address_space(4))) U64Ptr* out_bits = (const __attribute__((address_space(4))) U64Ptr*)a.out_bits;
   __shared__ unsigned int s_nulls[64];  // NULLs per column seen by this workgroup (flushed once at the end)
   if (threadIdx.x < 64) s_nulls[threadIdx.x] = 0u;
   __syncthreads();
@@ -992,7 +1003,7 @@ __global__ __launch_bounds__(256) void hash_rows_to_columns_kernel(const FdbHash
   const uint64_t n_groups = ((a.row_end < a.n_rows ? a.row_end : a.n_rows) + 63) >> 6;
   for (uint64_t G = (a.row_begin >> 6) + (uint64_t)blockIdx.x * 4 + wave; G < n_groups; G += (uint64_t)gridDim.x * 4) {
     const uint32_t rows = (uint32_t)(a.n_rows - G * 64 < 64 ? a.n_rows - G * 64 : 64);
-    const uint32_t* src = a.dense_keys + G * 64 * (uint64_t)kw;
+    const uint32_t* src = dense_keys + G * 64 * (uint64_t)kw;
     const uint32_t n_words = rows * (uint32_t)kw;
     for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
       uint32_t val[16];
@@ -1014,7 +1025,7 @@ __global__ __launch_bounds__(256) void hash_rows_to_columns_kernel(const FdbHash
     const unsigned long long vm = active ? (unsigned long long)k[0] | ((unsigned long long)k[1] << 32) : 0ull;
     for (int c = 0; c < a.n_cols; c++) {
       const FdbHashCol C = load_col(a.cols, c);
-      unsigned char* out = reinterpret_cast<unsigned char*>(a.out_key[c]);
+      unsigned char* out = out_key[c];
       const int width = C.src_word;  // (transport width of the column: 1, 2, 4 or 8 bytes)
       // sliced columns: [slice][column][row in slice] — a slice of all narrow columns is one contiguous run for the copy engine
       const uint64_t at = C.lut_len ? (o >> a.slice_shift) * a.slice_stride + (o & ((1ull << a.slice_shift) - 1ull)) * (uint64_t)width : o * (uint64_t)width;
@@ -1034,7 +1045,7 @@ __global__ __launch_bounds__(256) void hash_rows_to_columns_kernel(const FdbHash
       }
       const unsigned long long w = __ballot(ok);
       if (lane == 0) {
-        reinterpret_cast<unsigned long long*>(a.out_bits[c])[G] = w;
+        out_bits[c][G] = w;
         const uint32_t nulls = rows - (uint32_t)__popcll(w);
         if (nulls != 0u) atomicAdd(&s_nulls[c], nulls);
       }
@@ -1903,7 +1914,7 @@ hipError_t fdb_launch_hash_gather_rows(const FdbHashColumnsArgs& args, int devic
   const int64_t n_chunks = (int64_t)((args.capacity + 63) / 64);
   if (n_chunks == 0 || args.n_rows == 0) return hipSuccess;
   const int64_t cus = fdb_scan_default_grid(device) / 2;
-  hipLaunchKernelGGL(hash_gather_rows_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + 3) / 4, cus * 16)), dim3(256), 0, stream, args);
+  hipLaunchKernelGGL(hash_gather_rows_kernel, dim3((unsigned)std::min<int64_t>((n_chunks + 3) / 4, cus * 16)), dim3(256), 0, stream, args.table, args.keys, args.bases, args.dense_keys, args);
   return hipGetLastError();
 }
 
@@ -1919,7 +1930,7 @@ hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int d
   }
   const int64_t cus = fdb_scan_default_grid(device) / 2;
   const int64_t n_groups = (int64_t)((end - args.row_begin + 63) / 64);
-  hipLaunchKernelGGL(hash_rows_to_columns_kernel, dim3((unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * 16)), dim3(256), lds, stream, args);
+  hipLaunchKernelGGL(hash_rows_to_columns_kernel, dim3((unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * 16)), dim3(256), lds, stream, (const uint32_t*)args.dense_keys, args);
   return hipGetLastError();
 }
 
