@@ -422,6 +422,9 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   unsigned char* d_block = (unsigned char*)ctx_->dev_alloc(direct_bytes + narrow_bytes + 256);
   unsigned char* d_narrow = d_block + direct_bytes;
   std::vector<void*> owned{d_block};
+  // (device scratch goes back to the context's cache when this function leaves, also by exception — after the Quiesce guard
+  // below has waited for both queues)
+  struct FreeOwned { Context* c; std::vector<void*>* v; ~FreeOwned() { for (void* p : *v) c->dev_free(p); } } free_owned{ctx_, &owned};
   auto alloc = [&](size_t bytes) { void* p = ctx_->dev_alloc(bytes); owned.push_back(p); return p; };
   std::vector<void*> d_key(std::max<size_t>(n_cols, 1));
   std::vector<uint8_t*> d_bits(std::max<size_t>(n_cols, 1));
@@ -565,8 +568,6 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   if (copy_stream) hip_check(hipStreamSynchronize(copy_stream), "hipStreamSynchronize(copy queue)");
   sync();
   pt.mark("finish: copy");
-  for (void* p : owned) ctx_->dev_free(p);
-  if (pt.on) pt.mark("finish: dev_free");
   // post-processing that needs the data on the host: NULL counts, float64 MIN/MAX key decoding
   for (size_t c = 0; c < n_cols && n > 0; c++) {
     OutColumn& oc = (*out)[c];

@@ -594,6 +594,29 @@ def test_hash_path_growth_and_filter(pp, variant):
     assert_same_result(got, want, cols)
 
 
+def test_hash_finish_transport_widths_and_slices(pp):
+    """Finish of a big hash table ships dictionary indices at the narrowest width their dictionary allows and widens them on host
+    threads: a 1 000-entry dictionary (uint16 transport), a 70 000-entry one (uint32, copied as is), seven small ones (uint8), an
+    int64 key (8 bytes), NULLs in every label column; 1.1 M groups = two slices of 2^20 rows, the second one short."""
+    rng = np.random.default_rng(4242)
+    n = 1_100_000
+    cards = [1000, 70_000] + [3] * 7
+    arrays, names = [], []
+    for c, card in enumerate(cards):
+        idx = pa.array(rng.integers(0, card, n).astype(np.uint32), type=pa.uint32(), mask=rng.random(n) < 0.02)
+        arrays.append(pa.DictionaryArray.from_arrays(idx, pa.array([b"w%d_%05d" % (c, k) for k in range(card)], type=pa.binary())))
+        names.append("labels.l%02d" % c)
+    arrays += [pa.array(rng.integers(1, 4, n) * 1000, type=pa.int64()), pa.array(rng.integers(-100, 100, n), type=pa.int64()), pa.array(rng.uniform(0, 10, n))]
+    names += ["bucket", "value", "floatvalue"]
+    b = pa.RecordBatch.from_arrays(arrays, names=names)
+    aggs = [Count(Col("value")), Sum(Col("value")), Max(Col("floatvalue"))]
+    groups = [DynCol("labels"), Col("bucket")]
+    want = run_oracle([b], None, aggs, groups)
+    got = run_gpu(pp, [b], None, aggs, groups, resident=True)
+    assert len(want["count(value)"]) > (1 << 20)
+    assert_same_result(got, want, names[:10] + [a.Name() for a in aggs])
+
+
 def test_dense_to_hash_migration_and_merge(pp, variant):
     """First record: two label columns (dense table). Second record brings ten more label columns → the plan migrates
     its dense state into the hash table. Then a second chain in hash mode is merged in (Synchronizer + final stage)."""
