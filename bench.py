@@ -345,12 +345,21 @@ def traffic_for(tag, rows, kernel_name):
     return None, None
 
 
+def traffic_is_per_average_launch(tag):
+    """cfg 5's scan is cut into several launches: its traffic file holds the mean over all of them, like `avg_launch_ms`."""
+    tpath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{tag}_traffic.json")
+    if not os.path.exists(tpath):
+        return False
+    with open(tpath) as fh:
+        return bool(json.load(fh).get("per_average_launch"))
+
+
 def roofline_of(r, rows, steps, tag, ceiling=None):
     achieved = r["k_bytes"] / (r["k_ms"] * 1e-3) / 1e9 if r["k_ms"] > 0 else 0.0
     launches = max(r["k_launches"], 1)
     traffic, src = traffic_for(tag, rows, r["kernel"])
     # (a scan cut into several launches — the hash path's ≤ 4 M-row chunks — reports per-launch figures of the average launch)
-    if traffic is not None and launches != steps:
+    if traffic is not None and launches != steps and not traffic_is_per_average_launch(tag):
         traffic, src = None, None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": r["kernel"], "avg_launch_ms": r["k_ms"] / launches,
