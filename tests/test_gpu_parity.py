@@ -535,7 +535,7 @@ def test_golden_window_int64_group_keys(pp, variant, case):
     assert got == sorted(case["expected"], key=sort_key), case["cite"]
 
 
-def many_label_batch(rng, n, n_cols, card, n_groups=None, null_frac=0.03, int_key=False):
+def many_label_batch(rng, n, n_cols, card, n_groups=None, null_frac=0.03, int_key=False, sorted_rows=False):
     """n rows over `n_cols` dictionary label columns; if n_groups is given rows are drawn from that many distinct
     label tuples (mixed-radix digits of a group id, some digits NULL), like BASELINE.json's cfg 5."""
     if n_groups is None:
@@ -543,6 +543,8 @@ def many_label_batch(rng, n, n_cols, card, n_groups=None, null_frac=0.03, int_ke
         nulls = rng.random((n, n_cols)) < null_frac
     else:
         gid = rng.integers(0, n_groups, size=n)
+        if sorted_rows:  # rows of one group next to each other: a scan of a table sorted by its label columns
+            gid.sort()
         tab = rng.integers(0, card, size=(n_groups, n_cols))
         tnull = rng.random((n_groups, n_cols)) < null_frac
         digits, nulls = tab[gid], tnull[gid]
@@ -592,6 +594,22 @@ def test_hash_path_growth_and_filter(pp, variant):
     cols = key_cols_of(batches, extra=("bucket",)) + [a.Name() for a in aggs]
     assert len(want["value" if False else "sum(value)"]) > 100_000
     assert_same_result(got, want, cols)
+
+
+def test_hash_path_sorted_input_folds_runs_in_lanes_and_waves(pp, variant):
+    """Rows ordered by group (FrostDB's sorting columns): runs of equal keys are folded inside a lane's 4 rows and across the lanes
+    of a wave before the table is touched. Long runs (≈28 rows: they span lanes), short ones (≈3 rows), a filter that punches holes
+    into the runs, every reducer; against the oracle."""
+    rng = np.random.default_rng(4243)
+    aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("floatvalue")), Max(Col("floatvalue")), Sum(Col("floatvalue")), Min(Col("value"))]
+    batches = [many_label_batch(rng, 200_000, 12, 3, n_groups=7_000, sorted_rows=True),
+               many_label_batch(rng, 200_000, 12, 3, n_groups=60_000, sorted_rows=True),
+               many_label_batch(rng, 50_001, 12, 3, n_groups=40, sorted_rows=True)]
+    cols = key_cols_of(batches) + [a.Name() for a in aggs]
+    for f in (None, Col("value") > -40, And(Col("labels.l00") != "v0_1", Col("floatvalue") < 9.0)):
+        want = run_oracle(batches, f, aggs, [DynCol("labels")])
+        got = run_gpu(pp, batches, f, aggs, [DynCol("labels")], resident=True)
+        assert_same_result(got, want, cols, float_cols={"sum(floatvalue)"})
 
 
 def test_hash_finish_transport_widths_and_slices(pp):
