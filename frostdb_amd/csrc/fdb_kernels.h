@@ -287,8 +287,6 @@ struct FdbHashColumnsArgs {
 };
 hipError_t fdb_launch_hash_gather_rows(const FdbHashColumnsArgs& args, int device, hipStream_t stream);      // pass 1: all rows
 hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream);  // pass 2: rows [row_begin, row_end)
-// bits[i / 8] bit (i % 8) = bytes[i] != 0, for i < n (n rounded up to 8 inside; bytes must be readable up to the rounding).
-hipError_t fdb_launch_pack_bits(const uint8_t* bytes, uint8_t* bits, int64_t n, hipStream_t stream);
 
 // Inserts / merges `n` pre-aggregated entries (hash_compact's layout: {count, acc…} per entry + key tuples of
 // `in_key_words` words) into the table. cols[c] describes destination column c: where its words sit in the incoming

@@ -1087,15 +1087,6 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(uint32_t* __restrict__ 
   for (int k = 0; k < 4; k++) { if (i0 + k < n) counts[i0 + k] = run; run += v[k]; }
 }
 
-__global__ void pack_bits_kernel(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bits, int64_t n_bytes_out, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes_out; i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t b = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const int64_t r = i * 8 + k; if (r < n && bytes[r]) b |= 1u << k; }
-    bits[i] = (uint8_t)b;
-  }
-}
-
 __global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
   __shared__ unsigned int s_new;
   if (threadIdx.x == 0) s_new = 0;
@@ -1934,11 +1925,3 @@ hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int d
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_pack_bits(const uint8_t* bytes, uint8_t* bits, int64_t n, hipStream_t stream) {
-  if (n <= 0) return hipSuccess;
-  const int64_t nb = (n + 7) / 8;
-  int blocks = (int)((nb + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_bits_kernel, dim3(blocks), dim3(256), 0, stream, bytes, bits, nb, n);
-  return hipGetLastError();
-}
