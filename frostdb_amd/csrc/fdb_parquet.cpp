@@ -19,6 +19,7 @@
 #include <exception>
 #include <system_error>
 #include <thread>
+#include <unordered_map>
 #include <cstdlib>
 #include <cstring>
 
@@ -336,18 +337,32 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
   const bool is_bytes = c.physical_type == 6, is_fixed8 = c.physical_type == 2 || c.physical_type == 5;
   if (!is_bytes && !is_fixed8) throw Error(FDB_ERR_UNSUPPORTED, "parquet: only INT64, DOUBLE and BYTE_ARRAY columns are decoded on the device");
   ParsedChunk out;
-  if (c.codec != CODEC_NONE) {  // first walk: how big is the image
+  // First walk over the page headers: is an image needed — compressed pages, or BYTE_ARRAY data pages that are PLAIN (a writer's
+  // dictionary fallback: their values are dictionary-encoded HERE, one hash probe per value like the reference's own
+  // BinaryDictionaryBuilder.Append (pqarrow/writer/writer.go:391-405), and the indices are appended to the image as a 32-bit-wide
+  // bit-packed run, which is all the device needs) — and how big is it.
+  bool use_image = c.codec != CODEC_NONE;
+  {
     Thrift w{c.data, c.data + c.n_bytes};
     size_t need = 0;
     int64_t values = 0;
+    bool plain_bytes = false;
     while (w.p < w.end && values < n_rows) {
       const PageHeader h = read_page_header(w);
       if (h.compressed < 0 || h.uncompressed < 0 || (size_t)(w.end - w.p) < (size_t)h.compressed) throw Error(FDB_ERR_INVALID, "parquet: page runs past the end of the column chunk");
       w.p += (size_t)h.compressed;
-      if (h.type == PQ_DATA_PAGE || h.type == PQ_DATA_PAGE_V2) { need += (size_t)h.uncompressed + 8; values += std::max(h.num_values, 0); }
+      if (h.type == PQ_DATA_PAGE || h.type == PQ_DATA_PAGE_V2) {
+        need += (size_t)h.uncompressed + 8;
+        values += std::max(h.num_values, 0);
+        if (is_bytes && h.encoding == ENC_PLAIN) { plain_bytes = true; need += (size_t)std::max(h.num_values, 0) * 4 + 16; }
+      }
     }
-    out.image.allocate(need + 64);
+    use_image = use_image || plain_bytes;
+    if (use_image) out.image.allocate(need + 64);
   }
+  std::vector<std::string> dict_values;                    // the chunk's dictionary: its dictionary page, then values of PLAIN pages
+  std::unordered_map<std::string, uint32_t> dict_lookup;   // built when the first PLAIN page arrives
+  bool lookup_ready = false;
   const uint8_t* base = c.data;  // what run / page offsets are relative to: the chunk's bytes, or the image of its decompressed pages
   Thrift t{c.data, c.data + c.n_bytes};
   int64_t rows_done = 0, rank_done = 0;
@@ -363,11 +378,11 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
     std::vector<uint8_t> dict_tmp;
     const uint8_t* body = raw;
     size_t body_off = (size_t)(raw - c.data), body_len = (size_t)h.compressed;
-    if (c.codec != CODEC_NONE) {
+    if (use_image) {
       body_len = (size_t)h.uncompressed;
       const size_t plain_prefix = h.type == PQ_DATA_PAGE_V2 ? (size_t)h.v2_def_bytes + (size_t)h.v2_rep_bytes : 0;
       if (plain_prefix > (size_t)h.compressed || plain_prefix > body_len) throw Error(FDB_ERR_INVALID, "parquet: levels run past the page");
-      const bool packed = h.type != PQ_DATA_PAGE_V2 || h.v2_compressed;
+      const bool packed = c.codec != CODEC_NONE && (h.type != PQ_DATA_PAGE_V2 || h.v2_compressed);
       uint8_t* dst;
       size_t at = 0;
       if (h.type == PQ_DICTIONARY_PAGE) { dict_tmp.resize(body_len + 8); dst = dict_tmp.data(); }
@@ -386,20 +401,19 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
       body = dst;
       body_off = at;
     }
-    base = c.codec != CODEC_NONE ? out.image.data() : c.data;
+    base = use_image ? out.image.data() : c.data;
     if (h.type == PQ_DICTIONARY_PAGE) {
       if (!is_bytes) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary-encoded numeric columns are not supported on the device path");
       if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary page encoding");
-      std::vector<std::string> values;
-      values.reserve((size_t)std::max(h.num_values, 0));
+      if (have_dict) throw Error(FDB_ERR_INVALID, "parquet: two dictionary pages in one column chunk");
+      dict_values.reserve((size_t)std::max(h.num_values, 0));
       size_t o = 0;
       for (int32_t i = 0; i < h.num_values; i++) {
         if (o + 4 > body_len) throw Error(FDB_ERR_INVALID, "parquet: dictionary page truncated");
         uint32_t len; std::memcpy(&len, body + o, 4); o += 4;
         if (o + len > body_len) throw Error(FDB_ERR_INVALID, "parquet: dictionary page truncated");
-        values.emplace_back((const char*)body + o, len); o += len;
+        dict_values.emplace_back((const char*)body + o, len); o += len;
       }
-      out.dict = make_dictionary(std::move(values), c.utf8 ? "u" : "z");
       have_dict = true;
       continue;
     }
@@ -464,8 +478,39 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
         out.plain_pages.push_back(FdbPqPlainPage{rank_done, (int64_t)voff});
       }
     } else {
+      if (h.encoding == ENC_PLAIN) {
+        // dictionary fallback: <length><bytes> per non-NULL value → index into the chunk's (growing) dictionary
+        if (!lookup_ready) {
+          dict_lookup.reserve(dict_values.size() * 2 + 1024);
+          for (size_t i = 0; i < dict_values.size(); i++) dict_lookup.emplace(dict_values[i], (uint32_t)i);
+          lookup_ready = true;
+        }
+        size_t at = (out.image.used + 3) & ~(size_t)3;
+        if (at + (size_t)page_non_null * 4 + 8 > out.image.cap) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
+        uint32_t* idx = reinterpret_cast<uint32_t*>(out.image.p + at);
+        size_t o = voff;
+        const size_t end = voff + vlen;
+        for (int64_t i = 0; i < page_non_null; i++) {
+          if (o + 4 > end) throw Error(FDB_ERR_INVALID, "parquet: PLAIN BYTE_ARRAY page truncated");
+          uint32_t len; std::memcpy(&len, base + o, 4); o += 4;
+          if ((size_t)len > end - o) throw Error(FDB_ERR_INVALID, "parquet: PLAIN BYTE_ARRAY page truncated");
+          std::string v((const char*)base + o, len); o += len;
+          auto it = dict_lookup.find(v);
+          if (it == dict_lookup.end()) {
+            if (dict_values.size() >= 0xFFFFFFF0u) throw Error(FDB_ERR_UNSUPPORTED, "parquet: more than 2^32 distinct values in a column chunk");
+            it = dict_lookup.emplace(v, (uint32_t)dict_values.size()).first;
+            dict_values.push_back(std::move(v));
+          }
+          idx[i] = it->second;
+        }
+        out.image.used = at + (size_t)page_non_null * 4 + 8;
+        if (page_non_null > 0) { out.idx_runs.push_back(FdbPqRun{rank_done, (uint64_t)at * 8u, 32u, 1u}); out.max_index_bits = 32; }
+        rows_done += h.num_values;
+        rank_done += page_non_null;
+        continue;
+      }
       if (h.encoding != ENC_RLE_DICTIONARY && h.encoding != ENC_PLAIN_DICTIONARY)
-        throw Error(FDB_ERR_UNSUPPORTED, "parquet: BYTE_ARRAY pages must be dictionary-encoded (a writer that fell back to PLAIN is not supported on the device path)");
+        throw Error(FDB_ERR_UNSUPPORTED, "parquet: BYTE_ARRAY pages must be PLAIN, PLAIN_DICTIONARY or RLE_DICTIONARY (DELTA byte-array encodings are not decoded)");
       if (!have_dict) throw Error(FDB_ERR_INVALID, "parquet: dictionary-encoded page without a dictionary page");
       if (page_non_null > 0) {
         if (vlen < 1) throw Error(FDB_ERR_INVALID, "parquet: dictionary-index page without a bit width");
@@ -481,6 +526,7 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
   }
   if (rows_done != n_rows) throw Error(FDB_ERR_INVALID, std::string("parquet: column chunk ") + (c.name ? c.name : "?") + " holds " + std::to_string(rows_done) + " values, the row group has " + std::to_string(n_rows) + " rows");
   out.non_null = rank_done;
+  if (is_bytes) out.dict = make_dictionary(std::move(dict_values), c.utf8 ? "u" : "z");
   return out;
 }
 
@@ -541,7 +587,7 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
     // the chunk's bytes as they are (or the image of its decompressed pages), padded so that 8-byte windows at the very end stay
     // inside the allocation
     const uint8_t* src = P.image.empty() ? c.data : P.image.data();
-    const size_t src_bytes = c.codec == 0 ? (size_t)c.n_bytes : P.image.size();
+    const size_t src_bytes = P.image.empty() ? (size_t)c.n_bytes : P.image.size();
     uint8_t* d_chunk = (uint8_t*)ctx->dev_alloc(src_bytes + 64);
     scratch.push_back(d_chunk);
     if (src_bytes) hip_check(hipMemcpyAsync(d_chunk, src, src_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");

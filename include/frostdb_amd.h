@@ -380,7 +380,7 @@ int fdb_batch_export(const fdb_batch* batch, struct ArrowArray* out, struct Arro
  * fdb_plan_push_batch(es), fdb_plan_filter_batch, fdb_batch_export. The host side of this call reads page headers, the dictionary
  * page and the headers of RLE / bit-packed runs; definition levels → validity bitmaps, value ranks and the per-row dictionary
  * indices / values are computed in HBM. Covered: flat schemas; INT64 / DOUBLE with PLAIN data pages, INT64 also DELTA_BINARY_PACKED; BYTE_ARRAY with a
- * dictionary page + RLE_DICTIONARY data pages (→ dictionary<uint32, binary>, pqarrow/convert/convert.go:64-70; utf8 = 1 →
+ * dictionary page + RLE_DICTIONARY data pages and / or PLAIN data pages (dictionary-encoded on the host) (→ dictionary<uint32, binary>, pqarrow/convert/convert.go:64-70; utf8 = 1 →
  * dictionary<uint32, utf8>); required or optional; data pages V1 / V2; codecs as listed at `codec`. Everything else: FDB_ERR_UNSUPPORTED
  * (the caller falls back to its Arrow path for that row group). */
 typedef struct fdb_parquet_chunk {

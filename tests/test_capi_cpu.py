@@ -239,7 +239,7 @@ def test_local_communicator_endpoints_and_allocation_counters_without_a_gpu():
 
 def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     """fdb_batch_from_parquet reads page headers / run headers on the host BEFORE it touches a device: chunks outside the first
-    slice (BROTLI pages, DELTA encodings, truncated bytes) come back as FDB_ERR_UNSUPPORTED / FDB_ERR_INVALID here, without
+    slice (BROTLI pages, DELTA byte-array encodings, truncated bytes) come back as FDB_ERR_UNSUPPORTED / FDB_ERR_INVALID here, without
     a GPU; a well-formed chunk gets as far as the device call (FDB_ERR_DEVICE on this box)."""
     import numpy as np
     import pyarrow as pa
@@ -255,7 +255,7 @@ def test_parquet_chunks_are_parsed_and_refused_on_the_host():
         pp.ResidentBatch.from_parquet(good, rows)
     assert e.value.code == pp.FDB_ERR_DEVICE  # parsed fine, then no GPU
     for kw, code in ((dict(compression="BROTLI"), pp.FDB_ERR_UNSUPPORTED),
-                     (dict(use_dictionary=False, column_encoding={"ts": "DELTA_BINARY_PACKED", "labels.a": "PLAIN", "value": "PLAIN"}), pp.FDB_ERR_UNSUPPORTED)):
+                     (dict(use_dictionary=False, column_encoding={"ts": "PLAIN", "labels.a": "DELTA_BYTE_ARRAY", "value": "PLAIN"}), pp.FDB_ERR_UNSUPPORTED)):
         bad, rows = row_group_chunks(write_parquet(t, **kw), 0)
         with pytest.raises(pp.FdbError) as e:
             pp.ResidentBatch.from_parquet(bad, rows)
@@ -266,6 +266,15 @@ def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     assert e.value.code == pp.FDB_ERR_INVALID
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(good, rows + 1)
+    assert e.value.code == pp.FDB_ERR_INVALID
+    # PLAIN BYTE_ARRAY pages (a writer without dictionary, or its dictionary fallback) are dictionary-encoded on the host
+    plain, rows = row_group_chunks(write_parquet(t, use_dictionary=False), 0)
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet(plain, rows)
+    assert e.value.code == pp.FDB_ERR_DEVICE, str(e.value)
+    short = [(nm, ty, opt, u8, data[: len(data) - 9] if nm == "labels.a" else data, cd) for nm, ty, opt, u8, data, cd in plain]
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet(short, rows)
     assert e.value.code == pp.FDB_ERR_INVALID
     # DELTA_BINARY_PACKED INT64 pages: block / miniblock headers are walked on the host (the deltas are unpacked on the device)
     delta, rows = row_group_chunks(write_parquet(t, use_dictionary=["labels.a"], column_encoding={"ts": "DELTA_BINARY_PACKED"}), 0)

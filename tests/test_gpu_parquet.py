@@ -124,6 +124,35 @@ def test_delta_binary_packed_int64_columns(pp, n, version):
         rb.close()
 
 
+@pytest.mark.parametrize("mode", ["no_dictionary", "fallback", "fallback_snappy_v2"])
+def test_plain_byte_array_pages_are_dictionary_encoded_on_the_host(pp, mode):
+    """BYTE_ARRAY pages that are PLAIN — a writer without dictionaries, or one whose dictionary outgrew its limit half way through
+    the chunk (RLE_DICTIONARY pages first, PLAIN ones after) — become indices into the chunk's dictionary (its dictionary page plus
+    the new values) on the host; the device reads them as a 32-bit-wide run. NULLs, empty strings, several row groups."""
+    rng = np.random.default_rng(len(mode))
+    n = 90_000
+    t = pa.table({
+        "labels.many": pa.array([None if i % 11 == 0 else b"" if i % 13 == 0 else b"value-%06d" % v for i, v in enumerate(rng.integers(0, 30_000, n))], type=pa.binary()),
+        "labels.few": pa.array([b"k%d" % (i % 5) for i in range(n)], type=pa.binary()),
+        "text": pa.array([None if i % 7 == 0 else "s%d" % v for i, v in enumerate(rng.integers(0, 2_000, n))], type=pa.string()),
+        "value": pa.array(rng.normal(size=n)),
+    })
+    kw = dict(row_group_size=50_000, data_page_size=4096)
+    if mode == "no_dictionary":
+        kw.update(use_dictionary=False)
+    else:
+        kw.update(use_dictionary=["labels.many", "labels.few", "text"], dictionary_pagesize_limit=16 * 1024)
+        if mode == "fallback_snappy_v2":
+            kw.update(compression="SNAPPY", data_page_version="2.0")
+    data = write_parquet(t, **kw)
+    md = pq.ParquetFile(io.BytesIO(data)).metadata
+    encs = set(md.row_group(0).column(0).encodings)
+    assert "PLAIN" in encs and (mode == "no_dictionary" or "RLE_DICTIONARY" in encs), encs
+    for rg in range(md.num_row_groups):
+        rb, _ = decoded_equals_pyarrow(pp, data, rg)
+        rb.close()
+
+
 def test_several_row_groups_all_null_columns_and_wide_dictionaries(pp):
     """Row groups are decoded one by one; a column that is entirely NULL, a dictionary of 70 000 entries (17-bit indices) and a
     required column whose pages carry no definition levels."""
