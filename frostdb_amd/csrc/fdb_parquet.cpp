@@ -16,6 +16,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <exception>
 #include <system_error>
 #include <thread>
@@ -544,12 +545,21 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
   for (int32_t i = 0; i < n_chunks; i++) if (chunks[i].codec != 0 && chunks[i].n_bytes > 0) packed_bytes += (size_t)chunks[i].n_bytes;
   if (n_chunks > 1 && packed_bytes >= ((size_t)1 << 20)) {
     std::vector<std::exception_ptr> errs((size_t)n_chunks);
+    std::atomic<int32_t> next{0};
+    auto work = [&] {
+      for (;;) {
+        const int32_t i = next.fetch_add(1);
+        if (i >= n_chunks) return;
+        try { parsed[(size_t)i] = parse_chunk(chunks[i], n_rows); } catch (...) { errs[(size_t)i] = std::current_exception(); }
+      }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int n_workers = (int)std::min<unsigned>((unsigned)n_chunks, std::min(hw, 64u)) - 1;  // (this thread works too)
     std::vector<std::thread> workers;
-    auto work = [&](int32_t i) { try { parsed[(size_t)i] = parse_chunk(chunks[i], n_rows); } catch (...) { errs[(size_t)i] = std::current_exception(); } };
-    for (int32_t i = 1; i < n_chunks; i++) {
-      try { workers.emplace_back(work, i); } catch (const std::system_error&) { work(i); }
+    for (int w = 0; w < n_workers; w++) {
+      try { workers.emplace_back(work); } catch (const std::system_error&) { break; }  // fewer threads: the others take the rest
     }
-    work(0);
+    work();
     for (std::thread& w : workers) w.join();
     for (const std::exception_ptr& e : errs) if (e) std::rethrow_exception(e);
   } else {

@@ -267,6 +267,27 @@ def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(good, rows + 1)
     assert e.value.code == pp.FDB_ERR_INVALID
+    # big compressed row groups are parsed on several host threads (one column chunk at a time each): the first failure in
+    # column order comes back, whichever thread hit it
+    nb = 400_000
+    big = pa.table({"labels.a": pa.array([b"v%d" % (i % 97) for i in range(nb)], type=pa.binary()), "ts": pa.array(np.arange(nb, dtype=np.int64) * 1000),
+                    "value": pa.array(rng.random(nb)), "other": pa.array(rng.random(nb))})
+    chunks, rows = row_group_chunks(write_parquet(big, compression="SNAPPY"), 0)
+    assert sum(len(c[4]) for c in chunks) > (1 << 20)
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet(chunks, rows)
+    assert e.value.code == pp.FDB_ERR_DEVICE, str(e.value)
+    for victim in ("labels.a", "ts"):  # (the compressible chunks: damage lands on Snappy tags, not inside literals)
+        hurt = []
+        for nm, ty, opt, u8, data, cd in chunks:
+            b = bytearray(data)
+            if nm == victim:  # (0xFF = "copy with a 4-byte offset": offsets far outside what has been produced)
+                for k in range(len(b) // 2, min(len(b) // 2 + 4096, len(b))):
+                    b[k] = 0xFF
+            hurt.append((nm, ty, opt, u8, bytes(b), cd))
+        with pytest.raises(pp.FdbError) as e:
+            pp.ResidentBatch.from_parquet(hurt, rows)
+        assert e.value.code == pp.FDB_ERR_INVALID, victim
     # PLAIN BYTE_ARRAY pages (a writer without dictionary, or its dictionary fallback) are dictionary-encoded on the host
     plain, rows = row_group_chunks(write_parquet(t, use_dictionary=False), 0)
     with pytest.raises(pp.FdbError) as e:
