@@ -45,24 +45,36 @@ def test_version_and_error_strings(built_lib):
 
 
 def test_descriptor_struct_layout_matches_header():
-    # sizes the C compiler gives the descriptor structs vs the ctypes mirrors used by the binding
+    # sizes and field offsets the C compiler gives the structs of the header vs the ctypes mirrors used by the binding
     import subprocess
     import tempfile
     from frostdb_amd import logicalplan as lp
+    from frostdb_amd import physicalplan as pp
     src = r'''
     #include <stdio.h>
+    #include <stddef.h>
     #include "frostdb_amd.h"
-    int main(void) { printf("%zu %zu %zu %zu %zu\n", sizeof(fdb_literal), sizeof(fdb_expr), sizeof(fdb_aggregation),
-                            sizeof(fdb_group_expr), sizeof(fdb_plan_desc)); return 0; }
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(fdb_literal), sizeof(fdb_expr), sizeof(fdb_aggregation), sizeof(fdb_group_expr),
+             sizeof(fdb_plan_desc), sizeof(fdb_proj_node), sizeof(fdb_projection), sizeof(fdb_parquet_chunk));
+      printf("%zu %zu %zu %zu %zu %zu %zu\n", offsetof(fdb_parquet_chunk, name), offsetof(fdb_parquet_chunk, physical_type),
+             offsetof(fdb_parquet_chunk, optional), offsetof(fdb_parquet_chunk, utf8), offsetof(fdb_parquet_chunk, codec),
+             offsetof(fdb_parquet_chunk, data), offsetof(fdb_parquet_chunk, n_bytes));
+      printf("%zu %zu %zu %zu %zu %zu\n", offsetof(fdb_proj_node, kind), offsetof(fdb_proj_node, op), offsetof(fdb_proj_node, left),
+             offsetof(fdb_proj_node, right), offsetof(fdb_proj_node, column), offsetof(fdb_proj_node, literal));
+      return 0;
+    }
     '''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [ctypes.sizeof(lp.CLiteral), ctypes.sizeof(lp.CExpr), ctypes.sizeof(lp.CAggregation),
-                     ctypes.sizeof(lp.CGroupExpr), ctypes.sizeof(lp.CPlanDesc)]
+        lines = [[int(x) for x in ln.split()] for ln in subprocess.check_output([exe]).decode().splitlines()]
+    assert lines[0] == [ctypes.sizeof(lp.CLiteral), ctypes.sizeof(lp.CExpr), ctypes.sizeof(lp.CAggregation), ctypes.sizeof(lp.CGroupExpr),
+                        ctypes.sizeof(lp.CPlanDesc), ctypes.sizeof(lp.CProjNode), ctypes.sizeof(lp.CProjection), ctypes.sizeof(pp.ParquetChunk)]
+    assert lines[1] == [getattr(pp.ParquetChunk, f).offset for f in ("name", "physical_type", "optional", "utf8", "codec", "data", "n_bytes")]
+    assert lines[2] == [getattr(lp.CProjNode, f).offset for f in ("kind", "op", "left", "right", "column", "literal")]
 
 
 def test_invalid_descriptors_are_rejected_without_a_gpu(built_lib):
