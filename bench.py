@@ -369,10 +369,29 @@ def roofline_of(r, rows, steps, tag, ceiling=None):
             "measured_read_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling else None}
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout. RCCL prints a version banner with printf when a communicator is created (every
+    rank, flushed whenever libc pleases — usually at exit, i.e. AFTER the JSON line), and other libraries may do the same: from
+    here on file descriptor 1 is stderr for everybody, and the line goes to the saved descriptor."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(text):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (text + "\n").encode())
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)  # does not return
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -411,7 +430,26 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(fcomm.unique_id()), dtype=torch.uint8))
         if world > 1:
             dist.broadcast(uid, src=0)
-        comm = fcomm.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+        # The C-ABI communicator has only ever run with one rank per device on the boxes this was developed on: if joining it
+        # fails on this node, every rank agrees (over the process group) to merge through torch.distributed instead — the
+        # line then says so — rather than losing the scaling measurement. (A failure that hits only some ranks in the
+        # middle of a collective cannot be recovered from; this covers the symmetric ones: a missing symbol, a refused init.)
+        ok = 1
+        try:
+            comm = fcomm.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
+        except Exception as e:  # noqa: BLE001
+            ok, comm = 0, None
+            print(f"[bench] rank {rank}: fdb_comm_init_rank failed ({e}); proposing the torch.distributed merge", file=sys.stderr)
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            if comm is not None:
+                comm.close()
+            comm = None
+            args.torch_merge = True
+            args.merge_fallback = True
 
     headline = args.config == 0
     config = 2 if headline else args.config
@@ -445,7 +483,8 @@ def main():
                    "parallelism": (f"parts sharded over {world} GPU(s), no data-path collective; " +
                                    ("RCCL all-to-all of hash-partitioned partial tables, result sharded" if config == 5
                                     else "RCCL all-reduce of the partial tables (C ABI fdb_comm_*)" if not args.torch_merge
-                                    else "RCCL all-reduce of the partial tables (torch.distributed)")) if merging else "1 GPU"},
+                                    else "RCCL all-reduce of the partial tables (torch.distributed" +
+                                    ("; fallback: the C-ABI communicator could not be joined)" if getattr(args, "merge_fallback", False) else ")"))) if merging else "1 GPU"},
         "roofline": roofline_of(r, rows, args.steps, tag, ceiling),
         "cpu_baseline": cpu,
         "checked": r["checked"],
@@ -469,7 +508,7 @@ def main():
         line["other_configs"] = others
 
     if rank == 0:
-        print(json.dumps(line))
+        emit(json.dumps(line))
     if comm is not None:
         comm.close()
     if merging:
