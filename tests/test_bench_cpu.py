@@ -55,3 +55,21 @@ def test_expected_cfg2_is_an_independent_numpy_answer():
     assert set(got) == set(want)
     for k in want:
         assert np.isclose(got[k], want[k], rtol=1e-9)
+
+
+def test_stdout_carries_only_the_json_line():
+    """Libraries print to file descriptor 1 behind Python's back (RCCL's version banner when a communicator is created): after
+    claim_stdout() all of that lands on stderr and emit() alone reaches the real stdout."""
+    import subprocess
+    import sys
+    code = ("import importlib.util, os, sys\n"
+            "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "b.claim_stdout()\n"
+            "os.write(1, b'RCCL version : banner\\n')\n"
+            "print('python noise')\n"
+            "b.emit('{\"ok\": 1}')\n"
+            "os.write(1, b'late noise\\n')\n") % os.path.join(ROOT, "bench.py")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == '{"ok": 1}\n'
+    assert "RCCL version : banner" in p.stderr and "python noise" in p.stderr and "late noise" in p.stderr
