@@ -48,20 +48,24 @@ struct Thrift {
     throw Error(FDB_ERR_INVALID, "parquet: varint too long");
   }
   int64_t zigzag() { const uint64_t v = varint(); return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
-  void skip(int type, int depth = 0) {
+  // `in_collection`: a bool is one byte as a list / set / map element (as a struct field its value lives in the field header).
+  // Every collection element occupies at least one byte, so a count larger than what is left of the header is a damaged header —
+  // without that check a list of 2^60 zero-byte elements keeps a thread busy for ever.
+  void skip(int type, int depth = 0, bool in_collection = false) {
     if (depth > 16) throw Error(FDB_ERR_INVALID, "parquet: page header nested too deeply");
     switch (type) {
-      case 1: case 2: return;                       // bool (value lives in the field header)
+      case 1: case 2: if (in_collection) { need(1); p += 1; } return;
       case 3: need(1); p += 1; return;              // byte
       case 4: case 5: case 6: (void)zigzag(); return;
       case 7: need(8); p += 8; return;              // double
-      case 8: { const uint64_t n = varint(); need((size_t)n); p += n; return; }  // binary
+      case 8: { const uint64_t n = varint(); need((size_t)std::min<uint64_t>(n, (uint64_t)1 << 40)); p += n; return; }  // binary
       case 9: case 10: {                            // list / set
         need(1);
         const uint8_t h = *p++;
         uint64_t n = h >> 4;
         if (n == 15) n = varint();
-        for (uint64_t i = 0; i < n; i++) skip(h & 0x0F, depth + 1);
+        if (n > (uint64_t)(end - p)) throw Error(FDB_ERR_INVALID, "parquet: page header truncated");
+        for (uint64_t i = 0; i < n; i++) skip(h & 0x0F, depth + 1, true);
         return;
       }
       case 11: {                                    // map
@@ -69,7 +73,8 @@ struct Thrift {
         if (n == 0) return;
         need(1);
         const uint8_t kv = *p++;
-        for (uint64_t i = 0; i < n; i++) { skip(kv >> 4, depth + 1); skip(kv & 0x0F, depth + 1); }
+        if (n > (uint64_t)(end - p) / 2) throw Error(FDB_ERR_INVALID, "parquet: page header truncated");
+        for (uint64_t i = 0; i < n; i++) { skip(kv >> 4, depth + 1, true); skip(kv & 0x0F, depth + 1, true); }
         return;
       }
       case 12: skip_struct(depth + 1); return;
@@ -353,8 +358,10 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
       if (h.compressed < 0 || h.uncompressed < 0 || (size_t)(w.end - w.p) < (size_t)h.compressed) throw Error(FDB_ERR_INVALID, "parquet: page runs past the end of the column chunk");
       w.p += (size_t)h.compressed;
       if (h.type == PQ_DATA_PAGE || h.type == PQ_DATA_PAGE_V2) {
+        // (a damaged header must not size the image: no page holds more values than the row group has rows)
+        if (h.num_values < 0 || values + h.num_values > n_rows) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
         need += (size_t)h.uncompressed + 8;
-        values += std::max(h.num_values, 0);
+        values += h.num_values;
         if (is_bytes && h.encoding == ENC_PLAIN) { plain_bytes = true; need += (size_t)std::max(h.num_values, 0) * 4 + 16; }
       }
     }
@@ -407,7 +414,8 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
       if (!is_bytes) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary-encoded numeric columns are not supported on the device path");
       if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary page encoding");
       if (have_dict) throw Error(FDB_ERR_INVALID, "parquet: two dictionary pages in one column chunk");
-      dict_values.reserve((size_t)std::max(h.num_values, 0));
+      if (h.num_values < 0 || (size_t)h.num_values > body_len / 4) throw Error(FDB_ERR_INVALID, "parquet: dictionary page truncated");  // (every value has a 4-byte length)
+      dict_values.reserve((size_t)h.num_values);
       size_t o = 0;
       for (int32_t i = 0; i < h.num_values; i++) {
         if (o + 4 > body_len) throw Error(FDB_ERR_INVALID, "parquet: dictionary page truncated");

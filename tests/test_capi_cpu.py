@@ -249,6 +249,22 @@ def test_local_communicator_endpoints_and_allocation_counters_without_a_gpu():
         fcomm.Comm(b"short", 2, 0, 0)
 
 
+@pytest.mark.timeout(120)
+def test_parquet_page_header_with_an_absurd_collection_is_refused_at_once():
+    """Found by fuzzing the host parser: an unknown header field that is a list of 2^63 booleans (zero bytes each, had the reader
+    believed it) kept the parsing thread busy for ever. Collection counts are now checked against what is left of the header."""
+    from frostdb_amd import physicalplan as pp
+    for elem in (0xF1, 0xF2, 0xFC):  # list<bool true>, list<bool false>, list<struct>
+        bad = bytes([0xA9, elem]) + b"\xff" * 8 + b"\x7f" + b"\x00" * 32
+        with pytest.raises(pp.FdbError) as e:
+            pp.ResidentBatch.from_parquet([("x", pp.PARQUET_INT64, 0, False, bad, "UNCOMPRESSED")], 10)
+        assert e.value.code == pp.FDB_ERR_INVALID
+    bad = bytes([0xAB]) + b"\xff" * 8 + b"\x7f" + bytes([0x11]) + b"\x00" * 32  # map<bool, bool> with 2^63 pairs
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet([("x", pp.PARQUET_INT64, 0, False, bad, "UNCOMPRESSED")], 10)
+    assert e.value.code == pp.FDB_ERR_INVALID
+
+
 def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     """fdb_batch_from_parquet reads page headers / run headers on the host BEFORE it touches a device: chunks outside the first
     slice (BROTLI pages, DELTA byte-array encodings, truncated bytes) come back as FDB_ERR_UNSUPPORTED / FDB_ERR_INVALID here, without
