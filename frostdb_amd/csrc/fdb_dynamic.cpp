@@ -70,7 +70,7 @@ struct KeyReader {
 
 // ---- DescCopy ------------------------------------------------------------------------------------------------------------
 DescCopy::DescCopy(const fdb_plan_desc* d) {
-  if (d == nullptr) throw Error(FDB_ERR_INVALID, "null plan descriptor");
+  check_desc_shape(d);
   auto lit = [&](fdb_literal l) {
     if (l.data != nullptr && l.len > 0) { strs_.emplace_back(l.data, (size_t)l.len); l.data = strs_.back().data(); }
     else { l.data = nullptr; l.len = 0; }
@@ -139,7 +139,7 @@ fdb_plan_desc DescCopy::view(const std::vector<fdb_aggregation>& aggs, bool fina
 
 // ---- DynamicAggs -----------------------------------------------------------------------------------------------------------
 bool DynamicAggs::wanted(const fdb_plan_desc* d) {
-  if (d == nullptr) return false;
+  if (d == nullptr || d->n_aggs <= 0 || d->aggs == nullptr) return false;  // (a malformed descriptor is refused by whoever reads it next)
   for (int32_t i = 0; i < d->n_aggs; i++) if (d->aggs[i].dynamic != 0) return true;
   return false;
 }

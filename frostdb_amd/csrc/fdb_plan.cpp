@@ -262,8 +262,26 @@ bool ExprNode::regex_matches(const std::string& v) const {
   return r != 0;
 }
 
-Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(device) {
+void check_desc_shape(const fdb_plan_desc* d) {
   if (d == nullptr) throw Error(FDB_ERR_INVALID, "null plan descriptor");
+  auto arr = [](int32_t n, const void* p, const char* what) {
+    if (n < 0) throw Error(FDB_ERR_INVALID, std::string("negative ") + what + " count");
+    if (n > 0 && p == nullptr) throw Error(FDB_ERR_INVALID, std::string(what) + " count without an array");
+  };
+  arr(d->n_filter, d->filter, "filter node");
+  arr(d->n_aggs, d->aggs, "aggregation");
+  arr(d->n_groups, d->groups, "group expression");
+  arr(d->n_projections, d->projections, "projection");
+  for (int32_t i = 0; i < d->n_projections; i++) {
+    const fdb_projection& fp = d->projections[i];
+    if (fp.name == nullptr || fp.nodes == nullptr || fp.n_nodes <= 0 || fp.root < 0 || fp.root >= fp.n_nodes) throw Error(FDB_ERR_INVALID, "malformed projection");
+  }
+  for (int32_t i = 0; i < d->n_filter; i++)
+    if (d->filter[i].literal.len < 0) throw Error(FDB_ERR_INVALID, "literal with a negative length");
+}
+
+Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(device) {
+  check_desc_shape(d);
   for (int32_t i = 0; i < d->n_filter; i++) {
     const fdb_expr& fe = d->filter[i];
     ExprNode e;

@@ -20,6 +20,9 @@
 namespace fdb {
 
 void hip_check(hipError_t e, const char* what);
+// Counts and array pointers of a plan descriptor agree (no negative count, no missing array, no projection without nodes): what every
+// reader of the descriptor — the dynamic-aggregation copy, Draw, the plan itself — may then rely on. Throws FDB_ERR_INVALID.
+void check_desc_shape(const fdb_plan_desc* d);
 
 // One column of a record resident in HBM.
 struct DevColumn {

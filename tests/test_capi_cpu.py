@@ -77,6 +77,48 @@ def test_descriptor_struct_layout_matches_header():
     assert lines[2] == [getattr(lp.CProjNode, f).offset for f in ("kind", "op", "left", "right", "column", "literal")]
 
 
+def test_descriptor_counts_and_arrays_must_agree(built_lib):
+    """Found by tools/desc_fuzz.py: a projection without a node array under a dynamic aggregation was dereferenced by the copy the
+    dynamic-aggregation family makes of the descriptor, before the plan's own validation saw it. Counts and arrays are now checked
+    first, for every reader."""
+    from frostdb_amd.logicalplan import CAggregation, CExpr, CGroupExpr, CPlanDesc, CProjNode, CProjection
+
+    def explain(d):
+        buf = ctypes.create_string_buffer(1024)
+        need = ctypes.c_int64(0)
+        return built_lib.fdb_plan_explain(ctypes.byref(d), buf, ctypes.c_int64(len(buf)), ctypes.byref(need))
+
+    def base(dynamic):
+        d = CPlanDesc()
+        ag = (CAggregation * 1)()
+        ag[0].func, ag[0].dynamic, ag[0].column = 1, dynamic, b"value"
+        d.aggs, d.n_aggs = ctypes.cast(ag, ctypes.POINTER(CAggregation)), 1
+        return d, [ag]
+
+    for dynamic in (0, 1):
+        d, keep = base(dynamic)
+        assert explain(d) == 0
+        pj = (CProjection * 1)()
+        pj[0].name, pj[0].nodes, pj[0].n_nodes, pj[0].root = b"p", None, 1, 0  # nodes missing
+        d.projections, d.n_projections = ctypes.cast(pj, ctypes.POINTER(CProjection)), 1
+        assert explain(d) == 1
+        nodes = (CProjNode * 1)()
+        nodes[0].kind, nodes[0].column = 0, b"value"
+        pj[0].nodes, pj[0].name = ctypes.cast(nodes, ctypes.POINTER(CProjNode)), None  # name missing
+        assert explain(d) == 1
+        pj[0].name, pj[0].n_nodes = b"p", -1
+        assert explain(d) == 1
+        for field, count in (("filter", "n_filter"), ("groups", "n_groups"), ("projections", "n_projections"), ("aggs", "n_aggs")):
+            d, keep = base(dynamic)
+            setattr(d, count, 3)        # a count without its array
+            if field == "aggs":
+                d.aggs = None
+            assert explain(d) == 1, (field, dynamic)
+            d, keep = base(dynamic)
+            setattr(d, count, -1)       # a negative count
+            assert explain(d) == 1, (field, dynamic)
+
+
 def test_invalid_descriptors_are_rejected_without_a_gpu(built_lib):
     # Descriptor validation happens before any HIP call, so these error paths are observable on CPU.
     from frostdb_amd.logicalplan import CExpr, CPlanDesc
