@@ -94,8 +94,27 @@ std::shared_ptr<HostDict> make_dictionary(std::vector<std::string>&& values, con
   return d;
 }
 
+namespace {
+// What the C data interface lets a consumer verify without knowing buffer sizes: no negative lengths / offsets / counts, a buffer
+// table wherever buffers are announced, child tables and children wherever children are announced, a dictionary array wherever the
+// schema has a dictionary. Everything below dereferences these pointers; a producer's bug must come back as an error code.
+void check_array_shape(const ArrowArray* a, const ArrowSchema* s, const std::string& what, int depth) {
+  if (a == nullptr || s == nullptr) throw Error(FDB_ERR_INVALID, "missing array or schema: " + what);
+  if (depth > 8) throw Error(FDB_ERR_UNSUPPORTED, "array nested too deeply: " + what);
+  if (a->length < 0 || a->offset < 0) throw Error(FDB_ERR_INVALID, "negative length or offset: " + what);
+  if (a->n_buffers < 0 || a->n_children < 0 || s->n_children < 0) throw Error(FDB_ERR_INVALID, "negative buffer or child count: " + what);
+  if (a->n_buffers > 0 && a->buffers == nullptr) throw Error(FDB_ERR_INVALID, "buffers announced without a buffer table: " + what);
+  if (a->n_children != s->n_children) throw Error(FDB_ERR_INVALID, "schema/array children mismatch: " + what);
+  if (a->n_children > 0 && (a->children == nullptr || s->children == nullptr)) throw Error(FDB_ERR_INVALID, "children announced without a child table: " + what);
+  for (int64_t i = 0; i < a->n_children; i++) check_array_shape(a->children[i], s->children[i], what, depth + 1);
+  if ((s->dictionary != nullptr) != (a->dictionary != nullptr)) throw Error(FDB_ERR_INVALID, "dictionary column without a dictionary array: " + what);
+  if (s->dictionary != nullptr) check_array_shape(a->dictionary, s->dictionary, what, depth + 1);
+}
+}  // namespace
+
 void view_record(const ArrowArray* array, const ArrowSchema* schema, HostRecordView* out) {
   if (array == nullptr || schema == nullptr) throw Error(FDB_ERR_INVALID, "null record");
+  check_array_shape(array, schema, "record", 0);
   if (schema->format == nullptr || std::strcmp(schema->format, "+s") != 0)
     throw Error(FDB_ERR_INVALID, "record batch must be exported as a struct array (format \"+s\")");
   if (array->n_children != schema->n_children) throw Error(FDB_ERR_INVALID, "schema/array children mismatch");
@@ -144,11 +163,12 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
   const std::string value_format = (df == "u" || df == "U") ? "u" : "z";
   const int64_t n = da->length, off = da->offset;
   if (n < 0 || off < 0) throw Error(FDB_ERR_INVALID, "dictionary with a negative length / offset: " + col.name);
-  if (n > 0 && (da->n_buffers < 3 || da->buffers[1] == nullptr)) throw Error(FDB_ERR_INVALID, "dictionary without an offsets buffer: " + col.name);
+  if (n > 0 && (da->n_buffers < 3 || da->buffers == nullptr || da->buffers[1] == nullptr)) throw Error(FDB_ERR_INVALID, "dictionary without an offsets buffer: " + col.name);
   const char* data = da->n_buffers >= 3 ? (const char*)da->buffers[2] : nullptr;
   const bool wide = !(df == "u" || df == "z");
-  const int32_t* o32 = (const int32_t*)da->buffers[1];
-  const int64_t* o64 = (const int64_t*)da->buffers[1];
+  const void* offsets = da->n_buffers >= 2 ? da->buffers[1] : nullptr;  // (only read when n > 0)
+  const int32_t* o32 = (const int32_t*)offsets;
+  const int64_t* o64 = (const int64_t*)offsets;
   auto begin = [&](int64_t i) -> int64_t { return wide ? o64[off + i] : (int64_t)o32[off + i]; };
   // offsets must not decrease, and a dictionary with bytes needs a data buffer (a NULL entry reads as "", like arrow-go's
   // Binary.Value of a null slot)
@@ -194,10 +214,11 @@ std::shared_ptr<HostDict> encode_plain(const HostColView& col, std::vector<uint3
   const ArrowArray* a = col.array;
   const bool wide = col.format == "U" || col.format == "Z";
   const int64_t n = col.length, off = col.offset;
-  if (n > 0 && (a->n_buffers < 3 || a->buffers[1] == nullptr)) throw Error(FDB_ERR_INVALID, "string column without offsets: " + col.name);
-  const char* data = (const char*)a->buffers[2];
-  const int32_t* o32 = (const int32_t*)a->buffers[1];
-  const int64_t* o64 = (const int64_t*)a->buffers[1];
+  if (n > 0 && (a->n_buffers < 3 || a->buffers == nullptr || a->buffers[1] == nullptr)) throw Error(FDB_ERR_INVALID, "string column without offsets: " + col.name);
+  const char* data = a->n_buffers >= 3 ? (const char*)a->buffers[2] : nullptr;
+  const void* offsets = a->n_buffers >= 2 ? a->buffers[1] : nullptr;  // (only read when n > 0)
+  const int32_t* o32 = (const int32_t*)offsets;
+  const int64_t* o64 = (const int64_t*)offsets;
   auto begin = [&](int64_t i) -> int64_t { return wide ? o64[off + i] : (int64_t)o32[off + i]; };
   std::shared_ptr<HostDict> d(new HostDict());
   d->value_format = col.format;  // the column's own type, large or not: key columns and filter output keep it
@@ -209,7 +230,8 @@ std::shared_ptr<HostDict> encode_plain(const HostColView& col, std::vector<uint3
   for (int64_t i = 0; i < n; i++) {
     if (col.null_count > 0 && col.validity != nullptr && !((col.validity[(off + i) >> 3] >> ((off + i) & 7)) & 1)) continue;
     const int64_t b0 = begin(i), b1 = begin(i + 1);
-    if (b1 < b0) throw Error(FDB_ERR_INVALID, "string column with decreasing offsets: " + col.name);
+    if (b1 < b0 || b0 < 0) throw Error(FDB_ERR_INVALID, "string column with decreasing offsets: " + col.name);
+    if (b1 > b0 && data == nullptr) throw Error(FDB_ERR_INVALID, "string column without a data buffer: " + col.name);
     const std::string_view v(b1 > b0 ? data + b0 : "", (size_t)(b1 - b0));
     auto it = ids.find(v);
     if (it == ids.end()) {

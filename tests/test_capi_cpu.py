@@ -77,6 +77,44 @@ def test_descriptor_struct_layout_matches_header():
     assert lines[2] == [getattr(lp.CProjNode, f).offset for f in ("kind", "op", "left", "right", "column", "literal")]
 
 
+def test_arrow_records_with_missing_tables_are_refused(built_lib):
+    """Found by tools/arrow_fuzz.py: a string column that announced three buffers without a buffer table was dereferenced. Every
+    defect the C data interface lets a consumer see — NULL tables behind non-zero counts, negative lengths, a dictionary schema
+    without a dictionary array — now comes back as FDB_ERR_INVALID before anything is read."""
+    import pyarrow as pa
+    from frostdb_amd.arrow_c import ArrowArray, ArrowSchema, ExportedBatch
+    rb = pa.RecordBatch.from_arrays([pa.array(["a", None, "ccc"]), pa.array([1, 2, 3], type=pa.int64()),
+                                     pa.DictionaryArray.from_arrays(pa.array([0, 1, 0], type=pa.uint32()), pa.array([b"x", b"y"], type=pa.binary()))],
+                                    names=["s", "v", "d"])
+
+    def roundtrip(mutate):
+        with ExportedBatch(rb) as ex:
+            undo = mutate(ex)
+            out, outs = ArrowArray(), ArrowSchema()
+            rc = built_lib.fdb_arrow_roundtrip(ctypes.byref(ex.array), ctypes.byref(ex.schema), ctypes.byref(out), ctypes.byref(outs))
+            undo()
+            if rc == 0:
+                pa.RecordBatch._import_from_c(ctypes.addressof(out), ctypes.addressof(outs))
+            return rc
+
+    assert roundtrip(lambda ex: (lambda: None)) == 0
+
+    def field(path, name, value):
+        def mutate(ex):
+            st = path(ex)
+            raw = ctypes.string_at(ctypes.addressof(st), ctypes.sizeof(st))  # (a pointer field read through ctypes is a VIEW of the struct)
+            setattr(st, name, value)
+            return lambda: ctypes.memmove(ctypes.addressof(st), raw, len(raw))
+        return mutate
+
+    child = lambda k: (lambda ex: ex.array.children[k].contents)
+    for mut in (field(child(0), "buffers", None), field(child(1), "buffers", None), field(child(0), "length", -1), field(child(1), "offset", -3),
+                field(child(2), "dictionary", None), field(child(0), "n_buffers", -1), field(lambda ex: ex.array, "children", None),
+                field(lambda ex: ex.schema, "children", None), field(lambda ex: ex.array, "n_children", 9),
+                field(lambda ex: ex.schema.children[2].contents, "dictionary", None)):
+        assert roundtrip(mut) == 1
+
+
 def test_descriptor_counts_and_arrays_must_agree(built_lib):
     """Found by tools/desc_fuzz.py: a projection without a node array under a dynamic aggregation was dereferenced by the copy the
     dynamic-aggregation family makes of the descriptor, before the plan's own validation saw it. Counts and arrays are now checked
