@@ -78,6 +78,8 @@ int wrap_all(std::vector<std::unique_ptr<fdb::Comm>>&& v, fdb_comm** out) {
 }
 }  // namespace
 
+namespace fdb { void widen_indices(const void* src, int width, uint32_t* dst, size_t n); }  // fdb_widen.cc
+
 extern "C" {
 
 const char* fdb_version(void) { return "frostdb_amd 0.1.0 (gfx950)"; }
@@ -110,6 +112,13 @@ int fdb_plan_explain(const fdb_plan_desc* desc, char* buf, int64_t capacity, int
       std::memcpy(buf, s.data(), n);
       buf[n] = 0;
     }
+  });
+}
+
+int fdb_selftest_widen(const void* src, int32_t width, uint32_t* dst, int64_t n) {
+  return guard(nullptr, [&] {
+    if ((width != 1 && width != 2 && width != 4) || n < 0 || ((src == nullptr || dst == nullptr) && n > 0)) throw fdb::Error(FDB_ERR_INVALID, "widen: width 1, 2 or 4 and non-null buffers");
+    fdb::widen_indices(src, width, dst, (size_t)n);
   });
 }
 

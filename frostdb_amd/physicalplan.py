@@ -93,6 +93,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_read_ceiling.argtypes = [ctypes.c_int, ctypes.c_int64, i32, ctypes.POINTER(ctypes.c_double)]
     L.fdb_plan_last_kernel.argtypes = [vp]
     L.fdb_arrow_roundtrip.argtypes = [vp, vp, vp, vp]
+    L.fdb_selftest_widen.argtypes = [vp, i32, vp, i64]
     L.fdb_plan_explain.argtypes = [vp, ctypes.c_char_p, i64, P(i64)]
     L.fdb_plan_last_kernel.restype = ctypes.c_char_p
     L.fdb_comm_unique_id.argtypes = [vp]

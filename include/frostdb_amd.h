@@ -218,6 +218,10 @@ int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s);
  * in `out` with every column's type, values and NULLs unchanged, except that dictionary indices are uint32 and dictionaries with
  * large value types are narrowed. No device is touched, so it runs where there is no GPU. */
 int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out, struct ArrowSchema* out_schema);
+/* Host-only self-check of the widening step of a big Finish (dictionary indices cross PCIe as uint8 / uint16 / uint32 — `width` 1,
+ * 2 or 4 bytes — and are widened to Arrow's uint32 by host threads): dst[i] = src[i] for i < n, through the same routine (AVX2 with
+ * streaming stores where the CPU has it). No device is touched. */
+int fdb_selftest_widen(const void* src, int32_t width, uint32_t* dst, int64_t n);
 
 /* ---- plan life cycle (≙ physicalplan.Build for one chain, physicalplan.go:417-474) -------------- */
 int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);

@@ -77,6 +77,26 @@ def test_descriptor_struct_layout_matches_header():
     assert lines[2] == [getattr(lp.CProjNode, f).offset for f in ("kind", "op", "left", "right", "column", "literal")]
 
 
+def test_widening_of_narrow_result_indices(built_lib):
+    """The host half of a big Finish: uint8 / uint16 indices → uint32, vector path and scalar head / tail, at every destination
+    alignment and at sizes around the vector width."""
+    import numpy as np
+    rng = np.random.default_rng(12)
+    for width, dt in ((1, np.uint8), (2, np.uint16), (4, np.uint32)):
+        for n in (0, 1, 7, 31, 32, 33, 63, 64, 65, 1000, 4099):
+            for shift in (0, 1, 3, 7):  # destination 4·shift bytes past a 64-byte boundary: exercises the alignment head
+                src = rng.integers(0, np.iinfo(dt).max, n + 3, dtype=dt)[3:]  # (unaligned source too)
+                raw = np.zeros(n + 32, dtype=np.uint32)
+                base = (-raw.ctypes.data // 4) % 16
+                dst = raw[base + shift: base + shift + n]
+                guard_after = raw[base + shift + n: base + shift + n + 4].copy()
+                rc = built_lib.fdb_selftest_widen(ctypes.c_void_p(src.ctypes.data), ctypes.c_int32(width), ctypes.c_void_p(dst.ctypes.data), ctypes.c_int64(n))
+                assert rc == 0
+                assert np.array_equal(dst, src.astype(np.uint32)), (width, n, shift)
+                assert np.array_equal(raw[base + shift + n: base + shift + n + 4], guard_after)  # nothing written past the end
+    assert built_lib.fdb_selftest_widen(None, ctypes.c_int32(3), None, ctypes.c_int64(0)) == 1
+
+
 def test_arrow_records_with_missing_tables_are_refused(built_lib):
     """Found by tools/arrow_fuzz.py: a string column that announced three buffers without a buffer table was dereferenced. Every
     defect the C data interface lets a consumer see — NULL tables behind non-zero counts, negative lengths, a dictionary schema
