@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, pyarrow as pa
 from frostdb_amd import physicalplan as pp
 from frostdb_amd.arrow_c import ArrowArray, ArrowSchema, ExportedBatch, _RELEASE_FN
-lib = pp.lib()
+lib = ctypes.CDLL(os.environ['FDB_FUZZ_LIB']) if os.environ.get('FDB_FUZZ_LIB') else pp.lib()  # (e.g. the ASan build of tools/asan_arrow.sh)
 random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 rng = np.random.default_rng(3)
 
@@ -46,7 +46,7 @@ def mutate_array(a, depth=0, real_children=None):
 def mutate_schema(s, depth=0, real_children=None):
     r = random.random(); log.append(('schema', depth, round(r, 3), s.format, s.n_children))
     if r < 0.15:
-        f = random.choice([None, b"", b"?", b"+s", b"+l", b"tsu:", b"w:4", b"l", b"u", b"z", b"g"]); keep.append(f); s.format = f
+        f = random.choice([None, b"", b"?", b"+l", b"tsu:", b"w:4", b"+m"]); keep.append(f); s.format = f  # (never a known type of another width: that is a lie about buffer sizes, which the interface cannot express)
     elif r < 0.25: s.n_children = random.choice([0, -1, s.n_children + 2])
     elif r < 0.32: s.children = None
     elif r < 0.40: s.dictionary = None
