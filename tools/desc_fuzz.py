@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from frostdb_amd import physicalplan as pp
 from frostdb_amd.logicalplan import CLiteral, CExpr, CAggregation, CGroupExpr, CProjNode, CProjection, CPlanDesc
 lib = pp.lib()
+if os.environ.get('FDB_FUZZ_LIB'):  # an instrumented build of the whole library (hipcc -fsanitize=address,undefined -fno-gpu-sanitize)
+    lib = ctypes.CDLL(os.environ['FDB_FUZZ_LIB'])
+    lib.fdb_plan_explain.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
 random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 names = [b"labels.a", b"value", b"timestamp", b"", b"x" * 300, None, b"labels", b"sum(value)"]
 pats = [b"a.*", b"(", b"[", b"\\", b"", b"^x$", b"(a|b)+" * 50]
