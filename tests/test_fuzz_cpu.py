@@ -1,0 +1,39 @@
+"""Short, seeded runs of the three host-side fuzzers (tools/desc_fuzz.py, tools/arrow_fuzz.py, tools/asan_parquet_run.py) against the
+library as built — in child processes with a timeout, so that a crash or an endless loop is a failed test, not a dead test session.
+The long campaigns (and the ASan / UBSan builds) are tools/asan_full.sh's job; this keeps the three bugs they found from coming back."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_tool(args, env=None, timeout=240):
+    from frostdb_amd import build
+    build.build()
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, f"{args}: rc {p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-2000:]}"
+    return p.stdout
+
+
+@pytest.mark.timeout(300)
+def test_random_plan_descriptors_never_crash_explain():
+    out = run_tool([os.path.join(ROOT, "tools", "desc_fuzz.py"), "2500", "3"])
+    assert "codes" in out
+
+
+@pytest.mark.timeout(300)
+def test_arrow_records_with_detectable_defects_come_back_as_error_codes():
+    out = run_tool([os.path.join(ROOT, "tools", "arrow_fuzz.py"), "1200", "3"])
+    assert "codes" in out
+
+
+@pytest.mark.timeout(300)
+def test_mutated_parquet_chunks_are_refused_or_parsed_never_fatal():
+    lib = os.path.join(ROOT, "frostdb_amd", "libfrostdb_amd.so")
+    out = run_tool([os.path.join(ROOT, "tools", "asan_parquet_run.py"), "25", "3"], env={"FDB_ASAN_LIB": lib})
+    assert "runs 225" in out
