@@ -37,14 +37,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(inc) or open(inc).read() != new:
         with open(inc, "w") as f:
             f.write(new)
-    objs = []
+    # per-object staleness (a header change rebuilds everything), translation units compiled side by side
+    from concurrent.futures import ThreadPoolExecutor
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + ["fdb_kernels_h.inc"])
+    flags_sig = " ".join(FLAGS)
+    sig_path = os.path.join(CSRC, ".build_flags")
+    same_flags = os.path.exists(sig_path) and open(sig_path).read() == flags_sig
+    objs, jobs = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        fresh = (not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) >= hdr_t
+                 and os.path.getmtime(obj) >= os.path.getmtime(os.path.join(CSRC, src)))
+        if not fresh:
+            jobs.append([hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-        objs.append(obj)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs) or 1, os.cpu_count() or 4))) as ex:
+        list(ex.map(run, jobs))
+    with open(sig_path, "w") as f:
+        f.write(flags_sig)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhiprtc", "-ldl", "-lpthread", "-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

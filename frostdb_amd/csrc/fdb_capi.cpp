@@ -421,6 +421,7 @@ int fdb_comm_init_rank(const uint8_t id[FDB_COMM_ID_BYTES], int32_t n_ranks, int
 int fdb_comm_init_all(const int* devices, int32_t n, fdb_comm** out) {
   return comm_guard(nullptr, [&] {
     if (devices == nullptr || out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    for (int32_t i = 0; i < n && i < FDB_MAX_PARTS; i++) out[i] = nullptr;  // (nothing dangling if creation fails)
     wrap_all(fdb::rccl_init_all(devices, n), out);
   });
 }
@@ -428,6 +429,7 @@ int fdb_comm_init_all(const int* devices, int32_t n, fdb_comm** out) {
 int fdb_comm_init_local(const int* devices, int32_t n, fdb_comm** out) {
   return comm_guard(nullptr, [&] {
     if (devices == nullptr || out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    for (int32_t i = 0; i < n && i < FDB_MAX_PARTS; i++) out[i] = nullptr;  // (nothing dangling if creation fails)
     wrap_all(fdb::local_init(devices, n), out);
   });
 }

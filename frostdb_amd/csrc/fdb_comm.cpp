@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 
 #include "fdb_context.h"
@@ -359,13 +360,15 @@ std::vector<std::unique_ptr<Comm>> rccl_init_all(const int* devices, int n) {
   RcclApi& R = rccl();
   std::vector<ncclComm_t> comms((size_t)n, nullptr);
   nccl_check(R.CommInitAll(comms.data(), n, devices), "ncclCommInitAll");
-  std::vector<std::unique_ptr<Comm>> out;
+  // every raw handle gets its owner BEFORE anything that can fail: if rank r's setup throws, ~RcclComm destroys all n communicators
+  std::vector<std::unique_ptr<RcclComm>> owned;
   for (int r = 0; r < n; r++) {
-    std::unique_ptr<RcclComm> c(new RcclComm());
-    c->rank = r; c->size = n; c->device = devices[r]; c->comm = comms[(size_t)r];
-    c->setup();
-    out.push_back(std::move(c));
+    owned.emplace_back(new RcclComm());
+    owned.back()->rank = r; owned.back()->size = n; owned.back()->device = devices[r]; owned.back()->comm = comms[(size_t)r];
   }
+  for (auto& c : owned) c->setup();
+  std::vector<std::unique_ptr<Comm>> out;
+  for (auto& c : owned) out.push_back(std::move(c));
   return out;
 }
 
@@ -397,13 +400,22 @@ std::vector<std::unique_ptr<Comm>> local_init(const int* devices, int n) {
 
 // ---- plan-level merges --------------------------------------------------------------------------------------------------------
 bool Plan::comm_allreduce(Comm& comm) {
-  if (comm.device != device_) throw Error(FDB_ERR_INVALID, "communicator endpoint lives on another device than the plan");
-  settle();
-  hip_check(hipSetDevice(device_), "hipSetDevice");
+  // Whatever can fail on THIS rank before the first collective (a wrong device, a pending record that raises when it is scanned)
+  // is caught and VOTED: a rank that threw here while its peers entered the probe would leave them blocked inside RCCL for ever.
+  // The vote rides in the probe itself (the signature is 62 bits wide, so INT64_MAX in both of its words is no layout).
+  std::exception_ptr local;
   int64_t n_slots = 0;
-  const uint64_t sig = state_signature(&n_slots) & ((1ull << 62) - 1);
-  int64_t v[4] = {(int64_t)sig, -(int64_t)sig, n_slots, -n_slots};
+  int64_t v[4] = {INT64_MAX, INT64_MAX, 0, 0};
+  try {
+    if (comm.device != device_) throw Error(FDB_ERR_INVALID, "communicator endpoint lives on another device than the plan");
+    settle();
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    const uint64_t sig = state_signature(&n_slots) & ((1ull << 62) - 1);
+    v[0] = (int64_t)sig; v[1] = -(int64_t)sig; v[2] = n_slots; v[3] = -n_slots;
+  } catch (...) { local = std::current_exception(); }
   comm.probe_max(v);  // on the communicator's own stream: overlaps the scan still running on ours
+  if (local) std::rethrow_exception(local);
+  if (v[0] == INT64_MAX && v[1] == INT64_MAX) throw Error(FDB_ERR_STATE, "all-reduce merge abandoned: another rank failed before the collective");
   if (v[0] != -v[1] || v[2] != -v[3] || v[2] == 0) return false;
   std::vector<Comm::Red> reds;
   for (int32_t a = 0; a < num_state_arrays(); a++) {
@@ -478,14 +490,17 @@ void Plan::adopt_schema(const GroupSchema& s) {
 }
 
 void Plan::comm_exchange(Comm& comm, Plan& shard) {
-  if (comm.device != device_ || shard.device_ != device_) throw Error(FDB_ERR_INVALID, "communicator endpoint lives on another device than the plan");
-  settle();
-  hip_check(hipSetDevice(device_), "hipSetDevice");
   PhaseTimer pt;
   // 1. one group schema for all ranks: columns and dictionary values in first-seen order, ranks in rank order (the
-  //    Synchronizer's arrival order made deterministic); key ids assigned from it mean the same group everywhere
+  //    Synchronizer's arrival order made deterministic); key ids assigned from it mean the same group everywhere.
+  //    A rank that fails before this first collective still takes part in it — with an EMPTY message, which makes every rank
+  //    leave with an error instead of waiting inside RCCL for a peer that is gone.
   std::vector<uint8_t> blob;
-  {
+  std::exception_ptr local;
+  try {
+    if (comm.device != device_ || shard.device_ != device_) throw Error(FDB_ERR_INVALID, "communicator endpoint lives on another device than the plan");
+    settle();
+    hip_check(hipSetDevice(device_), "hipSetDevice");
     const GroupSchema mine = export_schema();
     put_u32(&blob, (uint32_t)mine.cols.size());
     for (const GroupSchemaCol& c : mine.cols) {
@@ -497,8 +512,11 @@ void Plan::comm_exchange(Comm& comm, Plan& shard) {
     }
     put_u32(&blob, (uint32_t)mine.agg_types.size());
     for (int32_t t : mine.agg_types) put_u32(&blob, (uint32_t)t);
-  }
+  } catch (...) { local = std::current_exception(); blob.clear(); }
   const std::vector<std::vector<uint8_t>> all = comm.all_gather_host(blob);
+  if (local) std::rethrow_exception(local);
+  for (const std::vector<uint8_t>& b : all)
+    if (b.empty()) throw Error(FDB_ERR_STATE, "exchange abandoned: another rank failed before the collective");
   GroupSchema uni;
   uni.agg_types.assign(aggs_.size(), FDB_T_NONE);
   std::vector<std::unordered_map<std::string, uint32_t>> seen;
@@ -532,20 +550,25 @@ void Plan::comm_exchange(Comm& comm, Plan& shard) {
       uni.agg_types[j] = t;
     }
   }
-  shard.adopt_schema(uni);
-  for (size_t j = 0; j < aggs_.size(); j++) if (aggs_[j].type == FDB_T_NONE) aggs_[j].type = uni.agg_types[j];
-  pt.mark("exchange: schema");
   // 2. re-key + partition on the device
   void* rows = nullptr;
   int64_t counts[FDB_MAX_PARTS] = {0};
   int32_t rw = 0;
-  hash_export(shard, comm.size, &rows, counts, &rw);  // synchronised: the rows are complete
-  pt.mark("exchange: export");
-  // 3. who sends how much to whom
   std::vector<uint8_t> cb((size_t)comm.size * 8 + 4);
-  std::memcpy(cb.data(), &rw, 4);
-  std::memcpy(cb.data() + 4, counts, (size_t)comm.size * 8);
+  try {
+    shard.adopt_schema(uni);
+    for (size_t j = 0; j < aggs_.size(); j++) if (aggs_[j].type == FDB_T_NONE) aggs_[j].type = uni.agg_types[j];
+    pt.mark("exchange: schema");
+    hash_export(shard, comm.size, &rows, counts, &rw);  // synchronised: the rows are complete
+    pt.mark("exchange: export");
+    std::memcpy(cb.data(), &rw, 4);
+    std::memcpy(cb.data() + 4, counts, (size_t)comm.size * 8);
+  } catch (...) { local = std::current_exception(); cb.clear(); }  // (a message of the wrong size: every rank refuses it below)
+  // 3. who sends how much to whom
   const std::vector<std::vector<uint8_t>> call = comm.all_gather_host(cb);
+  if (local) std::rethrow_exception(local);
+  for (int p = 0; p < comm.size; p++)
+    if (call[(size_t)p].empty()) throw Error(FDB_ERR_STATE, "exchange abandoned: another rank failed while exporting its table");
   std::vector<std::vector<int64_t>> words((size_t)comm.size, std::vector<int64_t>((size_t)comm.size, 0));
   int64_t recv_rows = 0;
   for (int p = 0; p < comm.size; p++) {

@@ -163,6 +163,9 @@ void scan_runs(const uint8_t* chunk, size_t off, size_t len, int bw, int64_t n_v
     if (h & 1) {
       const uint64_t groups = h >> 1;
       if (groups == 0) throw Error(FDB_ERR_INVALID, "parquet: empty bit-packed run");
+      // a run holds groups × 8 values, the last group padded: more groups than the values still missing is a damaged header —
+      // checked BEFORE multiplying (a varint of 2^59 groups would wrap `bytes` / `count` and pass the length test below)
+      if (groups > ((uint64_t)(n_values - done) + 7) / 8) throw Error(FDB_ERR_INVALID, "parquet: bit-packed run holds more values than its page");
       const uint64_t bytes = groups * (uint64_t)bw;
       int64_t count = (int64_t)(groups * 8);
       if (count > n_values - done) count = n_values - done;  // (the last group is padded)
@@ -535,6 +538,7 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
   }
   if (rows_done != n_rows) throw Error(FDB_ERR_INVALID, std::string("parquet: column chunk ") + (c.name ? c.name : "?") + " holds " + std::to_string(rows_done) + " values, the row group has " + std::to_string(n_rows) + " rows");
   out.non_null = rank_done;
+  if (is_bytes && rank_done > 0 && dict_values.empty()) throw Error(FDB_ERR_INVALID, std::string("parquet: column chunk ") + (c.name ? c.name : "?") + " has values but an empty dictionary");
   if (is_bytes) out.dict = make_dictionary(std::move(dict_values), c.utf8 ? "u" : "z");
   return out;
 }
@@ -677,7 +681,7 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
       d.null_count = n_rows - P.non_null;
       if (d.null_count > 0) { d.d_validity = (uint8_t*)b->arena + pieces[(size_t)i].bit_off; d.validity_bytes = (n_rows + 7) / 8; }
     }
-    if (d.kind == ColKind::DICT && P.max_index_bits > 0 && n_rows > 0) {
+    if (d.kind == ColKind::DICT && P.non_null > 0 && n_rows > 0) {  // (bit width 0 included: index 0 of an EMPTY dictionary is out of range too)
       // indices are validated like any imported dictionary column's (a corrupt page must not become an out-of-bounds LUT read)
       uint32_t* d_flag = (uint32_t*)ctx->dev_alloc(64);
       scratch.push_back(d_flag);

@@ -66,9 +66,20 @@ bool match_group(const GroupMatcher& m, const std::string& field) {  // logicalp
 // ---------------------------------------------------------------------------------------------------------
 // DeviceBatch
 // ---------------------------------------------------------------------------------------------------------
+void DeviceBatch::note_reader(hipStream_t s) const {
+  if (arena_ctx != nullptr) return;  // transient record: its arena returns to the cache of the very stream that reads it
+  std::lock_guard<std::mutex> lk(readers_mu_);
+  for (hipStream_t r : readers_) if (r == s) return;
+  readers_.push_back(s);
+}
+
 DeviceBatch::~DeviceBatch() {
   if (arena == nullptr) return;
   if (arena_ctx != nullptr) { arena_ctx->dev_free(arena); return; }
+  if (!readers_.empty()) {  // (an idle stream answers in about a microsecond)
+    (void)hipSetDevice(device);
+    for (hipStream_t s : readers_) (void)hipStreamSynchronize(s);
+  }
   device_pool_free(device, arena);
 }
 
@@ -1159,6 +1170,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   for (int i = 0; i < n; i++)
     if (bs[i]->device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
   hip_check(hipSetDevice(device_), "hipSetDevice");
+  for (int i = 0; i < n; i++) bs[i]->note_reader(stream_);
   PhaseTimer pt;
 
   std::vector<Resolved> Rs((size_t)n);
@@ -1901,6 +1913,11 @@ std::unique_ptr<DeviceBatch> Plan::filter_batch(const DeviceBatch& in, int64_t* 
   hip_check(hipSetDevice(device_), "hipSetDevice");
   std::unique_ptr<DeviceBatch> out(new DeviceBatch());
   out->device = device_;
+  // an error below must not hand `out`'s arena (or `in`, which the caller may release) back to the pool with kernels still queued
+  struct DrainOnUnwind {
+    hipStream_t s; int n = std::uncaught_exceptions();
+    ~DrainOnUnwind() { if (std::uncaught_exceptions() > n) (void)hipStreamSynchronize(s); }
+  } drain{stream_};
   for (const DevColumn& c : in.cols) {
     if (c.d_values == nullptr && in.rows > 0)
       throw Error(FDB_ERR_UNSUPPORTED, "filter output: column type " + c.format + " (" + c.name + ") is not supported on the device path");

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <regex>
 #include <string>
 #include <string_view>
@@ -46,9 +47,18 @@ struct DeviceBatch {
   size_t arena_bytes = 0;
   class Context* arena_ctx = nullptr;  // transient batches (fdb_plan_push): the arena is borrowed from the plan's block cache
   int64_t payload_bytes = 0;    // Σ value_bytes + validity_bytes
+  // Plans scan resident records asynchronously on their own streams and the caller may release a record as soon as the push
+  // call has returned: every launch that reads the arena notes its stream here, and the destructor waits for those streams
+  // before the block goes back to the pool (where another import, on another stream or thread, would overwrite it). Streams
+  // belong to pooled Contexts, which live as long as the process. Thread-safe (N chains push one record concurrently).
+  void note_reader(hipStream_t s) const;
   ~DeviceBatch();
   // Exactly-one-field lookup like ArrayRef.ArrowArray (binaryscalarexpr.go:22-29): -1 if absent or ambiguous.
   int find(const std::string& name) const;
+
+ private:
+  mutable std::mutex readers_mu_;
+  mutable std::vector<hipStream_t> readers_;
 };
 
 // Stages the columns of `view` accepted by `want(name)` (nullptr ⇒ all) to the device.

@@ -456,3 +456,59 @@ def test_parquet_chunks_are_parsed_and_refused_on_the_host():
         with pytest.raises(pp.FdbError) as e:
             pp.ResidentBatch.from_parquet(wrong, rows)
         assert e.value.code == pp.FDB_ERR_INVALID, codec
+
+
+def _thrift_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _thrift_i32(field_delta, v):
+    return bytes([(field_delta << 4) | 5]) + _thrift_varint((v << 1) ^ (v >> 31))
+
+
+def _parquet_page(page_type, body, num_values, encoding):
+    """A thrift-compact PageHeader (parquet.thrift) + body: type, sizes, then DataPageHeader (field 5) or DictionaryPageHeader (7)."""
+    hdr = _thrift_i32(1, page_type) + _thrift_i32(1, len(body)) + _thrift_i32(1, len(body))
+    if page_type == 0:  # DataPageHeader{num_values, encoding, definition_level_encoding = RLE, repetition_level_encoding = RLE}
+        hdr += bytes([(2 << 4) | 12]) + _thrift_i32(1, num_values) + _thrift_i32(1, encoding) + _thrift_i32(1, 3) + _thrift_i32(1, 3) + b"\x00"
+    else:               # DictionaryPageHeader{num_values, encoding}
+        hdr += bytes([(4 << 4) | 12]) + _thrift_i32(1, num_values) + _thrift_i32(1, encoding) + b"\x00"
+    return hdr + b"\x00" + body
+
+
+def test_parquet_run_headers_that_overflow_and_empty_dictionaries_are_refused_on_the_host():
+    """Two crafted BYTE_ARRAY RLE_DICTIONARY chunks (round-2 review): a bit-packed run whose varint header announces 2^59 groups of
+    32-bit indices (groups × width wraps to 0 bytes, so the old length test passed and the device would have read n_rows × 32 bits
+    that are not in the page; 2^60 groups of 16 bits turned the value count negative), and a chunk whose dictionary page is EMPTY
+    while its data page has bit width 0 (every row = index 0 of nothing). Both must come back FDB_ERR_INVALID before any device call;
+    the same pages with honest headers parse (FDB_ERR_DEVICE on this GPU-less box)."""
+    import struct
+    from frostdb_amd import physicalplan as pp
+    n = 1000
+    dict_page = _parquet_page(2, b"".join(struct.pack("<I", 2) + b"v%d" % i for i in range(4)), 4, 0)
+
+    def chunk(bw, groups, payload, dpage=dict_page):
+        body = bytes([bw]) + _thrift_varint((groups << 1) | 1) + payload
+        return dpage + _parquet_page(0, body, n, 8)
+
+    def code(data):
+        with pytest.raises(pp.FdbError) as e:
+            pp.ResidentBatch.from_parquet([("labels.a", pp.PARQUET_BYTE_ARRAY, 0, False, data, "UNCOMPRESSED")], n)
+        return e.value.code
+
+    assert code(chunk(32, 125, b"\x00" * (125 * 32))) == pp.FDB_ERR_DEVICE   # honest: 125 groups × 8 values
+    assert code(chunk(32, 125, b"")) == pp.FDB_ERR_INVALID                   # honest header, payload missing
+    assert code(chunk(32, 1 << 59, b"")) == pp.FDB_ERR_INVALID               # groups × 32 wraps to 0 bytes
+    assert code(chunk(16, 1 << 60, b"")) == pp.FDB_ERR_INVALID               # groups × 8 turns negative
+    assert code(chunk(32, 126, b"\x00" * (126 * 32))) == pp.FDB_ERR_INVALID  # more groups than the page has values
+    empty_dict = _parquet_page(2, b"", 0, 0)
+    assert code(empty_dict + _parquet_page(0, bytes([0]), n, 8)) == pp.FDB_ERR_INVALID  # bit width 0 into an empty dictionary
+    assert code(dict_page + _parquet_page(0, bytes([0]), n, 8)) == pp.FDB_ERR_DEVICE     # bit width 0, index 0 exists

@@ -53,8 +53,13 @@ for kw in variants:
                     b = b[: random.randrange(1, len(b))]
                 elif r < 0.75:
                     k = random.randrange(len(b)); b[k:k] = bytes(random.randrange(256) for _ in range(random.randint(1, 40)))
-                elif r < 0.9:
+                elif r < 0.82:
                     k = random.randrange(len(b)); l = random.randint(1, 64); b[k:k + l] = b"\xff" * l
+                elif r < 0.9:
+                    # a huge varint (2^56 … 2^63, as a run / block / collection header would carry it) written over a random spot
+                    k = random.randrange(len(b)); v = (1 << random.randint(56, 63)) | random.getrandbits(8); enc = bytearray()
+                    while v >= 0x80: enc.append((v & 0x7F) | 0x80); v >>= 7
+                    enc.append(v); b[k:k + len(enc)] = enc
                 else:
                     cd = random.choice(["SNAPPY", "UNCOMPRESSED", "ZSTD", "GZIP", "LZ4"]); opt = random.choice([0, 1])
             mut.append((nm, ty, opt, u8, bytes(b), cd))
