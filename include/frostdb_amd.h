@@ -224,6 +224,8 @@ int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* schema, st
 int fdb_selftest_widen(const void* src, int32_t width, uint32_t* dst, int64_t n);
 
 /* ---- plan life cycle (≙ physicalplan.Build for one chain, physicalplan.go:417-474) -------------- */
+/* `desc` and everything it points at (expression nodes, names, literals, patterns) is copied: the caller may free it as soon
+ * as the call has returned (the Go shim builds it in C memory and frees that right away, integration/go/gpuplan/operator.go). */
 int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
 /* ≙ PhysicalPlan.Callback: borrows `batch` for the duration of the call only (the reference releases
  * the record right after Callback returns, table.go:808,:827). The record is validated against the plan (errors it

@@ -12,13 +12,17 @@ package gpuplan
 #include <stdlib.h>
 #include "frostdb_amd.h"
 extern int32_t fdbRegexMatch(void*, char*, int64_t, uint8_t*, int64_t);
+// cgo exports take non-const pointers; this wrapper has fdb_regex_match_fn's exact (const-qualified) signature
+static int32_t fdbRegexMatchC(void* user, const char* pat, int64_t pat_len, const uint8_t* val, int64_t val_len) {
+	return fdbRegexMatch(user, (char*)pat, pat_len, (uint8_t*)val, val_len);
+}
+static fdb_regex_match_fn fdbRegexMatchFn(void) { return fdbRegexMatchC; }
 */
 import "C"
 
 import (
 	"context"
 	"errors"
-	"runtime"
 	"unsafe"
 
 	"github.com/apache/arrow-go/v18/arrow"
@@ -32,43 +36,74 @@ import (
 type Operator struct {
 	plan *C.fdb_plan
 	next physicalplan.PhysicalPlan
-	pin  runtime.Pinner // keeps the descriptor's C strings alive until Close
+}
+
+// cArena owns the C memory a descriptor is built from. The descriptor's arrays hold pointers (column names, literals), and cgo
+// forbids passing Go memory that itself contains Go pointers ("Go pointer to unpinned Go pointer"): everything the descriptor
+// points at is therefore C memory. fdb_plan_create copies what it keeps (names, literals, patterns), so the arena is freed as
+// soon as the call has returned.
+type cArena struct{ ptrs []unsafe.Pointer }
+
+func (a *cArena) str(s string) *C.char {
+	p := C.CString(s)
+	a.ptrs = append(a.ptrs, unsafe.Pointer(p))
+	return p
+}
+func (a *cArena) alloc(n int, size uintptr) unsafe.Pointer {
+	if n == 0 {
+		return nil
+	}
+	p := C.calloc(C.size_t(n), C.size_t(size))
+	a.ptrs = append(a.ptrs, p)
+	return p
+}
+func (a *cArena) free() {
+	for _, p := range a.ptrs {
+		C.free(p)
+	}
+	a.ptrs = nil
 }
 
 // New flattens the logical expressions into fdb_plan_desc. Op and AggFunc values are passed through unchanged:
 // fdb_op == logicalplan.Op and fdb_agg_func == logicalplan.AggFunc numerically (logicalplan/expr.go:17-35, :718-729).
 func New(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation) (*Operator, error) {
-	var nodes []C.fdb_expr
+	var mem cArena
+	defer mem.free()
+	var nodes []C.fdb_expr // Go slice while it grows; its strings are C memory already, the array is copied to C below
 	root := C.int32_t(-1)
 	if filter != nil {
-		r, err := flatten(filter, &nodes) // BinaryExpr{Column, Op, Literal} | And | Or  →  post-order array
+		r, err := flatten(filter, &nodes, &mem) // BinaryExpr{Column, Op, Literal} | And | Or  →  post-order array
 		if err != nil {
 			return nil, err // ≙ ErrUnsupportedBooleanExpression (filter.go:46)
 		}
 		root = C.int32_t(r)
 	}
-	aggs := make([]C.fdb_aggregation, len(agg.AggExprs))
+	cNodes := (*C.fdb_expr)(mem.alloc(len(nodes), unsafe.Sizeof(C.fdb_expr{})))
+	if len(nodes) > 0 {
+		copy(unsafe.Slice(cNodes, len(nodes)), nodes)
+	}
+	cAggs := (*C.fdb_aggregation)(mem.alloc(len(agg.AggExprs), unsafe.Sizeof(C.fdb_aggregation{})))
+	aggs := unsafe.Slice(cAggs, len(agg.AggExprs))
 	for i, a := range agg.AggExprs {
 		aggs[i]._func = C.int32_t(a.Func)
-		aggs[i].column = C.CString(a.Expr.Name())
+		aggs[i].column = mem.str(a.Expr.Name())
 		if _, dyn := a.Expr.(*logicalplan.DynamicColumn); dyn { // `max(foo)` over every foo.* column (aggregate.go:38-46)
 			aggs[i].dynamic = 1
 		}
 	}
-	groups := make([]C.fdb_group_expr, len(agg.GroupExprs))
+	cGroups := (*C.fdb_group_expr)(mem.alloc(len(agg.GroupExprs), unsafe.Sizeof(C.fdb_group_expr{})))
+	groups := unsafe.Slice(cGroups, len(agg.GroupExprs))
 	for i, g := range agg.GroupExprs {
 		_, dyn := g.(*logicalplan.DynamicColumn)
-		groups[i].name = C.CString(g.Name())
+		groups[i].name = mem.str(g.Name())
 		if dyn {
 			groups[i].dynamic = 1
 		}
 	}
-	desc := C.fdb_plan_desc{n_filter: C.int32_t(len(nodes)), filter_root: root,
-		n_aggs: C.int32_t(len(aggs)), n_groups: C.int32_t(len(groups)),
-		regex_match: C.fdb_regex_match_fn(C.fdbRegexMatch)} // `=~` / `!~` keep Go's regexp semantics, see below
-	if len(nodes) > 0 { desc.filter = &nodes[0] }
-	if len(aggs) > 0 { desc.aggs = &aggs[0] }
-	if len(groups) > 0 { desc.groups = &groups[0] }
+	// (desc itself is a Go value on this stack holding only C pointers: legal to pass by address)
+	desc := C.fdb_plan_desc{filter: cNodes, n_filter: C.int32_t(len(nodes)), filter_root: root,
+		aggs: cAggs, n_aggs: C.int32_t(len(aggs)), groups: cGroups, n_groups: C.int32_t(len(groups)),
+		regex_match: C.fdbRegexMatchFn()} // `=~` / `!~` keep Go's regexp semantics, see below
 	op := &Operator{}
 	if rc := C.fdb_plan_create(&desc, C.int(device), &op.plan); rc != C.FDB_OK {
 		return nil, errors.New(C.GoString(C.fdb_last_error()))
@@ -79,7 +114,7 @@ func New(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation) (*Op
 // fdbRegexMatch is the library's regex engine: it is called once per DISTINCT value of the filtered column (per dictionary
 // entry), never per row, so `labels.x =~ "(?i)foo.*"` selects exactly the rows the reference's RegExpFilter would
 // (regexpfilter.go:84-166: unanchored regexp.Match on the value's bytes; patterns compiled once, filter.go:105-124).
-// In the cgo preamble: `extern int32_t fdbRegexMatch(void*, char*, int64_t, uint8_t*, int64_t);`
+// The descriptor gets the const-correct C wrapper from the preamble (fdbRegexMatchFn), not this export directly.
 //
 //export fdbRegexMatch
 func fdbRegexMatch(_ unsafe.Pointer, pat *C.char, patLen C.int64_t, val *C.uint8_t, valLen C.int64_t) C.int32_t {
@@ -134,22 +169,30 @@ func (o *Operator) Draw() *physicalplan.Diagram {
 	if o.next != nil { child = o.next.Draw() }
 	return &physicalplan.Diagram{Details: C.GoString(C.fdb_plan_draw(o.plan)), Child: child}
 }
-func (o *Operator) Close() { C.fdb_plan_close(o.plan); o.plan = nil; o.next.Close() }
+func (o *Operator) Close() {
+	if o.plan != nil {
+		C.fdb_plan_close(o.plan)
+		o.plan = nil
+	}
+	if o.next != nil {
+		o.next.Close()
+	}
+}
 
 // flatten turns a boolean logicalplan.Expr into the post-order fdb_expr array the descriptor carries: leaves are
 // BinaryExpr{Column, Op, Literal} (filter.go:79-103), branches And / Or (filter.go:129-160). Anything else is
 // ErrUnsupportedBooleanExpression and the caller keeps the Go operators for that plan.
-func flatten(e logicalplan.Expr, out *[]C.fdb_expr) (int, error) {
+func flatten(e logicalplan.Expr, out *[]C.fdb_expr, mem *cArena) (int, error) {
 	b, ok := e.(*logicalplan.BinaryExpr)
 	if !ok {
 		return -1, physicalplan.ErrUnsupportedBooleanExpression
 	}
 	if b.Op == logicalplan.OpAnd || b.Op == logicalplan.OpOr {
-		l, err := flatten(b.Left, out)
+		l, err := flatten(b.Left, out, mem)
 		if err != nil {
 			return -1, err
 		}
-		r, err := flatten(b.Right, out)
+		r, err := flatten(b.Right, out, mem)
 		if err != nil {
 			return -1, err
 		}
@@ -164,8 +207,8 @@ func flatten(e logicalplan.Expr, out *[]C.fdb_expr) (int, error) {
 	if !ok {
 		return -1, physicalplan.ErrUnsupportedBooleanExpression
 	}
-	n := C.fdb_expr{op: C.int32_t(b.Op), left: -1, right: -1, column: C.CString(col.ColumnName)}
-	setLiteral(&n.literal, lit.Value) // scalar.Int64 → FDB_LIT_INT64, scalar.String → FDB_LIT_STRING (data, len), scalar.Null → FDB_LIT_NULL, …
+	n := C.fdb_expr{op: C.int32_t(b.Op), left: -1, right: -1, column: mem.str(col.ColumnName)}
+	setLiteral(&n.literal, lit.Value, mem) // scalar.Int64 → FDB_LIT_INT64, scalar.String → FDB_LIT_STRING (data, len), scalar.Null → FDB_LIT_NULL, …
 	*out = append(*out, n)
 	return len(*out) - 1, nil
 }
