@@ -1,22 +1,33 @@
 #!/usr/bin/env python
 """bench.py — rows/sec of the fused filter + group-by aggregate over synthetic Prometheus Arrow data.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W``. N > 1 means one rank per GPU: under
-``python -m torch.distributed.run`` the ranks read RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env; started plainly
-(``python bench.py --gpus 8``) the script launches those N ranks itself and refuses loudly if the box has fewer GPUs.
+Contract: ``python bench.py --gpus N --steps K --warmup W``.
 
-Headline workload (BASELINE.json ``metric``): filter + group-by over **1 B Prometheus rows** resident in the HBM of
-one GPU (cfg 2's query ``labels.code=='200' + SUM(value) GROUP BY labels.path``; 16.25 algorithmic B/row). At N > 1
-every GPU holds its own 1 B-row shard (weak scaling; parts shard with no data-path collective) and the per-GPU partial
-tables are merged with RCCL through the C ABI (``fdb_comm_*``). A *step* is one full pass of the hot path over this
-rank's shard: create the operator chain (fdb_plan_create), scan every resident record with the fused HIP kernel
-(fdb_plan_push_batches), merge (N > 1) and produce the final Arrow record (fdb_plan_finish). Inputs are resident in HBM
-before the timed region; the result of the timed path is checked against a numpy restatement of the query.
+N = 1 (default): the headline of BASELINE.json's ``metric`` — cfg 2's query ``labels.code=='200' + SUM(value) GROUP BY
+labels.path`` (16.25 algorithmic B/row) over **1 B Prometheus rows** resident in the HBM of one GPU.
 
-Rank 0 prints ONE JSON line: the metric, the HBM roofline of the scan kernel (hipEvent-timed on the plan's own stream
-over the timed steps), the CPU baseline (the oracle's restatement of the reference's algorithm on this box's host
-cores, bounded sample) and — at N = 1 with the default workload — ``other_configs``: the same measurement for
-BASELINE.json's cfg 3 (multi-predicate, 100 M rows) and cfg 5 (32 label columns, 10 M groups, 100 M rows).
+N > 1: **cfg 4 as BASELINE.json states it** — the same 1 B rows *in total*, sharded over the N GPUs (``shard_rows``: 125 M
+rows per GPU at N = 8; strong scaling), every GPU scanning its own resident parts with no data-path collective, then ONE merge
+of the per-GPU partial tables over RCCL through the C ABI (``fdb_plan_allreduce``; ≙ Synchronizer + HashAggregate(final=true),
+physicalplan.go:438-471). ``--weak`` keeps ``--rows`` (default 1 B) rows on EVERY GPU instead and says ``"scaling": "weak"``.
+Two ways to be N ranks:
+  * one process per GPU (the driver's form): under ``python -m torch.distributed.run`` the ranks read RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the env; started plainly (``python bench.py --gpus 8``) the script launches those ranks itself
+    and refuses loudly if the box has fewer GPUs;
+  * ``--one-process``: ONE process, one thread per GPU, ``fdb_comm_init_all`` (ncclCommInitAll) — the reference's own model of
+    N chains in one process (physicalplan.go:22, :337-347). ``--force-local`` swaps RCCL for the library's in-process
+    peer-to-peer transport, whose ranks may share a device: the functional check of the N-rank path on a 1-GPU box.
+
+A *step* is one full pass of the hot path over this rank's shard: create the operator chain (fdb_plan_create), scan every
+resident record with the fused HIP kernel (fdb_plan_push_batches), merge (N > 1) and produce the final Arrow record
+(fdb_plan_finish). Inputs are resident in HBM before the timed region; the result of the timed path is checked against a numpy
+restatement of the query (summed over the ranks at N > 1).
+
+Rank 0 prints ONE JSON line: the metric, the HBM roofline of the scan kernel (hipEvent-timed on the plan's own stream over the
+timed steps), the CPU baseline (the oracle's restatement of the reference's algorithm on this box's host cores, bounded
+sample) and — at N = 1 with the default workload — ``other_configs``: the same measurement for BASELINE.json's cfg 3 and
+cfg 5, the device-side ``filter()`` compaction (``select``), the PCIe-inclusive ``fdb_plan_push`` of host records
+(``host_records``), Parquet row groups decoded on the device (``parquet``) and what run-time specialisation cost (``jit``).
 """
 from __future__ import annotations
 
@@ -25,6 +36,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -34,7 +46,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HEADLINE_ROWS = 1_000_000_000
-PROFILE_ROUND = "round2"
+PROFILE_ROUNDS = ("round3", "round2", "round1")  # newest committed PMC pass of the same command first
 
 
 def parse_args(argv=None):
@@ -43,8 +55,12 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 5],
-                    help="0 (default): the headline — cfg 2's query over 1 B rows/GPU, plus cfg 3 / cfg 5 lines at N=1; 2 / 3 / 5: that BASELINE.json config alone (100 M rows)")
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: 1 B for the headline, 100 M for --config 2/3/5)")
+                    help="0 (default): the headline — cfg 2's query over 1 B rows (one GPU: all of them; N GPUs: sharded = cfg 4), plus the other lines at N=1; 2 / 3 / 5: that BASELINE.json config alone (100 M rows)")
+    ap.add_argument("--rows", type=int, default=0, help="TOTAL rows of the workload (default: 1 B for the headline, 100 M for --config 2/3/5); with --weak: rows per GPU")
+    ap.add_argument("--weak", action="store_true", help="N > 1: every GPU holds --rows rows (weak scaling) instead of a 1/N shard of them")
+    ap.add_argument("--one-process", action="store_true", help="N > 1: one process, one thread per GPU, fdb_comm_init_all (ncclCommInitAll)")
+    ap.add_argument("--force-local", action="store_true",
+                    help="N > 1 in one process over the library's in-process transport (fdb_comm_init_local); ranks share devices when the box has fewer than N")
     ap.add_argument("--batch-rows", type=int, default=25_000_000, help="rows per resident record (part)")
     ap.add_argument("--groups", type=int, default=10_000_000, help="cfg 5: distinct groups")
     ap.add_argument("--cfg5-sorted", action="store_true", help="cfg 5: every record's rows ordered by group (a scan of a table sorted by its label columns)")
@@ -57,10 +73,19 @@ def parse_args(argv=None):
     ap.add_argument("--force-merge", action="store_true", help="run the RCCL merge path even with one rank (functional check on a 1-GPU box)")
     ap.add_argument("--torch-merge", action="store_true", help="merge through torch.distributed (frostdb_amd.distributed) instead of the C ABI's fdb_comm_*")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg 3 / cfg 5 lines of the default run")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg 3 / cfg 5 / select / host_records / parquet lines of the default run")
+    ap.add_argument("--only-other", default="", help="comma-separated subset of other_configs to run (cfg3,cfg5,select,host_records,parquet)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=3.0)
     ap.add_argument("--sweep", action="store_true", help="kernel geometry sweep first (tuning aid; table on stderr)")
     return ap.parse_args(argv)
+
+
+def shard_rows(total: int, world: int, rank: int) -> int:
+    """Rows of rank `rank`'s shard when `total` rows are sharded over `world` GPUs (cfg 4: 1 B over 8 → 125 M each): equal
+    shares, the remainder one row each to the first ranks — Σ over ranks = total, always."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank / world out of range")
+    return total // world + (1 if rank < total % world else 0)
 
 
 def query(config):
@@ -120,8 +145,91 @@ def expected_cfg3(batch):
 
 def expected_cfg5(batch):
     """numpy statistics of one cfg 5 record that pin the grouped result without a host-side group-by: row count and Σ value."""
+    import numpy as np
     value = batch.column(batch.schema.get_field_index("value")).to_numpy()
-    return batch.num_rows, float(value.sum())
+    return np.array([batch.num_rows], dtype=np.int64), np.array([float(value.sum())])
+
+
+EXPECTED_OPS = {2: ("sum", "sum"), 3: ("sum", "min", "max", "sum"), 5: ("sum", "sum")}  # how the per-record / per-rank answers fold
+SELECT_THRESHOLD = 500.0  # `value > 500`: 50 % selectivity on U[0, 1000)
+
+
+def fold_expected(config, a, b):
+    import numpy as np
+    f = {"sum": lambda x, y: x + y, "min": np.minimum, "max": np.maximum}
+    return [f[op](x, y) for op, x, y in zip(EXPECTED_OPS[config], a, b)]
+
+
+# ---- the N ranks: processes (torch.distributed) or threads of this process -------------------------------------------------------
+class ProcGroup:
+    """Host-side control plane of the one-process-per-GPU form: barrier, max over ranks, sums of the numpy expectations. The
+    data-path merge never goes through here (it is fdb_comm_* inside the library) unless --torch-merge asks for it."""
+
+    def __init__(self, rank, world, device, dist):
+        self.rank, self.world, self.device, self.dist = rank, world, device, dist
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def device_sync(self):
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(self.device)
+
+    def reduce(self, arr, op):
+        import numpy as np
+        import torch
+        if self.world == 1:
+            return arr
+        t = torch.from_numpy(np.ascontiguousarray(arr)).clone()  # (all_reduce works in place: never on the caller's array)
+        if self.dist.get_backend() == "nccl":  # (gloo — the CPU tests of this control plane — reduces host tensors)
+            t = t.to(f"cuda:{self.device}")
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}[op])
+        return t.cpu().numpy()
+
+    def gather(self, value):
+        if self.world == 1:
+            return [value]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, value)
+        return out
+
+
+class ThreadShared:
+    def __init__(self, world):
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+
+class ThreadGroup:
+    """The same control plane for N ranks that are threads of this process (--one-process / --force-local)."""
+
+    def __init__(self, rank, world, device, shared):
+        self.rank, self.world, self.device, self.shared = rank, world, device, shared
+
+    def barrier(self):
+        self.shared.bar.wait()
+
+    def device_sync(self):
+        import torch
+        torch.cuda.synchronize(self.device)
+
+    def gather(self, value):
+        self.shared.slots[self.rank] = value
+        self.shared.bar.wait()
+        out = list(self.shared.slots)
+        self.shared.bar.wait()
+        return out
+
+    def reduce(self, arr, op):
+        import numpy as np
+        parts = self.gather(arr)
+        f = {"sum": np.add, "min": np.minimum, "max": np.maximum}[op]
+        out = parts[0].copy()
+        for p in parts[1:]:
+            out = f(out, p)
+        return out
 
 
 def self_launch(args):
@@ -131,7 +239,8 @@ def self_launch(args):
     out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
     n_dev = int(out.stdout.strip() or 0) if out.returncode == 0 else 0
     if n_dev < args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {n_dev} GPU(s); refusing to report a {args.gpus}-GPU number from fewer devices")
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {n_dev} GPU(s); refusing to report a {args.gpus}-GPU number from fewer devices "
+                         "(--force-local runs the N-rank path on the devices there are, as a functional check)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -143,11 +252,11 @@ def self_launch(args):
 class Workload:
     """One configuration made resident on this rank's GPU + the numpy expectation of its query."""
 
-    def __init__(self, args, config, rows, rank, local_rank):
+    def __init__(self, args, config, rows, rank, device, keep_host=0, gen_threads=None):
         from frostdb_amd import physicalplan as pp
         from frostdb_amd import synth
         from frostdb_amd.logicalplan import to_desc
-        self.args, self.config, self.rows, self.rank, self.local_rank = args, config, rows, rank, local_rank
+        self.args, self.config, self.rows, self.rank, self.device = args, config, rows, rank, device
         self.filt, self.aggs, self.groups, self.qdesc = query(config)
         self.desc = to_desc(self.filt, self.aggs, self.groups)  # planned once; every step instantiates a fresh operator chain
         t0 = time.time()
@@ -155,56 +264,53 @@ class Workload:
         n_chunks = (rows + br - 1) // br
         sizes = [min(br, rows - i * br) for i in range(n_chunks)]
         self.n_chunks = n_chunks
+        self.select_expected = []  # rows of the first records with value > SELECT_THRESHOLD (the `select` line)
 
         def gen(i):
             if config == 5:
                 b = synth.cfg5_chunk(rank, i, sizes[i], n_groups=args.groups, sorted_rows=args.cfg5_sorted)
-                return b, expected_cfg5(b)
+                return b, expected_cfg5(b), None
             b = synth.prometheus_chunk(rank, i, sizes[i], row_base=i * br, cfg3=(config == 3))
-            return b, (expected_cfg2(b) if config == 2 else expected_cfg3(b))
+            sel = None
+            if i < keep_host:
+                v = b.column(b.schema.get_field_index("value")).to_numpy()
+                sel = int((v > SELECT_THRESHOLD).sum())
+            return b, (expected_cfg2(b) if config == 2 else expected_cfg3(b)), sel
 
         if config == 5:
             synth.cfg5_chunk(rank, 0, 8, n_groups=args.groups)  # builds the per-group digit tables once, before the thread pool
         self.resident, self.host_batches, self.sample = [], [], None
         self.expected = None
-        workers = max(1, min(16, n_chunks, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+        workers = gen_threads or max(1, min(16, n_chunks, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
         with ThreadPoolExecutor(max_workers=workers) as ex:
-            for i, (b, e) in enumerate(ex.map(gen, range(n_chunks))):
-                self._fold(e)
-                if args.host_records:
+            for i, (b, e, sel) in enumerate(ex.map(gen, range(n_chunks))):
+                self.expected = list(e) if self.expected is None else fold_expected(config, self.expected, e)
+                if args.host_records or i < keep_host:
                     self.host_batches.append(b)
-                else:
-                    self.resident.append(pp.ResidentBatch(b, device=local_rank))
+                    self.select_expected.append(sel)
+                if not args.host_records:
+                    self.resident.append(pp.ResidentBatch(b, device=device))
                 if i == 0:
                     self.sample = b
         self.t_gen = time.time() - t0
         self.hbm_bytes = sum(r.device_bytes for r in self.resident)
-
-    def _fold(self, e):
-        import numpy as np
-        if self.expected is None:
-            self.expected = list(e)
-        elif self.config == 2 or self.config == 5:
-            self.expected = [a + b for a, b in zip(self.expected, e)]
-        else:
-            c, mn, mx, s = self.expected
-            self.expected = [c + e[0], np.minimum(mn, e[1]), np.maximum(mx, e[2]), s + e[3]]
 
     def release(self):
         for r in self.resident:
             r.close()
         self.resident, self.host_batches = [], []
 
-    # ---- the result of the timed path against the numpy restatement (single rank's shard) -------------------------------
-    def check(self, out):
+    # ---- the result of the timed path against the numpy restatement (`expected`: this rank's, or the sum over all ranks) ------
+    def check(self, out, expected, total_rows):
         from frostdb_amd import synth
         names = out.schema.names
         col = lambda n: out.column(names.index(n))  # noqa: E731
         if self.config == 5:
-            n_rows, total = self.expected
+            n_rows, total = int(expected[0][0]), float(expected[1][0])
             n_out = out.num_rows
             s = col("sum(value)").to_numpy()
-            assert n_out <= self.args.groups and (self.rows < 5 * self.args.groups or n_out > 0.99 * self.args.groups), n_out
+            assert n_rows == total_rows, (n_rows, total_rows)
+            assert n_out <= self.args.groups and (total_rows < 5 * self.args.groups or n_out > 0.99 * self.args.groups), n_out
             assert math.isclose(float(s.sum()), total, rel_tol=1e-9), (float(s.sum()), total)
             return {"groups_out": n_out, "sum_check": "Σ sum(value) == Σ value (1e-9 rel)"}
         paths = synth.PATHS + [None]
@@ -212,7 +318,7 @@ class Workload:
         key = key.dictionary_decode() if hasattr(key, "dictionary_decode") else key
         got_keys = key.to_pylist()
         if self.config == 2:
-            exp_sum, exp_cnt = self.expected
+            exp_sum, exp_cnt = expected
             got = dict(zip(got_keys, col("sum(value)").to_pylist()))
             for i, p in enumerate(paths):
                 if exp_cnt[i] == 0:
@@ -220,8 +326,8 @@ class Workload:
                 else:
                     assert math.isclose(got[p], exp_sum[i], rel_tol=1e-9), (p, got[p], exp_sum[i])
             assert len(got) == int((exp_cnt > 0).sum())
-            return {"groups_out": len(got)}
-        cnt, mn, mx, s = self.expected
+            return {"groups_out": len(got), "selected_rows": int(exp_cnt.sum())}
+        cnt, mn, mx, s = expected
         rows = dict(zip(got_keys, zip(col("count(value)").to_pylist(), col("min(timestamp)").to_pylist(), col("max(timestamp)").to_pylist(),
                                       col("sum(value)").to_pylist())))
         for i, p in enumerate(paths):
@@ -232,18 +338,18 @@ class Workload:
             assert g[0] == int(cnt[i]) and g[1] == int(mn[i]) and g[2] == int(mx[i]), (p, g, cnt[i], mn[i], mx[i])
             assert math.isclose(g[3], s[i], rel_tol=1e-9), (p, g[3], s[i])
         assert len(rows) == int((cnt > 0).sum())
-        return {"groups_out": len(rows)}
+        return {"groups_out": len(rows), "selected_rows": int(cnt.sum())}
 
 
-def run_workload(args, wl, steps, warmup, world, comm, dist):
+def run_workload(args, wl, steps, warmup, group, comm, total_rows):
     """Correctness step, warm-up, then the timed region (barrier + device sync on both sides, max over ranks)."""
-    import torch
+    import numpy as np
     from frostdb_amd import physicalplan as pp
-    rank, local_rank = wl.rank, wl.local_rank
+    rank, device, world = wl.rank, wl.device, group.world
     merging = world > 1 or args.force_merge
 
     def step(timing=False, tuning=None):
-        plan = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=local_rank, desc=wl.desc)
+        plan = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=device, desc=wl.desc)
         if timing:
             plan.set_timing(True)
         if tuning:
@@ -260,15 +366,16 @@ def run_workload(args, wl, steps, warmup, world, comm, dist):
             plan.CallbackResident(wl.resident)
         out = None
         if merging and args.torch_merge:
+            import torch
             from frostdb_amd.distributed import layout_probe, merge_plan, merge_plan_alltoall
             if wl.config == 5:  # high cardinality: hash-partitioned all-to-all; every rank finishes its own shard of the groups
-                shard = merge_plan_alltoall(plan, device=torch.device("cuda", local_rank))
+                shard = merge_plan_alltoall(plan, device=torch.device("cuda", device))
                 try:
                     out = shard.Finish()
                 finally:
                     shard.Close()
             else:
-                probe = layout_probe(plan, torch.device("cuda", local_rank))  # overlaps with the scan kernel
+                probe = layout_probe(plan, torch.device("cuda", device))  # overlaps with the scan kernel
                 out = merge_plan(plan, probe=probe)
         elif merging:
             if wl.config == 5:
@@ -287,16 +394,23 @@ def run_workload(args, wl, steps, warmup, world, comm, dist):
         plan.Close()
         return out, st
 
+    # ---- the first step of this shape in this process: pays hiprtc (or the disk cache) for its kernels ----
+    jit0 = pp.jit_stats()
+    t_first = time.perf_counter()
     out, _ = step()
+    first_step_ms = (time.perf_counter() - t_first) * 1e3
+    jit1 = pp.jit_stats()
     checked = None
-    if world == 1 and not args.host_records:
-        checked = wl.check(out)
-    elif wl.config == 5:
-        t = torch.tensor([out.num_rows], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t)  # shards of the all-to-all merge are disjoint
-        n_out = int(t.item())
-        assert n_out <= args.groups and n_out > 0, n_out
-        checked = {"groups_out": n_out}
+    if not args.host_records:
+        expected = [group.reduce(np.asarray(e), op) for e, op in zip(wl.expected, EXPECTED_OPS[wl.config])]
+        if wl.config == 5 and world > 1:  # the all-to-all merge leaves every rank with its own disjoint shard of the groups
+            sums = group.reduce(np.array([float(out.column(out.schema.names.index("sum(value)")).to_numpy().sum())]), "sum")
+            n_out = int(group.reduce(np.array([out.num_rows], dtype=np.int64), "sum")[0])
+            assert int(expected[0][0]) == total_rows and 0 < n_out <= args.groups, (int(expected[0][0]), total_rows, n_out)
+            assert math.isclose(float(sums[0]), float(expected[1][0]), rel_tol=1e-9), (float(sums[0]), float(expected[1][0]))
+            checked = {"groups_out": n_out, "sum_check": "Σ over ranks of Σ sum(value) == Σ value (1e-9 rel)"}
+        elif rank == 0:
+            checked = wl.check(out, expected, total_rows)
     del out
 
     if args.sweep:
@@ -313,53 +427,46 @@ def run_workload(args, wl, steps, warmup, world, comm, dist):
 
     for _ in range(warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    group.barrier()
+    group.device_sync()
     t0 = time.perf_counter()
-    k_ms, k_bytes, k_launches, kernel_name = 0.0, 0, 0, ""
+    k_ms, k_bytes, k_launches, kernel_name, merge_ms = 0.0, 0, 0, "", 0.0
     for _ in range(steps):
         _, st = step(timing=True)
-        k_ms += st["kernel_ms"]; k_bytes += st["algorithmic_bytes"]; k_launches += st["launches"]
+        k_ms += st["kernel_ms"]; k_bytes += st["algorithmic_bytes"]; k_launches += st["launches"]; merge_ms += st["merge_ms"]
         kernel_name = st["kernel"]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    group.barrier()
+    group.device_sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return {"elapsed": elapsed, "k_ms": k_ms, "k_bytes": k_bytes, "k_launches": k_launches, "kernel": kernel_name, "checked": checked}
+    elapsed = float(group.reduce(np.array([elapsed]), "max")[0])
+    # every rank's own kernel figures (rank order): the scan is rank-local, so the roofline fraction is a per-GPU quantity
+    per_rank = group.gather({"rank": rank, "rows": wl.rows, "kernel_ms_per_step": k_ms / max(steps, 1),
+                             "kernel_frac": (k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else 0.0,
+                             "merge_ms_per_step": merge_ms / max(steps, 1)})
+    return {"elapsed": elapsed, "k_ms": k_ms, "k_bytes": k_bytes, "k_launches": k_launches, "kernel": kernel_name, "checked": checked,
+            "per_rank": per_rank, "merge_ms": max(p["merge_ms_per_step"] for p in per_rank),
+            "first_step_ms": first_step_ms, "jit_compiled": jit1["compiled"] - jit0["compiled"], "jit_compile_ms": jit1["compile_ms"] - jit0["compile_ms"],
+            "jit_disk_loads": jit1["disk_loads"] - jit0["disk_loads"]}
 
 
 def traffic_for(tag, rows, kernel_name):
     """HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 cannot run inside the timed process)."""
-    for rnd in (PROFILE_ROUND, "round1"):
+    for rnd in PROFILE_ROUNDS:
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("rows") == rows and tj.get("kernel") == kernel_name:
-                return tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"], os.path.relpath(tpath, ROOT)
-    return None, None
-
-
-def traffic_is_per_average_launch(tag):
-    """cfg 5's scan is cut into several launches: its traffic file holds the mean over all of them, like `avg_launch_ms`."""
-    tpath = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{tag}_traffic.json")
-    if not os.path.exists(tpath):
-        return False
-    with open(tpath) as fh:
-        return bool(json.load(fh).get("per_average_launch"))
+                return tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"], os.path.relpath(tpath, ROOT), bool(tj.get("per_average_launch"))
+    return None, None, False
 
 
 def roofline_of(r, rows, steps, tag, ceiling=None):
     achieved = r["k_bytes"] / (r["k_ms"] * 1e-3) / 1e9 if r["k_ms"] > 0 else 0.0
     launches = max(r["k_launches"], 1)
-    traffic, src = traffic_for(tag, rows, r["kernel"])
-    # (a scan cut into several launches — the hash path's ≤ 4 M-row chunks — reports per-launch figures of the average launch)
-    if traffic is not None and launches != steps and not traffic_is_per_average_launch(tag):
+    traffic, src, per_avg = traffic_for(tag, rows, r["kernel"])
+    # (a scan cut into several launches — the hash path's chunks — reports per-launch figures of the average launch)
+    if traffic is not None and launches != steps and not per_avg:
         traffic, src = None, None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "kernel": r["kernel"], "avg_launch_ms": r["k_ms"] / launches,
@@ -367,6 +474,10 @@ def roofline_of(r, rows, steps, tag, ceiling=None):
             "algorithmic_bytes_per_launch": r["k_bytes"] / launches, "bytes_per_row": r["k_bytes"] / max(rows * steps, 1),
             "whole_step_frac": (r["k_bytes"] / max(steps, 1)) / (r["elapsed"] / max(steps, 1)) / 1e9 / HBM_PEAK_GBS,
             "measured_read_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling else None}
+
+
+def jit_of(r):
+    return {"first_step_ms": r["first_step_ms"], "kernels_compiled": r["jit_compiled"], "jit_compile_ms": r["jit_compile_ms"], "disk_cache_loads": r["jit_disk_loads"]}
 
 
 _REAL_STDOUT = None
@@ -387,8 +498,336 @@ def emit(text):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (text + "\n").encode())
 
 
+# ---- the secondary measurements of the default N = 1 run (other_configs) --------------------------------------------------------
+def measure_select(wl, steps=10, warmup=2):
+    """`filter()` on the device (filter.go:276-354 ≙ fdb_plan_filter_batch): `value > 500` (50 % selectivity) over the first
+    100 M resident rows, every column compacted. Algorithmic bytes = filter column once + every selected value / validity bit read
+    once and written once; `min_traffic_frac` counts what a sector-granular memory must at least move (all input + the output)."""
+    import torch
+    from frostdb_amd import physicalplan as pp
+    from frostdb_amd.logicalplan import Col
+    recs = wl.resident[:len(wl.select_expected)]
+    rows = sum(r.num_rows for r in recs)
+    filt = Col("value") > SELECT_THRESHOLD
+
+    def step(timing=False):
+        plan = pp.HashAggregatePlan(filt, device=wl.device)
+        if timing:
+            plan.set_timing(True)
+        outs = plan.FilterResidentMany(recs)
+        st = plan.stats() if timing else None
+        kernel = plan.last_kernel()
+        plan.Close()
+        return outs, st, kernel
+
+    outs, _, _ = step()
+    got = [o.num_rows for o in outs]
+    assert got == wl.select_expected, (got, wl.select_expected)
+    first = outs[0].to_arrow()
+    v0 = wl.host_batches[0].column(wl.host_batches[0].schema.get_field_index("value")).to_numpy()
+    assert first.column(first.schema.get_field_index("value")).to_numpy().tolist() == v0[v0 > SELECT_THRESHOLD].tolist()
+    for o in outs:
+        o.close()
+    for _ in range(warmup):
+        for o in step()[0]:
+            o.close()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k_ms = k_bytes = k_launches = 0
+    kernel = ""
+    for _ in range(steps):
+        outs, st, kernel = step(timing=True)
+        k_ms += st["kernel_ms"]; k_bytes += st["algorithmic_bytes"]; k_launches += st["launches"]
+        for o in outs:
+            o.close()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sel = sum(wl.select_expected) / rows
+    row_in = sum(r.device_bytes for r in recs) / rows  # ≈ 24.25: code 4 + path 4 + timestamp 8 + value 8 + two validity bits
+    min_traffic = rows * (row_in + sel * row_in)
+    ach = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, src, _ = traffic_for("select", rows, kernel)
+    return {"workload": f"select: filter() compaction of every column, value > {SELECT_THRESHOLD:g} over {rows} resident rows ({len(recs)} records), selectivity {sel:.4f}",
+            "value": rows * steps / el, "unit": "rows/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": src,
+                         "launches_per_step": k_launches / steps, "kernel_ms_per_step": k_ms / steps,
+                         "algorithmic_bytes_per_row": k_bytes / (rows * steps), "min_traffic_bytes_per_row": min_traffic / rows,
+                         "min_traffic_frac": (min_traffic * steps / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0,
+                         "whole_step_frac": (k_bytes / steps) / (el / steps) / 1e9 / HBM_PEAK_GBS},
+            "checked": {"selected_rows": sum(got), "first_record_values": "bit-identical to numpy's value[value > T]"}}
+
+
+def h2d_rate_gbs(device, nbytes=1 << 30):
+    """Pinned host → device copy rate of this box (the ceiling of anything that starts from host memory)."""
+    import torch
+    src = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{device}")
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    return 3 * nbytes / (time.perf_counter() - t0) / 1e9
+
+
+def measure_host_records(wl, steps=3):
+    """What `Callback(arrow.Record)` delivers (table.go:783-860): HOST Arrow records pushed through fdb_plan_push — copy of the
+    referenced columns over PCIe + scan — as 25 M-row records and as 65 536-row records. PCIe-bound; never the headline."""
+    import torch
+    from frostdb_amd import physicalplan as pp
+    h2d = h2d_rate_gbs(wl.device)
+    big = wl.host_batches
+    small = [big[0].slice(o, min(65536, big[0].num_rows - o)) for o in range(0, big[0].num_rows, 65536)]
+    out = {"bound": "pcie", "measured_h2d_GBps": h2d, "bytes_per_row_copied": 16.25}
+    for name, recs in (("records_25M_rows", big), ("records_65536_rows", small)):
+        rows = sum(r.num_rows for r in recs)
+        exported = [pp.ExportedBatch(r) for r in recs]  # pyarrow's C-data export is the caller's cost, not the library's
+
+        def once():
+            plan = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=wl.device, desc=wl.desc)
+            for ex in exported:
+                plan.CallbackExported(ex)
+            res = plan.Finish()
+            plan.Close()
+            return res
+        res = once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            once()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        gbs = rows * 16.25 / dt / 1e9
+        out[name] = {"records": len(recs), "rows": rows, "ms_per_pass": dt * 1e3, "value": rows / dt, "unit": "rows/s", "achieved_GBps": gbs,
+                     "frac_of_h2d": gbs / h2d, "groups_out": res.num_rows}
+        for ex in exported:
+            ex.close()
+    return out
+
+
+def measure_parquet(device, rows=20_000_000, passes=3):
+    """Parquet row groups (file bytes in pinned host memory) → columns decoded on the device
+    (fdb_batch_from_parquet) → cfg 2's query. Bytes = file bytes read + column bytes produced; host / device split from
+    fdb_parquet_stats. Two files: UNCOMPRESSED + PLAIN, and SNAPPY pages + DELTA_BINARY_PACKED timestamps."""
+    import io
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    import torch
+    from frostdb_amd import physicalplan as pp
+    from frostdb_amd import synth
+    from frostdb_amd.logicalplan import Col, Sum
+    from tests.parquet_util import row_group_chunks, write_parquet
+    rec = synth.prometheus_chunk(0, 0, rows)
+    exp_sum, exp_cnt = expected_cfg2(rec)
+    t = pa.Table.from_batches([rec])
+    t = t.set_column(0, "labels.code", t.column(0).cast(pa.binary())).set_column(1, "labels.path", t.column(1).cast(pa.binary()))
+    q = (Col("labels.code") == "200", [Sum(Col("value"))], [Col("labels.path")])
+    h2d = h2d_rate_gbs(device, 1 << 28)
+    out = {"rows": rows, "measured_h2d_GBps": h2d}
+    for variant, kw in (("plain", {}), ("delta_snappy", dict(compression="SNAPPY", column_encoding={"timestamp": "DELTA_BINARY_PACKED"},
+                                                             use_dictionary=["labels.code", "labels.path"]))):
+        data = write_parquet(t, row_group_size=5_000_000, data_page_size=1 << 20, **kw)
+        n_rg = pq.ParquetFile(io.BytesIO(data)).metadata.num_row_groups
+        pinned = torch.empty(len(data), dtype=torch.uint8, pin_memory=True)
+        pinned.numpy()[:] = np.frombuffer(data, dtype=np.uint8)
+        groups = []
+        for g in range(n_rg):
+            ch, n = row_group_chunks(data, g)
+            loc = []
+            for nm, ty, opt, u8, b, cd in ch:
+                off = data.find(b[:256])
+                assert data[off:off + len(b)] == b
+                loc.append((nm, ty, opt, u8, (pinned.data_ptr() + off, len(b)), cd))
+            groups.append((loc, n))
+
+        def once():
+            plan = pp.HashAggregatePlan(*q, device=device)
+            keep = [pp.ResidentBatch.from_parquet(ch, n, device=device) for ch, n in groups]
+            plan.CallbackResident(keep)
+            res = plan.Finish()
+            plan.Close()
+            for k in keep:
+                k.close()
+            return res
+        res = once()
+        got = dict(zip(res.column(0).to_pylist(), res.column(1).to_pylist()))
+        for i, p in enumerate(synth.PATHS + [None]):
+            if exp_cnt[i]:
+                assert math.isclose(got[p], exp_sum[i], rel_tol=1e-9), (variant, p)
+        s0 = pp.parquet_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            once()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / passes
+        s1 = pp.parquet_stats()
+        fb = (s1["file_bytes"] - s0["file_bytes"]) / passes
+        ob = (s1["out_bytes"] - s0["out_bytes"]) / passes
+        out[variant] = {"file_bytes": int(fb), "decoded_column_bytes": int(ob), "row_groups": n_rg, "ms_per_pass": dt * 1e3, "value": rows / dt, "unit": "rows/s",
+                        "file_GBps": fb / dt / 1e9, "file_plus_columns_GBps": (fb + ob) / dt / 1e9,
+                        "host_part_ms": (s1["host_ms"] - s0["host_ms"]) / passes, "device_part_ms": (s1["device_ms"] - s0["device_ms"]) / passes,
+                        "bound": "host" if (s1["host_ms"] - s0["host_ms"]) > (s1["device_ms"] - s0["device_ms"]) else "pcie", "frac_of_h2d": fb / dt / 1e9 / h2d}
+        del pinned
+    return out
+
+
+def other_configs(args, wl, rank, device, group, comm):
+    """BASELINE.json's other single-GPU configurations and the secondary measurements, same run, same method (fewer steps)."""
+    only = set(x for x in args.only_other.split(",") if x)
+    want = lambda k: not only or k in only  # noqa: E731
+    others = {}
+    if want("select") and wl.select_expected:
+        others["select"] = measure_select(wl)
+    if want("host_records") and wl.host_batches:
+        others["host_records"] = measure_host_records(wl)
+    wl.release()
+    for cfg, st, wu in ((3, max(5, args.steps // 2), 2), (5, 3, 1)):
+        if not want(f"cfg{cfg}"):
+            continue
+        w2 = Workload(args, cfg, 100_000_000, rank, device)
+        r2 = run_workload(args, w2, st, wu, group, comm, 100_000_000)
+        others[f"cfg{cfg}"] = {
+            "workload": f"cfg{cfg}: Prometheus schema, 100000000 rows, {w2.qdesc}",
+            "value": 100_000_000 * st / r2["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu,
+            "ms_per_step": r2["elapsed"] / st * 1e3, "roofline": roofline_of(r2, 100_000_000, st, f"cfg{cfg}"),
+            "checked": r2["checked"], "jit": jit_of(r2), "setup": {"gen_and_upload_s": w2.t_gen, "hbm_resident_bytes": w2.hbm_bytes},
+        }
+        w2.release()
+    if want("parquet"):
+        others["parquet"] = measure_parquet(device)
+    return others
+
+
+def run_rank(args, group, device, comm):
+    """Everything one rank does once it has its device, its control-plane group and (N > 1) its communicator endpoint.
+    Returns the JSON line's dict on rank 0, None elsewhere."""
+    from frostdb_amd import physicalplan as pp
+    rank, world = group.rank, group.world
+    headline = args.config == 0
+    config = 2 if headline else args.config
+    total = args.rows or (HEADLINE_ROWS if headline else 100_000_000)
+    if world > 1 and not args.weak:
+        rows, scaling, total_rows = shard_rows(total, world, rank), "strong", total
+    else:
+        rows, scaling, total_rows = total, "weak", total * world
+    merging = world > 1 or args.force_merge
+    secondary = headline and world == 1 and not args.no_other_configs and not args.host_records
+    wl = Workload(args, config, rows, rank, device, keep_host=4 if secondary else 0,
+                  gen_threads=max(1, min(16, (os.cpu_count() or 8) // world)) if isinstance(group, ThreadGroup) else None)
+    shard_sizes = group.gather(rows)
+    assert sum(shard_sizes) == total_rows, (shard_sizes, total_rows)
+    r = run_workload(args, wl, args.steps, args.warmup, group, comm, total_rows)
+    value = total_rows * args.steps / r["elapsed"]
+
+    # ---- CPU baseline (rank 0, N = 1 only): the oracle's restatement on this box's host cores, bounded sample ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wl.sample, wl.filt, wl.aggs, wl.groups, args.cpu_sample_seconds)
+    ceiling = None
+    if rank == 0 and world == 1:
+        ceiling = pp.read_ceiling(device, 2 << 30, 5)  # plain read kernel on this box, this run (SURVEY §8d)
+
+    tag = ("cfg1B" if rows == HEADLINE_ROWS and config == 2 else f"cfg{config}")
+    if world > 1 and config == 2:
+        name = (f"cfg4: {total} rows sharded over {world} GPUs" if scaling == "strong" else f"cfg4-weak: {total} rows on each of {world} GPUs")
+    else:
+        name = "headline" if headline else f"cfg{config}"
+    transport = None
+    if merging:
+        transport = ("torch.distributed (RCCL)" if args.torch_merge else "in-process peer-to-peer (fdb_comm_init_local)" if args.force_local
+                     else "RCCL, one process (fdb_comm_init_all)" if args.one_process else "RCCL, one process per GPU (fdb_comm_init_rank)")
+    line = {
+        "metric": "rows/sec filter+group-by on 1B-row Prometheus Arrow (HBM-resident); achieved HBM GB/s vs peak" if not args.host_records
+                  else "rows/sec filter+group-by on Prometheus Arrow (HOST records, PCIe-inclusive; secondary)",
+        "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{name}: Prometheus schema, {wl.qdesc}",
+                   "total_rows": total_rows, "rows_per_gpu": shard_sizes if world > 1 else rows, "records_per_gpu": wl.n_chunks,
+                   "groups": args.groups if config == 5 else 1025,
+                   "parallelism": (f"parts sharded over {world} GPU(s), no data-path collective; " +
+                                   ("all-to-all of hash-partitioned partial tables, result sharded" if config == 5
+                                    else "in-place all-reduce of the partial tables (fdb_plan_allreduce)" if not args.torch_merge
+                                    else "all-reduce of the partial tables" +
+                                    ("; fallback: the C-ABI communicator could not be joined" if getattr(args, "merge_fallback", False) else "")) +
+                                   f"; transport: {transport}") if merging else "1 GPU"},
+        "roofline": roofline_of(r, rows, args.steps, tag, ceiling),
+        "cpu_baseline": cpu,
+        "checked": r["checked"],
+        "jit": jit_of(r),
+        "setup": {"gen_and_upload_s": wl.t_gen, "hbm_resident_bytes": wl.hbm_bytes},
+    }
+    if merging:
+        line["merge_ms"] = r["merge_ms"]          # device time of the merge collectives per step (hipEvents on the plan's stream), max over ranks
+        line["per_rank"] = r["per_rank"]
+    if args.force_local:
+        import torch
+        line["devices_used"] = min(world, torch.cuda.device_count())
+        line["note"] = "functional check of the N-rank path over the in-process transport; not an N-GPU measurement unless devices_used == n_gpus"
+
+    if secondary:
+        line["other_configs"] = other_configs(args, wl, rank, device, group, comm)
+        line["jit_process_total"] = pp.jit_stats()
+    else:
+        wl.release()
+    return line if rank == 0 else None
+
+
+def main_one_process(args):
+    """N ranks as N threads of this process (the reference's own model: N chains in one process)."""
+    import torch
+    from frostdb_amd import build as fb
+    fb.build()
+    from frostdb_amd import comm as fcomm
+    n, n_dev = args.gpus, torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if args.force_local:
+        devices = [r % n_dev for r in range(n)]
+        comms = fcomm.Comm.init_local(devices)
+    else:
+        if n_dev < n:
+            raise SystemExit(f"bench.py --gpus {n} --one-process: this box has {n_dev} GPU(s) (RCCL refuses two ranks on one device; --force-local runs the functional check)")
+        devices = list(range(n))
+        comms = fcomm.Comm.init_all(devices)
+    shared = ThreadShared(n)
+    results, errors = [None] * n, [None] * n
+
+    def work(r):
+        try:
+            torch.cuda.set_device(devices[r])
+            results[r] = run_rank(args, ThreadGroup(r, n, devices[r], shared), devices[r], comms[r])
+        except BaseException as e:  # noqa: BLE001
+            errors[r] = e
+            shared.bar.abort()  # the other ranks leave their barriers instead of waiting for ever
+
+    threads = [threading.Thread(target=work, args=(r,), name=f"rank{r}") for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in comms:
+        c.close()
+    real = [e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if real or any(errors):
+        raise (real or [e for e in errors if e is not None])[0]
+    emit(json.dumps(results[0]))
+
+
 def main():
     args = parse_args()
+    if args.force_local:
+        args.one_process = True
+    if args.one_process:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--one-process / --force-local is ONE process: do not start it under torch.distributed.run")
+        claim_stdout()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        return main_one_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)  # does not return
     claim_stdout()
@@ -418,7 +857,6 @@ def main():
         fb.build()
     if world > 1:
         dist.barrier()
-    from frostdb_amd import physicalplan as pp
 
     comm = None
     if merging and not args.torch_merge:
@@ -430,10 +868,10 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(fcomm.unique_id()), dtype=torch.uint8))
         if world > 1:
             dist.broadcast(uid, src=0)
-        # The C-ABI communicator has only ever run with one rank per device on the boxes this was developed on: if joining it
-        # fails on this node, every rank agrees (over the process group) to merge through torch.distributed instead — the
-        # line then says so — rather than losing the scaling measurement. (A failure that hits only some ranks in the
-        # middle of a collective cannot be recovered from; this covers the symmetric ones: a missing symbol, a refused init.)
+        # If joining the C-ABI communicator fails on this node, every rank agrees (over the process group) to merge through
+        # torch.distributed instead — the line then says so — rather than losing the scaling measurement. (A failure that hits
+        # only some ranks in the middle of a collective cannot be recovered from; this covers the symmetric ones: a missing
+        # symbol, a refused init. Failures BEFORE a merge's first collective are voted inside the library, fdb_comm.cpp.)
         ok = 1
         try:
             comm = fcomm.Comm(bytes(uid.cpu().numpy().tobytes()), world, rank, local_rank)
@@ -451,62 +889,7 @@ def main():
             args.torch_merge = True
             args.merge_fallback = True
 
-    headline = args.config == 0
-    config = 2 if headline else args.config
-    rows = args.rows or (HEADLINE_ROWS if headline else 100_000_000)
-
-    wl = Workload(args, config, rows, rank, local_rank)
-    r = run_workload(args, wl, args.steps, args.warmup, world, comm, dist)
-    total_rows = rows * world * args.steps
-    value = total_rows / r["elapsed"]
-
-    # ---- CPU baseline (rank 0, N = 1 only): the oracle's restatement on this box's host cores, bounded sample ----
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(wl.sample, wl.filt, wl.aggs, wl.groups, args.cpu_sample_seconds)
-    ceiling = None
-    if rank == 0 and world == 1:
-        ceiling = pp.read_ceiling(local_rank, 2 << 30, 5)  # plain read kernel on this box, this run
-
-    tag = ("cfg1B" if rows == HEADLINE_ROWS and config == 2 else f"cfg{config}")
-    name = "headline" if headline else f"cfg{config}"
-    if world > 1 and config == 2:
-        name = "cfg4-style"
-    line = {
-        "metric": "rows/sec filter+group-by on 1B-row Prometheus Arrow (HBM-resident); achieved HBM GB/s vs peak" if not args.host_records
-                  else "rows/sec filter+group-by on Prometheus Arrow (HOST records, PCIe-inclusive; secondary)",
-        "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{name}: Prometheus schema, {rows} rows/GPU × {world} GPU, {wl.qdesc}",
-                   "rows_per_gpu": rows, "records_per_gpu": wl.n_chunks, "groups": args.groups if config == 5 else 1025,
-                   "parallelism": (f"parts sharded over {world} GPU(s), no data-path collective; " +
-                                   ("RCCL all-to-all of hash-partitioned partial tables, result sharded" if config == 5
-                                    else "RCCL all-reduce of the partial tables (C ABI fdb_comm_*)" if not args.torch_merge
-                                    else "RCCL all-reduce of the partial tables (torch.distributed" +
-                                    ("; fallback: the C-ABI communicator could not be joined)" if getattr(args, "merge_fallback", False) else ")"))) if merging else "1 GPU"},
-        "roofline": roofline_of(r, rows, args.steps, tag, ceiling),
-        "cpu_baseline": cpu,
-        "checked": r["checked"],
-        "setup": {"gen_and_upload_s": wl.t_gen, "hbm_resident_bytes": wl.hbm_bytes},
-    }
-
-    # ---- the other single-GPU configurations of BASELINE.json, same run, same measurement (fewer steps) ---------------------
-    if headline and world == 1 and not args.no_other_configs and not args.host_records:
-        wl.release()
-        others = {}
-        for cfg, st, wu in ((3, max(5, args.steps // 2), 2), (5, 3, 1)):
-            w2 = Workload(args, cfg, 100_000_000, rank, local_rank)
-            r2 = run_workload(args, w2, st, wu, world, comm, dist)
-            others[f"cfg{cfg}"] = {
-                "workload": f"cfg{cfg}: Prometheus schema, 100000000 rows, {w2.qdesc}",
-                "value": 100_000_000 * st / r2["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu,
-                "ms_per_step": r2["elapsed"] / st * 1e3, "roofline": roofline_of(r2, 100_000_000, st, f"cfg{cfg}"),
-                "checked": r2["checked"], "setup": {"gen_and_upload_s": w2.t_gen, "hbm_resident_bytes": w2.hbm_bytes},
-            }
-            w2.release()
-        line["other_configs"] = others
-
+    line = run_rank(args, ProcGroup(rank, world, local_rank, dist), local_rank, comm)
     if rank == 0:
         emit(json.dumps(line))
     if comm is not None:

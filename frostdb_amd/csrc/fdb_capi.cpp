@@ -7,6 +7,7 @@
 #include "fdb_comm.h"
 #include "fdb_context.h"
 #include "fdb_dynamic.h"
+#include "fdb_jit.h"
 #include "fdb_plan.h"
 
 // A plan handle: one operator chain. With aggregations over a DynamicColumn (fdb_dynamic.h) `plan` is the family's main plan
@@ -262,6 +263,21 @@ int fdb_plan_filter_batch(fdb_plan* plan, const fdb_batch* batch, fdb_batch** ou
   });
 }
 
+int fdb_plan_filter_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n, fdb_batch** out, int64_t* n_selected) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] {
+    if (n < 0 || (n > 0 && (batches == nullptr || out == nullptr || n_selected == nullptr))) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    std::vector<const fdb::DeviceBatch*> bs;
+    for (int32_t i = 0; i < n; i++) {
+      out[i] = nullptr;
+      if (batches[i] == nullptr || !batches[i]->b) throw fdb::Error(FDB_ERR_INVALID, "null batch");
+      bs.push_back(batches[i]->b.get());
+    }
+    std::vector<std::unique_ptr<fdb::DeviceBatch>> rs = plan->plan.filter_batches(bs.data(), n, n_selected);
+    for (int32_t i = 0; i < n; i++) out[i] = new fdb_batch{std::move(rs[(size_t)i])};
+  });
+}
+
 int fdb_plan_select_batch(fdb_plan* plan, const fdb_batch* batch, uint32_t* dev_indices, int64_t capacity, int64_t* n_selected) {
   if (!plan) return FDB_ERR_INVALID;
   return guard(plan, [&] {
@@ -368,6 +384,19 @@ int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms
     if (n_launches) *n_launches = plan->plan.stat_launches;
     if (rows_scanned) *rows_scanned = plan->plan.stat_rows;
   });
+}
+
+int fdb_parquet_stats(int64_t* calls, double* host_ms, double* device_ms, int64_t* file_bytes, int64_t* out_bytes) {
+  return guard(nullptr, [&] { fdb::parquet_stats(calls, host_ms, device_ms, file_bytes, out_bytes); });
+}
+
+int fdb_jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads) {
+  return guard(nullptr, [&] { fdb::jit_stats(n_compiled, compile_ms, n_disk_loads); });
+}
+
+int fdb_plan_merge_ms(fdb_plan* plan, double* merge_ms) {
+  if (!plan || !merge_ms) return FDB_ERR_INVALID;
+  return guard(plan, [&] { *merge_ms = plan->plan.stat_merge_ms; });
 }
 
 int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled) {

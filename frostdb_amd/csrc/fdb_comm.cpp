@@ -399,6 +399,15 @@ std::vector<std::unique_ptr<Comm>> local_init(const int* devices, int n) {
 }
 
 // ---- plan-level merges --------------------------------------------------------------------------------------------------------
+namespace {
+// Test hook ($FDB_TEST_FAIL_MERGE_RANK = r): rank r fails before the first collective of a merge, the way a pending record that
+// raises when it is scanned would — tests/test_gpu_comm.py checks that the OTHER ranks then leave with an error instead of waiting.
+void inject_merge_fault(int rank) {
+  const char* e = std::getenv("FDB_TEST_FAIL_MERGE_RANK");
+  if (e != nullptr && *e && std::atoi(e) == rank) throw Error(FDB_ERR_STATE, "injected failure before the merge (FDB_TEST_FAIL_MERGE_RANK)");
+}
+}  // namespace
+
 bool Plan::comm_allreduce(Comm& comm) {
   // Whatever can fail on THIS rank before the first collective (a wrong device, a pending record that raises when it is scanned)
   // is caught and VOTED: a rank that threw here while its peers entered the probe would leave them blocked inside RCCL for ever.
@@ -408,6 +417,7 @@ bool Plan::comm_allreduce(Comm& comm) {
   int64_t v[4] = {INT64_MAX, INT64_MAX, 0, 0};
   try {
     if (comm.device != device_) throw Error(FDB_ERR_INVALID, "communicator endpoint lives on another device than the plan");
+    inject_merge_fault(comm.rank);
     settle();
     hip_check(hipSetDevice(device_), "hipSetDevice");
     const uint64_t sig = state_signature(&n_slots) & ((1ull << 62) - 1);
@@ -423,7 +433,10 @@ bool Plan::comm_allreduce(Comm& comm) {
     if (op == 0) continue;  // COUNT is served by the row-count array
     reds.push_back(Comm::Red{d_state_ + (size_t)a * slots_alloc_, (size_t)n_slots_, op});
   }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
   comm.all_reduce(reds, stream_);  // ordered after the scan and the fold kernel; Finish / Close wait for this stream
+  if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); merge_events_.emplace_back(e0, e1); }
   state_dirty_ = true;
   return true;
 }
@@ -499,6 +512,7 @@ void Plan::comm_exchange(Comm& comm, Plan& shard) {
   std::exception_ptr local;
   try {
     if (comm.device != device_ || shard.device_ != device_) throw Error(FDB_ERR_INVALID, "communicator endpoint lives on another device than the plan");
+    inject_merge_fault(comm.rank);
     settle();
     hip_check(hipSetDevice(device_), "hipSetDevice");
     const GroupSchema mine = export_schema();
@@ -584,7 +598,10 @@ void Plan::comm_exchange(Comm& comm, Plan& shard) {
   // 4. partitions travel to their owners, owners merge on the device
   unsigned long long* recv = nullptr;
   if (recv_rows > 0) { recv = (unsigned long long*)shard.ctx_->dev_alloc((size_t)recv_rows * rw * 4); shard.scratch_.push_back(recv); }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
   comm.all_to_all((const unsigned long long*)rows, recv, words, stream_);
+  if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); merge_events_.emplace_back(e0, e1); }
   sync();  // the rows have arrived (and this plan's timing events / scratch are settled)
   pt.mark("exchange: all-to-all");
   shard.hash_import(recv, recv_rows);

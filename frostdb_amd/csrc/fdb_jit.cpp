@@ -18,6 +18,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -922,6 +924,8 @@ int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes) {
 
 namespace {
 // Process cache → disk cache → hiprtc; `key` identifies the shape, `make_source` is only called on a process-cache miss.
+std::atomic<int64_t> g_stat_compiled{0}, g_stat_compile_us{0}, g_stat_disk_loads{0};
+
 template <typename F>
 hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make_source) {
   if (g_disabled || std::getenv("FDB_NO_JIT") != nullptr) return nullptr;
@@ -957,9 +961,14 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
     code.clear();
     from_disk = false;
   }
+  if (from_disk) g_stat_disk_loads++;
   if (code.empty()) {
     std::string log;
-    if (!compile(src, &code, &log)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool compiled = compile(src, &code, &log);
+    g_stat_compile_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    g_stat_compiled++;
+    if (!compiled) {
       std::fprintf(stderr, "[frostdb_amd] %s specialisation failed, using the interpreting kernel: %s\n", kernel_name, log.c_str());
       if (std::getenv("FDB_JIT_DEBUG")) std::fprintf(stderr, "%s\n", src.c_str());
       g_cache.emplace(ckey, nullptr);
@@ -983,6 +992,12 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
   return fn;
 }
 }  // namespace
+
+void jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads) {
+  if (n_compiled) *n_compiled = g_stat_compiled.load();
+  if (compile_ms) *compile_ms = (double)g_stat_compile_us.load() / 1000.0;
+  if (n_disk_loads) *n_disk_loads = g_stat_disk_loads.load();
+}
 
 hipFunction_t jit_get(const JitShape& shape) {
   return get_kernel(shape.key(), "fdb_plan_kernel", [&] { return jit_source(shape); });

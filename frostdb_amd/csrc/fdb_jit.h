@@ -70,6 +70,9 @@ bool jit_shape_merge(JitShape* into, const JitShape& other);
 // Workgroups of `block` threads with `lds_bytes` of dynamic LDS that fit one CU (≥ 1).
 int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes);
 
+// Kernels compiled with hiprtc by this process, the time that took, and code objects loaded from the disk cache instead.
+void jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads);
+
 std::string jit_source(const JitShape& shape);
 // The compiled kernel for `shape` (cached in the process and on disk), or nullptr if specialisation is unavailable.
 hipFunction_t jit_get(const JitShape& shape);

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <system_error>
 #include <thread>
@@ -546,13 +547,24 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr size_t kTailPad = 256;
 
+std::atomic<int64_t> g_pq_calls{0}, g_pq_host_us{0}, g_pq_device_us{0}, g_pq_file_bytes{0}, g_pq_out_bytes{0};
+
 }  // namespace
+
+void parquet_stats(int64_t* calls, double* host_ms, double* device_ms, int64_t* file_bytes, int64_t* out_bytes) {
+  if (calls) *calls = g_pq_calls.load();
+  if (host_ms) *host_ms = (double)g_pq_host_us.load() / 1000.0;
+  if (device_ms) *device_ms = (double)g_pq_device_us.load() / 1000.0;
+  if (file_bytes) *file_bytes = g_pq_file_bytes.load();
+  if (out_bytes) *out_bytes = g_pq_out_bytes.load();
+}
 
 std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device) {
   if (chunks == nullptr || n_chunks <= 0 || n_rows < 0) throw Error(FDB_ERR_INVALID, "parquet: no column chunks");
   // (host-only: malformed / unsupported chunks are refused before any device call). Column chunks are independent: big ones —
   // inflating pages is the expensive part — are parsed on one thread each; the first failure in column order is reported.
   std::vector<ParsedChunk> parsed((size_t)n_chunks);
+  const auto t_host0 = std::chrono::steady_clock::now();
   size_t packed_bytes = 0;
   for (int32_t i = 0; i < n_chunks; i++) if (chunks[i].codec != 0 && chunks[i].n_bytes > 0) packed_bytes += (size_t)chunks[i].n_bytes;
   if (n_chunks > 1 && packed_bytes >= ((size_t)1 << 20)) {
@@ -577,6 +589,7 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
   } else {
     for (int32_t i = 0; i < n_chunks; i++) parsed[(size_t)i] = parse_chunk(chunks[i], n_rows);
   }
+  const auto t_host1 = std::chrono::steady_clock::now();
   hip_check(hipSetDevice(device), "hipSetDevice");
 
   std::unique_ptr<DeviceBatch> b(new DeviceBatch());
@@ -694,6 +707,16 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
     }
     b->payload_bytes += d.value_bytes + d.validity_bytes;
     b->cols.push_back(std::move(d));
+  }
+  {  // measurement hooks (fdb_parquet_stats): host = header walk + inflate + dictionary work, device = copies + pq_* kernels + waits
+    const auto t_end = std::chrono::steady_clock::now();
+    g_pq_calls++;
+    g_pq_host_us += std::chrono::duration_cast<std::chrono::microseconds>(t_host1 - t_host0).count();
+    g_pq_device_us += std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_host1).count();
+    int64_t fb = 0;
+    for (int32_t i = 0; i < n_chunks; i++) fb += chunks[i].n_bytes;
+    g_pq_file_bytes += fb;
+    g_pq_out_bytes += b->payload_bytes;
   }
   return b;
 }

@@ -422,6 +422,7 @@ Plan::~Plan() {
   (void)hipSetDevice(device_);
   (void)hipStreamSynchronize(stream_);
   for (auto& p : pending_events_) { ctx_->put_event(p.first); ctx_->put_event(p.second); }
+  for (auto& p : merge_events_) { ctx_->put_event(p.first); ctx_->put_event(p.second); }
   ctx_->dev_free(d_state_);
   ctx_->dev_free(h_table_);
   ctx_->dev_free(h_keys_);
@@ -522,6 +523,13 @@ void Plan::collect_timing() {
     ctx_->put_event(p.second);
   }
   pending_events_.clear();
+  for (auto& p : merge_events_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) stat_merge_ms += ms;
+    ctx_->put_event(p.first);
+    ctx_->put_event(p.second);
+  }
+  merge_events_.clear();
 }
 
 void* Plan::upload(const void* host, size_t bytes) { return ctx_->stage(host, bytes); }
@@ -1992,6 +2000,12 @@ std::unique_ptr<DeviceBatch> Plan::filter_batch(const DeviceBatch& in, int64_t* 
     stat_bytes += 2 * (total * cols[k].width) + (c.d_validity != nullptr ? 2 * ((total + 7) / 8) : 0);
   }
   sync();
+  return out;
+}
+
+std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch* const* in, int n, int64_t* n_selected) {
+  std::vector<std::unique_ptr<DeviceBatch>> out;
+  for (int i = 0; i < n; i++) out.push_back(filter_batch(*in[i], &n_selected[i]));
   return out;
 }
 

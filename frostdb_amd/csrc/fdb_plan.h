@@ -73,6 +73,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
 
 // Parquet column chunks of one row group → a resident batch (fdb_parquet.cpp).
 std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device);
+void parquet_stats(int64_t* calls, double* host_ms, double* device_ms, int64_t* file_bytes, int64_t* out_bytes);
 // The record of a resident batch as Arrow in host memory.
 void export_batch(const DeviceBatch& b, ArrowArray* out, ArrowSchema* out_schema);
 
@@ -219,6 +220,8 @@ class Plan {
   // The same for a record resident in HBM, results staying in HBM: the compacted record as a new resident batch / the
   // selection vector in a DEVICE buffer of `capacity` ≥ rows entries.
   std::unique_ptr<DeviceBatch> filter_batch(const DeviceBatch& in, int64_t* n_selected);
+  // The same for every record of a scan at once: one launch sequence, two host round trips in total (sizes, NULL counts).
+  std::vector<std::unique_ptr<DeviceBatch>> filter_batches(const DeviceBatch* const* in, int n, int64_t* n_selected);
   int64_t select_batch(const DeviceBatch& in, uint32_t* d_indices, int64_t capacity);
   const char* draw();                                                  // ≙ Draw
   int64_t num_groups();
@@ -255,6 +258,7 @@ class Plan {
   bool timing = false;
   int64_t stat_bytes = 0, stat_launches = 0, stat_rows = 0;
   double stat_ms = 0;
+  double stat_merge_ms = 0;      // device time of cross-GPU merges (hipEvent pairs around the collectives of comm_allreduce / comm_exchange)
   int rows_per_thread = 0;  // 0: slot (load-hoisting) kernel; 4 / 8: sequential kernel
   int grid_override = 0;
   int ablate = 0;
@@ -324,6 +328,7 @@ class Plan {
 
   Context* ctx_ = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> merge_events_;
   std::vector<void*> scratch_;  // device blocks in use by in-flight kernels; returned to the context at the next sync
   std::vector<std::unique_ptr<DeviceBatch>> pending_;   // queued small records (copies in flight or done), not scanned yet
   std::vector<std::unique_ptr<DeviceBatch>> inflight_;  // records a launched kernel may still be reading; dropped at the next sync

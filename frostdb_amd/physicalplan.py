@@ -81,6 +81,9 @@ def lib() -> ctypes.CDLL:
     L.fdb_batch_release.argtypes = [vp]
     L.fdb_batch_release.restype = None
     L.fdb_plan_stats.argtypes = [vp, P(i64), P(ctypes.c_double), P(i64), P(i64)]
+    L.fdb_parquet_stats.argtypes = [P(i64), P(ctypes.c_double), P(ctypes.c_double), P(i64), P(i64)]
+    L.fdb_jit_stats.argtypes = [P(i64), P(ctypes.c_double), P(i64)]
+    L.fdb_plan_merge_ms.argtypes = [vp, P(ctypes.c_double)]
     L.fdb_plan_set_timing.argtypes = [vp, i32]
     L.fdb_plan_stream.argtypes = [vp, P(vp)]
     L.fdb_plan_set_tuning.argtypes = [vp, i32, i32]
@@ -112,11 +115,26 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_exchange.argtypes = [vp, vp, P(vp)]
     L.fdb_live_allocations.argtypes = [P(i64), P(i64), P(i64)]
     L.fdb_plan_filter_batch.argtypes = [vp, vp, P(vp), P(i64)]
+    L.fdb_plan_filter_batches.argtypes = [vp, P(vp), i32, P(vp), P(i64)]
     L.fdb_plan_select_batch.argtypes = [vp, vp, vp, i64, P(i64)]
     L.fdb_batch_export.argtypes = [vp, vp, vp]
     L.fdb_batch_from_parquet.argtypes = [vp, i32, i64, ctypes.c_int, P(vp)]
     _lib = L
     return L
+
+
+def jit_stats() -> dict:
+    """Kernels compiled with hiprtc by this process, the wall time of those compilations, code objects loaded from the disk cache."""
+    n, ms, d = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
+    lib().fdb_jit_stats(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(d))
+    return {"compiled": n.value, "compile_ms": ms.value, "disk_loads": d.value}
+
+
+def parquet_stats() -> dict:
+    """fdb_batch_from_parquet accumulated over the process: calls, host-part and device-part wall ms, bytes in and out."""
+    c, h, d, fb, ob = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+    lib().fdb_parquet_stats(ctypes.byref(c), ctypes.byref(h), ctypes.byref(d), ctypes.byref(fb), ctypes.byref(ob))
+    return {"calls": c.value, "host_ms": h.value, "device_ms": d.value, "file_bytes": fb.value, "out_bytes": ob.value}
 
 
 def read_ceiling(device: int = 0, nbytes: int = 1 << 31, reps: int = 5) -> float:
@@ -296,6 +314,11 @@ class HashAggregatePlan:
         with ExportedBatch(record) as ex:
             self._check(lib().fdb_plan_push(self.handle, ctypes.addressof(ex.array), ctypes.addressof(ex.schema)))
 
+    def CallbackExported(self, ex: "ExportedBatch") -> None:
+        """Callback for a host record whose C-data export the caller keeps (fdb_plan_push only borrows the structs, so one export
+        can be pushed any number of times — measurement loops keep pyarrow's export cost out of the timed region)."""
+        self._check(lib().fdb_plan_push(self.handle, ctypes.addressof(ex.array), ctypes.addressof(ex.schema)))
+
     def CallbackResident(self, records: Sequence[ResidentBatch]) -> None:
         """Callback for several HBM-resident records at once: one fused kernel launch over all of them."""
         arr = (ctypes.c_void_p * len(records))(*[r.handle for r in records])
@@ -354,6 +377,15 @@ class HashAggregatePlan:
         out, n = ctypes.c_void_p(), ctypes.c_int64()
         self._check(lib().fdb_plan_filter_batch(self.handle, record.handle, ctypes.byref(out), ctypes.byref(n)))
         return ResidentBatch(None, device=self.device, _handle=out.value)
+
+    def FilterResidentMany(self, records: Sequence["ResidentBatch"]) -> List["ResidentBatch"]:
+        """≙ filter() over several resident records at once (fdb_plan_filter_batches): one launch sequence for all of them."""
+        n = len(records)
+        arr = (ctypes.c_void_p * n)(*[r.handle for r in records])
+        outs = (ctypes.c_void_p * n)()
+        counts = (ctypes.c_int64 * n)()
+        self._check(lib().fdb_plan_filter_batches(self.handle, arr, n, outs, counts))
+        return [ResidentBatch(None, device=self.device, _handle=outs[i]) for i in range(n)]
 
     def SelectResident(self, record: "ResidentBatch", dev_ptr: int, capacity: int) -> int:
         """Selection vector of a resident record into a DEVICE buffer (uint32 × capacity ≥ rows); returns the number selected."""
@@ -449,7 +481,9 @@ class HashAggregatePlan:
     def stats(self) -> dict:
         b, ms, n, r = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
         lib().fdb_plan_stats(self.handle, ctypes.byref(b), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(r))
-        return {"algorithmic_bytes": b.value, "kernel_ms": ms.value, "launches": n.value, "rows": r.value}
+        mm = ctypes.c_double()
+        lib().fdb_plan_merge_ms(self.handle, ctypes.byref(mm))
+        return {"algorithmic_bytes": b.value, "kernel_ms": ms.value, "launches": n.value, "rows": r.value, "merge_ms": mm.value}
 
     def __del__(self):
         try:

@@ -266,6 +266,10 @@ int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema
  * bitmap + per-tile counts, their prefix sums, and ONE streaming pass that compacts every column (wave prefix sums, LDS staging,
  * coalesced stores) — rows keep their order, the output is allocated at its exact size. */
 int fdb_plan_filter_batch(fdb_plan* plan, const fdb_batch* batch, fdb_batch** out, int64_t* n_selected);
+/* filter() over `n` resident records in ONE launch sequence (≙ PredicateFilter.Callback for every record of a scan, filter.go:255-323;
+ * what fdb_plan_push_batches is to the aggregate): out[i] / n_selected[i] are record i's compacted record and row count. All or
+ * nothing: on an error no output batch is returned. */
+int fdb_plan_filter_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n, fdb_batch** out, int64_t* n_selected);
 int fdb_plan_select_batch(fdb_plan* plan, const fdb_batch* batch, uint32_t* dev_indices, int64_t capacity, int64_t* n_selected);
 /* ≙ PhysicalPlan.Draw: "PredicateFilter (…) - HashAggregate (sum(value) by labels.path)". Owned by the plan. */
 const char* fdb_plan_draw(fdb_plan* plan);
@@ -408,6 +412,17 @@ int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, in
  * kernel) since the plan was created; `n_launches` scan-kernel launches. */
 int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms, int64_t* n_launches,
                    int64_t* rows_scanned);
+/* fdb_batch_from_parquet, accumulated over the process: calls, wall time of the host part (page-header walk, inflating compressed
+ * pages, dictionary pages) and of the device part (copies, pq_* kernels, the waits), bytes of column chunks read and of columns
+ * produced. */
+int fdb_parquet_stats(int64_t* calls, double* host_ms, double* device_ms, int64_t* file_bytes, int64_t* out_bytes);
+/* Run-time specialisation (hiprtc): kernels this process compiled, the wall time the compiler took (ms), and code objects it
+ * loaded from the on-disk cache ($FDB_JIT_CACHE) instead — what the FIRST query of a shape pays on top of its scan. */
+int fdb_jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads);
+/* Accumulated device time in ms of the cross-GPU merges this plan took part in (hipEvent pairs on the plan's stream around the
+ * collectives of fdb_plan_allreduce / the all-to-all of fdb_plan_exchange); 0 unless timing is enabled. Read it after
+ * fdb_plan_finish (or anything else that waits for the plan's stream). */
+int fdb_plan_merge_ms(fdb_plan* plan, double* merge_ms);
 /* Enables/disables the per-launch hipEvent timing above (off by default; costs two events per launch). */
 int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled);
 /* The hipStream_t the plan launches on, as an opaque pointer. */

@@ -73,3 +73,81 @@ def test_stdout_carries_only_the_json_line():
     assert p.returncode == 0, p.stderr
     assert p.stdout == '{"ok": 1}\n'
     assert "RCCL version : banner" in p.stderr and "python noise" in p.stderr and "late noise" in p.stderr
+
+
+def test_shard_rule_of_cfg4_one_billion_rows_over_n_gpus():
+    """BASELINE.json configs[3]: 1 B rows sharded across the GPUs — 125 M per GPU at N = 8 (SURVEY §8d cfg 4). The rule bench.py
+    uses at N > 1 (strong scaling): equal shares, remainders to the first ranks, Σ = total for every N."""
+    b = _bench()
+    assert [b.shard_rows(1_000_000_000, 8, r) for r in range(8)] == [125_000_000] * 8
+    assert [b.shard_rows(1_000_000_000, 1, 0)] == [1_000_000_000]
+    for world in (1, 2, 3, 4, 5, 6, 7, 8, 16):
+        shares = [b.shard_rows(1_000_000_000, world, r) for r in range(world)]
+        assert sum(shares) == 1_000_000_000 and max(shares) - min(shares) <= 1 and shares == sorted(shares, reverse=True)
+    assert [b.shard_rows(10, 3, r) for r in range(3)] == [4, 3, 3]
+    import pytest
+    with pytest.raises(ValueError):
+        b.shard_rows(10, 2, 2)
+    # the flags: N > 1 defaults to the sharded (strong) form; --weak keeps --rows on every GPU; --force-local implies one process
+    a = b.parse_args(["--gpus", "8"])
+    assert a.gpus == 8 and not a.weak and not a.one_process
+    assert b.parse_args(["--gpus", "2", "--force-local"]).force_local
+    assert b.HEADLINE_ROWS == 1_000_000_000
+
+
+def _group_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = _bench()
+        g = b.ProcGroup(rank, world, 0, dist)
+        g.barrier()
+        exp = [np.arange(5, dtype=np.float64) * (rank + 1), np.array([rank + 1, 10 - rank], dtype=np.int64)]
+        summed = [g.reduce(exp[0], "sum"), g.reduce(exp[1], "sum")]
+        mn, mx = g.reduce(exp[1], "min"), g.reduce(exp[1], "max")
+        shards = g.gather(b.shard_rows(1_000_000_007, world, rank))
+        slowest = float(g.reduce(np.array([0.5 + rank]), "max")[0])
+        q.put((rank, [a.tolist() for a in summed], mn.tolist(), mx.tolist(), shards, slowest))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_control_plane_of_the_n_rank_bench_on_gloo_world_size_2():
+    """bench.py's host-side control plane at N > 1 (barrier, max-over-ranks of the elapsed time, sums / mins / maxes of the
+    numpy expectations, the shard sizes) over torch.distributed — gloo here, RCCL on the GPU box; the thread form used by
+    --one-process gives the same answers."""
+    import socket
+    import threading
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, summed, mn, mx, shards, slowest in got:
+        assert summed == [[0.0, 3.0, 6.0, 9.0, 12.0], [3, 19]] and mn == [1, 9] and mx == [2, 10]
+        assert shards == [500_000_004, 500_000_003] and slowest == 1.5
+    # the same through the thread form
+    b = _bench()
+    shared = b.ThreadShared(2)
+    out = [None, None]
+
+    def work(r):
+        g = b.ThreadGroup(r, 2, 0, shared)
+        g.barrier()
+        out[r] = (g.reduce(np.array([r + 1, 10 - r], dtype=np.int64), "sum").tolist(), g.reduce(np.array([0.5 + r]), "max").tolist(),
+                  g.gather(b.shard_rows(1_000_000_007, 2, r)))
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert out[0] == out[1] == ([3, 19], [1.5], [500_000_004, 500_000_003])

@@ -6,6 +6,7 @@ all on device 0) — the plan-level code (layout probe, grouped in-place all-red
 exchange, import) is the same for both transports — and the RCCL transport itself runs with one rank (ncclCommInitRank /
 ncclCommInitAll, every collective on a 1-rank communicator). No torch, no gloo: everything goes through ctypes.
 """
+import math
 import threading
 
 import numpy as np
@@ -235,3 +236,79 @@ def test_empty_rank(pp, fcomm):
     assert_same_result(merged, want, cols, float_cols={"sum(value)"})
     for c in comms:
         c.close()
+
+
+@pytest.mark.parametrize("how", ["allreduce", "exchange"])
+def test_a_rank_that_fails_before_the_merge_takes_every_rank_out_with_an_error(pp, fcomm, how, monkeypatch):
+    """A rank that raises BEFORE a merge's first collective (a pending record that fails when it is scanned, a wrong device) must
+    not leave its peers blocked inside the collective: the failure is voted through that first collective — the layout probe of
+    fdb_plan_allreduce, the schema all-gather of fdb_plan_exchange — and every rank returns an error. Rank 1 fails here through
+    the library's test hook; ranks 0 and 2 must come back (run_ranks asserts nobody is stuck) with FDB_ERR_STATE."""
+    world = 3
+    rng = np.random.default_rng(11)
+    shards = [make_prometheus_batch(rng, 5_000, n_path=20, null_frac=0.0) for _ in range(world)]
+    comms = fcomm.Comm.init_local([0] * world)
+    monkeypatch.setenv("FDB_TEST_FAIL_MERGE_RANK", "1")
+    errors = [None] * world
+
+    def rank_fn(r):
+        plan = pp.HashAggregatePlan(CFG2["filter_expr"], CFG2["aggs"], CFG2["groups"])
+        try:
+            plan.Callback(shards[r])
+            try:
+                if how == "allreduce":
+                    comms[r].allreduce(plan)
+                else:
+                    comms[r].merge_alltoall(plan).Close()
+            except pp.FdbError as e:
+                errors[r] = e
+        finally:
+            plan.Close()
+
+    run_ranks(world, rank_fn)
+    assert all(e is not None for e in errors), errors
+    assert "injected failure" in str(errors[1])
+    for r in (0, 2):
+        assert errors[r].code == pp.FDB_ERR_STATE and "another rank failed" in str(errors[r]), str(errors[r])
+    monkeypatch.delenv("FDB_TEST_FAIL_MERGE_RANK")
+    # the communicator is still usable afterwards (nobody is half way through a collective)
+
+    def again(r):
+        plan = pp.HashAggregatePlan(CFG2["filter_expr"], CFG2["aggs"], CFG2["groups"])
+        try:
+            plan.Callback(shards[r])
+            assert comms[r].allreduce(plan) is True
+            return arrow_to_pydict(plan.Finish())
+        finally:
+            plan.Close()
+
+    want = run_oracle(shards, **CFG2)
+    for got in run_ranks(world, again):
+        assert_same_result(got, want, ["labels.path", "sum(value)"], float_cols={"sum(value)"})
+    for c in comms:
+        c.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_over_the_in_process_transport_is_cfg4_sharded():
+    """`bench.py --gpus 2 --force-local`: cfg 4 as BASELINE.json states it (1 B rows in total, sharded — here 2 × 500 M on the one
+    GPU of this box, merged through fdb_plan_allreduce over the in-process transport), one JSON line, shard sizes sum to 1 B, the
+    merged result checked against the numpy restatement summed over both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--force-local", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=850, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["workload"].startswith("cfg4: 1000000000 rows sharded over 2 GPUs")
+    assert line["config"]["rows_per_gpu"] == [500_000_000, 500_000_000] and sum(line["config"]["rows_per_gpu"]) == 1_000_000_000
+    assert line["config"]["total_rows"] == 1_000_000_000
+    assert line["checked"]["groups_out"] == 1025 and line["merge_ms"] > 0
+    assert len(line["per_rank"]) == 2 and all(r["kernel_frac"] > 0.3 for r in line["per_rank"])
+    assert line["roofline"]["kernel"] == "fdb_plan_kernel" and line["devices_used"] == 1
+    assert math.isclose(line["value"], 1e9 * 3 / (line["ms_per_step"] * 3e-3), rel_tol=1e-6)
