@@ -379,6 +379,7 @@ int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms
   if (!plan) return FDB_ERR_INVALID;
   return guard(plan, [&] {
     plan->plan.settle();  // queued small records count once they are scanned
+    if (plan->plan.timing) plan->plan.sync();  // (event pairs are read once their kernels have run: a rank whose merge emitted no record has not waited yet)
     if (algorithmic_bytes) *algorithmic_bytes = plan->plan.stat_bytes;
     if (kernel_ms) *kernel_ms = plan->plan.stat_ms;
     if (n_launches) *n_launches = plan->plan.stat_launches;
@@ -396,7 +397,7 @@ int fdb_jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads
 
 int fdb_plan_merge_ms(fdb_plan* plan, double* merge_ms) {
   if (!plan || !merge_ms) return FDB_ERR_INVALID;
-  return guard(plan, [&] { *merge_ms = plan->plan.stat_merge_ms; });
+  return guard(plan, [&] { if (plan->plan.timing) plan->plan.sync(); *merge_ms = plan->plan.stat_merge_ms; });
 }
 
 int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled) {

@@ -73,6 +73,14 @@ int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes);
 // Kernels compiled with hiprtc by this process, the time that took, and code objects loaded from the disk cache instead.
 void jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads);
 
+// filter() (Plan::filter_batches): the selection-bitmap kernel of a predicate shape — 256-thread workgroups, one wave per tile of
+// 2 048 rows (FDB_COMPACT_TILE): 64 mask words and one count per tile, plain stores. The argument blocks count tile_begin /
+// tile_end in units of FOUR tiles (a workgroup's share, all of one record) and carry the record's first tile in out_tile_base.
+std::string jit_flags_source(const JitShape& shape);
+hipFunction_t jit_flags_get(const JitShape& shape);
+hipError_t jit_flags_launch(hipFunction_t fn, const FdbScanArgs* d_parts, int n_parts, int64_t total_super_tiles, const FdbScanArgs& common, int grid, size_t lds_bytes,
+                            uint32_t* masks, uint32_t* tile_counts, hipStream_t stream);
+
 std::string jit_source(const JitShape& shape);
 // The compiled kernel for `shape` (cached in the process and on disk), or nullptr if specialisation is unavailable.
 hipFunction_t jit_get(const JitShape& shape);

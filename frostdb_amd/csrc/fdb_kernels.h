@@ -143,6 +143,7 @@ struct FdbScanArgs {
   int32_t cache_slots;      // lds_acc == 0 (table too big for LDS), specialised kernel only: entries (a power of two) of the workgroup's
                             // LDS combining cache [tag u32 | count u32 | acc u64 × n_aggs] placed after the LUT copies; 0: none
   FdbExprNode expr[FDB_MAX_EXPR_NODES];
+  int64_t out_tile_base;    // fdb_flags_kernel only: the record's first tile in the launch-wide mask / count arrays
 };
 
 // ---- high-cardinality path: global open-addressing hash table -------------------------------------------------
@@ -381,6 +382,8 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
 #define FDB_COMPACT_SUB 8                                  // a tile is 8 sub-tiles of (64 lanes × 4 consecutive rows)
 #define FDB_COMPACT_SUBTILE (64 * 4)
 #define FDB_COMPACT_TILE (FDB_COMPACT_SUBTILE * FDB_COMPACT_SUB)  // 2 048 rows, owned by one wave
+#define FDB_COMPACT_STREAM_WAVE_LDS 6144                   // compact_multi_kernel: 4 KiB of values (512 × 8 or 1 024 × 4 bytes) + 512 B of dump slots, then
+                                                           // ≤ 1 024 + 64 validity bytes — 24 KiB per workgroup, 6 workgroups (24 waves) per CU
 #define FDB_COMPACT_WAVE_LDS 5120                          // staging bytes per wave: 4 KiB of values + 1 KiB of validity bytes
 hipError_t fdb_launch_filter_flags(const FdbScanArgs& args, uint8_t* masks, uint32_t* tile_counts, int device, hipStream_t stream);
 // One column per launch. width 4 / 8: values of that many bytes (`src` → `dst`, validity bitmap `src_valid` (nullptr: no NULLs) →
@@ -388,6 +391,26 @@ hipError_t fdb_launch_filter_flags(const FdbScanArgs& args, uint8_t* masks, uint
 // NULLs among the selected rows — the caller adds the 64 partial counts); width 0: the selection vector — ascending row numbers — into `dst` (uint32).
 hipError_t fdb_launch_compact_col(int width, const void* src, const uint8_t* src_valid, void* dst, uint8_t* dst_valid, const uint8_t* masks,
                                   const uint32_t* tile_offsets, int64_t n_rows, unsigned long long* null_count, int device, hipStream_t stream);
+// filter() over every record of a scan at once (Plan::filter_batches): global tiles of FDB_COMPACT_TILE rows, record r owns
+// [recs[r].tile_begin, recs[r + 1].tile_begin) (the last one up to total_tiles); mask words [tile × 64, tile × 64 + 64).
+struct FdbCompactRec { int64_t tile_begin; int64_t n_rows; };
+struct FdbCompactCol { const void* src; const uint8_t* src_valid; void* dst; uint8_t* dst_valid; int32_t width; int32_t nullable; };  // width 4 / 8; nullable: the
+// same for the column in EVERY record of the launch — then src_valid / dst_valid are never null (a record without NULLs passes an all-ones bitmap)
+struct FdbZeroRegion { void* ptr; int64_t bytes; };  // 16-byte aligned, a multiple of 16 bytes
+// offsets[t] = Σ tile_counts[< t] (mod 2^32), rec_base[r] = the same sum in full at record r's first tile, rec_base[n_recs] = the
+// grand total. block_sums[b] = Σ tile_counts[1024 b …) (fdb_launch_sel_block_sums; nullptr: every workgroup adds up the counts in
+// front of its block itself — cheaper than a launch while there are only a few dozen blocks).
+hipError_t fdb_launch_sel_scan(const uint32_t* tile_counts, const unsigned long long* block_sums, int64_t total_tiles, uint32_t* offsets, const FdbCompactRec* recs,
+                               int n_recs, unsigned long long* rec_base, hipStream_t stream);
+hipError_t fdb_launch_sel_block_sums(const uint32_t* tile_counts, int64_t total_tiles, unsigned long long* block_sums, hipStream_t stream);
+hipError_t fdb_launch_zero_regions(const FdbZeroRegion* regions, int n_regions, int64_t max_bytes, hipStream_t stream);
+// Every column (cols[rec × n_cols + col]) of every record compacted in ONE launch; null_counts[(rec × n_cols + col) × 64 …] (zeroed).
+// Wave g of the launch works on the column c with col_wave_begin[c] ≤ g < col_wave_begin[c + 1] (device array of n_cols + 1 entries,
+// n_waves = its last one): the host deals the waves to the columns in proportion to their bytes.
+int fdb_compact_multi_blocks_per_cu(void);
+hipError_t fdb_launch_compact_multi(const FdbCompactRec* recs, int n_recs, const FdbCompactCol* cols, int n_cols, const int32_t* col_wave_begin, int n_waves,
+                                    const uint32_t* masks, const uint32_t* tile_offsets, const unsigned long long* rec_base, int64_t total_tiles,
+                                    unsigned long long* null_counts, hipStream_t stream);
 int fdb_scan_default_grid(int device);
 // ---- Parquet pages → columns in HBM (≙ pqarrow/arrow.go:711-823 writeColumnToArray + parquet-go's page decoders) ----
 // The host parses page headers and run headers only (fdb_parquet.cpp); every per-row step runs here, gather-style: a thread owns

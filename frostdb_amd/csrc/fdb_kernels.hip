@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 
 #define FDB_DEVICE_HELPERS 1
+#include <cstdlib>
+
 #include "fdb_kernels.h"
 
 namespace {
@@ -1618,6 +1620,319 @@ __global__ __launch_bounds__(FDB_COMPACT_BLOCK, 5) void compact_col_kernel(const
   }
 }
 
+// ---- filter() over every record of a scan at once (fdb_plan_filter_batches) -------------------------------------------------------
+// The selection bitmap and the per-tile counts come from a kernel GENERATED for the predicate (fdb_flags_kernel, fdb_jit.cpp: one
+// launch over all records, like the aggregate scan); this is the prefix-sum step — ONE launch: workgroup b owns tiles
+// [1024 b, 1024 b + 1024): its base is the sum of the earlier workgroups' block sums (accumulated by the flags kernel with one
+// atomic per wave), its tiles' offsets a workgroup-wide exclusive scan. Offsets are global (over all records) modulo 2^32; the
+// prefix at every record's first tile is written in full (rec_base), so a tile's place INSIDE its record's output is
+// offsets[tile] − (uint32)rec_base[record], and record r's row count rec_base[r + 1] − rec_base[r].
+__global__ __launch_bounds__(1024) void sel_scan_kernel(const uint32_t* __restrict__ tile_counts, const unsigned long long* __restrict__ block_sums, int64_t total_tiles,
+                                                        uint32_t* __restrict__ offsets, const FdbCompactRec* __restrict__ recs, int n_recs,
+                                                        unsigned long long* __restrict__ rec_base) {
+  __shared__ unsigned long long wave_sum[16];
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long part = 0;
+  if (block_sums != nullptr) { for (int64_t i = tid; i < (int64_t)blockIdx.x; i += 1024) part += block_sums[i]; }
+  else { for (int64_t i = tid; i < (int64_t)blockIdx.x * 1024; i += 1024) part += tile_counts[i]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += (unsigned long long)__shfl_xor((long long)part, o, 64);
+  if (lane == 0) wave_sum[wave] = part;
+  __syncthreads();
+  if (tid == 0) { unsigned long long b = 0; for (int w = 0; w < 16; w++) b += wave_sum[w]; s_base = b; }
+  __syncthreads();
+  const unsigned long long base = s_base;
+  const int64_t t = (int64_t)blockIdx.x * 1024 + tid;
+  const uint32_t c = t < total_tiles ? tile_counts[t] : 0u;
+  uint32_t incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  __syncthreads();  // (wave_sum is re-used)
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  unsigned long long before = base;
+  for (int w = 0; w < wave; w++) before += wave_sum[w];
+  const unsigned long long excl = before + incl - c;
+  if (t < total_tiles) {
+    offsets[t] = (uint32_t)excl;
+    // is this tile the first of a record? (recs[] is sorted by tile_begin; records without rows are not in it)
+    int lo = 0, hi = n_recs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (recs[mid].tile_begin <= t) lo = mid; else hi = mid - 1; }
+    if (recs[lo].tile_begin == t) rec_base[lo] = excl;
+    if (t == total_tiles - 1) rec_base[n_recs] = excl + c;
+  }
+}
+
+__global__ __launch_bounds__(256) void sel_block_sums_kernel(const uint32_t* __restrict__ counts, int64_t n, unsigned long long* __restrict__ sums) {
+  __shared__ unsigned int wave_sum[4];
+  const int64_t i0 = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (i0 + k < n) s += counts[i0 + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = (unsigned long long)wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+// Zeroes a list of byte ranges (the validity bitmaps of the output records, which the compaction ORs into) in one launch.
+__global__ __launch_bounds__(256) void zero_regions_kernel(const FdbZeroRegion* __restrict__ regions, int n_regions) {
+  const FdbZeroRegion R = regions[blockIdx.y];
+  (void)n_regions;
+  uint4* p = reinterpret_cast<uint4*>(R.ptr);
+  const int64_t n16 = R.bytes / 16;  // (regions are 16-byte multiples at 16-byte aligned addresses)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---- every column of every record in ONE launch, software-pipelined -----------------------------------------------------------------
+// What the first multi-column kernels taught (MI355X, 100 M rows, 4 columns, 50 % selected): with loads AND stores compiled out the
+// kernel still took 0.37 of its 0.83 ms — a wave's step is one long dependent chain (mask word → loads → ballots → LDS scatter →
+// wave barrier → LDS read → stores) and while it walks that chain it has nothing in flight; 4 … 8 waves per SIMD do not cover it.
+// So a wave now always has the NEXT step's loads in flight while it stages and stores the current one (two register sets, A / B,
+// alternating — no copies between them, which would wait for the loads), and it stays on ONE column for the whole launch (the
+// descriptor lives in scalar registers, the code is specialised for the column's width): waves are dealt to columns in proportion
+// to their bytes (col_wave_begin[]), and inside a column a wave takes every n-th tile. Mask words and tile offsets of the tile
+// after the next are prefetched too. Unselected rows are staged into dump slots instead of being branched around.
+template <int W>
+struct CompactUnit {
+  static constexpr int NS = W == 8 ? 2 : 4;
+  uint32_t sel[NS], vbyte[NS];  // vbyte: the RAW validity byte of the lane's row group (consumed a step later: nothing here waits for a load)
+  uint32_t x4[W == 4 ? NS : 1][4];
+  unsigned long long x8[W == 8 ? NS : 1][4];
+  void* dst; uint8_t* dst_valid;  // (wave-uniform)
+  uint32_t out0; int q, rec;
+};
+
+#define FDB_CONST __attribute__((address_space(4)))  // wave-uniform tables are read with scalar loads (their own counter: a prefetched tile offset does not wait for vector loads)
+template <int W, bool NULLABLE>
+__device__ __forceinline__ void compact_stream(const FdbCompactRec* __restrict__ recs, const int n_recs, const FdbCompactCol* __restrict__ cols, const int n_cols, const int col,
+                                               const int64_t first, const int64_t stride, const uint32_t* __restrict__ masks, const uint32_t* __restrict__ tile_offsets,
+                                               const unsigned long long* __restrict__ rec_base, const int64_t total_tiles, unsigned long long* __restrict__ null_counts,
+                                               unsigned char* stage, const int lane, const int spread) {
+  constexpr int R = 4, NS = CompactUnit<W>::NS, STEP_ROWS = NS * FDB_COMPACT_SUBTILE, Q = FDB_COMPACT_TILE / STEP_ROWS;
+  // staging region of the wave: STEP_ROWS values, 64 dump slots (where a lane parks rows that are not selected), then one validity
+  // byte per value slot
+  constexpr uint32_t DUMP = STEP_ROWS;
+  uint8_t* stage_valid = stage + (size_t)(STEP_ROWS + 64) * W;
+  // issue side: the record of `tile` (scalars)
+  int rec = -1;
+  int64_t rec_begin = 0, rec_end = 0, rec_rows = 0;
+  uint32_t rec_off = 0;
+  const void* src = nullptr; const uint8_t* src_valid = nullptr; void* dst = nullptr; uint8_t* dst_valid = nullptr;
+  int64_t tile = first;
+  int q = 0;
+  if (tile >= total_tiles) return;
+  const FDB_CONST uint32_t* s_offsets = (const FDB_CONST uint32_t*)tile_offsets;
+  const FDB_CONST FdbCompactRec* s_recs = (const FDB_CONST FdbCompactRec*)recs;
+  uint32_t word = as_global(masks)[tile * 64 + lane], toff = s_offsets[tile];
+  uint32_t word_nx = 0, toff_nx = 0;
+  if (tile + stride < total_tiles) { word_nx = as_global(masks)[(tile + stride) * 64 + lane]; toff_nx = s_offsets[tile + stride]; }
+
+  auto issue = [&](CompactUnit<W>& U) {  // the loads of step (tile, q); then (tile, q) moves on
+    if (tile >= rec_end) {
+      int lo = rec < 0 ? 0 : rec, hi = n_recs - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_recs[mid].tile_begin <= tile) lo = mid; else hi = mid - 1; }
+      rec = lo;
+      rec_begin = s_recs[rec].tile_begin; rec_rows = s_recs[rec].n_rows;
+      rec_end = rec + 1 < n_recs ? s_recs[rec + 1].tile_begin : total_tiles;
+      rec_off = (uint32_t)((const FDB_CONST unsigned long long*)rec_base)[rec];
+      const FDB_CONST FdbCompactCol* cd = (const FDB_CONST FdbCompactCol*)cols + ((size_t)rec * n_cols + col);
+      src = cd->src; src_valid = cd->src_valid; dst = cd->dst; dst_valid = cd->dst_valid;
+    }
+    const int64_t row0 = (tile - rec_begin) * FDB_COMPACT_TILE + (int64_t)q * STEP_ROWS + (int64_t)lane * R;
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+      const uint32_t w = __shfl(word, (q * NS + u) * 8 + (lane >> 3), 64);
+      const int64_t left = rec_rows - (row0 + (int64_t)u * FDB_COMPACT_SUBTILE);
+      U.sel[u] = (w >> ((lane & 7) * 4)) & (left >= R ? 0xFu : left > 0 ? ((1u << (int)left) - 1u) : 0u);
+    }
+    // straight-line loads: a lane without selected rows reads the column's first bytes (one cached line for all such lanes) instead
+    // of being branched around — with a branch per load the compiler waits for every load before it issues the next
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+      const int64_t r = U.sel[u] ? row0 + (int64_t)u * FDB_COMPACT_SUBTILE : 0;
+      U.vbyte[u] = NULLABLE ? (uint32_t)as_global(src_valid)[r >> 3] : 0xFFu;
+      if (W == 4) load_u32<R>(reinterpret_cast<const uint32_t*>(src) + r, U.x4[u]);
+      else load_u64<R>(reinterpret_cast<const unsigned long long*>(src) + r, U.x8[u]);
+    }
+    U.dst = dst; U.dst_valid = dst_valid; U.out0 = toff - rec_off; U.q = q; U.rec = rec;
+    if (++q == Q) {
+      q = 0; tile += stride; word = word_nx; toff = toff_nx;
+      if (tile + stride < total_tiles) { word_nx = as_global(masks)[(tile + stride) * 64 + lane]; toff_nx = s_offsets[tile + stride]; }
+    }
+  };
+
+  unsigned long long out = 0;  // next output row of the tile being written (wave-uniform)
+  uint32_t my_nulls = 0;
+  int nulls_rec = -1;
+  auto flush_nulls = [&]() {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my_nulls += __shfl_xor(my_nulls, o, 64);
+    if (lane == 0 && my_nulls != 0u && nulls_rec >= 0) atomicAdd(null_counts + ((size_t)nulls_rec * n_cols + col) * 64 + spread, (unsigned long long)my_nulls);
+    my_nulls = 0;
+  };
+  auto process = [&](const CompactUnit<W>& U) {  // positions → staging → coalesced stores
+    if (U.q == 0) out = U.out0;
+    if (U.rec != nulls_rec) { flush_nulls(); nulls_rec = U.rec; }
+    uint32_t pos[NS], total = 0;
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+      uint32_t p = total;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const unsigned long long b = __ballot((U.sel[u] >> r) & 1u);
+        p += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        total += (uint32_t)__popcll(b);
+      }
+      pos[u] = p;
+    }
+    if (total == 0u) return;  // (wave-uniform)
+    // NULLs are rare: a step in which every selected row is valid (one ballot) sets its run of output validity bits arithmetically,
+    // one 64-bit word per lane, and stages no validity bytes at all
+    bool all_valid = true;
+    uint32_t valid[NS];
+#pragma unroll
+    for (int u = 0; u < NS; u++) valid[u] = NULLABLE ? (U.vbyte[u] >> ((lane & 1) * 4)) & 0xFu : 0xFu;  // (a lane's 4 rows are one nibble of their validity byte)
+    if (NULLABLE) {
+      uint32_t missing = 0;
+#pragma unroll
+      for (int u = 0; u < NS; u++) missing |= U.sel[u] & ~valid[u];
+      all_valid = __ballot(missing != 0u) == 0ull;
+      if (!all_valid) {
+#pragma unroll
+        for (int u = 0; u < NS; u++) my_nulls += __popc(U.sel[u] & ~valid[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+      uint32_t p = pos[u];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const bool on = (U.sel[u] >> r) & 1u;
+        const uint32_t at = on ? p : DUMP + (uint32_t)lane;  // (no branch: rows that are not selected are parked in the lane's dump slot)
+        if (W == 4) reinterpret_cast<uint32_t*>(stage)[at] = ((valid[u] >> r) & 1u) ? U.x4[u][r] : 0u;
+        else reinterpret_cast<unsigned long long*>(stage)[at] = U.x8[u][r];
+        p += on ? 1u : 0u;
+      }
+    }
+    if (NULLABLE && !all_valid) {
+#pragma unroll
+      for (int u = 0; u < NS; u++) {
+        uint32_t p = pos[u];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const bool on = (U.sel[u] >> r) & 1u;
+          stage_valid[on ? p : DUMP + (uint32_t)lane] = (uint8_t)((valid[u] >> r) & 1u);
+          p += on ? 1u : 0u;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the staged values leave 16 bytes per lane and instruction: every LDS read of the step is issued before the first store
+    constexpr int CHUNKS = STEP_ROWS * W / 16 / 64;  // 4
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t chunk[CHUNKS];
+#pragma unroll
+    for (int k = 0; k < CHUNKS; k++) chunk[k] = reinterpret_cast<const u32x4_t*>(stage)[k * 64 + lane];
+    if (W == 8) {
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(U.dst) + out;
+#pragma unroll
+      for (int k = 0; k < CHUNKS; k++) {
+        const uint32_t i = (uint32_t)(k * 64 + lane) * 2u;  // first of the chunk's two values
+        if (i + 1 < total) *reinterpret_cast<u32x4_t*>(d + i) = chunk[k];
+        else if (i < total) d[i] = (unsigned long long)chunk[k].x | ((unsigned long long)chunk[k].y << 32);
+      }
+    } else {
+      uint32_t* d = reinterpret_cast<uint32_t*>(U.dst) + out;
+#pragma unroll
+      for (int k = 0; k < CHUNKS; k++) {
+        const uint32_t i = (uint32_t)(k * 64 + lane) * 4u;  // first of the chunk's four values
+        if (i + 3 < total) *reinterpret_cast<u32x4_t*>(d + i) = chunk[k];
+        else {
+          if (i < total) d[i] = chunk[k].x;
+          if (i + 1 < total) d[i + 1] = chunk[k].y;
+          if (i + 2 < total) d[i + 2] = chunk[k].z;
+        }
+      }
+    }
+    if (NULLABLE) {
+      unsigned long long* bits = reinterpret_cast<unsigned long long*>(U.dst_valid);
+      if (all_valid) {
+        // bits [out, out + total) ← 1: lane k owns word (out / 64) + k of the run (≤ STEP_ROWS / 64 + 1 words)
+        const unsigned long long w0 = out >> 6, lo = out, hi = out + total;  // [lo, hi)
+        const unsigned long long wk = w0 + (unsigned long long)lane;
+        const unsigned long long b0 = wk << 6, b1 = b0 + 64;
+        if (b0 < hi && b1 > lo) {
+          unsigned long long m = ~0ull;
+          if (lo > b0) m &= ~0ull << (lo - b0);
+          if (hi < b1) m &= ~0ull >> (b1 - hi);
+          atomicOr(bits + wk, m);
+        }
+      } else {
+#pragma unroll 1
+        for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          const unsigned long long w = __ballot(i < total && stage_valid[i] != 0);
+          if (lane == 0 && w != 0ull) {
+            const unsigned long long at = out + i0;
+            const uint32_t sh = (uint32_t)(at & 63ull);
+            atomicOr(bits + (at >> 6), w << sh);
+            if (sh != 0u && (w >> (64u - sh)) != 0ull) atomicOr(bits + (at >> 6) + 1, w >> (64u - sh));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    out += total;
+  };
+
+  CompactUnit<W> A, B;
+  issue(A);
+  for (;;) {
+    const bool more_b = tile < total_tiles;
+    if (more_b) issue(B);
+    process(A);
+    if (!more_b) break;
+    const bool more_a = tile < total_tiles;
+    if (more_a) issue(A);
+    process(B);
+    if (!more_a) break;
+  }
+  flush_nulls();
+}
+
+__global__ __launch_bounds__(FDB_COMPACT_BLOCK) void compact_multi_kernel(const FdbCompactRec* __restrict__ recs, const int n_recs, const FdbCompactCol* __restrict__ cols,
+                                                                          const int n_cols, const int32_t* __restrict__ col_wave_begin, const uint32_t* __restrict__ masks,
+                                                                          const uint32_t* __restrict__ tile_offsets, const unsigned long long* __restrict__ rec_base,
+                                                                          const int64_t total_tiles, unsigned long long* __restrict__ null_counts) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NW = FDB_COMPACT_BLOCK / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* stage = smem + (size_t)wave * FDB_COMPACT_STREAM_WAVE_LDS;
+  const int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * NW + wave);  // this wave's number; its column: col_wave_begin[col] ≤ g < col_wave_begin[col + 1]
+  int col = 0;
+  while (col + 1 < n_cols && g >= col_wave_begin[col + 1]) col++;
+  col = __builtin_amdgcn_readfirstlane(col);
+  const int begin = __builtin_amdgcn_readfirstlane(col_wave_begin[col]);
+  const int first = g - begin;
+  const int stride = __builtin_amdgcn_readfirstlane(col_wave_begin[col + 1]) - begin;
+  if (stride <= 0 || first >= stride) return;
+  // width and nullability are the same for every record of the launch (one schema; the host clears `nullable` unless EVERY record
+  // carries a bitmap for the column and passes all-ones bitmaps otherwise — see Plan::filter_batches)
+  const int width = __builtin_amdgcn_readfirstlane(cols[col].width), nullable = __builtin_amdgcn_readfirstlane(cols[col].nullable);
+#define FDB_RUN(W, N) compact_stream<W, N>(recs, n_recs, cols, n_cols, col, first, stride, masks, tile_offsets, rec_base, total_tiles, null_counts, stage, lane, g & 63)
+  if (width == 8) { if (nullable) FDB_RUN(8, true); else FDB_RUN(8, false); }
+  else { if (nullable) FDB_RUN(4, true); else FDB_RUN(4, false); }
+#undef FDB_RUN
+}
+
 int g_cu_count[16] = {0};
 
 }  // namespace
@@ -1840,6 +2155,48 @@ hipError_t fdb_launch_compact_col(int width, const void* src, const uint8_t* src
   return hipGetLastError();
 }
 
+
+hipError_t fdb_launch_sel_scan(const uint32_t* tile_counts, const unsigned long long* block_sums, int64_t total_tiles, uint32_t* offsets, const FdbCompactRec* recs,
+                               int n_recs, unsigned long long* rec_base, hipStream_t stream) {
+  if (total_tiles <= 0 || n_recs <= 0) return hipSuccess;
+  const int64_t n_blocks = (total_tiles + 1023) / 1024;
+  hipLaunchKernelGGL(sel_scan_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, stream, tile_counts, block_sums, total_tiles, offsets, recs, n_recs, rec_base);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_sel_block_sums(const uint32_t* tile_counts, int64_t total_tiles, unsigned long long* block_sums, hipStream_t stream) {
+  if (total_tiles <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sel_block_sums_kernel, dim3((unsigned)((total_tiles + 1023) / 1024)), dim3(256), 0, stream, tile_counts, total_tiles, block_sums);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_zero_regions(const FdbZeroRegion* regions, int n_regions, int64_t max_bytes, hipStream_t stream) {
+  if (n_regions <= 0) return hipSuccess;
+  int64_t gx = (max_bytes / 16 + 255) / 256;
+  gx = gx < 1 ? 1 : gx > 64 ? 64 : gx;
+  hipLaunchKernelGGL(zero_regions_kernel, dim3((unsigned)gx, (unsigned)n_regions), dim3(256), 0, stream, regions, n_regions);
+  return hipGetLastError();
+}
+
+int fdb_compact_multi_blocks_per_cu(void) {  // workgroups of compact_multi_kernel resident on one CU (registers and LDS): a wave's share of tiles is fixed at launch,
+  static const int n = [] {                   // so the launch must not be larger than what runs at once
+    int b = 0;
+    const size_t lds = (size_t)(FDB_COMPACT_BLOCK / 64) * FDB_COMPACT_STREAM_WAVE_LDS;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, compact_multi_kernel, FDB_COMPACT_BLOCK, lds) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; }
+    return b;
+  }();
+  return n;
+}
+
+hipError_t fdb_launch_compact_multi(const FdbCompactRec* recs, int n_recs, const FdbCompactCol* cols, int n_cols, const int32_t* col_wave_begin, int n_waves,
+                                    const uint32_t* masks, const uint32_t* tile_offsets, const unsigned long long* rec_base, int64_t total_tiles,
+                                    unsigned long long* null_counts, hipStream_t stream) {
+  if (total_tiles <= 0 || n_cols <= 0 || n_recs <= 0 || n_waves <= 0) return hipSuccess;
+  const size_t lds = (size_t)(FDB_COMPACT_BLOCK / 64) * FDB_COMPACT_STREAM_WAVE_LDS;
+  hipLaunchKernelGGL(compact_multi_kernel, dim3((unsigned)((n_waves + 3) / 4)), dim3(FDB_COMPACT_BLOCK), lds, stream, recs, n_recs, cols, n_cols, col_wave_begin, masks, tile_offsets,
+                     rec_base, total_tiles, null_counts);
+  return hipGetLastError();
+}
 
 hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t lds_bytes, hipStream_t stream) {
   const int64_t tile_rows = (int64_t)FDB_HASH_BLOCK;

@@ -1915,6 +1915,14 @@ int64_t Plan::select_batch(const DeviceBatch& in, uint32_t* d_indices, int64_t c
 }
 
 std::unique_ptr<DeviceBatch> Plan::filter_batch(const DeviceBatch& in, int64_t* n_selected) {
+  const DeviceBatch* p = &in;
+  std::vector<std::unique_ptr<DeviceBatch>> out = filter_batches(&p, 1, n_selected);  // (falls back to filter_batch_interp by itself)
+  return std::move(out[0]);
+}
+
+// The per-record path: interpreting flags kernel, one compaction launch per column (what runs when the predicate cannot be
+// specialised at run time, and the parity reference of the generated kernels).
+std::unique_ptr<DeviceBatch> Plan::filter_batch_interp(const DeviceBatch& in, int64_t* n_selected) {
   if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
   if (in.device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
   if (in.cols.size() > 128) throw Error(FDB_ERR_UNSUPPORTED, "filter output: more than 128 columns");
@@ -2003,9 +2011,276 @@ std::unique_ptr<DeviceBatch> Plan::filter_batch(const DeviceBatch& in, int64_t* 
   return out;
 }
 
+// ≙ PredicateFilter.Callback for every record of a scan at once (filter.go:255-323). Four launches whatever the number of records
+// (five above ≈130 M rows): selection bitmap + per-tile counts by a kernel generated for the predicate (fdb_flags_kernel) →
+// prefix sums (sel_scan_kernel) → [host: the records' row counts, outputs allocated at their exact sizes] → zero the output
+// bitmaps → every column of every record compacted (compact_multi_kernel). Two host round trips in total. Falls back to the
+// per-record path (interpreting flags kernel, one compaction launch per column) when the predicate cannot be specialised.
 std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch* const* in, int n, int64_t* n_selected) {
+  if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
   std::vector<std::unique_ptr<DeviceBatch>> out;
-  for (int i = 0; i < n; i++) out.push_back(filter_batch(*in[i], &n_selected[i]));
+  auto per_record = [&]() {
+    out.clear();
+    for (int i = 0; i < n; i++) out.push_back(filter_batch_interp(*in[i], &n_selected[i]));
+    return std::move(out);
+  };
+  std::vector<int> live;
+  for (int i = 0; i < n; i++) {
+    if (in[i]->device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
+    if (in[i]->cols.size() > 128) throw Error(FDB_ERR_UNSUPPORTED, "filter output: more than 128 columns");
+    if (in[i]->rows > 0) live.push_back(i);
+  }
+  // one column layout for the whole launch (parts of one table); anything else takes the per-record path
+  bool multi = jit_possible() && !live.empty() && !in[live[0]]->cols.empty();
+  for (size_t k = 1; k < live.size() && multi; k++) {
+    const DeviceBatch& a = *in[live[0]];
+    const DeviceBatch& b = *in[live[k]];
+    multi = a.cols.size() == b.cols.size();
+    for (size_t c = 0; c < a.cols.size() && multi; c++) multi = a.cols[c].kind == b.cols[c].kind && a.cols[c].name == b.cols[c].name;
+  }
+  if (!multi) return per_record();
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  for (int i : live) in[i]->note_reader(stream_);
+  struct DrainOnUnwind {
+    hipStream_t s; int n = std::uncaught_exceptions();
+    ~DrainOnUnwind() { if (std::uncaught_exceptions() > n) (void)hipStreamSynchronize(s); }
+  };
+  for (int i = 0; i < n; i++) {
+    std::unique_ptr<DeviceBatch> o(new DeviceBatch());
+    o->device = device_;
+    for (const DevColumn& c : in[i]->cols) {
+      if (c.d_values == nullptr && in[i]->rows > 0)
+        throw Error(FDB_ERR_UNSUPPORTED, "filter output: column type " + c.format + " (" + c.name + ") is not supported on the device path");
+      DevColumn d;
+      d.name = c.name; d.format = c.format; d.kind = c.kind; d.dict = c.dict;
+      o->cols.push_back(std::move(d));
+    }
+    out.push_back(std::move(o));
+    n_selected[i] = 0;
+  }
+  DrainOnUnwind drain{stream_};  // (declared after `out`: an error waits for the queued kernels before the arenas go back to the pool)
+
+  // ---- predicate of every record: program + LUTs; records with byte-identical LUT sets share one device copy and one class ----
+  const size_t nl = live.size();
+  std::vector<Resolved> Rs(nl);
+  std::vector<int> lut_class(nl, 0);
+  std::vector<size_t> blob_base(nl, 0);
+  Blob blob;
+  {
+    std::vector<size_t> reps;
+    for (size_t k = 0; k < nl; k++) {
+      Resolved& R = Rs[k];
+      std::memset(&R.args, 0, sizeof(R.args));
+      R.args.n_rows = in[live[k]]->rows;
+      int max_depth = 0;
+      R.truths = &truth_cache_;
+      emit_filter(filter_, filter_root_, *in[live[k]], &R, 0, &max_depth);
+      size_t found = reps.size();
+      for (size_t r = 0; r < reps.size(); r++) {
+        const Resolved& Q = Rs[reps[r]];
+        if (Q.blob.bytes == R.blob.bytes && Q.luts.size() == R.luts.size()) { found = r; break; }
+      }
+      if (found < reps.size()) { lut_class[k] = (int)found; blob_base[k] = blob_base[reps[found]]; }
+      else { lut_class[k] = (int)reps.size(); blob_base[k] = blob.add(R.blob.bytes.data(), R.blob.bytes.size()); reps.push_back(k); }
+    }
+  }
+  struct StageScope {
+    Context* c;
+    explicit StageScope(Context* ctx) : c(ctx) { c->defer_staging(true); }
+    ~StageScope() { try { c->defer_staging(false); } catch (...) {} }
+  };
+  size_t lut_lds_max = 0;
+  JitShape shape;
+  int row_bytes = 0;
+  const FdbScanArgs* d_parts = nullptr;
+  const FdbCompactRec* d_recs = nullptr;
+  std::vector<FdbScanArgs> parts;
+  std::vector<FdbCompactRec> recs;
+  int64_t total_tiles = 0, total_super = 0;
+  {
+    StageScope stage_scope(ctx_);
+    unsigned char* d_blob = blob.bytes.empty() ? nullptr : (unsigned char*)upload(blob.bytes.data(), blob.bytes.size());
+    for (size_t k = 0; k < nl; k++) {
+      Resolved& R = Rs[k];
+      FdbScanArgs& a = R.args;
+      size_t lds_off = 0;
+      for (const PendingLut& p : R.luts) {
+        const bool in_lds = p.len_bytes <= 16384 && lds_off + p.len_bytes <= 32768;
+        uint32_t lds = FDB_NO_LDS;
+        if (in_lds) { lds = (uint32_t)lds_off; lds_off = align_up(lds_off + p.len_bytes, 16); }
+        a.leaves[p.index].lut = d_blob + blob_base[k] + p.blob_off;
+        a.leaves[p.index].lut_lds = lds;
+      }
+      lut_lds_max = std::max(lut_lds_max, align_up(lds_off, 16));
+      a.lut_class = lut_class[k];
+      // every filter column in the early pools (the flags kernel has no late phase)
+      if (assign_slots(*in[live[k]], R, 2, /*relaxed=*/true) == 0) return per_record();
+      const JitShape si = jit_shape(a, true, 512);
+      if (k == 0) shape = si;
+      else if (!jit_shape_merge(&shape, si)) return per_record();  // records of different predicate shapes (schema drift)
+      // the flags kernel counts in workgroup shares of four tiles (all of one record), the other kernels in tiles
+      const int64_t rec_tiles = (a.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
+      a.out_tile_base = total_tiles;
+      a.tile_begin = total_super;
+      total_super += (rec_tiles + 3) / 4;
+      a.tile_end = total_super;
+      recs.push_back(FdbCompactRec{total_tiles, a.n_rows});
+      total_tiles += rec_tiles;
+    }
+    for (size_t k = 0; k < nl; k++) { Rs[k].args.lds_lut_bytes = (uint32_t)lut_lds_max; parts.push_back(Rs[k].args); }
+    for (int k = 0; k < shape.n_c4; k++) row_bytes += shape.c4[k].has_values ? 4 : 0;
+    for (int k = 0; k < shape.n_c8; k++) row_bytes += shape.c8[k].has_values ? 8 : 0;
+    d_parts = (const FdbScanArgs*)upload(parts.data(), parts.size() * sizeof(FdbScanArgs));
+    d_recs = (const FdbCompactRec*)upload(recs.data(), recs.size() * sizeof(FdbCompactRec));
+  }
+  hipFunction_t flags_fn = jit_flags_get(shape);
+  if (flags_fn == nullptr) return per_record();
+
+  // ---- selection bitmap, counts, prefix sums ------------------------------------------------------------------------------
+  const int64_t n_blocks = (total_tiles + 1023) / 1024;
+  const size_t counts_bytes = align_up((size_t)n_blocks * 8 + (size_t)total_tiles * 4, 256);
+  unsigned char* d_counts = (unsigned char*)ctx_->dev_alloc(counts_bytes);
+  uint32_t* d_masks = (uint32_t*)ctx_->dev_alloc((size_t)total_tiles * (FDB_COMPACT_TILE / 8) + 256);
+  uint32_t* d_offsets = (uint32_t*)ctx_->dev_alloc((size_t)total_tiles * 4 + 256);
+  unsigned long long* d_rec_base = (unsigned long long*)ctx_->dev_alloc((nl + 1) * 8 + 64);
+  scratch_.push_back(d_counts); scratch_.push_back(d_masks); scratch_.push_back(d_offsets); scratch_.push_back(d_rec_base);
+  unsigned long long* d_block_sums = (unsigned long long*)d_counts;
+  uint32_t* d_tile_counts = (uint32_t*)(d_counts + (size_t)n_blocks * 8);
+  auto timed = [&](const std::function<void()>& f) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
+    f();
+    if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
+  };
+  int per_cu = 1;
+  {
+    // a wave keeps 4 steps × 64 lanes × 4 rows of every filter column in flight: ≈128 KB per CU (twice jit_select's figure: the
+    // waves also spend time on words, counts and stores)
+    int waves = row_bytes > 0 ? (131072 / (64 * 4 * 4)) / row_bytes : 8;
+    waves = std::max(8, std::min(28, waves));
+    per_cu = std::max(1, std::min(jit_blocks_per_cu(flags_fn, 256, lut_lds_max), waves / 4));
+    static const int env_per_cu = std::getenv("FDB_FLAGS_BLOCKS_PER_CU") ? std::atoi(std::getenv("FDB_FLAGS_BLOCKS_PER_CU")) : 0;  // (tuning aid)
+    if (env_per_cu > 0) per_cu = env_per_cu;
+  }
+  int64_t grid = (int64_t)(fdb_scan_default_grid(device_) / 2) * per_cu;
+  if (grid_override > 0) grid = grid_override;
+  if (grid > total_super) grid = total_super;
+  const bool two_level = n_blocks > 64;  // (below that every scan workgroup adds up the counts in front of its block itself)
+  timed([&] {
+    hip_check(jit_flags_launch(flags_fn, d_parts, (int)parts.size(), total_super, parts[0], (int)grid, lut_lds_max, d_masks, d_tile_counts, stream_), "flags launch");
+    if (two_level) hip_check(fdb_launch_sel_block_sums(d_tile_counts, total_tiles, d_block_sums, stream_), "block sums launch");
+    hip_check(fdb_launch_sel_scan(d_tile_counts, two_level ? d_block_sums : nullptr, total_tiles, d_offsets, d_recs, (int)nl, d_rec_base, stream_), "prefix sums launch");
+  });
+  unsigned long long* h_base = (unsigned long long*)ctx_->host_alloc((nl + 1) * 8);
+  struct HostFree { Context* c; void* p; ~HostFree() { c->host_free(p); } } hf{ctx_, h_base};
+  hip_check(hipMemcpyAsync(h_base, d_rec_base, (nl + 1) * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(row counts)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (first host round trip: outputs are allocated at their exact sizes)
+
+  // ---- outputs: [values of every column | validity bitmaps of every column] per record --------------------------------------
+  const size_t n_cols = in[live[0]]->cols.size();
+  std::vector<FdbCompactCol> cols(nl * n_cols);
+  std::vector<FdbZeroRegion> regions;
+  int64_t max_region = 0, any_selected = 0;
+  // a column is compacted as nullable if ANY record of the launch has a bitmap for it (the kernel is specialised per column, not
+  // per record); the records that have none read an all-ones bitmap
+  std::vector<char> nullable(n_cols, 0);
+  int64_t ones_rows = 0;
+  for (size_t k = 0; k < nl; k++)
+    for (size_t c = 0; c < n_cols; c++) if (in[live[k]]->cols[c].d_validity != nullptr) nullable[c] = 1;
+  for (size_t k = 0; k < nl; k++)
+    for (size_t c = 0; c < n_cols; c++) if (nullable[c] && in[live[k]]->cols[c].d_validity == nullptr) ones_rows = std::max(ones_rows, in[live[k]]->rows);
+  uint8_t* d_ones = nullptr;
+  if (ones_rows > 0) {
+    const size_t ones_bytes = align_up((size_t)(ones_rows + 7) / 8 + kTailPad, 256);
+    d_ones = (uint8_t*)ctx_->dev_alloc(ones_bytes);
+    scratch_.push_back(d_ones);
+    hip_check(hipMemsetAsync(d_ones, 0xFF, ones_bytes, stream_), "hipMemsetAsync(all-valid bitmap)");
+  }
+  for (size_t k = 0; k < nl; k++) {
+    const DeviceBatch& src = *in[live[k]];
+    DeviceBatch& o = *out[(size_t)live[k]];
+    const int64_t total = (int64_t)(h_base[k + 1] - h_base[k]);
+    if (total < 0 || total > src.rows) throw Error(FDB_ERR_DEVICE, "internal: selection counts out of range");
+    n_selected[live[k]] = total;
+    o.rows = total;
+    any_selected += total;
+    stat_bytes += Rs[k].bytes;
+    stat_rows += src.rows;
+    size_t bytes = 0, bits_at = 0;
+    std::vector<size_t> val_off(n_cols), bit_off(n_cols, 0);
+    for (size_t c = 0; c < n_cols; c++) {
+      val_off[c] = bytes;
+      bytes += align_up((size_t)total * (src.cols[c].kind == ColKind::DICT ? 4 : 8) + kTailPad, 256);
+    }
+    bits_at = bytes;
+    for (size_t c = 0; c < n_cols; c++)
+      if (nullable[c]) { bit_off[c] = bytes; bytes += align_up(((size_t)total + 7) / 8 + kTailPad, 256); }
+    if (total > 0) {
+      o.arena = device_pool_alloc(device_, std::max<size_t>(bytes, 256));
+      o.arena_bytes = std::max<size_t>(bytes, 256);
+      if (bytes > bits_at) { regions.push_back(FdbZeroRegion{(unsigned char*)o.arena + bits_at, (int64_t)(bytes - bits_at)}); max_region = std::max<int64_t>(max_region, (int64_t)(bytes - bits_at)); }
+    }
+    for (size_t c = 0; c < n_cols; c++) {
+      FdbCompactCol& C = cols[k * n_cols + c];
+      C.src = src.cols[c].d_values;
+      C.width = src.cols[c].kind == ColKind::DICT ? 4 : 8;
+      C.nullable = nullable[c];
+      C.src_valid = nullable[c] ? (src.cols[c].d_validity != nullptr ? src.cols[c].d_validity : d_ones) : nullptr;
+      C.dst = total > 0 ? (unsigned char*)o.arena + val_off[c] : nullptr;
+      C.dst_valid = total > 0 && nullable[c] ? (uint8_t*)o.arena + bit_off[c] : nullptr;
+    }
+  }
+  std::vector<unsigned long long> h_nulls(nl * n_cols * 64, 0);
+  if (any_selected > 0) {
+    unsigned long long* d_nulls = (unsigned long long*)ctx_->dev_alloc(h_nulls.size() * 8);
+    scratch_.push_back(d_nulls);
+    regions.push_back(FdbZeroRegion{d_nulls, (int64_t)(h_nulls.size() * 8)});
+    max_region = std::max<int64_t>(max_region, (int64_t)(h_nulls.size() * 8));
+    const FdbCompactCol* d_cols = (const FdbCompactCol*)upload(cols.data(), cols.size() * sizeof(FdbCompactCol));
+    const FdbZeroRegion* d_regions = (const FdbZeroRegion*)upload(regions.data(), regions.size() * sizeof(FdbZeroRegion));
+    // waves are dealt to the columns in proportion to their bytes per row (a wave stays on its column for the whole launch):
+    // as many workgroups of 4 waves as are resident at once, at least one wave per column, never more waves than a column has tiles
+    static const int env_per_cu = std::getenv("FDB_COMPACT_BLOCKS_PER_CU") ? std::atoi(std::getenv("FDB_COMPACT_BLOCKS_PER_CU")) : 0;  // (tuning aid)
+    const int64_t budget = (int64_t)(fdb_scan_default_grid(device_) / 2) * (env_per_cu > 0 ? env_per_cu : fdb_compact_multi_blocks_per_cu()) * 4;
+    int64_t weight_sum = 0;
+    for (size_t c = 0; c < n_cols; c++) weight_sum += cols[c].width;
+    std::vector<int32_t> wave_begin(n_cols + 1, 0);
+    for (size_t c = 0; c < n_cols; c++) {
+      int64_t share = std::max<int64_t>(1, budget * cols[c].width / std::max<int64_t>(weight_sum, 1));
+      share = std::min<int64_t>(share, total_tiles);
+      wave_begin[c + 1] = wave_begin[c] + (int32_t)share;
+    }
+    const int32_t* d_wave_begin = (const int32_t*)upload(wave_begin.data(), wave_begin.size() * 4);
+    timed([&] {
+      hip_check(fdb_launch_zero_regions(d_regions, (int)regions.size(), max_region, stream_), "zero launch");
+      hip_check(fdb_launch_compact_multi(d_recs, (int)nl, d_cols, (int)n_cols, d_wave_begin, wave_begin[n_cols], d_masks, d_offsets, d_rec_base, total_tiles, d_nulls, stream_),
+                "compact launch");
+    });
+    hip_check(hipMemcpyAsync(h_nulls.data(), d_nulls, h_nulls.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  }
+  last_kernel_ = "fdb_flags_kernel + compact_multi_kernel";
+  stat_launches += (any_selected > 0 ? 4 : 2) + (two_level ? 1 : 0);
+  for (size_t k = 0; k < nl; k++) {
+    const DeviceBatch& src = *in[live[k]];
+    DeviceBatch& o = *out[(size_t)live[k]];
+    const int64_t total = o.rows;
+    for (size_t c = 0; c < n_cols; c++) {
+      const FdbCompactCol& C = cols[k * n_cols + c];
+      DevColumn& d = o.cols[c];
+      d.length = total;
+      unsigned long long nulls = 0;
+      for (int q = 0; q < 64; q++) nulls += h_nulls[(k * n_cols + c) * 64 + (size_t)q];
+      d.null_count = (int64_t)nulls;
+      d.d_values = C.dst;
+      d.value_bytes = src.cols[c].kind == ColKind::BOOL ? (total + 7) / 8 : total * C.width;
+      if (C.dst_valid != nullptr && d.null_count > 0) { d.d_validity = C.dst_valid; d.validity_bytes = (total + 7) / 8; }
+      o.payload_bytes += d.value_bytes + d.validity_bytes;
+      // algorithmic bytes of the compaction: every selected value read once and written once, validity likewise
+      stat_bytes += 2 * (total * C.width) + (src.cols[c].d_validity != nullptr ? 2 * ((total + 7) / 8) : 0);
+    }
+  }
+  sync();
   return out;
 }
 

@@ -221,6 +221,7 @@ class Plan {
   // selection vector in a DEVICE buffer of `capacity` ≥ rows entries.
   std::unique_ptr<DeviceBatch> filter_batch(const DeviceBatch& in, int64_t* n_selected);
   // The same for every record of a scan at once: one launch sequence, two host round trips in total (sizes, NULL counts).
+  std::unique_ptr<DeviceBatch> filter_batch_interp(const DeviceBatch& in, int64_t* n_selected);
   std::vector<std::unique_ptr<DeviceBatch>> filter_batches(const DeviceBatch* const* in, int n, int64_t* n_selected);
   int64_t select_batch(const DeviceBatch& in, uint32_t* d_indices, int64_t capacity);
   const char* draw();                                                  // ≙ Draw
@@ -266,6 +267,7 @@ class Plan {
   const char* last_kernel() const { return last_kernel_; }
   bool use_partials = true;  // LDS mode: flush workgroup tables with plain stores + a fold kernel instead of atomics
   struct Resolved;  // per-batch kernel arguments (fdb_plan.cpp)
+  void sync();      // waits for the plan's stream; timing events are read, scratch and consumed records go back to their caches
 
  private:
   const char* last_kernel_ = "";  // name of the scan kernel of the latest push
@@ -279,7 +281,6 @@ class Plan {
   void resolve_filter_only(const DeviceBatch& b, Resolved* R);  // predicate program + LUTs (staged), nothing else
   int64_t run_flags(const FdbScanArgs& a, uint8_t** d_masks, uint32_t** d_offsets);  // selection bitmap + tile offsets; returns the number selected
   void ensure_layout(const std::vector<uint32_t>& new_caps);
-  void sync();
   void collect_timing();
   void fetch_state(std::vector<unsigned long long>* cnt, std::vector<std::vector<unsigned long long>>* acc);
   void fetch_compact(CompactState* cs);

@@ -1873,7 +1873,7 @@ def _oracle_filter(rec, filt):
 
 
 @pytest.mark.parametrize("n", [0, 1, 5, 1023, 1024, 1025, 4097, 65_537, 1_000_003])
-def test_resident_filter_compaction_matches_the_oracle(pp, n):
+def test_resident_filter_compaction_matches_the_oracle(pp, n, variant):
     """The compacted record of fdb_plan_filter_batch (every column type the path stages: dictionary, nullable dictionary, int64,
     float64 with NULLs, bool, plain string) against the oracle's filter() — values, NULLs and row ORDER — across tile edges."""
     rng = np.random.default_rng(n + 3)
@@ -1900,6 +1900,61 @@ def test_resident_filter_compaction_matches_the_oracle(pp, n):
     finally:
         plan.Close()
         rb.close()
+
+
+def test_filter_of_many_resident_records_in_one_launch_sequence_matches_the_oracle(pp, variant):
+    """fdb_plan_filter_batches: PredicateFilter.Callback for every record of a scan at once (flags kernel generated for the
+    predicate over all records, one prefix-sum launch, one compaction launch for every column of every record). Records of very
+    different sizes — empty, one row, exact tile multiples, tile edges ± 1, many tiles — with different dictionaries (a LUT class
+    per record), NULLs in every nullable column, a record in which nothing qualifies and one in which everything does: every
+    output must equal the oracle's filter() of its record — values, NULLs and row ORDER — and what the per-record entry point gives."""
+    rng = np.random.default_rng(41)
+    sizes = [70_001, 0, 1, 2048, 2047, 2049, 4096, 300_000, 5, 1_048_576 + 17]
+    recs = []
+    for k, n in enumerate(sizes):
+        rec = make_prometheus_batch(rng, n, n_path=40 + 13 * k, null_frac=0.02) if n else make_prometheus_batch(rng, 1, n_path=3).slice(0, 0)
+        fv = pa.array(rng.uniform(0, 1, n), mask=(rng.random(n) < 0.1) if n else None)
+        recs.append(rec.append_column("fnull", fv).append_column("flag", pa.array(rng.random(n) < 0.5)))
+    lo = recs[3].column("value").to_numpy()
+    recs[3] = recs[3].set_column(recs[3].schema.get_field_index("value"), "value", pa.array(np.zeros(len(lo))))          # nothing qualifies
+    recs[4] = recs[4].set_column(recs[4].schema.get_field_index("value"), "value", pa.array(np.full(2047, 999.0)))       # (value part) everything does
+    filt = And(Or(Col("labels.code") == "200", Col("labels.code") == "404", Col("labels.code") == None), Col("value") > 250.0)  # noqa: E711
+    plan = pp.HashAggregatePlan(filt)
+    rbs = [pp.ResidentBatch(r) for r in recs]
+    try:
+        outs = plan.FilterResidentMany(rbs)
+        assert len(outs) == len(recs)
+        kernel = plan.last_kernel()
+        assert ("fdb_flags_kernel" in kernel) == (variant == "specialised"), kernel
+        for rec, rb, out in zip(recs, rbs, outs):
+            want, idx = _oracle_filter(rec, filt)
+            got = out.to_arrow()
+            assert got.num_rows == out.num_rows == len(idx), (rec.num_rows, got.num_rows, len(idx))
+            assert got.schema.names == rec.schema.names
+            if len(idx):
+                g = arrow_to_pydict(got)
+                for name in rec.schema.names:
+                    assert g[name] == want[name], (rec.num_rows, name)
+            single = plan.FilterResident(rb)
+            assert single.to_arrow().equals(got)
+            single.close()
+        for o in outs:
+            o.close()
+        # records whose column sets differ (schema drift) still come back right: the launch falls back to one pass per record
+        odd = [recs[0], recs[7].drop_columns(["flag"])]
+        rb2 = [pp.ResidentBatch(r) for r in odd]
+        outs = plan.FilterResidentMany(rb2)
+        for rec, out in zip(odd, outs):
+            want, idx = _oracle_filter(rec, filt)
+            g = arrow_to_pydict(out.to_arrow())
+            assert out.num_rows == len(idx) and all(g[nm] == want[nm] for nm in rec.schema.names)
+            out.close()
+        for r in rb2:
+            r.close()
+    finally:
+        plan.Close()
+        for r in rbs:
+            r.close()
 
 
 def test_resident_selection_vector_and_capacity_retry(pp):

@@ -5,12 +5,28 @@
 //       -I frostdb_amd/csrc --cuda-device-only -Rpass-analysis=kernel-resource-usage -c /tmp/k.hip -o /tmp/k.o
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "frostdb_amd.h"
 #include "fdb_kernels.h"
 #include "fdb_jit.h"
 
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "flags") {
+    // the selection-bitmap kernel of filter(): `value > T AND labels.code == <one of a few>` (an 8-byte compare + a dictionary truth table)
+    fdb::JitShape s;
+    s.block = 512; s.two_phase = true; s.lds_acc = false;
+    s.n_c8 = 1; s.c8[0].has_values = true; s.c8[0].has_validity = 0;
+    s.n_c4 = 1; s.c4[0].has_values = true; s.c4[0].has_validity = 2;
+    fdb::JitLeaf a; a.kind = FDB_LEAF_CMP_F64; a.slot = 0; a.wide = 1; a.op = 5;
+    fdb::JitLeaf b; b.kind = FDB_LEAF_DICT_BITS; b.slot = 0; b.wide = 0;
+    fdb::JitLeaf c; c.kind = FDB_LEAF_DICT_LUT; c.slot = 0; c.wide = 0; c.lut_in_lds = true;
+    s.leaves = {a, b, c};
+    s.code = {0, 1, FDB_CODE_AND, 2, FDB_CODE_OR};
+    if (argc > 2) { s.n_c4 = 0; s.leaves = {a}; s.code = {0}; }  // `value > T` alone (bench.py's select line)
+    std::fputs(fdb::jit_flags_source(s).c_str(), stdout);
+    return 0;
+  }
   const int n = argc > 1 ? std::atoi(argv[1]) : 32;
   const int kinds = argc > 2 ? std::atoi(argv[2]) : 0;  // 1: make the last column an int64 key
   fdb::JitHashShape s;

@@ -1,0 +1,22 @@
+"""Tuning aid: times fdb_plan_filter_batches (value > 500 over 4 × 25 M resident rows) without checking results — for kernel
+variants that deliberately break them (FDB_COMPACT_BLOCKS_PER_CU). Prints kernel ms per pass (hipEvents) and wall ms."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from frostdb_amd import physicalplan as pp, synth
+from frostdb_amd.logicalplan import Col
+recs = [pp.ResidentBatch(synth.prometheus_chunk(0, i, 25_000_000, row_base=i * 25_000_000)) for i in range(4)]
+filt = Col("value") > 500.0
+def step(timing=False):
+    plan = pp.HashAggregatePlan(filt)
+    plan.set_timing(timing)
+    outs = plan.FilterResidentMany(recs)
+    st = plan.stats() if timing else None
+    plan.Close()
+    for o in outs: o.close()
+    return st
+step(); step()
+torch.cuda.synchronize(); t0 = time.perf_counter(); k = 0.0
+for _ in range(5): k += step(True)["kernel_ms"]
+torch.cuda.synchronize()
+print(os.environ.get("FDB_COMPACT_BLOCKS_PER_CU", "0"), "kernel_ms", round(k / 5, 4), "wall_ms", round((time.perf_counter() - t0) / 5 * 1e3, 4))
