@@ -341,8 +341,10 @@ class Workload:
         return {"groups_out": len(rows), "selected_rows": int(cnt.sum())}
 
 
-def run_workload(args, wl, steps, warmup, group, comm, total_rows):
-    """Correctness step, warm-up, then the timed region (barrier + device sync on both sides, max over ranks)."""
+def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_finish=False):
+    """Correctness step, warm-up, then the timed region (barrier + device sync on both sides, max over ranks).
+    `resident_finish`: the step ends with fdb_plan_finish_batch (the result record stays in HBM, for a consumer on the device)
+    instead of fdb_plan_finish (Arrow record on the host)."""
     import numpy as np
     from frostdb_amd import physicalplan as pp
     rank, device, world = wl.rank, wl.device, group.world
@@ -386,6 +388,11 @@ def run_workload(args, wl, steps, warmup, group, comm, total_rows):
                     shard.Close()
             else:
                 out = comm.merge(plan, dst=0)  # rank 0 gets the record, the others None
+        elif resident_finish:
+            rb = plan.FinishResident()
+            out = rb.to_arrow() if not timing and tuning is None and not step.checked else None  # (exported once, for the check)
+            step.checked = True
+            rb.close()
         else:
             out = plan.Finish()
         st = plan.stats() if timing else None
@@ -394,6 +401,7 @@ def run_workload(args, wl, steps, warmup, group, comm, total_rows):
         plan.Close()
         return out, st
 
+    step.checked = False
     # ---- the first step of this shape in this process: pays hiprtc (or the disk cache) for its kernels ----
     jit0 = pp.jit_stats()
     t_first = time.perf_counter()
@@ -696,6 +704,12 @@ def other_configs(args, wl, rank, device, group, comm):
             "ms_per_step": r2["elapsed"] / st * 1e3, "roofline": roofline_of(r2, 100_000_000, st, f"cfg{cfg}"),
             "checked": r2["checked"], "jit": jit_of(r2), "setup": {"gen_and_upload_s": w2.t_gen, "hbm_resident_bytes": w2.hbm_bytes},
         }
+        if cfg == 5:  # the same scan finished for a consumer on the device (fdb_plan_finish_batch): no Arrow record crosses PCIe
+            r3 = run_workload(args, w2, st, wu, group, comm, 100_000_000, resident_finish=True)
+            others["cfg5_resident_finish"] = {
+                "workload": "cfg5 with the result left in HBM (fdb_plan_finish_batch) for a device-side consumer",
+                "value": 100_000_000 * st / r3["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r3["elapsed"] / st * 1e3,
+                "roofline": roofline_of(r3, 100_000_000, st, "cfg5"), "checked": r3["checked"]}
         w2.release()
     if want("parquet"):
         others["parquet"] = measure_parquet(device)

@@ -263,6 +263,17 @@ int fdb_plan_filter_batch(fdb_plan* plan, const fdb_batch* batch, fdb_batch** ou
   });
 }
 
+int fdb_plan_finish_batch(fdb_plan* plan, fdb_batch** out, int64_t* n_rows) {
+  if (!plan) return FDB_ERR_INVALID;
+  return guard(plan, [&] {
+    if (out == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    single_table_only(plan);
+    std::unique_ptr<fdb::DeviceBatch> r = plan->plan.finish_batch(n_rows);
+    *out = new fdb_batch{std::move(r)};
+  });
+}
+
 int fdb_plan_filter_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n, fdb_batch** out, int64_t* n_selected) {
   if (!plan) return FDB_ERR_INVALID;
   return guard(plan, [&] {

@@ -381,7 +381,9 @@ int host_threads_for(size_t elements) {
 }
 }  // namespace
 
-int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
+// `resident` (fdb_plan_finish_batch): the result STAYS in HBM — the columns are written once, at the width a resident record uses
+// (uint32 indices), into an arena the batch owns; nothing crosses PCIe but the per-column NULL counts.
+int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resident) {
   hip_check(hipSetDevice(device_), "hipSetDevice");
   PhaseTimer pt;
   const uint64_t n = hash_groups();
@@ -398,7 +400,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   size_t n_narrow = 0, last_narrow = 0;
   for (size_t c = 0; c < n_cols; c++) {
     const GroupColState& g = gcols_[c];
-    width[c] = g.kind != 0 ? 8 : g.values.size() <= 256 ? 1 : g.values.size() <= 65536 ? 2 : 4;
+    width[c] = g.kind != 0 ? 8 : resident != nullptr ? 4 : g.values.size() <= 256 ? 1 : g.values.size() <= 65536 ? 2 : 4;
     narrow[c] = g.kind == 0 && width[c] < 4;
     if (narrow[c]) { n_narrow++; last_narrow = c; }
   }
@@ -413,15 +415,28 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
   const size_t direct_begin = total;
   for (size_t c = 0; c < n_cols; c++) if (!narrow[c]) off_key[c] = place(np * (size_t)width[c]);
   for (size_t c = 0; c < n_cols; c++) off_bits[c] = place(np / 8 + 64);
-  for (size_t v = 0; v < n_vals; v++) off_val[v] = place(np * 8);
+  for (size_t v = 1; v < n_vals; v++) off_val[v] = place(np * 8);
   const size_t off_nulls = place(std::max<size_t>(n_cols, 1) * 8);  // NULLs per group column, counted by the kernel
+  // the per-group row counts go LAST: they only cross PCIe when a COUNT aggregation reads them (cfg 5: 80 MB that nobody asked for)
+  bool counts_wanted = false;
+  for (const AggState& A : aggs_) if (A.func == FDB_AGG_COUNT && !final_stage_) counts_wanted = true;
+  const size_t direct_copy_bytes = (counts_wanted ? total + align_up_sz(np * 8, 256) : total) - direct_begin;
+  off_val[0] = place(np * 8);
   const size_t direct_bytes = total - direct_begin;
   size_t slice_stride = 0;
   for (size_t c = 0; c < n_cols; c++) if (narrow[c]) { off_narrow[c] = slice_stride; slice_stride += kSliceRows * (size_t)width[c]; }
   const size_t narrow_bytes = slice_stride * std::max<size_t>(n_slices, 1);
-  unsigned char* d_block = (unsigned char*)ctx_->dev_alloc(direct_bytes + narrow_bytes + 256);
+  unsigned char* d_block = nullptr;
+  std::vector<void*> owned;
+  if (resident != nullptr) {  // the batch owns the block (process-wide pool: it outlives this plan)
+    d_block = (unsigned char*)device_pool_alloc(device_, direct_bytes + 256);
+    resident->arena = d_block;
+    resident->arena_bytes = direct_bytes + 256;
+  } else {
+    d_block = (unsigned char*)ctx_->dev_alloc(direct_bytes + narrow_bytes + 256);
+    owned.push_back(d_block);
+  }
   unsigned char* d_narrow = d_block + direct_bytes;
-  std::vector<void*> owned{d_block};
   // (device scratch goes back to the context's cache when this function leaves, also by exception — after the Quiesce guard
   // below has waited for both queues)
   struct FreeOwned { Context* c; std::vector<void*>* v; ~FreeOwned() { for (void* p : *v) c->dev_free(p); } } free_owned{ctx_, &owned};
@@ -463,6 +478,66 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
     hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, h_entry_words_, d_bases, d_bases + n_chunks + 4, d_n, stream_), "hash chunk bases");
     hip_check(hipMemsetAsync(a.out_nulls, 0, std::max<size_t>(n_cols, 1) * 8, stream_), "hipMemsetAsync(null counts)");
     hip_check(fdb_launch_hash_gather_rows(a, device_, stream_), "hash gather rows");
+  }
+  if (resident != nullptr) {
+    // ---- resident result: one column pass over all rows, the NULL counts to the host, the batch's column table ----------------
+    struct Quiesce1 { hipStream_t a; ~Quiesce1() { (void)hipStreamSynchronize(a); } } q1{stream_};
+    std::vector<unsigned long long> h_nulls(std::max<size_t>(n_cols, 1), 0);
+    if (n > 0) {
+      a.row_begin = 0; a.row_end = n;
+      hip_check(fdb_launch_hash_rows_to_columns(a, device_, stream_), "hash rows to columns");
+      for (size_t j = 0; j < aggs_.size(); j++)  // float64 MIN / MAX live as order-preserving integer keys: back to doubles, in place
+        if (aggs_[j].type == FDB_T_F64 && (aggs_[j].func == FDB_AGG_MIN || aggs_[j].func == FDB_AGG_MAX))
+          hip_check(fdb_launch_ordered_to_f64(d_vals[1 + j], (int64_t)n, stream_), "decode float keys");
+      if (n_cols > 0) hip_check(hipMemcpyAsync(h_nulls.data(), a.out_nulls, n_cols * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
+    }
+    sync();
+    resident->device = device_;
+    resident->rows = (int64_t)n;
+    for (size_t c = 0; c < n_cols; c++) {
+      const GroupColState& g = gcols_[c];
+      DevColumn d;
+      d.name = g.name; d.length = (int64_t)n; d.null_count = (int64_t)h_nulls[c];
+      if (g.kind == 0) {
+        d.kind = ColKind::DICT; d.format = "I";
+        std::vector<std::string> vals;
+        for (const std::string_view& v : g.values) vals.emplace_back(v);
+        d.dict = make_dictionary(std::move(vals), g.value_format);
+        if (g.plain) {  // a plain string / binary key column: its distinct values, marked as such (not interned with real dictionaries)
+          std::shared_ptr<HostDict> pd(new HostDict(*d.dict));
+          pd->plain = true;
+          d.dict = pd;
+        }
+        d.value_bytes = (int64_t)n * 4;
+      } else {
+        d.kind = g.is_bool ? ColKind::BOOL : g.is_u64 ? ColKind::U64 : ColKind::I64;
+        d.format = g.is_bool ? "b" : g.is_u64 ? "L" : "l";
+        d.value_bytes = g.is_bool ? (int64_t)(n + 7) / 8 : (int64_t)n * 8;
+      }
+      if (n > 0) {
+        d.d_values = d_key[c];
+        if (d.null_count > 0) { d.d_validity = d_bits[c]; d.validity_bytes = (int64_t)(n + 7) / 8; }
+      }
+      resident->payload_bytes += d.value_bytes + d.validity_bytes;
+      resident->cols.push_back(std::move(d));
+    }
+    for (size_t j = 0; j < aggs_.size(); j++) {
+      const AggState& A = aggs_[j];
+      const bool count_from_cnt = A.func == FDB_AGG_COUNT && !final_stage_;
+      DevColumn d;
+      d.name = A.result_name; d.length = (int64_t)n;
+      const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
+      d.kind = is_f64 ? ColKind::F64 : ColKind::I64;
+      d.format = is_f64 ? "g" : "l";
+      if (n > 0) d.d_values = d_vals[count_from_cnt ? 0 : 1 + j];
+      d.value_bytes = (int64_t)n * 8;
+      resident->payload_bytes += d.value_bytes;
+      resident->cols.push_back(std::move(d));
+    }
+    finished_ = true;
+    return (int64_t)n;
+  }
+  if (n > 0) {
     h_block = (unsigned char*)pinned_pool_alloc(total);
     backing = std::shared_ptr<void>(h_block, [](void* p) { pinned_pool_free(p); });
     if (n_narrow > 0) h_narrow = (unsigned char*)pinned_pool_alloc(narrow_bytes);
@@ -517,7 +592,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out) {
       landed[sl] = ctx_->get_event();
       hip_check(hipEventRecord(landed[sl], copy_stream), "hipEventRecord");
     }
-    hip_check(hipMemcpyAsync(h_block + direct_begin, d_block, direct_bytes, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(result)");
+    hip_check(hipMemcpyAsync(h_block + direct_begin, d_block, direct_copy_bytes, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(result)");
     if (n_narrow > 0) {
       // one task = one narrow column of one slice
       std::vector<size_t> narrow_cols;

@@ -360,6 +360,8 @@ hipError_t fdb_launch_scan_slots(const FdbScanArgs* d_parts, int n_parts, const 
 int fdb_slot_geometry(int two_phase, int mode, int lds_acc, size_t lds_bytes, int device, int* tile_rows, int* blocks_per_cu);
 int fdb_slot_kernel_block(void);      // threads per workgroup of the slot kernel
 hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value, int64_t n, hipStream_t stream);
+// v[i] ← bits of the float64 whose order-preserving integer key (fdb_f64_to_ordered) v[i] holds, in place.
+hipError_t fdb_launch_ordered_to_f64(unsigned long long* v, int64_t n, hipStream_t stream);
 // base[a * n + i] = idents[a] for a < n_arrays (≤ 1 + FDB_MAX_AGGS), i < n: the whole partial table in one launch.
 hipError_t fdb_launch_fill_state(unsigned long long* base, int64_t n, int n_arrays, const unsigned long long* idents, hipStream_t stream);
 // dst[map[i]] (op)= src[i] for i < n; op: fdb_agg_func (SUM/COUNT add, MIN/MAX signed 64-bit, f64 SUM when is_f64).

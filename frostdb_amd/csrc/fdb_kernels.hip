@@ -2042,6 +2042,24 @@ hipError_t fdb_launch_stream_read(const void* src, int64_t bytes, unsigned long 
   return hipGetLastError();
 }
 
+namespace {
+// v[i] ← the double whose order-preserving integer key v[i] holds (the inverse of f64_to_ordered: the same involution)
+__global__ void ordered_to_f64_kernel(unsigned long long* v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long k = (long long)v[i];
+    v[i] = (unsigned long long)(k ^ ((k >> 63) & 0x7FFFFFFFFFFFFFFFLL));
+  }
+}
+}  // namespace
+
+hipError_t fdb_launch_ordered_to_f64(unsigned long long* v, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ordered_to_f64_kernel, dim3(blocks), dim3(256), 0, stream, v, n);
+  return hipGetLastError();
+}
+
 hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value, int64_t n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   int blocks = (int)((n + 255) / 256);

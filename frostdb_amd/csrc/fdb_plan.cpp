@@ -1685,6 +1685,33 @@ void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
   pt.mark("finish: export");
 }
 
+std::unique_ptr<DeviceBatch> Plan::finish_batch(int64_t* n_rows) {
+  if (aggs_.empty() && matchers_.empty()) throw Error(FDB_ERR_STATE, "filter-only plan: nothing to finish");
+  settle();
+  bool composite = false;
+  for (const AggState& A : aggs_) if (A.role != 0) composite = true;  // UNIQUE / AND are finished on the host (validity from two accumulators)
+  if (mode_ == TableMode::HASH && h_table_ != nullptr && !ordered_ && !composite) {
+    std::unique_ptr<DeviceBatch> b(new DeviceBatch());
+    const int64_t n = finish_columns_hash(nullptr, b.get());
+    if (n_rows) *n_rows = n;
+    return b;
+  }
+  // small (dense) tables, ordered output, composite reducers: the ordinary Finish, then the record is made resident
+  ArrowArray arr;
+  ArrowSchema sch;
+  std::memset(&arr, 0, sizeof(arr));
+  std::memset(&sch, 0, sizeof(sch));
+  int64_t n = 0;
+  finish(&arr, &sch, &n);
+  struct Rel { ArrowArray* a; ArrowSchema* s; ~Rel() { if (a->release) a->release(a); if (s->release) s->release(s); } } rel{&arr, &sch};
+  HostRecordView view;
+  view_record(&arr, &sch, &view);
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, nullptr, stream_);
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  if (n_rows) *n_rows = n;
+  return b;
+}
+
 int64_t Plan::num_groups() {
   CompactState cs;
   fetch_compact(&cs);

@@ -211,6 +211,9 @@ class Plan {
   void push_batch(const DeviceBatch& batch);
   void push_batches(const DeviceBatch* const* batches, int n);         // one fused launch over n resident records
   void finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows);  // ≙ Finish
+  // ≙ Finish for a consumer on the device: the result record as a resident batch (group columns as dictionary / int64 / bool columns,
+  // one column per aggregation). Big hash tables are materialised in HBM without crossing PCIe; small tables take the host route.
+  std::unique_ptr<DeviceBatch> finish_batch(int64_t* n_rows);
   // The result as column descriptors (group-key columns first — n_key_columns() of them — then one column per aggregation).
   int64_t finish_columns(std::vector<OutColumn>* cols);
   size_t n_key_columns() const { return gcols_.size(); }
@@ -293,7 +296,7 @@ class Plan {
   void hash_reserve(uint64_t extra_groups, uint64_t expected_groups = 0);  // capacity ≥ 2 × (max(groups, expected) + extra): grow + rehash on the device
   void push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live);
   void fetch_compact_hash(CompactState* cs);
-  int64_t finish_columns_hash(std::vector<OutColumn>* cols);  // device-side column materialisation (big result sets)
+  int64_t finish_columns_hash(std::vector<OutColumn>* cols, DeviceBatch* resident = nullptr);  // device-side column materialisation (big result sets)
   void merge_hash(Plan& src);
   uint64_t hash_groups();                               // occupied slots (reads the device counter; waits for the stream)
   void hash_insert_entries(const std::vector<unsigned long long>& entries, const std::vector<uint32_t>& keys, int64_t n, int in_kw,

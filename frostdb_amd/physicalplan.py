@@ -115,6 +115,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_exchange.argtypes = [vp, vp, P(vp)]
     L.fdb_live_allocations.argtypes = [P(i64), P(i64), P(i64)]
     L.fdb_plan_filter_batch.argtypes = [vp, vp, P(vp), P(i64)]
+    L.fdb_plan_finish_batch.argtypes = [vp, P(vp), P(i64)]
     L.fdb_plan_filter_batches.argtypes = [vp, P(vp), i32, P(vp), P(i64)]
     L.fdb_plan_select_batch.argtypes = [vp, vp, vp, i64, P(i64)]
     L.fdb_batch_export.argtypes = [vp, vp, vp]
@@ -335,6 +336,12 @@ class HashAggregatePlan:
             if self._next_finish is not None:
                 self._next_finish()
         return rec
+
+    def FinishResident(self) -> "ResidentBatch":
+        """≙ Finish for a device-side consumer (fdb_plan_finish_batch): the result record stays in HBM."""
+        out, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._check(lib().fdb_plan_finish_batch(self.handle, ctypes.byref(out), ctypes.byref(n)))
+        return ResidentBatch(None, device=self.device, _handle=out.value)
 
     def SetNext(self, callback: Callable[[pa.RecordBatch], None], finish: Optional[Callable[[], None]] = None) -> None:
         self._next, self._next_finish = callback, finish

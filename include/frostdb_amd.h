@@ -266,6 +266,13 @@ int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema
  * bitmap + per-tile counts, their prefix sums, and ONE streaming pass that compacts every column (wave prefix sums, LDS staging,
  * coalesced stores) — rows keep their order, the output is allocated at its exact size. */
 int fdb_plan_filter_batch(fdb_plan* plan, const fdb_batch* batch, fdb_batch** out, int64_t* n_selected);
+/* ≙ PhysicalPlan.Finish for a consumer that lives on the device (another device stage, the cross-GPU exchange): the result record
+ * as a RESIDENT batch — group columns (dictionary<uint32> with the plan's distinct values, int64 / uint64, bool) then one column per
+ * aggregation, same names and types as fdb_plan_finish. A big hash table (cfg 5: 10 M groups × 32 label columns) is materialised in
+ * HBM by the same two column passes and nothing crosses PCIe but the per-column NULL counts; small tables take the host route and
+ * are imported back (microseconds). Release with fdb_batch_release; fdb_batch_export gives the Arrow record on the host.
+ * Not for plans with aggregations over a dynamic column set. */
+int fdb_plan_finish_batch(fdb_plan* plan, fdb_batch** out, int64_t* n_rows);
 /* filter() over `n` resident records in ONE launch sequence (≙ PredicateFilter.Callback for every record of a scan, filter.go:255-323;
  * what fdb_plan_push_batches is to the aggregate): out[i] / n_selected[i] are record i's compacted record and row count. All or
  * nothing: on an error no output batch is returned. */

@@ -581,6 +581,61 @@ def test_hash_path_many_columns_vs_oracle(pp, variant):
         assert_same_result(got, want, cols, float_cols={"sum(floatvalue)"})
 
 
+def test_resident_finish_keeps_the_result_in_hbm_and_equals_finish(pp):
+    """fdb_plan_finish_batch (≙ Finish for a consumer on the device): a hash table with 12 label columns + an int64 key, COUNT /
+    SUM / MIN / MAX over int64 and float64 (float MIN / MAX are decoded from their ordered keys on the device) is materialised as a
+    resident batch — its export equals fdb_plan_finish of an identical plan row for row (as sets) and the oracle; the batch is then
+    the INPUT of a final-stage plan (a device-side consumer: no host copy in between); small dense tables and plans with UNIQUE
+    take the host route and come back resident too."""
+    rng = np.random.default_rng(77)
+    aggs = [Sum(Col("value")), Count(Col("value")), Min(Col("value")), Max(Col("floatvalue")), Sum(Col("floatvalue")), Min(Col("floatvalue"))]
+    groups = [DynCol("labels"), Col("bucket")]
+    batches = [many_label_batch(rng, 40_000, 12, 3, n_groups=5000, int_key=True), many_label_batch(rng, 25_000, 12, 3, n_groups=3000, int_key=True)]
+    cols = key_cols_of(batches, extra=("bucket",)) + [a.Name() for a in aggs]
+    fcols = {"sum(floatvalue)"}
+    want = run_oracle(batches, None, aggs, groups)
+
+    def scanned():
+        p = pp.HashAggregatePlan(None, aggs, groups)
+        keep = [pp.ResidentBatch(b) for b in batches]
+        p.CallbackResident(keep)
+        return p, keep
+
+    p1, k1 = scanned()
+    p2, k2 = scanned()
+    try:
+        rb = p1.FinishResident()
+        host = p2.Finish()
+        got = rb.to_arrow()
+        assert rb.num_rows == host.num_rows == len(want[cols[0]])
+        assert got.schema.names == host.schema.names
+        assert [str(f.type) for f in got.schema] == [str(f.type) for f in host.schema]
+        assert_same_result(arrow_to_pydict(got), arrow_to_pydict(host), cols, float_cols=fcols)
+        assert_same_result(arrow_to_pydict(got), want, cols, float_cols=fcols)
+        # the resident partial record feeds a final-stage chain on the device
+        fin = pp.HashAggregatePlan(None, aggs, groups, final_stage=True)
+        fin.Callback(rb)
+        assert_same_result(arrow_to_pydict(fin.Finish()), want, cols, float_cols=fcols)
+        fin.Close()
+        rb.close()
+    finally:
+        for p in (p1, p2):
+            p.Close()
+        for k in k1 + k2:
+            k.close()
+    # a small dense table, and a composite reducer: host route, resident result
+    from frostdb_amd.logicalplan import Unique
+    small = make_prometheus_batch(rng, 20_000, n_path=30)
+    for a2 in ([Sum(Col("value")), Count(Col("value"))], [Unique(Col("timestamp")), Sum(Col("value"))]):
+        p = pp.HashAggregatePlan(Col("labels.code") == "200", a2, [Col("labels.path")])
+        q = pp.HashAggregatePlan(Col("labels.code") == "200", a2, [Col("labels.path")])
+        p.Callback(small); q.Callback(small)
+        rb = p.FinishResident()
+        names = ["labels.path"] + [a.Name() for a in a2]
+        assert_same_result(arrow_to_pydict(rb.to_arrow()), arrow_to_pydict(q.Finish()), names, float_cols={"sum(value)"})
+        rb.close(); p.Close(); q.Close()
+
+
 def test_hash_path_growth_and_filter(pp, variant):
     """> 100 k distinct groups: the table grows (device re-hash) several times while batches arrive; a filter runs in
     front of the hash scan; string + int64 key columns together."""
