@@ -653,7 +653,9 @@ def measure_parquet(device, rows=20_000_000, passes=3):
 
         def once():
             plan = pp.HashAggregatePlan(*q, device=device)
-            keep = [pp.ResidentBatch.from_parquet(ch, n, device=device) for ch, n in groups]
+            # two row groups in flight: the host part of one (page headers, inflating) runs beside the device part of another
+            with ThreadPoolExecutor(max_workers=2) as ex:
+                keep = list(ex.map(lambda g: pp.ResidentBatch.from_parquet(g[0], g[1], device=device), groups))
             plan.CallbackResident(keep)
             res = plan.Finish()
             plan.Close()

@@ -445,7 +445,7 @@ hipError_t fdb_launch_pq_validity(const uint8_t* chunk, const FdbPqRun* def_runs
                                   hipStream_t stream);
 // out[r] = the value of row r (0 for NULL rows). rank(r) = prefix[r / 32] + popcount(validity word below r) (prefix = exclusive
 // scan of the counts); validity == nullptr: required column, rank(r) = r. kind 0: PLAIN 8-byte values (pages[]); kind 1: dictionary
-// indices through idx_runs[] (uint32 out).
+// indices through idx_runs[] (uint32 out); kind 2: BOOLEAN bits through idx_runs[] (int64 out: 1 false / 2 true, 0 for NULL rows).
 hipError_t fdb_launch_pq_decode(int kind, const uint8_t* chunk, const uint32_t* validity, const uint32_t* prefix, const FdbPqPlainPage* pages, int32_t n_pages,
                                 const FdbPqRun* idx_runs, int32_t n_idx_runs, int64_t n_rows, void* out, hipStream_t stream);
 

@@ -1362,7 +1362,8 @@ __global__ void pq_decode_kernel(const uint8_t* __restrict__ chunk, const uint32
     } else {
       uint32_t v = 0;
       if (valid) { const int ri = pq_find_run(idx_runs, n_idx_runs, rank); v = pq_run_value(chunk, idx_runs[ri], rank); }
-      reinterpret_cast<uint32_t*>(out)[r] = v;
+      if (KIND == 2) reinterpret_cast<unsigned long long*>(out)[r] = valid ? 1ull + (unsigned long long)(v & 1u) : 0ull;  // BOOLEAN → 1 (false) / 2 (true)
+      else reinterpret_cast<uint32_t*>(out)[r] = v;
     }
   }
 }
@@ -2103,6 +2104,7 @@ hipError_t fdb_launch_pq_decode(int kind, const uint8_t* chunk, const uint32_t* 
   int64_t blocks = (n_rows + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   if (kind == 0) hipLaunchKernelGGL(pq_decode_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, chunk, validity, prefix, pages, n_pages, idx_runs, n_idx_runs, n_rows, out);
+  else if (kind == 2) hipLaunchKernelGGL(pq_decode_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, chunk, validity, prefix, pages, n_pages, idx_runs, n_idx_runs, n_rows, out);
   else hipLaunchKernelGGL(pq_decode_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, chunk, validity, prefix, pages, n_pages, idx_runs, n_idx_runs, n_rows, out);
   return hipGetLastError();
 }

@@ -8,7 +8,10 @@
 // rank of every row, dictionary index / PLAIN value of every row — runs in fdb_kernels.hip (pq_* kernels). The result is a
 // DeviceBatch with exactly the layout import_batch produces, so every plan entry point takes it.
 //
-// First slice (what FrostDB's default layouts produce, dynparquet/schema.go:508-560): flat schemas; INT64 / DOUBLE columns with
+// Covered (what pqarrow/convert/convert.go:28-102 maps to Arrow — UTF8 / BYTE_ARRAY, Int(64) signed and unsigned, BOOLEAN, DOUBLE — in the
+// encodings and codecs a FrostDB schema can ask for, schema.proto:54-86): BOOLEAN PLAIN / RLE; INT64 PLAIN / DELTA_BINARY_PACKED; DOUBLE PLAIN;
+// BYTE_ARRAY dictionary-encoded, PLAIN, DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY; UNCOMPRESSED, SNAPPY, GZIP, BROTLI, ZSTD, LZ4(_RAW).
+// Repeated (list) columns are refused. First slice, as it was built (what FrostDB's default layouts produce, dynparquet/schema.go:508-560): flat schemas; INT64 / DOUBLE columns with
 // PLAIN data pages; BYTE_ARRAY columns with a PLAIN dictionary page + RLE_DICTIONARY data pages (→ dictionary<uint32, binary>,
 // pqarrow/convert/convert.go:64-70); required or optional (max definition level 1); data pages V1 and V2; INT64 also DELTA_BINARY_PACKED (the reference's default for struct-tag schemas, internal/records/record_builder.go:146-148); pages UNCOMPRESSED, or SNAPPY / GZIP / ZSTD / LZ4_RAW (inflated on the host while the page headers are walked).
 // Anything else (DELTA_* encodings, compressed pages, dictionary fallback to PLAIN, nested columns) is FDB_ERR_UNSUPPORTED.
@@ -19,6 +22,11 @@
 #include <atomic>
 #include <chrono>
 #include <exception>
+#include <memory>
+#include <mutex>
+#include <functional>
+#include <deque>
+#include <condition_variable>
 #include <system_error>
 #include <thread>
 #include <unordered_map>
@@ -101,7 +109,8 @@ struct Thrift {
 };
 
 enum { PQ_DATA_PAGE = 0, PQ_DICTIONARY_PAGE = 2, PQ_DATA_PAGE_V2 = 3 };
-enum { ENC_PLAIN = 0, ENC_PLAIN_DICTIONARY = 2, ENC_RLE = 3, ENC_DELTA_BINARY_PACKED = 5, ENC_RLE_DICTIONARY = 8 };
+enum { ENC_PLAIN = 0, ENC_PLAIN_DICTIONARY = 2, ENC_RLE = 3, ENC_DELTA_BINARY_PACKED = 5, ENC_DELTA_LENGTH_BYTE_ARRAY = 6, ENC_DELTA_BYTE_ARRAY = 7, ENC_RLE_DICTIONARY = 8 };
+enum { PT_BOOLEAN = 0, PT_INT64 = 2, PT_DOUBLE = 5, PT_BYTE_ARRAY = 6 };  // parquet.thrift Type
 
 struct PageHeader {
   int32_t type = -1, uncompressed = 0, compressed = 0;
@@ -200,7 +209,7 @@ void scan_runs(const uint8_t* chunk, size_t off, size_t len, int bw, int64_t n_v
 // ---- page decompression (host): the device decodes VALUES; inflating a page is a byte-serial job the host does while it walks
 // the page headers anyway. The decompressed pages of a chunk are laid end to end in one image that goes to HBM instead of the
 // file's bytes. Codec numbers are parquet.thrift's CompressionCodec.
-enum { CODEC_NONE = 0, CODEC_SNAPPY = 1, CODEC_GZIP = 2, CODEC_LZ4_HADOOP = 5, CODEC_ZSTD = 6, CODEC_LZ4_RAW = 7 };
+enum { CODEC_NONE = 0, CODEC_SNAPPY = 1, CODEC_GZIP = 2, CODEC_BROTLI = 4, CODEC_LZ4_HADOOP = 5, CODEC_ZSTD = 6, CODEC_LZ4_RAW = 7 };
 
 bool snappy_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {  // the Snappy block format (format_description.txt)
   size_t ip = 0, op = 0;
@@ -257,6 +266,12 @@ std::pair<zstd_fn, zstd_err_fn> zstd_decompress() {
   return f;
 }
 
+typedef int (*brotli_fn)(size_t, const uint8_t*, size_t*, uint8_t*);
+brotli_fn brotli_decompress() {
+  static brotli_fn f = [] { void* h = dlopen("libbrotlidec.so.1", RTLD_NOW | RTLD_LOCAL); return h ? (brotli_fn)dlsym(h, "BrotliDecoderDecompress") : (brotli_fn) nullptr; }();
+  return f;
+}
+
 // dst[0, cap) = the decompressed bytes of src[0, n); throws on a codec that is not available or on corrupt input.
 void inflate_page(int codec, const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
   if (cap == 0) return;
@@ -282,6 +297,13 @@ void inflate_page(int codec, const uint8_t* src, size_t n, uint8_t* dst, size_t 
       if (f.second(got) || got != cap) throw Error(FDB_ERR_INVALID, "parquet: corrupt ZSTD page");
       return;
     }
+    case CODEC_BROTLI: {
+      brotli_fn f = brotli_decompress();
+      if (f == nullptr) throw Error(FDB_ERR_UNSUPPORTED, "parquet: BROTLI pages need libbrotlidec.so.1 on this host");
+      size_t got = cap;
+      if (f(n, src, &got, dst) != 1 || got != cap) throw Error(FDB_ERR_INVALID, "parquet: corrupt BROTLI page");
+      return;
+    }
     case CODEC_LZ4_RAW: case CODEC_LZ4_HADOOP: {
       lz4_fn f = lz4_decompress();
       if (f == nullptr) throw Error(FDB_ERR_UNSUPPORTED, "parquet: LZ4 pages need liblz4.so.1 on this host");
@@ -299,7 +321,83 @@ void inflate_page(int codec, const uint8_t* src, size_t n, uint8_t* dst, size_t 
       return;
     }
     default:
-      throw Error(FDB_ERR_UNSUPPORTED, "parquet: compression codec " + std::to_string(codec) + " is not supported (UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4_RAW are)");
+      throw Error(FDB_ERR_UNSUPPORTED, "parquet: compression codec " + std::to_string(codec) + " is not supported (UNCOMPRESSED, SNAPPY, GZIP, BROTLI, ZSTD, LZ4_RAW are)");
+  }
+}
+
+// DELTA_BINARY_PACKED on the host (parquet-format Encodings.md): only the LENGTH streams of the DELTA byte-array encodings are
+// decoded here (one integer per value; the values of INT64 columns are unpacked and summed on the device). Reads `count` values
+// — the header's own total must say the same — and leaves `d.p` behind the last miniblock that holds one.
+std::vector<int64_t> delta_bp_host(Thrift& d, int64_t count) {
+  const uint64_t block = d.varint(), n_mini = d.varint(), total = d.varint();
+  uint64_t cur = (uint64_t)d.zigzag();
+  if (block == 0 || block % 128 != 0 || n_mini == 0 || block % n_mini != 0 || (block / n_mini) % 32 != 0 || block > (1u << 24))
+    throw Error(FDB_ERR_INVALID, "parquet: malformed DELTA_BINARY_PACKED header");
+  if ((int64_t)total != count) throw Error(FDB_ERR_INVALID, "parquet: DELTA_BINARY_PACKED value count differs from the page's");
+  std::vector<int64_t> out;
+  if (count == 0) return out;
+  out.reserve((size_t)count);
+  out.push_back((int64_t)cur);
+  const uint64_t vpm = block / n_mini;
+  uint64_t left = total - 1;
+  while (left > 0) {
+    const uint64_t min_delta = (uint64_t)d.zigzag();
+    d.need((size_t)n_mini);
+    const uint8_t* widths = d.p;
+    d.p += n_mini;
+    for (uint64_t m = 0; m < n_mini && left > 0; m++) {
+      const uint32_t w = widths[m];
+      if (w > 64) throw Error(FDB_ERR_INVALID, "parquet: DELTA_BINARY_PACKED bit width > 64");
+      const size_t bytes = (size_t)(vpm / 8) * w;
+      d.need(bytes);
+      const uint64_t take = std::min<uint64_t>(left, vpm);
+      for (uint64_t i = 0; i < take; i++) {
+        uint64_t v = 0;
+        if (w != 0) {
+          const uint64_t bit = i * w;
+          const uint8_t* q = d.p + (bit >> 3);
+          const uint32_t sh = (uint32_t)(bit & 7);
+          // (≤ 9 bytes hold the value; byte-wise so that nothing past the miniblock is read)
+          const size_t nb = (size_t)((sh + w + 7) / 8);
+          unsigned __int128 acc = 0;
+          for (size_t k = 0; k < nb; k++) acc |= (unsigned __int128)q[k] << (8 * k);
+          v = (uint64_t)(acc >> sh);
+          if (w < 64) v &= ((uint64_t)1 << w) - 1;
+        }
+        cur += min_delta + v;  // (wraps like the reference's decoder)
+        out.push_back((int64_t)cur);
+      }
+      d.p += bytes;
+      left -= take;
+    }
+  }
+  return out;
+}
+
+// The non-NULL values of a DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY page, one std::string each.
+// DELTA_LENGTH_BYTE_ARRAY: <lengths, DELTA_BINARY_PACKED> <all bytes back to back>.
+// DELTA_BYTE_ARRAY: <prefix lengths, DELTA_BINARY_PACKED> <suffixes, DELTA_LENGTH_BYTE_ARRAY>; value i = first prefix[i] bytes of value i − 1 + suffix i.
+void delta_byte_array_host(const uint8_t* p, size_t len, int64_t count, bool with_prefixes, std::vector<std::string>* out) {
+  Thrift d{p, p + len};
+  std::vector<int64_t> prefixes;
+  if (with_prefixes) prefixes = delta_bp_host(d, count);
+  const std::vector<int64_t> lengths = delta_bp_host(d, count);
+  out->clear();
+  out->reserve((size_t)count);
+  std::string prev;
+  for (int64_t i = 0; i < count; i++) {
+    const int64_t l = lengths[(size_t)i];
+    if (l < 0 || (size_t)l > (size_t)(d.end - d.p)) throw Error(FDB_ERR_INVALID, "parquet: DELTA byte-array page truncated");
+    std::string v;
+    if (with_prefixes) {
+      const int64_t pl = prefixes[(size_t)i];
+      if (pl < 0 || (size_t)pl > prev.size()) throw Error(FDB_ERR_INVALID, "parquet: DELTA_BYTE_ARRAY prefix longer than the previous value");
+      v.assign(prev, 0, (size_t)pl);
+    }
+    v.append((const char*)d.p, (size_t)l);
+    d.p += l;
+    if (with_prefixes) prev = v;
+    out->push_back(std::move(v));
   }
 }
 
@@ -341,83 +439,92 @@ struct ParsedChunk {
   uint32_t max_index_bits = 0;
 };
 
-ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
+// A page whose body has to be inflated into the chunk's image: `at` is fixed by the first walk over the page headers, so the pages
+// of every chunk of a row group can be inflated side by side (they are independent) before anything is parsed.
+struct InflateJob { int codec; const uint8_t* raw; size_t comp, prefix, body_len; uint8_t* dst; };
+
+// First walk over a chunk's page headers: validates the page chain, decides whether the chunk needs an image — compressed pages, or
+// BYTE_ARRAY data pages that are not dictionary-encoded (their values are dictionary-encoded HERE, one hash probe per value like the
+// reference's own BinaryDictionaryBuilder.Append, pqarrow/writer/writer.go:391-405, and the indices are appended to the image as a
+// 32-bit-wide bit-packed run, which is all the device needs) — sizes it, and lists the inflate jobs of its data pages.
+void plan_chunk(const fdb_parquet_chunk& c, int64_t n_rows, ParsedChunk* out, std::vector<InflateJob>* jobs) {
   if (c.data == nullptr || c.n_bytes <= 0) throw Error(FDB_ERR_INVALID, std::string("parquet: empty column chunk for ") + (c.name ? c.name : "?"));
   if (c.optional != 0 && c.optional != 1) throw Error(FDB_ERR_UNSUPPORTED, "parquet: nested / repeated columns are not supported (max definition level > 1)");
-  const bool is_bytes = c.physical_type == 6, is_fixed8 = c.physical_type == 2 || c.physical_type == 5;
-  if (!is_bytes && !is_fixed8) throw Error(FDB_ERR_UNSUPPORTED, "parquet: only INT64, DOUBLE and BYTE_ARRAY columns are decoded on the device");
-  ParsedChunk out;
-  // First walk over the page headers: is an image needed — compressed pages, or BYTE_ARRAY data pages that are PLAIN (a writer's
-  // dictionary fallback: their values are dictionary-encoded HERE, one hash probe per value like the reference's own
-  // BinaryDictionaryBuilder.Append (pqarrow/writer/writer.go:391-405), and the indices are appended to the image as a 32-bit-wide
-  // bit-packed run, which is all the device needs) — and how big is it.
+  const bool is_bytes = c.physical_type == PT_BYTE_ARRAY, is_fixed8 = c.physical_type == PT_INT64 || c.physical_type == PT_DOUBLE, is_bool = c.physical_type == PT_BOOLEAN;
+  if (!is_bytes && !is_fixed8 && !is_bool)
+    throw Error(FDB_ERR_UNSUPPORTED, "parquet: only BOOLEAN, INT64, DOUBLE and BYTE_ARRAY columns are decoded (what pqarrow/convert/convert.go maps to Arrow)");
   bool use_image = c.codec != CODEC_NONE;
-  {
-    Thrift w{c.data, c.data + c.n_bytes};
-    size_t need = 0;
-    int64_t values = 0;
-    bool plain_bytes = false;
-    while (w.p < w.end && values < n_rows) {
-      const PageHeader h = read_page_header(w);
-      if (h.compressed < 0 || h.uncompressed < 0 || (size_t)(w.end - w.p) < (size_t)h.compressed) throw Error(FDB_ERR_INVALID, "parquet: page runs past the end of the column chunk");
-      w.p += (size_t)h.compressed;
-      if (h.type == PQ_DATA_PAGE || h.type == PQ_DATA_PAGE_V2) {
-        // (a damaged header must not size the image: no page holds more values than the row group has rows)
-        if (h.num_values < 0 || values + h.num_values > n_rows) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
-        need += (size_t)h.uncompressed + 8;
-        values += h.num_values;
-        if (is_bytes && h.encoding == ENC_PLAIN) { plain_bytes = true; need += (size_t)std::max(h.num_values, 0) * 4 + 16; }
-      }
-    }
-    use_image = use_image || plain_bytes;
-    if (use_image) out.image.allocate(need + 64);
+  Thrift w{c.data, c.data + c.n_bytes};
+  size_t need = 0, extra = 0;
+  int64_t values = 0;
+  struct Pg { const uint8_t* raw; size_t comp, prefix, body_len; bool packed; };
+  std::vector<Pg> pages;
+  while (w.p < w.end && values < n_rows) {
+    const PageHeader h = read_page_header(w);
+    if (h.compressed < 0 || h.uncompressed < 0 || (size_t)(w.end - w.p) < (size_t)h.compressed) throw Error(FDB_ERR_INVALID, "parquet: page runs past the end of the column chunk");
+    const uint8_t* raw = w.p;
+    w.p += (size_t)h.compressed;
+    if (h.type != PQ_DATA_PAGE && h.type != PQ_DATA_PAGE_V2) continue;
+    // (a damaged header must not size the image: no page holds more values than the row group has rows)
+    if (h.num_values < 0 || values + h.num_values > n_rows) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
+    values += h.num_values;
+    const size_t prefix = h.type == PQ_DATA_PAGE_V2 ? (size_t)h.v2_def_bytes + (size_t)h.v2_rep_bytes : 0;
+    if (prefix > (size_t)h.compressed || prefix > (size_t)h.uncompressed) throw Error(FDB_ERR_INVALID, "parquet: levels run past the page");
+    pages.push_back(Pg{raw, (size_t)h.compressed, prefix, (size_t)h.uncompressed, c.codec != CODEC_NONE && (h.type != PQ_DATA_PAGE_V2 || h.v2_compressed)});
+    need += (size_t)h.uncompressed + 8;  // (+8: keeps every 64-bit window of the device's readers inside the image)
+    if (is_bytes && h.encoding != ENC_RLE_DICTIONARY && h.encoding != ENC_PLAIN_DICTIONARY) { use_image = true; extra += (size_t)h.num_values * 4 + 16; }
   }
-  std::vector<std::string> dict_values;                    // the chunk's dictionary: its dictionary page, then values of PLAIN pages
-  std::unordered_map<std::string, uint32_t> dict_lookup;   // built when the first PLAIN page arrives
+  if (!use_image) return;
+  out->image.allocate(need + extra + 64);
+  size_t at = 0;
+  for (const Pg& g : pages) {
+    uint8_t* dst = out->image.p + at;
+    std::memcpy(dst, g.raw, g.prefix);  // a V2 page keeps its levels uncompressed in front of the (possibly) compressed values
+    if (g.packed) jobs->push_back(InflateJob{c.codec, g.raw, g.comp, g.prefix, g.body_len, dst});
+    else {
+      if (g.comp != g.body_len) throw Error(FDB_ERR_INVALID, "parquet: uncompressed page with differing sizes");
+      std::memcpy(dst + g.prefix, g.raw + g.prefix, g.body_len - g.prefix);
+    }
+    at += g.body_len + 8;
+  }
+  out->image.used = at;
+}
+
+inline void run_inflate(const InflateJob& j) { inflate_page(j.codec, j.raw + j.prefix, j.comp - j.prefix, j.dst + j.prefix, j.body_len - j.prefix); }
+
+// Second walk: page by page — bodies in place (uncompressed chunks) or in the image, where plan_chunk / the inflate jobs put them.
+void parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows, ParsedChunk* outp) {
+  ParsedChunk& out = *outp;
+  const bool is_bytes = c.physical_type == PT_BYTE_ARRAY, is_fixed8 = c.physical_type == PT_INT64 || c.physical_type == PT_DOUBLE, is_bool = c.physical_type == PT_BOOLEAN;
+  const bool use_image = out.image.p != nullptr;
+  std::vector<std::string> dict_values;                    // the chunk's dictionary: its dictionary page, then values of pages without dictionary indices
+  std::unordered_map<std::string, uint32_t> dict_lookup;   // built when the first such page arrives
   bool lookup_ready = false;
-  const uint8_t* base = c.data;  // what run / page offsets are relative to: the chunk's bytes, or the image of its decompressed pages
+  const uint8_t* base = use_image ? out.image.data() : c.data;  // what run / page offsets are relative to
   Thrift t{c.data, c.data + c.n_bytes};
   int64_t rows_done = 0, rank_done = 0;
+  size_t image_at = 0;  // next data page's place in the image
   bool have_dict = false;
+  std::vector<std::string> page_values;
   while (t.p < t.end && rows_done < n_rows) {
     const PageHeader h = read_page_header(t);
     if (h.compressed < 0 || h.uncompressed < 0 || (size_t)(t.end - t.p) < (size_t)h.compressed) throw Error(FDB_ERR_INVALID, "parquet: page runs past the end of the column chunk");
     if (c.codec == CODEC_NONE && h.compressed != h.uncompressed) throw Error(FDB_ERR_INVALID, "parquet: page sizes disagree in an UNCOMPRESSED chunk");
     const uint8_t* raw = t.p;  // the page's bytes in the file
     t.p += (size_t)h.compressed;
-    // `body` = the page's UNCOMPRESSED bytes: in place for an uncompressed chunk, else appended to the image. A V2 page keeps its
-    // levels uncompressed in front of the (possibly) compressed values.
-    std::vector<uint8_t> dict_tmp;
-    const uint8_t* body = raw;
-    size_t body_off = (size_t)(raw - c.data), body_len = (size_t)h.compressed;
-    if (use_image) {
-      body_len = (size_t)h.uncompressed;
-      const size_t plain_prefix = h.type == PQ_DATA_PAGE_V2 ? (size_t)h.v2_def_bytes + (size_t)h.v2_rep_bytes : 0;
-      if (plain_prefix > (size_t)h.compressed || plain_prefix > body_len) throw Error(FDB_ERR_INVALID, "parquet: levels run past the page");
-      const bool packed = c.codec != CODEC_NONE && (h.type != PQ_DATA_PAGE_V2 || h.v2_compressed);
-      uint8_t* dst;
-      size_t at = 0;
-      if (h.type == PQ_DICTIONARY_PAGE) { dict_tmp.resize(body_len + 8); dst = dict_tmp.data(); }
-      else {
-        // (+8: the next page starts 8 bytes on; keeps every 64-bit window inside the image). Pages that are neither dictionary nor
-        // data pages were not counted by the first walk and are not needed: skipped
-        if (h.type != PQ_DATA_PAGE && h.type != PQ_DATA_PAGE_V2) continue;
-        at = out.image.used;
-        if (at + body_len + 8 > out.image.cap) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
-        out.image.used = at + body_len + 8;
-        dst = out.image.p + at;
-      }
-      std::memcpy(dst, raw, plain_prefix);
-      if (packed) inflate_page(c.codec, raw + plain_prefix, (size_t)h.compressed - plain_prefix, dst + plain_prefix, body_len - plain_prefix);
-      else { if ((size_t)h.compressed != body_len) throw Error(FDB_ERR_INVALID, "parquet: uncompressed V2 page with differing sizes"); std::memcpy(dst + plain_prefix, raw + plain_prefix, body_len - plain_prefix); }
-      body = dst;
-      body_off = at;
-    }
-    base = use_image ? out.image.data() : c.data;
     if (h.type == PQ_DICTIONARY_PAGE) {
       if (!is_bytes) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary-encoded numeric columns are not supported on the device path");
       if (h.encoding != ENC_PLAIN && h.encoding != ENC_PLAIN_DICTIONARY) throw Error(FDB_ERR_UNSUPPORTED, "parquet: dictionary page encoding");
       if (have_dict) throw Error(FDB_ERR_INVALID, "parquet: two dictionary pages in one column chunk");
+      std::vector<uint8_t> dict_tmp;
+      const uint8_t* body = raw;
+      size_t body_len = (size_t)h.compressed;
+      if (c.codec != CODEC_NONE) {  // (small: inflated here)
+        body_len = (size_t)h.uncompressed;
+        dict_tmp.resize(body_len + 8);
+        inflate_page(c.codec, raw, (size_t)h.compressed, dict_tmp.data(), body_len);
+        body = dict_tmp.data();
+      }
       if (h.num_values < 0 || (size_t)h.num_values > body_len / 4) throw Error(FDB_ERR_INVALID, "parquet: dictionary page truncated");  // (every value has a 4-byte length)
       dict_values.reserve((size_t)h.num_values);
       size_t o = 0;
@@ -432,6 +539,12 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
     }
     if (h.type != PQ_DATA_PAGE && h.type != PQ_DATA_PAGE_V2) continue;  // (index pages etc.)
     if (h.num_values < 0 || rows_done + h.num_values > n_rows) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
+    size_t body_off = (size_t)(raw - c.data), body_len = (size_t)h.compressed;
+    if (use_image) {
+      body_off = image_at; body_len = (size_t)h.uncompressed;
+      image_at += body_len + 8;
+      if (image_at > out.image.cap) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
+    }
     size_t voff = body_off, vlen = body_len;  // the values part of the page
     int64_t page_non_null = h.num_values;
     if (h.type == PQ_DATA_PAGE_V2) {
@@ -451,8 +564,19 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
       scan_runs(base, voff + 4, dl, 1, h.num_values, rows_done, &out.def_runs, &page_non_null);
       voff += 4 + dl; vlen -= 4 + dl;
     }
-    if (is_fixed8) {
-      if (h.encoding == ENC_DELTA_BINARY_PACKED && c.physical_type == 2) {
+    if (is_bool) {
+      // PLAIN: one bit per value, LSB first; RLE (data page V2): <4-byte length> + the RLE / bit-packed hybrid at bit width 1
+      if (h.encoding == ENC_PLAIN) {
+        if ((size_t)(page_non_null + 7) / 8 > vlen) throw Error(FDB_ERR_INVALID, "parquet: PLAIN BOOLEAN page shorter than its values");
+        if (page_non_null > 0) out.idx_runs.push_back(FdbPqRun{rank_done, (uint64_t)voff * 8u, 1u, 1u});
+      } else if (h.encoding == ENC_RLE) {
+        if (vlen < 4) throw Error(FDB_ERR_INVALID, "parquet: RLE BOOLEAN page without its length");
+        uint32_t rl; std::memcpy(&rl, base + voff, 4);
+        if ((size_t)rl + 4 > vlen) throw Error(FDB_ERR_INVALID, "parquet: RLE BOOLEAN values run past the page");
+        if (page_non_null > 0) scan_runs(base, voff + 4, rl, 1, page_non_null, rank_done, &out.idx_runs, nullptr);
+      } else throw Error(FDB_ERR_UNSUPPORTED, "parquet: BOOLEAN pages must be PLAIN or RLE");
+    } else if (is_fixed8) {
+      if (h.encoding == ENC_DELTA_BINARY_PACKED && c.physical_type == PT_INT64) {
         // <block size> <miniblocks per block> <total value count> <first value> then per block <min delta> <bit widths> <miniblocks>
         // (parquet-format Encodings.md): only the headers are read here, the deltas are unpacked and summed on the device
         if (!out.plain_pages.empty()) throw Error(FDB_ERR_UNSUPPORTED, "parquet: PLAIN and DELTA_BINARY_PACKED pages in one column chunk");
@@ -490,40 +614,7 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
         if ((size_t)page_non_null * 8 > vlen) throw Error(FDB_ERR_INVALID, "parquet: PLAIN page shorter than its values");
         out.plain_pages.push_back(FdbPqPlainPage{rank_done, (int64_t)voff});
       }
-    } else {
-      if (h.encoding == ENC_PLAIN) {
-        // dictionary fallback: <length><bytes> per non-NULL value → index into the chunk's (growing) dictionary
-        if (!lookup_ready) {
-          dict_lookup.reserve(dict_values.size() * 2 + 1024);
-          for (size_t i = 0; i < dict_values.size(); i++) dict_lookup.emplace(dict_values[i], (uint32_t)i);
-          lookup_ready = true;
-        }
-        size_t at = (out.image.used + 3) & ~(size_t)3;
-        if (at + (size_t)page_non_null * 4 + 8 > out.image.cap) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
-        uint32_t* idx = reinterpret_cast<uint32_t*>(out.image.p + at);
-        size_t o = voff;
-        const size_t end = voff + vlen;
-        for (int64_t i = 0; i < page_non_null; i++) {
-          if (o + 4 > end) throw Error(FDB_ERR_INVALID, "parquet: PLAIN BYTE_ARRAY page truncated");
-          uint32_t len; std::memcpy(&len, base + o, 4); o += 4;
-          if ((size_t)len > end - o) throw Error(FDB_ERR_INVALID, "parquet: PLAIN BYTE_ARRAY page truncated");
-          std::string v((const char*)base + o, len); o += len;
-          auto it = dict_lookup.find(v);
-          if (it == dict_lookup.end()) {
-            if (dict_values.size() >= 0xFFFFFFF0u) throw Error(FDB_ERR_UNSUPPORTED, "parquet: more than 2^32 distinct values in a column chunk");
-            it = dict_lookup.emplace(v, (uint32_t)dict_values.size()).first;
-            dict_values.push_back(std::move(v));
-          }
-          idx[i] = it->second;
-        }
-        out.image.used = at + (size_t)page_non_null * 4 + 8;
-        if (page_non_null > 0) { out.idx_runs.push_back(FdbPqRun{rank_done, (uint64_t)at * 8u, 32u, 1u}); out.max_index_bits = 32; }
-        rows_done += h.num_values;
-        rank_done += page_non_null;
-        continue;
-      }
-      if (h.encoding != ENC_RLE_DICTIONARY && h.encoding != ENC_PLAIN_DICTIONARY)
-        throw Error(FDB_ERR_UNSUPPORTED, "parquet: BYTE_ARRAY pages must be PLAIN, PLAIN_DICTIONARY or RLE_DICTIONARY (DELTA byte-array encodings are not decoded)");
+    } else if (h.encoding == ENC_RLE_DICTIONARY || h.encoding == ENC_PLAIN_DICTIONARY) {
       if (!have_dict) throw Error(FDB_ERR_INVALID, "parquet: dictionary-encoded page without a dictionary page");
       if (page_non_null > 0) {
         if (vlen < 1) throw Error(FDB_ERR_INVALID, "parquet: dictionary-index page without a bit width");
@@ -533,6 +624,44 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
         if (bw == 0) out.idx_runs.push_back(FdbPqRun{rank_done, 0ull, 0u, 0u});  // every index is 0
         else scan_runs(base, voff + 1, vlen - 1, bw, page_non_null, rank_done, &out.idx_runs, nullptr);
       }
+    } else if (h.encoding == ENC_PLAIN || h.encoding == ENC_DELTA_LENGTH_BYTE_ARRAY || h.encoding == ENC_DELTA_BYTE_ARRAY) {
+      // values without dictionary indices — a writer without dictionaries, its dictionary fallback half way through a chunk, or
+      // the DELTA byte-array encodings a FrostDB schema may ask for (schema.proto:62-65): every non-NULL value → an index into
+      // the chunk's (growing) dictionary, the indices to the device as one 32-bit-wide bit-packed run
+      if (!lookup_ready) {
+        dict_lookup.reserve(dict_values.size() * 2 + 1024);
+        for (size_t i = 0; i < dict_values.size(); i++) dict_lookup.emplace(dict_values[i], (uint32_t)i);
+        lookup_ready = true;
+      }
+      const size_t at = (out.image.used + 3) & ~(size_t)3;
+      if (!use_image || at + (size_t)page_non_null * 4 + 8 > out.image.cap) throw Error(FDB_ERR_INVALID, "parquet: pages hold more values than the row group has rows");
+      uint32_t* idx = reinterpret_cast<uint32_t*>(out.image.p + at);
+      auto intern = [&](std::string&& v) -> uint32_t {
+        auto it = dict_lookup.find(v);
+        if (it == dict_lookup.end()) {
+          if (dict_values.size() >= 0xFFFFFFF0u) throw Error(FDB_ERR_UNSUPPORTED, "parquet: more than 2^32 distinct values in a column chunk");
+          it = dict_lookup.emplace(v, (uint32_t)dict_values.size()).first;
+          dict_values.push_back(std::move(v));
+        }
+        return it->second;
+      };
+      if (h.encoding == ENC_PLAIN) {  // <length><bytes> per value
+        size_t o = voff;
+        const size_t end = voff + vlen;
+        for (int64_t i = 0; i < page_non_null; i++) {
+          if (o + 4 > end) throw Error(FDB_ERR_INVALID, "parquet: PLAIN BYTE_ARRAY page truncated");
+          uint32_t len; std::memcpy(&len, base + o, 4); o += 4;
+          if ((size_t)len > end - o) throw Error(FDB_ERR_INVALID, "parquet: PLAIN BYTE_ARRAY page truncated");
+          idx[i] = intern(std::string((const char*)base + o, len)); o += len;
+        }
+      } else {
+        delta_byte_array_host(base + voff, vlen, page_non_null, h.encoding == ENC_DELTA_BYTE_ARRAY, &page_values);
+        for (int64_t i = 0; i < page_non_null; i++) idx[i] = intern(std::move(page_values[(size_t)i]));
+      }
+      out.image.used = at + (size_t)page_non_null * 4 + 8;
+      if (page_non_null > 0) { out.idx_runs.push_back(FdbPqRun{rank_done, (uint64_t)at * 8u, 32u, 1u}); out.max_index_bits = 32; }
+    } else {
+      throw Error(FDB_ERR_UNSUPPORTED, "parquet: BYTE_ARRAY pages must be PLAIN, (PLAIN_ / RLE_)DICTIONARY, DELTA_LENGTH_BYTE_ARRAY or DELTA_BYTE_ARRAY");
     }
     rows_done += h.num_values;
     rank_done += page_non_null;
@@ -541,8 +670,76 @@ ParsedChunk parse_chunk(const fdb_parquet_chunk& c, int64_t n_rows) {
   out.non_null = rank_done;
   if (is_bytes && rank_done > 0 && dict_values.empty()) throw Error(FDB_ERR_INVALID, std::string("parquet: column chunk ") + (c.name ? c.name : "?") + " has values but an empty dictionary");
   if (is_bytes) out.dict = make_dictionary(std::move(dict_values), c.utf8 ? "u" : "z");
-  return out;
 }
+
+// A small process-wide pool of host threads for the per-page / per-chunk work of a row group. Threads are created once: spawning
+// sixty threads per call cost more (≈1.3 ms) than inflating the pages they were spawned for.
+class HostPool {
+ public:
+  static HostPool& get() { static HostPool p; return p; }
+  size_t size() const { return workers_.size(); }
+  // fn(i) for i < n on the pool's threads and the calling one; the first exception in index order is rethrown.
+  template <typename F>
+  void parallel_for(size_t n, F&& fn) {
+    if (n == 0) return;
+    struct Job {
+      std::function<void(size_t)> fn;
+      size_t n;
+      std::atomic<size_t> next{0}, done{0};
+      std::vector<std::exception_ptr> errs;
+    };
+    auto job = std::make_shared<Job>();
+    job->fn = std::forward<F>(fn); job->n = n; job->errs.resize(n);
+    auto drain = [](const std::shared_ptr<Job>& j) {
+      for (;;) {
+        const size_t i = j->next.fetch_add(1);
+        if (i >= j->n) return;
+        try { j->fn(i); } catch (...) { j->errs[i] = std::current_exception(); }
+        j->done.fetch_add(1, std::memory_order_release);
+      }
+    };
+    if (n > 1 && !workers_.empty()) {
+      const size_t helpers = std::min(n - 1, workers_.size());
+      { std::lock_guard<std::mutex> lk(mu_); for (size_t k = 0; k < helpers; k++) queue_.push_back([job, drain] { drain(job); }); }
+      cv_.notify_all();
+    }
+    drain(job);
+    while (job->done.load(std::memory_order_acquire) < n) std::this_thread::yield();  // (helpers still inside their last fn)
+    for (const std::exception_ptr& e : job->errs) if (e) std::rethrow_exception(e);
+  }
+
+ private:
+  HostPool() {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n = std::min(hw > 1 ? hw - 1 : 0u, 31u);
+    for (unsigned i = 0; i < n; i++) {
+      try { workers_.emplace_back([this] { run(); }); } catch (const std::system_error&) { break; }
+    }
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (std::thread& t : workers_) t.join();
+  }
+  void run() {
+    for (;;) {
+      std::function<void()> task;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        if (stop_ && queue_.empty()) return;
+        task = std::move(queue_.front());
+        queue_.pop_front();
+      }
+      task();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> queue_;
+  std::vector<std::thread> workers_;
+  bool stop_ = false;
+};
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr size_t kTailPad = 256;
@@ -565,29 +762,18 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
   // inflating pages is the expensive part — are parsed on one thread each; the first failure in column order is reported.
   std::vector<ParsedChunk> parsed((size_t)n_chunks);
   const auto t_host0 = std::chrono::steady_clock::now();
-  size_t packed_bytes = 0;
-  for (int32_t i = 0; i < n_chunks; i++) if (chunks[i].codec != 0 && chunks[i].n_bytes > 0) packed_bytes += (size_t)chunks[i].n_bytes;
-  if (n_chunks > 1 && packed_bytes >= ((size_t)1 << 20)) {
-    std::vector<std::exception_ptr> errs((size_t)n_chunks);
-    std::atomic<int32_t> next{0};
-    auto work = [&] {
-      for (;;) {
-        const int32_t i = next.fetch_add(1);
-        if (i >= n_chunks) return;
-        try { parsed[(size_t)i] = parse_chunk(chunks[i], n_rows); } catch (...) { errs[(size_t)i] = std::current_exception(); }
-      }
-    };
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int n_workers = (int)std::min<unsigned>((unsigned)n_chunks, std::min(hw, 64u)) - 1;  // (this thread works too)
-    std::vector<std::thread> workers;
-    for (int w = 0; w < n_workers; w++) {
-      try { workers.emplace_back(work); } catch (const std::system_error&) { break; }  // fewer threads: the others take the rest
-    }
-    work();
-    for (std::thread& w : workers) w.join();
-    for (const std::exception_ptr& e : errs) if (e) std::rethrow_exception(e);
-  } else {
-    for (int32_t i = 0; i < n_chunks; i++) parsed[(size_t)i] = parse_chunk(chunks[i], n_rows);
+  {
+    // three phases: (1) page headers of every chunk — cheap, serial; (2) EVERY compressed page of the row group inflated side by
+    // side (pages are independent: a chunk of twenty 1 MiB pages used to be one thread's job); (3) the chunks parsed side by side
+    std::vector<InflateJob> jobs;
+    for (int32_t i = 0; i < n_chunks; i++) plan_chunk(chunks[i], n_rows, &parsed[(size_t)i], &jobs);
+    size_t job_bytes = 0, chunk_bytes = 0;
+    for (const InflateJob& j : jobs) job_bytes += j.body_len;
+    for (int32_t i = 0; i < n_chunks; i++) chunk_bytes += (size_t)std::max<int64_t>(chunks[i].n_bytes, 0);
+    if (job_bytes >= ((size_t)1 << 20)) HostPool::get().parallel_for(jobs.size(), [&](size_t k) { run_inflate(jobs[k]); });
+    else for (const InflateJob& j : jobs) run_inflate(j);
+    if (chunk_bytes >= ((size_t)1 << 20) && n_chunks > 1) HostPool::get().parallel_for((size_t)n_chunks, [&](size_t i) { parse_chunk(chunks[i], n_rows, &parsed[i]); });
+    else for (int32_t i = 0; i < n_chunks; i++) parse_chunk(chunks[i], n_rows, &parsed[(size_t)i]);
   }
   const auto t_host1 = std::chrono::steady_clock::now();
   hip_check(hipSetDevice(device), "hipSetDevice");
@@ -651,6 +837,12 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
       if (P.non_null > 0 && P.idx_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: values without index runs");
       if (P.idx_runs.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 4, stream), "hipMemsetAsync");
       else hip_check(fdb_launch_pq_decode(1, d_chunk, d_valid, d_prefix, nullptr, 0, d_idx, (int32_t)P.idx_runs.size(), n_rows, d_out, stream), "parquet decode");
+    } else if (c.physical_type == PT_BOOLEAN) {
+      // bits through the run tables like dictionary indices; the column is held as int64 1 (false) / 2 (true) like every bool column
+      const FdbPqRun* d_idx = (const FdbPqRun*)to_device(P.idx_runs.data(), P.idx_runs.size() * sizeof(FdbPqRun));
+      if (P.non_null > 0 && P.idx_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: values without runs");
+      if (P.idx_runs.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 8, stream), "hipMemsetAsync");
+      else hip_check(fdb_launch_pq_decode(2, d_chunk, d_valid, d_prefix, nullptr, 0, d_idx, (int32_t)P.idx_runs.size(), n_rows, d_out, stream), "parquet decode");
     } else {
       if (!P.delta_pages.empty()) {
         // DELTA_BINARY_PACKED: the non-NULL values are decoded densely (rank order) — straight into the column when it is
@@ -684,11 +876,13 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
     d.name = c.name ? c.name : "";
     d.length = n_rows;
     if (c.physical_type == 6) { d.kind = ColKind::DICT; d.format = "I"; d.dict = P.dict ? P.dict : make_dictionary({}, c.utf8 ? "u" : "z"); }
-    else if (c.physical_type == 2) { d.kind = ColKind::I64; d.format = "l"; }
+    else if (c.physical_type == PT_INT64 && c.utf8) { d.kind = ColKind::U64; d.format = "L"; }  // logical type Int(64, unsigned) (convert.go:76-82)
+    else if (c.physical_type == PT_INT64) { d.kind = ColKind::I64; d.format = "l"; }
+    else if (c.physical_type == PT_BOOLEAN) { d.kind = ColKind::BOOL; d.format = "b"; }
     else { d.kind = ColKind::F64; d.format = "g"; }
     const size_t w = c.physical_type == 6 ? 4 : 8;
     if (n_rows > 0) d.d_values = (unsigned char*)b->arena + pieces[(size_t)i].val_off;
-    d.value_bytes = n_rows * (int64_t)w;
+    d.value_bytes = d.kind == ColKind::BOOL ? (n_rows + 7) / 8 : n_rows * (int64_t)w;
     if (c.optional && n_rows > 0) {
       if ((int64_t)h_totals[(size_t)i] != P.non_null) throw Error(FDB_ERR_INVALID, "parquet: definition levels and value counts disagree in column " + d.name);
       d.null_count = n_rows - P.non_null;

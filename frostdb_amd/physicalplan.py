@@ -218,7 +218,7 @@ class ResidentBatch:
                 addr, size = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value, len(data)
             nm = name.encode()
             keep += [data, nm]
-            arr[i] = ParquetChunk(nm, ptype, 1 if optional else 0, 1 if utf8 else 0, codec, addr, size)
+            arr[i] = ParquetChunk(nm, ptype, int(optional), 1 if utf8 else 0, codec, addr, size)  # optional: the column's max definition level (0 / 1; more = nested)
         out = ctypes.c_void_p()
         rc = lib().fdb_batch_from_parquet(arr, len(chunks), n_rows, device, ctypes.byref(out))
         if rc != 0:

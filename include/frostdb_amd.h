@@ -396,18 +396,21 @@ int fdb_batch_export(const fdb_batch* batch, struct ArrowArray* out, struct Arro
  * BYTES as they sit in the file and gets a resident batch with the layout fdb_batch_import produces — usable with
  * fdb_plan_push_batch(es), fdb_plan_filter_batch, fdb_batch_export. The host side of this call reads page headers, the dictionary
  * page and the headers of RLE / bit-packed runs; definition levels → validity bitmaps, value ranks and the per-row dictionary
- * indices / values are computed in HBM. Covered: flat schemas; INT64 / DOUBLE with PLAIN data pages, INT64 also DELTA_BINARY_PACKED; BYTE_ARRAY with a
- * dictionary page + RLE_DICTIONARY data pages and / or PLAIN data pages (dictionary-encoded on the host) (→ dictionary<uint32, binary>, pqarrow/convert/convert.go:64-70; utf8 = 1 →
- * dictionary<uint32, utf8>); required or optional; data pages V1 / V2; codecs as listed at `codec`. Everything else: FDB_ERR_UNSUPPORTED
- * (the caller falls back to its Arrow path for that row group). */
+ * indices / values are computed in HBM. Covered — the types pqarrow/convert/convert.go:28-102 maps to Arrow, in the encodings and
+ * codecs a FrostDB schema can ask for (schema.proto:54-86): flat schemas; BOOLEAN (PLAIN, RLE → bool); INT64 (PLAIN,
+ * DELTA_BINARY_PACKED → int64, or uint64 for the logical type Int(64, unsigned)); DOUBLE (PLAIN); BYTE_ARRAY with a dictionary page +
+ * RLE_DICTIONARY data pages and / or PLAIN, DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY data pages (their values are dictionary-encoded
+ * on the host) (→ dictionary<uint32, binary>, convert.go:64-70; utf8 = 1 → dictionary<uint32, utf8>); required or optional; data
+ * pages V1 / V2; codecs as listed at `codec`. Repeated (list) columns and everything else: FDB_ERR_UNSUPPORTED (the caller falls
+ * back to its Arrow path for that row group). */
 typedef struct fdb_parquet_chunk {
   const char* name;        /* field name of the column in the record */
-  int32_t physical_type;   /* parquet Type: 2 INT64, 5 DOUBLE, 6 BYTE_ARRAY */
-  int32_t optional;        /* max definition level: 0 required, 1 optional */
-  int32_t utf8;            /* BYTE_ARRAY: logical type String */
-  int32_t codec;           /* parquet CompressionCodec of the chunk's pages: 0 UNCOMPRESSED, 1 SNAPPY, 2 GZIP, 6 ZSTD, 7 LZ4_RAW
-                              (5, the deprecated LZ4, is read as raw blocks or Hadoop-framed blocks). Pages are inflated on the host
-                              while their headers are walked; the device decodes the values. */
+  int32_t physical_type;   /* parquet Type: 0 BOOLEAN, 2 INT64, 5 DOUBLE, 6 BYTE_ARRAY */
+  int32_t optional;        /* max definition level: 0 required, 1 optional (> 1: nested / repeated columns — refused) */
+  int32_t utf8;            /* BYTE_ARRAY: logical type String; INT64: 1 = logical type Int(64, unsigned) → uint64 column */
+  int32_t codec;           /* parquet CompressionCodec of the chunk's pages: 0 UNCOMPRESSED, 1 SNAPPY, 2 GZIP, 4 BROTLI, 6 ZSTD, 7 LZ4_RAW
+                              (5, the deprecated LZ4, is read as raw blocks or Hadoop-framed blocks). The compressed pages of a row group
+                              are inflated on host threads, page by page in parallel; the device decodes the values. */
   const uint8_t* data;     /* [dictionary page] data pages …, each preceded by its thrift PageHeader, exactly as in the file */
   int64_t n_bytes;         /* ColumnMetaData.total_compressed_size */
 } fdb_parquet_chunk;

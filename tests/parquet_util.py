@@ -5,7 +5,7 @@ import io
 import pyarrow as pa
 import pyarrow.parquet as pq
 
-PHYSICAL = {"INT64": 2, "DOUBLE": 5, "BYTE_ARRAY": 6}
+PHYSICAL = {"BOOLEAN": 0, "INT32": 1, "INT64": 2, "FLOAT": 4, "DOUBLE": 5, "BYTE_ARRAY": 6}
 
 
 def write_parquet(table: pa.Table, **kw) -> bytes:
@@ -28,6 +28,7 @@ def row_group_chunks(data: bytes, rg: int):
         offs = [o for o in (col.dictionary_page_offset, col.data_page_offset) if o]
         start = min(offs)
         chunk = data[start:start + col.total_compressed_size]
-        utf8 = str(sc.logical_type).lower().startswith("string")
+        lt = str(sc.logical_type).lower()
+        utf8 = lt.startswith("string") or (col.physical_type == "INT64" and "int" in lt and "issigned=false" in lt.replace(" ", ""))  # (INT64: the unsigned flag)
         out.append((col.path_in_schema, PHYSICAL.get(col.physical_type, -1), sc.max_definition_level, utf8, chunk, col.compression))
     return out, md.num_rows

@@ -366,8 +366,8 @@ def test_parquet_page_header_with_an_absurd_collection_is_refused_at_once():
 
 
 def test_parquet_chunks_are_parsed_and_refused_on_the_host():
-    """fdb_batch_from_parquet reads page headers / run headers on the host BEFORE it touches a device: chunks outside the first
-    slice (BROTLI pages, DELTA byte-array encodings, truncated bytes) come back as FDB_ERR_UNSUPPORTED / FDB_ERR_INVALID here, without
+    """fdb_batch_from_parquet reads page headers / run headers on the host BEFORE it touches a device: chunks it does not decode
+    (INT32 / FLOAT columns, lists) or that are damaged (truncated bytes) come back as FDB_ERR_UNSUPPORTED / FDB_ERR_INVALID here, without
     a GPU; a well-formed chunk gets as far as the device call (FDB_ERR_DEVICE on this box)."""
     import numpy as np
     import pyarrow as pa
@@ -382,12 +382,21 @@ def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(good, rows)
     assert e.value.code == pp.FDB_ERR_DEVICE  # parsed fine, then no GPU
-    for kw, code in ((dict(compression="BROTLI"), pp.FDB_ERR_UNSUPPORTED),
-                     (dict(use_dictionary=False, column_encoding={"ts": "PLAIN", "labels.a": "DELTA_BYTE_ARRAY", "value": "PLAIN"}), pp.FDB_ERR_UNSUPPORTED)):
-        bad, rows = row_group_chunks(write_parquet(t, **kw), 0)
+    # every codec and string encoding a FrostDB schema can name (schema.proto:54-86) parses; what convert.go does not map either
+    # is refused: INT32 / FLOAT physical types, repeated (list) columns
+    for kw in (dict(compression="BROTLI"), dict(use_dictionary=False, column_encoding={"ts": "PLAIN", "labels.a": "DELTA_BYTE_ARRAY", "value": "PLAIN"}),
+               dict(use_dictionary=False, column_encoding={"ts": "DELTA_BINARY_PACKED", "labels.a": "DELTA_LENGTH_BYTE_ARRAY", "value": "PLAIN"}, compression="ZSTD")):
+        ok, rows = row_group_chunks(write_parquet(t, **kw), 0)
+        with pytest.raises(pp.FdbError) as e:
+            pp.ResidentBatch.from_parquet(ok, rows)
+        assert e.value.code == pp.FDB_ERR_DEVICE, (kw, str(e.value))
+    odd = pa.table({"i32": pa.array(np.arange(n, dtype=np.int32)), "f32": pa.array(rng.random(n).astype(np.float32)),
+                    "lst": pa.array([[1, 2] if i % 2 else [] for i in range(n)], type=pa.list_(pa.int64()))})
+    for name in ("i32", "f32", "lst"):
+        bad, rows = row_group_chunks(write_parquet(odd.select([name])), 0)
         with pytest.raises(pp.FdbError) as e:
             pp.ResidentBatch.from_parquet(bad, rows)
-        assert e.value.code == code, kw
+        assert e.value.code == pp.FDB_ERR_UNSUPPORTED, (name, str(e.value))
     cut = [(nm, ty, opt, u8, data[: len(data) // 2]) for nm, ty, opt, u8, data, _ in good]
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(cut, rows)

@@ -28,11 +28,14 @@ t = pa.table({"labels.a": pa.array([None if i % 9 == 0 else b"v%d" % (i % 13) fo
               "labels.b": pa.array([b"w%d" % v for v in rng.integers(0, 900, n)], type=pa.binary()),
               "ts": pa.array(np.cumsum(rng.integers(0, 50, n)).astype(np.int64)),
               "opt": pa.array(rng.integers(-10**9, 10**9, n), mask=rng.random(n) < 0.2),
+              "flag": pa.array(rng.random(n) < 0.5, mask=rng.random(n) < 0.1), "seq": pa.array(rng.integers(0, 2**62, n).astype(np.uint64)),
               "value": pa.array(rng.random(n), mask=rng.random(n) < 0.1)})
 variants = [dict(), dict(compression="SNAPPY"), dict(compression="GZIP"), dict(compression="ZSTD"), dict(compression="LZ4"),
             dict(use_dictionary=["labels.a", "labels.b"], column_encoding={"ts": "DELTA_BINARY_PACKED", "opt": "DELTA_BINARY_PACKED"}),
             dict(use_dictionary=False), dict(use_dictionary=False, compression="SNAPPY", data_page_version="2.0"),
-            dict(data_page_version="2.0", compression="ZSTD")]
+            dict(data_page_version="2.0", compression="ZSTD"), dict(compression="BROTLI"),
+            dict(use_dictionary=False, column_encoding={"labels.a": "DELTA_BYTE_ARRAY", "labels.b": "DELTA_LENGTH_BYTE_ARRAY", "ts": "DELTA_BINARY_PACKED"}),
+            dict(use_dictionary=False, column_encoding={"labels.a": "DELTA_LENGTH_BYTE_ARRAY", "labels.b": "DELTA_BYTE_ARRAY"}, compression="SNAPPY", data_page_version="2.0")]
 codes = {}; total = 0
 for kw in variants:
     data = write_parquet(t, data_page_size=2048, **kw)
