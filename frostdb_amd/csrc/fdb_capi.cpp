@@ -1,5 +1,6 @@
 // fdb_capi.cpp — the extern "C" surface declared in include/frostdb_amd.h. Every entry point converts C++
 // exceptions into fdb_status codes (never aborts: the Go side wraps chains in recovery.Do, physicalplan.go:142).
+#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
@@ -9,6 +10,7 @@
 #include "fdb_dynamic.h"
 #include "fdb_jit.h"
 #include "fdb_plan.h"
+#include "fdb_regex.h"
 
 // A plan handle: one operator chain. With aggregations over a DynamicColumn (fdb_dynamic.h) `plan` is the family's main plan
 // (static aggregations / group keys) and `dyn` holds the children.
@@ -395,6 +397,16 @@ int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms
     if (kernel_ms) *kernel_ms = plan->plan.stat_ms;
     if (n_launches) *n_launches = plan->plan.stat_launches;
     if (rows_scanned) *rows_scanned = plan->plan.stat_rows;
+  });
+}
+
+int fdb_regex_match(const char* pattern, int64_t pattern_len, const uint8_t* value, int64_t value_len, int32_t* matched) {
+  return guard(nullptr, [&] {
+    if (pattern == nullptr || pattern_len < 0 || value_len < 0 || (value == nullptr && value_len > 0) || matched == nullptr) throw fdb::Error(FDB_ERR_INVALID, "null argument");
+    std::string why;
+    std::shared_ptr<const fdb::Regex> re = fdb::Regex::compile(std::string(pattern, (size_t)pattern_len), &why);
+    if (!re) throw fdb::Error(FDB_ERR_INVALID, why);
+    *matched = re->match((const char*)value, (size_t)value_len) ? 1 : 0;
   });
 }
 

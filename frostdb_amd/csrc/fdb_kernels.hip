@@ -1687,11 +1687,6 @@ __global__ __launch_bounds__(256) void zero_regions_kernel(const FdbZeroRegion* 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-
 // ---- every column of every record in ONE launch, software-pipelined -----------------------------------------------------------------
 // What the first multi-column kernels taught (MI355X, 100 M rows, 4 columns, 50 % selected): with loads AND stores compiled out the
 // kernel still took 0.37 of its 0.83 ms — a wave's step is one long dependent chain (mask word → loads → ballots → LDS scatter →

@@ -267,7 +267,7 @@ std::string Literal::str() const {
 }
 
 bool ExprNode::regex_matches(const std::string& v) const {
-  if (re_fn == nullptr) return std::regex_search(v, *re);
+  if (re_fn == nullptr) return re->match(v);
   const int32_t r = re_fn(re_user, lit.bytes.data(), (int64_t)lit.bytes.size(), (const uint8_t*)v.data(), (int64_t)v.size());
   if (r < 0) throw Error(FDB_ERR_INVALID, "regexp: the host matcher rejected pattern " + lit.bytes);
   return r != 0;
@@ -310,8 +310,9 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
           e.re_fn = d->regex_match; e.re_user = d->regex_user;
           (void)e.regex_matches(std::string());  // surfaces a pattern that does not compile now, like regexp.Compile at plan build (filter.go:105-124)
         } else {
-          try { e.re = std::make_shared<std::regex>(e.lit.bytes, std::regex::ECMAScript); }  // compiled once per query
-          catch (const std::regex_error& ex) { throw Error(FDB_ERR_INVALID, std::string("regexp compile: ") + ex.what()); }
+          std::string why;
+          e.re = Regex::compile(e.lit.bytes, &why);  // compiled once per query, like regexp.Compile at plan build (filter.go:105-124)
+          if (!e.re) throw Error(FDB_ERR_INVALID, why);
         }
       }
     } else {

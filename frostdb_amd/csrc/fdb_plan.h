@@ -9,13 +9,13 @@
 #include <functional>
 #include <memory>
 #include <mutex>
-#include <regex>
 #include <string>
 #include <string_view>
 #include <unordered_map>
 #include <vector>
 
 #include "fdb_arrow.h"
+#include "fdb_regex.h"
 #include "fdb_kernels.h"
 
 namespace fdb {
@@ -113,7 +113,7 @@ struct ExprNode {
   int32_t op = 0, left = -1, right = -1;
   std::string column;
   Literal lit;
-  std::shared_ptr<std::regex> re;                           // std::regex engine (no host matcher given)
+  std::shared_ptr<const Regex> re;                          // the built-in RE2-syntax engine (fdb_regex.h; no host matcher given)
   fdb_regex_match_fn re_fn = nullptr;                       // the host application's engine (fdb_plan_desc.regex_match)
   void* re_user = nullptr;
   bool regex_matches(const std::string& v) const;           // unanchored match of this leaf's pattern against `v`

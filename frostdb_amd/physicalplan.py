@@ -81,6 +81,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_batch_release.argtypes = [vp]
     L.fdb_batch_release.restype = None
     L.fdb_plan_stats.argtypes = [vp, P(i64), P(ctypes.c_double), P(i64), P(i64)]
+    L.fdb_regex_match.argtypes = [ctypes.c_char_p, i64, ctypes.c_char_p, i64, P(i32)]
     L.fdb_parquet_stats.argtypes = [P(i64), P(ctypes.c_double), P(ctypes.c_double), P(i64), P(i64)]
     L.fdb_jit_stats.argtypes = [P(i64), P(ctypes.c_double), P(i64)]
     L.fdb_plan_merge_ms.argtypes = [vp, P(ctypes.c_double)]
@@ -129,6 +130,17 @@ def jit_stats() -> dict:
     n, ms, d = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
     lib().fdb_jit_stats(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(d))
     return {"compiled": n.value, "compile_ms": ms.value, "disk_loads": d.value}
+
+
+def regex_match(pattern, value: bytes) -> bool:
+    """The library's built-in RE2-syntax engine (fdb_regex_match): unanchored match like Go's regexp.Regexp.Match. Raises FdbError
+    (FDB_ERR_INVALID) for a pattern that does not compile."""
+    pat = pattern.encode() if isinstance(pattern, str) else bytes(pattern)
+    m = ctypes.c_int32()
+    rc = lib().fdb_regex_match(pat, len(pat), value, len(value), ctypes.byref(m))
+    if rc != 0:
+        _raise(rc, lib().fdb_last_error().decode())
+    return bool(m.value)
 
 
 def parquet_stats() -> dict:

@@ -196,9 +196,95 @@ class OracleBatch:
             pass
 
 
+def go_regexp_to_python(pattern: bytes) -> bytes:
+    """RE2 (Go regexp) syntax → Python `re` syntax for the constructs whose SPELLING differs; their meaning is the same. `$` without
+    the m flag is the end of the TEXT in Go (Python's would also match before a trailing newline) and `\\z` is Python's `\\Z`;
+    `(?U)` only changes which match is preferred (irrelevant for match / no match); `\\Q…\\E` quotes; POSIX classes are spelled out;
+    `(?<name>…)` is `(?P<name>…)`. Patterns using what Python lacks altogether (\\pL) are left alone and fail to compile there too."""
+    import re as _re
+    posix = {b"alnum": b"0-9A-Za-z", b"alpha": b"A-Za-z", b"ascii": b"\\x00-\\x7f", b"blank": b"\\t ", b"cntrl": b"\\x00-\\x1f\\x7f", b"digit": b"0-9",
+             b"graph": b"!-~", b"lower": b"a-z", b"print": b" -~", b"punct": b"!-/:-@\\[-`{-~", b"space": b"\\t\\n\\v\\f\\r ", b"upper": b"A-Z",
+             b"word": b"0-9A-Za-z_", b"xdigit": b"0-9A-Fa-f"}
+    out, i, n, in_class, multiline = bytearray(), 0, len(pattern), False, False
+    while i < n:
+        c = pattern[i:i + 1]
+        if c == b"\\" and i + 1 < n:
+            nx = pattern[i + 1:i + 2]
+            if nx == b"Q" and not in_class:
+                j = pattern.find(b"\\E", i + 2)
+                lit = pattern[i + 2: j if j >= 0 else n]
+                out += _re.escape(lit)
+                i = (j + 2) if j >= 0 else n
+                continue
+            if nx == b"z" and not in_class:
+                out += b"\\Z"; i += 2; continue
+            out += pattern[i:i + 2]; i += 2; continue
+        if in_class:
+            if c == b"[" and pattern[i + 1:i + 2] == b":":
+                j = pattern.find(b":]", i + 2)
+                name = pattern[i + 2:j] if j >= 0 else b""
+                neg = name.startswith(b"^")
+                if j >= 0 and name.lstrip(b"^") in posix and not neg:
+                    out += posix[name]; i = j + 2; continue
+            if c == b"]":
+                in_class = False
+            out += c; i += 1; continue
+        if c == b"[":
+            in_class = True
+            out += c; i += 1
+            if pattern[i:i + 1] == b"^":
+                out += b"^"; i += 1
+            if pattern[i:i + 1] == b"]":
+                out += b"\\]"; i += 1
+            continue
+        if c == b"(" and pattern[i + 1:i + 2] == b"?":
+            m = _re.match(rb"\(\?([imsU]*)(-[imsU]+)?([:)])", pattern[i:])
+            if m:
+                on = m.group(1).replace(b"U", b"")
+                off = (m.group(2) or b"").replace(b"U", b"")
+                if b"m" in on:
+                    multiline = True
+                flags = on + (off if len(off) > 1 else b"")
+                if m.group(3) == b")":
+                    out += (b"(?" + flags + b")") if flags else b""
+                else:
+                    out += (b"(?" + flags + b":") if flags else b"(?:"
+                i += m.end(); continue
+            if pattern[i + 2:i + 3] == b"<" and pattern[i + 3:i + 4] not in (b"=", b"!"):
+                out += b"(?P<"; i += 3; continue
+        if c == b"$" and not multiline:
+            out += b"\\Z"; i += 1; continue
+        out += c; i += 1
+    return bytes(out)
+
+
+_REGEX_CB_TYPE = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64)
+
+
+def _python_regex_callback():
+    """fdb_regex_match_fn over Python's `re` (str patterns on UTF-8 text: `.` and classes see runes, like Go's), compiled once per pattern."""
+    import re as _re
+    cache = {}
+
+    def cb(_user, pat_p, pat_n, val_p, val_n):
+        try:
+            pat = ctypes.string_at(pat_p, pat_n)
+            rx = cache.get(pat)
+            if rx is None:
+                rx = cache[pat] = _re.compile(go_regexp_to_python(pat).decode("utf-8"))
+            val = ctypes.string_at(val_p, val_n) if val_n else b""
+            return 1 if rx.search(val.decode("utf-8", "replace")) else 0
+        except Exception:  # noqa: BLE001  (does not compile)
+            return -1
+    return _REGEX_CB_TYPE(cb)
+
+
 class OraclePlan:
-    def __init__(self, filter_expr, aggs: Sequence = (), groups: Sequence = (), nchains: int = 1, seed: int = 0x5EED):
-        self._desc = Desc(filter_expr, list(aggs), list(groups))
+    def __init__(self, filter_expr, aggs: Sequence = (), groups: Sequence = (), nchains: int = 1, seed: int = 0x5EED, go_regexp: bool = True):
+        """`go_regexp` (default): `=~` / `!~` literals are RE2 syntax matched by Python's `re` on the translated pattern (Go's
+        regexp semantics, an engine independent of the product's); False: the restatement's own std::regex (ECMAScript)."""
+        self._regex_cb = _python_regex_callback() if go_regexp else None
+        self._desc = Desc(filter_expr, list(aggs), list(groups), regex_fn=ctypes.cast(self._regex_cb, ctypes.c_void_p).value if self._regex_cb else 0)
         out = ctypes.c_void_p()
         rc = lib().oracle_plan_create(self._desc.address, nchains, seed, ctypes.byref(out))
         if rc != 0:

@@ -148,7 +148,8 @@ def _proj_nodes(arena: _Arena, root):
 class Desc:
     """An fdb_plan_desc laid out by hand; `.address` is what oracle_plan_create takes."""
 
-    def __init__(self, filter_expr, aggs: Sequence, groups: Sequence):
+    def __init__(self, filter_expr, aggs: Sequence, groups: Sequence, regex_fn: int = 0):
+        """`regex_fn`: address of a C callback with fdb_regex_match_fn's signature (0: the oracle's std::regex)."""
         a = self._arena = _Arena()
         f_addr, n_filter = 0, 0
         if filter_expr is not None:
@@ -165,7 +166,7 @@ class Desc:
             projs.append(PROJECTION.pack(a.cstr(e.name.encode()), a.block(nb), n, 0))
         pb = b"".join(projs)
         self._desc = ctypes.create_string_buffer(
-            PLAN_DESC.pack(f_addr, n_filter, 0 if n_filter else -1, a.block(ab), len(aggs), len(groups), a.block(gb), 0, len(projs), a.block(pb), 0, 0, 0, 0), PLAN_DESC.size)
+            PLAN_DESC.pack(f_addr, n_filter, 0 if n_filter else -1, a.block(ab), len(aggs), len(groups), a.block(gb), 0, len(projs), a.block(pb), regex_fn, 0, 0, 0), PLAN_DESC.size)
 
     @property
     def address(self) -> int:

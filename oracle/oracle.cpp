@@ -27,7 +27,9 @@
 //   * github.com/apache/arrow-go/v18 v18.2.0: compute compare kernels, math.{Int64,Float64}.Sum — restated as
 //     plain loops (summation order = row order; the reference's SIMD order is unspecified → float tolerance).
 //   * github.com/RoaringBitmap/roaring v1.9.4: set algebra only — restated as a byte-per-row bitmap.
-//   * Go regexp (RE2 syntax): restated with std::regex (ECMAScript); identical on the patterns the
+//   * Go regexp (RE2 syntax): through the caller's engine when the descriptor carries one (oracle/__init__.py: Python's `re` on
+//     the pattern translated from RE2 syntax — independent of the product's own RE2-syntax engine); else std::regex
+//     (ECMAScript); identical on the patterns the
 //     reference's tests use ('value.', '', 'foo'); exotic RE2-only syntax is unpinned.
 //
 // Parity pins: every vector of logictest/testdata/exec/{filter,aggregate}/* that the hash path serves and
@@ -235,6 +237,16 @@ struct Expr {
   std::string column;
   Literal lit;
   std::shared_ptr<std::regex> re;
+  // the caller's regex engine (fdb_plan_desc.regex_match: oracle/__init__.py passes Python's `re` on the pattern translated from
+  // RE2 syntax): when given, every match goes through it — Go's regexp semantics instead of ECMAScript's
+  fdb_regex_match_fn re_fn = nullptr;
+  void* re_user = nullptr;
+  bool search(const std::string& v, bool* failed) const {
+    if (re_fn == nullptr) return std::regex_search(v, *re);
+    const int32_t r = re_fn(re_user, lit.bytes.data(), (int64_t)lit.bytes.size(), (const uint8_t*)v.data(), (int64_t)v.size());
+    if (r < 0 && failed) *failed = true;
+    return r > 0;
+  }
 };
 struct AggDesc { int32_t func; std::string column; std::string result_name; bool dynamic = false; };
 struct GroupDesc { std::string name; bool dynamic; };
@@ -290,7 +302,7 @@ bool eval_leaf(const Expr& e, const Record& r, Bitmap* res, EvalError* err) {
   const bool is_regex = e.op == FDB_OP_REGEX_MATCH || e.op == FDB_OP_REGEX_NOT_MATCH;
   if (ci < 0) {
     if (is_regex) {  // regexpfilter.go:23-33
-      const bool empty_match = std::regex_search(std::string(), *e.re);
+      const bool empty_match = e.search(std::string(), nullptr);
       const bool not_match = e.op == FDB_OP_REGEX_NOT_MATCH;
       if ((not_match && !empty_match) || (!not_match && empty_match)) res->assign(n, 1);
       return true;
@@ -315,13 +327,13 @@ bool eval_leaf(const Expr& e, const Record& r, Bitmap* res, EvalError* err) {
     const bool not_match = e.op == FDB_OP_REGEX_NOT_MATCH;
     if (c.type == T_STR) {
       for (int64_t i = 0; i < n; i++)
-        if (c.valid[i]) (*res)[i] = std::regex_search(c.strs[i], *e.re) != not_match;
+        if (c.valid[i]) (*res)[i] = e.search(c.strs[i], nullptr) != not_match;
       return true;
     }
     if (c.type == T_DICT) {
       if (c.dict->utf8) { *err = {FDB_ERR_UNSUPPORTED, "ArrayScalarRegexMatch: unsupported dictionary type: *array.String"}; return false; }
       for (int64_t i = 0; i < n; i++)
-        if (c.valid[i]) (*res)[i] = std::regex_search(c.dict->values[c.idx[i]], *e.re) != not_match;
+        if (c.valid[i]) (*res)[i] = e.search(c.dict->values[c.idx[i]], nullptr) != not_match;
       return true;
     }
     *err = {FDB_ERR_UNSUPPORTED, "ArrayScalarRegexMatch: unsupported type"};
@@ -948,8 +960,15 @@ int oracle_plan_create(const fdb_plan_desc* d, int32_t nchains, uint64_t seed, o
     e.lit.type = fe.literal.type; e.lit.i64 = fe.literal.i64; e.lit.u64 = fe.literal.u64; e.lit.f64 = fe.literal.f64;
     if (fe.literal.data && fe.literal.len > 0) e.lit.bytes.assign(fe.literal.data, fe.literal.len);
     if (e.op == FDB_OP_REGEX_MATCH || e.op == FDB_OP_REGEX_NOT_MATCH) {
-      try { e.re = std::make_shared<std::regex>(e.lit.bytes, std::regex::ECMAScript); }
-      catch (const std::regex_error& ex) { g_err = std::string("regexp compile: ") + ex.what(); return FDB_ERR_INVALID; }
+      if (d->regex_match != nullptr) {
+        e.re_fn = d->regex_match; e.re_user = d->regex_user;
+        bool failed = false;
+        (void)e.search(std::string(), &failed);  // regexp.Compile at plan build (filter.go:105-124)
+        if (failed) { g_err = "regexp compile: the pattern does not compile"; return FDB_ERR_INVALID; }
+      } else {
+        try { e.re = std::make_shared<std::regex>(e.lit.bytes, std::regex::ECMAScript); }
+        catch (const std::regex_error& ex) { g_err = std::string("regexp compile: ") + ex.what(); return FDB_ERR_INVALID; }
+      }
     }
     const bool leaf_ok = (e.op >= FDB_OP_EQ && e.op <= FDB_OP_REGEX_NOT_MATCH) || e.op == FDB_OP_CONTAINS || e.op == FDB_OP_NOT_CONTAINS;
     const bool branch_ok = e.op == FDB_OP_AND || e.op == FDB_OP_OR;

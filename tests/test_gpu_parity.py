@@ -995,10 +995,25 @@ def test_host_regex_engine_decides_regex_leaves(pp):
         assert np.array_equal(p.Select(b), want)
     finally:
         p.Close()
-    with pytest.raises(pp.FdbError):  # std::regex (ECMAScript) has no inline flags
-        pp.HashAggregatePlan(Col("name").RegexMatch("(?i)^ZETA$"))
     with pytest.raises(pp.FdbError):  # the host engine rejects the pattern: surfaces at create, like regexp.Compile at plan build
         pp.HashAggregatePlan(Col("name").RegexMatch("(unclosed"), regex=engine)
+    # Without a host engine the library's own RE2-syntax engine (fdb_regex.h) decides: inline flags, named groups, POSIX classes,
+    # \Q…\E, `$` = end of text — the same rows as the oracle, whose `=~` goes through Python's `re` on the translated pattern
+    # (an independent engine), on plain and dictionary columns, filter and aggregate alike.
+    for pat in ("(?i)^ZETA$", "(?P<head>w0)[0-4]$", "^[[:alpha:]]+[[:digit:]]?$", "\\Qw0\\E[5-9]|^$", "(?i:ze)ta|b{2,}", "^(?U)a+?b*$"):
+        builtin = pp.HashAggregatePlan(Col("name").RegexMatch(pat))
+        try:
+            got = builtin.Select(b)
+        finally:
+            builtin.Close()
+        _, idx = _oracle_filter(b, Col("name").RegexMatch(pat))
+        assert np.array_equal(got, idx), pat
+    f2 = And(Col("labels.code").RegexNotMatch("(?i)C[12]$"), Col("name").RegexMatch("(?s)^.{2,5}$"))
+    got = run_gpu(pp, [b], f2, [Count(Col("value"))], [Col("labels.code")])
+    want = run_oracle([b], f2, [Count(Col("value"))], [Col("labels.code")])
+    assert_same_result(got, want, ["labels.code", "count(value)"])
+    with pytest.raises(pp.FdbError):  # not RE2 syntax (look-ahead): refused at create
+        pp.HashAggregatePlan(Col("name").RegexMatch("(?=z)eta"))
 
 
 def test_plain_string_filter_errors(pp):

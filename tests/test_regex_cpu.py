@@ -1,0 +1,96 @@
+"""The library's built-in regular-expression engine (fdb_regex_match; what `=~` / `!~` use when the host passes no matcher): RE2
+syntax as Go's regexp compiles it (filter.go:105-124), matched unanchored like regexp.Regexp.Match (regexpfilter.go:84-166).
+
+The reference holds regex vectors only for plain patterns (logictest/testdata/exec/filter/filter:165-191: those run through the
+oracle in test_oracle_golden.py); what is checked here is the ENGINE, against an independent one: Python's `re` on the pattern
+translated by oracle.go_regexp_to_python (spelling differences only). Go-specific behaviour that Python does not share is listed
+explicitly with the expected answer and the place in Go's documentation it comes from."""
+import re
+import time
+
+import pytest
+
+
+@pytest.fixture(scope="module")
+def pp():
+    from frostdb_amd import physicalplan
+    return physicalplan
+
+
+CASES = [
+    ("", [b"", b"a"]), ("abc", [b"abc", b"xabcx", b"ab", b""]), ("^abc$", [b"abc", b"abcd", b"xabc"]),
+    ("a.c", [b"abc", b"a\nc", b"ac", "aéc".encode()]), ("(?s)a.c", [b"a\nc", b"abc"]), ("a|b|", [b"", b"c"]), ("a*", [b"", b"bbb"]),
+    ("a+b?c{2,3}", [b"aacc", b"abccc", b"ac", b"abcccc", b"xaccx"]), ("[a-c]+[^a-c]", [b"abcd", b"abc", b"d"]), ("[]a]", [b"]", b"a", b"b"]),
+    ("[^]a]", [b"]", b"b", b"a"]), (r"[a\]b]", [b"]", b"c"]), (r"\d+\.\d+", [b"3.14", b"314", b"a1.5b"]), (r"\w+@\w+\.com", [b"me@x.com", b"me@x.org"]),
+    (r"\bfoo\b", [b"foo", b"a foo b", b"foobar", b"xfoo"]), (r"\Bfoo", [b"xfoo", b"foo"]), ("(?i)hello", [b"HeLLo", b"help"]),
+    ("(?i:he)llo", [b"HEllo", b"HELLO"]), ("(?i)[a-c]x", [b"Bx", b"BX", b"dx"]), (r"(?P<year>\d{4})-(?P<m>\d\d)", [b"2024-05", b"24-05"]),
+    (r"(?<year>\d{4})", [b"in 2024", b"24"]), ("(?:ab)+c", [b"ababc", b"ac"]), ("(a|b)*c", [b"ababc", b"c", b"ab"]), ("(a*)*b", [b"aaab", b"b", b"aaa"]),
+    ("(a*)+$", [b"aaa", b"aab"]), ("x{0}", [b"", b"x"]), ("x{2}", [b"x", b"xx"]), ("x{2,}", [b"x", b"xxxxx"]), ("a{b", [b"a{b", b"ab"]),
+    (r"\.\*\+\?\(\)\[\]\{\}\|\^\$\\", [b".*+?()[]{}|^$\\", b"x"]), ("(?m)^b$", [b"a\nb\nc", b"ab"]), ("^b$", [b"a\nb\nc", b"b"]),
+    (r"\Aab\z", [b"ab", b"ab\n", b"xab"]), ("é+", ["éé".encode(), b"e"]), ("[à-ÿ]", ["é".encode(), b"e"]), ("/api/v[12]/.*(users|orders)$", [b"/api/v1/x/users", b"/api/v3/users", b"/api/v2/orders/1"]),
+    ("^(GET|POST) ", [b"GET /", b"PUT /"]), ("(?i)^get$", [b"GeT", b"gets"]), ("a.*b.*c", [b"a123b456c", b"acb"]), ("(ab|a)(bc|c)?$", [b"abc", b"ac", b"abcc"]),
+    ("[[:alpha:]]+[[:digit:]]", [b"abc1", b"1", b"abc"]), (r"[\d\s]+x", [b"1 2x", b"x"]), ("[a-]", [b"-", b"b"]), ("[-a]", [b"-"]), (r"\Qa.b*\E+", [b"a.b**", b"a.b", b"axb"]),
+    ("a??b", [b"b", b"ab"]), ("a*?b", [b"aab"]), ("(?U)a+b", [b"aab", b"b"]), ("(a|ab)(c|bcd)(d*)", [b"abcd", b"ad"]), ("[^\\x00-\\x7f]", ["€".encode(), b"abc"]),
+    ("(?i)STRASSE|strasse", [b"Strasse", b"street"]), ("node-[0-9]+\\.(eu|us)-(east|west)-[1-3]$", [b"node-12.eu-west-2", b"node-12.eu-west-4", b"node-.us-east-1"]),
+]
+
+
+def test_the_builtin_engine_agrees_with_an_independent_engine_on_re2_syntax(pp):
+    from oracle import go_regexp_to_python
+    n = 0
+    for pat, values in CASES:
+        rx = re.compile(go_regexp_to_python(pat.encode()).decode())
+        for v in values:
+            want = rx.search(v.decode("utf-8", "replace")) is not None
+            assert pp.regex_match(pat, v) == want, (pat, v, want)
+            n += 1
+    assert n > 120
+
+
+def test_go_specific_semantics(pp):
+    # `$` without the m flag is the end of the TEXT, not "before a trailing newline" (regexp/syntax: "at end of text (like \z not \Z)")
+    assert pp.regex_match("^abc$", b"abc\n") is False and pp.regex_match("(?m)^abc$", b"abc\n") is True
+    # `.` never matches a newline unless s is set, and sees RUNES: one invalid byte is one U+FFFD (utf8.DecodeRune)
+    assert pp.regex_match("^.$", b"\xff") is True and pp.regex_match("^.$", "é".encode()) is True and pp.regex_match("^.$", b"\xc3") is True
+    assert pp.regex_match("^..$", "é".encode()) is False and pp.regex_match("^[^a]$", "€".encode()) is True
+    # `{` that does not open a valid repetition is a literal; `{,n}` is not a repetition in RE2
+    assert pp.regex_match("a{,2}", b"a{,2}") is True and pp.regex_match("^a{,2}$", b"aa") is False
+    # flags apply to the rest of the enclosing group; a negated flag switches back
+    assert pp.regex_match("^a(?i)b$", b"aB") is True and pp.regex_match("^a(?i)b$", b"AB") is False
+    assert pp.regex_match("^(?i)a(?-i)b$", b"Ab") is True and pp.regex_match("^(?i)a(?-i)b$", b"AB") is False
+    assert pp.regex_match("^((?i)a)b$", b"Ab") is True and pp.regex_match("^((?i)a)b$", b"AB") is False
+    # octal and hex escapes
+    assert pp.regex_match(r"^\x41\x{263A}\101\0\012$", "A☺A\x00\n".encode()) is True
+    # the empty pattern matches everything (what regexpfilter.go:23-33 asks about a missing column)
+    assert pp.regex_match("", b"") is True and pp.regex_match("x*", b"") is True and pp.regex_match("x+", b"") is False
+
+
+@pytest.mark.parametrize("pat,why", [
+    (r"\pL", "Unicode classes"), ("a**", "invalid nested repetition operator"), ("(a", "missing closing )"), ("a)", "unexpected )"), ("[a", "missing closing ]"),
+    (r"\1", "invalid escape sequence"), ("(?=a)", "invalid or unsupported Perl syntax"), ("(?<!a)b", "invalid"), ("a{1001}", "invalid repeat count"),
+    (r"\C", "invalid escape sequence"), (r"\q", "invalid escape sequence"), ("x{3,2}", "invalid repeat count"), ("*a", "missing argument to repetition operator"),
+    ("(?i", "missing closing )"), ("[b-a]", "invalid character class range"), ("a\\", "trailing backslash"), ("(?P<n-1>a)", "invalid named capture"),
+    ("((((a{1000}){1000}){1000}){1000})", "too large"),
+])
+def test_what_re2_rejects_is_rejected_with_go_style_wording(pp, pat, why):
+    """No backreferences, no look-around, bounded repeat counts and program size: like RE2, so that no pattern can make matching
+    super-linear. A pattern that does not compile is FDB_ERR_INVALID — at fdb_plan_create too (regexp.Compile at plan build)."""
+    from frostdb_amd.logicalplan import Col
+    with pytest.raises(pp.FdbError) as e:
+        pp.regex_match(pat, b"x")
+    assert e.value.code == pp.FDB_ERR_INVALID and "error parsing regexp" in str(e.value) and why in str(e.value), str(e.value)
+    with pytest.raises(pp.FdbError) as e:
+        pp.explain(Col("labels.x").RegexMatch(pat))
+    assert e.value.code == pp.FDB_ERR_INVALID
+
+
+def test_matching_is_linear_in_the_value(pp):
+    """The classic backtracking bombs: (a+)+$ / (a|aa)*$ / (.*)*x over a long run of a's end in milliseconds (a backtracking
+    engine needs 2^n steps); a 1 MB value against a 60-state pattern in well under a second."""
+    bomb = b"a" * 5000 + b"!"
+    t0 = time.perf_counter()
+    for pat in ("(a+)+$", "^(a|aa)*$", "(.*)*x", "(a*)*b", "^(a?){40}a{40}$"):
+        assert pp.regex_match(pat, bomb) is False, pat
+    assert pp.regex_match("(x+x+)+y", b"x" * 100000) is False
+    assert pp.regex_match(r"[a-z]+\d{3}-(foo|bar|baz)+[^!]*!$", b"q" * 500000 + b"123-foobarbaz" + b"." * 500000 + b"!") is True
+    assert time.perf_counter() - t0 < 20.0
