@@ -37,3 +37,9 @@ def test_mutated_parquet_chunks_are_refused_or_parsed_never_fatal():
     lib = os.path.join(ROOT, "frostdb_amd", "libfrostdb_amd.so")
     out = run_tool([os.path.join(ROOT, "tools", "asan_parquet_run.py"), "25", "3"], env={"FDB_ASAN_LIB": lib})
     assert "runs 300" in out  # 12 file variants (codecs, page versions, DELTA byte-array encodings) × 25 mutations
+
+
+@pytest.mark.timeout(300)
+def test_random_regex_patterns_compile_or_are_refused_and_never_take_long():
+    out = run_tool([os.path.join(ROOT, "tools", "regex_fuzz.py"), "6000", "5"])
+    assert "runs 6000" in out and "slow 0" in out

@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 SRC="$ROOT/frostdb_amd/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 python -c "import sys; sys.path.insert(0, '$ROOT'); from frostdb_amd import build; build.build()" > /dev/null   # (writes fdb_kernels_h.inc)
-for f in fdb_arrow fdb_context fdb_plan fdb_hash fdb_jit fdb_dynamic fdb_comm fdb_parquet fdb_capi; do
+for f in fdb_arrow fdb_context fdb_plan fdb_hash fdb_jit fdb_dynamic fdb_comm fdb_parquet fdb_regex fdb_capi; do
   $HIPCC --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -munsafe-fp-atomics -fsanitize=address,undefined -fno-gpu-sanitize -x hip -c "$SRC/$f.cpp" -o "$OUT/$f.o"
 done
 $HIPCC --offload-arch=gfx950 -O1 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-sanitize -c "$SRC/fdb_kernels.hip" -o "$OUT/fdb_kernels.o"
