@@ -3,7 +3,7 @@
 # code is compiled as usual), built outside the tree, and the three CPU fuzzers run against it: plan descriptors through
 # fdb_plan_explain, Arrow records with detectable defects through fdb_arrow_roundtrip, mutated Parquet column chunks through
 # fdb_batch_from_parquet. No GPU needed (every path stops before, or at, the first device call).
-#   tools/asan_full.sh [descriptors, default 20000] [arrow records, default 5000] [parquet mutations per variant, default 100]
+#   tools/asan_full.sh [descriptors, default 20000] [arrow records, default 5000] [parquet mutations per variant, default 100] [regex patterns, default 20000]
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/fdb_asan_full
@@ -22,3 +22,4 @@ export LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0
 FDB_FUZZ_LIB="$OUT/libfdb_fullasan.so" python "$ROOT/tools/desc_fuzz.py" "${1:-20000}" 1
 FDB_FUZZ_LIB="$OUT/libfdb_fullasan.so" python "$ROOT/tools/arrow_fuzz.py" "${2:-5000}" 1
 FDB_ASAN_LIB="$OUT/libfdb_fullasan.so" python "$ROOT/tools/asan_parquet_run.py" "${3:-100}" 1
+FDB_ASAN_LIB="$OUT/libfdb_fullasan.so" python "$ROOT/tools/regex_fuzz.py" "${4:-20000}" 1
