@@ -432,6 +432,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
     d_block = (unsigned char*)device_pool_alloc(device_, direct_bytes + 256);
     resident->arena = d_block;
     resident->arena_bytes = direct_bytes + 256;
+    resident->note_reader(stream_);  // (whatever happens below: the block does not go back to the pool while a kernel of ours still writes it)
   } else {
     d_block = (unsigned char*)ctx_->dev_alloc(direct_bytes + narrow_bytes + 256);
     owned.push_back(d_block);
