@@ -1842,15 +1842,15 @@ __device__ __forceinline__ void compact_stream(const FdbCompactRec* __restrict__
 #pragma unroll
       for (int k = 0; k < CHUNKS; k++) {
         const uint32_t i = (uint32_t)(k * 64 + lane) * 2u;  // first of the chunk's two values
-        if (i + 1 < total) *reinterpret_cast<u32x4_t*>(d + i) = chunk[k];
-        else if (i < total) d[i] = (unsigned long long)chunk[k].x | ((unsigned long long)chunk[k].y << 32);
+        if (i + 1 < total) __builtin_nontemporal_store(chunk[k], reinterpret_cast<u32x4_t*>(d + i));  // (streamed out: nobody reads it back soon)
+        else if (i < total) __builtin_nontemporal_store((unsigned long long)chunk[k].x | ((unsigned long long)chunk[k].y << 32), d + i);
       }
     } else {
       uint32_t* d = reinterpret_cast<uint32_t*>(U.dst) + out;
 #pragma unroll
       for (int k = 0; k < CHUNKS; k++) {
         const uint32_t i = (uint32_t)(k * 64 + lane) * 4u;  // first of the chunk's four values
-        if (i + 3 < total) *reinterpret_cast<u32x4_t*>(d + i) = chunk[k];
+        if (i + 3 < total) __builtin_nontemporal_store(chunk[k], reinterpret_cast<u32x4_t*>(d + i));
         else {
           if (i < total) d[i] = chunk[k].x;
           if (i + 1 < total) d[i + 1] = chunk[k].y;

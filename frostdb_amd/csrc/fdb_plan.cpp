@@ -2267,9 +2267,12 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
     const FdbCompactCol* d_cols = (const FdbCompactCol*)upload(cols.data(), cols.size() * sizeof(FdbCompactCol));
     const FdbZeroRegion* d_regions = (const FdbZeroRegion*)upload(regions.data(), regions.size() * sizeof(FdbZeroRegion));
     // waves are dealt to the columns in proportion to their bytes per row (a wave stays on its column for the whole launch):
-    // as many workgroups of 4 waves as are resident at once, at least one wave per column, never more waves than a column has tiles
+    // 1.5 × the workgroups of 4 waves that are resident at once (a wave's share of tiles is fixed at launch: smaller shares even out
+    // the waves that finish late — measured 8 % faster than exactly-resident; handing tiles out dynamically, one ticket per tile or per
+    // 8 tiles on a per-column counter, was slower: 2.5 ms and 1.08 ms against 0.90), at least one wave per column, never more waves
+    // than a column has tiles
     static const int env_per_cu = std::getenv("FDB_COMPACT_BLOCKS_PER_CU") ? std::atoi(std::getenv("FDB_COMPACT_BLOCKS_PER_CU")) : 0;  // (tuning aid)
-    const int64_t budget = (int64_t)(fdb_scan_default_grid(device_) / 2) * (env_per_cu > 0 ? env_per_cu : fdb_compact_multi_blocks_per_cu()) * 4;
+    const int64_t budget = (int64_t)(fdb_scan_default_grid(device_) / 2) * (env_per_cu > 0 ? env_per_cu : (fdb_compact_multi_blocks_per_cu() * 3 + 1) / 2) * 4;
     int64_t weight_sum = 0;
     for (size_t c = 0; c < n_cols; c++) weight_sum += cols[c].width;
     std::vector<int32_t> wave_begin(n_cols + 1, 0);
