@@ -2027,6 +2027,44 @@ def test_filter_of_many_resident_records_in_one_launch_sequence_matches_the_orac
             r.close()
 
 
+def test_filter_batches_properties_at_scale(pp):
+    """Size-independent properties of fdb_plan_filter_batches at 48 M rows (4 records, sizes off the tile grid): a predicate and its
+    complement partition the non-NULL rows (counts add up, Σ value adds up to the column's own sum); filtering the result again
+    selects everything and leaves it unchanged (idempotence); rows keep their order (timestamps stay non-decreasing); NULL counts of
+    the outputs add up to the NULLs among the selected rows."""
+    from frostdb_amd import synth
+    sizes = [12_000_000, 11_999_999, 12_000_001, 12_345_678]
+    recs = [synth.prometheus_chunk(3, i, n, row_base=sum(sizes[:i])) for i, n in enumerate(sizes)]
+    rbs = [pp.ResidentBatch(r) for r in recs]
+    a = pp.HashAggregatePlan(Col("value") > 321.5)
+    b = pp.HashAggregatePlan(Col("value") <= 321.5)
+    try:
+        oa, ob = a.FilterResidentMany(rbs), b.FilterResidentMany(rbs)
+        for r, x, y in zip(recs, oa, ob):
+            v = r.column(r.schema.get_field_index("value")).to_numpy()
+            assert x.num_rows == int((v > 321.5).sum()) and x.num_rows + y.num_rows == r.num_rows
+        first = oa[1].to_arrow()
+        v1 = recs[1].column(recs[1].schema.get_field_index("value")).to_numpy()
+        m = v1 > 321.5
+        assert np.array_equal(first.column("value").to_numpy(), v1[m])
+        ts = first.column("timestamp").to_numpy()
+        assert np.all(np.diff(ts) >= 0)
+        code = recs[1].column(0)
+        assert first.column("labels.code").null_count == int(np.asarray(code.is_null())[m].sum())
+        total = sum(float(o.to_arrow().column("value").to_numpy().sum()) for o in (oa[3], ob[3]))
+        assert math.isclose(total, float(recs[3].column(recs[3].schema.get_field_index("value")).to_numpy().sum()), rel_tol=1e-12)
+        again = a.FilterResidentMany(oa)
+        for x, y in zip(oa, again):
+            assert y.num_rows == x.num_rows
+        assert again[2].to_arrow().equals(oa[2].to_arrow())
+        for o in oa + ob + again:
+            o.close()
+    finally:
+        a.Close(); b.Close()
+        for r in rbs:
+            r.close()
+
+
 def test_resident_selection_vector_and_capacity_retry(pp):
     """fdb_plan_select_batch writes the ascending selection vector into a device buffer; a 12 M-row record with a predicate that
     only matches in its second half defeats the strided sample less than it defeats a prefix sample — either way the result must
