@@ -2027,6 +2027,36 @@ def test_filter_of_many_resident_records_in_one_launch_sequence_matches_the_orac
             r.close()
 
 
+def test_filter_batches_when_only_some_records_have_nulls_in_a_column(pp):
+    """The compaction kernel is specialised per COLUMN (width × nullable) for the whole launch: a column that has a validity bitmap
+    in one record and none in another (a part without NULLs drops the bitmap) is compacted as nullable everywhere — the records
+    without a bitmap read an all-ones one — and each output keeps a bitmap only if NULLs were actually selected."""
+    rng = np.random.default_rng(99)
+    recs = []
+    for k, (n, nf) in enumerate([(40_000, 0.05), (30_001, 0.0), (2_048, 0.0), (55_555, 0.2), (10, 0.0)]):
+        recs.append(make_prometheus_batch(rng, n, n_path=25, null_frac=nf))
+    assert recs[1].column("labels.path").null_count == 0 and recs[0].column("labels.path").null_count > 0
+    filt = Or(Col("value") > 600.0, Col("labels.code") == "404")
+    plan = pp.HashAggregatePlan(filt)
+    rbs = [pp.ResidentBatch(r) for r in recs]
+    try:
+        outs = plan.FilterResidentMany(rbs)
+        assert "fdb_flags_kernel" in plan.last_kernel()
+        for rec, out in zip(recs, outs):
+            want, idx = _oracle_filter(rec, filt)
+            got = out.to_arrow()
+            assert got.num_rows == len(idx)
+            g = arrow_to_pydict(got)
+            for name in rec.schema.names:
+                assert g[name] == want[name], (rec.num_rows, name)
+                assert got.column(name).null_count == sum(v is None for v in want[name])
+            out.close()
+    finally:
+        plan.Close()
+        for r in rbs:
+            r.close()
+
+
 def test_filter_batches_properties_at_scale(pp):
     """Size-independent properties of fdb_plan_filter_batches at 48 M rows (4 records, sizes off the tile grid): a predicate and its
     complement partition the non-NULL rows (counts add up, Σ value adds up to the column's own sum); filtering the result again
