@@ -409,8 +409,8 @@ hipError_t fdb_launch_zero_regions(const FdbZeroRegion* regions, int n_regions, 
 // Every column (cols[rec × n_cols + col]) of every record compacted in ONE launch; null_counts[(rec × n_cols + col) × 64 …] (zeroed).
 // Wave g of the launch works on the column c with col_wave_begin[c] ≤ g < col_wave_begin[c + 1] (device array of n_cols + 1 entries,
 // n_waves = its last one): the host deals the waves to the columns in proportion to their bytes.
-int fdb_compact_multi_blocks_per_cu(void);
-hipError_t fdb_launch_compact_multi(const FdbCompactRec* recs, int n_recs, const FdbCompactCol* cols, int n_cols, const int32_t* col_wave_begin, int n_waves,
+int fdb_compact_multi_blocks_per_cu(int any_nullable);
+hipError_t fdb_launch_compact_multi(const FdbCompactRec* recs, int n_recs, const FdbCompactCol* cols, int n_cols, int any_nullable, const int32_t* col_wave_begin, int n_waves,
                                     const uint32_t* masks, const uint32_t* tile_offsets, const unsigned long long* rec_base, int64_t total_tiles,
                                     unsigned long long* null_counts, hipStream_t stream);
 int fdb_scan_default_grid(int device);

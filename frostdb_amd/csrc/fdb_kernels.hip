@@ -1636,7 +1636,10 @@ __global__ __launch_bounds__(1024) void sel_scan_kernel(const uint32_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned long long part = 0;
   if (block_sums != nullptr) { for (int64_t i = tid; i < (int64_t)blockIdx.x; i += 1024) part += block_sums[i]; }
-  else { for (int64_t i = tid; i < (int64_t)blockIdx.x * 1024; i += 1024) part += tile_counts[i]; }
+  else {  // (exactly blockIdx.x loads per thread, 8 in flight at a time: one after the other they were most of this kernel's 15 µs at 48 workgroups)
+#pragma unroll 8
+    for (int b = 0; b < (int)blockIdx.x; b++) part += as_global(tile_counts)[(int64_t)b * 1024 + tid];
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += (unsigned long long)__shfl_xor((long long)part, o, 64);
   if (lane == 0) wave_sum[wave] = part;
@@ -1698,13 +1701,22 @@ __global__ __launch_bounds__(256) void zero_regions_kernel(const FdbZeroRegion* 
 // after the next are prefetched too. Unselected rows are staged into dump slots instead of being branched around.
 template <int W>
 struct CompactUnit {
-  static constexpr int NS = W == 8 ? 2 : 4;
-  uint32_t sel[NS], vbyte[NS];  // vbyte: the RAW validity byte of the lane's row group (consumed a step later: nothing here waits for a load)
-  uint32_t x4[W == 4 ? NS : 1][4];
-  unsigned long long x8[W == 8 ? NS : 1][4];
-  void* dst; uint8_t* dst_valid;  // (wave-uniform)
+  static constexpr int G = W == 8 ? 8 : 16;  // groups of 64 rows per step: 512 × 8 or 1 024 × 4 bytes = 4 KiB of values
+  uint32_t word;             // the step's tile: its selection bitmap, one 32-bit word per lane (word k = rows [32 k, 32 k + 32) of the tile; rows past the record's end cleared)
+  unsigned long long vword;  // lane j < G: the RAW validity word of the step's group j (consumed a step later: nothing here waits for a load)
+  uint32_t x4[W == 4 ? G : 1];
+  unsigned long long x8[W == 8 ? G : 1];
+  void* dst; uint8_t* dst_valid;  // (wave-uniform, like everything below)
   uint32_t out0; int q, rec;
 };
+
+// rows [64 k, 64 k + 64) of a tile as ONE wave-uniform 64-bit word out of the per-lane copy of the tile's bitmap
+__device__ __forceinline__ unsigned long long compact_group_word(const uint32_t word, const int k) {
+  return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)word, 2 * k) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)word, 2 * k + 1) << 32);
+}
+__device__ __forceinline__ unsigned long long readlane_u64(const unsigned long long v, const int l) {
+  return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
+}
 
 #define FDB_CONST __attribute__((address_space(4)))  // wave-uniform tables are read with scalar loads (their own counter: a prefetched tile offset does not wait for vector loads)
 template <int W, bool NULLABLE>
@@ -1712,7 +1724,7 @@ __device__ __forceinline__ void compact_stream(const FdbCompactRec* __restrict__
                                                const int64_t first, const int64_t stride, const uint32_t* __restrict__ masks, const uint32_t* __restrict__ tile_offsets,
                                                const unsigned long long* __restrict__ rec_base, const int64_t total_tiles, unsigned long long* __restrict__ null_counts,
                                                unsigned char* stage, const int lane, const int spread) {
-  constexpr int R = 4, NS = CompactUnit<W>::NS, STEP_ROWS = NS * FDB_COMPACT_SUBTILE, Q = FDB_COMPACT_TILE / STEP_ROWS;
+  constexpr int G = CompactUnit<W>::G, STEP_ROWS = G * 64, Q = FDB_COMPACT_TILE / STEP_ROWS;
   // staging region of the wave: STEP_ROWS values, 64 dump slots (where a lane parks rows that are not selected), then one validity
   // byte per value slot
   constexpr uint32_t DUMP = STEP_ROWS;
@@ -1720,7 +1732,7 @@ __device__ __forceinline__ void compact_stream(const FdbCompactRec* __restrict__
   // issue side: the record of `tile` (scalars)
   int rec = -1;
   int64_t rec_begin = 0, rec_end = 0, rec_rows = 0;
-  uint32_t rec_off = 0;
+  uint32_t rec_off = 0, last_vword = 0;
   const void* src = nullptr; const uint8_t* src_valid = nullptr; void* dst = nullptr; uint8_t* dst_valid = nullptr;
   int64_t tile = first;
   int q = 0;
@@ -1739,25 +1751,34 @@ __device__ __forceinline__ void compact_stream(const FdbCompactRec* __restrict__
       rec_begin = s_recs[rec].tile_begin; rec_rows = s_recs[rec].n_rows;
       rec_end = rec + 1 < n_recs ? s_recs[rec + 1].tile_begin : total_tiles;
       rec_off = (uint32_t)((const FDB_CONST unsigned long long*)rec_base)[rec];
+      last_vword = rec_rows > 0 ? (uint32_t)((rec_rows - 1) >> 6) : 0u;
       const FDB_CONST FdbCompactCol* cd = (const FDB_CONST FdbCompactCol*)cols + ((size_t)rec * n_cols + col);
       src = cd->src; src_valid = cd->src_valid; dst = cd->dst; dst_valid = cd->dst_valid;
     }
-    const int64_t row0 = (tile - rec_begin) * FDB_COMPACT_TILE + (int64_t)q * STEP_ROWS + (int64_t)lane * R;
-#pragma unroll
-    for (int u = 0; u < NS; u++) {
-      const uint32_t w = __shfl(word, (q * NS + u) * 8 + (lane >> 3), 64);
-      const int64_t left = rec_rows - (row0 + (int64_t)u * FDB_COMPACT_SUBTILE);
-      U.sel[u] = (w >> ((lane & 7) * 4)) & (left >= R ? 0xFu : left > 0 ? ((1u << (int)left) - 1u) : 0u);
+    const int64_t step_row0 = (tile - rec_begin) * FDB_COMPACT_TILE + (int64_t)q * STEP_ROWS;
+    if (q == 0) {  // a new tile: bits of rows past the record's end are cleared once, in the per-lane copy (lane k: rows [32 k, 32 k + 32) of the tile)
+      const int64_t lane_left = rec_rows - step_row0 - (int64_t)lane * 32;
+      word &= lane_left >= 32 ? ~0u : lane_left > 0 ? (1u << (int)lane_left) - 1u : 0u;
     }
-    // straight-line loads: a lane without selected rows reads the column's first bytes (one cached line for all such lanes) instead
-    // of being branched around — with a branch per load the compiler waits for every load before it issues the next
+    // the step's loads are (scalar base + 32-bit lane offset); a step wholly past the record's end (the last tiles of a record's
+    // last group of 4) selects nothing and reads the column's first value
+    const char* step_base = reinterpret_cast<const char*>(src) + (step_row0 < rec_rows ? step_row0 * W : 0);
+    // straight-line loads, one row per lane and group (lane l: row 64 j + l — a group is one contiguous 256- or 512-byte read): a lane
+    // whose row is not selected reads the step's first value (one cached line for all such lanes) instead of being branched around —
+    // with a branch per load the compiler waits for every load before it issues the next
 #pragma unroll
-    for (int u = 0; u < NS; u++) {
-      const int64_t r = U.sel[u] ? row0 + (int64_t)u * FDB_COMPACT_SUBTILE : 0;
-      U.vbyte[u] = NULLABLE ? (uint32_t)as_global(src_valid)[r >> 3] : 0xFFu;
-      if (W == 4) load_u32<R>(reinterpret_cast<const uint32_t*>(src) + r, U.x4[u]);
-      else load_u64<R>(reinterpret_cast<const unsigned long long*>(src) + r, U.x8[u]);
+    for (int j = 0; j < G; j++) {
+      const bool on = __builtin_amdgcn_inverse_ballot_w64(compact_group_word(word, q * G + j));
+      const uint32_t off = on ? (uint32_t)(j * 64 + lane) * (uint32_t)W : 0u;
+      if (W == 4) U.x4[j] = __builtin_nontemporal_load(as_global(reinterpret_cast<const uint32_t*>(step_base + off)));
+      else U.x8[j] = __builtin_nontemporal_load(as_global(reinterpret_cast<const unsigned long long*>(step_base + off)));
     }
+    if (NULLABLE) {  // the step's G validity words, one per lane (bitmaps are 256-byte aligned and padded: fdb_plan.cpp kTailPad)
+      uint32_t vw = (uint32_t)(step_row0 >> 6) + (lane < G ? (uint32_t)lane : 0u);
+      vw = vw < last_vword ? vw : last_vword;
+      U.vword = as_global(reinterpret_cast<const unsigned long long*>(src_valid))[vw];
+    }
+    U.word = word;
     U.dst = dst; U.dst_valid = dst_valid; U.out0 = toff - rec_off; U.q = q; U.rec = rec;
     if (++q == Q) {
       q = 0; tile += stride; word = word_nx; toff = toff_nx;
@@ -1777,59 +1798,43 @@ __device__ __forceinline__ void compact_stream(const FdbCompactRec* __restrict__
   auto process = [&](const CompactUnit<W>& U) {  // positions → staging → coalesced stores
     if (U.q == 0) out = U.out0;
     if (U.rec != nulls_rec) { flush_nulls(); nulls_rec = U.rec; }
-    uint32_t pos[NS], total = 0;
-#pragma unroll
-    for (int u = 0; u < NS; u++) {
-      uint32_t p = total;
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        const unsigned long long b = __ballot((U.sel[u] >> r) & 1u);
-        p += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        total += (uint32_t)__popcll(b);
-      }
-      pos[u] = p;
-    }
-    if (total == 0u) return;  // (wave-uniform)
-    // NULLs are rare: a step in which every selected row is valid (one ballot) sets its run of output validity bits arithmetically,
-    // one 64-bit word per lane, and stages no validity bytes at all
+    // the selection words ARE the ballots: positions are scalar prefix sums + one mbcnt per group, ready before the loads are
+    // NULLs are rare: a step in which every selected row is valid sets its run of output validity bits arithmetically, one 64-bit
+    // word per lane, and stages no validity bytes at all
     bool all_valid = true;
-    uint32_t valid[NS];
+    if (NULLABLE) {  // lane j < G looks at group j: its selection word (two lanes of the tile's bitmap) against its validity word
+      const int k2 = 2 * (U.q * G + (lane & (G - 1)));
+      const unsigned long long selw = (unsigned long long)(uint32_t)__shfl((int)U.word, k2, 64) | ((unsigned long long)(uint32_t)__shfl((int)U.word, k2 + 1, 64) << 32);
+      const unsigned long long missing = lane < G ? selw & ~U.vword : 0ull;
+      all_valid = __ballot(missing != 0ull) == 0ull;
+      my_nulls += (uint32_t)__popcll(missing);
+    }
+    uint32_t base = 0;
+    if (!NULLABLE || all_valid) {
 #pragma unroll
-    for (int u = 0; u < NS; u++) valid[u] = NULLABLE ? (U.vbyte[u] >> ((lane & 1) * 4)) & 0xFu : 0xFu;  // (a lane's 4 rows are one nibble of their validity byte)
-    if (NULLABLE) {
-      uint32_t missing = 0;
+      for (int j = 0; j < G; j++) {
+        const unsigned long long sel = compact_group_word(U.word, U.q * G + j);
+        const uint32_t p = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
+        const uint32_t at = __builtin_amdgcn_inverse_ballot_w64(sel) ? p : DUMP + (uint32_t)lane;  // (no branch: rows that are not selected are parked in the lane's dump slot)
+        if (W == 4) reinterpret_cast<uint32_t*>(stage)[at] = U.x4[j];
+        else reinterpret_cast<unsigned long long*>(stage)[at] = U.x8[j];
+        base += (uint32_t)__popcll(sel);
+      }
+    } else {
 #pragma unroll
-      for (int u = 0; u < NS; u++) missing |= U.sel[u] & ~valid[u];
-      all_valid = __ballot(missing != 0u) == 0ull;
-      if (!all_valid) {
-#pragma unroll
-        for (int u = 0; u < NS; u++) my_nulls += __popc(U.sel[u] & ~valid[u]);
+      for (int j = 0; j < G; j++) {
+        const unsigned long long sel = compact_group_word(U.word, U.q * G + j);
+        const uint32_t p = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
+        const uint32_t at = __builtin_amdgcn_inverse_ballot_w64(sel) ? p : DUMP + (uint32_t)lane;
+        const bool ok = __builtin_amdgcn_inverse_ballot_w64(readlane_u64(U.vword, j));
+        if (W == 4) reinterpret_cast<uint32_t*>(stage)[at] = ok ? U.x4[j] : 0u;
+        else reinterpret_cast<unsigned long long*>(stage)[at] = U.x8[j];
+        stage_valid[at] = ok ? (uint8_t)1 : (uint8_t)0;
+        base += (uint32_t)__popcll(sel);
       }
     }
-#pragma unroll
-    for (int u = 0; u < NS; u++) {
-      uint32_t p = pos[u];
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        const bool on = (U.sel[u] >> r) & 1u;
-        const uint32_t at = on ? p : DUMP + (uint32_t)lane;  // (no branch: rows that are not selected are parked in the lane's dump slot)
-        if (W == 4) reinterpret_cast<uint32_t*>(stage)[at] = ((valid[u] >> r) & 1u) ? U.x4[u][r] : 0u;
-        else reinterpret_cast<unsigned long long*>(stage)[at] = U.x8[u][r];
-        p += on ? 1u : 0u;
-      }
-    }
-    if (NULLABLE && !all_valid) {
-#pragma unroll
-      for (int u = 0; u < NS; u++) {
-        uint32_t p = pos[u];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-          const bool on = (U.sel[u] >> r) & 1u;
-          stage_valid[on ? p : DUMP + (uint32_t)lane] = (uint8_t)((valid[u] >> r) & 1u);
-          p += on ? 1u : 0u;
-        }
-      }
-    }
+    const uint32_t total = base;
+    if (total == 0u) return;  // (wave-uniform; only dump slots were written)
     __builtin_amdgcn_wave_barrier();
     // the staged values leave 16 bytes per lane and instruction: every LDS read of the step is issued before the first store
     constexpr int CHUNKS = STEP_ROWS * W / 16 / 64;  // 4
@@ -1904,6 +1909,7 @@ __device__ __forceinline__ void compact_stream(const FdbCompactRec* __restrict__
   flush_nulls();
 }
 
+template <bool ANY_NULLABLE>  // (a launch without nullable columns runs the leaner code: fewer registers, one more wave per SIMD)
 __global__ __launch_bounds__(FDB_COMPACT_BLOCK) void compact_multi_kernel(const FdbCompactRec* __restrict__ recs, const int n_recs, const FdbCompactCol* __restrict__ cols,
                                                                           const int n_cols, const int32_t* __restrict__ col_wave_begin, const uint32_t* __restrict__ masks,
                                                                           const uint32_t* __restrict__ tile_offsets, const unsigned long long* __restrict__ rec_base,
@@ -1924,8 +1930,8 @@ __global__ __launch_bounds__(FDB_COMPACT_BLOCK) void compact_multi_kernel(const 
   // carries a bitmap for the column and passes all-ones bitmaps otherwise — see Plan::filter_batches)
   const int width = __builtin_amdgcn_readfirstlane(cols[col].width), nullable = __builtin_amdgcn_readfirstlane(cols[col].nullable);
 #define FDB_RUN(W, N) compact_stream<W, N>(recs, n_recs, cols, n_cols, col, first, stride, masks, tile_offsets, rec_base, total_tiles, null_counts, stage, lane, g & 63)
-  if (width == 8) { if (nullable) FDB_RUN(8, true); else FDB_RUN(8, false); }
-  else { if (nullable) FDB_RUN(4, true); else FDB_RUN(4, false); }
+  if (width == 8) { if (ANY_NULLABLE && nullable) FDB_RUN(8, true); else FDB_RUN(8, false); }
+  else { if (ANY_NULLABLE && nullable) FDB_RUN(4, true); else FDB_RUN(4, false); }
 #undef FDB_RUN
 }
 
@@ -2193,23 +2199,28 @@ hipError_t fdb_launch_zero_regions(const FdbZeroRegion* regions, int n_regions, 
   return hipGetLastError();
 }
 
-int fdb_compact_multi_blocks_per_cu(void) {  // workgroups of compact_multi_kernel resident on one CU (registers and LDS): a wave's share of tiles is fixed at launch,
-  static const int n = [] {                   // so the launch must not be larger than what runs at once
+int fdb_compact_multi_blocks_per_cu(int any_nullable) {  // workgroups of compact_multi_kernel resident on one CU (registers and LDS): a wave's share of tiles is fixed at
+  static const int n[2] = {[] {                          // launch, so the launch must not be larger than what runs at once
     int b = 0;
     const size_t lds = (size_t)(FDB_COMPACT_BLOCK / 64) * FDB_COMPACT_STREAM_WAVE_LDS;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, compact_multi_kernel, FDB_COMPACT_BLOCK, lds) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, compact_multi_kernel<false>, FDB_COMPACT_BLOCK, lds) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; }
     return b;
-  }();
-  return n;
+  }(), [] {
+    int b = 0;
+    const size_t lds = (size_t)(FDB_COMPACT_BLOCK / 64) * FDB_COMPACT_STREAM_WAVE_LDS;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, compact_multi_kernel<true>, FDB_COMPACT_BLOCK, lds) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 4; }
+    return b;
+  }()};
+  return n[any_nullable ? 1 : 0];
 }
 
-hipError_t fdb_launch_compact_multi(const FdbCompactRec* recs, int n_recs, const FdbCompactCol* cols, int n_cols, const int32_t* col_wave_begin, int n_waves,
+hipError_t fdb_launch_compact_multi(const FdbCompactRec* recs, int n_recs, const FdbCompactCol* cols, int n_cols, int any_nullable, const int32_t* col_wave_begin, int n_waves,
                                     const uint32_t* masks, const uint32_t* tile_offsets, const unsigned long long* rec_base, int64_t total_tiles,
                                     unsigned long long* null_counts, hipStream_t stream) {
   if (total_tiles <= 0 || n_cols <= 0 || n_recs <= 0 || n_waves <= 0) return hipSuccess;
   const size_t lds = (size_t)(FDB_COMPACT_BLOCK / 64) * FDB_COMPACT_STREAM_WAVE_LDS;
-  hipLaunchKernelGGL(compact_multi_kernel, dim3((unsigned)((n_waves + 3) / 4)), dim3(FDB_COMPACT_BLOCK), lds, stream, recs, n_recs, cols, n_cols, col_wave_begin, masks, tile_offsets,
-                     rec_base, total_tiles, null_counts);
+  hipLaunchKernelGGL(any_nullable ? compact_multi_kernel<true> : compact_multi_kernel<false>, dim3((unsigned)((n_waves + 3) / 4)), dim3(FDB_COMPACT_BLOCK), lds, stream, recs, n_recs,
+                     cols, n_cols, col_wave_begin, masks, tile_offsets, rec_base, total_tiles, null_counts);
   return hipGetLastError();
 }
 

@@ -2259,20 +2259,26 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
     }
   }
   std::vector<unsigned long long> h_nulls(nl * n_cols * 64, 0);
+  int any_nullable = 0;
+  for (size_t c = 0; c < n_cols; c++) any_nullable |= nullable[c] ? 1 : 0;
   if (any_selected > 0) {
-    unsigned long long* d_nulls = (unsigned long long*)ctx_->dev_alloc(h_nulls.size() * 8);
-    scratch_.push_back(d_nulls);
-    regions.push_back(FdbZeroRegion{d_nulls, (int64_t)(h_nulls.size() * 8)});
-    max_region = std::max<int64_t>(max_region, (int64_t)(h_nulls.size() * 8));
+    // NULL counts and validity bitmaps exist only when some column has a bitmap: without one there is nothing to zero, count or copy back
+    unsigned long long* d_nulls = nullptr;
+    if (any_nullable) {
+      d_nulls = (unsigned long long*)ctx_->dev_alloc(h_nulls.size() * 8);
+      scratch_.push_back(d_nulls);
+      regions.push_back(FdbZeroRegion{d_nulls, (int64_t)(h_nulls.size() * 8)});
+      max_region = std::max<int64_t>(max_region, (int64_t)(h_nulls.size() * 8));
+    }
     const FdbCompactCol* d_cols = (const FdbCompactCol*)upload(cols.data(), cols.size() * sizeof(FdbCompactCol));
-    const FdbZeroRegion* d_regions = (const FdbZeroRegion*)upload(regions.data(), regions.size() * sizeof(FdbZeroRegion));
+    const FdbZeroRegion* d_regions = regions.empty() ? nullptr : (const FdbZeroRegion*)upload(regions.data(), regions.size() * sizeof(FdbZeroRegion));
     // waves are dealt to the columns in proportion to their bytes per row (a wave stays on its column for the whole launch):
     // 1.5 × the workgroups of 4 waves that are resident at once (a wave's share of tiles is fixed at launch: smaller shares even out
     // the waves that finish late — measured 8 % faster than exactly-resident; handing tiles out dynamically, one ticket per tile or per
     // 8 tiles on a per-column counter, was slower: 2.5 ms and 1.08 ms against 0.90), at least one wave per column, never more waves
     // than a column has tiles
     static const int env_per_cu = std::getenv("FDB_COMPACT_BLOCKS_PER_CU") ? std::atoi(std::getenv("FDB_COMPACT_BLOCKS_PER_CU")) : 0;  // (tuning aid)
-    const int64_t budget = (int64_t)(fdb_scan_default_grid(device_) / 2) * (env_per_cu > 0 ? env_per_cu : (fdb_compact_multi_blocks_per_cu() * 3 + 1) / 2) * 4;
+    const int64_t budget = (int64_t)(fdb_scan_default_grid(device_) / 2) * (env_per_cu > 0 ? env_per_cu : (fdb_compact_multi_blocks_per_cu(any_nullable) * 3 + 1) / 2) * 4;
     int64_t weight_sum = 0;
     for (size_t c = 0; c < n_cols; c++) weight_sum += cols[c].width;
     std::vector<int32_t> wave_begin(n_cols + 1, 0);
@@ -2283,15 +2289,15 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
     }
     const int32_t* d_wave_begin = (const int32_t*)upload(wave_begin.data(), wave_begin.size() * 4);
     timed([&] {
-      hip_check(fdb_launch_zero_regions(d_regions, (int)regions.size(), max_region, stream_), "zero launch");
-      hip_check(fdb_launch_compact_multi(d_recs, (int)nl, d_cols, (int)n_cols, d_wave_begin, wave_begin[n_cols], d_masks, d_offsets, d_rec_base, total_tiles, d_nulls, stream_),
+      if (!regions.empty()) hip_check(fdb_launch_zero_regions(d_regions, (int)regions.size(), max_region, stream_), "zero launch");
+      hip_check(fdb_launch_compact_multi(d_recs, (int)nl, d_cols, (int)n_cols, any_nullable, d_wave_begin, wave_begin[n_cols], d_masks, d_offsets, d_rec_base, total_tiles, d_nulls, stream_),
                 "compact launch");
     });
-    hip_check(hipMemcpyAsync(h_nulls.data(), d_nulls, h_nulls.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
+    if (any_nullable) hip_check(hipMemcpyAsync(h_nulls.data(), d_nulls, h_nulls.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   }
   last_kernel_ = "fdb_flags_kernel + compact_multi_kernel";
-  stat_launches += (any_selected > 0 ? 4 : 2) + (two_level ? 1 : 0);
+  stat_launches += (any_selected > 0 ? (any_nullable ? 4 : 3) : 2) + (two_level ? 1 : 0);
   for (size_t k = 0; k < nl; k++) {
     const DeviceBatch& src = *in[live[k]];
     DeviceBatch& o = *out[(size_t)live[k]];

@@ -1,7 +1,7 @@
 """Tuning aid: times fdb_plan_filter_batches (value > 500 over 4 × 25 M resident rows) without checking results — for kernel
 variants that deliberately break them (FDB_COMPACT_BLOCKS_PER_CU). Prints kernel ms per pass (hipEvents) and wall ms."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("FDB_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (FDB_PKG_ROOT: A/B against another build of the package)
 import torch
 from frostdb_amd import physicalplan as pp, synth
 from frostdb_amd.logicalplan import Col
@@ -16,7 +16,9 @@ def step(timing=False):
     for o in outs: o.close()
     return st
 step(); step()
-torch.cuda.synchronize(); t0 = time.perf_counter(); k = 0.0
-for _ in range(5): k += step(True)["kernel_ms"]
+N = int(os.environ.get("FDB_PROBE_PASSES", "30"))
+torch.cuda.synchronize(); t0 = time.perf_counter(); ks = []
+for _ in range(N): ks.append(step(True)["kernel_ms"])
 torch.cuda.synchronize()
-print(os.environ.get("FDB_COMPACT_BLOCKS_PER_CU", "0"), "kernel_ms", round(k / 5, 4), "wall_ms", round((time.perf_counter() - t0) / 5 * 1e3, 4))
+ks.sort()
+print(os.environ.get("FDB_COMPACT_BLOCKS_PER_CU", "0"), "kernel_ms median", round(ks[N // 2], 4), "min", round(ks[0], 4), "wall_ms", round((time.perf_counter() - t0) / N * 1e3, 4))
