@@ -427,6 +427,8 @@ bool Plan::comm_allreduce(Comm& comm) {
   if (local) std::rethrow_exception(local);
   if (v[0] == INT64_MAX && v[1] == INT64_MAX) throw Error(FDB_ERR_STATE, "all-reduce merge abandoned: another rank failed before the collective");
   if (v[0] != -v[1] || v[2] != -v[3] || v[2] == 0) return false;
+  materialize_state();  // (a rank that scanned nothing still holds an unfilled table)
+  mirror_valid_ = false;
   std::vector<Comm::Red> reds;
   for (int32_t a = 0; a < num_state_arrays(); a++) {
     const int32_t op = state_array_op(a);

@@ -162,6 +162,8 @@ void Plan::switch_to_hash() {
   }
   ctx_->dev_free(d_state_);
   d_state_ = nullptr; d_cnt_ = nullptr;
+  state_virgin_ = false;
+  mirror_valid_ = false;
   for (AggState& a : aggs_) a.d_acc = nullptr;
   slots_alloc_ = 0; n_slots_ = 1;
 }

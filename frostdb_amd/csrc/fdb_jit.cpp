@@ -261,6 +261,8 @@ struct Gen {
     o << "#include \"fdb_kernels.h\"\n" << kPreamble;
     o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") void fdb_plan_kernel(const FdbScanArgs* __restrict__ parts, const int n_parts, const long long total_tiles, const FdbScanArgs c) {\n";
     o << "  extern __shared__ __align__(16) unsigned char smem[];\n  const uint32_t tid = threadIdx.x;\n  const uint32_t n_slots = c.n_slots;\n";
+    o << "  if (c.fill_state != nullptr)  // (a fresh table: its identity fill rides on this launch, see FdbScanArgs)\n";
+    o << "    for (uint32_t i = blockIdx.x * " << BLK << "u + tid; i < c.fill_words; i += gridDim.x * " << BLK << "u) c.fill_state[i] = c.fill_idents[i / c.fill_alloc];\n";
     o << "  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(smem + c.lds_lut_bytes);\n";
     o << "  unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + c.lds_lut_bytes + (((size_t)n_slots * 4 + 15) & ~(size_t)15));\n";
     if (s.lds_acc) {

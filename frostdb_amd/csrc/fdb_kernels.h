@@ -144,6 +144,13 @@ struct FdbScanArgs {
                             // LDS combining cache [tag u32 | count u32 | acc u64 × n_aggs] placed after the LUT copies; 0: none
   FdbExprNode expr[FDB_MAX_EXPR_NODES];
   int64_t out_tile_base;    // fdb_flags_kernel only: the record's first tile in the launch-wide mask / count arrays
+  // fdb_plan_kernel only, read from the by-value copy: a table that no kernel has touched yet gets its identity fill from the FIRST
+  // scan launch itself (the partial tables are folded into it by the next kernel on the stream) instead of a launch of its own in
+  // front of the scan — 6 µs + a dispatch gap of a 125 M-row shard's 350 µs step. nullptr: nothing to fill.
+  unsigned long long* fill_state;
+  uint32_t fill_words;      // slots allocated × arrays
+  uint32_t fill_alloc;      // slots allocated per array: word i belongs to array i / fill_alloc
+  unsigned long long fill_idents[1 + FDB_MAX_AGGS];
 };
 
 // ---- high-cardinality path: global open-addressing hash table -------------------------------------------------
@@ -346,9 +353,10 @@ hipError_t fdb_launch_scan_dense(const FdbScanArgs& args, int grid_blocks, size_
 // Number of workgroups fdb_launch_scan_dense will actually launch for `grid_blocks` requested (clamped to the tile count).
 int fdb_scan_grid(const FdbScanArgs& args, int grid_blocks, int rows_per_thread);
 // Folds the per-workgroup partial tables into the global table: state[arr * state_stride + slot] (op)= Σ_b partials[b][arr][slot].
-// funcs[arr]: 0 skip, 1 add u64, 2 add f64, 3 min i64, 4 max i64.
+// funcs[arr]: 0 skip, 1 add u64, 2 add f64, 3 min i64, 4 max i64. host_out (nullptr: none): pinned host memory laid out like `state`
+// that receives every updated slot (and the untouched contents of the skipped arrays) — the table's host copy without a copy command.
 hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_blocks, int n_arrays, uint32_t n_slots,
-                                      unsigned long long* state, uint64_t state_stride, const int32_t* funcs, hipStream_t stream);
+                                      unsigned long long* state, uint64_t state_stride, const int32_t* funcs, unsigned long long* host_out, hipStream_t stream);
 // The slot kernel over `n_parts` records in ONE launch. `d_parts` is the device copy of the per-record argument
 // blocks (global tile ranges filled in, in units of fdb_slot_geometry's tile_rows); `common` = any of them (table
 // pointers, aggregation functions, LDS layout are identical across records). sub_tiles: 1 or 2.

@@ -1219,57 +1219,64 @@ __global__ void fill_state_kernel(unsigned long long* base, int64_t n, int n_arr
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) base[i] = idents.v[i / n];
 }
 
-// Folds the per-workgroup partial tables into the global table. grid = (slot tiles of 64, arrays, splits): one
-// workgroup covers 64 consecutive slots of one array for a contiguous run of tables; each of its 4 waves keeps
-// ≈16 independent coalesced loads in flight, the waves combine through LDS and ONE atomic per slot per split
-// lands in the table — the whole fold is one memory round trip wide (≈3 µs for 1 024 tables × 1 025 slots).
-#define REDUCE_SPLITS 16
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const unsigned long long* __restrict__ partials, int n_blocks, int n_arrays,
-                                                              uint32_t n_slots, unsigned long long* state, uint64_t state_stride,
-                                                              FillIdents funcs) {
-  __shared__ unsigned long long part[4][64];
-  const int arr = blockIdx.y;
-  const int f = (int)funcs.v[arr];
-  if (f == 0) return;
+// Folds the per-workgroup partial tables into the global table. grid = (slot tiles of 64, arrays): one workgroup of 16 waves
+// covers 64 consecutive slots of one array; each wave folds a contiguous run of tables with ≈16 independent coalesced loads in
+// flight, the waves combine through LDS in wave order and wave 0 updates the table with a PLAIN read-modify-write — nothing else
+// touches these slots during the launch, so no atomics, and the order of a float sum is fixed by the launch geometry. The
+// updated value also goes to `host_out` (pinned host memory, same layout as the table; nullptr: none): Finish then needs no copy
+// command of its own — the 16 KB device→host copy of a 1 025-slot table was 15 µs on the stream, this kernel is ≈5.
+// (An earlier version split the tables over grid.z = 16 workgroups of 4 waves with one atomic per slot and split.)
+template <int F>
+__device__ __forceinline__ unsigned long long reduce_fold(unsigned long long a, unsigned long long v) {
+  if (F == 1) return a + v;
+  if (F == 2) return (unsigned long long)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)v));
+  if (F == 3) return (unsigned long long)min((long long)a, (long long)v);
+  return (unsigned long long)max((long long)a, (long long)v);
+}
+template <int F>
+__device__ __forceinline__ void reduce_partials_body(const unsigned long long* __restrict__ partials, const int n_blocks, const int n_arrays, const uint32_t n_slots,
+                                                     unsigned long long* dst, unsigned long long* host_dst, const uint32_t slot, const int arr,
+                                                     unsigned long long (*part)[64]) {
+  constexpr int NW = 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t slot = blockIdx.x * 64 + lane;
-  const int per_split = (n_blocks + REDUCE_SPLITS - 1) / REDUCE_SPLITS;
-  const int s0 = blockIdx.z * per_split, s1 = min(n_blocks, s0 + per_split);
-  const int per_wave = (s1 - s0 + 3) / 4;
-  const int b0 = s0 + wave * per_wave, b1 = min(s1, b0 + per_wave);
-  const unsigned long long ident = f == 3 ? (unsigned long long)FDB_I64_MAX : f == 4 ? (unsigned long long)FDB_I64_MIN : 0ull;
-  unsigned long long acc = ident;
+  const int per_wave = (n_blocks + NW - 1) / NW;
+  const int b0 = wave * per_wave, b1 = min(n_blocks, b0 + per_wave);
+  const unsigned long long ident = F == 3 ? (unsigned long long)FDB_I64_MAX : F == 4 ? (unsigned long long)FDB_I64_MIN : 0ull;
+  unsigned long long acc = ident, t = ident;
   if (slot < n_slots) {
+    if (wave == 0) t = *dst;  // (in flight together with the first tables)
     const unsigned long long* p = partials + (size_t)arr * n_slots + slot;
     const size_t stride = (size_t)n_arrays * n_slots;
-#pragma unroll 16
-    for (int b = b0; b < b1; b++) {
-      const unsigned long long v = p[(size_t)b * stride];
-      if (f == 1) acc += v;
-      else if (f == 2) acc = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)acc) + __longlong_as_double((long long)v));
-      else if (f == 3) acc = (unsigned long long)min((long long)acc, (long long)v);
-      else acc = (unsigned long long)max((long long)acc, (long long)v);
-    }
+#pragma unroll 32
+    for (int b = b0; b < b1; b++) acc = reduce_fold<F>(acc, p[(size_t)b * stride]);
   }
   part[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && slot < n_slots) {
-    unsigned long long t = part[0][lane];
-    for (int w = 1; w < 4; w++) {
-      const unsigned long long v = part[w][lane];
-      if (f == 1) t += v;
-      else if (f == 2) t = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)t) + __longlong_as_double((long long)v));
-      else if (f == 3) t = (unsigned long long)min((long long)t, (long long)v);
-      else t = (unsigned long long)max((long long)t, (long long)v);
-    }
-    unsigned long long* dst = state + (size_t)arr * state_stride + slot;
-    if (t != ident || f == 2) {
-      if (f == 1) atomicAdd(dst, t);
-      else if (f == 2) { if (__longlong_as_double((long long)t) != 0.0) atomicAdd(reinterpret_cast<double*>(dst), __longlong_as_double((long long)t)); }
-      else if (f == 3) atomicMin(reinterpret_cast<long long*>(dst), (long long)t);
-      else atomicMax(reinterpret_cast<long long*>(dst), (long long)t);
-    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) t = reduce_fold<F>(t, part[w][lane]);
+    *dst = t;
+    if (host_dst != nullptr) *host_dst = t;
   }
+}
+
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const unsigned long long* __restrict__ partials, int n_blocks, int n_arrays,
+                                                               uint32_t n_slots, unsigned long long* state, uint64_t state_stride,
+                                                               FillIdents funcs, unsigned long long* __restrict__ host_out) {
+  __shared__ unsigned long long part[16][64];
+  const int arr = blockIdx.y;
+  const int f = (int)funcs.v[arr];
+  const uint32_t slot = blockIdx.x * 64 + (threadIdx.x & 63);
+  unsigned long long* dst = state + (size_t)arr * state_stride + slot;
+  unsigned long long* host_dst = host_out != nullptr ? host_out + (size_t)arr * state_stride + slot : nullptr;
+  if (f == 0) {  // (an array no aggregation folds into: the host copy still gets its contents)
+    if (host_dst != nullptr && threadIdx.x < 64 && slot < n_slots) *host_dst = *dst;
+    return;
+  }
+  if (f == 1) reduce_partials_body<1>(partials, n_blocks, n_arrays, n_slots, dst, host_dst, slot, arr, part);
+  else if (f == 2) reduce_partials_body<2>(partials, n_blocks, n_arrays, n_slots, dst, host_dst, slot, arr, part);
+  else if (f == 3) reduce_partials_body<3>(partials, n_blocks, n_arrays, n_slots, dst, host_dst, slot, arr, part);
+  else reduce_partials_body<4>(partials, n_blocks, n_arrays, n_slots, dst, host_dst, slot, arr, part);
 }
 
 __global__ void merge_u64_kernel(unsigned long long* dst, const unsigned long long* src, const uint32_t* map, int64_t n,
@@ -1957,12 +1964,12 @@ int fdb_scan_grid(const FdbScanArgs& args, int grid_blocks, int rows_per_thread)
 }
 
 hipError_t fdb_launch_reduce_partials(const unsigned long long* partials, int n_blocks, int n_arrays, uint32_t n_slots,
-                                      unsigned long long* state, uint64_t state_stride, const int32_t* funcs, hipStream_t stream) {
+                                      unsigned long long* state, uint64_t state_stride, const int32_t* funcs, unsigned long long* host_out, hipStream_t stream) {
   if (n_blocks <= 0 || n_slots == 0) return hipSuccess;
   FillIdents f;
   for (int a = 0; a < 1 + FDB_MAX_AGGS; a++) f.v[a] = a < n_arrays ? (unsigned long long)funcs[a] : 0ull;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_slots + 63) / 64, n_arrays, REDUCE_SPLITS), dim3(256), 0, stream, partials, n_blocks,
-                     n_arrays, n_slots, state, state_stride, f);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((n_slots + 63) / 64, n_arrays), dim3(1024), 0, stream, partials, n_blocks, n_arrays, n_slots, state, state_stride, f,
+                     host_out);
   return hipGetLastError();
 }
 

@@ -424,6 +424,8 @@ Plan::~Plan() {
   (void)hipStreamSynchronize(stream_);
   for (auto& p : pending_events_) { ctx_->put_event(p.first); ctx_->put_event(p.second); }
   for (auto& p : merge_events_) { ctx_->put_event(p.first); ctx_->put_event(p.second); }
+  for (auto& t : trace_) (void)hipEventDestroy(t.second);
+  if (h_mirror_ != nullptr) ctx_->host_free(h_mirror_);
   ctx_->dev_free(d_state_);
   ctx_->dev_free(h_table_);
   ctx_->dev_free(h_keys_);
@@ -516,7 +518,51 @@ void Plan::sync() {
   inflight_.clear();  // (their arenas go back to the block cache)
 }
 
+void Plan::state_idents(unsigned long long* idents) const {
+  idents[0] = 0ull;
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    const int32_t f = aggs_[j].func;
+    idents[1 + j] = f == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : f == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
+  }
+}
+
+unsigned long long* Plan::mirror_target() {
+  constexpr size_t kMaxMirror = (size_t)256 << 10;
+  static const bool off = std::getenv("FDB_NO_HOST_MIRROR") != nullptr;  // (A/B aid)
+  const size_t bytes = (size_t)slots_alloc_ * 8 * (1 + aggs_.size());
+  if (off || d_state_ == nullptr || bytes == 0 || bytes > kMaxMirror) return nullptr;
+  if (h_mirror_ != nullptr && mirror_bytes_ != bytes) { ctx_->host_free(h_mirror_); h_mirror_ = nullptr; }
+  if (h_mirror_ == nullptr) { h_mirror_ = (unsigned long long*)ctx_->host_alloc(bytes); mirror_bytes_ = bytes; }
+  return h_mirror_;
+}
+
+void Plan::materialize_state() {
+  if (!state_virgin_ || d_state_ == nullptr) { state_virgin_ = false; return; }
+  unsigned long long idents[1 + FDB_MAX_AGGS];
+  state_idents(idents);
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  hip_check(fdb_launch_fill_state(d_state_, (int64_t)slots_alloc_, (int)(1 + aggs_.size()), idents, stream_), "fill state");
+  state_virgin_ = false;
+}
+
+void Plan::trace(const char* what) {
+  if (std::getenv("FDB_PROFILE") == nullptr) return;
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  if (hipEventRecord(e, stream_) != hipSuccess) { (void)hipEventDestroy(e); return; }
+  trace_.emplace_back(what, e);
+}
+
 void Plan::collect_timing() {
+  if (!trace_.empty()) {
+    for (size_t i = 1; i < trace_.size(); i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, trace_[i - 1].second, trace_[i].second) == hipSuccess)
+        std::fprintf(stderr, "[fdb] stream: %-24s → %-24s %8.1f us\n", trace_[i - 1].first, trace_[i].first, ms * 1e3);
+    }
+    for (auto& t : trace_) (void)hipEventDestroy(t.second);
+    trace_.clear();
+  }
   for (auto& p : pending_events_) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) stat_ms += ms;
@@ -875,13 +921,15 @@ void Plan::ensure_layout(const std::vector<uint32_t>& new_caps) {
     const uint64_t alloc = (remap && state_dirty_) ? cap : std::max<uint64_t>(cap, slots_alloc_ * 2);
     const size_t n_arrays = 1 + aggs_.size();
     unsigned long long* n_state = (unsigned long long*)ctx_->dev_alloc(alloc * 8 * n_arrays);
-    unsigned long long idents[1 + FDB_MAX_AGGS] = {0};
-    for (size_t j = 0; j < aggs_.size(); j++) {
-      const int32_t f = aggs_[j].func;
-      idents[1 + j] = f == FDB_AGG_MIN ? (unsigned long long)FDB_I64_MAX : f == FDB_AGG_MAX ? (unsigned long long)FDB_I64_MIN : 0ull;
+    mirror_valid_ = false;
+    const bool carry = state_dirty_ && d_state_ != nullptr;  // the old table holds groups: they move into the new one, which must be filled first
+    if (carry) {
+      unsigned long long idents[1 + FDB_MAX_AGGS];
+      state_idents(idents);
+      hip_check(fdb_launch_fill_state(n_state, (int64_t)alloc, (int)n_arrays, idents, stream_), "fill state");
     }
-    hip_check(fdb_launch_fill_state(n_state, (int64_t)alloc, (int)n_arrays, idents, stream_), "fill state");
-    if (state_dirty_ && d_state_ != nullptr) {
+    state_virgin_ = !carry;  // (otherwise filled lazily: by the first scan launch itself, or by materialize_state())
+    if (carry) {
       const uint32_t* d_map = nullptr;
       std::vector<uint32_t> map;
       if (remap) {
@@ -1180,6 +1228,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     if (bs[i]->device != device_) throw Error(FDB_ERR_INVALID, "batch lives on a different device than the plan");
   hip_check(hipSetDevice(device_), "hipSetDevice");
   for (int i = 0; i < n; i++) bs[i]->note_reader(stream_);
+  mirror_valid_ = false;
   PhaseTimer pt;
 
   std::vector<Resolved> Rs((size_t)n);
@@ -1432,21 +1481,40 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     if (grid > total_tiles) grid = (int)total_tiles;
     unsigned long long* partials = alloc_partials(grid);
     for (FdbScanArgs& a : parts) a.partials = partials;
+    if (state_virgin_ && jit_fn != nullptr && partials != nullptr && (uint64_t)slots_alloc_ * (1 + aggs_.size()) < (1ull << 32)) {
+      // nothing accumulates into the table before reduce_partials (the next kernel on the stream): the scan fills it on its way in
+      FdbScanArgs& a0 = parts[0];
+      a0.fill_state = d_state_;
+      a0.fill_words = (uint32_t)(slots_alloc_ * (1 + aggs_.size()));
+      a0.fill_alloc = (uint32_t)slots_alloc_;
+      state_idents(a0.fill_idents);
+      state_virgin_ = false;
+    } else {
+      materialize_state();
+    }
+    trace("before scan");
     const FdbScanArgs* d_parts = (const FdbScanArgs*)upload(parts.data(), parts.size() * sizeof(FdbScanArgs));
     ctx_->flush_staging();
     pt.mark("parts upload");
+    trace("after upload");
     timed_launch([&] {
       if (jit_fn != nullptr) hip_check(jit_launch(jit_fn, d_parts, (int)parts.size(), total_tiles, parts[0], grid, jit_block, lds_bytes, stream_), "scan launch");
       else hip_check(fdb_launch_scan_slots(d_parts, (int)parts.size(), parts[0], total_tiles, grid, lds_bytes, two_phase, sub, stream_), "scan launch");
     });
     last_kernel_ = jit_fn != nullptr ? "fdb_plan_kernel" : "scan_slots_kernel";
     pt.mark("scan launch");
-    if (partials != nullptr)
-      hip_check(fdb_launch_reduce_partials(partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, stream_), "reduce partials");
+    trace("after scan");
+    if (partials != nullptr) {
+      unsigned long long* host_out = mirror_target();
+      hip_check(fdb_launch_reduce_partials(partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, host_out, stream_), "reduce partials");
+      mirror_valid_ = host_out != nullptr;
+    }
+    trace("after reduce");
     stat_launches += 1;
   } else {
     // ---- sequential kernel, one launch per record ----------------------------------------------------------------
     const int rpt = rows_per_thread == 8 ? 8 : 4;
+    materialize_state();
     ctx_->flush_staging();
     for (int i : live) {
       FdbScanArgs& a = Rs[(size_t)i].args;
@@ -1456,8 +1524,12 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
       a.partials = alloc_partials(grid);
       timed_launch([&] { hip_check(fdb_launch_scan_dense(a, grid, lds_bytes, rpt, stream_), "scan launch"); });
       last_kernel_ = "scan_dense_kernel";
-      if (a.partials != nullptr)
-        hip_check(fdb_launch_reduce_partials(a.partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, stream_), "reduce partials");
+      mirror_valid_ = false;  // (a launch that flushes with atomics leaves the host copy behind)
+      if (a.partials != nullptr) {
+        unsigned long long* host_out = mirror_target();
+        hip_check(fdb_launch_reduce_partials(a.partials, grid, (int)(1 + aggs_.size()), n_slots_, d_state_, slots_alloc_, funcs, host_out, stream_), "reduce partials");
+        mirror_valid_ = host_out != nullptr;
+      }
       stat_launches += 1;
     }
   }
@@ -1471,12 +1543,20 @@ void Plan::fetch_state(std::vector<unsigned long long>* cnt, std::vector<std::ve
   hip_check(hipSetDevice(device_), "hipSetDevice");
   acc->assign(aggs_.size(), {});
   if (d_state_ == nullptr) { sync(); cnt->clear(); return; }
+  materialize_state();
+  if (mirror_valid_ && h_mirror_ != nullptr) {  // the fold kernel already wrote the table to pinned memory: one wait, no copy
+    sync();
+    cnt->assign(h_mirror_, h_mirror_ + n_slots_);
+    for (size_t j = 0; j < aggs_.size(); j++) (*acc)[j].assign(h_mirror_ + (1 + j) * slots_alloc_, h_mirror_ + (1 + j) * slots_alloc_ + n_slots_);
+    return;
+  }
   // one device→pinned copy of the whole table, then one wait
   const size_t n_arrays = 1 + aggs_.size();
   const size_t bytes = (size_t)slots_alloc_ * 8 * n_arrays;
   unsigned long long* h = (unsigned long long*)ctx_->host_alloc(bytes);
   hipError_t e = hipMemcpyAsync(h, d_state_, bytes, hipMemcpyDeviceToHost, stream_);
   if (e != hipSuccess) { ctx_->host_free(h); hip_check(e, "hipMemcpyAsync(state)"); }
+  trace("after state copy");
   try { sync(); } catch (...) { ctx_->host_free(h); throw; }
   cnt->assign(h, h + n_slots_);
   for (size_t j = 0; j < aggs_.size(); j++) (*acc)[j].assign(h + (1 + j) * slots_alloc_, h + (1 + j) * slots_alloc_ + n_slots_);
@@ -1773,8 +1853,9 @@ uint64_t Plan::state_signature(int64_t* n_slots_out) {
   return h;
 }
 
-void Plan::state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) const {
+void Plan::state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) {
   const bool ok = mode_ == TableMode::DENSE && d_state_ != nullptr;
+  if (ok) { materialize_state(); mirror_valid_ = false; }  // (the caller may write through these pointers)
   *base = ok ? (void*)d_state_ : nullptr;
   *array_stride = ok ? (int64_t)slots_alloc_ : 0;
   *n_slots = ok ? (int64_t)n_slots_ : 0;
@@ -1787,6 +1868,7 @@ void Plan::state_read(int32_t array, void* dst, int64_t capacity_bytes) {
   const size_t bytes = (size_t)n_slots_ * 8;
   if ((int64_t)bytes > capacity_bytes) throw Error(FDB_ERR_INVALID, "state_read: destination too small");
   hip_check(hipSetDevice(device_), "hipSetDevice");
+  materialize_state();
   hip_check(hipMemcpyAsync(dst, d_state_ + (size_t)array * slots_alloc_, bytes, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(state_read)");
   hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
@@ -1797,6 +1879,8 @@ void Plan::state_write(int32_t array, const void* src, int64_t bytes) {
   if (d_state_ == nullptr) throw Error(FDB_ERR_STATE, "the plan has no table yet");
   if (bytes != (int64_t)n_slots_ * 8) throw Error(FDB_ERR_INVALID, "state_write: size mismatch");
   hip_check(hipSetDevice(device_), "hipSetDevice");
+  materialize_state();
+  mirror_valid_ = false;
   hip_check(hipMemcpyAsync(d_state_ + (size_t)array * slots_alloc_, src, (size_t)bytes, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(state_write)");
   hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
@@ -1841,6 +1925,8 @@ void Plan::merge_from(Plan& src) {
     caps[gi] = (uint32_t)g.values.size() + 1;
   }
   ensure_layout(caps);
+  materialize_state();
+  mirror_valid_ = false;
   std::vector<uint32_t> map((size_t)src.n_slots_, 0xFFFFFFFFu);
   for (uint32_t s = 0; s < src.n_slots_; s++) {
     if (scnt[s] == 0) continue;

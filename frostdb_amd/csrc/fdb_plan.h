@@ -234,7 +234,7 @@ class Plan {
   char agg_format(int32_t agg) const;
   uint64_t state_signature(int64_t* n_slots);
   void state_read(int32_t array, void* dst, int64_t capacity_bytes);
-  void state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) const;
+  void state_pointers(void** base, int64_t* array_stride, int64_t* n_slots);
   void state_write(int32_t array, const void* src, int64_t bytes);
   // Reduction that merges table array `array` (0 = row counts, 1 + j = physical accumulator j) across plans / ranks:
   // 0 none (unused array), 1 integer sum, 2 float64 sum, 3 integer min, 4 integer max.
@@ -319,6 +319,17 @@ class Plan {
   unsigned long long* d_state_ = nullptr;  // one block: [cnt | acc 0 | acc 1 | …], slots_alloc_ entries each
   unsigned long long* d_cnt_ = nullptr;
   bool state_dirty_ = false;        // any kernel has accumulated into the table
+  bool state_virgin_ = false;       // d_state_ is allocated but NOT identity-filled yet: the first specialised scan launch fills it in its
+                                    // prologue (push_batches); anything else that reads or accumulates into it calls materialize_state() first
+  void materialize_state();
+  // Host copy of a small dense table, written by reduce_partials_kernel itself (pinned memory): valid from a push whose fold wrote
+  // it until anything else changes the table (another push, a merge, an all-reduce, a raw write, a re-layout). Finish reads it
+  // after the stream's sync instead of queueing a device→host copy first.
+  unsigned long long* h_mirror_ = nullptr;
+  size_t mirror_bytes_ = 0;
+  bool mirror_valid_ = false;
+  unsigned long long* mirror_target();  // the buffer for this table's layout (nullptr: table too big for the direct path)
+  void state_idents(unsigned long long* idents) const;  // [1 + aggs]: 0 / INT64_MAX (MIN) / INT64_MIN (MAX)
   TableMode mode_ = TableMode::DENSE;
   // hash table: entries [capacity][entry_words] u64, key tuples [capacity][key_words] u32
   unsigned long long* h_table_ = nullptr;
@@ -332,6 +343,8 @@ class Plan {
 
   Context* ctx_ = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
+  std::vector<std::pair<const char*, hipEvent_t>> trace_;  // FDB_PROFILE=1: points on the stream's own timeline, printed at the next sync (tuning aid)
+  void trace(const char* what);
   std::vector<std::pair<hipEvent_t, hipEvent_t>> merge_events_;
   std::vector<void*> scratch_;  // device blocks in use by in-flight kernels; returned to the context at the next sync
   std::vector<std::unique_ptr<DeviceBatch>> pending_;   // queued small records (copies in flight or done), not scanned yet
