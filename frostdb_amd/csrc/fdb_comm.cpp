@@ -440,6 +440,12 @@ bool Plan::comm_allreduce(Comm& comm) {
   comm.all_reduce(reds, stream_);  // ordered after the scan and the fold kernel; Finish / Close wait for this stream
   if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); merge_events_.emplace_back(e0, e1); }
   state_dirty_ = true;
+  // the merged table goes to the host copy from a kernel on the same stream (Finish then waits once and reads it; a device→host
+  // copy command behind the collective was 15 µs)
+  if (unsigned long long* host_out = mirror_target()) {
+    hip_check(fdb_launch_state_to_host(d_state_, host_out, n_slots_, slots_alloc_, (int)(1 + aggs_.size()), stream_), "state to host");
+    mirror_valid_ = true;
+  }
   return true;
 }
 

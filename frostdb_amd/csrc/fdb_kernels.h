@@ -372,6 +372,8 @@ hipError_t fdb_launch_fill_u64(unsigned long long* dst, unsigned long long value
 hipError_t fdb_launch_ordered_to_f64(unsigned long long* v, int64_t n, hipStream_t stream);
 // base[a * n + i] = idents[a] for a < n_arrays (≤ 1 + FDB_MAX_AGGS), i < n: the whole partial table in one launch.
 hipError_t fdb_launch_fill_state(unsigned long long* base, int64_t n, int n_arrays, const unsigned long long* idents, hipStream_t stream);
+// host_out[a * stride + s] = state[a * stride + s] for s < n_slots, a < n_arrays (host_out: pinned host memory).
+hipError_t fdb_launch_state_to_host(const unsigned long long* state, unsigned long long* host_out, uint32_t n_slots, uint64_t stride, int n_arrays, hipStream_t stream);
 // dst[map[i]] (op)= src[i] for i < n; op: fdb_agg_func (SUM/COUNT add, MIN/MAX signed 64-bit, f64 SUM when is_f64).
 hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long long* src, const uint32_t* map,
                                 int64_t n, int32_t func, int32_t is_f64, hipStream_t stream);

@@ -1219,6 +1219,13 @@ __global__ void fill_state_kernel(unsigned long long* base, int64_t n, int n_arr
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) base[i] = idents.v[i / n];
 }
 
+// The first n_slots entries of every array of a small table → pinned host memory (same layout): the host copy of a table that a
+// collective has just changed, without a copy command (Plan::allreduce; the fold kernel below writes its own).
+__global__ void state_to_host_kernel(const unsigned long long* __restrict__ state, unsigned long long* __restrict__ host_out, uint32_t n_slots, uint64_t stride) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < n_slots) host_out[(size_t)blockIdx.y * stride + slot] = state[(size_t)blockIdx.y * stride + slot];
+}
+
 // Folds the per-workgroup partial tables into the global table. grid = (slot tiles of 64, arrays): one workgroup of 16 waves
 // covers 64 consecutive slots of one array; each wave folds a contiguous run of tables with ≈16 independent coalesced loads in
 // flight, the waves combine through LDS in wave order and wave 0 updates the table with a PLAIN read-modify-write — nothing else
@@ -2084,6 +2091,12 @@ hipError_t fdb_launch_fill_state(unsigned long long* base, int64_t n, int n_arra
   int blocks = (int)((n * n_arrays + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(fill_state_kernel, dim3(blocks), dim3(256), 0, stream, base, n, n_arrays, f);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_state_to_host(const unsigned long long* state, unsigned long long* host_out, uint32_t n_slots, uint64_t stride, int n_arrays, hipStream_t stream) {
+  if (n_slots == 0 || n_arrays <= 0) return hipSuccess;
+  hipLaunchKernelGGL(state_to_host_kernel, dim3((n_slots + 255) / 256, n_arrays), dim3(256), 0, stream, state, host_out, n_slots, stride);
   return hipGetLastError();
 }
 
