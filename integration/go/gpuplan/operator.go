@@ -23,10 +23,14 @@ import "C"
 import (
 	"context"
 	"errors"
+	"fmt"
+	"regexp"
+	"sync"
 	"unsafe"
 
 	"github.com/apache/arrow-go/v18/arrow"
 	"github.com/apache/arrow-go/v18/arrow/cdata"
+	"github.com/apache/arrow-go/v18/arrow/scalar"
 
 	"github.com/polarsignals/frostdb/query/logicalplan"
 	"github.com/polarsignals/frostdb/query/physicalplan"
@@ -128,6 +132,63 @@ func fdbRegexMatch(_ unsafe.Pointer, pat *C.char, patLen C.int64_t, val *C.uint8
 	return 0
 }
 
+// compiled caches regexp.Compile per pattern text for the life of the process (the reference compiles once per plan,
+// filter.go:105-124; the library asks once per distinct dictionary value and pattern).
+var regexCache sync.Map // string → *regexp.Regexp
+
+func compiled(pattern string) (*regexp.Regexp, error) {
+	if re, ok := regexCache.Load(pattern); ok {
+		return re.(*regexp.Regexp), nil
+	}
+	re, err := regexp.Compile(pattern)
+	if err != nil {
+		return nil, err
+	}
+	regexCache.Store(pattern, re)
+	return re, nil
+}
+
+// setLiteral maps the scalar of a LiteralExpr (logicalplan/expr.go:586-588) onto fdb_literal. Strings and binaries are copied into
+// the arena (C memory); anything the filter of the reference does not compare with either (binaryscalarexpr.go:84-117) is an error
+// and the caller keeps the Go operators for that plan.
+func setLiteral(dst *C.fdb_literal, v scalar.Scalar, mem *cArena) error {
+	if v == nil || v == scalar.ScalarNull || !v.IsValid() {
+		dst._type = C.FDB_LIT_NULL
+		return nil
+	}
+	bytesLit := func(kind C.int32_t, b []byte) {
+		dst._type = kind
+		dst.len = C.int64_t(len(b))
+		if len(b) > 0 {
+			p := mem.alloc(len(b), 1)
+			copy(unsafe.Slice((*byte)(p), len(b)), b)
+			dst.data = (*C.char)(p)
+		}
+	}
+	switch x := v.(type) {
+	case *scalar.Int64:
+		dst._type, dst.i64 = C.FDB_LIT_INT64, C.int64_t(x.Value)
+	case *scalar.Int32:
+		dst._type, dst.i64 = C.FDB_LIT_INT64, C.int64_t(x.Value)
+	case *scalar.Uint64:
+		dst._type, dst.u64 = C.FDB_LIT_UINT64, C.uint64_t(x.Value)
+	case *scalar.Float64:
+		dst._type, dst.f64 = C.FDB_LIT_FLOAT64, C.double(x.Value)
+	case *scalar.Boolean:
+		dst._type = C.FDB_LIT_BOOL
+		if x.Value {
+			dst.i64 = 1
+		}
+	case *scalar.String:
+		bytesLit(C.FDB_LIT_STRING, x.Data())
+	case *scalar.Binary:
+		bytesLit(C.FDB_LIT_BINARY, x.Data())
+	default:
+		return fmt.Errorf("gpuplan: literal of type %s is not supported", v.DataType())
+	}
+	return nil
+}
+
 // Callback ≙ PredicateFilter.Callback + HashAggregate.Callback. The record is only borrowed (table.go:808,:827):
 // fdb_plan_push stages what it needs before returning.
 func (o *Operator) Callback(_ context.Context, r arrow.Record) error {
@@ -208,7 +269,9 @@ func flatten(e logicalplan.Expr, out *[]C.fdb_expr, mem *cArena) (int, error) {
 		return -1, physicalplan.ErrUnsupportedBooleanExpression
 	}
 	n := C.fdb_expr{op: C.int32_t(b.Op), left: -1, right: -1, column: mem.str(col.ColumnName)}
-	setLiteral(&n.literal, lit.Value, mem) // scalar.Int64 → FDB_LIT_INT64, scalar.String → FDB_LIT_STRING (data, len), scalar.Null → FDB_LIT_NULL, …
+	if err := setLiteral(&n.literal, lit.Value, mem); err != nil { // scalar.Int64 → FDB_LIT_INT64, scalar.String → FDB_LIT_STRING (data, len), scalar.Null → FDB_LIT_NULL, …
+		return -1, err
+	}
 	*out = append(*out, n)
 	return len(*out) - 1, nil
 }
@@ -259,9 +322,11 @@ func (o *Operator) MergeAcrossDevices(ctx context.Context, comm *C.fdb_comm) err
 // ResidentRowGroup decodes one Parquet row group on the device (fdb_batch_from_parquet) from the column chunks' bytes as
 // parquet-go's file metadata locates them; the batch can be pushed to any number of queries (fdb_plan_push_batches) and stays
 // in HBM until released. Each chunk names its pages' codec (fdb_parquet_chunk.codec = format.CompressionCodec of the column's
-// metadata: UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4_RAW are inflated by the library). Row groups outside the covered encodings
-// (nested columns, PLAIN byte arrays, BROTLI, …) return FDB_ERR_UNSUPPORTED: convert those with pqarrow as before and use
-// fdb_batch_import.
+// metadata: UNCOMPRESSED, SNAPPY, GZIP, ZSTD, LZ4_RAW and BROTLI are inflated by the library). Row groups outside the covered
+// layouts (repeated / nested columns, physical types other than BOOLEAN, INT64, DOUBLE, BYTE_ARRAY) return FDB_ERR_UNSUPPORTED:
+// convert those with pqarrow as before and use fdb_batch_import. The chunk descriptors hold pointers (column name, page bytes):
+// like the plan descriptor they must point at C memory (C.CString / C.CBytes, or an mmap of the file) — cgo refuses Go memory
+// that itself contains Go pointers; the library copies what it keeps before it returns.
 func ResidentRowGroup(device int, chunks []C.fdb_parquet_chunk, rows int64) (*C.fdb_batch, error) {
 	var b *C.fdb_batch
 	if rc := C.fdb_batch_from_parquet(&chunks[0], C.int32_t(len(chunks)), C.int64_t(rows), C.int(device), &b); rc != C.FDB_OK {
