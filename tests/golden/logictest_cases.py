@@ -263,6 +263,23 @@ FILTER_CASES = [
          filter=Or(And(L(3) == "value3", L(5) == None), And(L(3) == None, L(5) == "a")), rows=[1]),  # noqa: E711
 ]
 
+# ---- filter_contains: the `bytes` schema (logic_test.go:110-146): dynamic dictionary labels, a UINT64 timestamp and a PLAIN
+# (DELTA_LENGTH_BYTE_ARRAY → Arrow binary, no dictionary) `value` column; LIKE / NOT LIKE on the plain column ---------------------
+CONTAINS_FILE = "logictest/testdata/exec/filter/filter_contains"
+CONTAINS_TABLE = dict(  # filter_contains:4-8
+    cols=["labels.label1", "labels.label2", "labels.label3", "labels.label4", "timestamp", "value"],
+    rows=[
+        [b"value1", b"value2", None, None, 1, b"foo"],
+        [b"value2", b"value2", b"value3", None, 2, b"bar"],
+        [b"value3", b"value2", None, b"value4", 3, b"baz"],
+    ],
+)
+CONTAINS_CASES = [
+    dict(id="bytes_ts_eq", cite=f"{CONTAINS_FILE}:10-13", filter=TS == 2, rows=[1]),
+    dict(id="bytes_like", cite=f"{CONTAINS_FILE}:15-19", filter=Col("value").Contains("a"), rows=[1, 2]),
+    dict(id="bytes_not_like", cite=f"{CONTAINS_FILE}:21-24", filter=Col("value").NotContains("a"), rows=[0]),
+]
+
 # aggregate_test.go:23-148 TestAggregateInconsistentSchema: three single-row records with different label
 # sets; GROUP BY labels.label2 (a concrete column that the first record lacks). Expected values, sorted
 # descending like the test does (aggregate_test.go:141-145).

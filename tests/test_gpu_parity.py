@@ -119,6 +119,24 @@ def test_golden_aggregate_two_chains_merged(pp, case):
             p.Close()
 
 
+@pytest.mark.parametrize("case", G.CONTAINS_CASES, ids=[c["id"] for c in G.CONTAINS_CASES])
+def test_golden_filter_contains(pp, case):
+    """exec/filter/filter_contains on the device: the `bytes` schema's plain binary `value` column (LIKE / NOT LIKE) and its UINT64
+    timestamp; the selected rows and every column of the filtered record are the vector's."""
+    from tests.util import bytes_schema_record
+    rec = bytes_schema_record(G.CONTAINS_TABLE)
+    plan = pp.HashAggregatePlan(case["filter"])
+    try:
+        assert list(plan.Select(rec)) == case["rows"], case["cite"]
+        out = plan.Filter(rec)
+        d = arrow_to_pydict(out)
+        assert out.schema.names == rec.schema.names
+        for ci, name in enumerate(G.CONTAINS_TABLE["cols"]):
+            assert d[name] == [G.CONTAINS_TABLE["rows"][r][ci] for r in case["rows"]], (case["cite"], name)
+    finally:
+        plan.Close()
+
+
 @pytest.mark.parametrize("case", G.FILTER_CASES, ids=[c["id"] for c in G.FILTER_CASES])
 def test_golden_filter(pp, case):
     rec = table_records(G.FILTER_TABLE)[0]

@@ -88,6 +88,20 @@ def test_oracle_filter_golden(case):
     plan.close()
 
 
+@pytest.mark.parametrize("case", G.CONTAINS_CASES, ids=[c["id"] for c in G.CONTAINS_CASES])
+def test_oracle_filter_contains_golden(case):
+    """exec/filter/filter_contains: LIKE / NOT LIKE on a plain (non-dictionary) binary column, `=` on a UINT64 column."""
+    from tests.util import bytes_schema_record
+    rec = bytes_schema_record(G.CONTAINS_TABLE)
+    plan = OraclePlan(case["filter"])
+    out, idx = plan.filter(rec)
+    assert list(idx) == case["rows"], case["cite"]
+    d = out.to_pydict()
+    for ci, name in enumerate(G.CONTAINS_TABLE["cols"]):
+        assert d[name] == [G.CONTAINS_TABLE["rows"][r][ci] for r in case["rows"]], (case["cite"], name)
+    plan.close()
+
+
 @pytest.mark.parametrize("nchains", [1, 3])
 def test_oracle_inconsistent_schema(nchains):
     from frostdb_amd.logicalplan import Col, Count, Max, Min, Sum

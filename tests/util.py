@@ -65,6 +65,21 @@ def record_from_rows(cols: Sequence[str], rows: List[List[Any]]) -> pa.RecordBat
     return pa.RecordBatch.from_arrays(arrays, names=list(cols))
 
 
+def bytes_schema_record(table: Dict[str, Any]) -> pa.RecordBatch:
+    """A record of logictest's `bytes` schema (logic_test.go:110-146): labels.* dictionary strings, timestamp UINT64, value a plain
+    binary column (its DELTA_LENGTH_BYTE_ARRAY storage becomes Arrow binary, pqarrow/convert/convert.go:64-70)."""
+    arrays = []
+    for ci, c in enumerate(table["cols"]):
+        vals = [r[ci] for r in table["rows"]]
+        if c.startswith("labels."):
+            arrays.append(dict_array(vals))
+        elif c == "timestamp":
+            arrays.append(pa.array(vals, type=pa.uint64()))
+        else:
+            arrays.append(pa.array(vals, type=pa.binary()))
+    return pa.RecordBatch.from_arrays(arrays, names=list(table["cols"]))
+
+
 def table_records(table: Dict[str, Any]) -> List[pa.RecordBatch]:
     """One Arrow record per `insert` (an L0 part reaches the scan as a whole record, index/lsm.go:420-427)."""
     return [record_from_rows(table["cols"], parse_rows(table["cols"], text)) for text in table["inserts"]]
