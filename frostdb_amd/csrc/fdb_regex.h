@@ -9,8 +9,11 @@
 // change WHETHER something matches), flags i m s U — set `(?i)`, scoped `(?i:…)`, negated `(?-i)`. Like RE2: no backreferences, no
 // look-around (both are syntax errors), a repeat count above 1 000 is an error, matching is a Thompson / Pike simulation —
 // linear in the value's length, no backtracking blow-up whatever the pattern.
-// Not covered (a pattern using them does not compile → FDB_ERR_INVALID at fdb_plan_create, like any bad pattern): Unicode classes
-// \pL / \p{Greek}; case folding under (?i) covers ASCII letters only.
+// Unicode: general-category classes \pL \p{Lu} \P{Nd} \p{^Zs} \p{Any} (inside brackets too), and (?i) folds by case-folding ORBITS the
+// way regexp/syntax does with unicode.SimpleFold (k ↔ K ↔ U+212A, σ ↔ ς ↔ Σ, ß ↔ ẞ); tables generated from Unicode 13.0
+// (tools/gen_unicode_tables.py → fdb_unicode_tables.inc; Go 1.22 carries 15.0: runes assigned since are unassigned here).
+// Not covered (a pattern using them does not compile → FDB_ERR_INVALID at fdb_plan_create, like any bad pattern): Unicode SCRIPT
+// classes (\p{Greek}, \p{Han} …).
 #pragma once
 
 #include <cstddef>

@@ -170,9 +170,9 @@ typedef struct fdb_projection {
  * caller costs one call per distinct value and makes the result identical to the reference's by construction: the Go shim passes
  * a cgo-exported function around regexp.Regexp.Match. Returns 1 = matches, 0 = does not, < 0 = the pattern
  * does not compile / internal error (the call that triggered it fails with FDB_ERR_INVALID). Without one (NULL) the library
- * uses its own RE2-syntax engine (fdb_regex_match below): flags, named groups, POSIX classes, \Q…\E, \A \z \b; Unicode classes
- * (\pL) and non-ASCII case folding are not covered and rejected at fdb_plan_create. Must be callable from any thread that calls
- * into the plan. */
+ * uses its own RE2-syntax engine (fdb_regex_match below): flags, named groups, POSIX classes, \Q…\E, \A \z \b, Unicode general
+ * categories (\pL \p{Lu} \P{Nd} \p{^Zs} \p{Any}) and case folding by orbits under (?i); Unicode SCRIPT classes (\p{Greek}) are not
+ * covered and rejected at fdb_plan_create. Must be callable from any thread that calls into the plan. */
 typedef int32_t (*fdb_regex_match_fn)(void* user, const char* pattern, int64_t pattern_len, const uint8_t* value, int64_t value_len);
 
 typedef struct fdb_plan_desc {
@@ -222,8 +222,8 @@ int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* schema, st
 /* The library's built-in regular-expression engine (used for `=~` / `!~` when fdb_plan_desc.regex_match is NULL), exposed for
  * host-only checks: RE2 syntax — what Go's regexp compiles (filter.go:105-124) — matched unanchored on the value's bytes like
  * regexp.Regexp.Match (regexpfilter.go:84-166); linear-time (Thompson / Pike), no backreferences or look-around. *matched = 1 / 0;
- * FDB_ERR_INVALID with Go-style wording ("error parsing regexp: …") when the pattern does not compile. Not covered: Unicode classes
- * (\pL), case folding beyond ASCII. */
+ * FDB_ERR_INVALID with Go-style wording ("error parsing regexp: …") when the pattern does not compile. Not covered: Unicode script
+ * classes (\p{Greek}); the category and case-folding tables are Unicode 13.0 (Go 1.22: 15.0). */
 int fdb_regex_match(const char* pattern, int64_t pattern_len, const uint8_t* value, int64_t value_len, int32_t* matched);
 /* Host-only self-check of the widening step of a big Finish (dictionary indices cross PCIe as uint8 / uint16 / uint32 — `width` 1,
  * 2 or 4 bytes — and are widened to Arrow's uint32 by host threads): dst[i] = src[i] for i < n, through the same routine (AVX2 with

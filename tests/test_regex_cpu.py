@@ -66,7 +66,7 @@ def test_go_specific_semantics(pp):
 
 
 @pytest.mark.parametrize("pat,why", [
-    (r"\pL", "Unicode classes"), ("a**", "invalid nested repetition operator"), ("(a", "missing closing )"), ("a)", "unexpected )"), ("[a", "missing closing ]"),
+    (r"\p{Greek}", "not scripts"), (r"\p{Cn}", "invalid character class range"), (r"\p{", "invalid character class range"), ("a**", "invalid nested repetition operator"), ("(a", "missing closing )"), ("a)", "unexpected )"), ("[a", "missing closing ]"),
     (r"\1", "invalid escape sequence"), ("(?=a)", "invalid or unsupported Perl syntax"), ("(?<!a)b", "invalid"), ("a{1001}", "invalid repeat count"),
     (r"\C", "invalid escape sequence"), (r"\q", "invalid escape sequence"), ("x{3,2}", "invalid repeat count"), ("*a", "missing argument to repetition operator"),
     ("(?i", "missing closing )"), ("[b-a]", "invalid character class range"), ("a\\", "trailing backslash"), ("(?P<n-1>a)", "invalid named capture"),
@@ -82,6 +82,52 @@ def test_what_re2_rejects_is_rejected_with_go_style_wording(pp, pat, why):
     with pytest.raises(pp.FdbError) as e:
         pp.explain(Col("labels.x").RegexMatch(pat))
     assert e.value.code == pp.FDB_ERR_INVALID
+
+
+def test_unicode_general_categories_against_unicodedata(pp):
+    """\\p{..} general categories (what Go's regexp takes from unicode.Categories): every two-letter category and the one-letter
+    groups, positive and negated, inside and outside brackets, checked rune by rune against this interpreter's unicodedata on a
+    sample that covers every plane with assigned characters."""
+    import random
+    import unicodedata
+    rng = random.Random(7)
+    sample = list(range(0, 0x3000, 7)) + [rng.randrange(0x3000, 0x30000) for _ in range(3000)] + [0xE000, 0xF0000, 0x10FFFF, 0xE0001]
+    sample = [c for c in sample if not 0xD800 <= c <= 0xDFFF]
+    cats = sorted({unicodedata.category(chr(c)) for c in range(0x110000) if not 0xD800 <= c <= 0xDFFF} - {"Cn"})
+    assert "Lu" in cats and "Zs" in cats and "Co" in cats
+    for name in cats + ["L", "M", "N", "P", "S", "Z", "C"]:
+        brace = "{%s}" % name
+        for c in sample[::5] if len(name) == 2 else sample[::9]:
+            cat = unicodedata.category(chr(c))
+            want = cat == name if len(name) == 2 else (cat[0] == name and cat != "Cn")
+            v = chr(c).encode()
+            assert pp.regex_match("^\\p" + brace + "$", v) is want, (name, hex(c), cat)
+            assert pp.regex_match("^\\P" + brace + "$", v) is (not want), (name, hex(c))
+    for c in sample[::11]:
+        cat, v = unicodedata.category(chr(c)), chr(c).encode()
+        assert pp.regex_match(r"^\pL$", v) is (cat[0] == "L")
+        assert pp.regex_match(r"^[\p{Nd}\p{Lu}_]$", v) is (cat in ("Nd", "Lu") or c == 0x5F)
+        assert pp.regex_match(r"^[^\p{L}\p{N}]$", v) is (cat[0] not in "LN")
+        assert pp.regex_match(r"^\p{^Zs}$", v) is (cat != "Zs")
+        assert pp.regex_match(r"^\p{Any}$", v) is True
+
+
+def test_case_folding_follows_orbits_not_ascii(pp):
+    """(?i) folds the way regexp/syntax does with unicode.SimpleFold: a rune matches every rune of its case-folding orbit."""
+    yes = [("(?i)^k$", "K"), ("(?i)^k$", "\u212a"), ("(?i)^\u212a$", "k"), ("(?i)^σ$", "ς"), ("(?i)^ς$", "Σ"), ("(?i)^straße$", "STRAẞE"),
+           ("(?i)^ǆ$", "ǅ"), ("(?i)^µ$", "Μ"), ("(?i)^ÀÉÎ$", "àéî"), ("(?i)^[а-я]+$", "ПРИВЕТ"), ("(?i)^\\p{Lu}+$", "abc"), ("(?i)^[^a]$", "b"),
+           ("(?i)^ſ$", "S")]
+    no = [("(?i)^i$", "İ"), ("(?i)^I$", "ı"), ("^k$", "K"), ("(?i)^[^k]$", "\u212a"), ("(?i)^ß$", "ss"), ("(?i)^[^a]$", "A")]
+    for pat, val in yes:
+        assert pp.regex_match(pat, val.encode()) is True, (pat, val)
+    for pat, val in no:
+        assert pp.regex_match(pat, val.encode()) is False, (pat, val)
+    # every cased letter of the BMP against its own lower / upper forms, where those are single runes with the same simple folding
+    for c in range(0x80, 0x2000):
+        ch = chr(c)
+        for other in {ch.lower(), ch.upper()}:
+            if len(other) == 1 and other != ch and other.casefold() == ch.casefold() and len(ch.casefold()) == 1:
+                assert pp.regex_match("(?i)^" + re.escape(ch) + "$", other.encode()) is True, (hex(c), other)
 
 
 def test_matching_is_linear_in_the_value(pp):
