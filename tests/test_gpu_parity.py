@@ -119,6 +119,33 @@ def test_golden_aggregate_two_chains_merged(pp, case):
             p.Close()
 
 
+def test_binary_scalar_operation_shapes(pp):
+    """BenchmarkBinaryScalarOperation's input (binaryscalarexpr_test.go:15-41) on the device: 1 000 000 int64 values i % 10 against
+    the scalar 4 under =, !=, <, <=, >, >= — selected rows and the filtered column are the oracle's (counts follow from the input)."""
+    from tests.test_oracle_golden import BINARY_SCALAR_OPS, binary_scalar_record
+    rec = binary_scalar_record()
+    src = rec.column(0).to_numpy()
+    for name, make, want in BINARY_SCALAR_OPS:
+        plan = pp.HashAggregatePlan(make(Col("v")))
+        try:
+            idx = np.asarray(plan.Select(rec))
+            assert len(idx) == want, name
+            out = plan.Filter(rec)
+            assert out.num_rows == want and np.array_equal(out.column(0).to_numpy(), src[idx]), name
+            o = OraclePlanFilter(rec, make(Col("v")))
+            assert np.array_equal(idx, o), name
+        finally:
+            plan.Close()
+
+
+def OraclePlanFilter(rec, filt):
+    from oracle import OraclePlan
+    o = OraclePlan(filt)
+    _, idx = o.filter(rec)
+    o.close()
+    return np.asarray(idx)
+
+
 @pytest.mark.parametrize("case", G.CONTAINS_CASES, ids=[c["id"] for c in G.CONTAINS_CASES])
 def test_golden_filter_contains(pp, case):
     """exec/filter/filter_contains on the device: the `bytes` schema's plain binary `value` column (LIKE / NOT LIKE) and its UINT64

@@ -102,6 +102,39 @@ def test_oracle_filter_contains_golden(case):
     plan.close()
 
 
+BINARY_SCALAR_OPS = [("eq", lambda c: c == 4, 100_000), ("neq", lambda c: c != 4, 900_000), ("lt", lambda c: c < 4, 400_000),
+                     ("le", lambda c: c <= 4, 500_000), ("gt", lambda c: c > 4, 500_000), ("ge", lambda c: c >= 4, 600_000)]
+
+
+def binary_scalar_record():
+    """The input of BenchmarkBinaryScalarOperation (binaryscalarexpr_test.go:15-41): 1 000 000 int64 values i % 10, compared with the
+    scalar 4 under every comparison operator. The benchmark holds no expected output; the counts follow from the input."""
+    import numpy as np
+    import pyarrow as pa
+    return pa.RecordBatch.from_arrays([pa.array(np.arange(1_000_000) % 10, type=pa.int64())], names=["v"])
+
+
+@pytest.mark.parametrize("name,make,want", BINARY_SCALAR_OPS, ids=[o[0] for o in BINARY_SCALAR_OPS])
+def test_oracle_binary_scalar_operation_shapes(name, make, want):
+    from frostdb_amd.logicalplan import Col
+    rec = binary_scalar_record()
+    plan = OraclePlan(make(Col("v")))
+    out, idx = plan.filter(rec)
+    assert len(idx) == want and out.num_rows == want
+    v = out.to_pydict()["v"]
+    assert int(sum(v)) == {"eq": 4 * want, "neq": 41 * 100_000, "lt": 6 * 100_000, "le": 10 * 100_000, "gt": 35 * 100_000, "ge": 39 * 100_000}[name]
+    plan.close()
+
+
+def test_a_logical_operator_between_a_column_and_a_scalar_is_refused():
+    """TestBinaryScalarOperationNotImplemented (binaryscalarexpr_test.go:97-106): OpAnd is not an operation between an array and a
+    scalar — ErrUnsupportedBinaryOperation there, a refused expression at every layer here."""
+    import frostdb_amd.logicalplan as lp
+    from frostdb_amd.logicalplan import BinaryExpr, Col, Literal
+    with pytest.raises(TypeError):
+        OraclePlan(BinaryExpr(Col("v"), lp.OP_AND, Literal(4)))
+
+
 @pytest.mark.parametrize("nchains", [1, 3])
 def test_oracle_inconsistent_schema(nchains):
     from frostdb_amd.logicalplan import Col, Count, Max, Min, Sum
