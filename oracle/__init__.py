@@ -196,11 +196,74 @@ class OracleBatch:
             pass
 
 
+_UNICODE_CLASS_CACHE = {}
+# RE2's Perl classes as class bodies: (the set, its complement over all runes); \s has no \v in RE2
+_PERL_CLASS = {
+    b"d": (b"0-9", b"\\x00-/:-\\U0010FFFF"),
+    b"w": (b"0-9A-Za-z_", b"\\x00-/:-@\\[-\\^`{-\\U0010FFFF"),
+    b"s": (b"\\t\\n\\f\\r ", b"\\x00-\\x08\\x0b\\x0e-\\x1f!-\\U0010FFFF"),
+}
+_PERL_CLASS.update({k.upper(): v for k, v in list(_PERL_CLASS.items())})
+
+
+def _unicode_class_ranges(name: str, negated: bool):
+    """The body of a Python character class (\\UXXXXXXXX-\\UXXXXXXXX runs) for a Unicode general category (two letters), a group of them
+    (one letter) or Any — None for anything else (scripts). Built from this interpreter's unicodedata, rune by rune: independent of
+    the product's generated tables."""
+    import unicodedata
+    key = (name, negated)
+    if key in _UNICODE_CLASS_CACHE:
+        return _UNICODE_CLASS_CACHE[key]
+    if name == "Any":
+        member = lambda cat: True  # noqa: E731
+    elif len(name) == 2 and name != "Cn":
+        member = lambda cat: cat == name  # noqa: E731
+    elif len(name) == 1 and name in "LMNPSZC":
+        member = lambda cat: cat[0] == name and cat != "Cn"  # noqa: E731
+    else:
+        return None
+    runs, start, prev = [], None, None
+    for c in range(0x110000):
+        cat = "Cs" if 0xD800 <= c <= 0xDFFF else unicodedata.category(chr(c))
+        hit = member(cat) != negated
+        if 0xD800 <= c <= 0xDFFF:
+            hit = False  # (a str pattern cannot hold lone surrogates; no UTF-8 text decodes to one either)
+        if hit:
+            if start is None:
+                start = c
+            prev = c
+        elif start is not None:
+            runs.append((start, prev)); start = None
+    if start is not None:
+        runs.append((start, prev))
+    if not runs:
+        return None
+    body = "".join("\\U%08X" % a if a == b else "\\U%08X-\\U%08X" % (a, b) for a, b in runs).encode()
+    _UNICODE_CLASS_CACHE[key] = body
+    return body
+
+
+def _ascii_complement(body: bytes) -> bytes:
+    """The complement, over all runes, of a class body made of ASCII members (what `[[:^alpha:]]` means inside a bracket class)."""
+    import re as _re
+    rx = _re.compile(b"[" + body + b"]")
+    runs, start = [], None
+    for c in range(0x80):
+        if rx.match(bytes([c])) is None:
+            if start is None:
+                start = c
+        elif start is not None:
+            runs.append((start, c - 1)); start = None
+    runs.append((start if start is not None else 0x80, 0x10FFFF))
+    return "".join("\\U%08X" % a if a == b else "\\U%08X-\\U%08X" % (a, b) for a, b in runs).encode()
+
+
 def go_regexp_to_python(pattern: bytes) -> bytes:
     """RE2 (Go regexp) syntax → Python `re` syntax for the constructs whose SPELLING differs; their meaning is the same. `$` without
     the m flag is the end of the TEXT in Go (Python's would also match before a trailing newline) and `\\z` is Python's `\\Z`;
     `(?U)` only changes which match is preferred (irrelevant for match / no match); `\\Q…\\E` quotes; POSIX classes are spelled out;
-    `(?<name>…)` is `(?P<name>…)`. Patterns using what Python lacks altogether (\\pL) are left alone and fail to compile there too."""
+    `(?<name>…)` is `(?P<name>…)`; `\\p{..}` general categories are spelled out as ranges from unicodedata. Script classes (\\p{Greek}) are left alone and
+    fail to compile there too."""
     import re as _re
     posix = {b"alnum": b"0-9A-Za-z", b"alpha": b"A-Za-z", b"ascii": b"\\x00-\\x7f", b"blank": b"\\t ", b"cntrl": b"\\x00-\\x1f\\x7f", b"digit": b"0-9",
              b"graph": b"!-~", b"lower": b"a-z", b"print": b" -~", b"punct": b"!-/:-@\\[-`{-~", b"space": b"\\t\\n\\v\\f\\r ", b"upper": b"A-Z",
@@ -218,14 +281,41 @@ def go_regexp_to_python(pattern: bytes) -> bytes:
                 continue
             if nx == b"z" and not in_class:
                 out += b"\\Z"; i += 2; continue
+            if nx in _PERL_CLASS:  # \d \w \s are ASCII-only in RE2 (Python's are Unicode-aware on str patterns): spelled out
+                pos, comp = _PERL_CLASS[nx]
+                body = comp if nx.isupper() else pos
+                out += body if in_class else b"[" + body + b"]"
+                i += 2; continue
+            if nx in (b"b", b"B") and not in_class:  # ASCII word boundary (Python's \b counts é as a word character, Go's does not)
+                w = b"[0-9A-Za-z_]"
+                if nx == b"b":  # ((?-i: the boundary is about ASCII word characters whatever the case folding in force: K U+212A is none)
+                    out += b"(?-i:(?<=" + w + b")(?!" + w + b")|(?<!" + w + b")(?=" + w + b"))"
+                else:
+                    out += b"(?-i:(?<=" + w + b")(?=" + w + b")|(?<!" + w + b")(?!" + w + b"))"
+                i += 2; continue
+            if nx in (b"p", b"P"):  # \pL \p{Lu} \P{Nd} \p{^Zs} \p{Any}: spelled out as ranges from unicodedata (Python's re has no \p)
+                neg = nx == b"P"
+                if pattern[i + 2:i + 3] == b"{":
+                    j = pattern.find(b"}", i + 3)
+                    name = pattern[i + 3:j] if j >= 0 else None
+                    end = j + 1
+                else:
+                    name, end = pattern[i + 2:i + 3], i + 3
+                if name is not None and name.startswith(b"^"):
+                    neg, name = not neg, name[1:]
+                body = _unicode_class_ranges(name.decode("ascii", "replace"), neg) if name else None
+                if body is not None:
+                    out += body if in_class else b"[" + body + b"]"
+                    i = end; continue
             out += pattern[i:i + 2]; i += 2; continue
         if in_class:
             if c == b"[" and pattern[i + 1:i + 2] == b":":
                 j = pattern.find(b":]", i + 2)
                 name = pattern[i + 2:j] if j >= 0 else b""
                 neg = name.startswith(b"^")
-                if j >= 0 and name.lstrip(b"^") in posix and not neg:
-                    out += posix[name]; i = j + 2; continue
+                if j >= 0 and name.lstrip(b"^") in posix:
+                    out += _ascii_complement(posix[name[1:]]) if neg else posix[name]
+                    i = j + 2; continue
             if c == b"]":
                 in_class = False
             out += c; i += 1; continue

@@ -43,3 +43,12 @@ def test_mutated_parquet_chunks_are_refused_or_parsed_never_fatal():
 def test_random_regex_patterns_compile_or_are_refused_and_never_take_long():
     out = run_tool([os.path.join(ROOT, "tools", "regex_fuzz.py"), "6000", "5"])
     assert "runs 6000" in out and "slow 0" in out
+
+
+@pytest.mark.timeout(300)
+def test_random_re2_patterns_match_like_an_independent_engine():
+    """tools/regex_diff_fuzz.py: random patterns from an RE2 grammar (Unicode categories, case folding, POSIX and Perl classes,
+    lazy quantifiers, word boundaries, flags) against random values — the built-in engine and Python's `re` (on the translated
+    pattern) must agree on every match."""
+    out = run_tool([os.path.join(ROOT, "tools", "regex_diff_fuzz.py"), "2000", "4"])
+    assert "patterns 2000" in out and "disagreements 0" in out

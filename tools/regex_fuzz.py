@@ -10,8 +10,9 @@ lib.fdb_regex_match.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
 frags = ["a", "b", "é", ".", "*", "+", "?", "|", "(", ")", "(?:", "(?i)", "(?i:", "(?P<n>", "(?s)", "(?-i)", "[", "]", "[^", "a-z", "\\d", "\\W", "\\b", "\\B", "\\A", "\\z", "^", "$",
-         "{2}", "{1,3}", "{0,}", "{", "}", "{1000}", "{1001}", "\\Q", "\\E", "[:alpha:]", "[[:digit:]]", "\\x41", "\\x{1F600}", "\\101", "\\", "\\1", "\\p", "-", ",", "\xff", "\n", "(?", "(?<", "=", "!"]
-vals = [b"", b"a", b"ab" * 50, "éa".encode(), b"\xff\xfe", b"A1_b\n", b"(a)"]
+         "{2}", "{1,3}", "{0,}", "{", "}", "{1000}", "{1001}", "\\Q", "\\E", "[:alpha:]", "[[:digit:]]", "\\x41", "\\x{1F600}", "\\101", "\\", "\\1", "\\p", "-", ",", "\xff", "\n", "(?", "(?<", "=", "!",
+         "\\p{Lu}", "\\pL", "\\P{Nd}", "\\p{^Zs}", "\\p{Any}", "\\p{Greek}", "\\p{", "\\PZ", "σ", "ς", "\u212a", "ß", "Я"]
+vals = [b"", b"a", b"ab" * 50, "éa".encode(), b"\xff\xfe", b"A1_b\n", b"(a)", "Σσς K\u212a ẞ я".encode()]
 codes, slow = {}, 0
 for it in range(n):
     pat = "".join(random.choice(frags) for _ in range(random.randint(1, 12))).encode("utf-8", "surrogateescape") if random.random() < 0.9 else bytes(random.randrange(256) for _ in range(random.randint(1, 10)))
