@@ -135,6 +135,33 @@ def test_a_logical_operator_between_a_column_and_a_scalar_is_refused():
         OraclePlan(BinaryExpr(Col("v"), lp.OP_AND, Literal(4)))
 
 
+def test_oracle_float_specials_follow_the_reference_loops():
+    """NaN and ±Inf in a float64 column, as the reference's own loops treat them: comparisons are IEEE (Arrow's compare kernels,
+    binaryscalarexpr.go:119-152: NaN satisfies only `!=`); SUM propagates NaN and −Inf + Inf is NaN; MIN / MAX start from the
+    group's FIRST value and replace it on `<` / `>` (aggregate.go:847-860, :924-937) — so a NaN that comes first stays, a NaN
+    later in the group is skipped. (The device orders NaN by bit pattern instead: DESIGN §5, deliberate differences.)"""
+    import math
+    import pyarrow as pa
+    from frostdb_amd.logicalplan import Col, Count, Max, Min, Sum
+    from tests.util import dict_array
+    nan, inf = float("nan"), float("inf")
+    rec = pa.RecordBatch.from_arrays([dict_array([b"a", b"a", b"a", b"b", b"b", b"b", b"c", b"c"]), pa.array([nan, 1.0, 2.0, 1.0, nan, 3.0, -inf, inf])], names=["k", "v"])
+    o = OraclePlan(None, [Min(Col("v")), Max(Col("v")), Sum(Col("v")), Count(Col("v"))], [Col("k")])
+    o.push(rec)
+    d = o.finish().to_pydict()
+    o.close()
+    rows = {k: (mn, mx, sm, c) for k, mn, mx, sm, c in zip(d["k"], d["min(v)"], d["max(v)"], d["sum(v)"], d["count(v)"])}
+    assert math.isnan(rows[b"a"][0]) and math.isnan(rows[b"a"][1]) and math.isnan(rows[b"a"][2]) and rows[b"a"][3] == 3
+    assert rows[b"b"][0] == 1.0 and rows[b"b"][1] == 3.0 and math.isnan(rows[b"b"][2])
+    assert rows[b"c"][0] == -inf and rows[b"c"][1] == inf and math.isnan(rows[b"c"][2])
+    for filt, want in [(Col("v") > 1.5, [2, 5, 7]), (Col("v") != 1.0, [0, 2, 4, 5, 6, 7]), (Col("v") == 1.0, [1, 3]), (Col("v") <= inf, [1, 2, 3, 5, 6, 7]),
+                       (Col("v") < 1.5, [1, 3, 6]), (Col("v") >= -inf, [1, 2, 3, 5, 6, 7])]:
+        o = OraclePlan(filt)
+        _, idx = o.filter(rec)
+        assert list(idx) == want, str(filt)
+        o.close()
+
+
 @pytest.mark.parametrize("nchains", [1, 3])
 def test_oracle_inconsistent_schema(nchains):
     from frostdb_amd.logicalplan import Col, Count, Max, Min, Sum
