@@ -48,6 +48,12 @@ typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 #define G1 __attribute__((address_space(1)))
 template <typename T> __device__ __forceinline__ const G1 T* as_global(const T* p) { return (const G1 T*)p; }
 __device__ __forceinline__ long long f64_to_ordered(double d) { long long b = __double_as_longlong(d); return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL); }
+// (a NaN contributes the identity of MIN / MAX, −0.0 counts as +0.0: see f64_minmax_key in fdb_kernels.hip)
+__device__ __forceinline__ long long f64_minmax_key(double d, bool is_min) {
+  d += 0.0;
+  const long long k = f64_to_ordered(d);
+  return d != d ? (is_min ? 0x7FFFFFFFFFFFFFFFLL : (-0x7FFFFFFFFFFFFFFFLL - 1)) : k;
+}
 __device__ __forceinline__ u32x4 ld4(const void* base, uint32_t byte_off) {
   return __builtin_nontemporal_load(as_global(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + byte_off)));
 }
@@ -374,7 +380,7 @@ struct Gen {
         const std::string v = "v" + std::to_string(j);
         if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "      const double " << v << " = __longlong_as_double((long long)" << raw << ");\n";
         else if (A.func == FDB_AGG_SUM) o << "      const unsigned long long " << v << " = " << raw << ";\n";
-        else o << "      const long long " << v << " = " << (A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw)) << ";\n";
+        else o << "      const long long " << v << " = " << (A.type == FDB_T_F64 ? ("f64_minmax_key(__longlong_as_double((long long)" + raw + "), " + (A.func == FDB_AGG_MIN ? "true" : "false") + ")") : ("(long long)" + raw)) << ";\n";
         val[j] = v;
       }
       for (int t = 0; t < s.reg_slots; t++) {
@@ -428,7 +434,7 @@ struct Gen {
             if (A.type == FDB_T_F64) o << ind << "atomicAdd(reinterpret_cast<double*>" << where << ", __longlong_as_double((long long)" << raw << "));\n";
             else o << ind << "atomicAdd(" << where << ", " << raw << ");\n";
           } else {
-            const std::string key = A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw);
+            const std::string key = A.type == FDB_T_F64 ? ("f64_minmax_key(__longlong_as_double((long long)" + raw + "), " + (A.func == FDB_AGG_MIN ? "true" : "false") + ")") : ("(long long)" + raw);
             o << ind << (A.func == FDB_AGG_MIN ? "atomicMin" : "atomicMax") << "(reinterpret_cast<long long*>" << where << ", " << key << ");\n";
           }
         };
@@ -734,7 +740,7 @@ struct HashGen {
           const std::string v = "v" + std::to_string(j) + "_" + std::to_string(k);
           if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) o << "    double " << v << " = __longlong_as_double((long long)" << raw << ");\n";
           else if (A.func == FDB_AGG_SUM) o << "    unsigned long long " << v << " = " << raw << ";\n";
-          else o << "    long long " << v << " = " << (A.type == FDB_T_F64 ? ("f64_to_ordered(__longlong_as_double((long long)" + raw + "))") : ("(long long)" + raw)) << ";\n";
+          else o << "    long long " << v << " = " << (A.type == FDB_T_F64 ? ("f64_minmax_key(__longlong_as_double((long long)" + raw + "), " + (A.func == FDB_AGG_MIN ? "true" : "false") + ")") : ("(long long)" + raw)) << ";\n";
         }
       }
       for (int k = 1; k < 4; k++) {

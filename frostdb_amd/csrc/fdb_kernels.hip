@@ -31,6 +31,16 @@ __device__ __forceinline__ long long f64_to_ordered(double d) {
   long long b = __double_as_longlong(d);
   return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
 }
+// The key a float64 contributes to a MIN / MAX accumulator. A NaN contributes the accumulator's identity, i.e. nothing: the
+// reference's `if v < minV` loop (aggregate.go:846-857, :924-934) never replaces its running value by a NaN and never replaces a NaN,
+// so a NaN only survives there when it is the group's FIRST value — an answer that depends on row order; here a group's MIN / MAX is
+// that of its non-NaN values, and NaN (what the identity decodes to) only if it has no others. −0.0 counts as +0.0 (the reference
+// compares them equal and keeps whichever came first).
+__device__ __forceinline__ long long f64_minmax_key(double d, bool is_min) {
+  d += 0.0;
+  const long long k = f64_to_ordered(d);
+  return d != d ? (is_min ? FDB_I64_MAX : FDB_I64_MIN) : k;
+}
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(FDB_BLOCK, 8) void scan_dense_kernel(const FdbScanA
         long long key[R];
         if (A.type == FDB_T_F64) {
 #pragma unroll
-          for (int r = 0; r < R; r++) key[r] = f64_to_ordered(__longlong_as_double((long long)raw[r]));
+          for (int r = 0; r < R; r++) key[r] = f64_minmax_key(__longlong_as_double((long long)raw[r]), A.func == AGG_MIN);
         } else {
 #pragma unroll
           for (int r = 0; r < R; r++) key[r] = (long long)raw[r];
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(BLK) void scan_slots_kernel(const FdbScanArgs* __re
           long long key[R];
           if (P.agg[j].type == FDB_T_F64) {
 #pragma unroll
-            for (int r = 0; r < R; r++) key[r] = f64_to_ordered(__longlong_as_double((long long)raw[r]));
+            for (int r = 0; r < R; r++) key[r] = f64_minmax_key(__longlong_as_double((long long)raw[r]), P.agg[j].func == AGG_MIN);
           } else {
 #pragma unroll
             for (int r = 0; r < R; r++) key[r] = (long long)raw[r];
@@ -846,7 +856,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
         if (A.type == FDB_T_F64) atomicAdd(reinterpret_cast<double*>(acc), __longlong_as_double((long long)x));
         else atomicAdd(acc, x);
       } else {
-        const long long key = A.type == FDB_T_F64 ? f64_to_ordered(__longlong_as_double((long long)x)) : (long long)x;
+        const long long key = A.type == FDB_T_F64 ? f64_minmax_key(__longlong_as_double((long long)x), A.func == AGG_MIN) : (long long)x;
         if (A.func == AGG_MIN) atomicMin(reinterpret_cast<long long*>(acc), key);
         else atomicMax(reinterpret_cast<long long*>(acc), key);
       }

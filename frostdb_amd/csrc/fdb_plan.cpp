@@ -531,7 +531,12 @@ unsigned long long* Plan::mirror_target() {
   static const bool off = std::getenv("FDB_NO_HOST_MIRROR") != nullptr;  // (A/B aid)
   const size_t bytes = (size_t)slots_alloc_ * 8 * (1 + aggs_.size());
   if (off || d_state_ == nullptr || bytes == 0 || bytes > kMaxMirror) return nullptr;
-  if (h_mirror_ != nullptr && mirror_bytes_ != bytes) { ctx_->host_free(h_mirror_); h_mirror_ = nullptr; }
+  if (h_mirror_ != nullptr && mirror_bytes_ != bytes) {
+    // a fold kernel of an earlier push may still be writing the old mirror: it goes back to the process-wide pinned pool only
+    // once the stream is idle (rare: the table was re-laid-out between two pushes)
+    (void)hipStreamSynchronize(stream_);
+    ctx_->host_free(h_mirror_); h_mirror_ = nullptr; mirror_valid_ = false;
+  }
   if (h_mirror_ == nullptr) { h_mirror_ = (unsigned long long*)ctx_->host_alloc(bytes); mirror_bytes_ = bytes; }
   return h_mirror_;
 }
@@ -1481,6 +1486,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     if (grid > total_tiles) grid = (int)total_tiles;
     unsigned long long* partials = alloc_partials(grid);
     for (FdbScanArgs& a : parts) a.partials = partials;
+    bool fill_rides = false;
     if (state_virgin_ && jit_fn != nullptr && partials != nullptr && (uint64_t)slots_alloc_ * (1 + aggs_.size()) < (1ull << 32)) {
       // nothing accumulates into the table before reduce_partials (the next kernel on the stream): the scan fills it on its way in
       FdbScanArgs& a0 = parts[0];
@@ -1488,7 +1494,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
       a0.fill_words = (uint32_t)(slots_alloc_ * (1 + aggs_.size()));
       a0.fill_alloc = (uint32_t)slots_alloc_;
       state_idents(a0.fill_idents);
-      state_virgin_ = false;
+      fill_rides = true;
     } else {
       materialize_state();
     }
@@ -1501,6 +1507,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
       if (jit_fn != nullptr) hip_check(jit_launch(jit_fn, d_parts, (int)parts.size(), total_tiles, parts[0], grid, jit_block, lds_bytes, stream_), "scan launch");
       else hip_check(fdb_launch_scan_slots(d_parts, (int)parts.size(), parts[0], total_tiles, grid, lds_bytes, two_phase, sub, stream_), "scan launch");
     });
+    if (fill_rides) state_virgin_ = false;  // (only once the launch that carries the fill was accepted: a throw above leaves the table marked unfilled)
     last_kernel_ = jit_fn != nullptr ? "fdb_plan_kernel" : "scan_slots_kernel";
     pt.mark("scan launch");
     trace("after scan");
@@ -2211,6 +2218,7 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
   std::vector<FdbScanArgs> parts;
   std::vector<FdbCompactRec> recs;
   int64_t total_tiles = 0, total_super = 0;
+  bool fallback = false;
   {
     StageScope stage_scope(ctx_);
     unsigned char* d_blob = blob.bytes.empty() ? nullptr : (unsigned char*)upload(blob.bytes.data(), blob.bytes.size());
@@ -2228,10 +2236,12 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
       lut_lds_max = std::max(lut_lds_max, align_up(lds_off, 16));
       a.lut_class = lut_class[k];
       // every filter column in the early pools (the flags kernel has no late phase)
-      if (assign_slots(*in[live[k]], R, 2, /*relaxed=*/true) == 0) return per_record();
+      // (no `return per_record()` in here: the scope's destructor — which ends the deferral and ships what was staged — runs only
+      // AFTER a return expression has been evaluated, and the per-record path stages LUTs of its own)
+      if (assign_slots(*in[live[k]], R, 2, /*relaxed=*/true) == 0) { fallback = true; break; }
       const JitShape si = jit_shape(a, true, 512);
       if (k == 0) shape = si;
-      else if (!jit_shape_merge(&shape, si)) return per_record();  // records of different predicate shapes (schema drift)
+      else if (!jit_shape_merge(&shape, si)) { fallback = true; break; }  // records of different predicate shapes (schema drift)
       // the flags kernel counts in workgroup shares of four tiles (all of one record), the other kernels in tiles
       const int64_t rec_tiles = (a.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
       a.out_tile_base = total_tiles;
@@ -2241,12 +2251,15 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
       recs.push_back(FdbCompactRec{total_tiles, a.n_rows});
       total_tiles += rec_tiles;
     }
-    for (size_t k = 0; k < nl; k++) { Rs[k].args.lds_lut_bytes = (uint32_t)lut_lds_max; parts.push_back(Rs[k].args); }
+    for (size_t k = 0; k < nl && !fallback; k++) { Rs[k].args.lds_lut_bytes = (uint32_t)lut_lds_max; parts.push_back(Rs[k].args); }
     for (int k = 0; k < shape.n_c4; k++) row_bytes += shape.c4[k].has_values ? 4 : 0;
     for (int k = 0; k < shape.n_c8; k++) row_bytes += shape.c8[k].has_values ? 8 : 0;
-    d_parts = (const FdbScanArgs*)upload(parts.data(), parts.size() * sizeof(FdbScanArgs));
-    d_recs = (const FdbCompactRec*)upload(recs.data(), recs.size() * sizeof(FdbCompactRec));
+    if (!fallback) {
+      d_parts = (const FdbScanArgs*)upload(parts.data(), parts.size() * sizeof(FdbScanArgs));
+      d_recs = (const FdbCompactRec*)upload(recs.data(), recs.size() * sizeof(FdbCompactRec));
+    }
   }
+  if (fallback) return per_record();
   hipFunction_t flags_fn = jit_flags_get(shape);
   if (flags_fn == nullptr) return per_record();
 

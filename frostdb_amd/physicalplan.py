@@ -139,7 +139,7 @@ def regex_match(pattern, value: bytes) -> bool:
     m = ctypes.c_int32()
     rc = lib().fdb_regex_match(pat, len(pat), value, len(value), ctypes.byref(m))
     if rc != 0:
-        _raise(rc, lib().fdb_last_error().decode())
+        _raise(rc, lib().fdb_last_error().decode("utf-8", "replace"))
     return bool(m.value)
 
 
@@ -155,7 +155,7 @@ def read_ceiling(device: int = 0, nbytes: int = 1 << 31, reps: int = 5) -> float
     out = ctypes.c_double(0.0)
     rc = lib().fdb_read_ceiling(device, ctypes.c_int64(nbytes), reps, ctypes.byref(out))
     if rc != 0:
-        raise FdbError(rc, lib().fdb_last_error().decode())
+        raise FdbError(rc, lib().fdb_last_error().decode("utf-8", "replace"))
     return out.value
 
 
@@ -167,7 +167,7 @@ def explain(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction] = (
     need = ctypes.c_int64()
     rc = lib().fdb_plan_explain(ctypes.addressof(desc.desc), buf, len(buf), ctypes.byref(need))
     if rc != 0:
-        _raise(rc, lib().fdb_last_error().decode())
+        _raise(rc, lib().fdb_last_error().decode("utf-8", "replace"))
     return buf.value.decode()
 
 
@@ -177,7 +177,7 @@ def arrow_roundtrip(record: pa.RecordBatch) -> pa.RecordBatch:
     with ExportedBatch(record) as ex:
         rc = lib().fdb_arrow_roundtrip(ctypes.addressof(ex.array), ctypes.addressof(ex.schema), ctypes.addressof(arr), ctypes.addressof(sch))
     if rc != 0:
-        _raise(rc, lib().fdb_last_error().decode())
+        _raise(rc, lib().fdb_last_error().decode("utf-8", "replace"))
     return import_batch(arr, sch)
 
 
@@ -234,7 +234,7 @@ class ResidentBatch:
         out = ctypes.c_void_p()
         rc = lib().fdb_batch_from_parquet(arr, len(chunks), n_rows, device, ctypes.byref(out))
         if rc != 0:
-            _raise(rc, lib().fdb_last_error().decode())
+            _raise(rc, lib().fdb_last_error().decode("utf-8", "replace"))
         return cls(None, device=device, _handle=out.value)
 
     def __init__(self, batch: Optional[pa.RecordBatch], device: int = 0, _handle=None):
@@ -245,7 +245,7 @@ class ResidentBatch:
         with ExportedBatch(batch) as ex:
             rc = lib().fdb_batch_import(ctypes.addressof(ex.array), ctypes.addressof(ex.schema), device, ctypes.byref(out))
         if rc != 0:
-            _raise(rc, lib().fdb_last_error().decode())
+            _raise(rc, lib().fdb_last_error().decode("utf-8", "replace"))
         self.handle = out.value
         self.device = device
 
@@ -254,7 +254,7 @@ class ResidentBatch:
         arr, sch = ArrowArray(), ArrowSchema()
         rc = lib().fdb_batch_export(self.handle, ctypes.addressof(arr), ctypes.addressof(sch))
         if rc != 0:
-            _raise(rc, lib().fdb_last_error().decode())
+            _raise(rc, lib().fdb_last_error().decode("utf-8", "replace"))
         return import_batch(arr, sch)
 
     @property
@@ -291,7 +291,7 @@ class HashAggregatePlan:
         out = ctypes.c_void_p()
         rc = lib().fdb_plan_create(ctypes.addressof(self._desc.desc), device, ctypes.byref(out))
         if rc != 0:
-            _raise(rc, lib().fdb_last_error().decode())
+            _raise(rc, lib().fdb_last_error().decode("utf-8", "replace"))
         self.handle = out.value
         self.device = device
         self._next: Optional[Callable[[pa.RecordBatch], None]] = None
@@ -312,7 +312,7 @@ class HashAggregatePlan:
 
     def _check(self, rc: int) -> None:
         if rc != 0:
-            _raise(rc, lib().fdb_plan_last_error(self.handle).decode())
+            _raise(rc, lib().fdb_plan_last_error(self.handle).decode("utf-8", "replace"))
 
     def clone_empty(self) -> "HashAggregatePlan":
         """A fresh plan with the same descriptor on the same device (no state)."""

@@ -243,21 +243,6 @@ def _unicode_class_ranges(name: str, negated: bool):
     return body
 
 
-def _ascii_complement(body: bytes) -> bytes:
-    """The complement, over all runes, of a class body made of ASCII members (what `[[:^alpha:]]` means inside a bracket class)."""
-    import re as _re
-    rx = _re.compile(b"[" + body + b"]")
-    runs, start = [], None
-    for c in range(0x80):
-        if rx.match(bytes([c])) is None:
-            if start is None:
-                start = c
-        elif start is not None:
-            runs.append((start, c - 1)); start = None
-    runs.append((start if start is not None else 0x80, 0x10FFFF))
-    return "".join("\\U%08X" % a if a == b else "\\U%08X-\\U%08X" % (a, b) for a, b in runs).encode()
-
-
 def go_regexp_to_python(pattern: bytes) -> bytes:
     """RE2 (Go regexp) syntax → Python `re` syntax for the constructs whose SPELLING differs; their meaning is the same. `$` without
     the m flag is the end of the TEXT in Go (Python's would also match before a trailing newline) and `\\z` is Python's `\\Z`;
@@ -269,6 +254,18 @@ def go_regexp_to_python(pattern: bytes) -> bytes:
              b"graph": b"!-~", b"lower": b"a-z", b"print": b" -~", b"punct": b"!-/:-@\\[-`{-~", b"space": b"\\t\\n\\v\\f\\r ", b"upper": b"A-Z",
              b"word": b"0-9A-Za-z_", b"xdigit": b"0-9A-Fa-f"}
     out, i, n, in_class, multiline = bytearray(), 0, len(pattern), False, False
+    # A bracket class is collected and emitted at its `]`: members that are NEGATED named classes (\W, \P{..}, [:^alpha:]) cannot
+    # be spelled as their complement's ranges, because under (?i) regexp/syntax folds the POSITIVE class and negates afterwards
+    # (parser.appendGroup): `(?i)[\W]` does not match "k" although U+212A, which folds to k, is in the complement of \w. They
+    # become `[^…]` alternatives, which Python evaluates the same way (fold the rune, then test the negated set).
+    cls_pos, cls_neg, cls_negated = bytearray(), [], False
+
+    def close_class():
+        if not cls_neg:
+            return b"[" + (b"^" if cls_negated else b"") + bytes(cls_pos) + b"]"
+        alts = ([b"[" + bytes(cls_pos) + b"]"] if cls_pos else []) + [b"[^" + b + b"]" for b in cls_neg]
+        alt = b"(?:" + b"|".join(alts) + b")"
+        return b"(?:(?!" + alt + b")[\s\S])" if cls_negated else alt
     while i < n:
         c = pattern[i:i + 1]
         if c == b"\\" and i + 1 < n:
@@ -282,9 +279,16 @@ def go_regexp_to_python(pattern: bytes) -> bytes:
             if nx == b"z" and not in_class:
                 out += b"\\Z"; i += 2; continue
             if nx in _PERL_CLASS:  # \d \w \s are ASCII-only in RE2 (Python's are Unicode-aware on str patterns): spelled out
-                pos, comp = _PERL_CLASS[nx]
-                body = comp if nx.isupper() else pos
-                out += body if in_class else b"[" + body + b"]"
+                pos, _comp = _PERL_CLASS[nx]
+                if nx.isupper():
+                    if in_class:
+                        cls_neg.append(pos)
+                    else:
+                        out += b"[^" + pos + b"]"
+                elif in_class:
+                    cls_pos += pos
+                else:
+                    out += b"[" + pos + b"]"
                 i += 2; continue
             if nx in (b"b", b"B") and not in_class:  # ASCII word boundary (Python's \b counts é as a word character, Go's does not)
                 w = b"[0-9A-Za-z_]"
@@ -303,29 +307,46 @@ def go_regexp_to_python(pattern: bytes) -> bytes:
                     name, end = pattern[i + 2:i + 3], i + 3
                 if name is not None and name.startswith(b"^"):
                     neg, name = not neg, name[1:]
-                body = _unicode_class_ranges(name.decode("ascii", "replace"), neg) if name else None
+                body = _unicode_class_ranges(name.decode("ascii", "replace"), False) if name else None
                 if body is not None:
-                    out += body if in_class else b"[" + body + b"]"
+                    if neg and in_class:
+                        cls_neg.append(body)
+                    elif neg:
+                        out += b"[^" + body + b"]"
+                    elif in_class:
+                        cls_pos += body
+                    else:
+                        out += b"[" + body + b"]"
                     i = end; continue
-            out += pattern[i:i + 2]; i += 2; continue
+            if in_class:
+                cls_pos += pattern[i:i + 2]
+            else:
+                out += pattern[i:i + 2]
+            i += 2; continue
         if in_class:
             if c == b"[" and pattern[i + 1:i + 2] == b":":
                 j = pattern.find(b":]", i + 2)
                 name = pattern[i + 2:j] if j >= 0 else b""
                 neg = name.startswith(b"^")
                 if j >= 0 and name.lstrip(b"^") in posix:
-                    out += _ascii_complement(posix[name[1:]]) if neg else posix[name]
+                    if neg:
+                        cls_neg.append(posix[name[1:]])
+                    else:
+                        cls_pos += posix[name]
                     i = j + 2; continue
             if c == b"]":
                 in_class = False
-            out += c; i += 1; continue
+                out += close_class()
+                i += 1; continue
+            cls_pos += c; i += 1; continue
         if c == b"[":
             in_class = True
-            out += c; i += 1
+            cls_pos, cls_neg, cls_negated = bytearray(), [], False
+            i += 1
             if pattern[i:i + 1] == b"^":
-                out += b"^"; i += 1
+                cls_negated = True; i += 1
             if pattern[i:i + 1] == b"]":
-                out += b"\\]"; i += 1
+                cls_pos += b"\\]"; i += 1
             continue
         if c == b"(" and pattern[i + 1:i + 2] == b"?":
             m = _re.match(rb"\(\?([imsU]*)(-[imsU]+)?([:)])", pattern[i:])
@@ -345,6 +366,8 @@ def go_regexp_to_python(pattern: bytes) -> bytes:
         if c == b"$" and not multiline:
             out += b"\\Z"; i += 1; continue
         out += c; i += 1
+    if in_class:  # (unterminated: left for Python to refuse, like Go does)
+        out += b"[" + (b"^" if cls_negated else b"") + bytes(cls_pos)
     return bytes(out)
 
 

@@ -2072,6 +2072,32 @@ def test_filter_of_many_resident_records_in_one_launch_sequence_matches_the_orac
             r.close()
 
 
+def test_filter_batches_whose_records_need_different_predicate_shapes(pp):
+    """Parts of one table, same column set, but the filtered dictionary has 10 entries in one part and 200 in the next (the truth
+    table rides in a 64-bit immediate for ≤ 64 entries and in a byte LUT above) — and a part whose dictionary lacks the literal:
+    the shapes do not merge, the launch falls back to one pass per record, and that fall-back stages its own LUTs (it used to run
+    while the multi-record path's staging deferral was still in force, so the device read LUT bytes that had never been shipped)."""
+    rng = np.random.default_rng(2024)
+    recs = [make_prometheus_batch(rng, 50_000, n_path=10, null_frac=0.02), make_prometheus_batch(rng, 70_001, n_path=200, null_frac=0.02),
+            make_prometheus_batch(rng, 30_000, n_path=3, null_frac=0.0), make_prometheus_batch(rng, 2_048, n_path=65, null_frac=0.1)]
+    filt = And(Col("labels.path").RegexMatch("p000[1-7]$|p01[0-9]{2}$"), Col("value") > 100.0)
+    for trial in range(3):  # (the staging ring restarts between calls: repeat so that stale bytes of an earlier call cannot hide it)
+        plan = pp.HashAggregatePlan(filt)
+        rbs = [pp.ResidentBatch(r) for r in (recs if trial != 1 else recs[::-1])]
+        try:
+            outs = plan.FilterResidentMany(rbs)
+            for rec, out in zip(recs if trial != 1 else recs[::-1], outs):
+                want, idx = _oracle_filter(rec, filt)
+                g = arrow_to_pydict(out.to_arrow())
+                assert out.num_rows == len(idx), (trial, rec.num_rows, out.num_rows, len(idx))
+                assert all(g[nm] == want[nm] for nm in rec.schema.names)
+                out.close()
+        finally:
+            plan.Close()
+            for r in rbs:
+                r.close()
+
+
 def test_filter_batches_when_only_some_records_have_nulls_in_a_column(pp):
     """The compaction kernel is specialised per COLUMN (width × nullable) for the whole launch: a column that has a validity bitmap
     in one record and none in another (a part without NULLs drops the bitmap) is compacted as nullable everywhere — the records
@@ -2296,3 +2322,119 @@ def test_convert_isnull_if_projections_on_the_device(pp):
             got = run_gpu(pp, recs, filt, aggs, groups, resident=resident)
             want = run_oracle(recs, filt, aggs, groups)
             assert_same_result(got, want, cols, float_cols={a.Name() for a in aggs if "convert" in a.Name()})
+
+
+# ---- NaN / ±Inf / −0.0 in float64 columns --------------------------------------------------------------
+
+def _special_float_record(rng, n, n_path, special_first: bool):
+    """`value` float64 with NaN, ±Inf and ±0.0 sprinkled in. With special_first = False the first row of every group is an ordinary
+    number — the case in which the reference's first-value-wins loops (aggregate.go:846-857, :924-934) never keep a NaN."""
+    path = rng.integers(0, n_path, size=n).astype(np.uint32)
+    value = rng.uniform(-1000, 1000, size=n)
+    kind = rng.random(n)
+    value[kind < 0.05] = np.nan
+    value[(kind >= 0.05) & (kind < 0.08)] = np.inf
+    value[(kind >= 0.08) & (kind < 0.11)] = -np.inf
+    value[(kind >= 0.11) & (kind < 0.13)] = 0.0
+    value[(kind >= 0.13) & (kind < 0.15)] = -0.0
+    if not special_first:
+        first = np.unique(path, return_index=True)[1]
+        value[first] = rng.uniform(-1000, 1000, size=len(first))
+    names = pa.array([b"/p%03d" % i for i in range(n_path)], type=pa.binary())
+    return pa.RecordBatch.from_arrays([pa.DictionaryArray.from_arrays(pa.array(path), names), pa.array(value)], names=["labels.path", "value"])
+
+
+def _same_float(a, b):
+    return (math.isnan(a) and math.isnan(b)) or a == b  # (−0.0 == +0.0: numerically equal, which is the bar for float results)
+
+
+@pytest.mark.parametrize("resident", [False, True])
+def test_float_min_max_with_inf_and_nan_not_first_equal_the_reference(pp, variant, resident):
+    """±Inf are ordinary ordered values; a NaN that is not its group's first value is never kept by the reference — and never
+    by the device: MIN / MAX equal the oracle's bit for bit (up to the sign of a zero)."""
+    rng = np.random.default_rng(77)
+    recs = [_special_float_record(rng, 40_000, 37, special_first=False)]
+    aggs = [Min(Col("value")), Max(Col("value")), Count(Col("value"))]
+    got = run_gpu(pp, recs, None, aggs, [Col("labels.path")], resident=resident)
+    want = run_oracle(recs, None, aggs, [Col("labels.path")])
+    g = {k: (a, b, c) for k, a, b, c in zip(got["labels.path"], got["min(value)"], got["max(value)"], got["count(value)"])}
+    w = {k: (a, b, c) for k, a, b, c in zip(want["labels.path"], want["min(value)"], want["max(value)"], want["count(value)"])}
+    assert g.keys() == w.keys() and len(g) == 37
+    for k in g:
+        assert _same_float(g[k][0], w[k][0]) and _same_float(g[k][1], w[k][1]) and g[k][2] == w[k][2], (k, g[k], w[k])
+    assert any(v[0] == -math.inf for v in g.values()) and any(v[1] == math.inf for v in g.values())
+    # NaN-free data with infinities: SUM follows IEEE too (+Inf + −Inf = NaN, like the reference's plain adds)
+    v = np.array(recs[0].column("value"))
+    clean = recs[0].set_column(1, "value", pa.array(np.where(np.isnan(v), 1.5, v)))
+    gs = run_gpu(pp, [clean], None, [Sum(Col("value"))], [Col("labels.path")], resident=resident)
+    ws = run_oracle([clean], None, [Sum(Col("value"))], [Col("labels.path")])
+    gm, wm = dict(zip(gs["labels.path"], gs["sum(value)"])), dict(zip(ws["labels.path"], ws["sum(value)"]))
+    for k in wm:
+        assert _same_float(gm[k], wm[k]) or math.isclose(gm[k], wm[k], rel_tol=REL_TOL), (k, gm[k], wm[k])
+    assert any(math.isnan(x) or math.isinf(x) for x in wm.values())
+
+
+def test_float_min_max_device_rule_for_nan_and_negative_zero(pp, variant):
+    """The documented device rule, stated explicitly because the reference's own answer depends on row order
+    (a NaN survives its `if v < minV` loop only as the group's FIRST value, aggregate.go:846-857): the MIN / MAX of a group are those
+    of its non-NaN values; a group with nothing but NaNs gives NaN; −0.0 and +0.0 are one value, reported as +0.0. Where the
+    reference's order-dependent answer differs (NaN first) the test says so instead of hiding it."""
+    rng = np.random.default_rng(78)
+    rec = _special_float_record(rng, 30_000, 23, special_first=True)
+    path = np.array(rec.column("labels.path").indices)
+    v = np.array(rec.column("value"))
+    v[path == 5] = np.nan                      # a group of nothing but NaNs
+    v[path == 6] = np.where(rng.random((path == 6).sum()) < 0.5, 0.0, -0.0)  # a group of zeros of both signs
+    first7 = np.flatnonzero(path == 7)[0]
+    v[first7] = np.nan                         # NaN first: the reference answers NaN for this group, the device does not
+    rec = rec.set_column(1, "value", pa.array(v))
+    aggs = [Min(Col("value")), Max(Col("value"))]
+    for resident in (False, True):
+        got = run_gpu(pp, [rec], None, aggs, [Col("labels.path")], resident=resident)
+        g = {int(k[2:]): (a, b) for k, a, b in zip(got["labels.path"], got["min(value)"], got["max(value)"])}
+        for p in range(23):
+            x = v[path == p]
+            x = x[~np.isnan(x)]
+            if len(x) == 0:
+                assert math.isnan(g[p][0]) and math.isnan(g[p][1]), (p, g[p])
+            else:
+                assert g[p] == (x.min(), x.max()), (p, g[p], x.min(), x.max())
+        assert math.copysign(1.0, g[6][0]) == 1.0 and math.copysign(1.0, g[6][1]) == 1.0 and g[6] == (0.0, 0.0)
+    want = run_oracle([rec], None, aggs, [Col("labels.path")])
+    w = {int(k[2:]): (a, b) for k, a, b in zip(want["labels.path"], want["min(value)"], want["max(value)"])}
+    assert math.isnan(w[7][0]) and math.isnan(w[7][1]) and not math.isnan(g[7][0])  # the one documented difference
+    assert math.isnan(w[5][0]) and math.isnan(g[5][0])
+    # two-stage: partial results holding NaN (the all-NaN group) merge by the same rule
+    a, b = rec.slice(0, 15_000), rec.slice(15_000)
+    p1, p2 = pp.HashAggregatePlan(None, aggs, [Col("labels.path")]), pp.HashAggregatePlan(None, aggs, [Col("labels.path")])
+    try:
+        p1.Callback(a); p2.Callback(b)
+        p1.Merge(p2)
+        m = arrow_to_pydict(p1.Finish())
+        gm = {int(k[2:]): (x, y) for k, x, y in zip(m["labels.path"], m["min(value)"], m["max(value)"])}
+        for p in range(23):
+            assert all(_same_float(x, y) for x, y in zip(gm[p], g[p])), (p, gm[p], g[p])
+    finally:
+        p1.Close(); p2.Close()
+
+
+def test_float_compare_predicates_with_nan_rows_follow_ieee(pp, variant):
+    """`value > x`, `>=`, `<`, `<=`, `==` never select a NaN row, `!=` always does (IEEE compares — what Arrow's compare kernels
+    behind binaryscalarexpr.go:119-152 compute); ±Inf compare like numbers. Selection against the oracle, row for row."""
+    rng = np.random.default_rng(79)
+    rec = _special_float_record(rng, 50_000, 11, special_first=True)
+    v = np.array(rec.column("value"))
+    n_nan = int(np.isnan(v).sum())
+    assert n_nan > 1000
+    for expr, npsel in [(Col("value") > 10.0, v > 10.0), (Col("value") >= 0.0, v >= 0.0), (Col("value") < 0.0, v < 0.0), (Col("value") <= -0.0, v <= 0.0),
+                        (Col("value") == 0.0, v == 0.0), (Col("value") != 0.0, v != 0.0), (Col("value") > -math.inf, v > -np.inf),
+                        (Col("value") == math.inf, v == np.inf), (Col("value") < math.inf, v < np.inf)]:
+        plan = pp.HashAggregatePlan(expr)
+        try:
+            idx = plan.Select(rec)
+            want_tbl, want_idx = _oracle_filter(rec, expr)
+            assert list(idx) == list(want_idx) == list(np.flatnonzero(npsel)), expr
+        finally:
+            plan.Close()
+        got = run_gpu(pp, [rec], expr, [Count(Col("value"))], [])
+        assert got["count(value)"] == [int(npsel.sum())]

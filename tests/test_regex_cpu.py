@@ -139,6 +139,35 @@ def test_case_folding_follows_orbits_not_ascii(pp):
                 assert pp.regex_match("(?i)^" + re.escape(ch) + "$", other.encode()) is True, (hex(c), other)
 
 
+def test_negated_named_classes_fold_before_they_negate(pp):
+    """regexp/syntax folds the POSITIVE class and negates afterwards (parser.appendGroup, parseUnicodeClass; parse_test.go:
+    `(?i)\\W` → cc{0x0-0x2f 0x3a-0x40 0x5b-0x5e 0x60 0x7b-0x17e 0x180-0x2129 0x212b-0x10ffff}, i.e. WITHOUT U+017F and U+212A):
+    negating first would let the folding pull k / K / s / S back into the negated set."""
+    from oracle import go_regexp_to_python
+    no = [(r"(?i)^\W$", "k"), (r"(?i)^\W$", "K"), (r"(?i)^\W$", "s"), (r"(?i)^\W$", "S"), (r"(?i)^\W$", "\u212a"), (r"(?i)^\W$", "\u017f"),
+          (r"(?i)^[[:^alpha:]]$", "k"), (r"(?i)^[[:^alpha:]]$", "\u212a"), (r"(?i)^[\W]$", "s"), (r"(?i)^[^\W]$", "-"), (r"(?i)^\P{Lu}$", "a"),
+          (r"(?i)^\p{^Lu}$", "a"), (r"(?i)^[\P{Ll}]$", "A"), (r"(?i)^[[:^upper:]]$", "a"), (r"(?i)^[[:^lower:]x]$", "Q"), (r"^\W$", "k"),
+          (r"(?i)^[^\W\d]$", "7")]
+    yes = [(r"(?i)^\W$", "-"), (r"(?i)^\W$", "é"), (r"^\W$", "\u212a"), (r"^\W$", "\u017f"), (r"^[[:^alpha:]]$", "\u212a"), (r"(?i)^[^\W]$", "\u212a"),
+           (r"(?i)^[^\W]$", "k"), (r"(?i)^\D$", "x"), (r"(?i)^\S$", "x"), (r"(?i)^\P{Lu}$", "1"), (r"(?i)^[[:^alpha:]x]$", "X"), (r"(?i)^[[:^alpha:]]$", "1"),
+           (r"(?i)^[^\W\d]$", "\u017f")]
+    for want, cases in ((False, no), (True, yes)):
+        for pat, val in cases:
+            assert pp.regex_match(pat, val.encode()) is want, (pat, val, want)
+            rx = re.compile(go_regexp_to_python(pat.encode()).decode())  # the oracle's engine agrees (it had the same flaw)
+            assert (rx.search(val) is not None) is want, ("oracle", pat, val, want)
+
+
+def test_patterns_go_refuses(pp):
+    """regexp.Compile errors the built-in engine used to let through: a capture name used twice, and pattern bytes that are not UTF-8
+    (overlong forms, surrogates, runes past U+10FFFF)."""
+    for pat in (b"(?P<n>a)(?P<n>b)", b"(?<n>a)|(?P<n>b)", b"a\xc0\xafb", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"[\xe0\x80\xaf]"):
+        with pytest.raises(pp.FdbError) as e:
+            pp.regex_match(pat, b"x")
+        assert e.value.code == pp.FDB_ERR_INVALID, pat
+    assert pp.regex_match("(?P<a>x)(?P<b>x)", b"xx") is True
+
+
 def test_matching_is_linear_in_the_value(pp):
     """The classic backtracking bombs: (a+)+$ / (a|aa)*$ / (.*)*x over a long run of a's end in milliseconds (a backtracking
     engine needs 2^n steps); a 1 MB value against a 60-state pattern in well under a second."""
