@@ -238,7 +238,7 @@ def self_launch(args):
     import subprocess
     out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
     n_dev = int(out.stdout.strip() or 0) if out.returncode == 0 else 0
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and not (os.environ.get("FDB_BENCH_TEST_SHARE_DEVICE") == "1" and n_dev >= 1):
         raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {n_dev} GPU(s); refusing to report a {args.gpus}-GPU number from fewer devices "
                          "(--force-local runs the N-rank path on the devices there are, as a functional check)")
     with socket.socket() as s:
@@ -448,9 +448,12 @@ def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_fini
     elapsed = time.perf_counter() - t0
     elapsed = float(group.reduce(np.array([elapsed]), "max")[0])
     # every rank's own kernel figures (rank order): the scan is rank-local, so the roofline fraction is a per-GPU quantity
+    # (rccl_ranks_seen: what the transport itself reports as the communicator's size — ncclCommCount for RCCL — so that a line
+    # claiming N GPUs shows N ranks INSIDE the communicator of every rank, not just N processes)
     per_rank = group.gather({"rank": rank, "rows": wl.rows, "kernel_ms_per_step": k_ms / max(steps, 1),
                              "kernel_frac": (k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else 0.0,
-                             "merge_ms_per_step": merge_ms / max(steps, 1)})
+                             "merge_ms_per_step": merge_ms / max(steps, 1),
+                             "rccl_ranks_seen": comm.transport_ranks if comm is not None and hasattr(comm, "transport_ranks") else None})
     return {"elapsed": elapsed, "k_ms": k_ms, "k_bytes": k_bytes, "k_launches": k_launches, "kernel": kernel_name, "checked": checked,
             "per_rank": per_rank, "merge_ms": max(p["merge_ms_per_step"] for p in per_rank),
             "first_step_ms": first_step_ms, "jit_compiled": jit1["compiled"] - jit0["compiled"], "jit_compile_ms": jit1["compile_ms"] - jit0["compile_ms"],
@@ -780,6 +783,11 @@ def run_rank(args, group, device, comm):
     if merging:
         line["merge_ms"] = r["merge_ms"]          # device time of the merge collectives per step (hipEvents on the plan's stream), max over ranks
         line["per_rank"] = r["per_rank"]
+        line["rccl_ranks_seen"] = [p.get("rccl_ranks_seen") for p in r["per_rank"]]
+    if getattr(args, "share_device", False):
+        import torch
+        line["devices_used"] = min(world, torch.cuda.device_count())
+        line["note"] = "FDB_BENCH_TEST_SHARE_DEVICE: functional check of the one-process-per-rank path with ranks sharing devices; not an N-GPU measurement"
     if args.force_local:
         import torch
         line["devices_used"] = min(world, torch.cuda.device_count())
@@ -859,6 +867,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # Test hook (tests/test_gpu_fake_rccl.py): the one-process-per-rank path on a box with fewer GPUs than ranks — the ranks share
+    # devices, the control plane runs over gloo (torch's own RCCL refuses two ranks on a device) and the C-ABI communicator over
+    # whatever $FDB_RCCL_LIB names. A functional check; the line says so.
+    args.share_device = os.environ.get("FDB_BENCH_TEST_SHARE_DEVICE") == "1" and torch.cuda.device_count() < world
+    if args.share_device:
+        local_rank = local_rank % torch.cuda.device_count()
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: no GPU {local_rank} on this box ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
@@ -866,7 +880,11 @@ def main():
     if merging:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctl_dev = "cpu" if args.share_device else "cuda"
 
     from frostdb_amd import build as fb
     if rank == 0:
@@ -879,7 +897,7 @@ def main():
         # RCCL through the C ABI: rank 0's unique id travels over the already-initialised process group (as a Go host would
         # ship it over its own control plane), then every rank joins the communicator with fdb_comm_init_rank.
         from frostdb_amd import comm as fcomm
-        uid = torch.zeros(fcomm.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        uid = torch.zeros(fcomm.UNIQUE_ID_BYTES, dtype=torch.uint8, device=ctl_dev)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(fcomm.unique_id()), dtype=torch.uint8))
         if world > 1:
@@ -895,7 +913,7 @@ def main():
             ok, comm = 0, None
             print(f"[bench] rank {rank}: fdb_comm_init_rank failed ({e}); proposing the torch.distributed merge", file=sys.stderr)
         if world > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctl_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
         if not ok:

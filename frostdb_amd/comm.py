@@ -75,6 +75,11 @@ class Comm:
     def size(self) -> int:
         return _lib().fdb_comm_size(self.handle)
 
+    @property
+    def transport_ranks(self) -> int:
+        """What the transport itself says the communicator's size is (RCCL: ncclCommCount); -1 if it cannot say."""
+        return _lib().fdb_comm_transport_ranks(self.handle)
+
     # ---- plan-level merges (collective: every rank calls) --------------------------------------------------------------
     def allreduce(self, plan: "pp.HashAggregatePlan") -> bool:
         """In-place all-reduce of the plan's dense table when every rank has the same slot layout. False: nothing changed."""

@@ -489,6 +489,10 @@ int fdb_comm_init_local(const int* devices, int32_t n, fdb_comm** out) {
 
 int32_t fdb_comm_rank(const fdb_comm* comm) { return comm && comm->c ? comm->c->rank : -1; }
 int32_t fdb_comm_size(const fdb_comm* comm) { return comm && comm->c ? comm->c->size : 0; }
+int32_t fdb_comm_transport_ranks(fdb_comm* comm) {
+  if (comm == nullptr || !comm->c) return -1;
+  try { return comm->c->transport_ranks(); } catch (...) { return -1; }
+}
 const char* fdb_comm_last_error(const fdb_comm* comm) { return comm && comm->c ? comm->c->error.c_str() : g_last_error.c_str(); }
 void fdb_comm_destroy(fdb_comm* comm) { delete comm; }
 

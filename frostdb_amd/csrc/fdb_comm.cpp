@@ -21,7 +21,17 @@ namespace {
 
 // Bytes one rank sends to one peer per grouped send/recv round. Measured on MI355X / RCCL 2.26 (round 1): a single exchange
 // moving 1.4 GB between two buffers silently delivered only its first ≈0.69 GB, so big partitions travel in slices.
-constexpr int64_t kExchangeSliceWords = (128 << 20) / 8;
+constexpr int64_t kExchangeSliceWordsDefault = (128 << 20) / 8;
+// ($FDB_EXCHANGE_SLICE_BYTES: test hook — tests/test_gpu_fake_rccl.py forces 1 MiB slices so that the slicing itself is exercised
+// with several ranks; every rank of a communicator must see the same value)
+int64_t exchange_slice_words() {
+  static const int64_t words = [] {
+    const char* e = std::getenv("FDB_EXCHANGE_SLICE_BYTES");
+    const long long b = e != nullptr ? std::atoll(e) : 0;
+    return b >= 8 ? (int64_t)(b / 8) : kExchangeSliceWordsDefault;
+  }();
+  return words;
+}
 
 // ---- librccl, bound at run time -------------------------------------------------------------------------------------------
 struct RcclApi {
@@ -38,6 +48,7 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;  // optional: what the communicator itself says its size is (Comm::transport_ranks)
 
   RcclApi() {
     // The copy already mapped into the process wins (a host that also runs torch carries its own librccl; two RCCLs in one
@@ -65,6 +76,7 @@ struct RcclApi {
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    CommCount = (decltype(CommCount))dlsym(handle, "ncclCommCount");
   }
   bool ok() const { return handle != nullptr && why.empty(); }
 };
@@ -117,6 +129,14 @@ class RcclComm : public Comm {
       hip_check(hipHostMalloc((void**)&h_ctl, host_bytes, hipHostMallocDefault), "hipHostMalloc(comm scratch)");
       h_ctl_bytes = host_bytes;
     }
+  }
+
+  int transport_ranks() override {
+    RcclApi& R = rccl();
+    if (R.CommCount == nullptr || comm == nullptr) return -1;
+    int n = -1;
+    nccl_check(R.CommCount(comm, &n), "ncclCommCount");
+    return n;
   }
 
   void probe_max(int64_t v[4]) override {
@@ -186,6 +206,7 @@ class RcclComm : public Comm {
       for (int q = 0; q < size; q++) max_words = std::max(max_words, words[(size_t)p][(size_t)q]);
     }
     // every rank runs the same number of rounds (derived from the matrix all of them hold); a pair with nothing left skips
+    const int64_t kExchangeSliceWords = exchange_slice_words();
     const int64_t rounds = (max_words + kExchangeSliceWords - 1) / kExchangeSliceWords;
     for (int64_t k = 0; k < rounds; k++) {
       const int64_t lo = k * kExchangeSliceWords;

@@ -22,6 +22,9 @@ class Comm {
   virtual ~Comm() = default;
   int rank = 0, size = 1, device = 0;
   std::string error;  // text of the last failure on this handle (fdb_comm_last_error)
+  // Ranks the TRANSPORT reports for this communicator (RCCL: ncclCommCount; the in-process transport: its group's size; -1 when the
+  // library cannot say). bench.py prints it per rank so that a line claiming N GPUs shows N ranks inside the communicator itself.
+  virtual int transport_ranks() { return size; }
 
   // Host-level control exchange (blocking, collective): every rank's blob, in rank order.
   virtual std::vector<std::vector<uint8_t>> all_gather_host(const std::vector<uint8_t>& mine) = 0;

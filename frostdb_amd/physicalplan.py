@@ -108,6 +108,8 @@ def lib() -> ctypes.CDLL:
     L.fdb_comm_rank.restype = i32
     L.fdb_comm_size.argtypes = [vp]
     L.fdb_comm_size.restype = i32
+    L.fdb_comm_transport_ranks.argtypes = [vp]
+    L.fdb_comm_transport_ranks.restype = i32
     L.fdb_comm_last_error.argtypes = [vp]
     L.fdb_comm_last_error.restype = ctypes.c_char_p
     L.fdb_comm_destroy.argtypes = [vp]

@@ -365,6 +365,9 @@ int fdb_comm_init_all(const int* devices, int32_t n, fdb_comm** out /* [n] */);
 int fdb_comm_init_local(const int* devices, int32_t n, fdb_comm** out /* [n] */);
 int32_t fdb_comm_rank(const fdb_comm* comm);
 int32_t fdb_comm_size(const fdb_comm* comm);
+/* The size the TRANSPORT itself reports for this communicator (RCCL: ncclCommCount) — evidence that an N-GPU merge really ran
+ * over N ranks; -1 if the bound library has no such entry point. */
+int32_t fdb_comm_transport_ranks(fdb_comm* comm);
 const char* fdb_comm_last_error(const fdb_comm* comm);
 void fdb_comm_destroy(fdb_comm* comm);
 /* Low-cardinality merge (cfgs 2-4): when every rank's dense table has the same slot layout (fdb_plan_state_signature — parts of

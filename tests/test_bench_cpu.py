@@ -151,3 +151,41 @@ def test_control_plane_of_the_n_rank_bench_on_gloo_world_size_2():
     for t in ts:
         t.join(timeout=60)
     assert out[0] == out[1] == ([3, 19], [1.5], [500_000_004, 500_000_003])
+
+
+def test_self_launch_of_gpus_8_is_the_command_torch_distributed_run_expects(monkeypatch):
+    """`python bench.py --gpus 8 --steps K --warmup W` started plainly re-executes itself as the driver's own form: `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 …`. Checked
+    against torch's own argument parser (torch.distributed.run.get_args_parser), without a GPU: the device count is faked, execv
+    captured."""
+    import subprocess
+    import sys
+    import types
+    b = _bench()
+    captured = {}
+    monkeypatch.setattr(b.subprocess if hasattr(b, "subprocess") else subprocess, "run",
+                        lambda *a, **k: types.SimpleNamespace(returncode=0, stdout="8\n", stderr=""))
+
+    def fake_execv(exe, argv):
+        captured["exe"], captured["argv"] = exe, list(argv)
+        raise SystemExit(0)
+    monkeypatch.setattr(b.os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    args = b.parse_args()
+    try:
+        b.self_launch(args)
+    except SystemExit:
+        pass
+    argv = captured["argv"]
+    assert captured["exe"] == sys.executable and argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    from torch.distributed.run import get_args_parser
+    ns = get_args_parser().parse_args(argv[3:])
+    assert ns.nnodes == "1" and str(ns.nproc_per_node) == "8" and ns.master_addr == "127.0.0.1" and int(ns.master_port) > 0
+    assert os.path.basename(ns.training_script) == "bench.py" and os.path.isabs(ns.training_script)
+    assert ns.training_script_args == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    # fewer devices than ranks: refused (no N-GPU number from fewer GPUs) …
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout="1\n", stderr=""))
+    import pytest
+    with pytest.raises(SystemExit) as e:
+        b.self_launch(args)
+    assert "refusing" in str(e.value)
