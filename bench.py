@@ -416,9 +416,14 @@ def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_fini
             n_out = int(group.reduce(np.array([out.num_rows], dtype=np.int64), "sum")[0])
             assert int(expected[0][0]) == total_rows and 0 < n_out <= args.groups, (int(expected[0][0]), total_rows, n_out)
             assert math.isclose(float(sums[0]), float(expected[1][0]), rel_tol=1e-9), (float(sums[0]), float(expected[1][0]))
-            checked = {"groups_out": n_out, "sum_check": "Σ over ranks of Σ sum(value) == Σ value (1e-9 rel)"}
+            checked = {"groups_out": n_out, "sum_check": "Σ over ranks of Σ sum(value) == Σ value (1e-9 rel)",
+                       "against": "numpy expectation (row count and Σ value of every generated record); not the oracle"}
         elif rank == 0:
             checked = wl.check(out, expected, total_rows)
+            # what the timed path's result was compared with: at these sizes a numpy restatement of the query computed per generated
+            # record (bench.py expected_cfg2 / _cfg3 / _cfg5) — the ORACLE checks the same path at sizes it finishes in seconds (tests/)
+            checked["against"] = ("numpy expectation: every group's aggregates (bench.py expected_cfg%d), summed over records%s; not the oracle" % (wl.config, " and ranks" if world > 1 else "")
+                                  if wl.config in (2, 3) else "numpy expectation (row count and Σ value of every generated record) + group count bound; not the oracle")
     del out
 
     if args.sweep:
@@ -566,7 +571,8 @@ def measure_select(wl, steps=10, warmup=2):
                          "algorithmic_bytes_per_row": k_bytes / (rows * steps), "min_traffic_bytes_per_row": min_traffic / rows,
                          "min_traffic_frac": (min_traffic * steps / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0,
                          "whole_step_frac": (k_bytes / steps) / (el / steps) / 1e9 / HBM_PEAK_GBS},
-            "checked": {"selected_rows": sum(got), "first_record_values": "bit-identical to numpy's value[value > T]"}}
+            "checked": {"selected_rows": sum(got), "first_record_values": "bit-identical to numpy's value[value > T]",
+                        "against": "numpy expectation (selected-row counts of every record; the first records' compacted values); not the oracle"}}
 
 
 def h2d_rate_gbs(device, nbytes=1 << 30):
@@ -683,7 +689,8 @@ def measure_parquet(device, rows=20_000_000, passes=3):
         out[variant] = {"file_bytes": int(fb), "decoded_column_bytes": int(ob), "row_groups": n_rg, "ms_per_pass": dt * 1e3, "value": rows / dt, "unit": "rows/s",
                         "file_GBps": fb / dt / 1e9, "file_plus_columns_GBps": (fb + ob) / dt / 1e9,
                         "host_part_ms": (s1["host_ms"] - s0["host_ms"]) / passes, "device_part_ms": (s1["device_ms"] - s0["device_ms"]) / passes,
-                        "bound": "host" if (s1["host_ms"] - s0["host_ms"]) > (s1["device_ms"] - s0["device_ms"]) else "pcie", "frac_of_h2d": fb / dt / 1e9 / h2d}
+                        "bound": "host" if (s1["host_ms"] - s0["host_ms"]) > (s1["device_ms"] - s0["device_ms"]) else "pcie", "frac_of_h2d": fb / dt / 1e9 / h2d,
+                        "checked": {"groups_out": res.num_rows, "against": "numpy expectation: every group's sum (bench.py expected_cfg2 on the record the file was written from); not the oracle"}}
         del pinned
     return out
 
