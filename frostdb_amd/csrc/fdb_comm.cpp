@@ -440,6 +440,7 @@ bool Plan::comm_allreduce(Comm& comm) {
     if (comm.device != device_) throw Error(FDB_ERR_INVALID, "communicator endpoint lives on another device than the plan");
     inject_merge_fault(comm.rank);
     settle();
+    runs_to_table();  // (an ordered plan's collected runs become table entries before anything is merged)
     hip_check(hipSetDevice(device_), "hipSetDevice");
     const uint64_t sig = state_signature(&n_slots) & ((1ull << 62) - 1);
     v[0] = (int64_t)sig; v[1] = -(int64_t)sig; v[2] = n_slots; v[3] = -n_slots;
@@ -501,6 +502,7 @@ GroupSchema Plan::export_schema() const {
 }
 
 void Plan::adopt_schema(const GroupSchema& s) {
+  runs_to_table();
   if (mode_ == TableMode::DENSE) switch_to_hash();  // (before the column set changes)
   if (s.agg_types.size() != aggs_.size()) throw Error(FDB_ERR_INVALID, "plans have different aggregations");
   for (size_t j = 0; j < aggs_.size(); j++) {
@@ -543,6 +545,7 @@ void Plan::comm_exchange(Comm& comm, Plan& shard) {
     if (comm.device != device_ || shard.device_ != device_) throw Error(FDB_ERR_INVALID, "communicator endpoint lives on another device than the plan");
     inject_merge_fault(comm.rank);
     settle();
+    runs_to_table();  // (an ordered plan's collected runs become table entries before anything is merged)
     hip_check(hipSetDevice(device_), "hipSetDevice");
     const GroupSchema mine = export_schema();
     put_u32(&blob, (uint32_t)mine.cols.size());

@@ -109,15 +109,22 @@ void Plan::hash_insert_entries(const std::vector<unsigned long long>& entries, c
   if (n == 0) return;
   if (h_count_dev_ != nullptr) hash_groups();  // refresh the bound (waits for the stream)
   hash_reserve((uint64_t)n);
-  const int in_ew = (int)(1 + aggs_.size());
   void* d_entries = ctx_->dev_alloc(entries.size() * 8);
   void* d_keys = ctx_->dev_alloc(keys.size() * 4);
   scratch_.push_back(d_entries); scratch_.push_back(d_keys);
   hip_check(hipMemcpyAsync(d_entries, entries.data(), entries.size() * 8, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(entries)");
   hip_check(hipMemcpyAsync(d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(keys)");
+  hash_merge_device((const unsigned long long*)d_entries, (const uint32_t*)d_keys, n, in_kw, cols);
+  hip_check(hipStreamSynchronize(stream_), "sync(hash merge)");  // the host vectors must outlive the copies
+}
+
+// The merge launch itself: `n` pre-aggregated entries ({count, acc…} + key tuples of `in_kw` words) already on the device. The
+// table must have room (hash_reserve).
+void Plan::hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols) {
+  const int in_ew = (int)(1 + aggs_.size());
   FdbHashMergeArgs m;
   std::memset(&m, 0, sizeof(m));
-  m.entries = (const unsigned long long*)d_entries; m.in_keys = (const uint32_t*)d_keys; m.n = n;
+  m.entries = d_entries; m.in_keys = d_keys; m.n = n;
   m.table = h_table_; m.keys = h_keys_; m.n_groups = h_count_dev_; m.mask = h_capacity_ - 1;
   m.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
   m.n_cols = (int)cols.size(); m.in_key_words = in_kw; m.in_entry_words = in_ew; m.entry_words = h_entry_words_; m.key_words = h_key_words_;
@@ -127,7 +134,6 @@ void Plan::hash_insert_entries(const std::vector<unsigned long long>& entries, c
     m.funcs[j] = f == FDB_AGG_COUNT ? (final_stage_ ? 1 : 0) : f == FDB_AGG_SUM ? (aggs_[j].type == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
   }
   hip_check(fdb_launch_hash_merge(m, stream_), "hash merge");
-  hip_check(hipStreamSynchronize(stream_), "sync(hash merge)");  // the host vectors must outlive the copies
   state_dirty_ = true;
 }
 
@@ -168,7 +174,7 @@ void Plan::switch_to_hash() {
   slots_alloc_ = 0; n_slots_ = 1;
 }
 
-void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live) {
+void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live, bool runs) {
   hash_layout();
   uint64_t rows_left_total = 0;  // rows this call will still put into the table (what the cardinality estimate extrapolates to)
   for (int i : live) rows_left_total += (uint64_t)bs[i]->rows;
@@ -247,12 +253,52 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     // The run-time specialised kernel for this record's shape (fdb_jit.cpp), or the interpreting scan_hash_kernel
     hipFunction_t jit_fn = nullptr;
     int jit_grid = 0;
+    if (runs) h.runs.tuples = (unsigned char*)(uintptr_t)1;  // (the shape is that of a runs launch; the real pointers follow below)
+    const size_t run_lds = runs ? (size_t)4 * FDB_RUN_WAVE_LDS : 0;
     if (sub_tiles != 4 && a.lds_lut_bytes <= FDB_LDS_BUDGET) {
       JitHashShape shape = jit_hash_shape(h, hcols.data());
-      shape.ablate = ablate & 3;
+      shape.ablate = runs ? 0 : ablate & 3;
       jit_fn = jit_hash_get(shape);
       if (jit_fn != nullptr)
-        jit_grid = grid_override > 0 ? grid_override : (fdb_scan_default_grid(device_) / 2) * std::min(4, jit_blocks_per_cu(jit_fn, 256, a.lds_lut_bytes));
+        jit_grid = grid_override > 0 ? grid_override : (fdb_scan_default_grid(device_) / 2) * std::min(4, jit_blocks_per_cu(jit_fn, 256, a.lds_lut_bytes + run_lds));
+    }
+    if (runs && jit_fn == nullptr) {  // no specialised kernel after all (hiprtc failed): what was collected goes into the table, this record and the rest take the probing path
+      runs_to_table();
+      if (mode_ == TableMode::DENSE) switch_to_hash();
+      runs = false;
+      std::memset(&h.runs, 0, sizeof(h.runs));
+      h.key_words = h_key_words_; h.entry_words = h_entry_words_;
+    }
+    if (runs) {
+      // ---- table-free: ONE launch over the whole record; its runs land in a segment sized for the worst case (every row a run) ----
+      if (runs_.size() >= FDB_MAX_RUN_SEGMENTS) throw Error(FDB_ERR_STATE, "internal: run segments exhausted");  // (runs_wanted keeps this from happening)
+      const int64_t n_tiles = (b.rows + 1023) / 1024;
+      const int64_t launch_grid = std::min<int64_t>(jit_grid, n_tiles);
+      RunSegment seg;
+      seg.n_entries = n_tiles * 4;
+      const int64_t n_chunks = b.rows / (FDB_RUN_CHUNK - 256) + launch_grid * 4 + 2;  // a wave abandons < 256 slots when it changes chunks and keeps one chunk open
+      seg.capacity = n_chunks * FDB_RUN_CHUNK;
+      const size_t tuples_bytes = align_up_sz((size_t)seg.capacity * FDB_RUN_TUPLE_BYTES, 256), arr_bytes = align_up_sz((size_t)seg.capacity * 8, 256);
+      const size_t dir_bytes = align_up_sz((size_t)seg.n_entries * 8, 256);
+      seg.block = ctx_->dev_alloc(tuples_bytes + 2 * arr_bytes + dir_bytes + 256);
+      unsigned char* base = (unsigned char*)seg.block;
+      seg.tuples = base; seg.cnt = (unsigned long long*)(base + tuples_bytes); seg.acc = (unsigned long long*)(base + tuples_bytes + arr_bytes);
+      seg.dir = (uint32_t*)(base + tuples_bytes + 2 * arr_bytes); seg.cursor = (uint32_t*)(base + tuples_bytes + 2 * arr_bytes + dir_bytes);
+      runs_.push_back(seg);
+      hip_check(hipMemsetAsync(seg.dir, 0, dir_bytes + 256, stream_), "hipMemsetAsync(run directory)");
+      h.runs.tuples = seg.tuples; h.runs.cnt = seg.cnt; h.runs.acc = seg.acc; h.runs.dir = seg.dir; h.runs.chunk_cursor = seg.cursor;
+      h.table = nullptr; h.keys = nullptr; h.n_groups = nullptr; h.mask = 0;
+      h.row_begin = 0; h.row_end = b.rows;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
+      hip_check(jit_hash_launch(jit_fn, h, (int)launch_grid, a.lds_lut_bytes + run_lds, stream_), "run scan launch");
+      last_kernel_ = "fdb_hash_kernel(runs)";
+      if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
+      state_dirty_ = true;
+      stat_launches += 1;
+      stat_bytes += R.bytes;
+      stat_rows += b.rows;
+      continue;
     }
     for (int64_t r0 = 0; r0 < b.rows;) {
       // How many rows may go into the table before the next look at its group count: capacity / 2 − groups (every one of them
@@ -385,10 +431,12 @@ int host_threads_for(size_t elements) {
 
 // `resident` (fdb_plan_finish_batch): the result STAYS in HBM — the columns are written once, at the width a resident record uses
 // (uint32 indices), into an arena the batch owns; nothing crosses PCIe but the per-column NULL counts.
-int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resident) {
+int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resident, const RunsView* runs) {
   hip_check(hipSetDevice(device_), "hipSetDevice");
   PhaseTimer pt;
-  const uint64_t n = hash_groups();
+  // (`runs`: the groups come from an ordered plan's run store instead of the table — pass 1 below is runs_expand, everything
+  // after it — the column pass, transport widths, slices, widening, the resident form — is shared)
+  const uint64_t n = runs != nullptr ? (uint64_t)runs->n_groups : hash_groups();
   if (pt.on) pt.mark("finish: group count");
   const size_t n_cols = gcols_.size(), n_vals = 1 + aggs_.size();
   const size_t np = (size_t)((n + 63) & ~(uint64_t)63) + 64;  // padded row count of the buffers
@@ -477,7 +525,19 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
   std::shared_ptr<void> backing;
   unsigned char* h_block = nullptr;
   unsigned char* h_narrow = nullptr;  // pinned landing area of the narrow slices
-  if (n > 0) {
+  if (n > 0 && runs != nullptr) {
+    hip_check(hipMemsetAsync(a.out_nulls, 0, std::max<size_t>(n_cols, 1) * 8, stream_), "hipMemsetAsync(null counts)");
+    FdbRunsExpandArgs x;
+    std::memset(&x, 0, sizeof(x));
+    x.phys = runs->phys; x.flags = runs->flags; x.out_idx = runs->out_idx; x.n_runs = runs->n_runs;
+    x.dense_keys = a.dense_keys; x.vals_cnt = d_vals[0]; x.vals_acc = d_vals[1];
+    x.n_cols = (int)n_cols; x.key_words = h_key_words_; x.func = runs_func();
+    for (size_t c = 0; c < n_cols; c++) x.col_word[c] = gcols_[c].word;
+    // groups made of several runs (cut by a wave or record boundary) are folded with atomics: identity first
+    hip_check(hipMemsetAsync(d_vals[0], 0, (size_t)n * 8, stream_), "hipMemsetAsync(counts)");
+    hip_check(fdb_launch_fill_u64(d_vals[1], (int64_t)n, x.func == 3 ? (unsigned long long)FDB_I64_MAX : x.func == 4 ? (unsigned long long)FDB_I64_MIN : 0ull, stream_), "fill identity");
+    hip_check(fdb_launch_runs_expand(x, runs->segs, stream_), "runs expand");
+  } else if (n > 0) {
     hip_check(fdb_launch_hash_chunk_bases(h_table_, h_capacity_, h_entry_words_, d_bases, d_bases + n_chunks + 4, d_n, stream_), "hash chunk bases");
     hip_check(hipMemsetAsync(a.out_nulls, 0, std::max<size_t>(n_cols, 1) * 8, stream_), "hipMemsetAsync(null counts)");
     hip_check(fdb_launch_hash_gather_rows(a, device_, stream_), "hash gather rows");
@@ -528,7 +588,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
       const AggState& A = aggs_[j];
       const bool count_from_cnt = A.func == FDB_AGG_COUNT && !final_stage_;
       DevColumn d;
-      d.name = A.result_name; d.length = (int64_t)n;
+      d.name = A.emit_name; d.length = (int64_t)n;
       const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
       d.kind = is_f64 ? ColKind::F64 : ColKind::I64;
       d.format = is_f64 ? "g" : "l";
@@ -568,7 +628,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
     const AggState& A = aggs_[j];
     if (A.role == 2) continue;  // MAX half of UNIQUE
     OutColumn oc;
-    oc.name = A.result_name;
+    oc.name = A.emit_name;
     oc.length = (int64_t)n;
     const bool count_from_cnt = A.func == FDB_AGG_COUNT && !final_stage_;
     const bool is_f64 = !count_from_cnt && A.type == FDB_T_F64;
@@ -721,6 +781,7 @@ void Plan::group_schema(ArrowArray* out, ArrowSchema* out_schema) {
 }
 
 void Plan::seed_groups(const ArrowArray* array, const ArrowSchema* schema) {
+  runs_to_table();
   HostRecordView view;
   view_record(array, schema, &view);
   if (mode_ == TableMode::DENSE) switch_to_hash();  // (before the column set changes)
@@ -760,6 +821,8 @@ void Plan::seed_groups(const ArrowArray* array, const ArrowSchema* schema) {
 }
 
 void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32) {
+  runs_to_table();
+  layout.runs_to_table();
   if (n_parts < 1 || n_parts > FDB_MAX_PARTS) throw Error(FDB_ERR_INVALID, "partition count out of range");
   if (layout.device_ != device_) throw Error(FDB_ERR_INVALID, "layout plan lives on another device");
   if (layout.aggs_.size() != aggs_.size()) throw Error(FDB_ERR_INVALID, "plans have different aggregations");
@@ -837,6 +900,7 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
 }
 
 void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
+  runs_to_table();
   if (n_rows <= 0) return;
   hip_check(hipSetDevice(device_), "hipSetDevice");
   PhaseTimer pt;
@@ -876,6 +940,7 @@ void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
 // ≙ Synchronizer + final stage when either side holds a hash table: the source's occupied groups are re-keyed into
 // this plan's key ids on the device (per-column translation LUTs) and merged with atomics.
 void Plan::merge_hash(Plan& src) {
+  runs_to_table();
   if (src.mode_ == TableMode::HASH) {  // device only: re-key + pack on the source, merge here
     void* rows = nullptr;
     int64_t n = 0;
@@ -949,6 +1014,152 @@ void Plan::merge_hash(Plan& src) {
   }
   hash_insert_entries(entries, keys, cs.n, in_kw, cols);
   sync();
+}
+
+// ---- table-free OrderedAggregate: the run store (fdb_plan.h: RunSegment; fdb_kernels.h "run store") ---------------------------------
+
+// May the records of this push go through the run kernel? One aggregation that is not a composite, every group column a dictionary
+// column of ≤ 255 distinct values (a key id is one byte of a run's tuple), at most FDB_RUN_TUPLE_BYTES of them, every record
+// carrying all of the plan's group columns in the plan's order (a tuple byte IS a plan column), the specialised kernels available.
+bool Plan::runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>& Rs, const std::vector<int>& live) const {
+  static const bool off = std::getenv("FDB_NO_RUNS") != nullptr;  // (A/B and test aid: ordered plans take the hash table + sort)
+  if (off || !ordered_ || !jit_possible() || aggs_.size() != 1 || aggs_[0].role != 0) return false;
+  if (gcols_.empty() || gcols_.size() > FDB_RUN_TUPLE_BYTES) return false;
+  for (const GroupColState& g : gcols_) if (g.kind != 0 || g.values.size() > 254) return false;
+  if (runs_.size() + live.size() > FDB_MAX_RUN_SEGMENTS) return false;
+  for (int i : live) {
+    const Resolved& R = Rs[(size_t)i];
+    if (R.groups.size() != gcols_.size()) return false;
+    for (size_t g = 0; g < R.groups.size(); g++) if (R.groups[g].kind != 0 || R.groups[g].gi != (int)g) return false;
+    if ((uint64_t)bs[i]->rows >= (1ull << 31)) return false;
+  }
+  return true;
+}
+
+void Plan::runs_free() {
+  for (RunSegment& r : runs_) ctx_->dev_free(r.block);
+  runs_.clear();
+}
+
+int32_t Plan::runs_func() const {
+  const AggState& A = aggs_[0];
+  return A.func == FDB_AGG_COUNT ? (final_stage_ ? 1 : 0) : A.func == FDB_AGG_SUM ? (A.type == FDB_T_F64 ? 2 : 1) : A.func == FDB_AGG_MIN ? 3 : 4;
+}
+
+// The runs of every segment in row order: concatenated directory → prefix sums → (segment, index) of every logical run →
+// "starts a new key" flags (+ the order check) → prefix sums of those = the group of every run.
+bool Plan::runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned) {
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  auto alloc = [&](size_t bytes) { void* p = ctx_->dev_alloc(std::max<size_t>(bytes, 256)); owned->push_back(p); return p; };
+  std::memset(&v->segs, 0, sizeof(v->segs));
+  int64_t n_entries = 0;
+  v->segs.n_segs = (int32_t)runs_.size();
+  for (size_t k = 0; k < runs_.size(); k++) {
+    v->segs.tuples[k] = runs_[k].tuples; v->segs.cnt[k] = runs_[k].cnt; v->segs.acc[k] = runs_[k].acc;
+    v->segs.first_entry[k] = (uint32_t)n_entries;
+    n_entries += runs_[k].n_entries;
+  }
+  v->segs.first_entry[runs_.size()] = (uint32_t)n_entries;
+  if (n_entries >= (int64_t)1 << 31) throw Error(FDB_ERR_UNSUPPORTED, "ordered aggregate: too many rows for one run store");
+  uint32_t* d_dir = (uint32_t*)alloc((size_t)n_entries * 8);
+  for (size_t k = 0; k < runs_.size(); k++)
+    hip_check(hipMemcpyAsync(d_dir + (size_t)v->segs.first_entry[k] * 2, runs_[k].dir, (size_t)runs_[k].n_entries * 8, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(run directory)");
+  uint32_t* d_starts = (uint32_t*)alloc((size_t)n_entries * 4);
+  unsigned long long* d_scratch = (unsigned long long*)alloc(((size_t)std::max<int64_t>(n_entries, 1) / 1024 + 4) * 8 + 256);
+  unsigned long long* d_totals = (unsigned long long*)alloc(256);  // [0] runs, [1] groups, [2] order violation (low word)
+  hip_check(hipMemsetAsync(d_totals, 0, 256, stream_), "hipMemsetAsync(totals)");
+  hip_check(fdb_launch_scan_u32(d_dir + 1, 2, d_starts, n_entries, d_scratch, d_totals, stream_), "scan run counts");
+  unsigned long long h_tot[3] = {0, 0, 0};
+  hip_check(hipMemcpyAsync(h_tot, d_totals, 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(run count)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  v->n_runs = (int64_t)h_tot[0];
+  v->n_groups = 0;
+  if (v->n_runs == 0) return true;
+  if (v->n_runs >= (int64_t)1 << 32) throw Error(FDB_ERR_UNSUPPORTED, "ordered aggregate: too many runs");
+  v->phys = (unsigned long long*)alloc((size_t)v->n_runs * 8);
+  hip_check(fdb_launch_runs_map(d_dir, d_starts, n_entries, v->segs, v->phys, stream_), "runs map");
+  if (!check_order) { v->flags = nullptr; v->out_idx = nullptr; v->n_groups = v->n_runs; return true; }
+  // rank of every key id among its column's values (bytes ascending; NULL — id 0 — last: cursorHeap.Less, arrowutils/merge.go:84-112)
+  std::vector<unsigned char> rank(gcols_.size() * 256, 255);
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    const GroupColState& g = gcols_[c];
+    std::vector<uint32_t> order(g.values.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g.values[x] < g.values[y]; });
+    for (size_t r = 0; r < order.size(); r++) rank[c * 256 + order[r] + 1] = (unsigned char)r;
+  }
+  const unsigned char* d_rank = (const unsigned char*)upload(rank.data(), rank.size());
+  ctx_->flush_staging();
+  v->flags = (uint32_t*)alloc((size_t)v->n_runs * 4);
+  v->out_idx = (uint32_t*)alloc((size_t)v->n_runs * 4);
+  unsigned long long* d_scratch2 = (unsigned long long*)alloc(((size_t)v->n_runs / 1024 + 4) * 8 + 256);
+  hip_check(fdb_launch_runs_flags(v->phys, v->n_runs, v->segs, d_rank, (int)gcols_.size(), v->flags, (unsigned int*)(d_totals + 2), stream_), "runs flags");
+  hip_check(fdb_launch_scan_u32(v->flags, 1, v->out_idx, v->n_runs, d_scratch2, d_totals + 1, stream_), "scan run flags");
+  hip_check(hipMemcpyAsync(h_tot, d_totals, 24, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(group count)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  v->n_groups = (int64_t)h_tot[1];
+  return (h_tot[2] & 0xFFFFFFFFull) == 0;
+}
+
+// Every run becomes a pre-aggregated entry of the hash table (equal keys merge there): what any consumer other than Finish sees,
+// and where input that was not ordered ends up.
+void Plan::runs_to_table() {
+  if (runs_.empty()) return;
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  std::vector<void*> owned;
+  struct FreeOwned { Context* c; std::vector<void*>* v; hipStream_t s; ~FreeOwned() { (void)hipStreamSynchronize(s); for (void* p : *v) c->dev_free(p); } } free_owned{ctx_, &owned, stream_};
+  RunsView v;
+  runs_prepare(&v, /*check_order=*/false, &owned);
+  std::vector<RunSegment> segs;
+  segs.swap(runs_);  // (switch_to_hash / fetch paths below must not come back here)
+  struct FreeSegs { Context* c; std::vector<RunSegment>* v; hipStream_t s; ~FreeSegs() { (void)hipStreamSynchronize(s); for (RunSegment& r : *v) c->dev_free(r.block); } } free_segs{ctx_, &segs, stream_};
+  if (mode_ == TableMode::DENSE) { state_dirty_ = false; switch_to_hash(); }
+  hash_layout();
+  if (v.n_runs == 0) return;
+  if (h_count_dev_ != nullptr) hash_groups();
+  hash_reserve((uint64_t)v.n_runs);
+  const int kw = h_key_words_;
+  uint32_t* d_keys = (uint32_t*)ctx_->dev_alloc((size_t)v.n_runs * kw * 4 + 256);
+  owned.push_back(d_keys);
+  unsigned long long* d_entries = (unsigned long long*)ctx_->dev_alloc((size_t)v.n_runs * 16 + 256);
+  owned.push_back(d_entries);
+  // entries are {count, acc} pairs: expand with every run its own group writes them through two strided views
+  FdbRunsExpandArgs x;
+  std::memset(&x, 0, sizeof(x));
+  x.phys = v.phys; x.flags = nullptr; x.out_idx = nullptr; x.n_runs = v.n_runs;
+  x.dense_keys = d_keys; x.vals_cnt = d_entries; x.vals_acc = d_entries + 1; x.val_stride = 2;
+  x.n_cols = (int)gcols_.size(); x.key_words = kw; x.func = runs_func();
+  for (size_t c = 0; c < gcols_.size(); c++) x.col_word[c] = gcols_[c].word;
+  hip_check(fdb_launch_runs_expand(x, v.segs, stream_), "runs expand");
+  std::vector<FdbHashCol> cols(gcols_.size());
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    std::memset(&cols[c], 0, sizeof(FdbHashCol));
+    cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c; cols[c].lut_lds = FDB_NO_LDS;
+    cols[c].k1 = fdb_fp_k1((int)c); cols[c].k2 = fdb_fp_k2((int)c);
+    cols[c].src_word = gcols_[c].word;  // the expanded rows already have the table's own tuple layout
+  }
+  hash_merge_device(d_entries, d_keys, v.n_runs, kw, cols);
+  ctx_->flush_staging();
+  h_groups_bound_ += (uint64_t)v.n_runs;
+  h_bound_stale_ = true;
+  state_dirty_ = true;
+}
+
+// Finish straight from the run store. *ok = false: the keys were not in order — the runs are in the hash table now and the caller
+// takes the ordinary ordered Finish.
+int64_t Plan::finish_columns_runs(std::vector<OutColumn>* cols, DeviceBatch* resident, bool* ok) {
+  *ok = false;
+  std::vector<void*> owned;
+  struct FreeOwned { Context* c; std::vector<void*>* v; hipStream_t s; ~FreeOwned() { (void)hipStreamSynchronize(s); for (void* p : *v) c->dev_free(p); } } free_owned{ctx_, &owned, stream_};
+  hash_layout();
+  RunsView v;
+  if (!runs_prepare(&v, /*check_order=*/true, &owned)) { runs_to_table(); return 0; }
+  const int64_t n = finish_columns_hash(cols, resident, &v);
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  runs_free();
+  finished_ = true;
+  *ok = true;
+  return n;
 }
 
 }  // namespace fdb

@@ -609,6 +609,7 @@ struct HashGen {
     o << "#define FDB_DEVICE_HELPERS 1\n#include \"fdb_kernels.h\"\n" << kPreamble << kHashPreamble;
     o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") void fdb_hash_kernel(const FdbHashArgs h) {\n";
     o << "  extern __shared__ __align__(16) unsigned char smem[];\n  __shared__ unsigned int s_new;\n";
+    if (s.runs) o << "  __shared__ unsigned int s_runs[8];  // per wave: first run of its open chunk, runs used in it\n  if (threadIdx.x < 8) s_runs[threadIdx.x] = (threadIdx.x & 1u) ? " << FDB_RUN_CHUNK << "u : 0u;\n";
     o << "  const FdbScanArgs& a = h.base;\n  // descriptors are read through the constant address space: scalar loads, no vector registers\n  const __attribute__((address_space(4))) FdbHashCol* hc = (const __attribute__((address_space(4))) FdbHashCol*)h.hcols;\n  const uint32_t tid = threadIdx.x;\n  if (tid == 0) s_new = 0;\n";
     for (size_t l = 0; l < s.leaves.size(); l++) {
       o << "  const long long K_lit" << l << " = a.leaves[" << l << "].lit; const uint32_t K_len" << l << " = a.leaves[" << l << "].lut_len, K_lds" << l << " = a.leaves[" << l
@@ -668,6 +669,8 @@ struct HashGen {
       else o << "    const uint32_t " << r << "_m = 0xFu;\n";
     }
     o << "    unsigned long long h1_0 = 0, h1_1 = 0, h1_2 = 0, h1_3 = 0, h2_0 = 0, h2_1 = 0, h2_2 = 0, h2_3 = 0, vm_0 = 0, vm_1 = 0, vm_2 = 0, vm_3 = 0;\n";
+    // runs mode: the key ids of a row, one byte per group column, packed as they are computed (8 registers per row)
+    if (s.runs) for (int k = 0; k < 4; k++) o << "    u32x4 ta_" << k << " = {0u, 0u, 0u, 0u}, tb_" << k << " = {0u, 0u, 0u, 0u};\n";
     for (size_t c0 = 0; c0 < s.cols.size(); c0 += GROUP) {
       const size_t c1 = std::min(s.cols.size(), c0 + GROUP);
       o << "    {\n";
@@ -695,7 +698,9 @@ struct HashGen {
           else o << "        const uint32_t* L = hc[" << c << "].lut;\n";
           for (int k = 0; k < 4; k++) {
             o << "        { const uint32_t id = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_in_lds ? "L" : "as_global(L)") << "[" << r << comp4(k) << "] : 0u; fp_add32(h1_" << k << ", h2_"
-              << k << ", K1, K2, id); if (id != 0u) vm_" << k << " |= bit; }\n";
+              << k << ", K1, K2, id); if (id != 0u) vm_" << k << " |= bit;";
+            if (s.runs) o << " t" << (c < 16 ? "a" : "b") << "_" << k << comp4((int)((c % 16) / 4)) << " |= id << " << 8 * (c % 4) << ";";
+            o << " }\n";
           }
         } else if (C.kind == 1) {
           // int64 keys: NULL and the value 0 hash alike in the reference (dynparquet/hashed.go:254-272, zero hashes are skipped by
@@ -715,7 +720,10 @@ struct HashGen {
       // keep the next group's loads below this point: hoisting all 32 columns' loads to the top of the tile costs ≈390 VGPRs
       // and force the fingerprint updates to happen HERE: LLVM otherwise sinks all 32 columns' multiply-adds into the per-row
       // `if (selected)` blocks below and keeps 4 × 32 key ids live until then
-      o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3), \"+v\"(vm_0), \"+v\"(vm_1), \"+v\"(vm_2), \"+v\"(vm_3) :: \"memory\");\n    }\n";
+      o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3), \"+v\"(vm_0), \"+v\"(vm_1), \"+v\"(vm_2), \"+v\"(vm_3) :: \"memory\");\n";
+      // (same for the packed key ids of runs mode: pinned here, or all 4 × 32 ids stay live until the rows' tuples are stored)
+      if (s.runs) o << "      asm volatile(\"\" : \"+v\"(ta_0), \"+v\"(ta_1), \"+v\"(ta_2), \"+v\"(ta_3), \"+v\"(tb_0), \"+v\"(tb_1), \"+v\"(tb_2), \"+v\"(tb_3));\n";
+      o << "    }\n";
     }
     for (int k = 0; k < 4; k++) o << "    fp_final(h1_" << k << ", h2_" << k << ");\n";
     if (s.ablate & 1) o << "    if ((h1_0 ^ h2_0 ^ h1_1 ^ h2_1 ^ h1_2 ^ h2_2 ^ h1_3 ^ h2_3) == 0x1234567ull) h.table[0] = vm_0 ^ vm_1 ^ vm_2 ^ vm_3;\n    continue;\n";  // tuning aid
@@ -723,7 +731,7 @@ struct HashGen {
     // bring rows of one group next to each other. Rows of the lane with the same fingerprint as the row before them are folded
     // into it — count and every aggregate — and only the LAST row of such a run goes to the table: one probe + one set of atomics
     // per run instead of per row. Costs a few compares on unsorted input.
-    const bool combine = !(s.ablate & 2);
+    const bool combine = !(s.ablate & 2) || s.runs;
     if (combine) {
       for (int k = 0; k < 4; k++) o << "    unsigned long long cnt_" << k << " = 1ull;\n";
       for (size_t j = 0; j < s.aggs.size(); j++) {
@@ -810,6 +818,36 @@ struct HashGen {
       }
       o << "      }\n";
       o << "      if (has && wl < 63 && nh && na == ta && nb == tb) sel &= ~(1u << kl);\n    }\n";
+    }
+    if (s.runs) {
+      // Every row still selected is the LAST row of a run of equal keys inside this wave and holds the run's count and folded
+      // aggregate. Position of a run among the wave's runs: rows are ordered lane-major (a lane's 4 rows are consecutive).
+      const bool has_val = !s.aggs.empty() && s.aggs[0].func != FDB_AGG_COUNT;
+      const bool f64v = has_val && s.aggs[0].func == FDB_AGG_SUM && s.aggs[0].type == FDB_T_F64;
+      o << "    {\n      const unsigned long long act2 = __ballot(1);\n      const int wl2 = (int)(tid & 63u), wv = (int)(tid >> 6), first2 = __builtin_ctzll(act2);\n";
+      o << "      const unsigned long long b0 = __ballot((sel & 1u) != 0u), b1 = __ballot((sel & 2u) != 0u), b2 = __ballot((sel & 4u) != 0u), b3 = __ballot((sel & 8u) != 0u);\n";
+      o << "      const uint32_t n_w = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));\n";
+      o << "      if (n_w != 0u) {\n        const unsigned long long lt = (1ull << wl2) - 1ull;\n";
+      o << "        const uint32_t before = (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));\n";
+      o << "        uint32_t rb = s_runs[wv * 2], rp = s_runs[wv * 2 + 1];\n";
+      o << "        if (rp + n_w > " << FDB_RUN_CHUNK << "u) {\n          uint32_t nc = 0u;\n          if (wl2 == first2) nc = atomicAdd(h.runs.chunk_cursor, 1u);\n          rb = (uint32_t)__shfl((int)nc, first2, 64) * " << FDB_RUN_CHUNK
+        << "u; rp = 0u;\n        }\n";
+      o << "        const uint32_t base = rb + rp;\n        __builtin_amdgcn_wave_barrier();\n";
+      o << "        if (wl2 == first2) { s_runs[wv * 2] = rb; s_runs[wv * 2 + 1] = rp + n_w; *reinterpret_cast<uint2*>(h.runs.dir + ((size_t)tile * 4 + wv) * 2) = make_uint2(base, n_w); }\n";
+      o << "        u32x4* stage = reinterpret_cast<u32x4*>(smem + a.lds_lut_bytes + (size_t)wv * " << FDB_RUN_WAVE_LDS << ");\n";
+      for (int k = 0; k < 4; k++) {
+        o << "        if (sel & " << (1 << k) << "u) {\n          const uint32_t at = before + (uint32_t)__builtin_popcount(sel & " << ((1 << k) - 1) << "u);\n";
+        o << "          h.runs.cnt[base + at] = cnt_" << k << ";\n";
+        if (has_val) o << "          h.runs.acc[base + at] = " << (f64v ? "(unsigned long long)__double_as_longlong(v0_" + std::to_string(k) + ")" : "(unsigned long long)v0_" + std::to_string(k)) << ";\n";
+        else o << "          h.runs.acc[base + at] = 0ull;\n";
+        o << "          stage[at * 2] = ta_" << k << "; stage[at * 2 + 1] = tb_" << k << ";\n        }\n";
+      }
+      o << "        __builtin_amdgcn_wave_barrier();\n";
+      o << "        u32x4* out = reinterpret_cast<u32x4*>(h.runs.tuples) + (size_t)base * 2;\n";
+      // (only the lanes still in the tile copy: lanes past the record's end or without a selected row left it earlier)
+      o << "        const uint32_t n_act = (uint32_t)__popcll(act2), my_act = (uint32_t)__popcll(act2 & lt);\n";
+      o << "        for (uint32_t q = my_act; q < n_w * 2u; q += n_act) out[q] = stage[q];\n";
+      o << "        __builtin_amdgcn_wave_barrier();\n      }\n    }\n    continue;\n";
     }
     // Probe: the home entries of the 4 rows are requested together (one memory round trip for the common case "group exists
     // and sits in its home slot"); rows that miss there take the general find-or-insert path.
@@ -1090,7 +1128,7 @@ hipFunction_t jit_get(const JitShape& shape) {
 
 std::string JitHashShape::key() const {
   std::ostringstream k;
-  k << "a" << ablate << "c" << need_count << "|";
+  k << "a" << ablate << "c" << need_count << (runs ? "R" : "") << "|";
   for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
   k << '|';
   for (size_t l = 0; l < leaves.size(); l++) {
@@ -1114,6 +1152,7 @@ JitHashShape jit_hash_shape(const FdbHashArgs& h, const FdbHashCol* hcols) {
   for (int i = 0; i < a.n_expr; i++) s.exprs.push_back({a.expr[i].kind, a.expr[i].op, a.expr[i].left, a.expr[i].right, a.expr[i].slot, a.expr[i].type});
   s.n_expr_cols = a.n_l8;
   s.need_count = a.need_count != 0;
+  s.runs = h.runs.tuples != nullptr;
   for (int l = 0; l < a.n_leaves; l++) {
     const FdbLeaf& L = a.leaves[l];
     const bool wide = L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64;

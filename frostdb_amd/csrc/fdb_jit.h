@@ -54,6 +54,10 @@ struct JitHashShape {
   int n_expr_cols = 0;
   bool need_count = true;  // some aggregation is COUNT: otherwise the per-entry row count is never read (occupancy = fingerprint ≠ 0) and its atomic is skipped
   int ablate = 0;  // tuning aid (tools/cfg5_ablate.py): 1 = stream + fingerprint only, 2 = no count / aggregate atomics
+  // Table-free OrderedAggregate (FdbHashArgs.runs): no probe, no insert — every wave emits the runs of equal keys among its 256 rows
+  // (packed key ids, row count, folded aggregate) and notes them in the launch's directory. Dictionary columns with ≤ 255 values,
+  // at most FDB_RUN_TUPLE_BYTES of them, exactly one aggregation.
+  bool runs = false;
   std::string key() const;
 };
 // `hcols` = host copy of args.hcols.

@@ -184,8 +184,26 @@ static inline unsigned long long fdb_fp_k2(int gi) {
 
 // Table entry = entry_words × 8 bytes: [fingerprint lo (0 = empty) | fingerprint hi | selected-row count | acc 0 … ]
 // padded to a multiple of 32 bytes so that probe, count and accumulators of a group share one 64-byte sector.
+// Run store of the table-free OrderedAggregate (Plan::push_runs, fdb_hash_kernel in runs mode): a scan whose rows arrive ordered
+// by the group columns needs no table — a group is one RUN of consecutive rows (ordered_aggregate.go:163-409: group ranges, the
+// last group carried into the next record). Every wave emits the runs of its 256 rows — packed key ids (one byte per group
+// column, plan order; the mode is only chosen while every column has ≤ 255 distinct values), row count and the folded aggregate
+// of each — into chunks of FDB_RUN_CHUNK runs handed out by one global atomic per chunk, and notes (first run, number of runs) in
+// the directory entry of its (tile, wave). Runs cut by a wave / record boundary and keys that come back later are merged at Finish.
+#define FDB_RUN_CHUNK 4096
+#define FDB_RUN_TUPLE_BYTES 32
+#define FDB_RUN_WAVE_LDS (256 * FDB_RUN_TUPLE_BYTES)  // staging per wave: its ≤ 256 runs leave as one contiguous copy
+struct FdbRunsOut {
+  unsigned char* tuples;         // [capacity][FDB_RUN_TUPLE_BYTES]; nullptr: not a runs launch
+  unsigned long long* cnt;       // [capacity] rows of the run
+  unsigned long long* acc;       // [capacity] its aggregate (the accumulator's own representation)
+  unsigned int* dir;             // [4 × tiles of the launch][2]
+  unsigned int* chunk_cursor;    // next free chunk
+};
+
 struct FdbHashArgs {
   FdbScanArgs base;         // n_rows, filter program, aggregates (values / validity / func / type); dense fields unused
+  FdbRunsOut runs;          // runs mode only
   const FdbHashCol* hcols;  // device array [n_hcols]
   unsigned long long* table;
   uint32_t* keys;           // [capacity][key_words]: the key tuple of each occupied slot (written once, by the inserter)
@@ -307,6 +325,42 @@ struct FdbHashMergeArgs {
   int32_t funcs[FDB_MAX_AGGS];
 };
 hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t stream);
+
+// ---- Finish of a run store (fdb_kernels.hip: runs_*_kernel) ---------------------------------------------------------------------
+// A plan's runs live in SEGMENTS (one per launch), each with its own directory. Logical order = segments in launch order, within
+// a segment directory entries in order, within an entry the runs in order — i.e. row order of the scan.
+#define FDB_MAX_RUN_SEGMENTS 64
+struct FdbRunSegs {
+  const unsigned char* tuples[FDB_MAX_RUN_SEGMENTS];
+  const unsigned long long* cnt[FDB_MAX_RUN_SEGMENTS];
+  const unsigned long long* acc[FDB_MAX_RUN_SEGMENTS];
+  uint32_t first_entry[FDB_MAX_RUN_SEGMENTS + 1];  // directory entries of segment s = [first_entry[s], first_entry[s + 1]) of the concatenated directory
+  int32_t n_segs;
+};
+// Exclusive prefix sums of in[i * stride] (i < n) into out[i]; *total = the sum. `scratch`: ≥ (n / 1024 + 2) × 8 bytes.
+hipError_t fdb_launch_scan_u32(const uint32_t* in, int stride, uint32_t* out, int64_t n, unsigned long long* scratch, unsigned long long* total, hipStream_t stream);
+// phys[logical run] = (segment << 32) | index inside the segment, from the concatenated directory `dir` ([n_entries][2]) and the
+// exclusive prefix sums `starts` of its counts.
+hipError_t fdb_launch_runs_map(const uint32_t* dir, const uint32_t* starts, int64_t n_entries, const FdbRunSegs& segs, unsigned long long* phys, hipStream_t stream);
+// flags[i] = 1 if run i starts a new key (its tuple differs from run i − 1's), else 0. *violation is set when a new key does not
+// sort AFTER its predecessor — columns compared in plan order through `rank` ([n_cols][256]: rank of a key id among the column's
+// values, NULL = 255 = last): then the input was not ordered and the caller falls back to the hash table.
+hipError_t fdb_launch_runs_flags(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const unsigned char* rank, int n_cols, uint32_t* flags,
+                                 unsigned int* violation, hipStream_t stream);
+// Groups out: for every run i, group g = out_idx[i] (exclusive prefix sums of flags) if flags[i] else out_idx[i] − 1 (flags == nullptr:
+// every run is its own group, g = i). A group's first run writes its key tuple as one row of `dense_keys` ([n_groups][key_words]
+// u32: valid mask in words 0-1, column c's id in word col_word[c]); counts and aggregates are folded into vals_cnt / vals_acc
+// (func: 1 add u64, 2 add f64, 3 min i64, 4 max i64, 0 none) — plain stores for groups made of ONE run, atomics otherwise, so both
+// arrays must hold the identity beforehand when flags != nullptr.
+struct FdbRunsExpandArgs {
+  const unsigned long long* phys; const uint32_t* flags; const uint32_t* out_idx; int64_t n_runs;
+  uint32_t* dense_keys; unsigned long long* vals_cnt; unsigned long long* vals_acc;
+  int32_t n_cols, key_words, func;
+  int32_t val_stride;  // vals_cnt[g × val_stride], vals_acc[g × val_stride]; 0 = 1
+  int32_t col_word[FDB_RUN_TUPLE_BYTES];
+};
+hipError_t fdb_launch_runs_expand(const FdbRunsExpandArgs& args, const FdbRunSegs& segs, hipStream_t stream);
+hipError_t fdb_launch_fill_u64(unsigned long long* p, int64_t n, unsigned long long v, hipStream_t stream);
 
 // Export of a hash table for a merge elsewhere (another plan on this device, or — hash-partitioned — other ranks over RCCL):
 // every occupied entry is re-keyed into the DESTINATION layout (per-column id translation, destination word positions and

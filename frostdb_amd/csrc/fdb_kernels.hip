@@ -2338,3 +2338,208 @@ hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int d
   return hipGetLastError();
 }
 
+
+// ---- Finish of a run store (table-free OrderedAggregate; fdb_kernels.h "run store") ------------------------------------------------
+// Exclusive prefix sums of a (strided) u32 array in three launches: sums of 1 024-element blocks, a one-workgroup scan of those,
+// the blocks again with their base. (A one-workgroup scan of everything is the trap DESIGN §9 names.)
+__global__ __launch_bounds__(256) void scan_u32_sums_kernel(const uint32_t* __restrict__ in, int stride, int64_t n, unsigned long long* __restrict__ sums) {
+  __shared__ unsigned long long s_w[4];
+  const int64_t b = blockIdx.x;
+  unsigned long long v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int64_t i = b * 1024 + (int64_t)k * 256 + threadIdx.x; if (i < n) v += in[i * stride]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[b] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(1024) void scan_u64_single_kernel(unsigned long long* __restrict__ sums, int64_t n_blocks, unsigned long long* __restrict__ total) {
+  __shared__ unsigned long long s_w[16];
+  __shared__ unsigned long long s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+    const int64_t i = b0 + threadIdx.x;
+    const unsigned long long x = i < n_blocks ? sums[i] : 0ull;
+    unsigned long long incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += y; }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long wbase = s_carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += s_w[w];
+    if (i < n_blocks) sums[i] = wbase + incl - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = wbase + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(256) void scan_u32_apply_kernel(const uint32_t* __restrict__ in, int stride, int64_t n, const unsigned long long* __restrict__ sums, uint32_t* __restrict__ out) {
+  __shared__ uint32_t s_w[4];
+  const int64_t b = blockIdx.x;
+  uint32_t x[4], mine = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int64_t i = b * 1024 + (int64_t)threadIdx.x * 4 + k; x[k] = i < n ? in[i * stride] : 0u; mine += x[k]; }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o, 64); if ((int)(threadIdx.x & 63) >= o) incl += y; }
+  if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t ex = (uint32_t)sums[b] + incl - mine;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) ex += s_w[w];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int64_t i = b * 1024 + (int64_t)threadIdx.x * 4 + k; if (i < n) out[i] = ex; ex += x[k]; }
+}
+hipError_t fdb_launch_scan_u32(const uint32_t* in, int stride, uint32_t* out, int64_t n, unsigned long long* scratch, unsigned long long* total, hipStream_t stream) {
+  if (n <= 0) return hipMemsetAsync(total, 0, 8, stream);
+  const int64_t n_blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(scan_u32_sums_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, in, stride, n, scratch);
+  hipLaunchKernelGGL(scan_u64_single_kernel, dim3(1), dim3(1024), 0, stream, scratch, n_blocks, total);
+  hipLaunchKernelGGL(scan_u32_apply_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, in, stride, n, (const unsigned long long*)scratch, out);
+  return hipGetLastError();
+}
+
+// logical run → (segment, index): a workgroup takes 256 directory entries, lays their runs end to end and lets every thread find
+// its run's entry by bisection in LDS (the writes are coalesced; an entry holds ≤ 256 runs)
+__global__ __launch_bounds__(256) void runs_map_kernel(const uint32_t* __restrict__ dir, const uint32_t* __restrict__ starts, int64_t n_entries, const FdbRunSegs segs,
+                                                       unsigned long long* __restrict__ phys) {
+  __shared__ uint32_t s_start[257], s_base[256];
+  const int64_t e0 = (int64_t)blockIdx.x * 256;
+  const int64_t e = e0 + threadIdx.x;
+  const uint32_t n_here = e < n_entries ? dir[e * 2 + 1] : 0u;
+  s_start[threadIdx.x] = e < n_entries ? starts[e] : 0u;
+  s_base[threadIdx.x] = e < n_entries ? dir[e * 2] : 0u;
+  const int64_t last = (e0 + 255 < n_entries ? e0 + 255 : n_entries - 1);
+  if (e == last) s_start[256] = s_start[threadIdx.x] + n_here;  // (end of the block's range; entries past `last` hold 0 runs)
+  __syncthreads();
+  const uint32_t lo = s_start[0], hi = s_start[256];
+  const int n_valid = (int)(last - e0 + 1);
+  for (uint32_t r = lo + threadIdx.x; r < hi; r += 256) {
+    int a = 0, b = n_valid - 1;  // the last entry whose start ≤ r (entries with 0 runs share a start: the LAST of them that has runs wins by the search below)
+    while (a < b) { const int m = (a + b + 1) >> 1; if (s_start[m] <= r) a = m; else b = m - 1; }
+    const int64_t entry = e0 + a;
+    int seg = 0;
+    while (seg + 1 < segs.n_segs && (int64_t)segs.first_entry[seg + 1] <= entry) seg++;
+    phys[r] = ((unsigned long long)seg << 32) | (unsigned long long)(s_base[a] + (r - s_start[a]));
+  }
+}
+hipError_t fdb_launch_runs_map(const uint32_t* dir, const uint32_t* starts, int64_t n_entries, const FdbRunSegs& segs, unsigned long long* phys, hipStream_t stream) {
+  if (n_entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(runs_map_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, stream, dir, starts, n_entries, segs, phys);
+  return hipGetLastError();
+}
+
+typedef uint32_t run_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void runs_flags_kernel(const unsigned long long* __restrict__ phys, int64_t n_runs, const FdbRunSegs segs, const unsigned char* __restrict__ rank,
+                                                         int n_cols, uint32_t* __restrict__ flags, unsigned int* __restrict__ violation) {
+  __shared__ unsigned char s_rank[FDB_RUN_TUPLE_BYTES * 256];
+  for (int i = threadIdx.x; i < n_cols * 256; i += 256) s_rank[i] = rank[i];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_runs) return;
+  const unsigned long long p = phys[i];
+  const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[p >> 32] + (p & 0xFFFFFFFFull) * FDB_RUN_TUPLE_BYTES);
+  const run_u32x4 a0 = t[0], a1 = t[1];
+  if (i == 0) { flags[0] = 1u; return; }
+  const unsigned long long q = phys[i - 1];
+  const run_u32x4* u = reinterpret_cast<const run_u32x4*>(segs.tuples[q >> 32] + (q & 0xFFFFFFFFull) * FDB_RUN_TUPLE_BYTES);
+  const run_u32x4 b0 = u[0], b1 = u[1];
+  const bool same = a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w && a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
+  flags[i] = same ? 0u : 1u;
+  if (same) return;
+  // a new key must sort after its predecessor: first column whose ranks differ decides (ascending, NULLs last)
+  const uint32_t cur[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, prev[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  for (int c = 0; c < n_cols; c++) {
+    const uint32_t ic = (cur[c >> 2] >> (8 * (c & 3))) & 0xFFu, ip = (prev[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+    if (ic == ip) continue;
+    if (s_rank[c * 256 + ic] < s_rank[c * 256 + ip]) atomicOr(violation, 1u);
+    return;
+  }
+}
+hipError_t fdb_launch_runs_flags(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const unsigned char* rank, int n_cols, uint32_t* flags,
+                                 unsigned int* violation, hipStream_t stream) {
+  if (n_runs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(runs_flags_kernel, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, stream, phys, n_runs, segs, rank, n_cols, flags, violation);
+  return hipGetLastError();
+}
+
+// One wave per 64 consecutive logical runs. The key rows of the groups that START among them are consecutive in the output
+// (out_idx is monotone), so they are assembled in the wave's LDS tile and leave as one contiguous copy.
+__global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArgs a, const FdbRunSegs segs) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kw = a.key_words;
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * 64 * kw;
+  const int64_t i = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
+  const bool live = i < a.n_runs;
+  uint32_t fl = 0, g = 0;
+  unsigned long long cnt = 0, acc = 0;
+  run_u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+  bool single = true;
+  if (live) {
+    const unsigned long long p = a.phys[i];
+    const int seg = (int)(p >> 32);
+    const uint64_t at = p & 0xFFFFFFFFull;
+    const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[seg] + at * FDB_RUN_TUPLE_BYTES);
+    t0 = t[0]; t1 = t[1];
+    cnt = segs.cnt[seg][at]; acc = segs.acc[seg][at];
+    if (a.flags != nullptr) {
+      fl = a.flags[i];
+      g = a.out_idx[i] - (fl ? 0u : 1u);
+      single = fl != 0u && (i + 1 >= a.n_runs || a.flags[i + 1] != 0u);
+    } else { fl = 1u; g = (uint32_t)i; }
+  }
+  const unsigned long long starts = __ballot(live && fl != 0u);
+  if (live) {
+    const size_t vg = (size_t)g * (size_t)(a.val_stride > 0 ? a.val_stride : 1);
+    if (single) { a.vals_cnt[vg] = cnt; a.vals_acc[vg] = acc; }
+    else {
+      atomicAdd(a.vals_cnt + vg, cnt);
+      if (a.func == 1) atomicAdd(a.vals_acc + vg, acc);
+      else if (a.func == 2) atomicAdd(reinterpret_cast<double*>(a.vals_acc) + vg, __longlong_as_double((long long)acc));
+      else if (a.func == 3) atomicMin(reinterpret_cast<long long*>(a.vals_acc) + vg, (long long)acc);
+      else if (a.func == 4) atomicMax(reinterpret_cast<long long*>(a.vals_acc) + vg, (long long)acc);
+    }
+  }
+  if (starts == 0ull) return;
+  const uint32_t first_g = __shfl(g, __builtin_ctzll(starts), 64);  // (g of the first starting lane = the wave's first output row)
+  const uint32_t n_new = (uint32_t)__popcll(starts);
+  if (live && fl != 0u) {
+    const uint32_t r = g - first_g;
+    uint32_t* row = tile + (size_t)r * kw;
+    for (int w = 0; w < kw; w++) row[w] = 0u;
+    const uint32_t ids[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    unsigned long long vm = 0;
+    for (int c = 0; c < a.n_cols; c++) {
+      const uint32_t id = (ids[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+      row[a.col_word[c]] = id;
+      if (id != 0u) vm |= 1ull << c;
+    }
+    row[0] = (uint32_t)vm; row[1] = (uint32_t)(vm >> 32);
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint32_t* dst = a.dense_keys + (size_t)first_g * kw;
+  for (uint32_t t = lane; t < n_new * (uint32_t)kw; t += 64) dst[t] = tile[t];
+}
+hipError_t fdb_launch_runs_expand(const FdbRunsExpandArgs& args, const FdbRunSegs& segs, hipStream_t stream) {
+  if (args.n_runs <= 0) return hipSuccess;
+  const size_t lds = (size_t)4 * 64 * (size_t)args.key_words * 4;
+  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&runs_expand_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(runs_expand_kernel, dim3((unsigned)((args.n_runs + 255) / 256)), dim3(256), lds, stream, args, segs);
+  return hipGetLastError();
+}
+
+__global__ void fill_u64_kernel(unsigned long long* p, int64_t n, unsigned long long v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+hipError_t fdb_launch_fill_u64(unsigned long long* p, int64_t n, unsigned long long v, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, p, n, v);
+  return hipGetLastError();
+}

@@ -430,6 +430,7 @@ Plan::~Plan() {
   ctx_->dev_free(h_table_);
   ctx_->dev_free(h_keys_);
   ctx_->dev_free(h_count_dev_);
+  for (RunSegment& r : runs_) ctx_->dev_free(r.block);
   for (void* p : scratch_) ctx_->dev_free(p);
   pending_.clear();   // (queued / in-flight records hand their arenas back to this context: before it is released)
   inflight_.clear();
@@ -1256,6 +1257,15 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     }
     if (want_hash) switch_to_hash();
   }
+  // OrderedAggregate without a table: nothing accumulated yet (or already collecting runs) and the records fit the run kernel
+  if (ordered_ && ((mode_ == TableMode::DENSE && !state_dirty_ && h_table_ == nullptr) || !runs_.empty())) {
+    if (runs_wanted(bs, Rs, live)) {
+      push_hash(bs, Rs, live, /*runs=*/true);
+      pt.mark("run scan");
+      return;
+    }
+    runs_to_table();  // (no-op without runs) — from here on the ordinary paths
+  }
   if (mode_ == TableMode::HASH) {
     push_hash(bs, Rs, live);
     pt.mark("hash scan");
@@ -1573,6 +1583,7 @@ void Plan::fetch_state(std::vector<unsigned long long>* cnt, std::vector<std::ve
 // Occupied groups of the table, in a mode-independent host form (dense: enumerate slots with count > 0 and decode
 // the mixed-radix digits; hash: compact on the device, copy, decode key tuples).
 void Plan::fetch_compact(CompactState* cs) {
+  runs_to_table();
   cs->n = 0;
   cs->cnt.clear();
   cs->acc.assign(aggs_.size(), {});
@@ -1747,6 +1758,12 @@ int64_t Plan::finish_columns(std::vector<OutColumn>* cols) {
   PhaseTimer pt;
   cols->clear();
   int64_t n = 0;
+  if (!runs_.empty()) {
+    bool ok = false;
+    n = finish_columns_runs(cols, nullptr, &ok);
+    if (ok) { finished_ = true; return n; }
+    cols->clear();  // the keys were not in order: the runs are in the hash table now, the ordinary ordered Finish below sorts them
+  }
   if (mode_ == TableMode::HASH && h_table_ != nullptr && !ordered_) {
     // big result sets: columns are materialised on the device, the host only copies finished Arrow buffers
     n = finish_columns_hash(cols);
@@ -1778,6 +1795,12 @@ std::unique_ptr<DeviceBatch> Plan::finish_batch(int64_t* n_rows) {
   settle();
   bool composite = false;
   for (const AggState& A : aggs_) if (A.role != 0) composite = true;  // UNIQUE / AND are finished on the host (validity from two accumulators)
+  if (!runs_.empty()) {
+    std::unique_ptr<DeviceBatch> b(new DeviceBatch());
+    bool ok = false;
+    const int64_t n = finish_columns_runs(nullptr, b.get(), &ok);
+    if (ok) { if (n_rows) *n_rows = n; return b; }
+  }
   if (mode_ == TableMode::HASH && h_table_ != nullptr && !ordered_ && !composite) {
     std::unique_ptr<DeviceBatch> b(new DeviceBatch());
     const int64_t n = finish_columns_hash(nullptr, b.get());
@@ -1845,6 +1868,7 @@ void Plan::partial_state(int32_t agg, void* dst, int64_t capacity_bytes) {
 
 // ---- raw table access for the aligned-layout all-reduce (frostdb_amd/distributed.py) ---------------------------------
 uint64_t Plan::state_signature(int64_t* n_slots_out) {
+  runs_to_table();
   uint64_t h = 1469598103934665603ull;
   auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
   auto mix64 = [&](uint64_t v) { mix(&v, 8); };
@@ -1861,6 +1885,7 @@ uint64_t Plan::state_signature(int64_t* n_slots_out) {
 }
 
 void Plan::state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) {
+  runs_to_table();
   const bool ok = mode_ == TableMode::DENSE && d_state_ != nullptr;
   if (ok) { materialize_state(); mirror_valid_ = false; }  // (the caller may write through these pointers)
   *base = ok ? (void*)d_state_ : nullptr;
@@ -1869,6 +1894,7 @@ void Plan::state_pointers(void** base, int64_t* array_stride, int64_t* n_slots) 
 }
 
 void Plan::state_read(int32_t array, void* dst, int64_t capacity_bytes) {
+  runs_to_table();
   if (mode_ != TableMode::DENSE) throw Error(FDB_ERR_STATE, "raw table access needs the dense table");
   if (array < 0 || array > (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "table array index out of range");
   if (d_state_ == nullptr) throw Error(FDB_ERR_STATE, "the plan has no table yet");
@@ -1881,6 +1907,7 @@ void Plan::state_read(int32_t array, void* dst, int64_t capacity_bytes) {
 }
 
 void Plan::state_write(int32_t array, const void* src, int64_t bytes) {
+  runs_to_table();
   if (mode_ != TableMode::DENSE) throw Error(FDB_ERR_STATE, "raw table access needs the dense table");
   if (array < 0 || array > (int32_t)aggs_.size()) throw Error(FDB_ERR_INVALID, "table array index out of range");
   if (d_state_ == nullptr) throw Error(FDB_ERR_STATE, "the plan has no table yet");
@@ -1894,6 +1921,8 @@ void Plan::state_write(int32_t array, const void* src, int64_t bytes) {
 
 // ---- merge (≙ Synchronizer + final-stage HashAggregate, same device) -------------------------------------------
 void Plan::merge_from(Plan& src) {
+  runs_to_table();
+  src.runs_to_table();
   if (&src == this) throw Error(FDB_ERR_INVALID, "cannot merge a plan into itself");
   if (src.device_ != device_) throw Error(FDB_ERR_INVALID, "merge across devices goes through frostdb_amd.distributed (RCCL)");
   if (src.aggs_.size() != aggs_.size()) throw Error(FDB_ERR_INVALID, "plans have different aggregations");

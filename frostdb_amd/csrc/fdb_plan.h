@@ -294,9 +294,33 @@ class Plan {
   void switch_to_hash();
   void hash_layout();                                   // (re)assign key-tuple words; widen the key store if columns were added
   void hash_reserve(uint64_t extra_groups, uint64_t expected_groups = 0);  // capacity ≥ 2 × (max(groups, expected) + extra): grow + rehash on the device
-  void push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live);
+  void push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, const std::vector<int>& live, bool runs = false);
+  // Table-free OrderedAggregate (ordered_aggregate.go:163-551; fdb_kernels.h "run store"): while an ordered plan's records keep
+  // the shape the run kernel needs, their runs of equal keys are collected instead of probing a table. Finish merges what wave /
+  // record boundaries cut and, if the keys came in order, emits them as they are; anything else that wants the plan's state
+  // (a merge, an export, the raw accessors, input that was NOT ordered) first inserts the runs into the hash table.
+  struct RunSegment {
+    void* block = nullptr;  // one device allocation: [tuples | cnt | acc | directory | chunk cursor]
+    unsigned char* tuples = nullptr; unsigned long long* cnt = nullptr; unsigned long long* acc = nullptr; uint32_t* dir = nullptr; uint32_t* cursor = nullptr;
+    int64_t n_entries = 0, capacity = 0;
+  };
+  struct RunsView {  // the runs in logical (row) order, prepared for Finish
+    FdbRunSegs segs;
+    unsigned long long* phys = nullptr; uint32_t* flags = nullptr; uint32_t* out_idx = nullptr;
+    int64_t n_runs = 0, n_groups = 0;
+  };
+  std::vector<RunSegment> runs_;
+  bool runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>& Rs, const std::vector<int>& live) const;
+  void runs_free();
+  void runs_to_table();
+  // false: the keys did not arrive in order (the caller falls back to runs_to_table + the ordinary ordered Finish). Device blocks it
+  // allocates are appended to `owned` (freed by the caller through ctx_->dev_free).
+  bool runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned);
+  int32_t runs_func() const;  // how two runs' aggregates fold (FdbRunsExpandArgs.func)
+  void hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols);
+  int64_t finish_columns_runs(std::vector<OutColumn>* cols, DeviceBatch* resident, bool* ok);
   void fetch_compact_hash(CompactState* cs);
-  int64_t finish_columns_hash(std::vector<OutColumn>* cols, DeviceBatch* resident = nullptr);  // device-side column materialisation (big result sets)
+  int64_t finish_columns_hash(std::vector<OutColumn>* cols, DeviceBatch* resident = nullptr, const RunsView* runs = nullptr);  // device-side column materialisation (big result sets)
   void merge_hash(Plan& src);
   uint64_t hash_groups();                               // occupied slots (reads the device counter; waits for the stream)
   void hash_insert_entries(const std::vector<unsigned long long>& entries, const std::vector<uint32_t>& keys, int64_t n, int in_kw,

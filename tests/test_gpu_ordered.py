@@ -132,3 +132,159 @@ def test_large_sorted_input_is_the_hash_aggregate_in_key_order(pp):
     key = lambda r: (r[0], r[1] is None, r[1] or b"")  # noqa: E731
     assert orows == sorted(hrows, key=key)
     assert len(orows) > 20_000
+
+
+# ---- the table-free path (round 4): runs of equal keys collected by the scan, merged and checked for order at Finish ------------------
+
+def _sorted_label_records(rng, n_total, n_records, card=(5, 7, 3), null_frac=0.03, sort=True):
+    """Rows over three dictionary label columns, ordered by (l0, l1, l2) — values ascending bytewise, NULLs last, the order an
+    OrderedAggregate's input has — cut into records at arbitrary rows (groups straddle record boundaries)."""
+    cols = []
+    for c, k in enumerate(card):
+        v = rng.integers(0, k + 1, n_total)  # k = NULL
+        cols.append(np.where(rng.random(n_total) < null_frac, k, v))
+    if sort:
+        order = np.lexsort(tuple(reversed(cols)))
+        cols = [c[order] for c in cols]
+    val = rng.integers(-50, 1000, n_total).astype(np.int64)
+    fval = rng.uniform(0, 100, n_total)
+    cuts = [0] + sorted(rng.integers(1, n_total, n_records - 1).tolist()) + [n_total]
+    recs = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        arrays, names = [], []
+        for c, k in enumerate(card):
+            # dictionary in DESCENDING value order, so that key ids / dictionary indices do not happen to be ranks
+            d = pa.array([b"v%02d" % (k - 1 - i) for i in range(k)], type=pa.binary())
+            x = cols[c][a:b]
+            idx = pa.array(np.where(x == k, 0, k - 1 - x).astype(np.uint32), mask=x == k)
+            arrays.append(pa.DictionaryArray.from_arrays(idx, d)); names.append("labels.l%d" % c)
+        arrays += [pa.array(val[a:b]), pa.array(fval[a:b])]
+        names += ["v", "f"]
+        recs.append(pa.RecordBatch.from_arrays(arrays, names=names))
+    return recs
+
+
+def _run_plan(pp, recs, agg, groups, ordered, resident=False, filt=None, finish_resident=False):
+    plan = pp.HashAggregatePlan(filt, [agg], groups, ordered=ordered, final_stage=False)
+    keep = []
+    try:
+        if resident:
+            keep = [pp.ResidentBatch(r) for r in recs]
+            plan.CallbackResident(keep)
+        else:
+            for r in recs:
+                plan.Callback(r)
+        kernel = plan.last_kernel()
+        if finish_resident:
+            rb = plan.FinishResident()
+            out = rb.to_arrow()
+            rb.close()
+        else:
+            out = plan.Finish()
+        return out, kernel
+    finally:
+        plan.Close()
+        for k in keep:
+            k.close()
+
+
+def _rows(out):
+    cols = [(c.dictionary_decode() if pa.types.is_dictionary(c.type) else c).to_pylist() for c in out.columns]
+    return [tuple(c[i] for c in cols) for i in range(out.num_rows)]
+
+
+def _key_order(r, nkeys=3):
+    return tuple((x is None, x or b"") for x in r[:nkeys])
+
+
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("agg_name", ["sum_i", "sum_f", "min", "max", "count"])
+def test_table_free_ordered_aggregate_of_sorted_records(pp, agg_name, resident):
+    """Sorted label columns, 6 records cut at arbitrary rows: the scan collects runs (no hash kernel ran: last_kernel says so),
+    Finish merges the runs that wave and record boundaries cut and emits the groups in key order — equal to the hash aggregate's
+    groups sorted by key (values bit-exact for integers; float sums to 1e-9, the fold order differs)."""
+    rng = np.random.default_rng(11)
+    recs = _sorted_label_records(rng, 300_000, 6)
+    agg = {"sum_i": Sum(Col("v")), "sum_f": Sum(Col("f")), "min": Min(Col("v")), "max": Max(Col("f")), "count": Count(Col("v"))}[agg_name]
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    o, kernel = _run_plan(pp, recs, agg, groups, ordered=True, resident=resident)
+    assert kernel == "fdb_hash_kernel(runs)", kernel
+    h, hk = _run_plan(pp, recs, agg, groups, ordered=False, resident=resident)
+    assert "runs" not in hk
+    orows, hrows = _rows(o), sorted(_rows(h), key=_key_order)
+    assert len(orows) == len(hrows) > 100
+    assert [r[:3] for r in orows] == [r[:3] for r in hrows]  # same groups, in key order (NULLs last in every column)
+    for a, b in zip(orows, hrows):
+        assert a[3] == b[3] or (isinstance(a[3], float) and abs(a[3] - b[3]) <= 1e-9 * max(1.0, abs(b[3]))), (a, b)
+    assert o.schema.names[:3] == ["labels.l0", "labels.l1", "labels.l2"]
+    assert o.schema.names[3] == ("v" if agg_name not in ("sum_f", "max") else "f")  # partial-stage naming (ordered_aggregate.go:551-557)
+
+
+def test_table_free_ordered_aggregate_with_a_filter_and_a_resident_finish(pp):
+    rng = np.random.default_rng(12)
+    recs = _sorted_label_records(rng, 200_000, 3)
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    filt = Col("v") > 300
+    o, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True, resident=True, filt=filt, finish_resident=True)
+    assert kernel == "fdb_hash_kernel(runs)"
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False, resident=True, filt=filt)
+    assert _rows(o) == sorted(_rows(h), key=_key_order)
+
+
+def test_input_that_breaks_the_order_falls_back_to_the_table(pp):
+    """One record out of order (and one that is not sorted at all): Finish notices that a new key does not sort after its
+    predecessor, puts every run into the hash table and takes the ordinary ordered Finish — same groups, same order."""
+    rng = np.random.default_rng(13)
+    recs = _sorted_label_records(rng, 120_000, 4)
+    recs = [recs[2], recs[0], recs[3], recs[1]] + _sorted_label_records(rng, 30_000, 1, sort=False)
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    o, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True)
+    assert kernel == "fdb_hash_kernel(runs)"
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False)
+    assert _rows(o) == sorted(_rows(h), key=_key_order)
+
+
+def test_runs_become_table_entries_for_every_other_consumer(pp):
+    """Merge of two ordered plans, the group count, the partial keys: anything but Finish first inserts the collected runs into the
+    hash table (Plan::runs_to_table) — results equal the hash aggregate's."""
+    rng = np.random.default_rng(14)
+    recs = _sorted_label_records(rng, 150_000, 4)
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    p1 = pp.HashAggregatePlan(None, [Sum(Col("v"))], groups, ordered=True)
+    p2 = pp.HashAggregatePlan(None, [Sum(Col("v"))], groups, ordered=True)
+    try:
+        for r in recs[:2]:
+            p1.Callback(r)
+        for r in recs[2:]:
+            p2.Callback(r)
+        assert p1.last_kernel() == "fdb_hash_kernel(runs)" and p2.last_kernel() == "fdb_hash_kernel(runs)"
+        n2 = p2.num_groups()
+        p1.Merge(p2)
+        out = p1.Finish()
+    finally:
+        p1.Close(); p2.Close()
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False)
+    assert _rows(out) == sorted(_rows(h), key=_key_order)
+    h2, _ = _run_plan(pp, recs[2:], Sum(Col("v")), groups, ordered=False)
+    assert n2 == h2.num_rows
+
+
+def test_table_free_path_is_left_when_a_record_does_not_fit_it(pp):
+    """A dictionary that outgrows one byte of key ids, and a record that lacks one of the plan's group columns: the runs collected so
+    far go into the table and the scan continues there."""
+    rng = np.random.default_rng(15)
+    recs = _sorted_label_records(rng, 60_000, 2)
+    n = 5_000
+    wide = pa.RecordBatch.from_arrays(
+        [pa.DictionaryArray.from_arrays(pa.array(np.sort(rng.integers(0, 400, n)).astype(np.uint32)), pa.array([b"w%03d" % i for i in range(400)], type=pa.binary())),
+         pa.DictionaryArray.from_arrays(pa.array(np.zeros(n, dtype=np.uint32)), pa.array([b"v00"], type=pa.binary())),
+         pa.DictionaryArray.from_arrays(pa.array(np.zeros(n, dtype=np.uint32)), pa.array([b"v00"], type=pa.binary())),
+         pa.array(rng.integers(0, 9, n).astype(np.int64)), pa.array(rng.uniform(0, 1, n))], names=["labels.l0", "labels.l1", "labels.l2", "v", "f"])
+    missing = recs[1].drop_columns(["labels.l1"])
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    for extra in (wide, missing):
+        seq = [recs[0], extra, recs[1]]
+        o, kernel = _run_plan(pp, seq, Sum(Col("v")), groups, ordered=True)
+        assert kernel != "fdb_hash_kernel(runs)"
+        h, _ = _run_plan(pp, seq, Sum(Col("v")), groups, ordered=False)
+        assert _rows(o) == sorted(_rows(h), key=_key_order)
