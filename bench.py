@@ -252,13 +252,18 @@ def self_launch(args):
 class Workload:
     """One configuration made resident on this rank's GPU + the numpy expectation of its query."""
 
-    def __init__(self, args, config, rows, rank, device, keep_host=0, gen_threads=None):
+    def __init__(self, args, config, rows, rank, device, keep_host=0, gen_threads=None, cfg5_sorted=False):
         from frostdb_amd import physicalplan as pp
         from frostdb_amd import synth
         from frostdb_amd.logicalplan import to_desc
         self.args, self.config, self.rows, self.rank, self.device = args, config, rows, rank, device
         self.filt, self.aggs, self.groups, self.qdesc = query(config)
-        self.desc = to_desc(self.filt, self.aggs, self.groups)  # planned once; every step instantiates a fresh operator chain
+        # cfg 5 over a table SORTED by its label columns: the reference plans an OrderedAggregate for it (physicalplan.go:433-449,
+        # :525-560) — one aggregation, input ordered by the group columns — and so does this workload (fdb_plan_desc.ordered)
+        self.ordered = bool(config == 5 and (cfg5_sorted or args.cfg5_sorted))
+        if self.ordered:
+            self.qdesc += "; table sorted by its label columns → OrderedAggregate"
+        self.desc = to_desc(self.filt, self.aggs, self.groups, ordered=self.ordered)  # planned once; every step instantiates a fresh operator chain
         t0 = time.time()
         br = args.batch_rows
         n_chunks = (rows + br - 1) // br
@@ -268,7 +273,7 @@ class Workload:
 
         def gen(i):
             if config == 5:
-                b = synth.cfg5_chunk(rank, i, sizes[i], n_groups=args.groups, sorted_rows=args.cfg5_sorted)
+                b = synth.cfg5_chunk(rank, i, sizes[i], n_groups=args.groups, sorted_rows=self.ordered, of_chunks=n_chunks if self.ordered else 0)
                 return b, expected_cfg5(b), None
             b = synth.prometheus_chunk(rank, i, sizes[i], row_base=i * br, cfg3=(config == 3))
             sel = None
@@ -308,11 +313,17 @@ class Workload:
         if self.config == 5:
             n_rows, total = int(expected[0][0]), float(expected[1][0])
             n_out = out.num_rows
-            s = col("sum(value)").to_numpy()
+            s = col("value" if self.ordered else "sum(value)").to_numpy()  # (a partial-stage OrderedAggregate names its result after the column, ordered_aggregate.go:551-557)
             assert n_rows == total_rows, (n_rows, total_rows)
             assert n_out <= self.args.groups and (total_rows < 5 * self.args.groups or n_out > 0.99 * self.args.groups), n_out
             assert math.isclose(float(s.sum()), total, rel_tol=1e-9), (float(s.sum()), total)
-            return {"groups_out": n_out, "sum_check": "Σ sum(value) == Σ value (1e-9 rel)"}
+            res = {"groups_out": n_out, "sum_check": "Σ sum(value) == Σ value (1e-9 rel)"}
+            if self.ordered:  # the OrderedAggregate's record is in key order and holds every group once: ranks of the decoded group ids strictly increase
+                import numpy as np
+                ranks = synth._rev4_12(synth.cfg5_decode_group_ids(out))
+                assert bool(np.all(ranks[1:] > ranks[:-1])), "ordered result is not strictly increasing in key order"
+                res["key_order"] = "strictly increasing (every group once, sorted by the label columns)"
+            return res
         paths = synth.PATHS + [None]
         key = col("labels.path")
         key = key.dictionary_decode() if hasattr(key, "dictionary_decode") else key
@@ -723,6 +734,19 @@ def other_configs(args, wl, rank, device, group, comm):
                 "value": 100_000_000 * st / r3["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r3["elapsed"] / st * 1e3,
                 "roofline": roofline_of(r3, 100_000_000, st, "cfg5"), "checked": r3["checked"]}
         w2.release()
+        if cfg == 5 and want("cfg5_sorted"):  # the same table SORTED by its label columns: the table-free OrderedAggregate (no hash kernel runs)
+            w3 = Workload(args, 5, 100_000_000, rank, device, cfg5_sorted=True)
+            r4 = run_workload(args, w3, st, wu, group, comm, 100_000_000)
+            others["cfg5_sorted"] = {
+                "workload": f"cfg5_sorted: Prometheus schema, 100000000 rows, {w3.qdesc}",
+                "value": 100_000_000 * st / r4["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r4["elapsed"] / st * 1e3,
+                "roofline": roofline_of(r4, 100_000_000, st, "cfg5_sorted"), "checked": r4["checked"], "jit": jit_of(r4)}
+            r5 = run_workload(args, w3, st, wu, group, comm, 100_000_000, resident_finish=True)
+            others["cfg5_sorted_resident_finish"] = {
+                "workload": "cfg5_sorted with the result left in HBM (fdb_plan_finish_batch)",
+                "value": 100_000_000 * st / r5["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r5["elapsed"] / st * 1e3,
+                "roofline": roofline_of(r5, 100_000_000, st, "cfg5_sorted"), "checked": r5["checked"]}
+            w3.release()
     if want("parquet"):
         others["parquet"] = measure_parquet(device)
     return others

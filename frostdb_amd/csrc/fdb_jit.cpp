@@ -607,7 +607,13 @@ struct HashGen {
   std::string source() {
     const int BLK = 256, TILE = BLK * 4, GROUP = 8;
     o << "#define FDB_DEVICE_HELPERS 1\n#include \"fdb_kernels.h\"\n" << kPreamble << kHashPreamble;
-    o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") void fdb_hash_kernel(const FdbHashArgs h) {\n";
+    // The runs kernel wants 149 VGPRs (3 waves per SIMD); capped at 128 it spills 10 of them and runs 4 workgroups per CU — measured
+    // on cfg 5 sorted (round 4): 2.62 ms per 100 M rows against 2.79 uncapped (66 % against 62 % of the HBM peak).
+    // ($FDB_RUNS_WAVES_PER_EU: tuning aid, 0 = no cap)
+    const int waves_cap = !s.runs ? 0 : std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::atoi(std::getenv("FDB_RUNS_WAVES_PER_EU")) : 4;
+    o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") ";
+    if (waves_cap > 0) o << "__attribute__((amdgpu_waves_per_eu(" << waves_cap << ", " << waves_cap << "))) ";
+    o << "void fdb_hash_kernel(const FdbHashArgs h) {\n";
     o << "  extern __shared__ __align__(16) unsigned char smem[];\n  __shared__ unsigned int s_new;\n";
     if (s.runs) o << "  __shared__ unsigned int s_runs[8];  // per wave: first run of its open chunk, runs used in it\n  if (threadIdx.x < 8) s_runs[threadIdx.x] = (threadIdx.x & 1u) ? " << FDB_RUN_CHUNK << "u : 0u;\n";
     o << "  const FdbScanArgs& a = h.base;\n  // descriptors are read through the constant address space: scalar loads, no vector registers\n  const __attribute__((address_space(4))) FdbHashCol* hc = (const __attribute__((address_space(4))) FdbHashCol*)h.hcols;\n  const uint32_t tid = threadIdx.x;\n  if (tid == 0) s_new = 0;\n";
@@ -698,7 +704,7 @@ struct HashGen {
           else o << "        const uint32_t* L = hc[" << c << "].lut;\n";
           for (int k = 0; k < 4; k++) {
             o << "        { const uint32_t id = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_in_lds ? "L" : "as_global(L)") << "[" << r << comp4(k) << "] : 0u; fp_add32(h1_" << k << ", h2_"
-              << k << ", K1, K2, id); if (id != 0u) vm_" << k << " |= bit;";
+              << k << ", K1, K2, id);" << (s.runs ? "" : " if (id != 0u) vm_" + std::to_string(k) + " |= bit;");
             if (s.runs) o << " t" << (c < 16 ? "a" : "b") << "_" << k << comp4((int)((c % 16) / 4)) << " |= id << " << 8 * (c % 4) << ";";
             o << " }\n";
           }
@@ -720,7 +726,8 @@ struct HashGen {
       // keep the next group's loads below this point: hoisting all 32 columns' loads to the top of the tile costs ≈390 VGPRs
       // and force the fingerprint updates to happen HERE: LLVM otherwise sinks all 32 columns' multiply-adds into the per-row
       // `if (selected)` blocks below and keeps 4 × 32 key ids live until then
-      o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3), \"+v\"(vm_0), \"+v\"(vm_1), \"+v\"(vm_2), \"+v\"(vm_3) :: \"memory\");\n";
+      if (s.runs) o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3) :: \"memory\");\n";
+      else o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3), \"+v\"(vm_0), \"+v\"(vm_1), \"+v\"(vm_2), \"+v\"(vm_3) :: \"memory\");\n";
       // (same for the packed key ids of runs mode: pinned here, or all 4 × 32 ids stay live until the rows' tuples are stored)
       if (s.runs) o << "      asm volatile(\"\" : \"+v\"(ta_0), \"+v\"(ta_1), \"+v\"(ta_2), \"+v\"(ta_3), \"+v\"(tb_0), \"+v\"(tb_1), \"+v\"(tb_2), \"+v\"(tb_3));\n";
       o << "    }\n";
@@ -1128,7 +1135,7 @@ hipFunction_t jit_get(const JitShape& shape) {
 
 std::string JitHashShape::key() const {
   std::ostringstream k;
-  k << "a" << ablate << "c" << need_count << (runs ? "R" : "") << "|";
+  k << "a" << ablate << "c" << need_count << (runs ? "R" : "") << (runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::getenv("FDB_RUNS_WAVES_PER_EU") : "") << "|";
   for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
   k << '|';
   for (size_t l = 0; l < leaves.size(); l++) {

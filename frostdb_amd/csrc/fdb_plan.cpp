@@ -1245,6 +1245,15 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   for (int i = 0; i < n; i++) if (bs[i]->rows > 0) live.push_back(i);
   if (live.empty()) return;
 
+  // OrderedAggregate without a table: nothing accumulated yet (or already collecting runs) and the records fit the run kernel
+  if (ordered_ && ((mode_ == TableMode::DENSE && !state_dirty_ && h_table_ == nullptr) || !runs_.empty())) {
+    if (runs_wanted(bs, Rs, live)) {
+      push_hash(bs, Rs, live, /*runs=*/true);
+      pt.mark("run scan");
+      return;
+    }
+    runs_to_table();  // (no-op without runs) — from here on the ordinary paths
+  }
   // Dense (mixed-radix) table while the key space is small and every key column is a dictionary; otherwise the
   // global hash table (cfg 5: tens of label columns, millions of groups; int64 keys such as time buckets).
   if (mode_ == TableMode::DENSE) {
@@ -1256,15 +1265,6 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
       if (space > (1ull << 22)) { want_hash = true; break; }
     }
     if (want_hash) switch_to_hash();
-  }
-  // OrderedAggregate without a table: nothing accumulated yet (or already collecting runs) and the records fit the run kernel
-  if (ordered_ && ((mode_ == TableMode::DENSE && !state_dirty_ && h_table_ == nullptr) || !runs_.empty())) {
-    if (runs_wanted(bs, Rs, live)) {
-      push_hash(bs, Rs, live, /*runs=*/true);
-      pt.mark("run scan");
-      return;
-    }
-    runs_to_table();  // (no-op without runs) — from here on the ordinary paths
   }
   if (mode_ == TableMode::HASH) {
     push_hash(bs, Rs, live);

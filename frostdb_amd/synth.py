@@ -122,16 +122,41 @@ def cfg5_decode_group_ids(batch: pa.RecordBatch) -> np.ndarray:
     return gid
 
 
-def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000, sorted_rows: bool = False) -> pa.RecordBatch:
+def _rev4_12(x: np.ndarray) -> np.ndarray:
+    """The 12 base-4 digits of x in reverse order: group id ↔ its rank in the lexicographic order of (labels.l00, …, labels.l11) —
+    column c holds digit c of the id, least significant first, and the dictionary values "lCC=0" < … < "lCC=3" sort like the digits."""
+    out = np.zeros_like(x)
+    for i in range(12):
+        out |= ((x >> (2 * i)) & 3) << (2 * (11 - i))
+    return out
+
+
+def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000, sorted_rows: bool = False, of_chunks: int = 0) -> pa.RecordBatch:
     """`sorted_rows`: the record's rows ordered by group id — what a scan of a table SORTED by its label columns (FrostDB's sorting
-    columns) hands the aggregate: rows of one group arrive next to each other."""
+    columns) hands the aggregate: rows of one group arrive next to each other.
+    `of_chunks` > 0 (with sorted_rows): the TABLE is sorted, not just each record — rows are ordered by (labels.l00, labels.l01, …)
+    with dictionary values ascending, and chunk i of `of_chunks` holds the i-th slice of the key space, so the records of a scan
+    arrive in key order one after the other: the input an OrderedAggregate is planned for (physicalplan.go:525-560)."""
     if n_groups not in _CFG5_CACHE:
         _CFG5_CACHE[n_groups] = _cfg5_tables(n_groups)
     digits, nulls = _CFG5_CACHE[n_groups]
     rng = np.random.Generator(np.random.Philox(key=SEED + 5 + shard, counter=[0, 0, 0, chunk]))
-    gid = rng.integers(0, n_groups, size=rows, dtype=np.int64)
-    if sorted_rows:
-        gid.sort()
+    if sorted_rows and of_chunks > 0:
+        assert n_groups <= 4 ** 12
+        lo, hi = (4 ** 12) * chunk // of_chunks, (4 ** 12) * (chunk + 1) // of_chunks
+        parts, have = [], 0
+        while have < rows:  # ranks whose group id is < n_groups (ids are the digit-reversed ranks)
+            r = rng.integers(lo, hi, size=max(1024, int((rows - have) * 2.2)), dtype=np.int64)
+            r = r[_rev4_12(r) < n_groups]
+            parts.append(r)
+            have += len(r)
+        r = np.concatenate(parts)[:rows]
+        r.sort()
+        gid = _rev4_12(r)
+    else:
+        gid = rng.integers(0, n_groups, size=rows, dtype=np.int64)
+        if sorted_rows:
+            gid.sort()
     arrays, names = [], []
     for c in range(CFG5_COLS):
         idx = pa.array(digits[c][gid].astype(np.uint32), type=pa.uint32(), mask=nulls[c][gid] if c >= 12 else None)
