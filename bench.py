@@ -635,6 +635,95 @@ def measure_host_records(wl, steps=3):
     return out
 
 
+def measure_host_records_chains(wl, rows_per_chain=4_194_304):
+    """What the Go shim really drives: N chains pushing HOST records concurrently — one plan per chain on
+    its own stream, one thread per chain like one goroutine per chain (physicalplan.go:337-347), records of 1 024 rows (the
+    reference's batch floor, table.go:780), 8 192 and 65 536 rows, every chain its own rows. Wall time from the first Callback to
+    the last chain's Finish; the per-chain results are merged (fdb_plan_merge) and checked against the numpy expectation."""
+    import numpy as np
+    import torch
+    from frostdb_amd import physicalplan as pp
+    h2d = h2d_rate_gbs(wl.device)
+    src = wl.host_batches
+    total_src = sum(b.num_rows for b in src)
+    out = {"bound": "pcie / host", "measured_h2d_GBps": h2d, "bytes_per_row_copied": 16.25, "rows_per_chain": rows_per_chain}
+    for chains in (1, 8, 32):
+        per_chain = min(rows_per_chain, total_src // chains // 65536 * 65536)
+        for rec_rows in (1024, 8192, 65536):
+            # chain c owns rows [c × per_chain, (c + 1) × per_chain) of the host batches laid end to end
+            exported, expected = [], None
+            for c in range(chains):
+                lo, hi, recs = c * per_chain, (c + 1) * per_chain, []
+                base = 0
+                for b in src:
+                    a0, a1 = max(lo, base), min(hi, base + b.num_rows)
+                    for o in range(a0, a1, rec_rows):
+                        recs.append(b.slice(o - base, min(rec_rows, a1 - o)))
+                    base += b.num_rows
+                exported.append([pp.ExportedBatch(r) for r in recs])
+            for b_i, b in enumerate(src):
+                pass
+            # numpy expectation over the rows the chains own
+            need = chains * per_chain
+            base = 0
+            for b in src:
+                take = min(b.num_rows, max(0, need - base))
+                if take > 0:
+                    e = expected_cfg2(b.slice(0, take))
+                    expected = list(e) if expected is None else fold_expected(2, expected, e)
+                base += b.num_rows
+            errors = []
+
+            def run_all():
+                plans = [pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=wl.device, desc=wl.desc) for _ in range(chains)]
+                bar = threading.Barrier(chains + 1)
+
+                def work(c):
+                    try:
+                        bar.wait()
+                        plans[c].CallbackExportedMany(exported[c])
+                        plans[c].last_kernel()  # (settle: the queued records are scanned — launched from this chain's thread, not waited for)
+                    except BaseException as e:  # noqa: BLE001
+                        errors.append(e)
+                        bar.abort()
+                ts = [threading.Thread(target=work, args=(c,)) for c in range(chains)]
+                for t in ts:
+                    t.start()
+                bar.wait()
+                t0 = time.perf_counter()
+                for t in ts:
+                    t.join()
+                for p in plans[1:]:
+                    plans[0].Merge(p)
+                res = plans[0].Finish()
+                dt = time.perf_counter() - t0
+                for p in plans:
+                    p.Close()
+                if errors:
+                    raise errors[0]
+                return res, dt
+            res, _ = run_all()
+            got = dict(zip(res.column(0).to_pylist(), res.column(1).to_pylist()))
+            from frostdb_amd import synth
+            exp_sum, exp_cnt = expected
+            for i, p in enumerate(synth.PATHS + [None]):
+                if exp_cnt[i]:
+                    assert math.isclose(got[p], exp_sum[i], rel_tol=1e-9), (chains, rec_rows, p)
+            torch.cuda.synchronize()
+            dts = [run_all()[1] for _ in range(3)]
+            dt = sorted(dts)[1]
+            rows = chains * per_chain
+            gbs = rows * 16.25 / dt / 1e9
+            out[f"chains_{chains}_records_{rec_rows}"] = {"chains": chains, "record_rows": rec_rows, "records": sum(len(e) for e in exported), "rows": rows, "ms": dt * 1e3,
+                                                         "value": rows / dt, "unit": "rows/s", "achieved_GBps": gbs, "frac_of_h2d": gbs / h2d,
+                                                         "us_per_record_per_chain": dt * 1e6 / max(len(exported[0]), 1)}
+            for ex_list in exported:
+                for ex in ex_list:
+                    ex.close()
+    out["checked"] = {"against": "numpy expectation: every group's sum over the rows the chains own (bench.py expected_cfg2), chains merged with fdb_plan_merge; not the oracle"}
+    return out
+
+
 def measure_parquet(device, rows=20_000_000, passes=3):
     """Parquet row groups (file bytes in pinned host memory) → columns decoded on the device
     (fdb_batch_from_parquet) → cfg 2's query. Bytes = file bytes read + column bytes produced; host / device split from
@@ -715,6 +804,8 @@ def other_configs(args, wl, rank, device, group, comm):
         others["select"] = measure_select(wl)
     if want("host_records") and wl.host_batches:
         others["host_records"] = measure_host_records(wl)
+    if want("host_records_chains") and wl.host_batches:
+        others["host_records_chains"] = measure_host_records_chains(wl)
     wl.release()
     for cfg, st, wu in ((3, max(5, args.steps // 2), 2), (5, 3, 1)):
         if not want(f"cfg{cfg}"):

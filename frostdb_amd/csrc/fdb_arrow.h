@@ -27,6 +27,10 @@ struct HostDict {
   uint64_t hash = 0;         // content hash (lengths + bytes), computed at import
   bool unique = true;        // no two entries hold the same bytes (Arrow allows duplicates)
   bool plain = false;        // not an Arrow dictionary: the distinct values of a plain string / binary column, encoded by encode_plain
+  // The entries' lengths and their bytes laid end to end (read_dictionary / make_dictionary): "is this record's dictionary the one
+  // we know?" is then two memcmps instead of one per entry.
+  std::vector<uint32_t> lens;
+  std::string concat;
   bool utf8() const { return value_format == "u" || value_format == "U"; }
   bool same_content(const HostDict& o) const { return hash == o.hash && plain == o.plain && values == o.values; }
 };

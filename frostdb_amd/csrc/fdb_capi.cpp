@@ -180,6 +180,17 @@ int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* 
   return guard(plan, [&] { if (plan->dyn) plan->dyn->push(plan->plan, batch, schema); else plan->plan.push(batch, schema); });
 }
 
+int fdb_plan_push_many(fdb_plan* plan, struct ArrowArray* const* batches, struct ArrowSchema* const* schemas, int32_t n, int32_t* n_pushed) {
+  if (n_pushed) *n_pushed = 0;
+  if (!plan || n < 0 || (n > 0 && (!batches || !schemas))) return FDB_ERR_INVALID;
+  for (int32_t i = 0; i < n; i++) {
+    const int rc = fdb_plan_push(plan, batches[i], schemas[i]);
+    if (rc != 0) return rc;
+    if (n_pushed) *n_pushed = i + 1;
+  }
+  return 0;
+}
+
 int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch) {
   if (!plan || !batch) return FDB_ERR_INVALID;
   return guard(plan, [&] {

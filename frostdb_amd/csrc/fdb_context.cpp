@@ -40,8 +40,14 @@ Context* Context::acquire(int device) {
   return c;
 }
 
+void Context::free_retired() {
+  for (auto& r : retired_) { if (r.first) (void)hipHostFree(r.first); if (r.second) (void)hipFree(r.second); }
+  retired_.clear();
+}
+
 void Context::release(Context* c) {
   if (c == nullptr) return;
+  c->free_retired();
   c->stage_off_ = 0;
   std::lock_guard<std::mutex> lk(g_mu);
   g_free[c->device].push_back(c);
@@ -257,18 +263,21 @@ void Context::copy_out_parallel(void* host, const void* dev, size_t bytes) {
 void* Context::stage(const void* host, size_t payload) {
   const size_t bytes = (std::max<size_t>(payload, 1) + 255) / 256 * 256;
   if (stage_off_ + bytes > stage_cap_) {
-    flush_staging();  // (what is staged but not shipped goes out before the ring restarts)
-    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(staging)");
+    // The ring is full. What it holds may still be in use — tables staged earlier for a launch that has not been queued yet
+    // (a scan over 1 024 small records stages its predicate tables first and 1 024 argument blocks after them), or launches that
+    // are queued but have not run — so it is neither restarted nor freed here: it is RETIRED (kept until the stream is next known
+    // idle, reset_staging) and a bigger one takes over. (Until round 4 the ring restarted / was freed in place: the earlier tables
+    // of the same launch were overwritten — or, with several chains in flight, their freed block was handed to another thread's
+    // hipMalloc — and the scan read garbage LUTs.)
+    flush_staging();  // (pending bytes go to the ring they were staged in)
+    if (stage_h_ != nullptr) retired_.emplace_back(stage_h_, stage_d_);
+    stage_h_ = nullptr; stage_d_ = nullptr;
     stage_off_ = 0;
     stage_sent_ = 0;
-    if (bytes > stage_cap_) {
-      if (stage_h_) (void)hipHostFree(stage_h_);
-      if (stage_d_) (void)hipFree(stage_d_);
-      shadow_valid_ = 0;
-      stage_cap_ = std::max<size_t>(round_block(bytes * 2), 1 << 20);
-      hip_check(hipHostMalloc((void**)&stage_h_, stage_cap_, hipHostMallocDefault), "hipHostMalloc(staging)");
-      hip_check(hipMalloc((void**)&stage_d_, stage_cap_), "hipMalloc(staging)");
-    }
+    shadow_valid_ = 0;
+    stage_cap_ = std::max<size_t>(std::max<size_t>(round_block(bytes * 2), stage_cap_ * 2), 1 << 20);
+    hip_check(hipHostMalloc((void**)&stage_h_, stage_cap_, hipHostMallocDefault), "hipHostMalloc(staging)");
+    hip_check(hipMalloc((void**)&stage_d_, stage_cap_), "hipMalloc(staging)");
   }
   if (payload) std::memcpy(stage_h_ + stage_off_, host, payload);
   void* dst = stage_d_ + stage_off_;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstddef>
+#include <utility>
 #include <vector>
 
 namespace fdb {
@@ -37,6 +38,7 @@ class Context {
   void reset_staging() {  // the stream is idle (tables staged but not yet shipped — a deferred batch — stay where they are)
     if (stage_sent_ == stage_off_) stage_off_ = stage_sent_ = 0;
     copy_off_ = 0;
+    if (!retired_.empty()) free_retired();  // rings that filled up while something could still read them (stage())
   }
   // Several tables that feed ONE launch: between defer_staging(true) and flush_staging() stage() only fills the pinned ring
   // (the device address it returns is final), and flush_staging() ships everything staged since with one copy command —
@@ -57,6 +59,8 @@ class Context {
   std::vector<hipEvent_t> events_;
   unsigned char* stage_h_ = nullptr;
   unsigned char* stage_d_ = nullptr;
+  std::vector<std::pair<unsigned char*, unsigned char*>> retired_;  // (pinned, device) halves of rings that filled up: freed when the stream is idle
+  void free_retired();
   size_t stage_cap_ = 0, stage_off_ = 0, stage_sent_ = 0;  // [stage_sent_, stage_off_) is staged but not shipped yet
   // What the device half of the staging ring holds, as far as it is known ([0, shadow_valid_)): a flush whose bytes are already
   // there is not shipped again. A query repeated over resident data (same predicate tables, same launch descriptors, the same

@@ -12,12 +12,14 @@
 #include "fdb_jit.h"
 
 #include "fdb_context.h"
+#include "fdb_hostpool.h"
 #include "fdb_plan_internal.h"
 
 #include <algorithm>
 #include <cstring>
 #include <functional>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +35,10 @@ namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr size_t kTailPad = 256;  // bytes readable past every column so tail lanes may over-read
+}
+void copy_stream(void* dst, const void* src, size_t n);                          // fdb_widen.cc: streaming-store copies into the pinned slab
+uint32_t copy_stream_max_u32(uint32_t* dst, const uint32_t* src, size_t n);
+namespace {
 
 const char* op_str(int32_t op) {  // logicalplan/expr.go:37-72
   switch (op) {
@@ -74,7 +80,7 @@ void DeviceBatch::note_reader(hipStream_t s) const {
 }
 
 DeviceBatch::~DeviceBatch() {
-  if (arena == nullptr) return;
+  if (arena == nullptr || arena_borrowed) return;
   if (arena_ctx != nullptr) { arena_ctx->dev_free(arena); return; }
   if (!readers_.empty()) {  // (an idle stream answers in about a microsecond)
     (void)hipSetDevice(device);
@@ -108,11 +114,19 @@ void check_indices_host(const uint32_t* idx, const uint8_t* validity_bit0, int64
 }  // namespace
 
 std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device, const std::function<bool(const std::string&)>* want,
-                                          hipStream_t stream, Context* ctx, bool via_ring) {
+                                          hipStream_t stream, Context* ctx, bool via_ring, const RecordSink* sink) {
   std::unique_ptr<DeviceBatch> b(new DeviceBatch());
   b->device = device;
   b->rows = view.rows;
   hip_check(hipSetDevice(device), "hipSetDevice");
+  static const bool prof = std::getenv("FDB_PROFILE_PUSH") != nullptr;  // (tuning aid: phases of a record's import, summed per process)
+  static std::atomic<int64_t> p_ns[4], p_n;
+  auto tick = [] { return std::chrono::steady_clock::now(); };
+  auto t_prev = tick();
+  auto lap = [&](int k) { if (prof) { const auto n = tick(); p_ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - t_prev).count(); t_prev = n; } };
+  struct Report { ~Report() { if (prof && p_n.load() > 0) std::fprintf(stderr, "[fdb] import of %lld records: plan+dictionaries %.2f, reserve %.2f, copies %.2f, index check %.2f us per record\n", (long long)p_n.load(),
+                                                                      p_ns[0] / 1e3 / p_n, p_ns[1] / 1e3 / p_n, p_ns[2] / 1e3 / p_n, p_ns[3] / 1e3 / p_n); } };
+  static Report report;
   // plan the arena
   struct Piece { size_t col; bool validity; size_t off; size_t bytes; };
   std::vector<Piece> pieces;
@@ -148,19 +162,25 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     }
     b->cols.push_back(std::move(d));
   }
+  lap(0);
+  unsigned char* sink_host = nullptr;
   if (total > 0) {
-    if (ctx != nullptr) { b->arena = ctx->dev_alloc(total); b->arena_ctx = ctx; }
+    if (sink != nullptr) { (*sink)(total, &b->arena, &sink_host); b->arena_borrowed = true; }
+    else if (ctx != nullptr) { b->arena = ctx->dev_alloc(total); b->arena_ctx = ctx; }
     else b->arena = device_pool_alloc(device, total);
     b->arena_bytes = total;
   }
+  lap(1);
   // transient batches: every copy is queued on `stream`; re-packed buffers stay alive until the one wait at the end
+  std::vector<uint32_t> index_max(view.cols.size(), 0);
+  std::vector<char> index_max_known(view.cols.size(), 0);
   std::vector<std::vector<uint8_t>> keep_bits;
   std::vector<std::vector<uint32_t>> keep_idx;
   std::vector<std::vector<int64_t>> keep_i64;
   // via_ring: the whole arena is assembled in ONE piece of the pinned ring and shipped with one DMA
-  unsigned char* ring = (ctx != nullptr && via_ring && total > 0) ? ctx->copy_reserve(total) : nullptr;
+  unsigned char* ring = sink_host != nullptr ? sink_host : (ctx != nullptr && via_ring && total > 0) ? ctx->copy_reserve(total) : nullptr;
   auto h2d = [&](void* dst, const void* src, size_t bytes, const char* what) {
-    if (ring != nullptr) std::memcpy(ring + ((unsigned char*)dst - (unsigned char*)b->arena), src, bytes);
+    if (ring != nullptr) copy_stream(ring + ((unsigned char*)dst - (unsigned char*)b->arena), src, bytes);  // (splitting a 1 MB copy over pooled threads was measured: their wake-up costs more than it saves)
     else if (ctx != nullptr) hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream), what);
     else hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), what);
   };
@@ -205,6 +225,13 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
           }
         }
         h2d(dst, wide.data(), p.bytes, "hipMemcpy(indices)");
+      } else if (ring != nullptr && c.kind == ColKind::DICT && d.dict && !d.dict->plain) {
+        // indices into the pinned piece and their maximum in ONE pass (the separate validation pass re-read what had just been written: 27 µs
+        // of a 65 536-row record's 85)
+        const uint32_t* src = (const uint32_t*)c.values + c.offset;
+        uint32_t* out = (uint32_t*)(ring + (dst - (unsigned char*)b->arena));
+        index_max[p.col] = copy_stream_max_u32(out, src, (size_t)c.length);
+        index_max_known[p.col] = 1;
       } else {
         const size_t w = c.kind == ColKind::DICT ? 4 : 8;
         h2d(dst, (const unsigned char*)c.values + (size_t)c.offset * w, p.bytes, "hipMemcpy(values)");
@@ -212,6 +239,7 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
     }
   }
   for (const DevColumn& d : b->cols) b->payload_bytes += d.value_bytes + d.validity_bytes;
+  lap(2);
   // dictionary indices are validated before anything can scan the record (see check_indices_host)
   std::vector<size_t> dict_cols;
   for (size_t i = 0; i < b->cols.size(); i++)
@@ -219,11 +247,14 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
   if (ring != nullptr) {
     for (size_t i : dict_cols) {  // the bytes are in the pinned ring: checked by the CPU that just copied them
       const DevColumn& d = b->cols[i];
+      if (index_max_known[i] && (size_t)index_max[i] < d.dict->values.size()) continue;  // (the copy already saw every index)
       const unsigned char* base = ring;
       check_indices_host((const uint32_t*)(base + ((unsigned char*)d.d_values - (unsigned char*)b->arena)),
                          d.d_validity ? base + (d.d_validity - (unsigned char*)b->arena) : nullptr, b->rows, d.dict->values.size(), d.name);
     }
-    ctx->copy_commit(b->arena, ring, total);
+    if (sink_host == nullptr) ctx->copy_commit(b->arena, ring, total);  // (a sink's owner ships its slab itself)
+    lap(3);
+    if (prof) p_n++;
     return b;
   }
   if (!dict_cols.empty()) {  // big records: one streaming pass on the device behind the copies (4 B/row at HBM speed), one flag word per column
@@ -419,6 +450,9 @@ Plan::Plan(const Plan& proto, CloneTag)
 }
 
 Plan::~Plan() {
+  if (prof_push_n_ > 0 && std::getenv("FDB_PROFILE_PUSH") != nullptr)
+    std::fprintf(stderr, "[fdb] push of %lld small records: view %.2f import %.2f resolve %.2f queue/settle %.2f us per record\n", (long long)prof_push_n_, prof_push_[0] / prof_push_n_,
+                 prof_push_[1] / prof_push_n_, prof_push_[2] / prof_push_n_, prof_push_[3] / prof_push_n_);
   if (ctx_ == nullptr) return;
   (void)hipSetDevice(device_);
   (void)hipStreamSynchronize(stream_);
@@ -431,6 +465,8 @@ Plan::~Plan() {
   ctx_->dev_free(h_keys_);
   ctx_->dev_free(h_count_dev_);
   for (RunSegment& r : runs_) ctx_->dev_free(r.block);
+  for (RecordSlab& sl : inflight_slabs_) { ctx_->dev_free(sl.d); ctx_->host_free(sl.h); }
+  if (slab_.d != nullptr) { ctx_->dev_free(slab_.d); ctx_->host_free(slab_.h); }
   for (void* p : scratch_) ctx_->dev_free(p);
   pending_.clear();   // (queued / in-flight records hand their arenas back to this context: before it is released)
   inflight_.clear();
@@ -517,6 +553,9 @@ void Plan::sync() {
   for (void* p : scratch_) ctx_->dev_free(p);
   scratch_.clear();
   inflight_.clear();  // (their arenas go back to the block cache)
+  for (RecordSlab& sl : inflight_slabs_) { ctx_->dev_free(sl.d); ctx_->host_free(sl.h); }
+  inflight_slabs_.clear();
+  if (slab_.d != nullptr && pending_.empty() && slab_.shipped == slab_.used) slab_.used = slab_.shipped = 0;  // nothing refers to the open slab any more
 }
 
 void Plan::state_idents(unsigned long long* idents) const {
@@ -982,10 +1021,16 @@ bool Plan::jit_possible() const { return sub_tiles != 4 && ablate == 0 && std::g
 void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
   if (finished_) throw Error(FDB_ERR_STATE, "push after finish");
   if (aggs_.empty() && matchers_.empty()) throw Error(FDB_ERR_STATE, "filter-only plan: use fdb_plan_filter / fdb_plan_select");
+  // ($FDB_PROFILE_PUSH: tuning aid — where a small record's Callback goes, summed per plan and printed by the destructor)
+  static const bool prof = std::getenv("FDB_PROFILE_PUSH") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto lap = [&](std::chrono::steady_clock::time_point& t, double& acc) { if (prof) { const auto n = now(); acc += std::chrono::duration<double, std::micro>(n - t).count(); t = n; } };
+  std::chrono::steady_clock::time_point tp = now();
   HostRecordView view;
   view_record(array, schema, &view);
   std::function<bool(const std::string&)> want = [this](const std::string& n) { return references(n); };
   hip_check(hipSetDevice(device_), "hipSetDevice");
+  lap(tp, prof_push_[0]);
   size_t payload = 0;
   for (const HostColView& c : view.cols)
     if (want(c.name)) payload += (size_t)c.length * (c.kind == ColKind::DICT ? 4 : 8) + (size_t)(c.length + 7) / 8;
@@ -997,7 +1042,10 @@ void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
     return;
   }
   // small record: copy now (through pinned staging — the source is not touched after this call), scan later
-  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_, ctx_, /*via_ring=*/true);
+  const RecordSink sink = [this](size_t bytes, void** dev, unsigned char** pinned) { slab_reserve(bytes, dev, pinned); };
+  std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_, ctx_, /*via_ring=*/true, &sink);
+  if (slab_.used - slab_.shipped >= ((size_t)8 << 20)) slab_ship();
+  lap(tp, prof_push_[1]);
   {
     // errors the record would raise surface here, at its own Callback, not at some later launch
     Resolved R;
@@ -1006,14 +1054,44 @@ void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
     if (R.args.n_expr > 0 && !jit_possible())
       throw Error(FDB_ERR_UNSUPPORTED, "computed (projected) columns need the run-time specialised kernel (hiprtc unavailable or disabled)");
   }
+  lap(tp, prof_push_[2]);
   pending_rows_ += b->rows;
   pending_bytes_ += b->arena_bytes;
   pending_.push_back(std::move(b));
   if (pending_rows_ >= kFlushRows || pending_bytes_ >= kFlushBytes || pending_.size() >= kFlushRecords) settle();
+  lap(tp, prof_push_[3]);
+  prof_push_n_++;
+}
+
+void Plan::slab_reserve(size_t bytes, void** dev, unsigned char** pinned) {
+  constexpr size_t kSlabBytes = (size_t)32 << 20;
+  bytes = (bytes + 255) / 256 * 256;
+  if (slab_.d != nullptr && slab_.used + bytes > slab_.cap) {
+    settle();  // the queued records (pieces of this slab) are scanned; the slab stays alive until the stream is idle
+    inflight_slabs_.push_back(slab_);
+    slab_ = RecordSlab();
+    if (inflight_slabs_.size() >= 8) sync();  // (bounds what a long stream of records without a Finish can hold)
+  }
+  if (slab_.d == nullptr) {
+    slab_.cap = std::max(kSlabBytes, bytes);
+    slab_.d = ctx_->dev_alloc(slab_.cap);
+    slab_.h = (unsigned char*)ctx_->host_alloc(slab_.cap);
+    slab_.used = slab_.shipped = 0;
+  }
+  *dev = (unsigned char*)slab_.d + slab_.used;
+  *pinned = slab_.h + slab_.used;
+  slab_.used += bytes;
+}
+
+void Plan::slab_ship() {
+  if (slab_.d == nullptr || slab_.used <= slab_.shipped) return;
+  hip_check(hipMemcpyAsync((unsigned char*)slab_.d + slab_.shipped, slab_.h + slab_.shipped, slab_.used - slab_.shipped, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(record slab)");
+  slab_.shipped = slab_.used;
 }
 
 void Plan::settle() {
   if (pending_.empty()) return;
+  slab_ship();
   // The queued records must outlive the launch (until the next sync), and push_batches itself may synchronise (table
   // migration, growth) — which empties inflight_ — so they are held here until it returns.
   std::vector<std::unique_ptr<DeviceBatch>> batch = std::move(pending_);

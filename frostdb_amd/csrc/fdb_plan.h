@@ -45,6 +45,7 @@ struct DeviceBatch {
   std::vector<DevColumn> cols;
   void* arena = nullptr;        // one allocation per record
   size_t arena_bytes = 0;
+  bool arena_borrowed = false;  // the arena is a piece of a plan's record slab (small pushed records): nothing to free here
   class Context* arena_ctx = nullptr;  // transient batches (fdb_plan_push): the arena is borrowed from the plan's block cache
   int64_t payload_bytes = 0;    // Σ value_bytes + validity_bytes
   // Plans scan resident records asynchronously on their own streams and the caller may release a record as soon as the push
@@ -67,9 +68,12 @@ struct DeviceBatch {
 // (resident batches, which outlive any plan).
 // `via_ring` (with ctx): every buffer is first copied into the context's pinned ring (the source is fully read when the call
 // returns, nothing is waited for) — the deferred, coalescing mode of fdb_plan_push for small records.
+// `sink` (small pushed records): the record's device bytes are a piece of a slab the caller owns — sink(bytes, &device, &pinned) names
+// where they go and where they are assembled on the host; the CALLER ships the pinned piece (one DMA for many records).
+typedef std::function<void(size_t bytes, void** dev, unsigned char** pinned)> RecordSink;
 std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device,
                                           const std::function<bool(const std::string&)>* want, hipStream_t stream, class Context* ctx = nullptr,
-                                          bool via_ring = false);
+                                          bool via_ring = false, const RecordSink* sink = nullptr);
 
 // Parquet column chunks of one row group → a resident batch (fdb_parquet.cpp).
 std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device);
@@ -309,6 +313,16 @@ class Plan {
     unsigned long long* phys = nullptr; uint32_t* flags = nullptr; uint32_t* out_idx = nullptr;
     int64_t n_runs = 0, n_groups = 0;
   };
+  // Small pushed records are not allocated one by one (a record held until the next sync would cost a hipMalloc each: ≈25 µs, and
+  // a process-wide lock that N chains fight over): their bytes are pieces of a SLAB — a device block and a pinned block of the same
+  // size, filled at the same offsets — shipped with one DMA per ≈8 MiB and recycled when the stream is next idle.
+  struct RecordSlab { void* d = nullptr; unsigned char* h = nullptr; size_t cap = 0, used = 0, shipped = 0; };
+  RecordSlab slab_;
+  std::vector<RecordSlab> inflight_slabs_;
+  void slab_reserve(size_t bytes, void** dev, unsigned char** pinned);
+  void slab_ship();
+  double prof_push_[4] = {0, 0, 0, 0};  // $FDB_PROFILE_PUSH
+  int64_t prof_push_n_ = 0;
   std::vector<RunSegment> runs_;
   bool runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>& Rs, const std::vector<int>& live) const;
   void runs_free();

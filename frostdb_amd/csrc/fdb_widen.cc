@@ -37,7 +37,55 @@ __attribute__((target("avx2"))) void widen16_avx2(const uint16_t* s, uint32_t* d
   for (; i < n; i++) d[i] = s[i];
 }
 
+// Copies into the pinned record slab (Plan::push, small host records): the destination is written once and next read by the DMA
+// engine, never by this CPU — streaming stores skip the read-for-ownership a cached store pays (a third of the copy's memory
+// traffic, which is what 8 chains copying at once run out of). `dst` 32-byte aligned (slab pieces are 256-byte aligned).
+__attribute__((target("avx2"))) void copy_stream_avx2(unsigned char* d, const unsigned char* s, size_t n) {
+  size_t i = 0;
+  for (; i + 128 <= n; i += 128) {
+    const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 32));
+    const __m256i c = _mm256_loadu_si256((const __m256i*)(s + i + 64)), e = _mm256_loadu_si256((const __m256i*)(s + i + 96));
+    _mm256_stream_si256((__m256i*)(d + i), a); _mm256_stream_si256((__m256i*)(d + i + 32), b);
+    _mm256_stream_si256((__m256i*)(d + i + 64), c); _mm256_stream_si256((__m256i*)(d + i + 96), e);
+  }
+  _mm_sfence();
+  if (i < n) std::memcpy(d + i, s + i, n - i);
+}
+// the same for uint32 dictionary indices, returning their maximum (the validation pass for free)
+__attribute__((target("avx2"))) uint32_t copy_stream_max_u32_avx2(uint32_t* d, const uint32_t* s, size_t n) {
+  __m256i mx = _mm256_setzero_si256();
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 8));
+    const __m256i c = _mm256_loadu_si256((const __m256i*)(s + i + 16)), e = _mm256_loadu_si256((const __m256i*)(s + i + 24));
+    _mm256_stream_si256((__m256i*)(d + i), a); _mm256_stream_si256((__m256i*)(d + i + 8), b);
+    _mm256_stream_si256((__m256i*)(d + i + 16), c); _mm256_stream_si256((__m256i*)(d + i + 24), e);
+    mx = _mm256_max_epu32(mx, _mm256_max_epu32(_mm256_max_epu32(a, b), _mm256_max_epu32(c, e)));
+  }
+  _mm_sfence();
+  uint32_t lanes[8];
+  _mm256_storeu_si256((__m256i*)lanes, mx);
+  uint32_t m = 0;
+  for (uint32_t v : lanes) m = v > m ? v : m;
+  for (; i < n; i++) { d[i] = s[i]; m = s[i] > m ? s[i] : m; }
+  return m;
+}
+
 }  // namespace
+
+void copy_stream(void* dst, const void* src, size_t n) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2 && n >= 4096 && ((uintptr_t)dst & 31u) == 0) return copy_stream_avx2((unsigned char*)dst, (const unsigned char*)src, n);
+  std::memcpy(dst, src, n);
+}
+
+uint32_t copy_stream_max_u32(uint32_t* dst, const uint32_t* src, size_t n) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2 && n >= 1024 && ((uintptr_t)dst & 31u) == 0) return copy_stream_max_u32_avx2(dst, src, n);
+  uint32_t m = 0;
+  for (size_t i = 0; i < n; i++) { dst[i] = src[i]; m = src[i] > m ? src[i] : m; }
+  return m;
+}
 
 void widen_indices(const void* src, int width, uint32_t* dst, size_t n) {
   static const bool avx2 = __builtin_cpu_supports("avx2");

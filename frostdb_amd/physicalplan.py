@@ -108,6 +108,8 @@ def lib() -> ctypes.CDLL:
     L.fdb_comm_rank.restype = i32
     L.fdb_comm_size.argtypes = [vp]
     L.fdb_comm_size.restype = i32
+    L.fdb_plan_push_many.argtypes = [vp, vp, vp, i32, P(i32)]
+    L.fdb_plan_push_many.restype = i32
     L.fdb_comm_transport_ranks.argtypes = [vp]
     L.fdb_comm_transport_ranks.restype = i32
     L.fdb_comm_last_error.argtypes = [vp]
@@ -333,6 +335,15 @@ class HashAggregatePlan:
         """Callback for a host record whose C-data export the caller keeps (fdb_plan_push only borrows the structs, so one export
         can be pushed any number of times — measurement loops keep pyarrow's export cost out of the timed region)."""
         self._check(lib().fdb_plan_push(self.handle, ctypes.addressof(ex.array), ctypes.addressof(ex.schema)))
+
+    def CallbackExportedMany(self, exported: Sequence["ExportedBatch"]) -> None:
+        """fdb_plan_push_many: the Callbacks of a run of host records in ONE call into the library (a thread that drives a chain this
+        way holds the interpreter lock once per run, not once per record)."""
+        n = len(exported)
+        arrs = (ctypes.c_void_p * n)(*[ctypes.addressof(e.array) for e in exported])
+        schs = (ctypes.c_void_p * n)(*[ctypes.addressof(e.schema) for e in exported])
+        done = ctypes.c_int32()
+        self._check(lib().fdb_plan_push_many(self.handle, arrs, schs, n, ctypes.byref(done)))
 
     def CallbackResident(self, records: Sequence[ResidentBatch]) -> None:
         """Callback for several HBM-resident records at once: one fused kernel launch over all of them."""

@@ -245,6 +245,10 @@ int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
  * and plain utf8 / binary / large_utf8 / large_binary "u" "z" "U" "Z" (filter leaves, group keys: encoded to key ids on the host
  * during this call, emitted with their input type). Columns the plan does not reference may have any type: they are not read. */
 int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema);
+/* `n` Callbacks in one call, in order (≙ a chain handing over the records it has collected: table.go:783-860 calls Callback once
+ * per record; a host behind cgo / JNI pays its boundary crossing once per call instead of once per record). Stops at the first
+ * record that fails and returns its error; *n_pushed (may be NULL) = records accepted. */
+int fdb_plan_push_many(fdb_plan* plan, struct ArrowArray* const* batches, struct ArrowSchema* const* schemas, int32_t n, int32_t* n_pushed);
 /* Same, for a record that is already resident in HBM. */
 int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch);
 /* Same, for `n` resident records at once (≙ the TableScan handing a chain every part it owns): one fused kernel

@@ -2438,3 +2438,62 @@ def test_float_compare_predicates_with_nan_rows_follow_ieee(pp, variant):
             plan.Close()
         got = run_gpu(pp, [rec], expr, [Count(Col("value"))], [])
         assert got["count(value)"] == [int(npsel.sum())]
+
+
+@pytest.mark.timeout(600)
+def test_eight_chains_pushing_small_host_records_concurrently(pp):
+    """The reference's shape of a scan: N chains, each on its own thread, each handed host records of the batch floor (1 024 rows,
+    table.go:780) — here 8 chains × 2 500 records, so every chain scans its queue several times (one launch per 1 024 queued
+    records, each staging its predicate tables and then 1 024 argument blocks). Every chain's own result and the merged one must
+    equal the numpy expectation. (Until round 4 the staging ring restarted — or was freed and re-allocated — in the middle of such a
+    launch's staging: with several chains in flight another thread's allocation landed on the freed block and the scan read
+    garbage tables.)"""
+    import threading
+
+    import bench
+    from frostdb_amd import synth
+    from frostdb_amd.logicalplan import to_desc
+    chains, rec_rows, per_chain = 8, 1024, 2_560_000
+    filt, aggs, groups, _ = bench.query(2)
+    desc = to_desc(filt, aggs, groups)
+    src = synth.prometheus_chunk(0, 0, chains * per_chain)
+    names = synth.PATHS + [None]
+
+    def expect(b):
+        s, c = bench.expected_cfg2(b)
+        return {names[i]: s[i] for i in range(len(names)) if c[i]}
+    exported = [[pp.ExportedBatch(src.slice(c * per_chain + o, min(rec_rows, per_chain - o))) for o in range(0, per_chain, rec_rows)] for c in range(chains)]
+    plans = [pp.HashAggregatePlan(filt, aggs, groups, desc=desc) for _ in range(chains)]
+    errors = []
+
+    def work(c):
+        try:
+            plans[c].CallbackExportedMany(exported[c])
+            plans[c].last_kernel()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+    try:
+        ts = [threading.Thread(target=work, args=(c,)) for c in range(chains)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+        for c in range(chains):
+            keys = plans[c].partial_keys().column(0).to_pylist()
+            vals = np.zeros(len(keys), dtype=np.float64)
+            plans[c].partial_state_into(0, vals.ctypes.data, vals.nbytes)
+            want, got = expect(src.slice(c * per_chain, per_chain)), dict(zip(keys, vals.tolist()))
+            assert set(got) == set(want), c
+            assert all(math.isclose(got[k], want[k], rel_tol=1e-9) for k in want), c
+        for p in plans[1:]:
+            plans[0].Merge(p)
+        res = plans[0].Finish()
+        got, want = dict(zip(res.column(0).to_pylist(), res.column(1).to_pylist())), expect(src)
+        assert set(got) == set(want) and all(math.isclose(got[k], want[k], rel_tol=1e-9) for k in want)
+    finally:
+        for p in plans:
+            p.Close()
+        for ex_list in exported:
+            for ex in ex_list:
+                ex.close()
