@@ -12,8 +12,9 @@ import bench
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000_000
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 br = 25_000_000
-recs = [pp.ResidentBatch(synth.prometheus_chunk(0, i, min(br, rows - i * br), row_base=i * br)) for i in range((rows + br - 1) // br)]
-filt, aggs, groups, _ = bench.query(2)
+recs = [pp.ResidentBatch(synth.prometheus_chunk(0, i, min(br, rows - i * br), row_base=i * br, cfg3=os.environ.get("CFG", "2") == "3")) for i in range((rows + br - 1) // br)]
+cfg = int(os.environ.get("CFG", "2"))
+filt, aggs, groups, _ = bench.query(cfg)
 desc = to_desc(filt, aggs, groups)
 
 
