@@ -794,8 +794,25 @@ static void emit_filter(const std::vector<ExprNode>& nodes, int idx, const Devic
       a.code[a.n_code++] = (uint8_t)li;
       return;
     }
+    const int leaves0 = a.n_leaves, code0 = a.n_code;
+    const size_t luts0 = R->luts.size();
     emit_filter(nodes, e.left, b, R, depth, max_depth);
-    emit_filter(nodes, e.right, b, R, depth + 1, max_depth);
+    try {
+      emit_filter(nodes, e.right, b, R, depth + 1, max_depth);
+    } catch (const Error& err) {
+      // The reference would only notice a right side it cannot evaluate if the left side selected a row of this record
+      // (AndExpr.Eval returns the empty left bitmap without touching the right side, filter.go:178-180; filter_test.go:66-82).
+      if (e.op != FDB_OP_AND || err.code != FDB_ERR_UNSUPPORTED || !R->count_selected || b.rows == 0 || R->count_selected(e.left) != 0) throw;
+      // nothing selected on the left: for this record the whole AND is the empty selection
+      a.n_leaves = leaves0; a.n_code = code0;
+      R->luts.resize(luts0);
+      if (a.n_leaves >= FDB_MAX_LEAVES || a.n_code >= FDB_MAX_CODE) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too large");
+      FdbLeaf& L = a.leaves[a.n_leaves];
+      std::memset(&L, 0, sizeof(L));
+      L.lut_lds = FDB_NO_LDS; L.slot = -1; L.kind = FDB_LEAF_CONST; L.op = 0;
+      a.code[a.n_code++] = (uint8_t)a.n_leaves++;
+      return;
+    }
     if (a.n_code >= FDB_MAX_CODE) throw Error(FDB_ERR_UNSUPPORTED, "filter expression too large");
     a.code[a.n_code++] = e.op == FDB_OP_AND ? FDB_CODE_AND : FDB_CODE_OR;
     return;
@@ -1123,6 +1140,7 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
   a.n_rows = b.rows;
   int max_depth = 0;
   R.truths = &truth_cache_;
+  R.count_selected = [this, &b](int n) { return count_subtree(b, n); };
   if (filter_root_ >= 0) emit_filter(filter_, filter_root_, b, &R, 0, &max_depth);
 
   // group columns: every field matched by a matcher, in the record's field order (aggregate.go:286-303)
@@ -2076,12 +2094,44 @@ struct DevBuf {  // scratch from the context's caching allocator; the plan's str
 // ≙ filter() (filter.go:276-323): the reference turns the predicate's bitmap into index ranges, slices every column per range
 // and concatenates the slices. Here ONE kernel pass evaluates the predicate, gives every selected row its output position
 // (decoupled look-back over per-tile totals) and writes the compacted columns — see fdb_launch_compact.
+// Rows of `b` the filter sub-tree rooted at `node` selects (one launch of the interpreting flags kernel + a wait): only used where
+// the reference's lazy AND decides whether an error exists at all (emit_filter).
+int64_t Plan::count_subtree(const DeviceBatch& b, int node) {
+  if (b.rows == 0) return 0;
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  slab_ship();  // (a small pushed record may still sit in the pinned slab: its bytes go first)
+  Resolved R;
+  std::memset(&R.args, 0, sizeof(R.args));
+  R.args.n_rows = b.rows;
+  int max_depth = 0;
+  R.truths = &truth_cache_;
+  R.count_selected = [this, &b](int n) { return count_subtree(b, n); };
+  emit_filter(filter_, node, b, &R, 0, &max_depth);
+  FdbScanArgs& a = R.args;
+  size_t lds_off = 0;
+  unsigned char* d_blob = R.blob.bytes.empty() ? nullptr : (unsigned char*)upload(R.blob.bytes.data(), R.blob.bytes.size());
+  for (const PendingLut& p : R.luts) {
+    const bool in_lds = p.len_bytes <= 16384 && lds_off + p.len_bytes <= 32768;
+    uint32_t lds = FDB_NO_LDS;
+    if (in_lds) { lds = (uint32_t)lds_off; lds_off = align_up(lds_off + p.len_bytes, 16); }
+    a.leaves[p.index].lut = d_blob + p.blob_off;
+    a.leaves[p.index].lut_lds = lds;
+  }
+  a.lds_lut_bytes = (uint32_t)align_up(lds_off, 16);
+  ctx_->flush_staging();
+  b.note_reader(stream_);
+  uint8_t* masks = nullptr;
+  uint32_t* offs = nullptr;
+  return run_flags(a, &masks, &offs);
+}
+
 void Plan::resolve_filter_only(const DeviceBatch& b, Resolved* Rp) {
   Resolved& R = *Rp;
   std::memset(&R.args, 0, sizeof(R.args));
   R.args.n_rows = b.rows;
   int max_depth = 0;
   R.truths = &truth_cache_;
+  R.count_selected = [this, &b](int n) { return count_subtree(b, n); };
   emit_filter(filter_, filter_root_, b, &R, 0, &max_depth);
   FdbScanArgs& a = R.args;
   size_t lds_off = 0;
@@ -2302,6 +2352,7 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
       R.args.n_rows = in[live[k]]->rows;
       int max_depth = 0;
       R.truths = &truth_cache_;
+      R.count_selected = [this, rec = in[live[k]]](int n) { return count_subtree(*rec, n); };
       emit_filter(filter_, filter_root_, *in[live[k]], &R, 0, &max_depth);
       size_t found = reps.size();
       for (size_t r = 0; r < reps.size(); r++) {

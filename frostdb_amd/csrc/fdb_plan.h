@@ -286,6 +286,7 @@ class Plan {
   int resolve_projection(const Projection& p, const DeviceBatch& b, Resolved* R);
   void resolve_batch(const DeviceBatch& b, Resolved* R, std::vector<int>* batch_gcols);
   void resolve_filter_only(const DeviceBatch& b, Resolved* R);  // predicate program + LUTs (staged), nothing else
+  int64_t count_subtree(const DeviceBatch& b, int node);        // rows of `b` selected by the filter sub-tree rooted at `node` (lazy AND)
   int64_t run_flags(const FdbScanArgs& a, uint8_t** d_masks, uint32_t** d_offsets);  // selection bitmap + tile offsets; returns the number selected
   void ensure_layout(const std::vector<uint32_t>& new_caps);
   void collect_timing();

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -59,6 +60,10 @@ struct Plan::Resolved {
   int agg_col[FDB_MAX_AGGS];
   int expr_col[FDB_MAX_EXPR_NODES];       // batch column behind each expression column node
   std::vector<GroupRes> groups;           // group-by columns of this record (plan-level index, record column, kind, key-id LUT)
+  // AndExpr.Eval is lazy (filter.go:172-190): when the left side of an AND selects no row of the record the right side is not
+  // evaluated — so a right side that cannot be evaluated on this record (an operator its column type does not support) only is
+  // an error if the left side selects something. Set by the plan: rows of this record the sub-tree rooted at `node` selects.
+  std::function<int64_t(int node)> count_selected;
   Resolved() {
     for (int& v : leaf_col) v = -1;
     for (int& v : gcol_col) v = -1;

@@ -2497,3 +2497,60 @@ def test_eight_chains_pushing_small_host_records_concurrently(pp):
         for ex_list in exported:
             for ex in ex_list:
                 ex.close()
+
+
+def test_and_is_lazy_like_the_reference(pp, variant):
+    """AndExpr.Eval (filter.go:172-190; filter_test.go:66-82 TestAndExprShortCircuits): when the left side of an AND selects no row of a
+    record, the right side is not evaluated — a right side that could not be evaluated (here `<` on a dictionary column,
+    binaryscalarexpr.go:106-108) is then no error for that record. Where the left side does select rows, the error is the reference's."""
+    rng = np.random.default_rng(5)
+    rec = make_prometheus_batch(rng, 30_000, n_path=20)
+    bad = BinaryExpr(Col("labels.path"), 3, Literal("x"))  # OP_LT on a dictionary column: ErrUnsupportedBinaryOperation
+    from oracle import OraclePlan
+    for left, selects in ((Col("labels.code") == "no such code", False), (Col("value") < -1.0, False), (Col("labels.code") == "200", True)):
+        filt = And(left, bad)
+        o = OraclePlan(filt)
+        if selects:
+            with pytest.raises(Exception):
+                o.filter(rec)
+        else:
+            out, idx = o.filter(rec)
+            assert out is None and list(idx) == []
+        o.close()
+        for resident in (False, True):
+            plan = pp.HashAggregatePlan(filt, [Count(Col("value"))], [Col("labels.path")])
+            rb = pp.ResidentBatch(rec) if resident else None
+            try:
+                if selects:
+                    with pytest.raises(pp.FdbError) as e:
+                        plan.Callback(rb if resident else rec)
+                        plan.Finish()
+                    assert e.value.code == pp.FDB_ERR_UNSUPPORTED
+                else:
+                    plan.Callback(rb if resident else rec)
+                    assert plan.Finish().num_rows == 0
+            finally:
+                plan.Close()
+                if rb is not None:
+                    rb.close()
+        fp = pp.HashAggregatePlan(filt)
+        try:
+            if selects:
+                with pytest.raises(pp.FdbError):
+                    fp.Select(rec)
+            else:
+                assert list(fp.Select(rec)) == []
+        finally:
+            fp.Close()
+    # a record where the left side selects nothing next to one where it selects something: only the second raises
+    quiet = rec.set_column(rec.schema.get_field_index("value"), "value", pa.array(np.full(rec.num_rows, 5.0)))
+    filt = And(Col("value") > 100.0, bad)
+    plan = pp.HashAggregatePlan(filt, [Count(Col("value"))], [Col("labels.path")])
+    try:
+        plan.Callback(quiet)
+        assert plan.num_groups() == 0
+        with pytest.raises(pp.FdbError):
+            plan.Callback(rec)
+            plan.Finish()
+    finally:
+        plan.Close()
