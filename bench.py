@@ -635,7 +635,7 @@ def measure_host_records(wl, steps=3):
     return out
 
 
-def measure_host_records_chains(wl, rows_per_chain=4_194_304):
+def measure_host_records_chains(wl, rows_per_chain=2_097_152):
     """What the Go shim really drives: N chains pushing HOST records concurrently — one plan per chain on
     its own stream, one thread per chain like one goroutine per chain (physicalplan.go:337-347), records of 1 024 rows (the
     reference's batch floor, table.go:780), 8 192 and 65 536 rows, every chain its own rows. Wall time from the first Callback to
@@ -648,7 +648,7 @@ def measure_host_records_chains(wl, rows_per_chain=4_194_304):
     total_src = sum(b.num_rows for b in src)
     out = {"bound": "pcie / host", "measured_h2d_GBps": h2d, "bytes_per_row_copied": 16.25, "rows_per_chain": rows_per_chain}
     for chains in (1, 8, 32):
-        per_chain = min(rows_per_chain, total_src // chains // 65536 * 65536)
+        per_chain = min(rows_per_chain if chains <= 8 else rows_per_chain // 2, total_src // chains // 65536 * 65536)
         for rec_rows in (1024, 8192, 65536):
             # chain c owns rows [c × per_chain, (c + 1) × per_chain) of the host batches laid end to end
             exported, expected = [], None
@@ -661,8 +661,6 @@ def measure_host_records_chains(wl, rows_per_chain=4_194_304):
                         recs.append(b.slice(o - base, min(rec_rows, a1 - o)))
                     base += b.num_rows
                 exported.append([pp.ExportedBatch(r) for r in recs])
-            for b_i, b in enumerate(src):
-                pass
             # numpy expectation over the rows the chains own
             need = chains * per_chain
             base = 0

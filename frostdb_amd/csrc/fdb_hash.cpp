@@ -261,6 +261,8 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       jit_fn = jit_hash_get(shape);
       if (jit_fn != nullptr)
         jit_grid = grid_override > 0 ? grid_override : (fdb_scan_default_grid(device_) / 2) * std::min(4, jit_blocks_per_cu(jit_fn, 256, a.lds_lut_bytes + run_lds));
+      if (std::getenv("FDB_JIT_DEBUG")) std::fprintf(stderr, "[frostdb_amd] hash kernel%s: %d workgroups (%d fit a CU with %zu B of LDS)\n", runs ? " (runs)" : "", jit_grid,
+                                                   jit_fn ? jit_blocks_per_cu(jit_fn, 256, a.lds_lut_bytes + run_lds) : 0, (size_t)a.lds_lut_bytes + run_lds);
     }
     if (runs && jit_fn == nullptr) {  // no specialised kernel after all (hiprtc failed): what was collected goes into the table, this record and the rest take the probing path
       runs_to_table();
@@ -278,15 +280,15 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       seg.n_entries = n_tiles * 4;
       const int64_t n_chunks = b.rows / (FDB_RUN_CHUNK - 256) + launch_grid * 4 + 2;  // a wave abandons < 256 slots when it changes chunks and keeps one chunk open
       seg.capacity = n_chunks * FDB_RUN_CHUNK;
-      const size_t tuples_bytes = align_up_sz((size_t)seg.capacity * FDB_RUN_TUPLE_BYTES, 256), arr_bytes = align_up_sz((size_t)seg.capacity * 8, 256);
+      const size_t tuples_bytes = align_up_sz((size_t)seg.capacity * FDB_RUN_BYTES, 256);
       const size_t dir_bytes = align_up_sz((size_t)seg.n_entries * 8, 256);
-      seg.block = ctx_->dev_alloc(tuples_bytes + 2 * arr_bytes + dir_bytes + 256);
+      seg.block = ctx_->dev_alloc(tuples_bytes + dir_bytes + 256);
       unsigned char* base = (unsigned char*)seg.block;
-      seg.tuples = base; seg.cnt = (unsigned long long*)(base + tuples_bytes); seg.acc = (unsigned long long*)(base + tuples_bytes + arr_bytes);
-      seg.dir = (uint32_t*)(base + tuples_bytes + 2 * arr_bytes); seg.cursor = (uint32_t*)(base + tuples_bytes + 2 * arr_bytes + dir_bytes);
+      seg.tuples = base;
+      seg.dir = (uint32_t*)(base + tuples_bytes); seg.cursor = (uint32_t*)(base + tuples_bytes + dir_bytes);
       runs_.push_back(seg);
       hip_check(hipMemsetAsync(seg.dir, 0, dir_bytes + 256, stream_), "hipMemsetAsync(run directory)");
-      h.runs.tuples = seg.tuples; h.runs.cnt = seg.cnt; h.runs.acc = seg.acc; h.runs.dir = seg.dir; h.runs.chunk_cursor = seg.cursor;
+      h.runs.tuples = seg.tuples; h.runs.dir = seg.dir; h.runs.chunk_cursor = seg.cursor;
       h.table = nullptr; h.keys = nullptr; h.n_groups = nullptr; h.mask = 0;
       h.row_begin = 0; h.row_end = b.rows;
       hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1055,7 +1057,7 @@ bool Plan::runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned
   int64_t n_entries = 0;
   v->segs.n_segs = (int32_t)runs_.size();
   for (size_t k = 0; k < runs_.size(); k++) {
-    v->segs.tuples[k] = runs_[k].tuples; v->segs.cnt[k] = runs_[k].cnt; v->segs.acc[k] = runs_[k].acc;
+    v->segs.tuples[k] = runs_[k].tuples;
     v->segs.first_entry[k] = (uint32_t)n_entries;
     n_entries += runs_[k].n_entries;
   }

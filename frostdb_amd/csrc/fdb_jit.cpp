@@ -607,15 +607,14 @@ struct HashGen {
   std::string source() {
     const int BLK = 256, TILE = BLK * 4, GROUP = 8;
     o << "#define FDB_DEVICE_HELPERS 1\n#include \"fdb_kernels.h\"\n" << kPreamble << kHashPreamble;
-    // The runs kernel wants 149 VGPRs (3 waves per SIMD); capped at 128 it spills 10 of them and runs 4 workgroups per CU — measured
-    // on cfg 5 sorted (round 4): 2.62 ms per 100 M rows against 2.79 uncapped (66 % against 62 % of the HBM peak).
-    // ($FDB_RUNS_WAVES_PER_EU: tuning aid, 0 = no cap)
-    const int waves_cap = !s.runs ? 0 : std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::atoi(std::getenv("FDB_RUNS_WAVES_PER_EU")) : 4;
+    // The runs kernel wants ≈149 VGPRs = 3 waves per SIMD, which is also what its LDS stage (4 × 12 KiB per workgroup) lets a CU hold.
+    // ($FDB_RUNS_WAVES_PER_EU: tuning aid — caps the registers so that that many waves fit a SIMD; 0 / unset = no cap)
+    const int waves_cap = s.runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::atoi(std::getenv("FDB_RUNS_WAVES_PER_EU")) : 0;
     o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") ";
     if (waves_cap > 0) o << "__attribute__((amdgpu_waves_per_eu(" << waves_cap << ", " << waves_cap << "))) ";
     o << "void fdb_hash_kernel(const FdbHashArgs h) {\n";
     o << "  extern __shared__ __align__(16) unsigned char smem[];\n  __shared__ unsigned int s_new;\n";
-    if (s.runs) o << "  __shared__ unsigned int s_runs[8];  // per wave: first run of its open chunk, runs used in it\n  if (threadIdx.x < 8) s_runs[threadIdx.x] = (threadIdx.x & 1u) ? " << FDB_RUN_CHUNK << "u : 0u;\n";
+    if (s.runs) o << "  __shared__ unsigned int s_runs[16];  // per wave: first run of its open chunk, runs used in it, first of those still waiting in LDS\n  if (threadIdx.x < 16) s_runs[threadIdx.x] = (threadIdx.x & 3u) == 0u ? 0u : " << FDB_RUN_CHUNK << "u;\n";
     o << "  const FdbScanArgs& a = h.base;\n  // descriptors are read through the constant address space: scalar loads, no vector registers\n  const __attribute__((address_space(4))) FdbHashCol* hc = (const __attribute__((address_space(4))) FdbHashCol*)h.hcols;\n  const uint32_t tid = threadIdx.x;\n  if (tid == 0) s_new = 0;\n";
     for (size_t l = 0; l < s.leaves.size(); l++) {
       o << "  const long long K_lit" << l << " = a.leaves[" << l << "].lit; const uint32_t K_len" << l << " = a.leaves[" << l << "].lut_len, K_lds" << l << " = a.leaves[" << l
@@ -739,6 +738,7 @@ struct HashGen {
     // into it — count and every aggregate — and only the LAST row of such a run goes to the table: one probe + one set of atomics
     // per run instead of per row. Costs a few compares on unsorted input.
     const bool combine = !(s.ablate & 2) || s.runs;
+    const int runs_ablate = s.runs && std::getenv("FDB_RUNS_ABLATE") ? std::atoi(std::getenv("FDB_RUNS_ABLATE")) : 0;  // (tuning aid: 1 no stores, 2 no folding across lanes; results are wrong)
     if (combine) {
       for (int k = 0; k < 4; k++) o << "    unsigned long long cnt_" << k << " = 1ull;\n";
       for (size_t j = 0; j < s.aggs.size(); j++) {
@@ -781,6 +781,7 @@ struct HashGen {
       };
       // (lanes that left the tile early — rows past the end, nothing selected by the filter — do not take part: what a shuffle
       // reads from them is not data, so their bits in `act` gate every value that comes from another lane)
+      if (runs_ablate & 2) o << "    if (false)\n";
       o << "    {\n      const int wl = (int)(tid & 63u);\n      const bool has = sel != 0u;\n      const unsigned long long act = __ballot(1);\n";
       o << "      const int kf = has ? __builtin_ctz(sel) : 0, kl = has ? 31 - __builtin_clz(sel) : 0;\n";
       o << "      const unsigned long long fa = " << pick("h1", "kf") << ", fb = " << pick("h2", "kf") << ";\n";
@@ -834,26 +835,28 @@ struct HashGen {
       o << "    {\n      const unsigned long long act2 = __ballot(1);\n      const int wl2 = (int)(tid & 63u), wv = (int)(tid >> 6), first2 = __builtin_ctzll(act2);\n";
       o << "      const unsigned long long b0 = __ballot((sel & 1u) != 0u), b1 = __ballot((sel & 2u) != 0u), b2 = __ballot((sel & 4u) != 0u), b3 = __ballot((sel & 8u) != 0u);\n";
       o << "      const uint32_t n_w = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));\n";
-      o << "      if (n_w != 0u) {\n        const unsigned long long lt = (1ull << wl2) - 1ull;\n";
+      o << "      if (n_w != 0u" << ((runs_ablate & 1) ? " && h.row_begin == 12345" : "") << ") {\n        const unsigned long long lt = (1ull << wl2) - 1ull;\n";
       o << "        const uint32_t before = (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));\n";
-      o << "        uint32_t rb = s_runs[wv * 2], rp = s_runs[wv * 2 + 1];\n";
-      o << "        if (rp + n_w > " << FDB_RUN_CHUNK << "u) {\n          uint32_t nc = 0u;\n          if (wl2 == first2) nc = atomicAdd(h.runs.chunk_cursor, 1u);\n          rb = (uint32_t)__shfl((int)nc, first2, 64) * " << FDB_RUN_CHUNK
-        << "u; rp = 0u;\n        }\n";
-      o << "        const uint32_t base = rb + rp;\n        __builtin_amdgcn_wave_barrier();\n";
-      o << "        if (wl2 == first2) { s_runs[wv * 2] = rb; s_runs[wv * 2 + 1] = rp + n_w; *reinterpret_cast<uint2*>(h.runs.dir + ((size_t)tile * 4 + wv) * 2) = make_uint2(base, n_w); }\n";
+      // The wave's runs wait in its LDS stage (FDB_RUN_STAGE of them) and leave as one contiguous copy when the stage is full or the
+      // chunk changes: a store per tile made the next tile's loads wait for its acknowledgement.
+      o << "        uint32_t rb = s_runs[wv * 4], rp = s_runs[wv * 4 + 1], ps = s_runs[wv * 4 + 2];\n";
       o << "        u32x4* stage = reinterpret_cast<u32x4*>(smem + a.lds_lut_bytes + (size_t)wv * " << FDB_RUN_WAVE_LDS << ");\n";
-      for (int k = 0; k < 4; k++) {
-        o << "        if (sel & " << (1 << k) << "u) {\n          const uint32_t at = before + (uint32_t)__builtin_popcount(sel & " << ((1 << k) - 1) << "u);\n";
-        o << "          h.runs.cnt[base + at] = cnt_" << k << ";\n";
-        if (has_val) o << "          h.runs.acc[base + at] = " << (f64v ? "(unsigned long long)__double_as_longlong(v0_" + std::to_string(k) + ")" : "(unsigned long long)v0_" + std::to_string(k)) << ";\n";
-        else o << "          h.runs.acc[base + at] = 0ull;\n";
-        o << "          stage[at * 2] = ta_" << k << "; stage[at * 2 + 1] = tb_" << k << ";\n        }\n";
-      }
-      o << "        __builtin_amdgcn_wave_barrier();\n";
-      o << "        u32x4* out = reinterpret_cast<u32x4*>(h.runs.tuples) + (size_t)base * 2;\n";
-      // (only the lanes still in the tile copy: lanes past the record's end or without a selected row left it earlier)
       o << "        const uint32_t n_act = (uint32_t)__popcll(act2), my_act = (uint32_t)__popcll(act2 & lt);\n";
-      o << "        for (uint32_t q = my_act; q < n_w * 2u; q += n_act) out[q] = stage[q];\n";
+      o << "        const bool sw = rp + n_w > " << FDB_RUN_CHUNK << "u;\n";
+      o << "        if (sw || (rp - ps) + n_w > " << FDB_RUN_STAGE << "u) {\n";
+      o << "          u32x4* out = reinterpret_cast<u32x4*>(h.runs.tuples) + (size_t)(rb + ps) * 3;\n";
+      o << "          for (uint32_t q = my_act; q < (rp - ps) * 3u; q += n_act) out[q] = stage[q];\n";
+      o << "          __builtin_amdgcn_wave_barrier();\n          ps = rp;\n        }\n";
+      o << "        if (sw) {\n          uint32_t nc = 0u;\n          if (wl2 == first2) nc = atomicAdd(h.runs.chunk_cursor, 1u);\n          rb = (uint32_t)__shfl((int)nc, first2, 64) * " << FDB_RUN_CHUNK
+        << "u; rp = 0u; ps = 0u;\n        }\n";
+      o << "        const uint32_t base = rb + rp, sbase = rp - ps;\n        __builtin_amdgcn_wave_barrier();\n";
+      o << "        if (wl2 == first2) { s_runs[wv * 4] = rb; s_runs[wv * 4 + 1] = rp + n_w; s_runs[wv * 4 + 2] = ps; *reinterpret_cast<uint2*>(h.runs.dir + ((size_t)tile * 4 + wv) * 2) = make_uint2(base, n_w); }\n";
+      for (int k = 0; k < 4; k++) {
+        o << "        if (sel & " << (1 << k) << "u) {\n          const uint32_t at = sbase + before + (uint32_t)__builtin_popcount(sel & " << ((1 << k) - 1) << "u);\n";
+        o << "          stage[at * 3] = ta_" << k << "; stage[at * 3 + 1] = tb_" << k << ";\n";
+        o << "          *reinterpret_cast<u64x2*>(stage + at * 3 + 2) = u64x2{cnt_" << k << ", "
+          << (has_val ? (f64v ? "(unsigned long long)__double_as_longlong(v0_" + std::to_string(k) + ")" : "(unsigned long long)v0_" + std::to_string(k)) : std::string("0ull")) << "};\n        }\n";
+      }
       o << "        __builtin_amdgcn_wave_barrier();\n      }\n    }\n    continue;\n";
     }
     // Probe: the home entries of the 4 rows are requested together (one memory round trip for the common case "group exists
@@ -976,7 +979,16 @@ struct HashGen {
       o << "        asm volatile(\"\" ::: \"memory\");\n      }\n";
     }
     o << "    }\n";
-    o << "  }\n  __syncthreads();\n  if (tid == 0 && s_new != 0) atomicAdd(h.n_groups, (unsigned long long)s_new);\n}\n";
+    o << "  }\n";
+    if (s.runs) {
+      o << "  {  // the runs that still wait in the waves' stages\n    const int wv = (int)(tid >> 6), wl2 = (int)(tid & 63u);\n    __builtin_amdgcn_wave_barrier();\n";
+      o << "    const uint32_t rb = s_runs[wv * 4], rp = s_runs[wv * 4 + 1], ps = s_runs[wv * 4 + 2];\n";
+      o << "    if (rp != " << FDB_RUN_CHUNK << "u || ps != " << FDB_RUN_CHUNK << "u) {\n";
+      o << "      const u32x4* stage = reinterpret_cast<const u32x4*>(smem + a.lds_lut_bytes + (size_t)wv * " << FDB_RUN_WAVE_LDS << ");\n";
+      o << "      u32x4* out = reinterpret_cast<u32x4*>(h.runs.tuples) + (size_t)(rb + ps) * 3;\n";
+      o << "      for (uint32_t q = (uint32_t)wl2; q < (rp - ps) * 3u; q += 64u) out[q] = stage[q];\n    }\n  }\n";
+    }
+    o << "  __syncthreads();\n  if (tid == 0 && s_new != 0) atomicAdd(h.n_groups, (unsigned long long)s_new);\n}\n";
     return o.str();
   }
 };
@@ -1135,7 +1147,8 @@ hipFunction_t jit_get(const JitShape& shape) {
 
 std::string JitHashShape::key() const {
   std::ostringstream k;
-  k << "a" << ablate << "c" << need_count << (runs ? "R" : "") << (runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::getenv("FDB_RUNS_WAVES_PER_EU") : "") << "|";
+  k << "a" << ablate << "c" << need_count << (runs ? "R" : "") << (runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::getenv("FDB_RUNS_WAVES_PER_EU") : "")
+    << (runs && std::getenv("FDB_RUNS_ABLATE") ? std::string("x") + std::getenv("FDB_RUNS_ABLATE") : std::string()) << "|";
   for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
   k << '|';
   for (size_t l = 0; l < leaves.size(); l++) {

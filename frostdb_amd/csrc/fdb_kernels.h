@@ -192,11 +192,12 @@ static inline unsigned long long fdb_fp_k2(int gi) {
 // the directory entry of its (tile, wave). Runs cut by a wave / record boundary and keys that come back later are merged at Finish.
 #define FDB_RUN_CHUNK 4096
 #define FDB_RUN_TUPLE_BYTES 32
-#define FDB_RUN_WAVE_LDS (256 * FDB_RUN_TUPLE_BYTES)  // staging per wave: its ≤ 256 runs leave as one contiguous copy
+#define FDB_RUN_BYTES 48                              // one run: [key ids: 32 bytes | rows of the run: 8 | its aggregate, the accumulator's own representation: 8]
+#define FDB_RUN_STAGE 256                             // runs a wave can hold back in LDS (≥ the runs of one tile of 256 rows)
+#define FDB_RUN_WAVE_LDS (FDB_RUN_STAGE * FDB_RUN_BYTES)  // a wave's runs wait in LDS over several tiles and leave as ONE contiguous copy: stores issued every tile
+                                                      // made the next tile's loads wait for their acknowledgement (loads and stores share a counter): 3.06 → 2.3 ms per 100 M rows
 struct FdbRunsOut {
-  unsigned char* tuples;         // [capacity][FDB_RUN_TUPLE_BYTES]; nullptr: not a runs launch
-  unsigned long long* cnt;       // [capacity] rows of the run
-  unsigned long long* acc;       // [capacity] its aggregate (the accumulator's own representation)
+  unsigned char* tuples;         // [capacity][FDB_RUN_BYTES]; nullptr: not a runs launch
   unsigned int* dir;             // [4 × tiles of the launch][2]
   unsigned int* chunk_cursor;    // next free chunk
 };
@@ -331,9 +332,7 @@ hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t strea
 // a segment directory entries in order, within an entry the runs in order — i.e. row order of the scan.
 #define FDB_MAX_RUN_SEGMENTS 64
 struct FdbRunSegs {
-  const unsigned char* tuples[FDB_MAX_RUN_SEGMENTS];
-  const unsigned long long* cnt[FDB_MAX_RUN_SEGMENTS];
-  const unsigned long long* acc[FDB_MAX_RUN_SEGMENTS];
+  const unsigned char* tuples[FDB_MAX_RUN_SEGMENTS];   // [run][FDB_RUN_BYTES]
   uint32_t first_entry[FDB_MAX_RUN_SEGMENTS + 1];  // directory entries of segment s = [first_entry[s], first_entry[s + 1]) of the concatenated directory
   int32_t n_segs;
 };

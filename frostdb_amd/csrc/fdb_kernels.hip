@@ -2440,11 +2440,11 @@ __global__ __launch_bounds__(256) void runs_flags_kernel(const unsigned long lon
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_runs) return;
   const unsigned long long p = phys[i];
-  const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[p >> 32] + (p & 0xFFFFFFFFull) * FDB_RUN_TUPLE_BYTES);
+  const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[p >> 32] + (p & 0xFFFFFFFFull) * FDB_RUN_BYTES);
   const run_u32x4 a0 = t[0], a1 = t[1];
   if (i == 0) { flags[0] = 1u; return; }
   const unsigned long long q = phys[i - 1];
-  const run_u32x4* u = reinterpret_cast<const run_u32x4*>(segs.tuples[q >> 32] + (q & 0xFFFFFFFFull) * FDB_RUN_TUPLE_BYTES);
+  const run_u32x4* u = reinterpret_cast<const run_u32x4*>(segs.tuples[q >> 32] + (q & 0xFFFFFFFFull) * FDB_RUN_BYTES);
   const run_u32x4 b0 = u[0], b1 = u[1];
   const bool same = a0.x == b0.x && a0.y == b0.y && a0.z == b0.z && a0.w == b0.w && a1.x == b1.x && a1.y == b1.y && a1.z == b1.z && a1.w == b1.w;
   flags[i] = same ? 0u : 1u;
@@ -2482,9 +2482,9 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
     const unsigned long long p = a.phys[i];
     const int seg = (int)(p >> 32);
     const uint64_t at = p & 0xFFFFFFFFull;
-    const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[seg] + at * FDB_RUN_TUPLE_BYTES);
+    const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[seg] + at * FDB_RUN_BYTES);
     t0 = t[0]; t1 = t[1];
-    cnt = segs.cnt[seg][at]; acc = segs.acc[seg][at];
+    { const u64x2 ca = *reinterpret_cast<const u64x2*>(t + 2); cnt = ca.x; acc = ca.y; }
     if (a.flags != nullptr) {
       fl = a.flags[i];
       g = a.out_idx[i] - (fl ? 0u : 1u);

@@ -305,8 +305,8 @@ class Plan {
   // record boundaries cut and, if the keys came in order, emits them as they are; anything else that wants the plan's state
   // (a merge, an export, the raw accessors, input that was NOT ordered) first inserts the runs into the hash table.
   struct RunSegment {
-    void* block = nullptr;  // one device allocation: [tuples | cnt | acc | directory | chunk cursor]
-    unsigned char* tuples = nullptr; unsigned long long* cnt = nullptr; unsigned long long* acc = nullptr; uint32_t* dir = nullptr; uint32_t* cursor = nullptr;
+    void* block = nullptr;  // one device allocation: [runs of FDB_RUN_BYTES | directory | chunk cursor]
+    unsigned char* tuples = nullptr; uint32_t* dir = nullptr; uint32_t* cursor = nullptr;
     int64_t n_entries = 0, capacity = 0;
   };
   struct RunsView {  // the runs in logical (row) order, prepared for Finish
