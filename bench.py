@@ -46,7 +46,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HEADLINE_ROWS = 1_000_000_000
-PROFILE_ROUNDS = ("round3", "round2", "round1")  # newest committed PMC pass of the same command first
+PROFILE_ROUNDS = ("round4", "round3", "round2", "round1")  # newest committed PMC pass of the same command first
 
 
 def parse_args(argv=None):

@@ -940,7 +940,8 @@ __global__ void hash_compact_kernel(const unsigned long long* table, const uint3
 //   1. hash_gather_rows_kernel: one wave per 64-slot chunk (grid-stride). The occupied entries' key tuples are fetched
 //      cooperatively — lane ↦ word of the chunk's tuples laid end to end, 16 loads in flight per lane — and stored as ROWS of a
 //      dense row-major scratch array in slot order (one contiguous run per chunk); count and accumulators go to their columns.
-//   2. hash_rows_to_columns_kernel: one wave per group of 64 OUTPUT rows: the group's rows (one contiguous read) are parked in
+//   2. group_rows_to_columns_kernel (the column pass of EVERY big Finish: it reads dense key rows, whoever wrote them — the table's
+//      gather above or the run store's runs_expand_kernel): one wave per group of 64 OUTPUT rows: the group's rows (one contiguous read) are parked in
 //      the wave's LDS tile [64][key_words | 1] (odd pitch: conflict-free when lanes = rows), then each column leaves as one
 //      aligned 64 / 128 / 256 / 512-byte store (uint8 / uint16 / uint32 indices, 8-byte keys) plus one ballot = one 8-byte word of
 //      its validity bitmap.
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(256) void hash_gather_rows_kernel(const unsigned lo
   }
 }
 
-__global__ __launch_bounds__(256) void hash_rows_to_columns_kernel(const uint32_t* __restrict__ dense_keys, const FdbHashColumnsArgs a) {
+__global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32_t* __restrict__ dense_keys, const FdbHashColumnsArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const __attribute__((address_space(4))) BytePtr* out_key = (const __attribute__((address_space(4))) BytePtr*)a.out_key;
   const __attribute__((address_space(4))) U64Ptr* out_bits = (const __attribute__((address_space(4))) U64Ptr*)a.out_bits;
@@ -2329,12 +2330,12 @@ hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int d
   const size_t lds = (size_t)4 * 64 * (size_t)(args.key_words | 1) * 4;  // one tile per wave
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   if (lds > 48 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hash_rows_to_columns_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&group_rows_to_columns_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
   }
   const int64_t cus = fdb_scan_default_grid(device) / 2;
   const int64_t n_groups = (int64_t)((end - args.row_begin + 63) / 64);
-  hipLaunchKernelGGL(hash_rows_to_columns_kernel, dim3((unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * 16)), dim3(256), lds, stream, (const uint32_t*)args.dense_keys, args);
+  hipLaunchKernelGGL(group_rows_to_columns_kernel, dim3((unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * 16)), dim3(256), lds, stream, (const uint32_t*)args.dense_keys, args);
   return hipGetLastError();
 }
 
