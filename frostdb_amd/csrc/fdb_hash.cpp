@@ -1034,6 +1034,7 @@ bool Plan::runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>
     if (R.groups.size() != gcols_.size()) return false;
     for (size_t g = 0; g < R.groups.size(); g++) if (R.groups[g].kind != 0 || R.groups[g].gi != (int)g) return false;
     if ((uint64_t)bs[i]->rows >= (1ull << 31)) return false;
+    if ((uint64_t)bs[i]->rows * (FDB_RUN_BYTES + 4) > ((uint64_t)48 << 30)) return false;  // (the run store is sized for the worst case — every row a run)
   }
   return true;
 }

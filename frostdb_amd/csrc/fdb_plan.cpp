@@ -1061,7 +1061,8 @@ void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
   // small record: copy now (through pinned staging — the source is not touched after this call), scan later
   const RecordSink sink = [this](size_t bytes, void** dev, unsigned char** pinned) { slab_reserve(bytes, dev, pinned); };
   std::unique_ptr<DeviceBatch> b = import_batch(view, device_, &want, stream_, ctx_, /*via_ring=*/true, &sink);
-  if (slab_.used - slab_.shipped >= ((size_t)8 << 20)) slab_ship();
+  static const size_t ship_bytes = std::getenv("FDB_SLAB_SHIP_MB") ? (size_t)std::atoll(std::getenv("FDB_SLAB_SHIP_MB")) << 20 : (size_t)2 << 20;  // (tuning aid; 2 … 32 MiB measured within noise of each other, 2 MiB keeps the device busy earliest)
+  if (slab_.used - slab_.shipped >= ship_bytes) slab_ship();
   lap(tp, prof_push_[1]);
   {
     // errors the record would raise surface here, at its own Callback, not at some later launch

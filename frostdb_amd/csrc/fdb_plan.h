@@ -316,7 +316,7 @@ class Plan {
   };
   // Small pushed records are not allocated one by one (a record held until the next sync would cost a hipMalloc each: ≈25 µs, and
   // a process-wide lock that N chains fight over): their bytes are pieces of a SLAB — a device block and a pinned block of the same
-  // size, filled at the same offsets — shipped with one DMA per ≈8 MiB and recycled when the stream is next idle.
+  // size, filled at the same offsets — shipped with one DMA per ≈2 MiB and recycled when the stream is next idle.
   struct RecordSlab { void* d = nullptr; unsigned char* h = nullptr; size_t cap = 0, used = 0, shipped = 0; };
   RecordSlab slab_;
   std::vector<RecordSlab> inflight_slabs_;
