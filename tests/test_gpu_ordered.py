@@ -288,3 +288,53 @@ def test_table_free_path_is_left_when_a_record_does_not_fit_it(pp):
         assert kernel != "fdb_hash_kernel(runs)"
         h, _ = _run_plan(pp, seq, Sum(Col("v")), groups, ordered=False)
         assert _rows(o) == sorted(_rows(h), key=_key_order)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_run_path_against_the_hash_path_on_random_shapes(pp, seed):
+    """Differential: an ordered plan (run kernel + run-store Finish, or its fall-backs) against the plain hash aggregate sorted by key, over
+    shapes that stress the run store's bookkeeping — ragged records (1 row … tens of thousands, not multiples of the 256-row wave tile or
+    the 1 024-row workgroup tile), every row its own run (a wave's LDS stage fills and flushes inside one record, chunks of 4 096 runs
+    change), one run spanning whole records, NULL keys, a filter that drops most rows, more records than run segments (the path is left
+    mid-scan), sorted and unsorted input."""
+    rng = np.random.default_rng(1000 + seed)
+    n_rec = int(rng.integers(1, 80 if seed % 4 == 3 else 12))
+    card = [int(rng.integers(1, 200)), int(rng.integers(1, 9)), int(rng.integers(1, 4))]
+    n_total = int(rng.integers(n_rec, 150_000))
+    sort = seed % 3 != 2
+    cols = []
+    for k in card:
+        v = rng.integers(0, k + 1, n_total)
+        cols.append(np.where(rng.random(n_total) < 0.05, k, v))
+    if seed % 4 == 1:  # every row its own key: the first column counts up
+        card[0] = 250
+        cols[0] = np.sort(rng.integers(0, 250, n_total))
+        cols[1] = np.arange(n_total) % (card[1] + 1)
+    if seed % 4 == 2:  # one key for (almost) everything
+        cols = [np.zeros(n_total, dtype=np.int64) for _ in card]
+        cols[2][-3:] = 1 if card[2] > 1 else 0
+    if sort:
+        order = np.lexsort(tuple(reversed(cols)))
+        cols = [c[order] for c in cols]
+    val = rng.integers(-1000, 1000, n_total).astype(np.int64)
+    cuts = [0] + sorted(rng.integers(0, n_total + 1, n_rec - 1).tolist()) + [n_total]
+    recs = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a == b and rng.random() < 0.5:
+            continue
+        arrays, names = [], []
+        for c, k in enumerate(card):
+            d = pa.array([b"k%03d" % i for i in range(k)], type=pa.binary())
+            x = cols[c][a:b]
+            arrays.append(pa.DictionaryArray.from_arrays(pa.array(np.where(x >= k, 0, x).astype(np.uint32), mask=x >= k), d)); names.append("labels.l%d" % c)
+        arrays.append(pa.array(val[a:b])); names.append("v")
+        recs.append(pa.RecordBatch.from_arrays(arrays, names=names))
+    if not recs:
+        return
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    filt = (Col("v") > 900) if seed % 2 == 1 else None
+    agg = [Sum(Col("v")), Min(Col("v")), Max(Col("v")), Count(Col("v"))][seed % 4]
+    for resident in (False, True):
+        o, _ = _run_plan(pp, recs, agg, groups, ordered=True, resident=resident, filt=filt)
+        h, _ = _run_plan(pp, recs, agg, groups, ordered=False, resident=resident, filt=filt)
+        assert _rows(o) == sorted(_rows(h), key=_key_order), (seed, resident, n_rec, n_total)
