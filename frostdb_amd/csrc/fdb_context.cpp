@@ -226,6 +226,29 @@ hipEvent_t Context::get_event() {
 
 void Context::put_event(hipEvent_t e) { events_.push_back(e); }
 
+unsigned long long* Context::select_ctl(size_t want, uint32_t* epoch, unsigned long long* ticket_base, unsigned long long* arrival_base) {
+  const size_t words = FDB_SELECT_CTL_WORDS + want;
+  if (words > select_words_ || select_epoch_ >= (1u << 24) - 1u) {
+    if (words > select_words_) {
+      // (owned by the context like its staging ring: not a dev_alloc block, which would count as a live allocation of the plan)
+      if (select_ctl_ != nullptr) { (void)hipStreamSynchronize(stream); (void)hipFree(select_ctl_); select_ctl_ = nullptr; select_words_ = 0; }
+      const size_t n = std::max<size_t>(words + words / 2, 1u << 16);
+      void* p = nullptr;
+      hip_check(hipMalloc(&p, n * 8), "hipMalloc(select control block)");
+      select_ctl_ = (unsigned long long*)p;
+      select_words_ = n;
+    }
+    hip_check(hipMemsetAsync(select_ctl_, 0, select_words_ * 8, stream), "hipMemsetAsync(select control block)");
+    select_epoch_ = 0;
+    select_ticket_ = 0;
+    select_arrival_ = 0;
+  }
+  *epoch = ++select_epoch_;
+  *ticket_base = select_ticket_;
+  *arrival_base = select_arrival_;
+  return select_ctl_;
+}
+
 hipStream_t Context::aux_stream(int i) {
   if (i < 0 || i >= 3) i = 0;
   if (aux_[i] == nullptr) hip_check(hipStreamCreateWithFlags(&aux_[i], hipStreamNonBlocking), "hipStreamCreate(aux)");

@@ -32,6 +32,13 @@ class Context {
   // evenly than one: 1.35 GB went from 41 to ≈52 GB/s); ordered after everything queued on `stream`, complete when this returns.
   void copy_out_parallel(void* host, const void* dev, size_t bytes);
   hipStream_t aux_stream(int i);  // a second queue of this context (copies that overlap kernels on `stream`); created on first use
+  // filter()'s one-pass kernel (FdbSelectArgs, fdb_kernels.h): the control block — ticket counter, error word, one status word per
+  // tile — lives as long as the context and is cleared only when it is created or grown (or its 24-bit epoch wraps): status words
+  // carry the epoch of the launch that wrote them. Returns the block (≥ FDB_SELECT_CTL_WORDS + `words` words) and starts a new epoch;
+  // `*ticket_base` / `*arrival_base` = what the ticket and arrival counters hold now; the caller reports what its launch draws with select_ctl_drawn().
+  // The stream is idle between the calls of one filter() (it ends synchronised), which is what makes growing safe.
+  unsigned long long* select_ctl(size_t words, uint32_t* epoch, unsigned long long* ticket_base, unsigned long long* arrival_base);
+  void select_ctl_drawn(unsigned long long tickets, unsigned long long arrivals) { select_ticket_ += tickets; select_arrival_ += arrivals; }
 
   // Small host→device tables (LUTs, slot maps): staged in pinned memory, shipped with one async copy each.
   void* stage(const void* host, size_t bytes);
@@ -70,6 +77,10 @@ class Context {
   size_t shadow_valid_ = 0;
   bool defer_ = false;
   hipStream_t aux_[3] = {nullptr, nullptr, nullptr};
+  unsigned long long* select_ctl_ = nullptr;
+  size_t select_words_ = 0;
+  uint32_t select_epoch_ = 0;
+  unsigned long long select_ticket_ = 0, select_arrival_ = 0;
   unsigned char* copy_h_ = nullptr;  // pinned ring of copy_in (separate from the LUT staging ring: a wrap here never touches staged LUTs)
   size_t copy_cap_ = 0, copy_off_ = 0;
 };

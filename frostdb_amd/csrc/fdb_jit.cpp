@@ -588,6 +588,220 @@ struct Gen {
     o << "  }\n}\n";
     return o.str();
   }
+
+  // ---- filter() in one pass over the filter columns (Plan::filter_batches; FdbSelectArgs in fdb_kernels.h) ----------------------------
+  // fdb_flags_kernel's row evaluation with three additions. (1) Work is handed out by a ticket counter, one ticket per workgroup share
+  // of four tiles: whatever a look-back waits for is then held by workgroups that already run, never by one the dispatcher has not
+  // placed yet (several filter() scans, or scans of other plans, share the GPU). (2) The selected values of the fused slots are staged
+  // in the wave's LDS region at their local positions while the predicate is evaluated — the values are in registers at that point,
+  // the filter column is not read again. (3) The workgroup publishes the count of its share, its first wave sums the counts of the
+  // shares in front of it inside the record (decoupled look-back), publishes the inclusive prefix, and every wave writes its staged
+  // values to their final place, consecutive lanes consecutive 16 bytes; tile offsets are left behind for compact_multi_kernel.
+  // Geometry: 512-thread workgroups, a wave owns HALF a tile (1 024 rows = 4 steps → 8 KiB of LDS per 8-byte column and wave, 16 waves
+  // per CU). What the look-back costs is set by how many status words are "count only" at a time — everything evaluated within one
+  // look-back's duration — against how many one poll covers. A status per wave and 64 words per poll (the first version) left the
+  // nearest inclusive prefix thousands of words away: 0.2 ms of evaluation became 0.5. Hence ONE status per workgroup share (8 192
+  // rows, the waves' counts meet in LDS) and 256 words per poll (four loads per lane, one round trip). A workgroup publishes its
+  // count BEFORE it waits for anything: units that were placed one after the other by the same wave chained every unit of the
+  // launch behind its predecessor's look-back (measured: 43 ms).
+  struct Fused { bool wide; int slot; size_t off; };
+  static constexpr int kSelectBlock = 512, kSelectUnit = FDB_COMPACT_TILE / 2;
+  std::vector<Fused> fused(size_t* per_wave) const {
+    std::vector<Fused> f;
+    size_t at = 0;
+    for (int i = 0; i < s.n_c8; i++) if ((s.fuse8 >> i) & 1) { f.push_back({true, i, at}); at += (size_t)kSelectUnit * 8; }
+    for (int i = 0; i < s.n_c4; i++) if ((s.fuse4 >> i) & 1) { f.push_back({false, i, at}); at += (size_t)kSelectUnit * 4; }
+    if (per_wave != nullptr) *per_wave = at;
+    return f;
+  }
+  std::string select_source() {
+    const int BLK = kSelectBlock;
+    size_t per_wave = 0;
+    const std::vector<Fused> fz = fused(&per_wave);
+    // ($FDB_SELECT_ABLATE, tuning aid — results are WRONG: 1 = no look-back (every share at offset 0), 2 = staged values are not written out, 3 = nothing is staged either)
+    const int ablate = std::getenv("FDB_SELECT_ABLATE") ? std::atoi(std::getenv("FDB_SELECT_ABLATE")) : 0;
+    const int w_sleep = std::getenv("FDB_SELECT_SLEEP") ? std::atoi(std::getenv("FDB_SELECT_SLEEP")) : 4, s_sleep = std::getenv("FDB_SELECT_SCAN_SLEEP") ? std::atoi(std::getenv("FDB_SELECT_SCAN_SLEEP")) : 4;  // (tuning aids)
+    o << "#include \"fdb_kernels.h\"\n" << kPreamble;
+    // what one step (4 rows per lane) of the filter columns looks like in registers: filled by `load`, consumed by `pred` — apart, so that
+    // the NEXT share's loads are in flight while the workgroup waits for the current share's place
+    std::vector<std::pair<std::string, std::string>> raw_fields;  // (type, name)
+    for (int i = 0; i < s.n_c4; i++) {
+      const std::string r = reg(false, false, i);
+      if (s.c4[i].has_values) raw_fields.push_back({"u32x4", r});
+      raw_fields.push_back({"uint32_t", r + "_m"});
+    }
+    for (int i = 0; i < s.n_c8; i++) {
+      const std::string r = reg(true, false, i);
+      if (s.c8[i].has_values) { raw_fields.push_back({"u64x2", r + "a"}); raw_fields.push_back({"u64x2", r + "b"}); }
+      raw_fields.push_back({"uint32_t", r + "_m"});
+    }
+    o << "struct Raw {";
+    for (auto& f : raw_fields) o << " " << f.first << " " << f.second << ";";
+    o << " int none; };\n";
+    o << "__device__ __forceinline__ uint32_t lanes_below(const unsigned long long b) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u)); }\n";
+    o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") void fdb_select_kernel(const FdbScanArgs* __restrict__ parts, const int n_parts, const long long total_tiles, const FdbScanArgs c, uint32_t* __restrict__ masks, uint32_t* __restrict__ offsets, const FdbSelectArgs sa) {\n";
+    o << "  extern __shared__ __align__(16) unsigned char smem[];\n  __shared__ long long s_ticket[2];\n  __shared__ unsigned long long s_base;\n  __shared__ uint32_t s_cnt[2][8];\n";
+    o << "  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n";
+    for (int i = 0; i < s.n_c4; i++) o << "  const char* P_" << reg(false, false, i) << "_v = nullptr; const uint8_t* P_" << reg(false, false, i) << "_b = nullptr;\n";
+    for (int i = 0; i < s.n_c8; i++) o << "  const char* P_" << reg(true, false, i) << "_v = nullptr; const uint8_t* P_" << reg(true, false, i) << "_b = nullptr;\n";
+    for (size_t l = 0; l < s.leaves.size(); l++)
+      o << "  long long K_lit" << l << " = 0; uint32_t K_len" << l << " = 1, K_lds" << l << " = 0; int K_op" << l << " = 0; const uint8_t* K_lut" << l << " = nullptr;\n";
+    for (size_t k = 0; k < fz.size(); k++) o << "  char* D_" << k << " = nullptr;\n";
+  
+    o << "  long long n_rows = 0, tile_begin = 0, tile_end = 0, out_tile = 0; int part = -1, lut_class = -1;\n";
+    o << "  unsigned char* const stg = smem + sa.stage_off + (size_t)wave * " << per_wave << "u;\n  (void)stg;\n";
+    o << "  unsigned long long* const status = sa.ctl + sa.status_off;\n";
+    o << "  const unsigned long long ep = (unsigned long long)sa.epoch << 40, VAL = (1ull << 38) - 1ull;\n";
+    o << "  auto load = [&](const long long row, Raw& raw) {\n";
+    o << "      const size_t tile_off4 = (size_t)row * 4, tile_off8 = (size_t)row * 8, tile_offb = (size_t)(row >> 3);\n";
+    o << "      const uint32_t lane_off4 = 0u, lane_off8 = 0u, lane_offb = 0u, lane_shb = (uint32_t)row & 4u;\n";
+    o << "      (void)tile_off4; (void)tile_off8; (void)tile_offb; (void)lane_off4; (void)lane_off8; (void)lane_offb; (void)lane_shb; (void)raw;\n";
+    loads(false);
+    for (auto& f : raw_fields) o << "      raw." << f.second << " = " << f.second << ";\n";
+    o << "  };\n";
+    o << "  auto pred = [&](const Raw& raw) -> uint32_t {\n      (void)raw;\n";
+    for (auto& f : raw_fields) o << "      const " << f.first << " " << f.second << " = raw." << f.second << "; (void)" << f.second << ";\n";
+    o << "      return " << (s.code.empty() ? std::string("0xFu") : filter_expr()) << ";\n  };\n";
+    // the argument block of the record that holds workgroup share `st` (shares only ever grow): pointers, literals, LUTs into LDS
+    auto enter = [&]() {
+      o << "    if (part < 0 || st >= tile_end) {\n      int np = part < 0 ? 0 : part;\n      while (np + 1 < n_parts && st >= parts[np].tile_end) np++;\n      part = np;\n";
+      o << "      const FdbScanArgs& pa = parts[part];\n      n_rows = pa.n_rows; tile_begin = pa.tile_begin; tile_end = pa.tile_end; out_tile = pa.out_tile_base;\n";
+      for (int i = 0; i < s.n_c4; i++)
+        o << "      P_" << reg(false, false, i) << "_v = (const char*)pa.c4[" << i << "].values; P_" << reg(false, false, i) << "_b = pa.c4[" << i << "].validity;\n";
+      for (int i = 0; i < s.n_c8; i++)
+        o << "      P_" << reg(true, false, i) << "_v = (const char*)pa.c8[" << i << "].values; P_" << reg(true, false, i) << "_b = pa.c8[" << i << "].validity;\n";
+      for (size_t l = 0; l < s.leaves.size(); l++)
+        o << "      K_lit" << l << " = pa.leaves[" << l << "].lit; K_len" << l << " = pa.leaves[" << l << "].lut_len; K_lds" << l << " = pa.leaves[" << l << "].lut_lds; K_op" << l
+          << " = pa.leaves[" << l << "].op; K_lut" << l << " = pa.leaves[" << l << "].lut;\n";
+      for (size_t k = 0; k < fz.size(); k++) o << "      D_" << k << " = (char*)sa.sparts[part].dst[" << k << "];\n";
+      o << "      if (pa.lut_class != lut_class) {\n        lut_class = pa.lut_class;\n        __syncthreads();\n";
+      for (size_t l = 0; l < s.leaves.size(); l++)
+        if (s.leaves[l].kind == FDB_LEAF_DICT_LUT && s.leaves[l].lut_in_lds)
+          o << "        for (uint32_t i = tid; i < K_len" << l << "; i += " << BLK << ") smem[K_lds" << l << " + i] = as_global(K_lut" << l << ")[i];\n";
+      o << "        __syncthreads();\n      }\n    }\n";
+      o << "    unit = (st - tile_begin) * 8 + wave;  // this wave's half tile inside the record\n";
+      o << "    rbase = unit * " << kSelectUnit << "LL;\n    active = rbase < n_rows;  // (the record's last share may be short of units)\n";
+      o << "    if (active) {\n      const long long last_group = (n_rows - 1) & ~3LL;\n";
+      o << "#pragma unroll\n      for (int u = 0; u < 4; u++) {\n        const long long row = rbase + u * 256 + (long long)lane * 4;\n";
+      o << "        load(row < n_rows ? row : last_group, raw[u]);\n      }\n    }\n";
+    };
+    // The workgroup that arrives first does not filter: its first wave is the launch's SCANNER. It walks the shares in order, waits
+    // for each one's count, and hands every share its place (the exclusive prefix inside its record) in a word of its own, 128 bytes
+    // apart. A worker publishes its count and then polls that one word. (The first version let every workgroup sum the counts in
+    // front of it itself, 256 status words per poll: 512 workgroups polling the same sixteen cache lines — one memory channel —
+    // took 16 µs per round and set the kernel's pace; so did a status word per wave before that.) Nothing waits for a workgroup
+    // that is not running: the scanner runs (it arrived first), and the counts it waits for belong to tickets that were drawn by
+    // running workgroups, which publish before they wait.
+    o << "  __shared__ int s_scanner;\n  if (tid == 0) s_scanner = (atomicAdd(sa.ctl + 2, 1ull) - sa.arrival_base) == 0ull ? 1 : 0;\n  __syncthreads();\n";
+    o << "  unsigned long long* const place = sa.ctl + sa.place_off;  // place[16 st]: (epoch << 40) | exclusive prefix of share st\n";
+    o << "  if (s_scanner != 0) {\n    if (wave != 0u) return;\n";
+    o << "    long long pos = 0, p_end = parts[0].tile_end; int p = 0; unsigned long long running = 0; uint32_t spins = 0;\n";
+    o << "    while (pos < total_tiles) {\n      unsigned long long v[4];\n";
+    o << "#pragma unroll\n      for (int j = 0; j < 4; j++) {\n        const long long idx = pos + (long long)lane + 64 * j;\n        v[j] = 0ull;\n";
+    o << "        if (idx < p_end) v[j] = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n      }\n";
+    o << "      bool more = true; const long long pos0 = pos;\n";
+    o << "#pragma unroll\n      for (int j = 0; j < 4; j++) {\n        if (!more) continue;\n";
+    o << "        const long long idx = pos0 + (long long)lane + 64 * j;  // (== pos + lane: every earlier window was taken whole)\n";
+    o << "        const bool in_range = idx < p_end;\n";
+    o << "        const bool ready = in_range && (v[j] >> 40) == (unsigned long long)sa.epoch && ((v[j] >> 38) & 3ull) == 1ull;\n";
+    o << "        const unsigned long long wait = __ballot(in_range && !ready), have = __ballot(in_range);\n";
+    o << "        const int n = wait != 0ull ? __builtin_ctzll(wait) : __popcll(have);  // shares of this window whose counts are in, from the front\n";
+    o << "        unsigned long long cnt = (int)lane < n ? (v[j] & VAL) : 0ull, incl = cnt;\n";
+    o << "#pragma unroll\n        for (int sh = 1; sh < 64; sh <<= 1) { const unsigned long long t = (unsigned long long)__shfl_up((long long)incl, sh, 64); if ((int)lane >= sh) incl += t; }\n";
+    o << "        if ((int)lane < n) __hip_atomic_store(place + idx * 16, ep | (running + incl - cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n";
+    o << "        running += (unsigned long long)__shfl((long long)incl, 63, 64);\n        pos += n;\n        if (n < 64) more = false;\n      }\n";
+    o << "      if (pos == p_end) {  // the record is complete: its row count, and the next record starts from nothing\n";
+    o << "        if (lane == 0u) *sa.sparts[p].total = running;\n        running = 0; p++;\n        if (p < n_parts) p_end = parts[p].tile_end;\n      }\n";
+    o << "      if (pos == pos0) {\n        if (++spins > (1u << 22)) { if (lane == 0u) sa.ctl[1] = 1ull; break; }  // (never seen; a stuck launch must not hang the device)\n";
+    o << "        __builtin_amdgcn_s_sleep(" << s_sleep << ");\n      } else spins = 0;\n    }\n    return;\n  }\n";
+    // thread 0 always holds the ticket after the next one
+    o << "  long long next_ticket = 0;\n  if (tid == 0) { s_ticket[0] = (long long)(atomicAdd(sa.ctl, 1ull) - sa.ticket_base); next_ticket = s_ticket[0] < total_tiles ? (long long)(atomicAdd(sa.ctl, 1ull) - sa.ticket_base) : s_ticket[0]; }\n";
+    o << "  __syncthreads();\n  long long st = s_ticket[0];\n  if (st >= total_tiles) return;\n";
+    o << "  long long unit = 0, rbase = 0; bool active = false;\n  Raw raw[4];\n  {\n";
+    enter();
+    o << "  }\n";
+    o << "  for (uint32_t it = 0;; it++) {\n";
+    // 1. the current share: predicate, staging, bitmap
+    o << "    uint32_t cnt = 0;  // selected rows of the unit so far (wave-uniform)\n";
+    o << "    if (active) {\n      uint32_t sel[4];\n";
+    o << "#pragma unroll\n      for (int u = 0; u < 4; u++) {\n";
+    o << "        const long long left = n_rows - (rbase + u * 256 + (long long)lane * 4);\n";
+    o << "        sel[u] = pred(raw[u]) & (left >= 4 ? 0xFu : left > 0 ? ((1u << (int)left) - 1u) : 0u);\n      }\n";
+    o << "#pragma unroll\n      for (int u = 0; u < 4; u++) {\n        uint32_t w = sel[u];\n";
+    o << "        const unsigned long long b0 = __ballot(w & 1u), b1 = __ballot(w & 2u), b2 = __ballot(w & 4u), b3 = __ballot(w & 8u);\n";
+    if (!fz.empty() && ablate != 3) {
+      // rows keep their order: lane L's four rows sit behind every selected row of the lanes below it
+      o << "        const uint32_t p0 = cnt + lanes_below(b0) + lanes_below(b1) + lanes_below(b2) + lanes_below(b3);\n";
+      o << "        const uint32_t p1 = p0 + (w & 1u), p2 = p1 + ((w >> 1) & 1u), p3 = p2 + ((w >> 2) & 1u);\n";
+      for (size_t k = 0; k < fz.size(); k++) {
+        const std::string r = "raw[u]." + reg(fz[k].wide, false, fz[k].slot);
+        if (fz[k].wide) {
+          o << "        { unsigned long long* sk = reinterpret_cast<unsigned long long*>(stg + " << fz[k].off << "u);\n";
+          o << "          if (w & 1u) sk[p0] = " << r << "a.x; if (w & 2u) sk[p1] = " << r << "a.y; if (w & 4u) sk[p2] = " << r << "b.x; if (w & 8u) sk[p3] = " << r << "b.y; }\n";
+        } else {
+          o << "        { uint32_t* sk = reinterpret_cast<uint32_t*>(stg + " << fz[k].off << "u);\n";
+          o << "          if (w & 1u) sk[p0] = " << r << ".x; if (w & 2u) sk[p1] = " << r << ".y; if (w & 4u) sk[p2] = " << r << ".z; if (w & 8u) sk[p3] = " << r << ".w; }\n";
+        }
+      }
+    }
+    o << "        cnt += (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));\n";
+    // a step's 256 mask bits = 8 words: lane L's nibble sits at bits 4 (L % 8) of word L / 8
+    o << "        w |= (uint32_t)__shfl_down((int)w, 1, 64) << 4;\n        w |= (uint32_t)__shfl_down((int)w, 2, 64) << 8;\n        w |= (uint32_t)__shfl_down((int)w, 4, 64) << 16;\n";
+    o << "        sel[u] = w;\n      }\n";
+    o << "      if ((lane & 7u) == 0u) {\n        uint32_t* mw = masks + (size_t)(out_tile + (unit >> 1)) * 64 + (size_t)(unit & 1) * 32 + (lane >> 3);\n";
+    o << "        mw[0] = sel[0]; mw[8] = sel[1]; mw[16] = sel[2]; mw[24] = sel[3];\n      }\n";
+    o << "    }\n";
+    // 2. the waves' counts meet in LDS; the next ticket with them
+    o << "    if (lane == 0u) s_cnt[it & 1u][wave] = cnt;\n    if (tid == 0) s_ticket[(it + 1u) & 1u] = next_ticket;\n    __syncthreads();\n";
+    o << "    const long long c_st = st, c_out_tile = out_tile, c_unit = unit;\n    const bool c_active = active;\n";
+    for (size_t k = 0; k < fz.size(); k++) o << "    char* const c_D_" << k << " = D_" << k << "; (void)c_D_" << k << ";\n";
+    // the first wave publishes the share's count — before anything else is loaded or waited for
+    o << "    uint32_t share = 0;\n";
+    o << "    if (wave == 0u) {\n      share = lane < 8u ? s_cnt[it & 1u][lane] : 0u;\n";
+    o << "#pragma unroll\n      for (int sh = 4; sh > 0; sh >>= 1) share += (uint32_t)__shfl_xor((int)share, sh, 64);\n";
+    o << "      share = (uint32_t)__builtin_amdgcn_readfirstlane((int)share);\n";
+    o << "      if (lane == 0u) __hip_atomic_store(status + c_st, ep | (1ull << 38) | (unsigned long long)share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n    }\n";
+    // 3. the next share: its loads go out now and land while the first wave looks back
+    o << "    const long long nst = s_ticket[(it + 1u) & 1u];\n";
+    o << "    if (tid == 0 && nst < total_tiles) next_ticket = (long long)(atomicAdd(sa.ctl, 1ull) - sa.ticket_base);\n";
+    o << "    if (nst < total_tiles) {\n      st = nst;\n";
+    enter();
+    o << "    }\n";
+    // 4. the share's place, from the scanner
+    o << "    if (wave == 0u) {\n      unsigned long long excl = 0;\n";
+    if (ablate != 1) {
+      o << "      uint32_t spins = 0;\n      for (;;) {\n        const unsigned long long v = __hip_atomic_load(place + c_st * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n";
+      o << "        if ((v >> 40) == (unsigned long long)sa.epoch) { excl = v & VAL; break; }\n";
+      o << "        if (++spins > (1u << 22)) { if (lane == 0u) sa.ctl[1] = 1ull; break; }  // (never seen)\n";
+      o << "        __builtin_amdgcn_s_sleep(" << w_sleep << ");\n      }\n";
+    }
+    o << "      if (lane == 0u) s_base = excl;\n    }\n    __syncthreads();\n";
+    // 5. every wave writes its staged values to their place
+    o << "    if (c_active) {\n      unsigned long long excl = s_base;\n";
+    o << "      for (uint32_t w2 = 0; w2 < wave; w2++) excl += s_cnt[it & 1u][w2];\n";
+    o << "      if (lane == 0u && (c_unit & 1) == 0) offsets[c_out_tile + (c_unit >> 1)] = (uint32_t)excl;\n";
+    if (!fz.empty() && ablate < 2) {
+      for (size_t k = 0; k < fz.size(); k++) {
+        if (fz[k].wide) {
+          o << "      { unsigned long long* d = reinterpret_cast<unsigned long long*>(c_D_" << k << ") + excl;\n";
+          o << "        const u32x4* sv = reinterpret_cast<const u32x4*>(stg + " << fz[k].off << "u);\n";
+          o << "        for (uint32_t i = lane * 2u; i < cnt; i += 128u) {\n";
+          o << "          if (i + 1u < cnt) __builtin_nontemporal_store(sv[i >> 1], reinterpret_cast<u32x4*>(d + i));\n";
+          o << "          else d[i] = reinterpret_cast<const unsigned long long*>(sv)[i];\n        }\n      }\n";
+        } else {
+          o << "      { uint32_t* d = reinterpret_cast<uint32_t*>(c_D_" << k << ") + excl;\n";
+          o << "        const u32x4* sv = reinterpret_cast<const u32x4*>(stg + " << fz[k].off << "u);\n";
+          o << "        for (uint32_t i = lane * 4u; i < cnt; i += 256u) {\n";
+          o << "          if (i + 3u < cnt) __builtin_nontemporal_store(sv[i >> 2], reinterpret_cast<u32x4*>(d + i));\n";
+          o << "          else { const u32x4 t = sv[i >> 2]; d[i] = t.x; if (i + 1u < cnt) d[i + 1] = t.y; if (i + 2u < cnt) d[i + 2] = t.z; }\n        }\n      }\n";
+        }
+      }
+    }
+    o << "    }\n    __builtin_amdgcn_wave_barrier();  // (the next unit stages into the same region)\n";
+    o << "    if (nst >= total_tiles) break;\n";
+    o << "  }\n}\n";
+    return o.str();
+  }
 };
 
 
@@ -1122,6 +1336,19 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
   return fn;
 }
 }  // namespace
+
+std::string jit_select_source(const JitShape& shape) { return Gen(shape).select_source(); }
+size_t jit_select_stage_bytes(const JitShape& shape) { size_t n = 0; (void)Gen(shape).fused(&n); return n; }
+hipFunction_t jit_select_kernel_get(const JitShape& shape) {
+  return get_kernel("select|" + shape.key() + "|f" + std::to_string(shape.fuse4) + "," + std::to_string(shape.fuse8) + (std::getenv("FDB_SELECT_ABLATE") ? std::string("|a") + std::getenv("FDB_SELECT_ABLATE") : std::string()) + (std::getenv("FDB_SELECT_SLEEP") ? std::string("|s") + std::getenv("FDB_SELECT_SLEEP") : std::string()) + (std::getenv("FDB_SELECT_SCAN_SLEEP") ? std::string("|S") + std::getenv("FDB_SELECT_SCAN_SLEEP") : std::string()), "fdb_select_kernel", [&] { return jit_select_source(shape); });
+}
+hipError_t jit_select_launch(hipFunction_t fn, const FdbScanArgs* d_parts, int n_parts, int64_t total_super_tiles, const FdbScanArgs& common, int grid, size_t lds_bytes,
+                             uint32_t* masks, uint32_t* offsets, const FdbSelectArgs& sel, hipStream_t stream) {
+  long long tt = total_super_tiles;
+  void* args[] = {(void*)&d_parts, (void*)&n_parts, (void*)&tt, (void*)&common, (void*)&masks, (void*)&offsets, (void*)&sel};
+  return hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, (unsigned)Gen::kSelectBlock, 1, 1, (unsigned)lds_bytes, stream, args, nullptr);
+}
+int jit_select_block() { return Gen::kSelectBlock; }
 
 std::string jit_flags_source(const JitShape& shape) { return Gen(shape).flags_source(); }
 hipFunction_t jit_flags_get(const JitShape& shape) {

@@ -38,6 +38,8 @@ struct JitShape {
   // aggregate at the end; rows of other keys update the global table directly. Hot keys — which serialise on their cache
   // line in L2 when every row is a global atomic (sum by (path, instance): 11 ms per 50 M rows) — are first to get a place.
   bool cache = false;
+  // fdb_select_kernel only (not part of key()): early slots whose values the kernel compacts itself, bit i = slot i of c4 / c8
+  int fuse4 = 0, fuse8 = 0;
   std::string key(bool with_validity = true) const;
 };
 
@@ -84,6 +86,16 @@ std::string jit_flags_source(const JitShape& shape);
 hipFunction_t jit_flags_get(const JitShape& shape);
 hipError_t jit_flags_launch(hipFunction_t fn, const FdbScanArgs* d_parts, int n_parts, int64_t total_super_tiles, const FdbScanArgs& common, int grid, size_t lds_bytes,
                             uint32_t* masks, uint32_t* tile_counts, hipStream_t stream);
+
+// filter() in one pass over the filter columns (fdb_kernels.h, FdbSelectArgs): fdb_flags_kernel's geometry and bitmap, plus the tile
+// offsets (decoupled look-back inside each record, tiles handed out by a ticket counter) and the compacted values of the fused slots
+// (shape.fuse4 / fuse8), staged in LDS — jit_select_stage_bytes(shape) per wave (jit_select_block() / 64 of them) behind `stage_off`.
+std::string jit_select_source(const JitShape& shape);
+hipFunction_t jit_select_kernel_get(const JitShape& shape);
+size_t jit_select_stage_bytes(const JitShape& shape);
+int jit_select_block();  // threads per workgroup (8 waves, half a tile each)
+hipError_t jit_select_launch(hipFunction_t fn, const FdbScanArgs* d_parts, int n_parts, int64_t total_super_tiles, const FdbScanArgs& common, int grid, size_t lds_bytes,
+                             uint32_t* masks, uint32_t* offsets, const FdbSelectArgs& sel, hipStream_t stream);
 
 std::string jit_source(const JitShape& shape);
 // The compiled kernel for `shape` (cached in the process and on disk), or nullptr if specialisation is unavailable.

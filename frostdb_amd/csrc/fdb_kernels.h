@@ -397,6 +397,32 @@ static inline double fdb_ordered_to_f64_host(int64_t k) {
   return d;
 }
 
+// filter() in ONE pass over the filter columns (fdb_select_kernel, generated per predicate shape in fdb_jit.cpp; Plan::filter_batches):
+// the workgroup that evaluates a share of four tiles also learns the share's place in its record's output and writes the compacted
+// values of the filter columns it holds (≤ 8 bytes per row, columns without a validity bitmap) itself; the other columns follow in
+// compact_multi_kernel from the bitmap and the tile offsets it leaves behind. Places come from the launch's scanner (the workgroup
+// that arrives first): workers publish their share's count, the scanner sums them in order.
+// `ctl`: a zero-initialised block the context keeps across launches —
+//   word 0 the ticket counter shares are handed out from (in the order workgroups ask: a share's predecessors are then always held
+//   by RUNNING workgroups, whatever else occupies the GPU), word 1 an error flag (a wait that did not end), word 2 the arrival counter
+//   (who is the scanner), words [FDB_SELECT_CTL_WORDS, status_off) the selected rows of every record (FdbSelectPart::total points
+//   there: the host fetches error word and totals with one copy), words [status_off …) one status word per share:
+//   (epoch << 40) | (1 << 38) | count, words [place_off …) every share's place, sixteen words (128 bytes) apart: (epoch << 40) | prefix.
+// A word of an earlier launch carries an earlier epoch and reads as "not there yet", so nothing is cleared between launches.
+#define FDB_SELECT_CTL_WORDS 8
+#define FDB_SELECT_MAX_FUSED 2
+struct FdbSelectPart { void* dst[FDB_SELECT_MAX_FUSED]; unsigned long long* total; };  // per record: outputs of the fused columns (worst-case sized), selected rows
+struct FdbSelectArgs {
+  unsigned long long* ctl;
+  unsigned long long ticket_base;   // value of the ticket counter when the launch starts
+  unsigned long long arrival_base;  // value of the arrival counter when the launch starts
+  const FdbSelectPart* sparts;
+  uint32_t epoch;                   // 1 … 2^24 − 1
+  uint32_t stage_off;               // LDS: the waves' staging regions start here (behind the predicate's LUTs)
+  uint32_t status_off;              // first status word, in words from ctl
+  uint32_t place_off;               // first place word, in words from ctl
+};
+
 #ifndef FDB_DEVICE_ONLY
 // ---- launch wrappers (fdb_kernels.hip) ---------------------------------------------------------------
 // All launches are asynchronous on `stream`.

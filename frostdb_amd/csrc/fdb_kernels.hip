@@ -1775,7 +1775,7 @@ __device__ __forceinline__ void compact_stream(const FdbCompactRec* __restrict__
       rec = lo;
       rec_begin = s_recs[rec].tile_begin; rec_rows = s_recs[rec].n_rows;
       rec_end = rec + 1 < n_recs ? s_recs[rec + 1].tile_begin : total_tiles;
-      rec_off = (uint32_t)((const FDB_CONST unsigned long long*)rec_base)[rec];
+      rec_off = rec_base != nullptr ? (uint32_t)((const FDB_CONST unsigned long long*)rec_base)[rec] : 0u;  // (nullptr: the offsets are relative to their record already)
       last_vword = rec_rows > 0 ? (uint32_t)((rec_rows - 1) >> 6) : 0u;
       const FDB_CONST FdbCompactCol* cd = (const FDB_CONST FdbCompactCol*)cols + ((size_t)rec * n_cols + col);
       src = cd->src; src_valid = cd->src_valid; dst = cd->dst; dst_valid = cd->dst_valid;

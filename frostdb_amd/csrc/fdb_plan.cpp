@@ -80,13 +80,14 @@ void DeviceBatch::note_reader(hipStream_t s) const {
 }
 
 DeviceBatch::~DeviceBatch() {
-  if (arena == nullptr || arena_borrowed) return;
+  if ((arena == nullptr && extra_arenas.empty()) || arena_borrowed) return;
   if (arena_ctx != nullptr) { arena_ctx->dev_free(arena); return; }
   if (!readers_.empty()) {  // (an idle stream answers in about a microsecond)
     (void)hipSetDevice(device);
     for (hipStream_t s : readers_) (void)hipStreamSynchronize(s);
   }
-  device_pool_free(device, arena);
+  if (arena != nullptr) device_pool_free(device, arena);
+  for (void* p : extra_arenas) device_pool_free(device, p);
 }
 
 int DeviceBatch::find(const std::string& name) const {
@@ -2419,52 +2420,150 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
     }
   }
   if (fallback) return per_record();
-  hipFunction_t flags_fn = jit_flags_get(shape);
-  if (flags_fn == nullptr) return per_record();
+  const size_t n_cols = in[live[0]]->cols.size();
 
-  // ---- selection bitmap, counts, prefix sums ------------------------------------------------------------------------------
-  const int64_t n_blocks = (total_tiles + 1023) / 1024;
-  const size_t counts_bytes = align_up((size_t)n_blocks * 8 + (size_t)total_tiles * 4, 256);
-  unsigned char* d_counts = (unsigned char*)ctx_->dev_alloc(counts_bytes);
+  // ---- which kernel: one pass over the filter columns (fdb_select_kernel), or bitmap → prefix sums → compaction ----------------------
+  // One pass: the wave that evaluates a tile also places it (look-back) and writes the compacted values of the filter columns it has
+  // in registers — columns WITHOUT a validity bitmap in any record, ≤ 8 bytes per row together (their tile is staged in LDS), whose
+  // slot reads the record's own column (a remapped or widened copy is not the column). Their outputs must exist before the row
+  // count does: worst-case sized pool blocks (extra_arenas), repacked into the exact arena when less than 40 % of them is used.
+  const bool two_pass_env = std::getenv("FDB_SELECT_TWO_PASS") != nullptr;  // (A/B, tests, fall-back: the three-launch prefix sum; read per call)
+  struct FusedCol { bool wide; int slot; int col; };
+  std::vector<FusedCol> fused;
+  std::vector<int> fused_of(n_cols, -1);  // column → index in `fused`
+  if (!two_pass_env) {
+    int budget = 8;
+    auto try_slot = [&](bool wide, int slot) {
+      const JitSlot& js = wide ? shape.c8[slot] : shape.c4[slot];
+      const int w = wide ? 8 : 4;
+      if (!js.has_values || js.has_validity != 0 || w > budget || (int)fused.size() >= FDB_SELECT_MAX_FUSED) return;
+      int col = -1;
+      for (size_t k = 0; k < nl; k++) {
+        const DeviceBatch& b = *in[live[k]];
+        const void* v = wide ? Rs[k].args.c8[slot].values : Rs[k].args.c4[slot].values;
+        int found = -1;
+        for (size_t c = 0; c < n_cols; c++) if (b.cols[c].d_values == v && v != nullptr) { found = (int)c; break; }
+        if (found < 0 || (k > 0 && found != col)) return;
+        const DevColumn& dc = b.cols[(size_t)found];
+        if (dc.d_validity != nullptr || dc.kind == ColKind::BOOL || (dc.kind == ColKind::DICT) != !wide) return;
+        col = found;
+      }
+      if (col < 0 || fused_of[(size_t)col] >= 0) return;
+      fused_of[(size_t)col] = (int)fused.size();
+      fused.push_back(FusedCol{wide, slot, col});
+      budget -= w;
+    };
+    for (int i = 0; i < shape.n_c8; i++) try_slot(true, i);
+    for (int i = 0; i < shape.n_c4; i++) try_slot(false, i);
+    // (the kernel numbers its outputs 8-byte slots first, then 4-byte slots, in slot order — the order they were tried in)
+    for (const FusedCol& f : fused) { if (f.wide) shape.fuse8 |= 1 << f.slot; else shape.fuse4 |= 1 << f.slot; }
+  }
+  hipFunction_t select_fn = two_pass_env ? nullptr : jit_select_kernel_get(shape);
+  hipFunction_t flags_fn = select_fn == nullptr ? jit_flags_get(shape) : nullptr;
+  if (select_fn == nullptr) { fused.clear(); std::fill(fused_of.begin(), fused_of.end(), -1); }
+  if (select_fn == nullptr && flags_fn == nullptr) return per_record();
+  const bool one_pass = select_fn != nullptr;
+
+  // ---- selection bitmap, tile offsets, row counts -----------------------------------------------------------------------------
   uint32_t* d_masks = (uint32_t*)ctx_->dev_alloc((size_t)total_tiles * (FDB_COMPACT_TILE / 8) + 256);
   uint32_t* d_offsets = (uint32_t*)ctx_->dev_alloc((size_t)total_tiles * 4 + 256);
-  unsigned long long* d_rec_base = (unsigned long long*)ctx_->dev_alloc((nl + 1) * 8 + 64);
-  scratch_.push_back(d_counts); scratch_.push_back(d_masks); scratch_.push_back(d_offsets); scratch_.push_back(d_rec_base);
-  unsigned long long* d_block_sums = (unsigned long long*)d_counts;
-  uint32_t* d_tile_counts = (uint32_t*)(d_counts + (size_t)n_blocks * 8);
+  scratch_.push_back(d_masks); scratch_.push_back(d_offsets);
   auto timed = [&](const std::function<void()>& f) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
     f();
     if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
   };
+  const size_t stage_off = align_up(lut_lds_max, 16);
+  const int first_block = one_pass ? jit_select_block() : 256;
+  const size_t first_lds = one_pass ? stage_off + (size_t)(first_block / 64) * jit_select_stage_bytes(shape) : lut_lds_max;
   int per_cu = 1;
   {
     // a wave keeps 4 steps × 64 lanes × 4 rows of every filter column in flight: ≈128 KB per CU (twice jit_select's figure: the
     // waves also spend time on words, counts and stores)
     int waves = row_bytes > 0 ? (131072 / (64 * 4 * 4)) / row_bytes : 8;
     waves = std::max(8, std::min(28, waves));
-    per_cu = std::max(1, std::min(jit_blocks_per_cu(flags_fn, 256, lut_lds_max), waves / 4));
+    per_cu = std::max(1, std::min(jit_blocks_per_cu(one_pass ? select_fn : flags_fn, first_block, first_lds), waves / (first_block / 64)));
     static const int env_per_cu = std::getenv("FDB_FLAGS_BLOCKS_PER_CU") ? std::atoi(std::getenv("FDB_FLAGS_BLOCKS_PER_CU")) : 0;  // (tuning aid)
     if (env_per_cu > 0) per_cu = env_per_cu;
   }
   int64_t grid = (int64_t)(fdb_scan_default_grid(device_) / 2) * per_cu;
   if (grid_override > 0) grid = grid_override;
   if (grid > total_super) grid = total_super;
-  const bool two_level = n_blocks > 64;  // (below that every scan workgroup adds up the counts in front of its block itself)
-  timed([&] {
-    hip_check(jit_flags_launch(flags_fn, d_parts, (int)parts.size(), total_super, parts[0], (int)grid, lut_lds_max, d_masks, d_tile_counts, stream_), "flags launch");
-    if (two_level) hip_check(fdb_launch_sel_block_sums(d_tile_counts, total_tiles, d_block_sums, stream_), "block sums launch");
-    hip_check(fdb_launch_sel_scan(d_tile_counts, two_level ? d_block_sums : nullptr, total_tiles, d_offsets, d_recs, (int)nl, d_rec_base, stream_), "prefix sums launch");
-  });
-  unsigned long long* h_base = (unsigned long long*)ctx_->host_alloc((nl + 1) * 8);
+  unsigned long long* h_base = (unsigned long long*)ctx_->host_alloc((nl + 1 + FDB_SELECT_CTL_WORDS) * 8);
   struct HostFree { Context* c; void* p; ~HostFree() { c->host_free(p); } } hf{ctx_, h_base};
-  hip_check(hipMemcpyAsync(h_base, d_rec_base, (nl + 1) * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(row counts)");
-  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (first host round trip: outputs are allocated at their exact sizes)
+  std::vector<int64_t> totals(nl, 0);
+  int launches = 0;
+  const unsigned long long* d_rec_base_arg = nullptr;  // (one pass: the offsets are relative to their record already)
+  if (one_pass) {
+    // outputs of the fused columns: one worst-case block per record, owned by the result from here on
+    std::vector<FdbSelectPart> sparts(nl);
+    uint32_t epoch = 0;
+    unsigned long long ticket_base = 0, arrival_base = 0;
+    const size_t status_words = align_up((size_t)total_super, 16);
+    unsigned long long* d_ctl = ctx_->select_ctl(align_up(nl, 16) + status_words + 16 * (size_t)total_super, &epoch, &ticket_base, &arrival_base);
+    for (size_t k = 0; k < nl; k++) {
+      const DeviceBatch& src = *in[live[k]];
+      DeviceBatch& o = *out[(size_t)live[k]];
+      std::memset(&sparts[k], 0, sizeof(FdbSelectPart));
+      sparts[k].total = d_ctl + FDB_SELECT_CTL_WORDS + k;
+      if (fused.empty()) continue;
+      size_t bytes = 0;
+      std::vector<size_t> off(fused.size());
+      for (size_t f = 0; f < fused.size(); f++) { off[f] = bytes; bytes += align_up((size_t)src.rows * (fused[f].wide ? 8 : 4) + kTailPad, 256); }
+      void* block = device_pool_alloc(device_, bytes);
+      o.extra_arenas.push_back(block);
+      o.arena_bytes += bytes;
+      for (size_t f = 0; f < fused.size(); f++) sparts[k].dst[f] = (unsigned char*)block + off[f];
+    }
+    FdbSelectArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.ctl = d_ctl;
+    sa.ticket_base = ticket_base;
+    sa.epoch = epoch;
+    sa.stage_off = (uint32_t)stage_off;
+    sa.arrival_base = arrival_base;
+    sa.status_off = (uint32_t)(FDB_SELECT_CTL_WORDS + align_up(nl, 16));
+    sa.place_off = (uint32_t)(sa.status_off + status_words);
+    {
+      StageScope stage_scope(ctx_);
+      sa.sparts = (const FdbSelectPart*)upload(sparts.data(), sparts.size() * sizeof(FdbSelectPart));
+    }
+    timed([&] { hip_check(jit_select_launch(select_fn, d_parts, (int)parts.size(), total_super, parts[0], (int)grid + 1, first_lds, d_masks, d_offsets, sa, stream_), "select launch"); });
+    // (one workgroup more than workers: the scanner; every worker draws exactly one ticket past the end)
+    ctx_->select_ctl_drawn((unsigned long long)total_super + (unsigned long long)grid, (unsigned long long)grid + 1);
+    launches = 1;
+    hip_check(hipMemcpyAsync(h_base, d_ctl + 1, (FDB_SELECT_CTL_WORDS - 1 + nl) * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(row counts)");
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (first host round trip: the other columns' outputs are allocated at their exact sizes)
+    if (h_base[0] != 0ull) throw Error(FDB_ERR_DEVICE, "internal: filter() look-back did not complete");
+    for (size_t k = 0; k < nl; k++) totals[k] = (int64_t)h_base[FDB_SELECT_CTL_WORDS - 1 + k];
+  } else {
+    const int64_t n_blocks = (total_tiles + 1023) / 1024;
+    const size_t counts_bytes = align_up((size_t)n_blocks * 8 + (size_t)total_tiles * 4, 256);
+    unsigned char* d_counts = (unsigned char*)ctx_->dev_alloc(counts_bytes);
+    unsigned long long* d_rec_base = (unsigned long long*)ctx_->dev_alloc((nl + 1) * 8 + 64);
+    scratch_.push_back(d_counts); scratch_.push_back(d_rec_base);
+    unsigned long long* d_block_sums = (unsigned long long*)d_counts;
+    uint32_t* d_tile_counts = (uint32_t*)(d_counts + (size_t)n_blocks * 8);
+    const bool two_level = n_blocks > 64;  // (below that every scan workgroup adds up the counts in front of its block itself)
+    timed([&] {
+      hip_check(jit_flags_launch(flags_fn, d_parts, (int)parts.size(), total_super, parts[0], (int)grid, lut_lds_max, d_masks, d_tile_counts, stream_), "flags launch");
+      if (two_level) hip_check(fdb_launch_sel_block_sums(d_tile_counts, total_tiles, d_block_sums, stream_), "block sums launch");
+      hip_check(fdb_launch_sel_scan(d_tile_counts, two_level ? d_block_sums : nullptr, total_tiles, d_offsets, d_recs, (int)nl, d_rec_base, stream_), "prefix sums launch");
+    });
+    launches = two_level ? 3 : 2;
+    hip_check(hipMemcpyAsync(h_base, d_rec_base, (nl + 1) * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(row counts)");
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (first host round trip: outputs are allocated at their exact sizes)
+    for (size_t k = 0; k < nl; k++) totals[k] = (int64_t)(h_base[k + 1] - h_base[k]);
+    d_rec_base_arg = d_rec_base;  // (offsets are global here: compact_multi_kernel subtracts the record's base)
+  }
 
   // ---- outputs: [values of every column | validity bitmaps of every column] per record --------------------------------------
-  const size_t n_cols = in[live[0]]->cols.size();
-  std::vector<FdbCompactCol> cols(nl * n_cols);
+  // (`rest`: the columns compact_multi_kernel writes — all of them, minus what the one-pass kernel has written already)
+  std::vector<int> rest;
+  for (size_t c = 0; c < n_cols; c++) if (fused_of[c] < 0) rest.push_back((int)c);
+  const size_t n_rest = rest.size();
+  std::vector<FdbCompactCol> cols(nl * std::max<size_t>(n_rest, 1));
   std::vector<FdbZeroRegion> regions;
   int64_t max_region = 0, any_selected = 0;
   // a column is compacted as nullable if ANY record of the launch has a bitmap for it (the kernel is specialised per column, not
@@ -2482,97 +2581,136 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
     scratch_.push_back(d_ones);
     hip_check(hipMemsetAsync(d_ones, 0xFF, ones_bytes, stream_), "hipMemsetAsync(all-valid bitmap)");
   }
+  struct Placed { void* values = nullptr; uint8_t* valid = nullptr; };
+  std::vector<Placed> placed(nl * n_cols);
+  std::vector<void*> repacked;  // worst-case blocks whose contents moved into the exact arena: back to the pool once the copies are done
   for (size_t k = 0; k < nl; k++) {
     const DeviceBatch& src = *in[live[k]];
     DeviceBatch& o = *out[(size_t)live[k]];
-    const int64_t total = (int64_t)(h_base[k + 1] - h_base[k]);
+    const int64_t total = totals[k];
     if (total < 0 || total > src.rows) throw Error(FDB_ERR_DEVICE, "internal: selection counts out of range");
     n_selected[live[k]] = total;
     o.rows = total;
     any_selected += total;
     stat_bytes += Rs[k].bytes;
     stat_rows += src.rows;
+    // the fused columns stay where the kernel put them unless most of the block is unused
+    const bool repack = !fused.empty() && total > 0 && (double)total < 0.4 * (double)src.rows;
     size_t bytes = 0, bits_at = 0;
-    std::vector<size_t> val_off(n_cols), bit_off(n_cols, 0);
+    std::vector<size_t> val_off(n_cols, 0), bit_off(n_cols, 0);
     for (size_t c = 0; c < n_cols; c++) {
+      if (fused_of[c] >= 0 && !repack) continue;
       val_off[c] = bytes;
       bytes += align_up((size_t)total * (src.cols[c].kind == ColKind::DICT ? 4 : 8) + kTailPad, 256);
     }
     bits_at = bytes;
     for (size_t c = 0; c < n_cols; c++)
       if (nullable[c]) { bit_off[c] = bytes; bytes += align_up(((size_t)total + 7) / 8 + kTailPad, 256); }
-    if (total > 0) {
+    if (total > 0 && bytes > 0) {
       o.arena = device_pool_alloc(device_, std::max<size_t>(bytes, 256));
-      o.arena_bytes = std::max<size_t>(bytes, 256);
+      o.arena_bytes += std::max<size_t>(bytes, 256);
       if (bytes > bits_at) { regions.push_back(FdbZeroRegion{(unsigned char*)o.arena + bits_at, (int64_t)(bytes - bits_at)}); max_region = std::max<int64_t>(max_region, (int64_t)(bytes - bits_at)); }
     }
+    if (!fused.empty() && (total == 0 || repack)) {  // the worst-case block is not part of the result
+      void* block = o.extra_arenas.back();
+      o.extra_arenas.pop_back();
+      size_t worst = 0;
+      for (size_t f = 0; f < fused.size(); f++) {
+        const int w = fused[f].wide ? 8 : 4;
+        if (repack) hip_check(hipMemcpyAsync((unsigned char*)o.arena + val_off[(size_t)fused[f].col], (unsigned char*)block + worst, (size_t)total * w, hipMemcpyDeviceToDevice, stream_), "hipMemcpyAsync(repack)");
+        worst += align_up((size_t)src.rows * w + kTailPad, 256);
+      }
+      o.arena_bytes -= worst;
+      repacked.push_back(block);
+    }
     for (size_t c = 0; c < n_cols; c++) {
-      FdbCompactCol& C = cols[k * n_cols + c];
+      Placed& P = placed[k * n_cols + c];
+      if (fused_of[c] >= 0 && !repack) {
+        // (fused columns sit in the block in `fused` order)
+        size_t at = 0;
+        for (int f = 0; f < fused_of[c]; f++) at += align_up((size_t)src.rows * (fused[(size_t)f].wide ? 8 : 4) + kTailPad, 256);
+        P.values = total > 0 ? (unsigned char*)o.extra_arenas.back() + at : nullptr;
+      } else {
+        P.values = total > 0 ? (unsigned char*)o.arena + val_off[c] : nullptr;
+      }
+      P.valid = total > 0 && nullable[c] ? (uint8_t*)o.arena + bit_off[c] : nullptr;
+    }
+    for (size_t r = 0; r < n_rest; r++) {
+      const size_t c = (size_t)rest[r];
+      FdbCompactCol& C = cols[k * n_rest + r];
       C.src = src.cols[c].d_values;
       C.width = src.cols[c].kind == ColKind::DICT ? 4 : 8;
       C.nullable = nullable[c];
       C.src_valid = nullable[c] ? (src.cols[c].d_validity != nullptr ? src.cols[c].d_validity : d_ones) : nullptr;
-      C.dst = total > 0 ? (unsigned char*)o.arena + val_off[c] : nullptr;
-      C.dst_valid = total > 0 && nullable[c] ? (uint8_t*)o.arena + bit_off[c] : nullptr;
+      C.dst = placed[k * n_cols + c].values;
+      C.dst_valid = placed[k * n_cols + c].valid;
     }
   }
-  std::vector<unsigned long long> h_nulls(nl * n_cols * 64, 0);
+  struct PoolFree { int dev; std::vector<void*>* v; ~PoolFree() { for (void* p : *v) device_pool_free(dev, p); } };
+  std::vector<unsigned long long> h_nulls(nl * std::max<size_t>(n_rest, 1) * 64, 0);
   int any_nullable = 0;
-  for (size_t c = 0; c < n_cols; c++) any_nullable |= nullable[c] ? 1 : 0;
-  if (any_selected > 0) {
-    // NULL counts and validity bitmaps exist only when some column has a bitmap: without one there is nothing to zero, count or copy back
-    unsigned long long* d_nulls = nullptr;
-    if (any_nullable) {
-      d_nulls = (unsigned long long*)ctx_->dev_alloc(h_nulls.size() * 8);
-      scratch_.push_back(d_nulls);
-      regions.push_back(FdbZeroRegion{d_nulls, (int64_t)(h_nulls.size() * 8)});
-      max_region = std::max<int64_t>(max_region, (int64_t)(h_nulls.size() * 8));
+  for (size_t r = 0; r < n_rest; r++) any_nullable |= nullable[(size_t)rest[r]] ? 1 : 0;
+  {
+    PoolFree pool_free{device_, &repacked};  // (after the wait at the end of this block: the repacking copies have read them)
+    if (any_selected > 0 && n_rest > 0) {
+      // NULL counts and validity bitmaps exist only when some column has a bitmap: without one there is nothing to zero, count or copy back
+      unsigned long long* d_nulls = nullptr;
+      if (any_nullable) {
+        d_nulls = (unsigned long long*)ctx_->dev_alloc(h_nulls.size() * 8);
+        scratch_.push_back(d_nulls);
+        regions.push_back(FdbZeroRegion{d_nulls, (int64_t)(h_nulls.size() * 8)});
+        max_region = std::max<int64_t>(max_region, (int64_t)(h_nulls.size() * 8));
+      }
+      const FdbCompactCol* d_cols = (const FdbCompactCol*)upload(cols.data(), cols.size() * sizeof(FdbCompactCol));
+      const FdbZeroRegion* d_regions = regions.empty() ? nullptr : (const FdbZeroRegion*)upload(regions.data(), regions.size() * sizeof(FdbZeroRegion));
+      // waves are dealt to the columns in proportion to their bytes per row (a wave stays on its column for the whole launch):
+      // 1.5 × the workgroups of 4 waves that are resident at once (a wave's share of tiles is fixed at launch: smaller shares even out
+      // the waves that finish late — measured 8 % faster than exactly-resident; handing tiles out dynamically, one ticket per tile or per
+      // 8 tiles on a per-column counter, was slower: 2.5 ms and 1.08 ms against 0.90), at least one wave per column, never more waves
+      // than a column has tiles
+      static const int env_per_cu = std::getenv("FDB_COMPACT_BLOCKS_PER_CU") ? std::atoi(std::getenv("FDB_COMPACT_BLOCKS_PER_CU")) : 0;  // (tuning aid)
+      const int64_t budget = (int64_t)(fdb_scan_default_grid(device_) / 2) * (env_per_cu > 0 ? env_per_cu : (fdb_compact_multi_blocks_per_cu(any_nullable) * 3 + 1) / 2) * 4;
+      int64_t weight_sum = 0;
+      for (size_t r = 0; r < n_rest; r++) weight_sum += cols[r].width;
+      std::vector<int32_t> wave_begin(n_rest + 1, 0);
+      for (size_t r = 0; r < n_rest; r++) {
+        int64_t share = std::max<int64_t>(1, budget * cols[r].width / std::max<int64_t>(weight_sum, 1));
+        share = std::min<int64_t>(share, total_tiles);
+        wave_begin[r + 1] = wave_begin[r] + (int32_t)share;
+      }
+      const int32_t* d_wave_begin = (const int32_t*)upload(wave_begin.data(), wave_begin.size() * 4);
+      timed([&] {
+        if (!regions.empty()) hip_check(fdb_launch_zero_regions(d_regions, (int)regions.size(), max_region, stream_), "zero launch");
+        hip_check(fdb_launch_compact_multi(d_recs, (int)nl, d_cols, (int)n_rest, any_nullable, d_wave_begin, wave_begin[n_rest], d_masks, d_offsets, d_rec_base_arg, total_tiles, d_nulls, stream_),
+                  "compact launch");
+      });
+      launches += any_nullable ? 2 : 1;
+      if (any_nullable) hip_check(hipMemcpyAsync(h_nulls.data(), d_nulls, h_nulls.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
     }
-    const FdbCompactCol* d_cols = (const FdbCompactCol*)upload(cols.data(), cols.size() * sizeof(FdbCompactCol));
-    const FdbZeroRegion* d_regions = regions.empty() ? nullptr : (const FdbZeroRegion*)upload(regions.data(), regions.size() * sizeof(FdbZeroRegion));
-    // waves are dealt to the columns in proportion to their bytes per row (a wave stays on its column for the whole launch):
-    // 1.5 × the workgroups of 4 waves that are resident at once (a wave's share of tiles is fixed at launch: smaller shares even out
-    // the waves that finish late — measured 8 % faster than exactly-resident; handing tiles out dynamically, one ticket per tile or per
-    // 8 tiles on a per-column counter, was slower: 2.5 ms and 1.08 ms against 0.90), at least one wave per column, never more waves
-    // than a column has tiles
-    static const int env_per_cu = std::getenv("FDB_COMPACT_BLOCKS_PER_CU") ? std::atoi(std::getenv("FDB_COMPACT_BLOCKS_PER_CU")) : 0;  // (tuning aid)
-    const int64_t budget = (int64_t)(fdb_scan_default_grid(device_) / 2) * (env_per_cu > 0 ? env_per_cu : (fdb_compact_multi_blocks_per_cu(any_nullable) * 3 + 1) / 2) * 4;
-    int64_t weight_sum = 0;
-    for (size_t c = 0; c < n_cols; c++) weight_sum += cols[c].width;
-    std::vector<int32_t> wave_begin(n_cols + 1, 0);
-    for (size_t c = 0; c < n_cols; c++) {
-      int64_t share = std::max<int64_t>(1, budget * cols[c].width / std::max<int64_t>(weight_sum, 1));
-      share = std::min<int64_t>(share, total_tiles);
-      wave_begin[c + 1] = wave_begin[c] + (int32_t)share;
-    }
-    const int32_t* d_wave_begin = (const int32_t*)upload(wave_begin.data(), wave_begin.size() * 4);
-    timed([&] {
-      if (!regions.empty()) hip_check(fdb_launch_zero_regions(d_regions, (int)regions.size(), max_region, stream_), "zero launch");
-      hip_check(fdb_launch_compact_multi(d_recs, (int)nl, d_cols, (int)n_cols, any_nullable, d_wave_begin, wave_begin[n_cols], d_masks, d_offsets, d_rec_base, total_tiles, d_nulls, stream_),
-                "compact launch");
-    });
-    if (any_nullable) hip_check(hipMemcpyAsync(h_nulls.data(), d_nulls, h_nulls.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   }
-  last_kernel_ = "fdb_flags_kernel + compact_multi_kernel";
-  stat_launches += (any_selected > 0 ? (any_nullable ? 4 : 3) : 2) + (two_level ? 1 : 0);
+  last_kernel_ = one_pass ? (n_rest > 0 ? "fdb_select_kernel + compact_multi_kernel" : "fdb_select_kernel") : "fdb_flags_kernel + compact_multi_kernel";
+  stat_launches += launches;
   for (size_t k = 0; k < nl; k++) {
     const DeviceBatch& src = *in[live[k]];
     DeviceBatch& o = *out[(size_t)live[k]];
     const int64_t total = o.rows;
     for (size_t c = 0; c < n_cols; c++) {
-      const FdbCompactCol& C = cols[k * n_cols + c];
+      const Placed& P = placed[k * n_cols + c];
+      const int width = src.cols[c].kind == ColKind::DICT ? 4 : 8;
       DevColumn& d = o.cols[c];
       d.length = total;
       unsigned long long nulls = 0;
-      for (int q = 0; q < 64; q++) nulls += h_nulls[(k * n_cols + c) * 64 + (size_t)q];
+      size_t r = 0;
+      for (; r < n_rest; r++) if ((size_t)rest[r] == c) break;
+      if (r < n_rest) for (int q = 0; q < 64; q++) nulls += h_nulls[(k * n_rest + r) * 64 + (size_t)q];
       d.null_count = (int64_t)nulls;
-      d.d_values = C.dst;
-      d.value_bytes = src.cols[c].kind == ColKind::BOOL ? (total + 7) / 8 : total * C.width;
-      if (C.dst_valid != nullptr && d.null_count > 0) { d.d_validity = C.dst_valid; d.validity_bytes = (total + 7) / 8; }
+      d.d_values = P.values;
+      d.value_bytes = src.cols[c].kind == ColKind::BOOL ? (total + 7) / 8 : total * width;
+      if (P.valid != nullptr && d.null_count > 0) { d.d_validity = P.valid; d.validity_bytes = (total + 7) / 8; }
       o.payload_bytes += d.value_bytes + d.validity_bytes;
       // algorithmic bytes of the compaction: every selected value read once and written once, validity likewise
-      stat_bytes += 2 * (total * C.width) + (src.cols[c].d_validity != nullptr ? 2 * ((total + 7) / 8) : 0);
+      stat_bytes += 2 * (total * width) + (src.cols[c].d_validity != nullptr ? 2 * ((total + 7) / 8) : 0);
     }
   }
   sync();

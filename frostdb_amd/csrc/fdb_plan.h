@@ -45,6 +45,7 @@ struct DeviceBatch {
   std::vector<DevColumn> cols;
   void* arena = nullptr;        // one allocation per record
   size_t arena_bytes = 0;
+  std::vector<void*> extra_arenas;  // filter() results: columns the one-pass kernel wrote before the row count was known (worst-case sized pool blocks)
   bool arena_borrowed = false;  // the arena is a piece of a plan's record slab (small pushed records): nothing to free here
   class Context* arena_ctx = nullptr;  // transient batches (fdb_plan_push): the arena is borrowed from the plan's block cache
   int64_t payload_bytes = 0;    // Σ value_bytes + validity_bytes

@@ -2040,7 +2040,7 @@ def test_filter_of_many_resident_records_in_one_launch_sequence_matches_the_orac
         outs = plan.FilterResidentMany(rbs)
         assert len(outs) == len(recs)
         kernel = plan.last_kernel()
-        assert ("fdb_flags_kernel" in kernel) == (variant == "specialised"), kernel
+        assert ("fdb_select_kernel" in kernel) == (variant == "specialised"), kernel
         for rec, rb, out in zip(recs, rbs, outs):
             want, idx = _oracle_filter(rec, filt)
             got = out.to_arrow()
@@ -2112,7 +2112,7 @@ def test_filter_batches_when_only_some_records_have_nulls_in_a_column(pp):
     rbs = [pp.ResidentBatch(r) for r in recs]
     try:
         outs = plan.FilterResidentMany(rbs)
-        assert "fdb_flags_kernel" in plan.last_kernel()
+        assert "fdb_select_kernel" in plan.last_kernel()
         for rec, out in zip(recs, outs):
             want, idx = _oracle_filter(rec, filt)
             got = out.to_arrow()
@@ -2554,3 +2554,94 @@ def test_and_is_lazy_like_the_reference(pp, variant):
             plan.Finish()
     finally:
         plan.Close()
+
+
+@pytest.mark.parametrize("case", ["value", "method", "method_and_code", "value_and_method", "timestamp"])
+@pytest.mark.parametrize("thresh", [-1.0, 250.0, 800.0, 2000.0])
+def test_filter_in_one_pass_over_the_filter_columns(pp, case, thresh, monkeypatch):
+    """fdb_select_kernel: the wave that evaluates a tile's predicate also places it (decoupled look-back inside the record, tiles handed
+    out by tickets) and writes the compacted values of the filter columns it holds — `value` alone (8 bytes: the whole LDS budget), one
+    or two dictionary columns without NULLs (4 + 4 bytes), `value` with a dictionary column that no longer fits, an int64 column — over
+    records from one row to many tiles, with thresholds that select everything (worst-case blocks kept), ≈ 75 % (kept), ≈ 20 %
+    (repacked into the exact arena) and nothing. Every output equals the oracle's filter() of its record and, bit for bit, what the
+    three-launch path (bitmap → prefix sums → compaction, FDB_SELECT_TWO_PASS) returns."""
+    rng = np.random.default_rng(7)
+    sizes = [1, 2047, 2048, 2049, 8192, 70_001, 0, 300_000, 2_100_000]
+    recs = []
+    for k, n in enumerate(sizes):
+        rec = make_prometheus_batch(rng, n, n_path=20 + k, null_frac=0.0 if k % 2 == 0 else 0.03) if n else make_prometheus_batch(rng, 1, n_path=3).slice(0, 0)
+        if case == "method_and_code":  # `labels.code` without NULLs in EVERY record, or it is not fused
+            ci = rec.schema.get_field_index("labels.code")
+            c = rec.column(ci)
+            rec = rec.set_column(ci, "labels.code", pa.DictionaryArray.from_arrays(pa.array(np.asarray(c.indices.fill_null(0)), type=pa.uint32()), c.dictionary))
+        recs.append(rec)
+    v = Col("value") > thresh
+    m = Or(Col("labels.method") == "GET", Col("labels.method") == "PUT", Col("labels.method") == "DELETE") if thresh < 2000 else (Col("labels.method") == "PATCH")
+    filt = {"value": v, "method": m, "method_and_code": And(m, Or(Col("labels.code") == "200", Col("labels.code") == "500")),
+            "value_and_method": And(v, m), "timestamp": Col("timestamp") > int(1_700_000_000_000 + 15_000 * (thresh / 1000.0) * 40_000)}[case]
+    results = {}
+    for passes in ("one", "two"):
+        if passes == "two":
+            monkeypatch.setenv("FDB_SELECT_TWO_PASS", "1")
+        else:
+            monkeypatch.delenv("FDB_SELECT_TWO_PASS", raising=False)
+        plan = pp.HashAggregatePlan(filt)
+        rbs = [pp.ResidentBatch(r) for r in recs]
+        try:
+            outs = plan.FilterResidentMany(rbs)
+            assert ("fdb_select_kernel" in plan.last_kernel()) == (passes == "one"), plan.last_kernel()
+            results[passes] = [o.to_arrow() for o in outs]
+            assert [o.num_rows for o in outs] == [t.num_rows for t in results[passes]]
+            for o in outs:
+                o.close()
+        finally:
+            plan.Close()
+            for r in rbs:
+                r.close()
+    for rec, one, two in zip(recs, results["one"], results["two"]):
+        want, idx = _oracle_filter(rec, filt)
+        assert one.num_rows == two.num_rows == len(idx), (case, thresh, rec.num_rows, one.num_rows, two.num_rows, len(idx))
+        assert one.equals(two)
+        if len(idx):
+            g = arrow_to_pydict(one)
+            for name in rec.schema.names:
+                assert g[name] == want[name], (case, thresh, rec.num_rows, name)
+
+
+def test_filter_in_one_pass_many_scans_at_once(pp):
+    """Eight threads, one plan each, filter() over the same resident records concurrently: every scan's tiles are handed out by its own
+    ticket counter and its look-back only ever waits for waves that already run, whatever else occupies the GPU; the contexts' control
+    blocks are re-used from call to call (a status word of an earlier launch carries an earlier epoch)."""
+    import threading
+    rng = np.random.default_rng(17)
+    recs = [make_prometheus_batch(rng, n, n_path=30, null_frac=0.02) for n in (400_000, 3, 1_000_001, 2048)]
+    rbs = [pp.ResidentBatch(r) for r in recs]
+    filt = Col("value") > 500.0
+    want = [_oracle_filter(r, filt) for r in recs]
+    errors = []
+
+    def chain(t):
+        try:
+            for rep in range(6):
+                plan = pp.HashAggregatePlan(filt)
+                try:
+                    outs = plan.FilterResidentMany(rbs)
+                    for (w, idx), o in zip(want, outs):
+                        assert o.num_rows == len(idx)
+                        if rep == 5:
+                            g = arrow_to_pydict(o.to_arrow())
+                            assert g["value"] == w["value"] and g["labels.path"] == w["labels.path"]
+                        o.close()
+                finally:
+                    plan.Close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=chain, args=(t,)) for t in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for r in rbs:
+        r.close()
+    assert not errors, errors

@@ -12,7 +12,8 @@
 #include "fdb_jit.h"
 
 int main(int argc, char** argv) {
-  if (argc > 1 && std::string(argv[1]) == "flags") {
+  if (argc > 1 && (std::string(argv[1]) == "flags" || std::string(argv[1]) == "select")) {
+    const bool select = std::string(argv[1]) == "select";
     // the selection-bitmap kernel of filter(): `value > T AND labels.code == <one of a few>` (an 8-byte compare + a dictionary truth table)
     fdb::JitShape s;
     s.block = 512; s.two_phase = true; s.lds_acc = false;
@@ -24,7 +25,8 @@ int main(int argc, char** argv) {
     s.leaves = {a, b, c};
     s.code = {0, 1, FDB_CODE_AND, 2, FDB_CODE_OR};
     if (argc > 2) { s.n_c4 = 0; s.leaves = {a}; s.code = {0}; }  // `value > T` alone (bench.py's select line)
-    std::fputs(fdb::jit_flags_source(s).c_str(), stdout);
+    if (select) { s.fuse8 = 1; if (argc > 3) s.fuse4 = 1; }  // the one-pass kernel: `value` (and the dictionary column) compacted by the predicate's own wave
+    std::fputs((select ? fdb::jit_select_source(s) : fdb::jit_flags_source(s)).c_str(), stdout);
     return 0;
   }
   const int n = argc > 1 ? std::atoi(argv[1]) : 32;
