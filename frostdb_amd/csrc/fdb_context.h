@@ -39,6 +39,7 @@ class Context {
   // The stream is idle between the calls of one filter() (it ends synchronised), which is what makes growing safe.
   unsigned long long* select_ctl(size_t words, uint32_t* epoch, unsigned long long* ticket_base, unsigned long long* arrival_base);
   void select_ctl_drawn(unsigned long long tickets, unsigned long long arrivals) { select_ticket_ += tickets; select_arrival_ += arrivals; }
+  void select_ctl_reset() { select_epoch_ = (1u << 24); }  // a launch gave up: the counters are not what the host thinks — the next select_ctl() clears the block
 
   // Small host→device tables (LUTs, slot maps): staged in pinned memory, shipped with one async copy each.
   void* stage(const void* host, size_t bytes);

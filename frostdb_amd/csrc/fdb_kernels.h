@@ -466,7 +466,8 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
 //    waves per CU overlap each other's load → stage → store phases): its lanes read their mask bits, find their output positions
 //    with wave prefix sums, scatter the selected values into the wave's LDS staging buffer and write the buffer to its place in the
 //    output with consecutive lanes writing consecutive elements. Rows keep their input order; nothing is gathered through an index
-//    vector. (A one-pass version with a decoupled look-back over tile totals was built and measured first: with an INTERPRETED
+//    vector. (Round 4: for predicates whose filter columns it can hold, steps 1-2 and the filter columns' own compaction are ONE generated
+//    kernel — FdbSelectArgs above. Round 2: a one-pass version with a decoupled look-back over tile totals was built and measured first: with an INTERPRETED
 //    predicate every tile pays its 8 dependent load round trips inside the look-back chain — 0.13 ms per 25 M rows for the selection
 //    vector alone, whatever the tile size, window or occupancy)
 #define FDB_COMPACT_BLOCK 256

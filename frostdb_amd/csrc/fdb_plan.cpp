@@ -2458,7 +2458,20 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
     // (the kernel numbers its outputs 8-byte slots first, then 4-byte slots, in slot order — the order they were tried in)
     for (const FusedCol& f : fused) { if (f.wide) shape.fuse8 |= 1 << f.slot; else shape.fuse4 |= 1 << f.slot; }
   }
-  hipFunction_t select_fn = two_pass_env ? nullptr : jit_select_kernel_get(shape);
+  // When it pays (MI355X, 100 M rows, 4 columns): `value > x` 0.86 → 0.79 ms of kernels; with a second, unfused filter column the
+  // kernel needs 145 registers (one workgroup per CU) and loses what the saved read gains (0.84 → 0.86), cfg 3's three dictionary
+  // leaves 0.94 → 1.00. So: every filter column the predicate reads values of is fused, and they are the full 8 bytes per row.
+  // ($FDB_SELECT_ONE_PASS: whenever the kernel can be built — tests, A/B)
+  bool one_pass_wanted = !two_pass_env;
+  if (one_pass_wanted && std::getenv("FDB_SELECT_ONE_PASS") == nullptr) {
+    int fused_bytes = 0, value_slots = 0;
+    for (const FusedCol& f : fused) fused_bytes += f.wide ? 8 : 4;
+    for (int i = 0; i < shape.n_c8; i++) value_slots += shape.c8[i].has_values ? 1 : 0;
+    for (int i = 0; i < shape.n_c4; i++) value_slots += shape.c4[i].has_values ? 1 : 0;
+    one_pass_wanted = fused_bytes == 8 && value_slots == (int)fused.size();
+  }
+  if (!one_pass_wanted) { fused.clear(); std::fill(fused_of.begin(), fused_of.end(), -1); shape.fuse4 = shape.fuse8 = 0; }
+  hipFunction_t select_fn = one_pass_wanted ? jit_select_kernel_get(shape) : nullptr;
   hipFunction_t flags_fn = select_fn == nullptr ? jit_flags_get(shape) : nullptr;
   if (select_fn == nullptr) { fused.clear(); std::fill(fused_of.begin(), fused_of.end(), -1); }
   if (select_fn == nullptr && flags_fn == nullptr) return per_record();
@@ -2535,7 +2548,7 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
     launches = 1;
     hip_check(hipMemcpyAsync(h_base, d_ctl + 1, (FDB_SELECT_CTL_WORDS - 1 + nl) * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(row counts)");
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (first host round trip: the other columns' outputs are allocated at their exact sizes)
-    if (h_base[0] != 0ull) throw Error(FDB_ERR_DEVICE, "internal: filter() look-back did not complete");
+    if (h_base[0] != 0ull) { ctx_->select_ctl_reset(); throw Error(FDB_ERR_DEVICE, "internal: filter() placement did not complete"); }
     for (size_t k = 0; k < nl; k++) totals[k] = (int64_t)h_base[FDB_SELECT_CTL_WORDS - 1 + k];
   } else {
     const int64_t n_blocks = (total_tiles + 1023) / 1024;

@@ -13,6 +13,9 @@ PASSES = {
     "cfg3": ("fdb_plan_kernel", "fdb_plan_kernel", 100_000_000, "python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline"),
     "cfg5": ("fdb_hash_kernel", "fdb_hash_kernel", 100_000_000, "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline"),
     "cfg5_sorted": ("fdb_hash_kernel", "fdb_hash_kernel(runs)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline"),
+    # filter(): a step is several kernels — the traffic of a step is the sum of their per-launch means (each runs once per step)
+    "select": (["fdb_select_kernel", "compact_multi_kernel", "zero_regions_kernel"], "fdb_select_kernel + compact_multi_kernel", 100_000_000,
+               "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select"),
 }
 
 
@@ -33,10 +36,19 @@ for d in glob.glob(os.path.join(src, "*", "kt")):
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
 for name, (rk, bk, rows, cmd) in PASSES.items():
-    fetch, nf = counter_mean(name, "fetch", rk)
-    write, nw = counter_mean(name, "write", rk)
-    if fetch is None or write is None:
-        continue
+    if isinstance(rk, list):
+        parts = [(counter_mean(name, "fetch", k), counter_mean(name, "write", k)) for k in rk]
+        parts = [(f, w) for f, w in parts if f[0] is not None and w[0] is not None]
+        if not parts:
+            continue
+        fetch, write = sum(f[0] for f, _ in parts), sum(w[0] for _, w in parts)
+        nf = min(f[1] for f, _ in parts)
+        rk = " + ".join(rk)
+    else:
+        fetch, nf = counter_mean(name, "fetch", rk)
+        write, nw = counter_mean(name, "write", rk)
+        if fetch is None or write is None:
+            continue
     out = {"kernel": bk, "rows": rows, "fetch_bytes_per_launch": fetch * 1024 * 2, "write_bytes_per_launch": write * 1024,
            "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate, no tracing; tools/profile_round.sh {tag}) of `{cmd}`, mean of {nf} launches of {rk}; "
                      "FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE KiB x 1024",

@@ -27,7 +27,7 @@ prof cfg1B "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-c
 prof cfg3 "python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline" fetch write
 prof cfg5 "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline" fetch write
 prof cfg5_sorted "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline" fetch write
-prof select "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select" ${PMC_SELECT:-}
+prof select "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select" fetch write
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete; du -sh $O
 timeout 150 python tools/step_probe.py 2>&1 | grep -v amdgpu > $O/step_probe_125M.txt
 timeout 150 python tools/step_probe.py 100000000 2>&1 | grep -v amdgpu > $O/step_probe_100M.txt
