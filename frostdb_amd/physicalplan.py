@@ -43,9 +43,10 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: run `python -m frostdb_amd.build` (hipcc, gfx950). There is no CPU fallback.")
-    L = ctypes.CDLL(LIB_PATH)
+    path = os.environ.get("FDB_LIB_PATH") or LIB_PATH  # (FDB_LIB_PATH: an instrumented build of the same library — tools/asan_gpu.sh)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -m frostdb_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(path)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     P = ctypes.POINTER
     L.fdb_version.restype = ctypes.c_char_p
