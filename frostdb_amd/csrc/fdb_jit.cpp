@@ -1259,6 +1259,37 @@ bool jit_shape_merge(JitShape* into, const JitShape& other) {
   return true;
 }
 
+// jit_shape(b) would merge into `into` (= the shape of `a`, possibly merged with others already): the comparison key(false) makes,
+// field by field on the argument blocks themselves — a scan of 40 records built 80 key strings for this (≈ 1 µs per record, on the
+// critical path in front of the launch) — and the merge of the validity flags.
+bool jit_shape_merge_args(JitShape* into, const FdbScanArgs& a, const FdbScanArgs& b, bool two_phase) {
+  if (a.lds_acc != b.lds_acc || a.need_count != b.need_count || a.n_c4 != b.n_c4 || a.n_c8 != b.n_c8) return false;
+  if (two_phase && (a.n_l4 != b.n_l4 || a.n_l8 != b.n_l8)) return false;
+  if ((a.lds_acc == 0 && a.cache_slots > 0) != (b.lds_acc == 0 && b.cache_slots > 0)) return false;
+  auto values_same = [](const FdbColSlot* x, const FdbColSlot* y, int n) { for (int i = 0; i < n; i++) if ((x[i].values != nullptr) != (y[i].values != nullptr)) return false; return true; };
+  if (!values_same(a.c4, b.c4, a.n_c4) || !values_same(a.c8, b.c8, a.n_c8)) return false;
+  if (two_phase && (!values_same(a.l4, b.l4, a.n_l4) || !values_same(a.l8, b.l8, a.n_l8))) return false;
+  if (a.n_leaves != b.n_leaves || a.n_code != b.n_code || a.n_gcols != b.n_gcols || a.n_aggs != b.n_aggs || a.n_expr != b.n_expr) return false;
+  for (int l = 0; l < a.n_leaves; l++) {
+    const FdbLeaf& x = a.leaves[l]; const FdbLeaf& y = b.leaves[l];
+    if (x.kind != y.kind || x.slot != y.slot || x.wide != y.wide) return false;
+    if (x.kind >= FDB_LEAF_CMP_I64 && x.kind <= FDB_LEAF_CMP_I64_F64 && x.op != y.op) return false;
+    if ((x.kind == FDB_LEAF_DICT_LUT && x.lut_lds != FDB_NO_LDS) != (y.kind == FDB_LEAF_DICT_LUT && y.lut_lds != FDB_NO_LDS)) return false;
+  }
+  if (std::memcmp(a.code, b.code, (size_t)a.n_code) != 0) return false;
+  for (int g = 0; g < a.n_gcols; g++)
+    if (a.gcols[g].slot != b.gcols[g].slot || (a.gcols[g].lut_lds != FDB_NO_LDS) != (b.gcols[g].lut_lds != FDB_NO_LDS)) return false;
+  for (int j = 0; j < a.n_aggs; j++)
+    if (a.aggs[j].func != b.aggs[j].func || a.aggs[j].type != b.aggs[j].type || a.aggs[j].slot != b.aggs[j].slot || a.aggs[j].expr != b.aggs[j].expr) return false;
+  for (int i = 0; i < a.n_expr; i++) {
+    const auto& x = a.expr[i]; const auto& y = b.expr[i];
+    if (x.kind != y.kind || x.op != y.op || x.left != y.left || x.right != y.right || x.slot != y.slot || x.type != y.type) return false;
+  }
+  auto merge = [](JitSlot* s, const FdbColSlot* y, int n) { for (int i = 0; i < n; i++) if (s[i].has_validity != (y[i].validity != nullptr ? 1 : 0)) s[i].has_validity = 2; };
+  merge(into->c4, b.c4, into->n_c4); merge(into->c8, b.c8, into->n_c8); merge(into->l4, b.l4, into->n_l4); merge(into->l8, b.l8, into->n_l8);
+  return true;
+}
+
 int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes) {
   int occ = 0;
   if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, block, lds_bytes) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 1; }

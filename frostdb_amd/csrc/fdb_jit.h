@@ -73,6 +73,8 @@ hipError_t jit_hash_launch(hipFunction_t fn, const FdbHashArgs& args, int grid, 
 JitShape jit_shape(const FdbScanArgs& a, bool two_phase, int block);
 // Folds `other` into `into` when the two differ at most in which slots carry validity bitmaps; false otherwise.
 bool jit_shape_merge(JitShape* into, const JitShape& other);
+// The same for the shape of argument block `b`, decided on the blocks themselves (`a`: the block `into` was made from): no JitShape, no key strings.
+bool jit_shape_merge_args(JitShape* into, const FdbScanArgs& a, const FdbScanArgs& b, bool two_phase);
 // Workgroups of `block` threads with `lds_bytes` of dynamic LDS that fit one CU (≥ 1).
 int jit_blocks_per_cu(hipFunction_t fn, int block, size_t lds_bytes);
 

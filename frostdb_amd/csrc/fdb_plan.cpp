@@ -1526,10 +1526,10 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     if (sub_tiles != 4 && ablate == 0 && lds_bytes <= 150 * 1024) {  // (gfx950: up to 160 KiB of LDS per workgroup)
       JitShape shape;
       bool same = true, first = true;
+      const FdbScanArgs& args0 = Rs[(size_t)live[0]].args;
       for (int i : live) {
-        const JitShape si = jit_shape(Rs[(size_t)i].args, two_phase != 0, jit_block ? jit_block : 256);
-        if (first) { shape = si; first = false; }
-        else if (!jit_shape_merge(&shape, si)) { same = false; break; }
+        if (first) { shape = jit_shape(args0, two_phase != 0, jit_block ? jit_block : 256); first = false; }
+        else if (!jit_shape_merge_args(&shape, args0, Rs[(size_t)i].args, two_phase != 0)) { same = false; break; }
       }
       if (!same && live.size() > 1 && jit_possible) {
         // Records of different shapes (schema drift: a filter column missing here, a predicate value absent from that part's
@@ -1573,6 +1573,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     if (jit_fn == nullptr && !interp_ok) slots_ok = false;
   }
 
+  pt.mark("kernel select");
   if (slots_ok) {
     // ---- one launch of the slot kernel (specialised or interpreting) over every record -------------------------------------
     if (jit_fn != nullptr) {
@@ -1584,6 +1585,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     const int64_t tile_rows = tile_rows_i;
     int64_t total_tiles = 0;
     std::vector<FdbScanArgs> parts;
+    parts.reserve(live.size());  // (3 KB apiece: no re-growing copies)
     for (int i : live) {
       FdbScanArgs& a = Rs[(size_t)i].args;
       a.tile_begin = total_tiles;
@@ -1607,6 +1609,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
       materialize_state();
     }
     trace("before scan");
+    pt.mark("parts build");
     const FdbScanArgs* d_parts = (const FdbScanArgs*)upload(parts.data(), parts.size() * sizeof(FdbScanArgs));
     ctx_->flush_staging();
     pt.mark("parts upload");
@@ -2399,9 +2402,8 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
       // (no `return per_record()` in here: the scope's destructor — which ends the deferral and ships what was staged — runs only
       // AFTER a return expression has been evaluated, and the per-record path stages LUTs of its own)
       if (assign_slots(*in[live[k]], R, 2, /*relaxed=*/true) == 0) { fallback = true; break; }
-      const JitShape si = jit_shape(a, true, 512);
-      if (k == 0) shape = si;
-      else if (!jit_shape_merge(&shape, si)) { fallback = true; break; }  // records of different predicate shapes (schema drift)
+      if (k == 0) shape = jit_shape(a, true, 512);
+      else if (!jit_shape_merge_args(&shape, Rs[0].args, a, true)) { fallback = true; break; }  // records of different predicate shapes (schema drift)
       // the flags kernel counts in workgroup shares of four tiles (all of one record), the other kernels in tiles
       const int64_t rec_tiles = (a.n_rows + FDB_COMPACT_TILE - 1) / FDB_COMPACT_TILE;
       a.out_tile_base = total_tiles;
