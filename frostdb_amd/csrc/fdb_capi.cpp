@@ -457,6 +457,12 @@ int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_bl
   return FDB_OK;
 }
 
+int fdb_plan_set_deterministic(fdb_plan* plan, int32_t enabled) {
+  if (!plan) return FDB_ERR_INVALID;
+  plan->plan.deterministic = enabled != 0;
+  return FDB_OK;
+}
+
 const char* fdb_plan_last_kernel(fdb_plan* plan) {
   if (!plan) return "";
   (void)guard(plan, [&] { plan->plan.settle(); });

@@ -269,15 +269,19 @@ struct Gen {
     o << "  extern __shared__ __align__(16) unsigned char smem[];\n  const uint32_t tid = threadIdx.x;\n  const uint32_t n_slots = c.n_slots;\n";
     o << "  if (c.fill_state != nullptr)  // (a fresh table: its identity fill rides on this launch, see FdbScanArgs)\n";
     o << "    for (uint32_t i = blockIdx.x * " << BLK << "u + tid; i < c.fill_words; i += gridDim.x * " << BLK << "u) c.fill_state[i] = c.fill_idents[i / c.fill_alloc];\n";
-    o << "  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(smem + c.lds_lut_bytes);\n";
-    o << "  unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + c.lds_lut_bytes + (((size_t)n_slots * 4 + 15) & ~(size_t)15));\n";
+    // (wave_tables: the same layout once per wave, TB bytes apart; a wave sees only its own)
+    o << "  const size_t TB = (((size_t)n_slots * 4 + 15) & ~(size_t)15) + (size_t)n_slots * 8 * (size_t)c.n_aggs;\n  (void)TB;\n";
+    const std::string tbl = s.wave_tables ? "smem + c.lds_lut_bytes + (size_t)(tid >> 6) * TB" : "smem + c.lds_lut_bytes";
+    o << "  uint32_t* l_cnt = reinterpret_cast<uint32_t*>(" << tbl << ");\n";
+    o << "  unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(" << tbl << " + (((size_t)n_slots * 4 + 15) & ~(size_t)15));\n";
     if (s.lds_acc) {
-      o << "  for (uint32_t i = tid; i < n_slots; i += " << BLK << ") l_cnt[i] = 0;\n";
+      const std::string i0 = s.wave_tables ? "(tid & 63u)" : "tid", step = s.wave_tables ? "64" : std::to_string(BLK);
+      o << "  for (uint32_t i = " << i0 << "; i < n_slots; i += " << step << ") l_cnt[i] = 0;\n";
       for (size_t j = 0; j < s.aggs.size(); j++) {
         const JitAgg& A = s.aggs[j];
         if (A.func == FDB_AGG_COUNT) continue;
         const char* ident = A.func == FDB_AGG_MIN ? "0x7FFFFFFFFFFFFFFFull" : A.func == FDB_AGG_MAX ? "0x8000000000000000ull" : "0ull";
-        o << "  for (uint32_t i = tid; i < n_slots; i += " << BLK << ") l_acc[(size_t)" << j << " * n_slots + i] = " << ident << ";\n";
+        o << "  for (uint32_t i = " << i0 << "; i < n_slots; i += " << step << ") l_acc[(size_t)" << j << " * n_slots + i] = " << ident << ";\n";
       }
     }
     if (s.cache) {
@@ -500,7 +504,27 @@ struct Gen {
       o << "  }\n";
     }
     // flush
-    if (s.lds_acc) {
+    if (s.lds_acc && s.wave_tables) {
+      // the waves' tables, added up in wave order: the workgroup's partial table (the fold kernel adds the workgroups' in workgroup order)
+      o << "  __syncthreads();\n  {\n    unsigned long long* out = c.partials + (size_t)blockIdx.x * (size_t)(1 + c.n_aggs) * n_slots;\n";
+      o << "    const unsigned char* t0 = smem + c.lds_lut_bytes;\n";
+      o << "    for (uint32_t i = tid; i < n_slots; i += " << BLK << ") {\n      unsigned long long n = 0;\n";
+      o << "      for (int w = 0; w < " << BLK / 64 << "; w++) n += reinterpret_cast<const uint32_t*>(t0 + (size_t)w * TB)[i];\n      out[i] = n;\n";
+      for (size_t j = 0; j < s.aggs.size(); j++) {
+        const JitAgg& A = s.aggs[j];
+        if (A.func == FDB_AGG_COUNT) continue;
+        const std::string at = "reinterpret_cast<const unsigned long long*>(t0 + (size_t)w * TB + (((size_t)n_slots * 4 + 15) & ~(size_t)15))[(size_t)" + std::to_string(j) + " * n_slots + i]";
+        if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) {
+          o << "      { double v = 0.0; for (int w = 0; w < " << BLK / 64 << "; w++) v += __longlong_as_double((long long)" << at << "); out[(size_t)" << (1 + j) << " * n_slots + i] = (unsigned long long)__double_as_longlong(v); }\n";
+        } else if (A.func == FDB_AGG_SUM) {
+          o << "      { unsigned long long v = 0; for (int w = 0; w < " << BLK / 64 << "; w++) v += " << at << "; out[(size_t)" << (1 + j) << " * n_slots + i] = v; }\n";
+        } else {
+          o << "      { long long v = " << (A.func == FDB_AGG_MIN ? "0x7FFFFFFFFFFFFFFFLL" : "(-0x7FFFFFFFFFFFFFFFLL - 1)") << "; for (int w = 0; w < " << BLK / 64 << "; w++) { const long long y = (long long)" << at
+            << "; v = " << (A.func == FDB_AGG_MIN ? "y < v" : "y > v") << " ? y : v; } out[(size_t)" << (1 + j) << " * n_slots + i] = (unsigned long long)v; }\n";
+        }
+      }
+      o << "    }\n  }\n";
+    } else if (s.lds_acc) {
       o << "  __syncthreads();\n";
       o << "  if (c.partials != nullptr) {\n    unsigned long long* out = c.partials + (size_t)blockIdx.x * (size_t)(1 + c.n_aggs) * n_slots;\n";
       o << "    for (uint32_t i = tid; i < n_slots; i += " << BLK << ") out[i] = (unsigned long long)l_cnt[i];\n";
@@ -1211,7 +1235,7 @@ struct HashGen {
 
 std::string JitShape::key(bool with_validity) const {
   std::ostringstream k;
-  k << "b" << block << "l" << lds_acc << "c" << need_count << "t" << two_phase << "r" << reg_slots << "h" << cache << "|";
+  k << "b" << block << "l" << lds_acc << "c" << need_count << "t" << two_phase << "r" << reg_slots << "h" << cache << (wave_tables ? "w" : "") << "|";
   auto slots = [&](const JitSlot* p, int n) { for (int i = 0; i < n; i++) k << (p[i].has_values ? 'v' : '-') << (with_validity ? p[i].has_validity : 0); k << '|'; };
   slots(c4, n_c4); slots(c8, n_c8); slots(l4, n_l4); slots(l8, n_l8);
   for (const JitLeaf& L : leaves) k << L.kind << ',' << L.slot << ',' << L.wide << ',' << (L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64 ? L.op : 0) << ',' << L.lut_in_lds << ';';

@@ -38,6 +38,10 @@ struct JitShape {
   // aggregate at the end; rows of other keys update the global table directly. Hot keys — which serialise on their cache
   // line in L2 when every row is a global atomic (sum by (path, instance): 11 ms per 50 M rows) — are first to get a place.
   bool cache = false;
+  // Reproducible float sums (fdb_plan_set_deterministic): every WAVE accumulates into an LDS table of its own — rows reach a table in
+  // program order, lane order inside an instruction — and the flush adds the waves' tables up in wave order; with shared tables the
+  // order in which the waves' LDS atomics interleave differs from run to run, and float64 addition is not associative.
+  bool wave_tables = false;
   // fdb_select_kernel only (not part of key()): early slots whose values the kernel compacts itself, bit i = slot i of c4 / c8
   int fuse4 = 0, fuse8 = 0;
   std::string key(bool with_validity = true) const;

@@ -1364,7 +1364,11 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     }
     if (want_hash) switch_to_hash();
   }
+  // reproducible float sums (fdb_plan_set_deterministic) exist on the dense path of the specialised kernel only
+  bool fixed_order = false;
+  if (deterministic) for (const AggState& A : aggs_) if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) fixed_order = true;
   if (mode_ == TableMode::HASH) {
+    if (fixed_order) throw Error(FDB_ERR_UNSUPPORTED, "deterministic float sums: this scan needs the hash table (too many groups or non-dictionary keys)");
     push_hash(bs, Rs, live);
     pt.mark("hash scan");
     return;
@@ -1464,7 +1468,13 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   int lds_acc = 0;
   size_t lds_bytes = lut_lds_max;
   int base_grid = grid_override > 0 ? grid_override : fdb_scan_default_grid(device_);
-  if (lut_lds_max + acc_bytes <= FDB_LDS_BUDGET) { lds_acc = 1; lds_bytes += acc_bytes; }
+  if (fixed_order) {
+    // a table per wave, 4 waves (256-thread workgroups); no combining cache, no interpreting or sequential kernel
+    if (!jit_possible || !slots_ok || !use_partials) throw Error(FDB_ERR_UNSUPPORTED, "deterministic float sums need the run-time specialised dense kernel");
+    if (lut_lds_max + 4 * acc_bytes > 150 * 1024) throw Error(FDB_ERR_UNSUPPORTED, "deterministic float sums: four per-wave tables of " + std::to_string(acc_bytes) + " bytes do not fit LDS");
+    lds_acc = 1; lds_bytes += 4 * acc_bytes;
+  }
+  else if (lut_lds_max + acc_bytes <= FDB_LDS_BUDGET) { lds_acc = 1; lds_bytes += acc_bytes; }
   else if (lut_lds_max + acc_bytes <= 150 * 1024) { lds_acc = 1; lds_bytes += acc_bytes; if (grid_override <= 0) base_grid /= 2; }
   // table too big for LDS: the specialised kernel gets a combining cache instead (JitShape::cache), ≤ 48 KiB per workgroup
   int cache_slots = 0;
@@ -1513,6 +1523,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   const int sub = sub_tiles == 4 ? 0 : sub_tiles;  // kernel variant mode (0 = default, 4 = interpreting kernel only)
   hipFunction_t jit_fn = nullptr;
   int jit_block = sub == 1 ? 512 : sub == 2 ? 256 : sub == 3 ? 1024 : 0;  // 0: picked by occupancy
+  if (fixed_order) jit_block = 256;
   if (slots_ok) {
     // records that fit the single-phase layout also fit the two-phase one: re-assign them if the launch is mixed
     for (int l : layouts) if (l == 2) two_phase = 1;
@@ -1556,6 +1567,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
         for (const AggState& A : aggs_) if (A.func != FDB_AGG_COUNT || final_stage_) regs_per_slot += 2;
         if (n_slots_ >= 1 && n_slots_ <= 8 && (int)n_slots_ * regs_per_slot <= 48) shape.reg_slots = (int)n_slots_;
       }
+      shape.wave_tables = fixed_order;
       if (same) {
         if (jit_block != 0) { jit_fn = jit_get(shape); if (jit_fn != nullptr) per_cu = jit_blocks_per_cu(jit_fn, jit_block, lds_bytes); }
         else {
@@ -1572,6 +1584,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     // plan holds, computed columns) falls back to the sequential kernel when specialisation is unavailable
     if (jit_fn == nullptr && !interp_ok) slots_ok = false;
   }
+  if (fixed_order && jit_fn == nullptr) throw Error(FDB_ERR_UNSUPPORTED, "deterministic float sums need the run-time specialised dense kernel (records of one shape, hiprtc available)");
 
   pt.mark("kernel select");
   if (slots_ok) {

@@ -273,6 +273,7 @@ class Plan {
   int ablate = 0;
   int sub_tiles = 0;  // kernel variant mode: 0 default, 1: 512 thr, 2: 256 thr, 3: 1024 thr, 4: interpreting kernel only (no plan specialisation)
   const char* last_kernel() const { return last_kernel_; }
+  bool deterministic = false;  // fdb_plan_set_deterministic: wave-private LDS tables, fixed-order folds; scans that cannot have them are refused
   bool use_partials = true;  // LDS mode: flush workgroup tables with plain stores + a fold kernel instead of atomics
   struct Resolved;  // per-batch kernel arguments (fdb_plan.cpp)
   void sync();      // waits for the plan's stream; timing events are read, scratch and consumed records go back to their caches

@@ -89,6 +89,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_set_timing.argtypes = [vp, i32]
     L.fdb_plan_stream.argtypes = [vp, P(vp)]
     L.fdb_plan_set_tuning.argtypes = [vp, i32, i32]
+    L.fdb_plan_set_deterministic.argtypes = [vp, i32]
     L.fdb_plan_state_arrays.argtypes = [vp, P(i32)]
     L.fdb_plan_state_array_op.argtypes = [vp, i32, P(i32)]
     L.fdb_plan_group_schema.argtypes = [vp, vp, vp]
@@ -506,6 +507,10 @@ class HashAggregatePlan:
 
     def set_tuning(self, rows_per_thread: int = 8, grid_blocks: int = 0) -> None:
         lib().fdb_plan_set_tuning(self.handle, rows_per_thread, grid_blocks)
+
+    def set_deterministic(self, enabled: bool = True) -> None:
+        """Reproducible float64 sums (fdb_plan_set_deterministic): the same pushes give the same bits on every run."""
+        self._check(lib().fdb_plan_set_deterministic(self.handle, 1 if enabled else 0))
 
     def last_kernel(self) -> str:
         """Name of the scan kernel the latest push launched (``fdb_plan_kernel`` = run-time specialised)."""

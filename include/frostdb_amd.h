@@ -455,6 +455,17 @@ int fdb_plan_stream(fdb_plan* plan, void** stream_out);
  * 4 / 8 = sequential kernel with that many rows per lane; grid_blocks bits 0-19 = persistent grid size (0 = default),
  * bits 25-27 = variant (1/2/3: 512/256/1024-thread workgroups, 4: interpreting kernels only, no run-time specialisation). */
 int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_blocks);
+/* Reproducible float sums. float64 addition is not associative and the default scan accumulates a workgroup's rows with LDS atomics
+ * whose interleaving across waves differs from run to run: SUM(float64) (and AVG, which is lowered to it) agrees with the reference
+ * to ~1e-12 relative but not bit for bit between two runs. With `enabled` every wave accumulates into an LDS table of its own, the
+ * tables are added up in wave order and the workgroups' tables in workgroup order (no atomics anywhere): the same records pushed in
+ * the same calls give the same bits on every run (NOT the reference's bits: it adds in row order, aggregate.go:822-840). Costs LDS
+ * (4 tables per workgroup: ~10 % on cfg 2). Only the dense path of the run-time specialised kernel has it: a scan that needs the
+ * hash table, the combining cache (table too big for LDS), the interpreting kernels or 4 tables that do not fit LDS answers
+ * FDB_ERR_UNSUPPORTED — from the call that launches it: the push, or for queued small host records a later push / Finish — when the
+ * plan has a float64 SUM. MIN / MAX / COUNT and integer sums are exact in every mode.
+ * The cross-GPU merges are not covered (a ring all-reduce adds in ring order). */
+int fdb_plan_set_deterministic(fdb_plan* plan, int32_t enabled);
 /* Name of the scan kernel the latest push launched ("fdb_plan_kernel" = the run-time specialised kernel,
  * "scan_slots_kernel" / "scan_dense_kernel" = the interpreting kernels, "scan_hash_kernel" = the hash-table path);
  * "" before the first push. The string is static. */

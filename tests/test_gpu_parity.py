@@ -2647,3 +2647,57 @@ def test_filter_in_one_pass_many_scans_at_once(pp):
     for r in rbs:
         r.close()
     assert not errors, errors
+
+
+def test_deterministic_float_sums_are_bit_identical_from_run_to_run(pp):
+    """fdb_plan_set_deterministic: SUM(float64) with a table per wave and fixed-order folds — the same records pushed in the same calls
+    give the same BITS on every run (20 runs; values spread over 12 orders of magnitude, so that a different order of additions shows),
+    within the usual tolerance of the oracle; MIN / MAX / COUNT ride along. Both table shapes: ≤ 8 slots (lane-private registers first)
+    and 1 000 groups in LDS, and no group-by at all. A scan that cannot have per-wave tables is refused (at the call that launches it), not
+    answered approximately."""
+    rng = np.random.default_rng(2026)
+    n = 600_000
+    recs = []
+    for k in range(3):
+        rec = make_prometheus_batch(rng, n, n_path=1000, null_frac=0.02)
+        v = rng.uniform(-1.0, 1.0, n) * np.power(10.0, rng.integers(-6, 7, n))
+        recs.append(rec.set_column(rec.schema.get_field_index("value"), "value", pa.array(v)))
+    aggs = [Sum(Col("value")), Min(Col("value")), Max(Col("value")), Count(Col("value"))]
+    filt = Col("labels.code") != "404"
+    for groups in ([Col("labels.path")], [Col("labels.method")], []):
+        keys = [g.name for g in groups]
+        cols = keys + [a.Name() for a in aggs]
+        want = run_oracle(recs, filt, aggs, groups)
+        first = None
+        for run in range(20):
+            plan = pp.HashAggregatePlan(filt, aggs, groups)
+            plan.set_deterministic(True)
+            rbs = [pp.ResidentBatch(r) for r in recs]
+            try:
+                plan.CallbackResident(rbs)
+                out = plan.Finish()
+                assert plan.last_kernel() == "fdb_plan_kernel"
+            finally:
+                plan.Close()
+                for r in rbs:
+                    r.close()
+            d = arrow_to_pydict(out)
+            if first is None:
+                assert_same_result(d, want, cols, float_cols=("sum(value)",))
+            bits = dict(d)
+            bits["sum(value)"] = np.asarray(d["sum(value)"], dtype=np.float64).view(np.uint64).tolist()
+            rows = rows_of(bits, cols)
+            if first is None:
+                first = rows
+            assert rows == first, (keys, run)
+    # refused, not approximated: 32 group columns need the hash table
+    from frostdb_amd import synth
+    wide = synth.cfg5_chunk(0, 0, 50_000, n_groups=10_000)
+    plan = pp.HashAggregatePlan(None, [Sum(Col("value"))], [DynCol("labels")])
+    plan.set_deterministic(True)
+    try:
+        with pytest.raises(pp.UnsupportedError):  # (a small host record is queued: the scan — and its refusal — happens at the latest at Finish)
+            plan.Callback(wide)
+            plan.Finish()
+    finally:
+        plan.Close()
