@@ -29,6 +29,34 @@ int main(int argc, char** argv) {
     std::fputs((select ? fdb::jit_select_source(s) : fdb::jit_flags_source(s)).c_str(), stdout);
     return 0;
   }
+  if (argc > 1 && std::string(argv[1]) == "plan") {
+    // the dense scan kernel of a cfg 2-like shape (`labels.code == X` + SUM(float64) [+ MIN / COUNT] GROUP BY labels.path):
+    //   plan [variant]   variant: lds (default) | wave (per-wave tables: fdb_plan_set_deterministic) | reg (≤ 8 slots in registers) | cache (table too big for LDS) | two (two-phase layout, 4 aggregates)
+    const std::string v = argc > 2 ? argv[2] : "lds";
+    fdb::JitShape s;
+    s.block = v == "wave" ? 256 : 512;
+    s.two_phase = v == "two";
+    s.lds_acc = v != "cache"; s.cache = v == "cache"; s.need_count = v == "two";
+    s.wave_tables = v == "wave";
+    if (v == "reg") s.reg_slots = 6;
+    fdb::JitLeaf a; a.kind = FDB_LEAF_DICT_BITS; a.slot = 0; a.wide = 0;
+    s.leaves = {a};
+    s.code = {0};
+    if (s.two_phase) {
+      s.n_c4 = 1; s.c4[0].has_values = true; s.c4[0].has_validity = 1;
+      s.n_l4 = 1; s.l4[0].has_values = true; s.l4[0].has_validity = 2;
+      s.n_l8 = 2; s.l8[0].has_values = true; s.l8[1].has_values = true;
+      s.gcols.push_back({0, true});
+      s.aggs = {{FDB_AGG_COUNT, FDB_T_I64, 1, 0}, {FDB_AGG_MIN, FDB_T_I64, 0, 0}, {FDB_AGG_MAX, FDB_T_I64, 0, 0}, {FDB_AGG_SUM, FDB_T_F64, 1, 0}};
+    } else {
+      s.n_c4 = 2; s.c4[0].has_values = true; s.c4[0].has_validity = 1; s.c4[1].has_values = true; s.c4[1].has_validity = 1;
+      s.n_c8 = 1; s.c8[0].has_values = true;
+      s.gcols.push_back({1, true});
+      s.aggs = {{FDB_AGG_SUM, FDB_T_F64, 0, 0}, {FDB_AGG_MIN, FDB_T_F64, 0, 0}};
+    }
+    std::fputs(fdb::jit_source(s).c_str(), stdout);
+    return 0;
+  }
   const int n = argc > 1 ? std::atoi(argv[1]) : 32;
   const int kinds = argc > 2 ? std::atoi(argv[2]) : 0;  // 1: make the last column an int64 key
   fdb::JitHashShape s;
