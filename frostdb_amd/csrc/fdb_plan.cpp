@@ -2611,7 +2611,16 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
   }
   struct Placed { void* values = nullptr; uint8_t* valid = nullptr; };
   std::vector<Placed> placed(nl * n_cols);
-  std::vector<void*> repacked;  // worst-case blocks whose contents moved into the exact arena: back to the pool once the copies are done
+  // worst-case blocks whose contents moved into the exact arena (or of records nothing was selected from): back to the pool once the
+  // repacking copies have read them — after the wait below, or, when an error unwinds from here on, after a wait of its own
+  struct PoolFree {
+    int dev; hipStream_t s; std::vector<void*> v; int n = std::uncaught_exceptions();
+    ~PoolFree() {
+      if (!v.empty() && std::uncaught_exceptions() > n) (void)hipStreamSynchronize(s);
+      for (void* p : v) device_pool_free(dev, p);
+    }
+  } pool_free{device_, stream_, {}};
+  std::vector<void*>& repacked = pool_free.v;
   for (size_t k = 0; k < nl; k++) {
     const DeviceBatch& src = *in[live[k]];
     DeviceBatch& o = *out[(size_t)live[k]];
@@ -2674,12 +2683,10 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
       C.dst_valid = placed[k * n_cols + c].valid;
     }
   }
-  struct PoolFree { int dev; std::vector<void*>* v; ~PoolFree() { for (void* p : *v) device_pool_free(dev, p); } };
   std::vector<unsigned long long> h_nulls(nl * std::max<size_t>(n_rest, 1) * 64, 0);
   int any_nullable = 0;
   for (size_t r = 0; r < n_rest; r++) any_nullable |= nullable[(size_t)rest[r]] ? 1 : 0;
   {
-    PoolFree pool_free{device_, &repacked};  // (after the wait at the end of this block: the repacking copies have read them)
     if (any_selected > 0 && n_rest > 0) {
       // NULL counts and validity bitmaps exist only when some column has a bitmap: without one there is nothing to zero, count or copy back
       unsigned long long* d_nulls = nullptr;
@@ -2716,6 +2723,8 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
       if (any_nullable) hip_check(hipMemcpyAsync(h_nulls.data(), d_nulls, h_nulls.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
     }
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    for (void* p : repacked) device_pool_free(device_, p);
+    repacked.clear();
   }
   last_kernel_ = one_pass ? (n_rest > 0 ? "fdb_select_kernel + compact_multi_kernel" : "fdb_select_kernel") : "fdb_flags_kernel + compact_multi_kernel";
   stat_launches += launches;
