@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -243,6 +244,9 @@ unsigned long long* Context::select_ctl(size_t want, uint32_t* epoch, unsigned l
     select_ticket_ = 0;
     select_arrival_ = 0;
   }
+  // (test hook: jump to the end of the 24-bit epoch range, so that the wrap — clear the block, start over — is exercised by a
+  // handful of calls instead of sixteen million)
+  if (std::getenv("FDB_TEST_SELECT_EPOCH_JUMP") != nullptr && select_epoch_ + 3 < (1u << 24) - 1u) select_epoch_ = (1u << 24) - 4u;
   *epoch = ++select_epoch_;
   *ticket_base = select_ticket_;
   *arrival_base = select_arrival_;

@@ -2701,3 +2701,31 @@ def test_deterministic_float_sums_are_bit_identical_from_run_to_run(pp):
             plan.Finish()
     finally:
         plan.Close()
+
+
+def test_filter_in_one_pass_survives_the_epoch_wrap(pp, monkeypatch):
+    """The one-pass kernel's control block is never cleared between launches: status and place words carry the 24-bit epoch of the
+    launch that wrote them. When the epochs run out the context clears the block and starts over — exercised here by jumping to the end
+    of the range (FDB_TEST_SELECT_EPOCH_JUMP) so that every few calls cross the wrap; every result still equals the oracle's."""
+    monkeypatch.setenv("FDB_TEST_SELECT_EPOCH_JUMP", "1")
+    rng = np.random.default_rng(5)
+    recs = [make_prometheus_batch(rng, n, n_path=12, null_frac=0.01) for n in (300_000, 9_000, 1_200_000)]
+    rbs = [pp.ResidentBatch(r) for r in recs]
+    filt = Col("value") > 420.0
+    want = [_oracle_filter(r, filt) for r in recs]
+    try:
+        for rep in range(9):
+            plan = pp.HashAggregatePlan(filt)
+            try:
+                outs = plan.FilterResidentMany(rbs)
+                assert "fdb_select_kernel" in plan.last_kernel()
+                for (w, idx), o in zip(want, outs):
+                    assert o.num_rows == len(idx), rep
+                    g = arrow_to_pydict(o.to_arrow())
+                    assert g["value"] == w["value"] and g["labels.code"] == w["labels.code"], rep
+                    o.close()
+            finally:
+                plan.Close()
+    finally:
+        for r in rbs:
+            r.close()
