@@ -395,6 +395,41 @@ int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, in
   });
 }
 
+int fdb_snappy_decode_pages(const uint8_t* src, int64_t src_bytes, const fdb_snappy_page* pages, int32_t n_pages, uint8_t* dst, int64_t dst_bytes,
+                            int device, uint32_t* status, double* kernel_ms) {
+  static_assert(sizeof(fdb_snappy_page) == sizeof(FdbSnappyPage), "fdb_snappy_page mirrors FdbSnappyPage");
+  return guard(nullptr, [&] {
+    if (n_pages < 0 || src_bytes < 0 || dst_bytes < 0 || (n_pages > 0 && (pages == nullptr || status == nullptr))) throw fdb::Error(FDB_ERR_INVALID, "snappy: bad arguments");
+    for (int32_t i = 0; i < n_pages; i++)  // every page stays inside the buffers (the kernel checks a page against its own lengths only)
+      if (pages[i].src_off > (uint64_t)src_bytes || pages[i].src_len > (uint64_t)src_bytes - pages[i].src_off || pages[i].dst_off > (uint64_t)dst_bytes ||
+          pages[i].dst_len > (uint64_t)dst_bytes - pages[i].dst_off)
+        throw fdb::Error(FDB_ERR_INVALID, "snappy: page " + std::to_string(i) + " lies outside the buffers");
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (n_pages == 0) return;
+    fdb::hip_check(hipSetDevice(device), "hipSetDevice");
+    struct Dev { void* p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } d_src, d_dst, d_pages, d_status;
+    struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } e0, e1;
+    const size_t pad = 64;  // (the kernel's 16-byte moves never start past a page's last byte, but may end up to 15 bytes behind it)
+    fdb::hip_check(hipMalloc(&d_src.p, (size_t)src_bytes + pad), "hipMalloc");
+    fdb::hip_check(hipMalloc(&d_dst.p, (size_t)dst_bytes + pad), "hipMalloc");
+    fdb::hip_check(hipMalloc(&d_pages.p, (size_t)n_pages * sizeof(FdbSnappyPage)), "hipMalloc");
+    fdb::hip_check(hipMalloc(&d_status.p, (size_t)n_pages * 4), "hipMalloc");
+    fdb::hip_check(hipMemcpy(d_src.p, src, (size_t)src_bytes, hipMemcpyHostToDevice), "hipMemcpy");
+    fdb::hip_check(hipMemcpy(d_pages.p, pages, (size_t)n_pages * sizeof(FdbSnappyPage), hipMemcpyHostToDevice), "hipMemcpy");
+    fdb::hip_check(hipEventCreate(&e0.e), "hipEventCreate");
+    fdb::hip_check(hipEventCreate(&e1.e), "hipEventCreate");
+    fdb::hip_check(hipEventRecord(e0.e, nullptr), "hipEventRecord");
+    fdb::hip_check(fdb_launch_snappy_decode((const uint8_t*)d_src.p, (const FdbSnappyPage*)d_pages.p, n_pages, (uint8_t*)d_dst.p, (uint32_t*)d_status.p, nullptr), "snappy launch");
+    fdb::hip_check(hipEventRecord(e1.e, nullptr), "hipEventRecord");
+    fdb::hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    float ms = 0.f;
+    fdb::hip_check(hipEventElapsedTime(&ms, e0.e, e1.e), "hipEventElapsedTime");
+    if (kernel_ms) *kernel_ms = (double)ms;
+    fdb::hip_check(hipMemcpy(status, d_status.p, (size_t)n_pages * 4, hipMemcpyDeviceToHost), "hipMemcpy");
+    if (dst_bytes > 0) fdb::hip_check(hipMemcpy(dst, d_dst.p, (size_t)dst_bytes, hipMemcpyDeviceToHost), "hipMemcpy");
+  });
+}
+
 int64_t fdb_batch_num_rows(const fdb_batch* batch) { return batch ? batch->b->rows : 0; }
 int64_t fdb_batch_device_bytes(const fdb_batch* batch) { return batch ? (int64_t)batch->b->arena_bytes : 0; }
 void fdb_batch_release(fdb_batch* batch) { delete batch; }

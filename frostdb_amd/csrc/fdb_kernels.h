@@ -528,6 +528,16 @@ struct FdbPqDeltaPage {
 };
 // dense[rank] = value for every non-NULL value of the column (one workgroup per page: unpack, add min_delta, block-wide inclusive
 // scan with the running total of the page carried from tile to tile; int64 arithmetic wraps like the reference's decoder).
+// Snappy block format (format_description.txt) → bytes, on the device: one wave per page. Elements are byte-serial inside a page
+// (every tag says where the next one starts and copies refer to output already produced), pages are independent: the wave parses the
+// tags out of an LDS window of the compressed stream — every lane the same bytes, LDS latency instead of a global round trip per
+// element — and all 64 lanes move the bytes of the element: literals from the stream, copies from the page's own output (a copy's
+// source lies wholly before its destination, byte i of an overlapping pattern comes from source byte i mod offset: no lane waits for
+// another). The page's most recent 64 KiB of output live in an LDS ring (what copies read and write: LDS latency per element instead
+// of a trip to HBM) and leave for HBM in 16 KiB segments. status[page]: 0 = ok, else what failed first (1 length preamble, 2 truncated
+// input, 3 output overrun, 4 bad offset, 5 output short of the announced length, 6 a copy from further back than the ring holds). Building block for page decompression in HBM: not yet on fdb_batch_from_parquet's path.
+struct FdbSnappyPage { uint64_t src_off; uint64_t dst_off; uint32_t src_len; uint32_t dst_len; };
+hipError_t fdb_launch_snappy_decode(const uint8_t* src, const FdbSnappyPage* pages, int32_t n_pages, uint8_t* dst, uint32_t* status, hipStream_t stream);
 hipError_t fdb_launch_pq_delta(const uint8_t* chunk, const FdbPqDeltaPage* pages, int32_t n_pages, const FdbPqDeltaMini* minis, unsigned long long* dense,
                                hipStream_t stream);
 // validity[w] = the 32 definition levels (max level 1) of rows 32w … 32w+31, counts[w] = popcount; rows ≥ n_rows are 0.

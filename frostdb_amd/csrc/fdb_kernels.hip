@@ -2120,6 +2120,154 @@ hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long lon
   return hipGetLastError();
 }
 
+// ---- Snappy pages → bytes (see fdb_kernels.h) ---------------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t SNAPPY_WIN = 2048;    // bytes of the compressed stream held in LDS
+constexpr uint32_t SNAPPY_RING = 65536;  // the page's most recent output, in LDS: what copies read (a compressor's matches stay inside its 64 KiB fragment)
+constexpr uint32_t SNAPPY_SEG = 16384;   // the ring goes to HBM a segment at a time, 16 bytes per lane
+struct __attribute__((packed, aligned(1))) SnappyChunk { unsigned long long a, b; };  // 16 bytes at any address
+typedef uint32_t snappy_u32x4 __attribute__((ext_vector_type(4)));
+
+// First version: copies read the page's output back from HBM — correct, and 0.56 µs per ELEMENT (a dependent global round trip each):
+// 11 MB/s per page of dictionary indices. Elements now touch LDS only: tags come out of the input window, copies read and write the
+// output ring, and the ring leaves for HBM in 16 KiB segments.
+__global__ __launch_bounds__(64) void snappy_decode_kernel(const uint8_t* __restrict__ src, const FdbSnappyPage* __restrict__ pages, const int n_pages,
+                                                           uint8_t* __restrict__ dst, uint32_t* __restrict__ status) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint8_t* const win = smem;                 // [SNAPPY_WIN]
+  uint8_t* const ring = smem + SNAPPY_WIN;   // [SNAPPY_RING]
+  const uint32_t lane = threadIdx.x;
+  for (int pg = blockIdx.x; pg < n_pages; pg += gridDim.x) {
+    const FdbSnappyPage P = pages[pg];
+    const uint8_t* in = src + P.src_off;
+    uint8_t* out = dst + P.dst_off;
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.src_len), cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.dst_len);
+    uint32_t base = 0xFFFFFFFFu, ip = 0, op = 0, flushed = 0, err = 0;
+    // bytes [at, at + 8) of the stream through the window (zeros past the end: the bounds are checked on ip, not here)
+    auto fetch = [&](const uint32_t at) -> unsigned long long {
+      if (base == 0xFFFFFFFFu || at < base || at + 8u > base + SNAPPY_WIN) {
+        __builtin_amdgcn_wave_barrier();
+        base = at;
+        const uint32_t i = lane * 32u;  // 64 lanes × 32 bytes = the window
+        SnappyChunk c0 = {0ull, 0ull}, c1 = {0ull, 0ull};
+        if ((unsigned long long)base + i + 32u <= n) { c0 = *reinterpret_cast<const SnappyChunk*>(in + base + i); c1 = *reinterpret_cast<const SnappyChunk*>(in + base + i + 16); }
+        else {
+          uint8_t t[32];
+          for (uint32_t k = 0; k < 32u; k++) t[k] = (unsigned long long)base + i + k < n ? in[base + i + k] : (uint8_t)0;
+          __builtin_memcpy(&c0, t, 16); __builtin_memcpy(&c1, t + 16, 16);
+        }
+        *reinterpret_cast<SnappyChunk*>(win + i) = c0; *reinterpret_cast<SnappyChunk*>(win + i + 16) = c1;
+        __builtin_amdgcn_wave_barrier();
+      }
+      unsigned long long v = 0;
+      const uint32_t o = at - base;
+#pragma unroll
+      for (int k = 0; k < 8; k++) v |= (unsigned long long)win[o + k] << (8 * k);
+      // every lane read the same bytes: say so, and the tag arithmetic and the branches on it run on the scalar unit
+      return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+    };
+    // ring → HBM: every segment that is complete (all == false), or everything up to op (the page's end)
+    auto flush = [&](const bool all) {
+      __builtin_amdgcn_wave_barrier();
+      while (flushed + SNAPPY_SEG <= op) {
+        const uint32_t r0 = flushed & (SNAPPY_RING - 1u);
+        for (uint32_t i = lane * 16u; i < SNAPPY_SEG; i += 64u * 16u) {
+          const snappy_u32x4 v = *reinterpret_cast<const snappy_u32x4*>(ring + r0 + i);
+          SnappyChunk c; __builtin_memcpy(&c, &v, 16);
+          *reinterpret_cast<SnappyChunk*>(out + flushed + i) = c;
+        }
+        flushed += SNAPPY_SEG;
+      }
+      if (all) { for (uint32_t i = flushed + lane; i < op; i += 64u) out[i] = ring[i & (SNAPPY_RING - 1u)]; flushed = op; }
+      __builtin_amdgcn_wave_barrier();
+    };
+    // preamble: the uncompressed length as a varint
+    {
+      unsigned long long len = 0;
+      const unsigned long long w = fetch(0);
+      int shift = 0, k = 0;
+      for (;; k++, shift += 7) {
+        if ((uint32_t)k >= n || k >= 5) { err = 1; break; }
+        const uint32_t b = (uint32_t)(w >> (8 * k)) & 0xFFu;
+        len |= (unsigned long long)(b & 0x7Fu) << shift;
+        if (!(b & 0x80u)) { k++; break; }
+      }
+      ip = (uint32_t)k;
+      if (!err && len != (unsigned long long)cap) err = 1;
+    }
+    while (err == 0 && ip < n) {
+      const unsigned long long w = fetch(ip);
+      const uint32_t tag = (uint32_t)w & 0xFFu;
+      if ((tag & 3u) == 0u) {  // literal
+        uint32_t l = (tag >> 2) + 1u, hdr = 1u;
+        if (l > 60u) {
+          const uint32_t extra = l - 60u;  // 1 … 4 length bytes
+          if (ip + 1u + extra > n) { err = 2; break; }
+          l = (uint32_t)((w >> 8) & (extra == 4u ? 0xFFFFFFFFull : ((1ull << (8u * extra)) - 1ull))) + 1u;
+          hdr = 1u + extra;
+          if (l == 0u) { err = 2; break; }  // (2^32: more than a page can hold)
+        }
+        if ((unsigned long long)ip + hdr + l > n) { err = 2; break; }
+        if ((unsigned long long)op + l > cap) { err = 3; break; }
+        const uint32_t from = ip + hdr;
+        if (from >= base && from + l <= base + SNAPPY_WIN) {  // short and already in the window
+          for (uint32_t i = lane; i < l; i += 64u) ring[(op + i) & (SNAPPY_RING - 1u)] = win[from - base + i];
+          op += l;
+        } else {  // from the stream in HBM, at most a segment at a time (the ring must not lap what has not been flushed)
+          uint32_t done = 0;
+          while (done < l) {
+            const uint32_t room = SNAPPY_RING - (op - flushed), take = l - done < room ? l - done : room;
+            const uint32_t body = take & ~15u;
+            for (uint32_t i = lane * 16u; i < body; i += 64u * 16u) {
+              const SnappyChunk c = *reinterpret_cast<const SnappyChunk*>(in + from + done + i);
+              uint8_t t[16]; __builtin_memcpy(t, &c, 16);
+              const uint32_t r = (op + i) & (SNAPPY_RING - 1u);
+              if ((r & 15u) == 0u) { snappy_u32x4 v; __builtin_memcpy(&v, t, 16); *reinterpret_cast<snappy_u32x4*>(ring + r) = v; }
+              else { for (uint32_t k = 0; k < 16u; k++) ring[(r + k) & (SNAPPY_RING - 1u)] = t[k]; }
+            }
+            for (uint32_t i = body + lane; i < take; i += 64u) ring[(op + i) & (SNAPPY_RING - 1u)] = in[from + done + i];
+            op += take; done += take;
+            if (op - flushed >= SNAPPY_SEG) flush(false);
+          }
+        }
+        ip += hdr + l;
+        if (op - flushed >= 2u * SNAPPY_SEG) flush(false);
+        continue;
+      }
+      uint32_t l, off, hdr;
+      if ((tag & 3u) == 1u) { hdr = 2u; l = 4u + ((tag >> 2) & 7u); off = ((tag >> 5) << 8) | ((uint32_t)(w >> 8) & 0xFFu); }
+      else if ((tag & 3u) == 2u) { hdr = 3u; l = (tag >> 2) + 1u; off = (uint32_t)(w >> 8) & 0xFFFFu; }
+      else { hdr = 5u; l = (tag >> 2) + 1u; off = (uint32_t)(w >> 8); }
+      if (ip + hdr > n) { err = 2; break; }
+      if (off == 0u || off > op) { err = 4; break; }
+      if (off > SNAPPY_RING - 64u) { err = 6; break; }  // further back than the ring remembers (no compressor emits it)
+      if ((unsigned long long)op + l > cap) { err = 3; break; }
+      {  // l ≤ 64: one byte per lane; a pattern shorter than the copy repeats (every source byte lies before op)
+        const uint32_t i = lane;
+        uint8_t v = 0;
+        if (i < l) v = ring[(op - off + (off >= l ? i : ((off & (off - 1u)) == 0u ? (i & (off - 1u)) : i % off))) & (SNAPPY_RING - 1u)];
+        __builtin_amdgcn_wave_barrier();
+        if (i < l) ring[(op + i) & (SNAPPY_RING - 1u)] = v;
+      }
+      ip += hdr; op += l;
+      if (op - flushed >= 2u * SNAPPY_SEG) flush(false);
+    }
+    if (err == 0 && op != cap) err = 5;
+    if (err == 0) flush(true);
+    if (lane == 0) status[pg] = err;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+}  // namespace
+
+hipError_t fdb_launch_snappy_decode(const uint8_t* src, const FdbSnappyPage* pages, int32_t n_pages, uint8_t* dst, uint32_t* status, hipStream_t stream) {
+  if (n_pages <= 0) return hipSuccess;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(snappy_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SNAPPY_WIN + SNAPPY_RING)); attr_set = true; }
+  hipLaunchKernelGGL(snappy_decode_kernel, dim3((unsigned)std::min<int32_t>(n_pages, 8192)), dim3(64), SNAPPY_WIN + SNAPPY_RING, stream, src, pages, (int)n_pages, dst, status);
+  return hipGetLastError();
+}
+
 hipError_t fdb_launch_pq_validity(const uint8_t* chunk, const FdbPqRun* def_runs, int32_t n_runs, int64_t n_rows, uint32_t* validity, uint32_t* counts,
                                   hipStream_t stream) {
   const int64_t n_words = (n_rows + 31) / 32;

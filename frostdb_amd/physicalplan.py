@@ -90,6 +90,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_stream.argtypes = [vp, P(vp)]
     L.fdb_plan_set_tuning.argtypes = [vp, i32, i32]
     L.fdb_plan_set_deterministic.argtypes = [vp, i32]
+    L.fdb_snappy_decode_pages.argtypes = [vp, i64, vp, i32, vp, i64, ctypes.c_int, vp, P(ctypes.c_double)]
     L.fdb_plan_state_arrays.argtypes = [vp, P(i32)]
     L.fdb_plan_state_array_op.argtypes = [vp, i32, P(i32)]
     L.fdb_plan_group_schema.argtypes = [vp, vp, vp]
@@ -540,3 +541,28 @@ def execute(records: Sequence, filter_expr: Optional[Expr], aggs: Sequence[Aggre
         return plan.Finish()
     finally:
         plan.Close()
+
+
+def snappy_decode_pages(pages: "list[bytes]", sizes: "list[int]", device: int = 0):
+    """Snappy-compressed pages → their bytes, inflated on the device (fdb_snappy_decode_pages; tests and measurement).
+    Returns (list of bytes — None for a page the decoder refused —, list of status codes, kernel milliseconds)."""
+    import numpy as np
+    n = len(pages)
+    src = b"".join(pages)
+    table = np.zeros((n, 3), dtype=np.uint64)  # src_off, dst_off, (src_len | dst_len << 32)
+    so = do = 0
+    for i, (p, z) in enumerate(zip(pages, sizes)):
+        table[i] = (so, do, len(p) | (int(z) << 32))
+        so += len(p); do += int(z)
+    dst = np.zeros(max(do, 1), dtype=np.uint8)
+    status = np.zeros(max(n, 1), dtype=np.uint32)
+    ms = ctypes.c_double(0.0)
+    srcb = np.frombuffer(src, dtype=np.uint8) if src else np.zeros(1, dtype=np.uint8)
+    rc = lib().fdb_snappy_decode_pages(srcb.ctypes.data, len(src), table.ctypes.data, n, dst.ctypes.data, do, device, status.ctypes.data, ctypes.byref(ms))
+    if rc != FDB_OK:
+        _raise(rc, (lib().fdb_last_error() or b"").decode("utf-8", "replace"))
+    out, at = [], 0
+    for i, z in enumerate(sizes):
+        out.append(bytes(dst[at:at + int(z)]) if status[i] == 0 else None)
+        at += int(z)
+    return out, [int(x) for x in status[:n]], ms.value

@@ -429,6 +429,17 @@ typedef struct fdb_parquet_chunk {
   int64_t n_bytes;         /* ColumnMetaData.total_compressed_size */
 } fdb_parquet_chunk;
 int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device, fdb_batch** out);
+/* Snappy pages inflated on the device (one wave per page, fdb_kernels.h snappy_decode_kernel) — the building block for pages that cross
+ * PCIe compressed (pqarrow/arrow.go:711-823 inflates them on the host; so does fdb_batch_from_parquet today). This entry
+ * point takes HOST buffers, for tests and measurement: `src` holds the compressed pages (pages[i] = {src_off, dst_off, src_len,
+ * dst_len}: where page i starts in `src`, where its bytes go in `dst`, its compressed and uncompressed sizes), they are copied to the
+ * device, decoded by ONE launch, and `dst` is copied back. status[i]: 0 = ok, 1 length preamble ≠ dst_len, 2 truncated input,
+ * 3 output overrun, 4 copy offset outside the output, 5 output shorter than announced, 6 a copy from more than 65 472 bytes back (the
+ * format allows it, no compressor emits it: matches stay inside a 64 KiB fragment) (a page that fails leaves its part of `dst`
+ * undefined; the others are unaffected). *kernel_ms (may be NULL): device time of the launch. */
+typedef struct fdb_snappy_page { uint64_t src_off; uint64_t dst_off; uint32_t src_len; uint32_t dst_len; } fdb_snappy_page;
+int fdb_snappy_decode_pages(const uint8_t* src, int64_t src_bytes, const fdb_snappy_page* pages, int32_t n_pages, uint8_t* dst, int64_t dst_bytes,
+                            int device, uint32_t* status, double* kernel_ms);
 
 /* ---- measurement hooks (bench.py / rocprof correlation; not needed by the Go shim) -------------- */
 /* Algorithmic bytes (values-or-indices + validity of every referenced column, once per
