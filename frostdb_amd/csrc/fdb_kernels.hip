@@ -2134,8 +2134,8 @@ typedef uint32_t snappy_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void snappy_decode_kernel(const uint8_t* __restrict__ src, const FdbSnappyPage* __restrict__ pages, const int n_pages,
                                                            uint8_t* __restrict__ dst, uint32_t* __restrict__ status) {
   extern __shared__ __align__(16) unsigned char smem[];
-  uint8_t* const win = smem;                 // [SNAPPY_WIN]
-  uint8_t* const ring = smem + SNAPPY_WIN;   // [SNAPPY_RING]
+  uint8_t* const win = smem;                      // [SNAPPY_WIN + 16]
+  uint8_t* const ring = smem + SNAPPY_WIN + 16;   // [SNAPPY_RING]
   const uint32_t lane = threadIdx.x;
   for (int pg = blockIdx.x; pg < n_pages; pg += gridDim.x) {
     const FdbSnappyPage P = pages[pg];
@@ -2159,10 +2159,12 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const uint8_t* __rest
         *reinterpret_cast<SnappyChunk*>(win + i) = c0; *reinterpret_cast<SnappyChunk*>(win + i + 16) = c1;
         __builtin_amdgcn_wave_barrier();
       }
-      unsigned long long v = 0;
-      const uint32_t o = at - base;
-#pragma unroll
-      for (int k = 0; k < 8; k++) v |= (unsigned long long)win[o + k] << (8 * k);
+      // 8 bytes at any offset out of three aligned words (the window has a word of slack behind it)
+      const uint32_t o = at - base, sh = (o & 3u) * 8u;
+      const uint32_t* w32 = reinterpret_cast<const uint32_t*>(win + (o & ~3u));
+      const uint32_t w0 = w32[0], w1 = w32[1], w2 = w32[2];
+      unsigned long long v = ((unsigned long long)w1 << 32) | w0;
+      if (sh != 0u) v = (v >> sh) | ((unsigned long long)w2 << (64u - sh));
       // every lane read the same bytes: say so, and the tag arithmetic and the branches on it run on the scalar unit
       return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
     };
@@ -2242,10 +2244,16 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const uint8_t* __rest
       if (off == 0u || off > op) { err = 4; break; }
       if (off > SNAPPY_RING - 64u) { err = 6; break; }  // further back than the ring remembers (no compressor emits it)
       if ((unsigned long long)op + l > cap) { err = 3; break; }
-      {  // l ≤ 64: one byte per lane; a pattern shorter than the copy repeats (every source byte lies before op)
+      {  // l ≤ 64: one byte per lane; a pattern shorter than the copy repeats (every source byte lies before op). off and l are
+         // wave-uniform: the three cases are BRANCHES (as one select the division of the rare case was paid by every element)
         const uint32_t i = lane;
+        uint32_t at = i;
+        if (off < l) {
+          if ((off & (off - 1u)) == 0u) at = i & (off - 1u);
+          else at = i % off;
+        }
         uint8_t v = 0;
-        if (i < l) v = ring[(op - off + (off >= l ? i : ((off & (off - 1u)) == 0u ? (i & (off - 1u)) : i % off))) & (SNAPPY_RING - 1u)];
+        if (i < l) v = ring[(op - off + at) & (SNAPPY_RING - 1u)];
         __builtin_amdgcn_wave_barrier();
         if (i < l) ring[(op + i) & (SNAPPY_RING - 1u)] = v;
       }
@@ -2263,8 +2271,8 @@ __global__ __launch_bounds__(64) void snappy_decode_kernel(const uint8_t* __rest
 hipError_t fdb_launch_snappy_decode(const uint8_t* src, const FdbSnappyPage* pages, int32_t n_pages, uint8_t* dst, uint32_t* status, hipStream_t stream) {
   if (n_pages <= 0) return hipSuccess;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(snappy_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SNAPPY_WIN + SNAPPY_RING)); attr_set = true; }
-  hipLaunchKernelGGL(snappy_decode_kernel, dim3((unsigned)std::min<int32_t>(n_pages, 8192)), dim3(64), SNAPPY_WIN + SNAPPY_RING, stream, src, pages, (int)n_pages, dst, status);
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(snappy_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SNAPPY_WIN + 16 + SNAPPY_RING)); attr_set = true; }
+  hipLaunchKernelGGL(snappy_decode_kernel, dim3((unsigned)std::min<int32_t>(n_pages, 8192)), dim3(64), SNAPPY_WIN + 16 + SNAPPY_RING, stream, src, pages, (int)n_pages, dst, status);
   return hipGetLastError();
 }
 
