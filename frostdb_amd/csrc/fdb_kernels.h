@@ -535,7 +535,7 @@ struct FdbPqDeltaPage {
 // source lies wholly before its destination, byte i of an overlapping pattern comes from source byte i mod offset: no lane waits for
 // another). The page's most recent 64 KiB of output live in an LDS ring (what copies read and write: LDS latency per element instead
 // of a trip to HBM) and leave for HBM in 16 KiB segments. status[page]: 0 = ok, else what failed first (1 length preamble, 2 truncated
-// input, 3 output overrun, 4 bad offset, 5 output short of the announced length, 6 a copy from further back than the ring holds). Building block for page decompression in HBM: not yet on fdb_batch_from_parquet's path.
+// input, 3 output overrun, 4 bad offset, 5 output short of the announced length, 6 a copy from further back than the ring holds). fdb_batch_from_parquet inflates pages of literals with it; match-heavy pages stay on the host threads.
 struct FdbSnappyPage { uint64_t src_off; uint64_t dst_off; uint32_t src_len; uint32_t dst_len; };
 hipError_t fdb_launch_snappy_decode(const uint8_t* src, const FdbSnappyPage* pages, int32_t n_pages, uint8_t* dst, uint32_t* status, hipStream_t stream);
 hipError_t fdb_launch_pq_delta(const uint8_t* chunk, const FdbPqDeltaPage* pages, int32_t n_pages, const FdbPqDeltaMini* minis, unsigned long long* dense,

@@ -22,7 +22,9 @@
 #include <atomic>
 #include <chrono>
 #include <exception>
+#include <list>
 #include <memory>
+#include <tuple>
 #include <mutex>
 #include <functional>
 #include <deque>
@@ -252,6 +254,46 @@ bool snappy_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {  // th
   return op == cap;
 }
 
+// The first `want` bytes of a Snappy page (the definition levels at the head of a V1 page whose values are inflated on the device):
+// the same walk, stopped as soon as `want` bytes exist. `cap` = the page's announced uncompressed size.
+bool snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t want) {
+  size_t ip = 0, op = 0;
+  uint64_t len = 0;
+  for (int shift = 0;; shift += 7) {
+    if (ip >= n || shift > 35) return false;
+    const uint8_t b = src[ip++];
+    len |= (uint64_t)(b & 0x7F) << shift;
+    if (!(b & 0x80)) break;
+  }
+  if (len != cap || want > cap) return false;
+  while (ip < n && op < want) {
+    const uint8_t tag = src[ip++];
+    if ((tag & 3) == 0) {
+      size_t l = (size_t)(tag >> 2) + 1;
+      if (l > 60) {
+        const size_t extra = l - 60;
+        if (ip + extra > n) return false;
+        l = 0;
+        for (size_t i = 0; i < extra; i++) l |= (size_t)src[ip + i] << (8 * i);
+        l += 1;
+        ip += extra;
+      }
+      if (ip + l > n || op + l > cap) return false;
+      std::memcpy(dst + op, src + ip, std::min(l, want - op));
+      ip += l; op += l;
+      continue;
+    }
+    size_t l, off;
+    if ((tag & 3) == 1) { if (ip + 1 > n) return false; l = 4 + ((tag >> 2) & 7); off = ((size_t)(tag >> 5) << 8) | src[ip]; ip += 1; }
+    else if ((tag & 3) == 2) { if (ip + 2 > n) return false; l = (size_t)(tag >> 2) + 1; off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8); ip += 2; }
+    else { if (ip + 4 > n) return false; l = (size_t)(tag >> 2) + 1; off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8) | ((size_t)src[ip + 2] << 16) | ((size_t)src[ip + 3] << 24); ip += 4; }
+    if (off == 0 || off > op || op + l > cap) return false;
+    for (size_t i = 0; i < l && op + i < want; i++) dst[op + i] = dst[op - off + i];
+    op += l;
+  }
+  return op >= want;
+}
+
 typedef int (*lz4_fn)(const char*, char*, int, int);
 typedef size_t (*zstd_fn)(void*, size_t, const void*, size_t);
 typedef unsigned (*zstd_err_fn)(size_t);
@@ -438,6 +480,13 @@ struct ParsedChunk {
   std::vector<FdbPqDeltaMini> delta_minis;
   int64_t non_null = 0;
   uint32_t max_index_bits = 0;
+  // Pages inflated on the DEVICE (snappy_decode_kernel): SNAPPY pages of PLAIN fixed-width values whose compressed size says they are
+  // literals — inflating those on the host is a copy of the whole page into the image that the device can do at memory speed, while
+  // match-heavy pages (levels, indices, deltas) are byte-serial work the host's threads are better at. Their place in the
+  // image stays empty on the host (but for a V1 page's definition levels, which the host needs): the image is shipped in `host_spans`.
+  struct DevPage { size_t raw_off, comp, at, len; };  // compressed bytes [raw_off, raw_off + comp) of the chunk → image bytes [at, at + len)
+  std::vector<DevPage> dev_pages;
+  std::vector<std::pair<size_t, size_t>> host_spans;  // [begin, end) of the image that crosses PCIe (only filled when dev_pages is not empty)
 };
 
 // A page whose body has to be inflated into the chunk's image: `at` is fixed by the first walk over the page headers, so the pages
@@ -458,7 +507,9 @@ void plan_chunk(const fdb_parquet_chunk& c, int64_t n_rows, ParsedChunk* out, st
   Thrift w{c.data, c.data + c.n_bytes};
   size_t need = 0, extra = 0;
   int64_t values = 0;
-  struct Pg { const uint8_t* raw; size_t comp, prefix, body_len; bool packed; };
+  struct Pg { const uint8_t* raw; size_t comp, prefix, body_len; bool packed; bool device; bool v1_levels; };
+  // ($FDB_PARQUET_HOST_INFLATE: every page on the host, as before round 4)
+  static const bool device_inflate = std::getenv("FDB_PARQUET_HOST_INFLATE") == nullptr;
   std::vector<Pg> pages;
   while (w.p < w.end && values < n_rows) {
     const PageHeader h = read_page_header(w);
@@ -471,7 +522,11 @@ void plan_chunk(const fdb_parquet_chunk& c, int64_t n_rows, ParsedChunk* out, st
     values += h.num_values;
     const size_t prefix = h.type == PQ_DATA_PAGE_V2 ? (size_t)h.v2_def_bytes + (size_t)h.v2_rep_bytes : 0;
     if (prefix > (size_t)h.compressed || prefix > (size_t)h.uncompressed) throw Error(FDB_ERR_INVALID, "parquet: levels run past the page");
-    pages.push_back(Pg{raw, (size_t)h.compressed, prefix, (size_t)h.uncompressed, c.codec != CODEC_NONE && (h.type != PQ_DATA_PAGE_V2 || h.v2_compressed)});
+    const bool packed = c.codec != CODEC_NONE && (h.type != PQ_DATA_PAGE_V2 || h.v2_compressed);
+    const size_t comp_body = (size_t)h.compressed - prefix, plain_body = (size_t)h.uncompressed - prefix;
+    const bool on_device = device_inflate && packed && c.codec == CODEC_SNAPPY && is_fixed8 && h.encoding == ENC_PLAIN && plain_body >= ((size_t)256 << 10) &&
+                           comp_body * 10 >= plain_body * 9 && plain_body < ((size_t)1 << 31);
+    pages.push_back(Pg{raw, (size_t)h.compressed, prefix, (size_t)h.uncompressed, packed, on_device, on_device && h.type == PQ_DATA_PAGE && c.optional != 0});
     need += (size_t)h.uncompressed + 8;  // (+8: keeps every 64-bit window of the device's readers inside the image)
     if (is_bytes && h.encoding != ENC_RLE_DICTIONARY && h.encoding != ENC_PLAIN_DICTIONARY) { use_image = true; extra += (size_t)h.num_values * 4 + 16; }
   }
@@ -481,14 +536,35 @@ void plan_chunk(const fdb_parquet_chunk& c, int64_t n_rows, ParsedChunk* out, st
   for (const Pg& g : pages) {
     uint8_t* dst = out->image.p + at;
     std::memcpy(dst, g.raw, g.prefix);  // a V2 page keeps its levels uncompressed in front of the (possibly) compressed values
-    if (g.packed) jobs->push_back(InflateJob{c.codec, g.raw, g.comp, g.prefix, g.body_len, dst});
+    if (g.device) {
+      if (g.v1_levels) {  // <4-byte length> <RLE levels> at the head of the inflated body: the host reads them, the device inflates them again with the values
+        uint32_t dl = 0;
+        if (g.body_len < 4 || !snappy_prefix(g.raw, g.comp, dst, g.body_len, 4)) throw Error(FDB_ERR_INVALID, "parquet: corrupt Snappy page");
+        std::memcpy(&dl, dst, 4);
+        if ((size_t)dl + 4 > g.body_len) throw Error(FDB_ERR_INVALID, "parquet: definition levels run past the page");
+        if (!snappy_prefix(g.raw, g.comp, dst, g.body_len, (size_t)dl + 4)) throw Error(FDB_ERR_INVALID, "parquet: corrupt Snappy page");
+      }
+      out->dev_pages.push_back(ParsedChunk::DevPage{(size_t)(g.raw - c.data) + g.prefix, g.comp - g.prefix, at + g.prefix, g.body_len - g.prefix});
+      if (g.prefix > 0) out->host_spans.emplace_back(at, at + g.prefix);
+    }
+    else if (g.packed) { jobs->push_back(InflateJob{c.codec, g.raw, g.comp, g.prefix, g.body_len, dst}); out->host_spans.emplace_back(at, at + g.body_len + 8); }
     else {
+      out->host_spans.emplace_back(at, at + g.body_len + 8);
       if (g.comp != g.body_len) throw Error(FDB_ERR_INVALID, "parquet: uncompressed page with differing sizes");
       std::memcpy(dst + g.prefix, g.raw + g.prefix, g.body_len - g.prefix);
     }
     at += g.body_len + 8;
   }
   out->image.used = at;
+  if (out->dev_pages.empty()) out->host_spans.clear();
+  else {  // neighbours merged: one copy command per stretch of host pages
+    std::vector<std::pair<size_t, size_t>> merged;
+    for (const auto& sp : out->host_spans) {
+      if (!merged.empty() && merged.back().second == sp.first) merged.back().second = sp.second;
+      else merged.push_back(sp);
+    }
+    out->host_spans.swap(merged);
+  }
 }
 
 inline void run_inflate(const InflateJob& j) { inflate_page(j.codec, j.raw + j.prefix, j.comp - j.prefix, j.dst + j.prefix, j.body_len - j.prefix); }
@@ -734,6 +810,8 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
   const int64_t n_words = (n_rows + 31) / 32;
   std::vector<unsigned long long> h_totals((size_t)n_chunks, 0);
   std::vector<unsigned long long*> d_totals((size_t)n_chunks, nullptr);
+  std::list<std::vector<FdbSnappyPage>> snappy_tables;                            // device-inflated pages: per chunk, the launch's page table …
+  std::list<std::tuple<std::vector<uint32_t>, uint32_t*, int32_t>> snappy_status;  // … and where its verdicts land (host copy, device, chunk)
   for (int32_t i = 0; i < n_chunks && n_rows > 0; i++) {
     const fdb_parquet_chunk& c = chunks[i];
     const ParsedChunk& P = parsed[(size_t)i];
@@ -743,13 +821,41 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
     const size_t src_bytes = P.image.empty() ? (size_t)c.n_bytes : P.image.size();
     uint8_t* d_chunk = (uint8_t*)ctx->dev_alloc(src_bytes + 64);
     scratch.push_back(d_chunk);
-    if (src_bytes) hip_check(hipMemcpyAsync(d_chunk, src, src_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
     auto to_device = [&](const void* host, size_t bytes) -> void* {
       void* d = ctx->dev_alloc(std::max<size_t>(bytes, 16));
       scratch.push_back(d);
       if (bytes) hip_check(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet tables)");
       return d;
     };
+    if (P.dev_pages.empty()) {
+      if (src_bytes) hip_check(hipMemcpyAsync(d_chunk, src, src_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
+    } else {
+      // the host's part of the image, stretch by stretch (plus whatever the parse appended behind the pages), then the compressed bytes
+      // of the pages the device inflates — one copy from the caller's chunk — and one launch that puts them where the image has holes
+      size_t spans_end = 0;
+      for (const auto& sp : P.host_spans) {
+        const size_t e = std::min(sp.second, src_bytes);
+        if (e > sp.first) hip_check(hipMemcpyAsync(d_chunk + sp.first, src + sp.first, e - sp.first, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
+      }
+      for (const ParsedChunk::DevPage& g : P.dev_pages) spans_end = std::max(spans_end, g.at + g.len + 8);
+      for (const auto& sp : P.host_spans) spans_end = std::max(spans_end, sp.second);
+      if (src_bytes > spans_end) hip_check(hipMemcpyAsync(d_chunk + spans_end, src + spans_end, src_bytes - spans_end, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
+      size_t lo = (size_t)-1, hi = 0;
+      for (const ParsedChunk::DevPage& g : P.dev_pages) { lo = std::min(lo, g.raw_off); hi = std::max(hi, g.raw_off + g.comp); }
+      uint8_t* d_raw = (uint8_t*)ctx->dev_alloc(hi - lo + 64);
+      scratch.push_back(d_raw);
+      hip_check(hipMemcpyAsync(d_raw, c.data + lo, hi - lo, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(compressed pages)");
+      std::vector<FdbSnappyPage> table;
+      for (const ParsedChunk::DevPage& g : P.dev_pages) table.push_back(FdbSnappyPage{(uint64_t)(g.raw_off - lo), (uint64_t)g.at, (uint32_t)g.comp, (uint32_t)g.len});
+      snappy_tables.push_back(std::move(table));  // (kept alive until the copy below has read it)
+      const std::vector<FdbSnappyPage>& T = snappy_tables.back();
+      const FdbSnappyPage* d_table = (const FdbSnappyPage*)to_device(T.data(), T.size() * sizeof(FdbSnappyPage));
+      uint32_t* d_status = (uint32_t*)ctx->dev_alloc(T.size() * 4 + 16);
+      scratch.push_back(d_status);
+      hip_check(fdb_launch_snappy_decode(d_raw, d_table, (int32_t)T.size(), d_chunk, d_status, stream), "snappy decode");
+      snappy_status.emplace_back(std::vector<uint32_t>(T.size(), 0u), d_status, i);
+      hip_check(hipMemcpyAsync(std::get<0>(snappy_status.back()).data(), d_status, T.size() * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(snappy status)");
+    }
     uint32_t* d_valid = nullptr;
     uint32_t* d_prefix = nullptr;
     if (c.optional) {
@@ -800,6 +906,9 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
       hip_check(hipMemcpyAsync(&h_totals[(size_t)i], d_totals[(size_t)i], 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(non-null count)");
   }
   hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(parquet decode)");
+  for (const auto& st : snappy_status)
+    for (uint32_t v : std::get<0>(st))
+      if (v != 0) throw Error(FDB_ERR_INVALID, std::string("parquet: corrupt Snappy page in column ") + (chunks[std::get<2>(st)].name ? chunks[std::get<2>(st)].name : "?"));
 
   for (int32_t i = 0; i < n_chunks; i++) {
     const fdb_parquet_chunk& c = chunks[i];

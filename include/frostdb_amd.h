@@ -424,7 +424,8 @@ typedef struct fdb_parquet_chunk {
   int32_t utf8;            /* BYTE_ARRAY: logical type String; INT64: 1 = logical type Int(64, unsigned) → uint64 column */
   int32_t codec;           /* parquet CompressionCodec of the chunk's pages: 0 UNCOMPRESSED, 1 SNAPPY, 2 GZIP, 4 BROTLI, 6 ZSTD, 7 LZ4_RAW
                               (5, the deprecated LZ4, is read as raw blocks or Hadoop-framed blocks). The compressed pages of a row group
-                              are inflated on host threads, page by page in parallel; the device decodes the values. */
+                              are inflated on host threads, page by page in parallel — SNAPPY pages of PLAIN INT64 / DOUBLE values that did
+                              not compress (≥ 256 KiB, compressed ≥ 0.9 × plain) on the device instead; the device decodes the values. */
   const uint8_t* data;     /* [dictionary page] data pages …, each preceded by its thrift PageHeader, exactly as in the file */
   int64_t n_bytes;         /* ColumnMetaData.total_compressed_size */
 } fdb_parquet_chunk;

@@ -275,3 +275,55 @@ def test_repeated_and_unmapped_columns_are_refused_precisely(pp):
             pp.ResidentBatch.from_parquet(chunks, rows)
         assert e.value.code == pp.FDB_ERR_UNSUPPORTED and why in str(e.value), str(e.value)
     assert pp.live_allocations()["device_blocks"] == 0
+
+
+@pytest.mark.parametrize("version", ["1.0", "2.0"])
+def test_literal_snappy_pages_are_inflated_on_the_device(pp, version, monkeypatch):
+    """SNAPPY pages of PLAIN float64 / int64 values that do not compress (random values: a page of literals, compressed size ≈ plain
+    size) of ≥ 256 KiB are inflated by the device's block decoder, the rest (levels, dictionary indices, DELTA pages, small pages)
+    on the host's threads as before: 1 MiB pages, optional columns with NULLs (V1: the definition levels sit INSIDE the compressed body:
+    the host inflates just them) and required ones, two row groups, next to compressible columns in the same row group. Bit-identical
+    to pyarrow's reader, and to what the all-host path (FDB_PARQUET_HOST_INFLATE) decodes."""
+    rng = np.random.default_rng(77)
+    n = 700_000
+    t = pa.table({
+        "labels.path": pa.array([b"/p%03d" % i for i in rng.integers(0, 300, n)], type=pa.binary()),
+        "timestamp": pa.array(1_700_000_000_000 + np.arange(n, dtype=np.int64) * 15),          # compressible: stays on the host
+        "noise_req": pa.array(rng.integers(-2**62, 2**62, n)),                                    # literals, required
+        "noise_opt": pa.array(rng.integers(-2**62, 2**62, n), mask=rng.random(n) < 0.1),          # literals, 10 % NULLs (bit-packed levels)
+        "value": pa.array(rng.uniform(0, 1000, n), mask=rng.random(n) < 0.001),                   # literals, rare NULLs (RLE + bit-packed levels)
+        "value_req": pa.array(rng.uniform(0, 1000, n)),
+    }, schema=pa.schema([pa.field("labels.path", pa.binary()), pa.field("timestamp", pa.int64(), nullable=False), pa.field("noise_req", pa.int64(), nullable=False),
+                         pa.field("noise_opt", pa.int64()), pa.field("value", pa.float64()), pa.field("value_req", pa.float64(), nullable=False)]))
+    data = write_parquet(t, compression="SNAPPY", data_page_version=version, data_page_size=1 << 20, row_group_size=400_000)
+    for rg in range(2):
+        chunks, rows = row_group_chunks(data, rg)
+        sizes = {c[0]: len(c[4]) for c in chunks}
+        assert sizes["value_req"] > 0.9 * rows * 8 and sizes["noise_opt"] > 0.8 * rows * 8 and sizes["timestamp"] < 0.7 * rows * 8  # (the file is what the test thinks it is)
+        monkeypatch.delenv("FDB_PARQUET_HOST_INFLATE", raising=False)
+        rb, want = decoded_equals_pyarrow(pp, data, rg)
+        dev = rb.to_arrow()
+        rb.close()
+        monkeypatch.setenv("FDB_PARQUET_HOST_INFLATE", "1")
+        rb2, _ = decoded_equals_pyarrow(pp, data, rg)
+        assert rb2.to_arrow().equals(dev)
+        rb2.close()
+    # a damaged literal page is still refused (by the device's decoder now): flip the page's length preamble
+    monkeypatch.delenv("FDB_PARQUET_HOST_INFLATE", raising=False)
+    chunks, rows = row_group_chunks(data, 0)
+    bad = []
+    for c in chunks:
+        if c[0] == "value_req":
+            b = bytearray(c[4])
+            b[len(b) // 2] ^= 0xFF  # inside some page's literal … harmless for the decoder (a literal byte) but …
+            b[40] ^= 0x7F           # … this one sits in the first page's header / preamble region
+            c = (c[0], c[1], c[2], c[3], bytes(b), c[5])
+        bad.append(c)
+    try:
+        rb = pp.ResidentBatch.from_parquet(bad, rows)
+        got = rb.to_arrow().column("value_req").to_numpy(zero_copy_only=False)
+        rb.close()
+        # (if the flipped byte happened to be a literal too, the decode succeeds with different values: also fine — it must not crash)
+        assert len(got) == rows
+    except pp.FdbError:
+        pass
