@@ -36,9 +36,16 @@ variants = [dict(), dict(compression="SNAPPY"), dict(compression="GZIP"), dict(c
             dict(data_page_version="2.0", compression="ZSTD"), dict(compression="BROTLI"),
             dict(use_dictionary=False, column_encoding={"labels.a": "DELTA_BYTE_ARRAY", "labels.b": "DELTA_LENGTH_BYTE_ARRAY", "ts": "DELTA_BINARY_PACKED"}),
             dict(use_dictionary=False, column_encoding={"labels.a": "DELTA_LENGTH_BYTE_ARRAY", "labels.b": "DELTA_BYTE_ARRAY"}, compression="SNAPPY", data_page_version="2.0")]
+# pages of literals, big enough for the device's Snappy decoder (fdb_parquet.cpp plan_chunk: ≥ 256 KiB, compressed ≥ 0.9 × plain): the
+# host prefix-decodes a V1 page's definition levels out of the compressed body (snappy_prefix) and leaves the values to the device
+nb = 70_000
+t_big = pa.table({"noise": pa.array(rng.integers(-2**62, 2**62, nb), mask=rng.random(nb) < 0.1), "value": pa.array(rng.random(nb), mask=rng.random(nb) < 0.001),
+                  "req": pa.array(rng.random(nb))}, schema=pa.schema([pa.field("noise", pa.int64()), pa.field("value", pa.float64()), pa.field("req", pa.float64(), nullable=False)]))
+variants += [dict(compression="SNAPPY", big=True), dict(compression="SNAPPY", data_page_version="2.0", big=True)]
 codes = {}; total = 0
 for kw in variants:
-    data = write_parquet(t, data_page_size=2048, **kw)
+    kw = dict(kw); big = kw.pop("big", False)
+    data = write_parquet(t_big if big else t, data_page_size=(512 << 10) if big else 2048, **kw)
     chunks, rows = row_group_chunks(data, 0)
     rc = call(chunks, rows); codes[rc] = codes.get(rc, 0) + 1   # unmutated: parses, then fails at the device
     for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 100):

@@ -11,6 +11,7 @@ hipError_t fdb_launch_pq_decode(int, const uint8_t*, const uint32_t*, const uint
 hipError_t fdb_launch_pq_delta(const uint8_t*, const FdbPqDeltaPage*, int32_t, const FdbPqDeltaMini*, unsigned long long*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t fdb_launch_exclusive_scan(uint32_t*, int64_t, uint32_t*, unsigned long long*, hipStream_t) { return hipErrorNotSupported; }
 hipError_t fdb_launch_validate_indices(const uint32_t*, const uint8_t*, int64_t, uint32_t, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t fdb_launch_snappy_decode(const uint8_t*, const FdbSnappyPage*, int32_t, uint8_t*, uint32_t*, hipStream_t) { return hipErrorNotSupported; }
 static thread_local std::string g_err;
 extern "C" const char* fdb_last_error(void) { return g_err.c_str(); }
 extern "C" int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n, int64_t rows, int device, fdb_batch** out) {
