@@ -615,19 +615,19 @@ struct Gen {
 
   // ---- filter() in one pass over the filter columns (Plan::filter_batches; FdbSelectArgs in fdb_kernels.h) ----------------------------
   // fdb_flags_kernel's row evaluation with three additions. (1) Work is handed out by a ticket counter, one ticket per workgroup share
-  // of four tiles: whatever a look-back waits for is then held by workgroups that already run, never by one the dispatcher has not
+  // of four tiles: whatever a workgroup waits for is then held by workgroups that already run, never by one the dispatcher has not
   // placed yet (several filter() scans, or scans of other plans, share the GPU). (2) The selected values of the fused slots are staged
   // in the wave's LDS region at their local positions while the predicate is evaluated — the values are in registers at that point,
-  // the filter column is not read again. (3) The workgroup publishes the count of its share, its first wave sums the counts of the
-  // shares in front of it inside the record (decoupled look-back), publishes the inclusive prefix, and every wave writes its staged
-  // values to their final place, consecutive lanes consecutive 16 bytes; tile offsets are left behind for compact_multi_kernel.
+  // the filter column is not read again. (3) The workgroup publishes the count of its share and learns the share's place — the
+  // exclusive prefix of the counts inside the record — from the launch's SCANNER (the workgroup that arrived first: see below);
+  // every wave then writes its staged values to their final place, consecutive lanes consecutive 16 bytes; tile offsets are left
+  // behind for compact_multi_kernel. The next share's loads are issued before the wait (`load` and `pred` are generated apart).
   // Geometry: 512-thread workgroups, a wave owns HALF a tile (1 024 rows = 4 steps → 8 KiB of LDS per 8-byte column and wave, 16 waves
-  // per CU). What the look-back costs is set by how many status words are "count only" at a time — everything evaluated within one
-  // look-back's duration — against how many one poll covers. A status per wave and 64 words per poll (the first version) left the
-  // nearest inclusive prefix thousands of words away: 0.2 ms of evaluation became 0.5. Hence ONE status per workgroup share (8 192
-  // rows, the waves' counts meet in LDS) and 256 words per poll (four loads per lane, one round trip). A workgroup publishes its
-  // count BEFORE it waits for anything: units that were placed one after the other by the same wave chained every unit of the
-  // launch behind its predecessor's look-back (measured: 43 ms).
+  // per CU). How the places are found went through four versions: a decoupled look-back with a status word per
+  // wave (every unit evaluated within one look-back's duration is "count only", the nearest inclusive prefix thousands of words away:
+  // 0.2 ms of evaluation became 0.5); one status per share and 256 words per poll (512 workgroups polling the same sixteen cache lines:
+  // the polls set the pace); a ticket per four shares (a wave that places one unit before it has counted the next chains the whole
+  // launch behind its predecessor: 43 ms — a workgroup publishes every count BEFORE it waits for anything); the scanner (0.30 ms).
   struct Fused { bool wide; int slot; size_t off; };
   static constexpr int kSelectBlock = 512, kSelectUnit = FDB_COMPACT_TILE / 2;
   std::vector<Fused> fused(size_t* per_wave) const {
