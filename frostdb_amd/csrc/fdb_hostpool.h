@@ -90,7 +90,7 @@ class HostPool {
 
 // memcpy of a big block split over the pool (one core moves ≈12 GB/s into pinned memory; a 65 536-row record is 1 MB per Callback).
 inline void parallel_memcpy(void* dst, const void* src, size_t bytes) {
-  static const size_t kPiece = std::getenv("FDB_COPY_PIECE_KB") ? (size_t)std::atoll(std::getenv("FDB_COPY_PIECE_KB")) << 10 : (size_t)192 << 10;  // (tuning aid)
+  static const size_t kPiece = std::getenv("FDB_COPY_PIECE_KB") ? (size_t)std::max<long long>(1, std::atoll(std::getenv("FDB_COPY_PIECE_KB"))) << 10 : (size_t)192 << 10;  // (tuning aid)
   if (bytes < 2 * kPiece) { std::memcpy(dst, src, bytes); return; }
   const size_t n = std::min<size_t>(8, bytes / kPiece);
   const size_t piece = ((bytes + n - 1) / n + 63) & ~(size_t)63;

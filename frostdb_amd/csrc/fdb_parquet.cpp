@@ -294,6 +294,41 @@ bool snappy_prefix(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_
   return op >= want;
 }
 
+// May the device's decoder take this Snappy page? It keeps the page's last 64 KiB of output in an LDS ring, so a copy that reaches
+// further back than that (offset > 65 472: legal Snappy — a 4-byte-offset element, or a block longer than 64 KiB as klauspost/compress
+// writes them for parquet-go, go.mod) is beyond it. Walks the element tags only (literals are skipped, nothing is copied): a page of
+// literals has a handful of them. A malformed stream also answers "no": the host's inflate then reports it.
+bool snappy_device_ok(const uint8_t* src, size_t n) {
+  size_t ip = 0;
+  for (int shift = 0;; shift += 7) {
+    if (ip >= n || shift > 35) return false;
+    if (!(src[ip++] & 0x80)) break;
+  }
+  while (ip < n) {
+    const uint8_t tag = src[ip++];
+    if ((tag & 3) == 0) {
+      size_t l = (size_t)(tag >> 2) + 1;
+      if (l > 60) {
+        const size_t extra = l - 60;
+        if (ip + extra > n) return false;
+        l = 0;
+        for (size_t i = 0; i < extra; i++) l |= (size_t)src[ip + i] << (8 * i);
+        l += 1;
+        ip += extra;
+      }
+      if (l > n - ip) return false;
+      ip += l;
+      continue;
+    }
+    size_t off;
+    if ((tag & 3) == 1) { if (ip + 1 > n) return false; off = ((size_t)(tag >> 5) << 8) | src[ip]; ip += 1; }
+    else if ((tag & 3) == 2) { if (ip + 2 > n) return false; off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8); ip += 2; }
+    else { if (ip + 4 > n) return false; off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8) | ((size_t)src[ip + 2] << 16) | ((size_t)src[ip + 3] << 24); ip += 4; }
+    if (off > 65472) return false;
+  }
+  return true;
+}
+
 typedef int (*lz4_fn)(const char*, char*, int, int);
 typedef size_t (*zstd_fn)(void*, size_t, const void*, size_t);
 typedef unsigned (*zstd_err_fn)(size_t);
@@ -525,7 +560,7 @@ void plan_chunk(const fdb_parquet_chunk& c, int64_t n_rows, ParsedChunk* out, st
     const bool packed = c.codec != CODEC_NONE && (h.type != PQ_DATA_PAGE_V2 || h.v2_compressed);
     const size_t comp_body = (size_t)h.compressed - prefix, plain_body = (size_t)h.uncompressed - prefix;
     const bool on_device = device_inflate && packed && c.codec == CODEC_SNAPPY && is_fixed8 && h.encoding == ENC_PLAIN && plain_body >= ((size_t)256 << 10) &&
-                           comp_body * 10 >= plain_body * 9 && plain_body < ((size_t)1 << 31);
+                           comp_body * 10 >= plain_body * 9 && plain_body < ((size_t)1 << 31) && snappy_device_ok(raw + prefix, comp_body);
     pages.push_back(Pg{raw, (size_t)h.compressed, prefix, (size_t)h.uncompressed, packed, on_device, on_device && h.type == PQ_DATA_PAGE && c.optional != 0});
     need += (size_t)h.uncompressed + 8;  // (+8: keeps every 64-bit window of the device's readers inside the image)
     if (is_bytes && h.encoding != ENC_RLE_DICTIONARY && h.encoding != ENC_PLAIN_DICTIONARY) { use_image = true; extra += (size_t)h.num_values * 4 + 16; }

@@ -1343,9 +1343,14 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   for (int i = 0; i < n; i++) if (bs[i]->rows > 0) live.push_back(i);
   if (live.empty()) return;
 
+  // reproducible float sums (fdb_plan_set_deterministic) exist on the dense path of the specialised kernel only
+  bool fixed_order = false;
+  if (deterministic) for (const AggState& A : aggs_) if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) fixed_order = true;
   // OrderedAggregate without a table: nothing accumulated yet (or already collecting runs) and the records fit the run kernel
+  // (not under fixed_order: groups that a wave or record boundary cuts into several runs are folded with atomics at Finish — such a
+  // scan goes on to the dense kernel, or to the explicit refusal below)
   if (ordered_ && ((mode_ == TableMode::DENSE && !state_dirty_ && h_table_ == nullptr) || !runs_.empty())) {
-    if (runs_wanted(bs, Rs, live)) {
+    if (!fixed_order && runs_wanted(bs, Rs, live)) {
       push_hash(bs, Rs, live, /*runs=*/true);
       pt.mark("run scan");
       return;
@@ -1364,9 +1369,6 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
     }
     if (want_hash) switch_to_hash();
   }
-  // reproducible float sums (fdb_plan_set_deterministic) exist on the dense path of the specialised kernel only
-  bool fixed_order = false;
-  if (deterministic) for (const AggState& A : aggs_) if (A.func == FDB_AGG_SUM && A.type == FDB_T_F64) fixed_order = true;
   if (mode_ == TableMode::HASH) {
     if (fixed_order) throw Error(FDB_ERR_UNSUPPORTED, "deterministic float sums: this scan needs the hash table (too many groups or non-dictionary keys)");
     push_hash(bs, Rs, live);

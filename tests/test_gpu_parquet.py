@@ -327,3 +327,62 @@ def test_literal_snappy_pages_are_inflated_on_the_device(pp, version, monkeypatc
         assert len(got) == rows
     except pp.FdbError:
         pass
+
+
+def _thrift_page_header_v1(n_values: int, uncompressed: int, compressed: int) -> bytes:
+    """PageHeader{1: type = DATA_PAGE, 2: uncompressed_page_size, 3: compressed_page_size, 5: DataPageHeader{1: num_values, 2: PLAIN, 3: RLE,
+    4: RLE}} in Thrift's compact protocol (field header = delta << 4 | type; i32 = zigzag varint)."""
+    def zz(v):
+        v = (v << 1) ^ (v >> 31)
+        out = bytearray()
+        while v >= 0x80:
+            out.append((v & 0x7F) | 0x80); v >>= 7
+        out.append(v)
+        return bytes(out)
+    inner = b"\x15" + zz(n_values) + b"\x15" + zz(0) + b"\x15" + zz(3) + b"\x15" + zz(3) + b"\x00"
+    return b"\x15" + zz(0) + b"\x15" + zz(uncompressed) + b"\x15" + zz(compressed) + b"\x2c" + inner + b"\x00"
+
+
+@pytest.mark.parametrize("how", ["four_byte_offset", "two_byte_offset_past_the_ring"])
+def test_snappy_pages_with_copies_from_far_back_take_the_host_path(pp, how, monkeypatch):
+    """A legal Snappy page the device's decoder cannot take: a copy that reaches further back than the 64 KiB of output it keeps
+    (offset > 65 472) — what a 4-byte-offset element does, or a block longer than 64 KiB as klauspost/compress's Snappy encoder writes
+    them for parquet-go (go.mod). `plan_chunk` walks the page's tags and leaves such a page to the host's inflate; the row group
+    loads, bit-identical to the values the page was built from (it used to be refused as corrupt)."""
+    rng = np.random.default_rng(5)
+    n = 60_000                                      # 480 000 bytes of PLAIN doubles: ≥ 256 KiB, and they do not compress
+    vals = rng.uniform(0, 1000, n)
+    far = 200_000 if how == "four_byte_offset" else 65_500
+    raw = bytearray(vals.tobytes())
+    at = 300_000
+    raw[at:at + 64] = raw[at - far:at - far + 64]   # 64 bytes repeated from `far` bytes back
+    want = np.frombuffer(bytes(raw), dtype=np.float64)
+
+    def literal(b):
+        out = bytearray()
+        for i in range(0, len(b), 65536):
+            piece = b[i:i + 65536]
+            l = len(piece) - 1
+            out += (bytes([l << 2]) if l < 60 else bytes([61 << 2]) + l.to_bytes(2, "little")) + piece
+        return bytes(out)
+    def varint(v):
+        out = bytearray()
+        while v >= 0x80:
+            out.append((v & 0x7F) | 0x80); v >>= 7
+        out.append(v)
+        return bytes(out)
+    copy = (bytes([(63 << 2) | 3]) + far.to_bytes(4, "little")) if how == "four_byte_offset" else (bytes([(63 << 2) | 2]) + far.to_bytes(2, "little"))
+    body = varint(len(raw)) + literal(bytes(raw[:at])) + copy + literal(bytes(raw[at + 64:]))
+    import pyarrow as _pa
+    assert _pa.decompress(body, decompressed_size=len(raw), codec="snappy").to_pybytes() == bytes(raw)  # (the page is what the test thinks it is)
+    chunk = _thrift_page_header_v1(n, len(raw), len(body)) + body
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("FDB_PARQUET_HOST_INFLATE", "1")
+        else:
+            monkeypatch.delenv("FDB_PARQUET_HOST_INFLATE", raising=False)
+        rb = pp.ResidentBatch.from_parquet([("value", 5, 0, False, chunk, "SNAPPY")], n)
+        got = rb.to_arrow().column("value").to_numpy(zero_copy_only=False)
+        rb.close()
+        assert got.tobytes() == want.tobytes()
+    assert pp.live_allocations()["device_blocks"] == 0

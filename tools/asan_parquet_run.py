@@ -76,4 +76,4 @@ for kw in variants:
         import time as _t; _t0 = _t.time(); rc = call(mut, random.choice([rows, rows, rows, rows - 1, rows + 5])); _dt = _t.time() - _t0
         if _dt > 2: print("slow call", round(_dt, 1), "s variant", kw, "victim", chunks[victim][0], "rc", rc, flush=True)
         codes[rc] = codes.get(rc, 0) + 1; total += 1
-print("runs", total, "return codes", codes)
+print("variants", len(variants), "runs", total, "return codes", codes)
