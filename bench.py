@@ -73,6 +73,7 @@ def parse_args(argv=None):
     ap.add_argument("--force-merge", action="store_true", help="run the RCCL merge path even with one rank (functional check on a 1-GPU box)")
     ap.add_argument("--torch-merge", action="store_true", help="merge through torch.distributed (frostdb_amd.distributed) instead of the C ABI's fdb_comm_*")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-parity", action="store_true", help="skip the oracle-vs-GPU comparison on the first resident record (checked.oracle)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg 3 / cfg 5 / select / host_records / parquet lines of the default run")
     ap.add_argument("--only-other", default="", help="comma-separated subset of other_configs to run (cfg3,cfg5,select,host_records,parquet)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=3.0)
@@ -299,6 +300,7 @@ class Workload:
                     self.sample = b
         self.t_gen = time.time() - t0
         self.hbm_bytes = sum(r.device_bytes for r in self.resident)
+        self.oracle_checked = None  # what bench.oracle_parity found for this workload (run once)
 
     def release(self):
         for r in self.resident:
@@ -436,6 +438,14 @@ def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_fini
             checked["against"] = ("numpy expectation: every group's aggregates (bench.py expected_cfg%d), summed over records%s; not the oracle" % (wl.config, " and ranks" if world > 1 else "")
                                   if wl.config in (2, 3) else "numpy expectation (row count and Σ value of every generated record) + group count bound; not the oracle")
     del out
+    # ---- the oracle on the same rows (world 1, rank 0): the first resident record (cfg 5: its first 2^19 rows) ----
+    if checked is not None and world == 1 and not args.host_records and not args.no_oracle_parity and wl.resident and wl.sample is not None and not wl.oracle_checked:
+        checked["oracle"] = oracle_parity(wl, max_rows=(1 << 19) if wl.config == 5 else None)
+        wl.oracle_checked = checked["oracle"]
+        checked["against"] = ("oracle (first resident record: %d rows, %d groups) + " % (checked["oracle"]["rows"], checked["oracle"]["groups"])) + checked["against"].replace("; not the oracle", "")
+    elif checked is not None and getattr(wl, "oracle_checked", None):
+        checked["oracle"] = wl.oracle_checked
+        checked["against"] = ("oracle (first resident record: %d rows, %d groups) + " % (checked["oracle"]["rows"], checked["oracle"]["groups"])) + checked["against"].replace("; not the oracle", "")
 
     if args.sweep:
         for rpt, grid in [(4, 512), (0, 0), (0, 1024), (0, 1024 | (1 << 24)), (0, 2048)]:
@@ -1050,6 +1060,71 @@ def main():
         comm.close()
     if merging:
         dist.destroy_process_group()
+
+
+def compare_with_oracle(wl, got, want):
+    """`got`: the GPU path's record, `want`: the oracle's, for the SAME input rows — group by group: row counts and int64 MIN / MAX
+    bit-exact, float64 sums within 1e-9 relative (BASELINE.json's contract). Returns the number of groups compared."""
+    import numpy as np
+    from frostdb_amd import synth
+    if wl.config == 5:
+        gi, wi = synth.cfg5_decode_group_ids(got), synth.cfg5_decode_group_ids(want)
+        go, wo = np.argsort(gi, kind="stable"), np.argsort(wi, kind="stable")
+        assert len(gi) == len(wi) and np.array_equal(gi[go], wi[wo]), "oracle parity: the group sets differ"
+        gs = got.column(got.num_columns - 1).to_numpy()[go]   # ("sum(value)"; an ordered partial stage names it "value")
+        ws = want.column(want.num_columns - 1).to_numpy()[wo]
+        assert np.allclose(gs, ws, rtol=1e-9, atol=0.0), "oracle parity: a group's sum differs by more than 1e-9 relative"
+        return int(len(gi))
+
+    def rows(rec):
+        key = rec.column(rec.schema.names.index("labels.path"))
+        key = key.dictionary_decode() if hasattr(key, "dictionary_decode") else key
+        cols = [rec.column(rec.schema.names.index(n)).to_pylist() for n in rec.schema.names if n != "labels.path"]
+        names = [n for n in rec.schema.names if n != "labels.path"]
+        return {k: dict(zip(names, v)) for k, v in zip([x if not isinstance(x, str) else x.encode() for x in key.to_pylist()], zip(*cols))}
+    g, w = rows(got), rows(want)
+    assert g.keys() == w.keys(), "oracle parity: the group sets differ"
+    for k, wv in w.items():
+        for n, x in wv.items():
+            y = g[k][n]
+            if isinstance(x, float):
+                assert math.isclose(y, x, rel_tol=1e-9), (k, n, y, x)
+            else:
+                assert y == x, (k, n, y, x)
+    return len(w)
+
+
+def oracle_parity(wl, max_rows=None):
+    """oracle/ (the reference's algorithm restated on the CPU — the checker) and the timed GPU path on the SAME rows: the first
+    resident record of the workload (`max_rows`: its first rows only — cfg 5's final stage walks the whole group map per group
+    column like aggregate.go:586-590 and takes ≈ 20 µs per group). Returns what goes into the line's `checked.oracle`."""
+    from frostdb_amd import physicalplan as pp
+    import oracle  # noqa: F401
+    from oracle import OracleBatch, OraclePlan
+    sample = wl.sample if max_rows is None or max_rows >= wl.sample.num_rows else wl.sample.slice(0, max_rows)
+    rb = wl.resident[0] if sample.num_rows == wl.sample.num_rows else pp.ResidentBatch(sample, device=wl.device)
+    try:
+        plan = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=wl.device, desc=wl.desc)
+        plan.CallbackResident([rb])
+        got = plan.Finish()
+        plan.Close()
+    finally:
+        if rb is not wl.resident[0]:
+            rb.close()
+    threads, bs, n = os.cpu_count() or 1, 65536, sample.num_rows
+    batches = [OracleBatch.from_arrow(sample.slice(o, min(bs, n - o))) for o in range(0, n, bs)]
+    oplan = OraclePlan(wl.filt, wl.aggs, wl.groups, nchains=threads)
+    t = time.perf_counter()
+    res = oplan.execute(batches, threads)
+    dt = time.perf_counter() - t
+    want = res.to_arrow()
+    res.close(); oplan.close()
+    for b in batches:
+        b.close()
+    n_groups = compare_with_oracle(wl, got, want)
+    return {"rows": n, "groups": n_groups, "oracle_s": round(dt, 3),
+            "what": "oracle.OraclePlan.execute over the %s of the first resident record vs. the GPU path on the same rows: group sets equal, "
+                    "counts / int64 MIN / MAX bit-exact, float64 sums within 1e-9 relative" % ("whole" if n == wl.sample.num_rows else "first %d rows" % n)}
 
 
 def cpu_baseline(sample, filt, aggs, groups, target_seconds):

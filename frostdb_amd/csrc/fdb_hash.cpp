@@ -253,7 +253,12 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     // The run-time specialised kernel for this record's shape (fdb_jit.cpp), or the interpreting scan_hash_kernel
     hipFunction_t jit_fn = nullptr;
     int jit_grid = 0;
-    if (runs) h.runs.tuples = (unsigned char*)(uintptr_t)1;  // (the shape is that of a runs launch; the real pointers follow below)
+    if (runs) {  // (the shape is that of a runs launch; the real pointers follow below)
+      h.runs.tuples = (unsigned char*)(uintptr_t)1;
+      const bool narrow = runs_narrow_ok(R);
+      h.runs.run_words = narrow ? 0 : h_key_words_ + 4;
+      h.runs.stage_cap = narrow ? FDB_RUN_STAGE : FDB_RUN_WAVE_LDS / (h.runs.run_words * 4);
+    }
     const size_t run_lds = runs ? (size_t)4 * FDB_RUN_WAVE_LDS : 0;
     if (sub_tiles != 4 && a.lds_lut_bytes <= FDB_LDS_BUDGET) {
       JitHashShape shape = jit_hash_shape(h, hcols.data());
@@ -280,7 +285,8 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       seg.n_entries = n_tiles * 4;
       const int64_t n_chunks = b.rows / (FDB_RUN_CHUNK - 256) + launch_grid * 4 + 2;  // a wave abandons < 256 slots when it changes chunks and keeps one chunk open
       seg.capacity = n_chunks * FDB_RUN_CHUNK;
-      const size_t tuples_bytes = align_up_sz((size_t)seg.capacity * FDB_RUN_BYTES, 256);
+      seg.run_words = h.runs.run_words;
+      const size_t tuples_bytes = align_up_sz((size_t)seg.capacity * (seg.run_words ? (size_t)seg.run_words * 4 : (size_t)FDB_RUN_BYTES), 256);
       const size_t dir_bytes = align_up_sz((size_t)seg.n_entries * 8, 256);
       seg.block = ctx_->dev_alloc(tuples_bytes + dir_bytes + 256);
       unsigned char* base = (unsigned char*)seg.block;
@@ -294,7 +300,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
       hip_check(jit_hash_launch(jit_fn, h, (int)launch_grid, a.lds_lut_bytes + run_lds, stream_), "run scan launch");
-      last_kernel_ = "fdb_hash_kernel(runs)";
+      last_kernel_ = seg.run_words ? "fdb_hash_kernel(runs, wide)" : "fdb_hash_kernel(runs)";
       if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
       state_dirty_ = true;
       stat_launches += 1;
@@ -534,7 +540,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
     x.phys = runs->phys; x.flags = runs->flags; x.out_idx = runs->out_idx; x.n_runs = runs->n_runs;
     x.dense_keys = a.dense_keys; x.vals_cnt = d_vals[0]; x.vals_acc = d_vals[1];
     x.n_cols = (int)n_cols; x.key_words = h_key_words_; x.func = runs_func();
-    for (size_t c = 0; c < n_cols; c++) x.col_word[c] = gcols_[c].word;
+    for (size_t c = 0; c < n_cols && c < FDB_RUN_TUPLE_BYTES; c++) x.col_word[c] = gcols_[c].word;
     // groups made of several runs (cut by a wave or record boundary) are folded with atomics: identity first
     hip_check(hipMemsetAsync(d_vals[0], 0, (size_t)n * 8, stream_), "hipMemsetAsync(counts)");
     hip_check(fdb_launch_fill_u64(d_vals[1], (int64_t)n, x.func == 3 ? (unsigned long long)FDB_I64_MAX : x.func == 4 ? (unsigned long long)FDB_I64_MIN : 0ull, stream_), "fill identity");
@@ -1020,22 +1026,34 @@ void Plan::merge_hash(Plan& src) {
 
 // ---- table-free OrderedAggregate: the run store (fdb_plan.h: RunSegment; fdb_kernels.h "run store") ---------------------------------
 
-// May the records of this push go through the run kernel? One aggregation that is not a composite, every group column a dictionary
-// column of ≤ 255 distinct values (a key id is one byte of a run's tuple), at most FDB_RUN_TUPLE_BYTES of them, every record
-// carrying all of the plan's group columns in the plan's order (a tuple byte IS a plan column), the specialised kernels available.
+// May the records of this push go through the run kernel? One aggregation that is not a composite, the specialised kernels
+// available, room for the segments — and a run record that the waves' LDS stages can hold a useful number of. Which RECORD a launch
+// writes is decided per pushed record (runs_narrow_ok): the narrow one — a byte per key id — while every group column is a dictionary
+// column of ≤ 254 distinct values, there are at most FDB_RUN_TUPLE_BYTES of them and the record carries all of them in the plan's
+// order; otherwise the wide one (the table's own key tuple: any cardinality, int64 and computed keys, absent columns).
 bool Plan::runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>& Rs, const std::vector<int>& live) const {
   static const bool off = std::getenv("FDB_NO_RUNS") != nullptr;  // (A/B and test aid: ordered plans take the hash table + sort)
   if (off || !ordered_ || !jit_possible() || aggs_.size() != 1 || aggs_[0].role != 0) return false;
-  if (gcols_.empty() || gcols_.size() > FDB_RUN_TUPLE_BYTES) return false;
-  for (const GroupColState& g : gcols_) if (g.kind != 0 || g.values.size() > 254) return false;
+  if (gcols_.empty() || gcols_.size() > FDB_MAX_HASH_GCOLS) return false;
   if (runs_.size() + live.size() > FDB_MAX_RUN_SEGMENTS) return false;
+  size_t kw = 4;  // (hash_layout() has not seen the columns this push added yet)
+  for (const GroupColState& g : gcols_) kw += g.kind == 0 ? 1 : 2;
+  kw = (kw + 3) & ~(size_t)3;
+  const uint64_t wide_bytes = (uint64_t)(kw + 4) * 4;
+  if (wide_bytes * 16 > FDB_RUN_WAVE_LDS) return false;  // (a wave's stage should hold a tile's worth of runs of ordered input)
   for (int i : live) {
-    const Resolved& R = Rs[(size_t)i];
-    if (R.groups.size() != gcols_.size()) return false;
-    for (size_t g = 0; g < R.groups.size(); g++) if (R.groups[g].kind != 0 || R.groups[g].gi != (int)g) return false;
     if ((uint64_t)bs[i]->rows >= (1ull << 31)) return false;
-    if ((uint64_t)bs[i]->rows * (FDB_RUN_BYTES + 4) > ((uint64_t)48 << 30)) return false;  // (the run store is sized for the worst case — every row a run)
+    const uint64_t rec = runs_narrow_ok(Rs[(size_t)i]) ? (uint64_t)FDB_RUN_BYTES : wide_bytes;
+    if ((uint64_t)bs[i]->rows * (rec + 4) > ((uint64_t)48 << 30)) return false;  // (the run store is sized for the worst case — every row a run)
   }
+  return true;
+}
+
+bool Plan::runs_narrow_ok(const Resolved& R) const {
+  const bool force_wide = std::getenv("FDB_RUNS_WIDE") != nullptr;  // (A/B and test aid: every run launch writes wide records; read per record so that a test can switch it)
+  if (force_wide || gcols_.size() > FDB_RUN_TUPLE_BYTES || R.groups.size() != gcols_.size()) return false;
+  for (const GroupColState& g : gcols_) if (g.kind != 0 || g.values.size() > 254) return false;
+  for (size_t g = 0; g < R.groups.size(); g++) if (R.groups[g].kind != 0 || R.groups[g].gi != (int)g) return false;
   return true;
 }
 
@@ -1057,8 +1075,11 @@ bool Plan::runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned
   std::memset(&v->segs, 0, sizeof(v->segs));
   int64_t n_entries = 0;
   v->segs.n_segs = (int32_t)runs_.size();
+  bool any_wide = false;
   for (size_t k = 0; k < runs_.size(); k++) {
     v->segs.tuples[k] = runs_[k].tuples;
+    v->segs.run_words[k] = runs_[k].run_words;
+    any_wide = any_wide || runs_[k].run_words != 0;
     v->segs.first_entry[k] = (uint32_t)n_entries;
     n_entries += runs_[k].n_entries;
   }
@@ -1082,6 +1103,36 @@ bool Plan::runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned
   v->phys = (unsigned long long*)alloc((size_t)v->n_runs * 8);
   hip_check(fdb_launch_runs_map(d_dir, d_starts, n_entries, v->segs, v->phys, stream_), "runs map");
   if (!check_order) { v->flags = nullptr; v->out_idx = nullptr; v->n_groups = v->n_runs; return true; }
+  v->flags = (uint32_t*)alloc((size_t)v->n_runs * 4);
+  v->out_idx = (uint32_t*)alloc((size_t)v->n_runs * 4);
+  unsigned long long* d_scratch2 = (unsigned long long*)alloc(((size_t)v->n_runs / 1024 + 4) * 8 + 256);
+  if (any_wide) {
+    // wide segments: 32-bit rank tables (rank of every key id among its column's values, NULL — id 0 — last) and the columns' places
+    std::vector<FdbRunCol> rc(gcols_.size());
+    std::vector<uint32_t> rank32;
+    for (size_t c = 0; c < gcols_.size(); c++) {
+      const GroupColState& g = gcols_[c];
+      rc[c].kind = g.kind == 0 ? 0 : g.is_u64 ? 3 : 1; rc[c].word = g.word; rc[c].gi = (int32_t)c; rc[c].rank_off = (uint32_t)rank32.size();
+      if (g.kind != 0) continue;
+      std::vector<uint32_t> order(g.values.size());
+      for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g.values[x] < g.values[y]; });
+      const size_t off = rank32.size();
+      rank32.resize(off + g.values.size() + 1);
+      rank32[off] = 0xFFFFFFFFu;
+      for (size_t r = 0; r < order.size(); r++) rank32[off + order[r] + 1] = (uint32_t)r;
+    }
+    uint32_t* d_rank32 = (uint32_t*)alloc(rank32.size() * 4 + 16);
+    FdbRunCol* d_rc = (FdbRunCol*)alloc(rc.size() * sizeof(FdbRunCol) + 16);
+    hip_check(hipMemcpyAsync(d_rank32, rank32.data(), rank32.size() * 4, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(rank tables)");
+    hip_check(hipMemcpyAsync(d_rc, rc.data(), rc.size() * sizeof(FdbRunCol), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(run columns)");
+    hip_check(fdb_launch_runs_flags_wide(v->phys, v->n_runs, v->segs, d_rc, d_rank32, (int)gcols_.size(), v->flags, (unsigned int*)(d_totals + 2), stream_), "runs flags (wide)");
+    hip_check(fdb_launch_scan_u32(v->flags, 1, v->out_idx, v->n_runs, d_scratch2, d_totals + 1, stream_), "scan run flags");
+    hip_check(hipMemcpyAsync(h_tot, d_totals, 24, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(group count)");
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (the host vectors above outlive their copies)
+    v->n_groups = (int64_t)h_tot[1];
+    return (h_tot[2] & 0xFFFFFFFFull) == 0;
+  }
   // rank of every key id among its column's values (bytes ascending; NULL — id 0 — last: cursorHeap.Less, arrowutils/merge.go:84-112)
   std::vector<unsigned char> rank(gcols_.size() * 256, 255);
   for (size_t c = 0; c < gcols_.size(); c++) {
@@ -1093,9 +1144,6 @@ bool Plan::runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned
   }
   const unsigned char* d_rank = (const unsigned char*)upload(rank.data(), rank.size());
   ctx_->flush_staging();
-  v->flags = (uint32_t*)alloc((size_t)v->n_runs * 4);
-  v->out_idx = (uint32_t*)alloc((size_t)v->n_runs * 4);
-  unsigned long long* d_scratch2 = (unsigned long long*)alloc(((size_t)v->n_runs / 1024 + 4) * 8 + 256);
   hip_check(fdb_launch_runs_flags(v->phys, v->n_runs, v->segs, d_rank, (int)gcols_.size(), v->flags, (unsigned int*)(d_totals + 2), stream_), "runs flags");
   hip_check(fdb_launch_scan_u32(v->flags, 1, v->out_idx, v->n_runs, d_scratch2, d_totals + 1, stream_), "scan run flags");
   hip_check(hipMemcpyAsync(h_tot, d_totals, 24, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(group count)");
@@ -1132,7 +1180,7 @@ void Plan::runs_to_table() {
   x.phys = v.phys; x.flags = nullptr; x.out_idx = nullptr; x.n_runs = v.n_runs;
   x.dense_keys = d_keys; x.vals_cnt = d_entries; x.vals_acc = d_entries + 1; x.val_stride = 2;
   x.n_cols = (int)gcols_.size(); x.key_words = kw; x.func = runs_func();
-  for (size_t c = 0; c < gcols_.size(); c++) x.col_word[c] = gcols_[c].word;
+  for (size_t c = 0; c < gcols_.size() && c < FDB_RUN_TUPLE_BYTES; c++) x.col_word[c] = gcols_[c].word;
   hip_check(fdb_launch_runs_expand(x, v.segs, stream_), "runs expand");
   std::vector<FdbHashCol> cols(gcols_.size());
   for (size_t c = 0; c < gcols_.size(); c++) {

@@ -844,6 +844,9 @@ struct HashGen {
 
   std::string source() {
     const int BLK = 256, TILE = BLK * 4, GROUP = 8;
+    // runs: 1 = narrow records (a key id is a byte, packed while the fingerprint is computed), 2 = wide records (the table's own key tuple,
+    // written by the lanes that end a run from re-loaded columns — fdb_kernels.h FdbRunsOut)
+    const bool narrow = s.runs == 1, wide = s.runs == 2;
     o << "#define FDB_DEVICE_HELPERS 1\n#include \"fdb_kernels.h\"\n" << kPreamble << kHashPreamble;
     // The runs kernel wants ≈149 VGPRs = 3 waves per SIMD, which is also what its LDS stage (4 × 12 KiB per workgroup) lets a CU hold.
     // ($FDB_RUNS_WAVES_PER_EU: tuning aid — caps the registers so that that many waves fit a SIMD; 0 / unset = no cap)
@@ -913,7 +916,7 @@ struct HashGen {
     }
     o << "    unsigned long long h1_0 = 0, h1_1 = 0, h1_2 = 0, h1_3 = 0, h2_0 = 0, h2_1 = 0, h2_2 = 0, h2_3 = 0, vm_0 = 0, vm_1 = 0, vm_2 = 0, vm_3 = 0;\n";
     // runs mode: the key ids of a row, one byte per group column, packed as they are computed (8 registers per row)
-    if (s.runs) for (int k = 0; k < 4; k++) o << "    u32x4 ta_" << k << " = {0u, 0u, 0u, 0u}, tb_" << k << " = {0u, 0u, 0u, 0u};\n";
+    if (narrow) for (int k = 0; k < 4; k++) o << "    u32x4 ta_" << k << " = {0u, 0u, 0u, 0u}, tb_" << k << " = {0u, 0u, 0u, 0u};\n";
     for (size_t c0 = 0; c0 < s.cols.size(); c0 += GROUP) {
       const size_t c1 = std::min(s.cols.size(), c0 + GROUP);
       o << "    {\n";
@@ -941,8 +944,8 @@ struct HashGen {
           else o << "        const uint32_t* L = hc[" << c << "].lut;\n";
           for (int k = 0; k < 4; k++) {
             o << "        { const uint32_t id = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_in_lds ? "L" : "as_global(L)") << "[" << r << comp4(k) << "] : 0u; fp_add32(h1_" << k << ", h2_"
-              << k << ", K1, K2, id);" << (s.runs ? "" : " if (id != 0u) vm_" + std::to_string(k) + " |= bit;");
-            if (s.runs) o << " t" << (c < 16 ? "a" : "b") << "_" << k << comp4((int)((c % 16) / 4)) << " |= id << " << 8 * (c % 4) << ";";
+              << k << ", K1, K2, id);" << (narrow ? "" : " if (id != 0u) vm_" + std::to_string(k) + " |= bit;");
+            if (narrow) o << " t" << (c < 16 ? "a" : "b") << "_" << k << comp4((int)((c % 16) / 4)) << " |= id << " << 8 * (c % 4) << ";";
             o << " }\n";
           }
         } else if (C.kind == 1) {
@@ -963,10 +966,10 @@ struct HashGen {
       // keep the next group's loads below this point: hoisting all 32 columns' loads to the top of the tile costs ≈390 VGPRs
       // and force the fingerprint updates to happen HERE: LLVM otherwise sinks all 32 columns' multiply-adds into the per-row
       // `if (selected)` blocks below and keeps 4 × 32 key ids live until then
-      if (s.runs) o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3) :: \"memory\");\n";
+      if (narrow) o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3) :: \"memory\");\n";
       else o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3), \"+v\"(vm_0), \"+v\"(vm_1), \"+v\"(vm_2), \"+v\"(vm_3) :: \"memory\");\n";
       // (same for the packed key ids of runs mode: pinned here, or all 4 × 32 ids stay live until the rows' tuples are stored)
-      if (s.runs) o << "      asm volatile(\"\" : \"+v\"(ta_0), \"+v\"(ta_1), \"+v\"(ta_2), \"+v\"(ta_3), \"+v\"(tb_0), \"+v\"(tb_1), \"+v\"(tb_2), \"+v\"(tb_3));\n";
+      if (narrow) o << "      asm volatile(\"\" : \"+v\"(ta_0), \"+v\"(ta_1), \"+v\"(ta_2), \"+v\"(ta_3), \"+v\"(tb_0), \"+v\"(tb_1), \"+v\"(tb_2), \"+v\"(tb_3));\n";
       o << "    }\n";
     }
     for (int k = 0; k < 4; k++) o << "    fp_final(h1_" << k << ", h2_" << k << ");\n";
@@ -975,7 +978,7 @@ struct HashGen {
     // bring rows of one group next to each other. Rows of the lane with the same fingerprint as the row before them are folded
     // into it — count and every aggregate — and only the LAST row of such a run goes to the table: one probe + one set of atomics
     // per run instead of per row. Costs a few compares on unsorted input.
-    const bool combine = !(s.ablate & 2) || s.runs;
+    const bool combine = !(s.ablate & 2) || s.runs != 0;
     const int runs_ablate = s.runs && std::getenv("FDB_RUNS_ABLATE") ? std::atoi(std::getenv("FDB_RUNS_ABLATE")) : 0;  // (tuning aid: 1 no stores, 2 no folding across lanes; results are wrong)
     if (combine) {
       for (int k = 0; k < 4; k++) o << "    unsigned long long cnt_" << k << " = 1ull;\n";
@@ -1065,7 +1068,130 @@ struct HashGen {
       o << "      }\n";
       o << "      if (has && wl < 63 && nh && na == ta && nb == tb) sel &= ~(1u << kl);\n    }\n";
     }
-    if (s.runs) {
+    std::vector<int> cword(s.cols.size());
+    { int w = 4; for (size_t c = 0; c < s.cols.size(); c++) { cword[c] = w; w += s.cols[c].kind == 0 ? 1 : 2; } }
+    // (`for_runs`: the wide run records of an ordered plan take the same road — the "inserting" rows are the ones that end a run, the
+    // destinations d_0 … d_3 are the runs' places in the wave's LDS stage or in the chunk, and count + aggregate follow the tuple)
+    auto emit_tuple_stores = [&](bool for_runs) {
+    if (!for_runs) {
+      o << "    if (ins_mask != 0u) {\n";
+      o << "      atomicAdd(&s_new, (unsigned int)__builtin_popcount(ins_mask));\n";
+    } else {
+      o << "    {\n";
+    }
+    // (fresh opaque lane offsets: with the tile's own the compiler recognises these loads as the fingerprint phase's and keeps
+    // all 32 columns' values — 128 VGPRs — alive from there to here instead of re-loading)
+    o << "      uint32_t ioff4 = lane_off4, ioff8 = lane_off8, ioffb = lane_offb;\n      asm volatile(\"\" : \"+v\"(ioff4), \"+v\"(ioff8), \"+v\"(ioffb));\n";
+    if (!for_runs) for (int k = 0; k < 4; k++) o << "      uint32_t* d_" << k << " = h.keys + slot_" << k << " * (uint64_t)h.key_words;\n";
+    o << "      const bool canon = h.canonical != 0;\n";
+    o << "      if (!canon) {  // columns this record does not carry are NULL\n";
+    for (int k = 0; k < 4; k++) o << "        if (ins_mask & " << (1 << k) << "u) for (int w = 2; w < h.key_words; w++) d_" << k << "[w] = 0u;\n";
+    o << "      }\n";
+    for (int k = 0; k < 4; k++)
+      o << "      if (ins_mask & " << (1 << k) << "u) { if (canon) *reinterpret_cast<u32x4*>(d_" << k << ") = u32x4{(uint32_t)vm_" << k << ", (uint32_t)(vm_" << k << " >> 32), 0u, 0u}; else { d_" << k
+        << "[0] = (uint32_t)vm_" << k << "; d_" << k << "[1] = (uint32_t)(vm_" << k << " >> 32); } }\n";
+    for (size_t c0 = 0; c0 < s.cols.size(); c0 += GROUP) {
+      const size_t c1 = std::min(s.cols.size(), c0 + GROUP);
+      o << "      {\n";
+      for (size_t c = c0; c < c1; c++) {
+        const JitHashCol& C = s.cols[c];
+        const std::string r = "w" + std::to_string(c);
+        if (C.kind == 2) continue;
+        if (C.kind == 0) o << "        const u32x4 " << r << " = ld4(reinterpret_cast<const char*>(hc[" << c << "].values) + o4, ioff4);\n";
+        else {
+          o << "        const u64x2 " << r << "a = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, ioff8);\n";
+          o << "        const u64x2 " << r << "b = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, ioff8 + 16u);\n";
+        }
+        if (C.has_validity) o << "        const uint32_t " << r << "_m = ldv(hc[" << c << "].validity + ob, ioffb, lane_shb);\n";
+        else o << "        const uint32_t " << r << "_m = 0xFu;\n";
+      }
+      // key ids of the dictionary columns (only for rows that inserted: other rows of the tile's tail may hold anything)
+      for (size_t c = c0; c < c1; c++) {
+        const JitHashCol& C = s.cols[c];
+        if (C.kind != 0) continue;
+        const std::string r = "w" + std::to_string(c);
+        if (C.lut_in_lds) o << "        const uint32_t* L" << c << " = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
+        else o << "        const uint32_t* L" << c << " = hc[" << c << "].lut;\n";
+        for (int k = 0; k < 4; k++)
+          o << "        const uint32_t i" << c << "_" << k << " = ((ins_mask & " << (1 << k) << "u) && ((" << r << "_m >> " << k << ") & 1u)) ? " << (C.lut_in_lds ? "L" : "as_global(L") << c
+            << (C.lut_in_lds ? "" : ")") << "[" << r << comp4(k) << "] : 0u;\n";
+      }
+      // stores: aligned quads of dictionary columns as one 16-byte store when the layout is canonical
+      std::vector<bool> in_quad(s.cols.size(), false);
+      o << "        if (canon) {\n";
+      for (size_t c = c0; c + 4 <= c1; ) {
+        const bool quad = cword[c] % 4 == 0 && s.cols[c].kind == 0 && s.cols[c + 1].kind == 0 && s.cols[c + 2].kind == 0 && s.cols[c + 3].kind == 0;
+        if (!quad) { c++; continue; }
+        for (int k = 0; k < 4; k++)
+          o << "          if (ins_mask & " << (1 << k) << "u) *reinterpret_cast<u32x4*>(d_" << k << " + " << cword[c] << ") = u32x4{i" << c << "_" << k << ", i" << c + 1 << "_" << k << ", i" << c + 2 << "_" << k
+            << ", i" << c + 3 << "_" << k << "};\n";
+        in_quad[c] = in_quad[c + 1] = in_quad[c + 2] = in_quad[c + 3] = true;
+        c += 4;
+      }
+      o << "        }\n";
+      for (size_t c = c0; c < c1; c++) {
+        const JitHashCol& C = s.cols[c];
+        const std::string r = "w" + std::to_string(c);
+        o << "        " << (in_quad[c] ? "if (!canon) " : "") << "{\n          const int W = hc[" << c << "].word;\n";
+        if (C.kind == 0) {
+          for (int k = 0; k < 4; k++) o << "          if (ins_mask & " << (1 << k) << "u) d_" << k << "[W] = i" << c << "_" << k << ";\n";
+        } else if (C.kind == 1) {
+          for (int k = 0; k < 4; k++)
+            o << "          if (ins_mask & " << (1 << k) << "u) { const unsigned long long y = ((" << r << "_m >> " << k << ") & 1u) ? " << comp8(r, k) << " : 0ull; d_" << k << "[W] = (uint32_t)y; d_" << k
+              << "[W + 1] = (uint32_t)(y >> 32); }\n";
+        } else {
+          for (int k = 0; k < 4; k++) {
+            auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
+            auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
+            o << "          if (ins_mask & " << (1 << k) << "u) { const unsigned long long y = " << expr_valid(s.exprs, C.expr_root, col, colvalid) << " ? "
+              << expr_bits(s.exprs, C.expr_root, expr_value(s.exprs, C.expr_root, col, colvalid)) << " : 0ull; d_" << k << "[W] = (uint32_t)y; d_" << k << "[W + 1] = (uint32_t)(y >> 32); }\n";
+          }
+        }
+        o << "        }\n";
+      }
+      // (keep the next group's loads below this point: all 32 columns' loads hoisted to the top cost ≈100 more VGPRs)
+      o << "        asm volatile(\"\" ::: \"memory\");\n      }\n";
+    }
+    if (for_runs) {
+      const bool has_val = !s.aggs.empty() && s.aggs[0].func != FDB_AGG_COUNT;
+      const bool f64v = has_val && s.aggs[0].func == FDB_AGG_SUM && s.aggs[0].type == FDB_T_F64;
+      for (int k = 0; k < 4; k++)
+        o << "      if (ins_mask & " << (1 << k) << "u) *reinterpret_cast<u64x2*>(d_" << k << " + h.key_words) = u64x2{cnt_" << k << ", "
+          << (has_val ? (f64v ? "(unsigned long long)__double_as_longlong(v0_" + std::to_string(k) + ")" : "(unsigned long long)v0_" + std::to_string(k)) : std::string("0ull")) << "};\n";
+    }
+    o << "    }\n";
+    };
+    if (wide) {
+      // Wide records. As in the narrow case every row still selected ends a run of its wave and holds the run's count and folded
+      // aggregate; its key tuple is written from re-loaded columns by emit_tuple_stores. The wave's runs wait in its LDS stage
+      // (h.runs.stage_cap of them) and leave as one contiguous copy; a tile with more runs than the stage holds (input that is not
+      // really ordered) writes them straight into the chunk.
+      o << "    {\n      const unsigned long long act2 = __ballot(1);\n      const int wl2 = (int)(tid & 63u), wv = (int)(tid >> 6), first2 = __builtin_ctzll(act2);\n";
+      o << "      const unsigned long long b0 = __ballot((sel & 1u) != 0u), b1 = __ballot((sel & 2u) != 0u), b2 = __ballot((sel & 4u) != 0u), b3 = __ballot((sel & 8u) != 0u);\n";
+      o << "      const uint32_t n_w = (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));\n";
+      o << "      if (n_w != 0u) {\n        const unsigned long long lt = (1ull << wl2) - 1ull;\n";
+      o << "        const uint32_t before = (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));\n";
+      o << "        uint32_t rb = s_runs[wv * 4], rp = s_runs[wv * 4 + 1], ps = s_runs[wv * 4 + 2];\n";
+      o << "        const uint32_t RW = (uint32_t)h.runs.run_words, RQ = RW >> 2, CAP = (uint32_t)h.runs.stage_cap;\n";
+      o << "        u32x4* stage = reinterpret_cast<u32x4*>(smem + a.lds_lut_bytes + (size_t)wv * " << FDB_RUN_WAVE_LDS << ");\n";
+      o << "        const uint32_t n_act = (uint32_t)__popcll(act2), my_act = (uint32_t)__popcll(act2 & lt);\n";
+      o << "        const bool sw = rp + n_w > " << FDB_RUN_CHUNK << "u, direct = n_w > CAP;\n";
+      o << "        if (sw || direct || (rp - ps) + n_w > CAP) {\n";
+      o << "          u32x4* out = reinterpret_cast<u32x4*>(h.runs.tuples) + (size_t)(rb + ps) * RQ;\n";
+      o << "          for (uint32_t q = my_act; q < (rp - ps) * RQ; q += n_act) out[q] = stage[q];\n";
+      o << "          __builtin_amdgcn_wave_barrier();\n          ps = rp;\n        }\n";
+      o << "        if (sw) {\n          uint32_t nc = 0u;\n          if (wl2 == first2) nc = atomicAdd(h.runs.chunk_cursor, 1u);\n          rb = (uint32_t)__shfl((int)nc, first2, 64) * " << FDB_RUN_CHUNK
+        << "u; rp = 0u; ps = 0u;\n        }\n";
+      o << "        const uint32_t base = rb + rp, sbase = rp - ps;\n        __builtin_amdgcn_wave_barrier();\n";
+      o << "        if (wl2 == first2) { s_runs[wv * 4] = rb; s_runs[wv * 4 + 1] = rp + n_w; s_runs[wv * 4 + 2] = direct ? rp + n_w : ps; *reinterpret_cast<uint2*>(h.runs.dir + ((size_t)tile * 4 + wv) * 2) = make_uint2(base, n_w); }\n";
+      for (int k = 0; k < 4; k++)
+        o << "        uint32_t* d_" << k << " = direct ? reinterpret_cast<uint32_t*>(h.runs.tuples) + (size_t)(base + before + (uint32_t)__builtin_popcount(sel & " << ((1 << k) - 1) << "u)) * RW"
+          << " : reinterpret_cast<uint32_t*>(stage) + (size_t)(sbase + before + (uint32_t)__builtin_popcount(sel & " << ((1 << k) - 1) << "u)) * RW;\n";
+      o << "        const uint32_t ins_mask = sel;\n";
+      emit_tuple_stores(true);
+      o << "        __builtin_amdgcn_wave_barrier();\n      }\n    }\n    continue;\n";
+    }
+    if (narrow) {
       // Every row still selected is the LAST row of a run of equal keys inside this wave and holds the run's count and folded
       // aggregate. Position of a run among the wave's runs: rows are ordered lane-major (a lane's 4 rows are consecutive).
       const bool has_val = !s.aggs.empty() && s.aggs[0].func != FDB_AGG_COUNT;
@@ -1139,86 +1265,17 @@ struct HashGen {
     // Canonical layout (h.canonical: the record carries every group column of the table, in order): column c's word is the
     // constant 4 + Σ widths before it, tuples are 16-byte aligned, and an aligned quad of dictionary columns is ONE 16-byte store —
     // every store of a scattered tuple is its own write request, and with 34 four-byte stores those were most of an insert's cost.
-    std::vector<int> cword(s.cols.size());
-    { int w = 4; for (size_t c = 0; c < s.cols.size(); c++) { cword[c] = w; w += s.cols[c].kind == 0 ? 1 : 2; } }
-    o << "    if (ins_mask != 0u) {\n";
-    o << "      atomicAdd(&s_new, (unsigned int)__builtin_popcount(ins_mask));\n";
-    // (fresh opaque lane offsets: with the tile's own the compiler recognises these loads as the fingerprint phase's and keeps
-    // all 32 columns' values — 128 VGPRs — alive from there to here instead of re-loading)
-    o << "      uint32_t ioff4 = lane_off4, ioff8 = lane_off8, ioffb = lane_offb;\n      asm volatile(\"\" : \"+v\"(ioff4), \"+v\"(ioff8), \"+v\"(ioffb));\n";
-    for (int k = 0; k < 4; k++) o << "      uint32_t* d_" << k << " = h.keys + slot_" << k << " * (uint64_t)h.key_words;\n";
-    o << "      const bool canon = h.canonical != 0;\n";
-    o << "      if (!canon) {  // columns this record does not carry are NULL\n";
-    for (int k = 0; k < 4; k++) o << "        if (ins_mask & " << (1 << k) << "u) for (int w = 2; w < h.key_words; w++) d_" << k << "[w] = 0u;\n";
-    o << "      }\n";
-    for (int k = 0; k < 4; k++)
-      o << "      if (ins_mask & " << (1 << k) << "u) { if (canon) *reinterpret_cast<u32x4*>(d_" << k << ") = u32x4{(uint32_t)vm_" << k << ", (uint32_t)(vm_" << k << " >> 32), 0u, 0u}; else { d_" << k
-        << "[0] = (uint32_t)vm_" << k << "; d_" << k << "[1] = (uint32_t)(vm_" << k << " >> 32); } }\n";
-    for (size_t c0 = 0; c0 < s.cols.size(); c0 += GROUP) {
-      const size_t c1 = std::min(s.cols.size(), c0 + GROUP);
-      o << "      {\n";
-      for (size_t c = c0; c < c1; c++) {
-        const JitHashCol& C = s.cols[c];
-        const std::string r = "w" + std::to_string(c);
-        if (C.kind == 2) continue;
-        if (C.kind == 0) o << "        const u32x4 " << r << " = ld4(reinterpret_cast<const char*>(hc[" << c << "].values) + o4, ioff4);\n";
-        else {
-          o << "        const u64x2 " << r << "a = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, ioff8);\n";
-          o << "        const u64x2 " << r << "b = ld8(reinterpret_cast<const char*>(hc[" << c << "].values) + o8, ioff8 + 16u);\n";
-        }
-        if (C.has_validity) o << "        const uint32_t " << r << "_m = ldv(hc[" << c << "].validity + ob, ioffb, lane_shb);\n";
-        else o << "        const uint32_t " << r << "_m = 0xFu;\n";
-      }
-      // key ids of the dictionary columns (only for rows that inserted: other rows of the tile's tail may hold anything)
-      for (size_t c = c0; c < c1; c++) {
-        const JitHashCol& C = s.cols[c];
-        if (C.kind != 0) continue;
-        const std::string r = "w" + std::to_string(c);
-        if (C.lut_in_lds) o << "        const uint32_t* L" << c << " = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
-        else o << "        const uint32_t* L" << c << " = hc[" << c << "].lut;\n";
-        for (int k = 0; k < 4; k++)
-          o << "        const uint32_t i" << c << "_" << k << " = ((ins_mask & " << (1 << k) << "u) && ((" << r << "_m >> " << k << ") & 1u)) ? " << (C.lut_in_lds ? "L" : "as_global(L") << c
-            << (C.lut_in_lds ? "" : ")") << "[" << r << comp4(k) << "] : 0u;\n";
-      }
-      // stores: aligned quads of dictionary columns as one 16-byte store when the layout is canonical
-      std::vector<bool> in_quad(s.cols.size(), false);
-      o << "        if (canon) {\n";
-      for (size_t c = c0; c + 4 <= c1; ) {
-        const bool quad = cword[c] % 4 == 0 && s.cols[c].kind == 0 && s.cols[c + 1].kind == 0 && s.cols[c + 2].kind == 0 && s.cols[c + 3].kind == 0;
-        if (!quad) { c++; continue; }
-        for (int k = 0; k < 4; k++)
-          o << "          if (ins_mask & " << (1 << k) << "u) *reinterpret_cast<u32x4*>(d_" << k << " + " << cword[c] << ") = u32x4{i" << c << "_" << k << ", i" << c + 1 << "_" << k << ", i" << c + 2 << "_" << k
-            << ", i" << c + 3 << "_" << k << "};\n";
-        in_quad[c] = in_quad[c + 1] = in_quad[c + 2] = in_quad[c + 3] = true;
-        c += 4;
-      }
-      o << "        }\n";
-      for (size_t c = c0; c < c1; c++) {
-        const JitHashCol& C = s.cols[c];
-        const std::string r = "w" + std::to_string(c);
-        o << "        " << (in_quad[c] ? "if (!canon) " : "") << "{\n          const int W = hc[" << c << "].word;\n";
-        if (C.kind == 0) {
-          for (int k = 0; k < 4; k++) o << "          if (ins_mask & " << (1 << k) << "u) d_" << k << "[W] = i" << c << "_" << k << ";\n";
-        } else if (C.kind == 1) {
-          for (int k = 0; k < 4; k++)
-            o << "          if (ins_mask & " << (1 << k) << "u) { const unsigned long long y = ((" << r << "_m >> " << k << ") & 1u) ? " << comp8(r, k) << " : 0ull; d_" << k << "[W] = (uint32_t)y; d_" << k
-              << "[W + 1] = (uint32_t)(y >> 32); }\n";
-        } else {
-          for (int k = 0; k < 4; k++) {
-            auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
-            auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
-            o << "          if (ins_mask & " << (1 << k) << "u) { const unsigned long long y = " << expr_valid(s.exprs, C.expr_root, col, colvalid) << " ? "
-              << expr_bits(s.exprs, C.expr_root, expr_value(s.exprs, C.expr_root, col, colvalid)) << " : 0ull; d_" << k << "[W] = (uint32_t)y; d_" << k << "[W + 1] = (uint32_t)(y >> 32); }\n";
-          }
-        }
-        o << "        }\n";
-      }
-      // (keep the next group's loads below this point: all 32 columns' loads hoisted to the top cost ≈100 more VGPRs)
-      o << "        asm volatile(\"\" ::: \"memory\");\n      }\n";
-    }
-    o << "    }\n";
+    emit_tuple_stores(false);
     o << "  }\n";
-    if (s.runs) {
+    if (wide) {
+      o << "  {  // the runs that still wait in the waves' stages\n    const int wv = (int)(tid >> 6), wl2 = (int)(tid & 63u);\n    __builtin_amdgcn_wave_barrier();\n";
+      o << "    const uint32_t rb = s_runs[wv * 4], rp = s_runs[wv * 4 + 1], ps = s_runs[wv * 4 + 2], RQ = (uint32_t)h.runs.run_words >> 2;\n";
+      o << "    if (rp != " << FDB_RUN_CHUNK << "u || ps != " << FDB_RUN_CHUNK << "u) {\n";
+      o << "      const u32x4* stage = reinterpret_cast<const u32x4*>(smem + a.lds_lut_bytes + (size_t)wv * " << FDB_RUN_WAVE_LDS << ");\n";
+      o << "      u32x4* out = reinterpret_cast<u32x4*>(h.runs.tuples) + (size_t)(rb + ps) * RQ;\n";
+      o << "      for (uint32_t q = (uint32_t)wl2; q < (rp - ps) * RQ; q += 64u) out[q] = stage[q];\n    }\n  }\n";
+    }
+    if (narrow) {
       o << "  {  // the runs that still wait in the waves' stages\n    const int wv = (int)(tid >> 6), wl2 = (int)(tid & 63u);\n    __builtin_amdgcn_wave_barrier();\n";
       o << "    const uint32_t rb = s_runs[wv * 4], rp = s_runs[wv * 4 + 1], ps = s_runs[wv * 4 + 2];\n";
       o << "    if (rp != " << FDB_RUN_CHUNK << "u || ps != " << FDB_RUN_CHUNK << "u) {\n";
@@ -1429,7 +1486,7 @@ hipFunction_t jit_get(const JitShape& shape) {
 
 std::string JitHashShape::key() const {
   std::ostringstream k;
-  k << "a" << ablate << "c" << need_count << (runs ? "R" : "") << (runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::getenv("FDB_RUNS_WAVES_PER_EU") : "")
+  k << "a" << ablate << "c" << need_count << (runs == 1 ? "R" : runs == 2 ? "W" : "") << (runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::getenv("FDB_RUNS_WAVES_PER_EU") : "")
     << (runs && std::getenv("FDB_RUNS_ABLATE") ? std::string("x") + std::getenv("FDB_RUNS_ABLATE") : std::string()) << "|";
   for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
   k << '|';
@@ -1454,7 +1511,7 @@ JitHashShape jit_hash_shape(const FdbHashArgs& h, const FdbHashCol* hcols) {
   for (int i = 0; i < a.n_expr; i++) s.exprs.push_back({a.expr[i].kind, a.expr[i].op, a.expr[i].left, a.expr[i].right, a.expr[i].slot, a.expr[i].type});
   s.n_expr_cols = a.n_l8;
   s.need_count = a.need_count != 0;
-  s.runs = h.runs.tuples != nullptr;
+  s.runs = h.runs.tuples == nullptr ? 0 : h.runs.run_words != 0 ? 2 : 1;
   for (int l = 0; l < a.n_leaves; l++) {
     const FdbLeaf& L = a.leaves[l];
     const bool wide = L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64;

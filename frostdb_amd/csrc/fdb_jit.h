@@ -61,9 +61,11 @@ struct JitHashShape {
   bool need_count = true;  // some aggregation is COUNT: otherwise the per-entry row count is never read (occupancy = fingerprint ≠ 0) and its atomic is skipped
   int ablate = 0;  // tuning aid (tools/cfg5_ablate.py): 1 = stream + fingerprint only, 2 = no count / aggregate atomics
   // Table-free OrderedAggregate (FdbHashArgs.runs): no probe, no insert — every wave emits the runs of equal keys among its 256 rows
-  // (packed key ids, row count, folded aggregate) and notes them in the launch's directory. Dictionary columns with ≤ 255 values,
-  // at most FDB_RUN_TUPLE_BYTES of them, exactly one aggregation.
-  bool runs = false;
+  // (key ids, row count, folded aggregate) and notes them in the launch's directory. Exactly one aggregation. 1: narrow records —
+  // dictionary columns with ≤ 255 values, at most FDB_RUN_TUPLE_BYTES of them, ids packed one byte each while the fingerprint is
+  // computed; 2: wide records — the table's own key tuple (any cardinality, int64 / computed keys, absent columns), written by the lanes
+  // that end a run from re-loaded columns.
+  int runs = 0;
   std::string key() const;
 };
 // `hcols` = host copy of args.hcols.

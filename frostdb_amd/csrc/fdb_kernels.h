@@ -196,10 +196,17 @@ static inline unsigned long long fdb_fp_k2(int gi) {
 #define FDB_RUN_STAGE 256                             // runs a wave can hold back in LDS (≥ the runs of one tile of 256 rows)
 #define FDB_RUN_WAVE_LDS (FDB_RUN_STAGE * FDB_RUN_BYTES)  // a wave's runs wait in LDS over several tiles and leave as ONE contiguous copy: stores issued every tile
                                                       // made the next tile's loads wait for their acknowledgement (loads and stores share a counter): 3.06 → 2.3 ms per 100 M rows
+// The WIDE run record (round 5): [the run's key tuple in the hash table's own layout — valid mask in words 0-1, two words of padding,
+// one 32-bit word per dictionary column (key id, 0 = NULL / column absent), two per int64 column: key_words words | rows of the run: 2
+// words | its aggregate: 2 words] = run_words 32-bit words (a multiple of 4). Any cardinality, int64 / computed keys, records that lack
+// a group column. The scan does not carry key ids for it: a lane re-loads the columns (one 16-byte load per column for its 4 rows)
+// only when one of its rows ENDS a run, the way an inserting lane of the table path does.
 struct FdbRunsOut {
-  unsigned char* tuples;         // [capacity][FDB_RUN_BYTES]; nullptr: not a runs launch
+  unsigned char* tuples;         // [capacity][FDB_RUN_BYTES or run_words × 4]; nullptr: not a runs launch
   unsigned int* dir;             // [4 × tiles of the launch][2]
   unsigned int* chunk_cursor;    // next free chunk
+  int32_t run_words;             // 0: the narrow record (FDB_RUN_BYTES); else the wide record's words
+  int32_t stage_cap;             // runs a wave's LDS stage holds: FDB_RUN_STAGE (narrow), FDB_RUN_WAVE_LDS / (run_words × 4) (wide)
 };
 
 struct FdbHashArgs {
@@ -332,10 +339,15 @@ hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t strea
 // a segment directory entries in order, within an entry the runs in order — i.e. row order of the scan.
 #define FDB_MAX_RUN_SEGMENTS 64
 struct FdbRunSegs {
-  const unsigned char* tuples[FDB_MAX_RUN_SEGMENTS];   // [run][FDB_RUN_BYTES]
+  const unsigned char* tuples[FDB_MAX_RUN_SEGMENTS];   // [run][FDB_RUN_BYTES or run_words × 4]
   uint32_t first_entry[FDB_MAX_RUN_SEGMENTS + 1];  // directory entries of segment s = [first_entry[s], first_entry[s + 1]) of the concatenated directory
+  int32_t run_words[FDB_MAX_RUN_SEGMENTS];         // 0: narrow records; else the segment's wide record stride in words (FdbRunsOut.run_words of its launch)
   int32_t n_segs;
 };
+// A group column as the run store's Finish sees it (the plan's column order): kind 0 dictionary (rank table of its key ids at
+// rank + rank_off: rank[0] = NULL = 0xFFFFFFFF = last), 1 int64 / bool, 3 uint64 (NULL last, then by value); `word` = its place in a
+// wide record / a dense key row, `gi` = its bit in the valid mask.
+struct FdbRunCol { int32_t kind, word, gi; uint32_t rank_off; };
 // Exclusive prefix sums of in[i * stride] (i < n) into out[i]; *total = the sum. `scratch`: ≥ (n / 1024 + 2) × 8 bytes.
 hipError_t fdb_launch_scan_u32(const uint32_t* in, int stride, uint32_t* out, int64_t n, unsigned long long* scratch, unsigned long long* total, hipStream_t stream);
 // phys[logical run] = (segment << 32) | index inside the segment, from the concatenated directory `dir` ([n_entries][2]) and the
@@ -346,6 +358,10 @@ hipError_t fdb_launch_runs_map(const uint32_t* dir, const uint32_t* starts, int6
 // values, NULL = 255 = last): then the input was not ordered and the caller falls back to the hash table.
 hipError_t fdb_launch_runs_flags(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const unsigned char* rank, int n_cols, uint32_t* flags,
                                  unsigned int* violation, hipStream_t stream);
+// The same for a run store with wide segments (any mix of narrow and wide): columns compared one by one in plan order through `cols`
+// (device array [n_cols]) and the 32-bit rank tables `rank32`.
+hipError_t fdb_launch_runs_flags_wide(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const FdbRunCol* cols, const uint32_t* rank32, int n_cols,
+                                      uint32_t* flags, unsigned int* violation, hipStream_t stream);
 // Groups out: for every run i, group g = out_idx[i] (exclusive prefix sums of flags) if flags[i] else out_idx[i] − 1 (flags == nullptr:
 // every run is its own group, g = i). A group's first run writes its key tuple as one row of `dense_keys` ([n_groups][key_words]
 // u32: valid mask in words 0-1, column c's id in word col_word[c]); counts and aggregates are folded into vals_cnt / vals_acc

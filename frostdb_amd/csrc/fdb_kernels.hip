@@ -2622,6 +2622,66 @@ hipError_t fdb_launch_runs_flags(const unsigned long long* phys, int64_t n_runs,
   return hipGetLastError();
 }
 
+// Wide segments (or a mix): the two runs' columns are compared one by one in plan order. A narrow run's id of column c is byte c of
+// its tuple (columns the plan gained later: 0), a wide run's the word `cols[c].word` of its key tuple (past the tuple's end: 0 —
+// the record of that launch did not know the column); int64 columns exist in wide runs only, NULL = bit `gi` of the valid mask clear.
+struct RunRef { const uint32_t* t; int kw; };  // kw: key words of a wide run, 0 = narrow
+__device__ __forceinline__ RunRef run_ref(const FdbRunSegs& segs, unsigned long long p) {
+  const int seg = (int)(p >> 32);
+  const int rw = segs.run_words[seg];
+  RunRef r;
+  r.t = reinterpret_cast<const uint32_t*>(segs.tuples[seg] + (p & 0xFFFFFFFFull) * (uint64_t)(rw ? rw * 4 : FDB_RUN_BYTES));
+  r.kw = rw ? rw - 4 : 0;
+  return r;
+}
+__device__ __forceinline__ uint32_t run_dict_id(const RunRef& r, int c, int word) {
+  if (r.kw == 0) return c < FDB_RUN_TUPLE_BYTES ? (r.t[c >> 2] >> (8 * (c & 3))) & 0xFFu : 0u;
+  return word < r.kw ? r.t[word] : 0u;
+}
+__device__ __forceinline__ bool run_i64(const RunRef& r, int word, int gi, unsigned long long* v) {
+  if (r.kw == 0 || word + 1 >= r.kw) return false;
+  const unsigned long long vm = (unsigned long long)r.t[0] | ((unsigned long long)r.t[1] << 32);
+  if (!((vm >> gi) & 1ull)) return false;
+  *v = (unsigned long long)r.t[word] | ((unsigned long long)r.t[word + 1] << 32);
+  return true;
+}
+__global__ __launch_bounds__(256) void runs_flags_wide_kernel(const unsigned long long* __restrict__ phys, int64_t n_runs, const FdbRunSegs segs, const FdbRunCol* __restrict__ cols,
+                                                              const uint32_t* __restrict__ rank32, int n_cols, uint32_t* __restrict__ flags, unsigned int* __restrict__ violation) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_runs) return;
+  if (i == 0) { flags[0] = 1u; return; }
+  const RunRef a = run_ref(segs, phys[i]), b = run_ref(segs, phys[i - 1]);
+  typedef const __attribute__((address_space(4))) FdbRunCol* ConstRunCols;
+  ConstRunCols q = (ConstRunCols)cols;
+  for (int c = 0; c < n_cols; c++) {
+    const int kind = q[c].kind, word = q[c].word, gi = q[c].gi;
+    if (kind == 0) {
+      const uint32_t ic = run_dict_id(a, c, word), ip = run_dict_id(b, c, word);
+      if (ic == ip) continue;
+      flags[i] = 1u;
+      const uint32_t off = q[c].rank_off;
+      if (rank32[off + ic] < rank32[off + ip]) atomicOr(violation, 1u);  // ascending by value, NULL (rank 0xFFFFFFFF) last
+      return;
+    }
+    unsigned long long vc = 0, vp = 0;
+    const bool hc = run_i64(a, word, gi, &vc), hp = run_i64(b, word, gi, &vp);
+    if (hc == hp && (!hc || vc == vp)) continue;
+    flags[i] = 1u;
+    bool before;  // does the new key sort BEFORE its predecessor?
+    if (hc != hp) before = hc;  // a value after a NULL
+    else before = kind == 3 ? vc < vp : (long long)vc < (long long)vp;
+    if (before) atomicOr(violation, 1u);
+    return;
+  }
+  flags[i] = 0u;
+}
+hipError_t fdb_launch_runs_flags_wide(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const FdbRunCol* cols, const uint32_t* rank32, int n_cols,
+                                      uint32_t* flags, unsigned int* violation, hipStream_t stream) {
+  if (n_runs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(runs_flags_wide_kernel, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, stream, phys, n_runs, segs, cols, rank32, n_cols, flags, violation);
+  return hipGetLastError();
+}
+
 // One wave per 64 consecutive logical runs. The key rows of the groups that START among them are consecutive in the output
 // (out_idx is monotone), so they are assembled in the wave's LDS tile and leave as one contiguous copy.
 __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArgs a, const FdbRunSegs segs) {
@@ -2635,13 +2695,22 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
   unsigned long long cnt = 0, acc = 0;
   run_u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
   bool single = true;
+  const uint32_t* wide = nullptr;  // a wide run's key tuple (already a dense key row of `wide_kw` words)
+  int wide_kw = 0;
   if (live) {
     const unsigned long long p = a.phys[i];
     const int seg = (int)(p >> 32);
     const uint64_t at = p & 0xFFFFFFFFull;
-    const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[seg] + at * FDB_RUN_BYTES);
-    t0 = t[0]; t1 = t[1];
-    { const u64x2 ca = *reinterpret_cast<const u64x2*>(t + 2); cnt = ca.x; acc = ca.y; }
+    const int rw = segs.run_words[seg];
+    if (rw == 0) {
+      const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[seg] + at * FDB_RUN_BYTES);
+      t0 = t[0]; t1 = t[1];
+      { const u64x2 ca = *reinterpret_cast<const u64x2*>(t + 2); cnt = ca.x; acc = ca.y; }
+    } else {
+      wide = reinterpret_cast<const uint32_t*>(segs.tuples[seg] + at * (uint64_t)rw * 4);
+      wide_kw = rw - 4;
+      { const u64x2 ca = *reinterpret_cast<const u64x2*>(wide + wide_kw); cnt = ca.x; acc = ca.y; }
+    }
     if (a.flags != nullptr) {
       fl = a.flags[i];
       g = a.out_idx[i] - (fl ? 0u : 1u);
@@ -2666,15 +2735,21 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
   if (live && fl != 0u) {
     const uint32_t r = g - first_g;
     uint32_t* row = tile + (size_t)r * kw;
-    for (int w = 0; w < kw; w++) row[w] = 0u;
-    const uint32_t ids[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-    unsigned long long vm = 0;
-    for (int c = 0; c < a.n_cols; c++) {
-      const uint32_t id = (ids[c >> 2] >> (8 * (c & 3))) & 0xFFu;
-      row[a.col_word[c]] = id;
-      if (id != 0u) vm |= 1ull << c;
+    if (wide != nullptr) {
+      for (int w = 0; w < kw; w++) row[w] = w < wide_kw ? wide[w] : 0u;  // (columns the plan gained after this run's launch: NULL)
+      row[2] = 0u; row[3] = 0u;
+    } else {
+      for (int w = 0; w < kw; w++) row[w] = 0u;
+      const uint32_t ids[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      unsigned long long vm = 0;
+      const int nc = a.n_cols < FDB_RUN_TUPLE_BYTES ? a.n_cols : FDB_RUN_TUPLE_BYTES;
+      for (int c = 0; c < nc; c++) {
+        const uint32_t id = (ids[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+        row[a.col_word[c]] = id;
+        if (id != 0u) vm |= 1ull << c;
+      }
+      row[0] = (uint32_t)vm; row[1] = (uint32_t)(vm >> 32);
     }
-    row[0] = (uint32_t)vm; row[1] = (uint32_t)(vm >> 32);
   }
   __builtin_amdgcn_wave_barrier();
   uint32_t* dst = a.dense_keys + (size_t)first_g * kw;

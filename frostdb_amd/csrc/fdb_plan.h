@@ -307,9 +307,10 @@ class Plan {
   // record boundaries cut and, if the keys came in order, emits them as they are; anything else that wants the plan's state
   // (a merge, an export, the raw accessors, input that was NOT ordered) first inserts the runs into the hash table.
   struct RunSegment {
-    void* block = nullptr;  // one device allocation: [runs of FDB_RUN_BYTES | directory | chunk cursor]
+    void* block = nullptr;  // one device allocation: [runs of FDB_RUN_BYTES (narrow) or run_words × 4 bytes (wide) | directory | chunk cursor]
     unsigned char* tuples = nullptr; uint32_t* dir = nullptr; uint32_t* cursor = nullptr;
     int64_t n_entries = 0, capacity = 0;
+    int32_t run_words = 0;  // 0: narrow records; else the wide record's stride in 32-bit words (fdb_kernels.h FdbRunsOut)
   };
   struct RunsView {  // the runs in logical (row) order, prepared for Finish
     FdbRunSegs segs;
@@ -328,6 +329,7 @@ class Plan {
   int64_t prof_push_n_ = 0;
   std::vector<RunSegment> runs_;
   bool runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>& Rs, const std::vector<int>& live) const;
+  bool runs_narrow_ok(const Resolved& R) const;  // may this record's run launch write the narrow (byte per key id) records?
   void runs_free();
   void runs_to_table();
   // false: the keys did not arrive in order (the caller falls back to runs_to_table + the ordinary ordered Finish). Device blocks it

@@ -269,9 +269,10 @@ def test_runs_become_table_entries_for_every_other_consumer(pp):
     assert n2 == h2.num_rows
 
 
-def test_table_free_path_is_left_when_a_record_does_not_fit_it(pp):
-    """A dictionary that outgrows one byte of key ids, and a record that lacks one of the plan's group columns: the runs collected so
-    far go into the table and the scan continues there."""
+def test_records_that_do_not_fit_the_narrow_run_record_take_the_wide_one(pp):
+    """A dictionary that outgrows one byte of key ids, and a record that lacks one of the plan's group columns: round 4 left the
+    table-free path there; now such a record's launch writes WIDE run records (the table's own key tuple, from re-loaded columns)
+    and Finish merges narrow and wide segments alike."""
     rng = np.random.default_rng(15)
     recs = _sorted_label_records(rng, 60_000, 2)
     n = 5_000
@@ -282,12 +283,155 @@ def test_table_free_path_is_left_when_a_record_does_not_fit_it(pp):
          pa.array(rng.integers(0, 9, n).astype(np.int64)), pa.array(rng.uniform(0, 1, n))], names=["labels.l0", "labels.l1", "labels.l2", "v", "f"])
     missing = recs[1].drop_columns(["labels.l1"])
     groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
-    for extra in (wide, missing):
+    for extra, last in ((wide, "fdb_hash_kernel(runs, wide)"), (missing, "fdb_hash_kernel(runs)")):
         seq = [recs[0], extra, recs[1]]
         o, kernel = _run_plan(pp, seq, Sum(Col("v")), groups, ordered=True)
-        assert kernel != "fdb_hash_kernel(runs)"
+        assert kernel == last, kernel  # (the last record of the first sequence meets a 400-value dictionary: wide; of the second: narrow again)
         h, _ = _run_plan(pp, seq, Sum(Col("v")), groups, ordered=False)
         assert _rows(o) == sorted(_rows(h), key=_key_order)
+
+
+def _wide_sorted_records(rng, n_total, n_records, cards=(700, 3, 70_000), int_key=None, null_frac=0.02):
+    """Rows over dictionary label columns of the given cardinalities (and, `int_key` = position, an int64 key column there), ordered by
+    the columns in plan order — values ascending bytewise / numerically, NULLs last — cut into records at arbitrary rows. Dictionaries are
+    in DESCENDING value order so that neither indices nor key ids happen to be ranks."""
+    n_cols = len(cards)
+    cols = []
+    for c, k in enumerate(cards):
+        v = rng.integers(0, k, n_total) if c != int_key else rng.integers(-k, k, n_total)
+        if c == int_key:
+            # (no key 0 next to NULL keys: the hash table — the other side of this comparison — files an int64 key 0 and a NULL key under one
+            # fingerprint, as the reference's HashAggregate does, dynparquet/hashed.go:254-272; the run path keeps them apart like
+            # ordered_aggregate.go's group ranges)
+            v = np.where(v == 0, k, v)
+        cols.append(np.where(rng.random(n_total) < null_frac, np.iinfo(np.int64).max, v))
+    order = np.lexsort(tuple(reversed(cols)))
+    cols = [c[order] for c in cols]
+    val = rng.integers(-50, 1000, n_total).astype(np.int64)
+    cuts = [0] + sorted(rng.integers(1, n_total, n_records - 1).tolist()) + [n_total]
+    recs = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        arrays, names = [], []
+        for c, k in enumerate(cards):
+            x = cols[c][a:b]
+            null = x == np.iinfo(np.int64).max
+            if c == int_key:
+                arrays.append(pa.array(np.where(null, 0, x), mask=null)); names.append("bucket")
+            else:
+                d = pa.array([b"v%06d" % (k - 1 - i) for i in range(k)], type=pa.binary())
+                arrays.append(pa.DictionaryArray.from_arrays(pa.array(np.where(null, 0, k - 1 - x).astype(np.uint32), mask=null), d)); names.append("labels.l%d" % c)
+        arrays.append(pa.array(val[a:b])); names.append("v")
+        recs.append(pa.RecordBatch.from_arrays(arrays, names=names))
+    return recs
+
+
+def _key_order_mixed(r, nkeys):
+    return tuple((x is None, (x if x is not None else 0) if isinstance(x, (int, type(None))) and not isinstance(x, bytes) else x) for x in r[:nkeys])
+
+
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("agg_name", ["sum", "min", "count"])
+def test_wide_run_records_dictionaries_beyond_one_byte_of_key_ids(pp, agg_name, resident):
+    """Group columns of 700, 3 and 70 000 distinct values (a key id needs 2 and 3 bytes): the table-free path with wide run records —
+    no hash kernel ran — equals the hash aggregate's groups in key order."""
+    rng = np.random.default_rng(21)
+    recs = _wide_sorted_records(rng, 400_000, 5)
+    agg = {"sum": Sum(Col("v")), "min": Min(Col("v")), "count": Count(Col("v"))}[agg_name]
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    o, kernel = _run_plan(pp, recs, agg, groups, ordered=True, resident=resident)
+    assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    h, hk = _run_plan(pp, recs, agg, groups, ordered=False, resident=resident)
+    assert "runs" not in hk
+    orows, hrows = _rows(o), sorted(_rows(h), key=_key_order)
+    assert len(orows) > 100_000 and orows == hrows
+
+
+@pytest.mark.parametrize("pos", [0, 1])
+def test_wide_run_records_int64_keys(pp, pos):
+    """An int64 group key (a time bucket — the `window` vectors' shape) in front of / behind a dictionary column, with NULLs in both:
+    runs hold the raw value, the order check compares values (NULL last); equal to the hash aggregate sorted by key."""
+    rng = np.random.default_rng(22 + pos)
+    cards = (5_000, 40) if pos == 0 else (40, 5_000)
+    recs = _wide_sorted_records(rng, 300_000, 4, cards=cards, int_key=pos)
+    groups = [Col("bucket"), Col("labels.l1")] if pos == 0 else [Col("labels.l0"), Col("bucket")]
+    o, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True, resident=True)
+    assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False, resident=True)
+    key = lambda r: tuple((x is None, x if x is not None else 0) for x in r[:2])  # noqa: E731
+    orows = _rows(o)
+    assert len(orows) > 50_000 and orows == sorted(_rows(h), key=key)
+
+
+def test_wide_run_records_group_columns_that_come_and_go(pp):
+    """Dynamic label columns that appear later and disappear again (a record that lacks a group column: id 0 = NULL there; a plan that
+    gains a column: later segments have longer tuples) stay on the table-free path; equal to the hash aggregate."""
+    rng = np.random.default_rng(23)
+    n = 20_000
+    def col(k):
+        x = np.sort(rng.integers(0, k, n))
+        return pa.DictionaryArray.from_arrays(pa.array(x.astype(np.uint32)), pa.array([b"k%04d" % i for i in range(k)], type=pa.binary()))
+    v = lambda: pa.array(rng.integers(0, 100, n).astype(np.int64))  # noqa: E731
+    recs = [pa.RecordBatch.from_arrays([col(300), v()], names=["labels.a", "v"]),
+            pa.RecordBatch.from_arrays([col(300), col(7), v()], names=["labels.a", "labels.b", "v"]),
+            pa.RecordBatch.from_arrays([col(5), v()], names=["labels.b", "v"]),
+            pa.RecordBatch.from_arrays([col(300), col(7), col(2), v()], names=["labels.a", "labels.b", "labels.c", "v"])]
+    o, kernel = _run_plan(pp, recs, Sum(Col("v")), [DynCol("labels")], ordered=True)
+    assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), [DynCol("labels")], ordered=False)
+    assert o.schema.names == h.schema.names[:-1] + ["v"]
+    assert sorted(_rows(o), key=repr) == sorted(_rows(h), key=repr) and o.num_rows > 300
+
+
+def test_every_table_free_test_shape_with_wide_records_forced(pp, monkeypatch):
+    """FDB_RUNS_WIDE: the narrow-record shapes above through the wide-record kernel — same answers."""
+    monkeypatch.setenv("FDB_RUNS_WIDE", "1")
+    rng = np.random.default_rng(24)
+    recs = _sorted_label_records(rng, 250_000, 5)
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    for agg in (Sum(Col("v")), Sum(Col("f")), Max(Col("f")), Count(Col("v"))):
+        o, kernel = _run_plan(pp, recs, agg, groups, ordered=True, resident=True, filt=Col("v") > 100)
+        assert kernel == "fdb_hash_kernel(runs, wide)"
+        h, _ = _run_plan(pp, recs, agg, groups, ordered=False, resident=True, filt=Col("v") > 100)
+        orows, hrows = _rows(o), sorted(_rows(h), key=_key_order)
+        assert [r[:3] for r in orows] == [r[:3] for r in hrows]
+        for a, b in zip(orows, hrows):
+            assert a[3] == b[3] or (isinstance(a[3], float) and abs(a[3] - b[3]) <= 1e-9 * max(1.0, abs(b[3]))), (a, b)
+    # every row its own run (more runs in a tile than a wave's stage holds: they go straight into the chunk), unsorted input (falls back)
+    n = 70_000
+    uniq = pa.RecordBatch.from_arrays(
+        [pa.DictionaryArray.from_arrays(pa.array(np.arange(n, dtype=np.uint32)), pa.array([b"u%06d" % i for i in range(n)], type=pa.binary())),
+         pa.array(rng.integers(0, 9, n).astype(np.int64))], names=["labels.u", "v"])
+    for rec in (uniq, uniq.take(pa.array(rng.permutation(n)))):
+        o, kernel = _run_plan(pp, [rec], Sum(Col("v")), [Col("labels.u")], ordered=True, resident=True)
+        assert kernel == "fdb_hash_kernel(runs, wide)"
+        h, _ = _run_plan(pp, [rec], Sum(Col("v")), [Col("labels.u")], ordered=False, resident=True)
+        assert _rows(o) == sorted(_rows(h), key=lambda r: _key_order(r, 1)) and o.num_rows == n
+
+
+def test_benchmark_schema_query_over_a_table_sorted_by_path(pp):
+    """BASELINE.json config 2's query — labels.code == '200', SUM(value) GROUP BY labels.path (1 024 values: beyond the narrow record) —
+    over bench.py's generator with the rows of every record sorted by labels.path: an ordered plan takes the table-free path and
+    equals the hash aggregate; sums within 1e-9 (the fold order differs)."""
+    from frostdb_amd import synth
+    recs = []
+    for i in range(3):
+        b = synth.prometheus_chunk(3, i, 400_000, row_base=i * 400_000)
+        path = b.column(b.schema.get_field_index("labels.path"))
+        vals = np.array([v if v is not None else b"\xff" for v in path.dictionary.to_pylist()], dtype=object)
+        idx = path.indices.to_numpy(zero_copy_only=False)
+        keys = np.where(np.isnan(idx.astype(np.float64)), b"\xff\xff", vals[np.nan_to_num(idx.astype(np.float64)).astype(np.int64)])
+        recs.append(b.take(pa.array(np.argsort(keys, kind="stable"))))
+    # (each record is sorted; across records the keys restart, so Finish finds the order broken and merges through the table — still one
+    # run kernel per record; a single sorted record stays table-free to the end)
+    filt, aggs, groups = Col("labels.code") == "200", Sum(Col("value")), [Col("labels.path")]
+    for seq in (recs[:1], recs):
+        o, kernel = _run_plan(pp, seq, aggs, groups, ordered=True, resident=True, filt=filt)
+        assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+        h, _ = _run_plan(pp, seq, aggs, groups, ordered=False, resident=True, filt=filt)
+        orows, hrows = _rows(o), sorted(_rows(h), key=lambda r: _key_order(r, 1))
+        assert [r[0] for r in orows] == [r[0] for r in hrows] and len(orows) > 1000
+        for a, b in zip(orows, hrows):
+            assert abs(a[1] - b[1]) <= 1e-9 * abs(b[1]), (a, b)
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -2298,6 +2298,42 @@ def test_oracle_sees_ten_million_rows_of_the_benchmark_workloads(pp, cfg):
     assert_same_result(got, want, ["labels.path"] + [a.Name() for a in q["aggs"]], float_cols={"sum(value)"})
 
 
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_oracle_sees_all_hundred_million_rows_of_the_benchmark_workloads(pp, cfg):
+    """BASELINE.json configs 2 and 3 at their FULL size — 100 M rows, bench.py's generator and record size (4 × 25 M, one launch) —
+    against the ORACLE run the way bench.py's cpu_baseline runs it (one chain per host core → Synchronizer → final stage):
+    every group's count / MIN / MAX bit-exact, sums within 1e-9 relative. (Round 4 stopped at 10 M rows for the oracle and used numpy
+    at this size.)"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from frostdb_amd import synth
+    from oracle import OracleBatch, OraclePlan
+    q = CFG2 if cfg == "cfg2" else CFG3
+    per = 25_000_000
+    with ThreadPoolExecutor(4) as ex:
+        recs = list(ex.map(lambda i: synth.prometheus_chunk(0, i, per, row_base=i * per, cfg3=(cfg == "cfg3")), range(4)))
+    keep = [pp.ResidentBatch(r) for r in recs]
+    plan = pp.HashAggregatePlan(q["filter_expr"], q["aggs"], q["groups"])
+    try:
+        plan.CallbackResident(keep)
+        assert plan.last_kernel() == "fdb_plan_kernel"
+        got = arrow_to_pydict(plan.Finish())
+    finally:
+        plan.Close()
+        for k in keep:
+            k.close()
+    threads = os.cpu_count() or 1
+    batches = [OracleBatch.from_arrow(r.slice(o, min(1 << 20, per - o))) for r in recs for o in range(0, per, 1 << 20)]
+    oplan = OraclePlan(q["filter_expr"], q["aggs"], q["groups"], nchains=threads)
+    res = oplan.execute(batches, threads)
+    want = res.to_pydict()
+    res.close(); oplan.close()
+    for b in batches:
+        b.close()
+    assert sum(want["count(value)"]) > 10_000_000 if cfg == "cfg3" else len(want["labels.path"]) == 1025
+    assert_same_result(got, want, ["labels.path"] + [a.Name() for a in q["aggs"]], float_cols={"sum(value)"})
+
+
 def test_convert_isnull_if_projections_on_the_device(pp):
     """convertProjection / isNullProjection / ifExprProjection (project.go:493-702) fused into the scan: as aggregate inputs
     (`sum(convert(ivalue, float64) * value)`, `sum(if(ivalue > 10) { ivalue } else { 1})`) and as group keys (`isnull(ivalue)`,

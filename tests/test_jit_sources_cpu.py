@@ -23,6 +23,8 @@ SHAPES = [
     ("hash_32_columns", ["32"], "fdb_hash_kernel"),                  # cfg 5
     ("hash_int64_key", ["8", "1"], "fdb_hash_kernel"),
     ("runs_32_columns", ["32", "2"], "fdb_hash_kernel"),             # the table-free OrderedAggregate's run kernel
+    ("runs_wide_32_columns", ["32", "3"], "fdb_hash_kernel"),        # … writing wide records (any cardinality: tuples from re-loaded columns)
+    ("runs_wide_int64_key", ["3", "4"], "fdb_hash_kernel"),          # … with an int64 key column
 ]
 
 

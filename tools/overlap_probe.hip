@@ -170,6 +170,50 @@ __global__ __launch_bounds__(256) void pipelined_kernel(const Args a) {
   if (acc == 0x1234567u) *a.sink = acc;
 }
 
+
+// ---- C: how fast is ONE counter? every wave draws `per_wave` tickets from the same 8-byte word with a returning atomicAdd (one lane
+// per wave, the wave waits for the answer — what a wave that appends its new groups to a dense log would do once per tile)
+__global__ __launch_bounds__(256) void counter_kernel(u64* counter, int per_wave, u64* sink) {
+  u64 acc = 0;
+  for (int i = 0; i < per_wave; i++) {
+    u64 t = 0;
+    if ((threadIdx.x & 63) == 0) t = atomicAdd(counter, 22ull);
+    t = __shfl(t, 0, 64);
+    acc += t;
+    asm volatile("" : "+v"(acc));
+  }
+  if (acc == 0x1234567u) *sink = acc;
+}
+
+// ---- S: 144-byte key tuples (nine 16-byte stores from the inserting lane, as fdb_hash_kernel writes them), 35 % of the lanes insert:
+// at slot × 144 of a table-sized key store (today), or at consecutive positions of a dense log (one counter draw per wave)
+template <bool DENSE>
+__global__ __launch_bounds__(256) void tuples_kernel(u32x4* keys, u64 mask, u64 n_rows, u64* counter, u64* sink) {
+  const u64 n_tiles = (n_rows + 255) / 256;
+  const int lane = threadIdx.x & 63;
+  for (u64 t = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); t < n_tiles; t += (u64)gridDim.x * 4) {
+    const u64 row = t * 256 + (u64)lane * 4;
+    const u64 hsh = mix(row * 0x9E3779B97F4A7C15ULL + 777);
+    const bool ins = (hsh & 1023) < 358;  // 35 %
+    const unsigned long long b = __ballot(ins);
+    if (b == 0ull) continue;
+    u64 pos;
+    if (DENSE) {
+      u64 base = 0;
+      if (lane == __builtin_ctzll(b)) base = atomicAdd(counter, (u64)__popcll(b));
+      base = __shfl(base, __builtin_ctzll(b), 64);
+      pos = base + (u64)__popcll(b & ((1ull << lane) - 1ull));
+    } else {
+      pos = (hsh >> 10) & mask;
+    }
+    if (ins) {
+      u32x4* d = keys + pos * 9;
+#pragma unroll
+      for (int w = 0; w < 9; w++) d[w] = u32x4{(u32)row, (u32)w, (u32)hsh, 7u};
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const u64 n = argc > 1 ? strtoull(argv[1], nullptr, 10) : 100000000ull;
   const u64 table_mb = argc > 2 ? strtoull(argv[2], nullptr, 10) : 1024;
@@ -210,6 +254,29 @@ int main(int argc, char** argv) {
     const float P = timed([&] { hipLaunchKernelGGL(pipelined_kernel, dim3(g), dim3(256), 0, 0, a); });
     printf("F fused, %d workgroups/CU: stream + slots %7.3f ms, + entry loads %7.3f ms, + atomics %7.3f ms = %5.1f ps/row\n", per_cu, F0, F1, F2, F2 * 1e9 / n);
     printf("P fused + software pipelined, %d workgroups/CU:         %7.3f ms = %5.1f ps/row\n", per_cu, P, P * 1e9 / n);
+  }
+
+  if (want('C')) {
+    u64* counter; CHECK(hipMalloc(&counter, 256)); CHECK(hipMemset(counter, 0, 256));
+    for (int per_cu : {4, 8}) for (int per_wave : {16, 64}) {
+      const int g = cus * per_cu;
+      const float ms = timed([&] { hipLaunchKernelGGL(counter_kernel, dim3(g), dim3(256), 0, 0, counter, per_wave, a.sink); });
+      const double n_at = (double)g * 4 * per_wave;
+      printf("C one counter, %d workgroups/CU, %d draws per wave: %8.0f draws in %7.3f ms = %6.1f ns per draw (%5.1f M draws/s)\n", per_cu, per_wave, n_at, ms, ms * 1e6 / n_at, n_at / ms / 1e3);
+    }
+    CHECK(hipFree(counter));
+  }
+  if (want('S')) {
+    const u64 slots = 1ull << 26;  // a 64 M-slot key store: 9.7 GB (only the touched tuples are ever written)
+    u32x4* keys; CHECK(hipMalloc(&keys, slots * 144));
+    u64* counter; CHECK(hipMalloc(&counter, 256));
+    const u64 rows = 96ull << 20;  // 24 M lanes × 4 rows: the insert-heavy launch of cfg 5 (≈ 8.4 M inserts)
+    const int g = cus * 8;
+    const float s0 = timed([&] { hipLaunchKernelGGL(tuples_kernel<false>, dim3(g), dim3(256), 0, 0, keys, slots - 1, rows, counter, a.sink); });
+    const float s1 = timed([&] { CHECK(hipMemsetAsync(counter, 0, 8)); hipLaunchKernelGGL(tuples_kernel<true>, dim3(g), dim3(256), 0, 0, keys, slots - 1, rows, counter, a.sink); });
+    u64 n_ins = 0; CHECK(hipMemcpy(&n_ins, counter, 8, hipMemcpyDeviceToHost));
+    printf("S key tuples of %.1f M inserts (9 x 16-byte stores each): at slot x 144 of a 64 M-slot store %7.3f ms, at consecutive positions of a dense log %7.3f ms\n", n_ins / 1e6, s0, s1);
+    CHECK(hipFree(keys)); CHECK(hipFree(counter));
   }
   return 0;
 }
