@@ -64,6 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch-rows", type=int, default=25_000_000, help="rows per resident record (part)")
     ap.add_argument("--groups", type=int, default=10_000_000, help="cfg 5: distinct groups")
     ap.add_argument("--cfg5-sorted", action="store_true", help="cfg 5: every record's rows ordered by group (a scan of a table sorted by its label columns)")
+    ap.add_argument("--cfg2-sorted", action="store_true", help="cfg 2: the table sorted by labels.path, the plan an OrderedAggregate (the run kernel's wide records: 1 024 path values)")
+    ap.add_argument("--cfg5-wide-dicts", action="store_true", help="cfg 5: label dictionaries of 512 … 65 532 entries (with --cfg5-sorted: the run kernel's medium records)")
     ap.add_argument("--rows-per-thread", type=int, default=0, help="0: slot kernel (default); 4/8: sequential kernel")
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--host-records", action="store_true",
@@ -253,7 +255,7 @@ def self_launch(args):
 class Workload:
     """One configuration made resident on this rank's GPU + the numpy expectation of its query."""
 
-    def __init__(self, args, config, rows, rank, device, keep_host=0, gen_threads=None, cfg5_sorted=False):
+    def __init__(self, args, config, rows, rank, device, keep_host=0, gen_threads=None, cfg5_sorted=False, cfg5_wide=False, cfg2_sorted=False):
         from frostdb_amd import physicalplan as pp
         from frostdb_amd import synth
         from frostdb_amd.logicalplan import to_desc
@@ -261,9 +263,12 @@ class Workload:
         self.filt, self.aggs, self.groups, self.qdesc = query(config)
         # cfg 5 over a table SORTED by its label columns: the reference plans an OrderedAggregate for it (physicalplan.go:433-449,
         # :525-560) — one aggregation, input ordered by the group columns — and so does this workload (fdb_plan_desc.ordered)
-        self.ordered = bool(config == 5 and (cfg5_sorted or args.cfg5_sorted))
+        self.ordered = bool((config == 5 and (cfg5_sorted or args.cfg5_sorted)) or (config == 2 and (cfg2_sorted or args.cfg2_sorted)))
+        self.wide_dicts = bool(config == 5 and (cfg5_wide or args.cfg5_wide_dicts))
         if self.ordered:
-            self.qdesc += "; table sorted by its label columns → OrderedAggregate"
+            self.qdesc += "; table sorted by its label columns → OrderedAggregate" if config == 5 else "; table sorted by labels.path → OrderedAggregate (1 024 path values: wide run records)"
+        if self.wide_dicts:
+            self.qdesc += "; label dictionaries of 512 / 1 024 / 4 096 / 65 532 entries (key ids of two bytes: medium run records)"
         self.desc = to_desc(self.filt, self.aggs, self.groups, ordered=self.ordered)  # planned once; every step instantiates a fresh operator chain
         t0 = time.time()
         br = args.batch_rows
@@ -274,9 +279,9 @@ class Workload:
 
         def gen(i):
             if config == 5:
-                b = synth.cfg5_chunk(rank, i, sizes[i], n_groups=args.groups, sorted_rows=self.ordered, of_chunks=n_chunks if self.ordered else 0)
+                b = synth.cfg5_chunk(rank, i, sizes[i], n_groups=args.groups, sorted_rows=self.ordered, of_chunks=n_chunks if self.ordered else 0, wide_dicts=self.wide_dicts)
                 return b, expected_cfg5(b), None
-            b = synth.prometheus_chunk(rank, i, sizes[i], row_base=i * br, cfg3=(config == 3))
+            b = synth.prometheus_chunk(rank, i, sizes[i], row_base=i * br, cfg3=(config == 3), sorted_by_path=n_chunks if self.ordered else 0)
             sel = None
             if i < keep_host:
                 v = b.column(b.schema.get_field_index("value")).to_numpy()
@@ -332,14 +337,19 @@ class Workload:
         got_keys = key.to_pylist()
         if self.config == 2:
             exp_sum, exp_cnt = expected
-            got = dict(zip(got_keys, col("sum(value)").to_pylist()))
+            got = dict(zip(got_keys, col("value" if self.ordered else "sum(value)").to_pylist()))  # (partial-stage OrderedAggregate naming, ordered_aggregate.go:551-557)
             for i, p in enumerate(paths):
                 if exp_cnt[i] == 0:
                     assert p not in got, p
                 else:
                     assert math.isclose(got[p], exp_sum[i], rel_tol=1e-9), (p, got[p], exp_sum[i])
             assert len(got) == int((exp_cnt > 0).sum())
-            return {"groups_out": len(got), "selected_rows": int(exp_cnt.sum())}
+            res = {"groups_out": len(got), "selected_rows": int(exp_cnt.sum())}
+            if self.ordered:  # every group once, in key order (NULL last)
+                ks = [(k is None, k or b"") for k in got_keys]
+                assert all(a < b for a, b in zip(ks[:-1], ks[1:])), "ordered result is not strictly increasing in key order"
+                res["key_order"] = "strictly increasing (every group once, sorted by labels.path, NULL last)"
+            return res
         cnt, mn, mx, s = expected
         rows = dict(zip(got_keys, zip(col("count(value)").to_pylist(), col("min(timestamp)").to_pylist(), col("max(timestamp)").to_pylist(),
                                       col("sum(value)").to_pylist())))
@@ -846,6 +856,23 @@ def other_configs(args, wl, rank, device, group, comm):
                 "value": 100_000_000 * st / r5["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r5["elapsed"] / st * 1e3,
                 "roofline": roofline_of(r5, 100_000_000, st, "cfg5_sorted"), "checked": r5["checked"]}
             w3.release()
+        if cfg == 5 and want("cfg5_sorted_wide"):  # … with label dictionaries of 512 – 65 532 entries: the run kernel writes MEDIUM records, two bytes per key id (round 5)
+            w4 = Workload(args, 5, 100_000_000, rank, device, cfg5_sorted=True, cfg5_wide=True)
+            r6 = run_workload(args, w4, st, wu, group, comm, 100_000_000)
+            others["cfg5_sorted_wide"] = {
+                "workload": f"cfg5_sorted_wide: Prometheus schema, 100000000 rows, {w4.qdesc}",
+                "value": 100_000_000 * st / r6["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r6["elapsed"] / st * 1e3,
+                "roofline": roofline_of(r6, 100_000_000, st, "cfg5_sorted_wide"), "checked": r6["checked"], "jit": jit_of(r6)}
+            w4.release()
+    if want("cfg2_sorted"):  # the benchmark's own schema and query over a table sorted by labels.path: table-free OrderedAggregate, wide run records
+        w5 = Workload(args, 2, 100_000_000, rank, device, cfg2_sorted=True)
+        st2 = max(5, args.steps // 2)
+        r7 = run_workload(args, w5, st2, 2, group, comm, 100_000_000)
+        others["cfg2_sorted"] = {
+            "workload": f"cfg2_sorted: Prometheus schema, 100000000 rows, {w5.qdesc}",
+            "value": 100_000_000 * st2 / r7["elapsed"], "unit": "rows/s", "steps": st2, "warmup": 2, "ms_per_step": r7["elapsed"] / st2 * 1e3,
+            "roofline": roofline_of(r7, 100_000_000, st2, "cfg2_sorted"), "checked": r7["checked"], "jit": jit_of(r7)}
+        w5.release()
     if want("parquet"):
         others["parquet"] = measure_parquet(device)
     return others
@@ -1082,6 +1109,8 @@ def compare_with_oracle(wl, got, want):
         cols = [rec.column(rec.schema.names.index(n)).to_pylist() for n in rec.schema.names if n != "labels.path"]
         names = [n for n in rec.schema.names if n != "labels.path"]
         return {k: dict(zip(names, v)) for k, v in zip([x if not isinstance(x, str) else x.encode() for x in key.to_pylist()], zip(*cols))}
+    if wl.ordered and got.schema.names != want.schema.names and got.num_columns == want.num_columns:
+        got = got.rename_columns(want.schema.names)  # (a partial-stage OrderedAggregate names its result after the column, ordered_aggregate.go:551-557)
     g, w = rows(got), rows(want)
     assert g.keys() == w.keys(), "oracle parity: the group sets differ"
     for k, wv in w.items():

@@ -211,6 +211,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     // LUTs: predicate LUTs from the record's blob, key-id LUTs appended
     std::vector<FdbHashCol> hcols(R.groups.size());
     std::vector<size_t> lut_off(R.groups.size(), 0);
+    std::vector<char> lut_identity(R.groups.size(), 0);
     for (size_t g = 0; g < R.groups.size(); g++) {
       const GroupRes& gr = R.groups[g];
       FdbHashCol& C = hcols[g];
@@ -221,7 +222,16 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       if (gr.kind == 2) { C.src_word = gr.expr_root; has_expr = true; continue; }  // computed int64 key: no stored column
       const DevColumn& c = b.cols[(size_t)gr.ci];
       C.values = c.d_values; C.validity = c.d_validity;
-      if (gr.kind == 0) { C.lut_len = (uint32_t)gr.lut->size(); lut_off[g] = R.blob.add(gr.lut->data(), gr.lut->size() * 4); }
+      if (gr.kind == 0) {
+        // the record's dictionary IS the plan's value list of the column, in order (the usual case: the parts of a table share their
+        // dictionaries, and the plan interned the first one it saw entry by entry): key id = index + 1 — no table to ship or to read.
+        // ($FDB_NO_IDENTITY_LUT: A/B aid)
+        const std::vector<uint32_t>& L = *gr.lut;
+        bool identity = !L.empty() && L.front() == 1u && L.back() == (uint32_t)L.size() && std::getenv("FDB_NO_IDENTITY_LUT") == nullptr;
+        for (size_t i = 0; identity && i < L.size(); i++) identity = L[i] == (uint32_t)i + 1u;
+        C.lut_len = (uint32_t)L.size();
+        if (identity) lut_identity[g] = 1; else lut_off[g] = R.blob.add(L.data(), L.size() * 4);
+      }
     }
     // canonical: the record carries every group column of the plan, in the plan's order — then column c's word is a
     // compile-time constant of the specialised kernel (4 + the widths before it) and aligned quads of dictionary columns are
@@ -239,7 +249,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       a.leaves[p.index].lut_lds = lds;
     }
     for (size_t g = 0; g < hcols.size(); g++) {
-      if (hcols[g].kind != 0) continue;
+      if (hcols[g].kind != 0 || lut_identity[g]) continue;  // (identity: lut stays nullptr)
       const size_t bytes = (size_t)hcols[g].lut_len * 4;
       hcols[g].lut = (const uint32_t*)(d_blob + lut_off[g]);
       if (bytes <= 8192 && lds_off + bytes <= 60 * 1024) { hcols[g].lut_lds = (uint32_t)lds_off; lds_off = align_up_sz(lds_off + bytes, 16); }
@@ -255,9 +265,9 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     int jit_grid = 0;
     if (runs) {  // (the shape is that of a runs launch; the real pointers follow below)
       h.runs.tuples = (unsigned char*)(uintptr_t)1;
-      const bool narrow = runs_narrow_ok(R);
-      h.runs.run_words = narrow ? 0 : h_key_words_ + 4;
-      h.runs.stage_cap = narrow ? FDB_RUN_STAGE : FDB_RUN_WAVE_LDS / (h.runs.run_words * 4);
+      const int fmt = runs_format(R);
+      h.runs.run_words = fmt == 0 ? 0 : fmt == 1 ? FDB_RUN_MEDIUM_WORDS : h_key_words_ + 4;
+      h.runs.stage_cap = fmt == 0 ? FDB_RUN_STAGE : fmt == 1 ? FDB_RUN_WAVE_LDS / FDB_RUN_MEDIUM_BYTES : FDB_RUN_WAVE_LDS / (h.runs.run_words * 4);
     }
     const size_t run_lds = runs ? (size_t)4 * FDB_RUN_WAVE_LDS : 0;
     if (sub_tiles != 4 && a.lds_lut_bytes <= FDB_LDS_BUDGET) {
@@ -286,7 +296,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       const int64_t n_chunks = b.rows / (FDB_RUN_CHUNK - 256) + launch_grid * 4 + 2;  // a wave abandons < 256 slots when it changes chunks and keeps one chunk open
       seg.capacity = n_chunks * FDB_RUN_CHUNK;
       seg.run_words = h.runs.run_words;
-      const size_t tuples_bytes = align_up_sz((size_t)seg.capacity * (seg.run_words ? (size_t)seg.run_words * 4 : (size_t)FDB_RUN_BYTES), 256);
+      const size_t tuples_bytes = align_up_sz((size_t)seg.capacity * (seg.run_words == 0 ? (size_t)FDB_RUN_BYTES : seg.run_words == FDB_RUN_MEDIUM_WORDS ? (size_t)FDB_RUN_MEDIUM_BYTES : (size_t)seg.run_words * 4), 256);
       const size_t dir_bytes = align_up_sz((size_t)seg.n_entries * 8, 256);
       seg.block = ctx_->dev_alloc(tuples_bytes + dir_bytes + 256);
       unsigned char* base = (unsigned char*)seg.block;
@@ -300,7 +310,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
       hip_check(jit_hash_launch(jit_fn, h, (int)launch_grid, a.lds_lut_bytes + run_lds, stream_), "run scan launch");
-      last_kernel_ = seg.run_words ? "fdb_hash_kernel(runs, wide)" : "fdb_hash_kernel(runs)";
+      last_kernel_ = seg.run_words == 0 ? "fdb_hash_kernel(runs)" : seg.run_words == FDB_RUN_MEDIUM_WORDS ? "fdb_hash_kernel(runs, medium)" : "fdb_hash_kernel(runs, wide)";
       if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); pending_events_.emplace_back(e0, e1); }
       state_dirty_ = true;
       stat_launches += 1;
@@ -1028,7 +1038,7 @@ void Plan::merge_hash(Plan& src) {
 
 // May the records of this push go through the run kernel? One aggregation that is not a composite, the specialised kernels
 // available, room for the segments — and a run record that the waves' LDS stages can hold a useful number of. Which RECORD a launch
-// writes is decided per pushed record (runs_narrow_ok): the narrow one — a byte per key id — while every group column is a dictionary
+// writes is decided per pushed record (runs_format): the narrow one — a byte per key id — while every group column is a dictionary
 // column of ≤ 254 distinct values, there are at most FDB_RUN_TUPLE_BYTES of them and the record carries all of them in the plan's
 // order; otherwise the wide one (the table's own key tuple: any cardinality, int64 and computed keys, absent columns).
 bool Plan::runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>& Rs, const std::vector<int>& live) const {
@@ -1036,6 +1046,20 @@ bool Plan::runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>
   if (off || !ordered_ || !jit_possible() || aggs_.size() != 1 || aggs_[0].role != 0) return false;
   if (gcols_.empty() || gcols_.size() > FDB_MAX_HASH_GCOLS) return false;
   if (runs_.size() + live.size() > FDB_MAX_RUN_SEGMENTS) return false;
+  // Small key spaces stay with the dense table: a table that fits LDS is the fastest scan there is (one launch for every record, no run
+  // store to size and merge — cfg 2's query over a table sorted by labels.path: 0.3 ms per 100 M rows against 0.9 ms of run kernels and a
+  // Finish over 390 k runs) and its few thousand groups are sorted on the host in microseconds. The run store is for key spaces that would
+  // need the global table. ($FDB_RUNS_ALWAYS: test aid — the run machinery on small shapes)
+  if (runs_.empty() && std::getenv("FDB_RUNS_ALWAYS") == nullptr && gcols_.size() <= FDB_MAX_DENSE_GCOLS) {
+    bool dense = true;
+    uint64_t space = 1;
+    for (const GroupColState& g : gcols_) {
+      if (g.kind != 0) { dense = false; break; }
+      space *= (uint64_t)g.values.size() + 1;
+      if (space > 8192) { dense = false; break; }
+    }
+    if (dense) return false;
+  }
   size_t kw = 4;  // (hash_layout() has not seen the columns this push added yet)
   for (const GroupColState& g : gcols_) kw += g.kind == 0 ? 1 : 2;
   kw = (kw + 3) & ~(size_t)3;
@@ -1043,18 +1067,22 @@ bool Plan::runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>
   if (wide_bytes * 16 > FDB_RUN_WAVE_LDS) return false;  // (a wave's stage should hold a tile's worth of runs of ordered input)
   for (int i : live) {
     if ((uint64_t)bs[i]->rows >= (1ull << 31)) return false;
-    const uint64_t rec = runs_narrow_ok(Rs[(size_t)i]) ? (uint64_t)FDB_RUN_BYTES : wide_bytes;
+    const int fmt = runs_format(Rs[(size_t)i]);
+    const uint64_t rec = fmt == 0 ? (uint64_t)FDB_RUN_BYTES : fmt == 1 ? (uint64_t)FDB_RUN_MEDIUM_BYTES : wide_bytes;
     if ((uint64_t)bs[i]->rows * (rec + 4) > ((uint64_t)48 << 30)) return false;  // (the run store is sized for the worst case — every row a run)
   }
   return true;
 }
 
-bool Plan::runs_narrow_ok(const Resolved& R) const {
-  const bool force_wide = std::getenv("FDB_RUNS_WIDE") != nullptr;  // (A/B and test aid: every run launch writes wide records; read per record so that a test can switch it)
-  if (force_wide || gcols_.size() > FDB_RUN_TUPLE_BYTES || R.groups.size() != gcols_.size()) return false;
-  for (const GroupColState& g : gcols_) if (g.kind != 0 || g.values.size() > 254) return false;
-  for (size_t g = 0; g < R.groups.size(); g++) if (R.groups[g].kind != 0 || R.groups[g].gi != (int)g) return false;
-  return true;
+// Which run record does this record's launch write: 0 narrow (a byte per key id), 1 medium (two bytes), 2 wide.
+int Plan::runs_format(const Resolved& R) const {
+  const char* force = std::getenv("FDB_RUNS_WIDE");  // (A/B and test aid, read per record so that a test can switch it: "1" every launch writes wide records, "m" medium ones where narrow would do)
+  if ((force != nullptr && force[0] == '1') || gcols_.size() > FDB_RUN_TUPLE_BYTES || R.groups.size() != gcols_.size()) return 2;
+  size_t most = 0;
+  for (const GroupColState& g : gcols_) { if (g.kind != 0) return 2; most = std::max(most, g.values.size()); }
+  for (size_t g = 0; g < R.groups.size(); g++) if (R.groups[g].kind != 0 || R.groups[g].gi != (int)g) return 2;
+  if (most > 65534) return 2;
+  return most > 254 || force != nullptr ? 1 : 0;
 }
 
 void Plan::runs_free() {

@@ -846,7 +846,8 @@ struct HashGen {
     const int BLK = 256, TILE = BLK * 4, GROUP = 8;
     // runs: 1 = narrow records (a key id is a byte, packed while the fingerprint is computed), 2 = wide records (the table's own key tuple,
     // written by the lanes that end a run from re-loaded columns — fdb_kernels.h FdbRunsOut)
-    const bool narrow = s.runs == 1, wide = s.runs == 2;
+    // 3 = medium records: like 1 with TWO bytes per key id (≤ 65 534 distinct values per column; 16 more registers per row)
+    const bool narrow = s.runs == 1, wide = s.runs == 2, medium = s.runs == 3;
     o << "#define FDB_DEVICE_HELPERS 1\n#include \"fdb_kernels.h\"\n" << kPreamble << kHashPreamble;
     // The runs kernel wants ≈149 VGPRs = 3 waves per SIMD, which is also what its LDS stage (4 × 12 KiB per workgroup) lets a CU hold.
     // ($FDB_RUNS_WAVES_PER_EU: tuning aid — caps the registers so that that many waves fit a SIMD; 0 / unset = no cap)
@@ -865,7 +866,7 @@ struct HashGen {
         o << "  for (uint32_t i = tid; i < K_len" << l << "; i += " << BLK << ") smem[K_lds" << l << " + i] = as_global(K_lut" << l << ")[i];\n";
     }
     for (size_t c = 0; c < s.cols.size(); c++)
-      if (s.cols[c].kind == 0 && s.cols[c].lut_in_lds)
+      if (s.cols[c].kind == 0 && s.cols[c].lut_in_lds && !s.cols[c].lut_identity)
         o << "  { uint32_t* dst = reinterpret_cast<uint32_t*>(smem + hc[" << c << "].lut_lds); const uint32_t n = hc[" << c << "].lut_len; const uint32_t* src = hc[" << c
           << "].lut; for (uint32_t i = tid; i < n; i += " << BLK << ") dst[i] = as_global(src)[i]; }\n";
     o << "  __syncthreads();\n";
@@ -917,6 +918,7 @@ struct HashGen {
     o << "    unsigned long long h1_0 = 0, h1_1 = 0, h1_2 = 0, h1_3 = 0, h2_0 = 0, h2_1 = 0, h2_2 = 0, h2_3 = 0, vm_0 = 0, vm_1 = 0, vm_2 = 0, vm_3 = 0;\n";
     // runs mode: the key ids of a row, one byte per group column, packed as they are computed (8 registers per row)
     if (narrow) for (int k = 0; k < 4; k++) o << "    u32x4 ta_" << k << " = {0u, 0u, 0u, 0u}, tb_" << k << " = {0u, 0u, 0u, 0u};\n";
+    if (medium) for (int k = 0; k < 4; k++) o << "    u32x4 ta_" << k << " = {0u, 0u, 0u, 0u}, tb_" << k << " = {0u, 0u, 0u, 0u}, tc_" << k << " = {0u, 0u, 0u, 0u}, td_" << k << " = {0u, 0u, 0u, 0u};\n";
     for (size_t c0 = 0; c0 < s.cols.size(); c0 += GROUP) {
       const size_t c1 = std::min(s.cols.size(), c0 + GROUP);
       o << "    {\n";
@@ -940,12 +942,15 @@ struct HashGen {
         o << "      {\n        unsigned long long K1 = hc[" << c << "].k1, K2 = hc[" << c << "].k2; asm volatile(\"\" : \"+s\"(K1), \"+s\"(K2));\n        const unsigned long long bit = 1ull << hc[" << c
           << "].gi;\n";
         if (C.kind == 0) {
-          if (C.lut_in_lds) o << "        const uint32_t* L = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
+          // (lut_identity: the record's dictionary IS the plan's value list of this column, in order — key id = index + 1, no table to read)
+          if (C.lut_identity) {}
+          else if (C.lut_in_lds) o << "        const uint32_t* L = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
           else o << "        const uint32_t* L = hc[" << c << "].lut;\n";
           for (int k = 0; k < 4; k++) {
-            o << "        { const uint32_t id = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_in_lds ? "L" : "as_global(L)") << "[" << r << comp4(k) << "] : 0u; fp_add32(h1_" << k << ", h2_"
-              << k << ", K1, K2, id);" << (narrow ? "" : " if (id != 0u) vm_" + std::to_string(k) + " |= bit;");
+            o << "        { const uint32_t id = ((" << r << "_m >> " << k << ") & 1u) ? " << (C.lut_identity ? "(" + r + comp4(k) + " + 1u)" : std::string(C.lut_in_lds ? "L" : "as_global(L)") + "[" + r + comp4(k) + "]") << " : 0u; fp_add32(h1_" << k << ", h2_"
+              << k << ", K1, K2, id);" << (narrow || medium ? "" : " if (id != 0u) vm_" + std::to_string(k) + " |= bit;");
             if (narrow) o << " t" << (c < 16 ? "a" : "b") << "_" << k << comp4((int)((c % 16) / 4)) << " |= id << " << 8 * (c % 4) << ";";
+            if (medium) o << " t" << "abcd"[c / 8] << "_" << k << comp4((int)((c % 8) / 2)) << " |= id << " << 16 * (c % 2) << ";";
             o << " }\n";
           }
         } else if (C.kind == 1) {
@@ -966,10 +971,14 @@ struct HashGen {
       // keep the next group's loads below this point: hoisting all 32 columns' loads to the top of the tile costs ≈390 VGPRs
       // and force the fingerprint updates to happen HERE: LLVM otherwise sinks all 32 columns' multiply-adds into the per-row
       // `if (selected)` blocks below and keeps 4 × 32 key ids live until then
-      if (narrow) o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3) :: \"memory\");\n";
+      if (narrow || medium) o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3) :: \"memory\");\n";
       else o << "      asm volatile(\"\" : \"+v\"(h1_0), \"+v\"(h1_1), \"+v\"(h1_2), \"+v\"(h1_3), \"+v\"(h2_0), \"+v\"(h2_1), \"+v\"(h2_2), \"+v\"(h2_3), \"+v\"(vm_0), \"+v\"(vm_1), \"+v\"(vm_2), \"+v\"(vm_3) :: \"memory\");\n";
       // (same for the packed key ids of runs mode: pinned here, or all 4 × 32 ids stay live until the rows' tuples are stored)
       if (narrow) o << "      asm volatile(\"\" : \"+v\"(ta_0), \"+v\"(ta_1), \"+v\"(ta_2), \"+v\"(ta_3), \"+v\"(tb_0), \"+v\"(tb_1), \"+v\"(tb_2), \"+v\"(tb_3));\n";
+      if (medium) {  // (only the register quads this column group wrote: the others are still zero and need not be pinned)
+        const char q = "abcd"[c0 / 8];
+        o << "      asm volatile(\"\" : \"+v\"(t" << q << "_0), \"+v\"(t" << q << "_1), \"+v\"(t" << q << "_2), \"+v\"(t" << q << "_3));\n";
+      }
       o << "    }\n";
     }
     for (int k = 0; k < 4; k++) o << "    fp_final(h1_" << k << ", h2_" << k << ");\n";
@@ -1110,11 +1119,12 @@ struct HashGen {
         const JitHashCol& C = s.cols[c];
         if (C.kind != 0) continue;
         const std::string r = "w" + std::to_string(c);
-        if (C.lut_in_lds) o << "        const uint32_t* L" << c << " = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
+        if (C.lut_identity) {}
+        else if (C.lut_in_lds) o << "        const uint32_t* L" << c << " = reinterpret_cast<const uint32_t*>(smem + hc[" << c << "].lut_lds);\n";
         else o << "        const uint32_t* L" << c << " = hc[" << c << "].lut;\n";
         for (int k = 0; k < 4; k++)
-          o << "        const uint32_t i" << c << "_" << k << " = ((ins_mask & " << (1 << k) << "u) && ((" << r << "_m >> " << k << ") & 1u)) ? " << (C.lut_in_lds ? "L" : "as_global(L") << c
-            << (C.lut_in_lds ? "" : ")") << "[" << r << comp4(k) << "] : 0u;\n";
+          o << "        const uint32_t i" << c << "_" << k << " = ((ins_mask & " << (1 << k) << "u) && ((" << r << "_m >> " << k << ") & 1u)) ? "
+            << (C.lut_identity ? "(" + r + comp4(k) + " + 1u)" : std::string(C.lut_in_lds ? "L" : "as_global(L") + std::to_string(c) + (C.lut_in_lds ? "" : ")") + "[" + r + comp4(k) + "]") << " : 0u;\n";
       }
       // stores: aligned quads of dictionary columns as one 16-byte store when the layout is canonical
       std::vector<bool> in_quad(s.cols.size(), false);
@@ -1161,8 +1171,8 @@ struct HashGen {
     }
     o << "    }\n";
     };
-    if (wide) {
-      // Wide records. As in the narrow case every row still selected ends a run of its wave and holds the run's count and folded
+    if (wide || medium) {
+      // Wide records (and medium ones: the same bookkeeping, the tuple comes out of registers). As in the narrow case every row still selected ends a run of its wave and holds the run's count and folded
       // aggregate; its key tuple is written from re-loaded columns by emit_tuple_stores. The wave's runs wait in its LDS stage
       // (h.runs.stage_cap of them) and leave as one contiguous copy; a tile with more runs than the stage holds (input that is not
       // really ordered) writes them straight into the chunk.
@@ -1172,7 +1182,7 @@ struct HashGen {
       o << "      if (n_w != 0u) {\n        const unsigned long long lt = (1ull << wl2) - 1ull;\n";
       o << "        const uint32_t before = (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));\n";
       o << "        uint32_t rb = s_runs[wv * 4], rp = s_runs[wv * 4 + 1], ps = s_runs[wv * 4 + 2];\n";
-      o << "        const uint32_t RW = (uint32_t)h.runs.run_words, RQ = RW >> 2, CAP = (uint32_t)h.runs.stage_cap;\n";
+      o << "        const uint32_t RW = " << (medium ? std::to_string(FDB_RUN_MEDIUM_BYTES / 4) + "u" : std::string("(uint32_t)h.runs.run_words")) << ", RQ = RW >> 2, CAP = (uint32_t)h.runs.stage_cap;\n";
       o << "        u32x4* stage = reinterpret_cast<u32x4*>(smem + a.lds_lut_bytes + (size_t)wv * " << FDB_RUN_WAVE_LDS << ");\n";
       o << "        const uint32_t n_act = (uint32_t)__popcll(act2), my_act = (uint32_t)__popcll(act2 & lt);\n";
       o << "        const bool sw = rp + n_w > " << FDB_RUN_CHUNK << "u, direct = n_w > CAP;\n";
@@ -1187,8 +1197,19 @@ struct HashGen {
       for (int k = 0; k < 4; k++)
         o << "        uint32_t* d_" << k << " = direct ? reinterpret_cast<uint32_t*>(h.runs.tuples) + (size_t)(base + before + (uint32_t)__builtin_popcount(sel & " << ((1 << k) - 1) << "u)) * RW"
           << " : reinterpret_cast<uint32_t*>(stage) + (size_t)(sbase + before + (uint32_t)__builtin_popcount(sel & " << ((1 << k) - 1) << "u)) * RW;\n";
-      o << "        const uint32_t ins_mask = sel;\n";
-      emit_tuple_stores(true);
+      if (wide) {
+        o << "        const uint32_t ins_mask = sel;\n";
+        emit_tuple_stores(true);
+      } else {
+        const bool has_val = !s.aggs.empty() && s.aggs[0].func != FDB_AGG_COUNT;
+        const bool f64v = has_val && s.aggs[0].func == FDB_AGG_SUM && s.aggs[0].type == FDB_T_F64;
+        for (int k = 0; k < 4; k++) {
+          o << "        if (sel & " << (1 << k) << "u) {\n          u32x4* d = reinterpret_cast<u32x4*>(d_" << k << ");\n";
+          o << "          d[0] = ta_" << k << "; d[1] = tb_" << k << "; d[2] = tc_" << k << "; d[3] = td_" << k << ";\n";
+          o << "          *reinterpret_cast<u64x2*>(d + 4) = u64x2{cnt_" << k << ", "
+            << (has_val ? (f64v ? "(unsigned long long)__double_as_longlong(v0_" + std::to_string(k) + ")" : "(unsigned long long)v0_" + std::to_string(k)) : std::string("0ull")) << "};\n        }\n";
+        }
+      }
       o << "        __builtin_amdgcn_wave_barrier();\n      }\n    }\n    continue;\n";
     }
     if (narrow) {
@@ -1267,9 +1288,9 @@ struct HashGen {
     // every store of a scattered tuple is its own write request, and with 34 four-byte stores those were most of an insert's cost.
     emit_tuple_stores(false);
     o << "  }\n";
-    if (wide) {
+    if (wide || medium) {
       o << "  {  // the runs that still wait in the waves' stages\n    const int wv = (int)(tid >> 6), wl2 = (int)(tid & 63u);\n    __builtin_amdgcn_wave_barrier();\n";
-      o << "    const uint32_t rb = s_runs[wv * 4], rp = s_runs[wv * 4 + 1], ps = s_runs[wv * 4 + 2], RQ = (uint32_t)h.runs.run_words >> 2;\n";
+      o << "    const uint32_t rb = s_runs[wv * 4], rp = s_runs[wv * 4 + 1], ps = s_runs[wv * 4 + 2], RQ = " << (medium ? std::to_string(FDB_RUN_MEDIUM_BYTES / 16) + "u" : std::string("(uint32_t)h.runs.run_words >> 2")) << ";\n";
       o << "    if (rp != " << FDB_RUN_CHUNK << "u || ps != " << FDB_RUN_CHUNK << "u) {\n";
       o << "      const u32x4* stage = reinterpret_cast<const u32x4*>(smem + a.lds_lut_bytes + (size_t)wv * " << FDB_RUN_WAVE_LDS << ");\n";
       o << "      u32x4* out = reinterpret_cast<u32x4*>(h.runs.tuples) + (size_t)(rb + ps) * RQ;\n";
@@ -1486,9 +1507,9 @@ hipFunction_t jit_get(const JitShape& shape) {
 
 std::string JitHashShape::key() const {
   std::ostringstream k;
-  k << "a" << ablate << "c" << need_count << (runs == 1 ? "R" : runs == 2 ? "W" : "") << (runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::getenv("FDB_RUNS_WAVES_PER_EU") : "")
+  k << "a" << ablate << "c" << need_count << (runs == 1 ? "R" : runs == 2 ? "W" : runs == 3 ? "M" : "") << (runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::getenv("FDB_RUNS_WAVES_PER_EU") : "")
     << (runs && std::getenv("FDB_RUNS_ABLATE") ? std::string("x") + std::getenv("FDB_RUNS_ABLATE") : std::string()) << "|";
-  for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
+  for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_identity ? 'i' : C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
   k << '|';
   for (size_t l = 0; l < leaves.size(); l++) {
     const JitLeaf& L = leaves[l];
@@ -1507,11 +1528,12 @@ JitHashShape jit_hash_shape(const FdbHashArgs& h, const FdbHashCol* hcols) {
   JitHashShape s;
   const FdbScanArgs& a = h.base;
   for (int c = 0; c < h.n_hcols; c++)
-    s.cols.push_back({hcols[c].kind, hcols[c].validity != nullptr, hcols[c].kind == 0 && hcols[c].lut_lds != FDB_NO_LDS, hcols[c].kind == 2 ? hcols[c].src_word : -1});
+    s.cols.push_back({hcols[c].kind, hcols[c].validity != nullptr, hcols[c].kind == 0 && hcols[c].lut_lds != FDB_NO_LDS, hcols[c].kind == 2 ? hcols[c].src_word : -1,
+                      hcols[c].kind == 0 && hcols[c].lut == nullptr});
   for (int i = 0; i < a.n_expr; i++) s.exprs.push_back({a.expr[i].kind, a.expr[i].op, a.expr[i].left, a.expr[i].right, a.expr[i].slot, a.expr[i].type});
   s.n_expr_cols = a.n_l8;
   s.need_count = a.need_count != 0;
-  s.runs = h.runs.tuples == nullptr ? 0 : h.runs.run_words != 0 ? 2 : 1;
+  s.runs = h.runs.tuples == nullptr ? 0 : h.runs.run_words == 0 ? 1 : h.runs.run_words == FDB_RUN_MEDIUM_WORDS ? 3 : 2;
   for (int l = 0; l < a.n_leaves; l++) {
     const FdbLeaf& L = a.leaves[l];
     const bool wide = L.kind >= FDB_LEAF_CMP_I64 && L.kind <= FDB_LEAF_CMP_I64_F64;

@@ -48,7 +48,7 @@ struct JitShape {
 };
 
 // Shape of a high-cardinality (hash table) scan: fdb_hash_kernel.
-struct JitHashCol { int kind = 0; bool has_validity = false, lut_in_lds = false; int expr_root = -1; };  // kind 2: computed int64 key
+struct JitHashCol { int kind = 0; bool has_validity = false, lut_in_lds = false; int expr_root = -1; bool lut_identity = false; };  // kind 2: computed int64 key; lut_identity: key id = dictionary index + 1 (FdbHashCol.lut == nullptr)
 struct JitHashShape {
   std::vector<JitHashCol> cols;
   std::vector<JitLeaf> leaves;  // slot / wide describe the leaf's own column (wide = 8-byte values)

@@ -201,11 +201,17 @@ static inline unsigned long long fdb_fp_k2(int gi) {
 // words | its aggregate: 2 words] = run_words 32-bit words (a multiple of 4). Any cardinality, int64 / computed keys, records that lack
 // a group column. The scan does not carry key ids for it: a lane re-loads the columns (one 16-byte load per column for its 4 rows)
 // only when one of its rows ENDS a run, the way an inserting lane of the table path does.
+// The MEDIUM run record (round 5): the narrow record with TWO bytes per key id — [key ids: 64 bytes | rows: 8 | aggregate: 8] = 20 words —
+// for dictionary columns of ≤ 65 534 distinct values (still ≤ FDB_RUN_TUPLE_BYTES columns, all present, ids packed in registers while the
+// fingerprint is computed: no second pass over the columns). In FdbRunsOut.run_words / FdbRunSegs.run_words it is tagged with the value
+// FDB_RUN_MEDIUM_WORDS = 1 (a wide record has ≥ 12 words; 20 itself is a legal wide stride).
+#define FDB_RUN_MEDIUM_WORDS 1                        // the tag; the record itself has FDB_RUN_MEDIUM_BYTES
+#define FDB_RUN_MEDIUM_BYTES 80
 struct FdbRunsOut {
   unsigned char* tuples;         // [capacity][FDB_RUN_BYTES or run_words × 4]; nullptr: not a runs launch
   unsigned int* dir;             // [4 × tiles of the launch][2]
   unsigned int* chunk_cursor;    // next free chunk
-  int32_t run_words;             // 0: the narrow record (FDB_RUN_BYTES); else the wide record's words
+  int32_t run_words;             // 0: the narrow record (FDB_RUN_BYTES); FDB_RUN_MEDIUM_WORDS: the medium record; else the wide record's words
   int32_t stage_cap;             // runs a wave's LDS stage holds: FDB_RUN_STAGE (narrow), FDB_RUN_WAVE_LDS / (run_words × 4) (wide)
 };
 
@@ -341,7 +347,7 @@ hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t strea
 struct FdbRunSegs {
   const unsigned char* tuples[FDB_MAX_RUN_SEGMENTS];   // [run][FDB_RUN_BYTES or run_words × 4]
   uint32_t first_entry[FDB_MAX_RUN_SEGMENTS + 1];  // directory entries of segment s = [first_entry[s], first_entry[s + 1]) of the concatenated directory
-  int32_t run_words[FDB_MAX_RUN_SEGMENTS];         // 0: narrow records; else the segment's wide record stride in words (FdbRunsOut.run_words of its launch)
+  int32_t run_words[FDB_MAX_RUN_SEGMENTS];         // FdbRunsOut.run_words of the segment's launch: 0 narrow, FDB_RUN_MEDIUM_WORDS medium, else the wide record's stride in words
   int32_t n_segs;
 };
 // A group column as the run store's Finish sees it (the plan's column order): kind 0 dictionary (rank table of its key ids at

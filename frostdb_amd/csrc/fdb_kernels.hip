@@ -771,7 +771,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
   }
   for (int c = 0; c < h.n_hcols; c++) {
     const FdbHashCol C = load_col(h.hcols, c);
-    if (C.kind == 0 && C.lut_lds != FDB_NO_LDS) {
+    if (C.kind == 0 && C.lut_lds != FDB_NO_LDS && C.lut != nullptr) {
       uint32_t* dst = reinterpret_cast<uint32_t*>(smem + C.lut_lds);
       for (uint32_t i = tid; i < C.lut_len; i += FDB_HASH_BLOCK) dst[i] = as_global(C.lut)[i];
     }
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(FDB_HASH_BLOCK) void scan_hash_kernel(const FdbHash
         const bool valid = vbm[u] == nullptr || ((vb[u] >> (row & 7)) & 1u);
         if (kind[u] == 0) {
           uint32_t id = 0;
-          if (valid) id = lds[u] != FDB_NO_LDS ? reinterpret_cast<const uint32_t*>(smem + lds[u])[idx[u]] : as_global(lutg[u])[idx[u]];
+          if (valid) id = lutg[u] == nullptr ? idx[u] + 1u : lds[u] != FDB_NO_LDS ? reinterpret_cast<const uint32_t*>(smem + lds[u])[idx[u]] : as_global(lutg[u])[idx[u]];  // (no table: key id = index + 1)
           if (!(a.ablate & 4)) kstage[word[u] * FDB_HASH_BLOCK + tid] = id;
           fp_add32(h1, h2, k1[u], k2[u], id);  // id 0 (NULL) contributes nothing
           if (id != 0) vmask |= 1ull << gi[u];
@@ -2625,21 +2625,23 @@ hipError_t fdb_launch_runs_flags(const unsigned long long* phys, int64_t n_runs,
 // Wide segments (or a mix): the two runs' columns are compared one by one in plan order. A narrow run's id of column c is byte c of
 // its tuple (columns the plan gained later: 0), a wide run's the word `cols[c].word` of its key tuple (past the tuple's end: 0 —
 // the record of that launch did not know the column); int64 columns exist in wide runs only, NULL = bit `gi` of the valid mask clear.
-struct RunRef { const uint32_t* t; int kw; };  // kw: key words of a wide run, 0 = narrow
+__device__ __forceinline__ uint64_t run_bytes(int rw) { return rw == 0 ? (uint64_t)FDB_RUN_BYTES : rw == FDB_RUN_MEDIUM_WORDS ? (uint64_t)FDB_RUN_MEDIUM_BYTES : (uint64_t)rw * 4; }
+struct RunRef { const uint32_t* t; int kw; };  // kw: key words of a wide run, 0 = narrow (a byte per id), -1 = medium (two bytes per id)
 __device__ __forceinline__ RunRef run_ref(const FdbRunSegs& segs, unsigned long long p) {
   const int seg = (int)(p >> 32);
   const int rw = segs.run_words[seg];
   RunRef r;
-  r.t = reinterpret_cast<const uint32_t*>(segs.tuples[seg] + (p & 0xFFFFFFFFull) * (uint64_t)(rw ? rw * 4 : FDB_RUN_BYTES));
-  r.kw = rw ? rw - 4 : 0;
+  r.t = reinterpret_cast<const uint32_t*>(segs.tuples[seg] + (p & 0xFFFFFFFFull) * run_bytes(rw));
+  r.kw = rw == 0 ? 0 : rw == FDB_RUN_MEDIUM_WORDS ? -1 : rw - 4;
   return r;
 }
 __device__ __forceinline__ uint32_t run_dict_id(const RunRef& r, int c, int word) {
   if (r.kw == 0) return c < FDB_RUN_TUPLE_BYTES ? (r.t[c >> 2] >> (8 * (c & 3))) & 0xFFu : 0u;
+  if (r.kw < 0) return c < FDB_RUN_TUPLE_BYTES ? (r.t[c >> 1] >> (16 * (c & 1))) & 0xFFFFu : 0u;
   return word < r.kw ? r.t[word] : 0u;
 }
 __device__ __forceinline__ bool run_i64(const RunRef& r, int word, int gi, unsigned long long* v) {
-  if (r.kw == 0 || word + 1 >= r.kw) return false;
+  if (r.kw <= 0 || word + 1 >= r.kw) return false;
   const unsigned long long vm = (unsigned long long)r.t[0] | ((unsigned long long)r.t[1] << 32);
   if (!((vm >> gi) & 1ull)) return false;
   *v = (unsigned long long)r.t[word] | ((unsigned long long)r.t[word + 1] << 32);
@@ -2696,6 +2698,7 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
   run_u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
   bool single = true;
   const uint32_t* wide = nullptr;  // a wide run's key tuple (already a dense key row of `wide_kw` words)
+  const uint32_t* medium = nullptr;  // a medium run's 32 two-byte ids
   int wide_kw = 0;
   if (live) {
     const unsigned long long p = a.phys[i];
@@ -2706,6 +2709,9 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
       const run_u32x4* t = reinterpret_cast<const run_u32x4*>(segs.tuples[seg] + at * FDB_RUN_BYTES);
       t0 = t[0]; t1 = t[1];
       { const u64x2 ca = *reinterpret_cast<const u64x2*>(t + 2); cnt = ca.x; acc = ca.y; }
+    } else if (rw == FDB_RUN_MEDIUM_WORDS) {
+      medium = reinterpret_cast<const uint32_t*>(segs.tuples[seg] + at * FDB_RUN_MEDIUM_BYTES);
+      { const u64x2 ca = *reinterpret_cast<const u64x2*>(medium + 16); cnt = ca.x; acc = ca.y; }
     } else {
       wide = reinterpret_cast<const uint32_t*>(segs.tuples[seg] + at * (uint64_t)rw * 4);
       wide_kw = rw - 4;
@@ -2718,17 +2724,44 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
     } else { fl = 1u; g = (uint32_t)i; }
   }
   const unsigned long long starts = __ballot(live && fl != 0u);
-  if (live) {
-    const size_t vg = (size_t)g * (size_t)(a.val_stride > 0 ? a.val_stride : 1);
-    if (single) { a.vals_cnt[vg] = cnt; a.vals_acc[vg] = acc; }
-    else {
-      atomicAdd(a.vals_cnt + vg, cnt);
-      if (a.func == 1) atomicAdd(a.vals_acc + vg, acc);
-      else if (a.func == 2) atomicAdd(reinterpret_cast<double*>(a.vals_acc) + vg, __longlong_as_double((long long)acc));
-      else if (a.func == 3) atomicMin(reinterpret_cast<long long*>(a.vals_acc) + vg, (long long)acc);
-      else if (a.func == 4) atomicMax(reinterpret_cast<long long*>(a.vals_acc) + vg, (long long)acc);
+  // Runs of one group that sit next to each other in this wave are folded across its lanes first (g is monotone over the lanes, so a
+  // Kogge-Stone scan with "same group at distance d" is a segmented scan) and the LAST lane of such a stretch applies the total: a plain
+  // store when the whole group lies inside the wave, else one atomic per (wave, group). Without this a group that spans hundreds of runs
+  // — long groups: every wave-tile of the scan emits a run of it — was hundreds of atomics on ONE address from waves that run at the same
+  // time: 78 ns each, one after the other (cfg 2's query over a table sorted by labels.path: 390 k runs of 1 023 groups, 60 ms).
+  {
+    const uint32_t gg = live ? g : 0xFFFFFFFFu;
+    uint32_t has_start = live && fl != 0u ? 1u : 0u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t pg = __shfl_up(gg, off, 64), ps = __shfl_up(has_start, off, 64);
+      const unsigned long long pc = __shfl_up(cnt, off, 64), pa = __shfl_up(acc, off, 64);
+      if (lane >= off && pg == gg && live) {
+        cnt += pc;
+        has_start |= ps;
+        if (a.func == 1) acc += pa;
+        else if (a.func == 2) acc = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)acc) + __longlong_as_double((long long)pa));
+        else if (a.func == 3) acc = (unsigned long long)min((long long)acc, (long long)pa);
+        else if (a.func == 4) acc = (unsigned long long)max((long long)acc, (long long)pa);
+      }
+    }
+    const uint32_t ng = __shfl_down(gg, 1, 64);
+    const bool seg_end = live && (lane == 63 || ng != gg);
+    if (seg_end) {
+      // does the group end with this run? (the next run starts a new key, or there is none)
+      const bool ends = a.flags == nullptr || i + 1 >= a.n_runs || a.flags[i + 1] != 0u;
+      const size_t vg = (size_t)g * (size_t)(a.val_stride > 0 ? a.val_stride : 1);
+      if (has_start != 0u && ends) { a.vals_cnt[vg] = cnt; a.vals_acc[vg] = acc; }
+      else {
+        atomicAdd(a.vals_cnt + vg, cnt);
+        if (a.func == 1) atomicAdd(a.vals_acc + vg, acc);
+        else if (a.func == 2) atomicAdd(reinterpret_cast<double*>(a.vals_acc) + vg, __longlong_as_double((long long)acc));
+        else if (a.func == 3) atomicMin(reinterpret_cast<long long*>(a.vals_acc) + vg, (long long)acc);
+        else if (a.func == 4) atomicMax(reinterpret_cast<long long*>(a.vals_acc) + vg, (long long)acc);
+      }
     }
   }
+  (void)single;
   if (starts == 0ull) return;
   const uint32_t first_g = __shfl(g, __builtin_ctzll(starts), 64);  // (g of the first starting lane = the wave's first output row)
   const uint32_t n_new = (uint32_t)__popcll(starts);
@@ -2738,6 +2771,16 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
     if (wide != nullptr) {
       for (int w = 0; w < kw; w++) row[w] = w < wide_kw ? wide[w] : 0u;  // (columns the plan gained after this run's launch: NULL)
       row[2] = 0u; row[3] = 0u;
+    } else if (medium != nullptr) {
+      for (int w = 0; w < kw; w++) row[w] = 0u;
+      unsigned long long vm = 0;
+      const int nc = a.n_cols < FDB_RUN_TUPLE_BYTES ? a.n_cols : FDB_RUN_TUPLE_BYTES;
+      for (int c = 0; c < nc; c++) {
+        const uint32_t id = (medium[c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
+        row[a.col_word[c]] = id;
+        if (id != 0u) vm |= 1ull << c;
+      }
+      row[0] = (uint32_t)vm; row[1] = (uint32_t)(vm >> 32);
     } else {
       for (int w = 0; w < kw; w++) row[w] = 0u;
       const uint32_t ids[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};

@@ -329,7 +329,7 @@ class Plan {
   int64_t prof_push_n_ = 0;
   std::vector<RunSegment> runs_;
   bool runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>& Rs, const std::vector<int>& live) const;
-  bool runs_narrow_ok(const Resolved& R) const;  // may this record's run launch write the narrow (byte per key id) records?
+  int runs_format(const Resolved& R) const;  // the run record this record's launch writes: 0 narrow (a byte per key id), 1 medium (two bytes), 2 wide (the table's key tuple)
   void runs_free();
   void runs_to_table();
   // false: the keys did not arrive in order (the caller falls back to runs_to_table + the ordinary ordered Finish). Device blocks it

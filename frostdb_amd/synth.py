@@ -45,18 +45,28 @@ def _dict_col(idx: np.ndarray, values: List[bytes], null_mask) -> pa.DictionaryA
 
 
 def prometheus_chunk(shard: int, chunk: int, rows: int, row_base: int = 0, cfg3: bool = False,
-                     label_null_frac: float = 0.001) -> pa.RecordBatch:
+                     label_null_frac: float = 0.001, sorted_by_path: int = 0) -> pa.RecordBatch:
+    """`sorted_by_path` = n > 0: chunk `chunk` of n of a table SORTED by labels.path (values ascending, NULLs last): its rows hold the
+    chunk-th 1/n quantile slice of the path distribution, in order — the input an OrderedAggregate by labels.path is planned for. (The other
+    columns are independent draws, so only the path column has to be put in order.)"""
     rng = np.random.Generator(np.random.Philox(key=SEED + shard, counter=[0, 0, 0, chunk]))
     u = rng.random(rows, dtype=np.float32)
     code = np.searchsorted(_CODE_CDF, u, side="right").astype(np.uint32)
     np.minimum(code, len(CODES) - 1, out=code)
     u = rng.random(rows)
+    if sorted_by_path:
+        u = (chunk + u) / sorted_by_path
     path = np.searchsorted(_PATH_CDF, u, side="right").astype(np.uint32)
     np.minimum(path, N_PATH - 1, out=path)
     value = rng.random(rows) * 1000.0
     ts = T0 + 15_000 * ((row_base + np.arange(rows, dtype=np.int64)) // SERIES)
+    path_null = rng.random(rows, dtype=np.float32) < label_null_frac
+    if sorted_by_path:
+        path.sort()
+        k = int(path_null.sum()) if chunk == sorted_by_path - 1 else 0  # the table's NULL paths are its last rows
+        path_null = np.arange(rows) >= rows - k
     arrays = [_dict_col(code, CODES, rng.random(rows, dtype=np.float32) < label_null_frac),
-              _dict_col(path, PATHS, rng.random(rows, dtype=np.float32) < label_null_frac)]
+              _dict_col(path, PATHS, path_null)]
     names = ["labels.code", "labels.path"]
     if cfg3:
         arrays.append(_dict_col(rng.integers(0, len(METHODS), size=rows, dtype=np.uint32), METHODS,
@@ -112,14 +122,27 @@ def cfg5_group_ids(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000
 
 def cfg5_decode_group_ids(batch: pa.RecordBatch) -> np.ndarray:
     """Group id of every row of a record that carries cfg 5's label columns (input or result): columns 0-11 hold the base-4
-    digits of the id as the dictionary values b"lCC=D"."""
+    digits of the id as the dictionary values b"lCC=D" (wide dictionaries, `card` > 4: b"lCC=EEEEE" with digit = E // (card // 4))."""
     gid = np.zeros(batch.num_rows, dtype=np.int64)
     for c in range(12):
         col = batch.column(batch.schema.get_field_index("labels.l%02d" % c))
         assert col.null_count == 0
-        digit_of_entry = np.array([int(v.rsplit(b"=", 1)[1]) for v in col.dictionary.to_pylist()], dtype=np.int64)
+        vals = col.dictionary.to_pylist()
+        wide = len(vals[0].rsplit(b"=", 1)[1]) > 1
+        step = _cfg5_card(c, _CFG5_WIDE_CARDS) // CFG5_CARD if wide else 1
+        digit_of_entry = np.array([int(v.rsplit(b"=", 1)[1]) // step for v in vals], dtype=np.int64)
         gid |= digit_of_entry[col.indices.to_numpy(zero_copy_only=False).astype(np.int64)] << (2 * c)
     return gid
+
+
+# Wide dictionaries for cfg 5 (the table-free OrderedAggregate's wide run records, key ids beyond one byte): column c's dictionary has
+# cards[c % len(cards)] entries b"lCC=EEEEE", of which the four entries digit × step + (37 c mod step) are used (step = card // 4) —
+# monotone in the digit, so the table's sort order is the same as with the 4-entry dictionaries.
+_CFG5_WIDE_CARDS = (512, 1024, 4096, 65532)  # (65 534 is the most a two-byte key id holds: 0 = NULL; a multiple of 4 for the digit step)
+
+
+def _cfg5_card(c: int, cards) -> int:
+    return int(cards[c % len(cards)])
 
 
 def _rev4_12(x: np.ndarray) -> np.ndarray:
@@ -131,7 +154,10 @@ def _rev4_12(x: np.ndarray) -> np.ndarray:
     return out
 
 
-def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000, sorted_rows: bool = False, of_chunks: int = 0) -> pa.RecordBatch:
+_CFG5_DICTS = {}
+
+
+def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000, sorted_rows: bool = False, of_chunks: int = 0, wide_dicts: bool = False) -> pa.RecordBatch:
     """`sorted_rows`: the record's rows ordered by group id — what a scan of a table SORTED by its label columns (FrostDB's sorting
     columns) hands the aggregate: rows of one group arrive next to each other.
     `of_chunks` > 0 (with sorted_rows): the TABLE is sorted, not just each record — rows are ordered by (labels.l00, labels.l01, …)
@@ -159,8 +185,18 @@ def cfg5_chunk(shard: int, chunk: int, rows: int, n_groups: int = 10_000_000, so
             gid.sort()
     arrays, names = [], []
     for c in range(CFG5_COLS):
-        idx = pa.array(digits[c][gid].astype(np.uint32), type=pa.uint32(), mask=nulls[c][gid] if c >= 12 else None)
-        arrays.append(pa.DictionaryArray.from_arrays(idx, pa.array([b"l%02d=%d" % (c, k) for k in range(CFG5_CARD)], type=pa.binary())))
+        d = digits[c][gid].astype(np.uint32)
+        if wide_dicts:
+            card = _cfg5_card(c, _CFG5_WIDE_CARDS)
+            step = card // CFG5_CARD
+            d = d * np.uint32(step) + np.uint32((37 * c) % step)
+            if (c, card) not in _CFG5_DICTS:
+                _CFG5_DICTS[(c, card)] = pa.array([b"l%02d=%05d" % (c, k) for k in range(card)], type=pa.binary())
+            values = _CFG5_DICTS[(c, card)]
+        else:
+            values = pa.array([b"l%02d=%d" % (c, k) for k in range(CFG5_CARD)], type=pa.binary())
+        idx = pa.array(d, type=pa.uint32(), mask=nulls[c][gid] if c >= 12 else None)
+        arrays.append(pa.DictionaryArray.from_arrays(idx, values))
         names.append("labels.l%02d" % c)
     arrays.append(pa.array(rng.random(rows) * 1000.0))
     names.append("value")

@@ -20,6 +20,13 @@ def pp():
     return physicalplan
 
 
+@pytest.fixture(autouse=True)
+def _runs_on_small_shapes(monkeypatch):
+    """Ordered plans over SMALL key spaces (≤ 8 192 dense slots) keep the dense table since round 5 (Plan::runs_wanted); these tests are
+    about the run store, so they ask for it on small shapes too. test_small_key_spaces_keep_the_dense_table checks the default."""
+    monkeypatch.setenv("FDB_RUNS_ALWAYS", "1")
+
+
 def to_record(rec):
     arrays, names = [], []
     for name, vals in rec.items():
@@ -283,10 +290,12 @@ def test_records_that_do_not_fit_the_narrow_run_record_take_the_wide_one(pp):
          pa.array(rng.integers(0, 9, n).astype(np.int64)), pa.array(rng.uniform(0, 1, n))], names=["labels.l0", "labels.l1", "labels.l2", "v", "f"])
     missing = recs[1].drop_columns(["labels.l1"])
     groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
-    for extra, last in ((wide, "fdb_hash_kernel(runs, wide)"), (missing, "fdb_hash_kernel(runs)")):
+    for extra, last in ((wide, "fdb_hash_kernel(runs, medium)"), (missing, "fdb_hash_kernel(runs)")):
         seq = [recs[0], extra, recs[1]]
         o, kernel = _run_plan(pp, seq, Sum(Col("v")), groups, ordered=True)
-        assert kernel == last, kernel  # (the last record of the first sequence meets a 400-value dictionary: wide; of the second: narrow again)
+        # (the first sequence's last record meets a plan whose l0 has 400 values: medium records — two bytes per key id; in the second the
+        # record that lacks l1 wrote wide records and the last one narrow ones again)
+        assert kernel == last, kernel
         h, _ = _run_plan(pp, seq, Sum(Col("v")), groups, ordered=False)
         assert _rows(o) == sorted(_rows(h), key=_key_order)
 
@@ -331,15 +340,17 @@ def _key_order_mixed(r, nkeys):
 
 @pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("agg_name", ["sum", "min", "count"])
-def test_wide_run_records_dictionaries_beyond_one_byte_of_key_ids(pp, agg_name, resident):
-    """Group columns of 700, 3 and 70 000 distinct values (a key id needs 2 and 3 bytes): the table-free path with wide run records —
-    no hash kernel ran — equals the hash aggregate's groups in key order."""
+@pytest.mark.parametrize("cards,expect", [((700, 3, 70_000), "fdb_hash_kernel(runs, wide)"), ((700, 3, 40_000), "fdb_hash_kernel(runs, medium)")])
+def test_wide_run_records_dictionaries_beyond_one_byte_of_key_ids(pp, agg_name, resident, cards, expect):
+    """Group columns of 700, 3 and 40 000 / 70 000 distinct values: medium run records (two bytes per key id, kept in registers) up to
+    65 534 values, wide ones (the table's key tuple, from re-loaded columns) beyond — no hash kernel ran — equal the hash aggregate's
+    groups in key order."""
     rng = np.random.default_rng(21)
-    recs = _wide_sorted_records(rng, 400_000, 5)
+    recs = _wide_sorted_records(rng, 400_000, 5, cards=cards)
     agg = {"sum": Sum(Col("v")), "min": Min(Col("v")), "count": Count(Col("v"))}[agg_name]
     groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
     o, kernel = _run_plan(pp, recs, agg, groups, ordered=True, resident=resident)
-    assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    assert kernel == expect, kernel
     h, hk = _run_plan(pp, recs, agg, groups, ordered=False, resident=resident)
     assert "runs" not in hk
     orows, hrows = _rows(o), sorted(_rows(h), key=_key_order)
@@ -376,21 +387,22 @@ def test_wide_run_records_group_columns_that_come_and_go(pp):
             pa.RecordBatch.from_arrays([col(5), v()], names=["labels.b", "v"]),
             pa.RecordBatch.from_arrays([col(300), col(7), col(2), v()], names=["labels.a", "labels.b", "labels.c", "v"])]
     o, kernel = _run_plan(pp, recs, Sum(Col("v")), [DynCol("labels")], ordered=True)
-    assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    assert kernel == "fdb_hash_kernel(runs, medium)", kernel  # (the last record carries every column again: ids in registers; the ones before it wrote wide records)
     h, _ = _run_plan(pp, recs, Sum(Col("v")), [DynCol("labels")], ordered=False)
     assert o.schema.names == h.schema.names[:-1] + ["v"]
     assert sorted(_rows(o), key=repr) == sorted(_rows(h), key=repr) and o.num_rows > 300
 
 
-def test_every_table_free_test_shape_with_wide_records_forced(pp, monkeypatch):
-    """FDB_RUNS_WIDE: the narrow-record shapes above through the wide-record kernel — same answers."""
-    monkeypatch.setenv("FDB_RUNS_WIDE", "1")
+@pytest.mark.parametrize("force,name", [("1", "fdb_hash_kernel(runs, wide)"), ("m", "fdb_hash_kernel(runs, medium)")])
+def test_every_table_free_test_shape_with_wide_records_forced(pp, monkeypatch, force, name):
+    """FDB_RUNS_WIDE: the narrow-record shapes above through the wide-record / medium-record kernels — same answers."""
+    monkeypatch.setenv("FDB_RUNS_WIDE", force)
     rng = np.random.default_rng(24)
     recs = _sorted_label_records(rng, 250_000, 5)
     groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
     for agg in (Sum(Col("v")), Sum(Col("f")), Max(Col("f")), Count(Col("v"))):
         o, kernel = _run_plan(pp, recs, agg, groups, ordered=True, resident=True, filt=Col("v") > 100)
-        assert kernel == "fdb_hash_kernel(runs, wide)"
+        assert kernel == name
         h, _ = _run_plan(pp, recs, agg, groups, ordered=False, resident=True, filt=Col("v") > 100)
         orows, hrows = _rows(o), sorted(_rows(h), key=_key_order)
         assert [r[:3] for r in orows] == [r[:3] for r in hrows]
@@ -403,7 +415,7 @@ def test_every_table_free_test_shape_with_wide_records_forced(pp, monkeypatch):
          pa.array(rng.integers(0, 9, n).astype(np.int64))], names=["labels.u", "v"])
     for rec in (uniq, uniq.take(pa.array(rng.permutation(n)))):
         o, kernel = _run_plan(pp, [rec], Sum(Col("v")), [Col("labels.u")], ordered=True, resident=True)
-        assert kernel == "fdb_hash_kernel(runs, wide)"
+        assert kernel == "fdb_hash_kernel(runs, wide)"  # (70 000 distinct values: beyond two bytes whatever is forced)
         h, _ = _run_plan(pp, [rec], Sum(Col("v")), [Col("labels.u")], ordered=False, resident=True)
         assert _rows(o) == sorted(_rows(h), key=lambda r: _key_order(r, 1)) and o.num_rows == n
 
@@ -426,7 +438,7 @@ def test_benchmark_schema_query_over_a_table_sorted_by_path(pp):
     filt, aggs, groups = Col("labels.code") == "200", Sum(Col("value")), [Col("labels.path")]
     for seq in (recs[:1], recs):
         o, kernel = _run_plan(pp, seq, aggs, groups, ordered=True, resident=True, filt=filt)
-        assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+        assert kernel == "fdb_hash_kernel(runs, medium)", kernel  # (1 024 path values: two bytes per key id; FDB_RUNS_ALWAYS — by default this key space keeps the dense table)
         h, _ = _run_plan(pp, seq, aggs, groups, ordered=False, resident=True, filt=filt)
         orows, hrows = _rows(o), sorted(_rows(h), key=lambda r: _key_order(r, 1))
         assert [r[0] for r in orows] == [r[0] for r in hrows] and len(orows) > 1000
@@ -482,3 +494,18 @@ def test_run_path_against_the_hash_path_on_random_shapes(pp, seed):
         o, _ = _run_plan(pp, recs, agg, groups, ordered=True, resident=resident, filt=filt)
         h, _ = _run_plan(pp, recs, agg, groups, ordered=False, resident=resident, filt=filt)
         assert _rows(o) == sorted(_rows(h), key=_key_order), (seed, resident, n_rec, n_total)
+
+
+def test_small_key_spaces_keep_the_dense_table(pp, monkeypatch):
+    """Without FDB_RUNS_ALWAYS an ordered plan whose key space fits the LDS-resident dense table (here 6 × 8 × 4 slots; BASELINE.json
+    config 2's 1 025 paths) scans with the dense kernel and sorts its groups at Finish — same record as the run path's, in key order."""
+    monkeypatch.delenv("FDB_RUNS_ALWAYS", raising=False)
+    rng = np.random.default_rng(31)
+    recs = _sorted_label_records(rng, 200_000, 3)
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    o, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True, resident=True)
+    assert "runs" not in kernel, kernel
+    monkeypatch.setenv("FDB_RUNS_ALWAYS", "1")
+    r, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True, resident=True)
+    assert kernel == "fdb_hash_kernel(runs)"
+    assert _rows(o) == _rows(r) and o.schema.names == r.schema.names

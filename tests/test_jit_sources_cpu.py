@@ -25,6 +25,7 @@ SHAPES = [
     ("runs_32_columns", ["32", "2"], "fdb_hash_kernel"),             # the table-free OrderedAggregate's run kernel
     ("runs_wide_32_columns", ["32", "3"], "fdb_hash_kernel"),        # … writing wide records (any cardinality: tuples from re-loaded columns)
     ("runs_wide_int64_key", ["3", "4"], "fdb_hash_kernel"),          # … with an int64 key column
+    ("runs_medium_32_columns", ["32", "5"], "fdb_hash_kernel"),      # … writing medium records (two bytes per key id, ids kept in registers)
 ]
 
 

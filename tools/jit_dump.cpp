@@ -58,12 +58,12 @@ int main(int argc, char** argv) {
     return 0;
   }
   const int n = argc > 1 ? std::atoi(argv[1]) : 32;
-  const int kinds = argc > 2 ? std::atoi(argv[2]) : 0;  // 1: make the last column an int64 key; 2: run kernel, narrow records; 3: run kernel, wide records; 4: wide + an int64 key
+  const int kinds = argc > 2 ? std::atoi(argv[2]) : 0;  // 1: make the last column an int64 key; 2: run kernel, narrow records; 3: run kernel, wide records; 4: wide + an int64 key; 5: run kernel, medium records
   fdb::JitHashShape s;
   for (int c = 0; c < n; c++) s.cols.push_back({(kinds == 1 || kinds == 4) && c == n - 1 ? 1 : 0, true, c < 8, -1});
   s.aggs.push_back({FDB_AGG_SUM, FDB_T_F64, -1, 0});
   s.agg_validity.push_back(false);
-  if (kinds >= 2) s.runs = kinds == 2 ? 1 : 2;  // the table-free OrderedAggregate's run kernel (one aggregation)
+  if (kinds >= 2) s.runs = kinds == 2 ? 1 : kinds == 5 ? 3 : 2;  // the table-free OrderedAggregate's run kernel (one aggregation); 5: medium records (two bytes per key id)
   else { s.aggs.push_back({FDB_AGG_COUNT, FDB_T_I64, -1, 0}); s.agg_validity.push_back(false); }
   s.need_count = true;
   std::fputs(fdb::jit_hash_source(s).c_str(), stdout);
