@@ -1144,7 +1144,9 @@ bool Plan::runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned
       if (g.kind != 0) continue;
       std::vector<uint32_t> order(g.values.size());
       for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
-      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g.values[x] < g.values[y]; });
+      // (a dictionary whose values are already in order — what a writer that sorts its dictionary pages produces — needs no sort: 65 532 values × 8
+      // columns were 20 ms of a Finish)
+      if (!std::is_sorted(g.values.begin(), g.values.end())) std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g.values[x] < g.values[y]; });
       const size_t off = rank32.size();
       rank32.resize(off + g.values.size() + 1);
       rank32[off] = 0xFFFFFFFFu;

@@ -50,8 +50,12 @@ def device_rows(pp, records, agg, groups, final_stage=True):
     return out.schema.names, [tuple(c[i] for c in cols) for i in range(out.num_rows)]
 
 
+@pytest.mark.parametrize("records", ["narrow", "medium", "wide"])
 @pytest.mark.parametrize("case", ORDERED_CASES, ids=[c["id"] for c in ORDERED_CASES])
-def test_reference_vectors(pp, case):
+def test_reference_vectors(pp, case, records, monkeypatch):
+    """ordered_aggregate_test.go's vectors through the run store with each of its three run records (FDB_RUNS_WIDE forces the wider ones)."""
+    if records != "narrow":
+        monkeypatch.setenv("FDB_RUNS_WIDE", "m" if records == "medium" else "1")
     recs = []
     for groups, vals in case["records"]:
         rec = {"group%d" % i: [g.encode() if g else None for g in col] for i, col in enumerate(groups) if col}
@@ -63,8 +67,11 @@ def test_reference_vectors(pp, case):
     assert names[-1] == "vals"  # a partial-stage OrderedAggregate names its result after the column (ordered_aggregate.go:551-557)
 
 
+@pytest.mark.parametrize("records", ["narrow", "medium", "wide"])
 @pytest.mark.parametrize("func,agg", [(SUM, Sum), (MIN, Min), (MAX, Max), (COUNT, Count)])
-def test_random_partially_ordered_streams_with_null_keys(pp, func, agg):
+def test_random_partially_ordered_streams_with_null_keys(pp, func, agg, records, monkeypatch):
+    if records != "narrow":
+        monkeypatch.setenv("FDB_RUNS_WIDE", "m" if records == "medium" else "1")
     rng = np.random.default_rng(int(func) * 7)
     keys_a = [None, b"a", b"b", b"c", b"d"]
     recs = []
