@@ -164,6 +164,12 @@ class RcclComm : public Comm {
     nccl_check(end, "ncclGroupEnd");
   }
 
+  void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+    if (bytes == 0) return;
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    nccl_check(rccl().AllGather(send, recv, bytes / 8, ncclUint64, comm, stream), "ncclAllGather");
+  }
+
   std::vector<std::vector<uint8_t>> all_gather_host(const std::vector<uint8_t>& mine) override {
     hip_check(hipSetDevice(device), "hipSetDevice");
     RcclApi& R = rccl();
@@ -332,6 +338,22 @@ class LocalComm : public Comm {
     });
   }
 
+  void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+    if (bytes == 0) return;
+    guarded([&] {
+      hip_check(hipSetDevice(device), "hipSetDevice");
+      hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");  // this rank's block is complete
+      { std::lock_guard<std::mutex> lk(g->mu); g->send_ptr[(size_t)rank] = (const unsigned long long*)send; }
+      g->barrier();
+      std::vector<const unsigned long long*> ptrs;
+      { std::lock_guard<std::mutex> lk(g->mu); ptrs = g->send_ptr; }
+      for (int p = 0; p < size; p++)
+        hip_check(hipMemcpyAsync((unsigned char*)recv + (size_t)p * bytes, ptrs[(size_t)p], bytes, hipMemcpyDefault, stream), "hipMemcpyAsync(peer block)");
+      hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+      g->barrier();  // nobody's block changes while a peer still reads it
+    });
+  }
+
   void all_to_all(const unsigned long long* send, unsigned long long* recv, const std::vector<std::vector<int64_t>>& words,
                   hipStream_t stream) override {
     guarded([&] {
@@ -459,6 +481,27 @@ bool Plan::comm_allreduce(Comm& comm) {
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timing) { e0 = ctx_->get_event(); e1 = ctx_->get_event(); hip_check(hipEventRecord(e0, stream_), "hipEventRecord"); }
+  // Small tables (cfg 2 / 3 / 4: 1 025 slots × a few arrays): ONE all-gather of the packed table and a local fold in rank order, which
+  // also writes the host copy — one collective on the step's critical path instead of one all-reduce per array, and float64 sums that
+  // are bit-identical on every rank and in every run whatever order the ranks arrived in (what fdb_plan_set_deterministic
+  // promises for the scan now holds across GPUs too). Bigger tables keep the all-reduce. ($FDB_MERGE_ALLREDUCE: A/B aid)
+  const int n_arrays = num_state_arrays();
+  const size_t packed_bytes = (size_t)n_arrays * (size_t)n_slots_ * 8;
+  if (packed_bytes * (size_t)comm.size <= ((size_t)32 << 20) && std::getenv("FDB_MERGE_ALLREDUCE") == nullptr) {
+    unsigned long long* d_packed = (unsigned long long*)ctx_->dev_alloc(packed_bytes + 256);
+    unsigned long long* d_all = (unsigned long long*)ctx_->dev_alloc(packed_bytes * (size_t)comm.size + 256);
+    scratch_.push_back(d_packed); scratch_.push_back(d_all);
+    int32_t ops[1 + FDB_MAX_AGGS] = {0};
+    for (int32_t a = 0; a < n_arrays; a++) ops[a] = state_array_op(a);
+    hip_check(fdb_launch_state_pack(d_state_, d_packed, n_slots_, slots_alloc_, n_arrays, stream_), "state pack");
+    comm.all_gather(d_packed, d_all, packed_bytes, stream_);
+    unsigned long long* host_out = mirror_target();
+    hip_check(fdb_launch_state_fold_ranks(d_all, comm.size, n_slots_, n_arrays, ops, d_state_, slots_alloc_, host_out, stream_), "state fold (rank order)");
+    if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); merge_events_.emplace_back(e0, e1); }
+    state_dirty_ = true;
+    mirror_valid_ = host_out != nullptr;
+    return true;
+  }
   comm.all_reduce(reds, stream_);  // ordered after the scan and the fold kernel; Finish / Close wait for this stream
   if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); merge_events_.emplace_back(e0, e1); }
   state_dirty_ = true;

@@ -34,6 +34,8 @@ class Comm {
   // op: 1 int64 sum, 2 float64 sum, 3 int64 min, 4 int64 max (Plan::state_array_op's numbering).
   struct Red { void* buf; size_t count; int op; };
   virtual void all_reduce(const std::vector<Red>& reds, hipStream_t stream) = 0;
+  // All-gather of `bytes` bytes per rank (a multiple of 8): recv = every rank's send block, in rank order. Enqueued on `stream`.
+  virtual void all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) = 0;
   // Exchange of packed rows in 8-byte words. `send` holds this rank's `size` partitions back to back (words[rank][p] words for
   // rank p); `recv` receives words[p][rank] words from every rank p, grouped by source in rank order. The whole matrix is known
   // to every rank (all_gather_host). Complete on `stream` order; the caller synchronises before reading `recv`.

@@ -475,6 +475,12 @@ hipError_t fdb_launch_ordered_to_f64(unsigned long long* v, int64_t n, hipStream
 hipError_t fdb_launch_fill_state(unsigned long long* base, int64_t n, int n_arrays, const unsigned long long* idents, hipStream_t stream);
 // host_out[a * stride + s] = state[a * stride + s] for s < n_slots, a < n_arrays (host_out: pinned host memory).
 hipError_t fdb_launch_state_to_host(const unsigned long long* state, unsigned long long* host_out, uint32_t n_slots, uint64_t stride, int n_arrays, hipStream_t stream);
+// Rank-ordered cross-GPU merge of a small dense table (fdb_kernels.hip, state_fold_ranks_kernel): packed[array][slot] = the first n_slots
+// entries of every array; gathered = the ranks' packed tables back to back in rank order; ops[array]: 0 keep this rank's, 1 int64 sum,
+// 2 float64 sum, 3 int64 min, 4 int64 max (Plan::state_array_op). The fold writes the table and, if given, its pinned host copy.
+hipError_t fdb_launch_state_pack(const unsigned long long* state, unsigned long long* packed, uint32_t n_slots, uint64_t stride, int n_arrays, hipStream_t stream);
+hipError_t fdb_launch_state_fold_ranks(const unsigned long long* gathered, int n_ranks, uint32_t n_slots, int n_arrays, const int32_t* ops, unsigned long long* state,
+                                       uint64_t stride, unsigned long long* host_out, hipStream_t stream);
 // dst[map[i]] (op)= src[i] for i < n; op: fdb_agg_func (SUM/COUNT add, MIN/MAX signed 64-bit, f64 SUM when is_f64).
 hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long long* src, const uint32_t* map,
                                 int64_t n, int32_t func, int32_t is_f64, hipStream_t stream);

@@ -1237,6 +1237,38 @@ __global__ void state_to_host_kernel(const unsigned long long* __restrict__ stat
   if (slot < n_slots) host_out[(size_t)blockIdx.y * stride + slot] = state[(size_t)blockIdx.y * stride + slot];
 }
 
+// Cross-GPU merge of a small dense table in RANK ORDER (Plan::comm_allreduce): every rank packs the first n_slots entries of its
+// arrays ([array][slot], no allocation padding), ONE all-gather brings all ranks' packed tables, and every rank folds them locally —
+// rank 0's value first, then rank 1's, … — into its table and its pinned host copy. The order of a float64 sum is then a function of
+// the communicator alone: bit-identical whatever order the ranks arrived in and on every rank (an all-reduce's order is the
+// transport's business).
+__global__ void state_pack_kernel(const unsigned long long* __restrict__ state, unsigned long long* __restrict__ packed, uint32_t n_slots, uint64_t stride) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot < n_slots) packed[(size_t)blockIdx.y * n_slots + slot] = state[(size_t)blockIdx.y * stride + slot];
+}
+__global__ void state_fold_ranks_kernel(const unsigned long long* __restrict__ gathered, int n_ranks, uint32_t n_slots, int n_arrays, FillIdents ops,
+                                        unsigned long long* __restrict__ state, uint64_t stride, unsigned long long* __restrict__ host_out) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_slots) return;
+  const int arr = blockIdx.y;
+  const int op = (int)ops.v[arr];
+  const size_t per_rank = (size_t)n_arrays * n_slots;
+  unsigned long long acc;
+  if (op == 0) acc = state[(size_t)arr * stride + slot];  // (an array no aggregation folds into keeps this rank's contents)
+  else {
+    acc = gathered[(size_t)arr * n_slots + slot];
+    for (int p = 1; p < n_ranks; p++) {
+      const unsigned long long v = gathered[(size_t)p * per_rank + (size_t)arr * n_slots + slot];
+      if (op == 1) acc += v;
+      else if (op == 2) acc = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)acc) + __longlong_as_double((long long)v));
+      else if (op == 3) acc = (unsigned long long)min((long long)acc, (long long)v);
+      else acc = (unsigned long long)max((long long)acc, (long long)v);
+    }
+    state[(size_t)arr * stride + slot] = acc;
+  }
+  if (host_out != nullptr) host_out[(size_t)arr * stride + slot] = acc;
+}
+
 // Folds the per-workgroup partial tables into the global table. grid = (slot tiles of 64, arrays): one workgroup of 16 waves
 // covers 64 consecutive slots of one array; each wave folds a contiguous run of tables with ≈16 independent coalesced loads in
 // flight, the waves combine through LDS in wave order and wave 0 updates the table with a PLAIN read-modify-write — nothing else
@@ -2108,6 +2140,20 @@ hipError_t fdb_launch_fill_state(unsigned long long* base, int64_t n, int n_arra
 hipError_t fdb_launch_state_to_host(const unsigned long long* state, unsigned long long* host_out, uint32_t n_slots, uint64_t stride, int n_arrays, hipStream_t stream) {
   if (n_slots == 0 || n_arrays <= 0) return hipSuccess;
   hipLaunchKernelGGL(state_to_host_kernel, dim3((n_slots + 255) / 256, n_arrays), dim3(256), 0, stream, state, host_out, n_slots, stride);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_state_pack(const unsigned long long* state, unsigned long long* packed, uint32_t n_slots, uint64_t stride, int n_arrays, hipStream_t stream) {
+  if (n_slots == 0 || n_arrays <= 0) return hipSuccess;
+  hipLaunchKernelGGL(state_pack_kernel, dim3((n_slots + 255) / 256, n_arrays), dim3(256), 0, stream, state, packed, n_slots, stride);
+  return hipGetLastError();
+}
+hipError_t fdb_launch_state_fold_ranks(const unsigned long long* gathered, int n_ranks, uint32_t n_slots, int n_arrays, const int32_t* ops, unsigned long long* state,
+                                       uint64_t stride, unsigned long long* host_out, hipStream_t stream) {
+  if (n_slots == 0 || n_arrays <= 0) return hipSuccess;
+  FillIdents f;
+  for (int a = 0; a < 1 + FDB_MAX_AGGS; a++) f.v[a] = a < n_arrays ? (unsigned long long)ops[a] : 0ull;
+  hipLaunchKernelGGL(state_fold_ranks_kernel, dim3((n_slots + 255) / 256, n_arrays), dim3(256), 0, stream, gathered, n_ranks, n_slots, n_arrays, f, state, stride, host_out);
   return hipGetLastError();
 }
 

@@ -546,9 +546,29 @@ bool Plan::references(const std::string& column) const {
   return false;
 }
 
+// Waits for the plan's stream. hipStreamSynchronize parks the thread on an interrupt-driven signal; waking it costs ≈ 10 µs — a third of
+// what a 125 M-row shard step spends outside its kernel (profiles/round4_step_probe_125M.txt). A scan is over in a few hundred
+// microseconds, so the stream is first POLLED (hipStreamQuery: a load of the queue's completion signal) for up to FDB_SPIN_US (default
+// 2 000) microseconds, pausing between polls; anything longer falls back to the blocking wait, so a long merge or a busy GPU does not burn
+// a core. (FDB_SPIN_US=0: the blocking wait alone, as before round 5.)
+void Plan::wait_stream() {
+  static const long spin_us = [] { const char* e = std::getenv("FDB_SPIN_US"); return e != nullptr ? std::atol(e) : 2000L; }();
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t it = 0;; it++) {
+      const hipError_t q = hipStreamQuery(stream_);
+      if (q == hipSuccess) return;
+      if (q != hipErrorNotReady) { hip_check(q, "hipStreamQuery"); return; }
+      for (int k = 0; k < 32; k++) __builtin_ia32_pause();
+      if ((it & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+    }
+  }
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
 void Plan::sync() {
   hip_check(hipSetDevice(device_), "hipSetDevice");
-  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  wait_stream();
   collect_timing();
   ctx_->reset_staging();
   for (void* p : scratch_) ctx_->dev_free(p);

@@ -165,6 +165,46 @@ if world >= 3:
         for got in run_ranks(world, again):
             assert_same_result(got, want, ["labels.path", "sum(value)"], float_cols={"sum(value)"})
     report["failure_vote"] = "ok"
+# 5. the rank-ordered merge of small dense tables (one all-gather + a local fold in rank order): float64 sums are bit-identical on
+#    every rank and in every run whatever order the ranks reach the merge in, and equal the ranks' partial sums added in rank order
+import time
+shards = []
+for r in range(world):
+    b = make_prometheus_batch(np.random.default_rng(40 + r), 30_000, n_path=40, null_frac=0.0)
+    g = np.random.default_rng(90 + r)
+    wild = g.standard_normal(b.num_rows) * 10.0 ** g.integers(-8, 9, b.num_rows)  # magnitudes 1e-8 … 1e8: the sum's bits depend on its order
+    shards.append(b.set_column(b.schema.get_field_index("value"), "value", pa.array(wild)))
+def bits(out):
+    key = out.column(out.schema.names.index("labels.path")).dictionary_decode().to_pylist()
+    return dict(zip(key, out.column(out.schema.names.index("sum(value)")).to_numpy().view(np.uint64).tolist()))
+def one_pass(seed, merge=True):
+    delays = np.random.default_rng(seed).permutation(world) * 0.03
+    def rank_fn(r):
+        plan = pp.HashAggregatePlan(CFG2["filter_expr"], CFG2["aggs"], CFG2["groups"])
+        plan.set_deterministic(True)
+        rb = pp.ResidentBatch(shards[r])
+        try:
+            plan.CallbackResident([rb])
+            if merge:
+                time.sleep(float(delays[r]))  # a different arrival order every pass
+                assert comms[r].allreduce(plan) is True
+            return bits(plan.Finish())
+        finally:
+            plan.Close(); rb.close()
+    return run_ranks(world, rank_fn)
+a, b = one_pass(1), one_pass(2)
+assert all(x == a[0] for x in a), "ranks disagree on the merged sums' bits"
+assert a == b, "the merged sums' bits depend on the order the ranks arrived in"
+parts = one_pass(3, merge=False)
+expect = {}
+for k in a[0]:
+    acc = None
+    for r in range(world):
+        v = float(np.array([parts[r].get(k, 0)], dtype=np.uint64).view(np.float64)[0])
+        acc = v if acc is None else acc + v
+    expect[k] = int(np.array([acc], dtype=np.float64).view(np.uint64)[0])
+assert a[0] == expect, "the merge is not the rank-ordered fold of the ranks' partial sums"
+report["rank_ordered_merge"] = {"groups": len(expect)}
 for c in comms: c.close()
 print("REPORT " + json.dumps(report))
 '''
@@ -179,6 +219,7 @@ def test_rccl_transport_with_several_ranks_as_threads_init_all(fake_lib, world):
     rep = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("REPORT ")][-1][7:])
     assert rep["world"] == world and rep["transport_ranks"] == [world] * world
     assert rep["allreduce"] == "ok" and rep["exchange"] == "ok"
+    assert rep["rank_ordered_merge"]["groups"] > 30  # float sums bit-identical across ranks, runs and arrival orders (section 5 of the child)
     if world <= 4:
         assert rep["sliced_exchange"]["rows_bytes_per_rank_estimate"] / world > (1 << 20)  # more than one slice per peer
     if world >= 3:
