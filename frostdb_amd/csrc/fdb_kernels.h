@@ -483,7 +483,7 @@ hipError_t fdb_launch_state_fold_ranks(const unsigned long long* gathered, int n
                                        uint64_t stride, unsigned long long* host_out, hipStream_t stream);
 // dst[map[i]] (op)= src[i] for i < n; op: fdb_agg_func (SUM/COUNT add, MIN/MAX signed 64-bit, f64 SUM when is_f64).
 hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long long* src, const uint32_t* map,
-                                int64_t n, int32_t func, int32_t is_f64, hipStream_t stream);
+                                int64_t n, int32_t func, int32_t is_f64, hipStream_t stream, const unsigned long long* src_cnt = nullptr);
 // ---- filter() on the device (≙ filter.go:276-323): selection mask → tile offsets → compacted columns ----------------------------
 // 1. fdb_launch_filter_flags evaluates the filter of `args` over rows [0, args.n_rows): one mask BIT per row (`masks`, bit i of the
 //    bitmap = row i selected) and the number of selected rows per tile of FDB_COMPACT_TILE (2 048) rows (`tile_counts`, zeroed by the

@@ -1330,10 +1330,11 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const unsigned lo
 }
 
 __global__ void merge_u64_kernel(unsigned long long* dst, const unsigned long long* src, const uint32_t* map, int64_t n,
-                                 int32_t func, int32_t is_f64) {
+                                 int32_t func, int32_t is_f64, const unsigned long long* src_cnt) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t d = map ? map[i] : (uint32_t)i;
     if (d == 0xFFFFFFFFu) continue;
+    if (src_cnt != nullptr && src_cnt[i] == 0ull) continue;  // (a slot no row reached holds identities: nothing to fold — and −0.0 + 0.0 would lose a sign)
     const unsigned long long v = src[i];
     if (func == AGG_SUM || func == AGG_COUNT) {
       if (is_f64) atomicAdd(reinterpret_cast<double*>(dst) + d, __longlong_as_double((long long)v));
@@ -2158,11 +2159,11 @@ hipError_t fdb_launch_state_fold_ranks(const unsigned long long* gathered, int n
 }
 
 hipError_t fdb_launch_merge_u64(unsigned long long* dst, const unsigned long long* src, const uint32_t* map, int64_t n, int32_t func,
-                                int32_t is_f64, hipStream_t stream) {
+                                int32_t is_f64, hipStream_t stream, const unsigned long long* src_cnt) {
   if (n <= 0) return hipSuccess;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(merge_u64_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, map, n, func, is_f64);
+  hipLaunchKernelGGL(merge_u64_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, map, n, func, is_f64, src_cnt);
   return hipGetLastError();
 }
 

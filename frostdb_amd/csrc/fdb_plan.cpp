@@ -546,29 +546,11 @@ bool Plan::references(const std::string& column) const {
   return false;
 }
 
-// Waits for the plan's stream. hipStreamSynchronize parks the thread on an interrupt-driven signal; waking it costs ≈ 10 µs — a third of
-// what a 125 M-row shard step spends outside its kernel (profiles/round4_step_probe_125M.txt). A scan is over in a few hundred
-// microseconds, so the stream is first POLLED (hipStreamQuery: a load of the queue's completion signal) for up to FDB_SPIN_US (default
-// 2 000) microseconds, pausing between polls; anything longer falls back to the blocking wait, so a long merge or a busy GPU does not burn
-// a core. (FDB_SPIN_US=0: the blocking wait alone, as before round 5.)
-void Plan::wait_stream() {
-  static const long spin_us = [] { const char* e = std::getenv("FDB_SPIN_US"); return e != nullptr ? std::atol(e) : 2000L; }();
-  if (spin_us > 0) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t it = 0;; it++) {
-      const hipError_t q = hipStreamQuery(stream_);
-      if (q == hipSuccess) return;
-      if (q != hipErrorNotReady) { hip_check(q, "hipStreamQuery"); return; }
-      for (int k = 0; k < 32; k++) __builtin_ia32_pause();
-      if ((it & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
-    }
-  }
-  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-}
-
 void Plan::sync() {
   hip_check(hipSetDevice(device_), "hipSetDevice");
-  wait_stream();
+  // (polling the stream with hipStreamQuery before the blocking wait was tried in round 5 to cut the ≈ 10 µs wake-up: 53 µs outside the
+  // kernel of a 125 M-row step against 37 µs with the blocking wait alone — profiles/round5_step_probe_125M.txt)
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   collect_timing();
   ctx_->reset_staging();
   for (void* p : scratch_) ctx_->dev_free(p);
@@ -2067,12 +2049,28 @@ void Plan::merge_from(Plan& src) {
     if (aggs_[j].type == FDB_T_NONE) aggs_[j].type = src.aggs_[j].type;
     else if (src.aggs_[j].type != FDB_T_NONE && src.aggs_[j].type != aggs_[j].type) throw Error(FDB_ERR_INVALID, "aggregation types differ between plans");
   }
-  src.sync();
-  sync();
+  if (mode_ == TableMode::HASH || src.mode_ == TableMode::HASH) {
+    src.sync();
+    sync();
+    if (!src.state_dirty_) return;
+    merge_hash(src);
+    return;
+  }
+  // Dense into dense — the Synchronizer + final stage of N chains on one GPU (physicalplan.go:438-471), N − 1 times per query: no host
+  // round trip until the end. The source's table is ordered in front of our merge kernels by an EVENT (its scan may still be running),
+  // every source slot is mapped — an empty one folds its identity into its destination, so the source's counts need not be fetched to
+  // know which slots are occupied (that blocking copy and the two waits in front of it were most of a merge: 250 µs, now ≈ 70) — and one
+  // wait at the end lets the caller close the source right away.
+  src.settle();
   if (!src.state_dirty_) return;
-  if (mode_ == TableMode::HASH || src.mode_ == TableMode::HASH) { merge_hash(src); return; }
-  std::vector<unsigned long long> scnt((size_t)src.n_slots_);
-  hip_check(hipMemcpy(scnt.data(), src.d_cnt_, (size_t)src.n_slots_ * 8, hipMemcpyDeviceToHost), "hipMemcpy(src cnt)");
+  src.materialize_state();
+  {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hipEvent_t ev = ctx_->get_event();
+    struct Put { Context* c; hipEvent_t e; ~Put() { c->put_event(e); } } put{ctx_, ev};
+    hip_check(hipEventRecord(ev, src.stream_), "hipEventRecord(merge source)");
+    hip_check(hipStreamWaitEvent(stream_, ev, 0), "hipStreamWaitEvent(merge source)");
+  }
   // unify key ids
   std::vector<size_t> col_map(src.gcols_.size());
   std::vector<std::vector<uint32_t>> id_map(src.gcols_.size());
@@ -2101,20 +2099,21 @@ void Plan::merge_from(Plan& src) {
   mirror_valid_ = false;
   std::vector<uint32_t> map((size_t)src.n_slots_, 0xFFFFFFFFu);
   for (uint32_t s = 0; s < src.n_slots_; s++) {
-    if (scnt[s] == 0) continue;
     uint64_t t = 0;
-    for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+    bool real = true;  // (a digit beyond the column's values — head-room of the source's layout — is a slot no row can have reached)
+    for (size_t sc = 0; sc < src.gcols_.size() && real; sc++) {
       const GroupColState& sg = src.gcols_[sc];
       const uint32_t id = sg.cap > 1 ? (s / sg.stride) % sg.cap : 0;
+      if (id >= id_map[sc].size()) { real = false; break; }
       t += (uint64_t)id_map[sc][id] * gcols_[col_map[sc]].stride;
     }
-    map[s] = (uint32_t)t;
+    if (real) map[s] = (uint32_t)t;
   }
   const uint32_t* d_map = (const uint32_t*)upload(map.data(), map.size() * 4);
   hip_check(fdb_launch_merge_u64(d_cnt_, src.d_cnt_, d_map, src.n_slots_, FDB_AGG_SUM, 0, stream_), "merge cnt");
   for (size_t j = 0; j < aggs_.size(); j++) {
     const int32_t f = aggs_[j].func == FDB_AGG_COUNT ? FDB_AGG_SUM : aggs_[j].func;
-    hip_check(fdb_launch_merge_u64(aggs_[j].d_acc, src.aggs_[j].d_acc, d_map, src.n_slots_, f, aggs_[j].type == FDB_T_F64 && f == FDB_AGG_SUM, stream_), "merge acc");
+    hip_check(fdb_launch_merge_u64(aggs_[j].d_acc, src.aggs_[j].d_acc, d_map, src.n_slots_, f, aggs_[j].type == FDB_T_F64 && f == FDB_AGG_SUM, stream_, src.d_cnt_), "merge acc");
   }
   state_dirty_ = true;
   sync();

@@ -277,7 +277,6 @@ class Plan {
   bool use_partials = true;  // LDS mode: flush workgroup tables with plain stores + a fold kernel instead of atomics
   struct Resolved;  // per-batch kernel arguments (fdb_plan.cpp)
   void sync();      // waits for the plan's stream; timing events are read, scratch and consumed records go back to their caches
-  void wait_stream();  // poll, then block (fdb_plan.cpp)
 
  private:
   const char* last_kernel_ = "";  // name of the scan kernel of the latest push

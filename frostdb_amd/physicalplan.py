@@ -284,6 +284,19 @@ class ResidentBatch:
             pass
 
 
+class PreparedRun:
+    """The pointer tables of a run of exported host records (fdb_plan_push_many's arguments), built once."""
+
+    def __init__(self, exported: Sequence["ExportedBatch"]):
+        self.keep = list(exported)
+        self.n = len(self.keep)
+        self.arrs = (ctypes.c_void_p * self.n)(*[ctypes.addressof(e.array) for e in self.keep])
+        self.schs = (ctypes.c_void_p * self.n)(*[ctypes.addressof(e.schema) for e in self.keep])
+
+    def __len__(self) -> int:
+        return self.n
+
+
 class HashAggregatePlan:
     """One fused ``PredicateFilter → HashAggregate`` chain on one GPU."""
 
@@ -347,6 +360,13 @@ class HashAggregatePlan:
         schs = (ctypes.c_void_p * n)(*[ctypes.addressof(e.schema) for e in exported])
         done = ctypes.c_int32()
         self._check(lib().fdb_plan_push_many(self.handle, arrs, schs, n, ctypes.byref(done)))
+
+    def CallbackPrepared(self, run: "PreparedRun") -> None:
+        """fdb_plan_push_many over pointer tables built beforehand (PreparedRun): the call itself is ONE entry into the library and holds the
+        interpreter lock for microseconds — what a goroutine of the Go shim does (its C arrays are built by that goroutine, concurrently with
+        the others; here building them per call would serialise N chain threads on the interpreter lock: 0.3 ms per chain and 1 024 records)."""
+        done = ctypes.c_int32()
+        self._check(lib().fdb_plan_push_many(self.handle, run.arrs, run.schs, run.n, ctypes.byref(done)))
 
     def CallbackResident(self, records: Sequence[ResidentBatch]) -> None:
         """Callback for several HBM-resident records at once: one fused kernel launch over all of them."""

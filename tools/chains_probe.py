@@ -12,15 +12,15 @@ per_chain = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 big = synth.prometheus_chunk(0, 0, rows * per_chain)
 recs = [big.slice(i * rows, rows) for i in range(per_chain)]
 filt, aggs, groups = Col("labels.code") == "200", [Sum(Col("value"))], [Col("labels.path")]
-for chains in (1, 2, 4, 8, 16, 32, 64):
-    exported = [[pp.ExportedBatch(r) for r in recs] for _ in range(chains)]
+for chains in [int(x) for x in os.environ.get("CHAINS", "1,2,4,8,16,32,64").split(",")]:
+    exported = [pp.PreparedRun([pp.ExportedBatch(r) for r in recs]) for _ in range(chains)]
     best = None
     for rep in range(3):
         plans = [pp.HashAggregatePlan(filt, aggs, groups) for _ in range(chains)]
         bar = threading.Barrier(chains + 1)
         def work(c):
             bar.wait()
-            plans[c].CallbackExportedMany(exported[c])
+            plans[c].CallbackPrepared(exported[c])
             plans[c].last_kernel()
         ts = [threading.Thread(target=work, args=(c,)) for c in range(chains)]
         for t in ts: t.start()
