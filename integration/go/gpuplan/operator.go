@@ -211,11 +211,16 @@ func (o *Operator) CallbackMany(_ context.Context, rs []arrow.Record) (pushed in
 	if len(rs) == 0 {
 		return 0, nil
 	}
-	arrs := make([]cdata.CArrowArray, len(rs))
-	schs := make([]cdata.CArrowSchema, len(rs))
-	// the pointer arrays live in C memory: cgo must not see Go pointers to Go pointers
-	pa := (*[1 << 28]*C.struct_ArrowArray)(C.malloc(C.size_t(len(rs)) * C.size_t(unsafe.Sizeof(uintptr(0)))))
-	ps := (*[1 << 28]*C.struct_ArrowSchema)(C.malloc(C.size_t(len(rs)) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	// The ArrowArray / ArrowSchema structs AND the pointer tables live in C memory (C.calloc): cgo forbids storing Go pointers in C
+	// memory, and its argument check does not look inside C allocations — structs in a Go slice whose addresses sit in a C array happen to
+	// work today but break under a moving collector and under GODEBUG=cgocheck=2.
+	n := C.size_t(len(rs))
+	arrs := (*[1 << 24]cdata.CArrowArray)(C.calloc(n, C.size_t(unsafe.Sizeof(cdata.CArrowArray{}))))
+	schs := (*[1 << 24]cdata.CArrowSchema)(C.calloc(n, C.size_t(unsafe.Sizeof(cdata.CArrowSchema{}))))
+	pa := (*[1 << 28]*C.struct_ArrowArray)(C.malloc(n * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	ps := (*[1 << 28]*C.struct_ArrowSchema)(C.malloc(n * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(arrs))
+	defer C.free(unsafe.Pointer(schs))
 	defer C.free(unsafe.Pointer(pa))
 	defer C.free(unsafe.Pointer(ps))
 	for i, r := range rs {
@@ -223,17 +228,17 @@ func (o *Operator) CallbackMany(_ context.Context, rs []arrow.Record) (pushed in
 		pa[i] = (*C.struct_ArrowArray)(unsafe.Pointer(&arrs[i]))
 		ps[i] = (*C.struct_ArrowSchema)(unsafe.Pointer(&schs[i]))
 	}
-	defer func() {
+	defer func() {  // (registered after the frees above, so it runs before them)
 		for i := range rs {
 			cdata.ReleaseCArrowArray(&arrs[i])
 			cdata.ReleaseCArrowSchema(&schs[i])
 		}
 	}()
-	var n C.int32_t
-	if rc := C.fdb_plan_push_many(o.plan, &pa[0], &ps[0], C.int32_t(len(rs)), &n); rc != C.FDB_OK {
-		return int(n), errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))
+	var done C.int32_t
+	if rc := C.fdb_plan_push_many(o.plan, &pa[0], &ps[0], C.int32_t(len(rs)), &done); rc != C.FDB_OK {
+		return int(done), errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))
 	}
-	return int(n), nil
+	return int(done), nil
 }
 
 // SetDeterministic asks for float64 sums that are bit-identical from run to run (fdb_plan_set_deterministic; before the first

@@ -1,15 +1,15 @@
 #!/bin/bash
-# The profile recipe of a round (run on the GPU box: gpurun -- 'bash tools/profile_round.sh round4'): the default bench line, the
+# The profile recipe of a round (run on the GPU box: gpurun -- 'bash tools/profile_round.sh round5'): the default bench line, the
 # 2-rank functional lines, rocprofv3 kernel traces + statistics of the bench commands the judged numbers come from, and the HBM
 # traffic counters (FETCH_SIZE, WRITE_SIZE: separate --pmc passes, never together with a trace — MI355X_MICROARCH.md, rocprofv3
 # section). Everything lands under gpurun_out/<tag>/; tools/prof_summary.py condenses each pass into <name>.summary.txt, which is
 # what gets copied into profiles/ (tools/collect_profiles.py <tag>). Every rocprofv3 invocation runs under `timeout`: a counter
 # pass once hung for 25 GPU-minutes.
 set -u
-TAG=${1:-round4}
+TAG=${1:-round5}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
-timeout 400 python bench.py --steps 20 --warmup 3 > $O/bench_default_line.json 2> $O/bench_default.err; echo "bench rc=$?"
+timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench_default_line.json 2> $O/bench_default.err; echo "bench rc=$?"
 timeout 300 python bench.py --gpus 2 --force-local --steps 10 --warmup 2 > $O/cfg4_force_local_line.json 2> $O/cfg4_force_local.err; echo "force-local rc=$?"
 prof() { # name "command" [fetch] [write]
   local name=$1; shift
@@ -23,10 +23,11 @@ prof() { # name "command" [fetch] [write]
   done
   python tools/prof_summary.py $O/$name > $O/$name.summary.txt 2>&1
 }
-prof cfg1B "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs" ${PMC_1B:-}
+prof cfg1B "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs" ${PMC_1B:-fetch write}
 prof cfg3 "python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline" fetch write
 prof cfg5 "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline" fetch write
 prof cfg5_sorted "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline" fetch write
+prof cfg5_sorted_wide "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline" fetch write
 prof select "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select" fetch write
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete; du -sh $O
 timeout 150 python tools/step_probe.py 2>&1 | grep -v amdgpu > $O/step_probe_125M.txt
