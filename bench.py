@@ -781,7 +781,7 @@ def measure_parquet(device, rows=20_000_000, passes=3):
         def once():
             plan = pp.HashAggregatePlan(*q, device=device)
             # two row groups in flight: the host part of one (page headers, inflating) runs beside the device part of another
-            with ThreadPoolExecutor(max_workers=2) as ex:
+            with ThreadPoolExecutor(max_workers=int(os.environ.get("FDB_BENCH_PQ_WORKERS", "2"))) as ex:
                 keep = list(ex.map(lambda g: pp.ResidentBatch.from_parquet(g[0], g[1], device=device), groups))
             plan.CallbackResident(keep)
             res = plan.Finish()

@@ -1,5 +1,6 @@
 // fdb_jit.h — plan-specialised scan kernels (fdb_jit.cpp).
 #pragma once
+#include <cstdlib>
 
 #include <hip/hip_runtime_api.h>
 
@@ -42,6 +43,9 @@ struct JitShape {
   // program order, lane order inside an instruction — and the flush adds the waves' tables up in wave order; with shared tables the
   // order in which the waves' LDS atomics interleave differs from run to run, and float64 addition is not associative.
   bool wave_tables = false;
+  // LDS tables: when the slots of a wave's selected rows agree (sorted input) the updates go to a wave-uniform address, so that the compiler
+  // folds them across the lanes (fdb_jit.cpp, "Sorted input")
+  bool uniform_fold = std::getenv("FDB_NO_UNIFORM_FOLD") == nullptr;
   // fdb_select_kernel only (not part of key()): early slots whose values the kernel compacts itself, bit i = slot i of c4 / c8
   int fuse4 = 0, fuse8 = 0;
   std::string key(bool with_validity = true) const;

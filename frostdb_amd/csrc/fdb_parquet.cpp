@@ -805,11 +805,54 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
   // inflating pages is the expensive part — are parsed on one thread each; the first failure in column order is reported.
   std::vector<ParsedChunk> parsed((size_t)n_chunks);
   const auto t_host0 = std::chrono::steady_clock::now();
+  // The context (stream, staging, scratch cache) is taken as soon as the page headers have been walked — see the early copies below — or,
+  // when there is nothing to copy early, after the host part as before. Whatever happens, the stream is idle before anything is given back.
+  Context* ctx = nullptr;
+  hipStream_t copy_stream = nullptr;          // the early copies' own queue: chunk i's decode kernels run while chunk i + 1 still crosses PCIe
+  std::vector<hipEvent_t> copied;             // per early-copied chunk: its copy is complete
+  struct Release {
+    Context** c; hipStream_t* cs; std::vector<hipEvent_t>* ev;
+    ~Release() {
+      if (*c == nullptr) return;
+      if (*cs) (void)hipStreamSynchronize(*cs);
+      (void)hipStreamSynchronize((*c)->stream);
+      for (hipEvent_t e : *ev) if (e) (*c)->put_event(e);
+      (*c)->reset_staging();
+      Context::release(*c);
+    }
+  } rel{&ctx, &copy_stream, &copied};
+  std::vector<void*> scratch;
+  struct FreeScratch {
+    Context** c; hipStream_t* cs; std::vector<void*>* v;
+    ~FreeScratch() { if (*c) { if (*cs) (void)hipStreamSynchronize(*cs); (void)hipStreamSynchronize((*c)->stream); for (void* p : *v) (*c)->dev_free(p); } }
+  } fs{&ctx, &copy_stream, &scratch};
+  std::vector<uint8_t*> early((size_t)n_chunks, nullptr);  // device copies of chunks that cross PCIe as they are, started before the host part
   {
     // three phases: (1) page headers of every chunk — cheap, serial; (2) EVERY compressed page of the row group inflated side by
     // side (pages are independent: a chunk of twenty 1 MiB pages used to be one thread's job); (3) the chunks parsed side by side
     std::vector<InflateJob> jobs;
     for (int32_t i = 0; i < n_chunks; i++) plan_chunk(chunks[i], n_rows, &parsed[(size_t)i], &jobs);
+    // Chunks that need no image (uncompressed pages of fixed-width or dictionary-encoded values: the device decodes from the chunk's own
+    // bytes) start crossing PCIe NOW, while the host inflates and parses the rest — a row group's 1.3 ms of header walking used to sit in
+    // front of its 1.5 ms of copies (round 5; `profiles/README.md`). plan_chunk has already refused structurally damaged chunks; if no
+    // device can be had here (a CPU-only box: the host part still has to say what is wrong with the input) the copies happen later as before.
+    if (n_rows > 0 && hipSetDevice(device) == hipSuccess) {
+      try { ctx = Context::acquire(device); } catch (...) { ctx = nullptr; }
+      if (ctx != nullptr) {
+        copied.assign((size_t)n_chunks, nullptr);
+        copy_stream = std::getenv("FDB_PQ_EARLY_ON_MAIN") != nullptr ? ctx->stream : ctx->aux_stream(0);  // ($FDB_PQ_EARLY_ON_MAIN: A/B aid)
+        for (int32_t i = 0; i < n_chunks; i++) {
+          if (!parsed[(size_t)i].image.empty() || chunks[i].n_bytes <= 0) continue;
+          early[(size_t)i] = (uint8_t*)ctx->dev_alloc((size_t)chunks[i].n_bytes + 64);
+          scratch.push_back(early[(size_t)i]);
+          hip_check(hipMemcpyAsync(early[(size_t)i], chunks[i].data, (size_t)chunks[i].n_bytes, hipMemcpyHostToDevice, copy_stream), "hipMemcpyAsync(parquet chunk, early)");
+          copied[(size_t)i] = ctx->get_event();
+          hip_check(hipEventRecord(copied[(size_t)i], copy_stream), "hipEventRecord(parquet chunk)");
+        }
+      }
+    } else {
+      (void)hipGetLastError();
+    }
     size_t job_bytes = 0, chunk_bytes = 0;
     for (const InflateJob& j : jobs) job_bytes += j.body_len;
     for (int32_t i = 0; i < n_chunks; i++) chunk_bytes += (size_t)std::max<int64_t>(chunks[i].n_bytes, 0);
@@ -837,11 +880,8 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
   }
   if (n_rows > 0) { b->arena = device_pool_alloc(device, std::max<size_t>(total, 256)); b->arena_bytes = std::max<size_t>(total, 256); }
 
-  Context* ctx = Context::acquire(device);
-  struct Release { Context* c; ~Release() { if (c) { (void)hipStreamSynchronize(c->stream); c->reset_staging(); Context::release(c); } } } rel{ctx};
+  if (ctx == nullptr) ctx = Context::acquire(device);
   hipStream_t stream = ctx->stream;
-  std::vector<void*> scratch;
-  struct FreeScratch { Context* c; std::vector<void*>* v; ~FreeScratch() { (void)hipStreamSynchronize(c->stream); for (void* p : *v) c->dev_free(p); } } fs{ctx, &scratch};
   const int64_t n_words = (n_rows + 31) / 32;
   std::vector<unsigned long long> h_totals((size_t)n_chunks, 0);
   std::vector<unsigned long long*> d_totals((size_t)n_chunks, nullptr);
@@ -854,8 +894,10 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
     // inside the allocation
     const uint8_t* src = P.image.empty() ? c.data : P.image.data();
     const size_t src_bytes = P.image.empty() ? (size_t)c.n_bytes : P.image.size();
-    uint8_t* d_chunk = (uint8_t*)ctx->dev_alloc(src_bytes + 64);
-    scratch.push_back(d_chunk);
+    const bool copied_early = P.image.empty() && early[(size_t)i] != nullptr;
+    if (copied_early) hip_check(hipStreamWaitEvent(stream, copied[(size_t)i], 0), "hipStreamWaitEvent(parquet chunk)");  // this chunk's kernels wait for ITS copy only
+    uint8_t* d_chunk = copied_early ? early[(size_t)i] : (uint8_t*)ctx->dev_alloc(src_bytes + 64);
+    if (!copied_early) scratch.push_back(d_chunk);
     auto to_device = [&](const void* host, size_t bytes) -> void* {
       void* d = ctx->dev_alloc(std::max<size_t>(bytes, 16));
       scratch.push_back(d);
@@ -863,7 +905,7 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
       return d;
     };
     if (P.dev_pages.empty()) {
-      if (src_bytes) hip_check(hipMemcpyAsync(d_chunk, src, src_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
+      if (src_bytes && !copied_early) hip_check(hipMemcpyAsync(d_chunk, src, src_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
     } else {
       // the host's part of the image, stretch by stretch (plus whatever the parse appended behind the pages), then the compressed bytes
       // of the pages the device inflates — one copy from the caller's chunk — and one launch that puts them where the image has holes

@@ -2765,3 +2765,38 @@ def test_filter_in_one_pass_survives_the_epoch_wrap(pp, monkeypatch):
     finally:
         for r in rbs:
             r.close()
+
+
+@pytest.mark.parametrize("run_len", [1, 37, 300, 5000, 1 << 30])
+def test_dense_kernel_folds_waves_whose_rows_share_a_slot(pp, run_len, monkeypatch):
+    """A table sorted by its group column: the rows of a wave fall into one slot and the specialised dense kernel folds them across the
+    lanes before ONE LDS update (fdb_jit.cpp, "Sorted input") — single-phase shapes, SUM / MIN / MAX / COUNT, float64 and int64, with a
+    filter that empties some lanes and whole waves, NULL group keys, runs of equal keys from 1 row (nothing folds) to the whole record
+    (everything folds), ragged record sizes. Equal to the oracle, and bit-identical in the integer columns to the kernel without the
+    fold (FDB_NO_UNIFORM_FOLD)."""
+    from frostdb_amd.logicalplan import Max, Min
+    rng = np.random.default_rng(run_len % 1000 + 7)
+    n = 400_003
+    n_path = 50
+    starts = np.arange(0, n, min(run_len, n))
+    key_of_run = rng.integers(0, n_path + 1, len(starts))  # n_path = NULL
+    path = np.repeat(key_of_run, np.diff(np.append(starts, n)))[:n]
+    code = rng.integers(0, 3, n).astype(np.uint32)
+    code[100_000:103_000] = 1  # a stretch the filter removes altogether (whole waves without a selected row)
+    rec = pa.RecordBatch.from_arrays(
+        [pa.DictionaryArray.from_arrays(pa.array(code), pa.array([b"200", b"404", b"500"], type=pa.binary())),
+         pa.DictionaryArray.from_arrays(pa.array(np.where(path == n_path, 0, path).astype(np.uint32), mask=path == n_path), pa.array([b"/p%02d" % i for i in range(n_path)], type=pa.binary())),
+         pa.array(rng.uniform(-5, 1000, n))], names=["labels.code", "labels.path", "value"])
+    filt = Col("labels.code") != "404"
+    aggs = [Sum(Col("value")), Min(Col("value")), Max(Col("value")), Count(Col("value"))]
+    groups = [Col("labels.path")]
+    recs = [rec.slice(0, 150_001), rec.slice(150_001)]
+    cols = ["labels.path"] + [a.Name() for a in aggs]
+    want = run_oracle(recs, filt, aggs, groups)
+    got = run_gpu(pp, recs, filt, aggs, groups, resident=True)
+    assert_same_result(got, want, cols, float_cols={"sum(value)"})
+    monkeypatch.setenv("FDB_NO_UNIFORM_FOLD", "1")
+    plain = run_gpu(pp, recs, filt, aggs, groups, resident=True)
+    assert_same_result(plain, want, cols, float_cols={"sum(value)"})
+    for c in ("min(value)", "max(value)", "count(value)"):
+        assert dict(zip(got["labels.path"], got[c])) == dict(zip(plain["labels.path"], plain[c]))
