@@ -546,7 +546,7 @@ def emit(text):
 
 
 # ---- the secondary measurements of the default N = 1 run (other_configs) --------------------------------------------------------
-def measure_select(wl, steps=10, warmup=2):
+def measure_select(wl, steps=10, warmup=2, ceiling=None):
     """`filter()` on the device (filter.go:276-354 ≙ fdb_plan_filter_batch): `value > 500` (50 % selectivity) over the first
     100 M resident rows, every column compacted. Algorithmic bytes = filter column once + every selected value / validity bit read
     once and written once; `min_traffic_frac` counts what a sector-granular memory must at least move (all input + the output)."""
@@ -597,7 +597,7 @@ def measure_select(wl, steps=10, warmup=2):
     return {"workload": f"select: filter() compaction of every column, value > {SELECT_THRESHOLD:g} over {rows} resident rows ({len(recs)} records), selectivity {sel:.4f}",
             "value": rows * steps / el, "unit": "rows/s", "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": src,
+                         "traffic": traffic, "traffic_source": src, "measured_read_ceiling": ceiling, "frac_of_measured_ceiling": ach / ceiling if ceiling else None,
                          "launches_per_step": k_launches / steps, "kernel_ms_per_step": k_ms / steps,
                          "algorithmic_bytes_per_row": k_bytes / (rows * steps), "min_traffic_bytes_per_row": min_traffic / rows,
                          "min_traffic_frac": (min_traffic * steps / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0,
@@ -821,7 +821,7 @@ def other_configs(args, wl, rank, device, group, comm):
     from frostdb_amd import physicalplan as _pp
     ceiling = _pp.read_ceiling(device, 2 << 30, 5)  # the plain read kernel on this box, this run: every roofline below quotes it
     if want("select") and wl.select_expected:
-        others["select"] = measure_select(wl)
+        others["select"] = measure_select(wl, ceiling=ceiling)
     if want("host_records") and wl.host_batches:
         others["host_records"] = measure_host_records(wl)
     if want("host_records_chains") and wl.host_batches:

@@ -549,7 +549,7 @@ bool Plan::references(const std::string& column) const {
 void Plan::sync() {
   hip_check(hipSetDevice(device_), "hipSetDevice");
   // (polling the stream with hipStreamQuery before the blocking wait was tried in round 5 to cut the ≈ 10 µs wake-up: 53 µs outside the
-  // kernel of a 125 M-row step against 37 µs with the blocking wait alone — profiles/round5_step_probe_125M.txt)
+  // kernel of a 125 M-row step against 37 µs with the blocking wait alone — profiles/round5_step_probe_polling.txt)
   hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   collect_timing();
   ctx_->reset_staging();

@@ -9,14 +9,14 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 # name → (kernel as rocprof names it, kernel as bench.py names it, rows per launch group, the command)
 PASSES = {
-    "cfg1B": ("fdb_plan_kernel", "fdb_plan_kernel", 1_000_000_000, "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs"),
-    "cfg3": ("fdb_plan_kernel", "fdb_plan_kernel", 100_000_000, "python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline"),
-    "cfg5": ("fdb_hash_kernel", "fdb_hash_kernel", 100_000_000, "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline"),
-    "cfg5_sorted": ("fdb_hash_kernel", "fdb_hash_kernel(runs)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline"),
-    "cfg5_sorted_wide": ("fdb_hash_kernel", "fdb_hash_kernel(runs, medium)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline"),
+    "cfg1B": ("fdb_plan_kernel", "fdb_plan_kernel", 1_000_000_000, "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --no-oracle-parity"),
+    "cfg3": ("fdb_plan_kernel", "fdb_plan_kernel", 100_000_000, "python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline --no-oracle-parity"),
+    "cfg5": ("fdb_hash_kernel", "fdb_hash_kernel", 100_000_000, "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
+    "cfg5_sorted": ("fdb_hash_kernel", "fdb_hash_kernel(runs)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
+    "cfg5_sorted_wide": ("fdb_hash_kernel", "fdb_hash_kernel(runs, medium)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
     # filter(): a step is several kernels — the traffic of a step is the sum of their per-launch means (each runs once per step)
     "select": (["fdb_select_kernel", "compact_multi_kernel", "zero_regions_kernel"], "fdb_select_kernel + compact_multi_kernel", 100_000_000,
-               "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select"),
+               "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select --no-oracle-parity"),
 }
 
 

@@ -4,13 +4,16 @@
 # traffic counters (FETCH_SIZE, WRITE_SIZE: separate --pmc passes, never together with a trace — MI355X_MICROARCH.md, rocprofv3
 # section). Everything lands under gpurun_out/<tag>/; tools/prof_summary.py condenses each pass into <name>.summary.txt, which is
 # what gets copied into profiles/ (tools/collect_profiles.py <tag>). Every rocprofv3 invocation runs under `timeout`: a counter
-# pass once hung for 25 GPU-minutes.
+# pass once hung for 25 GPU-minutes. The profiled commands carry --no-oracle-parity: the parity scan over the first resident
+# record would be one more launch of the SAME kernel and skew its average duration and per-launch traffic.
 set -u
 TAG=${1:-round5}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+O=gpurun_out/$TAG; [ -z "${ONLY_PROF:-}" ] && rm -rf $O; mkdir -p $O
+if [ -z "${ONLY_PROF:-}" ]; then  # (ONLY_PROF=1: the rocprofv3 passes alone, into the same directory)
 timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench_default_line.json 2> $O/bench_default.err; echo "bench rc=$?"
 timeout 300 python bench.py --gpus 2 --force-local --steps 10 --warmup 2 > $O/cfg4_force_local_line.json 2> $O/cfg4_force_local.err; echo "force-local rc=$?"
+fi
 prof() { # name "command" [fetch] [write]
   local name=$1; shift
   local cmd="$1"; shift
@@ -23,12 +26,13 @@ prof() { # name "command" [fetch] [write]
   done
   python tools/prof_summary.py $O/$name > $O/$name.summary.txt 2>&1
 }
-prof cfg1B "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs" ${PMC_1B:-fetch write}
-prof cfg3 "python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline" fetch write
-prof cfg5 "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline" fetch write
-prof cfg5_sorted "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline" fetch write
-prof cfg5_sorted_wide "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline" fetch write
-prof select "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select" fetch write
+prof cfg1B "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --no-oracle-parity" ${PMC_1B:-fetch write}
+prof cfg3 "python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline --no-oracle-parity" fetch write
+prof cfg5 "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
+prof cfg5_sorted "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
+prof cfg5_sorted_wide "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
+prof select "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select --no-oracle-parity" fetch write
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete; du -sh $O
+[ -n "${ONLY_PROF:-}" ] && exit 0
 timeout 150 python tools/step_probe.py 2>&1 | grep -v amdgpu > $O/step_probe_125M.txt
 timeout 150 python tools/step_probe.py 100000000 2>&1 | grep -v amdgpu > $O/step_probe_100M.txt
