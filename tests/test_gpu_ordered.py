@@ -516,3 +516,61 @@ def test_small_key_spaces_keep_the_dense_table(pp, monkeypatch):
     r, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True, resident=True)
     assert kernel == "fdb_hash_kernel(runs)"
     assert _rows(o) == _rows(r) and o.schema.names == r.schema.names
+
+
+def test_wide_run_records_computed_int64_key(pp):
+    """`(timestamp / 1000) * 1000 as bucket` — the `window` vectors' computed key — as the FIRST group column of an ordered plan over rows
+    sorted by (timestamp, label): the key exists only inside the kernel (projection), the run record is the wide one and its tuple's bucket
+    words are recomputed by the lanes that end a run; equal to the hash aggregate sorted by key."""
+    rng = np.random.default_rng(41)
+    n = 300_000
+    ts = np.sort(rng.integers(0, 4_000_000, n)).astype(np.int64)
+    lab = rng.integers(0, 6, n)
+    order = np.lexsort((lab, ts // 1000))
+    ts, lab = ts[order], lab[order]
+    labels = pa.DictionaryArray.from_arrays(pa.array(np.where(lab == 5, 0, lab).astype(np.uint32), mask=lab == 5), pa.array([b"a", b"b", b"c", b"d", b"e"], type=pa.binary()))
+    rec = pa.RecordBatch.from_arrays([pa.array(ts), labels, pa.array(rng.integers(0, 1000, n).astype(np.int64))], names=["timestamp", "labels.x", "v"])
+    bucket = (Col("timestamp") / 1000 * 1000).Alias("bucket")
+    res = {}
+    for ordered in (True, False):
+        plan = pp.HashAggregatePlan(None, [Sum(Col("v"))], [bucket, Col("labels.x")], ordered=ordered, final_stage=False)
+        rbs = [pp.ResidentBatch(rec.slice(0, 100_001)), pp.ResidentBatch(rec.slice(100_001))]
+        try:
+            plan.CallbackResident(rbs)
+            kernel = plan.last_kernel()
+            res[ordered] = _rows(plan.Finish())
+        finally:
+            plan.Close()
+            for r in rbs:
+                r.close()
+        if ordered:
+            assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    key = lambda r: (r[0], r[1] is None, r[1] or b"")  # noqa: E731
+    assert len(res[True]) > 10_000 and res[True] == sorted(res[False], key=key)
+
+
+def test_deterministic_ordered_plans_do_not_collect_runs(pp):
+    """fdb_plan_set_deterministic on an ordered plan: groups cut by wave or record boundaries are folded with atomics at the
+    run store's Finish, so such a plan keeps the dense kernel (whose float sums ARE reproducible) — and two passes give the same bits."""
+    rng = np.random.default_rng(42)
+    recs = _sorted_label_records(rng, 200_000, 3)
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    outs = []
+    for _ in range(2):
+        plan = pp.HashAggregatePlan(None, [Sum(Col("f"))], groups, ordered=True, final_stage=False)
+        plan.set_deterministic(True)
+        keep = [pp.ResidentBatch(r) for r in recs]
+        try:
+            plan.CallbackResident(keep)
+            assert "runs" not in plan.last_kernel(), plan.last_kernel()
+            out = plan.Finish()
+        finally:
+            plan.Close()
+            for k in keep:
+                k.close()
+        outs.append(out)
+    assert outs[0].column(3).to_numpy().tobytes() == outs[1].column(3).to_numpy().tobytes()
+    h, _ = _run_plan(pp, recs, Sum(Col("f")), groups, ordered=False, resident=True)
+    a, b = _rows(outs[0]), sorted(_rows(h), key=_key_order)
+    assert [r[:3] for r in a] == [r[:3] for r in b]
+    assert all(abs(x[3] - y[3]) <= 1e-9 * max(1.0, abs(y[3])) for x, y in zip(a, b))
