@@ -1218,6 +1218,7 @@ void Plan::runs_to_table() {
     cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c; cols[c].lut_lds = FDB_NO_LDS;
     cols[c].k1 = fdb_fp_k1((int)c); cols[c].k2 = fdb_fp_k2((int)c);
     cols[c].src_word = gcols_[c].word;  // the expanded rows already have the table's own tuple layout
+    if (gcols_[c].kind != 0) cols[c].lut_len = (uint32_t)c;  // (int64 / computed keys: the bit of the incoming valid mask — hash_merge_kernel reads it from lut_len)
   }
   hash_merge_device(d_entries, d_keys, v.n_runs, kw, cols);
   ctx_->flush_staging();

@@ -375,10 +375,13 @@ int32_t fdb_comm_transport_ranks(fdb_comm* comm);
 const char* fdb_comm_last_error(const fdb_comm* comm);
 void fdb_comm_destroy(fdb_comm* comm);
 /* Low-cardinality merge (cfgs 2-4): when every rank's dense table has the same slot layout (fdb_plan_state_signature — parts of
- * one table share their dictionaries), slot i means the same group everywhere and the table arrays are all-reduced IN PLACE on
- * the plan's own stream: SUM for counts and sums, integer MIN / MAX for MIN / MAX (float64 MIN / MAX live as order-preserving
- * int64 keys). One grouped launch of 1 + #aggregations collectives of n_slots × 8 bytes; the layout check is one tiny MAX
- * all-reduce issued on the communicator's own stream, so it overlaps the scan kernel. *aligned = 1: every rank now holds the
+ * one table share their dictionaries), slot i means the same group everywhere and the tables are merged on the plan's own
+ * stream. Small tables (≤ 32 MiB over all ranks: every configuration of the benchmark's low-cardinality queries): the packed
+ * table of every rank is all-gathered — ONE collective — and folded locally in RANK ORDER into the table and its host copy, so
+ * float64 sums come out bit-identical on every rank and in every run whatever order the ranks arrived in. Bigger dense tables:
+ * the arrays are all-reduced in place, one grouped launch (SUM for counts and sums, integer MIN / MAX for MIN / MAX — float64
+ * MIN / MAX live as order-preserving int64 keys). The layout check is one tiny MAX all-reduce issued on the communicator's own
+ * stream, so it overlaps the scan kernel. *aligned = 1: every rank now holds the
  * merged table (call fdb_plan_finish on the rank that emits; the others just close). *aligned = 0: layouts differ (or the plan
  * is in hash mode) — nothing was changed, use fdb_plan_exchange. Collective: every rank of `comm` must call it. */
 int fdb_plan_allreduce(fdb_plan* plan, fdb_comm* comm, int32_t* aligned);
@@ -476,7 +479,9 @@ int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_bl
  * hash table, the combining cache (table too big for LDS), the interpreting kernels or 4 tables that do not fit LDS answers
  * FDB_ERR_UNSUPPORTED — from the call that launches it: the push, or for queued small host records a later push / Finish — when the
  * plan has a float64 SUM. MIN / MAX / COUNT and integer sums are exact in every mode.
- * The cross-GPU merges are not covered (a ring all-reduce adds in ring order). */
+ * Across GPUs: fdb_plan_allreduce's merge of small tables folds in rank order (reproducible, see there); the in-place all-reduce
+ * of big dense tables and the exchange of hash tables are not covered. An ordered plan (fdb_plan_desc.ordered) with this flag does
+ * not collect runs (their Finish folds cut groups with atomics): it keeps the dense kernel. */
 int fdb_plan_set_deterministic(fdb_plan* plan, int32_t enabled);
 /* Name of the scan kernel the latest push launched ("fdb_plan_kernel" = the run-time specialised kernel,
  * "scan_slots_kernel" / "scan_dense_kernel" = the interpreting kernels, "scan_hash_kernel" = the hash-table path);

@@ -519,34 +519,42 @@ def test_small_key_spaces_keep_the_dense_table(pp, monkeypatch):
 
 
 def test_wide_run_records_computed_int64_key(pp):
-    """`(timestamp / 1000) * 1000 as bucket` — the `window` vectors' computed key — as the FIRST group column of an ordered plan over rows
-    sorted by (timestamp, label): the key exists only inside the kernel (projection), the run record is the wide one and its tuple's bucket
-    words are recomputed by the lanes that end a run; equal to the hash aggregate sorted by key."""
+    """`(timestamp / 1000) * 1000 as bucket` — the `window` vectors' computed key — next to a label column in an ordered plan: the key exists
+    only inside the kernel (projection), the run record is the wide one and its tuple's bucket words are recomputed by the lanes that end a
+    run. The plan's key order is (labels.x, bucket) — stored columns first — so rows sorted by (bucket, label) BREAK it and the runs go through
+    the table (int64 valid bits must survive that road: they did not before this test), rows sorted by (label, bucket) stay table-free; both
+    equal the hash aggregate."""
     rng = np.random.default_rng(41)
     n = 300_000
-    ts = np.sort(rng.integers(0, 4_000_000, n)).astype(np.int64)
+    ts = np.sort(rng.integers(1000, 4_000_000, n)).astype(np.int64)  # (no bucket 0: an int64 key 0 and a NULL key are one group in the hash table, see _wide_sorted_records)
     lab = rng.integers(0, 6, n)
-    order = np.lexsort((lab, ts // 1000))
-    ts, lab = ts[order], lab[order]
-    labels = pa.DictionaryArray.from_arrays(pa.array(np.where(lab == 5, 0, lab).astype(np.uint32), mask=lab == 5), pa.array([b"a", b"b", b"c", b"d", b"e"], type=pa.binary()))
-    rec = pa.RecordBatch.from_arrays([pa.array(ts), labels, pa.array(rng.integers(0, 1000, n).astype(np.int64))], names=["timestamp", "labels.x", "v"])
     bucket = (Col("timestamp") / 1000 * 1000).Alias("bucket")
-    res = {}
-    for ordered in (True, False):
-        plan = pp.HashAggregatePlan(None, [Sum(Col("v"))], [bucket, Col("labels.x")], ordered=ordered, final_stage=False)
-        rbs = [pp.ResidentBatch(rec.slice(0, 100_001)), pp.ResidentBatch(rec.slice(100_001))]
-        try:
-            plan.CallbackResident(rbs)
-            kernel = plan.last_kernel()
-            res[ordered] = _rows(plan.Finish())
-        finally:
-            plan.Close()
-            for r in rbs:
-                r.close()
-        if ordered:
-            assert kernel == "fdb_hash_kernel(runs, wide)", kernel
-    key = lambda r: (r[0], r[1] is None, r[1] or b"")  # noqa: E731
-    assert len(res[True]) > 10_000 and res[True] == sorted(res[False], key=key)
+    vals = rng.integers(0, 1000, n).astype(np.int64)
+    for keys in ("bucket_first", "label_first"):
+      order = np.lexsort((lab, ts // 1000)) if keys == "bucket_first" else np.lexsort((ts // 1000, lab))
+      ts2, lab2 = ts[order], lab[order]
+      labels = pa.DictionaryArray.from_arrays(pa.array(np.where(lab2 == 5, 0, lab2).astype(np.uint32), mask=lab2 == 5), pa.array([b"a", b"b", b"c", b"d", b"e"], type=pa.binary()))
+      rec = pa.RecordBatch.from_arrays([pa.array(ts2), labels, pa.array(vals)], names=["timestamp", "labels.x", "v"])
+      res = {}
+      for ordered in (True, False):
+          plan = pp.HashAggregatePlan(None, [Sum(Col("v"))], [bucket, Col("labels.x")], ordered=ordered, final_stage=False)
+          rbs = [pp.ResidentBatch(rec.slice(0, 100_001)), pp.ResidentBatch(rec.slice(100_001))]
+          try:
+              plan.CallbackResident(rbs)
+              kernel = plan.last_kernel()
+              out = plan.Finish()
+              names = out.schema.names
+              ib, il = names.index("bucket"), names.index("labels.x")
+              iv = [i for i in range(3) if i not in (ib, il)][0]
+              res[ordered] = [(r[ib], r[il], r[iv]) for r in _rows(out)]  # (bucket, label, sum) whatever order the columns come back in
+          finally:
+              plan.Close()
+              for r in rbs:
+                  r.close()
+          if ordered:
+              assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+      key = lambda r: (r[1] is None, r[1] or b"", r[0])  # noqa: E731  (the plan's key order: labels.x, then bucket)
+      assert len(res[True]) > 10_000 and res[True] == sorted(res[False], key=key), keys
 
 
 def test_deterministic_ordered_plans_do_not_collect_runs(pp):
