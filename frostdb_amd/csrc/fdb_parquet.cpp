@@ -856,10 +856,30 @@ std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks,
     size_t job_bytes = 0, chunk_bytes = 0;
     for (const InflateJob& j : jobs) job_bytes += j.body_len;
     for (int32_t i = 0; i < n_chunks; i++) chunk_bytes += (size_t)std::max<int64_t>(chunks[i].n_bytes, 0);
+    static const bool prof = std::getenv("FDB_PROFILE_PARQUET") != nullptr;  // (tuning aid: the host part's phases on stderr)
+    const auto tp0 = std::chrono::steady_clock::now();
     if (job_bytes >= ((size_t)1 << 20)) HostPool::get().parallel_for(jobs.size(), [&](size_t k) { run_inflate(jobs[k]); });
     else for (const InflateJob& j : jobs) run_inflate(j);
-    if (chunk_bytes >= ((size_t)1 << 20) && n_chunks > 1) HostPool::get().parallel_for((size_t)n_chunks, [&](size_t i) { parse_chunk(chunks[i], n_rows, &parsed[i]); });
-    else for (int32_t i = 0; i < n_chunks; i++) parse_chunk(chunks[i], n_rows, &parsed[(size_t)i]);
+    const auto tp1 = std::chrono::steady_clock::now();
+    // (one thread per chunk. Walking a chunk's pages side by side and renumbering their runs afterwards was tried in round 5: with 1 MiB pages
+    // a dictionary-index chunk has two or three of them, and copying the per-page run tables together cost more than the second thread
+    // saved — cfg 2's `labels.code`, ≈ 600 k run headers per 5 M rows, 3.5–4 ms serial, 5.5–12 ms "parallel" on 8 cores. The walk of the
+    // RLE / bit-packed run headers is a serial chain per page; it is the host part's floor: DESIGN §10.6)
+    std::vector<double> parse_us((size_t)n_chunks, 0.0);
+    auto parse_one = [&](size_t i) {
+      const auto a = std::chrono::steady_clock::now();
+      parse_chunk(chunks[i], n_rows, &parsed[i]);
+      parse_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count();
+    };
+    if (chunk_bytes >= ((size_t)1 << 20) && n_chunks > 1) HostPool::get().parallel_for((size_t)n_chunks, parse_one);
+    else for (int32_t i = 0; i < n_chunks; i++) parse_one((size_t)i);
+    if (prof) {
+      const auto tp2 = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[fdb] parquet host part: headers %.0f us, inflate (%zu pages, %zu bytes) %.0f us, parse %.0f us (per chunk:", std::chrono::duration<double, std::micro>(tp0 - t_host0).count(),
+                   jobs.size(), job_bytes, std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(tp2 - tp1).count());
+      for (int32_t i = 0; i < n_chunks; i++) std::fprintf(stderr, " %s %.0f", chunks[i].name ? chunks[i].name : "?", parse_us[(size_t)i]);
+      std::fprintf(stderr, ")\n");
+    }
   }
   const auto t_host1 = std::chrono::steady_clock::now();
   hip_check(hipSetDevice(device), "hipSetDevice");
