@@ -2333,7 +2333,19 @@ std::unique_ptr<DeviceBatch> Plan::filter_batch_interp(const DeviceBatch& in, in
 // prefix sums (sel_scan_kernel) → [host: the records' row counts, outputs allocated at their exact sizes] → zero the output
 // bitmaps → every column of every record compacted (compact_multi_kernel). Two host round trips in total. Falls back to the
 // per-record path (interpreting flags kernel, one compaction launch per column) when the predicate cannot be specialised.
+// The one-pass select kernel's workers and its scanner wait for each other with BOUNDED polls (2^22 of them, ≈ 1–2 s): on a GPU shared
+// with long kernels of other processes, or with a queue that is preempted or debugged, a valid filter() can run into the bound. That is
+// not the caller's error: the batch is filtered again through the three-launch path (flags → prefix sums → compaction), which waits for
+// nothing on the device. ($FDB_TEST_SELECT_STALL: pretends the bound was hit — the test of this road)
 std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch* const* in, int n, int64_t* n_selected) {
+  try {
+    return filter_batches_impl(in, n, n_selected, /*force_two_pass=*/false);
+  } catch (const SelectStall&) {
+    return filter_batches_impl(in, n, n_selected, /*force_two_pass=*/true);
+  }
+}
+
+std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches_impl(const DeviceBatch* const* in, int n, int64_t* n_selected, bool force_two_pass) {
   if (filter_root_ < 0) throw Error(FDB_ERR_STATE, "plan has no filter");
   std::vector<std::unique_ptr<DeviceBatch>> out;
   auto per_record = [&]() {
@@ -2463,7 +2475,7 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
   // in registers — columns WITHOUT a validity bitmap in any record, ≤ 8 bytes per row together (their tile is staged in LDS), whose
   // slot reads the record's own column (a remapped or widened copy is not the column). Their outputs must exist before the row
   // count does: worst-case sized pool blocks (extra_arenas), repacked into the exact arena when less than 40 % of them is used.
-  const bool two_pass_env = std::getenv("FDB_SELECT_TWO_PASS") != nullptr;  // (A/B, tests, fall-back: the three-launch prefix sum; read per call)
+  const bool two_pass_env = force_two_pass || std::getenv("FDB_SELECT_TWO_PASS") != nullptr;  // (A/B, tests, fall-back: the three-launch prefix sum; read per call)
   struct FusedCol { bool wide; int slot; int col; };
   std::vector<FusedCol> fused;
   std::vector<int> fused_of(n_cols, -1);  // column → index in `fused`
@@ -2584,7 +2596,11 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches(const DeviceBatch
     launches = 1;
     hip_check(hipMemcpyAsync(h_base, d_ctl + 1, (FDB_SELECT_CTL_WORDS - 1 + nl) * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(row counts)");
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (first host round trip: the other columns' outputs are allocated at their exact sizes)
-    if (h_base[0] != 0ull) { ctx_->select_ctl_reset(); throw Error(FDB_ERR_DEVICE, "internal: filter() placement did not complete"); }
+    if (h_base[0] != 0ull || std::getenv("FDB_TEST_SELECT_STALL") != nullptr) {  // a wait ran into its bound: nothing of this attempt is kept
+      ctx_->select_ctl_reset();
+      hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+      throw SelectStall();
+    }
     for (size_t k = 0; k < nl; k++) totals[k] = (int64_t)h_base[FDB_SELECT_CTL_WORDS - 1 + k];
   } else {
     const int64_t n_blocks = (total_tiles + 1023) / 1024;

@@ -231,6 +231,8 @@ class Plan {
   // The same for every record of a scan at once: one launch sequence, two host round trips in total (sizes, NULL counts).
   std::unique_ptr<DeviceBatch> filter_batch_interp(const DeviceBatch& in, int64_t* n_selected);
   std::vector<std::unique_ptr<DeviceBatch>> filter_batches(const DeviceBatch* const* in, int n, int64_t* n_selected);
+  struct SelectStall {};  // the one-pass select kernel ran into its poll bound: filter_batches retries through the three-launch path
+  std::vector<std::unique_ptr<DeviceBatch>> filter_batches_impl(const DeviceBatch* const* in, int n, int64_t* n_selected, bool force_two_pass);
   int64_t select_batch(const DeviceBatch& in, uint32_t* d_indices, int64_t capacity);
   const char* draw();                                                  // ≙ Draw
   int64_t num_groups();

@@ -2800,3 +2800,34 @@ def test_dense_kernel_folds_waves_whose_rows_share_a_slot(pp, run_len, monkeypat
     assert_same_result(plain, want, cols, float_cols={"sum(value)"})
     for c in ("min(value)", "max(value)", "count(value)"):
         assert dict(zip(got["labels.path"], got[c])) == dict(zip(plain["labels.path"], plain[c]))
+
+
+def test_filter_retries_through_the_three_launch_path_when_the_one_pass_kernel_stalls(pp, monkeypatch):
+    """The one-pass select kernel's waits are bounded; running into the bound (a GPU shared with long kernels, a preempted queue —
+    pretended here with FDB_TEST_SELECT_STALL) is not the caller's error: the same call filters the records again through
+    flags → prefix sums → compaction and returns the same rows (it used to be FDB_ERR_DEVICE)."""
+    rng = np.random.default_rng(23)
+    recs = [make_prometheus_batch(rng, n, n_path=30, null_frac=0.02) for n in (300_000, 5, 70_001)]
+    rbs = [pp.ResidentBatch(r) for r in recs]
+    filt = Col("value") > 400.0
+    want = [_oracle_filter(r, filt) for r in recs]
+    try:
+        for stall in (False, True):
+            if stall:
+                monkeypatch.setenv("FDB_TEST_SELECT_STALL", "1")
+            plan = pp.HashAggregatePlan(filt)
+            try:
+                outs = plan.FilterResidentMany(rbs)
+                assert ("fdb_select_kernel" in plan.last_kernel()) == (not stall), plan.last_kernel()
+                for (w, idx), o in zip(want, outs):
+                    g = arrow_to_pydict(o.to_arrow())
+                    assert o.num_rows == len(idx)
+                    if w is not None:  # (the oracle returns no record for an empty selection)
+                        assert g["value"] == w["value"] and g["labels.path"] == w["labels.path"]
+                    o.close()
+            finally:
+                plan.Close()
+    finally:
+        for r in rbs:
+            r.close()
+    assert pp.live_allocations()["device_blocks"] == 0
