@@ -1,5 +1,5 @@
-// fdb_hostpool.h — a small process-wide pool of host threads (the per-page / per-chunk work of a Parquet row group, the copy of
-// a big pushed record into the pinned slab).
+// fdb_hostpool.h — a small process-wide pool of host threads (the per-page / per-chunk work of a Parquet row group). Copies of pushed
+// records into the pinned slab do NOT go through it: a pooled thread's wake-up costs more than half a megabyte of copying.
 #pragma once
 
 #include <algorithm>
@@ -86,24 +86,5 @@ class HostPool {
   std::vector<std::thread> workers_;
   bool stop_ = false;
 };
-
-
-// memcpy of a big block split over the pool (one core moves ≈12 GB/s into pinned memory; a 65 536-row record is 1 MB per Callback).
-inline void parallel_memcpy(void* dst, const void* src, size_t bytes) {
-  static const size_t kPiece = std::getenv("FDB_COPY_PIECE_KB") ? (size_t)std::max<long long>(1, std::atoll(std::getenv("FDB_COPY_PIECE_KB"))) << 10 : (size_t)192 << 10;  // (tuning aid)
-  if (bytes < 2 * kPiece) { std::memcpy(dst, src, bytes); return; }
-  // Several chains copying at once already ARE the parallelism: N callers splitting their blocks over the one pool gave N chains together
-  // what one chain gets alone (tools/push_bench, 65 536-row records: 1 chain 21 GB/s, 8 chains 25 GB/s in total — every record 7 × slower).
-  // From the third concurrent caller on a block is copied by its own thread; the second still gets half the split.
-  static std::atomic<int> callers{0};
-  struct Count { std::atomic<int>& c; int before; explicit Count(std::atomic<int>& x) : c(x), before(x.fetch_add(1, std::memory_order_relaxed)) {} ~Count() { c.fetch_sub(1, std::memory_order_relaxed); } } count(callers);
-  if (count.before >= 2) { std::memcpy(dst, src, bytes); return; }
-  const size_t n = std::min<size_t>(count.before == 0 ? 8 : 4, bytes / kPiece);
-  const size_t piece = ((bytes + n - 1) / n + 63) & ~(size_t)63;
-  HostPool::get().parallel_for(n, [&](size_t i) {
-    const size_t off = i * piece;
-    if (off < bytes) std::memcpy((unsigned char*)dst + off, (const unsigned char*)src + off, std::min(piece, bytes - off));
-  });
-}
 
 }  // namespace fdb
