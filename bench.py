@@ -364,14 +364,16 @@ class Workload:
         return {"groups_out": len(rows), "selected_rows": int(cnt.sum())}
 
 
-def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_finish=False):
+def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_finish=False, push_order=None):
     """Correctness step, warm-up, then the timed region (barrier + device sync on both sides, max over ranks).
+    `push_order`: the resident records are pushed in this order instead of the table's (an ordered workload then arrives as several ordered sets).
     `resident_finish`: the step ends with fdb_plan_finish_batch (the result record stays in HBM, for a consumer on the device)
     instead of fdb_plan_finish (Arrow record on the host)."""
     import numpy as np
     from frostdb_amd import physicalplan as pp
     rank, device, world = wl.rank, wl.device, group.world
     merging = world > 1 or args.force_merge
+    records = [wl.resident[i] for i in push_order] if push_order else wl.resident
 
     def step(timing=False, tuning=None):
         plan = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=device, desc=wl.desc)
@@ -385,10 +387,11 @@ def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_fini
             for hb in wl.host_batches:
                 plan.Callback(hb)
         elif args.per_record_launch:
-            for rb in wl.resident:
+            for rb in records:
                 plan.Callback(rb)
         else:
-            plan.CallbackResident(wl.resident)
+            plan.CallbackResident(records)
+        scan_kernel = plan.last_kernel()
         out = None
         if merging and args.torch_merge:
             import torch
@@ -420,7 +423,8 @@ def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_fini
             out = plan.Finish()
         st = plan.stats() if timing else None
         if st is not None:
-            st["kernel"] = plan.last_kernel()
+            st["kernel"] = scan_kernel
+        step.after_finish = plan.last_kernel()  # (an ordered Finish that had to sort its runs names the kernels it ran)
         plan.Close()
         return out, st
 
@@ -490,7 +494,7 @@ def run_workload(args, wl, steps, warmup, group, comm, total_rows, resident_fini
                              "kernel_frac": (k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else 0.0,
                              "merge_ms_per_step": merge_ms / max(steps, 1),
                              "rccl_ranks_seen": comm.transport_ranks if comm is not None and hasattr(comm, "transport_ranks") else None})
-    return {"elapsed": elapsed, "k_ms": k_ms, "k_bytes": k_bytes, "k_launches": k_launches, "kernel": kernel_name, "checked": checked,
+    return {"elapsed": elapsed, "k_ms": k_ms, "k_bytes": k_bytes, "k_launches": k_launches, "kernel": kernel_name, "checked": checked, "after_finish": getattr(step, "after_finish", None),
             "per_rank": per_rank, "merge_ms": max(p["merge_ms_per_step"] for p in per_rank),
             "first_step_ms": first_step_ms, "jit_compiled": jit1["compiled"] - jit0["compiled"], "jit_compile_ms": jit1["compile_ms"] - jit0["compile_ms"],
             "jit_disk_loads": jit1["disk_loads"] - jit0["disk_loads"]}
@@ -857,6 +861,14 @@ def other_configs(args, wl, rank, device, group, comm):
                 "workload": "cfg5_sorted with the result left in HBM (fdb_plan_finish_batch)",
                 "value": 100_000_000 * st / r5["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r5["elapsed"] / st * 1e3,
                 "roofline": roofline_of(r5, 100_000_000, st, "cfg5_sorted", ceiling), "checked": r5["checked"]}
+            if want("cfg5_sorted_sets") and len(w3.resident) == 4:
+                # the sorted table's four records pushed as FOUR ORDERED SETS (third, first, fourth, second quarter of the key range): Finish finds the
+                # keys out of order and sorts the runs on the device (runs_sort_keys_kernel + a radix sort per 64 bits of key rank) — no hash kernel
+                r8 = run_workload(args, w3, st, wu, group, comm, 100_000_000, push_order=[2, 0, 3, 1])
+                others["cfg5_sorted_sets"] = {
+                    "workload": "cfg5_sorted pushed as 4 ordered sets (records in the order 3, 1, 4, 2): the runs are sorted by key on the device at Finish",
+                    "value": 100_000_000 * st / r8["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r8["elapsed"] / st * 1e3,
+                    "finish_ran": r8["after_finish"], "roofline": roofline_of(r8, 100_000_000, st, "cfg5_sorted", ceiling), "checked": r8["checked"]}
             w3.release()
         if cfg == 5 and want("cfg5_sorted_wide"):  # … with label dictionaries of 512 – 65 532 entries: the run kernel writes MEDIUM records, two bytes per key id (round 5)
             w4 = Workload(args, 5, 100_000_000, rank, device, cfg5_sorted=True, cfg5_wide=True)

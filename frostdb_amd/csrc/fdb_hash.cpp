@@ -1135,31 +1135,11 @@ bool Plan::runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned
   v->out_idx = (uint32_t*)alloc((size_t)v->n_runs * 4);
   unsigned long long* d_scratch2 = (unsigned long long*)alloc(((size_t)v->n_runs / 1024 + 4) * 8 + 256);
   if (any_wide) {
-    // wide segments: 32-bit rank tables (rank of every key id among its column's values, NULL — id 0 — last) and the columns' places
-    std::vector<FdbRunCol> rc(gcols_.size());
-    std::vector<uint32_t> rank32;
-    for (size_t c = 0; c < gcols_.size(); c++) {
-      const GroupColState& g = gcols_[c];
-      rc[c].kind = g.kind == 0 ? 0 : g.is_u64 ? 3 : 1; rc[c].word = g.word; rc[c].gi = (int32_t)c; rc[c].rank_off = (uint32_t)rank32.size();
-      if (g.kind != 0) continue;
-      std::vector<uint32_t> order(g.values.size());
-      for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
-      // (a dictionary whose values are already in order — what a writer that sorts its dictionary pages produces — needs no sort: 65 532 values × 8
-      // columns were 20 ms of a Finish)
-      if (!std::is_sorted(g.values.begin(), g.values.end())) std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g.values[x] < g.values[y]; });
-      const size_t off = rank32.size();
-      rank32.resize(off + g.values.size() + 1);
-      rank32[off] = 0xFFFFFFFFu;
-      for (size_t r = 0; r < order.size(); r++) rank32[off + order[r] + 1] = (uint32_t)r;
-    }
-    uint32_t* d_rank32 = (uint32_t*)alloc(rank32.size() * 4 + 16);
-    FdbRunCol* d_rc = (FdbRunCol*)alloc(rc.size() * sizeof(FdbRunCol) + 16);
-    hip_check(hipMemcpyAsync(d_rank32, rank32.data(), rank32.size() * 4, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(rank tables)");
-    hip_check(hipMemcpyAsync(d_rc, rc.data(), rc.size() * sizeof(FdbRunCol), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(run columns)");
-    hip_check(fdb_launch_runs_flags_wide(v->phys, v->n_runs, v->segs, d_rc, d_rank32, (int)gcols_.size(), v->flags, (unsigned int*)(d_totals + 2), stream_), "runs flags (wide)");
+    runs_rank_tables(v, owned);
+    hip_check(fdb_launch_runs_flags_wide(v->phys, v->n_runs, v->segs, v->d_cols, v->d_rank32, (int)gcols_.size(), v->flags, (unsigned int*)(d_totals + 2), stream_), "runs flags (wide)");
     hip_check(fdb_launch_scan_u32(v->flags, 1, v->out_idx, v->n_runs, d_scratch2, d_totals + 1, stream_), "scan run flags");
     hip_check(hipMemcpyAsync(h_tot, d_totals, 24, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(group count)");
-    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (the host vectors above outlive their copies)
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     v->n_groups = (int64_t)h_tot[1];
     return (h_tot[2] & 0xFFFFFFFFull) == 0;
   }
@@ -1180,6 +1160,111 @@ bool Plan::runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned
   hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   v->n_groups = (int64_t)h_tot[1];
   return (h_tot[2] & 0xFFFFFFFFull) == 0;
+}
+
+// 32-bit rank tables (rank of every key id among its column's values, NULL — id 0 — last) and the columns' places, on the device.
+void Plan::runs_rank_tables(RunsView* v, std::vector<void*>* owned) {
+  if (v->d_cols != nullptr) return;
+  std::vector<FdbRunCol> rc(gcols_.size());
+  std::vector<uint32_t> rank32;
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    const GroupColState& g = gcols_[c];
+    rc[c].kind = g.kind == 0 ? 0 : g.is_u64 ? 3 : 1; rc[c].word = g.word; rc[c].gi = (int32_t)c; rc[c].rank_off = (uint32_t)rank32.size();
+    if (g.kind != 0) continue;
+    std::vector<uint32_t> order(g.values.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    // (a dictionary whose values are already in order — what a writer that sorts its dictionary pages produces — needs no sort: 65 532 values × 8
+    // columns were 20 ms of a Finish)
+    if (!std::is_sorted(g.values.begin(), g.values.end())) std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g.values[x] < g.values[y]; });
+    const size_t off = rank32.size();
+    rank32.resize(off + g.values.size() + 1);
+    rank32[off] = 0xFFFFFFFFu;
+    for (size_t r = 0; r < order.size(); r++) rank32[off + order[r] + 1] = (uint32_t)r;
+  }
+  uint32_t* d_rank32 = (uint32_t*)ctx_->dev_alloc(rank32.size() * 4 + 256);
+  owned->push_back(d_rank32);
+  FdbRunCol* d_rc = (FdbRunCol*)ctx_->dev_alloc(rc.size() * sizeof(FdbRunCol) + 256);
+  owned->push_back(d_rc);
+  if (!rank32.empty()) hip_check(hipMemcpyAsync(d_rank32, rank32.data(), rank32.size() * 4, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(rank tables)");
+  hip_check(hipMemcpyAsync(d_rc, rc.data(), rc.size() * sizeof(FdbRunCol), hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(run columns)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // (the host vectors above must outlive their copies)
+  v->d_cols = d_rc;
+  v->d_rank32 = d_rank32;
+}
+
+// Several ordered sets in one run store (≙ the k-way merge of OrderedAggregate's sets at Finish, ordered_aggregate.go:449-470; cursorHeap.Less,
+// arrowutils/merge.go:84-112): the runs are sorted by key on the device — a stable LSD radix sort of (key, run) pairs over groups of
+// columns, the last group column first, dictionary columns by the RANK of their ids packed as many to a 64-bit key as fit, int64 columns
+// by value and then by "is NULL" — and the flags / prefix sums are taken again over the sorted order; Finish then proceeds as if one
+// ordered set had arrived. Runs of one key end up next to each other in arrival order (the sort is stable), so the expand kernel folds
+// them as it folds the runs that wave and record boundaries cut. Cost ∝ runs × (key bits / 64), not ∝ groups × log groups on the host.
+bool Plan::runs_sort(RunsView* v, std::vector<void*>* owned) {
+  const bool off = std::getenv("FDB_RUNS_NO_SORT") != nullptr;  // (A/B and test aid, read per Finish: the table + host sort fallback)
+  if (off || v->n_runs < 2 || v->n_runs > ((int64_t)1 << 28)) return false;  // (32 bytes of sort buffers per run: 8 GiB at the limit)
+  auto alloc = [&](size_t bytes) { void* p = ctx_->dev_alloc(std::max<size_t>(bytes, 256)); owned->push_back(p); return p; };
+  runs_rank_tables(v, owned);
+  // the passes, least significant first
+  std::vector<FdbRunKeyPass> passes;
+  std::vector<int> pass_bits;
+  FdbRunKeyPass cur;
+  std::memset(&cur, 0, sizeof(cur));
+  int cur_bits = 0;
+  auto flush = [&] {
+    if (cur.n > 0 && cur_bits > 0) { passes.push_back(cur); pass_bits.push_back(cur_bits); }
+    std::memset(&cur, 0, sizeof(cur));
+    cur_bits = 0;
+  };
+  for (size_t k = gcols_.size(); k-- > 0;) {
+    const GroupColState& g = gcols_[k];
+    if (g.kind != 0) {
+      flush();
+      FdbRunKeyPass p;
+      std::memset(&p, 0, sizeof(p));
+      p.n = 1; p.col[0] = (int32_t)k;
+      p.mode = 1; passes.push_back(p); pass_bits.push_back(64);
+      p.mode = 2; passes.push_back(p); pass_bits.push_back(1);
+      continue;
+    }
+    const uint64_t n_values = g.values.size();  // ranks 0 … n_values − 1, NULL = n_values
+    int bits = 0;
+    while (bits < 33 && (n_values >> bits) != 0) bits++;
+    if (bits == 0) continue;  // (a column without values: every run holds NULL there)
+    if (cur_bits + bits > 64) flush();
+    cur.mode = 0;
+    cur.col[cur.n] = (int32_t)k; cur.shift[cur.n] = cur_bits; cur.null_rank[cur.n] = (uint32_t)n_values;
+    cur.n++;
+    cur_bits += bits;
+  }
+  flush();
+  const size_t n = (size_t)v->n_runs;
+  unsigned long long* keys_a = (unsigned long long*)alloc(n * 8);
+  unsigned long long* keys_b = (unsigned long long*)alloc(n * 8);
+  unsigned long long* phys_a = v->phys;
+  unsigned long long* phys_b = (unsigned long long*)alloc(n * 8);
+  size_t temp_bytes = 0;
+  hip_check(fdb_sort_pairs_u64(nullptr, &temp_bytes, keys_a, keys_b, phys_a, phys_b, v->n_runs, 64, stream_), "sort scratch size");
+  void* temp = alloc(temp_bytes);
+  for (size_t p = 0; p < passes.size(); p++) {
+    hip_check(fdb_launch_runs_sort_keys(phys_a, v->n_runs, v->segs, v->d_cols, v->d_rank32, passes[p], keys_a, stream_), "runs sort keys");
+    size_t tb = temp_bytes;
+    hip_check(fdb_sort_pairs_u64(temp, &tb, keys_a, keys_b, phys_a, phys_b, v->n_runs, pass_bits[p], stream_), "runs sort");
+    std::swap(phys_a, phys_b);
+  }
+  v->phys = phys_a;
+  if (v->flags == nullptr) v->flags = (uint32_t*)alloc(n * 4);
+  if (v->out_idx == nullptr) v->out_idx = (uint32_t*)alloc(n * 4);
+  unsigned long long* d_scratch = (unsigned long long*)alloc((n / 1024 + 4) * 8 + 256);
+  unsigned long long* d_totals = (unsigned long long*)alloc(256);  // [1] groups, [2] order violation (low word)
+  hip_check(hipMemsetAsync(d_totals, 0, 256, stream_), "hipMemsetAsync(totals)");
+  hip_check(fdb_launch_runs_flags_wide(v->phys, v->n_runs, v->segs, v->d_cols, v->d_rank32, (int)gcols_.size(), v->flags, (unsigned int*)(d_totals + 2), stream_), "runs flags (sorted)");
+  hip_check(fdb_launch_scan_u32(v->flags, 1, v->out_idx, v->n_runs, d_scratch, d_totals + 1, stream_), "scan run flags");
+  unsigned long long h_tot[3] = {0, 0, 0};
+  hip_check(hipMemcpyAsync(h_tot, d_totals, 24, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(group count)");
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  if ((h_tot[2] & 0xFFFFFFFFull) != 0) throw Error(FDB_ERR_DEVICE, "internal: the run store is not in key order after its sort");
+  v->n_groups = (int64_t)h_tot[1];
+  last_kernel_ = "runs_sort_keys_kernel + runs_expand_kernel";  // (what Finish ran: tests and the bench line name the path by it)
+  return true;
 }
 
 // Every run becomes a pre-aggregated entry of the hash table (equal keys merge there): what any consumer other than Finish sees,
@@ -1235,7 +1320,8 @@ int64_t Plan::finish_columns_runs(std::vector<OutColumn>* cols, DeviceBatch* res
   struct FreeOwned { Context* c; std::vector<void*>* v; hipStream_t s; ~FreeOwned() { (void)hipStreamSynchronize(s); for (void* p : *v) c->dev_free(p); } } free_owned{ctx_, &owned, stream_};
   hash_layout();
   RunsView v;
-  if (!runs_prepare(&v, /*check_order=*/true, &owned)) { runs_to_table(); return 0; }
+  // keys out of order — several ordered sets, or input that was not ordered at all: sorted on the device; beyond what that takes, the table
+  if (!runs_prepare(&v, /*check_order=*/true, &owned) && !runs_sort(&v, &owned)) { runs_to_table(); return 0; }
   const int64_t n = finish_columns_hash(cols, resident, &v);
   hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   runs_free();

@@ -368,6 +368,23 @@ hipError_t fdb_launch_runs_flags(const unsigned long long* phys, int64_t n_runs,
 // (device array [n_cols]) and the 32-bit rank tables `rank32`.
 hipError_t fdb_launch_runs_flags_wide(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const FdbRunCol* cols, const uint32_t* rank32, int n_cols,
                                       uint32_t* flags, unsigned int* violation, hipStream_t stream);
+// Runs whose keys did NOT arrive in order (several ordered sets pushed one after the other, a record out of place) are brought into key
+// order by a stable LSD radix sort of (key, phys) pairs, one pass per group of columns from the LAST group column to the first — after it
+// the flags / expand kernels above see one ordered set. A pass's 64-bit key:
+//   mode 0: the ranks of `n` dictionary columns packed side by side (column col[k]'s rank << shift[k]; NULL = null_rank[k] = the column's
+//           number of values, i.e. last), earlier columns in higher bits;
+//   mode 1: int64 column col[0]'s value (sign bit flipped unless uint64; 0 for NULL);   mode 2: 1 where int64 column col[0] is NULL.
+struct FdbRunKeyPass {
+  int32_t mode, n;
+  int32_t col[FDB_MAX_HASH_GCOLS], shift[FDB_MAX_HASH_GCOLS];
+  uint32_t null_rank[FDB_MAX_HASH_GCOLS];
+};
+hipError_t fdb_launch_runs_sort_keys(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const FdbRunCol* cols, const uint32_t* rank32,
+                                     const FdbRunKeyPass& pass, unsigned long long* keys, hipStream_t stream);
+// Stable sort of (key, value) pairs by the low `bits` bits of the key (fdb_sort.hip: rocPRIM's device radix sort — the one library primitive
+// of the kernel set; it sits on the ordered Finish's fallback path, not on the scan). temp == nullptr: *temp_bytes = the scratch it needs.
+hipError_t fdb_sort_pairs_u64(void* temp, size_t* temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const unsigned long long* vals_in,
+                              unsigned long long* vals_out, int64_t n, int bits, hipStream_t stream);
 // Groups out: for every run i, group g = out_idx[i] (exclusive prefix sums of flags) if flags[i] else out_idx[i] − 1 (flags == nullptr:
 // every run is its own group, g = i). A group's first run writes its key tuple as one row of `dense_keys` ([n_groups][key_words]
 // u32: valid mask in words 0-1, column c's id in word col_word[c]); counts and aggregates are folded into vals_cnt / vals_acc

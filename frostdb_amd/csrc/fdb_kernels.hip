@@ -2731,6 +2731,39 @@ hipError_t fdb_launch_runs_flags_wide(const unsigned long long* phys, int64_t n_
   return hipGetLastError();
 }
 
+// The sort key of every run for one pass of the LSD sort that restores key order (FdbRunKeyPass, fdb_kernels.h).
+__global__ __launch_bounds__(256) void runs_sort_keys_kernel(const unsigned long long* __restrict__ phys, int64_t n_runs, const FdbRunSegs segs, const FdbRunCol* __restrict__ cols,
+                                                             const uint32_t* __restrict__ rank32, const FdbRunKeyPass ps, unsigned long long* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_runs) return;
+  const RunRef a = run_ref(segs, phys[i]);
+  typedef const __attribute__((address_space(4))) FdbRunCol* ConstRunCols;
+  ConstRunCols q = (ConstRunCols)cols;
+  unsigned long long key = 0;
+  if (ps.mode == 0) {
+    for (int k = 0; k < ps.n; k++) {
+      const int c = ps.col[k];
+      const uint32_t id = run_dict_id(a, c, q[c].word);
+      uint32_t r = rank32[q[c].rank_off + id];
+      if (r == 0xFFFFFFFFu) r = ps.null_rank[k];  // NULL sorts after every value
+      key |= (unsigned long long)r << ps.shift[k];
+    }
+  } else {
+    const int c = ps.col[0];
+    unsigned long long v = 0;
+    const bool has = run_i64(a, q[c].word, q[c].gi, &v);
+    if (ps.mode == 1) key = has ? (q[c].kind == 3 ? v : v ^ 0x8000000000000000ull) : 0ull;
+    else key = has ? 0ull : 1ull;
+  }
+  keys[i] = key;
+}
+hipError_t fdb_launch_runs_sort_keys(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const FdbRunCol* cols, const uint32_t* rank32,
+                                     const FdbRunKeyPass& pass, unsigned long long* keys, hipStream_t stream) {
+  if (n_runs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(runs_sort_keys_kernel, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, stream, phys, n_runs, segs, cols, rank32, pass, keys);
+  return hipGetLastError();
+}
+
 // One wave per 64 consecutive logical runs. The key rows of the groups that START among them are consecutive in the output
 // (out_idx is monotone), so they are assembled in the wave's LDS tile and leave as one contiguous copy.
 __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArgs a, const FdbRunSegs segs) {

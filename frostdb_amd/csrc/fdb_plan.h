@@ -318,6 +318,7 @@ class Plan {
     FdbRunSegs segs;
     unsigned long long* phys = nullptr; uint32_t* flags = nullptr; uint32_t* out_idx = nullptr;
     int64_t n_runs = 0, n_groups = 0;
+    const FdbRunCol* d_cols = nullptr; const uint32_t* d_rank32 = nullptr;  // the columns' places and 32-bit rank tables on the device (runs_rank_tables), once somebody needed them
   };
   // Small pushed records are not allocated one by one (a record held until the next sync would cost a hipMalloc each: ≈25 µs, and
   // a process-wide lock that N chains fight over): their bytes are pieces of a SLAB — a device block and a pinned block of the same
@@ -337,6 +338,10 @@ class Plan {
   // false: the keys did not arrive in order (the caller falls back to runs_to_table + the ordinary ordered Finish). Device blocks it
   // allocates are appended to `owned` (freed by the caller through ctx_->dev_free).
   bool runs_prepare(RunsView* v, bool check_order, std::vector<void*>* owned);
+  void runs_rank_tables(RunsView* v, std::vector<void*>* owned);  // fills v->d_cols / d_rank32 (no-op when they are there)
+  // The runs of `v` brought into key order by a device sort (several ordered sets, a record out of place): phys / flags / out_idx / n_groups
+  // are replaced. false: not attempted (too many runs, $FDB_RUNS_NO_SORT) — the caller falls back to the table.
+  bool runs_sort(RunsView* v, std::vector<void*>* owned);
   int32_t runs_func() const;  // how two runs' aggregates fold (FdbRunsExpandArgs.func)
   void hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols);
   int64_t finish_columns_runs(std::vector<OutColumn>* cols, DeviceBatch* resident, bool* ok);

@@ -67,9 +67,12 @@ def test_reference_vectors(pp, case, records, monkeypatch):
     assert names[-1] == "vals"  # a partial-stage OrderedAggregate names its result after the column (ordered_aggregate.go:551-557)
 
 
+@pytest.mark.parametrize("fallback", ["sort", "table"])
 @pytest.mark.parametrize("records", ["narrow", "medium", "wide"])
 @pytest.mark.parametrize("func,agg", [(SUM, Sum), (MIN, Min), (MAX, Max), (COUNT, Count)])
-def test_random_partially_ordered_streams_with_null_keys(pp, func, agg, records, monkeypatch):
+def test_random_partially_ordered_streams_with_null_keys(pp, func, agg, records, fallback, monkeypatch):
+    if fallback == "table":  # (records out of order: sorted on the device by default, through the hash table with this)
+        monkeypatch.setenv("FDB_RUNS_NO_SORT", "1")
     if records != "narrow":
         monkeypatch.setenv("FDB_RUNS_WIDE", "m" if records == "medium" else "1")
     rng = np.random.default_rng(int(func) * 7)
@@ -195,6 +198,7 @@ def _run_plan(pp, recs, agg, groups, ordered, resident=False, filt=None, finish_
             rb.close()
         else:
             out = plan.Finish()
+        _run_plan.after_finish = plan.last_kernel()  # (an ordered Finish that had to sort its runs names the kernels it ran)
         return out, kernel
     finally:
         plan.Close()
@@ -245,17 +249,93 @@ def test_table_free_ordered_aggregate_with_a_filter_and_a_resident_finish(pp):
     assert _rows(o) == sorted(_rows(h), key=_key_order)
 
 
-def test_input_that_breaks_the_order_falls_back_to_the_table(pp):
+SORTED_FINISH = "runs_sort_keys_kernel + runs_expand_kernel"
+
+
+@pytest.mark.parametrize("fallback", ["sort", "table"])
+def test_input_that_breaks_the_order_is_sorted_on_the_device_or_falls_back_to_the_table(pp, fallback, monkeypatch):
     """One record out of order (and one that is not sorted at all): Finish notices that a new key does not sort after its
-    predecessor, puts every run into the hash table and takes the ordinary ordered Finish — same groups, same order."""
+    predecessor and sorts the runs by key on the device (round 5) — or, with $FDB_RUNS_NO_SORT, puts every run into the hash table and
+    takes the ordinary ordered Finish (round 4). Same groups, same order."""
+    if fallback == "table":
+        monkeypatch.setenv("FDB_RUNS_NO_SORT", "1")
     rng = np.random.default_rng(13)
     recs = _sorted_label_records(rng, 120_000, 4)
     recs = [recs[2], recs[0], recs[3], recs[1]] + _sorted_label_records(rng, 30_000, 1, sort=False)
     groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
     o, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True)
     assert kernel == "fdb_hash_kernel(runs)"
+    assert (_run_plan.after_finish == SORTED_FINISH) == (fallback == "sort"), _run_plan.after_finish
     h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False)
     assert _rows(o) == sorted(_rows(h), key=_key_order)
+
+
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("records", ["narrow", "medium", "wide"])
+@pytest.mark.parametrize("agg_name", ["sum_i", "sum_f", "min", "max", "count"])
+def test_several_ordered_sets_are_merged_without_the_table(pp, agg_name, records, resident, monkeypatch):
+    """Four ordered sets (≙ the sets OrderedAggregate merges at Finish, ordered_aggregate.go:449-470): every record sorted, pushed in an
+    order that is not the key order, groups shared between the sets. No hash kernel: the runs are sorted by key on the device and the
+    runs of one group folded where they meet. Equal to the hash aggregate's groups sorted by key — with each of the three run records."""
+    if records != "narrow":
+        monkeypatch.setenv("FDB_RUNS_WIDE", "m" if records == "medium" else "1")
+    rng = np.random.default_rng(31)
+    sets = [_sorted_label_records(rng, 60_000, 2, card=(6, 9, 4)) for _ in range(4)]  # (each set: two records that continue each other)
+    recs = [r for st in (sets[2], sets[0], sets[3], sets[1]) for r in st]
+    agg = {"sum_i": Sum(Col("v")), "sum_f": Sum(Col("f")), "min": Min(Col("v")), "max": Max(Col("f")), "count": Count(Col("v"))}[agg_name]
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    o, kernel = _run_plan(pp, recs, agg, groups, ordered=True, resident=resident, finish_resident=resident)
+    assert kernel.startswith("fdb_hash_kernel(runs"), kernel
+    assert _run_plan.after_finish == SORTED_FINISH, _run_plan.after_finish
+    h, _ = _run_plan(pp, recs, agg, groups, ordered=False, resident=resident)
+    orows, hrows = _rows(o), sorted(_rows(h), key=_key_order)
+    assert len(orows) == len(hrows) > 300
+    assert [r[:3] for r in orows] == [r[:3] for r in hrows]
+    for a, b in zip(orows, hrows):
+        assert a[3] == b[3] or (isinstance(a[3], float) and abs(a[3] - b[3]) <= 1e-9 * max(1.0, abs(b[3]))), (a, b)
+
+
+@pytest.mark.parametrize("pos", [0, 1])
+def test_ordered_sets_with_int64_keys_and_big_dictionaries_are_sorted_by_value(pp, pos):
+    """The sort's int64 passes (value with the sign bit flipped, then NULL last) and a dictionary of 70 000 values (17 bits of rank) next to
+    them: three ordered sets with negative, positive and NULL buckets, pushed out of order."""
+    rng = np.random.default_rng(33 + pos)
+    cards = (3_000, 70_000) if pos == 0 else (70_000, 3_000)
+    sets = [_wide_sorted_records(rng, 80_000, 2, cards=cards, int_key=pos) for _ in range(3)]
+    recs = [r for st in (sets[1], sets[2], sets[0]) for r in st]
+    groups = [Col("bucket"), Col("labels.l1")] if pos == 0 else [Col("labels.l0"), Col("bucket")]
+    o, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True, resident=True)
+    assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    assert _run_plan.after_finish == SORTED_FINISH, _run_plan.after_finish
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False, resident=True)
+    key = lambda r: tuple((x is None, x if x is not None else 0) for x in r[:2])  # noqa: E731
+    orows = _rows(o)
+    assert len(orows) > 100_000 and orows == sorted(_rows(h), key=key)
+
+
+def test_ordered_sets_whose_key_ranks_need_several_sort_passes(pp):
+    """Fourteen label columns of 90–130 values (7 bits of rank each: 98 bits, two 64-bit passes) over rows that are NOT sorted at all —
+    every row a run of its own, 200 000 runs into ≈ 60 000 groups: the least significant columns must be sorted first and the passes
+    must be stable for the result to come out in key order."""
+    rng = np.random.default_rng(35)
+    n, n_cols = 200_000, 14
+    cards = [int(c) for c in rng.integers(90, 131, n_cols)]
+    base = rng.integers(0, 60_000, n)  # the group of every row; its key: a fixed random tuple per group
+    tuples = np.stack([rng.integers(0, k + 1, 60_000) for k in cards], axis=1)  # k = NULL
+    arrays, names = [], []
+    for c, k in enumerate(cards):
+        x = tuples[base, c]
+        d = pa.array([b"v%03d" % (k - 1 - i) for i in range(k)], type=pa.binary())
+        arrays.append(pa.DictionaryArray.from_arrays(pa.array(np.where(x == k, 0, k - 1 - x).astype(np.uint32), mask=x == k), d)); names.append("labels.l%02d" % c)
+    arrays.append(pa.array(rng.integers(1, 100, n).astype(np.int64))); names.append("v")
+    rec = pa.RecordBatch.from_arrays(arrays, names=names)
+    groups = [Col("labels.l%02d" % c) for c in range(n_cols)]
+    o, kernel = _run_plan(pp, [rec.slice(0, 120_000), rec.slice(120_000)], Sum(Col("v")), groups, ordered=True)
+    assert kernel.startswith("fdb_hash_kernel(runs"), kernel
+    assert _run_plan.after_finish == SORTED_FINISH, _run_plan.after_finish
+    h, _ = _run_plan(pp, [rec], Sum(Col("v")), groups, ordered=False)
+    orows = _rows(o)
+    assert len(orows) > 50_000 and orows == sorted(_rows(h), key=lambda r: _key_order(r, n_cols))
 
 
 def test_runs_become_table_entries_for_every_other_consumer(pp):

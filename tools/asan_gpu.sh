@@ -11,14 +11,14 @@ OUT="$ROOT/tools/_asan"
 if [ "${1:-build}" = build ]; then
   mkdir -p "$OUT"
   SRC="$ROOT/frostdb_amd/csrc"
-  python -c "import sys; sys.path.insert(0, '$ROOT'); from frostdb_amd import build; build.build()" > /dev/null   # (fdb_kernels.o, fdb_kernels_h.inc)
+  python -c "import sys; sys.path.insert(0, '$ROOT'); from frostdb_amd import build; build.build()" > /dev/null   # (fdb_kernels.o, fdb_sort.o, fdb_kernels_h.inc)
   pids=()
   for f in fdb_arrow fdb_context fdb_plan fdb_hash fdb_jit fdb_dynamic fdb_comm fdb_parquet fdb_regex fdb_capi; do
     g++ -std=c++17 -O1 -g1 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c "$SRC/$f.cpp" -o "$OUT/$f.o" & pids+=($!)
   done
   g++ -std=c++17 -O1 -g1 -fPIC -fsanitize=address,undefined -c "$SRC/fdb_widen.cc" -o "$OUT/fdb_widen.o" & pids+=($!)
   for p in "${pids[@]}"; do wait $p; done
-  g++ -shared -fPIC -fsanitize=address,undefined -o "$OUT/libfdb_fullasan.so" "$OUT"/*.o "$SRC/fdb_kernels.o" -L/opt/rocm/lib -lamdhip64 -lhiprtc -ldl -lpthread -lz -Wl,-rpath,/opt/rocm/lib
+  g++ -shared -fPIC -fsanitize=address,undefined -o "$OUT/libfdb_fullasan.so" "$OUT"/*.o "$SRC/fdb_kernels.o" "$SRC/fdb_sort.o" -L/opt/rocm/lib -lamdhip64 -lhiprtc -ldl -lpthread -lz -Wl,-rpath,/opt/rocm/lib
   rm -f "$OUT"/*.o
   ls -la "$OUT"
   exit 0
