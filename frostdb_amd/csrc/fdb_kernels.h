@@ -379,8 +379,13 @@ struct FdbRunKeyPass {
   int32_t col[FDB_MAX_HASH_GCOLS], shift[FDB_MAX_HASH_GCOLS];
   uint32_t null_rank[FDB_MAX_HASH_GCOLS];
 };
-hipError_t fdb_launch_runs_sort_keys(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const FdbRunCol* cols, const uint32_t* rank32,
-                                     const FdbRunKeyPass& pass, unsigned long long* keys, hipStream_t stream);
+// Exactly one of `segs` (the things sorted are runs, phys[i] = (segment << 32) | index) and `rows` (they are dense key rows of `row_kw`
+// words — an ordered plan's groups out of the hash table; a row has the layout of a wide run's key tuple — and phys[i] is a row number).
+hipError_t fdb_launch_runs_sort_keys(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs* segs, const uint32_t* rows, int row_kw, const FdbRunCol* cols,
+                                     const uint32_t* rank32, const FdbRunKeyPass& pass, unsigned long long* keys, hipStream_t stream);
+hipError_t fdb_launch_iota_u64(unsigned long long* p, int64_t n, hipStream_t stream);  // p[i] = i
+hipError_t fdb_launch_gather_rows_u32(const uint32_t* src, int words, const unsigned long long* order, int64_t n, uint32_t* dst, hipStream_t stream);  // dst row i = src row order[i]
+hipError_t fdb_launch_gather_u64(const unsigned long long* src, const unsigned long long* order, int64_t n, unsigned long long* dst, hipStream_t stream);  // dst[i] = src[order[i]]
 // Stable sort of (key, value) pairs by the low `bits` bits of the key (fdb_sort.hip: rocPRIM's device radix sort — the one library primitive
 // of the kernel set; it sits on the ordered Finish's fallback path, not on the scan). temp == nullptr: *temp_bytes = the scratch it needs.
 hipError_t fdb_sort_pairs_u64(void* temp, size_t* temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, const unsigned long long* vals_in,

@@ -18,6 +18,7 @@
 
 #define FDB_DEVICE_HELPERS 1
 #include <cstdlib>
+#include <cstring>
 
 #include "fdb_kernels.h"
 
@@ -2731,12 +2732,16 @@ hipError_t fdb_launch_runs_flags_wide(const unsigned long long* phys, int64_t n_
   return hipGetLastError();
 }
 
-// The sort key of every run for one pass of the LSD sort that restores key order (FdbRunKeyPass, fdb_kernels.h).
-__global__ __launch_bounds__(256) void runs_sort_keys_kernel(const unsigned long long* __restrict__ phys, int64_t n_runs, const FdbRunSegs segs, const FdbRunCol* __restrict__ cols,
-                                                             const uint32_t* __restrict__ rank32, const FdbRunKeyPass ps, unsigned long long* __restrict__ keys) {
+// The sort key of every run for one pass of the LSD sort that restores key order (FdbRunKeyPass, fdb_kernels.h). `rows` != nullptr: the
+// things being sorted are not runs but dense key rows of `row_kw` words (an ordered plan's groups out of the hash table: a row has the
+// layout of a wide run's key tuple) and phys[i] is a row number.
+__global__ __launch_bounds__(256) void runs_sort_keys_kernel(const unsigned long long* __restrict__ phys, int64_t n_runs, const FdbRunSegs segs, const uint32_t* __restrict__ rows, int row_kw,
+                                                             const FdbRunCol* __restrict__ cols, const uint32_t* __restrict__ rank32, const FdbRunKeyPass ps, unsigned long long* __restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_runs) return;
-  const RunRef a = run_ref(segs, phys[i]);
+  RunRef a;
+  if (rows != nullptr) { a.t = rows + phys[i] * (unsigned long long)row_kw; a.kw = row_kw; }
+  else a = run_ref(segs, phys[i]);
   typedef const __attribute__((address_space(4))) FdbRunCol* ConstRunCols;
   ConstRunCols q = (ConstRunCols)cols;
   unsigned long long key = 0;
@@ -2757,10 +2762,47 @@ __global__ __launch_bounds__(256) void runs_sort_keys_kernel(const unsigned long
   }
   keys[i] = key;
 }
-hipError_t fdb_launch_runs_sort_keys(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs& segs, const FdbRunCol* cols, const uint32_t* rank32,
-                                     const FdbRunKeyPass& pass, unsigned long long* keys, hipStream_t stream) {
+hipError_t fdb_launch_runs_sort_keys(const unsigned long long* phys, int64_t n_runs, const FdbRunSegs* segs, const uint32_t* rows, int row_kw, const FdbRunCol* cols,
+                                     const uint32_t* rank32, const FdbRunKeyPass& pass, unsigned long long* keys, hipStream_t stream) {
   if (n_runs <= 0) return hipSuccess;
-  hipLaunchKernelGGL(runs_sort_keys_kernel, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, stream, phys, n_runs, segs, cols, rank32, pass, keys);
+  if ((segs == nullptr) == (rows == nullptr)) return hipErrorInvalidValue;
+  FdbRunSegs none;
+  if (segs == nullptr) std::memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(runs_sort_keys_kernel, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, stream, phys, n_runs, segs != nullptr ? *segs : none, rows, row_kw, cols, rank32, pass, keys);
+  return hipGetLastError();
+}
+
+// order[i] = i;  dst row i = src row order[i] (rows of `words` 32-bit words; one thread per word);  dst[i] = src[order[i]]
+__global__ __launch_bounds__(256) void iota_u64_kernel(unsigned long long* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = (unsigned long long)i;
+}
+__global__ __launch_bounds__(256) void gather_rows_u32_kernel(const uint32_t* __restrict__ src, int words, const unsigned long long* __restrict__ order, int64_t n, uint32_t* __restrict__ dst) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * words) return;
+  const int64_t i = t / words;
+  const int w = (int)(t - i * words);
+  dst[t] = src[order[i] * (unsigned long long)words + (unsigned long long)w];
+}
+__global__ __launch_bounds__(256) void gather_u64_kernel(const unsigned long long* __restrict__ src, const unsigned long long* __restrict__ order, int64_t n, unsigned long long* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[order[i]];
+}
+hipError_t fdb_launch_iota_u64(unsigned long long* p, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(iota_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n);
+  return hipGetLastError();
+}
+hipError_t fdb_launch_gather_rows_u32(const uint32_t* src, int words, const unsigned long long* order, int64_t n, uint32_t* dst, hipStream_t stream) {
+  if (n <= 0 || words <= 0) return hipSuccess;
+  const int64_t total = n * words;
+  if ((total + 255) / 256 > 0x7FFFFFFFll) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_rows_u32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, words, order, n, dst);
+  return hipGetLastError();
+}
+hipError_t fdb_launch_gather_u64(const unsigned long long* src, const unsigned long long* order, int64_t n, unsigned long long* dst, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, order, n, dst);
   return hipGetLastError();
 }
 

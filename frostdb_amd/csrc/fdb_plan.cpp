@@ -1872,6 +1872,17 @@ void Plan::build_agg_columns(const CompactState& cs, std::vector<OutColumn>* col
   }
 }
 
+// An ordered plan whose groups sit in the hash table: from a few thousand groups on they are sorted on the device (finish_columns_hash), below
+// that on the host (sort_compact: a handful of launches and a round trip cost more than sorting a few rows). $FDB_ORDERED_SORT_MIN moves
+// the threshold (0: always on the device — tests).
+bool Plan::ordered_finish_on_device() {
+  if (!ordered_ || mode_ != TableMode::HASH || h_table_ == nullptr) return false;
+  const char* e = std::getenv("FDB_ORDERED_SORT_MIN");
+  const uint64_t least = e != nullptr ? (uint64_t)std::max<long long>(0, std::atoll(e)) : 4096;
+  const uint64_t n = hash_groups();
+  return n >= least && n >= 2 && n <= ((uint64_t)1 << 28);
+}
+
 int64_t Plan::finish_columns(std::vector<OutColumn>* cols) {
   PhaseTimer pt;
   cols->clear();
@@ -1882,8 +1893,8 @@ int64_t Plan::finish_columns(std::vector<OutColumn>* cols) {
     if (ok) { finished_ = true; return n; }
     cols->clear();  // the keys were not in order: the runs are in the hash table now, the ordinary ordered Finish below sorts them
   }
-  if (mode_ == TableMode::HASH && h_table_ != nullptr && !ordered_) {
-    // big result sets: columns are materialised on the device, the host only copies finished Arrow buffers
+  if (mode_ == TableMode::HASH && h_table_ != nullptr && (!ordered_ || ordered_finish_on_device())) {
+    // big result sets: columns are materialised on the device (an ordered plan's: sorted there first), the host only copies finished Arrow buffers
     n = finish_columns_hash(cols);
     pt.mark("finish: columns");
   } else {
@@ -1919,13 +1930,13 @@ std::unique_ptr<DeviceBatch> Plan::finish_batch(int64_t* n_rows) {
     const int64_t n = finish_columns_runs(nullptr, b.get(), &ok);
     if (ok) { if (n_rows) *n_rows = n; return b; }
   }
-  if (mode_ == TableMode::HASH && h_table_ != nullptr && !ordered_ && !composite) {
+  if (mode_ == TableMode::HASH && h_table_ != nullptr && (!ordered_ || ordered_finish_on_device()) && !composite) {
     std::unique_ptr<DeviceBatch> b(new DeviceBatch());
     const int64_t n = finish_columns_hash(nullptr, b.get());
     if (n_rows) *n_rows = n;
     return b;
   }
-  // small (dense) tables, ordered output, composite reducers: the ordinary Finish, then the record is made resident
+  // small (dense) tables, small ordered results, composite reducers: the ordinary Finish, then the record is made resident
   ArrowArray arr;
   ArrowSchema sch;
   std::memset(&arr, 0, sizeof(arr));

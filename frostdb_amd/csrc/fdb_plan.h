@@ -342,6 +342,10 @@ class Plan {
   // The runs of `v` brought into key order by a device sort (several ordered sets, a record out of place): phys / flags / out_idx / n_groups
   // are replaced. false: not attempted (too many runs, $FDB_RUNS_NO_SORT) — the caller falls back to the table.
   bool runs_sort(RunsView* v, std::vector<void*>* owned);
+  bool ordered_finish_on_device();  // an ordered plan's groups out of the hash table: sorted on the device (big results) or on the host
+  // The stable LSD sort both ordered Finishes use (fdb_hash.cpp): runs of a run store, or the groups of the hash table as dense key rows.
+  unsigned long long* sort_by_group_columns(unsigned long long* order, int64_t n_things, const FdbRunSegs* segs, const uint32_t* rows, int row_kw, RunsView* tables,
+                                            std::vector<void*>* owned);
   int32_t runs_func() const;  // how two runs' aggregates fold (FdbRunsExpandArgs.func)
   void hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols);
   int64_t finish_columns_runs(std::vector<OutColumn>* cols, DeviceBatch* resident, bool* ok);

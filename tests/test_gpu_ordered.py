@@ -67,12 +67,14 @@ def test_reference_vectors(pp, case, records, monkeypatch):
     assert names[-1] == "vals"  # a partial-stage OrderedAggregate names its result after the column (ordered_aggregate.go:551-557)
 
 
-@pytest.mark.parametrize("fallback", ["sort", "table"])
+@pytest.mark.parametrize("fallback", ["sort", "table", "table-sorted-on-the-device"])
 @pytest.mark.parametrize("records", ["narrow", "medium", "wide"])
 @pytest.mark.parametrize("func,agg", [(SUM, Sum), (MIN, Min), (MAX, Max), (COUNT, Count)])
 def test_random_partially_ordered_streams_with_null_keys(pp, func, agg, records, fallback, monkeypatch):
-    if fallback == "table":  # (records out of order: sorted on the device by default, through the hash table with this)
+    if fallback != "sort":  # (records out of order: the runs are sorted on the device by default; with this they go through the hash table …)
         monkeypatch.setenv("FDB_RUNS_NO_SORT", "1")
+    if fallback == "table-sorted-on-the-device":  # (… whose groups an ordered Finish sorts on the host when there are few, on the device from 4 096 on: here always)
+        monkeypatch.setenv("FDB_ORDERED_SORT_MIN", "0")
     if records != "narrow":
         monkeypatch.setenv("FDB_RUNS_WIDE", "m" if records == "medium" else "1")
     rng = np.random.default_rng(int(func) * 7)
@@ -293,6 +295,62 @@ def test_several_ordered_sets_are_merged_without_the_table(pp, agg_name, records
     assert [r[:3] for r in orows] == [r[:3] for r in hrows]
     for a, b in zip(orows, hrows):
         assert a[3] == b[3] or (isinstance(a[3], float) and abs(a[3] - b[3]) <= 1e-9 * max(1.0, abs(b[3]))), (a, b)
+
+
+TABLE_SORTED_FINISH = "hash_gather_rows_kernel + runs_sort_keys_kernel"
+
+
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("agg_name", ["sum_i", "sum_f", "min", "count"])
+def test_ordered_plans_merged_like_chains_finish_in_key_order_on_the_device(pp, agg_name, resident):
+    """Two ordered plans (two chains over halves of a sorted table), merged (≙ Synchronizer + the final ordered aggregate): their runs go
+    into the hash table — key ids are per plan — and the ordered Finish out of the table sorts its 60 000 groups ON THE DEVICE (round 5;
+    before: every group to the host and a comparison sort there). Equal to the hash aggregate sorted by key; int64 and NULL keys included."""
+    rng = np.random.default_rng(41)
+    recs = _wide_sorted_records(rng, 200_000, 6, cards=(300, 2_000), int_key=1)
+    agg = {"sum_i": Sum(Col("v")), "sum_f": Sum(Col("v")), "min": Min(Col("v")), "count": Count(Col("v"))}[agg_name]
+    groups = [Col("labels.l0"), Col("bucket")]
+    p1 = pp.HashAggregatePlan(None, [agg], groups, ordered=True, final_stage=False)
+    p2 = pp.HashAggregatePlan(None, [agg], groups, ordered=True, final_stage=False)
+    try:
+        for r in recs[:3]:
+            p1.Callback(r)
+        for r in recs[3:]:
+            p2.Callback(r)
+        p1.Merge(p2)
+        if resident:
+            rb = p1.FinishResident()
+            out = rb.to_arrow()
+            rb.close()
+        else:
+            out = p1.Finish()
+        assert p1.last_kernel() == TABLE_SORTED_FINISH, p1.last_kernel()
+    finally:
+        p1.Close(); p2.Close()
+    h, _ = _run_plan(pp, recs, agg, groups, ordered=False)
+    key = lambda r: tuple((x is None, x if x is not None else 0) for x in r[:2])  # noqa: E731
+    orows = _rows(out)
+    assert len(orows) > 50_000 and orows == sorted(_rows(h), key=key)
+
+
+def test_small_ordered_results_out_of_the_table_are_still_sorted_on_the_host(pp, monkeypatch):
+    """Below 4 096 groups the ordered Finish out of the table keeps the host sort (a handful of launches cost more than sorting a few rows);
+    $FDB_ORDERED_SORT_MIN=0 sends the same result through the device sort — both equal the hash aggregate sorted by key."""
+    rng = np.random.default_rng(42)
+    recs = _sorted_label_records(rng, 50_000, 4)
+    recs = [recs[1], recs[3], recs[0], recs[2]]
+    groups = [Col("labels.l0"), Col("labels.l1"), Col("labels.l2")]
+    monkeypatch.setenv("FDB_RUNS_NO_SORT", "1")
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False)
+    want = sorted(_rows(h), key=_key_order)
+    o, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True)
+    assert _run_plan.after_finish not in (SORTED_FINISH, TABLE_SORTED_FINISH), _run_plan.after_finish
+    assert _rows(o) == want
+    monkeypatch.setenv("FDB_ORDERED_SORT_MIN", "0")
+    for finish_resident in (False, True):
+        o, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True, resident=finish_resident, finish_resident=finish_resident)
+        assert _run_plan.after_finish == TABLE_SORTED_FINISH, _run_plan.after_finish
+        assert _rows(o) == want
 
 
 @pytest.mark.parametrize("pos", [0, 1])
