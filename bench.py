@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch-rows", type=int, default=25_000_000, help="rows per resident record (part)")
     ap.add_argument("--groups", type=int, default=10_000_000, help="cfg 5: distinct groups")
     ap.add_argument("--cfg5-sorted", action="store_true", help="cfg 5: every record's rows ordered by group (a scan of a table sorted by its label columns)")
+    ap.add_argument("--push-order", default="", help="resident records are pushed in this order (comma-separated indices), e.g. 2,0,3,1: a sorted table then arrives as several ordered sets")
     ap.add_argument("--cfg2-sorted", action="store_true", help="cfg 2: the table sorted by labels.path, the plan an OrderedAggregate (the run kernel's wide records: 1 024 path values)")
     ap.add_argument("--cfg5-wide-dicts", action="store_true", help="cfg 5: label dictionaries of 512 … 65 532 entries (with --cfg5-sorted: the run kernel's medium records)")
     ap.add_argument("--rows-per-thread", type=int, default=0, help="0: slot kernel (default); 4/8: sequential kernel")
@@ -910,7 +911,7 @@ def run_rank(args, group, device, comm):
                   gen_threads=max(1, min(16, (os.cpu_count() or 8) // world)) if isinstance(group, ThreadGroup) else None)
     shard_sizes = group.gather(rows)
     assert sum(shard_sizes) == total_rows, (shard_sizes, total_rows)
-    r = run_workload(args, wl, args.steps, args.warmup, group, comm, total_rows)
+    r = run_workload(args, wl, args.steps, args.warmup, group, comm, total_rows, push_order=[int(x) for x in args.push_order.split(",") if x] or None)
     value = total_rows * args.steps / r["elapsed"]
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle's restatement on this box's host cores, bounded sample ----

@@ -10,13 +10,14 @@ set -u
 TAG=${1:-round5}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 O=gpurun_out/$TAG; [ -z "${ONLY_PROF:-}" ] && rm -rf $O; mkdir -p $O
-if [ -z "${ONLY_PROF:-}" ]; then  # (ONLY_PROF=1: the rocprofv3 passes alone, into the same directory)
+if [ -z "${ONLY_PROF:-}" ]; then  # (ONLY_PROF=1: the rocprofv3 passes alone, into the same directory; with ONLY_PASS=<name>: that pass alone)
 timeout 600 python bench.py --steps 20 --warmup 3 > $O/bench_default_line.json 2> $O/bench_default.err; echo "bench rc=$?"
 timeout 300 python bench.py --gpus 2 --force-local --steps 10 --warmup 2 > $O/cfg4_force_local_line.json 2> $O/cfg4_force_local.err; echo "force-local rc=$?"
 fi
 prof() { # name "command" [fetch] [write]
   local name=$1; shift
   local cmd="$1"; shift
+  [ -n "${ONLY_PASS:-}" ] && [ "$ONLY_PASS" != "$name" ] && return 0  # (ONLY_PASS=<name>: that pass alone)
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name/kt -o kt -- $cmd > $O/$name.kt.log 2>&1
   for p in "$@"; do
     case $p in
@@ -30,6 +31,7 @@ prof cfg1B "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-c
 prof cfg3 "python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline --no-oracle-parity" fetch write
 prof cfg5 "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
 prof cfg5_sorted "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
+prof cfg5_sorted_sets "python bench.py --config 5 --cfg5-sorted --push-order 2,0,3,1 --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"
 prof cfg5_sorted_wide "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
 prof select "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select --no-oracle-parity" fetch write
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete; du -sh $O
