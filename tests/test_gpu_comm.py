@@ -182,6 +182,65 @@ def test_local_ranks_high_cardinality_exchange(pp, fcomm):
         c.close()
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_ordered_plans_on_several_ranks_exchange_and_finish_their_shards_in_key_order(pp, fcomm, world, monkeypatch):
+    """Ordered plans (fdb_plan_desc.ordered) across ranks: every rank scans its part of a table sorted by (label, bucket) into a run store,
+    the exchange re-keys and partitions the runs through the hash table, and every rank finishes ITS shard of the groups in key order —
+    sorted on the device (round 5: the ordered Finish out of the table). Shards are disjoint, their union is the hash aggregate's result."""
+    monkeypatch.setenv("FDB_RUNS_ALWAYS", "1")
+    rng = np.random.default_rng(17)
+    n = 240_000
+    lab = rng.integers(0, 301, n)           # 300 = NULL
+    bucket = rng.integers(-2_000, 2_000, n)
+    bucket = np.where(bucket == 0, 2_000, bucket)  # (no int64 key 0 next to NULL keys: the hash table files them under one fingerprint, DESIGN §5)
+    bnull = rng.random(n) < 0.02
+    order = np.lexsort((np.where(bnull, np.iinfo(np.int64).max, bucket), lab))
+    lab, bucket, bnull = lab[order], bucket[order], bnull[order]
+    d = pa.array([b"v%03d" % (299 - i) for i in range(300)], type=pa.binary())  # (descending: ids are not ranks)
+    rec = pa.RecordBatch.from_arrays(
+        [pa.DictionaryArray.from_arrays(pa.array(np.where(lab == 300, 0, 299 - lab).astype(np.uint32), mask=lab == 300), d),
+         pa.array(np.where(bnull, 0, bucket).astype(np.int64), mask=bnull), pa.array(rng.integers(1, 100, n).astype(np.int64))], names=["labels.x", "bucket", "v"])
+    per = n // world
+    shards = [rec.slice(r * per, per if r + 1 < world else n - r * per) for r in range(world)]
+    aggs, groups = [Sum(Col("v"))], [Col("labels.x"), Col("bucket")]
+    comms = fcomm.Comm.init_local([0] * world)
+
+    def rank_fn(r):
+        plan = pp.HashAggregatePlan(None, aggs, groups, ordered=True)
+        try:
+            plan.Callback(shards[r])
+            assert "runs" in plan.last_kernel(), plan.last_kernel()
+            shard = comms[r].merge_alltoall(plan)
+            try:
+                out = shard.Finish()
+                ran = shard.last_kernel()
+            finally:
+                shard.Close()
+            return out, ran
+        finally:
+            plan.Close()
+
+    parts = run_ranks(world, rank_fn)
+    key = lambda r: (r[0] is None, r[0] or b"", r[1] is None, r[1] if r[1] is not None else 0)  # noqa: E731
+    rows = []
+    for out, ran in parts:
+        assert ran == "hash_gather_rows_kernel + runs_sort_keys_kernel", ran
+        cols = [(c.dictionary_decode() if pa.types.is_dictionary(c.type) else c).to_pylist() for c in out.columns]
+        mine = list(zip(*cols))
+        assert len(mine) > 20_000 and mine == sorted(mine, key=key)  # this rank's shard, in key order
+        rows += mine
+    h = pp.HashAggregatePlan(None, aggs, groups)
+    try:
+        h.Callback(rec)
+        want = h.Finish()
+    finally:
+        h.Close()
+    wcols = [(c.dictionary_decode() if pa.types.is_dictionary(c.type) else c).to_pylist() for c in want.columns]
+    assert sorted(rows, key=key) == sorted(zip(*wcols), key=key)
+    for c in comms:
+        c.close()
+
+
 def test_rccl_transport_single_rank_through_the_c_abi(pp, fcomm):
     """RCCL bound inside the library: unique id → ncclCommInitRank (1 rank) → layout probe + grouped in-place all-reduce on the
     plan's stream, and the send/recv exchange, each reproducing the plain Finish; then the same through ncclCommInitAll."""
