@@ -672,6 +672,7 @@ def measure_host_records_chains(wl, rows_per_chain=2_097_152):
     src = wl.host_batches
     total_src = sum(b.num_rows for b in src)
     out = {"bound": "pcie / host", "measured_h2d_GBps": h2d, "bytes_per_row_copied": 16.25, "rows_per_chain": rows_per_chain}
+    pinned = [True]
     for chains in (1, 8, 32):
         per_chain = min(rows_per_chain if chains <= 8 else rows_per_chain // 2, total_src // chains // 65536 * 65536)
         for rec_rows in (1024, 8192, 65536):
@@ -703,6 +704,11 @@ def measure_host_records_chains(wl, rows_per_chain=2_097_152):
 
                 def work(c):
                     try:
+                        # several chains: every chain's thread runs on the GPU's socket (physicalplan.local_cpus) — left to the scheduler the threads spread over
+                        # both sockets and 32 chains of 65 536-row records stop at 0.56–0.69 of the link instead of 0.92. ONE chain stays where the scheduler
+                        # put it, next to the records it reads: pinned to the GPU's socket it read them across the socket link and lost a quarter.
+                        if chains > 1:
+                            pinned[0] = pp.pin_thread_near(wl.device) and pinned[0]
                         bar.wait()
                         plans[c].CallbackPrepared(exported[c])
                         plans[c].last_kernel()  # (settle: the queued records are scanned — launched from this chain's thread, not waited for)
@@ -744,6 +750,7 @@ def measure_host_records_chains(wl, rows_per_chain=2_097_152):
                 for ex in run.keep:
                     ex.close()
     out["checked"] = {"against": "numpy expectation: every group's sum over the rows the chains own (bench.py expected_cfg2), chains merged with fdb_plan_merge; not the oracle"}
+    out["chain_threads"] = "8 and 32 chains: pinned to the cores of the GPU's NUMA node (physicalplan.pin_thread_near); 1 chain: where the scheduler put it" if pinned[0] else "not pinned (the GPU's local_cpulist could not be read or applied)"
     return out
 
 

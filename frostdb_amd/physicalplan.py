@@ -195,6 +195,46 @@ def live_allocations() -> dict:
     return {"device_blocks": a.value, "device_bytes": b.value, "pinned_blocks": c.value}
 
 
+def local_cpus(device: int = 0):
+    """The CPUs next to the GPU — sysfs ``local_cpulist`` of its PCI function, i.e. the cores of the NUMA node it hangs off — or None
+    when that cannot be told. Threads that push HOST records (one per chain, like the reference's goroutines) belong there: on a
+    two-socket MI355X box one chain moves 1.8 G rows/s of 65 536-row records from the GPU's socket and 1.36 from the other, eight chains on
+    the other socket stop at half the link (profiles/round5_push_bench_numa_sdma.txt). ``pin_thread_near(device)`` applies it to the
+    calling thread."""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return None
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % buf.value.decode().lower()) as f:
+            text = f.read().strip()
+        cpus = set()
+        for part in text.split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        return cpus or None
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
+def pin_thread_near(device: int = 0) -> bool:
+    """Restricts the CALLING thread to ``local_cpus(device)`` (intersected with what it may run on). False: left as it was."""
+    cpus = local_cpus(device)
+    if not cpus:
+        return False
+    try:
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return False
+        os.sched_setaffinity(0, allowed)
+        return True
+    except (OSError, AttributeError):
+        return False
+
+
 def device_count() -> int:
     n = ctypes.c_int(0)
     lib().fdb_device_count(ctypes.byref(n))
