@@ -521,3 +521,17 @@ def test_parquet_run_headers_that_overflow_and_empty_dictionaries_are_refused_on
     empty_dict = _parquet_page(2, b"", 0, 0)
     assert code(empty_dict + _parquet_page(0, bytes([0]), n, 8)) == pp.FDB_ERR_INVALID  # bit width 0 into an empty dictionary
     assert code(dict_page + _parquet_page(0, bytes([0]), n, 8)) == pp.FDB_ERR_DEVICE     # bit width 0, index 0 exists
+
+
+def test_gpu_local_cpus_helpers_say_so_when_there_is_no_gpu_to_ask():
+    """physicalplan.local_cpus / pin_thread_near (where chain threads belong on a two-socket host): without a device whose PCI address can be read they
+    return None / False and leave the calling thread's affinity alone."""
+    import os
+    from frostdb_amd import physicalplan as pp
+    before = os.sched_getaffinity(0)
+    cpus = pp.local_cpus(0)
+    assert cpus is None or (isinstance(cpus, set) and cpus and all(isinstance(c, int) for c in cpus))
+    if cpus is None:
+        assert pp.pin_thread_near(0) is False
+        assert os.sched_getaffinity(0) == before
+
