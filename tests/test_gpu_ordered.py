@@ -371,6 +371,63 @@ def test_ordered_sets_with_int64_keys_and_big_dictionaries_are_sorted_by_value(p
     assert len(orows) > 100_000 and orows == sorted(_rows(h), key=key)
 
 
+def test_ordered_sets_with_uint64_keys_beyond_the_sign_bit(pp):
+    """A uint64 group key (the bytes schema's timestamps, logic_test.go:110-146) with values on both sides of 2^63 and NULLs, behind a dictionary
+    column: the sort's value pass must NOT flip the sign bit for it (unsigned order), the order check compares unsigned, NULLs last. Three
+    ordered sets pushed out of order."""
+    rng = np.random.default_rng(51)
+    n = 90_000
+    lab = rng.integers(0, 41, n)  # 40 = NULL
+    ts = rng.integers(1, 1 << 62, n).astype(np.uint64) * np.uint64(4) + np.uint64(1)  # spread over [1, 2^64): never 0 (0 and NULL are one group in the hash table)
+    ts = (ts // np.uint64(1 << 50)) * np.uint64(1 << 50) + np.uint64(1)              # ≈ 16 k distinct values
+    tnull = rng.random(n) < 0.03
+    sets = []
+    for part in np.array_split(rng.permutation(n), 3):
+        o = part[np.lexsort((np.where(tnull[part], np.uint64(0xFFFFFFFFFFFFFFFF), ts[part]), lab[part]))]
+        d = pa.array([b"v%02d" % (39 - i) for i in range(40)], type=pa.binary())
+        sets.append(pa.RecordBatch.from_arrays(
+            [pa.DictionaryArray.from_arrays(pa.array(np.where(lab[o] == 40, 0, 39 - lab[o]).astype(np.uint32), mask=lab[o] == 40), d),
+             pa.array(np.where(tnull[o], np.uint64(0), ts[o]), type=pa.uint64(), mask=tnull[o]), pa.array(rng.integers(1, 100, len(o)).astype(np.int64))],
+            names=["labels.x", "ts", "v"]))
+    groups = [Col("labels.x"), Col("ts")]
+    o, kernel = _run_plan(pp, sets, Sum(Col("v")), groups, ordered=True)
+    assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    assert _run_plan.after_finish == SORTED_FINISH, _run_plan.after_finish
+    h, _ = _run_plan(pp, sets, Sum(Col("v")), groups, ordered=False)
+    key = lambda r: (r[0] is None, r[0] or b"", r[1] is None, r[1] if r[1] is not None else 0)  # noqa: E731
+    orows = _rows(o)
+    assert len(orows) > 40_000 and any(r[1] is not None and r[1] >= 1 << 63 for r in orows) and orows == sorted(_rows(h), key=key)
+
+
+def test_forty_group_columns_out_of_order_are_sorted_through_wide_records(pp):
+    """More group columns than a narrow or medium run record holds (40 > 32): wide records, whose sort keys come out of the records' key
+    tuples word by word; rows not sorted at all, columns that are constant, columns with NULLs, one column that only the second record has."""
+    rng = np.random.default_rng(52)
+    n, n_cols = 60_000, 40
+    g = rng.integers(0, 9_000, n)
+    arrays, names = [], []
+    for c in range(n_cols):
+        k = 1 if c % 7 == 3 else 6
+        x = (g // (1 + c)) % (k + 1) if k > 1 else np.zeros(n, dtype=np.int64)  # k = NULL (never for the constant columns)
+        d = pa.array([b"c%02d-%d" % (c, k - 1 - i) for i in range(k)], type=pa.binary())
+        arrays.append(pa.DictionaryArray.from_arrays(pa.array(np.where(x == k, 0, k - 1 - x).astype(np.uint32), mask=(x == k) if k > 1 else None), d))
+        names.append("labels.l%02d" % c)
+    arrays.append(pa.array(rng.integers(1, 50, n).astype(np.int64))); names.append("v")
+    rec = pa.RecordBatch.from_arrays(arrays, names=names)
+    first = rec.slice(0, 25_000).drop_columns(["labels.l39"])  # (the first record does not know the last column: NULL there)
+    recs = [first, rec.slice(25_000)]
+    groups = [DynCol("labels")]
+    o, kernel = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=True)
+    assert kernel == "fdb_hash_kernel(runs, wide)", kernel
+    assert _run_plan.after_finish == SORTED_FINISH, _run_plan.after_finish
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False)
+    onames = o.schema.names[:-1]
+    hidx = [h.schema.names.index(nm) for nm in onames] + [h.num_columns - 1]
+    hrows = [tuple(r[i] for i in hidx) for r in _rows(h)]
+    orows = _rows(o)
+    assert len(onames) == n_cols and len(orows) > 8_000 and orows == sorted(hrows, key=lambda r: _key_order(r, n_cols))
+
+
 def test_ordered_sets_whose_key_ranks_need_several_sort_passes(pp):
     """Fourteen label columns of 90–130 values (7 bits of rank each: 98 bits, two 64-bit passes) over rows that are NOT sorted at all —
     every row a run of its own, 200 000 runs into ≈ 60 000 groups: the least significant columns must be sorted first and the passes
