@@ -6,7 +6,7 @@ import numpy as np
 import pyarrow as pa
 import pytest
 
-from frostdb_amd.logicalplan import Col, Count, DynCol, Max, Min, Sum
+from frostdb_amd.logicalplan import Col, Count, DynCol, Max, Min, Sum, Unique
 from tests.golden.ordered_cases import ORDERED_CASES
 from tests.ordered_oracle import COUNT, MAX, MIN, SUM, OrderedAggregate
 
@@ -369,6 +369,52 @@ def test_ordered_sets_with_int64_keys_and_big_dictionaries_are_sorted_by_value(p
     key = lambda r: tuple((x is None, x if x is not None else 0) for x in r[:2])  # noqa: E731
     orows = _rows(o)
     assert len(orows) > 100_000 and orows == sorted(_rows(h), key=key)
+
+
+def test_ordered_unique_aggregation_finishes_out_of_the_table_in_key_order(pp):
+    """UNIQUE is a composite reducer (MIN and MAX side by side, NULL where they differ): such a plan never collects runs, its groups sit in
+    the hash table with THREE value arrays (count, min, max), and the ordered Finish sorts them on the device like any other — the value
+    arrays are gathered into key order together. Host Arrow result and resident result (which takes the host route for composites)."""
+    rng = np.random.default_rng(53)
+    recs = _wide_sorted_records(rng, 120_000, 3, cards=(60, 70_000), int_key=None)  # (4 M key combinations: the hash table, not the dense one)
+    # v: constant within most groups (UNIQUE keeps it), different within some (UNIQUE → NULL)
+    fixed = []
+    for r in recs:
+        l0 = r.column(0).indices.to_numpy(zero_copy_only=False)  # (dictionary indices; NaN where the key is NULL)
+        l1 = r.column(1).indices.to_numpy(zero_copy_only=False)
+        base = (np.nan_to_num(l0.astype(np.float64), nan=-1).astype(np.int64) * 100_000 + np.nan_to_num(l1.astype(np.float64), nan=-1).astype(np.int64))
+        v = np.where(base % 5 == 0, rng.integers(0, 3, len(base)), 7) + base
+        fixed.append(pa.RecordBatch.from_arrays([r.column(0), r.column(1), pa.array(v.astype(np.int64))], names=["labels.l0", "labels.l1", "v"]))
+    groups = [Col("labels.l0"), Col("labels.l1")]
+    h, _ = _run_plan(pp, fixed, Unique(Col("v")), groups, ordered=False)
+    want = sorted(_rows(h), key=lambda r: _key_order(r, 2))
+    assert len(want) > 20_000 and any(r[2] is None for r in want) and any(r[2] is not None for r in want)
+    for finish_resident in (False, True):
+        o, kernel = _run_plan(pp, [fixed[1], fixed[0], fixed[2]], Unique(Col("v")), groups, ordered=True, resident=finish_resident, finish_resident=finish_resident)
+        assert kernel in ("fdb_hash_kernel", "scan_hash_kernel"), kernel
+        assert _run_plan.after_finish == TABLE_SORTED_FINISH, _run_plan.after_finish
+        assert _rows(o) == want
+
+
+def test_tiny_ordered_results_through_every_sort(pp, monkeypatch):
+    """Zero, one and two groups through the run store's sort (two runs out of order), the table fallback sorted on the device
+    ($FDB_ORDERED_SORT_MIN=0) and a filter that selects nothing."""
+    d = pa.array([b"b", b"a"], type=pa.binary())
+
+    def rec(ids, vals):
+        return pa.RecordBatch.from_arrays([pa.DictionaryArray.from_arrays(pa.array(np.array(ids, dtype=np.uint32)), d), pa.array(np.array(vals, dtype=np.int64))], names=["labels.k", "v"])
+    groups = [Col("labels.k")]
+    for env in ({}, {"FDB_RUNS_NO_SORT": "1", "FDB_ORDERED_SORT_MIN": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        o, _ = _run_plan(pp, [rec([0, 0], [1, 2]), rec([1, 1], [10, 20])], Sum(Col("v")), groups, ordered=True)  # b, b then a, a: out of order
+        assert _rows(o) == [(b"a", 30), (b"b", 3)]
+        o, _ = _run_plan(pp, [rec([0], [5])], Sum(Col("v")), groups, ordered=True)
+        assert _rows(o) == [(b"b", 5)]
+        o, _ = _run_plan(pp, [rec([0, 1, 0], [1, 2, 4])], Sum(Col("v")), groups, ordered=True, filt=Col("v") > 100)
+        assert o.num_rows == 0
+        o, _ = _run_plan(pp, [rec([0, 1, 0], [1, 2, 4])], Sum(Col("v")), groups, ordered=True)  # b a b: three runs of two groups in one record
+        assert _rows(o) == [(b"a", 2), (b"b", 5)]
 
 
 def test_ordered_sets_with_uint64_keys_beyond_the_sign_bit(pp):
