@@ -197,7 +197,8 @@ typedef struct fdb_plan_desc {
                                       ordered_aggregate.go:449-470, arrowutils/merge.go:84-112); a partial-stage plan names its result
                                       column after the aggregated COLUMN, a final-stage one after the aggregation (:551-557). The
                                       groups and their values are those of the hash aggregate: the reference's ordered sets merge by
-                                      key. */
+                                      key. Input need NOT arrive ordered for the result to be right: records out of key order (several
+                                      ordered sets, none at all) cost a sort of the collected runs on the device at Finish. */
   int32_t _pad2;
 } fdb_plan_desc;
 
