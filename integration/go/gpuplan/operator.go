@@ -71,6 +71,21 @@ func (a *cArena) free() {
 // New flattens the logical expressions into fdb_plan_desc. Op and AggFunc values are passed through unchanged:
 // fdb_op == logicalplan.Op and fdb_agg_func == logicalplan.AggFunc numerically (logicalplan/expr.go:17-35, :718-729).
 func New(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation) (*Operator, error) {
+	return newOperator(device, filter, agg, false)
+}
+
+// NewOrdered is New for the chains of an OrderedAggregate (Build plans one when the scan is ordered by the group columns and there is ONE
+// aggregation, physicalplan.go:433-449, :525-528): the operator emits its record sorted by the group columns and names the result after the
+// aggregated column (ordered_aggregate.go:551-557), so OrderedSynchronizer and the final OrderedAggregate downstream see what they expect.
+// Records need not arrive in key order for the result to be right — out-of-order input costs a device-side sort at Finish.
+func NewOrdered(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation) (*Operator, error) {
+	if len(agg.AggExprs) != 1 {
+		return nil, errors.New("gpuplan: an ordered aggregate takes exactly one aggregation") // ≙ NewOrderedAggregate's signature
+	}
+	return newOperator(device, filter, agg, true)
+}
+
+func newOperator(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation, ordered bool) (*Operator, error) {
 	var mem cArena
 	defer mem.free()
 	var nodes []C.fdb_expr // Go slice while it grows; its strings are C memory already, the array is copied to C below
@@ -108,6 +123,9 @@ func New(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation) (*Op
 	desc := C.fdb_plan_desc{filter: cNodes, n_filter: C.int32_t(len(nodes)), filter_root: root,
 		aggs: cAggs, n_aggs: C.int32_t(len(aggs)), groups: cGroups, n_groups: C.int32_t(len(groups)),
 		regex_match: C.fdbRegexMatchFn()} // `=~` / `!~` keep Go's regexp semantics, see below
+	if ordered {
+		desc.ordered = 1
+	}
 	op := &Operator{}
 	if rc := C.fdb_plan_create(&desc, C.int(device), &op.plan); rc != C.FDB_OK {
 		return nil, errors.New(C.GoString(C.fdb_last_error()))
