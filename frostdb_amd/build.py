@@ -13,8 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfrostdb_amd.so")
 SOURCES = ["fdb_kernels.hip", "fdb_sort.hip", "fdb_arrow.cpp", "fdb_context.cpp", "fdb_plan.cpp", "fdb_hash.cpp", "fdb_jit.cpp", "fdb_dynamic.cpp", "fdb_comm.cpp", "fdb_parquet.cpp", "fdb_widen.cc", "fdb_regex.cpp", "fdb_capi.cpp"]
-HEADERS = ["fdb_kernels.h", "fdb_arrow.h", "fdb_context.h", "fdb_plan.h", "fdb_plan_internal.h", "fdb_jit.h", "fdb_comm.h", "fdb_dynamic.h", "fdb_regex.h", "fdb_hostpool.h", "fdb_unicode_tables.inc", "../../include/frostdb_amd.h", "../../include/arrow_c_data.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-result"]
+HEADERS = ["fdb_kernels.h", "fdb_arrow.h", "fdb_context.h", "fdb_plan.h", "fdb_plan_internal.h", "fdb_jit.h", "fdb_comm.h", "fdb_dynamic.h", "fdb_regex.h", "fdb_hostpool.h", "fdb_unicode_tables.inc", "exports.map", "../../include/frostdb_amd.h", "../../include/arrow_c_data.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-result",
+         "-fvisibility=hidden", "-fvisibility-inlines-hidden"]
 
 
 def _stale() -> bool:
@@ -61,7 +62,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     with open(sig_path, "w") as f:
         f.write(flags_sig)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhiprtc", "-ldl", "-lpthread", "-lz"]
+    # The dynamic symbol surface is include/frostdb_amd.h's FDB_API prototypes and nothing else: hidden visibility keeps the library's own
+    # C++ out, the version script also drops the weak template instantiations libstdc++'s headers force to default visibility.
+    vs = os.path.join(CSRC, "exports.map")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB] + objs + ["-lhiprtc", "-ldl", "-lpthread", "-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -29,6 +29,15 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the prototypes marked FDB_API are its whole dynamic symbol surface
+ * (tests/test_capi_cpu.py compares `nm -D --defined-only` with this header), so a cgo binary that links other C++ sees none of
+ * the library's internals. */
+#if defined(__GNUC__) || defined(__clang__)
+#define FDB_API __attribute__((visibility("default")))
+#else
+#define FDB_API
+#endif
+
 typedef enum fdb_status {
   FDB_OK = 0,
   FDB_ERR_INVALID = 1,      /* malformed descriptor / arguments */
@@ -206,35 +215,35 @@ typedef struct fdb_plan fdb_plan;   /* one operator chain; push is single-thread
 typedef struct fdb_batch fdb_batch; /* an Arrow record resident in HBM (a cached part / row group) */
 
 /* ---- library ---------------------------------------------------------------------------------- */
-const char* fdb_version(void);
+FDB_API const char* fdb_version(void);
 /* Text of the last error raised on the calling thread by a call that had no plan handle. */
-const char* fdb_last_error(void);
-int fdb_device_count(int* n_devices);
+FDB_API const char* fdb_last_error(void);
+FDB_API int fdb_device_count(int* n_devices);
 /* Measurement aid ("the measured ceiling of a plain read kernel on the same box in the same run"): streams
  * `bytes` of HBM through a load-only kernel `reps` times (hipEvent-timed, one launch each) and returns the best rate. */
-int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s);
+FDB_API int fdb_read_ceiling(int device, int64_t bytes, int32_t reps, double* gb_per_s);
 
 /* Host-only self-check of the Arrow C data code every entry point below relies on — what fdb_plan_push reads (column views
  * at any offset, dictionaries with any index width, plain string / binary columns encoded to distinct values + one id per row)
  * and what fdb_plan_finish / fdb_plan_filter write (dictionary, plain string, bool and fixed-width columns): `batch` comes back
  * in `out` with every column's type, values and NULLs unchanged, except that dictionary indices are uint32 and dictionaries with
  * large value types are narrowed. No device is touched, so it runs where there is no GPU. */
-int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out, struct ArrowSchema* out_schema);
+FDB_API int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* schema, struct ArrowArray* out, struct ArrowSchema* out_schema);
 /* The library's built-in regular-expression engine (used for `=~` / `!~` when fdb_plan_desc.regex_match is NULL), exposed for
  * host-only checks: RE2 syntax — what Go's regexp compiles (filter.go:105-124) — matched unanchored on the value's bytes like
  * regexp.Regexp.Match (regexpfilter.go:84-166); linear-time (Thompson / Pike), no backreferences or look-around. *matched = 1 / 0;
  * FDB_ERR_INVALID with Go-style wording ("error parsing regexp: …") when the pattern does not compile. Not covered: Unicode script
  * classes (\p{Greek}); the category and case-folding tables are Unicode 13.0 (Go 1.22: 15.0). */
-int fdb_regex_match(const char* pattern, int64_t pattern_len, const uint8_t* value, int64_t value_len, int32_t* matched);
+FDB_API int fdb_regex_match(const char* pattern, int64_t pattern_len, const uint8_t* value, int64_t value_len, int32_t* matched);
 /* Host-only self-check of the widening step of a big Finish (dictionary indices cross PCIe as uint8 / uint16 / uint32 — `width` 1,
  * 2 or 4 bytes — and are widened to Arrow's uint32 by host threads): dst[i] = src[i] for i < n, through the same routine (AVX2 with
  * streaming stores where the CPU has it). No device is touched. */
-int fdb_selftest_widen(const void* src, int32_t width, uint32_t* dst, int64_t n);
+FDB_API int fdb_selftest_widen(const void* src, int32_t width, uint32_t* dst, int64_t n);
 
 /* ---- plan life cycle (≙ physicalplan.Build for one chain, physicalplan.go:417-474) -------------- */
 /* `desc` and everything it points at (expression nodes, names, literals, patterns) is copied: the caller may free it as soon
  * as the call has returned (the Go shim builds it in C memory and frees that right away, integration/go/gpuplan/operator.go). */
-int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
+FDB_API int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
 /* ≙ PhysicalPlan.Callback: borrows `batch` for the duration of the call only (the reference releases
  * the record right after Callback returns, table.go:808,:827). The record is validated against the plan (errors it
  * would raise are returned by THIS call) and the columns the plan references are copied out before returning. Records
@@ -245,31 +254,31 @@ int fdb_plan_create(const fdb_plan_desc* desc, int device, fdb_plan** out);
  * (filter leaves, AND aggregation), dictionary<any integer index, utf8 / binary / large variants> (filter leaves, group keys),
  * and plain utf8 / binary / large_utf8 / large_binary "u" "z" "U" "Z" (filter leaves, group keys: encoded to key ids on the host
  * during this call, emitted with their input type). Columns the plan does not reference may have any type: they are not read. */
-int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema);
+FDB_API int fdb_plan_push(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema);
 /* `n` Callbacks in one call, in order (≙ a chain handing over the records it has collected: table.go:783-860 calls Callback once
  * per record; a host behind cgo / JNI pays its boundary crossing once per call instead of once per record). Stops at the first
  * record that fails and returns its error; *n_pushed (may be NULL) = records accepted. */
-int fdb_plan_push_many(fdb_plan* plan, struct ArrowArray* const* batches, struct ArrowSchema* const* schemas, int32_t n, int32_t* n_pushed);
+FDB_API int fdb_plan_push_many(fdb_plan* plan, struct ArrowArray* const* batches, struct ArrowSchema* const* schemas, int32_t n, int32_t* n_pushed);
 /* Same, for a record that is already resident in HBM. */
-int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch);
+FDB_API int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch);
 /* Same, for `n` resident records at once (≙ the TableScan handing a chain every part it owns): one fused kernel
  * launch scans all of them, so per-launch costs are paid once per scan instead of once per record. */
-int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n);
+FDB_API int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n);
 /* ≙ PhysicalPlan.Finish: waits for the device, emits ONE record (group columns in first-seen field
  * order with their input Arrow type, then one column per aggregation named "<func>(<column>)")
  * (aggregate.go:543-633). The caller owns `out`/`out_schema` and must call their release().
  * A plan that saw no selected rows emits a zero-row record and sets *n_rows = 0. */
-int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows);
+FDB_API int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows);
 /* ≙ Synchronizer + HashAggregate(final=true) on one device (synchronize.go:31-53): folds the partial
  * table of `src` into `dst` (SUM of sums and counts, MIN of mins, MAX of maxes). `src` stays valid. */
-int fdb_plan_merge(fdb_plan* dst, fdb_plan* src);
+FDB_API int fdb_plan_merge(fdb_plan* dst, fdb_plan* src);
 /* ≙ filter() (filter.go:276-323): the compacted record of the rows that satisfy the plan's filter.
  * *n_selected == 0 ⇒ `out`/`out_schema` are left untouched (the reference skips empty records, filter.go:264-266). */
-int fdb_plan_filter(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema,
+FDB_API int fdb_plan_filter(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema,
                     struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_selected);
 /* Selection vector only: ascending row indices of the rows that satisfy the filter, written to the
  * caller's host buffer `indices` (capacity ≥ batch length). */
-int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema,
+FDB_API int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema* schema,
                     uint32_t* indices, int64_t capacity, int64_t* n_selected);
 /* The same two for a record that is resident in HBM, with results that STAY in HBM (a PredicateFilter whose consumer is another
  * device stage; also what the compaction is measured with — inputs and outputs resident): *out is a new resident
@@ -277,57 +286,57 @@ int fdb_plan_select(fdb_plan* plan, struct ArrowArray* batch, struct ArrowSchema
  * nothing qualifies); `dev_indices` is a DEVICE buffer of `capacity` ≥ fdb_batch_num_rows entries. Three launches: selection
  * bitmap + per-tile counts, their prefix sums, and ONE streaming pass that compacts every column (wave prefix sums, LDS staging,
  * coalesced stores) — rows keep their order, the output is allocated at its exact size. */
-int fdb_plan_filter_batch(fdb_plan* plan, const fdb_batch* batch, fdb_batch** out, int64_t* n_selected);
+FDB_API int fdb_plan_filter_batch(fdb_plan* plan, const fdb_batch* batch, fdb_batch** out, int64_t* n_selected);
 /* ≙ PhysicalPlan.Finish for a consumer that lives on the device (another device stage, the cross-GPU exchange): the result record
  * as a RESIDENT batch — group columns (dictionary<uint32> with the plan's distinct values, int64 / uint64, bool) then one column per
  * aggregation, same names and types as fdb_plan_finish. A big hash table (cfg 5: 10 M groups × 32 label columns) is materialised in
  * HBM by the same two column passes and nothing crosses PCIe but the per-column NULL counts; small tables take the host route and
  * are imported back (microseconds). Release with fdb_batch_release; fdb_batch_export gives the Arrow record on the host.
  * Not for plans with aggregations over a dynamic column set. */
-int fdb_plan_finish_batch(fdb_plan* plan, fdb_batch** out, int64_t* n_rows);
+FDB_API int fdb_plan_finish_batch(fdb_plan* plan, fdb_batch** out, int64_t* n_rows);
 /* filter() over `n` resident records in ONE launch sequence (≙ PredicateFilter.Callback for every record of a scan, filter.go:255-323;
  * what fdb_plan_push_batches is to the aggregate): out[i] / n_selected[i] are record i's compacted record and row count. All or
  * nothing: on an error no output batch is returned. */
-int fdb_plan_filter_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n, fdb_batch** out, int64_t* n_selected);
-int fdb_plan_select_batch(fdb_plan* plan, const fdb_batch* batch, uint32_t* dev_indices, int64_t capacity, int64_t* n_selected);
+FDB_API int fdb_plan_filter_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n, fdb_batch** out, int64_t* n_selected);
+FDB_API int fdb_plan_select_batch(fdb_plan* plan, const fdb_batch* batch, uint32_t* dev_indices, int64_t capacity, int64_t* n_selected);
 /* ≙ PhysicalPlan.Draw: "PredicateFilter (…) - HashAggregate (sum(value) by labels.path)". Owned by the plan. */
-const char* fdb_plan_draw(fdb_plan* plan);
+FDB_API const char* fdb_plan_draw(fdb_plan* plan);
 /* The same string for a descriptor, without creating a plan or touching a device (≙ `explain`: the operator strings of
  * logictest/testdata/plan/{aggregate,filter}/…): validates `desc` like fdb_plan_create, writes at most `capacity` bytes
  * (NUL-terminated) to `buf` and the size needed to `*needed`. */
-int fdb_plan_explain(const fdb_plan_desc* desc, char* buf, int64_t capacity, int64_t* needed);
-const char* fdb_plan_last_error(const fdb_plan* plan);
+FDB_API int fdb_plan_explain(const fdb_plan_desc* desc, char* buf, int64_t capacity, int64_t* needed);
+FDB_API const char* fdb_plan_last_error(const fdb_plan* plan);
 /* ≙ PhysicalPlan.Close: frees every host and device buffer of the plan. NULL is a no-op. */
-void fdb_plan_close(fdb_plan* plan);
+FDB_API void fdb_plan_close(fdb_plan* plan);
 
 /* ---- cross-process merge support (the RCCL reduce of per-GPU partial tables) ------- */
 /* Number of groups currently in the plan's partial table (waits for the device). */
-int fdb_plan_num_groups(fdb_plan* plan, int64_t* n_groups);
+FDB_API int fdb_plan_num_groups(fdb_plan* plan, int64_t* n_groups);
 /* The group-key columns only, one row per table slot, in slot order (same types as fdb_plan_finish). */
-int fdb_plan_partial_keys(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema);
+FDB_API int fdb_plan_partial_keys(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema);
 /* Copies the partial accumulator of aggregation `agg` (n_groups × 8 bytes, slot order; int64 or
  * float64 per fdb_plan_agg_type) to `dst`, a host or device pointer (hipMemcpyDefault). */
-int fdb_plan_partial_state(fdb_plan* plan, int32_t agg, void* dst, int64_t capacity_bytes);
+FDB_API int fdb_plan_partial_state(fdb_plan* plan, int32_t agg, void* dst, int64_t capacity_bytes);
 /* Fast path of the cross-GPU merge: when every rank's table has the SAME slot layout (same group columns, same key
  * dictionaries in the same order — the usual case for parts of one table), slot i means the same group everywhere
  * and the raw table arrays can be all-reduced in place, with no key exchange. `signature` hashes the layout
  * (group column names, key values in id order, radix strides, aggregations); equal signatures ⇔ equal layouts. */
-int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slots);
+FDB_API int fdb_plan_state_signature(fdb_plan* plan, uint64_t* signature, int64_t* n_slots);
 /* Raw table array `array` (0: selected-row counts; 1 + j: accumulator of aggregation j) ⇄ `dst`/`src`, a DEVICE
  * pointer of n_slots × 8 bytes. int64 everywhere except float64 SUM; float64 MIN/MAX are stored as order-preserving
  * int64 keys, so integer MIN/MAX reductions are exact for them too. Both calls wait for the plan's stream. */
 /* Zero-copy variant: the device address of array 0, the distance between consecutive arrays (in 8-byte elements) and
  * the slot count, so that a collective library can reduce the arrays IN PLACE on the plan's stream (fdb_plan_stream);
  * nothing is synchronised. Dense tables only (n_slots = 0 otherwise). */
-int fdb_plan_state_pointers(fdb_plan* plan, void** base, int64_t* array_stride, int64_t* n_slots);
-int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes);
-int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t bytes);
+FDB_API int fdb_plan_state_pointers(fdb_plan* plan, void** base, int64_t* array_stride, int64_t* n_slots);
+FDB_API int fdb_plan_state_read(fdb_plan* plan, int32_t array, void* dst, int64_t capacity_bytes);
+FDB_API int fdb_plan_state_write(fdb_plan* plan, int32_t array, const void* src, int64_t bytes);
 /* How table array `array` merges across plans / ranks (0 = the row counts, 1 + j = PHYSICAL accumulator j — UNIQUE owns two,
  * see DESIGN.md §3): 0 unused, 1 integer sum, 2 float64 sum, 3 integer min, 4 integer max. *n_arrays = 1 + accumulators. */
-int fdb_plan_state_arrays(fdb_plan* plan, int32_t* n_arrays);
-int fdb_plan_state_array_op(fdb_plan* plan, int32_t array, int32_t* op);
+FDB_API int fdb_plan_state_arrays(fdb_plan* plan, int32_t* n_arrays);
+FDB_API int fdb_plan_state_array_op(fdb_plan* plan, int32_t array, int32_t* op);
 /* 'l' (int64) or 'g' (float64): the Arrow format of aggregation `agg`'s output column; 0 until the first push. */
-int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out);
+FDB_API int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out);
 
 /* ---- high-cardinality merge: hash-partitioned exchange of partial hash tables ("G large") -------------
  * ≙ Synchronizer + HashAggregate(final=true) (synchronize.go:31-53, aggregate.go:340-348) when the partial tables hold
@@ -342,12 +351,12 @@ int fdb_plan_agg_type(fdb_plan* plan, int32_t agg, char* format_out);
  *   3. after the exchange, fdb_plan_hash_import(seeded plan, rows, n) merges the received rows (SUM/COUNT add, MIN, MAX);
  *   4. fdb_plan_finish on the seeded plan emits this rank's shard of the final groups.
  * The same two calls with n_parts = 1 are the device-only path of fdb_plan_merge between two plans of one GPU. */
-int fdb_plan_group_schema(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema);
-int fdb_plan_seed_groups(fdb_plan* plan, struct ArrowArray* schema_record, struct ArrowSchema* schema);
+FDB_API int fdb_plan_group_schema(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema);
+FDB_API int fdb_plan_seed_groups(fdb_plan* plan, struct ArrowArray* schema_record, struct ArrowSchema* schema);
 /* *dev_rows: DEVICE pointer owned by `src` until its next push or close (NULL if the table is empty). */
-int fdb_plan_hash_export(fdb_plan* src, fdb_plan* layout, int32_t n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32);
+FDB_API int fdb_plan_hash_export(fdb_plan* src, fdb_plan* layout, int32_t n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32);
 /* dev_rows: DEVICE pointer to n_rows rows packed for `plan`'s layout; may be released when the call returns. */
-int fdb_plan_hash_import(fdb_plan* plan, const void* dev_rows, int64_t n_rows);
+FDB_API int fdb_plan_hash_import(fdb_plan* plan, const void* dev_rows, int64_t n_rows);
 
 /* ---- cross-GPU merge behind the C ABI: RCCL over xGMI, no Python in the loop -------------------------------
  * ≙ Synchronizer + HashAggregate(final=true) (synchronize.go:31-53, physicalplan.go:438-471) when the N chains of a query run
@@ -364,17 +373,17 @@ int fdb_plan_hash_import(fdb_plan* plan, const void* dev_rows, int64_t n_rows);
  * without RCCL can still load this library; fdb_comm_unique_id / _init_rank / _init_all then fail with FDB_ERR_UNSUPPORTED. */
 typedef struct fdb_comm fdb_comm;
 #define FDB_COMM_ID_BYTES 128
-int fdb_comm_unique_id(uint8_t id[FDB_COMM_ID_BYTES]);
-int fdb_comm_init_rank(const uint8_t id[FDB_COMM_ID_BYTES], int32_t n_ranks, int32_t rank, int device, fdb_comm** out);
-int fdb_comm_init_all(const int* devices, int32_t n, fdb_comm** out /* [n] */);
-int fdb_comm_init_local(const int* devices, int32_t n, fdb_comm** out /* [n] */);
-int32_t fdb_comm_rank(const fdb_comm* comm);
-int32_t fdb_comm_size(const fdb_comm* comm);
+FDB_API int fdb_comm_unique_id(uint8_t id[FDB_COMM_ID_BYTES]);
+FDB_API int fdb_comm_init_rank(const uint8_t id[FDB_COMM_ID_BYTES], int32_t n_ranks, int32_t rank, int device, fdb_comm** out);
+FDB_API int fdb_comm_init_all(const int* devices, int32_t n, fdb_comm** out /* [n] */);
+FDB_API int fdb_comm_init_local(const int* devices, int32_t n, fdb_comm** out /* [n] */);
+FDB_API int32_t fdb_comm_rank(const fdb_comm* comm);
+FDB_API int32_t fdb_comm_size(const fdb_comm* comm);
 /* The size the TRANSPORT itself reports for this communicator (RCCL: ncclCommCount) — evidence that an N-GPU merge really ran
  * over N ranks; -1 if the bound library has no such entry point. */
-int32_t fdb_comm_transport_ranks(fdb_comm* comm);
-const char* fdb_comm_last_error(const fdb_comm* comm);
-void fdb_comm_destroy(fdb_comm* comm);
+FDB_API int32_t fdb_comm_transport_ranks(fdb_comm* comm);
+FDB_API const char* fdb_comm_last_error(const fdb_comm* comm);
+FDB_API void fdb_comm_destroy(fdb_comm* comm);
 /* Low-cardinality merge (cfgs 2-4): when every rank's dense table has the same slot layout (fdb_plan_state_signature — parts of
  * one table share their dictionaries), slot i means the same group everywhere and the tables are merged on the plan's own
  * stream. Small tables (≤ 32 MiB over all ranks: every configuration of the benchmark's low-cardinality queries): the packed
@@ -385,28 +394,28 @@ void fdb_comm_destroy(fdb_comm* comm);
  * stream, so it overlaps the scan kernel. *aligned = 1: every rank now holds the
  * merged table (call fdb_plan_finish on the rank that emits; the others just close). *aligned = 0: layouts differ (or the plan
  * is in hash mode) — nothing was changed, use fdb_plan_exchange. Collective: every rank of `comm` must call it. */
-int fdb_plan_allreduce(fdb_plan* plan, fdb_comm* comm, int32_t* aligned);
+FDB_API int fdb_plan_allreduce(fdb_plan* plan, fdb_comm* comm, int32_t* aligned);
 /* General merge (any table mode, any key sets; cfg 5): ranks agree on one group schema (all-gather of column names + distinct key
  * values, union in rank order), every table is re-keyed and hash-partitioned on the device (fdb_plan_hash_export), partitions
  * travel point-to-point to their owners (grouped send / recv: all 7 xGMI links of a GPU busy at once; slices of ≤ 128 MiB per
  * peer), owners merge on the device. The result STAYS SHARDED: *shard is a new plan of the same descriptor holding this rank's
  * share of the final groups (fingerprint % n_ranks == rank) — fdb_plan_finish + fdb_plan_close it. Collective. */
-int fdb_plan_exchange(fdb_plan* plan, fdb_comm* comm, fdb_plan** shard);
+FDB_API int fdb_plan_exchange(fdb_plan* plan, fdb_comm* comm, fdb_plan** shard);
 
 /* Device memory owned by the library right now (≙ the reference's leak-checked allocator, memory.CheckedAllocator.AssertSize(0),
  * logictest/logic_test.go:169-177): blocks handed out by the per-device caching allocator and not yet returned, plus the arenas
  * of live resident batches; `pinned` counts result blocks whose Arrow release callback has not run. Cached-but-idle blocks are
  * not counted. All three are 0 once every plan, batch, communicator and result record has been closed / released. */
-int fdb_live_allocations(int64_t* device_blocks, int64_t* device_bytes, int64_t* pinned_blocks);
+FDB_API int fdb_live_allocations(int64_t* device_blocks, int64_t* device_bytes, int64_t* pinned_blocks);
 
 /* ---- resident batches (a part kept in HBM between queries; 288 GB per GPU) ---------------------- */
-int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int device, fdb_batch** out);
-int64_t fdb_batch_num_rows(const fdb_batch* batch);
+FDB_API int fdb_batch_import(struct ArrowArray* batch, struct ArrowSchema* schema, int device, fdb_batch** out);
+FDB_API int64_t fdb_batch_num_rows(const fdb_batch* batch);
 /* Bytes this batch occupies in HBM (values/indices + validity bitmaps; dictionaries stay on the host). */
-int64_t fdb_batch_device_bytes(const fdb_batch* batch);
-void fdb_batch_release(fdb_batch* batch);
+FDB_API int64_t fdb_batch_device_bytes(const fdb_batch* batch);
+FDB_API void fdb_batch_release(fdb_batch* batch);
 /* The record of a resident batch as Arrow in host memory (the caller owns `out` / `out_schema` and calls their release()). */
-int fdb_batch_export(const fdb_batch* batch, struct ArrowArray* out, struct ArrowSchema* out_schema);
+FDB_API int fdb_batch_export(const fdb_batch* batch, struct ArrowArray* out, struct ArrowSchema* out_schema);
 
 /* ---- Parquet column chunks decoded on the device ------------------------------------------------------------
  * ≙ pqarrow/arrow.go:711-823 (writeColumnToArray) + pqarrow/writer/writer.go:391-405: instead of decoding a row group into an
@@ -433,7 +442,7 @@ typedef struct fdb_parquet_chunk {
   const uint8_t* data;     /* [dictionary page] data pages …, each preceded by its thrift PageHeader, exactly as in the file */
   int64_t n_bytes;         /* ColumnMetaData.total_compressed_size */
 } fdb_parquet_chunk;
-int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device, fdb_batch** out);
+FDB_API int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device, fdb_batch** out);
 /* Snappy pages inflated on the device (one wave per page, fdb_kernels.h snappy_decode_kernel) — the building block for pages that cross
  * PCIe compressed (pqarrow/arrow.go:711-823 inflates them on the host; so does fdb_batch_from_parquet today). This entry
  * point takes HOST buffers, for tests and measurement: `src` holds the compressed pages (pages[i] = {src_off, dst_off, src_len,
@@ -443,34 +452,34 @@ int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, in
  * format allows it, no compressor emits it: matches stay inside a 64 KiB fragment) (a page that fails leaves its part of `dst`
  * undefined; the others are unaffected). *kernel_ms (may be NULL): device time of the launch. */
 typedef struct fdb_snappy_page { uint64_t src_off; uint64_t dst_off; uint32_t src_len; uint32_t dst_len; } fdb_snappy_page;
-int fdb_snappy_decode_pages(const uint8_t* src, int64_t src_bytes, const fdb_snappy_page* pages, int32_t n_pages, uint8_t* dst, int64_t dst_bytes,
+FDB_API int fdb_snappy_decode_pages(const uint8_t* src, int64_t src_bytes, const fdb_snappy_page* pages, int32_t n_pages, uint8_t* dst, int64_t dst_bytes,
                             int device, uint32_t* status, double* kernel_ms);
 
 /* ---- measurement hooks (bench.py / rocprof correlation; not needed by the Go shim) -------------- */
 /* Algorithmic bytes (values-or-indices + validity of every referenced column, once per
  * row) and accumulated device time in ms (hipEvent pairs on the plan's stream around each scan
  * kernel) since the plan was created; `n_launches` scan-kernel launches. */
-int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms, int64_t* n_launches,
+FDB_API int fdb_plan_stats(fdb_plan* plan, int64_t* algorithmic_bytes, double* kernel_ms, int64_t* n_launches,
                    int64_t* rows_scanned);
 /* fdb_batch_from_parquet, accumulated over the process: calls, wall time of the host part (page-header walk, inflating compressed
  * pages, dictionary pages) and of the device part (copies, pq_* kernels, the waits), bytes of column chunks read and of columns
  * produced. */
-int fdb_parquet_stats(int64_t* calls, double* host_ms, double* device_ms, int64_t* file_bytes, int64_t* out_bytes);
+FDB_API int fdb_parquet_stats(int64_t* calls, double* host_ms, double* device_ms, int64_t* file_bytes, int64_t* out_bytes);
 /* Run-time specialisation (hiprtc): kernels this process compiled, the wall time the compiler took (ms), and code objects it
  * loaded from the on-disk cache ($FDB_JIT_CACHE) instead — what the FIRST query of a shape pays on top of its scan. */
-int fdb_jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads);
+FDB_API int fdb_jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads);
 /* Accumulated device time in ms of the cross-GPU merges this plan took part in (hipEvent pairs on the plan's stream around the
  * collectives of fdb_plan_allreduce / the all-to-all of fdb_plan_exchange); 0 unless timing is enabled. Read it after
  * fdb_plan_finish (or anything else that waits for the plan's stream). */
-int fdb_plan_merge_ms(fdb_plan* plan, double* merge_ms);
+FDB_API int fdb_plan_merge_ms(fdb_plan* plan, double* merge_ms);
 /* Enables/disables the per-launch hipEvent timing above (off by default; costs two events per launch). */
-int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled);
+FDB_API int fdb_plan_set_timing(fdb_plan* plan, int32_t enabled);
 /* The hipStream_t the plan launches on, as an opaque pointer. */
-int fdb_plan_stream(fdb_plan* plan, void** stream_out);
+FDB_API int fdb_plan_stream(fdb_plan* plan, void** stream_out);
 /* Kernel geometry knobs for bench.py's variant sweeps: rows_per_thread 0 = load-hoisting slot kernel (default),
  * 4 / 8 = sequential kernel with that many rows per lane; grid_blocks bits 0-19 = persistent grid size (0 = default),
  * bits 25-27 = variant (1/2/3: 512/256/1024-thread workgroups, 4: interpreting kernels only, no run-time specialisation). */
-int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_blocks);
+FDB_API int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_blocks);
 /* Reproducible float sums. float64 addition is not associative and the default scan accumulates a workgroup's rows with LDS atomics
  * whose interleaving across waves differs from run to run: SUM(float64) (and AVG, which is lowered to it) agrees with the reference
  * to ~1e-12 relative but not bit for bit between two runs. With `enabled` every wave accumulates into an LDS table of its own, the
@@ -483,11 +492,11 @@ int fdb_plan_set_tuning(fdb_plan* plan, int32_t rows_per_thread, int32_t grid_bl
  * Across GPUs: fdb_plan_allreduce's merge of small tables folds in rank order (reproducible, see there); the in-place all-reduce
  * of big dense tables and the exchange of hash tables are not covered. An ordered plan (fdb_plan_desc.ordered) with this flag does
  * not collect runs (their Finish folds cut groups with atomics): it keeps the dense kernel. */
-int fdb_plan_set_deterministic(fdb_plan* plan, int32_t enabled);
+FDB_API int fdb_plan_set_deterministic(fdb_plan* plan, int32_t enabled);
 /* Name of the scan kernel the latest push launched ("fdb_plan_kernel" = the run-time specialised kernel,
  * "scan_slots_kernel" / "scan_dense_kernel" = the interpreting kernels, "scan_hash_kernel" = the hash-table path);
  * "" before the first push. The string is static. */
-const char* fdb_plan_last_kernel(fdb_plan* plan);
+FDB_API const char* fdb_plan_last_kernel(fdb_plan* plan);
 
 #ifdef __cplusplus
 }

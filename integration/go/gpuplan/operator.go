@@ -2,8 +2,35 @@
 // chain's PredicateFilter + HashAggregate(final=false) (query/physicalplan/physicalplan.go:417-474).
 //
 // This file lives at query/physicalplan/gpuplan/operator.go in a FrostDB checkout. It is real source, not pseudo-code, but this
-// repository's build image has no Go toolchain, so it has never been compiled here; it is written against arrow-go v18's
-// arrow/cdata and the header in ../../../include. See INTEGRATION.md for the option in physicalplan.Build that installs it.
+// repository's build image has no Go toolchain, so it has never been compiled here; what CAN be checked without a compiler is checked
+// by tests/test_go_shim_cpu.py (every C.fdb_* identifier and struct field against the header, the import graph, balanced syntax).
+//
+// Import graph (no cycle): gpuplan imports physicalplan and logicalplan; physicalplan never learns about gpuplan — Build consults an
+// OperatorFactory option (integration/go/patches/physicalplan_operator_factory.diff) and the USER passes gpuplan.Factory(device):
+//
+//	engine := query.NewEngine(pool, provider,
+//		query.WithPhysicalplanOptions(physicalplan.WithOperatorFactory(gpuplan.Factory(0))))
+//
+// Every identifier of the reference this file touches:
+//
+//	physicalplan.PhysicalPlan {Callback, Finish, SetNext, Draw, Close}   query/physicalplan/physicalplan.go:24-30
+//	physicalplan.Diagram {Details, Child}                                query/physicalplan/physicalplan.go:558-561
+//	physicalplan.ErrUnsupportedBooleanExpression                         query/physicalplan/filter.go:46
+//	physicalplan.FusedStage, OperatorFactory, ErrOperatorNotFused,
+//	  WithOperatorFactory                                                (new: the patch above, next to execOptions :260-285)
+//	logicalplan.Expr {Name()}                                            query/logicalplan/builder.go:69-101
+//	logicalplan.BinaryExpr {Left, Op, Right}                             query/logicalplan/expr.go:105-109
+//	logicalplan.Op, OpAnd, OpOr, OpAdd, OpSub, OpMul, OpDiv              query/logicalplan/expr.go:13-35
+//	logicalplan.Column {ColumnName}                                      query/logicalplan/expr.go:292-294
+//	logicalplan.DynamicColumn {ColumnName}                               query/logicalplan/expr.go:518-520
+//	logicalplan.LiteralExpr {Value scalar.Scalar}                        query/logicalplan/expr.go:586-588
+//	logicalplan.AggregationFunction {Func AggFunc, Expr}                 query/logicalplan/expr.go:648-651
+//	logicalplan.AliasExpr {Expr, Alias}                                  query/logicalplan/expr.go:1000-1003
+//	logicalplan.Aggregation {AggExprs, GroupExprs}                       query/logicalplan/logicalplan.go:409-412
+//	arrow.Record; array.Concatenate, array.NewRecord; memory.Allocator;
+//	  scalar.{Int64, Int32, Uint64, Float64, Boolean, String, Binary};
+//	  cdata.{CArrowArray, CArrowSchema, ExportArrowRecordBatch, ImportCRecordBatch,
+//	  ReleaseCArrowArray, ReleaseCArrowSchema}                           github.com/apache/arrow-go/v18 v18.2.0 (go.mod:7)
 package gpuplan
 
 /*
@@ -29,17 +56,73 @@ import (
 	"unsafe"
 
 	"github.com/apache/arrow-go/v18/arrow"
+	"github.com/apache/arrow-go/v18/arrow/array"
 	"github.com/apache/arrow-go/v18/arrow/cdata"
+	"github.com/apache/arrow-go/v18/arrow/memory"
 	"github.com/apache/arrow-go/v18/arrow/scalar"
 
 	"github.com/polarsignals/frostdb/query/logicalplan"
 	"github.com/polarsignals/frostdb/query/physicalplan"
 )
 
+// FactoryOption tunes what Factory's operators do around the C ABI.
+type FactoryOption func(*factoryConfig)
+
+type factoryConfig struct {
+	device         int
+	accountResults bool
+	deterministic  bool
+}
+
+// AccountResults makes every emitted record a copy built from the engine's memory.Allocator (FusedStage.Pool), so that
+// memory.CheckedAllocator sees the operator's output like the Go operators' (logictest/logic_test.go:169-177). Without it the record's
+// buffers stay the library's (pinned host memory released through the Arrow release callback): zero-copy, invisible to the allocator.
+func AccountResults() FactoryOption { return func(c *factoryConfig) { c.accountResults = true } }
+
+// Deterministic asks every operator for float64 sums that are bit-identical from run to run (fdb_plan_set_deterministic).
+func Deterministic() FactoryOption { return func(c *factoryConfig) { c.deterministic = true } }
+
+// Factory is what the user hands to physicalplan.WithOperatorFactory: Build calls the returned func once per chain for every
+// [Filter] [Projection] Aggregation|Distinct stage. A stage this library does not cover is declined with ErrOperatorNotFused and Build
+// plans the Go operators for it, so installing the factory never makes a query fail that worked before.
+func Factory(device int, opts ...FactoryOption) physicalplan.OperatorFactory {
+	cfg := factoryConfig{device: device}
+	for _, o := range opts {
+		o(&cfg)
+	}
+	return func(st physicalplan.FusedStage) (physicalplan.PhysicalPlan, error) {
+		if st.Final && st.Aggregation != nil {
+			// A single chain's lone HashAggregate is a FINAL stage reading raw rows (COUNT sums its input there, aggregate.go:965-969);
+			// the reference never runs that way in practice (concurrencyHardcoded = GOMAXPROCS, physicalplan.go:22). Keep the Go operator.
+			return nil, fmt.Errorf("gpuplan: single-chain plan: %w", physicalplan.ErrOperatorNotFused)
+		}
+		agg := st.Aggregation
+		if agg == nil { // Filter → Distinction (distinct.go:21-170): group matchers without aggregations
+			agg = &logicalplan.Aggregation{GroupExprs: st.Distinct}
+		}
+		if st.Ordered && len(agg.AggExprs) != 1 {
+			return nil, fmt.Errorf("gpuplan: ordered aggregate with %d aggregations: %w", len(agg.AggExprs), physicalplan.ErrOperatorNotFused)
+		}
+		op, err := newOperator(cfg.device, st.Filter, st.Projections, agg, st.Ordered)
+		if err != nil {
+			// Whatever the library refuses (an expression shape, a type) the Go operators may still take: decline, keep the reason.
+			return nil, fmt.Errorf("gpuplan: %v: %w", err, physicalplan.ErrOperatorNotFused)
+		}
+		if cfg.accountResults {
+			op.pool = st.Pool
+		}
+		if cfg.deterministic {
+			op.SetDeterministic(true)
+		}
+		return op, nil
+	}
+}
+
 // Operator implements physicalplan.PhysicalPlan (physicalplan.go:24-30) for one chain.
 type Operator struct {
 	plan *C.fdb_plan
 	next physicalplan.PhysicalPlan
+	pool memory.Allocator // non-nil: emitted records are copied into it (AccountResults)
 }
 
 // cArena owns the C memory a descriptor is built from. The descriptor's arrays hold pointers (column names, literals), and cgo
@@ -71,7 +154,7 @@ func (a *cArena) free() {
 // New flattens the logical expressions into fdb_plan_desc. Op and AggFunc values are passed through unchanged:
 // fdb_op == logicalplan.Op and fdb_agg_func == logicalplan.AggFunc numerically (logicalplan/expr.go:17-35, :718-729).
 func New(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation) (*Operator, error) {
-	return newOperator(device, filter, agg, false)
+	return newOperator(device, filter, nil, agg, false)
 }
 
 // NewOrdered is New for the chains of an OrderedAggregate (Build plans one when the scan is ordered by the group columns and there is ONE
@@ -82,10 +165,10 @@ func NewOrdered(device int, filter logicalplan.Expr, agg *logicalplan.Aggregatio
 	if len(agg.AggExprs) != 1 {
 		return nil, errors.New("gpuplan: an ordered aggregate takes exactly one aggregation") // ≙ NewOrderedAggregate's signature
 	}
-	return newOperator(device, filter, agg, true)
+	return newOperator(device, filter, nil, agg, true)
 }
 
-func newOperator(device int, filter logicalplan.Expr, agg *logicalplan.Aggregation, ordered bool) (*Operator, error) {
+func newOperator(device int, filter logicalplan.Expr, projections []logicalplan.Expr, agg *logicalplan.Aggregation, ordered bool) (*Operator, error) {
 	var mem cArena
 	defer mem.free()
 	var nodes []C.fdb_expr // Go slice while it grows; its strings are C memory already, the array is copied to C below
@@ -119,9 +202,35 @@ func newOperator(device int, filter logicalplan.Expr, agg *logicalplan.Aggregati
 			groups[i].dynamic = 1
 		}
 	}
+	// The computed part of the Projection between filter and aggregate (project.go:73-399): arithmetic over columns and literals is
+	// evaluated inside the scan kernel under the name the aggregate looks up; plain columns need nothing (only referenced columns are read).
+	var projs []C.fdb_projection
+	for _, e := range projections {
+		switch e.(type) {
+		case *logicalplan.Column, *logicalplan.DynamicColumn:
+			continue
+		}
+		var pn []C.fdb_proj_node
+		inner := e
+		if al, ok := e.(*logicalplan.AliasExpr); ok {
+			inner = al.Expr
+		}
+		r, err := flattenProjection(inner, &pn, &mem)
+		if err != nil {
+			return nil, err
+		}
+		cpn := (*C.fdb_proj_node)(mem.alloc(len(pn), unsafe.Sizeof(C.fdb_proj_node{})))
+		copy(unsafe.Slice(cpn, len(pn)), pn)
+		projs = append(projs, C.fdb_projection{name: mem.str(e.Name()), nodes: cpn, n_nodes: C.int32_t(len(pn)), root: C.int32_t(r)})
+	}
+	cProjs := (*C.fdb_projection)(mem.alloc(len(projs), unsafe.Sizeof(C.fdb_projection{})))
+	if len(projs) > 0 {
+		copy(unsafe.Slice(cProjs, len(projs)), projs)
+	}
 	// (desc itself is a Go value on this stack holding only C pointers: legal to pass by address)
 	desc := C.fdb_plan_desc{filter: cNodes, n_filter: C.int32_t(len(nodes)), filter_root: root,
 		aggs: cAggs, n_aggs: C.int32_t(len(aggs)), groups: cGroups, n_groups: C.int32_t(len(groups)),
+		projections: cProjs, n_projections: C.int32_t(len(projs)),
 		regex_match: C.fdbRegexMatchFn()} // `=~` / `!~` keep Go's regexp semantics, see below
 	if ordered {
 		desc.ordered = 1
@@ -209,7 +318,10 @@ func setLiteral(dst *C.fdb_literal, v scalar.Scalar, mem *cArena) error {
 
 // Callback ≙ PredicateFilter.Callback + HashAggregate.Callback. The record is only borrowed (table.go:808,:827):
 // fdb_plan_push stages what it needs before returning.
-func (o *Operator) Callback(_ context.Context, r arrow.Record) error {
+func (o *Operator) Callback(ctx context.Context, r arrow.Record) error {
+	if err := ctx.Err(); err != nil { // table.go:761-770 cancels a scan through its context: no crossing for a cancelled query
+		return err
+	}
 	var arr cdata.CArrowArray
 	var sch cdata.CArrowSchema
 	cdata.ExportArrowRecordBatch(r, &arr, &sch)
@@ -225,9 +337,12 @@ func (o *Operator) Callback(_ context.Context, r arrow.Record) error {
 // scheduler work plus the pinning of its arguments, which is comparable with what the library itself spends on a 1 024-row record
 // (≈ 10 µs) only when records are tiny — but a scan that hands over a row group's records at once (table.go:783-860 collects them per
 // granule) can batch them. On error `pushed` records were accepted; the error belongs to record `pushed`.
-func (o *Operator) CallbackMany(_ context.Context, rs []arrow.Record) (pushed int, err error) {
+func (o *Operator) CallbackMany(ctx context.Context, rs []arrow.Record) (pushed int, err error) {
 	if len(rs) == 0 {
 		return 0, nil
+	}
+	if err := ctx.Err(); err != nil {
+		return 0, err
 	}
 	// The ArrowArray / ArrowSchema structs AND the pointer tables live in C memory (C.calloc): cgo forbids storing Go pointers in C
 	// memory, and its argument check does not look inside C allocations — structs in a Go slice whose addresses sit in a C array happen to
@@ -271,6 +386,9 @@ func (o *Operator) SetDeterministic(on bool) {
 
 // Finish ≙ HashAggregate.Finish: emit the partial record downstream, then propagate Finish (aggregate.go:527-541).
 func (o *Operator) Finish(ctx context.Context) error {
+	if err := ctx.Err(); err != nil {
+		return err
+	}
 	var arr cdata.CArrowArray
 	var sch cdata.CArrowSchema
 	var n C.int64_t
@@ -283,17 +401,48 @@ func (o *Operator) Finish(ctx context.Context) error {
 	}
 	defer rec.Release()
 	if n > 0 { // finishAggregate skips empty aggregates (aggregate.go:547-549)
-		if err := o.next.Callback(ctx, rec); err != nil {
+		out := rec
+		if o.pool != nil {
+			if out, err = copyToPool(rec, o.pool); err != nil {
+				return err
+			}
+			defer out.Release()
+		}
+		if err := ctx.Err(); err != nil {
+			return err
+		}
+		if err := o.next.Callback(ctx, out); err != nil {
 			return err
 		}
 	}
 	return o.next.Finish(ctx)
 }
 
+// copyToPool rebuilds a record from the engine's allocator: array.Concatenate of ONE array allocates its buffers from `pool` and copies
+// (the call filter() itself makes per column, filter.go:314), dictionaries included.
+func copyToPool(rec arrow.Record, pool memory.Allocator) (arrow.Record, error) {
+	cols := make([]arrow.Array, 0, int(rec.NumCols()))
+	defer func() {
+		for _, c := range cols {
+			c.Release()
+		}
+	}()
+	for i := 0; i < int(rec.NumCols()); i++ {
+		c, err := array.Concatenate([]arrow.Array{rec.Column(i)}, pool)
+		if err != nil {
+			return nil, err
+		}
+		cols = append(cols, c)
+	}
+	return array.NewRecord(rec.Schema(), cols, rec.NumRows()), nil // NewRecord retains the columns
+}
+
 func (o *Operator) SetNext(next physicalplan.PhysicalPlan) { o.next = next }
 func (o *Operator) Draw() *physicalplan.Diagram {
 	var child *physicalplan.Diagram
-	if o.next != nil { child = o.next.Draw() }
+	if o.next != nil {
+		child = o.next.Draw()
+	}
 	return &physicalplan.Diagram{Details: C.GoString(C.fdb_plan_draw(o.plan)), Child: child}
 }
 func (o *Operator) Close() {
@@ -342,6 +491,42 @@ func flatten(e logicalplan.Expr, out *[]C.fdb_expr, mem *cArena) (int, error) {
 	return len(*out) - 1, nil
 }
 
+// flattenProjection turns arithmetic over columns and literals (binaryExprProjection, project.go:73-161) into the post-order
+// fdb_proj_node array: kind 0 column, 1 literal (INT64 / FLOAT64), 2 binary + - * /. Anything else declines the stage.
+func flattenProjection(e logicalplan.Expr, out *[]C.fdb_proj_node, mem *cArena) (int, error) {
+	switch x := e.(type) {
+	case *logicalplan.Column:
+		*out = append(*out, C.fdb_proj_node{kind: 0, left: -1, right: -1, column: mem.str(x.ColumnName)})
+	case *logicalplan.LiteralExpr:
+		n := C.fdb_proj_node{kind: 1, left: -1, right: -1}
+		if err := setLiteral(&n.literal, x.Value, mem); err != nil {
+			return -1, err
+		}
+		if n.literal._type != C.FDB_LIT_INT64 && n.literal._type != C.FDB_LIT_FLOAT64 {
+			return -1, fmt.Errorf("gpuplan: projection literal %s is not int64 / float64", x.Value)
+		}
+		*out = append(*out, n)
+	case *logicalplan.BinaryExpr:
+		switch x.Op {
+		case logicalplan.OpAdd, logicalplan.OpSub, logicalplan.OpMul, logicalplan.OpDiv:
+		default:
+			return -1, fmt.Errorf("gpuplan: projection operator %s is not fused", x.Op.String())
+		}
+		l, err := flattenProjection(x.Left, out, mem)
+		if err != nil {
+			return -1, err
+		}
+		r, err := flattenProjection(x.Right, out, mem)
+		if err != nil {
+			return -1, err
+		}
+		*out = append(*out, C.fdb_proj_node{kind: 2, op: C.int32_t(x.Op), left: C.int32_t(l), right: C.int32_t(r)})
+	default:
+		return -1, fmt.Errorf("gpuplan: projection %s is not fused", e.String())
+	}
+	return len(*out) - 1, nil
+}
+
 // ---- more than one GPU in this process (the reference's N chains live in ONE process, physicalplan.go:22, :337-347) ------------
 
 // Comms is one RCCL communicator over the node's GPUs: ncclCommInitAll behind fdb_comm_init_all; comms[d] belongs to device d.
@@ -364,6 +549,8 @@ func NewComms(devices []int) (Comms, error) {
 // all-reduced in place over xGMI and the chain on comms[0] emits the final record; otherwise the tables are hash-partitioned,
 // exchanged, merged, and EVERY chain emits its shard of the groups (OutputPlan's callback takes several records).
 func (o *Operator) MergeAcrossDevices(ctx context.Context, comm *C.fdb_comm) error {
+	// (no ctx.Err() shortcut here: the merge is collective — a rank that stayed out would leave its peers waiting inside RCCL;
+	// a cancelled query still takes part and drops its result afterwards)
 	var aligned C.int32_t
 	if rc := C.fdb_plan_allreduce(o.plan, comm, &aligned); rc != C.FDB_OK {
 		return errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))

@@ -37,6 +37,64 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert not missing, missing
 
 
+def test_library_exports_nothing_but_the_header(built_lib):
+    """`nm -D --defined-only` ⊆ include/frostdb_amd.h: no C++ internals (fdb::Plan…, kernel launch stubs, libstdc++ template
+    instantiations) in the dynamic symbol table — a cgo binary that links other C++ must not be able to collide with them."""
+    import subprocess
+    from frostdb_amd import build
+    out = subprocess.run(["nm", "-D", "--defined-only", build.LIB], check=True, capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()})
+    declared = declared_functions()
+    extra = [n for n in exported if n not in declared]
+    assert not extra, extra[:20]
+    assert exported == declared, sorted(set(declared) - set(exported))
+    # every prototype of the header carries the visibility macro (a new entry point without it would silently not be exported)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "frostdb_amd.h")).read(), flags=re.S)
+    protos = re.findall(r"^(?:FDB_API )?(?:int|const char\*|void|int32_t|int64_t) (fdb_[a-z_0-9]+)\(", text, flags=re.M)
+    marked = re.findall(r"^FDB_API (?:int|const char\*|void|int32_t|int64_t) (fdb_[a-z_0-9]+)\(", text, flags=re.M)
+    assert sorted(protos) == sorted(marked) == declared
+
+
+def test_header_is_plain_c99_and_links(built_lib, tmp_path):
+    """The boundary is a C ABI: a translation unit that includes ONLY include/frostdb_amd.h compiles as strict C99 (what cgo's
+    preamble is) and links against the library; it touches the handle-less entry points (no GPU needed)."""
+    import subprocess
+    from frostdb_amd import build
+    src = tmp_path / "tu.c"
+    src.write_text(r'''
+#include "frostdb_amd.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+  fdb_plan_desc d;
+  fdb_expr e;
+  fdb_aggregation a;
+  fdb_group_expr g;
+  char buf[256];
+  int64_t need = 0;
+  int rc;
+  memset(&d, 0, sizeof d); memset(&e, 0, sizeof e); memset(&a, 0, sizeof a); memset(&g, 0, sizeof g);
+  e.op = FDB_OP_EQ; e.left = -1; e.right = -1; e.column = "labels.code";
+  e.literal.type = FDB_LIT_STRING; e.literal.data = "200"; e.literal.len = 3;
+  a.func = FDB_AGG_SUM; a.column = "value";
+  g.name = "labels.path";
+  d.filter = &e; d.n_filter = 1; d.filter_root = 0; d.aggs = &a; d.n_aggs = 1; d.groups = &g; d.n_groups = 1;
+  rc = fdb_plan_explain(&d, buf, (int64_t)sizeof buf, &need);
+  if (rc != FDB_OK) { fprintf(stderr, "explain: %d %s\n", rc, fdb_last_error()); return 1; }
+  printf("%s|%s\n", fdb_version(), buf);
+  return 0;
+}
+''')
+    exe = tmp_path / "tu"
+    inc = os.path.join(ROOT, "include")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, str(src), build.LIB,
+                        "-Wl,-rpath," + os.path.dirname(build.LIB), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "gfx950" in out.stdout and "HashAggregate" in out.stdout, out.stdout
+
+
 def test_version_and_error_strings(built_lib):
     built_lib.fdb_version.restype = ctypes.c_char_p
     assert b"gfx950" in built_lib.fdb_version()

@@ -37,8 +37,13 @@ def jit_dump(tmp_path_factory):
         pytest.skip("no hipcc on this host")
     out = tmp_path_factory.mktemp("jit")
     exe = str(out / "jit_dump")
+    # the generators are library internals (hidden symbols: the .so exports the C ABI only), so the tool links the library's OBJECTS
+    import glob
+    objs = sorted(glob.glob(os.path.join(os.path.dirname(lib), "csrc", "*.o")))
+    assert objs, "frostdb_amd/csrc/*.o missing: build.build() keeps them next to the sources"
     subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "frostdb_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
-                           "-I", "/opt/rocm/include", os.path.join(ROOT, "tools", "jit_dump.cpp"), lib, "-o", exe, "-Wl,-rpath," + os.path.dirname(lib)])
+                           "-I", "/opt/rocm/include", os.path.join(ROOT, "tools", "jit_dump.cpp")] + objs +
+                          ["-L/opt/rocm/lib", "-lamdhip64", "-lhiprtc", "-ldl", "-lpthread", "-lz", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe, out
 
 

@@ -1,6 +1,8 @@
 // Tuning aid (CPU-only): prints the run-time specialised hash-scan kernel for a cfg 5-like shape (N dictionary key columns with
 // validity, SUM(float64) + COUNT) so that it can be compiled offline:
-//   g++ -std=c++17 -I frostdb_amd/csrc -I include tools/jit_dump.cpp frostdb_amd/libfrostdb_amd.so -o /tmp/jit_dump
+//   g++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I frostdb_amd/csrc -I include -I /opt/rocm/include tools/jit_dump.cpp frostdb_amd/csrc/*.o \
+//       -L/opt/rocm/lib -lamdhip64 -lhiprtc -ldl -lpthread -lz -Wl,-rpath,/opt/rocm/lib -o /tmp/jit_dump
+//   (the library's objects, not the .so: the generators are internals and the .so exports the C ABI only)
 //   /tmp/jit_dump 32 > /tmp/k.hip && hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DFDB_DEVICE_ONLY=1 \
 //       -I frostdb_amd/csrc --cuda-device-only -Rpass-analysis=kernel-resource-usage -c /tmp/k.hip -o /tmp/k.o
 #include <cstdio>
