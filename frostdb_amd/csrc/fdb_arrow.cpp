@@ -235,7 +235,9 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
     for (Recent& r : recent)
       if (r.holder && r.hash == h && same_content(**r.holder)) return std::shared_ptr<HostDict>(r.holder, r.holder->get());
   auto remember = [&](const std::shared_ptr<HostDict>& d) -> std::shared_ptr<HostDict> {
-    if (!l1) return d;
+    // (bounded: an entry keeps its dictionary alive for the thread's lifetime, so only small ones are cached — ≤ 16 × 256 KiB per pushing
+    // thread; with a bigger dictionary the pass over its bytes dwarfs the mutex and the reference count this cache exists to avoid)
+    if (!l1 || span + n * 4 > (int64_t)(256 << 10)) return d;
     Recent& r = recent[recent_next++ % 16];
     r.hash = h;
     r.holder = std::make_shared<std::shared_ptr<HostDict>>(d);

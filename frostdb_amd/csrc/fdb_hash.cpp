@@ -227,7 +227,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
         // dictionaries, and the plan interned the first one it saw entry by entry): key id = index + 1 — no table to ship or to read.
         // ($FDB_NO_IDENTITY_LUT: A/B aid)
         const std::vector<uint32_t>& L = *gr.lut;
-        bool identity = !L.empty() && L.front() == 1u && L.back() == (uint32_t)L.size() && std::getenv("FDB_NO_IDENTITY_LUT") == nullptr;
+        bool identity = !L.empty() && L.front() == 1u && L.back() == (uint32_t)L.size() && !knobs_.no_identity_lut;
         for (size_t i = 0; identity && i < L.size(); i++) identity = L[i] == (uint32_t)i + 1u;
         C.lut_len = (uint32_t)L.size();
         if (identity) lut_identity[g] = 1; else lut_off[g] = R.blob.add(L.data(), L.size() * 4);
@@ -454,7 +454,8 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
   PhaseTimer pt;
   // (`runs`: the groups come from an ordered plan's run store instead of the table — pass 1 below is runs_expand, everything
   // after it — the column pass, transport widths, slices, widening, the resident form — is shared)
-  const uint64_t n = runs != nullptr ? (uint64_t)runs->n_groups : hash_groups();
+  const uint64_t n = runs != nullptr ? (uint64_t)runs->n_groups : fresh_groups_ >= 0 ? (uint64_t)fresh_groups_ : hash_groups();
+  fresh_groups_ = -1;
   if (pt.on) pt.mark("finish: group count");
   const size_t n_cols = gcols_.size(), n_vals = 1 + aggs_.size();
   const size_t np = (size_t)((n + 63) & ~(uint64_t)63) + 64;  // padded row count of the buffers
@@ -1073,7 +1074,7 @@ bool Plan::runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>
   // store to size and merge — cfg 2's query over a table sorted by labels.path: 0.3 ms per 100 M rows against 0.9 ms of run kernels and a
   // Finish over 390 k runs) and its few thousand groups are sorted on the host in microseconds. The run store is for key spaces that would
   // need the global table. ($FDB_RUNS_ALWAYS: test aid — the run machinery on small shapes)
-  if (runs_.empty() && std::getenv("FDB_RUNS_ALWAYS") == nullptr && gcols_.size() <= FDB_MAX_DENSE_GCOLS) {
+  if (runs_.empty() && !knobs_.runs_always && gcols_.size() <= FDB_MAX_DENSE_GCOLS) {
     bool dense = true;
     uint64_t space = 1;
     for (const GroupColState& g : gcols_) {
@@ -1099,13 +1100,13 @@ bool Plan::runs_wanted(const DeviceBatch* const* bs, const std::vector<Resolved>
 
 // Which run record does this record's launch write: 0 narrow (a byte per key id), 1 medium (two bytes), 2 wide.
 int Plan::runs_format(const Resolved& R) const {
-  const char* force = std::getenv("FDB_RUNS_WIDE");  // (A/B and test aid, read per record so that a test can switch it: "1" every launch writes wide records, "m" medium ones where narrow would do)
-  if ((force != nullptr && force[0] == '1') || gcols_.size() > FDB_RUN_TUPLE_BYTES || R.groups.size() != gcols_.size()) return 2;
+  const char force = knobs_.runs_wide;  // (A/B and test aid: '1' every launch writes wide records, 'm' medium ones where narrow would do)
+  if (force == '1' || gcols_.size() > FDB_RUN_TUPLE_BYTES || R.groups.size() != gcols_.size()) return 2;
   size_t most = 0;
   for (const GroupColState& g : gcols_) { if (g.kind != 0) return 2; most = std::max(most, g.values.size()); }
   for (size_t g = 0; g < R.groups.size(); g++) if (R.groups[g].kind != 0 || R.groups[g].gi != (int)g) return 2;
   if (most > 65534) return 2;
-  return most > 254 || force != nullptr ? 1 : 0;
+  return most > 254 || force != 0 ? 1 : 0;
 }
 
 void Plan::runs_free() {
@@ -1280,7 +1281,7 @@ unsigned long long* Plan::sort_by_group_columns(unsigned long long* order, int64
 // ordered set had arrived. Runs of one key end up next to each other in arrival order (the sort is stable), so the expand kernel folds
 // them as it folds the runs that wave and record boundaries cut. Cost ∝ runs × (key bits / 64), not ∝ groups × log groups on the host.
 bool Plan::runs_sort(RunsView* v, std::vector<void*>* owned) {
-  const bool off = std::getenv("FDB_RUNS_NO_SORT") != nullptr;  // (A/B and test aid, read per Finish: the table + host sort fallback)
+  const bool off = knobs_.runs_no_sort;  // (A/B and test aid: the table + host sort fallback)
   if (off || v->n_runs < 2 || v->n_runs > ((int64_t)1 << 28)) return false;  // (48 bytes of sort buffers per run: 12 GiB at the limit)
   auto alloc = [&](size_t bytes) { void* p = ctx_->dev_alloc(std::max<size_t>(bytes, 256)); owned->push_back(p); return p; };
   const size_t n = (size_t)v->n_runs;

@@ -469,7 +469,6 @@ struct Gen {
       }
       o << "    }\n";
     }
-    for (int pass = 0; pass < 1; pass++) {
     for (int k = 0; k < 4 && s.reg_slots == 0; k++) {
       const std::string gidk = "gid" + std::to_string(k);
       o << "    if ((sel >> " << k << ") & 1u) {\n";
@@ -523,7 +522,6 @@ struct Gen {
       }
       o << "    }\n";
     }
-    }  // pass
     o << "  }\n";
     if (s.reg_slots > 0) {
       // lane-private tables → one value per wave (butterfly over the 64 lanes) → one update per wave and slot
@@ -1233,6 +1231,19 @@ struct HashGen {
       o << "        asm volatile(\"\" ::: \"memory\");\n      }\n";
     }
     if (for_runs) {
+      // A canonical tuple's padding words [used, key_words) are part of the run record: a segment only remembers its record width, so a group
+      // column the plan gains LATER lands on them and must read 0 = NULL there (the hash table tracks its used prefix instead, h_key_used_).
+      int used = 4;
+      for (size_t c = 0; c < s.cols.size(); c++) used += s.cols[c].kind == 0 ? 1 : 2;
+      if (used % 4 != 0) {
+        o << "      if (canon) {\n";
+        for (int k = 0; k < 4; k++) {
+          o << "        if (ins_mask & " << (1 << k) << "u) {";
+          for (int w = used; w < ((used + 3) & ~3); w++) o << " d_" << k << "[" << w << "] = 0u;";
+          o << " }\n";
+        }
+        o << "      }\n";
+      }
       const bool has_val = !s.aggs.empty() && s.aggs[0].func != FDB_AGG_COUNT;
       const bool f64v = has_val && s.aggs[0].func == FDB_AGG_SUM && s.aggs[0].type == FDB_T_F64;
       for (int k = 0; k < 4; k++)

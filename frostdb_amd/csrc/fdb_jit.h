@@ -45,7 +45,7 @@ struct JitShape {
   bool wave_tables = false;
   // LDS tables: when the slots of a wave's selected rows agree (sorted input) the updates go to a wave-uniform address, so that the compiler
   // folds them across the lanes (fdb_jit.cpp, "Sorted input")
-  bool uniform_fold = std::getenv("FDB_NO_UNIFORM_FOLD") == nullptr;
+  bool uniform_fold = true;  // ($FDB_NO_UNIFORM_FOLD, A/B aid: a plan reads it at create, Plan::Knobs)
   // fdb_select_kernel only (not part of key()): early slots whose values the kernel compacts itself, bit i = slot i of c4 / c8
   int fuse4 = 0, fuse8 = 0;
   std::string key(bool with_validity = true) const;

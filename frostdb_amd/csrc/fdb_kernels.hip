@@ -2818,7 +2818,6 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
   uint32_t fl = 0, g = 0;
   unsigned long long cnt = 0, acc = 0;
   run_u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
-  bool single = true;
   const uint32_t* wide = nullptr;  // a wide run's key tuple (already a dense key row of `wide_kw` words)
   const uint32_t* medium = nullptr;  // a medium run's 32 two-byte ids
   int wide_kw = 0;
@@ -2842,7 +2841,6 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
     if (a.flags != nullptr) {
       fl = a.flags[i];
       g = a.out_idx[i] - (fl ? 0u : 1u);
-      single = fl != 0u && (i + 1 >= a.n_runs || a.flags[i + 1] != 0u);
     } else { fl = 1u; g = (uint32_t)i; }
   }
   const unsigned long long starts = __ballot(live && fl != 0u);
@@ -2883,7 +2881,6 @@ __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArg
       }
     }
   }
-  (void)single;
   if (starts == 0ull) return;
   const uint32_t first_g = __shfl(g, __builtin_ctzll(starts), 64);  // (g of the first starting lane = the wave's first output row)
   const uint32_t n_new = (uint32_t)__popcll(starts);

@@ -1036,7 +1036,19 @@ constexpr size_t kFlushBytes = (size_t)96 << 20;
 constexpr size_t kFlushRecords = 1024;
 }  // namespace
 
-bool Plan::jit_possible() const { return sub_tiles != 4 && ablate == 0 && std::getenv("FDB_NO_JIT") == nullptr; }
+bool Plan::jit_possible() const { return sub_tiles != 4 && ablate == 0 && !knobs_.no_jit; }
+
+Plan::Knobs::Knobs() {
+  no_jit = std::getenv("FDB_NO_JIT") != nullptr;
+  runs_always = std::getenv("FDB_RUNS_ALWAYS") != nullptr;
+  no_identity_lut = std::getenv("FDB_NO_IDENTITY_LUT") != nullptr;
+  runs_no_sort = std::getenv("FDB_RUNS_NO_SORT") != nullptr;
+  no_uniform_fold = std::getenv("FDB_NO_UNIFORM_FOLD") != nullptr;
+  const char* w = std::getenv("FDB_RUNS_WIDE");
+  runs_wide = w != nullptr ? (w[0] == '1' ? '1' : 'm') : 0;
+  const char* e = std::getenv("FDB_ORDERED_SORT_MIN");
+  ordered_sort_min = e != nullptr ? std::max<long long>(0, std::atoll(e)) : 4096;
+}
 
 void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
   if (finished_) throw Error(FDB_ERR_STATE, "push after finish");
@@ -1436,7 +1448,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
   const size_t acc_bytes = align_up((size_t)n_slots_ * 4, 16) + (size_t)n_slots_ * 8 * aggs_.size();
   size_t lut_lds_max = 0;
   bool slots_ok = rows_per_thread == 0;
-  const bool jit_possible = sub_tiles != 4 && ablate == 0 && std::getenv("FDB_NO_JIT") == nullptr;
+  const bool jit_possible = this->jit_possible();
   bool interp_ok = true;  // every record also fits the interpreting slot kernel's limits
   std::vector<int> layouts;
   for (int i : live) {
@@ -1572,6 +1584,7 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
         if (n_slots_ >= 1 && n_slots_ <= 8 && (int)n_slots_ * regs_per_slot <= 48) shape.reg_slots = (int)n_slots_;
       }
       shape.wave_tables = fixed_order;
+      shape.uniform_fold = !knobs_.no_uniform_fold;
       if (same) {
         if (jit_block != 0) { jit_fn = jit_get(shape); if (jit_fn != nullptr) per_cu = jit_blocks_per_cu(jit_fn, jit_block, lds_bytes); }
         else {
@@ -1877,10 +1890,11 @@ void Plan::build_agg_columns(const CompactState& cs, std::vector<OutColumn>* col
 // the threshold (0: always on the device — tests).
 bool Plan::ordered_finish_on_device() {
   if (!ordered_ || mode_ != TableMode::HASH || h_table_ == nullptr) return false;
-  const char* e = std::getenv("FDB_ORDERED_SORT_MIN");
-  const uint64_t least = e != nullptr ? (uint64_t)std::max<long long>(0, std::atoll(e)) : 4096;
+  const uint64_t least = (uint64_t)knobs_.ordered_sort_min;
   const uint64_t n = hash_groups();
-  return n >= least && n >= 2 && n <= ((uint64_t)1 << 28);
+  const bool on_device = n >= least && n >= 2 && n <= ((uint64_t)1 << 28);
+  fresh_groups_ = on_device ? (int64_t)n : -1;  // (finish_columns_hash follows at once and does not fetch the count a second time)
+  return on_device;
 }
 
 int64_t Plan::finish_columns(std::vector<OutColumn>* cols) {
@@ -2072,8 +2086,9 @@ void Plan::merge_from(Plan& src) {
   // every source slot is mapped — an empty one folds its identity into its destination, so the source's counts need not be fetched to
   // know which slots are occupied (that blocking copy and the two waits in front of it were most of a merge: 250 µs, now ≈ 70) — and one
   // wait at the end lets the caller close the source right away.
+  settle();
   src.settle();
-  if (!src.state_dirty_) return;
+  if (!src.state_dirty_) { src.sync(); return; }  // (callers close or free `src` right after a merge: its stream is idle on every return)
   src.materialize_state();
   {
     hip_check(hipSetDevice(device_), "hipSetDevice");

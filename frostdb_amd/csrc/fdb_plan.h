@@ -342,6 +342,15 @@ class Plan {
   // The runs of `v` brought into key order by a device sort (several ordered sets, a record out of place): phys / flags / out_idx / n_groups
   // are replaced. false: not attempted (too many runs, $FDB_RUNS_NO_SORT) — the caller falls back to the table.
   bool runs_sort(RunsView* v, std::vector<void*>* owned);
+  // A/B and test switches of the environment, read ONCE per plan (at create): getenv on the per-record path costs a scan of the environment
+  // and is not safe against a concurrent setenv. A test sets them before it creates its plan.
+  struct Knobs {
+    bool no_jit, runs_always, no_identity_lut, runs_no_sort, no_uniform_fold;
+    char runs_wide;             // 0 unset, '1' wide records every launch, 'm' medium where narrow would do
+    long long ordered_sort_min; // groups from which an ordered Finish out of the table sorts on the device
+    Knobs();
+  } knobs_;
+  int64_t fresh_groups_ = -1;   // hash_groups() as just fetched by ordered_finish_on_device(), for the finish_columns_hash that follows at once
   bool ordered_finish_on_device();  // an ordered plan's groups out of the hash table: sorted on the device (big results) or on the host
   // The stable LSD sort both ordered Finishes use (fdb_hash.cpp): runs of a run store, or the groups of the hash table as dense key rows.
   unsigned long long* sort_by_group_columns(unsigned long long* order, int64_t n_things, const FdbRunSegs* segs, const uint32_t* rows, int row_kw, RunsView* tables,

@@ -641,6 +641,42 @@ def test_wide_run_records_group_columns_that_come_and_go(pp):
     assert sorted(_rows(o), key=repr) == sorted(_rows(h), key=repr) and o.num_rows > 300
 
 
+def test_wide_run_records_written_before_the_plan_gains_a_column_read_null_there(pp, monkeypatch):
+    """Canonical wide records of a 3-column plan pad their 7-word tuple to 8 words; a record that adds a 4th group column puts it on
+    exactly that word. The older runs must read NULL there (the padding is written as zeros), not whatever the LDS stage / the
+    segment's block held (advisor finding, round 5). Several passes so that recycled blocks carry old tuples."""
+    monkeypatch.setenv("FDB_RUNS_WIDE", "1")
+    rng = np.random.default_rng(61)
+    n = 30_000
+    def col(k, tag):
+        x = np.sort(rng.integers(0, k, n))
+        return pa.DictionaryArray.from_arrays(pa.array(x.astype(np.uint32)), pa.array([b"%s%03d" % (tag, i) for i in range(k)], type=pa.binary()))
+    v = lambda: pa.array(rng.integers(1, 100, n).astype(np.int64))  # noqa: E731
+    for _ in range(3):
+        three = [pa.RecordBatch.from_arrays([col(40, b"a"), col(9, b"b"), col(5, b"c"), v()], names=["labels.a", "labels.b", "labels.c", "v"]) for _ in range(2)]
+        four = pa.RecordBatch.from_arrays([col(40, b"a"), col(9, b"b"), col(5, b"c"), col(6, b"d"), v()], names=["labels.a", "labels.b", "labels.c", "labels.d", "v"])
+        recs = three + [four]
+        # one launch per record (a launch over all three would know labels.d from the start and write the 3-column records non-canonically)
+        plan = pp.HashAggregatePlan(None, [Sum(Col("v"))], [DynCol("labels")], ordered=True, final_stage=False)
+        keep = [pp.ResidentBatch(r) for r in recs]
+        try:
+            kernels = []
+            for k in keep:
+                plan.CallbackResident([k])
+                kernels.append(plan.last_kernel())
+            o = plan.Finish()
+        finally:
+            plan.Close()
+            for k in keep:
+                k.close()
+        assert kernels == ["fdb_hash_kernel(runs, wide)"] * 3, kernels
+        h, _ = _run_plan(pp, recs, Sum(Col("v")), [DynCol("labels")], ordered=False, resident=True)
+        assert sorted(_rows(o), key=repr) == sorted(_rows(h), key=repr) and o.num_rows > 300
+        # every group that came from the 3-column records has labels.d = NULL
+        d = o.column(o.schema.get_field_index("labels.d"))
+        assert d.null_count > 0
+
+
 @pytest.mark.parametrize("force,name", [("1", "fdb_hash_kernel(runs, wide)"), ("m", "fdb_hash_kernel(runs, medium)")])
 def test_every_table_free_test_shape_with_wide_records_forced(pp, monkeypatch, force, name):
     """FDB_RUNS_WIDE: the narrow-record shapes above through the wide-record / medium-record kernels — same answers."""
