@@ -78,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle-parity", action="store_true", help="skip the oracle-vs-GPU comparison on the first resident record (checked.oracle)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg 3 / cfg 5 / select / host_records / parquet lines of the default run")
-    ap.add_argument("--only-other", default="", help="comma-separated subset of other_configs to run (cfg3,cfg5,select,host_records,parquet)")
+    ap.add_argument("--only-other", default="", help="comma-separated subset of other_configs to run (cfg3,cfg5,cfg5_1B,cfg5_sorted,select,host_records,parquet,…)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=3.0)
     ap.add_argument("--sweep", action="store_true", help="kernel geometry sweep first (tuning aid; table on stderr)")
     return ap.parse_args(argv)
@@ -840,9 +840,14 @@ def other_configs(args, wl, rank, device, group, comm):
         others["host_records_chains"] = measure_host_records_chains(wl)
     wl.release()
     for cfg, st, wu in ((3, max(5, args.steps // 2), 2), (5, 3, 1)):
-        if not want(f"cfg{cfg}"):
+        if not want(f"cfg{cfg}") and not (cfg == 5 and only and "cfg5_merge" in only):
             continue
         w2 = Workload(args, cfg, 100_000_000, rank, device)
+        if cfg == 5 and not want("cfg5"):  # (--only-other cfg5_merge)
+            if len(w2.resident) >= 2:
+                others["cfg5_merge"] = measure_cfg5_merge(args, w2, st, wu, ceiling)
+            w2.release()
+            continue
         r2 = run_workload(args, w2, st, wu, group, comm, 100_000_000)
         others[f"cfg{cfg}"] = {
             "workload": f"cfg{cfg}: Prometheus schema, 100000000 rows, {w2.qdesc}",
@@ -850,6 +855,8 @@ def other_configs(args, wl, rank, device, group, comm):
             "ms_per_step": r2["elapsed"] / st * 1e3, "roofline": roofline_of(r2, 100_000_000, st, f"cfg{cfg}", ceiling),
             "checked": r2["checked"], "jit": jit_of(r2), "setup": {"gen_and_upload_s": w2.t_gen, "hbm_resident_bytes": w2.hbm_bytes},
         }
+        if cfg == 5 and want("cfg5_merge") and len(w2.resident) >= 2:
+            others["cfg5_merge"] = measure_cfg5_merge(args, w2, st, wu, ceiling)
         if cfg == 5:  # the same scan finished for a consumer on the device (fdb_plan_finish_batch): no Arrow record crosses PCIe
             r3 = run_workload(args, w2, st, wu, group, comm, 100_000_000, resident_finish=True)
             others["cfg5_resident_finish"] = {
@@ -886,6 +893,19 @@ def other_configs(args, wl, rank, device, group, comm):
                 "value": 100_000_000 * st / r6["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r6["elapsed"] / st * 1e3,
                 "roofline": roofline_of(r6, 100_000_000, st, "cfg5_sorted_wide", ceiling), "checked": r6["checked"], "jit": jit_of(r6)}
             w4.release()
+    if want("cfg5_1B"):
+        # BASELINE.json's metric at cfg 5's shape: 1 B rows × 32 label columns over 10 M groups, all of it resident on ONE GPU (138.5 GB of
+        # columns). At 100 M rows the scan creates its 10 M groups inside the timed step (one insert-heavy launch is a third of it); here ≈ 97 %
+        # of the rows meet a group that exists — the steady state of the probing kernel, which is what the metric's scale measures.
+        n1b = 1_000_000_000
+        w6 = Workload(args, 5, n1b, rank, device)
+        r9 = run_workload(args, w6, 2, 1, group, comm, n1b)
+        others["cfg5_1B"] = {
+            "workload": f"cfg5_1B: Prometheus schema, {n1b} rows resident on one GPU, {w6.qdesc}",
+            "value": n1b * 2 / r9["elapsed"], "unit": "rows/s", "steps": 2, "warmup": 1, "ms_per_step": r9["elapsed"] / 2 * 1e3,
+            "roofline": roofline_of(r9, n1b, 2, "cfg5_1B", ceiling), "checked": r9["checked"],
+            "setup": {"gen_and_upload_s": w6.t_gen, "hbm_resident_bytes": w6.hbm_bytes}}
+        w6.release()
     if want("cfg2_sorted"):  # the benchmark's own schema and query over a table sorted by labels.path: table-free OrderedAggregate, wide run records
         w5 = Workload(args, 2, 100_000_000, rank, device, cfg2_sorted=True)
         st2 = max(5, args.steps // 2)
@@ -1143,6 +1163,86 @@ def compare_with_oracle(wl, got, want):
             else:
                 assert y == x, (k, n, y, x)
     return len(w)
+
+
+def measure_cfg5_merge(args, wl, steps, warmup, ceiling):
+    """Two chains of one GPU at cfg 5 (≙ Synchronizer + final-stage HashAggregate, synchronize.go:31-53, aggregate.go:340-348): each
+    plan scans half of the resident records into its own hash table (≈ 5 – 10 M groups each, nearly all shared), fdb_plan_merge folds the
+    second table into the first on the device (fdb_merge.hip: hash_merge_wave_kernel over the source's slots), Finish emits the record.
+    Reports the merge alone (host clock around fdb_plan_merge, which returns with both streams idle) next to the whole step."""
+    import numpy as np
+    from frostdb_amd import physicalplan as pp
+    half = len(wl.resident) // 2
+    parts = (wl.resident[:half], wl.resident[half:])
+    rows = sum(r.num_rows for r in wl.resident)
+
+    def step():
+        a = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=wl.device, desc=wl.desc)
+        b = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=wl.device, desc=wl.desc)
+        try:
+            a.CallbackResident(parts[0]); b.CallbackResident(parts[1])
+            na, nb = a.num_groups(), b.num_groups()  # (waits for both scans)
+            t0 = time.perf_counter()
+            a.Merge(b)
+            t1 = time.perf_counter()
+            kernel = a.last_kernel()
+            out = a.Finish()
+        finally:
+            a.Close(); b.Close()
+        return out, (t1 - t0) * 1e3, na, nb, kernel
+
+    out, _, na, nb, kernel = step()
+    expected = [np.asarray(e) for e in wl.expected]
+    checked = wl.check(out, expected, rows)
+    checked["against"] = "numpy expectation (row count and Σ value of every generated record) + group count bound; not the oracle"
+    if not args.no_oracle_parity and wl.sample is not None:
+        checked["oracle"] = oracle_parity_merged(wl, 1 << 18)
+    n_out, n_key_cols = out.num_rows, out.num_columns - len(wl.aggs)
+    del out
+    for _ in range(warmup):
+        step()
+    merge_ms = []
+    t = time.perf_counter()
+    for _ in range(steps):
+        merge_ms.append(step()[1])
+    dt = time.perf_counter() - t
+    # what one merge moves: every source group's entry and key tuple read once; a new group's tuple and entry written, a known group's entry folded
+    kw_bytes, ew_bytes = 4 * ((2 + n_key_cols + 3) // 4 * 4), 32
+    moved = nb * (kw_bytes + ew_bytes) + (n_out - na) * (kw_bytes + ew_bytes) + (nb - (n_out - na)) * ew_bytes
+    ms = float(np.median(merge_ms))
+    return {"workload": f"cfg5_merge: two plans of {rows // 2} rows each ({na} + {nb} groups) -> fdb_plan_merge -> Finish ({n_out} groups)",
+            "merge_ms": ms, "merge_ms_all": [round(x, 3) for x in merge_ms], "merge_kernel": kernel, "groups_per_s": nb / (ms * 1e-3),
+            "merge_bytes": moved, "merge_GBps": moved / (ms * 1e-3) / 1e9, "merge_frac_of_read_ceiling": moved / (ms * 1e-3) / 1e9 / ceiling if ceiling else None,
+            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "value": rows * steps / dt, "unit": "rows/s", "checked": checked}
+
+
+def oracle_parity_merged(wl, max_rows):
+    """Two plans over two slices of the sample record, merged on the device, against the oracle over both slices."""
+    from frostdb_amd import physicalplan as pp
+    import oracle  # noqa: F401
+    from oracle import OracleBatch, OraclePlan
+    n = min(max_rows, wl.sample.num_rows // 2)
+    s0, s1 = wl.sample.slice(0, n), wl.sample.slice(wl.sample.num_rows - n, n)
+    r0, r1 = pp.ResidentBatch(s0, device=wl.device), pp.ResidentBatch(s1, device=wl.device)
+    a = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=wl.device, desc=wl.desc)
+    b = pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=wl.device, desc=wl.desc)
+    try:
+        a.CallbackResident([r0]); b.CallbackResident([r1])
+        a.Merge(b)
+        got = a.Finish()
+    finally:
+        a.Close(); b.Close(); r0.close(); r1.close()
+    threads, bs = os.cpu_count() or 1, 65536
+    batches = [OracleBatch.from_arrow(s.slice(o, min(bs, n - o))) for s in (s0, s1) for o in range(0, n, bs)]
+    oplan = OraclePlan(wl.filt, wl.aggs, wl.groups, nchains=threads)
+    res = oplan.execute(batches, threads)
+    want = res.to_arrow()
+    res.close(); oplan.close()
+    for x in batches:
+        x.close()
+    n_groups = compare_with_oracle(wl, got, want)
+    return {"rows": 2 * n, "groups": n_groups, "what": "oracle.OraclePlan.execute over the first and the last %d rows of the first resident record vs. two GPU plans "
+            "(one per slice) merged with fdb_plan_merge: group sets equal, counts bit-exact, float64 sums within 1e-9 relative" % n}
 
 
 def oracle_parity(wl, max_rows=None):

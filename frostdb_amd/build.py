@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfrostdb_amd.so")
-SOURCES = ["fdb_kernels.hip", "fdb_sort.hip", "fdb_arrow.cpp", "fdb_context.cpp", "fdb_plan.cpp", "fdb_hash.cpp", "fdb_jit.cpp", "fdb_dynamic.cpp", "fdb_comm.cpp", "fdb_parquet.cpp", "fdb_widen.cc", "fdb_regex.cpp", "fdb_capi.cpp"]
+SOURCES = ["fdb_kernels.hip", "fdb_merge.hip", "fdb_sort.hip", "fdb_arrow.cpp", "fdb_context.cpp", "fdb_plan.cpp", "fdb_hash.cpp", "fdb_jit.cpp", "fdb_dynamic.cpp", "fdb_comm.cpp", "fdb_parquet.cpp", "fdb_widen.cc", "fdb_regex.cpp", "fdb_capi.cpp"]
 HEADERS = ["fdb_kernels.h", "fdb_arrow.h", "fdb_context.h", "fdb_plan.h", "fdb_plan_internal.h", "fdb_jit.h", "fdb_comm.h", "fdb_dynamic.h", "fdb_regex.h", "fdb_hostpool.h", "fdb_unicode_tables.inc", "exports.map", "../../include/frostdb_amd.h", "../../include/arrow_c_data.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-result",
          "-fvisibility=hidden", "-fvisibility-inlines-hidden"]

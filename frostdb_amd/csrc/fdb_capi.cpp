@@ -120,7 +120,7 @@ int fdb_plan_explain(const fdb_plan_desc* desc, char* buf, int64_t capacity, int
 
 int fdb_selftest_widen(const void* src, int32_t width, uint32_t* dst, int64_t n) {
   return guard(nullptr, [&] {
-    if ((width != 1 && width != 2 && width != 4) || n < 0 || ((src == nullptr || dst == nullptr) && n > 0)) throw fdb::Error(FDB_ERR_INVALID, "widen: width 1, 2 or 4 and non-null buffers");
+    if ((width != 1 && width != 2 && width != 4 && width != -2 && width != -4) || n < 0 || ((src == nullptr || dst == nullptr) && n > 0)) throw fdb::Error(FDB_ERR_INVALID, "widen: width 1, 2, 4 (bytes) or -2, -4 (bits) and non-null buffers");
     fdb::widen_indices(src, width, dst, (size_t)n);
   });
 }

@@ -114,26 +114,42 @@ void Plan::hash_insert_entries(const std::vector<unsigned long long>& entries, c
   scratch_.push_back(d_entries); scratch_.push_back(d_keys);
   hip_check(hipMemcpyAsync(d_entries, entries.data(), entries.size() * 8, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(entries)");
   hip_check(hipMemcpyAsync(d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(keys)");
-  hash_merge_device((const unsigned long long*)d_entries, (const uint32_t*)d_keys, n, in_kw, cols);
+  hash_merge_device((const unsigned long long*)d_entries, (const uint32_t*)d_keys, n, in_kw, cols, /*unique_source=*/true);  // (both callers compact ONE table)
   hip_check(hipStreamSynchronize(stream_), "sync(hash merge)");  // the host vectors must outlive the copies
+}
+
+// What every merge launch shares: the destination side of the argument block and the reducers.
+void Plan::hash_merge_args(FdbHashMergeArgs* m, const std::vector<FdbHashCol>& cols, int in_stride_words) {
+  std::memset(m, 0, sizeof(*m));
+  m->table = h_table_; m->keys = h_keys_; m->n_groups = h_count_dev_; m->mask = h_capacity_ - 1;
+  static const FdbHashCol kNoCol = {};
+  m->cols = (const FdbHashCol*)(cols.empty() ? upload(&kNoCol, sizeof(FdbHashCol)) : upload(cols.data(), cols.size() * sizeof(FdbHashCol)));
+  m->n_cols = (int)gcols_.size(); m->entry_words = h_entry_words_; m->key_words = h_key_words_;
+  m->n_aggs = (int)aggs_.size();
+  for (size_t j = 0; j < aggs_.size(); j++) {
+    const int32_t f = aggs_[j].func;
+    m->funcs[j] = f == FDB_AGG_COUNT ? (final_stage_ ? 1 : 0) : f == FDB_AGG_SUM ? (aggs_[j].type == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
+  }
+  // how much of an incoming tuple the columns reach, and whether it already has our layout
+  int reach = 2;
+  bool same = true;
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    if (cols[c].src_word != cols[c].word) same = false;
+    if (cols[c].src_word >= 0) reach = std::max(reach, cols[c].src_word + (cols[c].kind == 0 ? 1 : 2));
+  }
+  m->in_words = std::min((reach + 3) & ~3, in_stride_words);
+  m->same_layout = same && m->in_words <= h_key_words_;
 }
 
 // The merge launch itself: `n` pre-aggregated entries ({count, acc…} + key tuples of `in_kw` words) already on the device. The
 // table must have room (hash_reserve).
-void Plan::hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols) {
-  const int in_ew = (int)(1 + aggs_.size());
+void Plan::hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols, bool unique_source) {
   FdbHashMergeArgs m;
-  std::memset(&m, 0, sizeof(m));
+  hash_merge_args(&m, cols, in_kw);
   m.entries = d_entries; m.in_keys = d_keys; m.n = n;
-  m.table = h_table_; m.keys = h_keys_; m.n_groups = h_count_dev_; m.mask = h_capacity_ - 1;
-  m.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
-  m.n_cols = (int)cols.size(); m.in_key_words = in_kw; m.in_entry_words = in_ew; m.entry_words = h_entry_words_; m.key_words = h_key_words_;
-  m.n_aggs = (int)aggs_.size();
-  for (size_t j = 0; j < aggs_.size(); j++) {
-    const int32_t f = aggs_[j].func;
-    m.funcs[j] = f == FDB_AGG_COUNT ? (final_stage_ ? 1 : 0) : f == FDB_AGG_SUM ? (aggs_[j].type == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
-  }
-  hip_check(fdb_launch_hash_merge(m, stream_), "hash merge");
+  m.in_key_words = in_kw; m.in_entry_words = (int)(1 + aggs_.size());
+  m.unique_source = unique_source;
+  hip_check(fdb_launch_hash_merge(m, device_, stream_), "hash merge");
   state_dirty_ = true;
 }
 
@@ -460,7 +476,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
   const size_t n_cols = gcols_.size(), n_vals = 1 + aggs_.size();
   const size_t np = (size_t)((n + 63) & ~(uint64_t)63) + 64;  // padded row count of the buffers
   int kSliceShift = 6;  // 2^20 rows per slice; a smaller result is one slice of the next power of two
-  while (kSliceShift < 20 && ((uint64_t)1 << kSliceShift) < n) kSliceShift++;
+  while (kSliceShift < knobs_.finish_slice_shift && ((uint64_t)1 << kSliceShift) < n) kSliceShift++;
   const size_t kSliceRows = (size_t)1 << kSliceShift;
   const size_t n_slices = (size_t)((n + kSliceRows - 1) >> kSliceShift);
   // transport width per group column: 1 / 2 bytes for dictionaries that fit, else the column's own width
@@ -469,7 +485,8 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
   size_t n_narrow = 0, last_narrow = 0;
   for (size_t c = 0; c < n_cols; c++) {
     const GroupColState& g = gcols_[c];
-    width[c] = g.kind != 0 ? 8 : resident != nullptr ? 4 : g.values.size() <= 256 ? 1 : g.values.size() <= 65536 ? 2 : 4;
+    // (negative: BITS per index, packed low bits first — a dictionary of ≤ 4 / ≤ 16 entries travels as 2 / 4 bits per row)
+    width[c] = g.kind != 0 ? 8 : resident != nullptr ? 4 : g.values.size() <= 4 ? -2 : g.values.size() <= 16 ? -4 : g.values.size() <= 256 ? 1 : g.values.size() <= 65536 ? 2 : 4;
     narrow[c] = g.kind == 0 && width[c] < 4;
     if (narrow[c]) { n_narrow++; last_narrow = c; }
   }
@@ -483,17 +500,21 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
   for (size_t c = 0; c < n_cols; c++) if (narrow[c]) off_key[c] = place(np * 4);
   const size_t direct_begin = total;
   for (size_t c = 0; c < n_cols; c++) if (!narrow[c]) off_key[c] = place(np * (size_t)width[c]);
-  for (size_t c = 0; c < n_cols; c++) off_bits[c] = place(np / 8 + 64);
   for (size_t v = 1; v < n_vals; v++) off_val[v] = place(np * 8);
   const size_t off_nulls = place(std::max<size_t>(n_cols, 1) * 8);  // NULLs per group column, counted by the kernel
-  // the per-group row counts go LAST: they only cross PCIe when a COUNT aggregation reads them (cfg 5: 80 MB that nobody asked for)
+  // the per-group row counts only cross PCIe when a COUNT aggregation reads them (cfg 5: 80 MB that nobody asked for), and a column's
+  // validity bitmap only when the column has a NULL (cfg 5: 12 of 32 label columns have none — known once the kernel's NULL counts
+  // are on the host, so the bitmaps go LAST and are copied one by one)
   bool counts_wanted = false;
   for (const AggState& A : aggs_) if (A.func == FDB_AGG_COUNT && !final_stage_) counts_wanted = true;
   const size_t direct_copy_bytes = (counts_wanted ? total + align_up_sz(np * 8, 256) : total) - direct_begin;
   off_val[0] = place(np * 8);
+  const size_t bitmap_bytes = np / 8 + 64;
+  for (size_t c = 0; c < n_cols; c++) off_bits[c] = place(bitmap_bytes);
   const size_t direct_bytes = total - direct_begin;
   size_t slice_stride = 0;
-  for (size_t c = 0; c < n_cols; c++) if (narrow[c]) { off_narrow[c] = slice_stride; slice_stride += kSliceRows * (size_t)width[c]; }
+  auto col_bytes = [&](size_t c, size_t rows) { return width[c] > 0 ? rows * (size_t)width[c] : ((rows * (size_t)(-width[c]) + 31) / 32) * 4; };  // (sub-byte columns are written as whole 32-bit words)
+  for (size_t c = 0; c < n_cols; c++) if (narrow[c]) { off_narrow[c] = slice_stride; slice_stride += col_bytes(c, kSliceRows); }
   const size_t narrow_bytes = slice_stride * std::max<size_t>(n_slices, 1);
   unsigned char* d_block = nullptr;
   std::vector<void*> owned;
@@ -692,12 +713,25 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
       hip_check(hipEventRecord(produced[sl], stream_), "hipEventRecord");
       hip_check(hipStreamWaitEvent(copy_stream, produced[sl], 0), "hipStreamWaitEvent");
       if (n_narrow == 0) continue;
-      const size_t bytes = rows == kSliceRows ? slice_stride : off_narrow[last_narrow] + rows * (size_t)width[last_narrow];  // (short last slice)
+      const size_t bytes = rows == kSliceRows ? slice_stride : off_narrow[last_narrow] + col_bytes(last_narrow, rows);  // (short last slice)
       hip_check(hipMemcpyAsync(h_narrow + sl * slice_stride, d_narrow + sl * slice_stride, bytes, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(narrow slice)");
       landed[sl] = ctx_->get_event();
       hip_check(hipEventRecord(landed[sl], copy_stream), "hipEventRecord");
     }
+    // the NULL counts first (a few bytes, behind the last slice): the host learns from them which bitmaps have to cross at all
+    hipEvent_t nulls_landed = ctx_->get_event();
+    struct PutEvent { Context* c; hipEvent_t e; ~PutEvent() { c->put_event(e); } } put_nulls{ctx_, nulls_landed};
+    hip_check(hipMemcpyAsync(h_block + off_nulls, d_block + (off_nulls - direct_begin), std::max<size_t>(n_cols, 1) * 8, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(null counts)");
+    hip_check(hipEventRecord(nulls_landed, copy_stream), "hipEventRecord");
     hip_check(hipMemcpyAsync(h_block + direct_begin, d_block, direct_copy_bytes, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(result)");
+    auto copy_bitmaps = [&] {  // (queued behind the direct part, which is still crossing when the counts are known)
+      hip_check(hipEventSynchronize(nulls_landed), "hipEventSynchronize(null counts)");
+      const unsigned long long* nulls = (const unsigned long long*)(h_block + off_nulls);
+      for (size_t c = 0; c < n_cols; c++)
+        if (nulls[c] != 0)
+          hip_check(hipMemcpyAsync(h_block + off_bits[c], d_block + (off_bits[c] - direct_begin), (size_t)(n + 7) / 8, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(validity bitmap)");
+    };
+    if (n_narrow == 0) copy_bitmaps();
     if (n_narrow > 0) {
       // one task = one narrow column of one slice
       std::vector<size_t> narrow_cols;
@@ -710,6 +744,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
       };
       const int n_threads = host_threads_for((size_t)n * n_narrow);
       if (n_threads <= 0) {
+        copy_bitmaps();
         hip_check(hipStreamSynchronize(copy_stream), "hipStreamSynchronize(copy queue)");
         for (size_t t = 0; t < n_tasks; t++) run_task(t);
       } else {
@@ -738,7 +773,10 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
         }
         if (pt.on) pt.mark("finish: slices landed");
         if (err != hipSuccess) failed.store(true);
-        else work();  // this thread helps with what is left
+        else {
+          try { copy_bitmaps(); } catch (...) { failed.store(true); for (std::thread& w : workers) w.join(); throw; }
+          work();  // this thread helps with what is left
+        }
         for (std::thread& w : workers) w.join();
         hip_check(err, "hipEventSynchronize(narrow slice)");
       }
@@ -757,7 +795,8 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
       for (uint64_t i = 0; i < n; i++) if (v[i] >= 2ull) oc.values[i >> 3] |= (uint8_t)(1u << (i & 7));
     }
     if (gcols_[c].kind == 0 && gcols_[c].plain)  // plain string / binary key column: entry indices → offsets + bytes
-      set_plain_strings(&oc, (const uint32_t*)(h_block + off_key[c]), h_block + off_bits[c], (int64_t)n, gcols_[c].values, gcols_[c].value_format);
+      set_plain_strings(&oc, (const uint32_t*)(h_block + off_key[c]), ((const unsigned long long*)(h_block + off_nulls))[c] != 0 ? h_block + off_bits[c] : nullptr, (int64_t)n, gcols_[c].values,
+                        gcols_[c].value_format);
     oc.null_count = (int64_t)((const unsigned long long*)(h_block + off_nulls))[c];
   }
   for (size_t j = 0; j < aggs_.size() && n > 0; j++) {  // composite reducers: UNIQUE's validity, AND's bits
@@ -906,7 +945,7 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
   }
   const int dkw = layout.h_key_words_;
   const int n_vals = (int)(1 + aggs_.size());
-  const int rw = ((dkw + 1) & ~1) + 2 * n_vals;
+  const int rw = fdb_packed_row_words(dkw, n_vals);
   *row_words32 = rw;
   const uint64_t n = hash_groups();
   for (int p = 0; p < n_parts; p++) counts[p] = 0;
@@ -922,22 +961,20 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
   a.out = d_rows; a.counts = d_counts;
   a.n_cols = (int)gcols_.size(); a.entry_words = h_entry_words_; a.key_words = h_key_words_; a.dst_key_words = dkw; a.row_words32 = rw;
   a.n_vals = n_vals; a.n_parts = n_parts;
-  // pass 1: rows per partition
-  hip_check(hipMemsetAsync(d_counts, 0, FDB_MAX_PARTS * 8, stream_), "hipMemsetAsync(partition counts)");
-  a.scatter = 0;
-  hip_check(fdb_launch_hash_partition(a, stream_), "hash partition (count)");
+  a.in_words = std::min((h_key_used_ + 3) & ~3, h_key_words_);
+  bool same = dkw >= a.in_words && layout.gcols_.size() == gcols_.size();  // (a layout column we do not have would keep what our tuple holds at its word)
+  for (size_t sc = 0; sc < gcols_.size(); sc++) if (cols[sc].src_word != cols[sc].word) same = false;
+  a.same_layout = same;
+  // counts per (wave, partition) → region bases → scatter: three launches back to back, one wait
+  void* d_part_scratch = ctx_->dev_alloc(fdb_hash_partition_scratch_bytes(device_, a));
+  scratch_.push_back(d_part_scratch);
+  hip_check(fdb_launch_hash_partition(a, device_, d_part_scratch, stream_), "hash partition");
   unsigned long long h_counts[FDB_MAX_PARTS];
   hip_check(hipMemcpyAsync(h_counts, d_counts, (size_t)n_parts * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(partition counts)");
-  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-  // pass 2: region bases become the running cursors
-  unsigned long long bases[FDB_MAX_PARTS] = {0};
+  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // the caller reads the rows next
   unsigned long long run = 0;
-  for (int p = 0; p < n_parts; p++) { bases[p] = run; run += h_counts[p]; counts[p] = (int64_t)h_counts[p]; }
+  for (int p = 0; p < n_parts; p++) { run += h_counts[p]; counts[p] = (int64_t)h_counts[p]; }
   if (run != n) throw Error(FDB_ERR_DEVICE, "internal: partition counts do not add up to the group count");
-  hip_check(hipMemcpyAsync(d_counts, bases, (size_t)n_parts * 8, hipMemcpyHostToDevice, stream_), "hipMemcpyAsync(partition bases)");
-  a.scatter = 1;
-  hip_check(fdb_launch_hash_partition(a, stream_), "hash partition (scatter)");
-  hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");  // `bases` is a stack array; the caller reads the rows next
   *dev_rows = d_rows;
 }
 
@@ -952,7 +989,7 @@ void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
   hash_reserve((uint64_t)n_rows);
   if (pt.on) { hip_check(hipStreamSynchronize(stream_), "sync"); pt.mark("import: reserve"); }
   const int kw = h_key_words_, n_vals = (int)(1 + aggs_.size());
-  const int rw = ((kw + 1) & ~1) + 2 * n_vals;
+  const int rw = fdb_packed_row_words(kw, n_vals);
   std::vector<FdbHashCol> cols(std::max<size_t>(gcols_.size(), 1));
   for (size_t c = 0; c < gcols_.size(); c++) {
     FdbHashCol& C = cols[c];
@@ -961,36 +998,87 @@ void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
     C.k1 = fdb_fp_k1((int)c); C.k2 = fdb_fp_k2((int)c);
   }
   FdbHashMergeArgs m;
-  std::memset(&m, 0, sizeof(m));
+  hash_merge_args(&m, cols, rw);
   m.in_keys = (const uint32_t*)dev_rows;
-  m.entries = (const unsigned long long*)((const uint32_t*)dev_rows + ((kw + 1) & ~1));
+  m.entries = (const unsigned long long*)((const uint32_t*)dev_rows + kw);
   m.n = n_rows;
-  m.table = h_table_; m.keys = h_keys_; m.n_groups = h_count_dev_; m.mask = h_capacity_ - 1;
-  m.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
-  m.n_cols = (int)gcols_.size(); m.in_key_words = rw; m.in_entry_words = rw / 2; m.entry_words = h_entry_words_; m.key_words = h_key_words_;
-  m.n_aggs = (int)aggs_.size();
-  for (size_t j = 0; j < aggs_.size(); j++) {
-    const int32_t f = aggs_[j].func;
-    m.funcs[j] = f == FDB_AGG_COUNT ? (final_stage_ ? 1 : 0) : f == FDB_AGG_SUM ? (aggs_[j].type == FDB_T_F64 ? 2 : 1) : f == FDB_AGG_MIN ? 3 : 4;
-  }
-  hip_check(fdb_launch_hash_merge(m, stream_), "hash merge");
+  m.in_key_words = rw; m.in_entry_words = rw / 2;
+  m.unique_source = 0;  // (rows of several ranks: a group comes once per rank that saw it)
+  hip_check(fdb_launch_hash_merge(m, device_, stream_), "hash merge");
   hip_check(hipStreamSynchronize(stream_), "sync(hash import)");  // the caller may free `dev_rows` when this returns
   pt.mark("import: merge kernel");
   state_dirty_ = true;
+}
+
+// Table into table, on the device, in ONE pass over the source's slots: the merge kernel reads the occupied tuples where they lie,
+// re-keys them into this plan's key ids (per-column LUTs; none for a column whose dictionaries agree value for value) and inserts /
+// folds them here. No packed intermediate (rounds 2-5 exported rows and imported them: two more passes over every tuple).
+void Plan::merge_hash_tables(Plan& src) {
+  if (src.device_ != device_) throw Error(FDB_ERR_INVALID, "source plan lives on another device");
+  if (src.aggs_.size() != aggs_.size()) throw Error(FDB_ERR_INVALID, "plans have different aggregations");
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  src.hash_layout();
+  if (mode_ == TableMode::DENSE) switch_to_hash();  // (before the column set changes: the dense slot decoding needs the old one)
+  const uint64_t n_src = src.h_table_ != nullptr ? src.hash_groups() : 0;
+  // adopt the source's columns and dictionary values
+  std::vector<int> dst_of(src.gcols_.size());
+  std::vector<std::vector<uint32_t>> id_map(src.gcols_.size());
+  for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+    const GroupColState& sg = src.gcols_[sc];
+    size_t gi = 0;
+    for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == sg.name) break;
+    if (gi == gcols_.size()) {
+      GroupColState g;
+      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.is_u64 = sg.is_u64; g.plain = sg.plain; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      gcols_.push_back(std::move(g));
+    }
+    GroupColState& g = gcols_[gi];
+    if (g.kind != sg.kind || g.plain != sg.plain || g.is_bool != sg.is_bool || g.is_u64 != sg.is_u64) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
+    dst_of[sc] = (int)gi;
+    if (sg.kind == 0) {
+      g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());
+      bool identity = true;
+      id_map[sc].assign(sg.values.size() + 1, 0);
+      for (size_t v = 0; v < sg.values.size(); v++) { id_map[sc][v + 1] = g.intern(sg.values[v]); identity = identity && id_map[sc][v + 1] == (uint32_t)(v + 1); }
+      if (identity) id_map[sc].clear();
+    }
+  }
+  if (gcols_.size() > FDB_MAX_HASH_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "too many group columns");
+  hash_layout();
+  if (n_src == 0) { hash_reserve(0); return; }
+  if (h_count_dev_ != nullptr) hash_groups();
+  hash_reserve(n_src);
+  std::vector<FdbHashCol> cols(std::max<size_t>(gcols_.size(), 1));
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    std::memset(&cols[c], 0, sizeof(FdbHashCol));
+    cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c; cols[c].src_word = -1; cols[c].lut_lds = FDB_NO_LDS;
+    cols[c].k1 = fdb_fp_k1((int)c); cols[c].k2 = fdb_fp_k2((int)c);
+  }
+  for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+    FdbHashCol& C = cols[(size_t)dst_of[sc]];
+    C.src_word = src.gcols_[sc].word;
+    if (src.gcols_[sc].kind == 0) { if (!id_map[sc].empty()) C.lut = (const uint32_t*)upload(id_map[sc].data(), id_map[sc].size() * 4); }
+    else C.lut_len = (uint32_t)sc;  // the source plan's column index: the bit of the incoming valid mask
+  }
+  FdbHashMergeArgs m;
+  hash_merge_args(&m, cols, src.h_key_words_);
+  m.src_table = src.h_table_; m.src_keys = src.h_keys_; m.src_capacity = src.h_capacity_;
+  m.src_key_words = src.h_key_words_; m.src_entry_words = src.h_entry_words_;
+  m.unique_source = 1;
+  // the source's stream may still be writing its table
+  src.sync();
+  hip_check(fdb_launch_hash_merge(m, device_, stream_), "hash merge (table)");
+  state_dirty_ = true;
+  h_groups_bound_ += n_src;
+  h_bound_stale_ = true;
+  sync();  // the caller may close `src` when this returns
 }
 
 // ≙ Synchronizer + final stage when either side holds a hash table: the source's occupied groups are re-keyed into
 // this plan's key ids on the device (per-column translation LUTs) and merged with atomics.
 void Plan::merge_hash(Plan& src) {
   runs_to_table();
-  if (src.mode_ == TableMode::HASH) {  // device only: re-key + pack on the source, merge here
-    void* rows = nullptr;
-    int64_t n = 0;
-    int32_t rw = 0;
-    src.hash_export(*this, 1, &rows, &n, &rw);
-    hash_import(rows, n);
-    return;
-  }
+  if (src.mode_ == TableMode::HASH) { merge_hash_tables(src); return; }
   CompactState cs;
   src.fetch_compact(&cs);
   if (cs.n == 0) return;
@@ -1341,7 +1429,7 @@ void Plan::runs_to_table() {
     cols[c].src_word = gcols_[c].word;  // the expanded rows already have the table's own tuple layout
     if (gcols_[c].kind != 0) cols[c].lut_len = (uint32_t)c;  // (int64 / computed keys: the bit of the incoming valid mask — hash_merge_kernel reads it from lut_len)
   }
-  hash_merge_device(d_entries, d_keys, v.n_runs, kw, cols);
+  hash_merge_device(d_entries, d_keys, v.n_runs, kw, cols, /*unique_source=*/false);  // (a key may come back in a later run)
   ctx_->flush_staging();
   h_groups_bound_ += (uint64_t)v.n_runs;
   h_bound_stale_ = true;

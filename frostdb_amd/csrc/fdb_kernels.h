@@ -328,17 +328,26 @@ struct FdbHashColumnsArgs {
 hipError_t fdb_launch_hash_gather_rows(const FdbHashColumnsArgs& args, int device, hipStream_t stream);      // pass 1: all rows
 hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream);  // pass 2: rows [row_begin, row_end)
 
-// Inserts / merges `n` pre-aggregated entries (hash_compact's layout: {count, acc…} per entry + key tuples of
-// `in_key_words` words) into the table. cols[c] describes destination column c: where its words sit in the incoming
-// tuple (src_word), and a LUT translating incoming dictionary key ids. funcs[j]: 1 add u64, 2 add f64, 3 min i64, 4 max i64, 0 skip.
+// Merges pre-aggregated groups into the table (fdb_merge.hip). Two kinds of source:
+//   packed rows — `n` entries ({count, acc…}, in_entry_words × 8 bytes apart) + key tuples (in_key_words × 4 bytes apart);
+//   a table     — src_table / src_keys / src_capacity, scanned in place (≙ the Synchronizer feeding a final-stage aggregate from a
+//                 second chain's table: no packed intermediate).
+// cols[c] describes DESTINATION column c: where its words sit in the incoming tuple (src_word, -1 = absent ⇒ NULL), a LUT
+// translating incoming dictionary key ids (nullptr = identity) and, for int64 columns, its bit in the incoming valid mask (lut_len).
+// funcs[j]: 1 add u64, 2 add f64, 3 min i64, 4 max i64, 0 skip.
 struct FdbHashMergeArgs {
   const unsigned long long* entries; const uint32_t* in_keys; int64_t n;
+  const unsigned long long* src_table; const uint32_t* src_keys; uint64_t src_capacity;
   unsigned long long* table; uint32_t* keys; unsigned long long* n_groups; uint64_t mask;
   const FdbHashCol* cols;   // device array [n_cols]
   int32_t n_cols, in_key_words, in_entry_words, entry_words, key_words, n_aggs;
+  int32_t src_key_words, src_entry_words;
+  int32_t in_words;       // words of an incoming tuple that the columns reach (0: its whole stride)
+  int32_t same_layout;    // every destination column sits at the same word of the incoming tuple, none is absent: translated in place
+  int32_t unique_source;  // every incoming group occurs once (a table, rows exported from ONE table): a new slot takes plain stores
   int32_t funcs[FDB_MAX_AGGS];
 };
-hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t stream);
+hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, int device, hipStream_t stream);
 
 // ---- Finish of a run store (fdb_kernels.hip: runs_*_kernel) ---------------------------------------------------------------------
 // A plan's runs live in SEGMENTS (one per launch), each with its own directory. Logical order = segments in launch order, within
@@ -408,20 +417,28 @@ hipError_t fdb_launch_fill_u64(unsigned long long* p, int64_t n, unsigned long l
 // Export of a hash table for a merge elsewhere (another plan on this device, or — hash-partitioned — other ranks over RCCL):
 // every occupied entry is re-keyed into the DESTINATION layout (per-column id translation, destination word positions and
 // column indices), its fingerprint is recomputed there, and the entry is written as one packed row
-//   [destination key tuple: dst_key_words × u32, padded to an even count | count | accumulators … ]   (row_words32 words)
+//   [destination key tuple: dst_key_words × u32 | count | accumulators … | padding to a multiple of 16 bytes ]   (row_words32 words)
 // into the region of the partition that owns it: partition = (fingerprint hi >> 32) % n_parts. The table slot uses the low
 // bits of the OTHER fingerprint half, so partitions stay uniformly spread inside each receiver's table.
 // cols[c] describes SOURCE column c: kind, word (source), src_word (DESTINATION word), gi (DESTINATION column index),
 // lut (source id → destination id, nullptr = identity), lut_len (SOURCE column index: bit of the source valid mask), k1/k2 (of gi).
+// Three launches without a host round trip: per-(wave, partition) counts, their prefix sums (region bases: partitions back to back,
+// waves in order inside a partition — no atomics, so the rows of a partition are in SLOT order), the scatter. `counts` receives the
+// rows per partition.
 #define FDB_MAX_PARTS 64
+static inline int fdb_packed_row_words(int dst_key_words, int n_vals) { return (dst_key_words + 2 * n_vals + 3) & ~3; }  // (dst_key_words is a multiple of 4: values are 8-byte aligned, rows 16-byte)
 struct FdbHashPartArgs {
   const unsigned long long* table; const uint32_t* keys; uint64_t capacity;
   const FdbHashCol* cols;       // device array [n_cols]
-  uint32_t* out;                // packed rows (scatter pass)
-  unsigned long long* counts;   // [n_parts] rows per partition (count pass: incremented; scatter pass: running cursors, start = region base)
-  int32_t n_cols, entry_words, key_words, dst_key_words, row_words32, n_vals, n_parts, scatter;
+  uint32_t* out;                // packed rows, 16-byte aligned
+  unsigned long long* counts;   // [n_parts] rows per partition (written by the launch)
+  unsigned long long* wave_bases; uint32_t* wave_counts;  // (set by fdb_launch_hash_partition from its scratch)
+  int32_t n_cols, entry_words, key_words, dst_key_words, row_words32, n_vals, n_parts;
+  int32_t in_words;     // words of a source tuple that the columns reach (0: the whole stride)
+  int32_t same_layout;  // source and destination tuples have one layout
 };
-hipError_t fdb_launch_hash_partition(const FdbHashPartArgs& args, hipStream_t stream);
+size_t fdb_hash_partition_scratch_bytes(int device, const FdbHashPartArgs& args);
+hipError_t fdb_launch_hash_partition(const FdbHashPartArgs& args, int device, void* scratch, hipStream_t stream);
 #endif  // FDB_DEVICE_ONLY
 
 // Identity elements stored in accumulators. MIN/MAX over float64 run on order-preserving int64 keys

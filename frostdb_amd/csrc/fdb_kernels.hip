@@ -1040,11 +1040,24 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
     for (int c = 0; c < a.n_cols; c++) {
       const FdbHashCol C = load_col(a.cols, c);
       unsigned char* out = out_key[c];
-      const int width = C.src_word;  // (transport width of the column: 1, 2, 4 or 8 bytes)
+      const int width = C.src_word;  // (transport width of the column: 1, 2, 4 or 8 bytes; −2 / −4: that many BITS per index)
       // sliced columns: [slice][column][row in slice] — a slice of all narrow columns is one contiguous run for the copy engine
-      const uint64_t at = C.lut_len ? (o >> a.slice_shift) * a.slice_stride + (o & ((1ull << a.slice_shift) - 1ull)) * (uint64_t)width : o * (uint64_t)width;
+      const uint64_t in_slice = C.lut_len ? (o & ((1ull << a.slice_shift) - 1ull)) : o;
+      const uint64_t at = (C.lut_len ? (o >> a.slice_shift) * a.slice_stride : 0ull) + (width > 0 ? in_slice * (uint64_t)width : (in_slice * (uint64_t)(-width)) >> 3);
       bool ok = false;
-      if (active) {
+      if (width < 0) {  // (wave-uniform) sub-byte indices: 16 / 8 lanes fold theirs into one 32-bit word, the first of them stores it
+        const uint32_t id = active ? k[C.word] : 0u;
+        ok = id != 0u;
+        uint32_t x = id ? id - 1u : 0u;
+        if (width == -2) {
+          x |= (uint32_t)__shfl_down((int)x, 1, 64) << 2; x |= (uint32_t)__shfl_down((int)x, 2, 64) << 4;
+          x |= (uint32_t)__shfl_down((int)x, 4, 64) << 8; x |= (uint32_t)__shfl_down((int)x, 8, 64) << 16;
+          if ((lane & 15) == 0 && (uint32_t)lane < rows) *reinterpret_cast<uint32_t*>(out + at) = x;
+        } else {
+          x |= (uint32_t)__shfl_down((int)x, 1, 64) << 4; x |= (uint32_t)__shfl_down((int)x, 2, 64) << 8; x |= (uint32_t)__shfl_down((int)x, 4, 64) << 16;
+          if ((lane & 7) == 0 && (uint32_t)lane < rows) *reinterpret_cast<uint32_t*>(out + at) = x;
+        }
+      } else if (active) {
         if (C.kind == 0) {
           const uint32_t id = k[C.word];
           const uint32_t idx = id ? id - 1u : 0u;
@@ -1101,125 +1114,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(uint32_t* __restrict__ 
   for (int k = 0; k < 4; k++) { if (i0 + k < n) counts[i0 + k] = run; run += v[k]; }
 }
 
-__global__ void hash_merge_kernel(const FdbHashMergeArgs m) {
-  __shared__ unsigned int s_new;
-  if (threadIdx.x == 0) s_new = 0;
-  __syncthreads();
-  const int ew = m.entry_words, kw = m.key_words, ikw = m.in_key_words;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t* in = m.in_keys + i * (int64_t)ikw;
-    unsigned long long h1 = 0, h2 = 0, vmask = 0;
-    for (int c = 0; c < m.n_cols; c++) {  // translate the incoming tuple column by column
-      const FdbHashCol C = load_col(m.cols, c);
-      if (C.src_word < 0) continue;
-      if (C.kind == 0) {
-        uint32_t id = in[C.src_word];
-        if (id != 0 && C.lut != nullptr) id = C.lut[id];
-        if (id != 0) { fp_add32(h1, h2, C.k1, C.k2, id); vmask |= 1ull << C.gi; }
-      } else {
-        const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
-        if ((in_mask >> C.lut_len) & 1ull) {  // lut_len carries the SOURCE plan's column index for int64 columns
-          const unsigned long long v = (unsigned long long)in[C.src_word] | ((unsigned long long)in[C.src_word + 1] << 32);
-          if (v != 0ull) fp_add(h1, h2, C.k1, C.k2, v);
-          vmask |= 1ull << C.gi;
-        }
-      }
-    }
-    fp_final(h1, h2);
-    bool inserted;
-    const uint64_t slot = hash_find_or_insert(m.table, m.mask, ew, h1, h2, inserted);
-    if (inserted) {
-      uint32_t* dst = m.keys + slot * (uint64_t)kw;
-      dst[0] = (uint32_t)vmask; dst[1] = (uint32_t)(vmask >> 32);
-      for (int c = 0; c < m.n_cols; c++) {
-        const FdbHashCol C = load_col(m.cols, c);
-        if (C.kind == 0) {
-          uint32_t id = C.src_word >= 0 ? in[C.src_word] : 0u;
-          if (id != 0 && C.lut != nullptr) id = C.lut[id];
-          dst[C.word] = id;
-        } else {
-          dst[C.word] = C.src_word >= 0 ? in[C.src_word] : 0u;
-          dst[C.word + 1] = C.src_word >= 0 ? in[C.src_word + 1] : 0u;
-        }
-      }
-      atomicAdd(&s_new, 1u);
-    }
-    const unsigned long long* e = m.entries + i * (int64_t)m.in_entry_words;
-    unsigned long long* d = m.table + slot * (uint64_t)ew;
-    atomicAdd(d + 2, e[0]);
-    for (int j = 0; j < m.n_aggs; j++) {
-      const int f = m.funcs[j];
-      const unsigned long long v = e[1 + j];
-      if (f == 1) atomicAdd(d + 3 + j, v);
-      else if (f == 2) atomicAdd(reinterpret_cast<double*>(d + 3 + j), __longlong_as_double((long long)v));
-      else if (f == 3) atomicMin(reinterpret_cast<long long*>(d + 3 + j), (long long)v);
-      else if (f == 4) atomicMax(reinterpret_cast<long long*>(d + 3 + j), (long long)v);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && s_new != 0) atomicAdd(m.n_groups, (unsigned long long)s_new);
-}
-
-// See FdbHashPartArgs. Two launches: scatter = 0 counts rows per partition, scatter = 1 writes them (the host turns the
-// counts into region bases in between). Per-partition positions are reserved per workgroup (LDS histogram → one global
-// atomic per partition and workgroup), so 10 M entries do not fight over ≤ 64 counters.
-__global__ __launch_bounds__(256) void hash_partition_kernel(const FdbHashPartArgs p) {
-  __shared__ unsigned int s_cnt[FDB_MAX_PARTS];
-  __shared__ unsigned long long s_base[FDB_MAX_PARTS];
-  const int ew = p.entry_words, kw = p.key_words;
-  const uint64_t per_block = (p.capacity + gridDim.x - 1) / gridDim.x;
-  const uint64_t b0 = (uint64_t)blockIdx.x * per_block, b1 = min(p.capacity, b0 + per_block);
-  for (uint64_t base = b0; base < b1; base += 256) {  // one batch of 256 slots at a time (block-uniform trip count)
-    if (threadIdx.x < FDB_MAX_PARTS) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t i = base + threadIdx.x;
-    const bool occ = i < b1 && p.table[i * (uint64_t)ew] != 0ull;
-    unsigned long long h1 = 0, h2 = 0, vmask = 0;
-    uint32_t part = 0, local = 0;
-    const uint32_t* in = p.keys + i * (uint64_t)kw;
-    if (occ) {
-      const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
-      for (int c = 0; c < p.n_cols; c++) {
-        const FdbHashCol C = load_col(p.cols, c);
-        if (C.kind == 0) {
-          uint32_t id = in[C.word];
-          if (id != 0 && C.lut != nullptr) id = C.lut[id];
-          if (id != 0) { fp_add32(h1, h2, C.k1, C.k2, id); vmask |= 1ull << C.gi; }
-        } else if ((in_mask >> C.lut_len) & 1ull) {
-          const unsigned long long v = (unsigned long long)in[C.word] | ((unsigned long long)in[C.word + 1] << 32);
-          if (v != 0ull) fp_add(h1, h2, C.k1, C.k2, v);
-          vmask |= 1ull << C.gi;
-        }
-      }
-      fp_final(h1, h2);
-      part = (uint32_t)((h2 >> 32) % (unsigned long long)p.n_parts);
-      local = atomicAdd(&s_cnt[part], 1u);
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < p.n_parts && s_cnt[threadIdx.x] != 0) s_base[threadIdx.x] = atomicAdd(&p.counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (occ && p.scatter) {
-      uint32_t* row = p.out + (s_base[part] + local) * (unsigned long long)p.row_words32;
-      for (int w = 0; w < p.dst_key_words; w++) row[w] = 0u;
-      row[0] = (uint32_t)vmask; row[1] = (uint32_t)(vmask >> 32);
-      const unsigned long long in_mask = (unsigned long long)in[0] | ((unsigned long long)in[1] << 32);
-      for (int c = 0; c < p.n_cols; c++) {
-        const FdbHashCol C = load_col(p.cols, c);
-        if (C.kind == 0) {
-          uint32_t id = in[C.word];
-          if (id != 0 && C.lut != nullptr) id = C.lut[id];
-          row[C.src_word] = id;
-        } else if ((in_mask >> C.lut_len) & 1ull) {
-          row[C.src_word] = in[C.word]; row[C.src_word + 1] = in[C.word + 1];
-        }
-      }
-      unsigned long long* vals = reinterpret_cast<unsigned long long*>(row + ((p.dst_key_words + 1) & ~1));
-      const unsigned long long* e = p.table + i * (uint64_t)ew;
-      for (int v = 0; v < p.n_vals; v++) vals[v] = e[2 + v];
-    }
-    __syncthreads();
-  }
-}
+// (hash_merge / hash_partition: fdb_merge.hip)
 
 __global__ void fill_u64_kernel(unsigned long long* dst, unsigned long long value, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = value;
@@ -2472,13 +2367,6 @@ hipError_t fdb_launch_scan_hash(const FdbHashArgs& args, int grid_blocks, size_t
   return hipGetLastError();
 }
 
-hipError_t fdb_launch_hash_partition(const FdbHashPartArgs& args, hipStream_t stream) {
-  if (args.capacity == 0) return hipSuccess;
-  int blocks = (int)std::min<uint64_t>((args.capacity + 255) / 256, 4096);
-  hipLaunchKernelGGL(hash_partition_kernel, dim3(blocks), dim3(256), 0, stream, args);
-  return hipGetLastError();
-}
-
 hipError_t fdb_launch_hash_init(unsigned long long* table, uint64_t capacity, int entry_words, int n_aggs, const unsigned long long* idents,
                                 hipStream_t stream) {
   HashIdents id;
@@ -2508,14 +2396,6 @@ hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32
                                    unsigned long long* out_entries, uint32_t* out_keys, const uint32_t* bases, hipStream_t stream) {
   hipLaunchKernelGGL(hash_compact_kernel, dim3(4096), dim3(256), 0, stream, table, keys, capacity, entry_words, key_words, out_entries, out_keys,
                      bases);
-  return hipGetLastError();
-}
-
-hipError_t fdb_launch_hash_merge(const FdbHashMergeArgs& args, hipStream_t stream) {
-  if (args.n <= 0) return hipSuccess;
-  int blocks = (int)((args.n + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(hash_merge_kernel, dim3(blocks), dim3(256), 0, stream, args);
   return hipGetLastError();
 }
 

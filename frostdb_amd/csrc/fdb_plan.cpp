@@ -1048,6 +1048,8 @@ Plan::Knobs::Knobs() {
   runs_wide = w != nullptr ? (w[0] == '1' ? '1' : 'm') : 0;
   const char* e = std::getenv("FDB_ORDERED_SORT_MIN");
   ordered_sort_min = e != nullptr ? std::max<long long>(0, std::atoll(e)) : 4096;
+  const char* fs = std::getenv("FDB_FINISH_SLICE_SHIFT");
+  finish_slice_shift = fs != nullptr ? std::max(6, std::min(20, std::atoi(fs))) : 20;
 }
 
 void Plan::push(const ArrowArray* array, const ArrowSchema* schema) {
@@ -1967,6 +1969,11 @@ std::unique_ptr<DeviceBatch> Plan::finish_batch(int64_t* n_rows) {
 }
 
 int64_t Plan::num_groups() {
+  if (mode_ == TableMode::HASH && runs_.empty()) {  // the table counts its own inserts: one 8-byte read behind the stream (a compaction of 10 M groups took 3 s)
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (h_table_ == nullptr || h_count_dev_ == nullptr) { sync(); return 0; }
+    return (int64_t)hash_groups();
+  }
   CompactState cs;
   fetch_compact(&cs);
   return cs.n;

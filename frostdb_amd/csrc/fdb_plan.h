@@ -348,6 +348,7 @@ class Plan {
     bool no_jit, runs_always, no_identity_lut, runs_no_sort, no_uniform_fold;
     char runs_wide;             // 0 unset, '1' wide records every launch, 'm' medium where narrow would do
     long long ordered_sort_min; // groups from which an ordered Finish out of the table sorts on the device
+    int finish_slice_shift;     // log2 of the rows per Finish slice ($FDB_FINISH_SLICE_SHIFT: tests reach several slices with a small result), 20
     Knobs();
   } knobs_;
   int64_t fresh_groups_ = -1;   // hash_groups() as just fetched by ordered_finish_on_device(), for the finish_columns_hash that follows at once
@@ -356,7 +357,9 @@ class Plan {
   unsigned long long* sort_by_group_columns(unsigned long long* order, int64_t n_things, const FdbRunSegs* segs, const uint32_t* rows, int row_kw, RunsView* tables,
                                             std::vector<void*>* owned);
   int32_t runs_func() const;  // how two runs' aggregates fold (FdbRunsExpandArgs.func)
-  void hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols);
+  void hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols, bool unique_source);
+  void hash_merge_args(FdbHashMergeArgs* m, const std::vector<FdbHashCol>& cols, int in_stride_words);
+  void merge_hash_tables(Plan& src);
   int64_t finish_columns_runs(std::vector<OutColumn>* cols, DeviceBatch* resident, bool* ok);
   void fetch_compact_hash(CompactState* cs);
   int64_t finish_columns_hash(std::vector<OutColumn>* cols, DeviceBatch* resident = nullptr, const RunsView* runs = nullptr);  // device-side column materialisation (big result sets)

@@ -87,8 +87,40 @@ uint32_t copy_stream_max_u32(uint32_t* dst, const uint32_t* src, size_t n) {
   return m;
 }
 
+namespace {
+// Sub-byte indices (2 / 4 bits per row, low bits first): one table entry per source byte holds its 4 / 2 indices as uint32.
+struct SubByteTables {
+  alignas(16) uint32_t two[256][4];
+  alignas(8) uint32_t four[256][2];
+  SubByteTables() {
+    for (int b = 0; b < 256; b++) {
+      for (int k = 0; k < 4; k++) two[b][k] = (uint32_t)(b >> (2 * k)) & 3u;
+      four[b][0] = (uint32_t)b & 15u; four[b][1] = (uint32_t)b >> 4;
+    }
+  }
+};
+const SubByteTables& sub_byte_tables() { static const SubByteTables t; return t; }
+
+void widen_bits(const uint8_t* s, int bits, uint32_t* d, size_t n) {
+  const SubByteTables& T = sub_byte_tables();
+  size_t i = 0;
+  if (bits == 2) {
+    if (((uintptr_t)d & 15u) == 0) {
+      for (; i + 4 <= n; i += 4) _mm_stream_si128((__m128i*)(d + i), _mm_load_si128((const __m128i*)T.two[s[i >> 2]]));
+      _mm_sfence();
+    }
+    for (; i < n; i++) d[i] = (uint32_t)(s[i >> 2] >> (2 * (i & 3))) & 3u;
+  } else {
+    for (; i + 2 <= n; i += 2) std::memcpy(d + i, T.four[s[i >> 1]], 8);
+    for (; i < n; i++) d[i] = (uint32_t)(s[i >> 1] >> (4 * (i & 1))) & 15u;
+  }
+}
+}  // namespace
+
+// width: 1 / 2 / 4 bytes per index, or −2 / −4: that many BITS per index (rows packed low bits first)
 void widen_indices(const void* src, int width, uint32_t* dst, size_t n) {
   static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (width < 0) return widen_bits((const uint8_t*)src, -width, dst, n);
   if (width == 1) {
     if (avx2) return widen8_avx2((const uint8_t*)src, dst, n);
     const uint8_t* s = (const uint8_t*)src;

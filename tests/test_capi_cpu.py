@@ -152,6 +152,21 @@ def test_widening_of_narrow_result_indices(built_lib):
                 assert rc == 0
                 assert np.array_equal(dst, src.astype(np.uint32)), (width, n, shift)
                 assert np.array_equal(raw[base + shift + n: base + shift + n + 4], guard_after)  # nothing written past the end
+    # sub-byte transport: 2 / 4 bits per index, rows packed low bits first
+    for bits in (2, 4):
+        for n in (0, 1, 3, 4, 5, 15, 16, 17, 64, 1000, 4099):
+            for shift in (0, 1, 2):
+                vals = rng.integers(0, 1 << bits, n, dtype=np.uint32)
+                packed = np.zeros((n * bits + 7) // 8 + 1, dtype=np.uint8)
+                for i, v in enumerate(vals):
+                    packed[(i * bits) >> 3] |= np.uint8(int(v) << ((i * bits) & 7))
+                raw = np.zeros(n + 32, dtype=np.uint32)
+                base = (-raw.ctypes.data // 4) % 16
+                dst = raw[base + shift: base + shift + n]
+                rc = built_lib.fdb_selftest_widen(ctypes.c_void_p(packed.ctypes.data), ctypes.c_int32(-bits), ctypes.c_void_p(dst.ctypes.data), ctypes.c_int64(n))
+                assert rc == 0
+                assert np.array_equal(dst, vals), (bits, n, shift)
+                assert not raw[base + shift + n: base + shift + n + 4].any()
     assert built_lib.fdb_selftest_widen(None, ctypes.c_int32(3), None, ctypes.c_int64(0)) == 1
 
 

@@ -671,7 +671,7 @@ def test_wide_run_records_written_before_the_plan_gains_a_column_read_null_there
                 k.close()
         assert kernels == ["fdb_hash_kernel(runs, wide)"] * 3, kernels
         h, _ = _run_plan(pp, recs, Sum(Col("v")), [DynCol("labels")], ordered=False, resident=True)
-        assert sorted(_rows(o), key=repr) == sorted(_rows(h), key=repr) and o.num_rows > 300
+        assert sorted(_rows(o), key=repr) == sorted(_rows(h), key=repr) and o.num_rows > 100  # (columns sorted one by one: ≈ the sum of their cardinalities)
         # every group that came from the 3-column records has labels.d = NULL
         d = o.column(o.schema.get_field_index("labels.d"))
         assert d.null_count > 0
