@@ -551,6 +551,52 @@ def emit(text):
 
 
 # ---- the secondary measurements of the default N = 1 run (other_configs) --------------------------------------------------------
+def oracle_aggregate(records, filt, aggs, groups):
+    """oracle.OraclePlan.execute (the reference's chains → Synchronizer → final stage, restated on the CPU — the checker) over `records`."""
+    import oracle  # noqa: F401
+    from oracle import OracleBatch, OraclePlan
+    threads, bs = os.cpu_count() or 1, 65536
+    batches = [OracleBatch.from_arrow(r.slice(o, min(bs, r.num_rows - o))) for r in records for o in range(0, r.num_rows, bs)]
+    plan = OraclePlan(filt, aggs, groups, nchains=threads)
+    res = plan.execute(batches, threads)
+    want = res.to_arrow()
+    res.close(); plan.close()
+    for b in batches:
+        b.close()
+    return want
+
+
+class _PathKeyed:  # (what compare_with_oracle needs to know about a cfg 2-shaped result)
+    config, ordered = 2, False
+
+
+def oracle_filter_parity(rec, filt, got, max_rows=1 << 23):
+    """The oracle's filter() (filter.go:276-354 restated) over the first rows of `rec` against the first rows of the device's compacted
+    record `got` — every column, bit for bit (the device record is the filter of the WHOLE record: its first k rows are the filter of
+    the first rows that hold k selected ones)."""
+    import oracle  # noqa: F401
+    from oracle import OraclePlan
+    head = rec.slice(0, min(max_rows, rec.num_rows))
+    plan = OraclePlan(filt)
+    out, idx = plan.filter(head)
+    plan.close()
+    want = out.to_arrow() if out is not None else None
+    if out is not None:
+        out.close()
+    k = len(idx)
+    assert want is None or want.num_rows == k
+    g = got.slice(0, k)
+    for name in rec.schema.names:
+        if k == 0:
+            break
+        a, b = g.column(g.schema.get_field_index(name)), want.column(want.schema.get_field_index(name))
+        a = a.dictionary_decode() if hasattr(a, "dictionary_decode") else a
+        b = b.dictionary_decode() if hasattr(b, "dictionary_decode") else b
+        assert a.cast(b.type).equals(b) if a.type != b.type else a.equals(b), "oracle parity: filter() column %s differs" % name
+    return {"rows": head.num_rows, "selected": k, "what": "oracle.OraclePlan.filter over the first %d rows of the first record vs. the first %d rows of the device's "
+            "compacted record: every column equal, value for value" % (head.num_rows, k)}
+
+
 def measure_select(wl, steps=10, warmup=2, ceiling=None):
     """`filter()` on the device (filter.go:276-354 ≙ fdb_plan_filter_batch): `value > 500` (50 % selectivity) over the first
     100 M resident rows, every column compacted. Algorithmic bytes = filter column once + every selected value / validity bit read
@@ -578,6 +624,7 @@ def measure_select(wl, steps=10, warmup=2, ceiling=None):
     first = outs[0].to_arrow()
     v0 = wl.host_batches[0].column(wl.host_batches[0].schema.get_field_index("value")).to_numpy()
     assert first.column(first.schema.get_field_index("value")).to_numpy().tolist() == v0[v0 > SELECT_THRESHOLD].tolist()
+    oracle_checked = oracle_filter_parity(wl.host_batches[0], filt, first) if not wl.args.no_oracle_parity else None
     for o in outs:
         o.close()
     for _ in range(warmup):
@@ -608,7 +655,8 @@ def measure_select(wl, steps=10, warmup=2, ceiling=None):
                          "min_traffic_frac": (min_traffic * steps / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k_ms > 0 else 0.0,
                          "whole_step_frac": (k_bytes / steps) / (el / steps) / 1e9 / HBM_PEAK_GBS},
             "checked": {"selected_rows": sum(got), "first_record_values": "bit-identical to numpy's value[value > T]",
-                        "against": "numpy expectation (selected-row counts of every record; the first records' compacted values); not the oracle"}}
+                        "against": ("oracle filter() (first record) + " if oracle_checked else "") + "numpy expectation (selected-row counts of every record; the first record's compacted values)" + ("" if oracle_checked else "; not the oracle"),
+                        "oracle": oracle_checked}}
 
 
 def h2d_rate_gbs(device, nbytes=1 << 30):
@@ -750,11 +798,43 @@ def measure_host_records_chains(wl, rows_per_chain=2_097_152):
                 for ex in run.keep:
                     ex.close()
     out["checked"] = {"against": "numpy expectation: every group's sum over the rows the chains own (bench.py expected_cfg2), chains merged with fdb_plan_merge; not the oracle"}
+    if not wl.args.no_oracle_parity and wl.host_batches:
+        # the oracle on the path's own input: the first 2^21 host rows cut into 65 536-row records, pushed by 8 chains (one plan each, fdb_plan_push_many), merged
+        import threading as _th
+        head = wl.host_batches[0].slice(0, min(1 << 21, wl.host_batches[0].num_rows))
+        parts = [head.slice(o, min(65536, head.num_rows - o)) for o in range(0, head.num_rows, 65536)]
+        plans = [pp.HashAggregatePlan(wl.filt, wl.aggs, wl.groups, device=wl.device, desc=wl.desc) for _ in range(8)]
+        errs = []
+
+        def push(c):
+            try:
+                for r in parts[c::8]:
+                    plans[c].Callback(r)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+        ts = [_th.Thread(target=push, args=(c,)) for c in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        try:
+            if errs:
+                raise errs[0]
+            for p in plans[1:]:
+                plans[0].Merge(p)
+            got = plans[0].Finish()
+        finally:
+            for p in plans:
+                p.Close()
+        n_groups = compare_with_oracle(_PathKeyed, got, oracle_aggregate([head], wl.filt, wl.aggs, wl.groups))
+        out["checked"]["oracle"] = {"rows": head.num_rows, "groups": n_groups, "what": "oracle.OraclePlan.execute over the first %d host rows vs. 8 chains pushing them as 65 536-row "
+                                    "host records (fdb_plan_push), merged with fdb_plan_merge: group sets equal, float64 sums within 1e-9 relative" % head.num_rows}
+        out["checked"]["against"] = "oracle (first %d host rows through 8 chains) + " % head.num_rows + out["checked"]["against"].replace("; not the oracle", "")
     out["chain_threads"] = "8 and 32 chains: pinned to the cores of the GPU's NUMA node (physicalplan.pin_thread_near); 1 chain: where the scheduler put it" if pinned[0] else "not pinned (the GPU's local_cpulist could not be read or applied)"
     return out
 
 
-def measure_parquet(device, rows=20_000_000, passes=3):
+def measure_parquet(device, rows=20_000_000, passes=3, use_oracle=True):
     """Parquet row groups (file bytes in pinned host memory) → columns decoded on the device
     (fdb_batch_from_parquet) → cfg 2's query. Bytes = file bytes read + column bytes produced; host / device split from
     fdb_parquet_stats. Two files: UNCOMPRESSED + PLAIN, and SNAPPY pages + DELTA_BINARY_PACKED timestamps."""
@@ -772,6 +852,9 @@ def measure_parquet(device, rows=20_000_000, passes=3):
     t = pa.Table.from_batches([rec])
     t = t.set_column(0, "labels.code", t.column(0).cast(pa.binary())).set_column(1, "labels.path", t.column(1).cast(pa.binary()))
     q = (Col("labels.code") == "200", [Sum(Col("value"))], [Col("labels.path")])
+    # the oracle over the record the files are written from (every row group of both files decodes to it)
+    oracle_want = oracle_aggregate([rec], *q) if use_oracle else None
+    n_oracle = 0
     h2d = h2d_rate_gbs(device, 1 << 28)
     out = {"rows": rows, "measured_h2d_GBps": h2d}
     for variant, kw in (("plain", {}), ("delta_snappy", dict(compression="SNAPPY", column_encoding={"timestamp": "DELTA_BINARY_PACKED"},
@@ -806,6 +889,8 @@ def measure_parquet(device, rows=20_000_000, passes=3):
         for i, p in enumerate(synth.PATHS + [None]):
             if exp_cnt[i]:
                 assert math.isclose(got[p], exp_sum[i], rel_tol=1e-9), (variant, p)
+        if oracle_want is not None:
+            n_oracle = compare_with_oracle(_PathKeyed, res, oracle_want)
         s0 = pp.parquet_stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -820,7 +905,9 @@ def measure_parquet(device, rows=20_000_000, passes=3):
                         "file_GBps": fb / dt / 1e9, "file_plus_columns_GBps": (fb + ob) / dt / 1e9,
                         "host_part_ms": (s1["host_ms"] - s0["host_ms"]) / passes, "device_part_ms": (s1["device_ms"] - s0["device_ms"]) / passes,
                         "bound": "host" if (s1["host_ms"] - s0["host_ms"]) > (s1["device_ms"] - s0["device_ms"]) else "pcie", "frac_of_h2d": fb / dt / 1e9 / h2d,
-                        "checked": {"groups_out": res.num_rows, "against": "numpy expectation: every group's sum (bench.py expected_cfg2 on the record the file was written from); not the oracle"}}
+                        "checked": {"groups_out": res.num_rows,
+                                    "against": ("oracle (all %d rows of the record the file was written from: %d groups equal, sums within 1e-9 relative) + " % (rows, n_oracle) if oracle_want is not None else "")
+                                    + "numpy expectation: every group's sum (bench.py expected_cfg2 on the same record)" + ("" if oracle_want is not None else "; not the oracle")}}
         del pinned
     return out
 
@@ -916,7 +1003,7 @@ def other_configs(args, wl, rank, device, group, comm):
             "roofline": roofline_of(r7, 100_000_000, st2, "cfg2_sorted", ceiling), "checked": r7["checked"], "jit": jit_of(r7)}
         w5.release()
     if want("parquet"):
-        others["parquet"] = measure_parquet(device)
+        others["parquet"] = measure_parquet(device, use_oracle=not args.no_oracle_parity)
     return others
 
 

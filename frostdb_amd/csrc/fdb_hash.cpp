@@ -1391,6 +1391,95 @@ bool Plan::runs_sort(RunsView* v, std::vector<void*>* owned) {
   return true;
 }
 
+// Two ordered plans merged AS RUNS (≙ the OrderedSynchronizer's k-way merge of the chains' sorted records, ordered_synchronizer.go:59-116,
+// and the ordered aggregate's merge of ordered sets, ordered_aggregate.go:449-470): the source's runs are re-keyed into this plan's key ids
+// (dictionaries are per plan: first-seen order) and column order and become one more segment of this plan's run store — one more ordered
+// set. Finish brings the sets into one key order with the run store's own sort and folds equal keys; no hash table is built.
+// false: not applicable (either side holds a table, the segments are used up, the sort is switched off) — the caller merges through the table.
+bool Plan::merge_runs(Plan& src) {
+  if (!ordered_ || !src.ordered_ || src.runs_.empty() || knobs_.runs_no_sort) return false;
+  // (a plan that holds runs keeps nothing in its dense table — runs_to_table relies on the same — and has a hash table only after a fall-back)
+  if (src.mode_ != TableMode::DENSE && src.h_table_ != nullptr) return false;
+  if (runs_.empty() ? (state_dirty_ || h_table_ != nullptr) : (mode_ != TableMode::DENSE && h_table_ != nullptr)) return false;
+  if (runs_.size() + 1 > FDB_MAX_RUN_SEGMENTS || aggs_.size() != 1 || src.aggs_.size() != 1) return false;
+  hip_check(hipSetDevice(device_), "hipSetDevice");
+  // adopt the source's columns and dictionary values
+  std::vector<int> dst_of(src.gcols_.size());
+  std::vector<std::vector<uint32_t>> id_map(src.gcols_.size());
+  for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+    const GroupColState& sg = src.gcols_[sc];
+    size_t gi = 0;
+    for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == sg.name) break;
+    if (gi == gcols_.size()) {
+      if (gcols_.size() >= FDB_MAX_HASH_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "too many group columns");
+      GroupColState g;
+      g.name = sg.name; g.kind = sg.kind; g.is_bool = sg.is_bool; g.is_u64 = sg.is_u64; g.plain = sg.plain; g.value_format = sg.value_format; g.cap = 1; g.stride = 0;
+      gcols_.push_back(std::move(g));
+    }
+    GroupColState& g = gcols_[gi];
+    if (g.kind != sg.kind || g.plain != sg.plain || g.is_bool != sg.is_bool || g.is_u64 != sg.is_u64) throw Error(FDB_ERR_INVALID, "group column " + sg.name + " has different types in the two plans");
+    dst_of[sc] = (int)gi;
+    if (sg.kind == 0) {
+      g.owners.insert(g.owners.end(), sg.owners.begin(), sg.owners.end());
+      bool identity = true;
+      id_map[sc].assign(sg.values.size() + 1, 0);
+      for (size_t v = 0; v < sg.values.size(); v++) { id_map[sc][v + 1] = g.intern(sg.values[v]); identity = identity && id_map[sc][v + 1] == (uint32_t)(v + 1); }
+      if (identity) id_map[sc].clear();
+    }
+  }
+  hash_layout();      // (no table on either side: assigns the wide tuple's words)
+  src.hash_layout();
+  // the record the new segment holds: the narrowest one this plan's id space allows
+  int fmt = 0;
+  if (gcols_.size() > FDB_RUN_TUPLE_BYTES) fmt = 2;
+  for (const GroupColState& g : gcols_) {
+    if (g.kind != 0 || g.values.size() > 65534) { fmt = 2; break; }
+    if (g.values.size() > 254) fmt = std::max(fmt, 1);
+  }
+  if (knobs_.runs_wide == '1') fmt = 2; else if (knobs_.runs_wide == 'm') fmt = std::max(fmt, 1);
+  const int out_rw = fmt == 0 ? 0 : fmt == 1 ? FDB_RUN_MEDIUM_WORDS : h_key_words_ + 4;
+  const size_t rec_bytes = fmt == 0 ? (size_t)FDB_RUN_BYTES : fmt == 1 ? (size_t)FDB_RUN_MEDIUM_BYTES : (size_t)out_rw * 4;
+  // the source's runs in their logical order
+  std::vector<void*> owned;
+  struct FreeOwned { Context* c; std::vector<void*>* v; hipStream_t a, b; ~FreeOwned() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); for (void* p : *v) c->dev_free(p); } } free_owned{src.ctx_, &owned, src.stream_, stream_};
+  RunsView v;
+  src.runs_prepare(&v, /*check_order=*/false, &owned);
+  src.sync();  // (the map of its runs is the last thing the source's stream wrote: our stream reads it next)
+  if (v.n_runs == 0) return true;
+  std::vector<FdbHashCol> cols(gcols_.size());
+  for (size_t c = 0; c < gcols_.size(); c++) {
+    std::memset(&cols[c], 0, sizeof(FdbHashCol));
+    cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c; cols[c].src_word = -1; cols[c].lut_lds = FDB_NO_LDS;
+  }
+  for (size_t sc = 0; sc < src.gcols_.size(); sc++) {
+    FdbHashCol& C = cols[(size_t)dst_of[sc]];
+    C.src_word = src.gcols_[sc].word;
+    C.lut_len = (uint32_t)sc;
+    if (src.gcols_[sc].kind == 0 && !id_map[sc].empty()) C.lut = (const uint32_t*)upload(id_map[sc].data(), id_map[sc].size() * 4);
+  }
+  RunSegment seg;
+  seg.n_entries = (v.n_runs + 255) / 256;
+  seg.capacity = v.n_runs;
+  seg.run_words = out_rw;
+  const size_t tuples_bytes = align_up_sz((size_t)v.n_runs * rec_bytes, 256), dir_bytes = align_up_sz((size_t)seg.n_entries * 8, 256);
+  seg.block = ctx_->dev_alloc(tuples_bytes + dir_bytes + 256);
+  seg.tuples = (unsigned char*)seg.block;
+  seg.dir = (uint32_t*)(seg.tuples + tuples_bytes); seg.cursor = (uint32_t*)(seg.tuples + tuples_bytes + dir_bytes);
+  runs_.push_back(seg);
+  FdbRunsTranslateArgs t;
+  std::memset(&t, 0, sizeof(t));
+  t.phys = v.phys; t.n_runs = v.n_runs;
+  t.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
+  t.out_tuples = seg.tuples; t.out_dir = seg.dir;
+  t.n_cols = (int)gcols_.size(); t.out_run_words = out_rw;
+  hip_check(fdb_launch_runs_translate(t, v.segs, stream_), "runs translate");
+  ctx_->flush_staging();
+  last_kernel_ = "runs_translate_kernel";
+  state_dirty_ = true;
+  sync();  // the caller may close `src` when this returns
+  return true;
+}
+
 // Every run becomes a pre-aggregated entry of the hash table (equal keys merge there): what any consumer other than Finish sees,
 // and where input that was not ordered ends up.
 void Plan::runs_to_table() {

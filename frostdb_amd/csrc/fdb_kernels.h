@@ -412,6 +412,20 @@ struct FdbRunsExpandArgs {
   int32_t col_word[FDB_RUN_TUPLE_BYTES];
 };
 hipError_t fdb_launch_runs_expand(const FdbRunsExpandArgs& args, const FdbRunSegs& segs, hipStream_t stream);
+// The runs of ANOTHER plan's run store, in their logical order, re-keyed into this plan's key ids and column order and written as one new
+// segment of this plan (the merge of two ordered plans AS RUNS: ≙ OrderedSynchronizer's merge of the chains' sorted records,
+// ordered_synchronizer.go:59-116, and the ordered aggregate's merge of its ordered sets, ordered_aggregate.go:449-470 — the sets meet
+// at Finish, where the run store's sort brings them into one key order). cols[c] describes DESTINATION column c: kind, word (its place
+// in a destination wide tuple), gi (= c), src_word (its place in a SOURCE wide tuple, −1: the source plan lacks the column), lut_len (the
+// SOURCE column index: byte / half-word of a narrow / medium source run, valid-mask bit of an int64 column), lut (source id →
+// destination id, nullptr = identity). The segment's directory is written too: entry k = (256 k, runs in block k).
+struct FdbRunsTranslateArgs {
+  const unsigned long long* phys; int64_t n_runs;
+  const FdbHashCol* cols;
+  unsigned char* out_tuples; uint32_t* out_dir;
+  int32_t n_cols, out_run_words;  // out_run_words: 0 narrow, FDB_RUN_MEDIUM_WORDS medium, else the wide stride (key words + 4)
+};
+hipError_t fdb_launch_runs_translate(const FdbRunsTranslateArgs& args, const FdbRunSegs& segs, hipStream_t stream);
 hipError_t fdb_launch_fill_u64(unsigned long long* p, int64_t n, unsigned long long v, hipStream_t stream);
 
 // Export of a hash table for a merge elsewhere (another plan on this device, or — hash-partitioned — other ranks over RCCL):

@@ -2688,6 +2688,74 @@ hipError_t fdb_launch_gather_u64(const unsigned long long* src, const unsigned l
 
 // One wave per 64 consecutive logical runs. The key rows of the groups that START among them are consecutive in the output
 // (out_idx is monotone), so they are assembled in the wave's LDS tile and leave as one contiguous copy.
+// See FdbRunsTranslateArgs. A thread re-keys one run; narrow / medium records are composed in registers (column index = compile-time
+// constant of an unrolled loop), a wide record is written word by word.
+__global__ __launch_bounds__(256) void runs_translate_kernel(const FdbRunsTranslateArgs a, const FdbRunSegs segs) {
+  typedef const __attribute__((address_space(4))) FdbHashCol* ConstHashCols;
+  ConstHashCols q = (ConstHashCols)a.cols;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x == 0) {
+    const int64_t first = (int64_t)blockIdx.x * 256;
+    a.out_dir[(int64_t)blockIdx.x * 2] = (uint32_t)first;
+    a.out_dir[(int64_t)blockIdx.x * 2 + 1] = (uint32_t)(a.n_runs - first < 256 ? a.n_runs - first : 256);
+  }
+  if (i >= a.n_runs) return;
+  const RunRef r = run_ref(segs, a.phys[i]);
+  const uint32_t* tail = r.kw == 0 ? r.t + 8 : r.kw < 0 ? r.t + 16 : r.t + r.kw;  // {rows of the run, its aggregate}
+  const u64x2 ca = *reinterpret_cast<const u64x2*>(tail);
+  auto dst_id = [&](int c) -> uint32_t {  // destination column c's key id in this run (0: NULL or the source lacks the column)
+    if (q[c].src_word < 0) return 0u;
+    uint32_t id = run_dict_id(r, (int)q[c].lut_len, q[c].src_word);
+    const uint32_t* lut = q[c].lut;
+    if (id != 0u && lut != nullptr) id = lut[id];
+    return id;
+  };
+  const int orw = a.out_run_words;
+  if (orw == 0) {
+    uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < FDB_RUN_TUPLE_BYTES; c++) if (c < a.n_cols) w[c >> 2] |= (dst_id(c) & 0xFFu) << (8 * (c & 3));
+    run_u32x4* o = reinterpret_cast<run_u32x4*>(a.out_tuples + (uint64_t)i * FDB_RUN_BYTES);
+    o[0] = run_u32x4{w[0], w[1], w[2], w[3]}; o[1] = run_u32x4{w[4], w[5], w[6], w[7]};
+    *reinterpret_cast<u64x2*>(o + 2) = ca;
+  } else if (orw == FDB_RUN_MEDIUM_WORDS) {
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = 0u;
+#pragma unroll
+    for (int c = 0; c < FDB_RUN_TUPLE_BYTES; c++) if (c < a.n_cols) w[c >> 1] |= (dst_id(c) & 0xFFFFu) << (16 * (c & 1));
+    run_u32x4* o = reinterpret_cast<run_u32x4*>(a.out_tuples + (uint64_t)i * FDB_RUN_MEDIUM_BYTES);
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = run_u32x4{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+    *reinterpret_cast<u64x2*>(o + 4) = ca;
+  } else {
+    const int okw = orw - 4;
+    uint32_t* o = reinterpret_cast<uint32_t*>(a.out_tuples + (uint64_t)i * (uint64_t)orw * 4);
+    for (int w = 0; w < okw; w++) o[w] = 0u;
+    unsigned long long vm = 0;
+    for (int c = 0; c < a.n_cols; c++) {
+      if (q[c].kind == 0) {
+        const uint32_t id = dst_id(c);
+        if (id != 0u) vm |= 1ull << q[c].gi;
+        o[q[c].word] = id;
+      } else {
+        unsigned long long v = 0;
+        if (q[c].src_word >= 0 && run_i64(r, q[c].src_word, (int)q[c].lut_len, &v)) {
+          vm |= 1ull << q[c].gi;
+          o[q[c].word] = (uint32_t)v; o[q[c].word + 1] = (uint32_t)(v >> 32);
+        }
+      }
+    }
+    o[0] = (uint32_t)vm; o[1] = (uint32_t)(vm >> 32);
+    *reinterpret_cast<u64x2*>(o + okw) = ca;
+  }
+}
+hipError_t fdb_launch_runs_translate(const FdbRunsTranslateArgs& args, const FdbRunSegs& segs, hipStream_t stream) {
+  if (args.n_runs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(runs_translate_kernel, dim3((unsigned)((args.n_runs + 255) / 256)), dim3(256), 0, stream, args, segs);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void runs_expand_kernel(const FdbRunsExpandArgs a, const FdbRunSegs segs) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

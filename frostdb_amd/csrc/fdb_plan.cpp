@@ -2071,8 +2071,6 @@ void Plan::state_write(int32_t array, const void* src, int64_t bytes) {
 
 // ---- merge (≙ Synchronizer + final-stage HashAggregate, same device) -------------------------------------------
 void Plan::merge_from(Plan& src) {
-  runs_to_table();
-  src.runs_to_table();
   if (&src == this) throw Error(FDB_ERR_INVALID, "cannot merge a plan into itself");
   if (src.device_ != device_) throw Error(FDB_ERR_INVALID, "merge across devices goes through frostdb_amd.distributed (RCCL)");
   if (src.aggs_.size() != aggs_.size()) throw Error(FDB_ERR_INVALID, "plans have different aggregations");
@@ -2081,6 +2079,9 @@ void Plan::merge_from(Plan& src) {
     if (aggs_[j].type == FDB_T_NONE) aggs_[j].type = src.aggs_[j].type;
     else if (src.aggs_[j].type != FDB_T_NONE && src.aggs_[j].type != aggs_[j].type) throw Error(FDB_ERR_INVALID, "aggregation types differ between plans");
   }
+  if (merge_runs(src)) return;  // two ordered plans whose state is runs: merged as runs (no table)
+  runs_to_table();
+  src.runs_to_table();
   if (mode_ == TableMode::HASH || src.mode_ == TableMode::HASH) {
     src.sync();
     sync();

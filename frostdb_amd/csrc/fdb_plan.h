@@ -360,6 +360,7 @@ class Plan {
   void hash_merge_device(const unsigned long long* d_entries, const uint32_t* d_keys, int64_t n, int in_kw, const std::vector<FdbHashCol>& cols, bool unique_source);
   void hash_merge_args(FdbHashMergeArgs* m, const std::vector<FdbHashCol>& cols, int in_stride_words);
   void merge_hash_tables(Plan& src);
+  bool merge_runs(Plan& src);  // two ordered plans that hold runs only: the source's runs become one more ordered set of ours
   int64_t finish_columns_runs(std::vector<OutColumn>* cols, DeviceBatch* resident, bool* ok);
   void fetch_compact_hash(CompactState* cs);
   int64_t finish_columns_hash(std::vector<OutColumn>* cols, DeviceBatch* resident = nullptr, const RunsView* runs = nullptr);  // device-side column materialisation (big result sets)

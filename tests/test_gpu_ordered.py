@@ -303,9 +303,10 @@ TABLE_SORTED_FINISH = "hash_gather_rows_kernel + runs_sort_keys_kernel"
 @pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("agg_name", ["sum_i", "sum_f", "min", "count"])
 def test_ordered_plans_merged_like_chains_finish_in_key_order_on_the_device(pp, agg_name, resident):
-    """Two ordered plans (two chains over halves of a sorted table), merged (≙ Synchronizer + the final ordered aggregate): their runs go
-    into the hash table — key ids are per plan — and the ordered Finish out of the table sorts its 60 000 groups ON THE DEVICE (round 5;
-    before: every group to the host and a comparison sort there). Equal to the hash aggregate sorted by key; int64 and NULL keys included."""
+    """Two ordered plans (two chains over halves of a sorted table), merged (≙ OrderedSynchronizer + the final ordered aggregate,
+    ordered_synchronizer.go:59-116): the second plan's runs are re-keyed into the first plan's key ids (runs_translate_kernel) and become
+    one more ordered set of its run store — no hash table is built (round 6; round 5 inserted every run into the table) — and Finish brings
+    the sets into key order on the device. Equal to the hash aggregate sorted by key; int64 and NULL keys included (wide run records)."""
     rng = np.random.default_rng(41)
     recs = _wide_sorted_records(rng, 200_000, 6, cards=(300, 2_000), int_key=1)
     agg = {"sum_i": Sum(Col("v")), "sum_f": Sum(Col("v")), "min": Min(Col("v")), "count": Count(Col("v"))}[agg_name]
@@ -318,19 +319,77 @@ def test_ordered_plans_merged_like_chains_finish_in_key_order_on_the_device(pp, 
         for r in recs[3:]:
             p2.Callback(r)
         p1.Merge(p2)
+        assert p1.last_kernel() == "runs_translate_kernel", p1.last_kernel()
         if resident:
             rb = p1.FinishResident()
             out = rb.to_arrow()
             rb.close()
         else:
             out = p1.Finish()
-        assert p1.last_kernel() == TABLE_SORTED_FINISH, p1.last_kernel()
+        # (the second chain's keys all sort behind the first chain's: the appended set continues the order and Finish needs no sort — no kernel of the table path ran either way)
+        assert p1.last_kernel() in ("runs_translate_kernel", SORTED_FINISH), p1.last_kernel()
     finally:
         p1.Close(); p2.Close()
     h, _ = _run_plan(pp, recs, agg, groups, ordered=False)
     key = lambda r: tuple((x is None, x if x is not None else 0) for x in r[:2])  # noqa: E731
     orows = _rows(out)
     assert len(orows) > 50_000 and orows == sorted(_rows(h), key=key)
+
+
+@pytest.mark.parametrize("shape", ["narrow", "medium", "drifting"])
+def test_ordered_plans_with_their_own_dictionaries_merge_as_runs(pp, shape, monkeypatch):
+    """The merge of ordered plans as runs across the record formats: three plans over thirds of a sorted table whose records carry
+    DIFFERENT dictionaries (every record's dictionary in its own order, so the plans' key ids disagree), merged pairwise. `narrow`: a byte
+    per key id stays a byte; `medium`: 300-value dictionaries (two bytes); `drifting`: the third plan has a label column the others lack and
+    lacks one they have (the merged record is wide where a narrow one cannot say "absent"... it can: id 0). Equal to the hash aggregate
+    over all records, in key order; the merged plan never runs a hash kernel."""
+    rng = np.random.default_rng({"narrow": 51, "medium": 52, "drifting": 53}[shape])
+    n = 120_000
+    cards = (300, 40, 9) if shape == "medium" else (40, 9, 5)
+    cols = [rng.integers(0, k + 1, n) for k in cards]  # k = NULL
+    order = np.lexsort(tuple(reversed(cols)))
+    cols = [c[order] for c in cols]
+    val = rng.integers(-50, 1000, n).astype(np.int64)
+    cuts = [0, n // 3, 2 * n // 3, n]
+    recs = []
+    for part, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        arrays, names = [], []
+        for c, k in enumerate(cards):
+            if shape == "drifting" and part == 2 and c == 1:
+                continue  # the third plan never sees labels.l1 …
+            perm = rng.permutation(k)  # this record's dictionary order: entry perm[v] holds value v
+            d = [None] * k
+            for v in range(k):
+                d[perm[v]] = b"v%03d" % v
+            x = cols[c][a:b]
+            idx = pa.array(np.where(x == k, 0, perm[np.minimum(x, k - 1)]).astype(np.uint32), mask=x == k)
+            arrays.append(pa.DictionaryArray.from_arrays(idx, pa.array(d, type=pa.binary()))); names.append("labels.l%d" % c)
+        if shape == "drifting" and part == 2:  # … and brings a column of its own (constant: the rows stay in key order)
+            arrays.append(pa.DictionaryArray.from_arrays(pa.array(np.zeros(b - a, dtype=np.uint32)), pa.array([b"only-here"], type=pa.binary()))); names.append("labels.l9")
+        arrays.append(pa.array(val[a:b])); names.append("v")
+        recs.append(pa.RecordBatch.from_arrays(arrays, names=names))
+    groups = [DynCol("labels")]
+    plans = [pp.HashAggregatePlan(None, [Sum(Col("v"))], groups, ordered=True, final_stage=False) for _ in recs]
+    keep = [pp.ResidentBatch(r) for r in recs]
+    try:
+        for p, k in zip(plans, keep):
+            p.CallbackResident([k])
+            assert p.last_kernel().startswith("fdb_hash_kernel(runs"), p.last_kernel()
+        plans[0].Merge(plans[2])
+        plans[0].Merge(plans[1])
+        assert plans[0].last_kernel() == "runs_translate_kernel"
+        out = plans[0].Finish()
+        assert plans[0].last_kernel() == SORTED_FINISH, plans[0].last_kernel()
+    finally:
+        for p in plans:
+            p.Close()
+        for k in keep:
+            k.close()
+    h, _ = _run_plan(pp, recs, Sum(Col("v")), groups, ordered=False, resident=True)
+    assert out.schema.names[:-1] == h.schema.names[:-1]
+    nk = out.num_columns - 1
+    orows = _rows(out)
+    assert len(orows) > 1000 and orows == sorted(_rows(h), key=lambda r: _key_order(r, nk))
 
 
 def test_small_ordered_results_out_of_the_table_are_still_sorted_on_the_host(pp, monkeypatch):
