@@ -3,6 +3,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
+#include <chrono>
+#include <string>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +40,24 @@ Context* Context::acquire(int device) {
   hip_check(hipSetDevice(device), "hipSetDevice");
   Context* c = new Context();
   c->device = device;
+  // The reference runs GOMAXPROCS chains (physicalplan.go:22: 256 on the bench host). Every chain gets a context, but not every context a
+  // stream of its own: the contexts of a device share $FDB_MAX_STREAMS streams (default 4; 0 = one stream per context). With a stream per
+  // chain the host→device rate of N chains pushing 65 536-row records fell from the link's 3.1 G rows/s to 1.4 beyond 32 chains (the
+  // runtime spreads the streams' copies over the same few copy engines and hardware queues); with 4 shared streams it stays at 2.9–3.2
+  // up to 128 chains (profiles/round6_push_bench.txt). Contexts that share a stream merely wait for each other's work in their own
+  // stream waits; nothing in the library makes one stream's kernel wait for another kernel on the device across plans.
+  static const int max_streams = std::getenv("FDB_MAX_STREAMS") ? std::atoi(std::getenv("FDB_MAX_STREAMS")) : 4;
+  if (max_streams > 0) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    static std::vector<hipStream_t> shared[16];
+    static size_t created[16];
+    const size_t k = created[device]++ % (size_t)max_streams;
+    if (k < shared[device].size()) { c->stream = shared[device][k]; return c; }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { created[device]--; delete c; hip_check(e, "hipStreamCreate"); }
+    shared[device].push_back(c->stream);
+    return c;
+  }
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; hip_check(e, "hipStreamCreate"); }
   return c;
@@ -61,7 +83,10 @@ void* Context::dev_alloc(size_t bytes) {
     if (!b.used && b.bytes >= bytes && (best == nullptr || b.bytes < best->bytes)) best = &b;
   if (best != nullptr && best->bytes <= bytes * 4) { best->used = true; note_device_alloc(best->bytes); return best->p; }
   void* p = nullptr;
+  static const bool prof = std::getenv("FDB_PROFILE_ALLOC") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&p, bytes);
+  if (prof && bytes >= ((size_t)1 << 20)) std::fprintf(stderr, "[fdb] hipMalloc(%zu) %.1f us\n", bytes, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
   if (e == hipErrorOutOfMemory) {  // drop the cache and retry once
     (void)hipGetLastError();
     for (Block& b : dev_blocks_) if (!b.used) { (void)hipFree(b.p); b.p = nullptr; }
@@ -87,6 +112,52 @@ void live_allocations(int64_t* device_blocks, int64_t* device_bytes, int64_t* pi
   if (pinned_blocks) *pinned_blocks = g_live_pinned.load();
 }
 
+// ---- pinned host memory next to the GPU ---------------------------------------------------------------------------------------
+// hipHostMalloc places its pages by the CALLING thread's memory policy — on the node the thread happens to run on. The reference runs
+// GOMAXPROCS chains (physicalplan.go:22), spread over every socket of the host; a chain on the far socket then gets pinned slabs on the
+// far node and the GPU's DMA engines read them across the socket link (N chains pushing host records: the host→device rate falls once
+// the GPU's own socket is full). The pinned blocks of this library are therefore allocated under a PREFERRED policy for the GPU's NUMA
+// node (sysfs numa_node of its PCI function; $FDB_PINNED_NUMA=0: leave the policy alone — A/B aid). Raw syscalls: no libnuma here.
+#include <sys/syscall.h>
+#include <unistd.h>
+namespace {
+int gpu_numa_node(int device) {
+  static std::mutex mu;
+  static int cached[16];
+  static bool known[16];
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= 16) return -1;
+  if (known[device]) return cached[device];
+  known[device] = true; cached[device] = -1;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  for (char* c = bus; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+  const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+  if (FILE* f = std::fopen(path.c_str(), "r")) {
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) == 1 && node >= 0 && node < 1024) cached[device] = node;
+    std::fclose(f);
+  }
+  return cached[device];
+}
+struct PreferNode {  // the calling thread's memory policy = "prefer `node`" for the lifetime of the object
+  bool set = false;
+  explicit PreferNode(int device) {
+    static const bool off = std::getenv("FDB_PINNED_NUMA") != nullptr && std::atoi(std::getenv("FDB_PINNED_NUMA")) == 0;
+    const int node = off ? -1 : gpu_numa_node(device);
+    if (node < 0) return;
+    unsigned long mask[16] = {0};
+    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+    set = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, (unsigned long)(sizeof(mask) * 8)) == 0;
+  }
+  ~PreferNode() { if (set) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul); }
+};
+}  // namespace
+hipError_t pinned_malloc_near(void** p, size_t bytes, int device) {
+  PreferNode prefer(device);
+  return hipHostMalloc(p, bytes, hipHostMallocDefault);
+}
+
 void* Context::host_alloc(size_t bytes) {
   bytes = round_block(bytes ? bytes : 1);
   Block* best = nullptr;
@@ -94,7 +165,10 @@ void* Context::host_alloc(size_t bytes) {
     if (!b.used && b.bytes >= bytes && (best == nullptr || b.bytes < best->bytes)) best = &b;
   if (best != nullptr) { best->used = true; return best->p; }
   void* p = nullptr;
-  hip_check(hipHostMalloc(&p, bytes, hipHostMallocDefault), "hipHostMalloc");
+  static const bool prof = std::getenv("FDB_PROFILE_ALLOC") != nullptr;  // (tuning aid: what the driver's allocators cost when many chains start at once)
+  const auto t0 = std::chrono::steady_clock::now();
+  hip_check(pinned_malloc_near(&p, bytes, device), "hipHostMalloc");
+  if (prof) std::fprintf(stderr, "[fdb] hipHostMalloc(%zu) %.1f us\n", bytes, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
   host_blocks_.push_back(Block{p, bytes, true});
   return p;
 }
@@ -121,7 +195,9 @@ void* pinned_pool_alloc(size_t bytes) {
     if (best != nullptr) { best->used = true; g_live_pinned++; return best->p; }
   }
   void* p = nullptr;
-  hip_check(hipHostMalloc(&p, want, hipHostMallocDefault), "hipHostMalloc(result)");
+  int cur_dev = 0;
+  (void)hipGetDevice(&cur_dev);
+  hip_check(pinned_malloc_near(&p, want, cur_dev), "hipHostMalloc(result)");
   std::lock_guard<std::mutex> lk(g_pin_mu);
   g_pinned.push_back(PinnedBlock{p, want, true});
   g_live_pinned++;
@@ -303,7 +379,7 @@ void* Context::stage(const void* host, size_t payload) {
     stage_sent_ = 0;
     shadow_valid_ = 0;
     stage_cap_ = std::max<size_t>(std::max<size_t>(round_block(bytes * 2), stage_cap_ * 2), 1 << 20);
-    hip_check(hipHostMalloc((void**)&stage_h_, stage_cap_, hipHostMallocDefault), "hipHostMalloc(staging)");
+    hip_check(pinned_malloc_near((void**)&stage_h_, stage_cap_, device), "hipHostMalloc(staging)");
     hip_check(hipMalloc((void**)&stage_d_, stage_cap_), "hipMalloc(staging)");
   }
   if (payload) std::memcpy(stage_h_ + stage_off_, host, payload);
@@ -338,7 +414,7 @@ unsigned char* Context::copy_reserve(size_t payload) {
     if (bytes > copy_cap_) {
       if (copy_h_) (void)hipHostFree(copy_h_);
       copy_cap_ = std::max<size_t>(round_block(bytes * 2), (size_t)32 << 20);
-      hip_check(hipHostMalloc((void**)&copy_h_, copy_cap_, hipHostMallocDefault), "hipHostMalloc(copy ring)");
+      hip_check(pinned_malloc_near((void**)&copy_h_, copy_cap_, device), "hipHostMalloc(copy ring)");
     }
   }
   unsigned char* p = copy_h_ + copy_off_;

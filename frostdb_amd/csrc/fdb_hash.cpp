@@ -453,6 +453,7 @@ void Plan::fetch_compact_hash(CompactState* cs) {
 // uint16, in slices of 2^20 rows, and host threads widen slice k into the record's uint32 buffers while slice k + 1 is in flight.
 // Returns the number of groups.
 void widen_indices(const void* src, int width, uint32_t* dst, size_t n);  // fdb_widen.cc
+void widen_indices_mapped(const void* src, int width, const uint32_t* table, size_t table_len, uint32_t* dst, size_t n);  // … through a rank → index table
 
 namespace {
 int host_threads_for(size_t elements) {
@@ -512,10 +513,8 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
   const size_t bitmap_bytes = np / 8 + 64;
   for (size_t c = 0; c < n_cols; c++) off_bits[c] = place(bitmap_bytes);
   const size_t direct_bytes = total - direct_begin;
-  size_t slice_stride = 0;
+  size_t slice_stride = 0, narrow_bytes = 0;  // (laid out once the transport widths are final: after the present-id pass below)
   auto col_bytes = [&](size_t c, size_t rows) { return width[c] > 0 ? rows * (size_t)width[c] : ((rows * (size_t)(-width[c]) + 31) / 32) * 4; };  // (sub-byte columns are written as whole 32-bit words)
-  for (size_t c = 0; c < n_cols; c++) if (narrow[c]) { off_narrow[c] = slice_stride; slice_stride += col_bytes(c, kSliceRows); }
-  const size_t narrow_bytes = slice_stride * std::max<size_t>(n_slices, 1);
   unsigned char* d_block = nullptr;
   std::vector<void*> owned;
   if (resident != nullptr) {  // the batch owns the block (process-wide pool: it outlives this plan)
@@ -524,10 +523,10 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
     resident->arena_bytes = direct_bytes + 256;
     resident->note_reader(stream_);  // (whatever happens below: the block does not go back to the pool while a kernel of ours still writes it)
   } else {
-    d_block = (unsigned char*)ctx_->dev_alloc(direct_bytes + narrow_bytes + 256);
+    d_block = (unsigned char*)ctx_->dev_alloc(direct_bytes + 256);
     owned.push_back(d_block);
   }
-  unsigned char* d_narrow = d_block + direct_bytes;
+  unsigned char* d_narrow = nullptr;
   // (device scratch goes back to the context's cache when this function leaves, also by exception — after the Quiesce guard
   // below has waited for both queues)
   struct FreeOwned { Context* c; std::vector<void*>* v; ~FreeOwned() { for (void* p : *v) c->dev_free(p); } } free_owned{ctx_, &owned};
@@ -536,7 +535,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
   std::vector<uint8_t*> d_bits(std::max<size_t>(n_cols, 1));
   std::vector<unsigned long long*> d_vals(n_vals);
   for (size_t c = 0; c < n_cols; c++) {
-    d_key[c] = narrow[c] ? d_narrow + off_narrow[c] : d_block + (off_key[c] - direct_begin);
+    d_key[c] = narrow[c] ? nullptr : d_block + (off_key[c] - direct_begin);  // (narrow columns: set with the narrow layout below)
     d_bits[c] = d_block + (off_bits[c] - direct_begin);
   }
   for (size_t v = 0; v < n_vals; v++) d_vals[v] = (unsigned long long*)(d_block + (off_val[v] - direct_begin));
@@ -544,20 +543,13 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
   const size_t n_chunks = (size_t)((h_capacity_ + 63) / 64);
   uint32_t* d_bases = (uint32_t*)alloc((n_chunks + 4 + n_chunks / 1024 + 8) * 4);
   std::vector<FdbHashCol> cols(std::max<size_t>(n_cols, 1));
-  for (size_t c = 0; c < n_cols; c++) {
-    std::memset(&cols[c], 0, sizeof(FdbHashCol));
-    cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c;
-    cols[c].src_word = width[c]; cols[c].lut_len = narrow[c] ? 1u : 0u;
-  }
   FdbHashColumnsArgs a;
   std::memset(&a, 0, sizeof(a));
   a.table = h_table_; a.keys = h_keys_; a.capacity = h_capacity_;
-  a.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
-  a.out_key = (void* const*)upload(d_key.data(), d_key.size() * sizeof(void*));
   a.out_vals = (unsigned long long* const*)upload(d_vals.data(), n_vals * sizeof(void*));
   a.out_bits = (uint8_t* const*)upload(d_bits.data(), d_bits.size() * sizeof(void*));
   a.bases = d_bases;
-  a.slice_stride = slice_stride; a.slice_shift = kSliceShift;
+  a.slice_shift = kSliceShift;
   a.n_rows = n;
   a.out_nulls = (unsigned long long*)(d_block + (off_nulls - direct_begin));
   a.dense_keys = (uint32_t*)alloc(std::max<size_t>((size_t)n, 1) * (size_t)h_key_words_ * 4 + 256);
@@ -605,6 +597,66 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
     hip_check(hipMemsetAsync(a.out_nulls, 0, std::max<size_t>(n_cols, 1) * 8, stream_), "hipMemsetAsync(null counts)");
     hip_check(fdb_launch_hash_gather_rows(a, device_, stream_), "hash gather rows");
   }
+  // ---- transport widths by the ids PRESENT (fdb_kernels.h FdbPresentArgs): a narrow column whose dictionary needs 1 or 2 bytes per
+  // index but whose result rows use ≤ 256 / 16 / 4 of its entries ships the rank of the id among the present ones; the host widens
+  // through the rank → index table. Worth a pass over the key rows (≈ 0.3 ms per 10 M × 144 B) when it can save tens of MB of PCIe.
+  std::vector<std::vector<uint32_t>> present_of(n_cols);  // rank → dictionary index (empty: the column ships id − 1)
+  std::vector<const uint32_t*> remap_of(n_cols, nullptr);
+  if (resident == nullptr && n > 0 && !knobs_.no_present_ids) {
+    std::vector<size_t> cand;
+    size_t at_stake = 0;
+    for (size_t c = 0; c < n_cols && cand.size() < FDB_MAX_HASH_GCOLS; c++)
+      if (narrow[c] && width[c] > 0) { cand.push_back(c); at_stake += (size_t)n * (size_t)width[c]; }
+    if (!cand.empty() && at_stake >= (size_t)knobs_.present_ids_min_bytes) {
+      FdbPresentArgs pa;
+      std::memset(&pa, 0, sizeof(pa));
+      pa.dense_keys = a.dense_keys; pa.n_rows = n; pa.key_words = h_key_words_; pa.n_cand = (int)cand.size();
+      size_t bm_words = 0, remap_words = 0;
+      for (size_t k = 0; k < cand.size(); k++) {
+        const size_t len = gcols_[cand[k]].values.size();
+        pa.word[k] = gcols_[cand[k]].word; pa.dict_len[k] = (uint32_t)len;
+        pa.bm_off[k] = (uint32_t)bm_words; pa.remap_off[k] = (uint32_t)remap_words;
+        bm_words += (len + 32) / 32; remap_words += len + 1;
+      }
+      pa.bitmaps = (uint32_t*)alloc(bm_words * 4);
+      pa.remap = (uint32_t*)alloc(remap_words * 4);
+      pa.present = (uint32_t*)alloc(remap_words * 4);
+      pa.counts = (unsigned long long*)alloc(cand.size() * 8 + 256);
+      hip_check(hipMemsetAsync(pa.bitmaps, 0, bm_words * 4, stream_), "hipMemsetAsync(present bitmaps)");
+      hip_check(fdb_launch_present_ids(pa, device_, stream_), "present ids");
+      hip_check(fdb_launch_rank_ids(pa, stream_), "rank ids");
+      std::vector<unsigned long long> h_counts(cand.size());
+      std::vector<uint32_t> h_present(cand.size() * 256);  // (a mapping is only used when ≤ 256 ids are present)
+      hip_check(hipMemcpyAsync(h_counts.data(), pa.counts, cand.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(present counts)");
+      for (size_t k = 0; k < cand.size(); k++)
+        hip_check(hipMemcpyAsync(h_present.data() + k * 256, pa.present + pa.remap_off[k], std::min<size_t>(256, pa.dict_len[k]) * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(present ids)");
+      hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+      for (size_t k = 0; k < cand.size(); k++) {
+        const size_t c = cand[k];
+        const unsigned long long cnt = h_counts[k];
+        const int w = cnt <= 4 ? -2 : cnt <= 16 ? -4 : cnt <= 256 ? 1 : width[c];
+        if (w == width[c]) continue;  // nothing gained
+        width[c] = w;
+        remap_of[c] = pa.remap + pa.remap_off[k];
+        present_of[c].assign(h_present.begin() + (ptrdiff_t)(k * 256), h_present.begin() + (ptrdiff_t)(k * 256 + std::max<unsigned long long>(cnt, 1)));
+        if (cnt == 0) present_of[c][0] = 0;  // (a column of NULLs only: every row carries rank 0, masked by its validity bit)
+      }
+      if (pt.on) pt.mark("finish: present ids");
+    }
+  }
+  for (size_t c = 0; c < n_cols; c++) if (narrow[c]) { off_narrow[c] = slice_stride; slice_stride += col_bytes(c, kSliceRows); }
+  narrow_bytes = slice_stride * std::max<size_t>(n_slices, 1);
+  if (resident == nullptr && narrow_bytes > 0) d_narrow = (unsigned char*)alloc(narrow_bytes + 256);
+  for (size_t c = 0; c < n_cols; c++) {
+    if (narrow[c]) d_key[c] = d_narrow + off_narrow[c];
+    std::memset(&cols[c], 0, sizeof(FdbHashCol));
+    cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c;
+    cols[c].src_word = width[c]; cols[c].lut_len = narrow[c] ? 1u : 0u;
+    cols[c].lut = remap_of[c];
+  }
+  a.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
+  a.out_key = (void* const*)upload(d_key.data(), d_key.size() * sizeof(void*));
+  a.slice_stride = slice_stride;
   if (resident != nullptr) {
     // ---- resident result: one column pass over all rows, the NULL counts to the host, the batch's column table ----------------
     struct Quiesce1 { hipStream_t a; ~Quiesce1() { (void)hipStreamSynchronize(a); } } q1{stream_};
@@ -740,7 +792,9 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
       auto run_task = [&](size_t t) {
         const size_t sl = t / narrow_cols.size(), c = narrow_cols[t % narrow_cols.size()];
         const size_t rows = std::min<size_t>(kSliceRows, (size_t)n - sl * kSliceRows);
-        widen_indices(h_narrow + sl * slice_stride + off_narrow[c], width[c], (uint32_t*)(h_block + off_key[c]) + sl * kSliceRows, rows);
+        uint32_t* dst = (uint32_t*)(h_block + off_key[c]) + sl * kSliceRows;
+        if (present_of[c].empty()) widen_indices(h_narrow + sl * slice_stride + off_narrow[c], width[c], dst, rows);
+        else widen_indices_mapped(h_narrow + sl * slice_stride + off_narrow[c], width[c], present_of[c].data(), present_of[c].size(), dst, rows);
       };
       const int n_threads = host_threads_for((size_t)n * n_narrow);
       if (n_threads <= 0) {

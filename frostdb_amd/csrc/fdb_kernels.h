@@ -308,7 +308,7 @@ hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32
                                    unsigned long long* out_entries, uint32_t* out_keys, const uint32_t* bases, hipStream_t stream);
 // Finish for big tables: the occupied entries go straight into COLUMN buffers on the device, so the host only copies (and, for
 // narrow dictionary columns, widens) finished buffers. cols[c].word / kind / gi describe the key tuple, cols[c].src_word the
-// TRANSPORT width of the column in bytes — dictionary indices (= key id - 1) travel as uint8 / uint16 when the dictionary has
+// TRANSPORT width of the column in bytes (negative: BITS) — cols[c].lut, when set, maps a key id to the value that travels instead of id − 1 (fdb_launch_rank_ids) —; dictionary indices (= key id - 1) travel as uint8 / uint16 when the dictionary has
 // ≤ 256 / ≤ 65 536 entries and are widened to Arrow's uint32 on the host (PCIe is the narrowest link of Finish), int64 keys are
 // 8 bytes — and cols[c].lut_len != 0 marks a SLICED column: out_key[c] + slice · slice_stride + (row in slice) · width with
 // 2^slice_shift rows per slice, so that one slice of all narrow columns is a contiguous run for the copy engine and the host can
@@ -325,6 +325,25 @@ struct FdbHashColumnsArgs {
   uint64_t slice_stride;
   int32_t n_cols, entry_words, key_words, n_vals, slice_shift;
 };
+// Which key ids does the RESULT hold? A result column usually uses a small part of its dictionary (a query filters, a table's parts
+// share big dictionaries), and what crosses PCIe is priced per row — so Finish can ship the ids at the width of the values PRESENT
+// instead of the dictionary's (cfg 5 with 65 532-entry dictionaries of which 4 entries occur: 2 bits per row instead of 16).
+// fdb_launch_present_ids: one pass over the dense key rows sets bit `id` of candidate k's bitmap (bitmaps + bm_off[k], 32-bit words;
+// bit 0 = NULL is not recorded) — per-workgroup bitmaps in LDS, OR-ed into the global ones at the end; candidates are taken in groups
+// whose bitmaps fit LDS. fdb_launch_rank_ids: per candidate, remap[id] = rank of id among the present ids (remap[0] = 0),
+// present[rank] = id − 1 (the dictionary index the host widens to), counts[k] = number of present ids.
+struct FdbPresentArgs {
+  const uint32_t* dense_keys; uint64_t n_rows; int32_t key_words, n_cand;
+  uint32_t* bitmaps;          // zeroed by the caller
+  uint32_t* remap;            // [Σ (dict_len[k] + 1)] at remap_off[k]
+  uint32_t* present;          // same offsets
+  unsigned long long* counts; // [n_cand]
+  int32_t word[FDB_MAX_HASH_GCOLS];      // the candidate's word in a key row
+  uint32_t dict_len[FDB_MAX_HASH_GCOLS]; // ids are 1 … dict_len
+  uint32_t bm_off[FDB_MAX_HASH_GCOLS], remap_off[FDB_MAX_HASH_GCOLS];
+};
+hipError_t fdb_launch_present_ids(const FdbPresentArgs& args, int device, hipStream_t stream);
+hipError_t fdb_launch_rank_ids(const FdbPresentArgs& args, hipStream_t stream);
 hipError_t fdb_launch_hash_gather_rows(const FdbHashColumnsArgs& args, int device, hipStream_t stream);      // pass 1: all rows
 hipError_t fdb_launch_hash_rows_to_columns(const FdbHashColumnsArgs& args, int device, hipStream_t stream);  // pass 2: rows [row_begin, row_end)
 

@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
       if (width < 0) {  // (wave-uniform) sub-byte indices: 16 / 8 lanes fold theirs into one 32-bit word, the first of them stores it
         const uint32_t id = active ? k[C.word] : 0u;
         ok = id != 0u;
-        uint32_t x = id ? id - 1u : 0u;
+        uint32_t x = id ? (C.lut != nullptr ? C.lut[id] : id - 1u) : 0u;
         if (width == -2) {
           x |= (uint32_t)__shfl_down((int)x, 1, 64) << 2; x |= (uint32_t)__shfl_down((int)x, 2, 64) << 4;
           x |= (uint32_t)__shfl_down((int)x, 4, 64) << 8; x |= (uint32_t)__shfl_down((int)x, 8, 64) << 16;
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
       } else if (active) {
         if (C.kind == 0) {
           const uint32_t id = k[C.word];
-          const uint32_t idx = id ? id - 1u : 0u;
+          const uint32_t idx = id ? (C.lut != nullptr ? C.lut[id] : id - 1u) : 0u;
           ok = id != 0u;
           if (width == 1) out[at] = (uint8_t)idx;
           else if (width == 2) *reinterpret_cast<uint16_t*>(out + at) = (uint16_t)idx;
@@ -1083,6 +1083,81 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
   if ((int)threadIdx.x < a.n_cols && s_nulls[threadIdx.x] != 0u) atomicAdd(a.out_nulls + threadIdx.x, (unsigned long long)s_nulls[threadIdx.x]);
 }
 
+// See FdbPresentArgs. Candidates [c0, c1) of this launch keep their bitmaps in LDS (lds_off[k] words into the dynamic block); a wave
+// reads 64 key rows cooperatively (coalesced) into its tile and every lane then marks its row's ids: one LDS OR per column, or ONE per
+// wave and column when the wave's rows agree (sorted results: the slow-changing columns).
+__global__ __launch_bounds__(256) void present_ids_kernel(const FdbPresentArgs a, const int c0, const int c1, const uint32_t bm_words_total, const uint32_t bm_base) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* s_bm = reinterpret_cast<uint32_t*>(smem);
+  const int kw = a.key_words, pitch = kw | 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* tile = s_bm + bm_words_total + (size_t)wave * 64 * pitch;
+  for (uint32_t i = threadIdx.x; i < bm_words_total; i += 256) s_bm[i] = 0u;
+  __syncthreads();
+  const uint32_t magic = (uint32_t)((0x100000000ull + (unsigned)kw - 1ull) / (unsigned)kw);
+  const uint64_t n_groups = (a.n_rows + 63) >> 6;
+  for (uint64_t G = (uint64_t)blockIdx.x * 4 + wave; G < n_groups; G += (uint64_t)gridDim.x * 4) {
+    const uint32_t rows = (uint32_t)(a.n_rows - G * 64 < 64 ? a.n_rows - G * 64 : 64);
+    const uint32_t* src = a.dense_keys + G * 64 * (uint64_t)kw;
+    const uint32_t n_words = rows * (uint32_t)kw;
+    for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
+      uint32_t val[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const uint32_t t = t0 + (uint32_t)u * 64 + lane; if (t < n_words) val[u] = src[t]; }
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+        if (t < n_words) { const uint32_t rr = __umulhi(t, magic); tile[rr * pitch + (t - rr * (uint32_t)kw)] = val[u]; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool active = (uint32_t)lane < rows;
+    for (int k = c0; k < c1; k++) {
+      const uint32_t id = active ? tile[lane * pitch + a.word[k]] : 0u;
+      const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+      uint32_t* bm = s_bm + (a.bm_off[k] - bm_base);
+      if (__ballot(active && id != first) == 0ull) {  // the wave's rows agree on this column
+        if (lane == 0 && first != 0u) atomicOr(&bm[first >> 5], 1u << (first & 31u));
+      } else if (id != 0u) {
+        atomicOr(&bm[id >> 5], 1u << (id & 31u));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < bm_words_total; i += 256) { const uint32_t w = s_bm[i]; if (w != 0u) atomicOr(&a.bitmaps[bm_base + i], w); }
+}
+// One workgroup per candidate: thread t owns a contiguous share of the bitmap's words; popcounts → exclusive scan over the threads →
+// every set bit gets its rank.
+__global__ __launch_bounds__(256) void rank_ids_kernel(const FdbPresentArgs a) {
+  __shared__ uint32_t s_sum[256];
+  const int k = blockIdx.x;
+  const uint32_t n_words = (a.dict_len[k] + 32u) / 32u;
+  const uint32_t* bm = a.bitmaps + a.bm_off[k];
+  uint32_t* remap = a.remap + a.remap_off[k];
+  uint32_t* present = a.present + a.remap_off[k];
+  const uint32_t per = (n_words + 255u) / 256u, w0 = threadIdx.x * per, w1 = w0 + per < n_words ? w0 + per : n_words;
+  uint32_t mine = 0;
+  for (uint32_t w = w0; w < w1; w++) mine += (uint32_t)__popc(bm[w]);
+  s_sum[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int t = 0; t < 256; t++) { const uint32_t v = s_sum[t]; s_sum[t] = run; run += v; }
+    a.counts[k] = run;
+    remap[0] = 0u;
+  }
+  __syncthreads();
+  uint32_t rank = s_sum[threadIdx.x];
+  for (uint32_t w = w0; w < w1; w++) {
+    uint32_t bits = bm[w];
+    for (uint32_t b = 0; b < 32u; b++) {
+      const uint32_t id = w * 32u + b;
+      if (id == 0u || id > a.dict_len[k]) continue;
+      if ((bits >> b) & 1u) { remap[id] = rank; present[rank] = id - 1u; rank++; } else remap[id] = 0u;
+    }
+  }
+}
 // Multi-workgroup exclusive scan, step 1 and 3 (step 2 = scan_counts_kernel over the per-1024 sums).
 __global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint32_t* __restrict__ counts, int64_t n, uint32_t* __restrict__ sums) {
   __shared__ unsigned int wave_sum[4];
@@ -2396,6 +2471,36 @@ hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32
                                    unsigned long long* out_entries, uint32_t* out_keys, const uint32_t* bases, hipStream_t stream) {
   hipLaunchKernelGGL(hash_compact_kernel, dim3(4096), dim3(256), 0, stream, table, keys, capacity, entry_words, key_words, out_entries, out_keys,
                      bases);
+  return hipGetLastError();
+}
+
+hipError_t fdb_launch_present_ids(const FdbPresentArgs& args, int device, hipStream_t stream) {
+  if (args.n_rows == 0 || args.n_cand <= 0) return hipSuccess;
+  const size_t tile_bytes = (size_t)4 * 64 * (size_t)(args.key_words | 1) * 4;
+  const size_t budget = ((size_t)150 << 10) - tile_bytes;  // LDS left for bitmaps
+  const int64_t cus = fdb_scan_default_grid(device) / 2;
+  const int64_t n_groups = (int64_t)((args.n_rows + 63) / 64);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&present_ids_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  (void)hipGetLastError();
+  int c0 = 0;
+  while (c0 < args.n_cand) {  // (the bitmaps of candidates c0 … c1 − 1 are contiguous: bm_off ascends)
+    int c1 = c0;
+    size_t words = 0;
+    while (c1 < args.n_cand) {
+      const size_t w = ((size_t)args.dict_len[c1] + 32) / 32;
+      if (c1 > c0 && (words + w) * 4 > budget) break;
+      if (w * 4 > budget) return hipErrorInvalidValue;
+      words += w; c1++;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * 2);
+    hipLaunchKernelGGL(present_ids_kernel, dim3(grid), dim3(256), words * 4 + tile_bytes, stream, args, c0, c1, (uint32_t)words, args.bm_off[c0]);
+    c0 = c1;
+  }
+  return hipGetLastError();
+}
+hipError_t fdb_launch_rank_ids(const FdbPresentArgs& args, hipStream_t stream) {
+  if (args.n_cand <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rank_ids_kernel, dim3((unsigned)args.n_cand), dim3(256), 0, stream, args);
   return hipGetLastError();
 }
 

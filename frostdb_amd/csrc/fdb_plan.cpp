@@ -1044,10 +1044,13 @@ Plan::Knobs::Knobs() {
   no_identity_lut = std::getenv("FDB_NO_IDENTITY_LUT") != nullptr;
   runs_no_sort = std::getenv("FDB_RUNS_NO_SORT") != nullptr;
   no_uniform_fold = std::getenv("FDB_NO_UNIFORM_FOLD") != nullptr;
+  no_present_ids = std::getenv("FDB_NO_PRESENT_IDS") != nullptr;  // (A/B aid: Finish ships dictionary indices at the dictionary's width)
   const char* w = std::getenv("FDB_RUNS_WIDE");
   runs_wide = w != nullptr ? (w[0] == '1' ? '1' : 'm') : 0;
   const char* e = std::getenv("FDB_ORDERED_SORT_MIN");
   ordered_sort_min = e != nullptr ? std::max<long long>(0, std::atoll(e)) : 4096;
+  const char* pm = std::getenv("FDB_PRESENT_IDS_MIN_BYTES");
+  present_ids_min_bytes = pm != nullptr ? std::max<long long>(0, std::atoll(pm)) : (long long)32 << 20;
   const char* fs = std::getenv("FDB_FINISH_SLICE_SHIFT");
   finish_slice_shift = fs != nullptr ? std::max(6, std::min(20, std::atoi(fs))) : 20;
 }

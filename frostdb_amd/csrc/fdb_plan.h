@@ -345,9 +345,10 @@ class Plan {
   // A/B and test switches of the environment, read ONCE per plan (at create): getenv on the per-record path costs a scan of the environment
   // and is not safe against a concurrent setenv. A test sets them before it creates its plan.
   struct Knobs {
-    bool no_jit, runs_always, no_identity_lut, runs_no_sort, no_uniform_fold;
+    bool no_jit, runs_always, no_identity_lut, runs_no_sort, no_uniform_fold, no_present_ids;
     char runs_wide;             // 0 unset, '1' wide records every launch, 'm' medium where narrow would do
     long long ordered_sort_min; // groups from which an ordered Finish out of the table sorts on the device
+    long long present_ids_min_bytes;  // index bytes a Finish must stand to save before it ranks the ids present ($FDB_PRESENT_IDS_MIN_BYTES), 32 MiB
     int finish_slice_shift;     // log2 of the rows per Finish slice ($FDB_FINISH_SLICE_SHIFT: tests reach several slices with a small result), 20
     Knobs();
   } knobs_;

@@ -117,6 +117,37 @@ void widen_bits(const uint8_t* s, int bits, uint32_t* d, size_t n) {
 }
 }  // namespace
 
+// The same through a table: what crossed PCIe is the RANK of a key id among the ids present in the result (fdb_kernels.h
+// FdbPresentArgs); dst[i] = table[rank]. Ranks ≥ table_len do not occur (the device ranked what it found); clamped all the same.
+void widen_indices_mapped(const void* src, int width, const uint32_t* table, size_t table_len, uint32_t* dst, size_t n) {
+  if (table_len == 0) { std::memset(dst, 0, n * 4); return; }
+  auto at = [&](uint32_t r) { return table[r < table_len ? r : table_len - 1]; };
+  const uint8_t* s = (const uint8_t*)src;
+  if (width == -2 || width == -4) {
+    const int bits = -width, per = 8 / bits;
+    alignas(16) uint32_t lut[256][4];  // a source byte → its 4 (2) indices
+    for (int b = 0; b < 256; b++) for (int k = 0; k < per; k++) lut[b][k] = at((uint32_t)(b >> (bits * k)) & ((1u << bits) - 1u));
+    size_t i = 0;
+    if (bits == 2 && ((uintptr_t)dst & 15u) == 0) {
+      for (; i + 4 <= n; i += 4) _mm_stream_si128((__m128i*)(dst + i), _mm_load_si128((const __m128i*)lut[s[i >> 2]]));
+      _mm_sfence();
+    } else if (bits == 4) {
+      for (; i + 2 <= n; i += 2) std::memcpy(dst + i, lut[s[i >> 1]], 8);
+    }
+    for (; i < n; i++) dst[i] = at((uint32_t)(s[(i * bits) >> 3] >> ((i * bits) & 7)) & ((1u << bits) - 1u));
+  } else if (width == 1) {
+    uint32_t lut[256];
+    for (int b = 0; b < 256; b++) lut[b] = at((uint32_t)b);
+    for (size_t i = 0; i < n; i++) dst[i] = lut[s[i]];
+  } else if (width == 2) {
+    const uint16_t* s2 = (const uint16_t*)src;
+    for (size_t i = 0; i < n; i++) dst[i] = at(s2[i]);
+  } else {
+    const uint32_t* s4 = (const uint32_t*)src;
+    for (size_t i = 0; i < n; i++) dst[i] = at(s4[i]);
+  }
+}
+
 // width: 1 / 2 / 4 bytes per index, or −2 / −4: that many BITS per index (rows packed low bits first)
 void widen_indices(const void* src, int width, uint32_t* dst, size_t n) {
   static const bool avx2 = __builtin_cpu_supports("avx2");
