@@ -385,6 +385,60 @@ void copy_bits(const uint8_t* src, int64_t offset, int64_t length, uint8_t* dst)
   if (tail) dst[nbytes - 1] &= (uint8_t)((1u << tail) - 1u);
 }
 
+namespace {
+inline bool large_offsets(const OutColumn& c) { return c.format == "U" || c.format == "Z"; }
+inline int64_t str_offset(const OutColumn& c, int64_t i) {
+  if (large_offsets(c)) { int64_t o; std::memcpy(&o, c.values.data() + (size_t)i * 8, 8); return o; }
+  int32_t o; std::memcpy(&o, c.values.data() + (size_t)i * 4, 4); return o;
+}
+}  // namespace
+
+int64_t plain_string_bytes(const OutColumn& c, int64_t i) { return str_offset(c, i + 1) - str_offset(c, i); }
+int64_t plain_string_total(const OutColumn& c, int64_t n) { return str_offset(c, n) - str_offset(c, 0); }
+
+std::vector<OutColumn> slice_columns(const std::vector<OutColumn>& cols, int64_t start, int64_t len) {
+  std::vector<OutColumn> out;
+  out.reserve(cols.size());
+  for (const OutColumn& c : cols) {
+    OutColumn o;
+    o.name = c.name; o.format = c.format; o.length = len;
+    const uint8_t* vbits = c.ext_validity != nullptr ? c.ext_validity : (c.validity.empty() ? nullptr : c.validity.data());
+    if (vbits != nullptr && c.null_count > 0 && len > 0) {
+      o.validity.assign((size_t)(len + 7) / 8, 0);
+      copy_bits(vbits, start, len, o.validity.data());
+      o.null_count = count_nulls(o.validity.data(), 0, len);
+      if (o.null_count == 0) o.validity.clear();
+    }
+    const uint8_t* vals = c.ext_values != nullptr ? c.ext_values : c.values.data();
+    if (c.is_str) {
+      const int64_t b0 = str_offset(c, start), b1 = str_offset(c, start + len);
+      const bool utf8 = c.format == "u" || c.format == "U";
+      const bool large = b1 - b0 > 0x7FFFFFFFll;
+      o.values.assign((size_t)(len + 1) * (large ? 8 : 4), 0);
+      for (int64_t i = 0; i <= len; i++) {
+        const int64_t v = str_offset(c, start + i) - b0;
+        if (large) std::memcpy(o.values.data() + (size_t)i * 8, &v, 8);
+        else { const int32_t v32 = (int32_t)v; std::memcpy(o.values.data() + (size_t)i * 4, &v32, 4); }
+      }
+      o.is_str = true;
+      o.format = utf8 ? (large ? "U" : "u") : (large ? "Z" : "z");
+      o.str_data.assign(c.str_data.begin() + (ptrdiff_t)b0, c.str_data.begin() + (ptrdiff_t)b1);
+    } else if (c.format == "b") {
+      o.values.assign((size_t)(len + 7) / 8 + 8, 0);
+      if (len > 0) copy_bits(vals, start, len, o.values.data());
+    } else {
+      const size_t w = c.format == "I" ? 4 : 8;
+      if (len > 0) o.values.assign(vals + (size_t)start * w, vals + (size_t)(start + len) * w);
+    }
+    if (c.is_dict) {
+      o.is_dict = true; o.dict_format = c.dict_format;
+      o.dict_offsets = c.dict_offsets; o.dict_offsets64 = c.dict_offsets64; o.dict_data = c.dict_data;
+    }
+    out.push_back(std::move(o));
+  }
+  return out;
+}
+
 // ---- export --------------------------------------------------------------------------------------------
 
 namespace {

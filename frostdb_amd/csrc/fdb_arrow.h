@@ -101,6 +101,13 @@ void set_plain_strings(OutColumn* oc, const uint32_t* idx, const uint8_t* valid_
 // Moves `cols` into a heap holder and fills `out`/`out_schema` (struct-typed record, `rows` long) whose
 // release callbacks free that holder.
 void export_record(std::vector<OutColumn>&& cols, int64_t rows, ArrowArray* out, ArrowSchema* out_schema);
+// Rows [start, start + len) of a finished record as columns of their own (buffers copied; a plain string column gets offsets that
+// start at 0 again — 32-bit ones when the slice's bytes allow, whatever the whole column needed). The several-records Finish
+// (aggregate.go:426-468) cuts its result with this.
+std::vector<OutColumn> slice_columns(const std::vector<OutColumn>& cols, int64_t start, int64_t len);
+// Bytes of value i of a plain string column built by set_plain_strings (32- or 64-bit offsets).
+int64_t plain_string_bytes(const OutColumn& c, int64_t i);
+int64_t plain_string_total(const OutColumn& c, int64_t n);  // bytes of its first n values
 
 // Host-only: `view` → OutColumns through the same code push / finish use (read_dictionary, encode_plain, copy_bits,
 // set_dictionary, set_plain_strings) → exported record. Throws FDB_ERR_UNSUPPORTED for column types the path does not handle.

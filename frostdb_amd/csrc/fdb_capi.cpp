@@ -223,6 +223,16 @@ int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* 
   });
 }
 
+int fdb_plan_finish_next(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows, int32_t* emitted) {
+  if (!plan || !out || !out_schema || !emitted) return FDB_ERR_INVALID;
+  *emitted = 0;
+  return guard(plan, [&] {
+    std::memset(out, 0, sizeof(*out));
+    std::memset(out_schema, 0, sizeof(*out_schema));
+    *emitted = plan->plan.finish_next(out, out_schema, n_rows) ? 1 : 0;  // (a family of plans behind a dynamic aggregation emits one record: nothing pending)
+  });
+}
+
 int fdb_plan_merge(fdb_plan* dst, fdb_plan* src) {
   if (!dst || !src) return FDB_ERR_INVALID;
   return guard(dst, [&] {

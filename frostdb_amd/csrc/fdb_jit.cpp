@@ -147,6 +147,7 @@ std::string expr_value(const std::vector<JitExprNode>& ex, int ni, F col, V colv
   const bool f = n.type == FDB_T_F64;
   if (n.kind == 0) return f ? ("__longlong_as_double((long long)" + col(ni) + ")") : ("(long long)" + col(ni));
   if (n.kind == 1) return f ? ("__longlong_as_double(K_elit" + std::to_string(ni) + ")") : ("K_elit" + std::to_string(ni));
+  if (n.kind == 7) return "(long long)" + col(ni);  // a column compared with a literal the way a filter leaf does it (project.go:409-447): col(ni) = the leaf's match bit of this row
   if (n.kind == 4) return "(double)(" + expr_value(ex, n.left, col, colvalid) + ")";  // float64(c.Value(i)): the raw slot (project.go:523-535)
   if (n.kind == 5) return "(" + colvalid(n.left) + " ? 0ll : 1ll)";                     // cols[0].IsNull(i) (project.go:588-590)
   if (n.kind == 6)  // cond.IsValid(i) && cond.Value(i) ? a.Value(i) : b.Value(i) (project.go:685-701); conditions here are never NULL
@@ -352,6 +353,11 @@ struct Gen {
     loads(false);
     o << "    uint32_t sel = left >= 4 ? 0xFu : ((1u << (int)left) - 1u);\n";
     if (!s.code.empty()) o << "    sel &= " << filter_expr() << ";\n";
+    {  // match bits of the leaves that boolean projections read (expression nodes of kind 7): leaves outside the filter program
+      std::vector<int> seen;
+      for (const JitExprNode& e : s.exprs)
+        if (e.kind == 7 && std::find(seen.begin(), seen.end(), e.slot) == seen.end()) { seen.push_back(e.slot); o << "    const uint32_t PM" << e.slot << " = " << leaf_expr(e.slot) << "; (void)PM" << e.slot << ";\n"; }
+    }
     // Sorted input (a table sorted by its label columns is FrostDB's normal case): every selected row of a wave falls into ONE slot, and
     // 256 LDS atomics on one address are 256 serialised updates (cfg 2's query over a table sorted by labels.path: 0.40 ms per 100 M rows
     // against 0.24 unsorted). Single-phase shapes therefore keep the wave together (a lane without selected rows stays, its rows
@@ -377,7 +383,7 @@ struct Gen {
         const JitAgg& A = s.aggs[j];
         const std::string comp = std::string(k < 2 ? "a" : "b") + (k % 2 == 0 ? ".x" : ".y");
         if (A.expr != 0) {
-          auto col = [&](int ni) { return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
+          auto col = [&](int ni) -> std::string { if (s.exprs[(size_t)ni].kind == 7) return "((PM" + std::to_string(s.exprs[(size_t)ni].slot) + " >> " + std::to_string(k) + ") & 1u)"; return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
           auto colvalid = [&](int ni) { return "((" + reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
           return "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
         }
@@ -441,7 +447,7 @@ struct Gen {
         if (A.func == FDB_AGG_COUNT) continue;
         std::string raw;
         if (A.expr != 0) {
-          auto col = [&](int ni) { return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
+          auto col = [&](int ni) -> std::string { if (s.exprs[(size_t)ni].kind == 7) return "((PM" + std::to_string(s.exprs[(size_t)ni].slot) + " >> " + std::to_string(k) + ") & 1u)"; return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
           auto colvalid = [&](int ni) { return "((" + reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
           raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
         } else {
@@ -492,7 +498,7 @@ struct Gen {
         const std::string comp = std::string(k < 2 ? "a" : "b") + (k % 2 == 0 ? ".x" : ".y");
         std::string raw;
         if (A.expr != 0) {  // computed input: the expression over this row's raw column values; a NULL (÷ 0) adds the zero slot
-          auto col = [&](int ni) { return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
+          auto col = [&](int ni) -> std::string { if (s.exprs[(size_t)ni].kind == 7) return "((PM" + std::to_string(s.exprs[(size_t)ni].slot) + " >> " + std::to_string(k) + ") & 1u)"; return reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + comp; };
           auto colvalid = [&](int ni) { return "((" + reg(true, s.two_phase, s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
           raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
         } else {
@@ -969,6 +975,14 @@ struct HashGen {
       o << "    sel &= " << Gen::filter_expr_of(s.code, [&](int l) { return Gen::leaf_expr_of(s.leaves[(size_t)l], l, "f" + std::to_string(l)); }) << ";\n";
       o << "    if (sel == 0u) continue;\n";
     }
+    {  // match bits of the leaves that boolean projections read (expression nodes of kind 7): leaves outside the filter program
+      std::vector<int> seen;
+      for (const JitExprNode& e : s.exprs)
+        if (e.kind == 7 && std::find(seen.begin(), seen.end(), e.slot) == seen.end()) {
+          seen.push_back(e.slot);
+          o << "    const uint32_t PM" << e.slot << " = " << Gen::leaf_expr_of(s.leaves[(size_t)e.slot], e.slot, "f" + std::to_string(e.slot)) << "; (void)PM" << e.slot << ";\n";
+        }
+    }
     // columns read by computed inputs / keys (base.l8), then the aggregated columns: requested now, consumed after the probe
     for (int x = 0; x < s.n_expr_cols; x++) {
       o << "    const u64x2 x" << x << "a = ld8(reinterpret_cast<const char*>(a.l8[" << x << "].values) + o8, lane_off8);\n";
@@ -1028,7 +1042,7 @@ struct HashGen {
             o << "        if ((" << r << "_m >> " << k << ") & 1u) { if (" << comp8(r, k) << " != 0ull) fp_add(h1_" << k << ", h2_" << k << ", K1, K2, " << comp8(r, k) << "); vm_" << k << " |= bit; }\n";
         } else {
           for (int k = 0; k < 4; k++) {
-            auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
+            auto col = [&](int ni) -> std::string { if (s.exprs[(size_t)ni].kind == 7) return "((PM" + std::to_string(s.exprs[(size_t)ni].slot) + " >> " + std::to_string(k) + ") & 1u)"; return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
             auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
             o << "        if (" << expr_valid(s.exprs, C.expr_root, col, colvalid) << ") { const unsigned long long y = " << expr_bits(s.exprs, C.expr_root, expr_value(s.exprs, C.expr_root, col, colvalid))
               << "; if (y != 0ull) fp_add(h1_" << k << ", h2_" << k << ", K1, K2, y); vm_" << k << " |= bit; }\n";
@@ -1066,7 +1080,7 @@ struct HashGen {
           const std::string r = "g" + std::to_string(j);
           std::string raw = "(((" + r + "_m >> " + std::to_string(k) + ") & 1u) ? " + comp8(r, k) + " : a.aggs[" + std::to_string(j) + "].null_value)";
           if (A.expr != 0) {
-            auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
+            auto col = [&](int ni) -> std::string { if (s.exprs[(size_t)ni].kind == 7) return "((PM" + std::to_string(s.exprs[(size_t)ni].slot) + " >> " + std::to_string(k) + ") & 1u)"; return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
             auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
             raw = "(" + expr_valid(s.exprs, A.expr - 1, col, colvalid) + " ? " + expr_bits(s.exprs, A.expr - 1, expr_value(s.exprs, A.expr - 1, col, colvalid)) + " : 0ull)";
           }
@@ -1219,7 +1233,7 @@ struct HashGen {
               << "[W + 1] = (uint32_t)(y >> 32); }\n";
         } else {
           for (int k = 0; k < 4; k++) {
-            auto col = [&](int ni) { return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
+            auto col = [&](int ni) -> std::string { if (s.exprs[(size_t)ni].kind == 7) return "((PM" + std::to_string(s.exprs[(size_t)ni].slot) + " >> " + std::to_string(k) + ") & 1u)"; return comp8("x" + std::to_string(s.exprs[(size_t)ni].slot), k); };
             auto colvalid = [&](int ni) { return "((x" + std::to_string(s.exprs[(size_t)ni].slot) + "_m >> " + std::to_string(k) + ") & 1u)"; };
             o << "          if (ins_mask & " << (1 << k) << "u) { const unsigned long long y = " << expr_valid(s.exprs, C.expr_root, col, colvalid) << " ? "
               << expr_bits(s.exprs, C.expr_root, expr_value(s.exprs, C.expr_root, col, colvalid)) << " : 0ull; d_" << k << "[W] = (uint32_t)y; d_" << k << "[W + 1] = (uint32_t)(y >> 32); }\n";

@@ -1116,9 +1116,11 @@ __global__ __launch_bounds__(256) void present_ids_kernel(const FdbPresentArgs a
       const uint32_t id = active ? tile[lane * pitch + a.word[k]] : 0u;
       const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
       uint32_t* bm = s_bm + (a.bm_off[k] - bm_base);
+      // (a bit that is already set costs a read: after the first tiles nearly every id has been seen, and 64 lanes OR-ing into a few
+      // LDS words serialise)
       if (__ballot(active && id != first) == 0ull) {  // the wave's rows agree on this column
-        if (lane == 0 && first != 0u) atomicOr(&bm[first >> 5], 1u << (first & 31u));
-      } else if (id != 0u) {
+        if (lane == 0 && first != 0u && !((bm[first >> 5] >> (first & 31u)) & 1u)) atomicOr(&bm[first >> 5], 1u << (first & 31u));
+      } else if (id != 0u && !((bm[id >> 5] >> (id & 31u)) & 1u)) {
         atomicOr(&bm[id >> 5], 1u << (id & 31u));
       }
     }

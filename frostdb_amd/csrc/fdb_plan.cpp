@@ -417,8 +417,13 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
         if (fn.column == nullptr) throw Error(FDB_ERR_INVALID, "projection column node without a name");
         n.column = fn.column;
       } else if (fn.kind == 1) {
-        if (fn.literal.type != FDB_LIT_INT64 && fn.literal.type != FDB_LIT_FLOAT64) throw Error(FDB_ERR_UNSUPPORTED, "projection literals must be int64 or float64");
+        // (int64 / float64 literals compute; a string / binary / NULL literal can only be the right side of a comparison with a column —
+        // boolExprProjection evaluates its expression like a filter does, project.go:409-470: checked when the record is resolved)
+        if (fn.literal.type != FDB_LIT_INT64 && fn.literal.type != FDB_LIT_FLOAT64 && fn.literal.type != FDB_LIT_STRING && fn.literal.type != FDB_LIT_BINARY && fn.literal.type != FDB_LIT_NULL)
+          throw Error(FDB_ERR_UNSUPPORTED, "projection literals must be int64, float64, string, binary or NULL");
         n.lit_type = fn.literal.type; n.i64 = fn.literal.i64; n.f64 = fn.literal.f64;
+        n.lit.type = fn.literal.type; n.lit.i64 = fn.literal.i64; n.lit.u64 = fn.literal.u64; n.lit.f64 = fn.literal.f64;
+        if (fn.literal.data && fn.literal.len > 0) n.lit.bytes.assign(fn.literal.data, (size_t)fn.literal.len);
       } else if (fn.kind == 2 || fn.kind == 3) {
         if (fn.kind == 2 && (fn.op < FDB_OP_ADD || fn.op > FDB_OP_DIV)) throw Error(FDB_ERR_UNSUPPORTED, "unsupported binary expression in projection");  // project.go:122-123
         if (fn.kind == 3 && (fn.op < FDB_OP_EQ || fn.op > FDB_OP_GT_EQ) && fn.op != FDB_OP_AND && fn.op != FDB_OP_OR) throw Error(FDB_ERR_UNSUPPORTED, "unsupported comparison in projection");
@@ -483,6 +488,8 @@ const Projection* Plan::find_projection(const std::string& name) const {
 // One expression becomes a run of FdbExprNode in the record's argument block (children before parents). Types follow
 // binaryExprProjection.Project: the result has the left operand's type and the right operand must have the same one
 // (project.go:104-160 type-switches on the left array and type-asserts the right one).
+static void resolve_leaf(const ExprNode& e, const DeviceBatch& b, Plan::Resolved* R, FdbLeaf* L);
+
 int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved* R) {
   FdbScanArgs& a = R->args;
   const int base = a.n_expr;
@@ -492,7 +499,42 @@ int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved
     FdbExprNode& e = a.expr[base + (int)k];
     std::memset(&e, 0, sizeof(e));
     e.kind = n.kind; e.op = n.op; e.left = e.right = -1; e.slot = -1;
-    if (n.kind == 0) {
+    // A comparison whose sides are a column and a string / binary / NULL literal — or a dictionary / string column and any literal — is
+    // what a FILTER leaf is: boolExprProjection.Project runs the expression through BooleanExpression.Eval (project.go:409-447), i.e.
+    // BinaryScalarExpr with its per-type rules (binaryscalarexpr.go:41-152). It is resolved as one more leaf of the record's argument
+    // block (truth table per dictionary entry; not part of the filter program) and the node reads that leaf's match bits (kind 7).
+    auto leaf_compare = [&](const ProjNode& cmp) {
+      if (cmp.kind != 3 || cmp.op == FDB_OP_AND || cmp.op == FDB_OP_OR) return false;
+      const ProjNode& l = p.nodes[(size_t)cmp.left];
+      const ProjNode& r = p.nodes[(size_t)cmp.right];
+      if (l.kind != 0 || r.kind != 1) return false;
+      if (r.lit_type == FDB_LIT_STRING || r.lit_type == FDB_LIT_BINARY || r.lit_type == FDB_LIT_NULL) return true;
+      const int ci = b.find(l.column);
+      return ci < 0 || b.cols[(size_t)ci].kind == ColKind::DICT;
+    };
+    auto operand_of_leaf = [&](size_t idx) {  // node `idx` is only ever read by leaf comparisons
+      bool any = false;
+      for (const ProjNode& q : p.nodes)
+        if (q.kind >= 2 && (q.left == (int)idx || q.right == (int)idx || (q.kind == 6 && q.op == (int)idx))) { if (!leaf_compare(q)) return false; any = true; }
+      return any;
+    };
+    if (n.kind == 0 && operand_of_leaf(k)) {
+      e.kind = 8; e.type = FDB_T_NONE;  // (an operand the leaf comparison consumes: the leaf reads the column itself; nothing is generated for the node)
+    } else if (n.kind == 1 && operand_of_leaf(k)) {
+      e.kind = 8; e.type = FDB_T_NONE;
+    } else if (leaf_compare(n)) {
+      if (a.n_leaves >= FDB_MAX_LEAVES) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": too many predicate leaves");
+      ExprNode fe;
+      fe.op = n.op; fe.column = p.nodes[(size_t)n.left].column; fe.lit = p.nodes[(size_t)n.right].lit;
+      const int li = a.n_leaves++;
+      FdbLeaf& L = a.leaves[li];
+      std::memset(&L, 0, sizeof(L));
+      L.lut_lds = FDB_NO_LDS; L.slot = -1;
+      R->luts.reserve(64);
+      R->cur_node = -1 - (int)(base + k);  // (truth tables are cached per (node, dictionary): projection nodes get ids of their own)
+      resolve_leaf(fe, b, R, &a.leaves[li]);
+      e.kind = 7; e.slot = li; e.left = e.right = -1; e.type = FDB_T_BOOL;
+    } else if (n.kind == 0) {
       const int ci = b.find(n.column);
       if (ci < 0) throw Error(FDB_ERR_NOT_FOUND, "projection " + p.name + ": column " + n.column + " not found");
       const DevColumn& c = b.cols[(size_t)ci];
@@ -502,6 +544,7 @@ int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved
       R->count(b, ci);
       R->expr_col[base + (int)k] = ci;
     } else if (n.kind == 1) {
+      if (n.lit_type != FDB_LIT_INT64 && n.lit_type != FDB_LIT_FLOAT64) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": a string / NULL literal can only be compared with a column");
       e.type = n.lit_type == FDB_LIT_INT64 ? FDB_T_I64 : FDB_T_F64;
       if (e.type == FDB_T_I64) e.lit = n.i64; else std::memcpy(&e.lit, &n.f64, 8);
     } else if (n.kind == 4) {  // convertProjection.convert (project.go:507-521): only int64 → float64 exists
@@ -1051,6 +1094,8 @@ Plan::Knobs::Knobs() {
   ordered_sort_min = e != nullptr ? std::max<long long>(0, std::atoll(e)) : 4096;
   const char* pm = std::getenv("FDB_PRESENT_IDS_MIN_BYTES");
   present_ids_min_bytes = pm != nullptr ? std::max<long long>(0, std::atoll(pm)) : (long long)32 << 20;
+  const char* mk = std::getenv("FDB_TEST_MAX_KEY_BYTES");
+  max_key_bytes = mk != nullptr ? std::max<long long>(1, std::atoll(mk)) : 0x7FFFFFFFll;
   const char* fs = std::getenv("FDB_FINISH_SLICE_SHIFT");
   finish_slice_shift = fs != nullptr ? std::max(6, std::min(20, std::atoi(fs))) : 20;
 }
@@ -1932,10 +1977,55 @@ int64_t Plan::finish_columns(std::vector<OutColumn>* cols) {
 void Plan::finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
   PhaseTimer pt;
   std::vector<OutColumn> cols;
-  const int64_t n = finish_columns(&cols);
+  int64_t n = finish_columns(&cols);
+  // ---- several records where one would pass the key builders' size limit (aggregate.go:426-468) -------------------------------
+  // The reference appends a new group's keys to the CURRENT aggregate's builders and, when a binary builder answers ErrMaxSizeReached
+  // (data + value > math.MaxInt32, optbuilders.go:221-224), rolls the group back and starts a new aggregate — a new output record —
+  // with it. Here the groups are cut the same way at Finish, in output order: a record ends in front of the first row whose value
+  // would take one of its plain string / binary key columns past the limit. (Which groups share a record differs — the reference
+  // cuts in arrival order —, the union of the records and the per-record bound are the same.)
+  pending_out_.clear();
+  const int64_t limit = knobs_.max_key_bytes;
+  // (only a plain BINARY column's builder has the limit: builder.NewBuilder gives *arrow.BinaryType an OptBinaryBuilder and every other
+  // type arrow's own builder, pqarrow/builder/utils.go:12-24 — a utf8 or large_binary key column keeps one record, with 64-bit offsets past 2 GiB)
+  auto limited = [&](size_t c) { return c < gcols_.size() && cols[c].is_str && gcols_[c].plain && gcols_[c].value_format == "z"; };
+  std::vector<size_t> str_cols;
+  for (size_t c = 0; c < cols.size(); c++)
+    if (limited(c) && n > 0 && plain_string_total(cols[c], n) > limit) str_cols.push_back(c);
+  if (!str_cols.empty()) {
+    str_cols.clear();
+    for (size_t c = 0; c < cols.size(); c++) if (limited(c)) str_cols.push_back(c);
+    std::vector<int64_t> cuts{0};
+    std::vector<int64_t> held(str_cols.size(), 0);
+    for (int64_t i = 0; i < n; i++) {
+      bool cut = false;
+      for (size_t k = 0; k < str_cols.size(); k++) {
+        const int64_t b = plain_string_bytes(cols[str_cols[k]], i);
+        if (b > limit) throw Error(FDB_ERR_INVALID, "max size reached: one value of group column " + cols[str_cols[k]].name + " is larger than a record's key builder takes");  // (the retry in the new aggregate fails too, aggregate.go:464-466)
+        if (held[k] + b > limit) cut = true;
+      }
+      if (cut) { cuts.push_back(i); std::fill(held.begin(), held.end(), 0); }
+      for (size_t k = 0; k < str_cols.size(); k++) held[k] += plain_string_bytes(cols[str_cols[k]], i);
+    }
+    cuts.push_back(n);
+    for (size_t r = cuts.size() - 1; r >= 2; r--)  // (kept in reverse: finish_next pops from the back)
+      pending_out_.emplace_back(slice_columns(cols, cuts[r - 1], cuts[r] - cuts[r - 1]), cuts[r] - cuts[r - 1]);
+    std::vector<OutColumn> first = slice_columns(cols, 0, cuts[1]);
+    n = cuts[1];
+    cols = std::move(first);
+  }
   if (n_rows) *n_rows = n;
   export_record(std::move(cols), n, out, out_schema);
   pt.mark("finish: export");
+}
+
+bool Plan::finish_next(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows) {
+  if (pending_out_.empty()) { if (n_rows) *n_rows = 0; return false; }
+  std::pair<std::vector<OutColumn>, int64_t> rec = std::move(pending_out_.back());
+  pending_out_.pop_back();
+  if (n_rows) *n_rows = rec.second;
+  export_record(std::move(rec.first), rec.second, out, out_schema);
+  return true;
 }
 
 std::unique_ptr<DeviceBatch> Plan::finish_batch(int64_t* n_rows) {

@@ -170,7 +170,7 @@ struct GroupColState {
 struct GroupMatcher { std::string name; bool dynamic; };
 
 // A computed column of the Projection between filter and aggregate (fdb_projection; project.go:58-161).
-struct ProjNode { int32_t kind = 0, op = 0, left = -1, right = -1; std::string column; int32_t lit_type = 0; int64_t i64 = 0; double f64 = 0; };
+struct ProjNode { int32_t kind = 0, op = 0, left = -1, right = -1; std::string column; int32_t lit_type = 0; int64_t i64 = 0; double f64 = 0; Literal lit; };  // (lit: the literal as a filter leaf takes it — a comparison of a column with a string / binary / NULL literal is evaluated as one, project.go:409-470)
 struct Projection { std::string name; std::vector<ProjNode> nodes; int32_t root = -1; };
 
 enum class TableMode { DENSE, HASH };
@@ -216,6 +216,10 @@ class Plan {
   void push_batch(const DeviceBatch& batch);
   void push_batches(const DeviceBatch* const* batches, int n);         // one fused launch over n resident records
   void finish(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows);  // ≙ Finish
+  // The records a Finish still owes: the reference starts a new output record when a plain string / binary key builder would pass
+  // 2 GiB (aggregate.go:426-468, optbuilders.go:221-224); finish() emits the first, finish_next() the others (false: none left).
+  bool finish_next(ArrowArray* out, ArrowSchema* out_schema, int64_t* n_rows);
+  std::vector<std::pair<std::vector<OutColumn>, int64_t>> pending_out_;
   // ≙ Finish for a consumer on the device: the result record as a resident batch (group columns as dictionary / int64 / bool columns,
   // one column per aggregation). Big hash tables are materialised in HBM without crossing PCIe; small tables take the host route.
   std::unique_ptr<DeviceBatch> finish_batch(int64_t* n_rows);
@@ -349,6 +353,7 @@ class Plan {
     char runs_wide;             // 0 unset, '1' wide records every launch, 'm' medium where narrow would do
     long long ordered_sort_min; // groups from which an ordered Finish out of the table sorts on the device
     long long present_ids_min_bytes;  // index bytes a Finish must stand to save before it ranks the ids present ($FDB_PRESENT_IDS_MIN_BYTES), 32 MiB
+    long long max_key_bytes;    // bytes one plain string / binary key column of ONE output record may hold ($FDB_TEST_MAX_KEY_BYTES; math.MaxInt32 like optbuilders.go:221-224)
     int finish_slice_shift;     // log2 of the rows per Finish slice ($FDB_FINISH_SLICE_SHIFT: tests reach several slices with a small result), 20
     Knobs();
   } knobs_;

@@ -480,8 +480,16 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
                 cl.i64 = int(e.value)
             elif cl.type == LIT_FLOAT64:
                 cl.f64 = float(e.value)
+            elif cl.type in (LIT_STRING, LIT_BINARY):  # the right side of a comparison inside a boolean projection (`labels.a == 'x'` as a key, project.go:409-470)
+                b = e.value.encode() if isinstance(e.value, str) else bytes(e.value)
+                buf = ctypes.create_string_buffer(b, len(b) + 1)
+                keep.append(buf)
+                cl.data = ctypes.cast(buf, ctypes.c_char_p)
+                cl.len = len(b)
+            elif cl.type == LIT_NULL:
+                pass
             else:
-                raise TypeError(f"unsupported literal in arithmetic: {e.value!r}")
+                raise TypeError(f"unsupported literal in a projection: {e.value!r}")
             nodes.append(CProjNode(kind=1, op=0, left=-1, right=-1, column=None, literal=cl))
         elif isinstance(e, BinaryExpr) and e.op in _ARITH:
             l = flatten(e.left, nodes)

@@ -57,6 +57,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_push_batch.argtypes = [vp, vp]
     L.fdb_plan_push_batches.argtypes = [vp, P(vp), i32]
     L.fdb_plan_finish.argtypes = [vp, vp, vp, P(i64)]
+    L.fdb_plan_finish_next.argtypes = [vp, vp, vp, P(i64), P(i32)]
     L.fdb_plan_merge.argtypes = [vp, vp]
     L.fdb_plan_filter.argtypes = [vp, vp, vp, vp, vp, P(i64)]
     L.fdb_plan_select.argtypes = [vp, vp, vp, vp, i64, P(i64)]
@@ -418,12 +419,36 @@ class HashAggregatePlan:
         n = ctypes.c_int64()
         self._check(lib().fdb_plan_finish(self.handle, ctypes.addressof(arr), ctypes.addressof(sch), ctypes.byref(n)))
         rec = import_batch(arr, sch)
-        if self._next is not None:  # ≙ next.Callback(record) then next.Finish() (aggregate.go:626, :540)
+        if self._next is not None:  # ≙ next.Callback(record) for every aggregate, then next.Finish() (aggregate.go:617-626, :540)
             if rec.num_rows:
                 self._next(rec)
+            while True:
+                more = self.FinishNext()
+                if more is None:
+                    break
+                self._next(more)
             if self._next_finish is not None:
                 self._next_finish()
         return rec
+
+    def FinishNext(self) -> Optional[pa.RecordBatch]:
+        """The next record of a Finish that emitted several (a plain string / binary key column that would pass 2 GiB in one record starts a
+        new one, aggregate.go:426-468); None when there is none left."""
+        arr, sch = ArrowArray(), ArrowSchema()
+        n, emitted = ctypes.c_int64(), ctypes.c_int32()
+        self._check(lib().fdb_plan_finish_next(self.handle, ctypes.addressof(arr), ctypes.addressof(sch), ctypes.byref(n), ctypes.byref(emitted)))
+        return import_batch(arr, sch) if emitted.value else None
+
+    def FinishAll(self) -> List[pa.RecordBatch]:
+        """≙ Finish as the next operator sees it: every record it emits, in order."""
+        recs = [self.Finish()] if self._next is None else []
+        if self._next is not None:
+            raise FdbError(1, "FinishAll: the plan has a next operator (SetNext): Finish hands it the records")
+        while True:
+            more = self.FinishNext()
+            if more is None:
+                return recs
+            recs.append(more)
 
     def FinishResident(self) -> "ResidentBatch":
         """≙ Finish for a device-side consumer (fdb_plan_finish_batch): the result record stays in HBM."""

@@ -158,7 +158,10 @@ typedef struct fdb_proj_node {
                           6 if(cond) { left } else { right }: int64 branches; cond (node index in `op`) is a comparison / isnull
                             node; a row takes `left`'s raw slot where cond is true, else `right`'s; always valid
                             (ifExprProjection + conditionalAddInt64, :603-702) */
-  int32_t op;          /* binary: FDB_OP_ADD / SUB / MUL / DIV; comparison: FDB_OP_EQ … FDB_OP_GT_EQ over numeric children,
+  int32_t op;          /* binary: FDB_OP_ADD / SUB / MUL / DIV; comparison: FDB_OP_EQ … FDB_OP_GT_EQ over numeric children — or over a
+                          COLUMN node and a LITERAL node of any filter literal type (string, binary, NULL …): that comparison is evaluated
+                          the way a filter leaf is (boolExprProjection runs BooleanExpression.Eval, project.go:409-447 → BinaryScalarExpr,
+                          binaryscalarexpr.go:41-152: dictionary / plain string columns, the missing-column rules) —,
                           or FDB_OP_AND / FDB_OP_OR over two comparison nodes (AndExpr / OrExpr, filter.go:172-220) */
   int32_t left;        /* binary: child indices into the projection's node array */
   int32_t right;
@@ -265,11 +268,16 @@ FDB_API int fdb_plan_push_batch(fdb_plan* plan, const fdb_batch* batch);
 /* Same, for `n` resident records at once (≙ the TableScan handing a chain every part it owns): one fused kernel
  * launch scans all of them, so per-launch costs are paid once per scan instead of once per record. */
 FDB_API int fdb_plan_push_batches(fdb_plan* plan, const fdb_batch* const* batches, int32_t n);
-/* ≙ PhysicalPlan.Finish: waits for the device, emits ONE record (group columns in first-seen field
+/* ≙ PhysicalPlan.Finish: waits for the device, emits a record (group columns in first-seen field
  * order with their input Arrow type, then one column per aggregation named "<func>(<column>)")
  * (aggregate.go:543-633). The caller owns `out`/`out_schema` and must call their release().
- * A plan that saw no selected rows emits a zero-row record and sets *n_rows = 0. */
+ * A plan that saw no selected rows emits a zero-row record and sets *n_rows = 0.
+ * The reference emits SEVERAL records when a plain string / binary key column would pass 2 GiB in one (a key builder answers
+ * ErrMaxSizeReached, the group is rolled back and starts a new aggregate: aggregate.go:426-468, optbuilders.go:221-224). Same here:
+ * fdb_plan_finish emits the first record, fdb_plan_finish_next every further one (*emitted = 1) until *emitted = 0 — the Go shim hands
+ * each to next.Callback like finishAggregate does (aggregate.go:617-624). $FDB_TEST_MAX_KEY_BYTES lowers the limit (tests). */
 FDB_API int fdb_plan_finish(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows);
+FDB_API int fdb_plan_finish_next(fdb_plan* plan, struct ArrowArray* out, struct ArrowSchema* out_schema, int64_t* n_rows, int32_t* emitted);
 /* ≙ Synchronizer + HashAggregate(final=true) on one device (synchronize.go:31-53): folds the partial
  * table of `src` into `dst` (SUM of sums and counts, MIN of mins, MAX of maxes). `src` stays valid. */
 FDB_API int fdb_plan_merge(fdb_plan* dst, fdb_plan* src);

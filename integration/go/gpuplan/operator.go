@@ -384,7 +384,9 @@ func (o *Operator) SetDeterministic(on bool) {
 	C.fdb_plan_set_deterministic(o.plan, v)
 }
 
-// Finish ≙ HashAggregate.Finish: emit the partial record downstream, then propagate Finish (aggregate.go:527-541).
+// Finish ≙ HashAggregate.Finish: emit the partial record(s) downstream, then propagate Finish (aggregate.go:527-541). The library emits
+// one record per "aggregate" like finishAggregate does (aggregate.go:617-624): fdb_plan_finish the first, fdb_plan_finish_next the others —
+// more than one only when a plain string / binary key column would pass 2 GiB in a single record (aggregate.go:426-468).
 func (o *Operator) Finish(ctx context.Context) error {
 	if err := ctx.Err(); err != nil {
 		return err
@@ -395,27 +397,42 @@ func (o *Operator) Finish(ctx context.Context) error {
 	if rc := C.fdb_plan_finish(o.plan, (*C.struct_ArrowArray)(unsafe.Pointer(&arr)), (*C.struct_ArrowSchema)(unsafe.Pointer(&sch)), &n); rc != C.FDB_OK {
 		return errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))
 	}
-	rec, err := cdata.ImportCRecordBatch(&arr, &sch) // takes ownership; release() frees the C++ holder
+	for {
+		if err := o.emit(ctx, &arr, &sch, int64(n)); err != nil {
+			return err
+		}
+		var emitted C.int32_t
+		if rc := C.fdb_plan_finish_next(o.plan, (*C.struct_ArrowArray)(unsafe.Pointer(&arr)), (*C.struct_ArrowSchema)(unsafe.Pointer(&sch)), &n, &emitted); rc != C.FDB_OK {
+			return errors.New(C.GoString(C.fdb_plan_last_error(o.plan)))
+		}
+		if emitted == 0 {
+			break
+		}
+	}
+	return o.next.Finish(ctx)
+}
+
+// emit imports one record of the library (taking ownership of the C structs) and hands it to the next operator.
+func (o *Operator) emit(ctx context.Context, arr *cdata.CArrowArray, sch *cdata.CArrowSchema, n int64) error {
+	rec, err := cdata.ImportCRecordBatch(arr, sch) // takes ownership; release() frees the C++ holder
 	if err != nil {
 		return err
 	}
 	defer rec.Release()
-	if n > 0 { // finishAggregate skips empty aggregates (aggregate.go:547-549)
-		out := rec
-		if o.pool != nil {
-			if out, err = copyToPool(rec, o.pool); err != nil {
-				return err
-			}
-			defer out.Release()
-		}
-		if err := ctx.Err(); err != nil {
-			return err
-		}
-		if err := o.next.Callback(ctx, out); err != nil {
-			return err
-		}
+	if n == 0 { // finishAggregate skips empty aggregates (aggregate.go:547-549)
+		return nil
 	}
-	return o.next.Finish(ctx)
+	out := rec
+	if o.pool != nil {
+		if out, err = copyToPool(rec, o.pool); err != nil {
+			return err
+		}
+		defer out.Release()
+	}
+	if err := ctx.Err(); err != nil {
+		return err
+	}
+	return o.next.Callback(ctx, out)
 }
 
 // copyToPool rebuilds a record from the engine's allocator: array.Concatenate of ONE array allocates its buffers from `pool` and copies

@@ -72,6 +72,7 @@ def lib() -> ctypes.CDLL:
         L.oracle_plan_push.argtypes = [vp, i32, vp]
         L.oracle_plan_filter.argtypes = [vp, vp, ctypes.POINTER(vp), ctypes.POINTER(i32), vp, ctypes.POINTER(i64)]
         L.oracle_plan_finish.argtypes = [vp, ctypes.POINTER(vp)]
+        L.oracle_plan_finish_next.argtypes = [vp, ctypes.POINTER(vp)]
         L.oracle_plan_execute.argtypes = [vp, ctypes.POINTER(vp), i64, i32, ctypes.POINTER(vp)]
         _lib = L
     return _lib
@@ -441,6 +442,13 @@ class OraclePlan:
         out = ctypes.c_void_p()
         self._check(lib().oracle_plan_finish(self.handle, ctypes.byref(out)))
         return OracleBatch(out.value)
+
+    def finish_next(self) -> Optional[OracleBatch]:
+        """The records of a Finish after the first (a plain binary key builder that reached its size limit started a new aggregate,
+        aggregate.go:426-468; $FDB_TEST_MAX_KEY_BYTES lowers math.MaxInt32 for tests); None when there is none left."""
+        out = ctypes.c_void_p()
+        self._check(lib().oracle_plan_finish_next(self.handle, ctypes.byref(out)))
+        return OracleBatch(out.value) if out.value else None
 
     def execute(self, batches: Sequence[OracleBatch], nthreads: int) -> OracleBatch:
         """The CPU baseline: `nthreads` chains pulling from one queue, then Synchronizer + final stage."""

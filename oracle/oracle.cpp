@@ -116,6 +116,7 @@ struct Col {
   std::string name;
   ColType type = T_I64;
   bool utf8 = false;               // T_STR: utf8 vs binary
+  bool dict_out = false;           // T_STR handed on by a partial stage whose key builder was a DICTIONARY builder (the reference keeps the input type, utils.go:22-24)
   std::vector<uint8_t> valid;      // 1 = valid; always length `len`
   std::vector<int64_t> i64;        // T_I64 / T_U64 (bit pattern) / T_BOOL (0/1)
   std::vector<double> f64;         // T_F64
@@ -480,6 +481,24 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
     for (int64_t i = 0; i < rows; i++) out->i64[(size_t)i] = (c.valid[(size_t)i] && c.i64[(size_t)i]) ? t.i64[(size_t)i] : e.i64[(size_t)i];
     return true;
   }
+  if (n.kind == 3 && n.op != FDB_OP_AND && n.op != FDB_OP_OR && pd.nodes[(size_t)n.left].kind == 0 && pd.nodes[(size_t)n.right].kind == 1) {
+    // boolExprProjection.Project (project.go:409-447) evaluates its expression with BooleanExpression.Eval — for `column ⟨op⟩ literal`
+    // that is BinaryScalarExpr.Eval, the same code a filter leaf runs (binaryscalarexpr.go:41-152: missing-column rules, dictionary and
+    // string compares, NULL never matches) — and appends bitmap.Contains(i) for every row: a valid bool per row.
+    const ProjNode& l = pd.nodes[(size_t)n.left];
+    const ProjNode& lit = pd.nodes[(size_t)n.right];
+    const int ci = r.find(l.column);
+    const bool stringy = lit.lit.type == FDB_LIT_STRING || lit.lit.type == FDB_LIT_BINARY || lit.lit.type == FDB_LIT_NULL ||
+                         ci < 0 || r.cols[(size_t)ci].type == T_DICT || r.cols[(size_t)ci].type == T_STR;
+    if (stringy) {
+      Expr e; e.op = n.op; e.column = l.column; e.lit = lit.lit;
+      Bitmap bm;
+      if (!eval_leaf(e, r, &bm, err)) return false;
+      out->type = T_BOOL; out->len = rows; out->valid.assign((size_t)rows, 1); out->i64.assign((size_t)rows, 0);
+      for (int64_t i = 0; i < rows; i++) out->i64[(size_t)i] = bm[(size_t)i] ? 1 : 0;
+      return true;
+    }
+  }
   Col a, b;
   if (!project_node(pd, n.left, r, &a, err) || !project_node(pd, n.right, r, &b, err)) return false;
   if (n.kind == 3) {
@@ -605,8 +624,25 @@ struct ValueBuilder {  // ≙ builder.ColumnBuilder for one group and one aggreg
 struct KeyBuilder {  // ≙ groupByCols[fieldName]
   ColType type = T_DICT; bool utf8 = false;
   std::vector<uint8_t> valid; std::vector<int64_t> i64; std::vector<std::string> strs;
+  bool from_dict = false;  // built from dictionary input: array.NewBuilder's dictionary builder, which knows no ErrMaxSizeReached
+  int64_t data_bytes = 0;  // len(b.data) of an OptBinaryBuilder — the builder of a plain BINARY column (builder.NewBuilder, pqarrow/builder/utils.go:12-15)
   size_t len() const { return valid.size(); }
   void append_null() { valid.push_back(0); i64.push_back(0); strs.emplace_back(); }
+  void rollback_previous() {  // builder.RollbackPrevious (utils.go:27-52): ResetToLength(Len() - 1)
+    if (valid.empty()) return;
+    if (valid.back()) data_bytes -= (int64_t)strs.back().size();
+    valid.pop_back(); i64.pop_back(); strs.pop_back();
+  }
+};
+
+// One `hashAggregate` of HashAggregate.aggregates (aggregate.go:118-128): its builders become one output record. A new one is started
+// when a key builder of the current one answers ErrMaxSizeReached (aggregate.go:426-468).
+struct AggregatePart {
+  std::vector<std::vector<ValueBuilder>> arrays;         // [aggregation][group of this part]
+  std::unordered_map<std::string, KeyBuilder> group_cols;
+  std::vector<std::string> col_ordering;
+  std::vector<uint64_t> group_hashes;                    // per group: the combined hash (for hashed.* emission)
+  int64_t row_count = 0;
 };
 
 bool match_group(const GroupDesc& g, const std::string& field) {  // expr.go:353-355, :564-566
@@ -622,21 +658,20 @@ struct HashAggregate {
   const PlanDesc* plan = nullptr;
   bool final_stage = false;
   uint64_t seed = 0;
-  std::unordered_map<uint64_t, uint32_t> hash_to_group;  // hashToAggregate (single aggregate: no 2 GiB spill modelled)
+  std::unordered_map<uint64_t, uint64_t> hash_to_group;  // hashToAggregate: hash → hashtuple{aggregate, array} packed (aggregate << 32 | array)
   std::vector<AggDesc> aggs;                             // aggregate.aggregations: the static ones, then dynamic ones as they are converted
   std::set<std::string> dyn_converted;                   // dynamicAggregationsConverted
-  std::vector<std::vector<ValueBuilder>> arrays;         // [aggregation][group]
   std::vector<ColType> agg_types;                        // type of each aggregation's input column
-  std::unordered_map<std::string, KeyBuilder> group_cols;
-  std::vector<std::string> col_ordering;
-  std::vector<uint64_t> group_hashes;                    // per group: the combined hash (for hashed.* emission)
-  int64_t row_count = 0;
+  std::vector<AggregatePart> parts;                      // a.aggregates: new groups always go to the LAST one (aggregate.go:412, :420)
+  int64_t max_key_bytes = 0x7FFFFFFFll;                  // math.MaxInt32 (optbuilders.go:221-224); $FDB_TEST_MAX_KEY_BYTES lowers it for tests
 
   void init(const PlanDesc* p, bool fin, uint64_t s) {
     plan = p; final_stage = fin; seed = s;
     aggs = p->aggs;
-    arrays.assign(aggs.size(), {});
+    parts.assign(1, AggregatePart());
+    parts[0].arrays.assign(aggs.size(), {});
     agg_types.assign(aggs.size(), (ColType)0);
+    if (const char* e = std::getenv("FDB_TEST_MAX_KEY_BYTES")) max_key_bytes = std::max<long long>(1, std::atoll(e));
   }
 
   // dynparquet/hashed.go:86-272
@@ -686,7 +721,7 @@ struct HashAggregate {
           a.func = d.func; a.column = fname; a.dynamic = true;
           a.result_name = final_stage ? std::string(agg_func_name(d.func)) + "(" + fname + ")" : fname;
           aggs.push_back(a);
-          arrays.emplace_back();  // arrays == nil: no builder for any existing group yet
+          for (AggregatePart& P : parts) P.arrays.emplace_back();  // arrays == nil: no builder for any existing group yet
           agg_types.push_back((ColType)0);
           column_to_aggregate.push_back(nullptr);
           dyn_converted.insert(fname);
@@ -731,29 +766,43 @@ struct HashAggregate {
         if (col_hashes[g][i] == 0) continue;
         hash = hash_combine(hash, hash_combine(field_hashes[g], col_hashes[g][i]));
       }
-      uint32_t group;
+      size_t part; uint32_t group;
       auto it = hash_to_group.find(hash);
       if (it == hash_to_group.end()) {
-        for (size_t j = 0; j < arrays.size(); j++) {
+        auto new_group = [&](AggregatePart& P) {  // aggregate.go:412-422: a builder per aggregation, the tuple, rowCount++
+          for (size_t j = 0; j < P.arrays.size(); j++) P.arrays[j].emplace_back();
+          group = (uint32_t)(P.arrays.empty() ? P.row_count : P.arrays[0].size() - 1);
+          P.row_count++;
+        };
+        for (size_t j = 0; j < parts.back().arrays.size(); j++) {
           // `builder.NewBuilder(a.pool, col.DataType())` for EVERY aggregation (:413-417): an aggregation without a column in
           // this record makes that a nil dereference — the reference panics (recovered into an error by recovery.Do)
           if (column_to_aggregate[j] == nullptr) { *err = {FDB_ERR_INVALID, "panic: a record without the column of aggregation " + aggs[j].column + " creates a new group (aggregate.go:413-417)"}; return false; }
-          arrays[j].emplace_back();
         }
-        group = (uint32_t)(arrays.empty() ? row_count : arrays[0].size() - 1);
-        hash_to_group.emplace(hash, group);
-        group_hashes.push_back(hash);
-        row_count++;
-        update_group_by_cols(i, r, group_fields);
+        new_group(parts.back());
+        if (!update_group_by_cols(i, r, group_fields)) {
+          // Max size reached: roll the aggregation creation back and create a new aggregate (aggregate.go:426-468)
+          AggregatePart& old = parts.back();
+          old.row_count--;
+          for (size_t j = 0; j < old.arrays.size(); j++) old.arrays[j].pop_back();
+          parts.emplace_back();
+          parts.back().arrays.assign(aggs.size(), {});
+          new_group(parts.back());
+          if (!update_group_by_cols(i, r, group_fields)) { *err = {FDB_ERR_INVALID, "max size reached"}; return false; }  // (:464-466: the error is returned)
+        }
+        part = parts.size() - 1;
+        hash_to_group.emplace(hash, ((uint64_t)part << 32) | group);
+        parts[part].group_hashes.push_back(hash);
       } else {
-        group = it->second;
+        part = (size_t)(it->second >> 32); group = (uint32_t)it->second;
       }
-      for (size_t j = 0; j < arrays.size(); j++) {  // builder.AppendValue (utils.go:54-58): null ⇒ AppendNull (slot = 0)
+      AggregatePart& P = parts[part];
+      for (size_t j = 0; j < P.arrays.size(); j++) {  // builder.AppendValue (utils.go:54-58): null ⇒ AppendNull (slot = 0)
         if (column_to_aggregate[j] == nullptr) continue;  // :472-475
-        if (arrays[j].empty()) arrays[j].emplace_back();  // :476-482: "the group exists, but the array to append to does not"
-        if (group >= arrays[j].size()) { *err = {FDB_ERR_INVALID, "panic: index out of range — a dynamic aggregation column that appears after a second group exists (aggregate.go:483)"}; return false; }
+        if (P.arrays[j].empty()) P.arrays[j].emplace_back();  // :476-482: "the group exists, but the array to append to does not"
+        if (group >= P.arrays[j].size()) { *err = {FDB_ERR_INVALID, "panic: index out of range — a dynamic aggregation column that appears after a second group exists (aggregate.go:483)"}; return false; }
         const Col& c = *column_to_aggregate[j];
-        ValueBuilder& b = arrays[j][group];
+        ValueBuilder& b = P.arrays[j][group];
         const bool v = c.valid[i];
         b.valid.push_back(v);
         if (c.type == T_F64) b.f64.push_back(v ? c.f64[i] : 0.0);
@@ -764,18 +813,29 @@ struct HashAggregate {
     return true;
   }
 
-  void update_group_by_cols(int64_t row, const Record& r, const std::vector<int>& group_fields) {  // aggregate.go:492-525
-    for (int gi : group_fields) {
-      const Col& c = r.cols[gi];
-      auto it = group_cols.find(c.name);
-      if (it == group_cols.end()) {
-        KeyBuilder kb; kb.type = c.type; kb.utf8 = c.type == T_DICT ? c.dict->utf8 : c.utf8;
-        it = group_cols.emplace(c.name, std::move(kb)).first;
-        col_ordering.push_back(c.name);
+  // aggregate.go:492-525, on the CURRENT aggregate. false = builder.ErrMaxSizeReached: the columns appended for this row so far are
+  // rolled back (:512-519).
+  bool update_group_by_cols(int64_t row, const Record& r, const std::vector<int>& group_fields) {
+    AggregatePart& P = parts.back();
+    for (size_t k = 0; k < group_fields.size(); k++) {
+      const Col& c = r.cols[group_fields[k]];
+      auto it = P.group_cols.find(c.name);
+      if (it == P.group_cols.end()) {
+        KeyBuilder kb; kb.type = c.type; kb.utf8 = c.type == T_DICT ? c.dict->utf8 : c.utf8; kb.from_dict = c.type == T_DICT || c.dict_out;
+        it = P.group_cols.emplace(c.name, std::move(kb)).first;
+        P.col_ordering.push_back(c.name);
       }
       KeyBuilder& kb = it->second;
-      while ((int64_t)kb.len() < row_count - 1) kb.append_null();
+      while ((int64_t)kb.len() < P.row_count - 1) kb.append_null();
       if (!c.valid[row]) { kb.append_null(); continue; }
+      if (c.type == T_STR && !c.utf8 && !kb.from_dict) {  // *arrow.BinaryType → OptBinaryBuilder.Append (optbuilders.go:221-224)
+        const int64_t add = (int64_t)c.strs[row].size();
+        if (kb.data_bytes + add > max_key_bytes) {
+          for (size_t j = 0; j < k; j++) P.group_cols[r.cols[group_fields[j]].name].rollback_previous();
+          return false;
+        }
+        kb.data_bytes += add;
+      }
       kb.valid.push_back(1);
       switch (c.type) {
         case T_DICT: kb.strs.push_back(c.dict->values[c.idx[row]]); kb.i64.push_back(0); break;
@@ -783,10 +843,28 @@ struct HashAggregate {
         default: kb.i64.push_back(c.i64[row]); kb.strs.emplace_back(); break;
       }
     }
+    return true;
   }
 
-  // aggregate.go:543-633 + reducers :734-971. Emits one record.
-  bool finish(Record* out, EvalError* err) {
+  // HashAggregate.Finish (aggregate.go:527-541): one record per aggregate, empty ones skipped by the caller.
+  bool finish_all(std::vector<Record>* out, EvalError* err) {
+    out->clear();
+    for (size_t k = 0; k < parts.size(); k++) {
+      out->emplace_back();
+      if (!finish(k, &out->back(), err)) return false;
+    }
+    return true;
+  }
+  bool finish(Record* out, EvalError* err) { return finish(0, out, err); }  // (callers that know there is one aggregate)
+
+  // finishAggregate (aggregate.go:543-633) + reducers :734-971. Emits the record of aggregate `part_idx`.
+  bool finish(size_t part_idx, Record* out, EvalError* err) {
+    AggregatePart& P = parts[part_idx];
+    std::vector<std::vector<ValueBuilder>>& arrays = P.arrays;
+    std::unordered_map<std::string, KeyBuilder>& group_cols = P.group_cols;
+    const std::vector<std::string>& col_ordering = P.col_ordering;
+    const std::vector<uint64_t>& group_hashes = P.group_hashes;
+    const int64_t row_count = P.row_count;
     out->rows = row_count;
     out->cols.clear();
     if (row_count == 0) return true;
@@ -798,7 +876,7 @@ struct HashAggregate {
       if (kb.type == T_DICT || kb.type == T_STR) {
         // Output keeps the input Arrow type (dictionary builder via array.NewBuilder, utils.go:22-24); the
         // oracle hands keys back as plain strings — key *values* are what parity is checked on.
-        c.type = T_STR; c.utf8 = kb.utf8; c.strs = kb.strs;
+        c.type = T_STR; c.utf8 = kb.utf8; c.strs = kb.strs; c.dict_out = kb.from_dict;
       } else {
         c.type = kb.type; c.i64 = kb.i64;
       }
@@ -887,9 +965,30 @@ struct oracle_plan {
   std::mutex next_mtx;  // Synchronizer.nextMtx (synchronize.go:18)
   std::string error;
   bool has_filter = false;
+  std::vector<Record> pending;  // the final stage's records after the first, last one first (oracle_plan_finish_next)
 };
 
+struct oracle_batch;
+static int emit_final(oracle_plan* p, oracle_batch** out);
+
 static thread_local std::string g_err;
+
+// The final stage's Finish: its first non-empty record is returned (a zero-row one if there is none), the others wait in p->pending.
+static int emit_final(oracle_plan* p, oracle_batch** out) {
+  EvalError err{0, ""};
+  std::vector<Record> recs;
+  if (!p->final_agg.finish_all(&recs, &err)) { p->error = err.msg; return err.code; }
+  std::vector<Record> full;
+  for (Record& r : recs) if (r.rows > 0) full.push_back(std::move(r));
+  std::unique_ptr<oracle_batch> o(new oracle_batch());
+  p->pending.clear();
+  if (!full.empty()) {
+    o->rec = std::move(full[0]);
+    for (size_t k = full.size(); k-- > 1;) p->pending.push_back(std::move(full[k]));
+  }
+  *out = o.release();
+  return FDB_OK;
+}
 
 extern "C" {
 
@@ -992,7 +1091,8 @@ int oracle_plan_create(const fdb_plan_desc* d, int32_t nchains, uint64_t seed, o
       const fdb_proj_node& fn = fp.nodes[k];
       ProjNode n; n.kind = fn.kind; n.op = fn.op; n.left = fn.left; n.right = fn.right;
       if (fn.column) n.column = fn.column;
-      n.lit.type = fn.literal.type; n.lit.i64 = fn.literal.i64; n.lit.f64 = fn.literal.f64;
+      n.lit.type = fn.literal.type; n.lit.i64 = fn.literal.i64; n.lit.u64 = fn.literal.u64; n.lit.f64 = fn.literal.f64;
+      if (fn.literal.data && fn.literal.len > 0) n.lit.bytes.assign(fn.literal.data, (size_t)fn.literal.len);
       pd.nodes.push_back(std::move(n));
     }
     p->desc.projs.push_back(std::move(pd));
@@ -1047,14 +1147,25 @@ int oracle_plan_filter(oracle_plan* p, const oracle_batch* b, oracle_batch** out
 int oracle_plan_finish(oracle_plan* p, oracle_batch** out) {
   EvalError err{0, ""};
   for (auto& h : p->partial) {
-    Record partial;
-    if (!h.finish(&partial, &err)) { p->error = err.msg; return err.code; }
-    if (partial.rows == 0) continue;  // finishAggregate skips empty aggregates (aggregate.go:547-549)
-    std::lock_guard<std::mutex> lk(p->next_mtx);
-    if (!p->final_agg.callback(partial, &err)) { p->error = err.msg; return err.code; }
+    std::vector<Record> partials;
+    if (!h.finish_all(&partials, &err)) { p->error = err.msg; return err.code; }
+    for (Record& partial : partials) {
+      if (partial.rows == 0) continue;  // finishAggregate skips empty aggregates (aggregate.go:547-549)
+      std::lock_guard<std::mutex> lk(p->next_mtx);
+      if (!p->final_agg.callback(partial, &err)) { p->error = err.msg; return err.code; }
+    }
   }
+  return emit_final(p, out);
+}
+
+// The records of a Finish after the first (a key builder that reached its size limit started a new aggregate, aggregate.go:426-468):
+// *out = nullptr when there is none left.
+int oracle_plan_finish_next(oracle_plan* p, oracle_batch** out) {
+  *out = nullptr;
+  if (p->pending.empty()) return FDB_OK;
   std::unique_ptr<oracle_batch> o(new oracle_batch());
-  if (!p->final_agg.finish(&o->rec, &err)) { p->error = err.msg; return err.code; }
+  o->rec = std::move(p->pending.back());
+  p->pending.pop_back();
   *out = o.release();
   return FDB_OK;
 }
@@ -1076,20 +1187,18 @@ int oracle_plan_execute(oracle_plan* p, const oracle_batch* const* batches, int6
       }
       if (rc.load() != FDB_OK) return;
       EvalError err{0, ""};
-      Record partial;
-      if (!p->partial[t].finish(&partial, &err)) { p->error = err.msg; rc.store(err.code); return; }
-      if (partial.rows == 0) return;
-      std::lock_guard<std::mutex> lk(p->next_mtx);
-      if (!p->final_agg.callback(partial, &err)) { p->error = err.msg; rc.store(err.code); }
+      std::vector<Record> partials;
+      if (!p->partial[t].finish_all(&partials, &err)) { p->error = err.msg; rc.store(err.code); return; }
+      for (Record& partial : partials) {
+        if (partial.rows == 0) continue;
+        std::lock_guard<std::mutex> lk(p->next_mtx);
+        if (!p->final_agg.callback(partial, &err)) { p->error = err.msg; rc.store(err.code); return; }
+      }
     });
   }
   for (auto& t : th) t.join();
   if (rc.load() != FDB_OK) return rc.load();
-  EvalError err{0, ""};
-  std::unique_ptr<oracle_batch> o(new oracle_batch());
-  if (!p->final_agg.finish(&o->rec, &err)) { p->error = err.msg; return err.code; }
-  *out = o.release();
-  return FDB_OK;
+  return emit_final(p, out);
 }
 
 }  // extern "C"

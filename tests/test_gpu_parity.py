@@ -769,6 +769,82 @@ def test_hash_finish_ships_the_ids_present_not_the_dictionary(pp, monkeypatch):
     assert_same_result(plain, want, names[:6] + [a.Name() for a in aggs])
 
 
+def test_finish_emits_several_records_at_the_key_builders_size_limit(pp, monkeypatch):
+    """Test_Aggregate_ArrayOverflow (query/physicalplan/aggregate_test.go:28-118) through the device path: 3 000 groups keyed by a fresh 1 KiB
+    binary `stacktrace` + an int64 `id`, the key builder's limit lowered from math.MaxInt32 to 64 KiB ($FDB_TEST_MAX_KEY_BYTES) — Finish
+    emits several records (fdb_plan_finish, then fdb_plan_finish_next until none is left; aggregate.go:426-468). The reference's assertions
+    (every record's columns have its length, the rows add up), the per-record bound, and the union of the records against the oracle's."""
+    from oracle import OraclePlan
+    from tests.test_oracle_golden import _overflow_records
+    limit = 64 * 1024
+    monkeypatch.setenv("FDB_TEST_MAX_KEY_BYTES", str(limit))
+    recs = _overflow_records()
+    aggs, groups = [Sum(Col("value"))], [Col("stacktrace"), Col("id")]
+
+    def rows_of(batches, device=True):
+        out = {}
+        for r in batches:
+            assert all(len(c) == r.num_rows for c in r.columns) and r.num_rows > 0
+            st = r.column(r.schema.get_field_index("stacktrace"))
+            if device:
+                assert pa.types.is_binary(st.type)  # (the key column keeps its input type: plain binary, 32-bit offsets)
+            else:
+                st = st.dictionary_decode() if pa.types.is_dictionary(st.type) else st  # (OracleBatch.to_arrow hands strings over as codes + table)
+            assert sum(len(x) for x in st.to_pylist()) <= limit
+            for k, i, v in zip(st.to_pylist(), r.column(r.schema.get_field_index("id")).to_pylist(), r.column(r.schema.get_field_index("sum(value)")).to_pylist()):
+                assert (k, i) not in out
+                out[(k, i)] = v
+        return out
+
+    oplan = OraclePlan(None, aggs, groups, nchains=1)
+    for r in recs:
+        oplan.push(r)
+    outs = [oplan.finish()]
+    while (more := oplan.finish_next()) is not None:
+        outs.append(more)
+    want = rows_of([o.to_arrow() for o in outs], device=False)
+    for o in outs:
+        o.close()
+    oplan.close()
+    for resident in (False, True):
+        plan = pp.HashAggregatePlan(None, aggs, groups)
+        keep = []
+        try:
+            for r in recs:
+                if resident:
+                    keep.append(pp.ResidentBatch(r))
+                    plan.Callback(keep[-1])
+                else:
+                    plan.Callback(r)
+            got = plan.FinishAll()
+        finally:
+            plan.Close()
+            for k in keep:
+                k.close()
+        assert len(got) >= 3000 * 1024 // limit and sum(r.num_rows for r in got) == 3000
+        assert rows_of(got) == want
+    # the next operator of a plan sees every record (≙ next.Callback per aggregate, aggregate.go:617-626)
+    seen, finished = [], []
+    plan = pp.HashAggregatePlan(None, aggs, groups)
+    try:
+        plan.SetNext(seen.append, lambda: finished.append(True))
+        for r in recs:
+            plan.Callback(r)
+        plan.Finish()
+    finally:
+        plan.Close()
+    assert finished == [True] and rows_of(seen) == want
+    # without the hook: one record (3 MB of keys are far below math.MaxInt32)
+    monkeypatch.delenv("FDB_TEST_MAX_KEY_BYTES")
+    plan = pp.HashAggregatePlan(None, aggs, groups)
+    try:
+        for r in recs:
+            plan.Callback(r)
+        assert len(plan.FinishAll()) == 1
+    finally:
+        plan.Close()
+
+
 def test_dense_to_hash_migration_and_merge(pp, variant):
     """First record: two label columns (dense table). Second record brings ten more label columns → the plan migrates
     its dense state into the hash table. Then a second chain in hash mode is merged in (Synchronizer + final stage)."""
@@ -1451,6 +1527,44 @@ def test_golden_distinct_bool_projection(pp, case):
     d = run_gpu(pp, table_records(case["table"]), None, [], case["groups"])
     rows = [tuple(0 if (v is None and c == "timestamp") else v for c, v in zip(case["out"], r)) for r in batch_rows(d, case["out"])]
     assert sorted(rows, key=sort_key) == sorted(case["expected"], key=sort_key), case["cite"]
+
+
+def test_bool_projection_over_string_and_dictionary_columns(pp):
+    """boolExprProjection evaluates its expression like a filter does (project.go:409-447 → BinaryScalarExpr.Eval,
+    binaryscalarexpr.go:41-152): `labels.l00 == 'v0_1'` as a distinct / group key is a per-dictionary-entry truth table (one more leaf of
+    the record's argument block, outside the filter program) whose match bit is the row's bool — never NULL: a NULL label compares
+    false. Dictionary and plain string columns, == and !=, a column the record lacks (the missing-column rules), AND / OR with a numeric
+    comparison, `if (labels… == …)` as an aggregate's input, records with different dictionaries; against the oracle."""
+    from frostdb_amd.logicalplan import IfExpr
+    rng = np.random.default_rng(9911)
+    batches = []
+    for n, ncols in ((60_000, 3), (25_000, 4)):
+        b = many_label_batch(rng, n, ncols, 4, n_groups=400, int_key=True)
+        user = pa.array(["u%d" % k for k in rng.integers(0, 5, n)], type=pa.string(), mask=rng.random(n) < 0.05)
+        batches.append(b.append_column("user", user))
+    first_vals = sorted({v for b in batches for v in b.column(b.schema.get_field_index("labels.l00")).dictionary.to_pylist()})
+    keys = (Col("labels.l00") == first_vals[1].decode(), Col("labels.l00") != first_vals[0].decode(), Col("user") == "u3", Col("user") > "u1",
+            Col("labels.l03") == "nope", Col("labels.l03") != "nope", Col("labels.l00") == None,  # noqa: E711
+            And(Col("labels.l01") == first_vals[0].decode().replace("v0_", "v1_"), Col("value") > 0),
+            Or(Col("user") == "u0", BinaryExpr(Col("bucket"), OP_LT_EQ, Literal(1000))))
+    aggs = [Sum(Col("value")), Count(Col("value"))]
+    for key in keys:
+        groups = [Col("labels.l02"), key]
+        want = run_oracle(batches, None, aggs, groups, nchains=2)
+        got = run_gpu(pp, batches, None, aggs, groups)
+        assert_same_result(got, want, ["labels.l02", key.name] + [a.Name() for a in aggs])
+        assert set(want[key.name]) <= {True, False} and None not in got[key.name]
+    # distinct over the projection alone, resident records
+    for key in keys[:4]:
+        want = run_oracle(batches, None, [], [key])
+        got = run_gpu(pp, batches, None, [], [key], resident=True)
+        assert sorted(got[key.name]) == sorted(want[key.name])
+    # the comparison as the condition of an if: sum(if (user == 'u2') value else 0)
+    cond_sum = [Sum(IfExpr(Col("user") == "u2", Col("value"), Literal(0)))]
+    for groups in ([Col("labels.l01")], [DynCol("labels"), Col("bucket")]):
+        want = run_oracle(batches, None, cond_sum, groups)
+        got = run_gpu(pp, batches, None, cond_sum, groups, resident=True)
+        assert_same_result(got, want, (key_cols_of(batches, extra=("bucket",)) if len(groups) == 2 else ["labels.l01"]) + [cond_sum[0].Name()])
 
 
 def test_bool_projection_key_at_scale(pp):

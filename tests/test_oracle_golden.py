@@ -553,3 +553,55 @@ def test_convert_isnull_if_projections_follow_the_reference():
     rows = sorted(zip(d["isnull(a)"], d["sum(if(a > 4) { b } else { 1})"], d["count(b)"]))
     assert rows == [(False, 10 + 30 + 1, 3), (True, 2, 2)]
     o.close()
+
+
+def _overflow_records(n_records=3, rows=1000, key_bytes=1024):
+    """Test_Aggregate_ArrayOverflow's input (query/physicalplan/aggregate_test.go:28-118), scaled: a fresh binary `stacktrace` per row — 8
+    random bytes and zeros, like randByteSlice — an int64 `id` that counts up across the records, a random int64 `value`."""
+    rng = np.random.default_rng(2024)
+    recs = []
+    for i in range(n_records):
+        traces = [rng.integers(0, 256, 8, dtype=np.uint8).tobytes() + bytes(key_bytes - 8) for _ in range(rows)]
+        recs.append(pa.RecordBatch.from_arrays(
+            [pa.array(rng.integers(0, 1 << 40, rows), type=pa.int64()), pa.array(np.arange(rows, dtype=np.int64) + i * rows), pa.array(traces, type=pa.binary())],
+            names=["value", "id", "stacktrace"]))
+    return recs
+
+
+def test_oracle_array_overflow_emits_several_records(monkeypatch):
+    """Test_Aggregate_ArrayOverflow (aggregate_test.go:28-118): more key bytes than one binary builder takes (math.MaxInt32,
+    optbuilders.go:221-224; lowered to 64 KiB here through $FDB_TEST_MAX_KEY_BYTES, the keys to 1 KiB) → the aggregate is split into several
+    records (aggregate.go:426-468). The reference's own assertions: every record's columns have the record's length, the rows add up to
+    n × rows; plus: no record holds more key bytes than the limit, there are several, and every group comes out once with its own sum."""
+    limit = 64 * 1024
+    monkeypatch.setenv("FDB_TEST_MAX_KEY_BYTES", str(limit))
+    recs = _overflow_records()
+    plan = OraclePlan(None, [Sum(Col("value"))], [Col("stacktrace"), Col("id")], nchains=1)
+    for r in recs:
+        plan.push(r)
+    outs = [plan.finish()]
+    while True:
+        more = plan.finish_next()
+        if more is None:
+            break
+        outs.append(more)
+    got = [o.to_arrow() for o in outs]
+    for o in outs:
+        o.close()
+    plan.close()
+    assert len(got) >= 3000 * 1024 // limit  # 47 records of ≤ 64 rows
+    total, seen = 0, {}
+    for r in got:
+        assert all(len(c) == r.num_rows for c in r.columns) and r.num_rows > 0
+        st = r.column(r.schema.get_field_index("stacktrace"))
+        assert sum(len(x) for x in st.to_pylist()) <= limit
+        for k, i, v in zip(st.to_pylist(), r.column(r.schema.get_field_index("id")).to_pylist(), r.column(r.schema.get_field_index("sum(value)")).to_pylist()):
+            assert (k, i) not in seen
+            seen[(k, i)] = v
+        total += r.num_rows
+    assert total == 3000
+    want = {}
+    for r in recs:
+        for v, i, k in zip(*(c.to_pylist() for c in r.columns)):
+            want[(k, i)] = want.get((k, i), 0) + v
+    assert seen == want
