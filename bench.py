@@ -46,7 +46,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HEADLINE_ROWS = 1_000_000_000
-PROFILE_ROUNDS = ("round5", "round4", "round3", "round2", "round1")  # newest committed PMC pass of the same command first
+PROFILE_ROUNDS = ("round6", "round5", "round4", "round3", "round2", "round1")  # newest committed PMC pass of the same command first
 
 
 def parse_args(argv=None):
@@ -830,6 +830,7 @@ def measure_host_records_chains(wl, rows_per_chain=2_097_152):
         out["checked"]["oracle"] = {"rows": head.num_rows, "groups": n_groups, "what": "oracle.OraclePlan.execute over the first %d host rows vs. 8 chains pushing them as 65 536-row "
                                     "host records (fdb_plan_push), merged with fdb_plan_merge: group sets equal, float64 sums within 1e-9 relative" % head.num_rows}
         out["checked"]["against"] = "oracle (first %d host rows through 8 chains) + " % head.num_rows + out["checked"]["against"].replace("; not the oracle", "")
+    out["cpu_quota_cpus"] = cpu_quota_cpus()  # (32 chain threads on a 16-CPU quota are throttled: profiles/round6_push_bench.txt)
     out["chain_threads"] = "8 and 32 chains: pinned to the cores of the GPU's NUMA node (physicalplan.pin_thread_near); 1 chain: where the scheduler put it" if pinned[0] else "not pinned (the GPU's local_cpulist could not be read or applied)"
     return out
 
@@ -1365,6 +1366,26 @@ def oracle_parity(wl, max_rows=None):
                     "counts / int64 MIN / MAX bit-exact, float64 sums within 1e-9 relative" % ("whole" if n == wl.sample.num_rows else "first %d rows" % n)}
 
 
+def cpu_quota_cpus():
+    """The container's CPU bandwidth limit in CPUs (cgroup v2 cpu.max / v1 cfs quota), or None: what the host-side numbers of this line
+    (cpu_baseline, host_records_chains, the widening threads of a big Finish) were really given — the bench boxes report 256 CPUs and
+    grant 16."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(sample, filt, aggs, groups, target_seconds):
     """Times oracle.OraclePlan.execute (T chains → Synchronizer → final stage, the reference's algorithm restated
     in C++) on a bounded sample of the same workload; the Go reference itself cannot run here (no Go toolchain)."""
@@ -1392,7 +1413,7 @@ def cpu_baseline(sample, filt, aggs, groups, target_seconds):
     for b in batches:
         b.close()
     nrows = nrows * passes
-    return {"value": rate, "unit": "rows/s", "cores": threads, "kind": "port",
+    return {"value": rate, "unit": "rows/s", "cores": threads, "cpu_quota_cpus": cpu_quota_cpus(), "kind": "port",
             "sample": f"{nrows} rows ({passes} passes over the first resident record) in {bs}-row records, {threads} chains, {dt:.2f} s wall"}
 
 

@@ -33,7 +33,7 @@ def test_cpu_baseline_leg_reports_the_contract_fields():
     filt, aggs, groups, _ = b.query(2)
     sample = synth.prometheus_chunk(0, 0, 200_000)
     out = b.cpu_baseline(sample, filt, aggs, groups, target_seconds=0.2)
-    assert set(out) == {"value", "unit", "cores", "kind", "sample"}
+    assert set(out) == {"value", "unit", "cores", "cpu_quota_cpus", "kind", "sample"}
     assert out["unit"] == "rows/s" and out["kind"] == "port" and out["cores"] == (os.cpu_count() or 1)
     assert out["value"] > 1e5 and "rows" in out["sample"]
 

@@ -4,7 +4,7 @@ statistics, the condensed summaries, the bench lines — and turns the FETCH_SIZ
 tallies 128-byte requests as 64 bytes, MI355X_MICROARCH.md HBM section), WRITE_SIZE KiB × 1024.   python tools/collect_profiles.py round4"""
 import csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "round5"
+tag = sys.argv[1] if len(sys.argv) > 1 else "round6"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 # name → (kernel as rocprof names it, kernel as bench.py names it, rows per launch group, the command)
@@ -14,6 +14,8 @@ PASSES = {
     "cfg5": ("fdb_hash_kernel", "fdb_hash_kernel", 100_000_000, "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
     "cfg5_sorted": ("fdb_hash_kernel", "fdb_hash_kernel(runs)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
     "cfg5_sorted_wide": ("fdb_hash_kernel", "fdb_hash_kernel(runs, medium)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
+    "cfg2_sorted": ("fdb_plan_kernel", "fdb_plan_kernel", 100_000_000, "python bench.py --config 2 --cfg2-sorted --steps 10 --warmup 2 --no-cpu-baseline --no-oracle-parity"),
+    "cfg5_1B": ("fdb_hash_kernel", "fdb_hash_kernel", 1_000_000_000, "python bench.py --rows 100000000 --steps 3 --warmup 1 --no-cpu-baseline --no-oracle-parity --only-other cfg5_1B"),
     # filter(): a step is several kernels — the traffic of a step is the sum of their per-launch means (each runs once per step)
     "select": (["fdb_select_kernel", "compact_multi_kernel", "zero_regions_kernel"], "fdb_select_kernel + compact_multi_kernel", 100_000_000,
                "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select --no-oracle-parity"),
