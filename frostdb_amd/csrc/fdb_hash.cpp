@@ -611,6 +611,8 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
       FdbPresentArgs pa;
       std::memset(&pa, 0, sizeof(pa));
       pa.dense_keys = a.dense_keys; pa.n_rows = n; pa.key_words = h_key_words_; pa.n_cand = (int)cand.size();
+      static const bool no_set = std::getenv("FDB_PRESENT_NO_SET") != nullptr;
+      pa.no_wave_set = no_set ? 1 : 0;
       size_t bm_words = 0, remap_words = 0;
       for (size_t k = 0; k < cand.size(); k++) {
         const size_t len = gcols_[cand[k]].values.size();

@@ -334,6 +334,7 @@ struct FdbHashColumnsArgs {
 // present[rank] = id − 1 (the dictionary index the host widens to), counts[k] = number of present ids.
 struct FdbPresentArgs {
   const uint32_t* dense_keys; uint64_t n_rows; int32_t key_words, n_cand;
+  int32_t no_wave_set;        // A/B aid ($FDB_PRESENT_NO_SET): ask the global bitmap for every (column, id) instead of the wave's LDS set first
   uint32_t* bitmaps;          // zeroed by the caller
   uint32_t* remap;            // [Σ (dict_len[k] + 1)] at remap_off[k]
   uint32_t* present;          // same offsets

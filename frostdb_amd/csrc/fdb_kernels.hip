@@ -1083,17 +1083,20 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
   if ((int)threadIdx.x < a.n_cols && s_nulls[threadIdx.x] != 0u) atomicAdd(a.out_nulls + threadIdx.x, (unsigned long long)s_nulls[threadIdx.x]);
 }
 
-// See FdbPresentArgs. Candidates [c0, c1) of this launch keep their bitmaps in LDS (lds_off[k] words into the dynamic block); a wave
-// reads 64 key rows cooperatively (coalesced) into its tile and every lane then marks its row's ids: one LDS OR per column, or ONE per
-// wave and column when the wave's rows agree (sorted results: the slow-changing columns).
-__global__ __launch_bounds__(256) void present_ids_kernel(const FdbPresentArgs a, const int c0, const int c1, const uint32_t bm_words_total, const uint32_t bm_base) {
+// See FdbPresentArgs. A wave reads 64 key rows cooperatively (coalesced) into its LDS tile and every lane then marks its row's ids in
+// the candidates' bitmaps — GLOBAL memory, a few hundred KB that stay in the L2: a bit is read first and OR-ed only when it is not set
+// yet (after the first tiles nearly every id has been seen), ONE lane does it when the wave's rows agree (sorted results: the
+// slow-changing columns). (First version: per-workgroup bitmaps in LDS, OR-ed together at the end — 8 KB per 65 532-entry column, so
+// the candidates went in three launches of one workgroup per CU: 1.5 ms per 10 M rows × 32 columns; this one: one launch, 4 per CU.)
+__global__ __launch_bounds__(256) void present_ids_kernel(const FdbPresentArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  uint32_t* s_bm = reinterpret_cast<uint32_t*>(smem);
   const int kw = a.key_words, pitch = kw | 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* tile = s_bm + bm_words_total + (size_t)wave * 64 * pitch;
-  for (uint32_t i = threadIdx.x; i < bm_words_total; i += 256) s_bm[i] = 0u;
-  __syncthreads();
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * 64 * pitch;
+  __shared__ uint32_t s_wset[4][512];
+  uint32_t* wset = s_wset[wave];
+  for (int i = lane; i < 512; i += 64) wset[i] = 0u;
+  __builtin_amdgcn_wave_barrier();
   const uint32_t magic = (uint32_t)((0x100000000ull + (unsigned)kw - 1ull) / (unsigned)kw);
   const uint64_t n_groups = (a.n_rows + 63) >> 6;
   for (uint64_t G = (uint64_t)blockIdx.x * 4 + wave; G < n_groups; G += (uint64_t)gridDim.x * 4) {
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(256) void present_ids_kernel(const FdbPresentArgs a
     for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
       uint32_t val[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) { const uint32_t t = t0 + (uint32_t)u * 64 + lane; if (t < n_words) val[u] = src[t]; }
+      for (int u = 0; u < 16; u++) { const uint32_t t = t0 + (uint32_t)u * 64 + lane; val[u] = src[t < n_words ? t : n_words - 1u]; }  // (unconditional: a conditional load is a basic block of its own and the batch stops being one)
 #pragma unroll
       for (int u = 0; u < 16; u++) {
         const uint32_t t = t0 + (uint32_t)u * 64 + lane;
@@ -1112,22 +1115,22 @@ __global__ __launch_bounds__(256) void present_ids_kernel(const FdbPresentArgs a
     }
     __builtin_amdgcn_wave_barrier();
     const bool active = (uint32_t)lane < rows;
-    for (int k = c0; k < c1; k++) {
+    // A wave remembers what it has already marked in a small direct-mapped set in LDS (key = candidate × 65 537 + id): a result's rows
+    // repeat the same few ids per column, so after its first tiles a wave answers nearly every (column, id) from LDS and touches the global
+    // bitmaps only for ids it meets for the first time. (Asking the global bitmap per column and tile — even with the loads of eight
+    // columns in flight together — was a chain of L2 round trips per tile: 1.0–1.9 ms per 10 M rows × 32 columns.)
+    for (int k = 0; k < a.n_cand; k++) {
       const uint32_t id = active ? tile[lane * pitch + a.word[k]] : 0u;
-      const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
-      uint32_t* bm = s_bm + (a.bm_off[k] - bm_base);
-      // (a bit that is already set costs a read: after the first tiles nearly every id has been seen, and 64 lanes OR-ing into a few
-      // LDS words serialise)
-      if (__ballot(active && id != first) == 0ull) {  // the wave's rows agree on this column
-        if (lane == 0 && first != 0u && !((bm[first >> 5] >> (first & 31u)) & 1u)) atomicOr(&bm[first >> 5], 1u << (first & 31u));
-      } else if (id != 0u && !((bm[id >> 5] >> (id & 31u)) & 1u)) {
-        atomicOr(&bm[id >> 5], 1u << (id & 31u));
+      const uint32_t key = (uint32_t)k * 65537u + id + 1u;
+      const uint32_t slot = (key * 2654435761u) >> 23;
+      if (id != 0u && (a.no_wave_set || wset[slot] != key)) {
+        uint32_t* w = a.bitmaps + a.bm_off[k] + (id >> 5);
+        if (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (id & 31u)) & 1u)) atomicOr(w, 1u << (id & 31u));
+        wset[slot] = key;  // (lanes that collide on a slot overwrite each other with valid keys: a lost entry costs one more look at the bitmap)
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < bm_words_total; i += 256) { const uint32_t w = s_bm[i]; if (w != 0u) atomicOr(&a.bitmaps[bm_base + i], w); }
 }
 // One workgroup per candidate: thread t owns a contiguous share of the bitmap's words; popcounts → exclusive scan over the threads →
 // every set bit gets its rank.
@@ -2479,25 +2482,15 @@ hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32
 hipError_t fdb_launch_present_ids(const FdbPresentArgs& args, int device, hipStream_t stream) {
   if (args.n_rows == 0 || args.n_cand <= 0) return hipSuccess;
   const size_t tile_bytes = (size_t)4 * 64 * (size_t)(args.key_words | 1) * 4;
-  const size_t budget = ((size_t)150 << 10) - tile_bytes;  // LDS left for bitmaps
+  if (tile_bytes > 150 * 1024) return hipErrorInvalidValue;
+  if (tile_bytes > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&present_ids_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipGetLastError();
+  }
   const int64_t cus = fdb_scan_default_grid(device) / 2;
   const int64_t n_groups = (int64_t)((args.n_rows + 63) / 64);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&present_ids_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  (void)hipGetLastError();
-  int c0 = 0;
-  while (c0 < args.n_cand) {  // (the bitmaps of candidates c0 … c1 − 1 are contiguous: bm_off ascends)
-    int c1 = c0;
-    size_t words = 0;
-    while (c1 < args.n_cand) {
-      const size_t w = ((size_t)args.dict_len[c1] + 32) / 32;
-      if (c1 > c0 && (words + w) * 4 > budget) break;
-      if (w * 4 > budget) return hipErrorInvalidValue;
-      words += w; c1++;
-    }
-    const unsigned grid = (unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * 2);
-    hipLaunchKernelGGL(present_ids_kernel, dim3(grid), dim3(256), words * 4 + tile_bytes, stream, args, c0, c1, (uint32_t)words, args.bm_off[c0]);
-    c0 = c1;
-  }
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)150 << 10) / tile_bytes));
+  hipLaunchKernelGGL(present_ids_kernel, dim3((unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * per_cu)), dim3(256), tile_bytes, stream, args);
   return hipGetLastError();
 }
 hipError_t fdb_launch_rank_ids(const FdbPresentArgs& args, hipStream_t stream) {
@@ -2690,6 +2683,36 @@ __global__ __launch_bounds__(256) void runs_flags_wide_kernel(const unsigned lon
   const RunRef a = run_ref(segs, phys[i]), b = run_ref(segs, phys[i - 1]);
   typedef const __attribute__((address_space(4))) FdbRunCol* ConstRunCols;
   ConstRunCols q = (ConstRunCols)cols;
+  if (a.kw == -1 && b.kw == -1) {
+    // two medium records (32 two-byte ids each): four 16-byte loads per record instead of a 4-byte load per column and record — 80 bytes
+    // apart from lane to lane, every one of those was a sector of its own (0.92 ms per 10 M runs); equal tuples, the usual case inside a
+    // group that a wave or record boundary cut, are decided by 8 compares
+    const run_u32x4* ta = reinterpret_cast<const run_u32x4*>(a.t);
+    const run_u32x4* tb = reinterpret_cast<const run_u32x4*>(b.t);
+    uint32_t wa[16], wb[16];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const run_u32x4 x = ta[v], y = tb[v];
+      wa[4 * v] = x.x; wa[4 * v + 1] = x.y; wa[4 * v + 2] = x.z; wa[4 * v + 3] = x.w;
+      wb[4 * v] = y.x; wb[4 * v + 1] = y.y; wb[4 * v + 2] = y.z; wb[4 * v + 3] = y.w;
+    }
+    uint32_t diff = 0;
+#pragma unroll
+    for (int v = 0; v < 16; v++) diff |= (wa[v] != wb[v]) ? (1u << v) : 0u;
+    if (diff == 0u) { flags[i] = 0u; return; }
+    flags[i] = 1u;
+    int c = 2 * __builtin_ctz(diff);  // the first word that differs holds columns c and c + 1
+    uint32_t xa = 0, xb = 0;
+#pragma unroll
+    for (int v = 0; v < 16; v++) if (v == (c >> 1)) { xa = wa[v]; xb = wb[v]; }
+    if ((xa & 0xFFFFu) == (xb & 0xFFFFu)) { c++; xa >>= 16; xb >>= 16; }
+    const uint32_t ic = xa & 0xFFFFu, ip = xb & 0xFFFFu;
+    if (c < n_cols && q[c].kind == 0) {
+      const uint32_t off = q[c].rank_off;
+      if (rank32[off + ic] < rank32[off + ip]) atomicOr(violation, 1u);
+    }
+    return;
+  }
   for (int c = 0; c < n_cols; c++) {
     const int kind = q[c].kind, word = q[c].word, gi = q[c].gi;
     if (kind == 0) {
