@@ -679,7 +679,18 @@ void Plan::comm_exchange(Comm& comm, Plan& shard) {
   if (timing) { hip_check(hipEventRecord(e1, stream_), "hipEventRecord"); merge_events_.emplace_back(e0, e1); }
   sync();  // the rows have arrived (and this plan's timing events / scratch are settled)
   pt.mark("exchange: all-to-all");
-  shard.hash_import(recv, recv_rows);
+  // The owners merge what they received RANK BY RANK (the regions of `recv` are in rank order): every launch holds a group at most once, and
+  // a group's partial sums are added in rank order — the merged float64 sums are a function of the ranks' partial sums and the
+  // communicator alone, whatever order the rows arrived in ("float sums merged in fixed rank order"; one launch over all
+  // rows added them with atomics in whatever order the waves ran).
+  {
+    const unsigned long long* at = recv;
+    for (int p = 0; p < comm.size; p++) {
+      const int64_t w = words[(size_t)p][(size_t)comm.rank];
+      if (w > 0) shard.hash_import(at, w / (rw / 2), /*unique_rows=*/true);
+      at += w;
+    }
+  }
   pt.mark("exchange: import");
 }
 

@@ -1034,7 +1034,7 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
   *dev_rows = d_rows;
 }
 
-void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
+void Plan::hash_import(const void* dev_rows, int64_t n_rows, bool unique_rows) {
   runs_to_table();
   if (n_rows <= 0) return;
   hip_check(hipSetDevice(device_), "hipSetDevice");
@@ -1059,7 +1059,7 @@ void Plan::hash_import(const void* dev_rows, int64_t n_rows) {
   m.entries = (const unsigned long long*)((const uint32_t*)dev_rows + kw);
   m.n = n_rows;
   m.in_key_words = rw; m.in_entry_words = rw / 2;
-  m.unique_source = 0;  // (rows of several ranks: a group comes once per rank that saw it)
+  m.unique_source = unique_rows ? 1 : 0;  // (rows of several ranks in one call: a group comes once per rank that saw it)
   hip_check(fdb_launch_hash_merge(m, device_, stream_), "hash merge");
   hip_check(hipStreamSynchronize(stream_), "sync(hash import)");  // the caller may free `dev_rows` when this returns
   pt.mark("import: merge kernel");

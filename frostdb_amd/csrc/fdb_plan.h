@@ -260,7 +260,9 @@ class Plan {
   // Re-keys every occupied entry into `layout`'s columns / key ids and packs it into partition (fingerprint % n_parts);
   // *dev_rows (owned by this plan until its next push / close) holds the partitions back to back, counts[p] rows each.
   void hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* counts, int32_t* row_words32);
-  void hash_import(const void* dev_rows, int64_t n_rows);       // rows packed for THIS plan's layout
+  // rows packed for THIS plan's layout. `unique_rows`: every group occurs at most once among them (the rows one rank exported from its
+  // one table) — a group they create takes plain stores
+  void hash_import(const void* dev_rows, int64_t n_rows, bool unique_rows = false);
   // Cross-GPU merges over a communicator (fdb_comm.cpp; ≙ Synchronizer + final stage, synchronize.go:31-53). Collective calls.
   bool comm_allreduce(Comm& comm);               // aligned dense tables: in-place all-reduce on this plan's stream; false = layouts differ, nothing changed
   void comm_exchange(Comm& comm, Plan& shard);   // any tables: schema agreement + hash-partitioned exchange into `shard` (a fresh clone)

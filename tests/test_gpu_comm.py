@@ -140,6 +140,59 @@ def test_local_ranks_unaligned_layouts_take_the_exchange(pp, fcomm, world):
         c.close()
 
 
+def test_exchange_adds_the_ranks_partial_sums_in_rank_order(pp, fcomm):
+    """The hash-partitioned exchange merges what an owner received RANK BY RANK: a group's float64 partial sums are added in rank order,
+    so the merged bits are a function of the ranks' partial sums alone — here every rank holds every group exactly once
+    (its partial sum IS its row's value), values spread over 12 orders of magnitude so that (a + b) + c ≠ a + (b + c) nearly everywhere;
+    the result must equal the left-to-right float64 sum over the ranks bit for bit, on several passes."""
+    world, n_groups = 4, 30_000
+    rng = np.random.default_rng(8)
+    vals = [rng.uniform(-1, 1, n_groups) * 10.0 ** rng.integers(-6, 7, n_groups) for _ in range(world)]
+
+    def shard(r):
+        order = rng.permutation(n_groups)  # (every rank meets the groups in its own order)
+        g = np.arange(n_groups)[order]
+        arrays, names = [], []
+        for c in range(10):
+            digit = ((g >> (2 * c)) & 3).astype(np.uint32)
+            arrays.append(pa.DictionaryArray.from_arrays(pa.array(digit), pa.array([b"c%02d=%d" % (c, k) for k in range(4)], type=pa.binary())))
+            names.append("labels.l%02d" % c)
+        arrays.append(pa.array(vals[r][order]))
+        names.append("value")
+        return pa.RecordBatch.from_arrays(arrays, names=names)
+
+    shards = [shard(r) for r in range(world)]
+    want = vals[0].copy()
+    for r in range(1, world):
+        want = want + vals[r]  # left to right: ((v0 + v1) + v2) + v3
+    aggs, groups = [Sum(Col("value"))], [DynCol("labels")]
+    for _ in range(3):
+        comms = fcomm.Comm.init_local([0] * world)
+
+        def rank_fn(r):
+            plan = pp.HashAggregatePlan(None, aggs, groups)
+            rb = pp.ResidentBatch(shards[r])
+            try:
+                plan.Callback(rb)
+                return comms[r].merge(plan)
+            finally:
+                plan.Close()
+                rb.close()
+
+        parts = run_ranks(world, rank_fn)
+        got = np.full(n_groups, np.nan)
+        for out in parts:
+            gid = np.zeros(out.num_rows, dtype=np.int64)
+            for c in range(10):
+                col = out.column(out.schema.get_field_index("labels.l%02d" % c))
+                digit = np.array([int(v.rsplit(b"=", 1)[1]) for v in col.dictionary.to_pylist()], dtype=np.int64)[col.indices.to_numpy()]
+                gid |= digit << (2 * c)
+            got[gid] = out.column(out.schema.get_field_index("sum(value)")).to_numpy()
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        for c in comms:
+            c.close()
+
+
 def test_local_ranks_high_cardinality_exchange(pp, fcomm):
     """Hash-mode tables (12 label columns, ≈60 k groups) on 4 ranks: shards are disjoint, their union is the oracle's result."""
     world, n_cols, n = 4, 12, 60_000
