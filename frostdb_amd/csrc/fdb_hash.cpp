@@ -1021,6 +1021,12 @@ void Plan::hash_export(Plan& layout, int n_parts, void** dev_rows, int64_t* coun
   bool same = dkw >= a.in_words && layout.gcols_.size() == gcols_.size();  // (a layout column we do not have would keep what our tuple holds at its word)
   for (size_t sc = 0; sc < gcols_.size(); sc++) if (cols[sc].src_word != cols[sc].word) same = false;
   a.same_layout = same;
+  bool same_ids = same;
+  for (size_t sc = 0; sc < gcols_.size() && same_ids; sc++) {
+    if (cols[sc].gi != (int)sc) same_ids = false;
+    for (size_t v = 1; v < id_map[sc].size() && same_ids; v++) if (id_map[sc][v] != (uint32_t)v) same_ids = false;
+  }
+  a.same_ids = same_ids;  // (the usual case for the parts of one table: every rank interned the same dictionaries in the same order)
   // counts per (wave, partition) → region bases → scatter: three launches back to back, one wait
   void* d_part_scratch = ctx_->dev_alloc(fdb_hash_partition_scratch_bytes(device_, a));
   scratch_.push_back(d_part_scratch);

@@ -470,6 +470,7 @@ struct FdbHashPartArgs {
   int32_t n_cols, entry_words, key_words, dst_key_words, row_words32, n_vals, n_parts;
   int32_t in_words;     // words of a source tuple that the columns reach (0: the whole stride)
   int32_t same_layout;  // source and destination tuples have one layout
+  int32_t same_ids;     // … and every column keeps its key ids and its index: the fingerprint stored in the table IS the destination's (the counting pass reads entries only)
 };
 size_t fdb_hash_partition_scratch_bytes(int device, const FdbHashPartArgs& args);
 hipError_t fdb_launch_hash_partition(const FdbHashPartArgs& args, int device, void* scratch, hipStream_t stream);
