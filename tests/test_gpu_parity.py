@@ -834,6 +834,32 @@ def test_finish_emits_several_records_at_the_key_builders_size_limit(pp, monkeyp
     finally:
         plan.Close()
     assert finished == [True] and rows_of(seen) == want
+    # every kind of column through the cut: a dictionary key with NULLs, a bool key, NULL stacktraces, float and count aggregates
+    rng = np.random.default_rng(7)
+    wide = []
+    for r in recs:
+        n = r.num_rows
+        st = pa.array([None if i % 17 == 0 else v for i, v in enumerate(r.column(2).to_pylist())], type=pa.binary())
+        lab = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 5, n).astype(np.uint32), mask=rng.random(n) < 0.1), pa.array([b"a", b"b", b"c", b"d", b"e"], type=pa.binary()))
+        wide.append(pa.RecordBatch.from_arrays([r.column(0), r.column(1), st, lab, pa.array(rng.random(n) < 0.5), pa.array(rng.uniform(0, 1, n))],
+                                                names=["value", "id", "stacktrace", "labels.x", "flag", "f"]))
+    aggs2, groups2 = [Sum(Col("value")), Count(Col("value")), Max(Col("f"))], [Col("stacktrace"), Col("labels.x"), Col("flag"), Col("id")]
+    monkeypatch.delenv("FDB_TEST_MAX_KEY_BYTES")  # (the oracle's one-record answer: the cut changes which record a group is in, not the groups)
+    want2 = run_oracle(wide, None, aggs2, groups2)
+    monkeypatch.setenv("FDB_TEST_MAX_KEY_BYTES", str(limit))
+    plan = pp.HashAggregatePlan(None, aggs2, groups2)
+    try:
+        for r in wide:
+            plan.Callback(r)
+        got_recs = plan.FinishAll()
+    finally:
+        plan.Close()
+    assert len(got_recs) > 20 and sum(r.num_rows for r in got_recs) == len(want2["id"])
+    for r in got_recs:
+        st = r.column(r.schema.get_field_index("stacktrace"))
+        assert sum(len(x) for x in st.to_pylist() if x is not None) <= limit
+    got2 = _concat_results(got_recs)
+    assert_same_result(got2, want2, ["stacktrace", "labels.x", "flag", "id"] + [a.Name() for a in aggs2])
     # without the hook: one record (3 MB of keys are far below math.MaxInt32)
     monkeypatch.delenv("FDB_TEST_MAX_KEY_BYTES")
     plan = pp.HashAggregatePlan(None, aggs, groups)
