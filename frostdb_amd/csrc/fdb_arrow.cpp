@@ -2,6 +2,7 @@
 #include "fdb_arrow.h"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string_view>
 #include <unordered_set>
@@ -307,6 +308,27 @@ std::shared_ptr<HostDict> encode_plain(const HostColView& col, std::vector<uint3
   return d;
 }
 
+const std::vector<int32_t>& HostDict::arrow_offsets() const {
+  std::call_once(offsets_once_, [this] {
+    arrow_offsets_.resize(values.size() + 1);
+    uint64_t off = 0;
+    for (size_t i = 0; i < values.size(); i++) { arrow_offsets_[i] = (int32_t)off; off += values[i].size(); }
+    arrow_offsets_[values.size()] = (int32_t)off;
+  });
+  return arrow_offsets_;
+}
+
+const std::vector<uint32_t>& HostDict::sorted_ranks() const {
+  std::call_once(ranks_once_, [this] {
+    std::vector<uint32_t> order(values.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    if (!std::is_sorted(values.begin(), values.end())) std::stable_sort(order.begin(), order.end(), [this](uint32_t x, uint32_t y) { return values[x] < values[y]; });
+    sorted_ranks_.resize(values.size());
+    for (size_t r = 0; r < order.size(); r++) sorted_ranks_[order[r]] = (uint32_t)r;
+  });
+  return sorted_ranks_;
+}
+
 template <typename S>
 void set_dictionary(OutColumn* oc, const std::vector<S>& values, const std::string& value_format) {
   const bool large = value_format == "U" || value_format == "Z";
@@ -432,7 +454,7 @@ std::vector<OutColumn> slice_columns(const std::vector<OutColumn>& cols, int64_t
     }
     if (c.is_dict) {
       o.is_dict = true; o.dict_format = c.dict_format;
-      o.dict_offsets = c.dict_offsets; o.dict_offsets64 = c.dict_offsets64; o.dict_data = c.dict_data;
+      o.dict_offsets = c.dict_offsets; o.dict_offsets64 = c.dict_offsets64; o.dict_data = c.dict_data; o.dict_ref = c.dict_ref;
     }
     out.push_back(std::move(o));
   }
@@ -526,15 +548,20 @@ void export_record(std::vector<OutColumn>&& cols_in, int64_t rows, ArrowArray* o
       ArrowArray& d = h->dict_arrays[i];
       std::memset(&d, 0, sizeof(d));
       const bool wide = !c.dict_offsets64.empty();
-      d.length = (int64_t)(wide ? c.dict_offsets64.size() : c.dict_offsets.size()) - 1;
+      d.length = c.dict_entries();
       d.null_count = 0;
       d.n_buffers = 3;
       std::vector<const void*>& db = h->buffers[n + i];
       db.resize(3);
       db[0] = nullptr;
-      db[1] = wide ? (const void*)c.dict_offsets64.data() : (const void*)c.dict_offsets.data();
       static const char kNoData = 0;
-      db[2] = c.dict_data.empty() ? (const void*)&kNoData : (const void*)c.dict_data.data();
+      if (c.dict_ref) {  // (the interned dictionary's own buffers: the holder keeps the reference until the consumer releases the record)
+        db[1] = (const void*)c.dict_ref->arrow_offsets().data();
+        db[2] = c.dict_ref->concat.empty() ? (const void*)&kNoData : (const void*)c.dict_ref->concat.data();
+      } else {
+        db[1] = wide ? (const void*)c.dict_offsets64.data() : (const void*)c.dict_offsets.data();
+        db[2] = c.dict_data.empty() ? (const void*)&kNoData : (const void*)c.dict_data.data();
+      }
       d.buffers = db.data();
       d.release = noop_release_array;
       a.dictionary = &d;

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <string_view>
@@ -22,6 +23,12 @@ enum class ColKind : int32_t { I64 = 1, U64 = 2, F64 = 3, BOOL = 4, STR = 5, DIC
 
 // The dictionary of one dictionary-encoded column, kept on the host (strings never go to the device).
 struct HostDict {
+  HostDict() = default;
+  HostDict(const HostDict& o) : values(o.values), value_format(o.value_format), hash(o.hash), unique(o.unique), plain(o.plain), lens(o.lens), concat(o.concat) {}  // (the lazily computed caches below are not copied)
+  HostDict& operator=(const HostDict& o) {
+    if (this != &o) { values = o.values; value_format = o.value_format; hash = o.hash; unique = o.unique; plain = o.plain; lens = o.lens; concat = o.concat; }
+    return *this;
+  }
   std::vector<std::string> values;
   std::string value_format;  // "z" (binary) or "u" (utf8); large dictionaries are narrowed on import, a plain column keeps "Z" / "U"
   uint64_t hash = 0;         // content hash (lengths + bytes), computed at import
@@ -31,8 +38,19 @@ struct HostDict {
   // we know?" is then two memcmps instead of one per entry.
   std::vector<uint32_t> lens;
   std::string concat;
+  // What depends on the CONTENT only is computed once per interned dictionary, not once per plan and Finish (a query creates its plans
+  // anew; the dictionaries of a table's parts are shared): the Arrow offsets of the entries (n + 1, into `concat`) and the rank of
+  // every entry among the sorted values (bytewise ascending; entries with equal bytes in entry order). 65 532-entry dictionaries on 32
+  // group columns: ≈ 4 ms of every Finish before.
+  const std::vector<int32_t>& arrow_offsets() const;
+  const std::vector<uint32_t>& sorted_ranks() const;
   bool utf8() const { return value_format == "u" || value_format == "U"; }
   bool same_content(const HostDict& o) const { return hash == o.hash && plain == o.plain && values == o.values; }
+
+ private:
+  mutable std::once_flag offsets_once_, ranks_once_;
+  mutable std::vector<int32_t> arrow_offsets_;
+  mutable std::vector<uint32_t> sorted_ranks_;
 };
 
 // A borrowed view of one column of an incoming record; valid only while the caller's ArrowArray is.
@@ -84,6 +102,10 @@ struct OutColumn {
   std::vector<int32_t> dict_offsets;  // n_dict + 1
   std::vector<int64_t> dict_offsets64;  // … for the large formats "Z" / "U" (instead of dict_offsets)
   std::vector<char> dict_data;
+  std::shared_ptr<const HostDict> dict_ref;  // instead of the three vectors above: the dictionary IS this interned one (its cached offsets, its bytes)
+  int64_t dict_entries() const { return dict_ref ? (int64_t)dict_ref->values.size() : (int64_t)(dict_offsets64.empty() ? dict_offsets.size() : dict_offsets64.size()) - 1; }
+  int64_t dict_offset(int64_t i) const { return dict_ref ? dict_ref->arrow_offsets()[(size_t)i] : dict_offsets64.empty() ? dict_offsets[(size_t)i] : dict_offsets64[(size_t)i]; }
+  const char* dict_bytes() const { return dict_ref ? dict_ref->concat.data() : dict_data.data(); }
   // plain string / binary columns (format u / z, or U / Z with 64-bit offsets past 2 GiB of data): `values` holds the offsets
   bool is_str = false;
   std::vector<char> str_data;

@@ -39,9 +39,8 @@ struct KeyReader {
     if (c->is_dict) {
       if (!ok) { k->push_back('\0'); return; }
       uint32_t idx; std::memcpy(&idx, vals + (size_t)i * 4, 4);
-      const bool wide = !c->dict_offsets64.empty();
-      const int64_t b0 = wide ? c->dict_offsets64[idx] : c->dict_offsets[idx], b1 = wide ? c->dict_offsets64[idx + 1] : c->dict_offsets[idx + 1];
-      put_bytes(c->dict_data.data() + b0, (size_t)(b1 - b0), k);
+      const int64_t b0 = c->dict_offset((int64_t)idx), b1 = c->dict_offset((int64_t)idx + 1);
+      put_bytes(c->dict_bytes() + b0, (size_t)(b1 - b0), k);
     } else if (c->is_str) {
       if (!ok) { k->push_back('\0'); return; }
       const bool wide = c->format == "U" || c->format == "Z";

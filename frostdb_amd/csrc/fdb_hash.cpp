@@ -737,7 +737,15 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
     oc.length = (int64_t)n;
     oc.format = g.kind == 0 ? "I" : g.is_bool ? "b" : g.is_u64 ? "L" : "l";
     if (n > 0) { oc.backing = backing; oc.ext_values = g.is_bool ? nullptr : h_block + off_key[c]; oc.ext_validity = h_block + off_bits[c]; }  // (narrow columns: the widened array)
-    if (g.kind == 0 && !g.plain) set_dictionary(&oc, g.values, g.value_format);
+    if (g.kind == 0 && !g.plain) {
+      // (the column's values ARE one interned dictionary — the usual case, parts of a table share theirs: its cached Arrow offsets and its
+      // bytes are handed out as they are instead of copying every value into a new buffer per Finish)
+      if (g.whole_dictionary() != nullptr && g.adopted->value_format == g.value_format && g.adopted->concat.size() <= 0x7FFFFFFFull) {
+        oc.is_dict = true; oc.dict_format = g.value_format; oc.dict_ref = g.adopted;
+      } else {
+        set_dictionary(&oc, g.values, g.value_format);
+      }
+    }
     out->push_back(std::move(oc));
   }
   std::vector<size_t> out_of_agg(aggs_.size(), (size_t)-1);  // physical aggregate → its output column
@@ -1345,14 +1353,19 @@ void Plan::runs_rank_tables(RunsView* v, std::vector<void*>* owned) {
     const GroupColState& g = gcols_[c];
     rc[c].kind = g.kind == 0 ? 0 : g.is_u64 ? 3 : 1; rc[c].word = g.word; rc[c].gi = (int32_t)c; rc[c].rank_off = (uint32_t)rank32.size();
     if (g.kind != 0) continue;
+    const size_t off = rank32.size();
+    rank32.resize(off + g.values.size() + 1);
+    rank32[off] = 0xFFFFFFFFu;
+    if (const HostDict* whole = g.whole_dictionary(); whole != nullptr && whole->unique) {  // the ranks of an interned dictionary are computed once per process
+      const std::vector<uint32_t>& r = whole->sorted_ranks();
+      std::copy(r.begin(), r.end(), rank32.begin() + (ptrdiff_t)off + 1);
+      continue;
+    }
     std::vector<uint32_t> order(g.values.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
     // (a dictionary whose values are already in order — what a writer that sorts its dictionary pages produces — needs no sort: 65 532 values × 8
     // columns were 20 ms of a Finish)
     if (!std::is_sorted(g.values.begin(), g.values.end())) std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g.values[x] < g.values[y]; });
-    const size_t off = rank32.size();
-    rank32.resize(off + g.values.size() + 1);
-    rank32[off] = 0xFFFFFFFFu;
     for (size_t r = 0; r < order.size(); r++) rank32[off + order[r] + 1] = (uint32_t)r;
   }
   uint32_t* d_rank32 = (uint32_t*)ctx_->dev_alloc(rank32.size() * 4 + 256);

@@ -1001,6 +1001,7 @@ std::shared_ptr<const std::vector<uint32_t>> GroupColState::lut_for(const std::s
     // different dictionary ever shows up)
     values.reserve(d->values.size());
     for (size_t e = 0; e < d->values.size(); e++) { values.emplace_back(d->values[e]); (*lut)[e] = (uint32_t)e + 1; }
+    adopted = d;
   } else {
     for (size_t e = 0; e < d->values.size(); e++) (*lut)[e] = intern(std::string_view(d->values[e]));
   }

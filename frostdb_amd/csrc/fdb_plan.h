@@ -152,6 +152,8 @@ struct GroupColState {
   std::string value_format = "z";
   std::vector<std::string_view> values;                     // id - 1 → value (views into `owners`)
   std::vector<std::shared_ptr<const HostDict>> owners;      // keep the viewed strings alive
+  std::shared_ptr<const HostDict> adopted;                  // the first dictionary, when its entries became ids 1 … n wholesale (lut_for); still the whole value list while values.size() == its size
+  const HostDict* whole_dictionary() const { return adopted && !adopted->plain && values.size() == adopted->values.size() ? adopted.get() : nullptr; }
   uint32_t cap = 1;                                         // ids live in [0, cap)
   uint32_t stride = 1;
 
