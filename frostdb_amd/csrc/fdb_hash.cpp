@@ -625,6 +625,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
       pa.present = (uint32_t*)alloc(remap_words * 4);
       pa.counts = (unsigned long long*)alloc(cand.size() * 8 + 256);
       hip_check(hipMemsetAsync(pa.bitmaps, 0, bm_words * 4, stream_), "hipMemsetAsync(present bitmaps)");
+      hip_check(hipMemsetAsync(pa.counts, 0, cand.size() * 8, stream_), "hipMemsetAsync(present counts)");  // (live counts of the marking pass)
       hip_check(fdb_launch_present_ids(pa, device_, stream_), "present ids");
       hip_check(fdb_launch_rank_ids(pa, stream_), "rank ids");
       std::vector<unsigned long long> h_counts(cand.size());

@@ -1083,53 +1083,62 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
   if ((int)threadIdx.x < a.n_cols && s_nulls[threadIdx.x] != 0u) atomicAdd(a.out_nulls + threadIdx.x, (unsigned long long)s_nulls[threadIdx.x]);
 }
 
-// See FdbPresentArgs. A wave reads 64 key rows cooperatively (coalesced) into its LDS tile and every lane then marks its row's ids in
-// the candidates' bitmaps — GLOBAL memory, a few hundred KB that stay in the L2: a bit is read first and OR-ed only when it is not set
-// yet (after the first tiles nearly every id has been seen), ONE lane does it when the wave's rows agree (sorted results: the
-// slow-changing columns). (First version: per-workgroup bitmaps in LDS, OR-ed together at the end — 8 KB per 65 532-entry column, so
-// the candidates went in three launches of one workgroup per CU: 1.5 ms per 10 M rows × 32 columns; this one: one launch, 4 per CU.)
+// See FdbPresentArgs. The dense key rows are streamed as they lie — a lane takes a 16-byte quad (4 consecutive words of one row: 4 group
+// columns), 4 quads in flight — and marks its words' ids in the candidates' bitmaps in GLOBAL memory (a few hundred KB that stay in
+// the L2). A wave first asks a small direct-mapped set in LDS for (candidate, id) pairs it has marked before: a result's rows repeat the
+// same few ids per column, so after its first rows a wave answers nearly everything from LDS. A candidate with more than 256 ids present
+// cannot be narrowed any more and is dropped by everybody (live counts in a.counts; rank_ids_kernel overwrites them with the exact ones).
+// (Versions 1-4 staged 64 rows in an LDS tile and walked the columns per row: 1.0-2.0 ms per 10 M rows x 32 columns, latency-bound.)
+typedef uint32_t pid_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void present_ids_kernel(const FdbPresentArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int kw = a.key_words, pitch = kw | 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t* tile = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * 64 * pitch;
   __shared__ uint32_t s_wset[4][512];
+  __shared__ int s_cand_of_word[256];      // key-row word -> candidate (or -1)
+  __shared__ unsigned int s_dead[FDB_MAX_HASH_GCOLS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* wset = s_wset[wave];
   for (int i = lane; i < 512; i += 64) wset[i] = 0u;
-  __builtin_amdgcn_wave_barrier();
-  const uint32_t magic = (uint32_t)((0x100000000ull + (unsigned)kw - 1ull) / (unsigned)kw);
-  const uint64_t n_groups = (a.n_rows + 63) >> 6;
-  for (uint64_t G = (uint64_t)blockIdx.x * 4 + wave; G < n_groups; G += (uint64_t)gridDim.x * 4) {
-    const uint32_t rows = (uint32_t)(a.n_rows - G * 64 < 64 ? a.n_rows - G * 64 : 64);
-    const uint32_t* src = a.dense_keys + G * 64 * (uint64_t)kw;
-    const uint32_t n_words = rows * (uint32_t)kw;
-    for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
-      uint32_t val[16];
+  for (int i = threadIdx.x; i < 256; i += 256) s_cand_of_word[i] = -1;
+  if (threadIdx.x < FDB_MAX_HASH_GCOLS) s_dead[threadIdx.x] = 0u;
+  __syncthreads();
+  if ((int)threadIdx.x < a.n_cand && a.word[threadIdx.x] < 256) s_cand_of_word[a.word[threadIdx.x]] = (int)threadIdx.x;
+  __syncthreads();
+  const uint32_t qpr = (uint32_t)a.key_words >> 2;  // quads per row
+  const uint32_t qmagic = (uint32_t)((0x100000000ull + qpr - 1ull) / qpr);  // x / qpr = umulhi(x, qmagic) for the small x below
+  const uint64_t total = a.n_rows * (uint64_t)qpr;
+  const pid_u32x4* src = reinterpret_cast<const pid_u32x4*>(a.dense_keys);
+  // (a wave's 4 loads cover 256 consecutive quads: load u takes quad wave_base + u * 64 + lane)
+  for (uint64_t wave_base = ((uint64_t)blockIdx.x * 4 + wave) * 256; wave_base < total; wave_base += (uint64_t)gridDim.x * 4 * 256) {
+    pid_u32x4 v[4];
+    uint64_t qi[4];
+    const uint32_t jb = (uint32_t)(wave_base % qpr);  // (wave-uniform: the quad-in-row of the wave's first quad)
 #pragma unroll
-      for (int u = 0; u < 16; u++) { const uint32_t t = t0 + (uint32_t)u * 64 + lane; val[u] = src[t < n_words ? t : n_words - 1u]; }  // (unconditional: a conditional load is a basic block of its own and the batch stops being one)
+    for (int u = 0; u < 4; u++) { qi[u] = wave_base + (uint64_t)u * 64 + lane; v[u] = src[qi[u] < total ? qi[u] : total - 1]; }
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
-        if (t < n_words) { const uint32_t rr = __umulhi(t, magic); tile[rr * pitch + (t - rr * (uint32_t)kw)] = val[u]; }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const bool active = (uint32_t)lane < rows;
-    // A wave remembers what it has already marked in a small direct-mapped set in LDS (key = candidate × 65 537 + id): a result's rows
-    // repeat the same few ids per column, so after its first tiles a wave answers nearly every (column, id) from LDS and touches the global
-    // bitmaps only for ids it meets for the first time. (Asking the global bitmap per column and tile — even with the loads of eight
-    // columns in flight together — was a chain of L2 round trips per tile: 1.0–1.9 ms per 10 M rows × 32 columns.)
-    for (int k = 0; k < a.n_cand; k++) {
-      const uint32_t id = active ? tile[lane * pitch + a.word[k]] : 0u;
-      const uint32_t key = (uint32_t)k * 65537u + id + 1u;
-      const uint32_t slot = (key * 2654435761u) >> 23;
-      if (id != 0u && (a.no_wave_set || wset[slot] != key)) {
-        uint32_t* w = a.bitmaps + a.bm_off[k] + (id >> 5);
-        if (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (id & 31u)) & 1u)) atomicOr(w, 1u << (id & 31u));
+    for (int u = 0; u < 4; u++) {
+      if (qi[u] >= total) continue;
+      const uint32_t x = jb + (uint32_t)u * 64u + (uint32_t)lane;
+      const uint32_t j = x - __umulhi(x, qmagic) * qpr;
+      const uint32_t ids[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const int k = s_cand_of_word[j * 4 + w];
+        const uint32_t id = ids[w];
+        if (k < 0 || id == 0u || s_dead[k] != 0u) continue;
+        const uint32_t key = (uint32_t)k * 65537u + id + 1u;
+        const uint32_t slot = (key * 2654435761u) >> 23;
+        if (wset[slot] == key) continue;
+        uint32_t* bw = a.bitmaps + a.bm_off[k] + (id >> 5);
+        const uint32_t bit = 1u << (id & 31u);
+        if (!(__hip_atomic_load(bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) {
+          if (!(atomicOr(bw, bit) & bit)) {  // this lane set it: one more id present
+            if (atomicAdd(a.counts + k, 1ull) + 1ull > 256ull) s_dead[k] = 1u;
+          }
+        } else if (__hip_atomic_load(a.counts + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 256ull) {
+          s_dead[k] = 1u;
+        }
         wset[slot] = key;  // (lanes that collide on a slot overwrite each other with valid keys: a lost entry costs one more look at the bitmap)
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 // One workgroup per candidate: thread t owns a contiguous share of the bitmap's words; popcounts → exclusive scan over the threads →
@@ -2481,16 +2490,11 @@ hipError_t fdb_launch_hash_compact(const unsigned long long* table, const uint32
 
 hipError_t fdb_launch_present_ids(const FdbPresentArgs& args, int device, hipStream_t stream) {
   if (args.n_rows == 0 || args.n_cand <= 0) return hipSuccess;
-  const size_t tile_bytes = (size_t)4 * 64 * (size_t)(args.key_words | 1) * 4;
-  if (tile_bytes > 150 * 1024) return hipErrorInvalidValue;
-  if (tile_bytes > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&present_ids_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipGetLastError();
-  }
+  if (args.key_words % 4 != 0 || args.key_words > 256 || ((uintptr_t)args.dense_keys & 15u) != 0) return hipErrorInvalidValue;
   const int64_t cus = fdb_scan_default_grid(device) / 2;
-  const int64_t n_groups = (int64_t)((args.n_rows + 63) / 64);
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ((size_t)150 << 10) / tile_bytes));
-  hipLaunchKernelGGL(present_ids_kernel, dim3((unsigned)std::min<int64_t>((n_groups + 3) / 4, cus * per_cu)), dim3(256), tile_bytes, stream, args);
+  const uint64_t total = args.n_rows * (uint64_t)(args.key_words / 4);
+  const int64_t blocks = (int64_t)((total + 1023) / 1024);
+  hipLaunchKernelGGL(present_ids_kernel, dim3((unsigned)std::min<int64_t>(blocks, cus * 8)), dim3(256), 0, stream, args);
   return hipGetLastError();
 }
 hipError_t fdb_launch_rank_ids(const FdbPresentArgs& args, hipStream_t stream) {
