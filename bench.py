@@ -928,30 +928,36 @@ def other_configs(args, wl, rank, device, group, comm):
         others["host_records_chains"] = measure_host_records_chains(wl)
     wl.release()
     for cfg, st, wu in ((3, max(5, args.steps // 2), 2), (5, 3, 1)):
-        if not want(f"cfg{cfg}") and not (cfg == 5 and only and "cfg5_merge" in only):
+        sub5 = {"cfg5_merge", "cfg5_sorted", "cfg5_sorted_sets", "cfg5_sorted_wide"}
+        if not want(f"cfg{cfg}") and not (cfg == 5 and only and (only & sub5)):
             continue
-        w2 = Workload(args, cfg, 100_000_000, rank, device)
-        if cfg == 5 and not want("cfg5"):  # (--only-other cfg5_merge)
-            if len(w2.resident) >= 2:
+        if cfg == 5 and not want("cfg5"):  # (--only-other with cfg5_* entries alone: the unsorted scan itself is not run)
+            if "cfg5_merge" in only:
+                w2 = Workload(args, cfg, 100_000_000, rank, device)
+                if len(w2.resident) >= 2:
+                    others["cfg5_merge"] = measure_cfg5_merge(args, w2, st, wu, ceiling)
+                w2.release()
+            only_sorted = True
+        else:
+            only_sorted = False
+        if not only_sorted:
+            w2 = Workload(args, cfg, 100_000_000, rank, device)
+            r2 = run_workload(args, w2, st, wu, group, comm, 100_000_000)
+            others[f"cfg{cfg}"] = {
+                "workload": f"cfg{cfg}: Prometheus schema, 100000000 rows, {w2.qdesc}",
+                "value": 100_000_000 * st / r2["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu,
+                "ms_per_step": r2["elapsed"] / st * 1e3, "roofline": roofline_of(r2, 100_000_000, st, f"cfg{cfg}", ceiling),
+                "checked": r2["checked"], "jit": jit_of(r2), "setup": {"gen_and_upload_s": w2.t_gen, "hbm_resident_bytes": w2.hbm_bytes},
+            }
+            if cfg == 5 and want("cfg5_merge") and len(w2.resident) >= 2:
                 others["cfg5_merge"] = measure_cfg5_merge(args, w2, st, wu, ceiling)
+            if cfg == 5:  # the same scan finished for a consumer on the device (fdb_plan_finish_batch): no Arrow record crosses PCIe
+                r3 = run_workload(args, w2, st, wu, group, comm, 100_000_000, resident_finish=True)
+                others["cfg5_resident_finish"] = {
+                    "workload": "cfg5 with the result left in HBM (fdb_plan_finish_batch) for a device-side consumer",
+                    "value": 100_000_000 * st / r3["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r3["elapsed"] / st * 1e3,
+                    "roofline": roofline_of(r3, 100_000_000, st, "cfg5", ceiling), "checked": r3["checked"]}
             w2.release()
-            continue
-        r2 = run_workload(args, w2, st, wu, group, comm, 100_000_000)
-        others[f"cfg{cfg}"] = {
-            "workload": f"cfg{cfg}: Prometheus schema, 100000000 rows, {w2.qdesc}",
-            "value": 100_000_000 * st / r2["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu,
-            "ms_per_step": r2["elapsed"] / st * 1e3, "roofline": roofline_of(r2, 100_000_000, st, f"cfg{cfg}", ceiling),
-            "checked": r2["checked"], "jit": jit_of(r2), "setup": {"gen_and_upload_s": w2.t_gen, "hbm_resident_bytes": w2.hbm_bytes},
-        }
-        if cfg == 5 and want("cfg5_merge") and len(w2.resident) >= 2:
-            others["cfg5_merge"] = measure_cfg5_merge(args, w2, st, wu, ceiling)
-        if cfg == 5:  # the same scan finished for a consumer on the device (fdb_plan_finish_batch): no Arrow record crosses PCIe
-            r3 = run_workload(args, w2, st, wu, group, comm, 100_000_000, resident_finish=True)
-            others["cfg5_resident_finish"] = {
-                "workload": "cfg5 with the result left in HBM (fdb_plan_finish_batch) for a device-side consumer",
-                "value": 100_000_000 * st / r3["elapsed"], "unit": "rows/s", "steps": st, "warmup": wu, "ms_per_step": r3["elapsed"] / st * 1e3,
-                "roofline": roofline_of(r3, 100_000_000, st, "cfg5", ceiling), "checked": r3["checked"]}
-        w2.release()
         if cfg == 5 and want("cfg5_sorted"):  # the same table SORTED by its label columns: the table-free OrderedAggregate (no hash kernel runs)
             w3 = Workload(args, 5, 100_000_000, rank, device, cfg5_sorted=True)
             r4 = run_workload(args, w3, st, wu, group, comm, 100_000_000)
