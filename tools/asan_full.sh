@@ -16,6 +16,7 @@ for f in fdb_arrow fdb_context fdb_plan fdb_hash fdb_jit fdb_dynamic fdb_comm fd
 done
 $HIPCC --offload-arch=gfx950 -O1 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-sanitize -c "$SRC/fdb_kernels.hip" -o "$OUT/fdb_kernels.o"
 $HIPCC --offload-arch=gfx950 -O1 -std=c++17 -fPIC -fno-gpu-sanitize -c "$SRC/fdb_sort.hip" -o "$OUT/fdb_sort.o"
+$HIPCC --offload-arch=gfx950 -O1 -std=c++17 -fPIC -munsafe-fp-atomics -fno-gpu-sanitize -c "$SRC/fdb_merge.hip" -o "$OUT/fdb_merge.o"
 $HIPCC -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -c "$SRC/fdb_widen.cc" -o "$OUT/fdb_widen.o"
 $HIPCC --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -o "$OUT/libfdb_fullasan.so" "$OUT"/*.o -lhiprtc -ldl -lpthread -lz
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
