@@ -508,9 +508,15 @@ func flatten(e logicalplan.Expr, out *[]C.fdb_expr, mem *cArena) (int, error) {
 	return len(*out) - 1, nil
 }
 
-// flattenProjection turns arithmetic over columns and literals (binaryExprProjection, project.go:73-161) into the post-order
-// fdb_proj_node array: kind 0 column, 1 literal (INT64 / FLOAT64), 2 binary + - * /. Anything else declines the stage.
+// flattenProjection turns arithmetic over columns and literals (binaryExprProjection, project.go:73-161) and boolean expressions
+// (boolExprProjection, project.go:397-470: comparisons, And / Or) into the post-order fdb_proj_node array: kind 0 column, 1 literal,
+// 2 binary + - * /, 3 comparison / AND / OR. A string / binary / NULL literal may only be the right side of a comparison with a column
+// (the library evaluates that comparison the way a filter leaf is evaluated). Anything else declines the stage.
 func flattenProjection(e logicalplan.Expr, out *[]C.fdb_proj_node, mem *cArena) (int, error) {
+	return flattenProjectionNode(e, out, mem, false)
+}
+
+func flattenProjectionNode(e logicalplan.Expr, out *[]C.fdb_proj_node, mem *cArena, rightOfCompare bool) (int, error) {
 	switch x := e.(type) {
 	case *logicalplan.Column:
 		*out = append(*out, C.fdb_proj_node{kind: 0, left: -1, right: -1, column: mem.str(x.ColumnName)})
@@ -519,25 +525,32 @@ func flattenProjection(e logicalplan.Expr, out *[]C.fdb_proj_node, mem *cArena) 
 		if err := setLiteral(&n.literal, x.Value, mem); err != nil {
 			return -1, err
 		}
-		if n.literal._type != C.FDB_LIT_INT64 && n.literal._type != C.FDB_LIT_FLOAT64 {
+		numeric := n.literal._type == C.FDB_LIT_INT64 || n.literal._type == C.FDB_LIT_FLOAT64
+		if !numeric && !rightOfCompare {
 			return -1, fmt.Errorf("gpuplan: projection literal %s is not int64 / float64", x.Value)
 		}
 		*out = append(*out, n)
 	case *logicalplan.BinaryExpr:
+		kind := C.int32_t(2)
 		switch x.Op {
 		case logicalplan.OpAdd, logicalplan.OpSub, logicalplan.OpMul, logicalplan.OpDiv:
+		case logicalplan.OpEq, logicalplan.OpNotEq, logicalplan.OpLt, logicalplan.OpLtEq, logicalplan.OpGt, logicalplan.OpGtEq,
+			logicalplan.OpAnd, logicalplan.OpOr:
+			kind = 3
 		default:
 			return -1, fmt.Errorf("gpuplan: projection operator %s is not fused", x.Op.String())
 		}
-		l, err := flattenProjection(x.Left, out, mem)
+		l, err := flattenProjectionNode(x.Left, out, mem, false)
 		if err != nil {
 			return -1, err
 		}
-		r, err := flattenProjection(x.Right, out, mem)
+		_, leftIsColumn := x.Left.(*logicalplan.Column)
+		compare := kind == 3 && x.Op != logicalplan.OpAnd && x.Op != logicalplan.OpOr
+		r, err := flattenProjectionNode(x.Right, out, mem, compare && leftIsColumn)
 		if err != nil {
 			return -1, err
 		}
-		*out = append(*out, C.fdb_proj_node{kind: 2, op: C.int32_t(x.Op), left: C.int32_t(l), right: C.int32_t(r)})
+		*out = append(*out, C.fdb_proj_node{kind: kind, op: C.int32_t(x.Op), left: C.int32_t(l), right: C.int32_t(r)})
 	default:
 		return -1, fmt.Errorf("gpuplan: projection %s is not fused", e.String())
 	}
