@@ -42,6 +42,15 @@ const char* kKernelsHeader =
 #include "fdb_kernels_h.inc"
     ;
 
+// Wide run records are written from RE-LOADED columns (the lanes that end a run): the first pass then has to leave the columns in the
+// L2 — with non-temporal loads the second pass went back to HBM (30.8 % of the roofline; 37.9 % with plain loads,
+// profiles/round6_wide_records_temporal_loads.txt; $FDB_RUNS_WIDE_NT=1 restores the non-temporal ones). The hash-table kernel's inserting
+// lanes re-load too, but there plain loads cost 3 % (they compete with the table's entries for the L2): it keeps the non-temporal ones.
+bool temporal_loads(int runs) {
+  const char* nt = std::getenv("FDB_RUNS_WIDE_NT");
+  return runs == 2 && !(nt != nullptr && std::atoi(nt) != 0);
+}
+
 const char* kPreamble = R"HIP(
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -54,12 +63,22 @@ __device__ __forceinline__ long long f64_minmax_key(double d, bool is_min) {
   const long long k = f64_to_ordered(d);
   return d != d ? (is_min ? 0x7FFFFFFFFFFFFFFFLL : (-0x7FFFFFFFFFFFFFFFLL - 1)) : k;
 }
+// (FDB_LD_TEMPORAL: the kernel reads its columns twice — wide run records — so the first pass must leave them in the L2)
+#ifdef FDB_LD_TEMPORAL
+__device__ __forceinline__ u32x4 ld4(const void* base, uint32_t byte_off) {
+  return *as_global(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+__device__ __forceinline__ u64x2 ld8(const void* base, uint32_t byte_off) {
+  return *as_global(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+#else
 __device__ __forceinline__ u32x4 ld4(const void* base, uint32_t byte_off) {
   return __builtin_nontemporal_load(as_global(reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + byte_off)));
 }
 __device__ __forceinline__ u64x2 ld8(const void* base, uint32_t byte_off) {
   return __builtin_nontemporal_load(as_global(reinterpret_cast<const u64x2*>(reinterpret_cast<const char*>(base) + byte_off)));
 }
+#endif
 __device__ __forceinline__ uint32_t ldv(const uint8_t* bm, uint32_t byte_off, uint32_t shift) { return (as_global(bm)[byte_off] >> shift) & 0xFu; }
 // dictionary truth table in a 64-bit immediate: 4 rows → 4-bit mask (NULL rows look up entry `null_at`)
 __device__ __forceinline__ uint32_t leaf_bits(u32x4 idx, uint32_t valid, unsigned long long bits, uint32_t null_at) {
@@ -922,6 +941,7 @@ struct HashGen {
     // written by the lanes that end a run from re-loaded columns — fdb_kernels.h FdbRunsOut)
     // 3 = medium records: like 1 with TWO bytes per key id (≤ 65 534 distinct values per column; 16 more registers per row)
     const bool narrow = s.runs == 1, wide = s.runs == 2, medium = s.runs == 3;
+    if (temporal_loads(s.runs)) o << "#define FDB_LD_TEMPORAL 1\n";
     o << "#define FDB_DEVICE_HELPERS 1\n#include \"fdb_kernels.h\"\n" << kPreamble << kHashPreamble;
     // The runs kernel wants ≈149 VGPRs = 3 waves per SIMD, which is also what its LDS stage (4 × 12 KiB per workgroup) lets a CU hold.
     // ($FDB_RUNS_WAVES_PER_EU: tuning aid — caps the registers so that that many waves fit a SIMD; 0 / unset = no cap)
@@ -1603,7 +1623,8 @@ hipFunction_t jit_get(const JitShape& shape) {
 std::string JitHashShape::key() const {
   std::ostringstream k;
   k << "a" << ablate << "c" << need_count << (runs == 1 ? "R" : runs == 2 ? "W" : runs == 3 ? "M" : "") << (runs && std::getenv("FDB_RUNS_WAVES_PER_EU") ? std::getenv("FDB_RUNS_WAVES_PER_EU") : "")
-    << (runs && std::getenv("FDB_RUNS_ABLATE") ? std::string("x") + std::getenv("FDB_RUNS_ABLATE") : std::string()) << "|";
+    << (runs && std::getenv("FDB_RUNS_ABLATE") ? std::string("x") + std::getenv("FDB_RUNS_ABLATE") : std::string())
+    << (temporal_loads(runs) ? "t" : "") << "|";
   for (const JitHashCol& C : cols) k << C.kind << (C.has_validity ? 'n' : '-') << (C.lut_identity ? 'i' : C.lut_in_lds ? 'l' : 'g') << (C.kind == 2 ? std::to_string(C.expr_root) : std::string());
   k << '|';
   for (size_t l = 0; l < leaves.size(); l++) {
