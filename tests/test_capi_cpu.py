@@ -455,6 +455,17 @@ def test_parquet_chunks_are_parsed_and_refused_on_the_host():
     with pytest.raises(pp.FdbError) as e:
         pp.ResidentBatch.from_parquet(good, rows)
     assert e.value.code == pp.FDB_ERR_DEVICE  # parsed fine, then no GPU
+    # several row groups in one call (fdb_batches_from_parquet): the same order — every chunk of every row group is parsed first
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet_many([(good, rows), (good, rows)])
+    assert e.value.code == pp.FDB_ERR_DEVICE
+    cut = [good[0], (good[1][0], good[1][1], good[1][2], good[1][3], bytes(good[1][4][:100]), *good[1][5:]), good[2]]
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet_many([(good, rows), (cut, rows), (good, rows)])
+    assert e.value.code == pp.FDB_ERR_INVALID, str(e.value)
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet_many([(good, rows), (good, rows + 1)])
+    assert e.value.code == pp.FDB_ERR_INVALID, str(e.value)
     # every codec and string encoding a FrostDB schema can name (schema.proto:54-86) parses; what convert.go does not map either
     # is refused: INT32 / FLOAT physical types, repeated (list) columns
     for kw in (dict(compression="BROTLI"), dict(use_dictionary=False, column_encoding={"ts": "PLAIN", "labels.a": "DELTA_BYTE_ARRAY", "value": "PLAIN"}),

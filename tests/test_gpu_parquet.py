@@ -50,10 +50,11 @@ def prometheus_table(rng, n, null_frac=0.05, n_path=700):
 def decoded_equals_pyarrow(pp, data, rg=0):
     chunks, rows = row_group_chunks(data, rg)
     rb = pp.ResidentBatch.from_parquet(chunks, rows)
-    try:
-        got = rb.to_arrow()
-    finally:
-        pass
+    return batch_equals_pyarrow(rb, data, rg, rows)
+
+
+def batch_equals_pyarrow(rb, data, rg, rows):
+    got = rb.to_arrow()
     want = pq.ParquetFile(io.BytesIO(data)).read_row_group(rg)
     assert got.num_rows == want.num_rows == rows
     assert got.schema.names == want.schema.names
@@ -174,6 +175,86 @@ def test_several_row_groups_all_null_columns_and_wide_dictionaries(pp):
         rb.close()
 
 
+def _many_files():
+    rng = np.random.default_rng(23)
+    prom = prometheus_table(rng, 230_001)
+    wide = pa.table({
+        "labels.wide": pa.array([b"k%06d" % i for i in rng.integers(0, 70_000, 90_000)], type=pa.binary()),
+        "labels.none": pa.array([None] * 90_000, type=pa.binary()),
+        "flag": pa.array(rng.random(90_000) < 0.3, mask=rng.random(90_000) < 0.1),
+        "value": pa.array(rng.normal(size=90_000)),
+    })
+    return {
+        "plain_v1": lambda: write_parquet(prom, row_group_size=50_000, data_page_version="1.0"),
+        "plain_v2_small_pages": lambda: write_parquet(prom, row_group_size=70_000, data_page_size=4096, data_page_version="2.0"),
+        "snappy_v1": lambda: write_parquet(prom, row_group_size=50_000, compression="SNAPPY", data_page_version="1.0"),
+        "zstd_v2_delta": lambda: write_parquet(prom, row_group_size=64_000, compression="ZSTD", data_page_version="2.0",
+                                               column_encoding={"timestamp": "DELTA_BINARY_PACKED", "ivalue": "DELTA_BINARY_PACKED"},
+                                               use_dictionary=["labels.code", "labels.path", "labels.req"]),
+        "no_dictionary_gzip": lambda: write_parquet(prom.slice(0, 60_000), row_group_size=25_000, compression="GZIP", use_dictionary=False),
+        "wide_and_all_null": lambda: write_parquet(wide, row_group_size=40_000, data_page_size=8192),
+    }
+
+
+@pytest.mark.parametrize("which", ["plain_v1", "plain_v2_small_pages", "snappy_v1", "zstd_v2_delta", "no_dictionary_gzip", "wide_and_all_null"])
+def test_row_groups_decoded_by_one_call_are_bit_identical_to_pyarrow(pp, which):
+    """fdb_batches_from_parquet: every row group of a file in ONE call (one copy queue, the host work of all of them side by side, a
+    row group's kernels launched while later ones are still being parsed) — each batch bit-identical to pyarrow's reading of its row
+    group, and to what the one-row-group call returns; the last row group is shorter than the others."""
+    data = _many_files()[which]()
+    n_rg = pq.ParquetFile(io.BytesIO(data)).metadata.num_row_groups
+    assert n_rg >= 3
+    groups = [row_group_chunks(data, rg) for rg in range(n_rg)]
+    calls0 = pp.parquet_stats()["calls"]
+    rbs = pp.ResidentBatch.from_parquet_many(groups)
+    assert pp.parquet_stats()["calls"] == calls0 + 1 and len(rbs) == n_rg
+    try:
+        for rg, rb in enumerate(rbs):
+            batch_equals_pyarrow(rb, data, rg, groups[rg][1])
+        # a subset, in another order, is as good a call as the whole file
+        some = pp.ResidentBatch.from_parquet_many([groups[n_rg - 1], groups[0]])
+        try:
+            batch_equals_pyarrow(some[0], data, n_rg - 1, groups[n_rg - 1][1])
+            batch_equals_pyarrow(some[1], data, 0, groups[0][1])
+        finally:
+            for rb in some:
+                rb.close()
+    finally:
+        for rb in rbs:
+            rb.close()
+
+
+def test_one_call_over_row_groups_reports_a_damaged_chunk_and_returns_nothing(pp):
+    """A truncated chunk in the LAST row group of a call: the call fails with that chunk's error (the host threads of the other row
+    groups are joined, the copies already queued are waited for), no batch comes back, and the next call works."""
+    rng = np.random.default_rng(29)
+    data = write_parquet(prometheus_table(rng, 120_000), row_group_size=30_000, compression="SNAPPY")
+    groups = [row_group_chunks(data, rg) for rg in range(4)]
+    chunks3, rows3 = groups[3]
+    nm, ty, opt, u8, b, cd = chunks3[1]
+    broken = list(chunks3)
+    broken[1] = (nm, ty, opt, u8, bytes(b[: len(b) // 2]), cd)
+    with pytest.raises(pp.FdbError) as e:
+        pp.ResidentBatch.from_parquet_many(groups[:3] + [(broken, rows3)])
+    assert e.value.code == pp.FDB_ERR_INVALID and "parquet" in str(e.value)
+    # … and a corrupt Snappy stream (the page chain is intact, a page body is not) in the FIRST row group
+    nm, ty, opt, u8, b, cd = groups[0][0][4]
+    garbled = bytearray(b)
+    for k in range(len(garbled) // 2, len(garbled) // 2 + 64):
+        garbled[k] ^= 0xFF
+    bad0 = list(groups[0][0])
+    bad0[4] = (nm, ty, opt, u8, bytes(garbled), cd)
+    with pytest.raises(pp.FdbError):
+        pp.ResidentBatch.from_parquet_many([(bad0, groups[0][1])] + groups[1:])
+    rbs = pp.ResidentBatch.from_parquet_many(groups)
+    try:
+        for rg, rb in enumerate(rbs):
+            batch_equals_pyarrow(rb, data, rg, groups[rg][1])
+    finally:
+        for rb in rbs:
+            rb.close()
+
+
 def test_decoded_batches_feed_the_aggregate_like_imported_ones(pp):
     """Parquet bytes → resident batch → fused filter + aggregate, against the oracle run on pyarrow's reading of the same file."""
     rng = np.random.default_rng(11)
@@ -183,9 +264,8 @@ def test_decoded_batches_feed_the_aggregate_like_imported_ones(pp):
     plan = pp.HashAggregatePlan(filt, aggs, groups)
     keep, recs = [], []
     try:
+        keep = pp.ResidentBatch.from_parquet_many([row_group_chunks(data, rg) for rg in range(3)])
         for rg in range(3):
-            chunks, rows = row_group_chunks(data, rg)
-            keep.append(pp.ResidentBatch.from_parquet(chunks, rows))
             recs.append(pq.ParquetFile(io.BytesIO(data)).read_row_group(rg).to_batches()[0])
         plan.CallbackResident(keep)
         got = arrow_to_pydict(plan.Finish())
@@ -280,7 +360,7 @@ def test_repeated_and_unmapped_columns_are_refused_precisely(pp):
 @pytest.mark.parametrize("version", ["1.0", "2.0"])
 def test_literal_snappy_pages_are_inflated_on_the_device(pp, version, monkeypatch):
     """SNAPPY pages of PLAIN float64 / int64 values that do not compress (random values: a page of literals, compressed size ≈ plain
-    size) of ≥ 256 KiB are inflated by the device's block decoder, the rest (levels, dictionary indices, DELTA pages, small pages)
+    size) of ≥ 32 KiB are inflated by the device's block decoder, the rest (levels, dictionary indices, DELTA pages, small pages)
     on the host's threads as before: 1 MiB pages, optional columns with NULLs (V1: the definition levels sit INSIDE the compressed body:
     the host inflates just them) and required ones, two row groups, next to compressible columns in the same row group. Bit-identical
     to pyarrow's reader, and to what the all-host path (FDB_PARQUET_HOST_INFLATE) decodes."""

@@ -38,7 +38,8 @@ q = (Col("labels.code") == "200", [Sum(Col("value"))], [Col("labels.path")])
 
 def run_device():
     plan = pp.HashAggregatePlan(*q)
-    keep = [pp.ResidentBatch.from_parquet(ch, n) for ch, n in groups]
+    # every row group in one call (fdb_batches_from_parquet); $PQ_ONE_BY_ONE: one call per row group, one after the other
+    keep = [pp.ResidentBatch.from_parquet(ch, n) for ch, n in groups] if os.environ.get("PQ_ONE_BY_ONE") else pp.ResidentBatch.from_parquet_many(groups)
     plan.CallbackResident(keep)
     out = plan.Finish(); plan.Close()
     for k in keep: k.close()
@@ -57,7 +58,7 @@ a, b = run_device(), run_host_decode()
 da = dict(zip(a.column(0).to_pylist(), a.column(1).to_pylist())); db = dict(zip(b.column(0).to_pylist(), b.column(1).to_pylist()))
 assert da.keys() == db.keys() and all(abs(da[k] - db[k]) <= 1e-9 * abs(db[k]) for k in da)
 res = {}
-for name, fn in (("device_decode", run_device), ("host_decode_pyarrow", run_host_decode)):
+for name, fn in ((("device_decode", run_device),) if os.environ.get("PQ_DEVICE_ONLY") else (("device_decode", run_device), ("host_decode_pyarrow", run_host_decode))):
     fn(); t0 = time.perf_counter(); n = 3
     for _ in range(n): fn()
     dt = (time.perf_counter() - t0) / n
