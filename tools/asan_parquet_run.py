@@ -22,6 +22,22 @@ def call(chunks, rows):
         arr[i] = ParquetChunk(n, ty, opt, 1 if u8 else 0, CODECS[cd], ctypes.addressof(buf), len(data))
     out = ctypes.c_void_p()
     return lib.fdb_batch_from_parquet(arr, len(chunks), ctypes.c_int64(rows), 0, ctypes.byref(out))
+class ParquetRowGroup(ctypes.Structure):
+    _fields_ = [("chunks", ctypes.c_void_p), ("n_chunks", ctypes.c_int32), ("n_rows", ctypes.c_int64)]
+lib.fdb_batches_from_parquet.restype = ctypes.c_int
+def call_many(groups):
+    """fdb_batches_from_parquet: the row groups' chunks are planned, inflated and parsed side by side on the pool's threads"""
+    rgs = (ParquetRowGroup * len(groups))(); keep = []
+    for g, (chunks, rows) in enumerate(groups):
+        arr = (ParquetChunk * len(chunks))()
+        for i, (nm, ty, opt, u8, data, cd) in enumerate(chunks):
+            buf = (ctypes.c_ubyte * len(data)).from_buffer_copy(data) if len(data) else (ctypes.c_ubyte * 1)()
+            keep.append(buf); n = nm.encode(); keep.append(n)
+            arr[i] = ParquetChunk(n, ty, opt, 1 if u8 else 0, CODECS[cd], ctypes.addressof(buf), len(data))
+        keep.append(arr)
+        rgs[g] = ParquetRowGroup(ctypes.addressof(arr), len(chunks), rows)
+    outs = (ctypes.c_void_p * len(groups))()
+    return lib.fdb_batches_from_parquet(rgs, len(groups), 0, outs)
 rng = np.random.default_rng(7); random.seed(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 n = 3000
 t = pa.table({"labels.a": pa.array([None if i % 9 == 0 else b"v%d" % (i % 13) for i in range(n)], type=pa.binary()),
@@ -73,7 +89,15 @@ for kw in variants:
                 else:
                     cd = random.choice(["SNAPPY", "UNCOMPRESSED", "ZSTD", "GZIP", "LZ4"]); opt = random.choice([0, 1])
             mut.append((nm, ty, opt, u8, bytes(b), cd))
-        import time as _t; _t0 = _t.time(); rc = call(mut, random.choice([rows, rows, rows, rows - 1, rows + 5])); _dt = _t.time() - _t0
+        import time as _t; _t0 = _t.time()
+        n_rows = random.choice([rows, rows, rows, rows - 1, rows + 5])
+        if it % 4 == 3:   # the damaged row group between intact ones, one call
+            order = [(chunks, rows), (mut, n_rows), (chunks, rows)]
+            random.shuffle(order)
+            rc = call_many(order)
+        else:
+            rc = call(mut, n_rows)
+        _dt = _t.time() - _t0
         if _dt > 2: print("slow call", round(_dt, 1), "s variant", kw, "victim", chunks[victim][0], "rc", rc, flush=True)
         codes[rc] = codes.get(rc, 0) + 1; total += 1
 print("variants", len(variants), "runs", total, "return codes", codes)

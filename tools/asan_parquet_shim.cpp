@@ -19,6 +19,11 @@ extern "C" int fdb_batch_from_parquet(const fdb_parquet_chunk* chunks, int32_t n
   catch (const fdb::Error& e) { g_err = e.what(); return e.code; }
   catch (const std::exception& e) { g_err = e.what(); return FDB_ERR_INVALID; }
 }
+extern "C" int fdb_batches_from_parquet(const fdb_parquet_row_group* groups, int32_t n_groups, int device, fdb_batch** out) {
+  try { auto b = fdb::batches_from_parquet(groups, n_groups, device); (void)b; return 0; }
+  catch (const fdb::Error& e) { g_err = e.what(); return e.code; }
+  catch (const std::exception& e) { g_err = e.what(); return FDB_ERR_INVALID; }
+}
 namespace fdb {
 void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) { (void)hipGetLastError(); throw Error(e == hipErrorOutOfMemory ? FDB_ERR_OOM : FDB_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
