@@ -628,11 +628,14 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
       hip_check(hipMemsetAsync(pa.counts, 0, cand.size() * 8, stream_), "hipMemsetAsync(present counts)");  // (live counts of the marking pass)
       hip_check(fdb_launch_present_ids(pa, device_, stream_), "present ids");
       hip_check(fdb_launch_rank_ids(pa, stream_), "rank ids");
-      std::vector<unsigned long long> h_counts(cand.size());
-      std::vector<uint32_t> h_present(cand.size() * 256);  // (a mapping is only used when ≤ 256 ids are present)
-      hip_check(hipMemcpyAsync(h_counts.data(), pa.counts, cand.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(present counts)");
+      // (into PINNED memory: out of a pageable vector each of these up to 33 small copies made this thread wait for the stream — a
+      // round trip apiece, ≈ 0.5 ms per Finish of 32 columns)
+      struct PinnedBack { Context* c; void* p; ~PinnedBack() { c->host_free(p); } } pin{ctx_, ctx_->host_alloc(cand.size() * 8 + cand.size() * 256 * 4)};
+      unsigned long long* h_counts = (unsigned long long*)pin.p;
+      uint32_t* h_present = (uint32_t*)(h_counts + cand.size());  // (a mapping is only used when ≤ 256 ids are present)
+      hip_check(hipMemcpyAsync(h_counts, pa.counts, cand.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(present counts)");
       for (size_t k = 0; k < cand.size(); k++)
-        hip_check(hipMemcpyAsync(h_present.data() + k * 256, pa.present + pa.remap_off[k], std::min<size_t>(256, pa.dict_len[k]) * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(present ids)");
+        hip_check(hipMemcpyAsync(h_present + k * 256, pa.present + pa.remap_off[k], std::min<size_t>(256, pa.dict_len[k]) * 4, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(present ids)");
       hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
       for (size_t k = 0; k < cand.size(); k++) {
         const size_t c = cand[k];
@@ -641,7 +644,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
         if (w == width[c]) continue;  // nothing gained
         width[c] = w;
         remap_of[c] = pa.remap + pa.remap_off[k];
-        present_of[c].assign(h_present.begin() + (ptrdiff_t)(k * 256), h_present.begin() + (ptrdiff_t)(k * 256 + std::max<unsigned long long>(cnt, 1)));
+        present_of[c].assign(h_present + k * 256, h_present + k * 256 + std::max<unsigned long long>(cnt, 1));
         if (cnt == 0) present_of[c][0] = 0;  // (a column of NULLs only: every row carries rank 0, masked by its validity bit)
       }
       if (pt.on) pt.mark("finish: present ids");
