@@ -14,6 +14,7 @@ PASSES = {
     "cfg5": ("fdb_hash_kernel", "fdb_hash_kernel", 100_000_000, "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
     "cfg5_sorted": ("fdb_hash_kernel", "fdb_hash_kernel(runs)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
     "cfg5_sorted_wide": ("fdb_hash_kernel", "fdb_hash_kernel(runs, medium)", 100_000_000, "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
+    "cfg5_sorted_widerec": ("fdb_hash_kernel", "fdb_hash_kernel(runs, wide)", 100_000_000, "env FDB_RUNS_WIDE=1 python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"),
     "cfg2_sorted": ("fdb_plan_kernel", "fdb_plan_kernel", 100_000_000, "python bench.py --config 2 --cfg2-sorted --steps 10 --warmup 2 --no-cpu-baseline --no-oracle-parity"),
     "cfg5_1B": ("fdb_hash_kernel", "fdb_hash_kernel", 1_000_000_000, "python bench.py --rows 100000000 --steps 3 --warmup 1 --no-cpu-baseline --no-oracle-parity --only-other cfg5_1B"),
     # filter(): a step is several kernels — the traffic of a step is the sum of their per-launch means (each runs once per step)

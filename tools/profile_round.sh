@@ -33,10 +33,12 @@ prof cfg5 "python bench.py --config 5 --steps 5 --warmup 1 --no-cpu-baseline --n
 prof cfg5_sorted "python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
 prof cfg5_sorted_sets "python bench.py --config 5 --cfg5-sorted --push-order 2,0,3,1 --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity"
 prof cfg5_sorted_wide "python bench.py --config 5 --cfg5-sorted --cfg5-wide-dicts --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
+prof cfg5_sorted_widerec "env FDB_RUNS_WIDE=1 python bench.py --config 5 --cfg5-sorted --steps 5 --warmup 1 --no-cpu-baseline --no-oracle-parity" fetch write
 prof select "python bench.py --rows 100000000 --steps 5 --warmup 1 --no-cpu-baseline --only-other select --no-oracle-parity" fetch write
 prof cfg2_sorted "python bench.py --config 2 --cfg2-sorted --steps 10 --warmup 2 --no-cpu-baseline --no-oracle-parity" fetch write
 prof cfg5_merge "python bench.py --rows 100000000 --steps 3 --warmup 1 --no-cpu-baseline --no-oracle-parity --only-other cfg5_merge"
 prof cfg5_1B "python bench.py --rows 100000000 --steps 3 --warmup 1 --no-cpu-baseline --no-oracle-parity --only-other cfg5_1B" fetch write
+prof parquet "python bench.py --rows 100000000 --steps 3 --warmup 1 --no-cpu-baseline --no-oracle-parity --only-other parquet"
 prof cfg5_exchange "python bench.py --gpus 2 --force-local --config 5 --steps 3 --warmup 1 --no-cpu-baseline"
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete; du -sh $O
 [ -n "${ONLY_PROF:-}" ] && exit 0
