@@ -196,6 +196,25 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
   const int32_t* o32 = (const int32_t*)offsets;
   const int64_t* o64 = (const int64_t*)offsets;
   auto begin = [&](int64_t i) -> int64_t { return wide ? o64[off + i] : (int64_t)o32[off + i]; };
+  // A thread's recent dictionaries (see below), asked FIRST and by content alone: a record whose dictionary is one of them — the usual
+  // case, record after record of one part — is recognised by two memcmps (its raw offsets, its bytes: ≈ 0.4 µs for 1 024 entries of 12
+  // bytes) instead of three passes over the entries and a serial multiply chain over every byte (≈ 4 µs: more than half of what a
+  // 1 024-row record's Callback cost). Offsets equal to those of a dictionary that was validated are valid.
+  struct Recent { uint64_t hash = 0; std::shared_ptr<std::shared_ptr<HostDict>> holder; std::vector<int32_t> raw_off; };
+  static thread_local Recent recent[16];
+  static thread_local unsigned recent_next = 0;
+  static const bool l1 = std::getenv("FDB_NO_DICT_L1") == nullptr;
+  static const bool l1_fast = l1 && std::getenv("FDB_NO_DICT_L1_FAST") == nullptr;  // (A/B aid)
+  if (l1_fast && !wide && n > 0)
+    for (unsigned k = 0; k < 16; k++) {
+      const Recent& r = recent[(recent_next + 15 - k) % 16];  // (most recent first)
+      if (!r.holder || r.raw_off.size() != (size_t)n + 1) continue;
+      const HostDict& o = **r.holder;
+      if (o.plain || o.value_format != value_format || std::memcmp(o32 + off, r.raw_off.data(), ((size_t)n + 1) * 4) != 0) continue;
+      const int64_t s0 = r.raw_off[0], sp = (int64_t)r.raw_off[(size_t)n] - s0;
+      if ((int64_t)o.concat.size() != sp || (sp > 0 && (data == nullptr || std::memcmp(data + s0, o.concat.data(), (size_t)sp) != 0))) continue;
+      return std::shared_ptr<HostDict>(r.holder, r.holder->get());
+    }
   // offsets must not decrease, and a dictionary with bytes needs a data buffer (a NULL entry reads as "", like arrow-go's
   // Binary.Value of a null slot)
   for (int64_t i = 0; i < n; i++)
@@ -228,10 +247,6 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
   // whatever N (0.60 G rows/s at 8 chains, 0.63 at 32: round 4). A hit here touches neither: the returned pointer ALIASES the interned
   // object (same address: "same dictionary?" stays a pointer compare everywhere) but counts its references in a control block that
   // belongs to this thread's cache entry, which in turn holds the interned object alive. ($FDB_NO_DICT_L1: A/B aid)
-  struct Recent { uint64_t hash = 0; std::shared_ptr<std::shared_ptr<HostDict>> holder; };
-  static thread_local Recent recent[16];
-  static thread_local unsigned recent_next = 0;
-  static const bool l1 = std::getenv("FDB_NO_DICT_L1") == nullptr;
   if (l1)
     for (Recent& r : recent)
       if (r.holder && r.hash == h && same_content(**r.holder)) return std::shared_ptr<HostDict>(r.holder, r.holder->get());
@@ -242,6 +257,8 @@ std::shared_ptr<HostDict> read_dictionary(const HostColView& col) {
     Recent& r = recent[recent_next++ % 16];
     r.hash = h;
     r.holder = std::make_shared<std::shared_ptr<HostDict>>(d);
+    r.raw_off.clear();
+    if (!wide && n > 0 && lens_fit) r.raw_off.assign(o32 + off, o32 + off + n + 1);  // (what the content-only lookup above compares)
     return std::shared_ptr<HostDict>(r.holder, d.get());
   };
   for (const std::shared_ptr<HostDict>& other : table.candidates(h))

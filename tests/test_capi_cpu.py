@@ -313,6 +313,33 @@ def test_arrow_import_export_roundtrip_without_a_gpu(built_lib):
         pp.arrow_roundtrip(pa.RecordBatch.from_arrays([pa.array([[1], [2]])], names=["list"]))
 
 
+def test_a_threads_recent_dictionaries_are_recognised_by_content_not_by_shape(built_lib):
+    """read_dictionary asks the calling thread's recent dictionaries first, by two memcmps (raw offsets, bytes) instead of a content
+    hash: records that follow each other with (a) the same dictionary in other buffers, (b) the same OFFSETS over different bytes,
+    (c) the same BYTES cut differently, (d) a slice of a bigger dictionary (offsets that do not start at 0) must each decode to their
+    own values, in any order and repeatedly."""
+    import pyarrow as pa
+    from frostdb_amd import physicalplan as pp
+
+    def rec(values, typ=pa.binary()):
+        idx = pa.array([i % len(values) for i in range(97)], type=pa.uint32())
+        return pa.RecordBatch.from_arrays([pa.DictionaryArray.from_arrays(idx, pa.array(values, type=typ))], names=["labels.k"])
+
+    a1 = rec([b"ab", b"c", b"def"])
+    a2 = rec([bytes(b"ab"), bytes(b"c"), bytes(b"def")])          # same content, other buffers
+    b = rec([b"xy", b"z", b"uvw"])                                 # same offsets, other bytes
+    c = rec([b"a", b"bc", b"def"])                                 # same bytes, other offsets
+    big = pa.array([b"pad", b"ab", b"c", b"def", b"tail"], type=pa.binary())
+    d = pa.RecordBatch.from_arrays([pa.DictionaryArray.from_arrays(pa.array([i % 3 for i in range(97)], type=pa.uint32()), big.slice(1, 3))], names=["labels.k"])
+    e = rec(["ab", "c", "def"], pa.string())                       # same bytes and offsets, utf8 instead of binary
+    for r in (a1, a2, b, a1, c, d, b, e, c, a2, d, e, a1):
+        out = pp.arrow_roundtrip(r)
+        want = r.column(0).dictionary_decode().to_pylist()
+        got = out.column(0).dictionary_decode().to_pylist()
+        assert [v.encode() if isinstance(v, str) else v for v in got] == [v.encode() if isinstance(v, str) else v for v in want]
+        assert pa.types.is_string(out.column(0).type.value_type) == pa.types.is_string(r.column(0).type.value_type)
+
+
 def _explain_cases():
     from tests.golden import logictest_cases as G
     return G.EXPLAIN_CASES
