@@ -759,6 +759,9 @@ struct Gen {
     o << "extern \"C\" __global__ __launch_bounds__(" << BLK << ") void fdb_select_kernel(const FdbScanArgs* __restrict__ parts, const int n_parts, const long long total_tiles, const FdbScanArgs c, uint32_t* __restrict__ masks, uint32_t* __restrict__ offsets, const FdbSelectArgs sa) {\n";
     o << "  extern __shared__ __align__(16) unsigned char smem[];\n  __shared__ long long s_ticket[2];\n  __shared__ unsigned long long s_base;\n  __shared__ uint32_t s_cnt[2][8];\n";
     o << "  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n";
+    // (FdbSelectArgs::zero: every workgroup — the scanner too — clears its share of the regions the NEXT launch accumulates into)
+    o << "  for (int zr = 0; zr < sa.n_zero; zr++) {\n    u32x4* zp = reinterpret_cast<u32x4*>(sa.zero[2 * zr]);\n    const long long zq = (long long)(sa.zero[2 * zr + 1] >> 4);\n";
+    o << "    for (long long zi = (long long)blockIdx.x * " << BLK << " + tid; zi < zq; zi += (long long)gridDim.x * " << BLK << ") zp[zi] = u32x4{0u, 0u, 0u, 0u};\n  }\n";
     for (int i = 0; i < s.n_c4; i++) o << "  const char* P_" << reg(false, false, i) << "_v = nullptr; const uint8_t* P_" << reg(false, false, i) << "_b = nullptr;\n";
     for (int i = 0; i < s.n_c8; i++) o << "  const char* P_" << reg(true, false, i) << "_v = nullptr; const uint8_t* P_" << reg(true, false, i) << "_b = nullptr;\n";
     for (size_t l = 0; l < s.leaves.size(); l++)

@@ -517,6 +517,11 @@ struct FdbSelectArgs {
   uint32_t stage_off;               // LDS: the waves' staging regions start here (behind the predicate's LUTs)
   uint32_t status_off;              // first status word, in words from ctl
   uint32_t place_off;               // first place word, in words from ctl
+  // Regions the launch zeroes on its way in — the validity bitmaps and NULL counters the compaction launch behind it ORs / adds into
+  // (allocated at their worst-case size before this launch: the exact one is only known after it) — instead of a launch of their own:
+  // pairs (address, bytes), 16-byte aligned, multiples of 16 bytes.
+  const unsigned long long* zero;
+  int32_t n_zero;
 };
 
 #ifndef FDB_DEVICE_ONLY

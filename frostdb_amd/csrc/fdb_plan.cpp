@@ -2684,6 +2684,11 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches_impl(const Device
   std::vector<int64_t> totals(nl, 0);
   int launches = 0;
   const unsigned long long* d_rec_base_arg = nullptr;  // (one pass: the offsets are relative to their record already)
+  std::vector<char> pre_nullable(n_cols, 0);         // one pass: what the select launch zeroed on its way in (below)
+  std::vector<void*> pre_bits(nl, nullptr);
+  std::vector<size_t> pre_bits_bytes(nl, 0);
+  unsigned long long* pre_nulls = nullptr;
+  size_t pre_nulls_words = 0;
   if (one_pass) {
     // outputs of the fused columns: one worst-case block per record, owned by the result from here on
     std::vector<FdbSelectPart> sparts(nl);
@@ -2705,6 +2710,37 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches_impl(const Device
       o.arena_bytes += bytes;
       for (size_t f = 0; f < fused.size(); f++) sparts[k].dst[f] = (unsigned char*)block + off[f];
     }
+    // The other columns' validity bitmaps and NULL counters — what the compaction launch ORs / adds into — are zeroed by THIS launch on
+    // its way in (FdbSelectArgs::zero) instead of by a launch of their own between the two: they must exist before the row counts do,
+    // so a record's bitmaps get a worst-case block of their own (rows / 8 bytes per nullable column; the values still go into an arena
+    // of the exact size).
+    for (size_t k = 0; k < nl; k++)
+      for (size_t c = 0; c < n_cols; c++) if (in[live[k]]->cols[c].d_validity != nullptr) pre_nullable[c] = 1;
+    size_t n_rest_pre = 0;
+    bool any_nullable_pre = false;
+    for (size_t c = 0; c < n_cols; c++) if (fused_of[c] < 0) { n_rest_pre++; any_nullable_pre = any_nullable_pre || pre_nullable[c]; }
+    std::vector<unsigned long long> zero_tab;
+    if (any_nullable_pre) {
+      for (size_t k = 0; k < nl; k++) {
+        const DeviceBatch& src = *in[live[k]];
+        DeviceBatch& o = *out[(size_t)live[k]];
+        size_t bytes = 0;
+        for (size_t c = 0; c < n_cols; c++) if (pre_nullable[c]) bytes += align_up((size_t)(src.rows + 7) / 8 + kTailPad, 256);
+        void* block = device_pool_alloc(device_, std::max<size_t>(bytes, 256));
+        pre_bits[k] = block;
+        pre_bits_bytes[k] = std::max<size_t>(bytes, 256);
+        // (in FRONT of the fused columns' block: that one stays extra_arenas.back())
+        o.extra_arenas.insert(o.extra_arenas.begin(), block);
+        o.arena_bytes += pre_bits_bytes[k];
+        zero_tab.push_back((unsigned long long)(uintptr_t)block);
+        zero_tab.push_back((unsigned long long)pre_bits_bytes[k]);
+      }
+      pre_nulls_words = nl * std::max<size_t>(n_rest_pre, 1) * 64;
+      pre_nulls = (unsigned long long*)ctx_->dev_alloc(align_up(pre_nulls_words * 8, 256));
+      scratch_.push_back(pre_nulls);
+      zero_tab.push_back((unsigned long long)(uintptr_t)pre_nulls);
+      zero_tab.push_back((unsigned long long)align_up(pre_nulls_words * 8, 256));
+    }
     FdbSelectArgs sa;
     std::memset(&sa, 0, sizeof(sa));
     sa.ctl = d_ctl;
@@ -2717,6 +2753,7 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches_impl(const Device
     {
       StageScope stage_scope(ctx_);
       sa.sparts = (const FdbSelectPart*)upload(sparts.data(), sparts.size() * sizeof(FdbSelectPart));
+      if (!zero_tab.empty()) { sa.zero = (const unsigned long long*)upload(zero_tab.data(), zero_tab.size() * 8); sa.n_zero = (int32_t)(zero_tab.size() / 2); }
     }
     timed([&] { hip_check(jit_select_launch(select_fn, d_parts, (int)parts.size(), total_super, parts[0], (int)grid + 1, first_lds, d_masks, d_offsets, sa, stream_), "select launch"); });
     // (one workgroup more than workers: the scanner; every worker draws exactly one ticket past the end)
@@ -2806,12 +2843,23 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches_impl(const Device
       bytes += align_up((size_t)total * (src.cols[c].kind == ColKind::DICT ? 4 : 8) + kTailPad, 256);
     }
     bits_at = bytes;
-    for (size_t c = 0; c < n_cols; c++)
-      if (nullable[c]) { bit_off[c] = bytes; bytes += align_up(((size_t)total + 7) / 8 + kTailPad, 256); }
+    uint8_t* const bits_block = (uint8_t*)pre_bits[k];  // (one pass with nullable columns: zeroed by the select launch, worst-case sized)
+    if (bits_block != nullptr) {
+      size_t at = 0;
+      for (size_t c = 0; c < n_cols; c++) if (nullable[c]) { bit_off[c] = at; at += align_up((size_t)(src.rows + 7) / 8 + kTailPad, 256); }
+    } else {
+      for (size_t c = 0; c < n_cols; c++)
+        if (nullable[c]) { bit_off[c] = bytes; bytes += align_up(((size_t)total + 7) / 8 + kTailPad, 256); }
+    }
     if (total > 0 && bytes > 0) {
       o.arena = device_pool_alloc(device_, std::max<size_t>(bytes, 256));
       o.arena_bytes += std::max<size_t>(bytes, 256);
       if (bytes > bits_at) { regions.push_back(FdbZeroRegion{(unsigned char*)o.arena + bits_at, (int64_t)(bytes - bits_at)}); max_region = std::max<int64_t>(max_region, (int64_t)(bytes - bits_at)); }
+    }
+    if (bits_block != nullptr && total == 0) {  // nothing selected: the record's result has no buffers at all
+      o.extra_arenas.erase(o.extra_arenas.begin());
+      o.arena_bytes -= pre_bits_bytes[k];
+      repacked.push_back(bits_block);
     }
     if (!fused.empty() && (total == 0 || repack)) {  // the worst-case block is not part of the result
       void* block = o.extra_arenas.back();
@@ -2835,7 +2883,7 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches_impl(const Device
       } else {
         P.values = total > 0 ? (unsigned char*)o.arena + val_off[c] : nullptr;
       }
-      P.valid = total > 0 && nullable[c] ? (uint8_t*)o.arena + bit_off[c] : nullptr;
+      P.valid = total > 0 && nullable[c] ? (bits_block != nullptr ? bits_block : (uint8_t*)o.arena) + bit_off[c] : nullptr;
     }
     for (size_t r = 0; r < n_rest; r++) {
       const size_t c = (size_t)rest[r];
@@ -2855,7 +2903,9 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches_impl(const Device
     if (any_selected > 0 && n_rest > 0) {
       // NULL counts and validity bitmaps exist only when some column has a bitmap: without one there is nothing to zero, count or copy back
       unsigned long long* d_nulls = nullptr;
-      if (any_nullable) {
+      if (any_nullable && pre_nulls != nullptr && pre_nulls_words >= h_nulls.size()) {
+        d_nulls = pre_nulls;  // (zeroed by the select launch)
+      } else if (any_nullable) {
         d_nulls = (unsigned long long*)ctx_->dev_alloc(h_nulls.size() * 8);
         scratch_.push_back(d_nulls);
         regions.push_back(FdbZeroRegion{d_nulls, (int64_t)(h_nulls.size() * 8)});
@@ -2884,7 +2934,7 @@ std::vector<std::unique_ptr<DeviceBatch>> Plan::filter_batches_impl(const Device
         hip_check(fdb_launch_compact_multi(d_recs, (int)nl, d_cols, (int)n_rest, any_nullable, d_wave_begin, wave_begin[n_rest], d_masks, d_offsets, d_rec_base_arg, total_tiles, d_nulls, stream_),
                   "compact launch");
       });
-      launches += any_nullable ? 2 : 1;
+      launches += regions.empty() ? 1 : 2;
       if (any_nullable) hip_check(hipMemcpyAsync(h_nulls.data(), d_nulls, h_nulls.size() * 8, hipMemcpyDeviceToHost, stream_), "hipMemcpyAsync(null counts)");
     }
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
