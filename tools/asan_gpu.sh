@@ -18,7 +18,7 @@ if [ "${1:-build}" = build ]; then
   done
   g++ -std=c++17 -O1 -g1 -fPIC -fsanitize=address,undefined -c "$SRC/fdb_widen.cc" -o "$OUT/fdb_widen.o" & pids+=($!)
   for p in "${pids[@]}"; do wait $p; done
-  g++ -shared -fPIC -fsanitize=address,undefined -o "$OUT/libfdb_fullasan.so" "$OUT"/*.o "$SRC/fdb_kernels.o" "$SRC/fdb_sort.o" -L/opt/rocm/lib -lamdhip64 -lhiprtc -ldl -lpthread -lz -Wl,-rpath,/opt/rocm/lib
+  g++ -shared -fPIC -fsanitize=address,undefined -o "$OUT/libfdb_fullasan.so" "$OUT"/*.o "$SRC/fdb_kernels.o" "$SRC/fdb_merge.o" "$SRC/fdb_sort.o" -L/opt/rocm/lib -lamdhip64 -lhiprtc -ldl -lpthread -lz -Wl,-rpath,/opt/rocm/lib
   rm -f "$OUT"/*.o
   ls -la "$OUT"
   exit 0
