@@ -659,6 +659,7 @@ int64_t Plan::finish_columns_hash(std::vector<OutColumn>* out, DeviceBatch* resi
     cols[c].kind = gcols_[c].kind; cols[c].word = gcols_[c].word; cols[c].gi = (int)c;
     cols[c].src_word = width[c]; cols[c].lut_len = narrow[c] ? 1u : 0u;
     cols[c].lut = remap_of[c];
+    if (remap_of[c] != nullptr) a.any_lut = 1;
   }
   a.cols = (const FdbHashCol*)upload(cols.data(), cols.size() * sizeof(FdbHashCol));
   a.out_key = (void* const*)upload(d_key.data(), d_key.size() * sizeof(void*));

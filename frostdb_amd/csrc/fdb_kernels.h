@@ -324,6 +324,7 @@ struct FdbHashColumnsArgs {
   uint64_t row_begin, row_end;  // pass 2 only: the output rows of this launch (row_begin a multiple of 64)
   uint64_t slice_stride;
   int32_t n_cols, entry_words, key_words, n_vals, slice_shift;
+  int32_t any_lut;  // some column of `cols` leaves through a table (FdbHashCol::lut): pass 2 translates those in its LDS tile first
 };
 // Which key ids does the RESULT hold? A result column usually uses a small part of its dictionary (a query filters, a table's parts
 // share big dictionaries), and what crosses PCIe is priced per row — so Finish can ship the ids at the width of the values PRESENT

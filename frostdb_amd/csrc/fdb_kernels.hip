@@ -1036,29 +1036,79 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * 64 * pitch;
   const uint32_t magic = (uint32_t)((0x100000000ull + (unsigned)kw - 1ull) / (unsigned)kw);
+  const bool quads = (kw & 3) == 0 && (reinterpret_cast<uintptr_t>(dense_keys) & 15u) == 0;
+  const uint32_t qmagic = (uint32_t)((0x100000000ull + ((unsigned)kw >> 2) - 1ull) / (((unsigned)kw >> 2) > 0 ? ((unsigned)kw >> 2) : 1u));
   const uint64_t n_groups = ((a.row_end < a.n_rows ? a.row_end : a.n_rows) + 63) >> 6;
   for (uint64_t G = (a.row_begin >> 6) + (uint64_t)blockIdx.x * 4 + wave; G < n_groups; G += (uint64_t)gridDim.x * 4) {
     const uint32_t rows = (uint32_t)(a.n_rows - G * 64 < 64 ? a.n_rows - G * 64 : 64);
     const uint32_t* src = dense_keys + G * 64 * (uint64_t)kw;
     const uint32_t n_words = rows * (uint32_t)kw;
-    for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
-      uint32_t val[16];
+    if (quads) {
+      // 16-byte pieces (rows are multiples of 16 bytes, 16-byte aligned): 64 rows of 144 bytes are 576 pieces — 9 loads per lane, not 36
+      const uint32_t Q = (uint32_t)kw >> 2, n_quads = rows * Q;
+      for (uint32_t t0 = 0; t0 < n_quads; t0 += 64 * 4) {
+        u32x4 val[4];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
-        if (t < n_words) val[u] = src[t];
+        for (int u = 0; u < 4; u++) {
+          const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+          val[u] = *reinterpret_cast<const u32x4*>(src + (size_t)(t < n_quads ? t : n_quads - 1u) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+          if (t < n_quads) {
+            const uint32_t rr = __umulhi(t, qmagic);
+            uint32_t* d = tile + rr * pitch + (t - rr * Q) * 4u;
+            d[0] = val[u].x; d[1] = val[u].y; d[2] = val[u].z; d[3] = val[u].w;
+          }
+        }
       }
+    } else {
+      for (uint32_t t0 = 0; t0 < n_words; t0 += 64 * 16) {
+        uint32_t val[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
-        if (t < n_words) { const uint32_t rr = __umulhi(t, magic); tile[rr * pitch + (t - rr * (uint32_t)kw)] = val[u]; }
+        for (int u = 0; u < 16; u++) {
+          const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+          if (t < n_words) val[u] = src[t];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const uint32_t t = t0 + (uint32_t)u * 64 + lane;
+          if (t < n_words) { const uint32_t rr = __umulhi(t, magic); tile[rr * pitch + (t - rr * (uint32_t)kw)] = val[u]; }
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
     const bool active = (uint32_t)lane < rows;
     const uint64_t o = G * 64 + lane;
-    const uint32_t* k = tile + lane * pitch;
+    uint32_t* k = tile + lane * pitch;
     const unsigned long long vm = active ? (unsigned long long)k[0] | ((unsigned long long)k[1] << 32) : 0ull;
+    // Key ids that leave through a table (FdbHashCol::lut: the rank of the id among the ids present) are translated IN THE TILE first,
+    // eight columns' lookups in flight together: the column loop below then holds no vector LOAD at all. With one in it the compiler has
+    // to wait at the head of every iteration for whatever the previous one left outstanding (a register may still be the target of a
+    // load) — and on gfx950 stores count on the same counter: every column waited for the previous column's store to be acknowledged,
+    // ≈ 2 µs apiece, 67 µs per 64 rows × 33 columns (0.26 ms per 2^20 rows; round 6).
+    if (a.any_lut) {
+      for (int c0 = 0; c0 < a.n_cols; c0 += 8) {
+        uint32_t xv[8];
+        int wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int c = c0 + u < a.n_cols ? c0 + u : a.n_cols - 1;
+          const FdbHashCol C = load_col(a.cols, c);
+          const bool has = C.kind == 0 && C.lut != nullptr;  // (wave-uniform)
+          wv[u] = has && c0 + u < a.n_cols ? C.word : -1;
+          // (an unconditional load — entry 0 of the table, or of the key rows for a column without one — so that the eight of them are
+          // issued back to back instead of one behind each branch)
+          const uint32_t id = has && active ? k[C.word] : 0u;
+          const uint32_t* L = has ? C.lut : dense_keys;
+          const uint32_t v = L[id];
+          xv[u] = id != 0u ? v + 1u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (wv[u] >= 0 && active) k[wv[u]] = xv[u];
+      }
+    }
     for (int c = 0; c < a.n_cols; c++) {
       const FdbHashCol C = load_col(a.cols, c);
       unsigned char* out = out_key[c];
@@ -1070,7 +1120,7 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
       if (width < 0) {  // (wave-uniform) sub-byte indices: 16 / 8 lanes fold theirs into one 32-bit word, the first of them stores it
         const uint32_t id = active ? k[C.word] : 0u;
         ok = id != 0u;
-        uint32_t x = id ? (C.lut != nullptr ? C.lut[id] : id - 1u) : 0u;
+        uint32_t x = id ? id - 1u : 0u;  // (translated in the tile above when the column has a table)
         if (width == -2) {
           x |= (uint32_t)__shfl_down((int)x, 1, 64) << 2; x |= (uint32_t)__shfl_down((int)x, 2, 64) << 4;
           x |= (uint32_t)__shfl_down((int)x, 4, 64) << 8; x |= (uint32_t)__shfl_down((int)x, 8, 64) << 16;
@@ -1082,7 +1132,7 @@ __global__ __launch_bounds__(256) void group_rows_to_columns_kernel(const uint32
       } else if (active) {
         if (C.kind == 0) {
           const uint32_t id = k[C.word];
-          const uint32_t idx = id ? (C.lut != nullptr ? C.lut[id] : id - 1u) : 0u;
+          const uint32_t idx = id ? id - 1u : 0u;
           ok = id != 0u;
           if (width == 1) out[at] = (uint8_t)idx;
           else if (width == 2) *reinterpret_cast<uint16_t*>(out + at) = (uint16_t)idx;
