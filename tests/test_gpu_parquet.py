@@ -255,6 +255,31 @@ def test_one_call_over_row_groups_reports_a_damaged_chunk_and_returns_nothing(pp
             rb.close()
 
 
+def test_concurrent_calls_over_row_groups_do_not_disturb_each_other(pp):
+    """Four threads (N scan chains reading parts), each decoding another file's row groups with one call at a time, three times over:
+    the calls share the host pool's threads, the pinned pools and the device's streams — every batch still equals pyarrow's reading."""
+    from concurrent.futures import ThreadPoolExecutor
+    files = _many_files()
+    names = ["plain_v1", "snappy_v1", "zstd_v2_delta", "wide_and_all_null"]
+    datas = {nm: files[nm]() for nm in names}
+    groups = {nm: [row_group_chunks(datas[nm], rg) for rg in range(pq.ParquetFile(io.BytesIO(datas[nm])).metadata.num_row_groups)] for nm in names}
+
+    def work(nm):
+        for _ in range(3):
+            rbs = pp.ResidentBatch.from_parquet_many(groups[nm])
+            try:
+                for rg, rb in enumerate(rbs):
+                    batch_equals_pyarrow(rb, datas[nm], rg, groups[nm][rg][1])
+            finally:
+                for rb in rbs:
+                    rb.close()
+        return nm
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        assert sorted(ex.map(work, names)) == sorted(names)
+    assert pp.live_allocations()["device_blocks"] == 0
+
+
 def test_decoded_batches_feed_the_aggregate_like_imported_ones(pp):
     """Parquet bytes → resident batch → fused filter + aggregate, against the oracle run on pyarrow's reading of the same file."""
     rng = np.random.default_rng(11)
