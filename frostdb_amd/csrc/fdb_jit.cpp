@@ -96,6 +96,7 @@ __device__ __forceinline__ long long i64_add(long long a, long long b) { return 
 __device__ __forceinline__ long long i64_sub(long long a, long long b) { return (long long)((unsigned long long)a - (unsigned long long)b); }
 __device__ __forceinline__ long long i64_mul(long long a, long long b) { return (long long)((unsigned long long)a * (unsigned long long)b); }
 __device__ __forceinline__ long long i64_div(long long a, long long b) { return b == 0 ? 0 : b == -1 ? (long long)(0ull - (unsigned long long)a) : a / b; }
+__device__ __forceinline__ long long u64_div(long long a, long long b) { return b == 0 ? 0 : (long long)((unsigned long long)a / (unsigned long long)b); }  // DivUint64s (project.go:379-395)
 __device__ __forceinline__ double f64_div(double a, double b) { return b == 0.0 ? 0.0 : a / b; }
 template <int OP, typename T> __device__ __forceinline__ bool cmp1(T a, T b) {
   return OP == 1 ? a == b : OP == 2 ? a != b : OP == 3 ? a < b : OP == 4 ? a <= b : OP == 5 ? a > b : a >= b;
@@ -184,7 +185,8 @@ std::string expr_value(const std::vector<JitExprNode>& ex, int ni, F col, V colv
     if (n.op == FDB_OP_DIV) return "f64_div(" + a + ", " + b + ")";
     return "(" + a + (n.op == FDB_OP_ADD ? " + " : n.op == FDB_OP_SUB ? " - " : " * ") + b + ")";
   }
-  return std::string(n.op == FDB_OP_ADD ? "i64_add(" : n.op == FDB_OP_SUB ? "i64_sub(" : n.op == FDB_OP_MUL ? "i64_mul(" : "i64_div(") + a + ", " + b + ")";
+  // (uint64: the same bits for + − × — both wrap modulo 2^64 —, an unsigned quotient)
+  return std::string(n.op == FDB_OP_ADD ? "i64_add(" : n.op == FDB_OP_SUB ? "i64_sub(" : n.op == FDB_OP_MUL ? "i64_mul(" : n.type == FDB_T_U64 ? "u64_div(" : "i64_div(") + a + ", " + b + ")";
 }
 // Validity of the ROOT value: only an outermost division can be NULL (divisor 0); `colvalid(node)` for a bare column.
 template <typename F, typename V>

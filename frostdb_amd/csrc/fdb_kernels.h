@@ -69,7 +69,8 @@ struct FdbGroupCol {
   int32_t slot;             // c4 slot
 };
 
-enum FdbAggType : int32_t { FDB_T_NONE = 0, FDB_T_I64 = 1, FDB_T_F64 = 2, FDB_T_BOOL = 3 /* expression nodes only: a comparison's 0 / 1 */ };
+enum FdbAggType : int32_t { FDB_T_NONE = 0, FDB_T_I64 = 1, FDB_T_F64 = 2, FDB_T_BOOL = 3 /* expression nodes only: a comparison's 0 / 1 */,
+                            FDB_T_U64 = 4 /* expression nodes only: uint64 arithmetic (project.go:138-150); no aggregation takes it (aggregate.go:736) */ };
 
 struct FdbAgg {
   const void* values;       // nullptr for COUNT (row count only) and for computed inputs

@@ -419,9 +419,10 @@ Plan::Plan(const fdb_plan_desc* d, int device, bool explain_only) : device_(devi
       } else if (fn.kind == 1) {
         // (int64 / float64 literals compute; a string / binary / NULL literal can only be the right side of a comparison with a column —
         // boolExprProjection evaluates its expression like a filter does, project.go:409-470: checked when the record is resolved)
-        if (fn.literal.type != FDB_LIT_INT64 && fn.literal.type != FDB_LIT_FLOAT64 && fn.literal.type != FDB_LIT_STRING && fn.literal.type != FDB_LIT_BINARY && fn.literal.type != FDB_LIT_NULL)
-          throw Error(FDB_ERR_UNSUPPORTED, "projection literals must be int64, float64, string, binary or NULL");
-        n.lit_type = fn.literal.type; n.i64 = fn.literal.i64; n.f64 = fn.literal.f64;
+        if (fn.literal.type != FDB_LIT_INT64 && fn.literal.type != FDB_LIT_FLOAT64 && fn.literal.type != FDB_LIT_UINT64 && fn.literal.type != FDB_LIT_STRING && fn.literal.type != FDB_LIT_BINARY &&
+            fn.literal.type != FDB_LIT_NULL)
+          throw Error(FDB_ERR_UNSUPPORTED, "projection literals must be int64, uint64, float64, string, binary or NULL");
+        n.lit_type = fn.literal.type; n.i64 = fn.literal.type == FDB_LIT_UINT64 ? (int64_t)fn.literal.u64 : fn.literal.i64; n.f64 = fn.literal.f64;
         n.lit.type = fn.literal.type; n.lit.i64 = fn.literal.i64; n.lit.u64 = fn.literal.u64; n.lit.f64 = fn.literal.f64;
         if (fn.literal.data && fn.literal.len > 0) n.lit.bytes.assign(fn.literal.data, (size_t)fn.literal.len);
       } else if (fn.kind == 2 || fn.kind == 3) {
@@ -510,7 +511,7 @@ int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved
       if (l.kind != 0 || r.kind != 1) return false;
       if (r.lit_type == FDB_LIT_STRING || r.lit_type == FDB_LIT_BINARY || r.lit_type == FDB_LIT_NULL) return true;
       const int ci = b.find(l.column);
-      return ci < 0 || b.cols[(size_t)ci].kind == ColKind::DICT;
+      return ci < 0 || b.cols[(size_t)ci].kind == ColKind::DICT || b.cols[(size_t)ci].kind == ColKind::U64;  // (uint64: compared unsigned, as a leaf is)
     };
     auto operand_of_leaf = [&](size_t idx) {  // node `idx` is only ever read by leaf comparisons
       bool any = false;
@@ -538,15 +539,15 @@ int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved
       const int ci = b.find(n.column);
       if (ci < 0) throw Error(FDB_ERR_NOT_FOUND, "projection " + p.name + ": column " + n.column + " not found");
       const DevColumn& c = b.cols[(size_t)ci];
-      e.type = c.kind == ColKind::I64 ? FDB_T_I64 : c.kind == ColKind::F64 ? FDB_T_F64 : FDB_T_NONE;
+      e.type = c.kind == ColKind::I64 ? FDB_T_I64 : c.kind == ColKind::F64 ? FDB_T_F64 : c.kind == ColKind::U64 ? FDB_T_U64 : FDB_T_NONE;  // (Int32 columns do not exist on this path)
       if (e.type == FDB_T_NONE) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": unsupported type of column " + n.column);  // project.go:157-159
       if (c.d_values == nullptr) throw Error(FDB_ERR_INVALID, "column not staged: " + c.name);
       R->count(b, ci);
       R->expr_col[base + (int)k] = ci;
     } else if (n.kind == 1) {
-      if (n.lit_type != FDB_LIT_INT64 && n.lit_type != FDB_LIT_FLOAT64) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": a string / NULL literal can only be compared with a column");
-      e.type = n.lit_type == FDB_LIT_INT64 ? FDB_T_I64 : FDB_T_F64;
-      if (e.type == FDB_T_I64) e.lit = n.i64; else std::memcpy(&e.lit, &n.f64, 8);
+      if (n.lit_type != FDB_LIT_INT64 && n.lit_type != FDB_LIT_FLOAT64 && n.lit_type != FDB_LIT_UINT64) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": a string / NULL literal can only be compared with a column");
+      e.type = n.lit_type == FDB_LIT_INT64 ? FDB_T_I64 : n.lit_type == FDB_LIT_UINT64 ? FDB_T_U64 : FDB_T_F64;
+      if (e.type != FDB_T_F64) e.lit = n.i64; else std::memcpy(&e.lit, &n.f64, 8);
     } else if (n.kind == 4) {  // convertProjection.convert (project.go:507-521): only int64 → float64 exists
       e.left = base + n.left;
       if (a.expr[e.left].type != FDB_T_I64) throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": unsupported conversion (only int64 to float64)");
@@ -568,11 +569,13 @@ int Plan::resolve_projection(const Projection& p, const DeviceBatch& b, Resolved
         throw Error(FDB_ERR_INVALID, "projection " + p.name + ": AND / OR need boolean operands");
       if (!logical && (a.expr[e.left].type == FDB_T_BOOL || a.expr[e.right].type == FDB_T_BOOL))
         throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": comparison of boolean values");
+      if (!logical && (a.expr[e.left].type == FDB_T_U64 || a.expr[e.right].type == FDB_T_U64))
+        throw Error(FDB_ERR_UNSUPPORTED, "projection " + p.name + ": comparison of computed uint64 values");
       e.type = FDB_T_BOOL;
     } else {
       e.left = base + n.left; e.right = base + n.right;
       if (a.expr[e.left].type != a.expr[e.right].type || a.expr[e.left].type == FDB_T_BOOL)
-        throw Error(FDB_ERR_INVALID, "projection " + p.name + ": operand types differ (int64 vs float64)");
+        throw Error(FDB_ERR_INVALID, "projection " + p.name + ": operand types differ (the reference type-asserts the right array to the left one's type, project.go:112-160)");
       e.type = a.expr[e.left].type;
     }
   }
@@ -1253,18 +1256,18 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
     const Projection* P = find_projection(m.name);
     if (P == nullptr) continue;
     const int root = resolve_projection(*P, b, &R);
-    if (a.expr[root].type != FDB_T_I64 && a.expr[root].type != FDB_T_BOOL)  // HashArray panics on float64 (dynparquet/hashed.go:102-103)
+    if (a.expr[root].type != FDB_T_I64 && a.expr[root].type != FDB_T_BOOL && a.expr[root].type != FDB_T_U64)  // HashArray panics on float64 (dynparquet/hashed.go:102-103)
       throw Error(FDB_ERR_UNSUPPORTED, "group by on a float64 expression (" + m.name + ") is not supported");
-    const bool is_bool = a.expr[root].type == FDB_T_BOOL;
+    const bool is_bool = a.expr[root].type == FDB_T_BOOL, is_u64 = a.expr[root].type == FDB_T_U64;
     size_t gi = 0;
     for (; gi < gcols_.size(); gi++) if (gcols_[gi].name == m.name) break;
     if (gi == gcols_.size()) {
       if (gcols_.size() >= FDB_MAX_HASH_GCOLS) throw Error(FDB_ERR_UNSUPPORTED, "more than 64 group-by columns");
       GroupColState g;
-      g.name = m.name; g.kind = 1; g.is_bool = is_bool; g.cap = 1; g.stride = 0;
+      g.name = m.name; g.kind = 1; g.is_bool = is_bool; g.is_u64 = is_u64; g.cap = 1; g.stride = 0;
       gcols_.push_back(std::move(g));
     }
-    if (gcols_[gi].kind != 1 || gcols_[gi].is_bool != is_bool || gcols_[gi].is_u64) throw Error(FDB_ERR_UNSUPPORTED, "group column " + m.name + " changed type between batches");
+    if (gcols_[gi].kind != 1 || gcols_[gi].is_bool != is_bool || gcols_[gi].is_u64 != is_u64) throw Error(FDB_ERR_UNSUPPORTED, "group column " + m.name + " changed type between batches");
     GroupRes gr;
     gr.gi = (int)gi; gr.ci = -1; gr.kind = 2; gr.expr_root = root;
     R.groups.push_back(std::move(gr));
@@ -1289,7 +1292,7 @@ void Plan::resolve_batch(const DeviceBatch& b, Resolved* Rp, std::vector<int>* b
       if (A.func == FDB_AGG_COUNT) continue;  // arr.Len(): nothing is read
       const int root = resolve_projection(*P, b, &R);
       const int32_t t = a.expr[root].type;
-      if (t == FDB_T_BOOL) throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported type for ") + agg_name(A.func) + " aggregation, expected int64 or float64");
+      if (t == FDB_T_BOOL || t == FDB_T_U64) throw Error(FDB_ERR_UNSUPPORTED, std::string("unsupported type for ") + agg_name(A.func) + " aggregation, expected int64 or float64");  // aggregate.go:736, :782, :862
       if (A.type == FDB_T_NONE) A.type = t;
       else if (A.type != t) throw Error(FDB_ERR_UNSUPPORTED, "aggregated column " + A.column + " changed type between batches");
       K.type = t;

@@ -480,6 +480,8 @@ def to_desc(filter_expr: Optional[Expr], aggs: Sequence[AggregationFunction], gr
                 cl.i64 = int(e.value)
             elif cl.type == LIT_FLOAT64:
                 cl.f64 = float(e.value)
+            elif cl.type == LIT_UINT64:  # uint64 arithmetic (project.go:138-150): the scalar must be a uint64 too
+                cl.u64 = int(e.value)
             elif cl.type in (LIT_STRING, LIT_BINARY):  # the right side of a comparison inside a boolean projection (`labels.a == 'x'` as a key, project.go:409-470)
                 b = e.value.encode() if isinstance(e.value, str) else bytes(e.value)
                 buf = ctypes.create_string_buffer(b, len(b) + 1)

@@ -166,7 +166,7 @@ typedef struct fdb_proj_node {
   int32_t left;        /* binary: child indices into the projection's node array */
   int32_t right;
   const char* column;  /* column: exact name (ArrayRef.ColumnName) */
-  fdb_literal literal; /* literal: INT64 or FLOAT64 */
+  fdb_literal literal; /* literal: INT64, FLOAT64 or UINT64 (arithmetic: both operands of one type, project.go:104-160 — int64, float64 or uint64; uint64 quotients are unsigned, a zero divisor gives NULL); any filter literal on the right of a column comparison */
 } fdb_proj_node;
 
 typedef struct fdb_projection {

@@ -525,9 +525,9 @@ func flattenProjectionNode(e logicalplan.Expr, out *[]C.fdb_proj_node, mem *cAre
 		if err := setLiteral(&n.literal, x.Value, mem); err != nil {
 			return -1, err
 		}
-		numeric := n.literal._type == C.FDB_LIT_INT64 || n.literal._type == C.FDB_LIT_FLOAT64
+		numeric := n.literal._type == C.FDB_LIT_INT64 || n.literal._type == C.FDB_LIT_FLOAT64 || n.literal._type == C.FDB_LIT_UINT64
 		if !numeric && !rightOfCompare {
-			return -1, fmt.Errorf("gpuplan: projection literal %s is not int64 / float64", x.Value)
+			return -1, fmt.Errorf("gpuplan: projection literal %s is not int64 / uint64 / float64", x.Value)
 		}
 		*out = append(*out, n)
 	case *logicalplan.BinaryExpr:

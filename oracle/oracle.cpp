@@ -438,7 +438,7 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
     const int ci = r.find(n.column);
     if (ci < 0) { *err = {FDB_ERR_NOT_FOUND, "projection: column " + n.column + " not found"}; return false; }
     const Col& c = r.cols[(size_t)ci];
-    if (c.type != T_I64 && c.type != T_F64) { *err = {FDB_ERR_UNSUPPORTED, "unsupported type in arithmetic projection: " + n.column}; return false; }
+    if (c.type != T_I64 && c.type != T_F64 && c.type != T_U64) { *err = {FDB_ERR_UNSUPPORTED, "unsupported type in arithmetic projection: " + n.column}; return false; }  // project.go:111-160: Int64, Int32 (no such column here), Uint64, Float64
     *out = c;
     return true;
   }
@@ -447,6 +447,7 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
     out->valid.assign((size_t)rows, 1);
     if (n.lit.type == FDB_LIT_INT64) { out->type = T_I64; out->i64.assign((size_t)rows, n.lit.i64); }
     else if (n.lit.type == FDB_LIT_FLOAT64) { out->type = T_F64; out->f64.assign((size_t)rows, n.lit.f64); }
+    else if (n.lit.type == FDB_LIT_UINT64) { out->type = T_U64; out->i64.assign((size_t)rows, (int64_t)n.lit.u64); }
     else { *err = {FDB_ERR_UNSUPPORTED, "unsupported literal in arithmetic projection"}; return false; }
     return true;
   }
@@ -489,7 +490,7 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
     const ProjNode& lit = pd.nodes[(size_t)n.right];
     const int ci = r.find(l.column);
     const bool stringy = lit.lit.type == FDB_LIT_STRING || lit.lit.type == FDB_LIT_BINARY || lit.lit.type == FDB_LIT_NULL ||
-                         ci < 0 || r.cols[(size_t)ci].type == T_DICT || r.cols[(size_t)ci].type == T_STR;
+                         ci < 0 || r.cols[(size_t)ci].type == T_DICT || r.cols[(size_t)ci].type == T_STR || r.cols[(size_t)ci].type == T_U64;
     if (stringy) {
       Expr e; e.op = n.op; e.column = l.column; e.lit = lit.lit;
       Bitmap bm;
@@ -511,6 +512,7 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
       return true;
     }
     if (a.type == T_BOOL || b.type == T_BOOL) { *err = {FDB_ERR_UNSUPPORTED, "boolean projection: comparison of boolean values"}; return false; }
+    if (a.type == T_U64 || b.type == T_U64) { *err = {FDB_ERR_UNSUPPORTED, "boolean projection: comparison of computed uint64 values"}; return false; }
     for (int64_t i = 0; i < rows; i++) {
       if (!a.valid[(size_t)i] || !b.valid[(size_t)i]) continue;
       bool m;
@@ -524,7 +526,22 @@ bool project_node(const ProjDesc& pd, int32_t ni, const Record& r, Col* out, Eva
   out->type = a.type;
   out->len = rows;
   out->valid.assign((size_t)rows, 1);
-  if (a.type == T_I64) {
+  if (a.type == T_U64) {
+    // AddUint64s / SubUint64s / MulUint64s / DivUint64s (project.go:335-395): Go's uint64 arithmetic wraps; a zero divisor appends NULL
+    out->i64.assign((size_t)rows, 0);
+    for (int64_t i = 0; i < rows; i++) {
+      const uint64_t x = (uint64_t)a.i64[(size_t)i], y = (uint64_t)b.i64[(size_t)i];
+      switch (n.op) {
+        case FDB_OP_ADD: out->i64[(size_t)i] = (int64_t)(x + y); break;
+        case FDB_OP_SUB: out->i64[(size_t)i] = (int64_t)(x - y); break;
+        case FDB_OP_MUL: out->i64[(size_t)i] = (int64_t)(x * y); break;
+        case FDB_OP_DIV:
+          if (y == 0) out->valid[(size_t)i] = 0; else out->i64[(size_t)i] = (int64_t)(x / y);
+          break;
+        default: *err = {FDB_ERR_UNSUPPORTED, "unsupported binary expression in projection"}; return false;
+      }
+    }
+  } else if (a.type == T_I64) {
     out->i64.assign((size_t)rows, 0);
     for (int64_t i = 0; i < rows; i++) {
       const uint64_t x = (uint64_t)a.i64[(size_t)i], y = (uint64_t)b.i64[(size_t)i];  // wrap-around like Go's int64

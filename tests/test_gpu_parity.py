@@ -10,7 +10,7 @@ import pyarrow as pa
 import pyarrow.compute as pc
 import pytest
 
-from frostdb_amd.logicalplan import OP_LT_EQ, OP_NOT_EQ, And, BinaryExpr, Col, Count, DynCol, Literal, Max, Min, Or, Sum, UInt64
+from frostdb_amd.logicalplan import OP_GT, OP_LT_EQ, OP_NOT_EQ, And, BinaryExpr, Col, Count, DynCol, Literal, Max, Min, Or, Sum, UInt64
 from tests.golden import logictest_cases as G
 from tests.util import (arrow_to_pydict, batch_rows, dict_array, fmt, make_prometheus_batch, parse_rows, record_from_rows,
                         sort_key, table_records)
@@ -1502,6 +1502,47 @@ def test_projection_dense_and_hash_vs_oracle(pp):
                 if not k.startswith("labels."):
                     d[k] = [0 if v is None else v for v in d[k]]
         assert_same_result(got, want, cols, float_cols=float_cols)
+
+
+def test_uint64_arithmetic_projections_vs_oracle(pp):
+    """binaryExprProjection over *array.Uint64 (project.go:138-150, :335-395): + − × wrap modulo 2^64, the quotient is unsigned (values
+    beyond 2^63 stay positive), a zero divisor is a NULL; the computed column is a uint64 group key. A uint64 column compared with a
+    uint64 literal inside a boolean projection goes the way a filter leaf does (unsigned). What the reference refuses is refused:
+    aggregating a uint64 expression (aggregate.go:736), mixing uint64 with an int64 scalar (the type assertion at project.go:139-147),
+    comparing computed uint64 values. The oracle restates the four Go loops; no reference vector exists for them (parity unpinned)."""
+    rng = np.random.default_rng(93)
+    n = 40_000
+    a = rng.integers(0, 2**63, n).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, n).astype(np.uint64)
+    small = rng.integers(0, 6, n).astype(np.uint64)
+    recs = []
+    for lo, hi in ((0, 25_000), (25_000, n)):
+        recs.append(pa.RecordBatch.from_arrays([pa.array(a[lo:hi] >> np.uint64(50), mask=rng.random(hi - lo) < 0.1), pa.array(small[lo:hi]),
+                                                pa.array(a[lo:hi]), pa.array(rng.integers(0, 100, hi - lo))], names=["a", "b", "big", "value"]))
+    A, B, BIG, V = Col("a"), Col("b"), Col("big"), Col("value")
+    aggs = [Sum(V), Count(V)]
+    for groups in ([(A / B).Alias("q")],                                   # NULL where b == 0
+                   [(B * B - B).Alias("w")],
+                   [(BIG / UInt64(1 << 61)).Alias("top"), (B - UInt64(3)).Alias("wrapped")],   # quotients of values ≥ 2^63; 0 − 3 wraps to 2^64 − 3
+                   # (one computed key per case from here on: the reference's group identity is the 64-bit combination of the columns'
+                   # IDENTITY hashes — two small-integer keys collide there, e.g. (6286, 1) and (6578, 2), and the oracle restates that)
+                   [(A + A).Alias("s")], [(B / UInt64(2)).Alias("h")],
+                   [A > UInt64(5000)]):
+        want = run_oracle(recs, V >= 0, aggs, groups)
+        got = run_gpu(pp, recs, V >= 0, aggs, groups, resident=True)
+        keys = [g.name for g in groups]
+        for d in (want, got):  # (a key of 0 and a NULL key are one group, as for computed int64 keys)
+            for k in keys:
+                d[k] = [0 if v is None else v for v in d[k]]
+        assert_same_result(got, want, keys + [x.Name() for x in aggs])
+        if "wrapped" in keys:
+            assert 2**64 - 3 in got["wrapped"] and max(got["wrapped"]) == 2**64 - 1 and max(got["top"]) >= 4
+    for bad_aggs, bad_groups, code in (([Sum(A + A)], [B], pp.FDB_ERR_UNSUPPORTED), ([Sum(V)], [(A + 5).Alias("x")], pp.FDB_ERR_INVALID),
+                                       ([Sum(V)], [BinaryExpr(A + A, OP_GT, Literal(UInt64(3))).Alias("c")], pp.FDB_ERR_UNSUPPORTED)):
+        with pytest.raises(pp.FdbError) as e:
+            run_gpu(pp, recs, None, bad_aggs, bad_groups)
+        assert e.value.code == code, str(e.value)
+        with pytest.raises(Exception):
+            run_oracle(recs, None, bad_aggs, bad_groups)
 
 
 def test_projection_needs_specialised_kernel(pp, monkeypatch):

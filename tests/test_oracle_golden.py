@@ -252,6 +252,33 @@ def test_oracle_window_golden_with_fused_projection(case):
     assert got == sorted(case["expected"], key=sort_key), case["cite"]
 
 
+def test_oracle_uint64_arithmetic_known_answers():
+    """AddUint64s / SubUint64s / MulUint64s / DivUint64s (project.go:335-395) restated: hand-computed rows — wrap-around modulo 2^64,
+    an unsigned quotient beyond 2^63, NULL for a zero divisor, no NULL propagation (the loops read raw slots). No vector of the
+    reference covers these four functions: this pins the restatement on their text alone (parity unpinned, as DESIGN §8 says)."""
+    from frostdb_amd.logicalplan import UInt64
+    M = 2**64
+    a = [5, 2**63 + 4, M - 1, 0, 7]
+    b = [2, 4, 3, 9, 0]
+    rec = pa.RecordBatch.from_arrays([pa.array(a, type=pa.uint64()), pa.array(b, type=pa.uint64()), pa.array([1, 2, 3, 4, 5], type=pa.int64())], names=["a", "b", "value"])
+    A, B = Col("a"), Col("b")
+    for expr, want in (((A + B).Alias("k"), [(x + y) % M for x, y in zip(a, b)]),
+                       ((A - B).Alias("k"), [(x - y) % M for x, y in zip(a, b)]),
+                       ((A * B).Alias("k"), [(x * y) % M for x, y in zip(a, b)]),
+                       ((A / B).Alias("k"), [x // y if y else None for x, y in zip(a, b)]),
+                       ((B - UInt64(3)).Alias("k"), [(y - 3) % M for y in b])):
+        res = _oracle_runner(None, [Sum(Col("value"))], [expr])([rec])
+        got = dict(zip(res["k"], res["sum(value)"]))
+        exp = {}
+        for k, v in zip(want, [1, 2, 3, 4, 5]):  # (a key of 0 and a NULL key hash alike in the reference: one group)
+            exp[0 if k is None else k] = exp.get(0 if k is None else k, 0) + v
+        assert {(0 if k is None else k): v for k, v in got.items()} == exp, expr.name
+    with pytest.raises(Exception):
+        _oracle_runner(None, [Sum(A + B)], [Col("value")])([rec])        # ErrUnsupportedSumType (aggregate.go:736)
+    with pytest.raises(Exception):
+        _oracle_runner(None, [Sum(Col("value"))], [(A + 1).Alias("k")])([rec])  # an int64 scalar next to a uint64 array: the type assertion at project.go:139-147
+
+
 def test_config1_simple_schema_known_answer():
     """BASELINE.json configs[0]: examples/simple schema, 10 k rows, `names.first_name == 'Frederic'` + SUM(value) — the
     reference's own CPU-runnable case (examples/simple/simple.go:66-75 filters exactly this). Known answer from numpy."""
