@@ -24,6 +24,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -106,8 +108,18 @@ template <int OP, typename T> __device__ __forceinline__ uint32_t cmp4(T a, T b,
 }
 )HIP";
 
+// device | shape key → function. An entry is published BEFORE it is built: the thread that created it builds it (disk load or hiprtc,
+// 130–500 ms) without holding g_mu, threads that want the same kernel wait for that entry alone, and everybody else's lookups go
+// straight through. (Until round 6 the build ran under g_mu: while one chain compiled a new shape, every other query of the process —
+// cached shapes too — stood still for the length of a compilation.)
+struct KernelEntry {
+  std::mutex m;
+  std::condition_variable cv;
+  bool ready = false;
+  hipFunction_t fn = nullptr;
+};
 std::mutex g_mu;
-std::unordered_map<std::string, hipFunction_t> g_cache;  // device | shape key → function
+std::unordered_map<std::string, std::shared_ptr<KernelEntry>> g_cache;
 bool g_disabled = false;
 
 uint64_t fnv(const std::string& s) {
@@ -1529,9 +1541,24 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
   int dev = 0;
   (void)hipGetDevice(&dev);
   const std::string ckey = std::to_string(dev) + "|" + kernel_name + "|" + key;  // a loaded module belongs to one device
-  std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_cache.find(ckey);
-  if (it != g_cache.end()) return it->second;
+  std::shared_ptr<KernelEntry> entry;
+  bool builder = false;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.find(ckey);
+    if (it == g_cache.end()) { entry = std::make_shared<KernelEntry>(); g_cache.emplace(ckey, entry); builder = true; }
+    else entry = it->second;
+  }
+  if (!builder) {
+    std::unique_lock<std::mutex> lk(entry->m);
+    entry->cv.wait(lk, [&] { return entry->ready; });
+    return entry->fn;
+  }
+  // (whatever happens below, the entry is completed: a waiter must not wait for ever — a failed build publishes nullptr = "interpret")
+  struct Publish {
+    KernelEntry* e; hipFunction_t fn = nullptr;
+    ~Publish() { { std::lock_guard<std::mutex> lk(e->m); e->fn = fn; e->ready = true; } e->cv.notify_all(); }
+  } publish{entry.get()};
   const std::string src = make_source();
   std::vector<char> code;
   char name[64];
@@ -1562,13 +1589,18 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
   if (code.empty()) {
     std::string log;
     const auto t0 = std::chrono::steady_clock::now();
-    const bool compiled = compile(src, &code, &log);
+    bool compiled;
+    {
+      // (one compilation at a time: the compiler is not known to tolerate concurrent programs, and lookups no longer wait behind it)
+      static std::mutex compile_mu;
+      std::lock_guard<std::mutex> lk(compile_mu);
+      compiled = compile(src, &code, &log);
+    }
     g_stat_compile_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     g_stat_compiled++;
     if (!compiled) {
       std::fprintf(stderr, "[frostdb_amd] %s specialisation failed, using the interpreting kernel: %s\n", kernel_name, log.c_str());
       if (std::getenv("FDB_JIT_DEBUG")) std::fprintf(stderr, "%s\n", src.c_str());
-      g_cache.emplace(ckey, nullptr);
       return nullptr;
     }
     if (!path.empty()) {  // publish atomically, and only a file that was written completely
@@ -1585,7 +1617,7 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
     std::fprintf(stderr, "[frostdb_amd] could not load a specialised %s, using the interpreting kernel\n", kernel_name);
     fn = nullptr;
   }
-  g_cache.emplace(ckey, fn);
+  publish.fn = fn;
   return fn;
 }
 }  // namespace
