@@ -25,8 +25,10 @@
 #include <cstring>
 #include <fstream>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <sstream>
 #include <string>
 #include <unordered_map>
@@ -1535,31 +1537,14 @@ namespace {
 // Process cache → disk cache → hiprtc; `key` identifies the shape, `make_source` is only called on a process-cache miss.
 std::atomic<int64_t> g_stat_compiled{0}, g_stat_compile_us{0}, g_stat_disk_loads{0};
 
-template <typename F>
-hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make_source) {
-  if (g_disabled || std::getenv("FDB_NO_JIT") != nullptr) return nullptr;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const std::string ckey = std::to_string(dev) + "|" + kernel_name + "|" + key;  // a loaded module belongs to one device
-  std::shared_ptr<KernelEntry> entry;
-  bool builder = false;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_cache.find(ckey);
-    if (it == g_cache.end()) { entry = std::make_shared<KernelEntry>(); g_cache.emplace(ckey, entry); builder = true; }
-    else entry = it->second;
-  }
-  if (!builder) {
-    std::unique_lock<std::mutex> lk(entry->m);
-    entry->cv.wait(lk, [&] { return entry->ready; });
-    return entry->fn;
-  }
-  // (whatever happens below, the entry is completed: a waiter must not wait for ever — a failed build publishes nullptr = "interpret")
+// Disk cache → hiprtc → module, for the entry its caller owns; whatever happens the entry is completed (a waiter must not wait for
+// ever — a failed build publishes nullptr = "interpret").
+hipFunction_t build_kernel(KernelEntry* entry, const std::string& kernel_name_s, const std::string& src) {
+  const char* kernel_name = kernel_name_s.c_str();
   struct Publish {
     KernelEntry* e; hipFunction_t fn = nullptr;
     ~Publish() { { std::lock_guard<std::mutex> lk(e->m); e->fn = fn; e->ready = true; } e->cv.notify_all(); }
-  } publish{entry.get()};
-  const std::string src = make_source();
+  } publish{entry};
   std::vector<char> code;
   char name[64];
   std::snprintf(name, sizeof name, "/k_%016llx_%zu.hsaco", (unsigned long long)(fnv(src) ^ (fnv(kKernelsHeader) * 31)), src.size());
@@ -1588,15 +1573,15 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
   if (from_disk) g_stat_disk_loads++;
   if (code.empty()) {
     std::string log;
-    const auto t0 = std::chrono::steady_clock::now();
     bool compiled;
     {
       // (one compilation at a time: the compiler is not known to tolerate concurrent programs, and lookups no longer wait behind it)
       static std::mutex compile_mu;
       std::lock_guard<std::mutex> lk(compile_mu);
+      const auto t0 = std::chrono::steady_clock::now();
       compiled = compile(src, &code, &log);
+      g_stat_compile_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     }
-    g_stat_compile_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     g_stat_compiled++;
     if (!compiled) {
       std::fprintf(stderr, "[frostdb_amd] %s specialisation failed, using the interpreting kernel: %s\n", kernel_name, log.c_str());
@@ -1619,6 +1604,51 @@ hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make
   }
   publish.fn = fn;
   return fn;
+}
+
+// $FDB_JIT_ASYNC=1 (opt-in): a caller that CAN do without the specialised kernel (jit_may_defer: the interpreting kernels serve its
+// launch) does not wait for a kernel that has to be built first — the build runs on a thread of this pool, the call returns nullptr
+// ("interpret"), and the next query of the shape finds the kernel. The first query of a new shape then costs an interpreted scan
+// instead of 130–500 ms of compiler. The threads are joined before the cache they publish into is destroyed.
+thread_local bool t_may_defer = false;
+struct Builders {
+  std::mutex m;
+  std::vector<std::thread> threads;
+  void spawn(std::function<void()> job) { std::lock_guard<std::mutex> lk(m); threads.emplace_back(std::move(job)); }
+  ~Builders() { for (std::thread& t : threads) if (t.joinable()) t.join(); }
+} g_builders;
+
+template <typename F>
+hipFunction_t get_kernel(const std::string& key, const char* kernel_name, F make_source) {
+  if (g_disabled || std::getenv("FDB_NO_JIT") != nullptr) return nullptr;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const std::string ckey = std::to_string(dev) + "|" + kernel_name + "|" + key;  // a loaded module belongs to one device
+  std::shared_ptr<KernelEntry> entry;
+  bool builder = false;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.find(ckey);
+    if (it == g_cache.end()) { entry = std::make_shared<KernelEntry>(); g_cache.emplace(ckey, entry); builder = true; }
+    else entry = it->second;
+  }
+  const char* as = t_may_defer ? std::getenv("FDB_JIT_ASYNC") : nullptr;
+  const bool defer = as != nullptr && std::atoi(as) != 0;
+  if (!builder) {
+    std::unique_lock<std::mutex> lk(entry->m);
+    if (defer && !entry->ready) return nullptr;  // still being built: this launch is interpreted
+    entry->cv.wait(lk, [&] { return entry->ready; });
+    return entry->fn;
+  }
+  std::string src;
+  try { src = make_source(); }
+  catch (...) { { std::lock_guard<std::mutex> lk(entry->m); entry->ready = true; } entry->cv.notify_all(); throw; }
+  if (defer) {
+    const std::string kn = kernel_name;
+    g_builders.spawn([entry, kn, src, dev] { (void)hipSetDevice(dev); (void)build_kernel(entry.get(), kn, src); });
+    return nullptr;
+  }
+  return build_kernel(entry.get(), kernel_name, src);
 }
 }  // namespace
 
@@ -1652,6 +1682,9 @@ void jit_stats(int64_t* n_compiled, double* compile_ms, int64_t* n_disk_loads) {
   if (compile_ms) *compile_ms = (double)g_stat_compile_us.load() / 1000.0;
   if (n_disk_loads) *n_disk_loads = g_stat_disk_loads.load();
 }
+
+JitDeferScope::JitDeferScope(bool may_defer) : prev_(t_may_defer) { t_may_defer = may_defer; }
+JitDeferScope::~JitDeferScope() { t_may_defer = prev_; }
 
 hipFunction_t jit_get(const JitShape& shape) {
   return get_kernel(shape.key(), "fdb_plan_kernel", [&] { return jit_source(shape); });

@@ -111,6 +111,17 @@ hipError_t jit_select_launch(hipFunction_t fn, const FdbScanArgs* d_parts, int n
 
 std::string jit_source(const JitShape& shape);
 // The compiled kernel for `shape` (cached in the process and on disk), or nullptr if specialisation is unavailable.
+// While one of these with may_defer = true is alive on a thread, a jit_*get of a kernel that is not built yet may return nullptr at once
+// and leave the build to a background thread ($FDB_JIT_ASYNC=1 only): set by callers whose launch the interpreting kernels can serve.
+class JitDeferScope {
+ public:
+  explicit JitDeferScope(bool may_defer);
+  ~JitDeferScope();
+  JitDeferScope(const JitDeferScope&) = delete;
+  JitDeferScope& operator=(const JitDeferScope&) = delete;
+ private:
+  bool prev_;
+};
 hipFunction_t jit_get(const JitShape& shape);
 // jit_get plus the launch geometry: workgroup size and workgroups per CU such that ≈64 KB of loads are in flight per CU
 // (`row_bytes` = bytes of column data the scan reads per row).

@@ -1640,6 +1640,8 @@ void Plan::push_batches(const DeviceBatch* const* bs, int n) {
       shape.wave_tables = fixed_order;
       shape.uniform_fold = !knobs_.no_uniform_fold;
       if (same) {
+        // ($FDB_JIT_ASYNC=1: a shape whose kernel still has to be built is scanned by the interpreting kernel meanwhile — when that one can)
+        JitDeferScope defer(interp_ok && !fixed_order);
         if (jit_block != 0) { jit_fn = jit_get(shape); if (jit_fn != nullptr) per_cu = jit_blocks_per_cu(jit_fn, jit_block, lds_bytes); }
         else {
           int row_bytes = 0;

@@ -1545,6 +1545,65 @@ def test_uint64_arithmetic_projections_vs_oracle(pp):
             run_oracle(recs, None, bad_aggs, bad_groups)
 
 
+def test_a_new_shape_is_interpreted_while_its_kernel_is_built(pp, monkeypatch, tmp_path):
+    """$FDB_JIT_ASYNC=1: the first query of a shape does not wait for hiprtc (130–500 ms) — its scan runs on the interpreting slot
+    kernel while a background thread builds the specialised one, and a later query of the shape finds it. Same results either way.
+    (A private, empty cache directory: nothing can come from the disk.)"""
+    import os
+    import time
+    os.chmod(tmp_path, 0o700)
+    monkeypatch.setenv("FDB_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("FDB_JIT_ASYNC", "1")
+    rng = np.random.default_rng(1234)
+    recs = [make_prometheus_batch(rng, 30_011, n_path=37), make_prometheus_batch(rng, 20_003, n_path=37)]
+    # (a shape no other test of the process uses: these four aggregates behind this three-leaf predicate)
+    filt = And(Or(Col("labels.code") == "200", Col("labels.method") != "PUT"), Col("value") <= 777.25)
+    aggs, groups = [Max(Col("timestamp")), Min(Col("value")), Count(Col("value")), Sum(Col("timestamp"))], [Col("labels.path")]
+    want = run_oracle(recs, filt, aggs, groups)
+    cols = ["labels.path"] + [a.Name() for a in aggs]
+    before = pp.jit_stats()["compiled"]
+
+    def query():
+        plan = pp.HashAggregatePlan(filt, aggs, groups)
+        rbs = [pp.ResidentBatch(r) for r in recs]
+        try:
+            plan.CallbackResident(rbs)
+            out = arrow_to_pydict(plan.Finish())
+            return out, plan.last_kernel()
+        finally:
+            plan.Close()
+            for r in rbs:
+                r.close()
+
+    got, kernel = query()
+    assert kernel == "scan_slots_kernel", kernel   # interpreted: the kernel of this shape did not exist
+    assert_same_result(got, want, cols)
+    deadline = time.time() + 60
+    while pp.jit_stats()["compiled"] == before and time.time() < deadline:
+        time.sleep(0.02)
+    assert pp.jit_stats()["compiled"] > before
+    for _ in range(200):  # (compiled, then loaded: the entry is published a moment later)
+        got2, kernel2 = query()
+        if kernel2 == "fdb_plan_kernel":
+            break
+        time.sleep(0.02)
+    assert kernel2 == "fdb_plan_kernel", kernel2
+    assert_same_result(got2, want, cols)
+    assert any(f.endswith(".hsaco") for f in os.listdir(tmp_path))
+    # without the switch the same first query waits for its kernel
+    monkeypatch.delenv("FDB_JIT_ASYNC")
+    filt2 = And(Or(Col("labels.code") == "500", Col("labels.method") != "GET"), Col("value") <= 12.5, Col("timestamp") > 5)
+    plan = pp.HashAggregatePlan(filt2, aggs, groups)
+    rb = pp.ResidentBatch(recs[0])
+    try:
+        plan.CallbackResident([rb])
+        plan.Finish()
+        assert plan.last_kernel() == "fdb_plan_kernel"
+    finally:
+        plan.Close()
+        rb.close()
+
+
 def test_projection_needs_specialised_kernel(pp, monkeypatch):
     monkeypatch.setenv("FDB_NO_JIT", "1")
     rng = np.random.default_rng(92)
