@@ -289,6 +289,7 @@ void Plan::push_hash(const DeviceBatch* const* bs, std::vector<Resolved>& Rs, co
     if (sub_tiles != 4 && a.lds_lut_bytes <= FDB_LDS_BUDGET) {
       JitHashShape shape = jit_hash_shape(h, hcols.data());
       shape.ablate = runs ? 0 : ablate & 3;
+      JitDeferScope defer(!runs && a.n_expr == 0);  // ($FDB_JIT_ASYNC=1: the probing scan can be interpreted while its kernel is built; a run store cannot)
       jit_fn = jit_hash_get(shape);
       if (jit_fn != nullptr)
         jit_grid = grid_override > 0 ? grid_override : (fdb_scan_default_grid(device_) / 2) * std::min(4, jit_blocks_per_cu(jit_fn, 256, a.lds_lut_bytes + run_lds));
