@@ -193,10 +193,11 @@ def _many_files():
                                                use_dictionary=["labels.code", "labels.path", "labels.req"]),
         "no_dictionary_gzip": lambda: write_parquet(prom.slice(0, 60_000), row_group_size=25_000, compression="GZIP", use_dictionary=False),
         "wide_and_all_null": lambda: write_parquet(wide, row_group_size=40_000, data_page_size=8192),
+        "forty_small_row_groups": lambda: write_parquet(prom.slice(0, 40_000), row_group_size=1_000, compression="SNAPPY"),
     }
 
 
-@pytest.mark.parametrize("which", ["plain_v1", "plain_v2_small_pages", "snappy_v1", "zstd_v2_delta", "no_dictionary_gzip", "wide_and_all_null"])
+@pytest.mark.parametrize("which", ["plain_v1", "plain_v2_small_pages", "snappy_v1", "zstd_v2_delta", "no_dictionary_gzip", "wide_and_all_null", "forty_small_row_groups"])
 def test_row_groups_decoded_by_one_call_are_bit_identical_to_pyarrow(pp, which):
     """fdb_batches_from_parquet: every row group of a file in ONE call (one copy queue, the host work of all of them side by side, a
     row group's kernels launched while later ones are still being parsed) — each batch bit-identical to pyarrow's reading of its row
