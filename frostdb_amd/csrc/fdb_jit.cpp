@@ -1612,10 +1612,20 @@ hipFunction_t build_kernel(KernelEntry* entry, const std::string& kernel_name_s,
 // instead of 130–500 ms of compiler. The threads are joined before the cache they publish into is destroyed.
 thread_local bool t_may_defer = false;
 struct Builders {
+  struct Slot { std::thread t; std::shared_ptr<std::atomic<bool>> done; };
   std::mutex m;
-  std::vector<std::thread> threads;
-  void spawn(std::function<void()> job) { std::lock_guard<std::mutex> lk(m); threads.emplace_back(std::move(job)); }
-  ~Builders() { for (std::thread& t : threads) if (t.joinable()) t.join(); }
+  std::vector<Slot> slots;
+  void spawn(std::function<void()> job) {
+    std::lock_guard<std::mutex> lk(m);
+    // (threads that have finished are joined here: an unjoined thread keeps its stack, and a long-lived process meets many shapes)
+    for (size_t k = 0; k < slots.size();) {
+      if (slots[k].done->load(std::memory_order_acquire)) { slots[k].t.join(); slots[k] = std::move(slots.back()); slots.pop_back(); }
+      else k++;
+    }
+    auto done = std::make_shared<std::atomic<bool>>(false);
+    slots.push_back(Slot{std::thread([job = std::move(job), done] { job(); done->store(true, std::memory_order_release); }), done});
+  }
+  ~Builders() { for (Slot& s : slots) if (s.t.joinable()) s.t.join(); }
 } g_builders;
 
 template <typename F>
