@@ -81,7 +81,7 @@ int wrap_all(std::vector<std::unique_ptr<fdb::Comm>>&& v, fdb_comm** out) {
 }
 }  // namespace
 
-namespace fdb { void widen_indices(const void* src, int width, uint32_t* dst, size_t n); }  // fdb_widen.cc
+namespace fdb { void widen_indices(const void* src, int width, uint32_t* dst, size_t n); void widen_indices_mapped(const void* src, int width, const uint32_t* table, size_t table_len, uint32_t* dst, size_t n); }  // fdb_widen.cc
 
 extern "C" {
 
@@ -120,7 +120,14 @@ int fdb_plan_explain(const fdb_plan_desc* desc, char* buf, int64_t capacity, int
 
 int fdb_selftest_widen(const void* src, int32_t width, uint32_t* dst, int64_t n) {
   return guard(nullptr, [&] {
-    if ((width != 1 && width != 2 && width != 4 && width != -2 && width != -4) || n < 0 || ((src == nullptr || dst == nullptr) && n > 0)) throw fdb::Error(FDB_ERR_INVALID, "widen: width 1, 2, 4 (bytes) or -2, -4 (bits) and non-null buffers");
+    if ((width != 1 && width != 2 && width != 4 && width != -2 && width != -4 && width != -12 && width != -14) || n < 0 || ((src == nullptr || dst == nullptr) && n > 0))
+      throw fdb::Error(FDB_ERR_INVALID, "widen: width 1, 2, 4 (bytes) or -2, -4 (bits) and non-null buffers");
+    if (width == -12 || width == -14) {  // the rank → index road of the same widths, through the table t[r] = 3 r + 5 of 4 / 16 entries
+      uint32_t table[16];
+      for (uint32_t r = 0; r < 16; r++) table[r] = 3 * r + 5;
+      fdb::widen_indices_mapped(src, width + 10, table, width == -12 ? 4 : 16, dst, (size_t)n);
+      return;
+    }
     fdb::widen_indices(src, width, dst, (size_t)n);
   });
 }

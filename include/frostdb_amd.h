@@ -240,8 +240,9 @@ FDB_API int fdb_arrow_roundtrip(struct ArrowArray* batch, struct ArrowSchema* sc
 FDB_API int fdb_regex_match(const char* pattern, int64_t pattern_len, const uint8_t* value, int64_t value_len, int32_t* matched);
 /* Host-only self-check of the widening step of a big Finish (dictionary indices cross PCIe at the narrowest width their dictionary
  * allows — `width` 1, 2 or 4 BYTES, or -2 / -4: that many BITS per index, rows packed low bits first — and are widened to Arrow's
- * uint32 by host threads): dst[i] = src[i] for i < n, through the same routine (AVX2 with streaming stores where the CPU has it).
- * No device is touched. */
+ * uint32 by host threads): dst[i] = src[i] for i < n, through the same routine (AVX2 / AVX-512 with streaming stores where the CPU has
+ * them). `width` -12 / -14: the 2- / 4-bit road THROUGH a rank → index table (what a Finish that ships the ids present uses), with the
+ * table t[r] = 3 r + 5: dst[i] = 3 src[i] + 5. No device is touched. */
 FDB_API int fdb_selftest_widen(const void* src, int32_t width, uint32_t* dst, int64_t n);
 
 /* ---- plan life cycle (≙ physicalplan.Build for one chain, physicalplan.go:417-474) -------------- */

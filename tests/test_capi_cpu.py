@@ -154,8 +154,8 @@ def test_widening_of_narrow_result_indices(built_lib):
                 assert np.array_equal(raw[base + shift + n: base + shift + n + 4], guard_after)  # nothing written past the end
     # sub-byte transport: 2 / 4 bits per index, rows packed low bits first
     for bits in (2, 4):
-        for n in (0, 1, 3, 4, 5, 15, 16, 17, 64, 1000, 4099):
-            for shift in (0, 1, 2):
+        for n in (0, 1, 3, 4, 5, 15, 16, 17, 64, 255, 256, 1000, 4099):
+            for shift in (0, 1, 2, 4, 12):  # (4, 12: 16-byte aligned, not 64: the vector path's scalar head)
                 vals = rng.integers(0, 1 << bits, n, dtype=np.uint32)
                 packed = np.zeros((n * bits + 7) // 8 + 1, dtype=np.uint8)
                 for i, v in enumerate(vals):
@@ -166,6 +166,12 @@ def test_widening_of_narrow_result_indices(built_lib):
                 rc = built_lib.fdb_selftest_widen(ctypes.c_void_p(packed.ctypes.data), ctypes.c_int32(-bits), ctypes.c_void_p(dst.ctypes.data), ctypes.c_int64(n))
                 assert rc == 0
                 assert np.array_equal(dst, vals), (bits, n, shift)
+                assert not raw[base + shift + n: base + shift + n + 4].any()
+                # … and through a rank → index table (width −12 / −14: the selftest's table is t[r] = 3 r + 5)
+                raw[:] = 0
+                rc = built_lib.fdb_selftest_widen(ctypes.c_void_p(packed.ctypes.data), ctypes.c_int32(-bits - 10), ctypes.c_void_p(dst.ctypes.data), ctypes.c_int64(n))
+                assert rc == 0
+                assert np.array_equal(dst, 3 * vals + 5), (bits, n, shift)
                 assert not raw[base + shift + n: base + shift + n + 4].any()
     assert built_lib.fdb_selftest_widen(None, ctypes.c_int32(3), None, ctypes.c_int64(0)) == 1
 
